@@ -1,0 +1,176 @@
+/* =====================================================================================
+ * serenade_hip.h -- C ABI of libserenade_hip.so: the MI355X (gfx950) implementation of
+ * Serenade's VMIS-kNN `predict_next` hot path.
+ *
+ * The reference (bolcom/serenade @ 2024-11-08, pure Rust) has no FFI of its own; its boundary for
+ * this path is the Rust signature
+ *
+ *   vmisknn::predict<I: SimilarityComputationNew + Send + Sync>(index: &I,
+ *       evolving_session: &[u64], k: usize, m: usize, how_many: usize,
+ *       enable_business_logic: bool) -> BinaryHeap<ItemScore>        src/vmisknn/mod.rs:118-125
+ *
+ * plus the index constructors VMISIndex::new_from_csv (src/vmisknn/vmis_index.rs:38-83) and the
+ * trait accessors (src/vmisknn/similarity_indexed.rs:8-24).  The entry points below are what a Rust
+ * `extern "C"` block in the reference would bind to swap that path for the GPU one (INTEGRATION.md
+ * shows the binding).  Plain pointers and sizes only; every function returns 0 or a negative
+ * SRN_E* code and never unwinds across the boundary; srn_last_error() gives a thread-local
+ * message for the last failure on the calling thread.
+ *
+ * There is NO CPU fallback behind this ABI: predict calls on an index without an attached device
+ * fail with SRN_ENODEV.
+ *
+ * Result order: every predict entry point writes results score-descending (ties: ascending item
+ * id), i.e. already in the `into_sorted_vec()` order all reference callers use
+ * (src/bin/evaluator.rs:67-71, src/endpoints/recommend_resource.rs:58-62).
+ * ===================================================================================== */
+#ifndef SERENADE_HIP_H
+#define SERENADE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRN_OK 0
+#define SRN_EINVAL (-1) /* null pointer, empty evolving session (reference panics: mod.rs:157), bad CSR */
+#define SRN_ENOMEM (-2)
+#define SRN_EHIP (-3)    /* a HIP runtime call failed; see srn_last_error() */
+#define SRN_ERANGE (-4)  /* k / m / how_many / session length above the compiled kernel limits */
+#define SRN_EIO (-5)
+#define SRN_ENODEV (-6)  /* index has no device attached (built with device < 0) or no GPU present */
+
+/* compiled kernel limits (srn_limits() reports the same numbers at run time) */
+#define SRN_MAX_HOW_MANY 512
+#define SRN_MAX_SESSION_LEN 255
+#define SRN_MAX_K 8192
+
+/* attribute flags, one byte per item (ProductAttributes, src/vmisknn/vmis_index.rs:23-26) */
+#define SRN_ATTR_ADULT 1u
+#define SRN_ATTR_FOR_SALE 2u
+#define SRN_ATTR_NONE 0xFFu /* item has no attributes (find_attributes() == None, vmis_index.rs:417-419) */
+
+/* predict flags */
+#define SRN_FLAG_BUSINESS_LOGIC 1u /* enable_business_logic = true (mod.rs:162-182) */
+
+typedef struct srn_index srn_index_t;
+typedef struct srn_sessions srn_sessions_t;
+
+/* Training sessions in the form prepare_hashmap() consumes (src/vmisknn/vmis_index.rs:422-427):
+ * session i owns items[sess_off[i] .. sess_off[i+1]) (ascending, de-duplicated item ids) and
+ * max_ts[i]; the session's index i is the reference's dense session id. */
+typedef struct {
+    const uint64_t* sess_off; /* [n_sessions + 1] */
+    const uint64_t* items;    /* [sess_off[n_sessions]] */
+    const uint32_t* max_ts;   /* [n_sessions] */
+    size_t n_sessions;
+} srn_sessions_view_t;
+
+typedef struct {
+    uint64_t n_items;          /* distinct items in kept sessions */
+    uint64_t n_sessions_total; /* sessions handed to the builder */
+    uint64_t n_sessions_kept;  /* sessions with len <= max_session_len (vmis_index.rs:452) */
+    uint64_t nnz_rows;         /* (session,item) pairs of kept sessions = idf numerator (vmis_index.rs:509) */
+    uint64_t nnz_postings;     /* posting entries after truncation to m_index (vmis_index.rs:504) */
+    uint64_t m_index;
+    uint64_t max_session_len;
+    uint64_t max_row_len;      /* longest kept row */
+    uint64_t device_bytes;     /* HBM held by the index (0 if host-only) */
+    int32_t device;            /* HIP device ordinal, -1 = host-only */
+    int32_t offsets_64bit;     /* row offsets stored as u64 (nnz_rows >= 2^32) */
+    double idf_weighting;
+} srn_index_info_t;
+
+typedef struct {
+    uint32_t max_how_many, max_session_len, max_k, reserved;
+} srn_limits_t;
+
+/* ---- training data ---------------------------------------------------------------------- */
+
+/* TSV "SessionId\tItemId\tTime" -> sessions, with the loader semantics of read_from_file()
+ * (src/vmisknn/vmis_index.rs:591-686): stable order inside a session, first-occurrence de-dup then
+ * ascending sort, max-timestamp updated on non-duplicate rows only, the final row closes the current
+ * session without being added and the last session is dropped. */
+int srn_sessions_from_tsv(const char* path, srn_sessions_t** out);
+int srn_sessions_view(const srn_sessions_t* s, srn_sessions_view_t* out);
+/* exact q-quantile of the session lengths (linear interpolation, rounded): the default stand-in for
+ * the reference's t-digest estimate qty_events_p99_5 (vmis_index.rs:689-716, used at :67). */
+int srn_sessions_length_quantile(const srn_sessions_t* s, double q, uint64_t* out);
+void srn_sessions_free(srn_sessions_t* s);
+
+/* ---- index ------------------------------------------------------------------------------ */
+
+/* prepare_hashmap() (src/vmisknn/vmis_index.rs:422-528) into the flat HBM layout:
+ * sessions longer than max_session_len are left out, posting lists are most-recent-first (ties:
+ * larger session index first) and truncated to m_index, idf = ln(pairs / sessions_with_item) *
+ * idf_weighting, every item {for_sale, not adult}.  device >= 0 uploads to that GPU; device < 0
+ * keeps a host-only index (build / save / inspect; predict then fails with SRN_ENODEV). */
+int srn_index_build(const srn_sessions_view_t* sessions, size_t m_index, size_t max_session_len,
+                    double idf_weighting, int device, srn_index_t** out);
+/* VMISIndex::new_from_csv(path, m_most_recent_sessions, idf_weighting) (vmis_index.rs:38-83);
+ * max_session_len = 0 selects the exact p99.5 of the session lengths. */
+int srn_index_new_from_csv(const char* path, size_t m_most_recent_sessions, double idf_weighting,
+                           size_t max_session_len, int device, srn_index_t** out);
+int srn_index_save(const srn_index_t* idx, const char* path);
+int srn_index_load(const char* path, int device, srn_index_t** out);
+/* replace ProductAttributes of the given items (the Avro path carries real flags, vmis_index.rs:223-228) */
+int srn_index_set_attributes(srn_index_t* idx, const uint64_t* item_ids, const uint8_t* flags, size_t n);
+int srn_index_info(const srn_index_t* idx, srn_index_info_t* out);
+/* posting list of one item as reference session indices (most recent first) and its idf;
+ * *out_len = -1 if the item is unknown.  For index-parity tests and debugging. */
+int srn_index_postings(const srn_index_t* idx, uint64_t item_id, uint32_t* out_sessions, size_t cap,
+                       int64_t* out_len, double* out_idf);
+void srn_index_free(srn_index_t* idx);
+
+/* ---- predict ---------------------------------------------------------------------------- */
+
+/* One evolving session (oldest item first, like the reference slice).  out_ids / out_scores have
+ * room for how_many entries; *out_n receives the number written.  Unknown items give *out_n = 0
+ * with SRN_OK (vmis_index.rs:350); an empty session is SRN_EINVAL (the reference panics). */
+int srn_predict(const srn_index_t* idx, const uint64_t* evolving, size_t len, size_t k, size_t m,
+                size_t how_many, int enable_business_logic, uint64_t* out_ids, double* out_scores,
+                size_t* out_n);
+
+/* nq sessions in CSR form: session q = items_flat[q_off[q] .. q_off[q+1]).  Host pointers.
+ * out_ids / out_scores are [nq * how_many] (row q at q * how_many), out_counts [nq]. */
+int srn_predict_batch(const srn_index_t* idx, const uint64_t* items_flat, const uint32_t* q_off, size_t nq,
+                      size_t k, size_t m, size_t how_many, unsigned flags, uint64_t* out_ids,
+                      double* out_scores, uint32_t* out_counts);
+
+/* Same with every buffer already resident in the index's device memory, enqueued on `stream`
+ * (a hipStream_t; NULL = the null stream) without host synchronisation.  max_len_hint must be
+ * >= the longest session in the batch (<= SRN_MAX_SESSION_LEN).  A query the kernel cannot serve
+ * (empty or over-long session) gets out_counts[q] = 0xFFFFFFFF. */
+int srn_predict_batch_device(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off,
+                             size_t nq, size_t max_len_hint, size_t k, size_t m, size_t how_many,
+                             unsigned flags, uint64_t* d_out_ids, double* d_out_scores,
+                             uint32_t* d_out_counts, void* stream);
+
+/* Debug / measurement variant of srn_predict_batch (host pointers; any of the three extra outputs
+ * may be NULL):
+ *   out_stats  [nq * 8]  P, C, K, I, D, H, L, status per query -- the per-query terms of the
+ *                        algorithmic-bytes formula
+ *   out_nb_sessions / out_nb_num [nq * k], out_nb_counts [nq]: the selected neighbour sessions
+ *                        (reference session indices, unordered) and their integer similarity
+ *                        numerators (similarity = num / distinct evolving items). */
+int srn_predict_batch_debug(const srn_index_t* idx, const uint64_t* items_flat, const uint32_t* q_off, size_t nq,
+                            size_t k, size_t m, size_t how_many, unsigned flags, uint64_t* out_ids,
+                            double* out_scores, uint32_t* out_counts, uint32_t* out_stats,
+                            uint32_t* out_nb_sessions, uint32_t* out_nb_num, uint32_t* out_nb_counts);
+
+/* Average duration in milliseconds of the predict kernel launches enqueued by the most recent
+ * srn_predict_batch* call on this thread, measured with HIP events on the launch stream (blocks
+ * until that work has finished); *out_launches = number of kernel launches it covered. */
+int srn_last_kernel_ms(const srn_index_t* idx, double* out_ms_main, double* out_ms_retry, uint32_t* out_retried);
+
+/* ---- misc ------------------------------------------------------------------------------- */
+int srn_device_count(int* out);
+void srn_limits(srn_limits_t* out);
+const char* srn_last_error(void);
+const char* srn_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SERENADE_HIP_H */

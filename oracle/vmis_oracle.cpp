@@ -1,0 +1,669 @@
+// =====================================================================================
+// oracle/vmis_oracle.cpp  --  TEST INFRASTRUCTURE ONLY.  NOT part of the product path.
+//
+// CPU restatement (C++17, no GPU, no product code) of the reference's VMIS-kNN
+// `predict_next` hot path, bolcom/serenade @ 2024-11-08.  Only tests/, the smoke check in
+// __graft_entry__.py and the `cpu_baseline` leg of bench.py may load this library.
+//
+// Two restatements live here, each function citing the reference lines it follows:
+//
+//   LITERAL    same sequential loop structure as the reference (hash map + 8-ary time heap +
+//              binary score heaps, f64 arithmetic, one query per call).  Used (a) to pin the
+//              restatement against the reference's own known answers and (b) as the timed
+//              CPU baseline ("port").
+//   CANONICAL  closed form of the same algorithm with a deterministic total tie-break
+//              (SURVEY.md section 8a "canonical semantics").  Integer-exact up to the final
+//              idf multiplication; this is what the HIP path is compared with bit-for-bit.
+//
+// Parity pinning (see tests/test_oracle_pins.py): KAT-1 `should_train_and_predict`
+// (src/vmisknn/mod.rs:229-310), the heap-order known answers (mod.rs:313-411), the README
+// response for item 13598 (README.md:154), the README evaluator aggregates (README.md:170-172,
+// 931 evaluations / HitRate@20 0.6402) -- the latter two need assets/example and run only
+// where /root/reference exists.
+//
+// What is NOT pinned by the reference (third-party containers, sources absent, Cargo.lock
+// ignored): hashbrown 0.11 iteration order, dary_heap 0.2.x sibling tie order, tdigest 0.2
+// quantile estimate.  They only decide behaviour among exact ties; the
+// literal restatement uses a fixed, documented choice for each.
+// =====================================================================================
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------------------------
+// Containers restated from the crates the reference uses on the hot path.
+// ---------------------------------------------------------------------------------
+
+static inline uint64_t mix64(uint64_t x) {
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
+    x ^= x >> 27; x *= 0x94d049bb133111ebULL;
+    x ^= x >> 31; return x;
+}
+
+// Open-addressing map standing in for hashbrown::HashMap (Cargo.toml:31).  Iteration order is
+// slot order under mix64 -- hashbrown's real order is unspecified and seeded per process, so
+// any fixed order is a valid instance of the reference's behaviour.
+template <typename K, typename V>
+struct FlatMap {
+    static constexpr uint8_t EMPTY = 0, FULL = 1, TOMB = 2;
+    std::vector<K> keys; std::vector<V> vals; std::vector<uint8_t> state;
+    size_t n_full = 0, n_used = 0, mask = 0;
+    explicit FlatMap(size_t cap = 0) { rehash(cap_for(cap)); }
+    static size_t cap_for(size_t n) { size_t c = 8; while (c * 7 < n * 8 + 8) c <<= 1; return c; }
+    void rehash(size_t c) {
+        std::vector<K> ok; std::vector<V> ov; std::vector<uint8_t> os;
+        ok.swap(keys); ov.swap(vals); os.swap(state);
+        keys.assign(c, K()); vals.assign(c, V()); state.assign(c, EMPTY);
+        mask = c - 1; n_full = n_used = 0;
+        for (size_t i = 0; i < os.size(); ++i) if (os[i] == FULL) *insert_slot(ok[i]) = ov[i];
+    }
+    size_t len() const { return n_full; }
+    V* get(const K& k) {
+        size_t i = mix64((uint64_t)k) & mask;
+        while (state[i] != EMPTY) { if (state[i] == FULL && keys[i] == k) return &vals[i]; i = (i + 1) & mask; }
+        return nullptr;
+    }
+    const V* get(const K& k) const { return const_cast<FlatMap*>(this)->get(k); }
+    // returns slot of existing or freshly inserted (value-initialised) entry
+    V* insert_slot(const K& k, bool* fresh = nullptr) {
+        if ((n_used + 1) * 8 > (mask + 1) * 7) rehash((mask + 1) * 2);
+        size_t i = mix64((uint64_t)k) & mask; size_t tomb = (size_t)-1;
+        while (state[i] != EMPTY) {
+            if (state[i] == FULL && keys[i] == k) { if (fresh) *fresh = false; return &vals[i]; }
+            if (state[i] == TOMB && tomb == (size_t)-1) tomb = i;
+            i = (i + 1) & mask;
+        }
+        if (tomb != (size_t)-1) i = tomb; else ++n_used;
+        state[i] = FULL; keys[i] = k; vals[i] = V(); ++n_full;
+        if (fresh) *fresh = true;
+        return &vals[i];
+    }
+    bool remove(const K& k) {
+        size_t i = mix64((uint64_t)k) & mask;
+        while (state[i] != EMPTY) {
+            if (state[i] == FULL && keys[i] == k) { state[i] = TOMB; --n_full; return true; }
+            i = (i + 1) & mask;
+        }
+        return false;
+    }
+    template <typename F> void for_each(F f) const {
+        for (size_t i = 0; i <= mask; ++i) if (state[i] == FULL) f(keys[i], vals[i]);
+    }
+};
+
+// Rust `Ordering` as int: -1 Less, 0 Equal, 1 Greater.
+// ARITY-ary max-heap by `Cmp`, restating std::collections::BinaryHeap (ARITY 2) and
+// dary_heap::OctonaryHeap (ARITY 8, Cargo.toml:38): push = sift-up with a hole, peek_mut +
+// overwrite = sift-down from the root choosing the greatest child.  Among equal children the
+// right-most is taken (std's `child += (l <= r)` rule; for dary_heap 0.2.x this detail is
+// unpinned -- SURVEY.md N1).
+template <typename T, typename Cmp, int ARITY>
+struct RustHeap {
+    std::vector<T> data; Cmp cmp;
+    bool le(const T& a, const T& b) const { return cmp(a, b) <= 0; }
+    bool lt(const T& a, const T& b) const { return cmp(a, b) < 0; }
+    bool ge(const T& a, const T& b) const { return cmp(a, b) >= 0; }
+    size_t len() const { return data.size(); }
+    void push(const T& v) {
+        data.push_back(v);
+        size_t pos = data.size() - 1; T elt = data[pos];
+        while (pos > 0) {
+            size_t parent = (pos - 1) / ARITY;
+            if (le(elt, data[parent])) break;
+            data[pos] = data[parent]; pos = parent;
+        }
+        data[pos] = elt;
+    }
+    T& peek() { return data[0]; }
+    void sift_down_range(size_t pos, size_t end) {
+        T elt = data[pos];
+        size_t child = ARITY * pos + 1;
+        while (child < end) {
+            size_t last = std::min(child + ARITY, end), best = child;
+            for (size_t c = child + 1; c < last; ++c) if (le(data[best], data[c])) best = c;
+            if (ge(elt, data[best])) break;
+            data[pos] = data[best]; pos = best; child = ARITY * pos + 1;
+        }
+        data[pos] = elt;
+    }
+    void replace_top(const T& v) { data[0] = v; sift_down_range(0, data.size()); }   // PeekMut drop
+    T pop() {
+        T top = data[0]; T last = data.back(); data.pop_back();
+        if (!data.empty()) { data[0] = last; sift_down_range(0, data.size()); }
+        return top;
+    }
+    std::vector<T> into_sorted_vec() {   // ascending by Cmp (std: swap root to the end, re-sift)
+        size_t end = data.size();
+        while (end > 1) { --end; std::swap(data[0], data[end]); sift_down_range(0, end); }
+        return std::move(data);
+    }
+};
+
+// src/vmisknn/mod.rs:15-43 (SessionScore), :45-74 (ItemScore): Ord reversed on score, NaN -> Equal.
+struct SessionScore { uint32_t id; double score; };
+struct ItemScore { uint64_t id; double score; };
+struct RevScoreCmp {
+    template <typename T> int operator()(const T& a, const T& b) const {
+        if (a.score < b.score) return 1;
+        if (a.score > b.score) return -1;
+        return 0;
+    }
+};
+// src/vmisknn/mod.rs:77-107 (SessionTime): Ord reversed on time.
+struct SessionTime { uint32_t session_id; uint32_t time; };
+struct RevTimeCmp {
+    int operator()(const SessionTime& a, const SessionTime& b) const {
+        return b.time < a.time ? -1 : (b.time > a.time ? 1 : 0);
+    }
+};
+using ScoreHeapS = RustHeap<SessionScore, RevScoreCmp, 2>;
+using ScoreHeapI = RustHeap<ItemScore, RevScoreCmp, 2>;
+using TimeHeap = RustHeap<SessionTime, RevTimeCmp, 8>;
+
+// ---------------------------------------------------------------------------------
+// The index: src/vmisknn/vmis_index.rs:28-35.
+// ---------------------------------------------------------------------------------
+struct Postings { uint64_t off; uint32_t len; };
+
+struct Index {
+    // item_to_top_sessions_ordered: HashMap<u64, Vec<u32>>  (vectors flattened, same probes)
+    FlatMap<uint64_t, Postings> item_to_top_sessions_ordered; std::vector<uint32_t> postings;
+    std::vector<uint32_t> session_to_max_time_stamp;
+    FlatMap<uint64_t, double> item_to_idf_score;
+    // session_to_items_sorted: Vec<Vec<u64>> flattened to CSR (ALL sessions)
+    std::vector<uint64_t> sess_off; std::vector<uint64_t> sess_items;
+    FlatMap<uint64_t, uint8_t> item_to_product_attributes;  // bit0 is_adult, bit1 is_for_sale
+    size_t total_pairs = 0;
+    const uint64_t* row(uint32_t s, size_t* len) const {
+        *len = (size_t)(sess_off[s + 1] - sess_off[s]); return sess_items.data() + sess_off[s];
+    }
+};
+
+// src/vmisknn/vmis_index.rs:532-588: stable left / right binary searches.
+static size_t bsearch_left(const std::vector<uint64_t>& a, uint64_t key) {
+    size_t top = a.size(), bottom = 0;
+    while (bottom < top) { size_t mid = bottom + (top - bottom) / 2; if (a[mid] < key) bottom = mid + 1; else top = mid; }
+    return top;
+}
+static size_t bsearch_right(const std::vector<uint64_t>& a, uint64_t key) {
+    size_t top = a.size(), bottom = 0;
+    while (bottom < top) { size_t mid = bottom + (top - bottom) / 2; if (a[mid] > key) top = mid; else bottom = mid + 1; }
+    return top - 1;
+}
+
+// prepare_hashmap, src/vmisknn/vmis_index.rs:422-528, step for step.
+static void prepare_hashmap_literal(Index& ix, size_t m_most_recent_sessions,
+                                    size_t max_training_session_length, double idf_weighting) {
+    const size_t n_sessions = ix.session_to_max_time_stamp.size();
+    std::vector<uint64_t> values; std::vector<uint32_t> sidx; std::vector<uint64_t> tss;
+    for (size_t s = 0; s < n_sessions; ++s) {                                  // :451-463
+        size_t len; const uint64_t* r = ix.row((uint32_t)s, &len);
+        if (len <= max_training_session_length)
+            for (size_t j = 0; j < len; ++j) {
+                values.push_back(r[j]); sidx.push_back((uint32_t)s);
+                tss.push_back(ix.session_to_max_time_stamp[s]);
+            }
+    }
+    std::vector<size_t> order(values.size());
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return values[a] < values[b]; });   // :466 (sort_by_key is stable)
+    std::vector<uint64_t> v_sorted(order.size()), t_sorted(order.size()); std::vector<uint32_t> s_sorted(order.size());
+    for (size_t i = 0; i < order.size(); ++i) { v_sorted[i] = values[order[i]]; s_sorted[i] = sidx[order[i]]; t_sorted[i] = tss[order[i]]; }
+    std::vector<uint64_t> unique_items = v_sorted;
+    unique_items.erase(std::unique(unique_items.begin(), unique_items.end()), unique_items.end());    // :481-482
+    ix.total_pairs = v_sorted.size();
+    for (uint64_t item : unique_items) {                                        // :487-518
+        size_t left = bsearch_left(v_sorted, item), right = bsearch_right(v_sorted, item);
+        size_t cnt = right + 1 - left;
+        std::vector<size_t> ti(cnt); std::iota(ti.begin(), ti.end(), 0);
+        std::stable_sort(ti.begin(), ti.end(), [&](size_t a, size_t b) { return t_sorted[left + a] < t_sorted[left + b]; });   // :498
+        std::vector<uint32_t> sessions(cnt);
+        for (size_t i = 0; i < cnt; ++i) sessions[i] = s_sorted[left + ti[i]];
+        std::reverse(sessions.begin(), sessions.end());                         // :503
+        if (sessions.size() > m_most_recent_sessions) sessions.resize(m_most_recent_sessions);   // :504
+        Postings p{ix.postings.size(), (uint32_t)sessions.size()};
+        ix.postings.insert(ix.postings.end(), sessions.begin(), sessions.end());
+        *ix.item_to_top_sessions_ordered.insert_slot(item) = p;
+        double idf = std::log((double)v_sorted.size() / (double)cnt) * idf_weighting;              // :509-512
+        *ix.item_to_idf_score.insert_slot(item) = idf;
+        *ix.item_to_product_attributes.insert_slot(item) = 2;                   // :514-517 {adult:false, for_sale:true}
+    }
+}
+
+// Same result as prepare_hashmap_literal in O(nnz) (counting sort over recency order); used for
+// the 60 M-interaction baseline index, and checked equal to the literal builder in the tests.
+static void prepare_hashmap_fast(Index& ix, size_t m_most_recent_sessions,
+                                 size_t max_training_session_length, double idf_weighting) {
+    const size_t n_sessions = ix.session_to_max_time_stamp.size();
+    std::vector<uint32_t> kept;
+    for (size_t s = 0; s < n_sessions; ++s)
+        if (ix.sess_off[s + 1] - ix.sess_off[s] <= max_training_session_length) kept.push_back((uint32_t)s);
+    // most recent first; ties -> larger session index first (stable ascending sort, then reversed)
+    std::stable_sort(kept.begin(), kept.end(), [&](uint32_t a, uint32_t b) {
+        return ix.session_to_max_time_stamp[a] < ix.session_to_max_time_stamp[b]; });
+    std::reverse(kept.begin(), kept.end());
+    FlatMap<uint64_t, uint32_t> dense(1024); std::vector<uint64_t> ids; std::vector<uint32_t> cnt;
+    size_t total = 0;
+    for (uint32_t s : kept) { size_t len; const uint64_t* r = ix.row(s, &len); total += len;
+        for (size_t j = 0; j < len; ++j) { bool fresh; uint32_t* d = dense.insert_slot(r[j], &fresh);
+            if (fresh) { *d = (uint32_t)ids.size(); ids.push_back(r[j]); cnt.push_back(0); } ++cnt[*d]; } }
+    ix.total_pairs = total;
+    std::vector<uint64_t> off(ids.size() + 1, 0);
+    for (size_t i = 0; i < ids.size(); ++i) off[i + 1] = off[i] + std::min<size_t>(cnt[i], m_most_recent_sessions);
+    ix.postings.assign(off.back(), 0);
+    std::vector<uint32_t> fill(ids.size(), 0);
+    for (uint32_t s : kept) { size_t len; const uint64_t* r = ix.row(s, &len);
+        for (size_t j = 0; j < len; ++j) { uint32_t d = *dense.get(r[j]);
+            if (fill[d] < m_most_recent_sessions) ix.postings[off[d] + fill[d]++] = s; } }
+    ix.item_to_top_sessions_ordered = FlatMap<uint64_t, Postings>(ids.size());
+    ix.item_to_idf_score = FlatMap<uint64_t, double>(ids.size());
+    ix.item_to_product_attributes = FlatMap<uint64_t, uint8_t>(ids.size());
+    for (size_t i = 0; i < ids.size(); ++i) {
+        *ix.item_to_top_sessions_ordered.insert_slot(ids[i]) = Postings{off[i], (uint32_t)(off[i + 1] - off[i])};
+        *ix.item_to_idf_score.insert_slot(ids[i]) = std::log((double)total / (double)cnt[i]) * idf_weighting;
+        *ix.item_to_product_attributes.insert_slot(ids[i]) = 2;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// LITERAL hot path.
+// ---------------------------------------------------------------------------------
+
+// find_neighbors, src/vmisknn/vmis_index.rs:325-415.
+static ScoreHeapS find_neighbors_literal(const Index& ix, const uint64_t* evolving, size_t len, size_t k, size_t m) {
+    TimeHeap heap_timestamps; heap_timestamps.data.reserve(m);                  // :332
+    FlatMap<uint32_t, double> session_similarities(m);                          // :333
+    std::vector<uint64_t> unique(evolving, evolving + len);                     // :335-337
+    std::sort(unique.begin(), unique.end());
+    unique.erase(std::unique(unique.begin(), unique.end()), unique.end());
+    const double qty_unique_session_items = (double)unique.size();              // :339
+    FlatMap<uint64_t, size_t> hash_items(len);                                  // :341
+    for (size_t pos = 0; pos < len; ++pos) {                                    // :344 reversed walk
+        const uint64_t item_id = evolving[len - 1 - pos];
+        bool fresh; size_t* slot = hash_items.insert_slot(item_id, &fresh); *slot = pos;   // :346
+        if (!fresh) continue;                                                   // :347
+        const Postings* similar = ix.item_to_top_sessions_ordered.get(item_id); // :350
+        if (!similar) continue;
+        const double decay_factor = (double)(len - pos) / qty_unique_session_items;   // :351-352
+        for (uint32_t j = 0; j < similar->len; ++j) {                           // :354
+            const uint32_t session_id = ix.postings[similar->off + j];
+            if (double* sim = session_similarities.get(session_id)) { *sim += decay_factor; continue; }   // :355-356
+            const uint32_t ts = ix.session_to_max_time_stamp[session_id];       // :358-359
+            if (session_similarities.len() < m) {                               // :360-366
+                *session_similarities.insert_slot(session_id) = decay_factor;
+                heap_timestamps.push(SessionTime{session_id, ts});
+            } else {
+                SessionTime& bottom = heap_timestamps.peek();                   // :368
+                if (ts > bottom.time) {                                         // :369-380
+                    session_similarities.remove(bottom.session_id);
+                    *session_similarities.insert_slot(session_id) = decay_factor;
+                    heap_timestamps.replace_top(SessionTime{session_id, ts});
+                } else break;                                                   // :381-383
+            }
+        }
+    }
+    ScoreHeapS closest; closest.data.reserve(k);                                // :394
+    session_similarities.for_each([&](uint32_t session_id, double score) {      // :395
+        if (closest.len() < k) { closest.push(SessionScore{session_id, score}); return; }
+        if (k == 0) return;   // (reference would panic on peek_mut of an empty heap)
+        SessionScore& bottom = closest.peek();
+        if (score > bottom.score) closest.replace_top(SessionScore{session_id, score});   // :401-403
+        else if (std::fabs(score - bottom.score) < 2.220446049250313e-16 &&
+                 ix.session_to_max_time_stamp[session_id] > ix.session_to_max_time_stamp[bottom.id])
+            closest.replace_top(SessionScore{session_id, score});               // :404-410
+    });
+    return closest;
+}
+
+// linear_score, src/vmisknn/mod.rs:110-116.
+static inline double linear_score(size_t pos) { return pos < 100 ? 1.0 - (0.1 * (double)pos) : 0.0; }
+
+// passes_business_rules, src/vmisknn/mod.rs:162-182.  attribute byte 0xFF = None.
+static inline bool passes_business_rules(int cur, int reco) {
+    if (reco < 0) return false;
+    if (reco & 2) { if (reco & 1) return cur >= 0 ? (cur & 1) != 0 : false; return true; }
+    return false;
+}
+
+enum { ORC_OK = 0, ORC_EPANIC = -1 };
+
+// predict, src/vmisknn/mod.rs:118-215.  Returns the heap already turned into
+// `into_sorted_vec()` order (score-descending), as every caller does (evaluator.rs:67-71).
+static int predict_literal(const Index& ix, const uint64_t* evolving, size_t len, size_t k, size_t m,
+                           size_t how_many, bool enable_business_logic, std::vector<ItemScore>& out) {
+    out.clear();
+    if (len == 0) return ORC_EPANIC;                                            // :157 unwrap on empty
+    ScoreHeapS neighbors = find_neighbors_literal(ix, evolving, len, k, m);     // :126
+    FlatMap<uint64_t, double> item_scores(1000);                                // :128
+    for (const SessionScore& scored_session : neighbors.data) {                 // :130 heap storage order
+        size_t rl; const uint64_t* training_item_ids = ix.row(scored_session.id, &rl);   // :131
+        size_t first_match_index = (size_t)-1;
+        for (size_t i = 0; i < len && first_match_index == (size_t)-1; ++i) {   // :133-138
+            const uint64_t it = evolving[len - 1 - i];
+            for (size_t j = 0; j < rl; ++j) if (training_item_ids[j] == it) { first_match_index = i; break; }
+        }
+        if (first_match_index == (size_t)-1) return ORC_EPANIC;                 // :138 unwrap
+        const double session_weight = linear_score(first_match_index + 1);      // :140-142
+        for (size_t j = 0; j < rl; ++j) {                                       // :144-153
+            const double* idfp = ix.item_to_idf_score.get(training_item_ids[j]);
+            if (!idfp) return ORC_EPANIC;                                       // vmis_index.rs:322 map index
+            const double item_idf = *idfp;
+            double* e = item_scores.insert_slot(training_item_ids[j]);
+            if (item_idf > 0.0) *e += session_weight * item_idf * scored_session.score;
+            else *e += session_weight * scored_session.score;
+        }
+    }
+    const uint64_t most_recent_item = evolving[len - 1];                        // :157-160
+    item_scores.remove(most_recent_item);
+    ScoreHeapI top_items; top_items.data.reserve(how_many);                     // :185
+    const uint8_t* ca = ix.item_to_product_attributes.get(most_recent_item);    // :186
+    const int cur = ca ? (int)*ca : -1;
+    item_scores.for_each([&](uint64_t reco_id, double reco_score) {             // :187
+        auto passes = [&]() { const uint8_t* ra = ix.item_to_product_attributes.get(reco_id);
+                              return passes_business_rules(cur, ra ? (int)*ra : -1); };
+        if (top_items.len() < how_many) {                                       // :190-198
+            if (!enable_business_logic || passes()) top_items.push(ItemScore{reco_id, reco_score});
+        } else if (how_many > 0) {
+            if (reco_score > top_items.peek().score)                            // :199-211
+                if (!enable_business_logic || passes()) top_items.replace_top(ItemScore{reco_id, reco_score});
+        }
+    });
+    out = top_items.into_sorted_vec();
+    return ORC_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// CANONICAL hot path (SURVEY.md 8a "canonical semantics", steps 1-6).
+// ---------------------------------------------------------------------------------
+struct Neighbor { uint32_t sid; uint32_t num; };
+struct Stats { uint64_t P, C, K, I, D, H, L; };
+
+static void neighbors_canonical(const Index& ix, const uint64_t* evolving, size_t len, size_t k, size_t m,
+                                std::vector<Neighbor>& out, size_t* U_out, Stats* st) {
+    out.clear();
+    std::vector<uint64_t> seen; std::unordered_map<uint32_t, uint32_t> num; size_t P = 0;
+    for (size_t pos = 0; pos < len; ++pos) {
+        const uint64_t item = evolving[len - 1 - pos];
+        if (std::find(seen.begin(), seen.end(), item) != seen.end()) continue;  // Q2: most recent occurrence only
+        seen.push_back(item);
+        const Postings* p = ix.item_to_top_sessions_ordered.get(item);
+        if (!p) continue;
+        const uint32_t w = (uint32_t)(len - pos);                               // Q1 numerator (with duplicates)
+        P += std::min<size_t>(p->len, m);
+        for (uint32_t j = 0; j < p->len; ++j) num[ix.postings[p->off + j]] += w;
+    }
+    *U_out = seen.size();                                                       // Q1 denominator (distinct raw ids)
+    auto more_recent = [&](uint32_t a, uint32_t b) {                            // strict total recency order
+        const uint32_t ta = ix.session_to_max_time_stamp[a], tb = ix.session_to_max_time_stamp[b];
+        return ta != tb ? ta > tb : a > b; };
+    std::vector<Neighbor> cand; cand.reserve(num.size());
+    for (auto& kv : num) cand.push_back(Neighbor{kv.first, kv.second});
+    std::sort(cand.begin(), cand.end(), [&](const Neighbor& a, const Neighbor& b) { return more_recent(a.sid, b.sid); });
+    if (cand.size() > m) cand.resize(m);                                        // step 1: m most recent of the union
+    const size_t C = cand.size();
+    std::stable_sort(cand.begin(), cand.end(), [&](const Neighbor& a, const Neighbor& b) { return a.num > b.num; });
+    if (cand.size() > k) cand.resize(k);                                        // step 3: (num desc, recency desc)
+    out = cand;
+    if (st) { st->P = P; st->C = C; st->K = out.size(); st->L = len; }
+}
+
+struct Scored { uint64_t id; double score; int64_t acc; };
+
+// all scored items before removal / filtering / cut (steps 4-5); returns false on "panic" inputs
+static bool scores_canonical(const Index& ix, const uint64_t* evolving, size_t len, size_t k, size_t m,
+                             std::vector<Scored>& all, std::vector<Neighbor>* nb_out, Stats* st) {
+    all.clear();
+    if (len == 0) return false;
+    std::vector<Neighbor> nb; size_t U = 0;
+    neighbors_canonical(ix, evolving, len, k, m, nb, &U, st);
+    std::unordered_map<uint64_t, int64_t> acc; size_t I = 0;
+    for (const Neighbor& n : nb) {
+        size_t rl; const uint64_t* row = ix.row(n.sid, &rl); I += rl;
+        size_t p = 0;
+        for (size_t i = 0; i < len && !p; ++i)
+            if (std::find(row, row + rl, evolving[len - 1 - i]) != row + rl) p = i + 1;    // Q4: full row
+        if (!p) return false;
+        const int64_t w10 = p < 100 ? 10 - (int64_t)p : 0;                      // Q3: 10*linear_score, exact
+        for (size_t j = 0; j < rl; ++j) acc[row[j]] += w10 * (int64_t)n.num;
+    }
+    const double denom = (double)(10 * U);
+    for (auto& kv : acc) {
+        const double* idfp = ix.item_to_idf_score.get(kv.first);
+        if (!idfp) return false;
+        const double idf_eff = *idfp > 0.0 ? *idfp : 1.0;
+        all.push_back(Scored{kv.first, idf_eff * (double)kv.second / denom, kv.second});
+    }
+    std::sort(all.begin(), all.end(), [](const Scored& a, const Scored& b) {
+        return a.score != b.score ? a.score > b.score : a.id < b.id; });
+    if (nb_out) *nb_out = nb;
+    if (st) { st->I = I; st->D = all.size(); }
+    return true;
+}
+
+static int predict_canonical(const Index& ix, const uint64_t* evolving, size_t len, size_t k, size_t m,
+                             size_t how_many, bool enable_business_logic, std::vector<Scored>& out, Stats* st) {
+    out.clear();
+    std::vector<Scored> all;
+    if (!scores_canonical(ix, evolving, len, k, m, all, nullptr, st)) return ORC_EPANIC;
+    const uint64_t cur_item = evolving[len - 1];
+    const uint8_t* ca = ix.item_to_product_attributes.get(cur_item);
+    const int cur = ca ? (int)*ca : -1;
+    for (const Scored& s : all) {
+        if (out.size() >= how_many) break;
+        if (s.id == cur_item) continue;                                         // Q6
+        if (enable_business_logic) { const uint8_t* ra = ix.item_to_product_attributes.get(s.id);
+            if (!passes_business_rules(cur, ra ? (int)*ra : -1)) continue; }
+        out.push_back(s);
+    }
+    if (st) st->H = out.size();
+    return ORC_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// read_from_file, src/vmisknn/vmis_index.rs:591-752 (TSV -> sessions), quirks Q8 kept.
+// ---------------------------------------------------------------------------------
+struct Sessions { std::vector<uint64_t> off, items; std::vector<uint32_t> ts; std::vector<uint64_t> session_ids; };
+
+static bool read_from_file_literal(const char* path, Sessions& out) {
+    FILE* f = fopen(path, "r"); if (!f) return false;
+    std::vector<uint64_t> session_id, item_id, time; char line[512];
+    bool header = true;
+    while (fgets(line, sizeof line, f)) {
+        if (header) { header = false; continue; }                               // has_headers(true) :596
+        unsigned long long s, i; double t;
+        if (sscanf(line, "%llu\t%llu\t%lf", &s, &i, &t) != 3) { fprintf(stderr, "Unable to parse input!\n"); continue; }   // :614-616
+        session_id.push_back(s); item_id.push_back(i); time.push_back((uint64_t)std::llround(t));    // :607-609 f64.round()
+    }
+    fclose(f);
+    const size_t n = session_id.size(); if (!n) return false;
+    std::vector<size_t> idx(n); std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return session_id[a] < session_id[b]; });   // :620-621
+    std::vector<uint64_t> ss(n), is(n), ts(n);
+    for (size_t i = 0; i < n; ++i) { ss[i] = session_id[idx[i]]; is[i] = item_id[idx[i]]; ts[i] = time[idx[i]]; }
+    out.off.assign(1, 0);
+    std::vector<uint64_t> history_session{is[0]}; uint64_t max_time_stamp = ts[0]; uint64_t cur_sid = ss[0];   // :664-667
+    for (size_t i = 1; i < n; ++i) {
+        if (ss[i] == ss[i - 1] && i != n - 1) {                                 // :669 (last-row quirk)
+            if (std::find(history_session.begin(), history_session.end(), is[i]) == history_session.end()) {
+                history_session.push_back(is[i]);
+                if (ts[i] > max_time_stamp) max_time_stamp = ts[i];             // only on non-duplicate rows :671-673
+            }
+        } else {
+            std::vector<uint64_t> sorted = history_session; std::sort(sorted.begin(), sorted.end());   // :676-678
+            out.items.insert(out.items.end(), sorted.begin(), sorted.end());
+            out.off.push_back(out.items.size()); out.ts.push_back((uint32_t)max_time_stamp);   // :680
+            out.session_ids.push_back(cur_sid);
+            history_session.assign(1, is[i]); max_time_stamp = ts[i]; cur_sid = ss[i];        // :681-685
+        }
+    }
+    return true;
+}
+
+static Index* index_from_sessions(const uint64_t* off, const uint64_t* items, const uint32_t* ts, size_t n,
+                                  size_t m_index, size_t max_len, double idf_w, bool fast) {
+    Index* ix = new Index();
+    ix->sess_off.assign(off, off + n + 1); ix->sess_items.assign(items, items + off[n]);
+    ix->session_to_max_time_stamp.assign(ts, ts + n);
+    if (fast) prepare_hashmap_fast(*ix, m_index, max_len, idf_w);
+    else prepare_hashmap_literal(*ix, m_index, max_len, idf_w);
+    return ix;
+}
+
+}  // namespace
+
+// =====================================================================================
+// C interface (ctypes) -- tests / smoke / bench cpu_baseline only.
+// =====================================================================================
+extern "C" {
+
+void* orc_index_build(const uint64_t* sess_off, const uint64_t* items, const uint32_t* ts, size_t n_sessions,
+                      size_t m_index, size_t max_len, double idf_weighting, int fast) {
+    return index_from_sessions(sess_off, items, ts, n_sessions, m_index, max_len, idf_weighting, fast != 0);
+}
+void orc_index_free(void* h) { delete (Index*)h; }
+
+// read_from_file restated; caller then copies the arrays out and frees.
+void* orc_sessions_read_tsv(const char* path) { Sessions* s = new Sessions(); if (!read_from_file_literal(path, *s)) { delete s; return nullptr; } return s; }
+size_t orc_sessions_count(void* h) { return ((Sessions*)h)->ts.size(); }
+size_t orc_sessions_nnz(void* h) { return ((Sessions*)h)->items.size(); }
+void orc_sessions_copy(void* h, uint64_t* off, uint64_t* items, uint32_t* ts, uint64_t* session_ids) {
+    Sessions* s = (Sessions*)h;
+    memcpy(off, s->off.data(), s->off.size() * 8); memcpy(items, s->items.data(), s->items.size() * 8);
+    memcpy(ts, s->ts.data(), s->ts.size() * 4); memcpy(session_ids, s->session_ids.data(), s->session_ids.size() * 8);
+}
+void orc_sessions_free(void* h) { delete (Sessions*)h; }
+
+int orc_index_set_attributes(void* h, const uint64_t* ids, const uint8_t* flags, size_t n) {
+    Index* ix = (Index*)h;   // flags: bit0 is_adult, bit1 is_for_sale, 0xFF = remove attributes (None)
+    for (size_t i = 0; i < n; ++i) { if (flags[i] == 0xFF) ix->item_to_product_attributes.remove(ids[i]);
+                                      else *ix->item_to_product_attributes.insert_slot(ids[i]) = flags[i] & 3; }
+    return 0;
+}
+size_t orc_index_num_items(void* h) { return ((Index*)h)->item_to_idf_score.len(); }
+size_t orc_index_total_pairs(void* h) { return ((Index*)h)->total_pairs; }
+// posting list + idf of one item (for index-parity tests); returns length or -1 if unknown
+long orc_index_postings(void* h, uint64_t item, uint32_t* out, size_t cap, double* idf) {
+    Index* ix = (Index*)h; const Postings* p = ix->item_to_top_sessions_ordered.get(item);
+    if (!p) return -1;
+    for (size_t j = 0; j < p->len && j < cap; ++j) out[j] = ix->postings[p->off + j];
+    if (idf) *idf = *ix->item_to_idf_score.get(item);
+    return (long)p->len;
+}
+
+int orc_predict_literal(void* h, const uint64_t* evolving, size_t len, size_t k, size_t m, size_t how_many,
+                        int business, uint64_t* out_ids, double* out_scores, size_t* out_n) {
+    std::vector<ItemScore> r;
+    int rc = predict_literal(*(Index*)h, evolving, len, k, m, how_many, business != 0, r);
+    *out_n = r.size();
+    for (size_t i = 0; i < r.size(); ++i) { out_ids[i] = r[i].id; out_scores[i] = r[i].score; }
+    return rc;
+}
+// neighbours in heap storage order (what predict iterates over), scores = similarity
+int orc_find_neighbors_literal(void* h, const uint64_t* evolving, size_t len, size_t k, size_t m,
+                               uint32_t* out_sid, double* out_score, size_t* out_n) {
+    ScoreHeapS nb = find_neighbors_literal(*(Index*)h, evolving, len, k, m);
+    *out_n = nb.len();
+    for (size_t i = 0; i < nb.len(); ++i) { out_sid[i] = nb.data[i].id; out_score[i] = nb.data[i].score; }
+    return 0;
+}
+int orc_predict_canonical(void* h, const uint64_t* evolving, size_t len, size_t k, size_t m, size_t how_many,
+                          int business, uint64_t* out_ids, double* out_scores, size_t* out_n, uint64_t* stats7) {
+    std::vector<Scored> r; Stats st{};
+    int rc = predict_canonical(*(Index*)h, evolving, len, k, m, how_many, business != 0, r, &st);
+    *out_n = r.size();
+    for (size_t i = 0; i < r.size(); ++i) { out_ids[i] = r[i].id; out_scores[i] = r[i].score; }
+    if (stats7) { stats7[0] = st.P; stats7[1] = st.C; stats7[2] = st.K; stats7[3] = st.I; stats7[4] = st.D; stats7[5] = st.H; stats7[6] = st.L; }
+    return rc;
+}
+int orc_neighbors_canonical(void* h, const uint64_t* evolving, size_t len, size_t k, size_t m,
+                            uint32_t* out_sid, uint32_t* out_num, size_t* out_n, size_t* out_U) {
+    std::vector<Neighbor> nb; size_t U = 0;
+    neighbors_canonical(*(Index*)h, evolving, len, k, m, nb, &U, nullptr);
+    *out_n = nb.size(); if (out_U) *out_U = U;
+    for (size_t i = 0; i < nb.size(); ++i) { out_sid[i] = nb[i].sid; out_num[i] = nb[i].num; }
+    return 0;
+}
+// every scored item (sorted score desc, id asc) with its exact integer accumulator; cap-limited
+long orc_scores_canonical(void* h, const uint64_t* evolving, size_t len, size_t k, size_t m,
+                          uint64_t* out_ids, double* out_scores, int64_t* out_acc, size_t cap) {
+    std::vector<Scored> all;
+    if (!scores_canonical(*(Index*)h, evolving, len, k, m, all, nullptr, nullptr)) return -1;
+    for (size_t i = 0; i < all.size() && i < cap; ++i) { out_ids[i] = all[i].id; out_scores[i] = all[i].score; if (out_acc) out_acc[i] = all[i].acc; }
+    return (long)all.size();
+}
+
+// Batch drivers.  which: 0 literal, 1 canonical.  Queries are CSR (items_flat, q_off).  Results are
+// written [nq x how_many]; stats (canonical only) [nq x 7] may be NULL.  `threads` worker threads
+// share the read-only index like the reference's actix workers (src/bin/serving.rs:62-94).
+// lat_us (optional, [nq]) receives the per-call wall time in microseconds, measured around each
+// call exactly as src/bin/evaluator.rs:57-66 does.  Returns elapsed seconds for the whole batch.
+double orc_predict_batch(void* h, int which, const uint64_t* items_flat, const uint32_t* q_off, size_t nq,
+                         size_t k, size_t m, size_t how_many, int business, int threads,
+                         uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint64_t* stats, double* lat_us) {
+    const Index& ix = *(Index*)h;
+    if (threads < 1) threads = 1;
+    std::atomic<size_t> next{0};
+    auto t0 = std::chrono::steady_clock::now();
+    auto work = [&]() {
+        std::vector<ItemScore> rl; std::vector<Scored> rc;
+        for (;;) {
+            size_t q0 = next.fetch_add(64); if (q0 >= nq) break;
+            for (size_t q = q0; q < std::min(nq, q0 + 64); ++q) {
+                const uint64_t* ev = items_flat + q_off[q]; size_t len = q_off[q + 1] - q_off[q];
+                auto c0 = std::chrono::steady_clock::now();
+                size_t n = 0;
+                if (which == 0) { predict_literal(ix, ev, len, k, m, how_many, business != 0, rl); n = rl.size(); }
+                else { Stats st{}; predict_canonical(ix, ev, len, k, m, how_many, business != 0, rc, &st); n = rc.size();
+                       if (stats) { uint64_t* s = stats + q * 7; s[0] = st.P; s[1] = st.C; s[2] = st.K; s[3] = st.I; s[4] = st.D; s[5] = st.H; s[6] = st.L; } }
+                auto c1 = std::chrono::steady_clock::now();
+                if (lat_us) lat_us[q] = std::chrono::duration<double, std::micro>(c1 - c0).count();
+                if (out_counts) out_counts[q] = (uint32_t)n;
+                if (out_ids) for (size_t i = 0; i < n; ++i) {
+                    out_ids[q * how_many + i] = which == 0 ? rl[i].id : rc[i].id;
+                    out_scores[q * how_many + i] = which == 0 ? rl[i].score : rc[i].score; }
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// Heap known-answer helpers (mod.rs:313-411): keep the `how_many` best with the reference's
+// push / peek_mut-replace protocol, then pop everything; returns ids in pop order.
+size_t orc_kat_itemscore_heap(const uint64_t* ids, const double* scores, size_t n, size_t how_many, uint64_t* popped) {
+    ScoreHeapI h;
+    for (size_t i = 0; i < n; ++i) {
+        if (h.len() < how_many) h.push(ItemScore{ids[i], scores[i]});
+        else if (scores[i] > h.peek().score) h.replace_top(ItemScore{ids[i], scores[i]});
+    }
+    size_t c = 0; while (h.len()) popped[c++] = h.pop().id; return c;
+}
+size_t orc_kat_itemscore_sorted(const uint64_t* ids, const double* scores, size_t n, uint64_t* out) {
+    ScoreHeapI h; for (size_t i = 0; i < n; ++i) h.push(ItemScore{ids[i], scores[i]});
+    auto v = h.into_sorted_vec(); for (size_t i = 0; i < v.size(); ++i) out[i] = v[i].id; return v.size();
+}
+size_t orc_kat_sessiontime_heap(const uint32_t* ids, const uint32_t* times, size_t n, size_t how_many, uint32_t* popped) {
+    TimeHeap h;
+    for (size_t i = 0; i < n; ++i) {
+        if (h.len() < how_many) h.push(SessionTime{ids[i], times[i]});
+        else if (times[i] > h.peek().time) h.replace_top(SessionTime{ids[i], times[i]});
+    }
+    size_t c = 0; while (h.len()) popped[c++] = h.pop().session_id; return c;
+}
+
+}  // extern "C"

@@ -1,0 +1,51 @@
+"""Builds libserenade_hip.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
+
+hipcc cross-compiles without a GPU, so this runs in the CPU-only container; the resulting .so
+travels to the GPU box with the source snapshot (it is git-ignored, not gpurun-ignored).
+"""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libserenade_hip.so")
+SYNTH_LIB = os.path.join(HERE, "libsrn_synth.so")
+SOURCES = ["srn_index.cpp", "srn_capi.cpp", "srn_kernels.hip"]
+HEADERS = ["srn_internal.h", os.path.join("..", "..", "include", "serenade_hip.h")]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_hip(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
+    if force or _stale(LIB, deps):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+               "-Wno-unused-value", "-o", LIB] + srcs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+def build_synth(force=False):
+    src = os.path.join(CSRC, "srn_synth.cpp")
+    if force or _stale(SYNTH_LIB, [src]):
+        subprocess.check_call(["g++", "-O3", "-march=x86-64-v3", "-std=c++17", "-fPIC", "-shared", "-pthread",
+                               "-o", SYNTH_LIB, src])
+    return SYNTH_LIB
+
+
+def build_all(force=False, verbose=False):
+    build_hip(force, verbose)
+    build_synth(force)
+
+
+if __name__ == "__main__":
+    build_all(force=True, verbose=True)

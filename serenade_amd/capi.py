@@ -1,0 +1,104 @@
+"""ctypes binding of libserenade_hip.so (include/serenade_hip.h).  Thin: every call maps 1:1 onto a C
+entry point and raises SerenadeError with srn_last_error() on a negative return code."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+SRN_OK, SRN_EINVAL, SRN_ENOMEM, SRN_EHIP, SRN_ERANGE, SRN_EIO, SRN_ENODEV = 0, -1, -2, -3, -4, -5, -6
+ATTR_ADULT, ATTR_FOR_SALE, ATTR_NONE = 1, 2, 0xFF
+FLAG_BUSINESS_LOGIC = 1
+MAX_HOW_MANY, MAX_SESSION_LEN, MAX_K = 512, 255, 8192
+
+_CODES = {SRN_EINVAL: "SRN_EINVAL", SRN_ENOMEM: "SRN_ENOMEM", SRN_EHIP: "SRN_EHIP", SRN_ERANGE: "SRN_ERANGE",
+          SRN_EIO: "SRN_EIO", SRN_ENODEV: "SRN_ENODEV"}
+
+
+class SerenadeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s: %s" % (_CODES.get(code, code), msg))
+        self.code = code
+
+
+class SessionsView(C.Structure):
+    _fields_ = [("sess_off", C.c_void_p), ("items", C.c_void_p), ("max_ts", C.c_void_p), ("n_sessions", C.c_size_t)]
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_items", "n_sessions_total", "n_sessions_kept", "nnz_rows", "nnz_postings",
+                                          "m_index", "max_session_len", "max_row_len", "device_bytes")] + \
+               [("device", C.c_int32), ("offsets_64bit", C.c_int32), ("idf_weighting", C.c_double)]
+
+
+class Limits(C.Structure):
+    _fields_ = [("max_how_many", C.c_uint32), ("max_session_len", C.c_uint32), ("max_k", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+# every symbol include/serenade_hip.h declares: (restype, argtypes)
+_vp, _sz, _u64, _i = C.c_void_p, C.c_size_t, C.c_uint64, C.c_int
+SYMBOLS = {
+    "srn_sessions_from_tsv": (_i, [C.c_char_p, C.POINTER(_vp)]),
+    "srn_sessions_view": (_i, [_vp, C.POINTER(SessionsView)]),
+    "srn_sessions_length_quantile": (_i, [_vp, C.c_double, C.POINTER(_u64)]),
+    "srn_sessions_free": (None, [_vp]),
+    "srn_index_build": (_i, [C.POINTER(SessionsView), _sz, _sz, C.c_double, _i, C.POINTER(_vp)]),
+    "srn_index_new_from_csv": (_i, [C.c_char_p, _sz, C.c_double, _sz, _i, C.POINTER(_vp)]),
+    "srn_index_save": (_i, [_vp, C.c_char_p]),
+    "srn_index_load": (_i, [C.c_char_p, _i, C.POINTER(_vp)]),
+    "srn_index_set_attributes": (_i, [_vp, _vp, _vp, _sz]),
+    "srn_index_info": (_i, [_vp, C.POINTER(IndexInfo)]),
+    "srn_index_postings": (_i, [_vp, _u64, _vp, _sz, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "srn_index_free": (None, [_vp]),
+    "srn_predict": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _i, _vp, _vp, C.POINTER(_sz)]),
+    "srn_predict_batch": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint, _vp, _vp, _vp]),
+    "srn_predict_batch_device": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, C.c_uint, _vp, _vp, _vp, _vp]),
+    "srn_predict_batch_debug": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "srn_last_kernel_ms": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
+    "srn_device_count": (_i, [C.POINTER(_i)]),
+    "srn_limits": (None, [C.POINTER(Limits)]),
+    "srn_last_error": (C.c_char_p, []),
+    "srn_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the in-tree HIP library.  Fails loudly if it is missing: there is no fallback path."""
+    global _lib
+    if _lib is None:
+        path = _build.LIB
+        if not os.path.exists(path):
+            raise ImportError("libserenade_hip.so is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no CPU fallback for the predict path)")
+        L = C.CDLL(path)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise SerenadeError(rc, lib().srn_last_error().decode(errors="replace"))
+
+
+def ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def as_u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def as_u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def device_count():
+    n = C.c_int()
+    check(lib().srn_device_count(C.byref(n)))
+    return n.value

@@ -1,0 +1,212 @@
+// C ABI of libserenade_hip.so (include/serenade_hip.h): argument validation, error codes, handle
+// ownership.  No compute happens here -- predict calls go to the HIP kernels or fail.
+#include <algorithm>
+#include <cstring>
+#include <new>
+
+#include "srn_internal.h"
+
+namespace srn { const char* last_error_cstr(); int device_count(); }
+using namespace srn;
+
+namespace {
+template <typename F> int guarded(F f) {   // never let an exception cross the C boundary
+    try { return f(); }
+    catch (const std::bad_alloc&) { return fail(SRN_ENOMEM, "out of host memory"); }
+    catch (const std::exception& e) { return fail(SRN_EINVAL, std::string("internal error: ") + e.what()); }
+    catch (...) { return fail(SRN_EINVAL, "internal error"); }
+}
+
+int check_predict_args(const srn_index_t* idx, size_t k, size_t m, size_t how_many) {
+    if (!idx) return fail(SRN_EINVAL, "null index");
+    if (!idx->dev) return fail(SRN_ENODEV, "index has no device attached; there is no CPU fallback behind this ABI");
+    // the reference panics (peek_mut().unwrap() on an empty heap) when any of these is zero
+    if (k == 0 || m == 0 || how_many == 0) return fail(SRN_EINVAL, "k, m and how_many must be > 0");
+    if (how_many > SRN_MAX_HOW_MANY) return fail(SRN_ERANGE, "how_many above SRN_MAX_HOW_MANY");
+    if (k > SRN_MAX_K) return fail(SRN_ERANGE, "k above SRN_MAX_K");
+    if (m > 0x7FFFFFFFull) return fail(SRN_ERANGE, "m too large");
+    return SRN_OK;
+}
+
+int predict_host(const srn_index_t* idx, const uint64_t* items_flat, const uint32_t* q_off, size_t nq, size_t k, size_t m,
+                 size_t how_many, unsigned flags, uint64_t* out_ids, double* out_scores, uint32_t* out_counts,
+                 uint32_t* out_stats, uint32_t* out_nb_sessions, uint32_t* out_nb_num, uint32_t* out_nb_counts) {
+    int rc = check_predict_args(idx, k, m, how_many); if (rc) return rc;
+    if (nq == 0) return SRN_OK;
+    if (!items_flat || !q_off || !out_ids || !out_scores || !out_counts) return fail(SRN_EINVAL, "null buffer");
+    if (nq > 0x7FFFFFFFull) return fail(SRN_ERANGE, "too many queries in one batch");
+    if ((out_nb_sessions != nullptr) != (out_nb_num != nullptr) || (out_nb_sessions != nullptr) != (out_nb_counts != nullptr))
+        return fail(SRN_EINVAL, "neighbour debug outputs must be given together");
+    uint32_t max_len = 0;
+    for (size_t q = 0; q < nq; ++q) {
+        if (q_off[q + 1] < q_off[q]) return fail(SRN_EINVAL, "q_off not monotone");
+        const uint32_t len = q_off[q + 1] - q_off[q];
+        if (len == 0) return fail(SRN_EINVAL, "empty evolving session (the reference panics: src/vmisknn/mod.rs:157)");
+        max_len = std::max(max_len, len);
+    }
+    if (max_len > SRN_MAX_SESSION_LEN) return fail(SRN_ERANGE, "evolving session longer than SRN_MAX_SESSION_LEN");
+    LaunchParams p{};
+    p.nq = (uint32_t)nq; p.k = (uint32_t)k; p.m = (uint32_t)m; p.how_many = (uint32_t)how_many; p.flags = flags; p.max_len = max_len;
+    rc = device_predict(idx->dev, idx->flat, p, false, nullptr, items_flat, q_off, out_ids, out_scores, out_counts, out_stats,
+                        out_nb_sessions, out_nb_num, out_nb_counts);
+    if (rc) return rc;
+    for (size_t q = 0; q < nq; ++q)
+        if (out_counts[q] == 0xFFFFFFFFu) return fail(SRN_ERANGE, "a query exceeded the kernel's table limits");
+    if (out_nb_sessions)   // recency rank -> reference session index
+        for (size_t q = 0; q < nq; ++q)
+            for (uint32_t j = 0; j < out_nb_counts[q]; ++j) {
+                uint32_t& r = out_nb_sessions[q * k + j];
+                r = idx->flat.rank_to_session[r];
+            }
+    return SRN_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char* srn_last_error(void) { return last_error_cstr(); }
+const char* srn_version(void) { return "serenade_hip 0.1 (gfx950)"; }
+int srn_device_count(int* out) { if (!out) return fail(SRN_EINVAL, "null argument"); *out = device_count(); return SRN_OK; }
+void srn_limits(srn_limits_t* out) { if (out) *out = srn_limits_t{SRN_MAX_HOW_MANY, SRN_MAX_SESSION_LEN, SRN_MAX_K, 0}; }
+
+int srn_sessions_from_tsv(const char* path, srn_sessions_t** out) {
+    return guarded([&]() -> int {
+        if (!path || !out) return fail(SRN_EINVAL, "null argument");
+        *out = nullptr;
+        srn_sessions* s = new srn_sessions();
+        int rc = sessions_from_tsv(path, s->s);
+        if (rc) { delete s; return rc; }
+        *out = s; return SRN_OK; });
+}
+int srn_sessions_view(const srn_sessions_t* s, srn_sessions_view_t* out) {
+    if (!s || !out) return fail(SRN_EINVAL, "null argument");
+    out->sess_off = s->s.off.data(); out->items = s->s.items.data(); out->max_ts = s->s.ts.data(); out->n_sessions = s->s.ts.size();
+    return SRN_OK;
+}
+int srn_sessions_length_quantile(const srn_sessions_t* s, double q, uint64_t* out) {
+    if (!s || !out || !(q >= 0.0 && q <= 1.0)) return fail(SRN_EINVAL, "bad argument");
+    return guarded([&]() -> int { *out = sessions_length_quantile(s->s.off.data(), s->s.ts.size(), q); return SRN_OK; });
+}
+void srn_sessions_free(srn_sessions_t* s) { delete s; }
+
+int srn_index_build(const srn_sessions_view_t* sessions, size_t m_index, size_t max_session_len, double idf_weighting,
+                    int device, srn_index_t** out) {
+    return guarded([&]() -> int {
+        if (!sessions || !out) return fail(SRN_EINVAL, "null argument");
+        *out = nullptr;
+        srn_index* ix = new srn_index();
+        int rc = build_flat_index(*sessions, m_index, max_session_len, idf_weighting, ix->flat);
+        if (rc == SRN_OK && device >= 0) { ix->dev = device_attach(ix->flat, device); ix->device = device; if (!ix->dev) rc = SRN_EHIP; }
+        if (rc) { delete ix; return rc; }
+        *out = ix; return SRN_OK; });
+}
+
+int srn_index_new_from_csv(const char* path, size_t m_most_recent_sessions, double idf_weighting, size_t max_session_len,
+                           int device, srn_index_t** out) {
+    return guarded([&]() -> int {
+        if (!path || !out) return fail(SRN_EINVAL, "null argument");
+        Sessions s; int rc = sessions_from_tsv(path, s); if (rc) return rc;
+        if (max_session_len == 0) max_session_len = sessions_length_quantile(s.off.data(), s.ts.size(), 0.995);
+        srn_sessions_view_t v{s.off.data(), s.items.data(), s.ts.data(), s.ts.size()};
+        return srn_index_build(&v, m_most_recent_sessions, max_session_len, idf_weighting, device, out); });
+}
+
+int srn_index_save(const srn_index_t* idx, const char* path) {
+    if (!idx || !path) return fail(SRN_EINVAL, "null argument");
+    return guarded([&]() -> int { return save_flat_index(idx->flat, path); });
+}
+int srn_index_load(const char* path, int device, srn_index_t** out) {
+    return guarded([&]() -> int {
+        if (!path || !out) return fail(SRN_EINVAL, "null argument");
+        *out = nullptr;
+        srn_index* ix = new srn_index();
+        int rc = load_flat_index(path, ix->flat);
+        if (rc == SRN_OK && device >= 0) { ix->dev = device_attach(ix->flat, device); ix->device = device; if (!ix->dev) rc = SRN_EHIP; }
+        if (rc) { delete ix; return rc; }
+        *out = ix; return SRN_OK; });
+}
+int srn_index_set_attributes(srn_index_t* idx, const uint64_t* item_ids, const uint8_t* flags, size_t n) {
+    if (!idx || (n && (!item_ids || !flags))) return fail(SRN_EINVAL, "null argument");
+    return guarded([&]() -> int {
+        for (size_t i = 0; i < n; ++i) {
+            const uint32_t j = idx->flat.lookup(item_ids[i]);
+            if (j == kNone) continue;   // attributes of items outside the index can never be consulted
+            idx->flat.attr[j] = flags[i] == SRN_ATTR_NONE ? (uint8_t)SRN_ATTR_NONE : (uint8_t)(flags[i] & 3u);
+        }
+        return idx->dev ? device_update_attr(idx->dev, idx->flat) : SRN_OK; });
+}
+int srn_index_info(const srn_index_t* idx, srn_index_info_t* out) {
+    if (!idx || !out) return fail(SRN_EINVAL, "null argument");
+    const FlatIndex& f = idx->flat;
+    *out = srn_index_info_t{f.n_items, f.n_sessions_total, f.n_kept, f.nnz_rows, f.nnz_post, f.m_index, f.max_session_len,
+                            f.max_row_len, device_bytes(idx->dev), idx->dev ? idx->device : -1,
+                            f.nnz_rows >= 0xFFFFFFFFull ? 1 : 0, f.idf_weighting};
+    return SRN_OK;
+}
+int srn_index_postings(const srn_index_t* idx, uint64_t item_id, uint32_t* out_sessions, size_t cap, int64_t* out_len, double* out_idf) {
+    if (!idx || !out_len) return fail(SRN_EINVAL, "null argument");
+    const FlatIndex& f = idx->flat;
+    const uint32_t j = f.lookup(item_id);
+    if (j == kNone) { *out_len = -1; return SRN_OK; }
+    const uint64_t o0 = f.post_off[j], o1 = f.post_off[j + 1];
+    *out_len = (int64_t)(o1 - o0);
+    if (out_sessions) for (uint64_t t = o0; t < o1 && t - o0 < cap; ++t) out_sessions[t - o0] = f.rank_to_session[f.post_rank[t]];
+    if (out_idf) *out_idf = f.idf[j];
+    return SRN_OK;
+}
+void srn_index_free(srn_index_t* idx) {
+    if (!idx) return;
+    device_release(idx->dev);
+    delete idx;
+}
+
+int srn_predict(const srn_index_t* idx, const uint64_t* evolving, size_t len, size_t k, size_t m, size_t how_many,
+                int enable_business_logic, uint64_t* out_ids, double* out_scores, size_t* out_n) {
+    return guarded([&]() -> int {
+        if (!out_n) return fail(SRN_EINVAL, "null out_n");
+        *out_n = 0;
+        if (!evolving || len == 0) return fail(SRN_EINVAL, "empty evolving session (the reference panics: src/vmisknn/mod.rs:157)");
+        if (len > SRN_MAX_SESSION_LEN) return fail(SRN_ERANGE, "evolving session longer than SRN_MAX_SESSION_LEN");
+        const uint32_t q_off[2] = {0, (uint32_t)len}; uint32_t cnt = 0;
+        int rc = predict_host(idx, evolving, q_off, 1, k, m, how_many, enable_business_logic ? SRN_FLAG_BUSINESS_LOGIC : 0, out_ids,
+                              out_scores, &cnt, nullptr, nullptr, nullptr, nullptr);
+        if (rc == SRN_OK) *out_n = cnt;
+        return rc; });
+}
+
+int srn_predict_batch(const srn_index_t* idx, const uint64_t* items_flat, const uint32_t* q_off, size_t nq, size_t k, size_t m,
+                      size_t how_many, unsigned flags, uint64_t* out_ids, double* out_scores, uint32_t* out_counts) {
+    return guarded([&]() -> int { return predict_host(idx, items_flat, q_off, nq, k, m, how_many, flags, out_ids, out_scores,
+                                                       out_counts, nullptr, nullptr, nullptr, nullptr); });
+}
+
+int srn_predict_batch_debug(const srn_index_t* idx, const uint64_t* items_flat, const uint32_t* q_off, size_t nq, size_t k, size_t m,
+                            size_t how_many, unsigned flags, uint64_t* out_ids, double* out_scores, uint32_t* out_counts,
+                            uint32_t* out_stats, uint32_t* out_nb_sessions, uint32_t* out_nb_num, uint32_t* out_nb_counts) {
+    return guarded([&]() -> int { return predict_host(idx, items_flat, q_off, nq, k, m, how_many, flags, out_ids, out_scores,
+                                                       out_counts, out_stats, out_nb_sessions, out_nb_num, out_nb_counts); });
+}
+
+int srn_predict_batch_device(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq,
+                             size_t max_len_hint, size_t k, size_t m, size_t how_many, unsigned flags, uint64_t* d_out_ids,
+                             double* d_out_scores, uint32_t* d_out_counts, void* stream) {
+    return guarded([&]() -> int {
+        int rc = check_predict_args(idx, k, m, how_many); if (rc) return rc;
+        if (nq == 0) return SRN_OK;
+        if (!d_items_flat || !d_q_off || !d_out_ids || !d_out_scores || !d_out_counts) return fail(SRN_EINVAL, "null buffer");
+        if (nq > 0x7FFFFFFFull) return fail(SRN_ERANGE, "too many queries in one batch");
+        if (max_len_hint == 0 || max_len_hint > SRN_MAX_SESSION_LEN) return fail(SRN_ERANGE, "max_len_hint out of range");
+        LaunchParams p{};
+        p.nq = (uint32_t)nq; p.k = (uint32_t)k; p.m = (uint32_t)m; p.how_many = (uint32_t)how_many; p.flags = flags;
+        p.max_len = (uint32_t)max_len_hint;
+        p.items_flat = d_items_flat; p.q_off = d_q_off; p.out_ids = d_out_ids; p.out_scores = d_out_scores; p.out_counts = d_out_counts;
+        return device_predict(idx->dev, idx->flat, p, true, stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                              nullptr, nullptr); });
+}
+
+int srn_last_kernel_ms(const srn_index_t* idx, double* out_ms_main, double* out_ms_retry, uint32_t* out_retried) {
+    if (!idx || !idx->dev) return fail(SRN_ENODEV, "index has no device attached");
+    return guarded([&]() -> int { return device_last_kernel_ms(idx->dev, out_ms_main, out_ms_retry, out_retried); });
+}
+
+}  // extern "C"

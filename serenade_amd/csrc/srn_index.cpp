@@ -1,0 +1,246 @@
+// Host side of the index: TSV loader, flat-index builder, binary save / load.
+//
+// Mirrors the *semantics* of the reference's index construction so that the GPU path consumes the
+// same logical index -- read_from_file (src/vmisknn/vmis_index.rs:591-686) and prepare_hashmap
+// (:422-528) -- but produces the flat CSR layout described in DESIGN.md instead of hash maps of
+// vectors: item ids become dense indices in ascending-id order, sessions are renumbered by recency
+// rank (so "more recent" == larger u32 and the timestamp gather of find_neighbors disappears),
+// postings and rows are two CSR arrays.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+
+#include "srn_internal.h"
+
+namespace srn {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+const char* last_error_cstr() { return g_err.c_str(); }
+
+// ---------------------------------------------------------------------------------------------
+// TSV loader
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct Row { uint64_t session, item, time; };
+
+// one "SessionId\tItemId\tTime" line; false = unparsable (the reference skips such rows, :614-616)
+bool parse_line(const char* p, const char* end, Row& r) {
+    auto parse_u64 = [&](uint64_t& v) {
+        if (p >= end || *p < '0' || *p > '9') return false;
+        v = 0; while (p < end && *p >= '0' && *p <= '9') v = v * 10 + (uint64_t)(*p++ - '0');
+        return true; };
+    if (!parse_u64(r.session)) return false;
+    if (p >= end || *p != '\t') return false; ++p;
+    if (!parse_u64(r.item)) return false;
+    if (p >= end || *p != '\t') return false; ++p;
+    char buf[64]; size_t n = std::min<size_t>((size_t)(end - p), sizeof buf - 1);
+    memcpy(buf, p, n); buf[n] = 0;
+    char* stop = nullptr; double t = strtod(buf, &stop);
+    if (stop == buf) return false;
+    while (*stop == ' ' || *stop == '\r') ++stop;
+    if (*stop != 0 && *stop != '\t') return false;
+    if (!(t >= 0)) t = 0;                 // `as usize` saturates negatives / NaN to 0
+    r.time = (uint64_t)std::llround(t);   // f64::round(): half away from zero (:607-609)
+    return true;
+}
+}  // namespace
+
+int sessions_from_tsv(const char* path, Sessions& out) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(SRN_EIO, std::string("cannot open ") + path);
+    std::vector<char> text;
+    { char chunk[1 << 16]; size_t n; while ((n = fread(chunk, 1, sizeof chunk, f)) > 0) text.insert(text.end(), chunk, chunk + n); }
+    fclose(f);
+    std::vector<Row> rows;
+    const char* p = text.data(); const char* end = p + text.size(); bool header = true;
+    while (p < end) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p)); if (!nl) nl = end;
+        if (header) header = false;
+        else if (nl > p) { Row r; if (parse_line(p, nl, r)) rows.push_back(r); }
+        p = nl + 1;
+    }
+    if (rows.empty()) return fail(SRN_EINVAL, "no training rows");
+    // the data is unsorted: stable order by session id keeps file order inside a session (:620-621)
+    std::stable_sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { return a.session < b.session; });
+    out = Sessions(); out.off.push_back(0);
+    std::vector<uint64_t> cur{rows[0].item}; uint64_t cur_max = rows[0].time, cur_sid = rows[0].session;
+    const size_t n = rows.size();
+    for (size_t i = 1; i < n; ++i) {
+        const bool same = rows[i].session == rows[i - 1].session && i != n - 1;   // final row never extends (:669)
+        if (same) {
+            if (std::find(cur.begin(), cur.end(), rows[i].item) == cur.end()) {
+                cur.push_back(rows[i].item);
+                cur_max = std::max(cur_max, rows[i].time);   // only non-duplicate rows move the max (:670-673)
+            }
+        } else {
+            std::sort(cur.begin(), cur.end());
+            out.items.insert(out.items.end(), cur.begin(), cur.end());
+            out.off.push_back(out.items.size()); out.ts.push_back((uint32_t)cur_max); out.session_ids.push_back(cur_sid);
+            cur.assign(1, rows[i].item); cur_max = rows[i].time; cur_sid = rows[i].session;
+        }
+    }
+    // the session open at the end of the loop is never pushed (:675-686)
+    return SRN_OK;
+}
+
+uint64_t sessions_length_quantile(const uint64_t* off, size_t n, double q) {
+    if (n == 0) return 0;
+    std::vector<uint64_t> len(n);
+    for (size_t i = 0; i < n; ++i) len[i] = off[i + 1] - off[i];
+    std::sort(len.begin(), len.end());
+    const double pos = q * (double)(n - 1); const size_t lo = (size_t)std::floor(pos);
+    const size_t hi = std::min(n - 1, lo + 1); const double frac = pos - (double)lo;
+    return (uint64_t)std::llround((double)len[lo] + frac * ((double)len[hi] - (double)len[lo]));
+}
+
+// ---------------------------------------------------------------------------------------------
+// flat index builder
+// ---------------------------------------------------------------------------------------------
+int build_flat_index(const srn_sessions_view_t& v, size_t m_index, size_t max_session_len, double idf_weighting,
+                     FlatIndex& ix) {
+    if (!v.sess_off || !v.max_ts || (v.sess_off[v.n_sessions] && !v.items)) return fail(SRN_EINVAL, "null session arrays");
+    if (m_index == 0) return fail(SRN_EINVAL, "m_index must be > 0");
+    if (v.n_sessions >= 0xFFFFFFFFull) return fail(SRN_ERANGE, "too many sessions");
+    ix = FlatIndex();
+    ix.n_sessions_total = v.n_sessions; ix.m_index = m_index; ix.max_session_len = max_session_len; ix.idf_weighting = idf_weighting;
+
+    // 1. kept sessions in ascending recency order: (timestamp, session index) lexicographic
+    std::vector<uint64_t> key; key.reserve(v.n_sessions);
+    for (size_t s = 0; s < v.n_sessions; ++s) {
+        if (v.sess_off[s + 1] < v.sess_off[s]) return fail(SRN_EINVAL, "sess_off not monotone");
+        const uint64_t len = v.sess_off[s + 1] - v.sess_off[s];
+        if (len == 0 || len > max_session_len) continue;   // :452 (an empty session contributes nothing)
+        key.push_back(((uint64_t)v.max_ts[s] << 32) | (uint64_t)s);
+        ix.nnz_rows += len; ix.max_row_len = std::max<uint64_t>(ix.max_row_len, len);
+    }
+    std::sort(key.begin(), key.end());
+    ix.n_kept = key.size();
+    ix.rank_to_session.resize(ix.n_kept);
+    for (size_t r = 0; r < ix.n_kept; ++r) ix.rank_to_session[r] = (uint32_t)(key[r] & 0xFFFFFFFFull);
+    std::vector<uint64_t>().swap(key);
+
+    // 2. dictionary: provisional dense index in first-seen order, then renumber ascending by id
+    size_t cap = 1024; while (cap < ix.nnz_rows / 4 + 16) cap <<= 1;   // grows on demand below
+    std::vector<IdSlot> tab(cap, IdSlot{0, kNone, 0}); size_t tmask = cap - 1;
+    std::vector<uint64_t> ids; std::vector<uint32_t> cnt;
+    std::vector<uint32_t> prov(ix.nnz_rows);
+    ix.row_off.assign(ix.n_kept + 1, 0);
+    auto grow = [&]() {
+        std::vector<IdSlot> nt(tab.size() * 2, IdSlot{0, kNone, 0}); const size_t nm = nt.size() - 1;
+        for (const IdSlot& s : tab) if (s.idx != kNone) { size_t h = mix64(s.key) & nm; while (nt[h].idx != kNone) h = (h + 1) & nm; nt[h] = s; }
+        tab.swap(nt); tmask = nm; };
+    size_t w = 0;
+    for (size_t r = 0; r < ix.n_kept; ++r) {
+        const uint32_t s = ix.rank_to_session[r];
+        uint64_t prev = 0; bool first = true;
+        for (uint64_t j = v.sess_off[s]; j < v.sess_off[s + 1]; ++j) {
+            const uint64_t id = v.items[j];
+            if (!first && id <= prev) return fail(SRN_EINVAL, "session rows must be strictly ascending item ids");
+            prev = id; first = false;
+            size_t h = mix64(id) & tmask;
+            for (;;) {
+                IdSlot& sl = tab[h];
+                if (sl.idx == kNone) {
+                    if (ids.size() >= 0xFFFFFFF0ull) return fail(SRN_ERANGE, "too many items");
+                    sl.key = id; sl.idx = (uint32_t)ids.size(); ids.push_back(id); cnt.push_back(0);
+                    prov[w] = sl.idx;
+                    if (ids.size() * 2 > tab.size()) grow();
+                    break;
+                }
+                if (sl.key == id) { prov[w] = sl.idx; break; }
+                h = (h + 1) & tmask;
+            }
+            ++cnt[prov[w]]; ++w;
+        }
+        ix.row_off[r + 1] = w;
+    }
+    ix.n_items = ids.size();
+    std::vector<uint32_t> order(ix.n_items); std::iota(order.begin(), order.end(), 0u);
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ids[a] < ids[b]; });
+    std::vector<uint32_t> remap(ix.n_items);
+    ix.item_id.resize(ix.n_items);
+    std::vector<uint32_t> count(ix.n_items);
+    for (uint32_t i = 0; i < ix.n_items; ++i) { remap[order[i]] = i; ix.item_id[i] = ids[order[i]]; count[i] = cnt[order[i]]; }
+    ix.row_items.resize(ix.nnz_rows);
+    for (size_t i = 0; i < ix.nnz_rows; ++i) ix.row_items[i] = remap[prov[i]];
+    std::vector<uint32_t>().swap(prov); std::vector<uint64_t>().swap(ids); std::vector<uint32_t>().swap(cnt);
+    std::vector<IdSlot>().swap(tab);
+
+    // 3. postings: walk ranks newest -> oldest; each item's list is filled most-recent-first and
+    //    stops at m_index (:497-504).  Rank order == (timestamp desc, session index desc).
+    ix.post_off.assign(ix.n_items + 1, 0);
+    for (uint32_t i = 0; i < ix.n_items; ++i) ix.post_off[i + 1] = ix.post_off[i] + std::min<uint64_t>(count[i], m_index);
+    ix.nnz_post = ix.post_off[ix.n_items];
+    ix.post_rank.resize(ix.nnz_post);
+    std::vector<uint32_t> fill(ix.n_items, 0);
+    for (size_t r = ix.n_kept; r-- > 0;) {
+        for (uint64_t j = ix.row_off[r]; j < ix.row_off[r + 1]; ++j) {
+            const uint32_t it = ix.row_items[j];
+            if (fill[it] < m_index) ix.post_rank[ix.post_off[it] + fill[it]++] = (uint32_t)r;
+        }
+    }
+
+    // 4. idf = ln(total kept pairs / sessions containing the item before truncation) * weighting (:509-512)
+    ix.idf.resize(ix.n_items); ix.attr.assign(ix.n_items, (uint8_t)SRN_ATTR_FOR_SALE);   // :514-517
+    for (uint32_t i = 0; i < ix.n_items; ++i)
+        ix.idf[i] = std::log((double)ix.nnz_rows / (double)count[i]) * idf_weighting;
+
+    // 5. public id -> idx table for the query side (load factor <= 0.5)
+    size_t tcap = 16; while (tcap < ix.n_items * 2) tcap <<= 1;
+    ix.id_table.assign(tcap, IdSlot{0, kNone, 0}); ix.id_mask = (uint32_t)(tcap - 1);
+    for (uint32_t i = 0; i < ix.n_items; ++i) {
+        uint32_t h = (uint32_t)mix64(ix.item_id[i]) & ix.id_mask;
+        while (ix.id_table[h].idx != kNone) h = (h + 1) & ix.id_mask;
+        ix.id_table[h] = IdSlot{ix.item_id[i], i, 0};
+    }
+    return SRN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// binary save / load ("SRNFLAT1": header of u64 fields, then raw arrays)
+// ---------------------------------------------------------------------------------------------
+namespace {
+template <typename T> bool wr(FILE* f, const std::vector<T>& v) {
+    uint64_t n = v.size();
+    return fwrite(&n, 8, 1, f) == 1 && (n == 0 || fwrite(v.data(), sizeof(T), n, f) == n);
+}
+template <typename T> bool rd(FILE* f, std::vector<T>& v) {
+    uint64_t n = 0; if (fread(&n, 8, 1, f) != 1) return false;
+    v.resize(n); return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
+}
+}  // namespace
+
+int save_flat_index(const FlatIndex& ix, const char* path) {
+    FILE* f = fopen(path, "wb"); if (!f) return fail(SRN_EIO, std::string("cannot create ") + path);
+    const char magic[8] = {'S', 'R', 'N', 'F', 'L', 'A', 'T', '1'};
+    uint64_t hdr[9] = {ix.n_items, ix.n_sessions_total, ix.n_kept, ix.nnz_rows, ix.nnz_post, ix.m_index, ix.max_session_len, ix.max_row_len, ix.id_mask};
+    bool ok = fwrite(magic, 8, 1, f) == 1 && fwrite(hdr, 8, 9, f) == 9 && fwrite(&ix.idf_weighting, 8, 1, f) == 1 &&
+              wr(f, ix.item_id) && wr(f, ix.idf) && wr(f, ix.attr) && wr(f, ix.post_off) && wr(f, ix.post_rank) &&
+              wr(f, ix.row_off) && wr(f, ix.row_items) && wr(f, ix.rank_to_session) && wr(f, ix.id_table);
+    ok = (fclose(f) == 0) && ok;
+    return ok ? SRN_OK : fail(SRN_EIO, std::string("short write to ") + path);
+}
+
+int load_flat_index(const char* path, FlatIndex& ix) {
+    FILE* f = fopen(path, "rb"); if (!f) return fail(SRN_EIO, std::string("cannot open ") + path);
+    char magic[8]; uint64_t hdr[9]; ix = FlatIndex();
+    bool ok = fread(magic, 8, 1, f) == 1 && memcmp(magic, "SRNFLAT1", 8) == 0 && fread(hdr, 8, 9, f) == 9 &&
+              fread(&ix.idf_weighting, 8, 1, f) == 1;
+    if (ok) {
+        ix.n_items = hdr[0]; ix.n_sessions_total = hdr[1]; ix.n_kept = hdr[2]; ix.nnz_rows = hdr[3]; ix.nnz_post = hdr[4];
+        ix.m_index = hdr[5]; ix.max_session_len = hdr[6]; ix.max_row_len = hdr[7]; ix.id_mask = (uint32_t)hdr[8];
+        ok = rd(f, ix.item_id) && rd(f, ix.idf) && rd(f, ix.attr) && rd(f, ix.post_off) && rd(f, ix.post_rank) &&
+             rd(f, ix.row_off) && rd(f, ix.row_items) && rd(f, ix.rank_to_session) && rd(f, ix.id_table);
+        ok = ok && ix.item_id.size() == ix.n_items && ix.idf.size() == ix.n_items && ix.attr.size() == ix.n_items &&
+             ix.post_off.size() == ix.n_items + 1 && ix.post_rank.size() == ix.nnz_post && ix.row_off.size() == ix.n_kept + 1 &&
+             ix.row_items.size() == ix.nnz_rows && ix.rank_to_session.size() == ix.n_kept && ix.id_table.size() == (size_t)ix.id_mask + 1;
+    }
+    fclose(f);
+    return ok ? SRN_OK : fail(SRN_EIO, std::string("not a valid SRNFLAT1 index: ") + path);
+}
+
+}  // namespace srn

@@ -1,0 +1,105 @@
+// Internal declarations shared by the host index builder, the C ABI glue and the HIP kernels.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/serenade_hip.h"
+
+namespace srn {
+
+// ---- error plumbing (thread-local message behind srn_last_error) ---------------------------
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+// ---- u64 item id -> dense item index: open addressing, 16-byte slots (one load per probe) ----
+struct IdSlot {
+    uint64_t key;
+    uint32_t idx;  // 0xFFFFFFFF = empty
+    uint32_t pad;
+};
+static constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+static inline uint64_t mix64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33; return x;
+}
+
+// ---- training sessions (host) ------------------------------------------------------------
+struct Sessions {
+    std::vector<uint64_t> off, items;
+    std::vector<uint32_t> ts;
+    std::vector<uint64_t> session_ids;  // original SessionId column, for diagnostics
+};
+int sessions_from_tsv(const char* path, Sessions& out);
+uint64_t sessions_length_quantile(const uint64_t* off, size_t n, double q);
+
+// ---- the flat index (host copy).  Layout and invariants: DESIGN.md "Data layout in HBM" ----
+struct FlatIndex {
+    uint64_t n_items = 0, n_sessions_total = 0, n_kept = 0, nnz_rows = 0, nnz_post = 0;
+    uint64_t m_index = 0, max_session_len = 0, max_row_len = 0;
+    double idf_weighting = 1.0;
+    std::vector<uint64_t> item_id;          // [n_items]   public ids, ascending  => idx order == id order
+    std::vector<double> idf;                // [n_items]
+    std::vector<uint8_t> attr;              // [n_items]   SRN_ATTR_* or SRN_ATTR_NONE
+    std::vector<uint64_t> post_off;         // [n_items+1]
+    std::vector<uint32_t> post_rank;        // [nnz_post]  recency ranks, strictly descending per item
+    std::vector<uint64_t> row_off;          // [n_kept+1]  rows addressed by recency rank
+    std::vector<uint32_t> row_items;        // [nnz_rows]  item idx, ascending per row
+    std::vector<uint32_t> rank_to_session;  // [n_kept]    reference session index of each rank
+    std::vector<IdSlot> id_table;           // power-of-two open addressing table
+    uint32_t id_mask = 0;
+    uint32_t lookup(uint64_t id) const {
+        if (id_table.empty()) return kNone;
+        uint32_t h = (uint32_t)mix64(id) & id_mask;
+        for (;;) { const IdSlot& s = id_table[h]; if (s.idx == kNone) return kNone; if (s.key == id) return s.idx; h = (h + 1) & id_mask; }
+    }
+};
+int build_flat_index(const srn_sessions_view_t& v, size_t m_index, size_t max_session_len, double idf_weighting,
+                     FlatIndex& out);
+int save_flat_index(const FlatIndex& ix, const char* path);
+int load_flat_index(const char* path, FlatIndex& ix);
+
+// ---- device side ---------------------------------------------------------------------------
+struct DeviceIndex {  // pointers into HBM; passed by value to the kernels
+    const IdSlot* id_table; uint32_t id_mask;
+    const uint64_t* item_id; const double* idf; const uint8_t* attr;
+    const uint64_t* post_off; const uint32_t* post_rank;
+    const void* row_off;  // uint32_t* or uint64_t* (offsets_64bit)
+    const uint32_t* row_items;
+    uint32_t n_items, n_kept;
+};
+
+struct LaunchParams {
+    uint32_t nq, k, m, how_many, flags, max_len;
+    const uint64_t* items_flat; const uint32_t* q_off;   // device
+    uint64_t* out_ids; double* out_scores; uint32_t* out_counts;   // device
+    uint32_t* stats;      // [nq*8] or null
+    uint32_t* nb_rank; uint32_t* nb_num; uint32_t* nb_cnt;   // debug neighbour dump or null
+};
+
+struct Workspace;   // per-call device scratch + events, owned by the index handle's pool
+struct DeviceState;  // uploaded arrays + workspace pool
+
+DeviceState* device_attach(const FlatIndex& ix, int device);   // nullptr on failure (error set)
+void device_release(DeviceState* d);
+int device_update_attr(DeviceState* d, const FlatIndex& ix);
+uint64_t device_bytes(const DeviceState* d);
+int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p, bool buffers_on_device, void* stream,
+                   // host-pointer mode: these are host buffers copied in/out by the call
+                   const uint64_t* h_items, const uint32_t* h_qoff, uint64_t* h_ids, double* h_scores,
+                   uint32_t* h_counts, uint32_t* h_stats, uint32_t* h_nb_rank, uint32_t* h_nb_num, uint32_t* h_nb_cnt);
+int device_last_kernel_ms(DeviceState* d, double* ms_main, double* ms_retry, uint32_t* retried);
+
+}  // namespace srn
+
+struct srn_index {
+    srn::FlatIndex flat;
+    srn::DeviceState* dev = nullptr;
+    int device = -1;
+};
+struct srn_sessions {
+    srn::Sessions s;
+};

@@ -1,0 +1,154 @@
+"""Host-side mirror of the reference's interface for the VMIS-kNN hot path, over the C ABI.
+
+Reference (bolcom/serenade, Rust)                      here
+---------------------------------------------------   -------------------------------------------
+vmis_index::VMISIndex::new_from_csv(path, m, idf_w)    VMISIndex.new_from_csv(path, m, idf_w)
+  (src/vmisknn/vmis_index.rs:38-83)
+vmisknn::predict(&index, &session, k, m, how_many,     predict(index, session, k, m, how_many,
+                 enable_business_logic)                        enable_business_logic)
+  -> BinaryHeap<ItemScore>, callers take               -> list[ItemScore] already in
+     .into_sorted_vec()  (src/vmisknn/mod.rs:118-215)     into_sorted_vec() order (score-descending)
+ItemScore { id: u64, score: f64 } (mod.rs:45-49)       ItemScore(id, score)
+
+All compute happens in libserenade_hip.so on the GPU.  There is no Python or CPU implementation of
+the path in this package; without the library or without a GPU the calls raise.
+"""
+import ctypes as C
+from collections import namedtuple
+
+import numpy as np
+
+from . import capi
+from .capi import SerenadeError  # noqa: F401  (re-export)
+
+ItemScore = namedtuple("ItemScore", ["id", "score"])
+
+
+class VMISIndex:
+    """Owns an srn_index_t handle (flat CSR index in HBM)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    # ---- constructors ---------------------------------------------------------------------
+    @classmethod
+    def new_from_csv(cls, path_to_training, m_most_recent_sessions, idf_weighting, max_session_len=0, device=0):
+        """VMISIndex::new_from_csv (vmis_index.rs:38-83).  max_session_len=0: exact p99.5 of session lengths
+        (the reference uses a t-digest estimate of the same quantile, vmis_index.rs:689-716)."""
+        h = C.c_void_p()
+        capi.check(capi.lib().srn_index_new_from_csv(str(path_to_training).encode(), int(m_most_recent_sessions),
+                                                     float(idf_weighting), int(max_session_len), int(device), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_sessions(cls, sess_off, items, max_ts, m_index, max_session_len, idf_weighting=1.0, device=0):
+        """prepare_hashmap (vmis_index.rs:422-528) on sessions already in (ascending, de-duplicated) row form."""
+        sess_off, items, max_ts = capi.as_u64(sess_off), capi.as_u64(items), capi.as_u32(max_ts)
+        if len(sess_off) != len(max_ts) + 1 or (len(sess_off) and int(sess_off[-1]) != len(items)):
+            raise ValueError("inconsistent session CSR")
+        v = capi.SessionsView(sess_off.ctypes.data, items.ctypes.data, max_ts.ctypes.data, len(max_ts))
+        h = C.c_void_p()
+        capi.check(capi.lib().srn_index_build(C.byref(v), int(m_index), int(max_session_len), float(idf_weighting),
+                                              int(device), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def load(cls, path, device=0):
+        h = C.c_void_p()
+        capi.check(capi.lib().srn_index_load(str(path).encode(), int(device), C.byref(h)))
+        return cls(h)
+
+    def save(self, path):
+        capi.check(capi.lib().srn_index_save(self._h, str(path).encode()))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            capi.lib().srn_index_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # ---- accessors ------------------------------------------------------------------------
+    @property
+    def info(self):
+        out = capi.IndexInfo()
+        capi.check(capi.lib().srn_index_info(self._h, C.byref(out)))
+        return {n: getattr(out, n) for n, _ in capi.IndexInfo._fields_}
+
+    def set_attributes(self, item_ids, flags):
+        ids, fl = capi.as_u64(item_ids), np.ascontiguousarray(flags, np.uint8)
+        capi.check(capi.lib().srn_index_set_attributes(self._h, capi.ptr(ids), capi.ptr(fl), len(ids)))
+
+    def postings(self, item_id):
+        """(reference session indices most-recent-first, idf) of one item, or (None, None) if unknown."""
+        n, idf = C.c_int64(), C.c_double()
+        capi.check(capi.lib().srn_index_postings(self._h, int(item_id), None, 0, C.byref(n), C.byref(idf)))
+        if n.value < 0:
+            return None, None
+        out = np.zeros(max(n.value, 1), np.uint32)
+        capi.check(capi.lib().srn_index_postings(self._h, int(item_id), capi.ptr(out), n.value, C.byref(n), C.byref(idf)))
+        return out[:n.value], idf.value
+
+    def last_kernel_ms(self):
+        """(avg ms of the main predict kernel, ms of the retry pass, #queries retried) for the last call."""
+        a, b, r = C.c_double(), C.c_double(), C.c_uint32()
+        capi.check(capi.lib().srn_last_kernel_ms(self._h, C.byref(a), C.byref(b), C.byref(r)))
+        return a.value, b.value, r.value
+
+
+def _flatten(sessions):
+    if isinstance(sessions, tuple) and len(sessions) == 2:
+        return capi.as_u64(sessions[0]), capi.as_u32(sessions[1])
+    off = np.zeros(len(sessions) + 1, np.uint32)
+    off[1:] = np.cumsum([len(s) for s in sessions])
+    flat = np.fromiter((x for s in sessions for x in s), dtype=np.uint64, count=int(off[-1]))
+    return flat, off
+
+
+def predict(index, evolving_session, k, m, how_many, enable_business_logic):
+    """vmisknn::predict (src/vmisknn/mod.rs:118-125); returns list[ItemScore], score-descending."""
+    ev = capi.as_u64(evolving_session)
+    ids, sc, n = np.zeros(max(how_many, 1), np.uint64), np.zeros(max(how_many, 1)), C.c_size_t()
+    capi.check(capi.lib().srn_predict(index._h, capi.ptr(ev), len(ev), int(k), int(m), int(how_many),
+                                      int(bool(enable_business_logic)), capi.ptr(ids), capi.ptr(sc), C.byref(n)))
+    return [ItemScore(int(i), float(s)) for i, s in zip(ids[:n.value], sc[:n.value])]
+
+
+def predict_batch(index, sessions, k, m, how_many, enable_business_logic=False):
+    """Many evolving sessions in one call (list of sequences, or (items_flat, q_off)).
+    -> (ids u64[nq, how_many], scores f64[nq, how_many], counts u32[nq])."""
+    flat, off = _flatten(sessions)
+    nq = len(off) - 1
+    ids, sc, cnt = np.zeros((nq, how_many), np.uint64), np.zeros((nq, how_many)), np.zeros(nq, np.uint32)
+    capi.check(capi.lib().srn_predict_batch(index._h, capi.ptr(flat), capi.ptr(off), nq, int(k), int(m), int(how_many),
+                                            capi.FLAG_BUSINESS_LOGIC if enable_business_logic else 0,
+                                            capi.ptr(ids), capi.ptr(sc), capi.ptr(cnt)))
+    return ids, sc, cnt
+
+
+def predict_batch_debug(index, sessions, k, m, how_many, enable_business_logic=False, neighbours=True):
+    """predict_batch plus per-query stats [nq, 8] = (P, C, K, I, D, H, L, status) and, optionally, the selected
+    neighbour sessions (reference session indices) with their integer similarity numerators."""
+    flat, off = _flatten(sessions)
+    nq = len(off) - 1
+    ids, sc, cnt = np.zeros((nq, how_many), np.uint64), np.zeros((nq, how_many)), np.zeros(nq, np.uint32)
+    stats = np.zeros((nq, 8), np.uint32)
+    nb_s = np.zeros((nq, k), np.uint32) if neighbours else None
+    nb_n = np.zeros((nq, k), np.uint32) if neighbours else None
+    nb_c = np.zeros(nq, np.uint32) if neighbours else None
+    capi.check(capi.lib().srn_predict_batch_debug(index._h, capi.ptr(flat), capi.ptr(off), nq, int(k), int(m), int(how_many),
+                                                  capi.FLAG_BUSINESS_LOGIC if enable_business_logic else 0,
+                                                  capi.ptr(ids), capi.ptr(sc), capi.ptr(cnt), capi.ptr(stats),
+                                                  capi.ptr(nb_s), capi.ptr(nb_n), capi.ptr(nb_c)))
+    return dict(ids=ids, scores=sc, counts=cnt, stats=stats, nb_sessions=nb_s, nb_num=nb_n, nb_counts=nb_c)
+
+
+def predict_batch_device(index, d_items_flat, d_q_off, nq, max_len, k, m, how_many, enable_business_logic,
+                         d_out_ids, d_out_scores, d_out_counts, stream=0):
+    """Device-resident variant: arguments are raw device addresses (e.g. torch.Tensor.data_ptr()) on the
+    index's GPU and a hipStream_t handle (e.g. torch.cuda.current_stream().cuda_stream); asynchronous."""
+    capi.check(capi.lib().srn_predict_batch_device(index._h, C.c_void_p(d_items_flat), C.c_void_p(d_q_off), int(nq),
+                                                   int(max_len), int(k), int(m), int(how_many),
+                                                   capi.FLAG_BUSINESS_LOGIC if enable_business_logic else 0,
+                                                   C.c_void_p(d_out_ids), C.c_void_p(d_out_scores),
+                                                   C.c_void_p(d_out_counts), C.c_void_p(stream)))

@@ -1,0 +1,195 @@
+"""GPU parity: the HIP path (through the C ABI) against the canonical CPU oracle on the same inputs.
+
+Bar (BASELINE.json north_star): same ranked item lists, scores within 1e-5.  What is actually asserted
+is stronger: item ids and order identical, neighbour (session, numerator) sets identical, per-query
+counters identical, and scores equal to 1e-12 relative (they are one f64 multiply + divide of an exact
+integer accumulator on both sides).
+"""
+import numpy as np
+import pytest
+
+from helpers import flatten, random_queries, small_dataset
+
+pytestmark = pytest.mark.gpu
+
+SCORE_RTOL = 1e-12   # north_star tolerance is 1e-5; integer-exact accumulation lets us hold 1e-12
+
+
+def _oracle():
+    from oracle import oracle
+    return oracle
+
+
+def _check_batch(gix, oix, queries, k, m, how_many, business=False, check_neighbours=True):
+    import serenade_amd as sa
+    res = sa.predict_batch_debug(gix, queries, k, m, how_many, business, neighbours=check_neighbours)
+    flat, off = flatten(queries)
+    ref = oix.predict_batch("canonical", flat, off, k, m, how_many, business, threads=4, want_stats=True)
+    assert np.array_equal(res["counts"], ref["counts"]), "result counts differ"
+    for q in range(len(queries)):
+        n = int(ref["counts"][q])
+        assert np.array_equal(res["ids"][q, :n], ref["ids"][q, :n]), (q, queries[q], res["ids"][q, :n], ref["ids"][q, :n])
+        np.testing.assert_allclose(res["scores"][q, :n], ref["scores"][q, :n], rtol=SCORE_RTOL, atol=0)
+    assert np.array_equal(res["stats"][:, :7].astype(np.uint64), ref["stats"]), "P,C,K,I,D,H,L counters differ"
+    if check_neighbours:
+        for q in range(len(queries)):
+            sid, num, _U = oix.neighbors_canonical(queries[q], k, m)
+            kq = int(res["nb_counts"][q])
+            got = sorted(zip(res["nb_sessions"][q, :kq].tolist(), res["nb_num"][q, :kq].tolist()))
+            assert got == sorted(zip(sid.tolist(), num.tolist())), (q, queries[q])
+    return res
+
+
+def test_kat1_should_train_and_predict():
+    """src/vmisknn/mod.rs:229-310: two sessions, query [920005] -> 4 results, 920004 first."""
+    import serenade_amd as sa
+    off = np.array([0, 3, 7], np.uint64)
+    items = np.array([920004, 920005, 920006, 920002, 920003, 920004, 920005], np.uint64)
+    ts = np.array([1, 1], np.uint32)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, 5, 5, 1.0)
+    recs = sa.predict(gix, [920005], 500, 500, 20, False)
+    assert len(recs) == 4
+    assert recs[0].id == 920004
+    assert recs[0].score == pytest.approx(2.2549733432916628, rel=1e-12)
+    assert [r.id for r in recs[1:]] == [920002, 920003, 920006]          # 3-way tie, canonical order = id asc
+    for r in recs[1:]:
+        assert r.score == pytest.approx(1.751319134149782, rel=1e-12)
+
+
+@pytest.mark.parametrize("tied", [False, True])
+def test_small_random_vs_oracle(tied):
+    import serenade_amd as sa
+    O = _oracle()
+    off, items, ts, ids = small_dataset(11 + tied, n_sessions=3000, n_items=400, tied_timestamps=tied)
+    for (m_index, max_len, idfw) in [(200, 12, 1.0), (40, 8, 2.0)]:
+        gix = sa.VMISIndex.from_sessions(off, items, ts, m_index, max_len, idfw)
+        oix = O.OracleIndex(off, items, ts, m_index, max_len, idfw)
+        qs = random_queries(5, ids, 300, max_len=6)
+        for (k, m, n) in [(50, 200, 21), (10, 30, 5), (500, 500, 100), (1, 1, 1), (3, 1000, 512)]:
+            _check_batch(gix, oix, qs, k, m, n)
+
+
+def test_long_sessions_negative_weights_and_duplicates():
+    """L up to 14: linear_score goes to 0 at position 10 and negative beyond (Q3); duplicates (Q1/Q2)."""
+    import serenade_amd as sa
+    O = _oracle()
+    off, items, ts, ids = small_dataset(3, n_sessions=2500, n_items=120, max_len=10)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, 300, 10, 1.0)
+    oix = O.OracleIndex(off, items, ts, 300, 10, 1.0)
+    qs = random_queries(9, ids, 200, max_len=14, unknown_rate=0.1, dup_rate=0.3)
+    res = _check_batch(gix, oix, qs, 100, 300, 50)
+    assert (res["scores"] < 0).any(), "expected some negative scores from positions > 10"
+
+
+def test_unknown_items_and_single_predict():
+    import serenade_amd as sa
+    off, items, ts, ids = small_dataset(5)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, 100, 12, 1.0)
+    assert sa.predict(gix, [1, 2, 3], 10, 10, 5, False) == []                     # unknown items -> empty, no error
+    with pytest.raises(sa.SerenadeError) as e:
+        sa.predict(gix, [], 10, 10, 5, False)                                     # reference panics (mod.rs:157)
+    assert e.value.code == -1
+    with pytest.raises(sa.SerenadeError):
+        sa.predict(gix, [int(ids[0])], 10, 10, 513, False)                        # SRN_ERANGE
+    with pytest.raises(sa.SerenadeError):
+        sa.predict(gix, [int(ids[0])], 0, 10, 5, False)
+
+
+def test_business_rules():
+    import serenade_amd as sa
+    O = _oracle()
+    off, items, ts, ids = small_dataset(21, n_sessions=2000, n_items=200)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, 200, 12, 1.0)
+    oix = O.OracleIndex(off, items, ts, 200, 12, 1.0)
+    rng = np.random.default_rng(4)
+    known = np.unique(items)
+    flags = rng.choice(np.array([0, 1, 2, 3, 0xFF], np.uint8), size=len(known), p=[0.1, 0.05, 0.55, 0.2, 0.1])
+    gix.set_attributes(known, flags)
+    oix.set_attributes(known, flags)
+    qs = random_queries(6, ids, 300, max_len=4, unknown_rate=0.0)
+    _check_batch(gix, oix, qs, 60, 200, 21, business=True, check_neighbours=False)
+    _check_batch(gix, oix, qs, 60, 200, 21, business=False, check_neighbours=False)
+
+
+def test_example_golden_fixture():
+    """tests/golden/example_golden.npz: the reference's own example data (assets/example), 931 evaluator
+    queries, expected outputs produced by the pinned oracle (tests/golden/make_golden.py)."""
+    import os
+    import serenade_amd as sa
+    from helpers import GOLDEN
+    path = os.path.join(GOLDEN, "example_golden.npz")
+    g = np.load(path)
+    for tag in ("a", "b"):
+        m, k, n, idfw, max_len = (int(x) for x in g["params_" + tag])
+        gix = sa.VMISIndex.from_sessions(g["sess_off"], g["items"], g["ts"], m, max_len, float(idfw))
+        ids, sc, cnt = sa.predict_batch(gix, (g["q_items_" + tag], g["q_off_" + tag]), k, m, n, True)
+        assert np.array_equal(cnt, g["counts_" + tag])
+        assert np.array_equal(ids, g["ids_" + tag])
+        np.testing.assert_allclose(sc, g["scores_" + tag], rtol=SCORE_RTOL, atol=0)
+
+
+def test_retry_path_with_global_tables():
+    """Queries whose candidate set cannot fit the LDS session table go through the global-table pass."""
+    import serenade_amd as sa
+    O = _oracle()
+    rng = np.random.default_rng(8)
+    n_items, n_sessions = 60, 60000
+    ids = (np.arange(n_items, dtype=np.uint64) + 1) * 1000
+    off, items = [0], []
+    for s in range(n_sessions):                      # short sessions over few items -> long, mostly disjoint lists
+        row = np.unique(ids[rng.choice(n_items, size=int(rng.integers(1, 3)))])
+        items.extend(row.tolist()); off.append(len(items))
+    ts = (1 + rng.permutation(n_sessions)).astype(np.uint32)
+    off, items = np.array(off, np.uint64), np.array(items, np.uint64)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, 2000, 5, 1.0)
+    oix = O.OracleIndex(off, items, ts, 2000, 5, 1.0, fast=True)
+    qs = [ids[rng.permutation(n_items)[:40]].tolist() for _ in range(6)] + [[int(ids[0])], [int(ids[1]), int(ids[2])]]
+    res = _check_batch(gix, oix, qs, 1500, 40000, 21, check_neighbours=False)
+    assert (res["stats"][:6, 7] == 1).all(), "long queries should have been served by the global-table pass"
+    assert (res["stats"][6:, 7] == 0).all()
+
+
+def test_synthetic_tiny_config_matches_oracle():
+    """The bench generator's `tiny` config end to end (u64 hashed ids, unique timestamps, k/m cuts hit)."""
+    import serenade_amd as sa
+    from serenade_amd import synth
+    O = _oracle()
+    inter, n_items, k, m, idfw = synth.CONFIGS["tiny"]
+    off, items, ts = synth.training_sessions(inter, n_items)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw)
+    oix = O.OracleIndex(off, items, ts, m, 34, idfw, fast=True)
+    qi, qo = synth.queries(600, n_items)
+    nq = len(qo) - 1
+    qs = [qi[qo[i]:qo[i + 1]].tolist() for i in range(nq)]
+    res = _check_batch(gix, oix, qs, k, m, synth.HOW_MANY, check_neighbours=False)
+    st = res["stats"]
+    assert (st[:, 1] == m).any() and (st[:, 2] == k).any(), "workload should hit both the m-cut and the k-cut"
+
+
+def test_device_pointer_entry_point_matches_host_entry_point():
+    torch = pytest.importorskip("torch")
+    import serenade_amd as sa
+    off, items, ts, ids = small_dataset(31, n_sessions=3000, n_items=300)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, 200, 12, 1.0)
+    qs = random_queries(2, ids, 500, max_len=5)
+    flat, qoff = flatten(qs)
+    k, m, n = 50, 200, 21
+    ids_h, sc_h, cnt_h = sa.predict_batch(gix, (flat, qoff), k, m, n)
+    dev = torch.device("cuda:0")
+    d_flat = torch.from_numpy(flat.view(np.int64)).to(dev)
+    d_off = torch.from_numpy(qoff.view(np.int32)).to(dev)
+    d_ids = torch.zeros(len(qs) * n, dtype=torch.int64, device=dev)
+    d_sc = torch.zeros(len(qs) * n, dtype=torch.float64, device=dev)
+    d_cnt = torch.zeros(len(qs), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream()
+    sa.predict_batch_device(gix, d_flat.data_ptr(), d_off.data_ptr(), len(qs), 5, k, m, n, False,
+                            d_ids.data_ptr(), d_sc.data_ptr(), d_cnt.data_ptr(), stream.cuda_stream)
+    stream.synchronize()
+    cnt_d = d_cnt.cpu().numpy().view(np.uint32)
+    assert np.array_equal(cnt_d, cnt_h)
+    ids_d = d_ids.cpu().numpy().view(np.uint64).reshape(len(qs), n)
+    sc_d = d_sc.cpu().numpy().reshape(len(qs), n)
+    for q in range(len(qs)):
+        c = int(cnt_h[q])
+        assert np.array_equal(ids_d[q, :c], ids_h[q, :c])
+        assert np.array_equal(sc_d[q, :c], sc_h[q, :c])
