@@ -65,6 +65,25 @@ SYMBOLS = {
 _lib = None
 
 
+def _preload_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  Two HIP runtimes
+    in one process each open the KFD and the second one sees no GPU, so when torch is installed we load
+    ITS runtime first; libserenade_hip.so's DT_NEEDED libamdhip64.so.7 then binds to it and torch
+    (device memory, streams, torch.distributed/RCCL) shares one runtime with our kernels.
+    SRN_HIP_RUNTIME=system skips this and uses /opt/rocm's runtime (no torch in the process then)."""
+    if os.environ.get("SRN_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.submodule_search_locations:
+            p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+            if os.path.exists(p):
+                C.CDLL(p, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def lib():
     """Load the in-tree HIP library.  Fails loudly if it is missing: there is no fallback path."""
     global _lib
@@ -73,6 +92,7 @@ def lib():
         if not os.path.exists(path):
             raise ImportError("libserenade_hip.so is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(there is no CPU fallback for the predict path)")
+        _preload_hip_runtime()
         L = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)

@@ -77,8 +77,12 @@ def test_long_sessions_negative_weights_and_duplicates():
     gix = sa.VMISIndex.from_sessions(off, items, ts, 300, 10, 1.0)
     oix = O.OracleIndex(off, items, ts, 300, 10, 1.0)
     qs = random_queries(9, ids, 200, max_len=14, unknown_rate=0.1, dup_rate=0.3)
-    res = _check_batch(gix, oix, qs, 100, 300, 50)
-    assert (res["scores"] < 0).any(), "expected some negative scores from positions > 10"
+    _check_batch(gix, oix, qs, 100, 300, 50)
+    # all-unknown recent items push every first match beyond position 10: weights <= 0 everywhere
+    rng = np.random.default_rng(1)
+    deep = [[int(x) for x in ids[rng.choice(len(ids), size=3)]] + [7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17] for _ in range(50)]
+    res = _check_batch(gix, oix, deep, 100, 300, 512)
+    assert (res["scores"] < 0).any() and (res["scores"] == 0).any(), "expected zero and negative scores (Q3)"
 
 
 def test_unknown_items_and_single_predict():
