@@ -164,6 +164,16 @@ int srn_predict_batch_debug(const srn_index_t* idx, const uint64_t* items_flat, 
  * until that work has finished); *out_launches = number of kernel launches it covered. */
 int srn_last_kernel_ms(const srn_index_t* idx, double* out_ms_main, double* out_ms_retry, uint32_t* out_retried);
 
+/* The same for the most recent min(max_n, 64) predict calls (oldest first): per-call duration in ms of
+ * the main kernel and of the retry pass, from HIP events recorded on the launch stream around each
+ * launch.  This is what bench.py reports as the kernel's live-measured launch duration. */
+int srn_kernel_times(const srn_index_t* idx, uint32_t max_n, double* out_ms_main, double* out_ms_retry, uint32_t* out_n);
+
+/* Profiling aid: returns (and clears) 16 counters of shader cycles summed over workgroups, one per
+ * kernel phase (DESIGN.md "Kernel phases"), accumulated by predict calls made while enabled; then
+ * switches the accounting on (enable != 0) or off.  Not for production use. */
+int srn_debug_phase_cycles(const srn_index_t* idx, int enable, uint64_t* out16);
+
 /* ---- misc ------------------------------------------------------------------------------- */
 int srn_device_count(int* out);
 void srn_limits(srn_limits_t* out);

@@ -56,6 +56,8 @@ SYMBOLS = {
     "srn_predict_batch_device": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, C.c_uint, _vp, _vp, _vp, _vp]),
     "srn_predict_batch_debug": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "srn_last_kernel_ms": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
+    "srn_kernel_times": (_i, [_vp, C.c_uint32, _vp, _vp, C.POINTER(C.c_uint32)]),
+    "srn_debug_phase_cycles": (_i, [_vp, _i, _vp]),
     "srn_device_count": (_i, [C.POINTER(_i)]),
     "srn_limits": (None, [C.POINTER(Limits)]),
     "srn_last_error": (C.c_char_p, []),

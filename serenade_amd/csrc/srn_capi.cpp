@@ -209,4 +209,15 @@ int srn_last_kernel_ms(const srn_index_t* idx, double* out_ms_main, double* out_
     return guarded([&]() -> int { return device_last_kernel_ms(idx->dev, out_ms_main, out_ms_retry, out_retried); });
 }
 
+int srn_kernel_times(const srn_index_t* idx, uint32_t max_n, double* out_ms_main, double* out_ms_retry, uint32_t* out_n) {
+    if (!idx || !idx->dev) return fail(SRN_ENODEV, "index has no device attached");
+    if (!out_n) return fail(SRN_EINVAL, "null argument");
+    return guarded([&]() -> int { return device_kernel_times(idx->dev, max_n, out_ms_main, out_ms_retry, out_n); });
+}
+
+int srn_debug_phase_cycles(const srn_index_t* idx, int enable, uint64_t* out16) {
+    if (!idx || !idx->dev) return fail(SRN_ENODEV, "index has no device attached");
+    return guarded([&]() -> int { return device_phase_cycles(idx->dev, enable, (unsigned long long*)out16); });
+}
+
 }  // extern "C"

@@ -78,6 +78,7 @@ struct LaunchParams {
     uint64_t* out_ids; double* out_scores; uint32_t* out_counts;   // device
     uint32_t* stats;      // [nq*8] or null
     uint32_t* nb_rank; uint32_t* nb_num; uint32_t* nb_cnt;   // debug neighbour dump or null
+    unsigned long long* phase_cycles;                       // [16] per-phase shader cycles (debug) or null
 };
 
 struct Workspace;   // per-call device scratch + events, owned by the index handle's pool
@@ -92,6 +93,8 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p, b
                    const uint64_t* h_items, const uint32_t* h_qoff, uint64_t* h_ids, double* h_scores,
                    uint32_t* h_counts, uint32_t* h_stats, uint32_t* h_nb_rank, uint32_t* h_nb_num, uint32_t* h_nb_cnt);
 int device_last_kernel_ms(DeviceState* d, double* ms_main, double* ms_retry, uint32_t* retried);
+int device_phase_cycles(DeviceState* d, int enable, unsigned long long* out16);   // debug profiling aid
+int device_kernel_times(DeviceState* d, uint32_t max_n, double* ms_main, double* ms_retry, uint32_t* out_n);
 
 }  // namespace srn
 

@@ -41,20 +41,20 @@ namespace srn {
 static constexpr uint32_t EMPTY32 = 0xFFFFFFFFu;
 static constexpr int CAND_CAP = 1024;       // candidate buffer of the final top-n (entries)
 static constexpr int MISC_WORDS = 64;       // scalar words at the head of LDS
-static constexpr int LMAX = SRN_MAX_SESSION_LEN + 1;
+static constexpr int MAX_PROBES = 96;       // open-addressing probe budget before a table is declared full
+static constexpr int MAX_ITEM_PASSES = 64;  // item-space partition passes before giving up on the LDS table
 
-// launch-time geometry, identical for every block of a launch
+// launch-time geometry, identical for every block of a launch (all LDS offsets multiples of 16)
 struct KernelCfg {
-    uint32_t sess_slots, sess_cap;   // session table: slots, max distinct before overflow
-    uint32_t item_slots, item_cap;   // item table
-    uint32_t num_bits;               // low bits of a session slot that hold the numerator
-    uint32_t region_a_bytes, region_b_bytes;
-    uint32_t rows_lanes;             // lanes per neighbour row in phase 3 (power of two <= 64)
+    uint32_t sess_slots, item_slots;   // table sizes, powers of two
+    uint32_t num_bits;                 // low bits of a session slot that hold the numerator
+    uint32_t q_cap;                    // capacity of the per-query item arrays (>= max_len, multiple of 4)
+    uint32_t off_q, off_wave, off_b, off_a;   // LDS byte offsets: query arrays, per-wave scratch, region B, region A
 };
 
 // LDS scalar slots
 enum { S_CNT = 0, S_OVF, S_XLO, S_RMAX, S_U, S_P, S_SUMW, S_SELD, S_SELR, S_NB, S_ICNT, S_CCNT, S_I, S_HAVE_T, S_TIDX,
-       S_ERR, S_TKEY_LO, S_TKEY_HI, S_QCUR };
+       S_ERR, S_TKEY_LO, S_TKEY_HI, S_COVF };
 
 template <typename T> struct SlotTraits;
 template <> struct SlotTraits<uint32_t> { static constexpr uint32_t EMPTY = 0xFFFFFFFFu; };
@@ -65,7 +65,10 @@ __device__ __forceinline__ uint64_t dev_mix64(uint64_t x) {
     x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
     x ^= x >> 33; return x;
 }
-__device__ __forceinline__ uint32_t hash_slot(uint32_t key, uint32_t slots) { return __umulhi(key * 0x9E3779B1u, slots); }
+// double hashing over a power-of-two table: start slot from the high product bits, odd stride
+__device__ __forceinline__ uint32_t hash_start(uint32_t key, uint32_t mask) { return ((key * 0x9E3779B1u) >> 7) & mask; }
+__device__ __forceinline__ uint32_t hash_step(uint32_t key, uint32_t mask) { return (((key * 0x85EBCA6Bu) >> 9) | 1u) & mask; }
+__device__ __forceinline__ uint32_t hash_part(uint32_t key, uint32_t parts) { return __umulhi(key * 0xC2B2AE35u, parts); }
 __device__ __forceinline__ int bits_for(uint32_t v) { return v ? 32 - __clz((int)v) : 0; }
 
 __device__ __forceinline__ uint64_t score_key(double s) {   // order-preserving f64 -> u64
@@ -86,22 +89,44 @@ __device__ __forceinline__ bool business_ok(uint32_t cur, uint32_t reco) {
     return false;
 }
 
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+// one LDS atomic per wave: returns this lane's slot in a shared append buffer (only meaningful if pred)
+__device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0) return 0;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
 // -------------------------------------------------------------------------------------
-// r-th largest key among the valid entries of `n` slots (keys distinct, r >= 1, r <= #valid):
-// MSD radix select, 8 bits per pass, histogram in LDS.  keyfn(i, &key) -> valid.
+// r-th largest key among the valid entries of `n` slots (keys distinct and < 2^nbits, 1 <= r <= #valid):
+// MSD radix select, 8 bits per pass starting at the top SIGNIFICANT bit (so the first histogram is not
+// degenerate), histogram in LDS.  keyfn(i, key&) -> valid.
 // -------------------------------------------------------------------------------------
 template <int BLOCK, typename KeyT, typename F>
 __device__ KeyT block_select_desc(F keyfn, uint32_t n, int nbits, uint32_t r, uint32_t* hist, volatile uint32_t* misc) {
     const int tid = threadIdx.x;
-    KeyT prefix = 0;
+    KeyT prefix = 0;   // value of the bits above `rem`
     uint32_t remain = r;
-    for (int shift = ((nbits + 7) / 8) * 8 - 8; shift >= 0; shift -= 8) {
+    int rem = nbits;
+    while (rem > 0) {
+        const int w = rem < 8 ? rem : 8, shift = rem - w;
         for (int i = tid; i < 256; i += BLOCK) hist[i] = 0;
         __syncthreads();
-        const KeyT hi_mask = (shift + 8 >= (int)(8 * sizeof(KeyT))) ? (KeyT)0 : (KeyT)((~(KeyT)0) << (shift + 8));
         for (uint32_t i = tid; i < n; i += BLOCK) {
             KeyT key;
-            if (keyfn(i, key) && (key & hi_mask) == prefix) atomicAdd(&hist[(uint32_t)(key >> shift) & 255u], 1u);
+            if (keyfn(i, key)) {
+                const KeyT above = rem >= (int)(8 * sizeof(KeyT)) ? (KeyT)0 : (KeyT)(key >> rem);
+                if (above == prefix) atomicAdd(&hist[(uint32_t)(key >> shift) & ((1u << w) - 1u)], 1u);
+            }
         }
         __syncthreads();
         if (tid < 64) {
@@ -117,8 +142,9 @@ __device__ KeyT block_select_desc(F keyfn, uint32_t n, int nbits, uint32_t r, ui
             if (a0 < remain && remain <= a0 + c0) { misc[S_SELD] = 4 * tid + 0; misc[S_SELR] = remain - a0; }
         }
         __syncthreads();
-        prefix |= (KeyT)misc[S_SELD] << shift;
+        prefix = (KeyT)((prefix << w) | (KeyT)misc[S_SELD]);
         remain = misc[S_SELR];
+        rem = shift;
     }
     return prefix;
 }
@@ -149,35 +175,80 @@ __device__ void block_sort_candidates(uint64_t* skey, uint32_t* sidx, uint32_t n
     }
 }
 
+// insert-or-add into the packed session table: slot = (rank << NB) | numerator.  Returns 1 if the
+// rank was new, 0 if it existed, -1 if the probe budget ran out (table too full).
+template <typename SlotT>
+__device__ __forceinline__ int sess_insert(SlotT* stab, uint32_t mask, uint32_t NB, uint32_t r, uint32_t w) {
+    constexpr SlotT SEMPTY = SlotTraits<SlotT>::EMPTY;
+    uint32_t h = hash_start(r, mask);
+    const uint32_t step = hash_step(r, mask);
+    for (int probe = 0; probe < MAX_PROBES; ++probe) {
+        SlotT cur = __atomic_load_n(&stab[h], __ATOMIC_RELAXED);
+        if (cur == SEMPTY) {
+            const SlotT old = atomicCAS(&stab[h], SEMPTY, ((SlotT)r << NB) | (SlotT)w);
+            if (old == SEMPTY) return 1;
+            cur = old;
+        }
+        if ((uint32_t)(cur >> NB) == r) { atomicAdd(&stab[h], (SlotT)w); return 0; }
+        h = (h + step) & mask;
+    }
+    return -1;
+}
+// the same for the item table (separate key / accumulator arrays; accumulators are signed)
+__device__ __forceinline__ int item_insert(uint32_t* ikeys, int* iacc, uint32_t mask, uint32_t it, int w) {
+    uint32_t h = hash_start(it, mask);
+    const uint32_t step = hash_step(it, mask);
+    for (int probe = 0; probe < MAX_PROBES; ++probe) {
+        uint32_t cur = __atomic_load_n(&ikeys[h], __ATOMIC_RELAXED);
+        int fresh = 0;
+        if (cur == EMPTY32) {
+            const uint32_t old = atomicCAS(&ikeys[h], EMPTY32, it);
+            if (old == EMPTY32) { cur = it; fresh = 1; } else cur = old;
+        }
+        if (cur == it) { atomicAdd(&iacc[h], w); return fresh; }
+        h = (h + step) & mask;
+    }
+    return -1;
+}
+
+// optional per-phase cycle accounting (debug; p.phase_cycles == nullptr in normal operation)
+#define SRN_TICK(ph)                                                                                         \
+    do { if (p.phase_cycles && tid == 0) { const long long t_ = clock64(); atomicAdd(&p.phase_cycles[ph], (unsigned long long)(t_ - t_prev)); t_prev = t_; } } while (0)
+
 template <int BLOCK, typename SlotT, typename OffT, bool GLOBAL_TABLES>
 __global__ __launch_bounds__(BLOCK) void vmis_predict_kernel(DeviceIndex ix, LaunchParams p, KernelCfg c,
                                                              const uint32_t* __restrict__ qlist, const uint32_t* __restrict__ qlist_n,
                                                              uint32_t* retry_list, uint32_t* retry_cnt,
-                                                             char* gscratch, unsigned long long gscratch_stride) {
+                                                             char* gscratch, unsigned long long gscratch_stride, char* nb_spill_base) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NWAVES = BLOCK / 64;
     constexpr SlotT SEMPTY = SlotTraits<SlotT>::EMPTY;
 
-    // ---- LDS carve-up (every offset a multiple of 16) ------------------------------------
+    // ---- LDS carve-up ------------------------------------------------------------------
     volatile uint32_t* misc = (volatile uint32_t*)smem;                       // MISC_WORDS
     uint32_t* hist = (uint32_t*)(smem + MISC_WORDS * 4);                      // 256
-    uint64_t* q_raw = (uint64_t*)(smem + MISC_WORDS * 4 + 1024);              // LMAX
-    unsigned long long* l_base = (unsigned long long*)(q_raw + LMAX);         // LMAX
-    uint32_t* q_idx = (uint32_t*)(l_base + LMAX);                             // LMAX
-    uint32_t* l_len = q_idx + LMAX;                                           // LMAX
-    char* region_b = (char*)(l_len + LMAX);
-    char* region_a = GLOBAL_TABLES ? (gscratch + (size_t)blockIdx.x * gscratch_stride) : (region_b + c.region_b_bytes);
+    uint64_t* q_raw = (uint64_t*)(smem + c.off_q);                            // q_cap   raw ids, pos 0 = most recent
+    unsigned long long* l_base = (unsigned long long*)(q_raw + c.q_cap);      // q_cap   posting list start
+    uint32_t* q_idx = (uint32_t*)(l_base + c.q_cap);                          // q_cap   dense idx or kNone
+    uint32_t* l_len = q_idx + c.q_cap;                                        // q_cap   truncated list length (0 = inactive)
+    uint32_t* l_pre = l_len + c.q_cap;                                        // q_cap+4 exclusive prefix of l_len
+    uint32_t* wmin = (uint32_t*)(smem + c.off_wave) + wave * 64;              // per-wave first-match scratch
+    char* region_b = smem + c.off_b;
+    char* region_a = GLOBAL_TABLES ? (gscratch + (size_t)blockIdx.x * gscratch_stride) : (smem + c.off_a);
 
     SlotT* stab = (SlotT*)region_a;                                           // phase 1-2
     uint32_t* ikeys = (uint32_t*)region_a;                                    // phase 3-4
     int* iacc = (int*)(region_a + (size_t)c.item_slots * 4);
     SlotT* nbl = (SlotT*)region_b;                                            // neighbours (phase 2-3)
+    SlotT* nb_spill = nb_spill_base ? (SlotT*)nb_spill_base + (size_t)blockIdx.x * p.k : nullptr;   // copy kept across item partitions
     uint64_t* ckey = (uint64_t*)region_b;                                     // candidates (phase 4)
     uint32_t* cidx = (uint32_t*)(region_b + CAND_CAP * 8);
 
     const OffT* __restrict__ row_off = (const OffT*)ix.row_off;
     const uint32_t NB = c.num_bits;
     const SlotT num_mask = ((SlotT)1 << NB) - 1;
+    const uint32_t smask = c.sess_slots - 1, imask = c.item_slots - 1;
     const uint32_t nq_eff = qlist ? *qlist_n : p.nq;
 
     for (uint32_t qi = blockIdx.x; qi < nq_eff; qi += gridDim.x) {
@@ -192,12 +263,13 @@ __global__ __launch_bounds__(BLOCK) void vmis_predict_kernel(DeviceIndex ix, Lau
         }
         // ---- phase 0: reset, translate items ---------------------------------------------
         __syncthreads();   // previous query's LDS reads are done
+        long long t_prev = p.phase_cycles ? clock64() : 0;
         if (tid < MISC_WORDS) misc[tid] = 0;
         for (uint32_t i = tid; i < c.sess_slots; i += BLOCK) stab[i] = SEMPTY;
-        if (tid < L) q_raw[tid] = p.items_flat[qb + (L - 1 - tid)];   // pos 0 = most recent item
-        phase_sync<GLOBAL_TABLES>();
-        if (tid < L) {
-            const uint32_t pos = tid; const uint64_t raw = q_raw[pos];
+        for (uint32_t i = tid; i < L; i += BLOCK) q_raw[i] = p.items_flat[qb + (L - 1 - i)];   // pos 0 = most recent item
+        __syncthreads();
+        for (uint32_t pos = tid; pos < L; pos += BLOCK) {
+            const uint64_t raw = q_raw[pos];
             bool first = true;
             for (uint32_t j = 0; j < pos; ++j) first = first && (q_raw[j] != raw);   // Q2: most recent occurrence only
             uint32_t idx = kNone;
@@ -213,42 +285,48 @@ __global__ __launch_bounds__(BLOCK) void vmis_predict_kernel(DeviceIndex ix, Lau
                 if (len) {
                     atomicMax((uint32_t*)&misc[S_RMAX], ix.post_rank[o0]);
                     if (len >= p.m) atomicMax((uint32_t*)&misc[S_XLO], ix.post_rank[o0 + p.m - 1]);
-                    atomicAdd((uint32_t*)&misc[S_P], len);
                     atomicAdd((uint32_t*)&misc[S_SUMW], L - pos);
                 }
             }
             l_len[pos] = len;
         }
         __syncthreads();
-        const uint32_t x_lo = misc[S_XLO], r_max = misc[S_RMAX], U = misc[S_U];
+        if (tid == 0) { uint32_t acc = 0; for (uint32_t i = 0; i < L; ++i) { l_pre[i] = acc; acc += l_len[i]; } l_pre[L] = acc; misc[S_P] = acc; }
+        phase_sync<GLOBAL_TABLES>();
+        const uint32_t x_lo = misc[S_XLO], r_max = misc[S_RMAX], U = misc[S_U], P = misc[S_P];
         const uint32_t cur_idx = q_idx[0];
+        SRN_TICK(0);
 
         // ---- phase 1: posting lists -> session table -------------------------------------
-        // Entries below x_lo (the m-th entry of a full list) can never be among the m most
-        // recent distinct sessions; lists are rank-descending, so a lane stops at the first one.
-        for (uint32_t pos = 0; pos < L; ++pos) {
-            const uint32_t len = l_len[pos];
-            if (!len) continue;
-            const uint32_t* __restrict__ list = ix.post_rank + l_base[pos];
-            const SlotT w = (SlotT)(L - pos);
-            for (uint32_t i = tid; i < len; i += BLOCK) {
-                const uint32_t r = list[i];
-                if (r < x_lo) break;
-                if (misc[S_CNT] > c.sess_cap) { misc[S_OVF] = 1; break; }
-                uint32_t h = hash_slot(r, c.sess_slots);
-                bool placed = false;
-                for (uint32_t probe = 0; probe < c.sess_slots; ++probe) {
-                    SlotT cur = __atomic_load_n(&stab[h], __ATOMIC_RELAXED);
-                    if (cur == SEMPTY) {
-                        const SlotT old = atomicCAS(&stab[h], SEMPTY, ((SlotT)r << NB) | w);
-                        if (old == SEMPTY) { atomicAdd((uint32_t*)&misc[S_CNT], 1u); placed = true; break; }
-                        cur = old;
+        // All <= U lists are walked as one flattened range (lane <-> list element, coalesced).  Entries
+        // below x_lo (the m-th entry of a full list) can never be among the m most recent distinct
+        // sessions, so they are read but not inserted.
+        {
+            uint32_t fresh = 0, pos = 0;
+            bool ovf = false;
+            for (uint32_t e0 = tid; e0 < P; e0 += 4 * BLOCK) {
+                uint32_t r[4], w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t e = e0 + u * BLOCK;
+                    r[u] = 0; w[u] = 0;
+                    if (e < P) {
+                        while (e >= l_pre[pos + 1]) ++pos;
+                        r[u] = ix.post_rank[l_base[pos] + (e - l_pre[pos])];
+                        w[u] = L - pos;
                     }
-                    if ((uint32_t)(cur >> NB) == r) { atomicAdd(&stab[h], w); placed = true; break; }
-                    h = (h + 1 == c.sess_slots) ? 0 : h + 1;
                 }
-                if (!placed) { misc[S_OVF] = 1; break; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (w[u] && r[u] >= x_lo) {
+                        const int res = sess_insert<SlotT>(stab, smask, NB, r[u], w[u]);
+                        if (res < 0) ovf = true; else fresh += (uint32_t)res;
+                    }
+                }
             }
+            fresh = wave_sum(fresh);
+            if (lane == 0 && fresh) atomicAdd((uint32_t*)&misc[S_CNT], fresh);
+            if (ovf) misc[S_OVF] = 1;
         }
         phase_sync<GLOBAL_TABLES>();
         if (misc[S_OVF]) {   // block-uniform: hand the query to the global-table pass
@@ -256,6 +334,7 @@ __global__ __launch_bounds__(BLOCK) void vmis_predict_kernel(DeviceIndex ix, Lau
             else if (tid == 0) retry_list[atomicAdd(retry_cnt, 1u)] = q;
             continue;
         }
+        SRN_TICK(1);
         const uint32_t Call = misc[S_CNT];
         const uint32_t Cm = min(Call, p.m);
 
@@ -266,6 +345,7 @@ __global__ __launch_bounds__(BLOCK) void vmis_predict_kernel(DeviceIndex ix, Lau
                 [&](uint32_t i, uint32_t& key) { const SlotT s = stab[i]; key = (uint32_t)(s >> NB) - x_lo; return s != SEMPTY; },
                 c.sess_slots, bits_for(r_max - x_lo), p.m, hist, misc);
         }
+        SRN_TICK(2);
         const int rbits = bits_for(r_max - tau);
         unsigned long long kappa = 0;   // composite threshold: (num << rbits) | (rank - tau)
         if (Cm > p.k) {
@@ -277,99 +357,170 @@ __global__ __launch_bounds__(BLOCK) void vmis_predict_kernel(DeviceIndex ix, Lau
             if (nbits <= 32) kappa = block_select_desc<BLOCK, uint32_t>(comp, c.sess_slots, nbits, p.k, hist, misc);
             else kappa = block_select_desc<BLOCK, unsigned long long>(comp, c.sess_slots, nbits, p.k, hist, misc);
         }
-        for (uint32_t i = tid; i < c.sess_slots; i += BLOCK) {
-            const SlotT s = stab[i];
-            const uint32_t r = (uint32_t)(s >> NB);
-            if (s != SEMPTY && r >= tau && ((((unsigned long long)(s & num_mask)) << rbits) | (r - tau)) >= kappa) {
-                const uint32_t at = atomicAdd((uint32_t*)&misc[S_NB], 1u);
-                nbl[at] = s;
-                if (p.nb_rank) { p.nb_rank[(size_t)q * p.k + at] = r; p.nb_num[(size_t)q * p.k + at] = (uint32_t)(s & num_mask); }
-            }
+        SRN_TICK(3);
+        for (uint32_t i0 = 0; i0 < c.sess_slots; i0 += BLOCK) {   // sess_slots is a multiple of BLOCK or smaller than it
+            const uint32_t i = i0 + tid;
+            SlotT s = SEMPTY; uint32_t r = 0; bool sel = false;
+            if (i < c.sess_slots) { s = stab[i]; r = (uint32_t)(s >> NB);
+                sel = s != SEMPTY && r >= tau && ((((unsigned long long)(s & num_mask)) << rbits) | (r - tau)) >= kappa; }
+            const uint32_t at = wave_append(sel, (uint32_t*)&misc[S_NB]);
+            if (sel) { nbl[at] = s;
+                if (p.nb_rank) { p.nb_rank[(size_t)q * p.k + at] = r; p.nb_num[(size_t)q * p.k + at] = (uint32_t)(s & num_mask); } }
         }
         __syncthreads();
         const uint32_t K = misc[S_NB];
-        for (uint32_t i = tid; i < c.item_slots; i += BLOCK) { ikeys[i] = EMPTY32; iacc[i] = 0; }
-        phase_sync<GLOBAL_TABLES>();
+        SRN_TICK(4);
 
         // ---- phase 3: neighbour rows -> item table ---------------------------------------
-        {
-            const uint32_t G = c.rows_lanes, g = tid & (G - 1), per_iter = BLOCK / G;
-            for (uint32_t base = 0; base < K; base += per_iter) {
-                const uint32_t j = base + tid / G;
-                const bool live = j < K;
-                uint32_t r = 0, num = 0; unsigned long long o0 = 0, o1 = 0;
-                if (live) { const SlotT s = nbl[j]; r = (uint32_t)(s >> NB); num = (uint32_t)(s & num_mask);
-                            o0 = row_off[r]; o1 = row_off[r + 1]; }
-                uint32_t minpos = 0xFFFFu;
-                for (unsigned long long t = o0 + g; t < o1; t += G) {
-                    const uint32_t it = ix.row_items[t];
-                    for (uint32_t pp = 0; pp < L; ++pp) if (q_idx[pp] == it) { minpos = min(minpos, pp); break; }
-                }
-                for (uint32_t d = 1; d < G; d <<= 1) minpos = min(minpos, (uint32_t)__shfl_xor((int)minpos, (int)d, 64));
-                if (live) {
-                    if (minpos == 0xFFFFu) misc[S_ERR] = 1;   // inconsistent index (reference: unwrap panic, mod.rs:138)
-                    const int p1 = (int)minpos + 1;
-                    const int w = (p1 < 100 ? 10 - p1 : 0) * (int)num;   // 10 * linear_score(pos) * numerator, exact (Q3)
-                    if (p.stats && g == 0) atomicAdd((uint32_t*)&misc[S_I], (uint32_t)(o1 - o0));
-                    for (unsigned long long t = o0 + g; t < o1; t += G) {
-                        const uint32_t it = ix.row_items[t];
-                        if (misc[S_ICNT] > c.item_cap) { misc[S_OVF] = 1; break; }
-                        uint32_t h = hash_slot(it, c.item_slots);
-                        bool placed = false;
-                        for (uint32_t probe = 0; probe < c.item_slots; ++probe) {
-                            uint32_t cur = __atomic_load_n(&ikeys[h], __ATOMIC_RELAXED);
-                            if (cur == EMPTY32) {
-                                const uint32_t old = atomicCAS(&ikeys[h], EMPTY32, it);
-                                if (old == EMPTY32) { atomicAdd((uint32_t*)&misc[S_ICNT], 1u); cur = it; } else cur = old;
-                            }
-                            if (cur == it) { atomicAdd(&iacc[h], w); placed = true; break; }
-                            h = (h + 1 == c.item_slots) ? 0 : h + 1;
-                        }
-                        if (!placed) { misc[S_OVF] = 1; break; }
-                    }
-                }
-            }
-        }
-        phase_sync<GLOBAL_TABLES>();
-        if (misc[S_OVF]) {
-            if (GLOBAL_TABLES) { if (tid == 0) { p.out_counts[q] = 0xFFFFFFFFu; if (p.stats) p.stats[(size_t)q * 8 + 7] = 3; } }
-            else if (tid == 0) retry_list[atomicAdd(retry_cnt, 1u)] = q;
-            continue;
-        }
-
-        // ---- phase 4: scores, business rules, top-n --------------------------------------
+        // A wave takes 64 neighbours at a time, one per lane (row offset, length, numerator in registers),
+        // prefix-sums the lengths across lanes and then walks the concatenated rows with lane <-> row element
+        // (adjacent lanes read adjacent items of the same row: coalesced).  The owning lane of an element is
+        // found by a 6-step shuffle binary search.  Pass B1 finds each row's first-match position against the
+        // FULL row (Q4), pass B2 adds w10 * num into the item table.  If the table overflows, the item space is
+        // split into `parts` hash partitions that are accumulated and harvested (phase 4) one after the other.
         const double denom = (double)(10u * U);
         const bool business = (p.flags & SRN_FLAG_BUSINESS_LOGIC) != 0;
         const uint32_t cur_attr = (business && cur_idx != kNone) ? ix.attr[cur_idx] : SRN_ATTR_NONE;
         const uint32_t n_out = p.how_many;
-        for (uint32_t base = 0; base < c.item_slots; base += BLOCK) {
-            const uint32_t i = base + tid;
-            if (i < c.item_slots) {
-                const uint32_t it = ikeys[i];
-                if (it != EMPTY32 && it != cur_idx && (!business || business_ok(cur_attr, ix.attr[it]))) {   // Q6 + rules
-                    const double idf = ix.idf[it];
-                    const double sc = (idf > 0.0 ? idf : 1.0) * (double)iacc[i] / denom;
-                    const uint64_t sk = score_key(sc);
-                    bool take = true;
-                    if (misc[S_HAVE_T]) { const uint64_t tk = ((uint64_t)misc[S_TKEY_HI] << 32) | misc[S_TKEY_LO];
-                                          take = sk > tk || (sk == tk && it < misc[S_TIDX]); }
-                    if (take) { const uint32_t at = atomicAdd((uint32_t*)&misc[S_CCNT], 1u); ckey[at] = sk; cidx[at] = it; }
+        uint32_t parts = 1, part = 0, d_total = 0;
+        bool failed = false;
+        for (;;) {
+            for (uint32_t i = tid; i < c.item_slots; i += BLOCK) { ikeys[i] = EMPTY32; iacc[i] = 0; }
+            if (tid == 0) { misc[S_OVF] = 0; misc[S_ICNT] = 0; }
+            phase_sync<GLOBAL_TABLES>();
+            {
+                uint32_t fresh = 0, isum = 0;
+                bool ovf = false;
+                for (uint32_t g0 = wave * 64; g0 < K; g0 += NWAVES * 64) {
+                    const uint32_t j = g0 + lane;
+                    uint32_t num = 0, len = 0; OffT o0 = 0;
+                    if (j < K) { const SlotT s = parts == 1 ? nbl[j] : nb_spill[j]; const uint32_t r = (uint32_t)(s >> NB); num = (uint32_t)(s & num_mask);
+                                 o0 = row_off[r]; len = (uint32_t)(row_off[r + 1] - o0); }
+                    uint32_t incl = len;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+                    const uint32_t excl = incl - len;
+                    const uint32_t T = __shfl(incl, 63, 64);
+                    isum += (lane == 0) ? T : 0;
+                    wmin[lane] = 0xFFFFu;
+                    // B1: first-match position of every row
+                    for (uint32_t base = 0; base < T; base += 64) {
+                        const uint32_t e = base + lane;
+                        uint32_t lo = 0, hi = 63;
+#pragma unroll
+                        for (int sdepth = 0; sdepth < 6; ++sdepth) { const uint32_t mid = (lo + hi) >> 1; const uint32_t v = __shfl(incl, (int)mid, 64);
+                                                                      if (v > e) hi = mid; else lo = mid + 1; }
+                        const uint32_t ex = __shfl(excl, (int)lo, 64);
+                        const OffT ob = (OffT)__shfl(o0, (int)lo, 64);
+                        if (e < T) {
+                            const uint32_t it = ix.row_items[(size_t)ob + (e - ex)];
+                            for (uint32_t pp = 0; pp < L; ++pp) if (q_idx[pp] == it) { atomicMin(&wmin[lo], pp); break; }
+                        }
+                    }
+                    const uint32_t mp = wmin[lane];
+                    if (j < K && mp == 0xFFFFu) misc[S_ERR] = 1;   // inconsistent index (reference: unwrap panic, mod.rs:138)
+                    const int p1 = (int)mp + 1;
+                    const int wrow = (p1 < 100 ? 10 - p1 : 0) * (int)num;   // 10 * linear_score(pos) * numerator, exact (Q3)
+                    // B2: accumulate
+                    for (uint32_t base = 0; base < T; base += 64) {
+                        const uint32_t e = base + lane;
+                        uint32_t lo = 0, hi = 63;
+#pragma unroll
+                        for (int sdepth = 0; sdepth < 6; ++sdepth) { const uint32_t mid = (lo + hi) >> 1; const uint32_t v = __shfl(incl, (int)mid, 64);
+                                                                      if (v > e) hi = mid; else lo = mid + 1; }
+                        const uint32_t ex = __shfl(excl, (int)lo, 64);
+                        const OffT ob = (OffT)__shfl(o0, (int)lo, 64);
+                        const int w = __shfl(wrow, (int)lo, 64);
+                        if (e < T) {
+                            const uint32_t it = ix.row_items[(size_t)ob + (e - ex)];
+                            if (parts == 1 || hash_part(it, parts) == part) {
+                                const int res = item_insert(ikeys, iacc, imask, it, w);
+                                if (res < 0) ovf = true; else fresh += (uint32_t)res;
+                            }
+                        }
+                    }
+                }
+                fresh = wave_sum(fresh);
+                if (lane == 0) { if (fresh) atomicAdd((uint32_t*)&misc[S_ICNT], fresh); if (p.stats && part == 0 && isum) atomicAdd((uint32_t*)&misc[S_I], isum); }
+                if (ovf) misc[S_OVF] = 1;
+            }
+            phase_sync<GLOBAL_TABLES>();
+            if (misc[S_OVF]) {   // block-uniform: split the item space finer and start the accumulation over
+                __syncthreads();
+                if (parts >= MAX_ITEM_PASSES || GLOBAL_TABLES || !nb_spill) { failed = true; break; }
+                // phase 4 reuses the neighbour list's LDS for its candidates: keep a copy in global scratch
+                if (parts == 1) { for (uint32_t i = tid; i < K; i += BLOCK) nb_spill[i] = nbl[i]; __threadfence(); }
+                parts *= 2; part = 0; d_total = 0;
+                if (tid == 0) { misc[S_CCNT] = 0; misc[S_HAVE_T] = 0; misc[S_I] = 0; }
+                continue;
+            }
+            d_total += misc[S_ICNT];
+            SRN_TICK(5);
+
+            // ---- phase 4: scores, business rules, top-n (per partition, one running candidate set) ----
+            // Chunks of BLOCK slots; the first chunk is a sample whose n-th best score becomes a threshold,
+            // later chunks are taken 4 at a time without barriers and only candidates beating the threshold
+            // are appended.  If the buffer would overflow the round is redone chunk by chunk (exact).
+            {
+                const uint32_t n_chunks = (c.item_slots + BLOCK - 1) / BLOCK;
+                uint32_t u = 0, ru = 1;
+                while (u < n_chunks) {
+                    const uint32_t cnt0 = misc[S_CCNT];
+                    const bool have_t = misc[S_HAVE_T] != 0;
+                    const uint64_t tk = ((uint64_t)misc[S_TKEY_HI] << 32) | misc[S_TKEY_LO];
+                    const uint32_t tix = misc[S_TIDX];
+                    const uint32_t u_end = min(u + ru, n_chunks);
+                    for (uint32_t uu = u; uu < u_end; ++uu) {
+                        const uint32_t i = uu * BLOCK + tid;
+                        bool take = false; uint64_t sk = 0; uint32_t it = EMPTY32;
+                        if (i < c.item_slots) {
+                            it = ikeys[i];
+                            if (it != EMPTY32 && it != cur_idx && (!business || business_ok(cur_attr, ix.attr[it]))) {   // Q6 + rules
+                                const double idf = ix.idf[it];
+                                sk = score_key((idf > 0.0 ? idf : 1.0) * (double)iacc[i] / denom);
+                                take = !have_t || sk > tk || (sk == tk && it < tix);
+                            }
+                        }
+                        const uint32_t at = wave_append(take, (uint32_t*)&misc[S_CCNT]);
+                        if (take) { if (at < CAND_CAP) { ckey[at] = sk; cidx[at] = it; } else misc[S_COVF] = 1; }
+                    }
+                    __syncthreads();
+                    if (misc[S_COVF]) {   // block-uniform: too many survivors for one optimistic round
+                        __syncthreads();
+                        if (tid == 0) { misc[S_CCNT] = cnt0; misc[S_COVF] = 0; }
+                        ru = 1;
+                        __syncthreads();
+                        continue;
+                    }
+                    u = u_end;
+                    const uint32_t cnt = misc[S_CCNT];
+                    const bool last = u >= n_chunks && part + 1 == parts;
+                    // before a single-chunk round the buffer must have room for BLOCK appends (exact path);
+                    // also sort once as soon as n candidates exist, to get a threshold
+                    const bool must_prune = cnt + BLOCK > CAND_CAP || (!have_t && cnt >= n_out && cnt > 1);
+                    if ((must_prune && !last) || (last && cnt > 1)) {
+                        uint32_t n2 = 2; while (n2 < cnt) n2 <<= 1;
+                        for (uint32_t t = cnt + tid; t < n2; t += BLOCK) { ckey[t] = 0; cidx[t] = EMPTY32; }
+                        __syncthreads();
+                        block_sort_candidates<BLOCK>(ckey, cidx, n2);
+                        if (tid == 0 && cnt >= n_out) {
+                            misc[S_CCNT] = n_out; misc[S_HAVE_T] = 1; misc[S_TIDX] = cidx[n_out - 1];
+                            misc[S_TKEY_LO] = (uint32_t)ckey[n_out - 1]; misc[S_TKEY_HI] = (uint32_t)(ckey[n_out - 1] >> 32);
+                        }
+                        __syncthreads();
+                    }
+                    // optimistic 4-chunk rounds once a threshold exists and the buffer is at most half full
+                    ru = (misc[S_HAVE_T] && misc[S_CCNT] * 2 <= CAND_CAP) ? 4u : 1u;
                 }
             }
+            SRN_TICK(6);
+            if (++part >= parts) break;
             __syncthreads();
-            const uint32_t cnt = misc[S_CCNT];
-            const bool last = base + BLOCK >= c.item_slots;
-            if (cnt > CAND_CAP - BLOCK || (last && cnt > 1)) {   // block-uniform
-                uint32_t n2 = 2; while (n2 < cnt) n2 <<= 1;
-                for (uint32_t t = cnt + tid; t < n2; t += BLOCK) { ckey[t] = 0; cidx[t] = EMPTY32; }
-                __syncthreads();
-                block_sort_candidates<BLOCK>(ckey, cidx, n2);
-                if (tid == 0 && cnt >= n_out) {
-                    misc[S_CCNT] = n_out; misc[S_HAVE_T] = 1; misc[S_TIDX] = cidx[n_out - 1];
-                    misc[S_TKEY_LO] = (uint32_t)ckey[n_out - 1]; misc[S_TKEY_HI] = (uint32_t)(ckey[n_out - 1] >> 32);
-                }
-                __syncthreads();
-            }
+        }
+        if (failed) {
+            if (GLOBAL_TABLES) { if (tid == 0) { p.out_counts[q] = 0xFFFFFFFFu; if (p.stats) p.stats[(size_t)q * 8 + 7] = 3; } }
+            else if (tid == 0) retry_list[atomicAdd(retry_cnt, 1u)] = q;
+            continue;
         }
         const uint32_t H = min(misc[S_CCNT], n_out);
         if (tid < H) {
@@ -380,8 +531,8 @@ __global__ __launch_bounds__(BLOCK) void vmis_predict_kernel(DeviceIndex ix, Lau
             p.out_counts[q] = H;
             if (p.nb_cnt) p.nb_cnt[q] = K;
             if (p.stats) { uint32_t* st = p.stats + (size_t)q * 8;
-                st[0] = misc[S_P]; st[1] = Cm; st[2] = K; st[3] = misc[S_I]; st[4] = misc[S_ICNT]; st[5] = H; st[6] = L;
-                st[7] = misc[S_ERR] ? 4u : (GLOBAL_TABLES ? 1u : 0u); }
+                st[0] = P; st[1] = Cm; st[2] = K; st[3] = misc[S_I]; st[4] = d_total; st[5] = H; st[6] = L;
+                st[7] = misc[S_ERR] ? 4u : (GLOBAL_TABLES ? 1u : (parts > 1 ? 0x100u * parts : 0u)); }
         }
     }
 }
@@ -391,11 +542,13 @@ __global__ __launch_bounds__(BLOCK) void vmis_predict_kernel(DeviceIndex ix, Lau
 // =====================================================================================
 struct Workspace {
     hipStream_t stream = nullptr;   // own stream for host-pointer calls
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool timed = false; uint32_t last_retry = 0;
+    static constexpr int RING = 64;               // per-call event triples (start, after main kernel, after retry pass)
+    hipEvent_t ev[RING][3] = {};
+    uint64_t calls = 0; uint32_t last_retry = 0;
     // device scratch
     uint32_t* retry_list = nullptr; size_t retry_cap = 0; uint32_t* retry_cnt = nullptr;
     char* gscratch = nullptr; size_t gscratch_bytes = 0;
+    char* spill = nullptr; size_t spill_bytes = 0;   // per-block neighbour-list copies for multi-partition item passes
     // staging for host-pointer calls
     char* stage = nullptr; size_t stage_bytes = 0;
     uint32_t* h_retry = nullptr;   // pinned
@@ -412,6 +565,7 @@ struct DeviceState {
     std::mutex mu; std::vector<Workspace*> free_ws; std::vector<Workspace*> all_ws;
     std::vector<std::pair<void*, Workspace*>> stream_ws;   // device-pointer calls: one workspace per user stream
     Workspace* last_ws = nullptr;   // for srn_last_kernel_ms (single-threaded measurement use)
+    unsigned long long* d_phase = nullptr; bool phase_on = false;   // debug per-phase cycle counters
 };
 
 namespace {
@@ -451,9 +605,10 @@ static void ws_free(Workspace* w) {
     if (w->retry_list) hipFree(w->retry_list);
     if (w->retry_cnt) hipFree(w->retry_cnt);
     if (w->gscratch) hipFree(w->gscratch);
+    if (w->spill) hipFree(w->spill);
     if (w->stage) hipFree(w->stage);
     if (w->h_retry) hipHostFree(w->h_retry);
-    for (auto& e : w->ev) if (e) hipEventDestroy(e);
+    for (auto& t : w->ev) for (auto& e : t) if (e) hipEventDestroy(e);
     if (w->stream) hipStreamDestroy(w->stream);
     delete w;
 }
@@ -483,7 +638,7 @@ static Workspace* ws_acquire(DeviceState* d, bool bind_to_stream, void* user_str
     if (!bind_to_stream && !d->free_ws.empty()) { Workspace* w = d->free_ws.back(); d->free_ws.pop_back(); return w; }
     Workspace* w = new Workspace();
     if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { delete w; return nullptr; }
-    for (auto& e : w->ev) if (hipEventCreate(&e) != hipSuccess) { ws_free(w); return nullptr; }
+    for (auto& t : w->ev) for (auto& e : t) if (hipEventCreate(&e) != hipSuccess) { ws_free(w); return nullptr; }
     if (hipMalloc((void**)&w->retry_cnt, 16) != hipSuccess || hipHostMalloc((void**)&w->h_retry, 16) != hipSuccess) { ws_free(w); return nullptr; }
     d->all_ws.push_back(w);
     if (bind_to_stream) d->stream_ws.emplace_back(user_stream, w);
@@ -510,13 +665,13 @@ static inline int bits_host(uint64_t v) { int b = 0; while (v) { ++b; v >>= 1; }
 template <int BLOCK, bool GLOBAL_TABLES>
 static hipError_t launch_variant(bool slot64, bool off64, dim3 grid, size_t lds, hipStream_t st, const DeviceIndex& di,
                                  const LaunchParams& p, const KernelCfg& c, const uint32_t* qlist, const uint32_t* qn,
-                                 uint32_t* retry_list, uint32_t* retry_cnt, char* gs, unsigned long long gstride) {
+                                 uint32_t* retry_list, uint32_t* retry_cnt, char* gs, unsigned long long gstride, char* spill) {
 #define SRN_LAUNCH(SLOT, OFF)                                                                                             \
     do {                                                                                                                  \
         auto kern = vmis_predict_kernel<BLOCK, SLOT, OFF, GLOBAL_TABLES>;                                                 \
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
         if (e != hipSuccess) return e;                                                                                    \
-        hipLaunchKernelGGL(kern, grid, dim3(BLOCK), lds, st, di, p, c, qlist, qn, retry_list, retry_cnt, gs, gstride);    \
+        hipLaunchKernelGGL(kern, grid, dim3(BLOCK), lds, st, di, p, c, qlist, qn, retry_list, retry_cnt, gs, gstride, spill); \
         return hipGetLastError();                                                                                         \
     } while (0)
     if (!slot64 && !off64) SRN_LAUNCH(uint32_t, uint32_t);
@@ -527,7 +682,8 @@ static hipError_t launch_variant(bool slot64, bool off64, dim3 grid, size_t lds,
 }
 
 static constexpr int kBlock = 512;
-static constexpr uint32_t kFixedLds = MISC_WORDS * 4 + 1024 + LMAX * (8 + 8 + 4 + 4);
+static inline uint32_t floor_pow2(uint64_t v) { uint32_t p2 = 1; while ((uint64_t)p2 * 2 <= v) p2 <<= 1; return p2; }
+static inline uint64_t ceil_pow2(uint64_t v) { uint64_t p2 = 1; while (p2 < v) p2 <<= 1; return p2; }
 
 int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in, bool on_device, void* user_stream,
                    const uint64_t* h_items, const uint32_t* h_qoff, uint64_t* h_ids, double* h_scores, uint32_t* h_counts,
@@ -535,6 +691,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     HIP_TRY(hipSetDevice(d->device));
     LaunchParams p = p_in;
     if (p.nq == 0) return SRN_OK;
+    p.phase_cycles = d->phase_on ? d->d_phase : nullptr;
     Workspace* w = ws_acquire(d, on_device, user_stream);
     if (!w) return fail(SRN_EHIP, "cannot create HIP stream / events");
     struct Rel { DeviceState* d; Workspace* w; bool b; ~Rel() { ws_release(d, w, b); } } rel{d, w, on_device};
@@ -546,25 +703,31 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     const int rank_bits = std::max(1, bits_host(ix.n_kept ? ix.n_kept - 1 : 0));
     const bool slot64 = rank_bits + num_bits > 32 || ix.n_kept >= 0xFFFFFFF0ull;
     const uint32_t slot_bytes = slot64 ? 8 : 4;
-    KernelCfg c{};
-    c.num_bits = (uint32_t)num_bits;
-    c.region_b_bytes = round_up(std::max<uint32_t>(p.k * slot_bytes, CAND_CAP * 12), 16);
-    const uint32_t lds_budget = 80 * 1024 - 256;   // two 512-thread blocks per CU
-    if (kFixedLds + c.region_b_bytes + 16 * 1024 > (uint32_t)std::min(d->lds_per_block_max, 160 * 1024))
-        return fail(SRN_ERANGE, "k too large for the LDS neighbour list");
-    const uint32_t total_budget = std::max(lds_budget, kFixedLds + c.region_b_bytes + 16 * 1024);
-    c.region_a_bytes = (total_budget - kFixedLds - c.region_b_bytes) / 16 * 16;
     // what the query set could need at most
     const uint64_t m_eff = std::min<uint64_t>(p.m, ix.m_index);
-    const uint64_t need_sess = std::min<uint64_t>(Lmax * m_eff, ix.n_kept);
-    const uint64_t need_item = std::min<uint64_t>((uint64_t)p.k * ix.max_row_len, ix.n_items);
-    c.sess_slots = (uint32_t)std::min<uint64_t>(c.region_a_bytes / slot_bytes, need_sess * 3 / 2 + 64);
-    c.item_slots = (uint32_t)std::min<uint64_t>(c.region_a_bytes / 8, need_item * 3 / 2 + 64);
-    c.sess_cap = (uint32_t)std::min<uint64_t>(need_sess, (uint64_t)c.sess_slots * 85 / 100);
-    c.item_cap = (uint32_t)std::min<uint64_t>(need_item, (uint64_t)c.item_slots * 85 / 100);
-    c.rows_lanes = 4;
-    const size_t lds = kFixedLds + c.region_b_bytes + c.region_a_bytes;
-    const bool may_overflow = c.sess_cap < need_sess || c.item_cap < need_item;
+    const uint64_t need_sess = std::max<uint64_t>(1, std::min<uint64_t>(Lmax * m_eff, ix.n_kept));
+    const uint64_t need_item = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)p.k * ix.max_row_len, ix.n_items));
+    KernelCfg c{};
+    c.num_bits = (uint32_t)num_bits;
+    c.q_cap = round_up((uint32_t)Lmax + 1, 4);
+    c.off_q = MISC_WORDS * 4 + 1024;
+    c.off_wave = round_up(c.off_q + c.q_cap * 24 + (c.q_cap + 4) * 4, 16);
+    c.off_b = c.off_wave + (kBlock / 64) * 256;
+    const uint32_t region_b = round_up(std::max<uint32_t>(p.k * slot_bytes, CAND_CAP * 12), 16);
+    c.off_a = c.off_b + region_b;
+    const uint32_t lds_max = (uint32_t)std::min(d->lds_per_block_max, 160 * 1024);
+    uint32_t budget = 80 * 1024;                          // two 512-thread blocks per CU
+    if (c.off_a + 32 * 1024 > budget) budget = lds_max;   // long sessions / large k: one block per CU
+    if (c.off_a + 8 * 1024 > budget) return fail(SRN_ERANGE, "k / session length too large for the LDS layout");
+    const uint32_t a_max = budget - c.off_a;
+    c.item_slots = std::min<uint32_t>(floor_pow2(a_max / 8), (uint32_t)std::min<uint64_t>(1u << 30, ceil_pow2(need_item * 2)));
+    c.sess_slots = std::min<uint32_t>(floor_pow2(a_max / slot_bytes), (uint32_t)std::min<uint64_t>(1u << 30, ceil_pow2(need_sess * 2)));
+    c.item_slots = std::max<uint32_t>(c.item_slots, 64); c.sess_slots = std::max<uint32_t>(c.sess_slots, 64);
+    const uint32_t region_a = std::max<uint32_t>(c.item_slots * 8, c.sess_slots * slot_bytes);
+    const size_t lds = (size_t)c.off_a + region_a;
+    // tables at least twice the worst case cannot exhaust the probe budget: no retry machinery needed
+    const bool sess_may_overflow = (uint64_t)c.sess_slots < need_sess * 2, item_may_overflow = (uint64_t)c.item_slots < need_item * 2;
+    const bool may_overflow = sess_may_overflow || item_may_overflow;
 
     // ---- buffers -----------------------------------------------------------------------
     const size_t n_out = (size_t)p.nq * p.how_many;
@@ -593,31 +756,36 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     if (may_overflow) {
         if (w->retry_cap < p.nq) { if (w->retry_list) HIP_TRY(hipFree(w->retry_list)); w->retry_list = nullptr; w->retry_cap = 0;
             HIP_TRY(hipMalloc((void**)&w->retry_list, (size_t)p.nq * 4 + 64)); w->retry_cap = p.nq; }
-        cg.sess_slots = (uint32_t)std::min<uint64_t>(0xFFFFFF00ull, need_sess * 2 + 64); cg.sess_cap = (uint32_t)need_sess + 1;
-        cg.item_slots = (uint32_t)std::min<uint64_t>(0xFFFFFF00ull, need_item * 2 + 64); cg.item_cap = (uint32_t)need_item + 1;
+        cg.sess_slots = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(64, ceil_pow2(need_sess * 2)));
+        cg.item_slots = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(64, ceil_pow2(need_item * 2)));
         g_stride = std::max<uint64_t>((uint64_t)cg.sess_slots * slot_bytes, (uint64_t)cg.item_slots * 8);
         g_stride = (g_stride + 255) / 256 * 256;
-        retry_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(2 * (uint64_t)d->n_cu, (4ull << 30) / g_stride));
+        retry_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)d->n_cu, (2ull << 30) / g_stride));
         int rc = ensure(&w->gscratch, &w->gscratch_bytes, g_stride * retry_blocks); if (rc) return rc;
-        cg.region_a_bytes = 0;
         HIP_TRY(hipMemsetAsync(w->retry_cnt, 0, 4, st));
     }
 
     // ---- launches ----------------------------------------------------------------------
     const uint32_t blocks_per_cu = std::max<uint32_t>(1, (160 * 1024) / (uint32_t)lds);
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * blocks_per_cu * 4);
-    HIP_TRY(hipEventRecord(w->ev[0], st));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * std::min<uint32_t>(blocks_per_cu, 2048 / kBlock) * 4);
+    char* spill = nullptr;
+    if (item_may_overflow) {
+        int rc = ensure(&w->spill, &w->spill_bytes, (size_t)grid * p.k * slot_bytes); if (rc) return rc;
+        spill = w->spill;
+    }
+    hipEvent_t* ev = w->ev[w->calls % Workspace::RING];
+    HIP_TRY(hipEventRecord(ev[0], st));
     HIP_TRY((launch_variant<kBlock, false>(slot64, d->off64, dim3(grid), lds, st, d->di, p, c, nullptr, nullptr,
-                                            w->retry_list, w->retry_cnt, nullptr, 0)));
-    HIP_TRY(hipEventRecord(w->ev[1], st));
+                                            w->retry_list, w->retry_cnt, nullptr, 0, spill)));
+    HIP_TRY(hipEventRecord(ev[1], st));
     if (may_overflow) {
-        const size_t lds_g = kFixedLds + cg.region_b_bytes;
+        const size_t lds_g = c.off_a;
         HIP_TRY((launch_variant<kBlock, true>(slot64, d->off64, dim3(retry_blocks), lds_g, st, d->di, p, cg, w->retry_list, w->retry_cnt,
-                                               nullptr, nullptr, w->gscratch, g_stride)));
+                                               nullptr, nullptr, w->gscratch, g_stride, nullptr)));
         HIP_TRY(hipMemcpyAsync(w->h_retry, w->retry_cnt, 4, hipMemcpyDeviceToHost, st));
     }
-    HIP_TRY(hipEventRecord(w->ev[2], st));
-    w->timed = true; w->last_retry = may_overflow ? 1 : 0;
+    HIP_TRY(hipEventRecord(ev[2], st));
+    ++w->calls; w->last_retry = may_overflow ? 1 : 0;
 
     if (!on_device) {
         HIP_TRY(hipMemcpyAsync(h_ids, p.out_ids, n_out * 8, hipMemcpyDeviceToHost, st));
@@ -638,14 +806,46 @@ int device_last_kernel_ms(DeviceState* d, double* ms_main, double* ms_retry, uin
     HIP_TRY(hipSetDevice(d->device));
     Workspace* w;
     { std::lock_guard<std::mutex> lk(d->mu); w = d->last_ws; }
-    if (!w || !w->timed) return fail(SRN_EINVAL, "no timed predict call yet");
-    HIP_TRY(hipEventSynchronize(w->ev[2]));
+    if (!w || !w->calls) return fail(SRN_EINVAL, "no timed predict call yet");
+    hipEvent_t* ev = w->ev[(w->calls - 1) % Workspace::RING];
+    HIP_TRY(hipEventSynchronize(ev[2]));
     float a = 0, b = 0;
-    HIP_TRY(hipEventElapsedTime(&a, w->ev[0], w->ev[1]));
-    HIP_TRY(hipEventElapsedTime(&b, w->ev[1], w->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&a, ev[0], ev[1]));
+    HIP_TRY(hipEventElapsedTime(&b, ev[1], ev[2]));
     if (ms_main) *ms_main = a;
     if (ms_retry) *ms_retry = b;
     if (retried) *retried = w->last_retry ? *w->h_retry : 0;
+    return SRN_OK;
+}
+
+int device_phase_cycles(DeviceState* d, int enable, unsigned long long* out16) {
+    HIP_TRY(hipSetDevice(d->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (!d->d_phase) { HIP_TRY(hipMalloc((void**)&d->d_phase, 16 * 8)); d->allocs.push_back(d->d_phase); HIP_TRY(hipMemset(d->d_phase, 0, 16 * 8)); }
+    if (out16) HIP_TRY(hipMemcpy(out16, d->d_phase, 16 * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(d->d_phase, 0, 16 * 8));
+    d->phase_on = enable != 0;
+    return SRN_OK;
+}
+
+// durations of the most recent min(max_n, calls, RING) predict launches of the last-used workspace, oldest first
+int device_kernel_times(DeviceState* d, uint32_t max_n, double* ms_main, double* ms_retry, uint32_t* out_n) {
+    HIP_TRY(hipSetDevice(d->device));
+    Workspace* w;
+    { std::lock_guard<std::mutex> lk(d->mu); w = d->last_ws; }
+    *out_n = 0;
+    if (!w || !w->calls) return SRN_OK;
+    const uint64_t n = std::min<uint64_t>(std::min<uint64_t>(max_n, w->calls), Workspace::RING);
+    HIP_TRY(hipEventSynchronize(w->ev[(w->calls - 1) % Workspace::RING][2]));
+    for (uint64_t i = 0; i < n; ++i) {
+        hipEvent_t* ev = w->ev[(w->calls - n + i) % Workspace::RING];
+        float a = 0, b = 0;
+        HIP_TRY(hipEventElapsedTime(&a, ev[0], ev[1]));
+        HIP_TRY(hipEventElapsedTime(&b, ev[1], ev[2]));
+        if (ms_main) ms_main[i] = a;
+        if (ms_retry) ms_retry[i] = b;
+    }
+    *out_n = (uint32_t)n;
     return SRN_OK;
 }
 

@@ -96,6 +96,21 @@ class VMISIndex:
         return a.value, b.value, r.value
 
 
+    def kernel_times(self, max_n=64):
+        """Per-call (main kernel ms, retry pass ms) of the most recent predict calls, oldest first (HIP events
+        recorded on the launch stream around each launch)."""
+        a, b, n = np.zeros(max_n), np.zeros(max_n), C.c_uint32()
+        capi.check(capi.lib().srn_kernel_times(self._h, max_n, capi.ptr(a), capi.ptr(b), C.byref(n)))
+        return a[:n.value].copy(), b[:n.value].copy()
+
+
+    def debug_phase_cycles(self, enable):
+        """Profiling aid: fetch-and-clear the per-phase shader-cycle counters, then switch accounting on/off."""
+        out = np.zeros(16, np.uint64)
+        capi.check(capi.lib().srn_debug_phase_cycles(self._h, int(bool(enable)), capi.ptr(out)))
+        return out
+
+
 def _flatten(sessions):
     if isinstance(sessions, tuple) and len(sessions) == 2:
         return capi.as_u64(sessions[0]), capi.as_u32(sessions[1])

@@ -1,0 +1,27 @@
+"""Scratch experiment driver (GPU box): phase-cycle breakdown at a given config. Not part of the product."""
+import sys, time, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import serenade_amd as sa
+from serenade_amd import synth
+cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
+inter, n_items, k, m, idfw = synth.CONFIGS[cfg]
+off, items, ts = synth.training_sessions(inter, n_items)
+ix = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw, device=0)
+qi, qo = synth.queries(int(B / 3) + 2048, n_items, seed=synth.SEED + 7919)
+qi, qo = qi[:qo[B]], qo[:B + 1]
+print("cpus", os.cpu_count(), len(os.sched_getaffinity(0)), open("/sys/fs/cgroup/cpu.max").read().strip() if os.path.exists("/sys/fs/cgroup/cpu.max") else "no cgroup cpu.max")
+for rep in range(2):
+    sa.predict_batch(ix, (qi, qo), k, m, 21)
+ix.debug_phase_cycles(True)
+t0 = time.time(); r = sa.predict_batch_debug(ix, (qi, qo), k, m, 21, neighbours=False); dt = time.time() - t0
+cyc = ix.debug_phase_cycles(False).astype(np.float64)
+ms, msr, _ = ix.last_kernel_ms()
+names = ["0 prep+clear", "1 postings->sess", "2 m-cut select", "3 k-cut select", "4 compact+clear", "5 rows->items", "6 score+topn"]
+print("main %.2f ms retry %.2f ms  total cycles %.3g" % (ms, msr, cyc.sum()))
+for n, c in zip(names, cyc):
+    print("  %-18s %6.2f%%  %.0f cyc/query" % (n, 100 * c / cyc.sum(), c / B))
+st = r["stats"].astype(np.float64)
+print("mean P,C,K,I,D,H,L", st[:, :7].mean(0).round(1), "retry frac", (st[:, 7] == 1).mean())
+print("D pct", np.percentile(st[:, 4], [50, 90, 99, 100]), "I pct", np.percentile(st[:, 3], [50, 90, 99, 100]), "P pct", np.percentile(st[:,0],[50,90,99,100]))
