@@ -34,6 +34,18 @@ def algorithmic_bytes(stats):
     return 4 * s[:, 0] + 4 * s[:, 1] + 8 * s[:, 2] + 4 * s[:, 3] + 8 * s[:, 4] + 16 * s[:, 5] + 8 * s[:, 6]
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,7 +199,7 @@ def main():
         t1 = time.time()
         oix = O.OracleIndex(off, items, ts, m, 34, idfw, fast=True)
         t_obuild = time.time() - t1
-        cores = os.cpu_count() or 1
+        cores = usable_cores()
         probe_n = min(B, 64 * cores)
         r = oix.predict_batch("literal", flat0[:qo0[probe_n]], qo0[:probe_n + 1], k, m, how_many, False, threads=cores, want_results=False)
         rate = probe_n / max(r["elapsed"], 1e-6)

@@ -70,6 +70,7 @@ struct DeviceIndex {  // pointers into HBM; passed by value to the kernels
     const void* row_off;  // uint32_t* or uint64_t* (offsets_64bit)
     const uint32_t* row_items;
     uint32_t n_items, n_kept;
+    double idf_hi, idf_lo;   // max / min over items of (idf > 0 ? idf : 1)
 };
 
 struct LaunchParams {

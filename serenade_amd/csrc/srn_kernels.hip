@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -42,7 +44,8 @@ static constexpr uint32_t EMPTY32 = 0xFFFFFFFFu;
 static constexpr int CAND_CAP = 1024;       // candidate buffer of the final top-n (entries)
 static constexpr int MISC_WORDS = 64;       // scalar words at the head of LDS
 static constexpr int MAX_PROBES = 96;       // open-addressing probe budget before a table is declared full
-static constexpr int MAX_ITEM_PASSES = 64;  // item-space partition passes before giving up on the LDS table
+static constexpr int MAX_ITEM_PASSES = 64;
+static constexpr int ROW_CACHE = 16;        // row elements per lane kept in registers per 64-row group (covers 1024 elements)  // item-space partition passes before giving up on the LDS table
 
 // launch-time geometry, identical for every block of a launch (all LDS offsets multiples of 16)
 struct KernelCfg {
@@ -216,7 +219,7 @@ __device__ __forceinline__ int item_insert(uint32_t* ikeys, int* iacc, uint32_t 
     do { if (p.phase_cycles && tid == 0) { const long long t_ = clock64(); atomicAdd(&p.phase_cycles[ph], (unsigned long long)(t_ - t_prev)); t_prev = t_; } } while (0)
 
 template <int BLOCK, typename SlotT, typename OffT, bool GLOBAL_TABLES>
-__global__ __launch_bounds__(BLOCK) void vmis_predict_kernel(DeviceIndex ix, LaunchParams p, KernelCfg c,
+__global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(DeviceIndex ix, LaunchParams p, KernelCfg c,
                                                              const uint32_t* __restrict__ qlist, const uint32_t* __restrict__ qlist_n,
                                                              uint32_t* retry_list, uint32_t* retry_cnt,
                                                              char* gscratch, unsigned long long gscratch_stride, char* nb_spill_base) {
@@ -391,11 +394,21 @@ __global__ __launch_bounds__(BLOCK) void vmis_predict_kernel(DeviceIndex ix, Lau
             {
                 uint32_t fresh = 0, isum = 0;
                 bool ovf = false;
-                for (uint32_t g0 = wave * 64; g0 < K; g0 += NWAVES * 64) {
-                    const uint32_t j = g0 + lane;
-                    uint32_t num = 0, len = 0; OffT o0 = 0;
+                // the (<= 4) most common case keeps the evolving items in registers; longer sessions scan LDS
+                const uint32_t qv0 = q_idx[0], qv1 = L > 1 ? q_idx[1] : kNone, qv2 = L > 2 ? q_idx[2] : kNone, qv3 = L > 3 ? q_idx[3] : kNone;
+                auto match_pos = [&](uint32_t it) -> uint32_t {   // reverse position of `it` in the evolving session, or 0xFFFF
+                    if (it == qv0) return 0; if (it == qv1) return 1; if (it == qv2) return 2; if (it == qv3) return 3;
+                    for (uint32_t pp = 4; pp < L; ++pp) if (q_idx[pp] == it) return pp;
+                    return 0xFFFFu; };
+                auto load_group = [&](uint32_t g0, uint32_t& num, uint32_t& len, OffT& o0) {
+                    const uint32_t j = g0 + lane; num = 0; len = 0; o0 = 0;
                     if (j < K) { const SlotT s = parts == 1 ? nbl[j] : nb_spill[j]; const uint32_t r = (uint32_t)(s >> NB); num = (uint32_t)(s & num_mask);
-                                 o0 = row_off[r]; len = (uint32_t)(row_off[r + 1] - o0); }
+                                 o0 = row_off[r]; len = (uint32_t)(row_off[r + 1] - o0); } };
+                uint32_t num, len, nnum = 0, nlen = 0; OffT o0, no0 = 0;
+                if (wave * 64 < K) load_group(wave * 64, num, len, o0);
+                for (uint32_t g0 = wave * 64; g0 < K; g0 += NWAVES * 64) {
+                    const uint32_t gn = g0 + NWAVES * 64;
+                    if (gn < K) load_group(gn, nnum, nlen, no0);   // prefetch the next group's row offsets under this group's work
                     uint32_t incl = len;
 #pragma unroll
                     for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
@@ -403,31 +416,56 @@ __global__ __launch_bounds__(BLOCK) void vmis_predict_kernel(DeviceIndex ix, Lau
                     const uint32_t T = __shfl(incl, 63, 64);
                     isum += (lane == 0) ? T : 0;
                     wmin[lane] = 0xFFFFu;
-                    // B1: first-match position of every row
-                    for (uint32_t base = 0; base < T; base += 64) {
-                        const uint32_t e = base + lane;
+                    auto owner_of = [&](uint32_t e) -> uint32_t {   // lane whose row holds flattened element e (e < T)
                         uint32_t lo = 0, hi = 63;
 #pragma unroll
-                        for (int sdepth = 0; sdepth < 6; ++sdepth) { const uint32_t mid = (lo + hi) >> 1; const uint32_t v = __shfl(incl, (int)mid, 64);
-                                                                      if (v > e) hi = mid; else lo = mid + 1; }
-                        const uint32_t ex = __shfl(excl, (int)lo, 64);
-                        const OffT ob = (OffT)__shfl(o0, (int)lo, 64);
-                        if (e < T) {
-                            const uint32_t it = ix.row_items[(size_t)ob + (e - ex)];
-                            for (uint32_t pp = 0; pp < L; ++pp) if (q_idx[pp] == it) { atomicMin(&wmin[lo], pp); break; }
+                        for (int sd = 0; sd < 6; ++sd) { const uint32_t mid = (lo + hi) >> 1; const uint32_t v = __shfl(incl, (int)mid, 64);
+                                                          if (v > e) hi = mid; else lo = mid + 1; }
+                        return lo & 63u; };
+                    // gather: all of the group's row elements are requested before any is consumed
+                    uint32_t itc[ROW_CACHE], own[ROW_CACHE / 4];   // owner lanes packed 4 x 8 bit
+#pragma unroll
+                    for (int u = 0; u < ROW_CACHE; ++u) {
+                        itc[u] = EMPTY32; if ((u & 3) == 0) own[u >> 2] = 0;
+                        if ((uint32_t)u * 64 < T) {   // wave-uniform
+                            const uint32_t e = u * 64 + lane;
+                            const uint32_t lo = owner_of(e);
+                            const uint32_t ex = __shfl(excl, (int)lo, 64);
+                            const OffT ob = (OffT)__shfl(o0, (int)lo, 64);
+                            own[u >> 2] |= lo << ((u & 3) * 8);
+                            if (e < T) itc[u] = ix.row_items[(size_t)ob + (e - ex)];
                         }
                     }
+                    // B1: first-match position of every row (Q4: against the full row)
+#pragma unroll
+                    for (int u = 0; u < ROW_CACHE; ++u)
+                        if ((uint32_t)u * 64 < T && itc[u] != EMPTY32) { const uint32_t mp = match_pos(itc[u]); if (mp != 0xFFFFu) atomicMin(&wmin[(own[u >> 2] >> ((u & 3) * 8)) & 63u], mp); }
+                    for (uint32_t base = ROW_CACHE * 64; base < T; base += 64) {   // rows longer than the register cache
+                        const uint32_t e = base + lane;
+                        const uint32_t lo = owner_of(e);
+                        const uint32_t ex = __shfl(excl, (int)lo, 64);
+                        const OffT ob = (OffT)__shfl(o0, (int)lo, 64);
+                        if (e < T) { const uint32_t mp = match_pos(ix.row_items[(size_t)ob + (e - ex)]); if (mp != 0xFFFFu) atomicMin(&wmin[lo], mp); }
+                    }
                     const uint32_t mp = wmin[lane];
-                    if (j < K && mp == 0xFFFFu) misc[S_ERR] = 1;   // inconsistent index (reference: unwrap panic, mod.rs:138)
+                    if (g0 + lane < K && mp == 0xFFFFu) misc[S_ERR] = 1;   // inconsistent index (reference: unwrap panic, mod.rs:138)
                     const int p1 = (int)mp + 1;
                     const int wrow = (p1 < 100 ? 10 - p1 : 0) * (int)num;   // 10 * linear_score(pos) * numerator, exact (Q3)
                     // B2: accumulate
-                    for (uint32_t base = 0; base < T; base += 64) {
-                        const uint32_t e = base + lane;
-                        uint32_t lo = 0, hi = 63;
 #pragma unroll
-                        for (int sdepth = 0; sdepth < 6; ++sdepth) { const uint32_t mid = (lo + hi) >> 1; const uint32_t v = __shfl(incl, (int)mid, 64);
-                                                                      if (v > e) hi = mid; else lo = mid + 1; }
+                    for (int u = 0; u < ROW_CACHE; ++u) {
+                        if ((uint32_t)u * 64 < T) {
+                            const int w = __shfl(wrow, (int)((own[u >> 2] >> ((u & 3) * 8)) & 63u), 64);
+                            const uint32_t it = itc[u];
+                            if (it != EMPTY32 && (parts == 1 || hash_part(it, parts) == part)) {
+                                const int res = item_insert(ikeys, iacc, imask, it, w);
+                                if (res < 0) ovf = true; else fresh += (uint32_t)res;
+                            }
+                        }
+                    }
+                    for (uint32_t base = ROW_CACHE * 64; base < T; base += 64) {
+                        const uint32_t e = base + lane;
+                        const uint32_t lo = owner_of(e);
                         const uint32_t ex = __shfl(excl, (int)lo, 64);
                         const OffT ob = (OffT)__shfl(o0, (int)lo, 64);
                         const int w = __shfl(wrow, (int)lo, 64);
@@ -439,6 +477,7 @@ __global__ __launch_bounds__(BLOCK) void vmis_predict_kernel(DeviceIndex ix, Lau
                             }
                         }
                     }
+                    num = nnum; len = nlen; o0 = no0;
                 }
                 fresh = wave_sum(fresh);
                 if (lane == 0) { if (fresh) atomicAdd((uint32_t*)&misc[S_ICNT], fresh); if (p.stats && part == 0 && isum) atomicAdd((uint32_t*)&misc[S_I], isum); }
@@ -469,20 +508,39 @@ __global__ __launch_bounds__(BLOCK) void vmis_predict_kernel(DeviceIndex ix, Lau
                     const bool have_t = misc[S_HAVE_T] != 0;
                     const uint64_t tk = ((uint64_t)misc[S_TKEY_HI] << 32) | misc[S_TKEY_LO];
                     const uint32_t tix = misc[S_TIDX];
+                    const bool t_pos = have_t && tk > 0x8000000000000000ull;   // threshold score > 0: non-positive accumulators cannot make it
                     const uint32_t u_end = min(u + ru, n_chunks);
-                    for (uint32_t uu = u; uu < u_end; ++uu) {
-                        const uint32_t i = uu * BLOCK + tid;
-                        bool take = false; uint64_t sk = 0; uint32_t it = EMPTY32;
-                        if (i < c.item_slots) {
-                            it = ikeys[i];
+                    __syncthreads();   // every wave has read the round's state before any wave appends (and moves S_CCNT)
+                    // gather first (up to 4 chunks' idf loads in flight per lane), then score + append.  Once the
+                    // threshold score is positive, an item whose upper bound idf_hi * acc / denom (same operations and
+                    // rounding as the score, so monotone and safe) is below it is dropped without touching idf[].
+                    uint32_t its[4]; int accs[4]; double idfs[4];
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        its[x] = EMPTY32; accs[x] = 0; idfs[x] = 0.0;
+                        const uint32_t i = (u + x) * BLOCK + tid;
+                        if (u + x < u_end && i < c.item_slots) {
+                            const uint32_t it = ikeys[i];
                             if (it != EMPTY32 && it != cur_idx && (!business || business_ok(cur_attr, ix.attr[it]))) {   // Q6 + rules
-                                const double idf = ix.idf[it];
-                                sk = score_key((idf > 0.0 ? idf : 1.0) * (double)iacc[i] / denom);
-                                take = !have_t || sk > tk || (sk == tk && it < tix);
+                                const int acc = iacc[i];
+                                const uint64_t ubk = score_key(ix.idf_hi * (double)acc / denom);
+                                const bool hopeless = t_pos & ((acc <= 0) | (ubk < tk));   // branch-free on purpose
+                                if (!hopeless) { its[x] = it; accs[x] = acc; idfs[x] = ix.idf[it]; }
                             }
                         }
-                        const uint32_t at = wave_append(take, (uint32_t*)&misc[S_CCNT]);
-                        if (take) { if (at < CAND_CAP) { ckey[at] = sk; cidx[at] = it; } else misc[S_COVF] = 1; }
+                    }
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        if (u + x < u_end) {   // block-uniform
+                            const uint32_t it = its[x];
+                            bool take = false; uint64_t sk = 0;
+                            if (it != EMPTY32) {
+                                sk = score_key((idfs[x] > 0.0 ? idfs[x] : 1.0) * (double)accs[x] / denom);
+                                take = !have_t || sk > tk || (sk == tk && it < tix);
+                            }
+                            const uint32_t at = wave_append(take, (uint32_t*)&misc[S_CCNT]);
+                            if (take) { if (at < CAND_CAP) { ckey[at] = sk; cidx[at] = it; } else misc[S_COVF] = 1; }
+                        }
                     }
                     __syncthreads();
                     if (misc[S_COVF]) {   // block-uniform: too many survivors for one optimistic round
@@ -596,6 +654,10 @@ DeviceState* device_attach(const FlatIndex& ix, int device) {
     else { std::vector<uint32_t> o32(ix.row_off.begin(), ix.row_off.end()); d->di.row_off = upload(d, o32, ok); }
     d->di.row_items = upload(d, ix.row_items, ok);
     d->di.n_items = (uint32_t)ix.n_items; d->di.n_kept = (uint32_t)ix.n_kept;
+    double hi = 1.0, lo = 1.0; bool any = false;   // bounds of idf_eff = (idf > 0 ? idf : 1) for the top-n pre-filter
+    for (double v : ix.idf) { const double e = v > 0.0 ? v : 1.0; if (!any) { hi = lo = e; any = true; } else { hi = std::max(hi, e); lo = std::min(lo, e); } }
+    d->di.idf_hi = hi; d->di.idf_lo = lo;
+    if (getenv("SRN_DEBUG")) fprintf(stderr, "[srn] idf_hi=%g idf_lo=%g n_items=%zu\n", hi, lo, (size_t)ix.n_items);
     if (!ok) { device_release(d); return nullptr; }
     return d;
 }
