@@ -70,6 +70,7 @@ def main():
     import torch
     import torch.distributed as dist
     import serenade_amd as sa
+    from serenade_amd import distributed as D
     from serenade_amd import synth
 
     if not torch.cuda.is_available():
@@ -77,9 +78,7 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    D.init("nccl", dev)   # RCCL; control plane only (barrier + max-over-ranks), the data path has no collective
 
     inter, n_items, k, m, idfw = synth.CONFIGS[args.config]
     how_many, last_items = synth.HOW_MANY, synth.LAST_ITEMS
@@ -117,9 +116,7 @@ def main():
         sa.predict_batch_device(index, d_flat.data_ptr(), d_off.data_ptr(), B, last_items, k, m, how_many, False,
                                 out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), stream.cuda_stream)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    barrier = D.barrier
 
     for i in range(args.warmup):
         step(i)
@@ -135,10 +132,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = D.max_over_ranks(elapsed, dev)
     step_ms = np.array([a.elapsed_time(b) for a, b in ev])
     k_main, k_retry = index.kernel_times(min(64, args.steps))
     served = int((out_cnt.cpu().numpy().view(np.uint32) != 0xFFFFFFFF).sum())

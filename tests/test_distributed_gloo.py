@@ -1,0 +1,86 @@
+"""world_size-2 gloo test of the N>1 path's host logic (query sharding, max-over-ranks timing, result gather).
+The per-shard compute is the GPU path and is covered by tests/test_gpu_parity.py; here the shards carry a
+deterministic stand-in payload so that the plumbing can be checked on CPU."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from serenade_amd import distributed as D
+
+
+def test_shard_range_is_a_partition():
+    for n in (0, 1, 7, 8, 1000, 131072):
+        for world in (1, 2, 3, 4, 8):
+            cover = []
+            for r in range(world):
+                lo, hi = D.shard_range(n, r, world)
+                assert 0 <= lo <= hi <= n
+                cover.extend(range(lo, hi))
+            assert cover == list(range(n))
+            sizes = [D.shard_range(n, r, world)[1] - D.shard_range(n, r, world)[0] for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_shard_queries_rebases_offsets():
+    rng = np.random.default_rng(0)
+    lens = rng.integers(1, 5, size=101)
+    off = np.zeros(102, np.uint32); off[1:] = np.cumsum(lens)
+    flat = rng.integers(1, 10**9, size=int(off[-1])).astype(np.uint64)
+    seen = []
+    for r in range(3):
+        f, o, lo, hi = D.shard_queries(flat, off, r, 3)
+        assert o[0] == 0 and len(o) == hi - lo + 1 and o[-1] == len(f)
+        for i in range(hi - lo):
+            assert np.array_equal(f[o[i]:o[i + 1]], flat[off[lo + i]:off[lo + i + 1]])
+        seen.append((lo, hi))
+    assert seen[0][0] == 0 and seen[-1][1] == 101
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    try:
+        r, w = D.init("gloo")
+        assert (r, w) == (rank, world)
+        nq, n = 37, 5
+        lo, hi = D.shard_range(nq, rank, world)
+        ids = (np.arange(lo, hi, dtype=np.uint64)[:, None] * 100 + np.arange(n, dtype=np.uint64)[None, :])
+        scores = ids.astype(np.float64) / 7.0
+        counts = (np.arange(lo, hi) % (n + 1)).astype(np.uint32)
+        D.barrier()
+        slow = D.max_over_ranks(1.0 + rank)                       # the slowest rank defines the step time
+        g_ids, g_sc, g_cnt = D.gather_results(ids, scores, counts, nq)
+        q.put((rank, slow, g_ids.tolist(), g_sc.tolist(), g_cnt.tolist()))
+        D.barrier()
+    except Exception as e:  # pragma: no cover
+        q.put((rank, "error: %r" % (e,)))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharding_and_gather():
+    mp = pytest.importorskip("torch.multiprocessing")
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    nq, n = 37, 5
+    exp_ids = (np.arange(nq, dtype=np.uint64)[:, None] * 100 + np.arange(n, dtype=np.uint64)[None, :])
+    for res in out:
+        assert len(res) == 5, res
+        _rank, slow, g_ids, g_sc, g_cnt = res
+        assert slow == 2.0
+        assert np.array_equal(np.array(g_ids, np.uint64), exp_ids)
+        np.testing.assert_allclose(np.array(g_sc), exp_ids.astype(np.float64) / 7.0)
+        assert g_cnt == [i % (n + 1) for i in range(nq)]

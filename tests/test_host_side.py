@@ -1,0 +1,192 @@
+"""Host side of the product without a GPU: the C ABI loads and exports every declared symbol, the TSV loader
+and the flat-index builder agree with the oracle's restatement of the reference, error codes are right.
+No predict call is made here (that path needs the GPU and has no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import serenade_amd as sa
+from serenade_amd import capi, synth
+from helpers import ROOT, extract_example, have_reference_assets, small_dataset
+from oracle import oracle as O
+
+
+def test_library_exports_every_symbol_the_header_declares():
+    header = open(os.path.join(ROOT, "include", "serenade_hip.h")).read()
+    declared = set(re.findall(r"\b(srn_[a-z0-9_]+)\s*\(", header))
+    declared -= {n for n in declared if n.endswith("_t")}
+    assert declared == set(capi.SYMBOLS), (declared ^ set(capi.SYMBOLS))
+    L = capi.lib()
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert L.srn_version().startswith(b"serenade_hip")
+    lim = capi.Limits()
+    L.srn_limits(C.byref(lim))
+    assert (lim.max_how_many, lim.max_session_len, lim.max_k) == (capi.MAX_HOW_MANY, capi.MAX_SESSION_LEN, capi.MAX_K)
+
+
+def _write_tsv(path, rows):
+    with open(path, "w") as f:
+        f.write("SessionId\tItemId\tTime\n")
+        for s, i, t in rows:
+            f.write("%d\t%d\t%s\n" % (s, i, t))
+
+
+def _product_sessions(path):
+    h = C.c_void_p()
+    capi.check(capi.lib().srn_sessions_from_tsv(str(path).encode(), C.byref(h)))
+    v = capi.SessionsView()
+    capi.check(capi.lib().srn_sessions_view(h, C.byref(v)))
+    n = v.n_sessions
+    off = np.ctypeslib.as_array(C.cast(v.sess_off, C.POINTER(C.c_uint64)), (n + 1,)).copy()
+    items = np.ctypeslib.as_array(C.cast(v.items, C.POINTER(C.c_uint64)), (int(off[-1]),)).copy()
+    ts = np.ctypeslib.as_array(C.cast(v.max_ts, C.POINTER(C.c_uint32)), (n,)).copy()
+    q = C.c_uint64()
+    capi.check(capi.lib().srn_sessions_length_quantile(h, 0.995, C.byref(q)))
+    capi.lib().srn_sessions_free(h)
+    return off, items, ts, q.value
+
+
+def test_tsv_loader_matches_read_from_file_quirks(tmp_path):
+    """Q8: unsorted input, stable order inside a session, de-dup keeps first, max-ts only from non-duplicate rows,
+    f64 timestamps rounded, last row never added and last session dropped."""
+    rng = np.random.default_rng(0)
+    rows = []
+    for s in rng.permutation(200):
+        for j in range(int(rng.integers(1, 9))):
+            rows.append((int(s) * 3 + 1, int(rng.integers(1, 40)), "%.1f" % (1.59e9 + float(rng.integers(0, 10**6)) + 0.5 * (j % 2))))
+    order = rng.permutation(len(rows))
+    rows = [rows[i] for i in order]
+    path = tmp_path / "train.tsv"
+    _write_tsv(path, rows)
+    off, items, ts, q995 = _product_sessions(path)
+    o_off, o_items, o_ts, _ = O.read_tsv(str(path))
+    assert np.array_equal(off, o_off) and np.array_equal(items, o_items) and np.array_equal(ts, o_ts)
+    # hand-made file: session 9's final row is never added; a trailing single-row session is dropped entirely
+    p2 = tmp_path / "tiny.tsv"
+    _write_tsv(p2, [(7, 30, "10.4"), (9, 5, "20.0"), (7, 10, "11.6"), (7, 30, "99.0"), (9, 6, "21.0"), (9, 8, "22.0")])
+    off2, items2, ts2, _ = _product_sessions(p2)
+    assert off2.tolist() == [0, 2, 4] and items2.tolist() == [10, 30, 5, 6]
+    assert ts2.tolist() == [12, 21]                         # 11.6 rounds to 12; the duplicate row (t=99) does not move the max
+    _write_tsv(p2, [(7, 30, "10.0"), (7, 10, "11.0"), (9, 5, "20.0")])
+    off3, items3, ts3, _ = _product_sessions(p2)
+    assert off3.tolist() == [0, 2] and items3.tolist() == [10, 30] and ts3.tolist() == [11]
+    lens = np.diff(off.astype(np.int64))
+    assert q995 == int(round(float(np.quantile(lens, 0.995))))
+
+
+@pytest.mark.skipif(not have_reference_assets(), reason="/root/reference assets not present (GPU box)")
+def test_new_from_csv_on_reference_example(tmp_path):
+    d = extract_example(tmp_path)
+    path = os.path.join(d, "train.txt")
+    off, items, ts, q995 = _product_sessions(path)
+    o_off, o_items, o_ts, _ = O.read_tsv(path)
+    assert np.array_equal(off, o_off) and np.array_equal(items, o_items) and np.array_equal(ts, o_ts)
+    assert q995 == 15
+    ix = sa.VMISIndex.new_from_csv(path, 500, 1.0, device=-1)     # VMISIndex::new_from_csv(path, m, idf_weighting)
+    info = ix.info
+    assert info["n_sessions_total"] == 23753 and info["max_session_len"] == 15 and info["device"] == -1
+    oix = O.OracleIndex(o_off, o_items, o_ts, 500, 15, 1.0)
+    assert info["n_items"] == oix.num_items and info["nnz_rows"] == oix.total_pairs
+    for it in np.unique(o_items)[::5]:
+        a, ia = ix.postings(int(it))
+        b, ib = oix.postings(int(it))
+        if b is None:
+            assert a is None
+            continue
+        assert np.array_equal(a, b) and ia == ib
+
+
+@pytest.mark.parametrize("tied", [False, True])
+def test_flat_index_matches_prepare_hashmap(tied):
+    """Posting order (timestamp desc, session index desc), truncation to m, idf and the p99.5 filter (Q5, Q7, Q9)."""
+    off, items, ts, ids = small_dataset(40 + tied, n_sessions=4000, n_items=300, tied_timestamps=tied)
+    for (m_index, max_len, idfw) in [(50, 7, 1.0), (1000, 12, 2.0), (1, 3, 0.0)]:
+        ix = sa.VMISIndex.from_sessions(off, items, ts, m_index, max_len, idfw, device=-1)
+        oix = O.OracleIndex(off, items, ts, m_index, max_len, idfw)
+        info = ix.info
+        lens = np.diff(off.astype(np.int64))
+        assert info["n_sessions_kept"] == int((lens <= max_len).sum())
+        assert info["n_items"] == oix.num_items and info["nnz_rows"] == oix.total_pairs
+        for it in ids:
+            a, ia = ix.postings(int(it))
+            b, ib = oix.postings(int(it))
+            if b is None:
+                assert a is None
+                continue
+            assert np.array_equal(a, b), it
+            assert ia == ib
+        assert ix.postings(5)[0] is None
+
+
+def test_save_load_roundtrip(tmp_path):
+    off, items, ts, ids = small_dataset(3)
+    ix = sa.VMISIndex.from_sessions(off, items, ts, 40, 12, 1.0, device=-1)
+    p = tmp_path / "index.srn"
+    ix.save(p)
+    ix2 = sa.VMISIndex.load(p, device=-1)
+    assert ix.info == ix2.info
+    for it in ids[::3]:
+        a, ia = ix.postings(int(it))
+        b, ib = ix2.postings(int(it))
+        assert (a is None and b is None) or (np.array_equal(a, b) and ia == ib)
+    with open(p, "r+b") as f:
+        f.write(b"garbage!")
+    with pytest.raises(sa.SerenadeError) as e:
+        sa.VMISIndex.load(p, device=-1)
+    assert e.value.code == capi.SRN_EIO
+
+
+def test_error_codes_without_a_device():
+    off, items, ts, ids = small_dataset(4, n_sessions=200, n_items=50)
+    ix = sa.VMISIndex.from_sessions(off, items, ts, 10, 12, 1.0, device=-1)
+    with pytest.raises(sa.SerenadeError) as e:
+        sa.predict(ix, [int(ids[0])], 10, 10, 5, False)          # no device attached, and no CPU fallback
+    assert e.value.code == capi.SRN_ENODEV
+    with pytest.raises(sa.SerenadeError) as e:
+        sa.predict_batch(ix, [[int(ids[0])]], 10, 10, 5)
+    assert e.value.code == capi.SRN_ENODEV
+    with pytest.raises(sa.SerenadeError) as e:
+        sa.VMISIndex.from_sessions(off, items[::-1].copy(), ts, 10, 12, 1.0, device=-1)     # rows not ascending
+    assert e.value.code == capi.SRN_EINVAL
+    with pytest.raises(sa.SerenadeError) as e:
+        sa.VMISIndex.from_sessions(off, items, ts, 0, 12, 1.0, device=-1)                    # m_index = 0
+    assert e.value.code == capi.SRN_EINVAL
+    with pytest.raises(sa.SerenadeError) as e:
+        sa.VMISIndex.new_from_csv("/nonexistent/train.txt", 10, 1.0, device=-1)
+    assert e.value.code == capi.SRN_EIO
+    if capi.device_count() == 0:
+        with pytest.raises(sa.SerenadeError) as e:
+            sa.VMISIndex.from_sessions(off, items, ts, 10, 12, 1.0, device=0)                # no GPU here: loud failure
+        assert e.value.code == capi.SRN_EHIP
+
+
+def test_set_attributes_host_only():
+    off, items, ts, ids = small_dataset(6, n_sessions=200, n_items=50)
+    ix = sa.VMISIndex.from_sessions(off, items, ts, 10, 12, 1.0, device=-1)
+    ix.set_attributes(ids[:5], np.array([0, 1, 2, 3, 0xFF], np.uint8))     # accepted; consulted only by GPU predict
+
+
+def test_synthetic_generator_is_deterministic_and_shaped():
+    a = synth.training_sessions(50_000, 5_000)
+    b = synth.training_sessions(50_000, 5_000)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    off, items, ts = a
+    lens = np.diff(off.astype(np.int64))
+    assert lens.min() >= 1 and lens.max() <= 34
+    pct = np.percentile(lens, [25, 50, 75, 90, 95, 99])                        # vmis_index.rs:116-126: 2 3 6 10 14 27
+    assert pct[0] == 2 and pct[1] in (2, 3) and pct[2] in (5, 6) and pct[3] in (9, 10) and pct[4] in (13, 14) and 24 <= pct[5] <= 28
+    assert len(np.unique(ts)) == len(ts)                                       # unique timestamps
+    assert int(items.max()) < (1 << 48) and int(items.max()) > (1 << 32)       # u64 id path
+    for s in range(0, len(ts), 997):
+        row = items[off[s]:off[s + 1]]
+        assert np.all(row[1:] > row[:-1])
+    qi, qo = synth.queries(500, 5_000)
+    ql = np.diff(qo.astype(np.int64))
+    assert ql.min() >= 1 and ql.max() <= synth.LAST_ITEMS
+    qi2, qo2 = synth.queries(500, 5_000, seed=synth.SEED + 1)
+    assert not (len(qi) == len(qi2) and np.array_equal(qi, qi2))

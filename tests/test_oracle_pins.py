@@ -1,0 +1,166 @@
+"""Pins the CPU oracle (oracle/vmis_oracle.cpp) against every known answer the reference holds for the hot path
+ before anything is compared with it.  No GPU needed."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import (GOLDEN, assert_valid_topn, evaluator_queries, extract_example, flatten, have_reference_assets,
+                     mrr_hitrate, random_queries, read_test_data_evolving, small_dataset)
+from oracle import oracle as O
+
+KAT_OFF = np.array([0, 3, 7], np.uint64)
+KAT_ITEMS = np.array([920004, 920005, 920006, 920002, 920003, 920004, 920005], np.uint64)   # rows ascending
+KAT_TS = np.array([1, 1], np.uint32)
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_kat1_should_train_and_predict(fast):
+    """src/vmisknn/mod.rs:229-310: 2 sessions, n_most_recent=5, max_len=5, idf_weighting=1; predict([920005],
+    k=500, m=500, how_many=20) -> exactly 4 recommendations, 920004 first."""
+    ix = O.OracleIndex(KAT_OFF, KAT_ITEMS, KAT_TS, 5, 5, 1.0, fast=fast)
+    post, idf = ix.postings(920005)
+    assert post.tolist() == [1, 0]                                  # timestamp tie -> larger session index first (Q9)
+    assert idf == pytest.approx(np.log(7 / 2), rel=1e-15)           # pairs / sessions-with-item (Q5)
+    for predict in (ix.predict_literal, ix.predict_canonical):
+        ids, sc = predict([920005], 500, 500, 20)
+        assert len(ids) == 4
+        assert ids[0] == 920004
+        assert sc[0] == pytest.approx(2.2549733432916628, rel=1e-14)
+        assert sorted(ids[1:].tolist()) == [920002, 920003, 920006]
+        np.testing.assert_allclose(sc[1:], 1.751319134149782, rtol=1e-14)
+
+
+def test_heap_order_known_answers():
+    """src/vmisknn/mod.rs:313-411 and similarity_hashed.rs:35-58."""
+    assert O.kat_itemscore_heap([123, 543, 234], [5000.0, 1.0, 100.0], 2) == [234, 123]      # min-heap on score
+    assert O.kat_itemscore_sorted([123, 543, 234], [5000.0, 1.0, 100.0]) == [123, 234, 543]  # into_sorted_vec: score desc
+    assert O.kat_sessiontime_heap([123, 345, 456, 234], [5000, 99, 1, 499], 2) == [234, 123]  # 8-ary heap, oldest at root
+
+
+def test_panic_inputs_are_reported():
+    ix = O.OracleIndex(KAT_OFF, KAT_ITEMS, KAT_TS, 5, 5, 1.0)
+    with pytest.raises(RuntimeError):
+        ix.predict_literal([], 10, 10, 5)            # mod.rs:157 unwrap on empty session
+    with pytest.raises(RuntimeError):
+        ix.predict_canonical([], 10, 10, 5)
+    ids, _ = ix.predict_literal([1, 2, 3], 10, 10, 5)   # unknown items are skipped (vmis_index.rs:350)
+    assert len(ids) == 0
+
+
+def test_fast_index_builder_equals_literal_prepare_hashmap():
+    for seed, tied in ((1, False), (2, True)):
+        off, items, ts, ids = small_dataset(seed, n_sessions=2000, n_items=250, tied_timestamps=tied)
+        a = O.OracleIndex(off, items, ts, 60, 9, 1.5, fast=False)
+        b = O.OracleIndex(off, items, ts, 60, 9, 1.5, fast=True)
+        assert a.num_items == b.num_items and a.total_pairs == b.total_pairs
+        for it in ids:
+            pa, ia = a.postings(int(it))
+            pb, ib = b.postings(int(it))
+            if pa is None:
+                assert pb is None
+                continue
+            assert np.array_equal(pa, pb) and ia == ib
+
+
+def test_literal_is_a_valid_instance_of_canonical_when_timestamps_are_unique():
+    """With unique timestamps the reference's sequential find_neighbors equals the closed form;
+    what is left to hash/heap order is only WHICH of several equal-score entries sit at a cut (N2/N3)."""
+    off, items, ts, ids = small_dataset(7, n_sessions=3000, n_items=300)
+    ix = O.OracleIndex(off, items, ts, 150, 12, 1.0)
+    qs = random_queries(3, ids, 250, max_len=6)
+    for (k, m, n) in [(40, 150, 21), (500, 60, 10)]:
+        for q in qs:
+            sid_l, sim_l = ix.find_neighbors_literal(q, k, m)
+            sid_c, num_c, U = ix.neighbors_canonical(q, k, m)
+            assert len(sid_l) == len(sid_c)
+            if len(sid_c) == 0:
+                continue
+            sim_c = num_c / U
+            # every candidate's similarity agrees with the closed form, and the literal set is a valid top-k by score
+            full_sid, full_num, _ = ix.neighbors_canonical(q, 10**6, m)
+            table = dict(zip(full_sid.tolist(), (full_num / U).tolist()))
+            for s, v in zip(sid_l.tolist(), sim_l.tolist()):
+                assert table[s] == pytest.approx(v, rel=1e-12)
+            assert sorted(sim_l.tolist(), reverse=True) == pytest.approx(sorted(sim_c.tolist(), reverse=True), rel=1e-12)
+            # same neighbour set -> same item scores
+            if set(sid_l.tolist()) == set(sid_c.tolist()):
+                ids_l, sc_l = ix.predict_literal(q, k, m, n)
+                all_ids, all_sc, _ = ix.scores_canonical(q, k, m)
+                assert_valid_topn(ids_l, sc_l, all_ids, all_sc, n, exclude=[q[-1]])
+
+
+def test_canonical_topn_is_sorted_and_excludes_current_item():
+    off, items, ts, ids = small_dataset(9, n_sessions=1500, n_items=150)
+    ix = O.OracleIndex(off, items, ts, 100, 12, 1.0)
+    for q in random_queries(4, ids, 100, max_len=5):
+        out_ids, sc = ix.predict_canonical(q, 30, 100, 15)
+        assert q[-1] not in out_ids.tolist()
+        assert all(sc[i] > sc[i + 1] or (sc[i] == sc[i + 1] and out_ids[i] < out_ids[i + 1]) for i in range(len(sc) - 1))
+
+
+def test_golden_fixture_is_reproduced_by_the_oracle():
+    """tests/golden/example_golden.npz travels to the GPU box; the oracle must still produce exactly that."""
+    g = np.load(os.path.join(GOLDEN, "example_golden.npz"))
+    for tag in ("a", "b"):
+        m, k, n, idfw, max_len = (int(x) for x in g["params_" + tag])
+        ix = O.OracleIndex(g["sess_off"], g["items"], g["ts"], m, max_len, float(idfw), fast=True)
+        r = ix.predict_batch("canonical", g["q_items_" + tag], g["q_off_" + tag], k, m, n, business=True, threads=4)
+        assert np.array_equal(r["counts"], g["counts_" + tag])
+        assert np.array_equal(r["ids"], g["ids_" + tag])
+        assert np.array_equal(r["scores"], g["scores_" + tag])
+    assert len(g["q_off_a"]) - 1 == 931                              # README.md:172 "Qty test evaluations: 931"
+
+
+needs_ref = pytest.mark.skipif(not have_reference_assets(), reason="/root/reference assets not present (GPU box)")
+
+
+@needs_ref
+def test_reference_example_readme_vectors(tmp_path):
+    """GV-1 and AGG-1/2 of SURVEY.md 8c, straight from the reference's example data and README."""
+    d = extract_example(tmp_path)
+    off, items, ts, _ = O.read_tsv(os.path.join(d, "train.txt"))
+    assert len(ts) == 23753                                          # last session dropped by the loader quirk (Q8)
+    lens = np.diff(off.astype(np.int64))
+    max_len = int(round(float(np.quantile(lens, 0.995))))
+    assert max_len == 15
+    test = read_test_data_evolving(os.path.join(d, "test.txt"))
+
+    # GV-1: README.md:154, /v1/recommend?item_id=13598 with the shipped example.toml (m=500, k=50, how_many=21)
+    readme = [2835, 10, 12068, 4313, 3097, 8028, 3545, 7812, 17519, 1164, 17935, 1277, 13335, 8655, 14664, 14556, 6868,
+              13509, 9248, 2498, 11724]
+    ix = O.OracleIndex(off, items, ts, 500, max_len, 1.0, fast=True)
+    all_ids, all_sc, _ = ix.scores_canonical([13598], 50, 500)
+    table = dict(zip(all_ids.tolist(), all_sc.tolist()))
+    assert_valid_topn(np.array(readme, np.uint64), np.array([table[i] for i in readme]), all_ids, all_sc, 21, exclude=[13598])
+    for predict in (ix.predict_literal, ix.predict_canonical):
+        ids, sc = predict([13598], 50, 500, 21, True)
+        assert set(ids.tolist()) == set(readme)
+        np.testing.assert_allclose(sc[:3], [10.134, 9.5101, 9.1452], rtol=2e-4)
+
+    # AGG-1: README.md:170-172 -- 931 evaluations, HitRate@20 0.6402, Mrr@20 0.3277 (tie noise on MRR only)
+    qs = evaluator_queries(test, 2)
+    assert len(qs) == 931
+    flat, qoff = flatten([q for q, _ in qs])
+    nxt = [n for _, n in qs]
+    for which, mrr_tol in (("literal", 0.002), ("canonical", 0.005)):
+        r = ix.predict_batch(which, flat, qoff, 50, 500, 20, business=True, threads=4)
+        recs = [r["ids"][i, :r["counts"][i]].tolist() for i in range(len(qs))]
+        mrr, hit = mrr_hitrate(recs, nxt, 20)
+        assert hit == pytest.approx(0.6402, abs=0.0025)
+        assert mrr == pytest.approx(0.3277, abs=mrr_tol)
+    mrr, hit = mrr_hitrate([r["ids"][i, :r["counts"][i]].tolist() for i in range(len(qs))], nxt, 20)
+    assert round(hit, 4) == 0.6402                                  # canonical tie-break reproduces the README digit for digit
+
+    # AGG-2: README.md:64-71 -- TPE optimum m=1502 k=288 last_items=4 idf_weighting=2 -> test MRR@20 0.3401
+    ix2 = O.OracleIndex(off, items, ts, 1502, max_len, 2.0, fast=True)
+    qs4 = evaluator_queries(test, 4)
+    flat, qoff = flatten([q for q, _ in qs4])
+    r = ix2.predict_batch("literal", flat, qoff, 288, 1502, 20, business=True, threads=4)
+    mrr, _ = mrr_hitrate([r["ids"][i, :r["counts"][i]].tolist() for i in range(len(qs4))], [n for _, n in qs4], 20)
+    assert mrr == pytest.approx(0.3401, abs=0.005)
+    # no k/m cut is ever hit on this data, so literal and canonical neighbour sets coincide on all 931 queries
+    for q, _ in qs4[::7]:
+        a, _ = ix2.find_neighbors_literal(q, 288, 1502)
+        b, _, _ = ix2.neighbors_canonical(q, 288, 1502)
+        assert set(a.tolist()) == set(b.tolist())
