@@ -43,9 +43,9 @@ namespace srn {
 static constexpr uint32_t EMPTY32 = 0xFFFFFFFFu;
 static constexpr int CAND_CAP = 1024;       // candidate buffer of the final top-n (entries)
 static constexpr int MISC_WORDS = 64;       // scalar words at the head of LDS
-static constexpr int MAX_PROBES = 96;       // open-addressing probe budget before a table is declared full
+static constexpr int MAX_PROBES = 48;       // bucket probes (4 slots each) before a table is declared full
 static constexpr int MAX_ITEM_PASSES = 64;
-static constexpr int ROW_CACHE = 16;        // row elements per lane kept in registers per 64-row group (covers 1024 elements)  // item-space partition passes before giving up on the LDS table
+static constexpr int ROW_CACHE = 8;         // row elements per lane kept in registers per 64-row group (covers 1024 elements)  // item-space partition passes before giving up on the LDS table
 
 // launch-time geometry, identical for every block of a launch (all LDS offsets multiples of 16)
 struct KernelCfg {
@@ -178,38 +178,111 @@ __device__ void block_sort_candidates(uint64_t* skey, uint32_t* sidx, uint32_t n
     }
 }
 
-// insert-or-add into the packed session table: slot = (rank << NB) | numerator.  Returns 1 if the
-// rank was new, 0 if it existed, -1 if the probe budget ran out (table too full).
-template <typename SlotT>
-__device__ __forceinline__ int sess_insert(SlotT* stab, uint32_t mask, uint32_t NB, uint32_t r, uint32_t w) {
-    constexpr SlotT SEMPTY = SlotTraits<SlotT>::EMPTY;
-    uint32_t h = hash_start(r, mask);
-    const uint32_t step = hash_step(r, mask);
-    for (int probe = 0; probe < MAX_PROBES; ++probe) {
-        SlotT cur = __atomic_load_n(&stab[h], __ATOMIC_RELAXED);
-        if (cur == SEMPTY) {
-            const SlotT old = atomicCAS(&stab[h], SEMPTY, ((SlotT)r << NB) | (SlotT)w);
-            if (old == SEMPTY) return 1;
-            cur = old;
+// ---- top-64 of the candidate buffer without a full block sort (how_many <= 64, the common case) ---------------
+// Every wave bitonic-sorts 64 candidates at a time in registers (cross-lane shuffles, no barriers) and folds them
+// into its running best-64; the 8 per-wave runs are then merged pairwise through LDS (3 barriers).  Order:
+// (key desc, idx asc); padding = (0, EMPTY32), which is worse than any real candidate.
+__device__ __forceinline__ bool cand_better(uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib) { return ka > kb || (ka == kb && ia < ib); }
+__device__ __forceinline__ void wave_merge_clean(uint64_t& k, uint32_t& i, int lane, int from_stride) {   // bitonic -> descending
+#pragma unroll
+    for (int stride = 32; stride > 0; stride >>= 1) {
+        if (stride > from_stride) continue;
+        const uint64_t pk = ((uint64_t)__shfl_xor((uint32_t)(k >> 32), stride, 64) << 32) | __shfl_xor((uint32_t)k, stride, 64);
+        const uint32_t pi = __shfl_xor(i, stride, 64);
+        const bool lower = (lane & stride) == 0;
+        if (cand_better(k, i, pk, pi) != lower) { k = pk; i = pi; }
+    }
+}
+__device__ __forceinline__ void wave_sort_desc(uint64_t& k, uint32_t& i, int lane) {
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const uint64_t pk = ((uint64_t)__shfl_xor((uint32_t)(k >> 32), stride, 64) << 32) | __shfl_xor((uint32_t)k, stride, 64);
+            const uint32_t pi = __shfl_xor(i, stride, 64);
+            const bool keep_better = ((lane & stride) == 0) == ((lane & size) == 0);   // descending sub-block: lower lane keeps the better
+            if (cand_better(k, i, pk, pi) != keep_better) { k = pk; i = pi; }
         }
-        if ((uint32_t)(cur >> NB) == r) { atomicAdd(&stab[h], (SlotT)w); return 0; }
-        h = (h + step) & mask;
+    }
+}
+// fold a descending run (sk, si) into the descending running best (rk, ri): keep the best 64 of the 128
+__device__ __forceinline__ void wave_fold(uint64_t& rk, uint32_t& ri, uint64_t sk, uint32_t si, int lane) {
+    const uint64_t pk = ((uint64_t)__shfl((uint32_t)(sk >> 32), 63 - lane, 64) << 32) | __shfl((uint32_t)sk, 63 - lane, 64);
+    const uint32_t pi = __shfl(si, 63 - lane, 64);
+    if (!cand_better(rk, ri, pk, pi)) { rk = pk; ri = pi; }
+    wave_merge_clean(rk, ri, lane, 32);
+}
+template <int BLOCK>
+__device__ void block_top64(uint64_t* ckey, uint32_t* cidx, uint32_t cnt) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NW = BLOCK / 64;
+    uint64_t rk = 0; uint32_t ri = EMPTY32;
+    bool first = true;
+    for (uint32_t c0 = wave * 64; c0 < cnt; c0 += NW * 64) {   // wave-uniform
+        const uint32_t e = c0 + lane;
+        uint64_t k = e < cnt ? ckey[e] : 0; uint32_t i = e < cnt ? cidx[e] : EMPTY32;
+        wave_sort_desc(k, i, lane);
+        if (first) { rk = k; ri = i; first = false; } else wave_fold(rk, ri, k, i, lane);
+    }
+    __syncthreads();   // every chunk has been read
+    ckey[wave * 64 + lane] = rk; cidx[wave * 64 + lane] = ri;
+    __syncthreads();
+#pragma unroll
+    for (int half = NW / 2; half >= 1; half >>= 1) {
+        if (wave < half) {
+            wave_fold(rk, ri, ckey[(wave + half) * 64 + lane], cidx[(wave + half) * 64 + lane], lane);
+            ckey[wave * 64 + lane] = rk; cidx[wave * 64 + lane] = ri;
+        }
+        __syncthreads();
+    }
+}
+
+// Both LDS tables are bucketized: 4 consecutive slots (16 B) form a bucket that one ds_read_b128 fetches, and
+// double hashing walks buckets.  A wave waits for its unluckiest lane, and the longest of 64 probe sequences at
+// load 0.8 is ~16 single slots but only ~4-5 four-slot buckets.
+//
+// insert-or-add into the packed session table: slot = (rank << NB) | numerator.  Returns 1 if the rank was new,
+// 0 if it existed, -1 if the probe budget ran out (table too full).
+template <typename SlotT>
+__device__ __forceinline__ int sess_insert(SlotT* stab, uint32_t bmask, uint32_t NB, uint32_t r, uint32_t w) {
+    constexpr SlotT SEMPTY = SlotTraits<SlotT>::EMPTY;
+    uint32_t b = hash_start(r, bmask);
+    const uint32_t step = hash_step(r, bmask);
+    for (int probe = 0; probe < MAX_PROBES;) {
+        SlotT c[4];
+        if constexpr (sizeof(SlotT) == 4) { const uint4 v = *reinterpret_cast<const uint4*>(&stab[4 * b]); c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w; }
+        else { const ulonglong2 v0 = *reinterpret_cast<const ulonglong2*>(&stab[4 * b]), v1 = *reinterpret_cast<const ulonglong2*>(&stab[4 * b + 2]);
+               c[0] = v0.x; c[1] = v0.y; c[2] = v1.x; c[3] = v1.y; }
+        int hit = -1, empty = -1;
+#pragma unroll
+        for (int i = 3; i >= 0; --i) { if (c[i] == SEMPTY) empty = i; else if ((uint32_t)(c[i] >> NB) == r) hit = i; }
+        if (hit >= 0) { atomicAdd(&stab[4 * b + hit], (SlotT)w); return 0; }
+        if (empty >= 0) {
+            const SlotT old = atomicCAS(&stab[4 * b + empty], SEMPTY, ((SlotT)r << NB) | (SlotT)w);
+            if (old == SEMPTY) return 1;
+            if ((uint32_t)(old >> NB) == r) { atomicAdd(&stab[4 * b + empty], (SlotT)w); return 0; }
+            continue;   // another rank took that slot meanwhile: look at this bucket again
+        }
+        b = (b + step) & bmask; ++probe;
     }
     return -1;
 }
 // the same for the item table (separate key / accumulator arrays; accumulators are signed)
-__device__ __forceinline__ int item_insert(uint32_t* ikeys, int* iacc, uint32_t mask, uint32_t it, int w) {
-    uint32_t h = hash_start(it, mask);
-    const uint32_t step = hash_step(it, mask);
-    for (int probe = 0; probe < MAX_PROBES; ++probe) {
-        uint32_t cur = __atomic_load_n(&ikeys[h], __ATOMIC_RELAXED);
-        int fresh = 0;
-        if (cur == EMPTY32) {
-            const uint32_t old = atomicCAS(&ikeys[h], EMPTY32, it);
-            if (old == EMPTY32) { cur = it; fresh = 1; } else cur = old;
+__device__ __forceinline__ int item_insert(uint32_t* ikeys, int* iacc, uint32_t bmask, uint32_t it, int w) {
+    uint32_t b = hash_start(it, bmask);
+    const uint32_t step = hash_step(it, bmask);
+    for (int probe = 0; probe < MAX_PROBES;) {
+        const uint4 v = *reinterpret_cast<const uint4*>(&ikeys[4 * b]);
+        const int hit = v.x == it ? 0 : v.y == it ? 1 : v.z == it ? 2 : v.w == it ? 3 : -1;
+        if (hit >= 0) { atomicAdd(&iacc[4 * b + hit], w); return 0; }
+        const int empty = v.x == EMPTY32 ? 0 : v.y == EMPTY32 ? 1 : v.z == EMPTY32 ? 2 : v.w == EMPTY32 ? 3 : -1;
+        if (empty >= 0) {
+            const uint32_t old = atomicCAS(&ikeys[4 * b + empty], EMPTY32, it);
+            if (old == EMPTY32) { atomicAdd(&iacc[4 * b + empty], w); return 1; }
+            if (old == it) { atomicAdd(&iacc[4 * b + empty], w); return 0; }
+            continue;   // another item took that slot meanwhile: look at this bucket again
         }
-        if (cur == it) { atomicAdd(&iacc[h], w); return fresh; }
-        h = (h + step) & mask;
+        b = (b + step) & bmask; ++probe;
     }
     return -1;
 }
@@ -251,7 +324,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
     const OffT* __restrict__ row_off = (const OffT*)ix.row_off;
     const uint32_t NB = c.num_bits;
     const SlotT num_mask = ((SlotT)1 << NB) - 1;
-    const uint32_t smask = c.sess_slots - 1, imask = c.item_slots - 1;
+    const uint32_t smask = c.sess_slots / 4 - 1, imask = c.item_slots / 4 - 1;   // bucket masks (4 slots per bucket)
     const uint32_t nq_eff = qlist ? *qlist_n : p.nq;
 
     for (uint32_t qi = blockIdx.x; qi < nq_eff; qi += gridDim.x) {
@@ -391,6 +464,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
             for (uint32_t i = tid; i < c.item_slots; i += BLOCK) { ikeys[i] = EMPTY32; iacc[i] = 0; }
             if (tid == 0) { misc[S_OVF] = 0; misc[S_ICNT] = 0; }
             phase_sync<GLOBAL_TABLES>();
+            SRN_TICK(8);
             {
                 uint32_t fresh = 0, isum = 0;
                 bool ovf = false;
@@ -404,6 +478,18 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                     const uint32_t j = g0 + lane; num = 0; len = 0; o0 = 0;
                     if (j < K) { const SlotT s = parts == 1 ? nbl[j] : nb_spill[j]; const uint32_t r = (uint32_t)(s >> NB); num = (uint32_t)(s & num_mask);
                                  o0 = row_off[r]; len = (uint32_t)(row_off[r + 1] - o0); } };
+                // The evolving items themselves occur in (almost) every neighbour row -- one LDS address hit by many
+                // lanes of every insert instruction, which serialises.  Positions 0..3 are accumulated in registers
+                // instead and added to the table once per wave.
+                int qacc[4] = {0, 0, 0, 0}; uint32_t qseen = 0;
+                auto accumulate = [&](uint32_t it, int w) {
+                    if (parts > 1 && hash_part(it, parts) != part) return;
+                    if (it == qv0) { qacc[0] += w; qseen |= 1u; return; }
+                    if (it == qv1) { qacc[1] += w; qseen |= 2u; return; }
+                    if (it == qv2) { qacc[2] += w; qseen |= 4u; return; }
+                    if (it == qv3) { qacc[3] += w; qseen |= 8u; return; }
+                    const int res = item_insert(ikeys, iacc, imask, it, w);
+                    if (res < 0) ovf = true; else fresh += (uint32_t)res; };
                 uint32_t num, len, nnum = 0, nlen = 0; OffT o0, no0 = 0;
                 if (wave * 64 < K) load_group(wave * 64, num, len, o0);
                 for (uint32_t g0 = wave * 64; g0 < K; g0 += NWAVES * 64) {
@@ -416,6 +502,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                     const uint32_t T = __shfl(incl, 63, 64);
                     isum += (lane == 0) ? T : 0;
                     wmin[lane] = 0xFFFFu;
+                    SRN_TICK(9);
                     auto owner_of = [&](uint32_t e) -> uint32_t {   // lane whose row holds flattened element e (e < T)
                         uint32_t lo = 0, hi = 63;
 #pragma unroll
@@ -436,6 +523,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                             if (e < T) itc[u] = ix.row_items[(size_t)ob + (e - ex)];
                         }
                     }
+                    SRN_TICK(10);
                     // B1: first-match position of every row (Q4: against the full row)
 #pragma unroll
                     for (int u = 0; u < ROW_CACHE; ++u)
@@ -451,16 +539,13 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                     if (g0 + lane < K && mp == 0xFFFFu) misc[S_ERR] = 1;   // inconsistent index (reference: unwrap panic, mod.rs:138)
                     const int p1 = (int)mp + 1;
                     const int wrow = (p1 < 100 ? 10 - p1 : 0) * (int)num;   // 10 * linear_score(pos) * numerator, exact (Q3)
+                    SRN_TICK(11);
                     // B2: accumulate
 #pragma unroll
                     for (int u = 0; u < ROW_CACHE; ++u) {
                         if ((uint32_t)u * 64 < T) {
                             const int w = __shfl(wrow, (int)((own[u >> 2] >> ((u & 3) * 8)) & 63u), 64);
-                            const uint32_t it = itc[u];
-                            if (it != EMPTY32 && (parts == 1 || hash_part(it, parts) == part)) {
-                                const int res = item_insert(ikeys, iacc, imask, it, w);
-                                if (res < 0) ovf = true; else fresh += (uint32_t)res;
-                            }
+                            if (itc[u] != EMPTY32) accumulate(itc[u], w);
                         }
                     }
                     for (uint32_t base = ROW_CACHE * 64; base < T; base += 64) {
@@ -470,20 +555,25 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                         const OffT ob = (OffT)__shfl(o0, (int)lo, 64);
                         const int w = __shfl(wrow, (int)lo, 64);
                         if (e < T) {
-                            const uint32_t it = ix.row_items[(size_t)ob + (e - ex)];
-                            if (parts == 1 || hash_part(it, parts) == part) {
-                                const int res = item_insert(ikeys, iacc, imask, it, w);
-                                if (res < 0) ovf = true; else fresh += (uint32_t)res;
-                            }
+                            accumulate(ix.row_items[(size_t)ob + (e - ex)], w);
                         }
                     }
                     num = nnum; len = nlen; o0 = no0;
+                    SRN_TICK(12);
+                }
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {   // flush the evolving items' private accumulators: one insert per wave
+                    const unsigned long long seen = __ballot((qseen >> pp) & 1u);
+                    const int tot = (int)wave_sum((uint32_t)qacc[pp]);
+                    if (seen && lane == 0) { const int res = item_insert(ikeys, iacc, imask, pp == 0 ? qv0 : pp == 1 ? qv1 : pp == 2 ? qv2 : qv3, tot);
+                                             if (res < 0) ovf = true; else fresh += (uint32_t)res; }
                 }
                 fresh = wave_sum(fresh);
                 if (lane == 0) { if (fresh) atomicAdd((uint32_t*)&misc[S_ICNT], fresh); if (p.stats && part == 0 && isum) atomicAdd((uint32_t*)&misc[S_I], isum); }
                 if (ovf) misc[S_OVF] = 1;
             }
             phase_sync<GLOBAL_TABLES>();
+            SRN_TICK(13);
             if (misc[S_OVF]) {   // block-uniform: split the item space finer and start the accumulation over
                 __syncthreads();
                 if (parts >= MAX_ITEM_PASSES || GLOBAL_TABLES || !nb_spill) { failed = true; break; }
@@ -494,12 +584,12 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                 continue;
             }
             d_total += misc[S_ICNT];
-            SRN_TICK(5);
 
             // ---- phase 4: scores, business rules, top-n (per partition, one running candidate set) ----
-            // Chunks of BLOCK slots; the first chunk is a sample whose n-th best score becomes a threshold,
-            // later chunks are taken 4 at a time without barriers and only candidates beating the threshold
-            // are appended.  If the buffer would overflow the round is redone chunk by chunk (exact).
+            // Chunks of BLOCK slots; the first chunk is a sample whose n-th best score becomes a threshold, then all
+            // the other chunks are swept in one barrier-free round (4 chunks' gathers in flight at a time) and only
+            // candidates beating the threshold are appended.  If the buffer would overflow, the round is redone
+            // chunk by chunk with a prune whenever needed (exact).
             {
                 const uint32_t n_chunks = (c.item_slots + BLOCK - 1) / BLOCK;
                 uint32_t u = 0, ru = 1;
@@ -514,12 +604,13 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                     // gather first (up to 4 chunks' idf loads in flight per lane), then score + append.  Once the
                     // threshold score is positive, an item whose upper bound idf_hi * acc / denom (same operations and
                     // rounding as the score, so monotone and safe) is below it is dropped without touching idf[].
+                    for (uint32_t ub = u; ub < u_end; ub += 4) {   // sub-batches of 4 chunks, no barrier in between
                     uint32_t its[4]; int accs[4]; double idfs[4];
 #pragma unroll
                     for (int x = 0; x < 4; ++x) {
                         its[x] = EMPTY32; accs[x] = 0; idfs[x] = 0.0;
-                        const uint32_t i = (u + x) * BLOCK + tid;
-                        if (u + x < u_end && i < c.item_slots) {
+                        const uint32_t i = (ub + x) * BLOCK + tid;
+                        if (ub + x < u_end && i < c.item_slots) {
                             const uint32_t it = ikeys[i];
                             if (it != EMPTY32 && it != cur_idx && (!business || business_ok(cur_attr, ix.attr[it]))) {   // Q6 + rules
                                 const int acc = iacc[i];
@@ -531,7 +622,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                     }
 #pragma unroll
                     for (int x = 0; x < 4; ++x) {
-                        if (u + x < u_end) {   // block-uniform
+                        if (ub + x < u_end) {   // block-uniform
                             const uint32_t it = its[x];
                             bool take = false; uint64_t sk = 0;
                             if (it != EMPTY32) {
@@ -541,6 +632,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                             const uint32_t at = wave_append(take, (uint32_t*)&misc[S_CCNT]);
                             if (take) { if (at < CAND_CAP) { ckey[at] = sk; cidx[at] = it; } else misc[S_COVF] = 1; }
                         }
+                    }
                     }
                     __syncthreads();
                     if (misc[S_COVF]) {   // block-uniform: too many survivors for one optimistic round
@@ -557,18 +649,22 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                     // also sort once as soon as n candidates exist, to get a threshold
                     const bool must_prune = cnt + BLOCK > CAND_CAP || (!have_t && cnt >= n_out && cnt > 1);
                     if ((must_prune && !last) || (last && cnt > 1)) {
-                        uint32_t n2 = 2; while (n2 < cnt) n2 <<= 1;
-                        for (uint32_t t = cnt + tid; t < n2; t += BLOCK) { ckey[t] = 0; cidx[t] = EMPTY32; }
-                        __syncthreads();
-                        block_sort_candidates<BLOCK>(ckey, cidx, n2);
+                        if (n_out <= 64) block_top64<BLOCK>(ckey, cidx, cnt);   // leaves the best min(cnt, 64) sorted at the front
+                        else {
+                            uint32_t n2 = 2; while (n2 < cnt) n2 <<= 1;
+                            for (uint32_t t = cnt + tid; t < n2; t += BLOCK) { ckey[t] = 0; cidx[t] = EMPTY32; }
+                            __syncthreads();
+                            block_sort_candidates<BLOCK>(ckey, cidx, n2);
+                        }
                         if (tid == 0 && cnt >= n_out) {
                             misc[S_CCNT] = n_out; misc[S_HAVE_T] = 1; misc[S_TIDX] = cidx[n_out - 1];
                             misc[S_TKEY_LO] = (uint32_t)ckey[n_out - 1]; misc[S_TKEY_HI] = (uint32_t)(ckey[n_out - 1] >> 32);
                         }
                         __syncthreads();
                     }
-                    // optimistic 4-chunk rounds once a threshold exists and the buffer is at most half full
-                    ru = (misc[S_HAVE_T] && misc[S_CCNT] * 2 <= CAND_CAP) ? 4u : 1u;
+                    // once a threshold exists and the buffer is at most half full: ONE optimistic round over all the
+                    // remaining chunks (a round that overflows the buffer is redone chunk by chunk, see above)
+                    ru = (misc[S_HAVE_T] && misc[S_CCNT] * 2 <= CAND_CAP) ? n_chunks : 1u;
                 }
             }
             SRN_TICK(6);

@@ -12,13 +12,16 @@ ix = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw, device=0)
 qi, qo = synth.queries(int(B / 3) + 2048, n_items, seed=synth.SEED + 7919)
 qi, qo = qi[:qo[B]], qo[:B + 1]
 print("cpus", os.cpu_count(), len(os.sched_getaffinity(0)), open("/sys/fs/cgroup/cpu.max").read().strip() if os.path.exists("/sys/fs/cgroup/cpu.max") else "no cgroup cpu.max")
+import serenade_amd.capi as capi
+FL = int(os.environ.get("SRN_FL", "0"), 0)
+capi.FLAG_BUSINESS_LOGIC = FL
 for rep in range(2):
-    sa.predict_batch(ix, (qi, qo), k, m, 21)
+    sa.predict_batch(ix, (qi, qo), k, m, 21, bool(FL))
 ix.debug_phase_cycles(True)
-t0 = time.time(); r = sa.predict_batch_debug(ix, (qi, qo), k, m, 21, neighbours=False); dt = time.time() - t0
+t0 = time.time(); r = sa.predict_batch_debug(ix, (qi, qo), k, m, 21, bool(FL), neighbours=False); dt = time.time() - t0
 cyc = ix.debug_phase_cycles(False).astype(np.float64)
 ms, msr, _ = ix.last_kernel_ms()
-names = ["0 prep+clear", "1 postings->sess", "2 m-cut select", "3 k-cut select", "4 compact+clear", "5 rows->items", "6 score+topn"]
+names = ["0 prep+clear", "1 postings->sess", "2 m-cut select", "3 k-cut select", "4 compact+clear", "5 (unused)", "6 score+topn", "7", "8 p5 clear+sync", "9 p5 group load+scan", "10 p5 gather", "11 p5 B1", "12 p5 B2", "13 p5 flush+wait", "14", "15"]
 print("main %.2f ms retry %.2f ms  total cycles %.3g" % (ms, msr, cyc.sum()))
 for n, c in zip(names, cyc):
     print("  %-18s %6.2f%%  %.0f cyc/query" % (n, 100 * c / cyc.sum(), c / B))
