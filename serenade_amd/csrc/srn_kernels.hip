@@ -111,9 +111,15 @@ __device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
 
 // -------------------------------------------------------------------------------------
 // r-th largest key among the valid entries of `n` slots (keys distinct and < 2^nbits, 1 <= r <= #valid):
-// MSD radix select, 8 bits per pass starting at the top SIGNIFICANT bit (so the first histogram is not
-// degenerate), histogram in LDS.  keyfn(i, key&) -> valid.
+// MSD radix select, 11 bits per pass starting at the top SIGNIFICANT bit (so the first histogram is not
+// degenerate), 2048-bin histogram in LDS.  `hist` must be all zero on entry and is all zero on return
+// (the digit search clears the bins it reads), so a pass costs two barriers.  keyfn(i, key&) -> valid.
 // -------------------------------------------------------------------------------------
+static constexpr int SEL_BITS = 11, SEL_BINS = 1 << SEL_BITS;
+// bin b lives at word b + (b >> 5): the digit search gives every lane 32 consecutive bins, and without the
+// one-word skew all 64 lanes would read the same LDS bank (64-way conflict on each of the 32 reads)
+static constexpr int SEL_WORDS = SEL_BINS + SEL_BINS / 32;
+__device__ __forceinline__ uint32_t sel_word(uint32_t bin) { return bin + (bin >> 5); }
 template <int BLOCK, typename KeyT, typename F>
 __device__ KeyT block_select_desc(F keyfn, uint32_t n, int nbits, uint32_t r, uint32_t* hist, volatile uint32_t* misc) {
     const int tid = threadIdx.x;
@@ -121,28 +127,36 @@ __device__ KeyT block_select_desc(F keyfn, uint32_t n, int nbits, uint32_t r, ui
     uint32_t remain = r;
     int rem = nbits;
     while (rem > 0) {
-        const int w = rem < 8 ? rem : 8, shift = rem - w;
-        for (int i = tid; i < 256; i += BLOCK) hist[i] = 0;
-        __syncthreads();
-        for (uint32_t i = tid; i < n; i += BLOCK) {
-            KeyT key;
-            if (keyfn(i, key)) {
-                const KeyT above = rem >= (int)(8 * sizeof(KeyT)) ? (KeyT)0 : (KeyT)(key >> rem);
-                if (above == prefix) atomicAdd(&hist[(uint32_t)(key >> shift) & ((1u << w) - 1u)], 1u);
+        const int w = rem < SEL_BITS ? rem : SEL_BITS, shift = rem - w;
+        for (uint32_t i0 = tid; i0 < n; i0 += 8 * BLOCK) {   // a wave is LDS-latency bound: 8 independent reads per wait
+            KeyT key[8]; bool ok[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const uint32_t i = i0 + u * BLOCK; key[u] = 0; ok[u] = i < n && keyfn(i, key[u]); }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const KeyT above = rem >= (int)(8 * sizeof(KeyT)) ? (KeyT)0 : (KeyT)(key[u] >> rem);
+                if (ok[u] && above == prefix) atomicAdd(&hist[sel_word((uint32_t)(key[u] >> shift) & ((1u << w) - 1u))], 1u);
             }
         }
         __syncthreads();
-        if (tid < 64) {
-            const uint32_t c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
-            const uint32_t s = c0 + c1 + c2 + c3;
+        if (tid < 64) {   // lane owns bins [32 lane, 32 lane + 32); suffix sums from the top bin down
+            constexpr int PER = SEL_BINS / 64;
+            uint32_t c[PER], s = 0;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) { c[j] = hist[sel_word(PER * tid + j)]; s += c[j]; }
+#pragma unroll
+            for (int j = 0; j < PER; ++j) hist[sel_word(PER * tid + j)] = 0;
             uint32_t inc = s;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_down(inc, d, 64); if (tid + d < 64) inc += t; }
-            const uint32_t a3 = inc - s, a2 = a3 + c3, a1 = a2 + c2, a0 = a1 + c1;
-            if (a3 < remain && remain <= a3 + c3) { misc[S_SELD] = 4 * tid + 3; misc[S_SELR] = remain - a3; }
-            if (a2 < remain && remain <= a2 + c2) { misc[S_SELD] = 4 * tid + 2; misc[S_SELR] = remain - a2; }
-            if (a1 < remain && remain <= a1 + c1) { misc[S_SELD] = 4 * tid + 1; misc[S_SELR] = remain - a1; }
-            if (a0 < remain && remain <= a0 + c0) { misc[S_SELD] = 4 * tid + 0; misc[S_SELR] = remain - a0; }
+            uint32_t above = inc - s;   // entries in bins owned by higher lanes
+            if (above < remain && remain <= above + s) {   // the target bin is one of mine
+#pragma unroll
+                for (int j = PER - 1; j >= 0; --j) {
+                    if (above < remain && remain <= above + c[j]) { misc[S_SELD] = PER * tid + j; misc[S_SELR] = remain - above; }
+                    above += c[j];
+                }
+            }
         }
         __syncthreads();
         prefix = (KeyT)((prefix << w) | (KeyT)misc[S_SELD]);
@@ -303,7 +317,6 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
 
     // ---- LDS carve-up ------------------------------------------------------------------
     volatile uint32_t* misc = (volatile uint32_t*)smem;                       // MISC_WORDS
-    uint32_t* hist = (uint32_t*)(smem + MISC_WORDS * 4);                      // 256
     uint64_t* q_raw = (uint64_t*)(smem + c.off_q);                            // q_cap   raw ids, pos 0 = most recent
     unsigned long long* l_base = (unsigned long long*)(q_raw + c.q_cap);      // q_cap   posting list start
     uint32_t* q_idx = (uint32_t*)(l_base + c.q_cap);                          // q_cap   dense idx or kNone
@@ -311,6 +324,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
     uint32_t* l_pre = l_len + c.q_cap;                                        // q_cap+4 exclusive prefix of l_len
     uint32_t* wmin = (uint32_t*)(smem + c.off_wave) + wave * 64;              // per-wave first-match scratch
     char* region_b = smem + c.off_b;
+    uint32_t* hist = (uint32_t*)region_b;                                     // 2048-bin select histogram (phase 2 only)
     char* region_a = GLOBAL_TABLES ? (gscratch + (size_t)blockIdx.x * gscratch_stride) : (smem + c.off_a);
 
     SlotT* stab = (SlotT*)region_a;                                           // phase 1-2
@@ -324,7 +338,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
     const OffT* __restrict__ row_off = (const OffT*)ix.row_off;
     const uint32_t NB = c.num_bits;
     const SlotT num_mask = ((SlotT)1 << NB) - 1;
-    const uint32_t smask = c.sess_slots / 4 - 1, imask = c.item_slots / 4 - 1;   // bucket masks (4 slots per bucket)
+    const uint32_t imask = c.item_slots / 4 - 1;   // bucket mask (4 slots per bucket)
     const uint32_t nq_eff = qlist ? *qlist_n : p.nq;
 
     for (uint32_t qi = blockIdx.x; qi < nq_eff; qi += gridDim.x) {
@@ -341,7 +355,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
         __syncthreads();   // previous query's LDS reads are done
         long long t_prev = p.phase_cycles ? clock64() : 0;
         if (tid < MISC_WORDS) misc[tid] = 0;
-        for (uint32_t i = tid; i < c.sess_slots; i += BLOCK) stab[i] = SEMPTY;
+        for (uint32_t i = tid; i < SEL_WORDS; i += BLOCK) hist[i] = 0;
         for (uint32_t i = tid; i < L; i += BLOCK) q_raw[i] = p.items_flat[qb + (L - 1 - i)];   // pos 0 = most recent item
         __syncthreads();
         for (uint32_t pos = tid; pos < L; pos += BLOCK) {
@@ -371,6 +385,11 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
         phase_sync<GLOBAL_TABLES>();
         const uint32_t x_lo = misc[S_XLO], r_max = misc[S_RMAX], U = misc[S_U], P = misc[S_P];
         const uint32_t cur_idx = q_idx[0];
+        // session table sized to this query: at most P entries are inserted, keep the load <= 2/3
+        uint32_t sslots = 256; while (sslots < c.sess_slots && sslots * 2 < P * 3) sslots <<= 1;
+        const uint32_t smask = sslots / 4 - 1;   // bucket mask (4 slots per bucket)
+        for (uint32_t i = tid; i < sslots; i += BLOCK) stab[i] = SEMPTY;
+        phase_sync<GLOBAL_TABLES>();
         SRN_TICK(0);
 
         // ---- phase 1: posting lists -> session table -------------------------------------
@@ -419,7 +438,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
         if (Call > p.m) {
             tau = x_lo + block_select_desc<BLOCK, uint32_t>(
                 [&](uint32_t i, uint32_t& key) { const SlotT s = stab[i]; key = (uint32_t)(s >> NB) - x_lo; return s != SEMPTY; },
-                c.sess_slots, bits_for(r_max - x_lo), p.m, hist, misc);
+                sslots, bits_for(r_max - x_lo), p.m, hist, misc);
         }
         SRN_TICK(2);
         const int rbits = bits_for(r_max - tau);
@@ -430,18 +449,31 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                 const SlotT s = stab[i]; const uint32_t r = (uint32_t)(s >> NB);
                 key = ((decltype(key + 0))(s & num_mask) << rbits) | (r - tau);
                 return s != SEMPTY && r >= tau; };
-            if (nbits <= 32) kappa = block_select_desc<BLOCK, uint32_t>(comp, c.sess_slots, nbits, p.k, hist, misc);
-            else kappa = block_select_desc<BLOCK, unsigned long long>(comp, c.sess_slots, nbits, p.k, hist, misc);
+            if (nbits <= 32) kappa = block_select_desc<BLOCK, uint32_t>(comp, sslots, nbits, p.k, hist, misc);
+            else kappa = block_select_desc<BLOCK, unsigned long long>(comp, sslots, nbits, p.k, hist, misc);
         }
         SRN_TICK(3);
-        for (uint32_t i0 = 0; i0 < c.sess_slots; i0 += BLOCK) {   // sess_slots is a multiple of BLOCK or smaller than it
-            const uint32_t i = i0 + tid;
-            SlotT s = SEMPTY; uint32_t r = 0; bool sel = false;
-            if (i < c.sess_slots) { s = stab[i]; r = (uint32_t)(s >> NB);
-                sel = s != SEMPTY && r >= tau && ((((unsigned long long)(s & num_mask)) << rbits) | (r - tau)) >= kappa; }
-            const uint32_t at = wave_append(sel, (uint32_t*)&misc[S_NB]);
-            if (sel) { nbl[at] = s;
-                if (p.nb_rank) { p.nb_rank[(size_t)q * p.k + at] = r; p.nb_num[(size_t)q * p.k + at] = (uint32_t)(s & num_mask); } }
+        for (uint32_t i0 = 0; i0 < sslots; i0 += 8 * BLOCK) {
+            SlotT sv[8]; unsigned long long bm[8]; uint32_t total = 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const uint32_t i = i0 + u * BLOCK + tid; sv[u] = i < sslots ? stab[i] : SEMPTY; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t r = (uint32_t)(sv[u] >> NB);
+                const bool sel = sv[u] != SEMPTY && r >= tau && ((((unsigned long long)(sv[u] & num_mask)) << rbits) | (r - tau)) >= kappa;
+                bm[u] = __ballot(sel); total += (uint32_t)__popcll(bm[u]);
+            }
+            uint32_t base = 0;
+            if (total) { if (lane == 0) base = atomicAdd((uint32_t*)&misc[S_NB], total); base = __shfl(base, 0, 64); }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if ((bm[u] >> lane) & 1ull) {
+                    const uint32_t at = base + (uint32_t)__popcll(bm[u] & ((1ull << lane) - 1ull));
+                    nbl[at] = sv[u];
+                    if (p.nb_rank) { p.nb_rank[(size_t)q * p.k + at] = (uint32_t)(sv[u] >> NB); p.nb_num[(size_t)q * p.k + at] = (uint32_t)(sv[u] & num_mask); }
+                }
+                base += (uint32_t)__popcll(bm[u]);
+            }
         }
         __syncthreads();
         const uint32_t K = misc[S_NB];
@@ -880,7 +912,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     const uint32_t a_max = budget - c.off_a;
     c.item_slots = std::min<uint32_t>(floor_pow2(a_max / 8), (uint32_t)std::min<uint64_t>(1u << 30, ceil_pow2(need_item * 2)));
     c.sess_slots = std::min<uint32_t>(floor_pow2(a_max / slot_bytes), (uint32_t)std::min<uint64_t>(1u << 30, ceil_pow2(need_sess * 2)));
-    c.item_slots = std::max<uint32_t>(c.item_slots, 64); c.sess_slots = std::max<uint32_t>(c.sess_slots, 64);
+    c.item_slots = std::max<uint32_t>(c.item_slots, 256); c.sess_slots = std::max<uint32_t>(c.sess_slots, 256);
     const uint32_t region_a = std::max<uint32_t>(c.item_slots * 8, c.sess_slots * slot_bytes);
     const size_t lds = (size_t)c.off_a + region_a;
     // tables at least twice the worst case cannot exhaust the probe budget: no retry machinery needed
@@ -914,8 +946,8 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     if (may_overflow) {
         if (w->retry_cap < p.nq) { if (w->retry_list) HIP_TRY(hipFree(w->retry_list)); w->retry_list = nullptr; w->retry_cap = 0;
             HIP_TRY(hipMalloc((void**)&w->retry_list, (size_t)p.nq * 4 + 64)); w->retry_cap = p.nq; }
-        cg.sess_slots = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(64, ceil_pow2(need_sess * 2)));
-        cg.item_slots = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(64, ceil_pow2(need_item * 2)));
+        cg.sess_slots = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(256, ceil_pow2(need_sess * 2)));
+        cg.item_slots = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(256, ceil_pow2(need_item * 2)));
         g_stride = std::max<uint64_t>((uint64_t)cg.sess_slots * slot_bytes, (uint64_t)cg.item_slots * 8);
         g_stride = (g_stride + 255) / 256 * 256;
         retry_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)d->n_cu, (2ull << 30) / g_stride));
