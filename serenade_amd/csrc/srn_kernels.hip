@@ -45,7 +45,7 @@ static constexpr int CAND_CAP = 1024;       // candidate buffer of the final top
 static constexpr int MISC_WORDS = 64;       // scalar words at the head of LDS
 static constexpr int MAX_PROBES = 48;       // bucket probes (4 slots each) before a table is declared full
 static constexpr int MAX_ITEM_PASSES = 64;
-static constexpr int ROW_CACHE = 8;         // row elements per lane kept in registers per 64-row group (covers 1024 elements)  // item-space partition passes before giving up on the LDS table
+static constexpr int ROW_CACHE = 4;  // row elements per lane kept in registers per 64-row group (covers 1024 elements)  // item-space partition passes before giving up on the LDS table
 
 // launch-time geometry, identical for every block of a launch (all LDS offsets multiples of 16)
 struct KernelCfg {
@@ -510,16 +510,8 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                     const uint32_t j = g0 + lane; num = 0; len = 0; o0 = 0;
                     if (j < K) { const SlotT s = parts == 1 ? nbl[j] : nb_spill[j]; const uint32_t r = (uint32_t)(s >> NB); num = (uint32_t)(s & num_mask);
                                  o0 = row_off[r]; len = (uint32_t)(row_off[r + 1] - o0); } };
-                // The evolving items themselves occur in (almost) every neighbour row -- one LDS address hit by many
-                // lanes of every insert instruction, which serialises.  Positions 0..3 are accumulated in registers
-                // instead and added to the table once per wave.
-                int qacc[4] = {0, 0, 0, 0}; uint32_t qseen = 0;
                 auto accumulate = [&](uint32_t it, int w) {
                     if (parts > 1 && hash_part(it, parts) != part) return;
-                    if (it == qv0) { qacc[0] += w; qseen |= 1u; return; }
-                    if (it == qv1) { qacc[1] += w; qseen |= 2u; return; }
-                    if (it == qv2) { qacc[2] += w; qseen |= 4u; return; }
-                    if (it == qv3) { qacc[3] += w; qseen |= 8u; return; }
                     const int res = item_insert(ikeys, iacc, imask, it, w);
                     if (res < 0) ovf = true; else fresh += (uint32_t)res; };
                 uint32_t num, len, nnum = 0, nlen = 0; OffT o0, no0 = 0;
@@ -541,64 +533,48 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                         for (int sd = 0; sd < 6; ++sd) { const uint32_t mid = (lo + hi) >> 1; const uint32_t v = __shfl(incl, (int)mid, 64);
                                                           if (v > e) hi = mid; else lo = mid + 1; }
                         return lo & 63u; };
-                    // gather: all of the group's row elements are requested before any is consumed
+                    // The group's row elements are handled in batches of ROW_CACHE*64: all loads of a batch are requested
+                    // before any is consumed (one memory latency per batch, not per element).  B1 runs over every batch,
+                    // then B2; the last batch is still in registers for B2, earlier ones (only when the group holds more
+                    // than one batch of elements) are gathered again, from L1/L2 by then.
+                    constexpr uint32_t BATCH = ROW_CACHE * 64;
                     uint32_t itc[ROW_CACHE], own[ROW_CACHE / 4];   // owner lanes packed 4 x 8 bit
+                    auto gather = [&](uint32_t base0) {
 #pragma unroll
-                    for (int u = 0; u < ROW_CACHE; ++u) {
-                        itc[u] = EMPTY32; if ((u & 3) == 0) own[u >> 2] = 0;
-                        if ((uint32_t)u * 64 < T) {   // wave-uniform
-                            const uint32_t e = u * 64 + lane;
-                            const uint32_t lo = owner_of(e);
-                            const uint32_t ex = __shfl(excl, (int)lo, 64);
-                            const OffT ob = (OffT)__shfl(o0, (int)lo, 64);
-                            own[u >> 2] |= lo << ((u & 3) * 8);
-                            if (e < T) itc[u] = ix.row_items[(size_t)ob + (e - ex)];
-                        }
-                    }
+                        for (int u = 0; u < ROW_CACHE; ++u) {
+                            itc[u] = EMPTY32; if ((u & 3) == 0) own[u >> 2] = 0;
+                            if (base0 + (uint32_t)u * 64 < T) {   // wave-uniform
+                                const uint32_t e = base0 + u * 64 + lane;
+                                const uint32_t lo = owner_of(e);
+                                const uint32_t ex = __shfl(excl, (int)lo, 64);
+                                const OffT ob = (OffT)__shfl(o0, (int)lo, 64);
+                                own[u >> 2] |= lo << ((u & 3) * 8);
+                                if (e < T) itc[u] = ix.row_items[(size_t)ob + (e - ex)];
+                            }
+                        } };
+                    const uint32_t nbat = (T + BATCH - 1) / BATCH;
                     SRN_TICK(10);
-                    // B1: first-match position of every row (Q4: against the full row)
+                    // steps 0..nbat-1: B1 (first-match position of every row, Q4: against the full row) on batch `step`;
+                    // then the row weights; steps nbat..2 nbat-1: B2 (accumulate), starting with the batch still cached
+                    int wrow = 0;
+                    for (uint32_t step = 0; step < 2 * nbat; ++step) {
+                        const bool b2 = step >= nbat;
+                        if (step == nbat) {
+                            const uint32_t mp = wmin[lane];
+                            if (g0 + lane < K && mp == 0xFFFFu) misc[S_ERR] = 1;   // inconsistent index (reference: unwrap panic, mod.rs:138)
+                            const int p1 = (int)mp + 1;
+                            wrow = (p1 < 100 ? 10 - p1 : 0) * (int)num;            // 10 * linear_score(pos) * numerator, exact (Q3)
+                            SRN_TICK(11);
+                        } else gather((b2 ? step - nbat - 1 : step) * BATCH);
 #pragma unroll
-                    for (int u = 0; u < ROW_CACHE; ++u)
-                        if ((uint32_t)u * 64 < T && itc[u] != EMPTY32) { const uint32_t mp = match_pos(itc[u]); if (mp != 0xFFFFu) atomicMin(&wmin[(own[u >> 2] >> ((u & 3) * 8)) & 63u], mp); }
-                    for (uint32_t base = ROW_CACHE * 64; base < T; base += 64) {   // rows longer than the register cache
-                        const uint32_t e = base + lane;
-                        const uint32_t lo = owner_of(e);
-                        const uint32_t ex = __shfl(excl, (int)lo, 64);
-                        const OffT ob = (OffT)__shfl(o0, (int)lo, 64);
-                        if (e < T) { const uint32_t mp = match_pos(ix.row_items[(size_t)ob + (e - ex)]); if (mp != 0xFFFFu) atomicMin(&wmin[lo], mp); }
-                    }
-                    const uint32_t mp = wmin[lane];
-                    if (g0 + lane < K && mp == 0xFFFFu) misc[S_ERR] = 1;   // inconsistent index (reference: unwrap panic, mod.rs:138)
-                    const int p1 = (int)mp + 1;
-                    const int wrow = (p1 < 100 ? 10 - p1 : 0) * (int)num;   // 10 * linear_score(pos) * numerator, exact (Q3)
-                    SRN_TICK(11);
-                    // B2: accumulate
-#pragma unroll
-                    for (int u = 0; u < ROW_CACHE; ++u) {
-                        if ((uint32_t)u * 64 < T) {
-                            const int w = __shfl(wrow, (int)((own[u >> 2] >> ((u & 3) * 8)) & 63u), 64);
-                            if (itc[u] != EMPTY32) accumulate(itc[u], w);
-                        }
-                    }
-                    for (uint32_t base = ROW_CACHE * 64; base < T; base += 64) {
-                        const uint32_t e = base + lane;
-                        const uint32_t lo = owner_of(e);
-                        const uint32_t ex = __shfl(excl, (int)lo, 64);
-                        const OffT ob = (OffT)__shfl(o0, (int)lo, 64);
-                        const int w = __shfl(wrow, (int)lo, 64);
-                        if (e < T) {
-                            accumulate(ix.row_items[(size_t)ob + (e - ex)], w);
+                        for (int u = 0; u < ROW_CACHE; ++u) {
+                            const uint32_t owner = (own[u >> 2] >> ((u & 3) * 8)) & 63u;
+                            if (!b2) { if (itc[u] != EMPTY32) { const uint32_t mp = match_pos(itc[u]); if (mp != 0xFFFFu) atomicMin(&wmin[owner], mp); } }
+                            else { const int w = __shfl(wrow, (int)owner, 64); if (itc[u] != EMPTY32) accumulate(itc[u], w); }
                         }
                     }
                     num = nnum; len = nlen; o0 = no0;
                     SRN_TICK(12);
-                }
-#pragma unroll
-                for (int pp = 0; pp < 4; ++pp) {   // flush the evolving items' private accumulators: one insert per wave
-                    const unsigned long long seen = __ballot((qseen >> pp) & 1u);
-                    const int tot = (int)wave_sum((uint32_t)qacc[pp]);
-                    if (seen && lane == 0) { const int res = item_insert(ikeys, iacc, imask, pp == 0 ? qv0 : pp == 1 ? qv1 : pp == 2 ? qv2 : qv3, tot);
-                                             if (res < 0) ovf = true; else fresh += (uint32_t)res; }
                 }
                 fresh = wave_sum(fresh);
                 if (lane == 0) { if (fresh) atomicAdd((uint32_t*)&misc[S_ICNT], fresh); if (p.stats && part == 0 && isum) atomicAdd((uint32_t*)&misc[S_I], isum); }
@@ -631,6 +607,9 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                     const uint64_t tk = ((uint64_t)misc[S_TKEY_HI] << 32) | misc[S_TKEY_LO];
                     const uint32_t tix = misc[S_TIDX];
                     const bool t_pos = have_t && tk > 0x8000000000000000ull;   // threshold score > 0: non-positive accumulators cannot make it
+                    // smallest accumulator that could still reach the threshold: score <= idf_hi * acc / denom, so an item needs
+                    // acc >= thr * denom / idf_hi; shaved by a relative 1e-9 and one unit so that rounding can only keep more
+                    const int acc_floor = t_pos ? (int)fmin(2147483000.0, fmax(1.0, floor(key_score(tk) * denom / ix.idf_hi * (1.0 - 1e-9)) - 1.0)) : 0;
                     const uint32_t u_end = min(u + ru, n_chunks);
                     __syncthreads();   // every wave has read the round's state before any wave appends (and moves S_CCNT)
                     // gather first (up to 4 chunks' idf loads in flight per lane), then score + append.  Once the
@@ -646,8 +625,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                             const uint32_t it = ikeys[i];
                             if (it != EMPTY32 && it != cur_idx && (!business || business_ok(cur_attr, ix.attr[it]))) {   // Q6 + rules
                                 const int acc = iacc[i];
-                                const uint64_t ubk = score_key(ix.idf_hi * (double)acc / denom);
-                                const bool hopeless = t_pos & ((acc <= 0) | (ubk < tk));   // branch-free on purpose
+                                const bool hopeless = t_pos & (acc < acc_floor);   // branch-free on purpose (see DESIGN.md hazards)
                                 if (!hopeless) { its[x] = it; accs[x] = acc; idfs[x] = ix.idf[it]; }
                             }
                         }
