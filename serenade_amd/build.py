@@ -42,9 +42,23 @@ def build_synth(force=False):
     return SYNTH_LIB
 
 
+EVALUATOR = os.path.join(HERE, "bin", "evaluator")
+
+
+def build_evaluator(force=False):
+    """Host program over the C ABI (mirror of the reference's evaluator / evaluate_file binaries)."""
+    src = os.path.join(CSRC, "host", "evaluator.cpp")
+    if force or _stale(EVALUATOR, [src, LIB]):
+        os.makedirs(os.path.dirname(EVALUATOR), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", EVALUATOR, src, "-L" + HERE, "-lserenade_hip",
+                               "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"])
+    return EVALUATOR
+
+
 def build_all(force=False, verbose=False):
     build_hip(force, verbose)
     build_synth(force)
+    build_evaluator(force)
 
 
 if __name__ == "__main__":

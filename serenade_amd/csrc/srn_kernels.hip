@@ -658,6 +658,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                     // before a single-chunk round the buffer must have room for BLOCK appends (exact path);
                     // also sort once as soon as n candidates exist, to get a threshold
                     const bool must_prune = cnt + BLOCK > CAND_CAP || (!have_t && cnt >= n_out && cnt > 1);
+                    SRN_TICK(14);
                     if ((must_prune && !last) || (last && cnt > 1)) {
                         if (n_out <= 64) block_top64<BLOCK>(ckey, cidx, cnt);   // leaves the best min(cnt, 64) sorted at the front
                         else {
@@ -672,6 +673,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                         }
                         __syncthreads();
                     }
+                    SRN_TICK(15);
                     // once a threshold exists and the buffer is at most half full: ONE optimistic round over all the
                     // remaining chunks (a round that overflows the buffer is redone chunk by chunk, see above)
                     ru = (misc[S_HAVE_T] && misc[S_CCNT] * 2 <= CAND_CAP) ? n_chunks : 1u;

@@ -31,6 +31,9 @@ def main():
     lens = np.diff(off.astype(np.int64))
     max_len = int(round(float(np.quantile(lens, 0.995))))
     out = dict(sess_off=off.astype(np.uint32), items=items.astype(np.uint32), ts=ts)
+    # raw rows of test.txt (session, item, rounded time) so that the evaluator binary can be run on the GPU box
+    rows = [l.split() for l in open(os.path.join(d, "test.txt")).read().splitlines()[1:]]
+    out["test_rows"] = np.array([(int(a), int(b), round(float(c))) for a, b, c in rows], np.int64)
     for tag, (m, k, last, n, idfw) in dict(a=(1502, 288, 4, 21, 1.0), b=(500, 50, 2, 21, 1.0)).items():
         qs = evaluator_queries(test, last)
         flat, qoff = flatten([q for q, _ in qs])

@@ -197,3 +197,41 @@ def test_device_pointer_entry_point_matches_host_entry_point():
         c = int(cnt_h[q])
         assert np.array_equal(ids_d[q, :c], ids_h[q, :c])
         assert np.array_equal(sc_d[q, :c], sc_h[q, :c])
+
+
+def test_evaluator_binary_on_reference_example(tmp_path):
+    """The drop-in `evaluator <config.toml>` host program (mirror of src/bin/evaluator.rs) on the reference's example data,
+    rebuilt from the golden fixture: 931 evaluations, HitRate@20 0.6402, the README's metric line (README.md:170-172)."""
+    import os
+    import subprocess
+    from helpers import GOLDEN
+    from serenade_amd import build
+    g = np.load(os.path.join(GOLDEN, "example_golden.npz"))
+    off, items, ts = g["sess_off"].astype(np.int64), g["items"], g["ts"]
+    with open(tmp_path / "train.txt", "w") as f:
+        f.write("SessionId\tItemId\tTime\n")
+        for s in range(len(ts)):
+            for it in items[off[s]:off[s + 1]]:
+                f.write("%d\t%d\t%d.0\n" % (s + 1, it, ts[s]))
+        f.write("%d\t1\t1.0\n" % (len(ts) + 1))          # the loader never adds the final row (vmis_index.rs:669)
+    with open(tmp_path / "test.txt", "w") as f:
+        f.write("SessionId\tItemId\tTime\n")
+        for s, it, t in g["test_rows"]:
+            f.write("%d\t%d\t%d.0\n" % (s, it, t))
+    with open(tmp_path / "example.toml", "w") as f:
+        f.write('config_type = "toml"\n[data]\ntraining_data_path="train.txt"\n[model]\nm_most_recent_sessions = 500\n'
+                'neighborhood_size_k = 50\nmax_items_in_session = 2\nnum_items_to_recommend = 20\nidf_weighting = 1\n'
+                '[logic]\nenable_business_logic = true\n[hyperparam]\ntest_data_path = "test.txt"\n')
+    exe = build.build_evaluator()
+    for extra in ([], ["--per-call"]):
+        r = subprocess.run([exe, "example.toml"] + extra, cwd=tmp_path, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        lines = r.stdout.splitlines()
+        assert "Qty test evaluations: 931" in lines
+        hdr = lines.index("qty_evaluations,Mrr@20,Ndcg@20,HitRate@20,Popularity@20,Precision@20,Coverage@20,Recall@20,F1score@20")
+        vals = [float(x) for x in lines[hdr + 1].split(",")]
+        assert vals[0] == 931 and vals[3] == 0.6402
+        for got, want, tol in zip(vals[1:], [0.3277, 0.3553, 0.6402, 0.0499, 0.0680, 0.2765, 0.4456, 0.1180],
+                                  [0.005, 0.005, 0.0001, 0.002, 0.0005, 0.005, 0.003, 0.001]):
+            assert abs(got - want) <= tol + 1e-9, vals
+    assert any(l.startswith("p90 (microseconds)") for l in lines)

@@ -190,3 +190,46 @@ def test_synthetic_generator_is_deterministic_and_shaped():
     assert ql.min() >= 1 and ql.max() <= synth.LAST_ITEMS
     qi2, qo2 = synth.queries(500, 5_000, seed=synth.SEED + 1)
     assert not (len(qi) == len(qi2) and np.array_equal(qi, qi2))
+
+
+def _evaluator():
+    from serenade_amd import build
+    return build.build_evaluator()
+
+
+def test_evaluator_metric_known_answers():
+    """serenade_amd/csrc/host/evaluator.cpp restates src/metrics/*.rs; its self-test runs the reference's metric KATs
+    (mrr.rs:53-61, ndcg.rs:76-84, precision.rs:64-74, recall.rs:65-75, f1score.rs:51-64, hitrate.rs:55-68)."""
+    import subprocess
+    r = subprocess.run([_evaluator(), "--metrics-selftest"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count(" ok") == 8 and "MISMATCH" not in r.stdout
+
+
+@pytest.mark.skipif(not have_reference_assets(), reason="/root/reference assets not present (GPU box)")
+def test_evaluate_file_reproduces_readme_metrics(tmp_path):
+    """evaluate_file.rs mirror on the oracle's predictions for the reference example (example.toml parameters, how_many=20):
+    README.md:170-172 -> Mrr 0.3277 Ndcg 0.3553 HitRate 0.6402 Popularity 0.0499 Precision 0.0680 Coverage 0.2765
+    Recall 0.4456 F1 0.1180 over 931 evaluations (rank metrics carry the reference's tie noise)."""
+    import subprocess
+    from helpers import evaluator_queries, flatten, read_test_data_evolving
+    d = extract_example(tmp_path)
+    off, items, ts, _ = O.read_tsv(os.path.join(d, "train.txt"))
+    ix = O.OracleIndex(off, items, ts, 500, 15, 1.0, fast=True)
+    qs = evaluator_queries(read_test_data_evolving(os.path.join(d, "test.txt")), 2)
+    flat, qoff = flatten([q for q, _ in qs])
+    r = ix.predict_batch("canonical", flat, qoff, 50, 500, 20, business=True, threads=4)
+    pred = tmp_path / "pred.txt"
+    with open(pred, "w") as f:
+        for i, (_, nxt) in enumerate(qs):
+            f.write(",".join(str(x) for x in r["ids"][i, :r["counts"][i]]) + ";" + ",".join(str(x) for x in nxt) + "\n")
+    out = subprocess.run([_evaluator(), "--evaluate-file", os.path.join(d, "train.txt"), str(pred)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert lines[-2] == "qty_evaluations,Mrr@20,Ndcg@20,HitRate@20,Popularity@20,Precision@20,Coverage@20,Recall@20,F1score@20"
+    vals = [float(x) for x in lines[-1].split(",")]
+    assert vals[0] == 931
+    readme = [0.3277, 0.3553, 0.6402, 0.0499, 0.0680, 0.2765, 0.4456, 0.1180]
+    tol = [0.005, 0.005, 0.0001, 0.002, 0.0005, 0.005, 0.003, 0.001]
+    for got, want, t in zip(vals[1:], readme, tol):
+        assert abs(got - want) <= t + 1e-9, (vals, readme)
