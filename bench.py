@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--pool", type=int, default=4, help="distinct query batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--traffic-file", default=None, help="profiles/*_traffic_<config>.json from the PMC passes (default: newest match)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -162,6 +163,19 @@ def main():
         lat.append((time.perf_counter() - t1) * 1e6)
     lat = np.array(lat[20:])
 
+    # HBM traffic per launch comes from separate rocprofv3 --pmc passes over this same command (tools/pmc_bench.sh);
+    # the committed summary is read back here so that the line carries it (null if no summary matches the workload)
+    traffic, traffic_src = None, None
+    try:
+        import glob
+        cand = [args.traffic_file] if args.traffic_file else sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic_%s.json" % args.config)))
+        if cand:
+            tj = json.load(open(cand[-1]))
+            if tj.get("config") == args.config and tj.get("batch_per_gpu") == B:
+                traffic, traffic_src = tj["traffic_bytes_per_launch"], os.path.relpath(cand[-1], ROOT)
+    except Exception:
+        pass
+
     result = {
         "metric": "predict_next queries/sec", "value": args.gpus * args.steps * B / elapsed, "unit": "queries/s",
         "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -176,7 +190,8 @@ def main():
                    "parallelism": "query-sharded replicas x%d (no data-path collective)" % args.gpus,
                    "setup_s": {"generate": round(t_gen, 2), "index_build_upload": round(t_build, 2)}},
         "roofline": {"bound": "hbm", "kernel": "vmis_predict_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE)",
+                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_per_launch,
                      "algorithmic_bytes_per_query": float(bq.mean()), "queries_per_launch": B,
                      "kernel_ms_avg": kernel_ms, "kernel_ms_min": float(k_main.min()) if len(k_main) else None,
                      "retry_pass_ms_avg": float(k_retry.mean()) if len(k_retry) else None,
