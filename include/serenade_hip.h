@@ -164,6 +164,32 @@ int srn_predict_batch_debug(const srn_index_t* idx, const uint64_t* items_flat, 
  * until that work has finished); *out_launches = number of kernel launches it covered. */
 int srn_last_kernel_ms(const srn_index_t* idx, double* out_ms_main, double* out_ms_retry, uint32_t* out_retried);
 
+/* ---- item-sharded index: one shard per GPU ---------------------------------------------------
+ * For indices that outgrow one GPU (BASELINE config 5) the index is split by item: shard g holds postings, row
+ * fragments and idf of the items with owner(id) == g (a fixed hash of the public id), while session recency
+ * ranks stay global.  A batch then takes three kernel stages around three collectives that the HOST runs over
+ * RCCL (serenade_amd/sharded.py): A -> all-gather(candidates) -> B -> all-reduce-min(first-match positions) ->
+ * C -> all-gather(per-shard top-n) -> merge.  All buffers are device memory; calls are asynchronous on `stream`.
+ * Packed candidate / neighbour entries are srn_shard_slot_bytes() wide (4, or 8 when rank bits + weight bits
+ * exceed 32).  Results are bit-identical to the unsharded path (tests/test_gpu_sharded.py). */
+int srn_index_build_shard(const srn_sessions_view_t* sessions, size_t m_index, size_t max_session_len,
+                          double idf_weighting, uint32_t shard, uint32_t n_shards, int device, srn_index_t** out);
+int srn_shard_slot_bytes(const srn_index_t* idx, size_t max_len_hint, uint32_t* out);
+/* A: this shard's candidates of every query: d_cand [nq * m] packed (rank, partial numerator), d_cand_cnt [nq] */
+int srn_shard_stage_a(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq,
+                      size_t max_len_hint, size_t k, size_t m, void* d_cand, uint32_t* d_cand_cnt, void* stream);
+/* B: d_gathered [n_shards][nq * m] / d_gathered_cnt [n_shards][nq] (all-gathered stage-A output) -> the global
+ * neighbour list d_nb [nq * k] (identical on every shard), d_nb_cnt [nq], and this shard's partial first-match
+ * positions d_minpos [nq * (k + 1)] (int32, 0x7FFFFFFF = none; last column: the current item's attribute byte) */
+int srn_shard_stage_b(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq,
+                      size_t max_len_hint, size_t k, size_t m, uint32_t n_shards, const void* d_gathered,
+                      const uint32_t* d_gathered_cnt, void* d_nb, uint32_t* d_nb_cnt, int32_t* d_minpos, void* stream);
+/* C: d_minpos after all-reduce(min) -> exact top-how_many among the items this shard owns */
+int srn_shard_stage_c(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq,
+                      size_t max_len_hint, size_t k, size_t m, size_t how_many, unsigned flags, const void* d_nb,
+                      const uint32_t* d_nb_cnt, const int32_t* d_minpos, uint64_t* d_out_ids, double* d_out_scores,
+                      uint32_t* d_out_counts, void* stream);
+
 /* The same for the most recent min(max_n, 64) predict calls (oldest first): per-call duration in ms of
  * the main kernel and of the retry pass, from HIP events recorded on the launch stream around each
  * launch.  This is what bench.py reports as the kernel's live-measured launch duration. */

@@ -56,6 +56,11 @@ SYMBOLS = {
     "srn_predict_batch_device": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, C.c_uint, _vp, _vp, _vp, _vp]),
     "srn_predict_batch_debug": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "srn_last_kernel_ms": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
+    "srn_index_build_shard": (_i, [C.POINTER(SessionsView), _sz, _sz, C.c_double, C.c_uint32, C.c_uint32, _i, C.POINTER(_vp)]),
+    "srn_shard_slot_bytes": (_i, [_vp, _sz, C.POINTER(C.c_uint32)]),
+    "srn_shard_stage_a": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp]),
+    "srn_shard_stage_b": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "srn_shard_stage_c": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, C.c_uint, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "srn_kernel_times": (_i, [_vp, C.c_uint32, _vp, _vp, C.POINTER(C.c_uint32)]),
     "srn_debug_phase_cycles": (_i, [_vp, _i, _vp]),
     "srn_device_count": (_i, [C.POINTER(_i)]),

@@ -95,7 +95,7 @@ int srn_index_build(const srn_sessions_view_t* sessions, size_t m_index, size_t 
         if (!sessions || !out) return fail(SRN_EINVAL, "null argument");
         *out = nullptr;
         srn_index* ix = new srn_index();
-        int rc = build_flat_index(*sessions, m_index, max_session_len, idf_weighting, ix->flat);
+        int rc = build_flat_index(*sessions, m_index, max_session_len, idf_weighting, 0, 1, ix->flat);
         if (rc == SRN_OK && device >= 0) { ix->dev = device_attach(ix->flat, device); ix->device = device; if (!ix->dev) rc = SRN_EHIP; }
         if (rc) { delete ix; return rc; }
         *out = ix; return SRN_OK; });
@@ -207,6 +207,60 @@ int srn_predict_batch_device(const srn_index_t* idx, const uint64_t* d_items_fla
 int srn_last_kernel_ms(const srn_index_t* idx, double* out_ms_main, double* out_ms_retry, uint32_t* out_retried) {
     if (!idx || !idx->dev) return fail(SRN_ENODEV, "index has no device attached");
     return guarded([&]() -> int { return device_last_kernel_ms(idx->dev, out_ms_main, out_ms_retry, out_retried); });
+}
+
+// ---- item-sharded index (DESIGN.md "Multi-GPU"): one shard per GPU, three kernel stages around three collectives ----
+int srn_index_build_shard(const srn_sessions_view_t* sessions, size_t m_index, size_t max_session_len, double idf_weighting,
+                          uint32_t shard, uint32_t n_shards, int device, srn_index_t** out) {
+    return guarded([&]() -> int {
+        if (!sessions || !out) return fail(SRN_EINVAL, "null argument");
+        *out = nullptr;
+        srn_index* ix = new srn_index();
+        int rc = build_flat_index(*sessions, m_index, max_session_len, idf_weighting, shard, n_shards, ix->flat);
+        if (rc == SRN_OK && device >= 0) { ix->dev = device_attach(ix->flat, device); ix->device = device; if (!ix->dev) rc = SRN_EHIP; }
+        if (rc) { delete ix; return rc; }
+        *out = ix; return SRN_OK; });
+}
+int srn_shard_slot_bytes(const srn_index_t* idx, size_t max_len_hint, uint32_t* out) {
+    if (!idx || !idx->dev || !out) return fail(SRN_ENODEV, "index has no device attached");
+    const int b = device_slot_bytes(idx->dev, idx->flat, (uint32_t)max_len_hint);
+    if (b < 0) return SRN_ERANGE;
+    *out = (uint32_t)b; return SRN_OK;
+}
+static int shard_stage(const srn_index_t* idx, int stage, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq, size_t max_len_hint,
+                       size_t k, size_t m, size_t how_many, unsigned flags, const ShardIO& sh, uint64_t* d_out_ids, double* d_out_scores,
+                       uint32_t* d_out_counts, void* stream) {
+    return guarded([&]() -> int {
+        int rc = check_predict_args(idx, k, m, how_many ? how_many : 1); if (rc) return rc;
+        if (nq == 0) return SRN_OK;
+        if (!d_items_flat || !d_q_off) return fail(SRN_EINVAL, "null buffer");
+        if (nq > 0x7FFFFFFFull) return fail(SRN_ERANGE, "too many queries in one batch");
+        if (max_len_hint == 0 || max_len_hint > SRN_MAX_SESSION_LEN) return fail(SRN_ERANGE, "max_len_hint out of range");
+        LaunchParams p{};
+        p.nq = (uint32_t)nq; p.k = (uint32_t)k; p.m = (uint32_t)m; p.how_many = (uint32_t)(how_many ? how_many : 1); p.flags = flags;
+        p.max_len = (uint32_t)max_len_hint; p.items_flat = d_items_flat; p.q_off = d_q_off;
+        p.out_ids = d_out_ids; p.out_scores = d_out_scores; p.out_counts = d_out_counts;
+        return device_shard_stage(idx->dev, idx->flat, stage, p, sh, stream); });
+}
+int srn_shard_stage_a(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq, size_t max_len_hint,
+                      size_t k, size_t m, void* d_cand, uint32_t* d_cand_cnt, void* stream) {
+    if (!d_cand || !d_cand_cnt) return fail(SRN_EINVAL, "null buffer");
+    ShardIO sh{}; sh.cand = d_cand; sh.cand_cnt = d_cand_cnt;
+    return shard_stage(idx, 1, d_items_flat, d_q_off, nq, max_len_hint, k, m, 0, 0, sh, nullptr, nullptr, nullptr, stream);
+}
+int srn_shard_stage_b(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq, size_t max_len_hint,
+                      size_t k, size_t m, uint32_t n_shards, const void* d_gathered, const uint32_t* d_gathered_cnt,
+                      void* d_nb, uint32_t* d_nb_cnt, int32_t* d_minpos, void* stream) {
+    if (!d_gathered || !d_gathered_cnt || !d_nb || !d_nb_cnt || !d_minpos || n_shards == 0) return fail(SRN_EINVAL, "null buffer");
+    ShardIO sh{}; sh.gathered = d_gathered; sh.gathered_cnt = d_gathered_cnt; sh.n_shards = n_shards; sh.nb = d_nb; sh.nb_cnt = d_nb_cnt; sh.minpos = d_minpos;
+    return shard_stage(idx, 2, d_items_flat, d_q_off, nq, max_len_hint, k, m, 0, 0, sh, nullptr, nullptr, nullptr, stream);
+}
+int srn_shard_stage_c(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq, size_t max_len_hint,
+                      size_t k, size_t m, size_t how_many, unsigned flags, const void* d_nb, const uint32_t* d_nb_cnt,
+                      const int32_t* d_minpos, uint64_t* d_out_ids, double* d_out_scores, uint32_t* d_out_counts, void* stream) {
+    if (!d_nb || !d_nb_cnt || !d_minpos || !d_out_ids || !d_out_scores || !d_out_counts || how_many == 0) return fail(SRN_EINVAL, "null buffer");
+    ShardIO sh{}; sh.nb = const_cast<void*>(d_nb); sh.nb_cnt = const_cast<uint32_t*>(d_nb_cnt); sh.minpos = const_cast<int32_t*>(d_minpos);
+    return shard_stage(idx, 3, d_items_flat, d_q_off, nq, max_len_hint, k, m, how_many, flags, sh, d_out_ids, d_out_scores, d_out_counts, stream);
 }
 
 int srn_kernel_times(const srn_index_t* idx, uint32_t max_n, double* out_ms_main, double* out_ms_retry, uint32_t* out_n) {

@@ -101,12 +101,14 @@ uint64_t sessions_length_quantile(const uint64_t* off, size_t n, double q) {
 // flat index builder
 // ---------------------------------------------------------------------------------------------
 int build_flat_index(const srn_sessions_view_t& v, size_t m_index, size_t max_session_len, double idf_weighting,
-                     FlatIndex& ix) {
+                     uint32_t shard, uint32_t n_shards, FlatIndex& ix) {
     if (!v.sess_off || !v.max_ts || (v.sess_off[v.n_sessions] && !v.items)) return fail(SRN_EINVAL, "null session arrays");
     if (m_index == 0) return fail(SRN_EINVAL, "m_index must be > 0");
+    if (n_shards == 0 || shard >= n_shards) return fail(SRN_EINVAL, "bad shard / n_shards");
     if (v.n_sessions >= 0xFFFFFFFFull) return fail(SRN_ERANGE, "too many sessions");
     ix = FlatIndex();
     ix.n_sessions_total = v.n_sessions; ix.m_index = m_index; ix.max_session_len = max_session_len; ix.idf_weighting = idf_weighting;
+    ix.shard = shard; ix.n_shards = n_shards;
 
     // 1. kept sessions in ascending recency order: (timestamp, session index) lexicographic
     std::vector<uint64_t> key; key.reserve(v.n_sessions);
@@ -115,7 +117,7 @@ int build_flat_index(const srn_sessions_view_t& v, size_t m_index, size_t max_se
         const uint64_t len = v.sess_off[s + 1] - v.sess_off[s];
         if (len == 0 || len > max_session_len) continue;   // :452 (an empty session contributes nothing)
         key.push_back(((uint64_t)v.max_ts[s] << 32) | (uint64_t)s);
-        ix.nnz_rows += len; ix.max_row_len = std::max<uint64_t>(ix.max_row_len, len);
+        ix.total_pairs += len;
     }
     std::sort(key.begin(), key.end());
     ix.n_kept = key.size();
@@ -124,10 +126,11 @@ int build_flat_index(const srn_sessions_view_t& v, size_t m_index, size_t max_se
     std::vector<uint64_t>().swap(key);
 
     // 2. dictionary: provisional dense index in first-seen order, then renumber ascending by id
-    size_t cap = 1024; while (cap < ix.nnz_rows / 4 + 16) cap <<= 1;   // grows on demand below
+    // (item-sharded: recency ranks stay global, only the items this shard owns get postings, row fragments and idf)
+    size_t cap = 1024; while (cap < ix.total_pairs / n_shards / 4 + 16) cap <<= 1;   // grows on demand below
     std::vector<IdSlot> tab(cap, IdSlot{0, kNone, 0}); size_t tmask = cap - 1;
     std::vector<uint64_t> ids; std::vector<uint32_t> cnt;
-    std::vector<uint32_t> prov(ix.nnz_rows);
+    std::vector<uint32_t> prov(ix.total_pairs);
     ix.row_off.assign(ix.n_kept + 1, 0);
     auto grow = [&]() {
         std::vector<IdSlot> nt(tab.size() * 2, IdSlot{0, kNone, 0}); const size_t nm = nt.size() - 1;
@@ -141,6 +144,7 @@ int build_flat_index(const srn_sessions_view_t& v, size_t m_index, size_t max_se
             const uint64_t id = v.items[j];
             if (!first && id <= prev) return fail(SRN_EINVAL, "session rows must be strictly ascending item ids");
             prev = id; first = false;
+            if (n_shards > 1 && item_owner(id, n_shards) != shard) continue;
             size_t h = mix64(id) & tmask;
             for (;;) {
                 IdSlot& sl = tab[h];
@@ -157,7 +161,9 @@ int build_flat_index(const srn_sessions_view_t& v, size_t m_index, size_t max_se
             ++cnt[prov[w]]; ++w;
         }
         ix.row_off[r + 1] = w;
+        ix.max_row_len = std::max<uint64_t>(ix.max_row_len, w - ix.row_off[r]);
     }
+    ix.nnz_rows = w; prov.resize(w);
     ix.n_items = ids.size();
     std::vector<uint32_t> order(ix.n_items); std::iota(order.begin(), order.end(), 0u);
     std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ids[a] < ids[b]; });
@@ -187,7 +193,7 @@ int build_flat_index(const srn_sessions_view_t& v, size_t m_index, size_t max_se
     // 4. idf = ln(total kept pairs / sessions containing the item before truncation) * weighting (:509-512)
     ix.idf.resize(ix.n_items); ix.attr.assign(ix.n_items, (uint8_t)SRN_ATTR_FOR_SALE);   // :514-517
     for (uint32_t i = 0; i < ix.n_items; ++i)
-        ix.idf[i] = std::log((double)ix.nnz_rows / (double)count[i]) * idf_weighting;
+        ix.idf[i] = std::log((double)ix.total_pairs / (double)count[i]) * idf_weighting;
 
     // 5. public id -> idx table for the query side (load factor <= 0.5)
     size_t tcap = 16; while (tcap < ix.n_items * 2) tcap <<= 1;
@@ -201,7 +207,7 @@ int build_flat_index(const srn_sessions_view_t& v, size_t m_index, size_t max_se
 }
 
 // ---------------------------------------------------------------------------------------------
-// binary save / load ("SRNFLAT1": header of u64 fields, then raw arrays)
+// binary save / load ("SRNFLAT2": header of u64 fields, then raw arrays)
 // ---------------------------------------------------------------------------------------------
 namespace {
 template <typename T> bool wr(FILE* f, const std::vector<T>& v) {
@@ -216,9 +222,10 @@ template <typename T> bool rd(FILE* f, std::vector<T>& v) {
 
 int save_flat_index(const FlatIndex& ix, const char* path) {
     FILE* f = fopen(path, "wb"); if (!f) return fail(SRN_EIO, std::string("cannot create ") + path);
-    const char magic[8] = {'S', 'R', 'N', 'F', 'L', 'A', 'T', '1'};
-    uint64_t hdr[9] = {ix.n_items, ix.n_sessions_total, ix.n_kept, ix.nnz_rows, ix.nnz_post, ix.m_index, ix.max_session_len, ix.max_row_len, ix.id_mask};
-    bool ok = fwrite(magic, 8, 1, f) == 1 && fwrite(hdr, 8, 9, f) == 9 && fwrite(&ix.idf_weighting, 8, 1, f) == 1 &&
+    const char magic[8] = {'S', 'R', 'N', 'F', 'L', 'A', 'T', '2'};
+    uint64_t hdr[12] = {ix.n_items, ix.n_sessions_total, ix.n_kept, ix.nnz_rows, ix.nnz_post, ix.m_index, ix.max_session_len, ix.max_row_len, ix.id_mask,
+                        ix.shard, ix.n_shards, ix.total_pairs};
+    bool ok = fwrite(magic, 8, 1, f) == 1 && fwrite(hdr, 8, 12, f) == 12 && fwrite(&ix.idf_weighting, 8, 1, f) == 1 &&
               wr(f, ix.item_id) && wr(f, ix.idf) && wr(f, ix.attr) && wr(f, ix.post_off) && wr(f, ix.post_rank) &&
               wr(f, ix.row_off) && wr(f, ix.row_items) && wr(f, ix.rank_to_session) && wr(f, ix.id_table);
     ok = (fclose(f) == 0) && ok;
@@ -227,12 +234,13 @@ int save_flat_index(const FlatIndex& ix, const char* path) {
 
 int load_flat_index(const char* path, FlatIndex& ix) {
     FILE* f = fopen(path, "rb"); if (!f) return fail(SRN_EIO, std::string("cannot open ") + path);
-    char magic[8]; uint64_t hdr[9]; ix = FlatIndex();
-    bool ok = fread(magic, 8, 1, f) == 1 && memcmp(magic, "SRNFLAT1", 8) == 0 && fread(hdr, 8, 9, f) == 9 &&
+    char magic[8]; uint64_t hdr[12]; ix = FlatIndex();
+    bool ok = fread(magic, 8, 1, f) == 1 && memcmp(magic, "SRNFLAT2", 8) == 0 && fread(hdr, 8, 12, f) == 12 &&
               fread(&ix.idf_weighting, 8, 1, f) == 1;
     if (ok) {
         ix.n_items = hdr[0]; ix.n_sessions_total = hdr[1]; ix.n_kept = hdr[2]; ix.nnz_rows = hdr[3]; ix.nnz_post = hdr[4];
         ix.m_index = hdr[5]; ix.max_session_len = hdr[6]; ix.max_row_len = hdr[7]; ix.id_mask = (uint32_t)hdr[8];
+        ix.shard = (uint32_t)hdr[9]; ix.n_shards = (uint32_t)hdr[10]; ix.total_pairs = hdr[11];
         ok = rd(f, ix.item_id) && rd(f, ix.idf) && rd(f, ix.attr) && rd(f, ix.post_off) && rd(f, ix.post_rank) &&
              rd(f, ix.row_off) && rd(f, ix.row_items) && rd(f, ix.rank_to_session) && rd(f, ix.id_table);
         ok = ok && ix.item_id.size() == ix.n_items && ix.idf.size() == ix.n_items && ix.attr.size() == ix.n_items &&
@@ -240,7 +248,7 @@ int load_flat_index(const char* path, FlatIndex& ix) {
              ix.row_items.size() == ix.nnz_rows && ix.rank_to_session.size() == ix.n_kept && ix.id_table.size() == (size_t)ix.id_mask + 1;
     }
     fclose(f);
-    return ok ? SRN_OK : fail(SRN_EIO, std::string("not a valid SRNFLAT1 index: ") + path);
+    return ok ? SRN_OK : fail(SRN_EIO, std::string("not a valid SRNFLAT2 index: ") + path);
 }
 
 }  // namespace srn

@@ -41,6 +41,8 @@ struct FlatIndex {
     uint64_t n_items = 0, n_sessions_total = 0, n_kept = 0, nnz_rows = 0, nnz_post = 0;
     uint64_t m_index = 0, max_session_len = 0, max_row_len = 0;
     double idf_weighting = 1.0;
+    uint32_t shard = 0, n_shards = 1;       // item-sharded index: this shard holds the items with owner(id) == shard
+    uint64_t total_pairs = 0;               // (session,item) pairs of ALL kept sessions = idf numerator (== nnz_rows when unsharded)
     std::vector<uint64_t> item_id;          // [n_items]   public ids, ascending  => idx order == id order
     std::vector<double> idf;                // [n_items]
     std::vector<uint8_t> attr;              // [n_items]   SRN_ATTR_* or SRN_ATTR_NONE
@@ -58,7 +60,8 @@ struct FlatIndex {
     }
 };
 int build_flat_index(const srn_sessions_view_t& v, size_t m_index, size_t max_session_len, double idf_weighting,
-                     FlatIndex& out);
+                     uint32_t shard, uint32_t n_shards, FlatIndex& out);
+static inline uint32_t item_owner(uint64_t id, uint32_t n_shards) { return (uint32_t)(mix64(id ^ 0x9E3779B97F4A7C15ull) % n_shards); }
 int save_flat_index(const FlatIndex& ix, const char* path);
 int load_flat_index(const char* path, FlatIndex& ix);
 
@@ -93,6 +96,14 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p, b
                    // host-pointer mode: these are host buffers copied in/out by the call
                    const uint64_t* h_items, const uint32_t* h_qoff, uint64_t* h_ids, double* h_scores,
                    uint32_t* h_counts, uint32_t* h_stats, uint32_t* h_nb_rank, uint32_t* h_nb_num, uint32_t* h_nb_cnt);
+struct ShardIO {
+    void* cand; uint32_t* cand_cnt;                                       // A out: [nq * m] packed slots, [nq]
+    const void* gathered; const uint32_t* gathered_cnt; uint32_t n_shards;   // B in: [G][nq * m], [G][nq]
+    void* nb; uint32_t* nb_cnt; int* minpos;                             // B out / C in: [nq * k], [nq], [nq * (k + 1)]
+};
+
+int device_shard_stage(DeviceState* d, const FlatIndex& ix, int stage, const LaunchParams& p, const ShardIO& sh, void* stream);
+int device_slot_bytes(DeviceState* d, const FlatIndex& ix, uint32_t max_len);
 int device_last_kernel_ms(DeviceState* d, double* ms_main, double* ms_retry, uint32_t* retried);
 int device_phase_cycles(DeviceState* d, int enable, unsigned long long* out16);   // debug profiling aid
 int device_kernel_times(DeviceState* d, uint32_t max_n, double* ms_main, double* ms_retry, uint32_t* out_n);

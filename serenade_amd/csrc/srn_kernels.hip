@@ -301,15 +301,43 @@ __device__ __forceinline__ int item_insert(uint32_t* ikeys, int* iacc, uint32_t 
     return -1;
 }
 
+// Item-sharded pipeline (DESIGN.md "Multi-GPU"): the fused kernel cut at its two exchange points.
+//   STAGE 1 (A)  phases 0-1 + local m-cut          -> this shard's candidate (rank, partial numerator) list
+//   -- all-gather of the candidate lists --
+//   STAGE 2 (B)  merge the G lists, global m-cut / k-cut, neighbours sorted by rank (same order on every shard),
+//                partial first-match position of each neighbour over the evolving items THIS shard owns
+//   -- all-reduce(min) of the first-match positions (+ the current item's attribute byte) --
+//   STAGE 3 (C)  phases 3-4 over this shard's row fragments -> exact top-n of the items it owns
+//   -- all-gather of the per-shard top-n, merged on every rank --
+static constexpr int MINPOS_NONE = 0x7FFFFFFF;
+
+// in-LDS bitonic sort, descending, of n (power of two) packed session slots; pads must be 0
+template <int BLOCK, typename SlotT>
+__device__ void block_sort_slots(SlotT* a, uint32_t n) {
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t kk = 2; kk <= n; kk <<= 1) {
+        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < (n >> 1); t += BLOCK) {
+                const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                const SlotT x = a[lo], y = a[hi];
+                const bool descending = (lo & kk) == 0;
+                if ((x > y) != descending) { a[lo] = y; a[hi] = x; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // optional per-phase cycle accounting (debug; p.phase_cycles == nullptr in normal operation)
 #define SRN_TICK(ph)                                                                                         \
     do { if (p.phase_cycles && tid == 0) { const long long t_ = clock64(); atomicAdd(&p.phase_cycles[ph], (unsigned long long)(t_ - t_prev)); t_prev = t_; } } while (0)
 
-template <int BLOCK, typename SlotT, typename OffT, bool GLOBAL_TABLES>
+template <int BLOCK, typename SlotT, typename OffT, bool GLOBAL_TABLES, int STAGE = 0>
 __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(DeviceIndex ix, LaunchParams p, KernelCfg c,
                                                              const uint32_t* __restrict__ qlist, const uint32_t* __restrict__ qlist_n,
                                                              uint32_t* retry_list, uint32_t* retry_cnt,
-                                                             char* gscratch, unsigned long long gscratch_stride, char* nb_spill_base) {
+                                                             char* gscratch, unsigned long long gscratch_stride, char* nb_spill_base,
+                                                             ShardIO sh) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NWAVES = BLOCK / 64;
@@ -381,7 +409,10 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
             l_len[pos] = len;
         }
         __syncthreads();
-        if (tid == 0) { uint32_t acc = 0; for (uint32_t i = 0; i < L; ++i) { l_pre[i] = acc; acc += l_len[i]; } l_pre[L] = acc; misc[S_P] = acc; }
+        if (tid == 0) { uint32_t acc = 0; for (uint32_t i = 0; i < L; ++i) { l_pre[i] = acc; acc += l_len[i]; } l_pre[L] = acc; misc[S_P] = acc;
+            if (STAGE == 2) {   // the candidates come from the G gathered lists instead of the posting lists
+                uint32_t tot = 0; for (uint32_t g = 0; g < sh.n_shards; ++g) tot += sh.gathered_cnt[(size_t)g * p.nq + q];
+                misc[S_P] = tot; misc[S_XLO] = 0xFFFFFFFFu; misc[S_RMAX] = 0; } }
         phase_sync<GLOBAL_TABLES>();
         const uint32_t x_lo = misc[S_XLO], r_max = misc[S_RMAX], U = misc[S_U], P = misc[S_P];
         const uint32_t cur_idx = q_idx[0];
@@ -392,11 +423,31 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
         phase_sync<GLOBAL_TABLES>();
         SRN_TICK(0);
 
+        uint32_t K = 0, Cm = 0;
+        if constexpr (STAGE != 3) {
         // ---- phase 1: posting lists -> session table -------------------------------------
         // All <= U lists are walked as one flattened range (lane <-> list element, coalesced).  Entries
         // below x_lo (the m-th entry of a full list) can never be among the m most recent distinct
         // sessions, so they are read but not inserted.
-        {
+        if constexpr (STAGE == 2) {
+            uint32_t fresh = 0, rmin = 0xFFFFFFFFu, rmax = 0;
+            bool ovf = false;
+            for (uint32_t g = 0; g < sh.n_shards; ++g) {
+                const SlotT* list = (const SlotT*)sh.gathered + ((size_t)g * p.nq + q) * p.m;
+                const uint32_t cnt = sh.gathered_cnt[(size_t)g * p.nq + q];
+                for (uint32_t e = tid; e < cnt; e += BLOCK) {
+                    const SlotT v = list[e]; const uint32_t r = (uint32_t)(v >> NB);
+                    rmin = min(rmin, r); rmax = max(rmax, r);
+                    const int res = sess_insert<SlotT>(stab, smask, NB, r, (uint32_t)(v & num_mask));
+                    if (res < 0) ovf = true; else fresh += (uint32_t)res;
+                }
+            }
+            fresh = wave_sum(fresh);
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) { rmin = min(rmin, (uint32_t)__shfl_xor((int)rmin, d, 64)); rmax = max(rmax, (uint32_t)__shfl_xor((int)rmax, d, 64)); }
+            if (lane == 0) { if (fresh) atomicAdd((uint32_t*)&misc[S_CNT], fresh); atomicMin((uint32_t*)&misc[S_XLO], rmin); atomicMax((uint32_t*)&misc[S_RMAX], rmax); }
+            if (ovf) misc[S_OVF] = 1;
+        } else {
             uint32_t fresh = 0, pos = 0;
             bool ovf = false;
             for (uint32_t e0 = tid; e0 < P; e0 += 4 * BLOCK) {
@@ -425,26 +476,28 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
         }
         phase_sync<GLOBAL_TABLES>();
         if (misc[S_OVF]) {   // block-uniform: hand the query to the global-table pass
-            if (GLOBAL_TABLES) { if (tid == 0) { p.out_counts[q] = 0xFFFFFFFFu; if (p.stats) p.stats[(size_t)q * 8 + 7] = 3; } }
+            if (STAGE != 0) { if (tid == 0) { if (STAGE == 1) sh.cand_cnt[q] = 0xFFFFFFFFu; else sh.nb_cnt[q] = 0xFFFFFFFFu; } }
+            else if (GLOBAL_TABLES) { if (tid == 0) { p.out_counts[q] = 0xFFFFFFFFu; if (p.stats) p.stats[(size_t)q * 8 + 7] = 3; } }
             else if (tid == 0) retry_list[atomicAdd(retry_cnt, 1u)] = q;
             continue;
         }
         SRN_TICK(1);
         const uint32_t Call = misc[S_CNT];
-        const uint32_t Cm = min(Call, p.m);
+        Cm = min(Call, p.m);
+        const uint32_t x_lo2 = STAGE == 2 ? (Call ? misc[S_XLO] : 0u) : x_lo, r_max2 = STAGE == 2 ? misc[S_RMAX] : r_max;
 
         // ---- phase 2: m-cut, k-cut, compaction -------------------------------------------
-        uint32_t tau = x_lo;
+        uint32_t tau = x_lo2;
         if (Call > p.m) {
-            tau = x_lo + block_select_desc<BLOCK, uint32_t>(
-                [&](uint32_t i, uint32_t& key) { const SlotT s = stab[i]; key = (uint32_t)(s >> NB) - x_lo; return s != SEMPTY; },
-                sslots, bits_for(r_max - x_lo), p.m, hist, misc);
+            tau = x_lo2 + block_select_desc<BLOCK, uint32_t>(
+                [&](uint32_t i, uint32_t& key) { const SlotT s = stab[i]; key = (uint32_t)(s >> NB) - x_lo2; return s != SEMPTY; },
+                sslots, bits_for(r_max2 - x_lo2), p.m, hist, misc);
         }
         SRN_TICK(2);
-        const int rbits = bits_for(r_max - tau);
+        const int rbits = bits_for(r_max2 - tau);
         unsigned long long kappa = 0;   // composite threshold: (num << rbits) | (rank - tau)
-        if (Cm > p.k) {
-            const int nbits = rbits + bits_for(misc[S_SUMW]);
+        if (STAGE != 1 && Cm > p.k) {   // (a shard's stage A keeps all of its <= m candidates: the k-cut is global)
+            const int nbits = rbits + bits_for(STAGE == 2 ? L * (L + 1) / 2 : misc[S_SUMW]);
             auto comp = [&](uint32_t i, auto& key) {
                 const SlotT s = stab[i]; const uint32_t r = (uint32_t)(s >> NB);
                 key = ((decltype(key + 0))(s & num_mask) << rbits) | (r - tau);
@@ -469,15 +522,28 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
             for (int u = 0; u < 8; ++u) {
                 if ((bm[u] >> lane) & 1ull) {
                     const uint32_t at = base + (uint32_t)__popcll(bm[u] & ((1ull << lane) - 1ull));
-                    nbl[at] = sv[u];
-                    if (p.nb_rank) { p.nb_rank[(size_t)q * p.k + at] = (uint32_t)(sv[u] >> NB); p.nb_num[(size_t)q * p.k + at] = (uint32_t)(sv[u] & num_mask); }
+                    if (STAGE == 1) ((SlotT*)sh.cand)[(size_t)q * p.m + at] = sv[u]; else nbl[at] = sv[u];
+                    if (STAGE == 0 && p.nb_rank) { p.nb_rank[(size_t)q * p.k + at] = (uint32_t)(sv[u] >> NB); p.nb_num[(size_t)q * p.k + at] = (uint32_t)(sv[u] & num_mask); }
                 }
                 base += (uint32_t)__popcll(bm[u]);
             }
         }
         __syncthreads();
-        const uint32_t K = misc[S_NB];
+        K = misc[S_NB];
         SRN_TICK(4);
+        if constexpr (STAGE == 1) { if (tid == 0) sh.cand_cnt[q] = K; continue; }
+        if constexpr (STAGE == 2) {   // same neighbour order on every shard: sort by the (unique) packed value, descending
+            uint32_t n2 = 2; while (n2 < K) n2 <<= 1;
+            for (uint32_t i = K + tid; i < n2; i += BLOCK) nbl[i] = 0;
+            __syncthreads();
+            block_sort_slots<BLOCK, SlotT>(nbl, n2);
+            for (uint32_t i = tid; i < K; i += BLOCK) ((SlotT*)sh.nb)[(size_t)q * p.k + i] = nbl[i];
+            if (tid == 0) { sh.nb_cnt[q] = K; sh.minpos[(size_t)q * (p.k + 1) + p.k] = cur_idx != kNone ? (int)ix.attr[cur_idx] : MINPOS_NONE; }
+        }
+        } else {   // STAGE == 3: the neighbours and their first-match positions arrive from stage B + all-reduce
+            K = sh.nb_cnt[q];
+            if (K == 0xFFFFFFFFu) { if (tid == 0) p.out_counts[q] = 0xFFFFFFFFu; continue; }
+        }
 
         // ---- phase 3: neighbour rows -> item table ---------------------------------------
         // A wave takes 64 neighbours at a time, one per lane (row offset, length, numerator in registers),
@@ -488,12 +554,16 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
         // split into `parts` hash partitions that are accumulated and harvested (phase 4) one after the other.
         const double denom = (double)(10u * U);
         const bool business = (p.flags & SRN_FLAG_BUSINESS_LOGIC) != 0;
-        const uint32_t cur_attr = (business && cur_idx != kNone) ? ix.attr[cur_idx] : SRN_ATTR_NONE;
+        uint32_t cur_attr = SRN_ATTR_NONE;
+        if (business) {
+            if (STAGE == 3) { const int v = sh.minpos[(size_t)q * (p.k + 1) + p.k]; if (v != MINPOS_NONE) cur_attr = (uint32_t)v; }   // owner shard's byte, all-reduced
+            else if (cur_idx != kNone) cur_attr = ix.attr[cur_idx];
+        }
         const uint32_t n_out = p.how_many;
         uint32_t parts = 1, part = 0, d_total = 0;
         bool failed = false;
         for (;;) {
-            for (uint32_t i = tid; i < c.item_slots; i += BLOCK) { ikeys[i] = EMPTY32; iacc[i] = 0; }
+            if (STAGE != 2) for (uint32_t i = tid; i < c.item_slots; i += BLOCK) { ikeys[i] = EMPTY32; iacc[i] = 0; }
             if (tid == 0) { misc[S_OVF] = 0; misc[S_ICNT] = 0; }
             phase_sync<GLOBAL_TABLES>();
             SRN_TICK(8);
@@ -508,7 +578,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                     return 0xFFFFu; };
                 auto load_group = [&](uint32_t g0, uint32_t& num, uint32_t& len, OffT& o0) {
                     const uint32_t j = g0 + lane; num = 0; len = 0; o0 = 0;
-                    if (j < K) { const SlotT s = parts == 1 ? nbl[j] : nb_spill[j]; const uint32_t r = (uint32_t)(s >> NB); num = (uint32_t)(s & num_mask);
+                    if (j < K) { const SlotT s = STAGE == 3 ? ((const SlotT*)sh.nb)[(size_t)q * p.k + j] : (parts == 1 ? nbl[j] : nb_spill[j]); const uint32_t r = (uint32_t)(s >> NB); num = (uint32_t)(s & num_mask);
                                  o0 = row_off[r]; len = (uint32_t)(row_off[r + 1] - o0); } };
                 auto accumulate = [&](uint32_t it, int w) {
                     if (parts > 1 && hash_part(it, parts) != part) return;
@@ -556,16 +626,21 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                     SRN_TICK(10);
                     // steps 0..nbat-1: B1 (first-match position of every row, Q4: against the full row) on batch `step`;
                     // then the row weights; steps nbat..2 nbat-1: B2 (accumulate), starting with the batch still cached
+                    // (sharded pipeline: stage B stops after B1 and publishes the partial positions; stage C starts at B2 with
+                    //  the all-reduced positions)
                     int wrow = 0;
-                    for (uint32_t step = 0; step < 2 * nbat; ++step) {
+                    if (STAGE == 3) { const int mp = g0 + lane < K ? sh.minpos[(size_t)q * (p.k + 1) + g0 + lane] : MINPOS_NONE;
+                                      wrow = (mp < 99 ? 10 - (mp + 1) : 0) * (int)num; }
+                    const uint32_t step0 = STAGE == 3 ? nbat : 0, step1 = STAGE == 2 ? nbat : 2 * nbat;
+                    for (uint32_t step = step0; step < step1; ++step) {
                         const bool b2 = step >= nbat;
-                        if (step == nbat) {
+                        if (STAGE != 3 && step == nbat) {
                             const uint32_t mp = wmin[lane];
-                            if (g0 + lane < K && mp == 0xFFFFu) misc[S_ERR] = 1;   // inconsistent index (reference: unwrap panic, mod.rs:138)
+                            if (STAGE == 0 && g0 + lane < K && mp == 0xFFFFu) misc[S_ERR] = 1;   // inconsistent index (reference: unwrap panic, mod.rs:138)
                             const int p1 = (int)mp + 1;
                             wrow = (p1 < 100 ? 10 - p1 : 0) * (int)num;            // 10 * linear_score(pos) * numerator, exact (Q3)
                             SRN_TICK(11);
-                        } else gather((b2 ? step - nbat - 1 : step) * BATCH);
+                        } else gather((STAGE == 3 ? step - nbat : (b2 ? step - nbat - 1 : step)) * BATCH);
 #pragma unroll
                         for (int u = 0; u < ROW_CACHE; ++u) {
                             const uint32_t owner = (own[u >> 2] >> ((u & 3) * 8)) & 63u;
@@ -573,6 +648,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                             else { const int w = __shfl(wrow, (int)owner, 64); if (itc[u] != EMPTY32) accumulate(itc[u], w); }
                         }
                     }
+                    if (STAGE == 2 && g0 + lane < K) sh.minpos[(size_t)q * (p.k + 1) + g0 + lane] = wmin[lane] == 0xFFFFu ? MINPOS_NONE : (int)wmin[lane];
                     num = nnum; len = nlen; o0 = no0;
                     SRN_TICK(12);
                 }
@@ -580,13 +656,14 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                 if (lane == 0) { if (fresh) atomicAdd((uint32_t*)&misc[S_ICNT], fresh); if (p.stats && part == 0 && isum) atomicAdd((uint32_t*)&misc[S_I], isum); }
                 if (ovf) misc[S_OVF] = 1;
             }
+            if constexpr (STAGE == 2) break;
             phase_sync<GLOBAL_TABLES>();
             SRN_TICK(13);
             if (misc[S_OVF]) {   // block-uniform: split the item space finer and start the accumulation over
                 __syncthreads();
-                if (parts >= MAX_ITEM_PASSES || GLOBAL_TABLES || !nb_spill) { failed = true; break; }
+                if (parts >= MAX_ITEM_PASSES || GLOBAL_TABLES || (STAGE != 3 && !nb_spill)) { failed = true; break; }
                 // phase 4 reuses the neighbour list's LDS for its candidates: keep a copy in global scratch
-                if (parts == 1) { for (uint32_t i = tid; i < K; i += BLOCK) nb_spill[i] = nbl[i]; __threadfence(); }
+                if (parts == 1 && STAGE != 3) { for (uint32_t i = tid; i < K; i += BLOCK) nb_spill[i] = nbl[i]; __threadfence(); }
                 parts *= 2; part = 0; d_total = 0;
                 if (tid == 0) { misc[S_CCNT] = 0; misc[S_HAVE_T] = 0; misc[S_I] = 0; }
                 continue;
@@ -683,8 +760,9 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
             if (++part >= parts) break;
             __syncthreads();
         }
+        if constexpr (STAGE == 2) continue;
         if (failed) {
-            if (GLOBAL_TABLES) { if (tid == 0) { p.out_counts[q] = 0xFFFFFFFFu; if (p.stats) p.stats[(size_t)q * 8 + 7] = 3; } }
+            if (GLOBAL_TABLES || STAGE == 3) { if (tid == 0) { p.out_counts[q] = 0xFFFFFFFFu; if (p.stats) p.stats[(size_t)q * 8 + 7] = 3; } }
             else if (tid == 0) retry_list[atomicAdd(retry_cnt, 1u)] = q;
             continue;
         }
@@ -832,16 +910,17 @@ static int ensure(char** p, size_t* have, size_t need) {
 static inline uint32_t round_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
 static inline int bits_host(uint64_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
 
-template <int BLOCK, bool GLOBAL_TABLES>
+template <int BLOCK, bool GLOBAL_TABLES, int STAGE = 0>
 static hipError_t launch_variant(bool slot64, bool off64, dim3 grid, size_t lds, hipStream_t st, const DeviceIndex& di,
                                  const LaunchParams& p, const KernelCfg& c, const uint32_t* qlist, const uint32_t* qn,
-                                 uint32_t* retry_list, uint32_t* retry_cnt, char* gs, unsigned long long gstride, char* spill) {
+                                 uint32_t* retry_list, uint32_t* retry_cnt, char* gs, unsigned long long gstride, char* spill,
+                                 const ShardIO& sh = ShardIO{}) {
 #define SRN_LAUNCH(SLOT, OFF)                                                                                             \
     do {                                                                                                                  \
-        auto kern = vmis_predict_kernel<BLOCK, SLOT, OFF, GLOBAL_TABLES>;                                                 \
+        auto kern = vmis_predict_kernel<BLOCK, SLOT, OFF, GLOBAL_TABLES, STAGE>;                                                 \
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
         if (e != hipSuccess) return e;                                                                                    \
-        hipLaunchKernelGGL(kern, grid, dim3(BLOCK), lds, st, di, p, c, qlist, qn, retry_list, retry_cnt, gs, gstride, spill); \
+        hipLaunchKernelGGL(kern, grid, dim3(BLOCK), lds, st, di, p, c, qlist, qn, retry_list, retry_cnt, gs, gstride, spill, sh); \
         return hipGetLastError();                                                                                         \
     } while (0)
     if (!slot64 && !off64) SRN_LAUNCH(uint32_t, uint32_t);
@@ -854,6 +933,45 @@ static hipError_t launch_variant(bool slot64, bool off64, dim3 grid, size_t lds,
 static constexpr int kBlock = 512;
 static inline uint32_t floor_pow2(uint64_t v) { uint32_t p2 = 1; while ((uint64_t)p2 * 2 <= v) p2 <<= 1; return p2; }
 static inline uint64_t ceil_pow2(uint64_t v) { uint64_t p2 = 1; while (p2 < v) p2 <<= 1; return p2; }
+
+struct Geometry {
+    KernelCfg c{}; bool slot64 = false; uint32_t slot_bytes = 4; size_t lds = 0;
+    uint64_t need_sess = 0, need_item = 0; bool sess_may_overflow = false, item_may_overflow = false;
+};
+// LDS layout + table sizes for one launch (all blocks alike).  min_region_b: extra room the caller needs in region B.
+static int make_geometry(const DeviceState* d, const FlatIndex& ix, const LaunchParams& p, uint32_t min_region_b, Geometry& g) {
+    const uint64_t Lmax = p.max_len;
+    const int num_bits = std::max(1, bits_host(Lmax * (Lmax + 1) / 2));
+    const int rank_bits = std::max(1, bits_host(ix.n_kept ? ix.n_kept - 1 : 0));
+    g.slot64 = rank_bits + num_bits > 32 || ix.n_kept >= 0xFFFFFFF0ull;
+    g.slot_bytes = g.slot64 ? 8 : 4;
+    const uint32_t slot_bytes = g.slot_bytes;
+    // what the query set could need at most
+    const uint64_t m_eff = std::min<uint64_t>(p.m, ix.m_index);
+    g.need_sess = std::max<uint64_t>(1, std::min<uint64_t>(Lmax * m_eff, ix.n_kept));
+    g.need_item = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)p.k * std::max<uint64_t>(1, ix.max_row_len), ix.n_items));
+    KernelCfg& c = g.c;
+    c.num_bits = (uint32_t)num_bits;
+    c.q_cap = round_up((uint32_t)Lmax + 1, 4);
+    c.off_q = MISC_WORDS * 4 + 1024;
+    c.off_wave = round_up(c.off_q + c.q_cap * 24 + (c.q_cap + 4) * 4, 16);
+    c.off_b = c.off_wave + (kBlock / 64) * 256;
+    const uint32_t region_b = round_up(std::max<uint32_t>(std::max<uint32_t>(p.k * slot_bytes, CAND_CAP * 12), min_region_b), 16);
+    c.off_a = c.off_b + region_b;
+    const uint32_t lds_max = (uint32_t)std::min(d->lds_per_block_max, 160 * 1024);
+    uint32_t budget = 80 * 1024;                          // two 512-thread blocks per CU
+    if (c.off_a + 32 * 1024 > budget) budget = lds_max;   // long sessions / large k: one block per CU
+    if (c.off_a + 8 * 1024 > budget) return fail(SRN_ERANGE, "k / session length too large for the LDS layout");
+    const uint32_t a_max = budget - c.off_a;
+    c.item_slots = std::min<uint32_t>(floor_pow2(a_max / 8), (uint32_t)std::min<uint64_t>(1u << 30, ceil_pow2(g.need_item * 2)));
+    c.sess_slots = std::min<uint32_t>(floor_pow2(a_max / slot_bytes), (uint32_t)std::min<uint64_t>(1u << 30, ceil_pow2(g.need_sess * 2)));
+    c.item_slots = std::max<uint32_t>(c.item_slots, 256); c.sess_slots = std::max<uint32_t>(c.sess_slots, 256);
+    const uint32_t region_a = std::max<uint32_t>(c.item_slots * 8, c.sess_slots * slot_bytes);
+    g.lds = (size_t)c.off_a + region_a;
+    // tables at least twice the worst case cannot exhaust the probe budget: no retry machinery needed
+    g.sess_may_overflow = (uint64_t)c.sess_slots < g.need_sess * 2; g.item_may_overflow = (uint64_t)c.item_slots < g.need_item * 2;
+    return SRN_OK;
+}
 
 int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in, bool on_device, void* user_stream,
                    const uint64_t* h_items, const uint32_t* h_qoff, uint64_t* h_ids, double* h_scores, uint32_t* h_counts,
@@ -868,36 +986,10 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     hipStream_t st = on_device ? (hipStream_t)user_stream : w->stream;
 
     // ---- geometry ----------------------------------------------------------------------
-    const uint64_t Lmax = p.max_len;
-    const int num_bits = std::max(1, bits_host(Lmax * (Lmax + 1) / 2));
-    const int rank_bits = std::max(1, bits_host(ix.n_kept ? ix.n_kept - 1 : 0));
-    const bool slot64 = rank_bits + num_bits > 32 || ix.n_kept >= 0xFFFFFFF0ull;
-    const uint32_t slot_bytes = slot64 ? 8 : 4;
-    // what the query set could need at most
-    const uint64_t m_eff = std::min<uint64_t>(p.m, ix.m_index);
-    const uint64_t need_sess = std::max<uint64_t>(1, std::min<uint64_t>(Lmax * m_eff, ix.n_kept));
-    const uint64_t need_item = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)p.k * ix.max_row_len, ix.n_items));
-    KernelCfg c{};
-    c.num_bits = (uint32_t)num_bits;
-    c.q_cap = round_up((uint32_t)Lmax + 1, 4);
-    c.off_q = MISC_WORDS * 4 + 1024;
-    c.off_wave = round_up(c.off_q + c.q_cap * 24 + (c.q_cap + 4) * 4, 16);
-    c.off_b = c.off_wave + (kBlock / 64) * 256;
-    const uint32_t region_b = round_up(std::max<uint32_t>(p.k * slot_bytes, CAND_CAP * 12), 16);
-    c.off_a = c.off_b + region_b;
-    const uint32_t lds_max = (uint32_t)std::min(d->lds_per_block_max, 160 * 1024);
-    uint32_t budget = 80 * 1024;                          // two 512-thread blocks per CU
-    if (c.off_a + 32 * 1024 > budget) budget = lds_max;   // long sessions / large k: one block per CU
-    if (c.off_a + 8 * 1024 > budget) return fail(SRN_ERANGE, "k / session length too large for the LDS layout");
-    const uint32_t a_max = budget - c.off_a;
-    c.item_slots = std::min<uint32_t>(floor_pow2(a_max / 8), (uint32_t)std::min<uint64_t>(1u << 30, ceil_pow2(need_item * 2)));
-    c.sess_slots = std::min<uint32_t>(floor_pow2(a_max / slot_bytes), (uint32_t)std::min<uint64_t>(1u << 30, ceil_pow2(need_sess * 2)));
-    c.item_slots = std::max<uint32_t>(c.item_slots, 256); c.sess_slots = std::max<uint32_t>(c.sess_slots, 256);
-    const uint32_t region_a = std::max<uint32_t>(c.item_slots * 8, c.sess_slots * slot_bytes);
-    const size_t lds = (size_t)c.off_a + region_a;
-    // tables at least twice the worst case cannot exhaust the probe budget: no retry machinery needed
-    const bool sess_may_overflow = (uint64_t)c.sess_slots < need_sess * 2, item_may_overflow = (uint64_t)c.item_slots < need_item * 2;
-    const bool may_overflow = sess_may_overflow || item_may_overflow;
+    Geometry geo; { int rc = make_geometry(d, ix, p, 0, geo); if (rc) return rc; }
+    const KernelCfg& c = geo.c; const bool slot64 = geo.slot64; const uint32_t slot_bytes = geo.slot_bytes; const size_t lds = geo.lds;
+    const uint64_t need_sess = geo.need_sess, need_item = geo.need_item;
+    const bool item_may_overflow = geo.item_may_overflow, may_overflow = geo.sess_may_overflow || geo.item_may_overflow;
 
     // ---- buffers -----------------------------------------------------------------------
     const size_t n_out = (size_t)p.nq * p.how_many;
@@ -970,6 +1062,31 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         HIP_TRY(hipStreamSynchronize(st));
     }
     return SRN_OK;
+}
+
+// One stage of the item-sharded pipeline (device buffers, asynchronous on `stream`); see ShardIO.
+int device_shard_stage(DeviceState* d, const FlatIndex& ix, int stage, const LaunchParams& p_in, const ShardIO& sh, void* stream) {
+    HIP_TRY(hipSetDevice(d->device));
+    LaunchParams p = p_in;
+    if (p.nq == 0) return SRN_OK;
+    p.phase_cycles = nullptr;
+    Geometry geo;
+    const uint32_t sort_room = stage == 2 ? (uint32_t)ceil_pow2(std::max<uint32_t>(p.k, 2)) * 8 : 0;   // stage B sorts the neighbour list in region B
+    int rc = make_geometry(d, ix, p, sort_room, geo); if (rc) return rc;
+    const uint32_t blocks_per_cu = std::max<uint32_t>(1, (160 * 1024) / (uint32_t)geo.lds);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * std::min<uint32_t>(blocks_per_cu, 2048 / kBlock) * 4);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e;
+    if (stage == 1) e = launch_variant<kBlock, false, 1>(geo.slot64, d->off64, dim3(grid), geo.lds, st, d->di, p, geo.c, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, sh);
+    else if (stage == 2) e = launch_variant<kBlock, false, 2>(geo.slot64, d->off64, dim3(grid), geo.lds, st, d->di, p, geo.c, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, sh);
+    else if (stage == 3) e = launch_variant<kBlock, false, 3>(geo.slot64, d->off64, dim3(grid), geo.lds, st, d->di, p, geo.c, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, sh);
+    else return fail(SRN_EINVAL, "bad stage");
+    if (e != hipSuccess) return fail(SRN_EHIP, std::string("shard stage launch: ") + hipGetErrorString(e));
+    return SRN_OK;
+}
+int device_slot_bytes(DeviceState* d, const FlatIndex& ix, uint32_t max_len) {   // element size of the packed candidate / neighbour buffers
+    LaunchParams p{}; p.max_len = max_len; p.k = 1; p.m = 1; Geometry g;
+    return make_geometry(d, ix, p, 0, g) == SRN_OK ? (int)g.slot_bytes : -1;
 }
 
 int device_last_kernel_ms(DeviceState* d, double* ms_main, double* ms_retry, uint32_t* retried) {

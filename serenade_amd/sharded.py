@@ -1,0 +1,182 @@
+"""Item-sharded VMIS-kNN index across the GPUs of one node (BASELINE.json north star / config 5).
+
+Shard g (one process, one GPU) holds the postings, row fragments and idf of the items with owner(id) == g; session
+recency ranks are global.  A batch of evolving sessions, replicated on every rank, takes three kernel stages around
+three collectives (RCCL over xGMI when the backend is "nccl"):
+
+    stage A  (kernel)   this shard's candidate sessions (rank, partial similarity numerator), locally cut to m
+    all-gather          candidate lists                      <= m * 4..8 B per query and shard
+    stage B  (kernel)   merge, global m-cut and k-cut -> the neighbour list (identical on every rank);
+                        partial first-match positions over the evolving items this shard owns
+    all-reduce(min)     first-match positions                (k + 1) * 4 B per query
+    stage C  (kernel)   accumulate over this shard's row fragments, exact top-n among the items it owns
+    all-gather          per-shard top-n                      n * 16 B per query and shard
+    merge               top-n of the G * n candidates by (score desc, item id asc) -- a few torch ops on device
+
+An item's whole score lives on its owner, and every integer that enters it (neighbour set, numerators, first-match
+positions) is global, so the result is bit-identical to the unsharded path.  The exchange volumes make this the mode
+for indices that do not fit one GPU, not the fast path: while the index fits, query-sharded replicas
+(serenade_amd.distributed) need no collective at all.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+MINPOS_NONE = 0x7FFFFFFF
+
+
+class ShardedVMISIndex:
+    """One shard (srn_index_build_shard).  Every rank passes the SAME training sessions and its own shard number."""
+
+    def __init__(self, sess_off, items, max_ts, m_index, max_session_len, idf_weighting, shard, n_shards, device=0):
+        sess_off, items, max_ts = capi.as_u64(sess_off), capi.as_u64(items), capi.as_u32(max_ts)
+        v = capi.SessionsView(sess_off.ctypes.data, items.ctypes.data, max_ts.ctypes.data, len(max_ts))
+        h = C.c_void_p()
+        capi.check(capi.lib().srn_index_build_shard(C.byref(v), int(m_index), int(max_session_len), float(idf_weighting),
+                                                    int(shard), int(n_shards), int(device), C.byref(h)))
+        self._h, self.shard, self.n_shards, self.device = h, int(shard), int(n_shards), int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            capi.lib().srn_index_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def info(self):
+        out = capi.IndexInfo()
+        capi.check(capi.lib().srn_index_info(self._h, C.byref(out)))
+        return {n: getattr(out, n) for n, _ in capi.IndexInfo._fields_}
+
+    def slot_bytes(self, max_len):
+        out = C.c_uint32()
+        capi.check(capi.lib().srn_shard_slot_bytes(self._h, int(max_len), C.byref(out)))
+        return out.value
+
+
+class DistComm:
+    """Collectives of the sharded pipeline over torch.distributed.  With backend "nccl" (RCCL) tensors stay on the GPU;
+    with "gloo" (CPU tests) they are staged through host memory."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group)
+        self.staged = dist.get_backend(group) != "nccl"
+
+    def all_gather(self, t):
+        import torch
+        src = (t.cpu() if self.staged else t).contiguous()
+        out = torch.empty(self.world * src.numel(), dtype=src.dtype, device=src.device)   # flat: accepted by every backend
+        self.dist.all_gather_into_tensor(out, src.view(-1), group=self.group)
+        out = out.view((self.world,) + tuple(src.shape))
+        return out.to(t.device) if self.staged else out
+
+    def all_reduce_min(self, t):
+        if self.staged:
+            h = t.cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.MIN, group=self.group)
+            t.copy_(h)
+        else:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+        return t
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _stage_a(ix, d_flat, d_off, nq, max_len, k, m, dtype, stream):
+    import torch
+    cand = torch.empty(nq * m, dtype=dtype, device=d_flat.device)
+    cnt = torch.empty(nq, dtype=torch.int32, device=d_flat.device)
+    capi.check(capi.lib().srn_shard_stage_a(ix._h, _ptr(d_flat), _ptr(d_off), nq, max_len, k, m, _ptr(cand), _ptr(cnt), C.c_void_p(stream)))
+    return cand, cnt
+
+
+def _stage_b(ix, d_flat, d_off, nq, max_len, k, m, gathered, gathered_cnt, dtype, stream):
+    import torch
+    dev = d_flat.device
+    nb = torch.zeros(nq * k, dtype=dtype, device=dev)
+    nb_cnt = torch.empty(nq, dtype=torch.int32, device=dev)
+    minpos = torch.full((nq * (k + 1),), MINPOS_NONE, dtype=torch.int32, device=dev)
+    capi.check(capi.lib().srn_shard_stage_b(ix._h, _ptr(d_flat), _ptr(d_off), nq, max_len, k, m, gathered.shape[0],
+                                            _ptr(gathered), _ptr(gathered_cnt), _ptr(nb), _ptr(nb_cnt), _ptr(minpos), C.c_void_p(stream)))
+    return nb, nb_cnt, minpos
+
+
+def _stage_c(ix, d_flat, d_off, nq, max_len, k, m, how_many, business, nb, nb_cnt, minpos, stream):
+    import torch
+    dev = d_flat.device
+    ids = torch.zeros(nq * how_many, dtype=torch.int64, device=dev)
+    sc = torch.zeros(nq * how_many, dtype=torch.float64, device=dev)
+    cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
+    capi.check(capi.lib().srn_shard_stage_c(ix._h, _ptr(d_flat), _ptr(d_off), nq, max_len, k, m, how_many,
+                                            capi.FLAG_BUSINESS_LOGIC if business else 0, _ptr(nb), _ptr(nb_cnt), _ptr(minpos),
+                                            _ptr(ids), _ptr(sc), _ptr(cnt), C.c_void_p(stream)))
+    return ids, sc, cnt
+
+
+def merge_topn(ids, scores, counts, how_many):
+    """[G, nq, n] per-shard top-n -> [nq, n] global top-n by (score desc, item id asc); counts [G, nq] -> [nq].
+    Item ids are u64 carried in int64: flipping the sign bit makes the signed order the unsigned one."""
+    import torch
+    G, nq, n = ids.shape
+    if bool((counts == -1).any()):
+        raise capi.SerenadeError(capi.SRN_ERANGE, "a query exceeded the kernel's table limits on some shard")
+    valid = torch.arange(n, device=ids.device).view(1, 1, n) < counts.view(G, nq, 1)
+    key = (ids ^ torch.iinfo(torch.int64).min).masked_fill(~valid, torch.iinfo(torch.int64).max)
+    sc = scores.masked_fill(~valid, float("-inf"))
+    key = key.permute(1, 0, 2).reshape(nq, G * n)
+    sc = sc.permute(1, 0, 2).reshape(nq, G * n)
+    o1 = torch.argsort(key, dim=1, stable=True)                          # secondary key: id ascending
+    key, sc = torch.gather(key, 1, o1), torch.gather(sc, 1, o1)
+    o2 = torch.argsort(sc, dim=1, descending=True, stable=True)          # primary key: score descending
+    key, sc = torch.gather(key, 1, o2)[:, :how_many], torch.gather(sc, 1, o2)[:, :how_many]
+    total = counts.to(torch.int64).sum(0).clamp(max=how_many).to(torch.int32)
+    keep = torch.arange(how_many, device=ids.device).view(1, -1) < total.view(-1, 1)
+    out_ids = (key ^ torch.iinfo(torch.int64).min).masked_fill(~keep, 0)
+    out_sc = sc.masked_fill(~keep, 0.0)
+    return out_ids.contiguous(), out_sc.contiguous(), total
+
+
+def predict_batch_sharded(index, comm, d_items_flat, d_q_off, nq, max_len, k, m, how_many, enable_business_logic=False, stream=None):
+    """One batch through the sharded pipeline on this rank.  d_items_flat (int64 view of the u64 ids) and d_q_off
+    (int32) are torch tensors on the shard's GPU and hold the SAME batch on every rank.  Returns torch tensors
+    (ids int64 [nq, n] = u64 bit patterns, scores f64 [nq, n], counts int32 [nq]), identical on every rank."""
+    import torch
+    if stream is None:
+        stream = torch.cuda.current_stream(d_items_flat.device).cuda_stream
+    dtype = torch.int32 if index.slot_bytes(max_len) == 4 else torch.int64
+    cand, cand_cnt = _stage_a(index, d_items_flat, d_q_off, nq, max_len, k, m, dtype, stream)
+    gathered, gathered_cnt = comm.all_gather(cand), comm.all_gather(cand_cnt)
+    if bool((gathered_cnt == -1).any()):
+        raise capi.SerenadeError(capi.SRN_ERANGE, "a query exceeded the session-table limits on some shard")
+    nb, nb_cnt, minpos = _stage_b(index, d_items_flat, d_q_off, nq, max_len, k, m, gathered.contiguous(), gathered_cnt.contiguous(), dtype, stream)
+    comm.all_reduce_min(minpos)
+    ids, sc, cnt = _stage_c(index, d_items_flat, d_q_off, nq, max_len, k, m, how_many, enable_business_logic, nb, nb_cnt, minpos, stream)
+    g_ids = comm.all_gather(ids.view(nq, how_many))
+    g_sc = comm.all_gather(sc.view(nq, how_many))
+    g_cnt = comm.all_gather(cnt)
+    return merge_topn(g_ids, g_sc, g_cnt, how_many)
+
+
+def predict_batch_sharded_local(shards, d_items_flat, d_q_off, nq, max_len, k, m, how_many, enable_business_logic=False):
+    """All shards in ONE process on one GPU (tests, debugging): the collectives become tensor ops."""
+    import torch
+    stream = torch.cuda.current_stream(d_items_flat.device).cuda_stream
+    dtype = torch.int32 if shards[0].slot_bytes(max_len) == 4 else torch.int64
+    a = [_stage_a(ix, d_items_flat, d_q_off, nq, max_len, k, m, dtype, stream) for ix in shards]
+    gathered, gathered_cnt = torch.stack([x[0] for x in a]).contiguous(), torch.stack([x[1] for x in a]).contiguous()
+    if bool((gathered_cnt == -1).any()):
+        raise capi.SerenadeError(capi.SRN_ERANGE, "a query exceeded the session-table limits on some shard")
+    b = [_stage_b(ix, d_items_flat, d_q_off, nq, max_len, k, m, gathered, gathered_cnt, dtype, stream) for ix in shards]
+    for x in b[1:]:   # stage B computes the same neighbour list on every shard
+        assert torch.equal(x[0], b[0][0]) and torch.equal(x[1], b[0][1]), "shards disagree on the neighbour list"
+    minpos = torch.stack([x[2] for x in b]).min(dim=0).values.contiguous()
+    c = [_stage_c(ix, d_items_flat, d_q_off, nq, max_len, k, m, how_many, enable_business_logic, b[0][0], b[0][1], minpos, stream) for ix in shards]
+    return merge_topn(torch.stack([x[0].view(nq, how_many) for x in c]), torch.stack([x[1].view(nq, how_many) for x in c]),
+                      torch.stack([x[2] for x in c]), how_many)
