@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--config", default="cfg3", help="tiny | cfg2 | cfg3 | cfg4 (synth.CONFIGS)")
     ap.add_argument("--batch", type=int, default=131072, help="evolving sessions per step and per GPU")
     ap.add_argument("--pool", type=int, default=4, help="distinct query batches cycled through")
+    ap.add_argument("--mode", default="replicas", choices=["replicas", "item-sharded"],
+                    help="replicas: every GPU holds the index and serves its own queries (default, no data-path collective); "
+                         "item-sharded: the north-star capacity mode, index split by item over the GPUs, 3 RCCL collectives per batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--traffic-file", default=None, help="profiles/*_traffic_<config>.json from the PMC passes (default: newest match)")
@@ -87,7 +90,15 @@ def main():
     off, items, ts = synth.training_sessions(inter, n_items)
     t_gen = time.time() - t0
     t0 = time.time()
-    index = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw, device=local_rank)
+    sharded_mode = args.mode == "item-sharded"
+    if sharded_mode:
+        from serenade_amd import sharded as SH
+        index = SH.ShardedVMISIndex(off, items, ts, m, 34, idfw, rank, world, device=local_rank)
+        comm = SH.DistComm() if world > 1 else SH.SoloComm()
+        if args.batch == 131072:
+            args.batch = 16384          # the exchange buffers are m * 4 B per query and shard
+    else:
+        index = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw, device=local_rank)
     t_build = time.time() - t0
     info = index.info
 
@@ -96,7 +107,8 @@ def main():
     need = B * args.pool
     n_sess = max(1024, int(need / 3.2) + 4096)
     while True:
-        q_items, q_off = synth.queries(n_sess, n_items, seed=synth.SEED + 7919 * (rank + 1), max_items=last_items)
+        # replicas: every rank draws its own slice of the query stream; item-sharded: all ranks see the same batch
+        q_items, q_off = synth.queries(n_sess, n_items, seed=synth.SEED + 7919 * ((0 if sharded_mode else rank) + 1), max_items=last_items)
         if len(q_off) - 1 >= need:
             break
         n_sess = int(n_sess * 1.5)
@@ -114,8 +126,12 @@ def main():
 
     def step(i):
         d_flat, d_off, _, _ = batches[i % args.pool]
-        sa.predict_batch_device(index, d_flat.data_ptr(), d_off.data_ptr(), B, last_items, k, m, how_many, False,
-                                out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), stream.cuda_stream)
+        if sharded_mode:
+            res = SH.predict_batch_sharded(index, comm, d_flat, d_off, B, last_items, k, m, how_many, False, stream.cuda_stream)
+            out_cnt.copy_(res[2])
+        else:
+            sa.predict_batch_device(index, d_flat.data_ptr(), d_off.data_ptr(), B, last_items, k, m, how_many, False,
+                                    out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), stream.cuda_stream)
 
     barrier = D.barrier
 
@@ -135,8 +151,21 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = D.max_over_ranks(elapsed, dev)
     step_ms = np.array([a.elapsed_time(b) for a, b in ev])
-    k_main, k_retry = index.kernel_times(min(64, args.steps))
     served = int((out_cnt.cpu().numpy().view(np.uint32) != 0xFFFFFFFF).sum())
+    if sharded_mode:
+        if rank == 0:
+            print(json.dumps({"metric": "predict_next queries/sec", "value": args.steps * B / elapsed, "unit": "queries/s", "n_gpus": args.gpus,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+                              "scaling": "strong", "vs_baseline": None, "dtype": "u32 ids / i32 accumulators / f64 scores", "data": "synthetic",
+                              "config": {"workload": "synth.CONFIGS[%s], index item-sharded over %d GPU(s), every rank sees the whole batch" % (args.config, world),
+                                         "name": args.config, "batch": B, "parallelism": "item-sharded x%d: all-gather + all-reduce(min) + all-gather per batch" % world,
+                                         "items_on_rank0": int(info["n_items"]), "index_bytes_hbm_rank0": int(info["device_bytes"])},
+                              "roofline": None, "cpu_baseline": None, "queries_served_last_step": served,
+                              "note": "capacity mode; the headline bench line is --mode replicas"}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    k_main, k_retry = index.kernel_times(min(64, args.steps))
 
     if rank != 0:
         if world > 1:

@@ -85,6 +85,17 @@ class DistComm:
         return t
 
 
+class SoloComm:
+    """world size 1 (single shard): the collectives degenerate."""
+    world = 1
+
+    def all_gather(self, t):
+        return t.unsqueeze(0)
+
+    def all_reduce_min(self, t):
+        return t
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr())
 
