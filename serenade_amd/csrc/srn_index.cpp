@@ -3,7 +3,7 @@
 // Mirrors the *semantics* of the reference's index construction so that the GPU path consumes the
 // same logical index -- read_from_file (src/vmisknn/vmis_index.rs:591-686) and prepare_hashmap
 // (:422-528) -- but produces the flat CSR layout described in DESIGN.md instead of hash maps of
-// vectors: item ids become dense indices in ascending-id order, sessions are renumbered by recency
+// vectors: item ids become dense indices in popularity order, sessions are renumbered by recency
 // rank (so "more recent" == larger u32 and the timestamp gather of find_neighbors disappears),
 // postings and rows are two CSR arrays.
 #include <algorithm>
@@ -165,12 +165,18 @@ int build_flat_index(const srn_sessions_view_t& v, size_t m_index, size_t max_se
     }
     ix.nnz_rows = w; prov.resize(w);
     ix.n_items = ids.size();
+    // dense idx = popularity order (most sessions first, ties by ascending id): the kernel direct-maps the accumulators of
+    // the first few thousand idx, and hot items' metadata share cache lines.  Ties in the final ranking are broken by
+    // ascending PUBLIC id, carried as id_rank.
     std::vector<uint32_t> order(ix.n_items); std::iota(order.begin(), order.end(), 0u);
-    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ids[a] < ids[b]; });
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cnt[a] != cnt[b] ? cnt[a] > cnt[b] : ids[a] < ids[b]; });
     std::vector<uint32_t> remap(ix.n_items);
     ix.item_id.resize(ix.n_items);
     std::vector<uint32_t> count(ix.n_items);
     for (uint32_t i = 0; i < ix.n_items; ++i) { remap[order[i]] = i; ix.item_id[i] = ids[order[i]]; count[i] = cnt[order[i]]; }
+    { std::vector<uint32_t> by_id(ix.n_items); std::iota(by_id.begin(), by_id.end(), 0u);
+      std::sort(by_id.begin(), by_id.end(), [&](uint32_t a, uint32_t b) { return ix.item_id[a] < ix.item_id[b]; });
+      ix.id_rank.resize(ix.n_items); for (uint32_t r = 0; r < ix.n_items; ++r) ix.id_rank[by_id[r]] = r; }
     ix.row_items.resize(ix.nnz_rows);
     for (size_t i = 0; i < ix.nnz_rows; ++i) ix.row_items[i] = remap[prov[i]];
     std::vector<uint32_t>().swap(prov); std::vector<uint64_t>().swap(ids); std::vector<uint32_t>().swap(cnt);
@@ -207,7 +213,7 @@ int build_flat_index(const srn_sessions_view_t& v, size_t m_index, size_t max_se
 }
 
 // ---------------------------------------------------------------------------------------------
-// binary save / load ("SRNFLAT2": header of u64 fields, then raw arrays)
+// binary save / load ("SRNFLAT3": header of u64 fields, then raw arrays)
 // ---------------------------------------------------------------------------------------------
 namespace {
 template <typename T> bool wr(FILE* f, const std::vector<T>& v) {
@@ -222,11 +228,11 @@ template <typename T> bool rd(FILE* f, std::vector<T>& v) {
 
 int save_flat_index(const FlatIndex& ix, const char* path) {
     FILE* f = fopen(path, "wb"); if (!f) return fail(SRN_EIO, std::string("cannot create ") + path);
-    const char magic[8] = {'S', 'R', 'N', 'F', 'L', 'A', 'T', '2'};
+    const char magic[8] = {'S', 'R', 'N', 'F', 'L', 'A', 'T', '3'};
     uint64_t hdr[12] = {ix.n_items, ix.n_sessions_total, ix.n_kept, ix.nnz_rows, ix.nnz_post, ix.m_index, ix.max_session_len, ix.max_row_len, ix.id_mask,
                         ix.shard, ix.n_shards, ix.total_pairs};
     bool ok = fwrite(magic, 8, 1, f) == 1 && fwrite(hdr, 8, 12, f) == 12 && fwrite(&ix.idf_weighting, 8, 1, f) == 1 &&
-              wr(f, ix.item_id) && wr(f, ix.idf) && wr(f, ix.attr) && wr(f, ix.post_off) && wr(f, ix.post_rank) &&
+              wr(f, ix.item_id) && wr(f, ix.id_rank) && wr(f, ix.idf) && wr(f, ix.attr) && wr(f, ix.post_off) && wr(f, ix.post_rank) &&
               wr(f, ix.row_off) && wr(f, ix.row_items) && wr(f, ix.rank_to_session) && wr(f, ix.id_table);
     ok = (fclose(f) == 0) && ok;
     return ok ? SRN_OK : fail(SRN_EIO, std::string("short write to ") + path);
@@ -235,20 +241,20 @@ int save_flat_index(const FlatIndex& ix, const char* path) {
 int load_flat_index(const char* path, FlatIndex& ix) {
     FILE* f = fopen(path, "rb"); if (!f) return fail(SRN_EIO, std::string("cannot open ") + path);
     char magic[8]; uint64_t hdr[12]; ix = FlatIndex();
-    bool ok = fread(magic, 8, 1, f) == 1 && memcmp(magic, "SRNFLAT2", 8) == 0 && fread(hdr, 8, 12, f) == 12 &&
+    bool ok = fread(magic, 8, 1, f) == 1 && memcmp(magic, "SRNFLAT3", 8) == 0 && fread(hdr, 8, 12, f) == 12 &&
               fread(&ix.idf_weighting, 8, 1, f) == 1;
     if (ok) {
         ix.n_items = hdr[0]; ix.n_sessions_total = hdr[1]; ix.n_kept = hdr[2]; ix.nnz_rows = hdr[3]; ix.nnz_post = hdr[4];
         ix.m_index = hdr[5]; ix.max_session_len = hdr[6]; ix.max_row_len = hdr[7]; ix.id_mask = (uint32_t)hdr[8];
         ix.shard = (uint32_t)hdr[9]; ix.n_shards = (uint32_t)hdr[10]; ix.total_pairs = hdr[11];
-        ok = rd(f, ix.item_id) && rd(f, ix.idf) && rd(f, ix.attr) && rd(f, ix.post_off) && rd(f, ix.post_rank) &&
+        ok = rd(f, ix.item_id) && rd(f, ix.id_rank) && rd(f, ix.idf) && rd(f, ix.attr) && rd(f, ix.post_off) && rd(f, ix.post_rank) &&
              rd(f, ix.row_off) && rd(f, ix.row_items) && rd(f, ix.rank_to_session) && rd(f, ix.id_table);
-        ok = ok && ix.item_id.size() == ix.n_items && ix.idf.size() == ix.n_items && ix.attr.size() == ix.n_items &&
+        ok = ok && ix.item_id.size() == ix.n_items && ix.id_rank.size() == ix.n_items && ix.idf.size() == ix.n_items && ix.attr.size() == ix.n_items &&
              ix.post_off.size() == ix.n_items + 1 && ix.post_rank.size() == ix.nnz_post && ix.row_off.size() == ix.n_kept + 1 &&
              ix.row_items.size() == ix.nnz_rows && ix.rank_to_session.size() == ix.n_kept && ix.id_table.size() == (size_t)ix.id_mask + 1;
     }
     fclose(f);
-    return ok ? SRN_OK : fail(SRN_EIO, std::string("not a valid SRNFLAT2 index: ") + path);
+    return ok ? SRN_OK : fail(SRN_EIO, std::string("not a valid SRNFLAT3 index: ") + path);
 }
 
 }  // namespace srn

@@ -43,13 +43,14 @@ struct FlatIndex {
     double idf_weighting = 1.0;
     uint32_t shard = 0, n_shards = 1;       // item-sharded index: this shard holds the items with owner(id) == shard
     uint64_t total_pairs = 0;               // (session,item) pairs of ALL kept sessions = idf numerator (== nnz_rows when unsharded)
-    std::vector<uint64_t> item_id;          // [n_items]   public ids, ascending  => idx order == id order
+    std::vector<uint64_t> item_id;          // [n_items]   public id of each dense idx; idx = popularity order (count desc, id asc)
+    std::vector<uint32_t> id_rank;          // [n_items]   rank of the public id in ascending order (final tie-break key)
     std::vector<double> idf;                // [n_items]
     std::vector<uint8_t> attr;              // [n_items]   SRN_ATTR_* or SRN_ATTR_NONE
     std::vector<uint64_t> post_off;         // [n_items+1]
     std::vector<uint32_t> post_rank;        // [nnz_post]  recency ranks, strictly descending per item
     std::vector<uint64_t> row_off;          // [n_kept+1]  rows addressed by recency rank
-    std::vector<uint32_t> row_items;        // [nnz_rows]  item idx, ascending per row
+    std::vector<uint32_t> row_items;        // [nnz_rows]  item idx (row order = ascending public id, as handed in)
     std::vector<uint32_t> rank_to_session;  // [n_kept]    reference session index of each rank
     std::vector<IdSlot> id_table;           // power-of-two open addressing table
     uint32_t id_mask = 0;
@@ -66,9 +67,15 @@ int save_flat_index(const FlatIndex& ix, const char* path);
 int load_flat_index(const char* path, FlatIndex& ix);
 
 // ---- device side ---------------------------------------------------------------------------
+struct ItemMeta {   // one 16-byte gather per scored item
+    double idf;
+    uint32_t id_rank;   // rank of the public id (ascending): tie-break key of the final ranking
+    uint32_t attr;      // SRN_ATTR_* byte
+};
 struct DeviceIndex {  // pointers into HBM; passed by value to the kernels
     const IdSlot* id_table; uint32_t id_mask;
-    const uint64_t* item_id; const double* idf; const uint8_t* attr;
+    const ItemMeta* meta;        // [n_items] by dense idx
+    const uint64_t* id_sorted;   // [n_items] public ids ascending (indexed by id_rank)
     const uint64_t* post_off; const uint32_t* post_rank;
     const void* row_off;  // uint32_t* or uint64_t* (offsets_64bit)
     const uint32_t* row_items;

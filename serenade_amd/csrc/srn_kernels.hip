@@ -49,7 +49,10 @@ static constexpr int ROW_CACHE = 4;  // row elements per lane kept in registers 
 
 // launch-time geometry, identical for every block of a launch (all LDS offsets multiples of 16)
 struct KernelCfg {
-    uint32_t sess_slots, item_slots;   // table sizes, powers of two
+    uint32_t sess_slots, item_slots;   // session table: power of two; item hash table: 4 * item_buckets slots
+    uint32_t item_buckets;             // prime number of 4-slot buckets (double hashing needs a full cycle)
+    uint32_t hot_slots;                // direct-mapped accumulators for dense idx < hot_slots (idx = popularity order)
+    uint32_t sum_bits;                 // hot accumulator = (touch count << sum_bits) + signed weight sum
     uint32_t num_bits;                 // low bits of a session slot that hold the numerator
     uint32_t q_cap;                    // capacity of the per-query item arrays (>= max_len, multiple of 4)
     uint32_t off_q, off_wave, off_b, off_a;   // LDS byte offsets: query arrays, per-wave scratch, region B, region A
@@ -282,9 +285,9 @@ __device__ __forceinline__ int sess_insert(SlotT* stab, uint32_t bmask, uint32_t
     return -1;
 }
 // the same for the item table (separate key / accumulator arrays; accumulators are signed)
-__device__ __forceinline__ int item_insert(uint32_t* ikeys, int* iacc, uint32_t bmask, uint32_t it, int w) {
-    uint32_t b = hash_start(it, bmask);
-    const uint32_t step = hash_step(it, bmask);
+__device__ __forceinline__ int item_insert(uint32_t* ikeys, int* iacc, uint32_t nb, uint32_t it, int w) {
+    uint32_t b = __umulhi(it * 0x9E3779B1u, nb);                       // nb is prime: any step in [1, nb) cycles through all buckets
+    const uint32_t step = 1u + __umulhi(it * 0x85EBCA6Bu, nb - 1u);
     for (int probe = 0; probe < MAX_PROBES;) {
         const uint4 v = *reinterpret_cast<const uint4*>(&ikeys[4 * b]);
         const int hit = v.x == it ? 0 : v.y == it ? 1 : v.z == it ? 2 : v.w == it ? 3 : -1;
@@ -296,7 +299,8 @@ __device__ __forceinline__ int item_insert(uint32_t* ikeys, int* iacc, uint32_t 
             if (old == it) { atomicAdd(&iacc[4 * b + empty], w); return 0; }
             continue;   // another item took that slot meanwhile: look at this bucket again
         }
-        b = (b + step) & bmask; ++probe;
+        b += step; if (b >= nb) b -= nb;
+        ++probe;
     }
     return -1;
 }
@@ -356,8 +360,9 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
     char* region_a = GLOBAL_TABLES ? (gscratch + (size_t)blockIdx.x * gscratch_stride) : (smem + c.off_a);
 
     SlotT* stab = (SlotT*)region_a;                                           // phase 1-2
-    uint32_t* ikeys = (uint32_t*)region_a;                                    // phase 3-4
-    int* iacc = (int*)(region_a + (size_t)c.item_slots * 4);
+    uint32_t* hot = (uint32_t*)region_a;                                      // phase 3-4: direct-mapped accumulators (idx < hot_slots)
+    uint32_t* ikeys = (uint32_t*)(region_a + (size_t)c.hot_slots * 4);        //            hash table keys (buckets of 4), then accumulators
+    int* iacc = (int*)(region_a + (size_t)c.hot_slots * 4 + (size_t)c.item_slots * 4);
     SlotT* nbl = (SlotT*)region_b;                                            // neighbours (phase 2-3)
     SlotT* nb_spill = nb_spill_base ? (SlotT*)nb_spill_base + (size_t)blockIdx.x * p.k : nullptr;   // copy kept across item partitions
     uint64_t* ckey = (uint64_t*)region_b;                                     // candidates (phase 4)
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
     const OffT* __restrict__ row_off = (const OffT*)ix.row_off;
     const uint32_t NB = c.num_bits;
     const SlotT num_mask = ((SlotT)1 << NB) - 1;
-    const uint32_t imask = c.item_slots / 4 - 1;   // bucket mask (4 slots per bucket)
+    const uint32_t inb = c.item_buckets, H = c.hot_slots, SB = c.sum_bits;
     const uint32_t nq_eff = qlist ? *qlist_n : p.nq;
 
     for (uint32_t qi = blockIdx.x; qi < nq_eff; qi += gridDim.x) {
@@ -538,7 +543,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
             __syncthreads();
             block_sort_slots<BLOCK, SlotT>(nbl, n2);
             for (uint32_t i = tid; i < K; i += BLOCK) ((SlotT*)sh.nb)[(size_t)q * p.k + i] = nbl[i];
-            if (tid == 0) { sh.nb_cnt[q] = K; sh.minpos[(size_t)q * (p.k + 1) + p.k] = cur_idx != kNone ? (int)ix.attr[cur_idx] : MINPOS_NONE; }
+            if (tid == 0) { sh.nb_cnt[q] = K; sh.minpos[(size_t)q * (p.k + 1) + p.k] = cur_idx != kNone ? (int)ix.meta[cur_idx].attr : MINPOS_NONE; }
         }
         } else {   // STAGE == 3: the neighbours and their first-match positions arrive from stage B + all-reduce
             K = sh.nb_cnt[q];
@@ -557,13 +562,14 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
         uint32_t cur_attr = SRN_ATTR_NONE;
         if (business) {
             if (STAGE == 3) { const int v = sh.minpos[(size_t)q * (p.k + 1) + p.k]; if (v != MINPOS_NONE) cur_attr = (uint32_t)v; }   // owner shard's byte, all-reduced
-            else if (cur_idx != kNone) cur_attr = ix.attr[cur_idx];
+            else if (cur_idx != kNone) cur_attr = ix.meta[cur_idx].attr;
         }
         const uint32_t n_out = p.how_many;
         uint32_t parts = 1, part = 0, d_total = 0;
         bool failed = false;
         for (;;) {
-            if (STAGE != 2) for (uint32_t i = tid; i < c.item_slots; i += BLOCK) { ikeys[i] = EMPTY32; iacc[i] = 0; }
+            if (STAGE != 2) { for (uint32_t i = tid; i < c.item_slots; i += BLOCK) { ikeys[i] = EMPTY32; iacc[i] = 0; }
+                              for (uint32_t i = tid; i < H; i += BLOCK) hot[i] = 0; }
             if (tid == 0) { misc[S_OVF] = 0; misc[S_ICNT] = 0; }
             phase_sync<GLOBAL_TABLES>();
             SRN_TICK(8);
@@ -582,7 +588,8 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                                  o0 = row_off[r]; len = (uint32_t)(row_off[r + 1] - o0); } };
                 auto accumulate = [&](uint32_t it, int w) {
                     if (parts > 1 && hash_part(it, parts) != part) return;
-                    const int res = item_insert(ikeys, iacc, imask, it, w);
+                    if (it < H) { atomicAdd(&hot[it], (1u << SB) + (uint32_t)w); return; }   // popular item: one LDS add, no probing
+                    const int res = item_insert(ikeys, iacc, inb, it, w);
                     if (res < 0) ovf = true; else fresh += (uint32_t)res; };
                 uint32_t num, len, nnum = 0, nlen = 0; OffT o0, no0 = 0;
                 if (wave * 64 < K) load_group(wave * 64, num, len, o0);
@@ -668,6 +675,11 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                 if (tid == 0) { misc[S_CCNT] = 0; misc[S_HAVE_T] = 0; misc[S_I] = 0; }
                 continue;
             }
+            if (p.stats && H) {   // debug counters only: distinct items = hash inserts + touched direct-mapped entries
+                uint32_t touched = 0; for (uint32_t i = tid; i < H; i += BLOCK) touched += hot[i] != 0;
+                touched = wave_sum(touched); if (lane == 0 && touched) atomicAdd((uint32_t*)&misc[S_ICNT], touched);
+                __syncthreads();
+            }
             d_total += misc[S_ICNT];
 
             // ---- phase 4: scores, business rules, top-n (per partition, one running candidate set) ----
@@ -676,7 +688,8 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
             // candidates beating the threshold are appended.  If the buffer would overflow, the round is redone
             // chunk by chunk with a prune whenever needed (exact).
             {
-                const uint32_t n_chunks = (c.item_slots + BLOCK - 1) / BLOCK;
+                const uint32_t n_entries = H + c.item_slots;   // direct-mapped entries first, then the hash slots
+                const uint32_t n_chunks = (n_entries + BLOCK - 1) / BLOCK;
                 uint32_t u = 0, ru = 1;
                 while (u < n_chunks) {
                     const uint32_t cnt0 = misc[S_CCNT];
@@ -693,31 +706,32 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                     // threshold score is positive, an item whose upper bound idf_hi * acc / denom (same operations and
                     // rounding as the score, so monotone and safe) is below it is dropped without touching idf[].
                     for (uint32_t ub = u; ub < u_end; ub += 4) {   // sub-batches of 4 chunks, no barrier in between
-                    uint32_t its[4]; int accs[4]; double idfs[4];
+                    uint32_t its[4]; int accs[4]; ItemMeta metas[4];
 #pragma unroll
                     for (int x = 0; x < 4; ++x) {
-                        its[x] = EMPTY32; accs[x] = 0; idfs[x] = 0.0;
+                        its[x] = EMPTY32; accs[x] = 0; metas[x] = ItemMeta{0.0, 0u, 0u};
                         const uint32_t i = (ub + x) * BLOCK + tid;
-                        if (ub + x < u_end && i < c.item_slots) {
-                            const uint32_t it = ikeys[i];
-                            if (it != EMPTY32 && it != cur_idx && (!business || business_ok(cur_attr, ix.attr[it]))) {   // Q6 + rules
-                                const int acc = iacc[i];
+                        if (ub + x < u_end && i < n_entries) {
+                            uint32_t it = EMPTY32; int acc = 0;
+                            if (i < H) { const uint32_t v = hot[i]; if (v) { it = i; acc = (int)(v - (((v + (1u << (SB - 1))) >> SB) << SB)); } }
+                            else { it = ikeys[i - H]; acc = iacc[i - H]; }
+                            if (it != EMPTY32 && it != cur_idx) {   // Q6
                                 const bool hopeless = t_pos & (acc < acc_floor);   // branch-free on purpose (see DESIGN.md hazards)
-                                if (!hopeless) { its[x] = it; accs[x] = acc; idfs[x] = ix.idf[it]; }
+                                if (!hopeless) { its[x] = it; accs[x] = acc; metas[x] = ix.meta[it]; }
                             }
                         }
                     }
 #pragma unroll
                     for (int x = 0; x < 4; ++x) {
                         if (ub + x < u_end) {   // block-uniform
-                            const uint32_t it = its[x];
+                            const uint32_t tie = metas[x].id_rank;   // ties are broken by ascending public id
                             bool take = false; uint64_t sk = 0;
-                            if (it != EMPTY32) {
-                                sk = score_key((idfs[x] > 0.0 ? idfs[x] : 1.0) * (double)accs[x] / denom);
-                                take = !have_t || sk > tk || (sk == tk && it < tix);
+                            if (its[x] != EMPTY32 && (!business || business_ok(cur_attr, metas[x].attr))) {   // business rules
+                                sk = score_key((metas[x].idf > 0.0 ? metas[x].idf : 1.0) * (double)accs[x] / denom);
+                                take = !have_t || sk > tk || (sk == tk && tie < tix);
                             }
                             const uint32_t at = wave_append(take, (uint32_t*)&misc[S_CCNT]);
-                            if (take) { if (at < CAND_CAP) { ckey[at] = sk; cidx[at] = it; } else misc[S_COVF] = 1; }
+                            if (take) { if (at < CAND_CAP) { ckey[at] = sk; cidx[at] = tie; } else misc[S_COVF] = 1; }
                         }
                     }
                     }
@@ -768,7 +782,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
         }
         const uint32_t H = min(misc[S_CCNT], n_out);
         if (tid < H) {
-            p.out_ids[(size_t)q * n_out + tid] = ix.item_id[cidx[tid]];
+            p.out_ids[(size_t)q * n_out + tid] = ix.id_sorted[cidx[tid]];
             p.out_scores[(size_t)q * n_out + tid] = key_score(ckey[tid]);
         }
         if (tid == 0) {
@@ -802,7 +816,7 @@ struct DeviceState {
     int device = 0;
     std::vector<void*> allocs; uint64_t bytes = 0;
     DeviceIndex di{};
-    uint8_t* d_attr = nullptr;
+    ItemMeta* d_meta = nullptr;
     bool off64 = false;
     int n_cu = 256;
     int lds_per_block_max = 65536;
@@ -832,8 +846,9 @@ DeviceState* device_attach(const FlatIndex& ix, int device) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) { d->n_cu = prop.multiProcessorCount; d->lds_per_block_max = (int)prop.sharedMemPerBlock; }
     bool ok = true;
     d->di.id_table = upload(d, ix.id_table, ok); d->di.id_mask = ix.id_mask;
-    d->di.item_id = upload(d, ix.item_id, ok); d->di.idf = upload(d, ix.idf, ok);
-    d->d_attr = (uint8_t*)upload(d, ix.attr, ok); d->di.attr = d->d_attr;
+    { std::vector<ItemMeta> meta(ix.n_items); std::vector<uint64_t> id_sorted(ix.n_items);
+      for (size_t i = 0; i < ix.n_items; ++i) { meta[i] = ItemMeta{ix.idf[i], ix.id_rank[i], ix.attr[i]}; id_sorted[ix.id_rank[i]] = ix.item_id[i]; }
+      d->d_meta = (ItemMeta*)upload(d, meta, ok); d->di.meta = d->d_meta; d->di.id_sorted = upload(d, id_sorted, ok); }
     d->di.post_off = upload(d, ix.post_off, ok); d->di.post_rank = upload(d, ix.post_rank, ok);
     d->off64 = ix.nnz_rows >= 0xFFFFFFFFull;
     if (d->off64) d->di.row_off = upload(d, ix.row_off, ok);
@@ -871,7 +886,9 @@ void device_release(DeviceState* d) {
 
 int device_update_attr(DeviceState* d, const FlatIndex& ix) {
     HIP_TRY(hipSetDevice(d->device));
-    HIP_TRY(hipMemcpy(d->d_attr, ix.attr.data(), ix.attr.size(), hipMemcpyHostToDevice));
+    std::vector<ItemMeta> meta(ix.n_items);
+    for (size_t i = 0; i < ix.n_items; ++i) meta[i] = ItemMeta{ix.idf[i], ix.id_rank[i], ix.attr[i]};
+    HIP_TRY(hipMemcpy(d->d_meta, meta.data(), meta.size() * sizeof(ItemMeta), hipMemcpyHostToDevice));
     return SRN_OK;
 }
 uint64_t device_bytes(const DeviceState* d) { return d ? d->bytes : 0; }
@@ -933,6 +950,9 @@ static hipError_t launch_variant(bool slot64, bool off64, dim3 grid, size_t lds,
 static constexpr int kBlock = 512;
 static inline uint32_t floor_pow2(uint64_t v) { uint32_t p2 = 1; while ((uint64_t)p2 * 2 <= v) p2 <<= 1; return p2; }
 static inline uint64_t ceil_pow2(uint64_t v) { uint64_t p2 = 1; while (p2 < v) p2 <<= 1; return p2; }
+static inline bool is_prime(uint32_t n) { if (n < 2) return false; for (uint32_t d = 2; (uint64_t)d * d <= n; ++d) if (n % d == 0) return false; return true; }
+static inline uint32_t prime_at_most(uint32_t n) { while (n > 2 && !is_prime(n)) --n; return std::max<uint32_t>(n, 2); }
+static inline uint32_t prime_at_least(uint64_t n) { uint32_t v = (uint32_t)std::min<uint64_t>(n, 0x3FFFFFFFull); while (!is_prime(v)) ++v; return v; }
 
 struct Geometry {
     KernelCfg c{}; bool slot64 = false; uint32_t slot_bytes = 4; size_t lds = 0;
@@ -963,10 +983,20 @@ static int make_geometry(const DeviceState* d, const FlatIndex& ix, const Launch
     if (c.off_a + 32 * 1024 > budget) budget = lds_max;   // long sessions / large k: one block per CU
     if (c.off_a + 8 * 1024 > budget) return fail(SRN_ERANGE, "k / session length too large for the LDS layout");
     const uint32_t a_max = budget - c.off_a;
-    c.item_slots = std::min<uint32_t>(floor_pow2(a_max / 8), (uint32_t)std::min<uint64_t>(1u << 30, ceil_pow2(g.need_item * 2)));
     c.sess_slots = std::min<uint32_t>(floor_pow2(a_max / slot_bytes), (uint32_t)std::min<uint64_t>(1u << 30, ceil_pow2(g.need_sess * 2)));
-    c.item_slots = std::max<uint32_t>(c.item_slots, 256); c.sess_slots = std::max<uint32_t>(c.sess_slots, 256);
-    const uint32_t region_a = std::max<uint32_t>(c.item_slots * 8, c.sess_slots * slot_bytes);
+    c.sess_slots = std::max<uint32_t>(c.sess_slots, 256);
+    // item side of region A: direct-mapped accumulators for the most popular idx, the rest a hash of 4-slot buckets.
+    // A direct-mapped word packs (touch count, signed weight sum); if those do not fit 32 bits the hot part is disabled.
+    const uint64_t w_max = (uint64_t)p.k * 9 * (Lmax * (Lmax + 1) / 2) + 1;
+    const int sbits = std::max(2, bits_host(w_max) + 1), cbits = bits_host(p.k);
+    uint32_t hot = sbits + cbits <= 32 ? 2048u : 0u;
+    if (const char* e = getenv("SRN_HOT_SLOTS")) hot = sbits + cbits <= 32 ? (uint32_t)atoi(e) : 0u;   // test knob
+    hot = std::min<uint32_t>(std::min<uint32_t>(hot, a_max / 8), round_up((uint32_t)std::min<uint64_t>(ix.n_items, 1u << 20), 4)) / 4 * 4;
+    c.hot_slots = hot; c.sum_bits = (uint32_t)sbits;
+    const uint64_t want_buckets = std::max<uint64_t>(61, g.need_item / 2 + 8);          // load <= 0.5 at the worst case
+    c.item_buckets = prime_at_most((uint32_t)std::min<uint64_t>((a_max - hot * 4) / 32, want_buckets));
+    c.item_slots = c.item_buckets * 4;
+    const uint32_t region_a = std::max<uint32_t>(hot * 4 + c.item_slots * 8, c.sess_slots * slot_bytes);
     g.lds = (size_t)c.off_a + region_a;
     // tables at least twice the worst case cannot exhaust the probe budget: no retry machinery needed
     g.sess_may_overflow = (uint64_t)c.sess_slots < g.need_sess * 2; g.item_may_overflow = (uint64_t)c.item_slots < g.need_item * 2;
@@ -1019,8 +1049,8 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         if (w->retry_cap < p.nq) { if (w->retry_list) HIP_TRY(hipFree(w->retry_list)); w->retry_list = nullptr; w->retry_cap = 0;
             HIP_TRY(hipMalloc((void**)&w->retry_list, (size_t)p.nq * 4 + 64)); w->retry_cap = p.nq; }
         cg.sess_slots = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(256, ceil_pow2(need_sess * 2)));
-        cg.item_slots = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(256, ceil_pow2(need_item * 2)));
-        g_stride = std::max<uint64_t>((uint64_t)cg.sess_slots * slot_bytes, (uint64_t)cg.item_slots * 8);
+        cg.item_buckets = prime_at_least(need_item / 2 + 64); cg.item_slots = cg.item_buckets * 4;
+        g_stride = std::max<uint64_t>((uint64_t)cg.sess_slots * slot_bytes, (uint64_t)cg.hot_slots * 4 + (uint64_t)cg.item_slots * 8);
         g_stride = (g_stride + 255) / 256 * 256;
         retry_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)d->n_cu, (2ull << 30) / g_stride));
         int rc = ensure(&w->gscratch, &w->gscratch_bytes, g_stride * retry_blocks); if (rc) return rc;
