@@ -45,7 +45,7 @@ static constexpr int CAND_CAP = 1024;       // candidate buffer of the final top
 static constexpr int MISC_WORDS = 64;       // scalar words at the head of LDS
 static constexpr int MAX_PROBES = 48;       // bucket probes (4 slots each) before a table is declared full
 static constexpr int MAX_ITEM_PASSES = 64;
-static constexpr int ROW_CACHE = 4;  // row elements per lane kept in registers per 64-row group (covers 1024 elements)  // item-space partition passes before giving up on the LDS table
+// item-space partition passes (MAX_ITEM_PASSES) before giving up on the LDS table; the row cache size is per instantiation
 
 // launch-time geometry, identical for every block of a launch (all LDS offsets multiples of 16)
 struct KernelCfg {
@@ -260,7 +260,8 @@ __device__ void block_top64(uint64_t* ckey, uint32_t* cidx, uint32_t cnt) {
 //
 // insert-or-add into the packed session table: slot = (rank << NB) | numerator.  Returns 1 if the rank was new,
 // 0 if it existed, -1 if the probe budget ran out (table too full).
-template <typename SlotT>
+// MASKS: the low NB bits are a bit set of evolving-session positions (OR-combined) instead of a sum of weights.
+template <typename SlotT, bool MASKS>
 __device__ __forceinline__ int sess_insert(SlotT* stab, uint32_t bmask, uint32_t NB, uint32_t r, uint32_t w) {
     constexpr SlotT SEMPTY = SlotTraits<SlotT>::EMPTY;
     uint32_t b = hash_start(r, bmask);
@@ -273,11 +274,11 @@ __device__ __forceinline__ int sess_insert(SlotT* stab, uint32_t bmask, uint32_t
         int hit = -1, empty = -1;
 #pragma unroll
         for (int i = 3; i >= 0; --i) { if (c[i] == SEMPTY) empty = i; else if ((uint32_t)(c[i] >> NB) == r) hit = i; }
-        if (hit >= 0) { atomicAdd(&stab[4 * b + hit], (SlotT)w); return 0; }
+        if (hit >= 0) { if (MASKS) atomicOr(&stab[4 * b + hit], (SlotT)w); else atomicAdd(&stab[4 * b + hit], (SlotT)w); return 0; }
         if (empty >= 0) {
             const SlotT old = atomicCAS(&stab[4 * b + empty], SEMPTY, ((SlotT)r << NB) | (SlotT)w);
             if (old == SEMPTY) return 1;
-            if ((uint32_t)(old >> NB) == r) { atomicAdd(&stab[4 * b + empty], (SlotT)w); return 0; }
+            if ((uint32_t)(old >> NB) == r) { if (MASKS) atomicOr(&stab[4 * b + empty], (SlotT)w); else atomicAdd(&stab[4 * b + empty], (SlotT)w); return 0; }
             continue;   // another rank took that slot meanwhile: look at this bucket again
         }
         b = (b + step) & bmask; ++probe;
@@ -336,7 +337,7 @@ __device__ void block_sort_slots(SlotT* a, uint32_t n) {
 #define SRN_TICK(ph)                                                                                         \
     do { if (p.phase_cycles && tid == 0) { const long long t_ = clock64(); atomicAdd(&p.phase_cycles[ph], (unsigned long long)(t_ - t_prev)); t_prev = t_; } } while (0)
 
-template <int BLOCK, typename SlotT, typename OffT, bool GLOBAL_TABLES, int STAGE = 0>
+template <int BLOCK, typename SlotT, typename OffT, bool GLOBAL_TABLES, int STAGE = 0, bool MASKS = false>
 __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(DeviceIndex ix, LaunchParams p, KernelCfg c,
                                                              const uint32_t* __restrict__ qlist, const uint32_t* __restrict__ qlist_n,
                                                              uint32_t* retry_list, uint32_t* retry_cnt,
@@ -371,6 +372,12 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
     const OffT* __restrict__ row_off = (const OffT*)ix.row_off;
     const uint32_t NB = c.num_bits;
     const SlotT num_mask = ((SlotT)1 << NB) - 1;
+    // MASKS (sessions of <= 8 items, m <= m_index): a session slot carries the SET of evolving positions whose posting
+    // list holds the session.  For a candidate (rank >= x_lo) that set is exactly "which evolving items the row
+    // contains" (lists are complete above their m-th entry), so both the similarity numerator (table lookup) and the
+    // first-match position (lowest set bit) come from it and phase 3 needs no first-match pass over the rows.
+    uint8_t* wlut = (uint8_t*)(smem + MISC_WORDS * 4);                        // 256 B: numerator of each position set
+    auto num_of = [&](SlotT sl) -> uint32_t { return MASKS ? (uint32_t)wlut[(uint32_t)(sl & num_mask)] : (uint32_t)(sl & num_mask); };
     const uint32_t inb = c.item_buckets, H = c.hot_slots, SB = c.sum_bits;
     const uint32_t nq_eff = qlist ? *qlist_n : p.nq;
 
@@ -390,6 +397,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
         if (tid < MISC_WORDS) misc[tid] = 0;
         for (uint32_t i = tid; i < SEL_WORDS; i += BLOCK) hist[i] = 0;
         for (uint32_t i = tid; i < L; i += BLOCK) q_raw[i] = p.items_flat[qb + (L - 1 - i)];   // pos 0 = most recent item
+        if (MASKS && tid < 256) { uint32_t acc = 0; for (uint32_t b = 0; b < L; ++b) if ((tid >> b) & 1) acc += L - b; wlut[tid] = (uint8_t)acc; }
         __syncthreads();
         for (uint32_t pos = tid; pos < L; pos += BLOCK) {
             const uint64_t raw = q_raw[pos];
@@ -443,7 +451,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                 for (uint32_t e = tid; e < cnt; e += BLOCK) {
                     const SlotT v = list[e]; const uint32_t r = (uint32_t)(v >> NB);
                     rmin = min(rmin, r); rmax = max(rmax, r);
-                    const int res = sess_insert<SlotT>(stab, smask, NB, r, (uint32_t)(v & num_mask));
+                    const int res = sess_insert<SlotT, MASKS>(stab, smask, NB, r, (uint32_t)(v & num_mask));
                     if (res < 0) ovf = true; else fresh += (uint32_t)res;
                 }
             }
@@ -464,13 +472,13 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                     if (e < P) {
                         while (e >= l_pre[pos + 1]) ++pos;
                         r[u] = ix.post_rank[l_base[pos] + (e - l_pre[pos])];
-                        w[u] = L - pos;
+                        w[u] = MASKS ? (1u << pos) : L - pos;
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     if (w[u] && r[u] >= x_lo) {
-                        const int res = sess_insert<SlotT>(stab, smask, NB, r[u], w[u]);
+                        const int res = sess_insert<SlotT, MASKS>(stab, smask, NB, r[u], w[u]);
                         if (res < 0) ovf = true; else fresh += (uint32_t)res;
                     }
                 }
@@ -505,7 +513,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
             const int nbits = rbits + bits_for(STAGE == 2 ? L * (L + 1) / 2 : misc[S_SUMW]);
             auto comp = [&](uint32_t i, auto& key) {
                 const SlotT s = stab[i]; const uint32_t r = (uint32_t)(s >> NB);
-                key = ((decltype(key + 0))(s & num_mask) << rbits) | (r - tau);
+                key = ((decltype(key + 0))num_of(s) << rbits) | (r - tau);
                 return s != SEMPTY && r >= tau; };
             if (nbits <= 32) kappa = block_select_desc<BLOCK, uint32_t>(comp, sslots, nbits, p.k, hist, misc);
             else kappa = block_select_desc<BLOCK, unsigned long long>(comp, sslots, nbits, p.k, hist, misc);
@@ -518,7 +526,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const uint32_t r = (uint32_t)(sv[u] >> NB);
-                const bool sel = sv[u] != SEMPTY && r >= tau && ((((unsigned long long)(sv[u] & num_mask)) << rbits) | (r - tau)) >= kappa;
+                const bool sel = sv[u] != SEMPTY && r >= tau && ((((unsigned long long)num_of(sv[u])) << rbits) | (r - tau)) >= kappa;
                 bm[u] = __ballot(sel); total += (uint32_t)__popcll(bm[u]);
             }
             uint32_t base = 0;
@@ -528,7 +536,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                 if ((bm[u] >> lane) & 1ull) {
                     const uint32_t at = base + (uint32_t)__popcll(bm[u] & ((1ull << lane) - 1ull));
                     if (STAGE == 1) ((SlotT*)sh.cand)[(size_t)q * p.m + at] = sv[u]; else nbl[at] = sv[u];
-                    if (STAGE == 0 && p.nb_rank) { p.nb_rank[(size_t)q * p.k + at] = (uint32_t)(sv[u] >> NB); p.nb_num[(size_t)q * p.k + at] = (uint32_t)(sv[u] & num_mask); }
+                    if (STAGE == 0 && p.nb_rank) { p.nb_rank[(size_t)q * p.k + at] = (uint32_t)(sv[u] >> NB); p.nb_num[(size_t)q * p.k + at] = num_of(sv[u]); }
                 }
                 base += (uint32_t)__popcll(bm[u]);
             }
@@ -582,7 +590,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                     if (it == qv0) return 0; if (it == qv1) return 1; if (it == qv2) return 2; if (it == qv3) return 3;
                     for (uint32_t pp = 4; pp < L; ++pp) if (q_idx[pp] == it) return pp;
                     return 0xFFFFu; };
-                auto load_group = [&](uint32_t g0, uint32_t& num, uint32_t& len, OffT& o0) {
+                auto load_group = [&](uint32_t g0, uint32_t& num, uint32_t& len, OffT& o0) {   // (MASKS: num = the position set)
                     const uint32_t j = g0 + lane; num = 0; len = 0; o0 = 0;
                     if (j < K) { const SlotT s = STAGE == 3 ? ((const SlotT*)sh.nb)[(size_t)q * p.k + j] : (parts == 1 ? nbl[j] : nb_spill[j]); const uint32_t r = (uint32_t)(s >> NB); num = (uint32_t)(s & num_mask);
                                  o0 = row_off[r]; len = (uint32_t)(row_off[r + 1] - o0); } };
@@ -614,6 +622,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                     // before any is consumed (one memory latency per batch, not per element).  B1 runs over every batch,
                     // then B2; the last batch is still in registers for B2, earlier ones (only when the group holds more
                     // than one batch of elements) are gathered again, from L1/L2 by then.
+                    constexpr int ROW_CACHE = MASKS ? 8 : 4;        // row elements per lane kept in registers per batch
                     constexpr uint32_t BATCH = ROW_CACHE * 64;
                     uint32_t itc[ROW_CACHE], own[ROW_CACHE / 4];   // owner lanes packed 4 x 8 bit
                     auto gather = [&](uint32_t base0) {
@@ -636,18 +645,22 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                     // (sharded pipeline: stage B stops after B1 and publishes the partial positions; stage C starts at B2 with
                     //  the all-reduced positions)
                     int wrow = 0;
-                    if (STAGE == 3) { const int mp = g0 + lane < K ? sh.minpos[(size_t)q * (p.k + 1) + g0 + lane] : MINPOS_NONE;
-                                      wrow = (mp < 99 ? 10 - (mp + 1) : 0) * (int)num; }
-                    const uint32_t step0 = STAGE == 3 ? nbat : 0, step1 = STAGE == 2 ? nbat : 2 * nbat;
+                    constexpr bool SKIP_B1 = MASKS || STAGE == 3;   // first-match positions already known
+                    if (MASKS) { const int mp = num ? __ffs((int)num) - 1 : MINPOS_NONE;   // lowest set position = first match (Q4)
+                                 if (STAGE == 2 && g0 + lane < K) sh.minpos[(size_t)q * (p.k + 1) + g0 + lane] = mp;
+                                 wrow = (mp < 99 ? 10 - (mp + 1) : 0) * (int)wlut[num]; }
+                    else if (STAGE == 3) { const int mp = g0 + lane < K ? sh.minpos[(size_t)q * (p.k + 1) + g0 + lane] : MINPOS_NONE;
+                                           wrow = (mp < 99 ? 10 - (mp + 1) : 0) * (int)num; }
+                    const uint32_t step0 = SKIP_B1 ? nbat : 0, step1 = STAGE == 2 ? (MASKS ? 0u : nbat) : 2 * nbat;
                     for (uint32_t step = step0; step < step1; ++step) {
                         const bool b2 = step >= nbat;
-                        if (STAGE != 3 && step == nbat) {
+                        if (!SKIP_B1 && step == nbat) {
                             const uint32_t mp = wmin[lane];
                             if (STAGE == 0 && g0 + lane < K && mp == 0xFFFFu) misc[S_ERR] = 1;   // inconsistent index (reference: unwrap panic, mod.rs:138)
                             const int p1 = (int)mp + 1;
                             wrow = (p1 < 100 ? 10 - p1 : 0) * (int)num;            // 10 * linear_score(pos) * numerator, exact (Q3)
                             SRN_TICK(11);
-                        } else gather((STAGE == 3 ? step - nbat : (b2 ? step - nbat - 1 : step)) * BATCH);
+                        } else gather((SKIP_B1 ? step - nbat : (b2 ? step - nbat - 1 : step)) * BATCH);
 #pragma unroll
                         for (int u = 0; u < ROW_CACHE; ++u) {
                             const uint32_t owner = (own[u >> 2] >> ((u & 3) * 8)) & 63u;
@@ -655,7 +668,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                             else { const int w = __shfl(wrow, (int)owner, 64); if (itc[u] != EMPTY32) accumulate(itc[u], w); }
                         }
                     }
-                    if (STAGE == 2 && g0 + lane < K) sh.minpos[(size_t)q * (p.k + 1) + g0 + lane] = wmin[lane] == 0xFFFFu ? MINPOS_NONE : (int)wmin[lane];
+                    if (!MASKS && STAGE == 2 && g0 + lane < K) sh.minpos[(size_t)q * (p.k + 1) + g0 + lane] = wmin[lane] == 0xFFFFu ? MINPOS_NONE : (int)wmin[lane];
                     num = nnum; len = nlen; o0 = no0;
                     SRN_TICK(12);
                 }
@@ -927,14 +940,14 @@ static int ensure(char** p, size_t* have, size_t need) {
 static inline uint32_t round_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
 static inline int bits_host(uint64_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
 
-template <int BLOCK, bool GLOBAL_TABLES, int STAGE = 0>
+template <int BLOCK, bool GLOBAL_TABLES, int STAGE = 0, bool MASKS = false>
 static hipError_t launch_variant(bool slot64, bool off64, dim3 grid, size_t lds, hipStream_t st, const DeviceIndex& di,
                                  const LaunchParams& p, const KernelCfg& c, const uint32_t* qlist, const uint32_t* qn,
                                  uint32_t* retry_list, uint32_t* retry_cnt, char* gs, unsigned long long gstride, char* spill,
                                  const ShardIO& sh = ShardIO{}) {
 #define SRN_LAUNCH(SLOT, OFF)                                                                                             \
     do {                                                                                                                  \
-        auto kern = vmis_predict_kernel<BLOCK, SLOT, OFF, GLOBAL_TABLES, STAGE>;                                                 \
+        auto kern = vmis_predict_kernel<BLOCK, SLOT, OFF, GLOBAL_TABLES, STAGE, MASKS>;                                                 \
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
         if (e != hipSuccess) return e;                                                                                    \
         hipLaunchKernelGGL(kern, grid, dim3(BLOCK), lds, st, di, p, c, qlist, qn, retry_list, retry_cnt, gs, gstride, spill, sh); \
@@ -955,13 +968,15 @@ static inline uint32_t prime_at_most(uint32_t n) { while (n > 2 && !is_prime(n))
 static inline uint32_t prime_at_least(uint64_t n) { uint32_t v = (uint32_t)std::min<uint64_t>(n, 0x3FFFFFFFull); while (!is_prime(v)) ++v; return v; }
 
 struct Geometry {
-    KernelCfg c{}; bool slot64 = false; uint32_t slot_bytes = 4; size_t lds = 0;
+    KernelCfg c{}; bool slot64 = false, masks = false; uint32_t slot_bytes = 4; size_t lds = 0;
     uint64_t need_sess = 0, need_item = 0; bool sess_may_overflow = false, item_may_overflow = false;
 };
 // LDS layout + table sizes for one launch (all blocks alike).  min_region_b: extra room the caller needs in region B.
 static int make_geometry(const DeviceState* d, const FlatIndex& ix, const LaunchParams& p, uint32_t min_region_b, Geometry& g) {
     const uint64_t Lmax = p.max_len;
-    const int num_bits = std::max(1, bits_host(Lmax * (Lmax + 1) / 2));
+    // position-set slots (no first-match pass over the rows) need <= 8 evolving items and lists complete above x_lo
+    g.masks = Lmax <= 8 && p.m <= ix.m_index && !getenv("SRN_NO_MASKS");
+    const int num_bits = g.masks ? (int)Lmax : std::max(1, bits_host(Lmax * (Lmax + 1) / 2));
     const int rank_bits = std::max(1, bits_host(ix.n_kept ? ix.n_kept - 1 : 0));
     g.slot64 = rank_bits + num_bits > 32 || ix.n_kept >= 0xFFFFFFF0ull;
     g.slot_bytes = g.slot64 ? 8 : 4;
@@ -1067,13 +1082,17 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     }
     hipEvent_t* ev = w->ev[w->calls % Workspace::RING];
     HIP_TRY(hipEventRecord(ev[0], st));
-    HIP_TRY((launch_variant<kBlock, false>(slot64, d->off64, dim3(grid), lds, st, d->di, p, c, nullptr, nullptr,
-                                            w->retry_list, w->retry_cnt, nullptr, 0, spill)));
+    if (geo.masks) HIP_TRY((launch_variant<kBlock, false, 0, true>(slot64, d->off64, dim3(grid), lds, st, d->di, p, c, nullptr, nullptr,
+                                                                   w->retry_list, w->retry_cnt, nullptr, 0, spill)));
+    else HIP_TRY((launch_variant<kBlock, false, 0, false>(slot64, d->off64, dim3(grid), lds, st, d->di, p, c, nullptr, nullptr,
+                                                           w->retry_list, w->retry_cnt, nullptr, 0, spill)));
     HIP_TRY(hipEventRecord(ev[1], st));
     if (may_overflow) {
         const size_t lds_g = c.off_a;
-        HIP_TRY((launch_variant<kBlock, true>(slot64, d->off64, dim3(retry_blocks), lds_g, st, d->di, p, cg, w->retry_list, w->retry_cnt,
-                                               nullptr, nullptr, w->gscratch, g_stride, nullptr)));
+        if (geo.masks) HIP_TRY((launch_variant<kBlock, true, 0, true>(slot64, d->off64, dim3(retry_blocks), lds_g, st, d->di, p, cg, w->retry_list,
+                                                                      w->retry_cnt, nullptr, nullptr, w->gscratch, g_stride, nullptr)));
+        else HIP_TRY((launch_variant<kBlock, true, 0, false>(slot64, d->off64, dim3(retry_blocks), lds_g, st, d->di, p, cg, w->retry_list,
+                                                              w->retry_cnt, nullptr, nullptr, w->gscratch, g_stride, nullptr)));
         HIP_TRY(hipMemcpyAsync(w->h_retry, w->retry_cnt, 4, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipEventRecord(ev[2], st));
@@ -1107,9 +1126,11 @@ int device_shard_stage(DeviceState* d, const FlatIndex& ix, int stage, const Lau
     const uint32_t grid = (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * std::min<uint32_t>(blocks_per_cu, 2048 / kBlock) * 4);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;
-    if (stage == 1) e = launch_variant<kBlock, false, 1>(geo.slot64, d->off64, dim3(grid), geo.lds, st, d->di, p, geo.c, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, sh);
-    else if (stage == 2) e = launch_variant<kBlock, false, 2>(geo.slot64, d->off64, dim3(grid), geo.lds, st, d->di, p, geo.c, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, sh);
-    else if (stage == 3) e = launch_variant<kBlock, false, 3>(geo.slot64, d->off64, dim3(grid), geo.lds, st, d->di, p, geo.c, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, sh);
+#define SRN_STAGE(N, M) launch_variant<kBlock, false, N, M>(geo.slot64, d->off64, dim3(grid), geo.lds, st, d->di, p, geo.c, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, sh)
+    if (stage == 1) e = geo.masks ? SRN_STAGE(1, true) : SRN_STAGE(1, false);
+    else if (stage == 2) e = geo.masks ? SRN_STAGE(2, true) : SRN_STAGE(2, false);
+    else if (stage == 3) e = geo.masks ? SRN_STAGE(3, true) : SRN_STAGE(3, false);
+#undef SRN_STAGE
     else return fail(SRN_EINVAL, "bad stage");
     if (e != hipSuccess) return fail(SRN_EHIP, std::string("shard stage launch: ") + hipGetErrorString(e));
     return SRN_OK;
