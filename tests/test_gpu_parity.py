@@ -56,8 +56,22 @@ def test_kat1_should_train_and_predict():
         assert r.score == pytest.approx(1.751319134149782, rel=1e-12)
 
 
+@pytest.fixture(params=["default", "no_masks", "no_hot", "hot64"])
+def kernel_path(request, monkeypatch):
+    """The kernel picks code paths per launch: position-set slots (sessions <= 8 items) vs numerator slots + first-match
+    pass; direct-mapped accumulators for popular items vs hash only.  The knobs force each combination."""
+    if request.param == "no_masks":
+        monkeypatch.setenv("SRN_NO_MASKS", "1")
+    elif request.param == "no_hot":
+        monkeypatch.setenv("SRN_HOT_SLOTS", "0")
+    elif request.param == "hot64":
+        monkeypatch.setenv("SRN_HOT_SLOTS", "64")
+        monkeypatch.setenv("SRN_NO_MASKS", "1")
+    return request.param
+
+
 @pytest.mark.parametrize("tied", [False, True])
-def test_small_random_vs_oracle(tied):
+def test_small_random_vs_oracle(tied, kernel_path):
     import serenade_amd as sa
     O = _oracle()
     off, items, ts, ids = small_dataset(11 + tied, n_sessions=3000, n_items=400, tied_timestamps=tied)
@@ -69,7 +83,7 @@ def test_small_random_vs_oracle(tied):
             _check_batch(gix, oix, qs, k, m, n)
 
 
-def test_long_sessions_negative_weights_and_duplicates():
+def test_long_sessions_negative_weights_and_duplicates(kernel_path):
     """L up to 14: linear_score goes to 0 at position 10 and negative beyond (Q3); duplicates (Q1/Q2)."""
     import serenade_amd as sa
     O = _oracle()
@@ -153,7 +167,7 @@ def test_retry_path_with_global_tables():
     assert (res["stats"][6:, 7] == 0).all()
 
 
-def test_synthetic_tiny_config_matches_oracle():
+def test_synthetic_tiny_config_matches_oracle(kernel_path):
     """The bench generator's `tiny` config end to end (u64 hashed ids, unique timestamps, k/m cuts hit)."""
     import serenade_amd as sa
     from serenade_amd import synth
