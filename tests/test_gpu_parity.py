@@ -249,3 +249,34 @@ def test_evaluator_binary_on_reference_example(tmp_path):
                                   [0.005, 0.005, 0.0001, 0.002, 0.0005, 0.005, 0.003, 0.001]):
             assert abs(got - want) <= tol + 1e-9, vals
     assert any(l.startswith("p90 (microseconds)") for l in lines)
+
+
+@pytest.mark.parametrize("config,n_check", [("cfg2", 6000), ("cfg3", 3000)])
+def test_baseline_configs_full_size(config, n_check, monkeypatch):
+    """BASELINE.json configs[1] (2 M interactions / 100 K items, k=500 m=1000) and configs[2] (60 M / 1.76 M, k=1500 m=2500,
+    idf_weighting=2) at FULL size: a sample of the evaluator-style query stream against the canonical oracle (ids, order,
+    counters exact; scores 1e-12), and -- size-independent property -- the two independent first-match implementations
+    (position-set slots vs numerator slots + row pass) must agree bit for bit on a much larger sample."""
+    import serenade_amd as sa
+    from serenade_amd import synth
+    O = _oracle()
+    inter, n_items, k, m, idfw = synth.CONFIGS[config]
+    off, items, ts = synth.training_sessions(inter, n_items)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw)
+    qi, qo = synth.queries(12000, n_items)
+    nq = len(qo) - 1
+    oix = O.OracleIndex(off, items, ts, m, 34, idfw, fast=True)
+    res = sa.predict_batch_debug(gix, (qi[:qo[n_check]], qo[:n_check + 1]), k, m, synth.HOW_MANY, neighbours=False)
+    ref = oix.predict_batch("canonical", qi[:qo[n_check]], qo[:n_check + 1], k, m, synth.HOW_MANY, threads=16, want_stats=True)
+    assert np.array_equal(res["counts"], ref["counts"])
+    assert np.array_equal(res["ids"], ref["ids"])
+    np.testing.assert_allclose(res["scores"], ref["scores"], rtol=SCORE_RTOL, atol=0)
+    assert np.array_equal(res["stats"][:, :7].astype(np.uint64), ref["stats"])
+    assert (res["stats"][:, 1] == m).any() and (res["stats"][:, 2] == k).any()      # both cuts are exercised at this size
+    a = sa.predict_batch(gix, (qi, qo), k, m, synth.HOW_MANY)
+    monkeypatch.setenv("SRN_NO_MASKS", "1")
+    monkeypatch.setenv("SRN_HOT_SLOTS", "0")
+    b = sa.predict_batch(gix, (qi, qo), k, m, synth.HOW_MANY)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert nq > 30000
