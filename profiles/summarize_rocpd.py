@@ -11,10 +11,10 @@ print("%-110s %8s %14s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "pc
 for name, calls, total, avg, pct in db.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
     print("%-110s %8d %14.1f %12.2f %6.2f%%" % (name[:110], calls, total, avg, pct))
 rows = db.execute("select grid_x, workgroup_x, lds_size, vgpr_count, sgpr_count, scratch_size, (end - start) / 1e6 from kernels "
-                  "where name like '%vmis_predict_kernel%false>%' and grid_x >= 1024 * workgroup_x order by start").fetchall()
+                  "where name like '%vmis_predict_kernel%' and name like '%int, false%' and grid_x >= 1024 * workgroup_x order by start").fetchall()
 if rows:
     ms = [r[6] for r in rows]
-    print("\n# full-batch launches of vmis_predict_kernel<..., GLOBAL_TABLES=false>: %d" % len(rows))
+    print("\n# full-batch launches of vmis_predict_kernel<..., GLOBAL_TABLES=false, ...>: %d" % len(rows))
     print("grid_threads=%d workgroup=%d lds_bytes=%d vgpr=%d sgpr=%d scratch=%d" % rows[0][:6])
     print("duration_ms: " + " ".join("%.3f" % v for v in ms))
     print("avg_ms=%.3f min_ms=%.3f max_ms=%.3f" % (sum(ms) / len(ms), min(ms), max(ms)))
