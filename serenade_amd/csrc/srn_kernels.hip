@@ -143,23 +143,36 @@ __device__ KeyT block_select_desc(F keyfn, uint32_t n, int nbits, uint32_t r, ui
         }
         __syncthreads();
         if (tid < 64) {   // lane owns bins [32 lane, 32 lane + 32); suffix sums from the top bin down
-            constexpr int PER = SEL_BINS / 64;
-            uint32_t c[PER], s = 0;
+            constexpr int PER = SEL_BINS / 64;   // 32 bins per lane, kept as 4 group sums of 8 (not 32 registers)
+            uint32_t g[4];
 #pragma unroll
-            for (int j = 0; j < PER; ++j) { c[j] = hist[sel_word(PER * tid + j)]; s += c[j]; }
+            for (int gi = 0; gi < 4; ++gi) { uint32_t t = 0;
 #pragma unroll
-            for (int j = 0; j < PER; ++j) hist[sel_word(PER * tid + j)] = 0;
+                for (int j = 0; j < 8; ++j) t += hist[sel_word(PER * tid + gi * 8 + j)];
+                g[gi] = t; }
+            const uint32_t s = g[0] + g[1] + g[2] + g[3];
             uint32_t inc = s;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_down(inc, d, 64); if (tid + d < 64) inc += t; }
             uint32_t above = inc - s;   // entries in bins owned by higher lanes
-            if (above < remain && remain <= above + s) {   // the target bin is one of mine
+            if (above < remain && remain <= above + s) {   // the target bin is one of mine: find the group of 8, then the bin
+                int gsel = -1; uint32_t ab = above;
 #pragma unroll
-                for (int j = PER - 1; j >= 0; --j) {
-                    if (above < remain && remain <= above + c[j]) { misc[S_SELD] = PER * tid + j; misc[S_SELR] = remain - above; }
-                    above += c[j];
+                for (int gi = 3; gi >= 0; --gi) {
+                    if (gsel < 0 && ab < remain && remain <= ab + g[gi]) { gsel = gi; above = ab; }
+                    ab += g[gi];
+                }
+                uint32_t cj[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) cj[j] = hist[sel_word(PER * tid + gsel * 8 + j)];
+#pragma unroll
+                for (int j = 7; j >= 0; --j) {
+                    if (above < remain && remain <= above + cj[j]) { misc[S_SELD] = PER * tid + gsel * 8 + j; misc[S_SELR] = remain - above; }
+                    above += cj[j];
                 }
             }
+#pragma unroll 8
+            for (int j = 0; j < PER; ++j) hist[sel_word(PER * tid + j)] = 0;
         }
         __syncthreads();
         prefix = (KeyT)((prefix << w) | (KeyT)misc[S_SELD]);
@@ -718,10 +731,10 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                     // gather first (up to 4 chunks' idf loads in flight per lane), then score + append.  Once the
                     // threshold score is positive, an item whose upper bound idf_hi * acc / denom (same operations and
                     // rounding as the score, so monotone and safe) is below it is dropped without touching idf[].
-                    for (uint32_t ub = u; ub < u_end; ub += 4) {   // sub-batches of 4 chunks, no barrier in between
-                    uint32_t its[4]; int accs[4]; ItemMeta metas[4];
+                    for (uint32_t ub = u; ub < u_end; ub += 2) {   // sub-batches of 2 chunks, no barrier in between
+                    uint32_t its[2]; int accs[2]; ItemMeta metas[2];
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) {
+                    for (int x = 0; x < 2; ++x) {
                         its[x] = EMPTY32; accs[x] = 0; metas[x] = ItemMeta{0.0, 0u, 0u};
                         const uint32_t i = (ub + x) * BLOCK + tid;
                         if (ub + x < u_end && i < n_entries) {
@@ -735,7 +748,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                         }
                     }
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) {
+                    for (int x = 0; x < 2; ++x) {
                         if (ub + x < u_end) {   // block-uniform
                             const uint32_t tie = metas[x].id_rank;   // ties are broken by ascending public id
                             bool take = false; uint64_t sk = 0;
