@@ -666,7 +666,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                                            wrow = (mp < 99 ? 10 - (mp + 1) : 0) * (int)num; }
                     const uint32_t step0 = SKIP_B1 ? nbat : 0, step1 = STAGE == 2 ? (MASKS ? 0u : nbat) : 2 * nbat;
                     for (uint32_t step = step0; step < step1; ++step) {
-                        const bool b2 = step >= nbat;
+                        const bool b2 = SKIP_B1 || step >= nbat;   // (compile-time true when the first-match pass is not needed)
                         if (!SKIP_B1 && step == nbat) {
                             const uint32_t mp = wmin[lane];
                             if (STAGE == 0 && g0 + lane < K && mp == 0xFFFFu) misc[S_ERR] = 1;   // inconsistent index (reference: unwrap panic, mod.rs:138)
