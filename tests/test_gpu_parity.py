@@ -280,3 +280,39 @@ def test_baseline_configs_full_size(config, n_check, monkeypatch):
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
     assert nq > 30000
+
+
+def test_concurrent_host_threads_share_one_index():
+    """The handle is re-entrant like the reference's Arc<VMISIndex> shared by actix workers (src/bin/serving.rs:62-94):
+    several host threads call srn_predict / srn_predict_batch on one index at the same time (ctypes releases the GIL)."""
+    import threading
+    import serenade_amd as sa
+    O = _oracle()
+    off, items, ts, ids = small_dataset(61, n_sessions=4000, n_items=500)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, 200, 12, 1.0)
+    oix = O.OracleIndex(off, items, ts, 200, 12, 1.0)
+    qs = random_queries(13, ids, 240, max_len=5, unknown_rate=0.02)
+    flat, qoff = flatten(qs)
+    ref = oix.predict_batch("canonical", flat, qoff, 50, 200, 21, threads=4)
+    errors = []
+
+    def worker(t):
+        try:
+            for rep in range(3):
+                if t % 2 == 0:
+                    ids_, sc_, cnt_ = sa.predict_batch(gix, (flat, qoff), 50, 200, 21)
+                    assert np.array_equal(cnt_, ref["counts"]) and np.array_equal(ids_, ref["ids"])
+                else:
+                    for q in range(t, len(qs), 8):
+                        recs = sa.predict(gix, qs[q], 50, 200, 21, False)
+                        n = int(ref["counts"][q])
+                        assert [r.id for r in recs] == ref["ids"][q, :n].tolist()
+        except Exception as e:  # pragma: no cover
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
