@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--mode", default="replicas", choices=["replicas", "item-sharded"],
                     help="replicas: every GPU holds the index and serves its own queries (default, no data-path collective); "
                          "item-sharded: the north-star capacity mode, index split by item over the GPUs, 3 RCCL collectives per batch")
+    ap.add_argument("--builder", default="gpu", choices=["gpu", "host"], help="index construction: rocPRIM sorts on the GPU, or the host builder (same bytes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--traffic-file", default=None, help="profiles/*_traffic_<config>.json from the PMC passes (default: newest match)")
@@ -98,7 +99,7 @@ def main():
         if args.batch == 131072:
             args.batch = 16384          # the exchange buffers are m * 4 B per query and shard
     else:
-        index = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw, device=local_rank)
+        index = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw, device=local_rank, builder=args.builder)
     t_build = time.time() - t0
     info = index.info
 
@@ -217,7 +218,7 @@ def main():
                    "sessions": int(info["n_sessions_kept"]), "items": int(info["n_items"]), "interactions": int(info["nnz_rows"]),
                    "posting_entries": int(info["nnz_postings"]), "index_bytes_hbm": int(info["device_bytes"]),
                    "parallelism": "query-sharded replicas x%d (no data-path collective)" % args.gpus,
-                   "setup_s": {"generate": round(t_gen, 2), "index_build_upload": round(t_build, 2)}},
+                   "setup_s": {"generate": round(t_gen, 2), "index_build_upload": round(t_build, 2), "index_builder": "item-sharded host" if sharded_mode else args.builder}},
         "roofline": {"bound": "hbm", "kernel": "vmis_predict_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE)",
                      "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_per_launch,

@@ -108,6 +108,10 @@ void srn_sessions_free(srn_sessions_t* s);
  * keeps a host-only index (build / save / inspect; predict then fails with SRN_ENODEV). */
 int srn_index_build(const srn_sessions_view_t* sessions, size_t m_index, size_t max_session_len,
                     double idf_weighting, int device, srn_index_t** out);
+/* The same index built on the GPU (rocPRIM radix sorts instead of host loops; < 2^32 sessions and interactions).
+ * Bit-identical to srn_index_build(); 582 M interactions take seconds instead of ~45 s on one host core. */
+int srn_index_build_gpu(const srn_sessions_view_t* sessions, size_t m_index, size_t max_session_len,
+                        double idf_weighting, int device, srn_index_t** out);
 /* VMISIndex::new_from_csv(path, m_most_recent_sessions, idf_weighting) (vmis_index.rs:38-83);
  * max_session_len = 0 selects the exact p99.5 of the session lengths. */
 int srn_index_new_from_csv(const char* path, size_t m_most_recent_sessions, double idf_weighting,

@@ -101,6 +101,19 @@ int srn_index_build(const srn_sessions_view_t* sessions, size_t m_index, size_t 
         *out = ix; return SRN_OK; });
 }
 
+int srn_index_build_gpu(const srn_sessions_view_t* sessions, size_t m_index, size_t max_session_len, double idf_weighting,
+                        int device, srn_index_t** out) {
+    return guarded([&]() -> int {
+        if (!sessions || !out) return fail(SRN_EINVAL, "null argument");
+        if (device < 0) return fail(SRN_ENODEV, "the GPU index builder needs a device");
+        *out = nullptr;
+        srn_index* ix = new srn_index();
+        int rc = build_flat_index_gpu(*sessions, m_index, max_session_len, idf_weighting, device, ix->flat);
+        if (rc == SRN_OK) { ix->dev = device_attach(ix->flat, device); ix->device = device; if (!ix->dev) rc = SRN_EHIP; }
+        if (rc) { delete ix; return rc; }
+        *out = ix; return SRN_OK; });
+}
+
 int srn_index_new_from_csv(const char* path, size_t m_most_recent_sessions, double idf_weighting, size_t max_session_len,
                            int device, srn_index_t** out) {
     return guarded([&]() -> int {

@@ -41,15 +41,16 @@ class VMISIndex:
         return cls(h)
 
     @classmethod
-    def from_sessions(cls, sess_off, items, max_ts, m_index, max_session_len, idf_weighting=1.0, device=0):
-        """prepare_hashmap (vmis_index.rs:422-528) on sessions already in (ascending, de-duplicated) row form."""
+    def from_sessions(cls, sess_off, items, max_ts, m_index, max_session_len, idf_weighting=1.0, device=0, builder="host"):
+        """prepare_hashmap (vmis_index.rs:422-528) on sessions already in (ascending, de-duplicated) row form.
+        builder="gpu" constructs the identical index with rocPRIM sorts on the device (needs device >= 0)."""
         sess_off, items, max_ts = capi.as_u64(sess_off), capi.as_u64(items), capi.as_u32(max_ts)
         if len(sess_off) != len(max_ts) + 1 or (len(sess_off) and int(sess_off[-1]) != len(items)):
             raise ValueError("inconsistent session CSR")
         v = capi.SessionsView(sess_off.ctypes.data, items.ctypes.data, max_ts.ctypes.data, len(max_ts))
         h = C.c_void_p()
-        capi.check(capi.lib().srn_index_build(C.byref(v), int(m_index), int(max_session_len), float(idf_weighting),
-                                              int(device), C.byref(h)))
+        build = capi.lib().srn_index_build_gpu if builder == "gpu" else capi.lib().srn_index_build
+        capi.check(build(C.byref(v), int(m_index), int(max_session_len), float(idf_weighting), int(device), C.byref(h)))
         return cls(h)
 
     @classmethod
