@@ -121,7 +121,10 @@ int srn_index_new_from_csv(const char* path, size_t m_most_recent_sessions, doub
         Sessions s; int rc = sessions_from_tsv(path, s); if (rc) return rc;
         if (max_session_len == 0) max_session_len = sessions_length_quantile(s.off.data(), s.ts.size(), 0.995);
         srn_sessions_view_t v{s.off.data(), s.items.data(), s.ts.data(), s.ts.size()};
-        return srn_index_build(&v, m_most_recent_sessions, max_session_len, idf_weighting, device, out); });
+        // same bytes either way; the GPU builder covers what fits 32-bit ranks and offsets
+        const bool gpu = device >= 0 && s.ts.size() < 0xFFFFFFFFull && s.items.size() < 0xFFFFFFFFull;
+        return gpu ? srn_index_build_gpu(&v, m_most_recent_sessions, max_session_len, idf_weighting, device, out)
+                   : srn_index_build(&v, m_most_recent_sessions, max_session_len, idf_weighting, device, out); });
 }
 
 int srn_index_save(const srn_index_t* idx, const char* path) {
