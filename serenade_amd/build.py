@@ -22,12 +22,26 @@ def _stale(target, deps):
 
 
 def build_hip(force=False, verbose=False):
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
-    if force or _stale(LIB, deps):
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-               "-Wno-unused-value", "-o", LIB] + srcs
+    """One object per source (rebuilt only when that source or a header changed), then one link."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    extra = os.environ.get("SRN_CFLAGS", "").split()          # experiments only (e.g. -DSRN_ABLATE=1)
+    objdir = os.path.join(CSRC, "_obj")
+    headers = [os.path.join(CSRC, h) for h in HEADERS]
+    if not force and not extra and not _stale(LIB, [os.path.join(CSRC, n) for n in SOURCES] + headers):
+        return LIB                                              # (the objects do not travel to the GPU box; the library does)
+    os.makedirs(objdir, exist_ok=True)
+    objs, relink = [], force or not os.path.exists(LIB)
+    for name in SOURCES:
+        src, obj = os.path.join(CSRC, name), os.path.join(objdir, name + ".o")
+        if force or extra or _stale(obj, [src] + headers):
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-value"] + extra + ["-c", "-o", obj, src]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            relink = True
+        objs.append(obj)
+    if relink or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -74,13 +74,17 @@ struct ItemMeta {   // one 16-byte gather per scored item
     uint32_t id_rank;   // rank of the public id (ascending): tie-break key of the final ranking
     uint32_t attr;      // SRN_ATTR_* byte
 };
+struct alignas(16) RowQuad { uint32_t x, y, z, w; };
 struct DeviceIndex {  // pointers into HBM; passed by value to the kernels
     const IdSlot* id_table; uint32_t id_mask;
     const ItemMeta* meta;        // [n_items] by dense idx
     const uint64_t* id_sorted;   // [n_items] public ids ascending (indexed by id_rank)
     const uint64_t* post_off; const uint32_t* post_rank;
-    const void* row_off;  // uint32_t* or uint64_t* (offsets_64bit)
-    const uint32_t* row_items;
+    // Rows in HBM: one 64-byte, 64-byte-aligned slot per session, addressed by recency rank -- ONE line fetch per
+    // neighbour and no offset lookup.  word 0 = row length; length <= 15: words 1..15 hold the items; longer rows:
+    // word 1 = offset (in items) of items 14.. in row_ext, words 2..15 = items 0..13.
+    const RowQuad* row_slots;   // 4 quads per slot
+    const uint32_t* row_ext;
     uint32_t n_items, n_kept;
     double idf_hi, idf_lo;   // max / min over items of (idf > 0 ? idf : 1)
 };

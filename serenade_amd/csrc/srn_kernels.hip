@@ -52,6 +52,7 @@ struct KernelCfg {
     uint32_t sess_slots, item_slots;   // session table: power of two; item hash table: 4 * item_buckets slots
     uint32_t item_buckets;             // prime number of 4-slot buckets (double hashing needs a full cycle)
     uint32_t hot_slots;                // direct-mapped accumulators for dense idx < hot_slots (idx = popularity order)
+    uint32_t sketch_slots, sketch_shift;   // power-of-two upper-bound words for every other item (0 = none); 32 - log2
     uint32_t sum_bits;                 // hot accumulator = (touch count << sum_bits) + signed weight sum
     uint32_t num_bits;                 // low bits of a session slot that hold the numerator
     uint32_t q_cap;                    // capacity of the per-query item arrays (>= max_len, multiple of 4)
@@ -60,7 +61,7 @@ struct KernelCfg {
 
 // LDS scalar slots
 enum { S_CNT = 0, S_OVF, S_XLO, S_RMAX, S_U, S_P, S_SUMW, S_SELD, S_SELR, S_NB, S_ICNT, S_CCNT, S_I, S_HAVE_T, S_TIDX,
-       S_ERR, S_TKEY_LO, S_TKEY_HI, S_COVF };
+       S_ERR, S_TKEY_LO, S_TKEY_HI, S_COVF, S_SORTED, S_LIVE };
 
 template <typename T> struct SlotTraits;
 template <> struct SlotTraits<uint32_t> { static constexpr uint32_t EMPTY = 0xFFFFFFFFu; };
@@ -75,6 +76,9 @@ __device__ __forceinline__ uint64_t dev_mix64(uint64_t x) {
 __device__ __forceinline__ uint32_t hash_start(uint32_t key, uint32_t mask) { return ((key * 0x9E3779B1u) >> 7) & mask; }
 __device__ __forceinline__ uint32_t hash_step(uint32_t key, uint32_t mask) { return (((key * 0x85EBCA6Bu) >> 9) | 1u) & mask; }
 __device__ __forceinline__ uint32_t hash_part(uint32_t key, uint32_t parts) { return __umulhi(key * 0xC2B2AE35u, parts); }
+// sketch word of a non-hot item: full-rate 24-bit multiply (items that differ only above bit 23 share a word -- still an upper bound)
+// (hipcc's __umul24 yields a signed int: without the cast the shift is arithmetic and half the indices go negative)
+__device__ __forceinline__ uint32_t sketch_hash(uint32_t it, uint32_t shift) { return (uint32_t)__umul24(it, 0x9E3779u) >> shift; }
 __device__ __forceinline__ int bits_for(uint32_t v) { return v ? 32 - __clz((int)v) : 0; }
 
 __device__ __forceinline__ uint64_t score_key(double s) {   // order-preserving f64 -> u64
@@ -328,6 +332,7 @@ __device__ __forceinline__ int item_insert(uint32_t* ikeys, int* iacc, uint32_t 
 //   STAGE 3 (C)  phases 3-4 over this shard's row fragments -> exact top-n of the items it owns
 //   -- all-gather of the per-shard top-n, merged on every rank --
 static constexpr int MINPOS_NONE = 0x7FFFFFFF;
+struct __attribute__((packed, aligned(4))) RowVec { uint32_t x, y, z, w; };   // 4 row items; rows are only 4-byte aligned
 
 // in-LDS bitonic sort, descending, of n (power of two) packed session slots; pads must be 0
 template <int BLOCK, typename SlotT>
@@ -350,7 +355,7 @@ __device__ void block_sort_slots(SlotT* a, uint32_t n) {
 #define SRN_TICK(ph)                                                                                         \
     do { if (p.phase_cycles && tid == 0) { const long long t_ = clock64(); atomicAdd(&p.phase_cycles[ph], (unsigned long long)(t_ - t_prev)); t_prev = t_; } } while (0)
 
-template <int BLOCK, typename SlotT, typename OffT, bool GLOBAL_TABLES, int STAGE = 0, bool MASKS = false>
+template <int BLOCK, typename SlotT, bool GLOBAL_TABLES, int STAGE = 0, bool MASKS = false>
 __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(DeviceIndex ix, LaunchParams p, KernelCfg c,
                                                              const uint32_t* __restrict__ qlist, const uint32_t* __restrict__ qlist_n,
                                                              uint32_t* retry_list, uint32_t* retry_cnt,
@@ -368,21 +373,20 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
     uint32_t* q_idx = (uint32_t*)(l_base + c.q_cap);                          // q_cap   dense idx or kNone
     uint32_t* l_len = q_idx + c.q_cap;                                        // q_cap   truncated list length (0 = inactive)
     uint32_t* l_pre = l_len + c.q_cap;                                        // q_cap+4 exclusive prefix of l_len
-    uint32_t* wmin = (uint32_t*)(smem + c.off_wave) + wave * 64;              // per-wave first-match scratch
     char* region_b = smem + c.off_b;
     uint32_t* hist = (uint32_t*)region_b;                                     // 2048-bin select histogram (phase 2 only)
     char* region_a = GLOBAL_TABLES ? (gscratch + (size_t)blockIdx.x * gscratch_stride) : (smem + c.off_a);
 
     SlotT* stab = (SlotT*)region_a;                                           // phase 1-2
     uint32_t* hot = (uint32_t*)region_a;                                      // phase 3-4: direct-mapped accumulators (idx < hot_slots)
-    uint32_t* ikeys = (uint32_t*)(region_a + (size_t)c.hot_slots * 4);        //            hash table keys (buckets of 4), then accumulators
-    int* iacc = (int*)(region_a + (size_t)c.hot_slots * 4 + (size_t)c.item_slots * 4);
+    uint32_t* sketch = hot + c.hot_slots;                                     //            upper bounds of all other items' accumulators, by hash
+    uint32_t* ikeys = sketch + c.sketch_slots;                                //            exact hash table keys (buckets of 4), then accumulators
+    int* iacc = (int*)(ikeys + c.item_slots);
     SlotT* nbl = (SlotT*)region_b;                                            // neighbours (phase 2-3)
-    SlotT* nb_spill = nb_spill_base ? (SlotT*)nb_spill_base + (size_t)blockIdx.x * p.k : nullptr;   // copy kept across item partitions
+    SlotT* nb_spill = nb_spill_base ? (SlotT*)nb_spill_base + (size_t)blockIdx.x * p.k : nullptr;   // global copy: phase 4a reuses the LDS
     uint64_t* ckey = (uint64_t*)region_b;                                     // candidates (phase 4)
     uint32_t* cidx = (uint32_t*)(region_b + CAND_CAP * 8);
 
-    const OffT* __restrict__ row_off = (const OffT*)ix.row_off;
     const uint32_t NB = c.num_bits;
     const SlotT num_mask = ((SlotT)1 << NB) - 1;
     // MASKS (sessions of <= 8 items, m <= m_index): a session slot carries the SET of evolving positions whose posting
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
     // first-match position (lowest set bit) come from it and phase 3 needs no first-match pass over the rows.
     uint8_t* wlut = (uint8_t*)(smem + MISC_WORDS * 4);                        // 256 B: numerator of each position set
     auto num_of = [&](SlotT sl) -> uint32_t { return MASKS ? (uint32_t)wlut[(uint32_t)(sl & num_mask)] : (uint32_t)(sl & num_mask); };
-    const uint32_t inb = c.item_buckets, H = c.hot_slots, SB = c.sum_bits;
+    const uint32_t inb = c.item_buckets, H = c.hot_slots, SB = c.sum_bits, SK = c.sketch_slots, SKSH = c.sketch_shift;
     const uint32_t nq_eff = qlist ? *qlist_n : p.nq;
 
     for (uint32_t qi = blockIdx.x; qi < nq_eff; qi += gridDim.x) {
@@ -548,7 +552,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
             for (int u = 0; u < 8; ++u) {
                 if ((bm[u] >> lane) & 1ull) {
                     const uint32_t at = base + (uint32_t)__popcll(bm[u] & ((1ull << lane) - 1ull));
-                    if (STAGE == 1) ((SlotT*)sh.cand)[(size_t)q * p.m + at] = sv[u]; else nbl[at] = sv[u];
+                    if (STAGE == 1) ((SlotT*)sh.cand)[(size_t)q * p.m + at] = sv[u]; else { nbl[at] = sv[u]; if (STAGE == 0) nb_spill[at] = sv[u]; }
                     if (STAGE == 0 && p.nb_rank) { p.nb_rank[(size_t)q * p.k + at] = (uint32_t)(sv[u] >> NB); p.nb_num[(size_t)q * p.k + at] = num_of(sv[u]); }
                 }
                 base += (uint32_t)__popcll(bm[u]);
@@ -571,13 +575,19 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
             if (K == 0xFFFFFFFFu) { if (tid == 0) p.out_counts[q] = 0xFFFFFFFFu; continue; }
         }
 
-        // ---- phase 3: neighbour rows -> item table ---------------------------------------
-        // A wave takes 64 neighbours at a time, one per lane (row offset, length, numerator in registers),
-        // prefix-sums the lengths across lanes and then walks the concatenated rows with lane <-> row element
-        // (adjacent lanes read adjacent items of the same row: coalesced).  The owning lane of an element is
-        // found by a 6-step shuffle binary search.  Pass B1 finds each row's first-match position against the
-        // FULL row (Q4), pass B2 adds w10 * num into the item table.  If the table overflows, the item space is
-        // split into `parts` hash partitions that are accumulated and harvested (phase 4) one after the other.
+        // ---- phase 3: neighbour rows -> item accumulators --------------------------------
+        // A wave takes 64 neighbours at a time, ONE PER LANE: the lane reads its neighbour's row with 16-byte loads and
+        // applies the row's weight w10 * num to every element itself -- no cross-lane traffic, no dependent LDS round
+        // trips in the loop.  Two walks over the rows:
+        //   walk A  idx < H (the most popular items): exact, one LDS add into the direct-mapped word;  every other
+        //           element adds max(w, 0) into sketch[hash(idx)] -- an UPPER BOUND of the item's accumulator, again a
+        //           fire-and-forget LDS add
+        //   -- phase 4a: exact top-n of the direct-mapped items -> threshold score --
+        //   walk B  an element reaches the exact hash table only if its sketch word could still beat the threshold
+        //           (same integer floor as the top-n pre-filter); all elements of an item share the sketch word, so
+        //           an item is either accumulated completely or not at all.  With no threshold (fewer than n valid
+        //           direct-mapped items, or a non-positive threshold score) every element is inserted.
+        // If the hash table overflows, the item space is split into hash partitions handled one after the other.
         const double denom = (double)(10u * U);
         const bool business = (p.flags & SRN_FLAG_BUSINESS_LOGIC) != 0;
         uint32_t cur_attr = SRN_ATTR_NONE;
@@ -586,158 +596,152 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
             else if (cur_idx != kNone) cur_attr = ix.meta[cur_idx].attr;
         }
         const uint32_t n_out = p.how_many;
-        uint32_t parts = 1, part = 0, d_total = 0;
-        bool failed = false;
-        for (;;) {
-            if (STAGE != 2) { for (uint32_t i = tid; i < c.item_slots; i += BLOCK) { ikeys[i] = EMPTY32; iacc[i] = 0; }
-                              for (uint32_t i = tid; i < H; i += BLOCK) hot[i] = 0; }
-            if (tid == 0) { misc[S_OVF] = 0; misc[S_ICNT] = 0; }
-            phase_sync<GLOBAL_TABLES>();
-            SRN_TICK(8);
-            {
-                uint32_t fresh = 0, isum = 0;
-                bool ovf = false;
-                // the (<= 4) most common case keeps the evolving items in registers; longer sessions scan LDS
-                const uint32_t qv0 = q_idx[0], qv1 = L > 1 ? q_idx[1] : kNone, qv2 = L > 2 ? q_idx[2] : kNone, qv3 = L > 3 ? q_idx[3] : kNone;
-                auto match_pos = [&](uint32_t it) -> uint32_t {   // reverse position of `it` in the evolving session, or 0xFFFF
-                    if (it == qv0) return 0; if (it == qv1) return 1; if (it == qv2) return 2; if (it == qv3) return 3;
-                    for (uint32_t pp = 4; pp < L; ++pp) if (q_idx[pp] == it) return pp;
-                    return 0xFFFFu; };
-                auto load_group = [&](uint32_t g0, uint32_t& num, uint32_t& len, OffT& o0) {   // (MASKS: num = the position set)
-                    const uint32_t j = g0 + lane; num = 0; len = 0; o0 = 0;
-                    if (j < K) { const SlotT s = STAGE == 3 ? ((const SlotT*)sh.nb)[(size_t)q * p.k + j] : (parts == 1 ? nbl[j] : nb_spill[j]); const uint32_t r = (uint32_t)(s >> NB); num = (uint32_t)(s & num_mask);
-                                 o0 = row_off[r]; len = (uint32_t)(row_off[r + 1] - o0); } };
-                auto accumulate = [&](uint32_t it, int w) {
-                    if (parts > 1 && hash_part(it, parts) != part) return;
-                    if (it < H) { atomicAdd(&hot[it], (1u << SB) + (uint32_t)w); return; }   // popular item: one LDS add, no probing
-                    const int res = item_insert(ikeys, iacc, inb, it, w);
-                    if (res < 0) ovf = true; else fresh += (uint32_t)res; };
-                uint32_t num, len, nnum = 0, nlen = 0; OffT o0, no0 = 0;
-                if (wave * 64 < K) load_group(wave * 64, num, len, o0);
-                for (uint32_t g0 = wave * 64; g0 < K; g0 += NWAVES * 64) {
-                    const uint32_t gn = g0 + NWAVES * 64;
-                    if (gn < K) load_group(gn, nnum, nlen, no0);   // prefetch the next group's row offsets under this group's work
-                    uint32_t incl = len;
+        const bool use_filter = SK != 0 && p.stats == nullptr;   // the debug counters need every distinct item in the table
+        // the (<= 4) most common case keeps the evolving items in registers; longer sessions scan LDS
+        const uint32_t qv0 = q_idx[0], qv1 = L > 1 ? q_idx[1] : kNone, qv2 = L > 2 ? q_idx[2] : kNone, qv3 = L > 3 ? q_idx[3] : kNone;
+        auto match_pos = [&](uint32_t it) -> uint32_t {   // reverse position of `it` in the evolving session, or 0xFFFF
+            if (it == qv0) return 0; if (it == qv1) return 1; if (it == qv2) return 2; if (it == qv3) return 3;
+            for (uint32_t pp = 4; pp < L; ++pp) if (q_idx[pp] == it) return pp;
+            return 0xFFFFu; };
+        // Walk the rows of this wave's neighbour groups, one row per lane: per_row(j, num, for_row) is called once per
+        // group; for_row(g8) feeds the lane's row to g8(it[8]) eight items at a time (EMPTY32 = none), as often as asked.
+        // Memory schedule per group, all loads unconditional (inactive lanes read slot 0) and in this order: second half
+        // of this group's slots (same line as the first half), first 8 items of this group's overflow rows, first half of
+        // the NEXT group's slots.  Loads return in order, so waiting for this group's data never waits for the next
+        // group's HBM miss, which has a whole group's work to land.
+        auto walk_rows = [&](auto nb_at, auto&& per_row) -> uint32_t {
+            uint32_t isum = 0;
+            if (K == 0) return 0u;
+            auto slot_of = [&](uint32_t j, uint32_t& num) -> size_t {   // lanes past the last neighbour read the all-EMPTY slot n_kept
+                const SlotT s = nb_at(min(j, K - 1));
+                num = j < K ? (uint32_t)(s & num_mask) : 0u;
+                return j < K ? (size_t)(uint32_t)(s >> NB) : (size_t)ix.n_kept; };
+            constexpr uint32_t GSTEP = NWAVES * 64;
+            uint32_t num, nnum;
+            size_t r = slot_of(wave * 64 + lane, num), nr;
+            RowQuad a = ix.row_slots[4 * r], b = ix.row_slots[4 * r + 1], na, nb;
+            for (uint32_t g0 = wave * 64; g0 < K; g0 += GSTEP) {
+                // unused slot words are EMPTY32 in memory, so only a long row's word 1 (its overflow offset) needs masking;
+                // short rows read the EMPTY32 words at the start of row_ext
+                const uint32_t len = a.x;
+                const bool big = len > 15;                       // word 1 = offset of items 14.. in row_ext, items 0..13 in words 2..15
+                const RowQuad c4 = ix.row_slots[4 * r + 2], d4 = ix.row_slots[4 * r + 3];
+                const uint32_t* ext = ix.row_ext + (big ? a.y : 0u);
+                const RowVec e0 = *reinterpret_cast<const RowVec*>(ext), e1 = *reinterpret_cast<const RowVec*>(ext + 4);
+                nr = slot_of(g0 + GSTEP + lane, nnum);
+                na = ix.row_slots[4 * nr]; nb = ix.row_slots[4 * nr + 1];
+                isum += len;
+                auto for_row = [&](auto&& g8) {
+                    { const uint32_t it7[7] = {big ? EMPTY32 : a.y, a.z, a.w, b.x, b.y, b.z, b.w};   // words 1..7
+                      g8(it7); }
+                    if (__ballot(len > 7) == 0ull) return;
+                    uint32_t it[8];
+                    it[0] = c4.x; it[1] = c4.y; it[2] = c4.z; it[3] = c4.w; it[4] = d4.x; it[5] = d4.y; it[6] = d4.z; it[7] = d4.w;   // words 8..15
+                    g8(it);
+                    if (__ballot(big) == 0ull) return;
+                    it[0] = e0.x; it[1] = e0.y; it[2] = e0.z; it[3] = e0.w; it[4] = e1.x; it[5] = e1.y; it[6] = e1.z; it[7] = e1.w;   // items 14..21
 #pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
-                    const uint32_t excl = incl - len;
-                    const uint32_t T = __shfl(incl, 63, 64);
-                    isum += (lane == 0) ? T : 0;
-                    wmin[lane] = 0xFFFFu;
-                    SRN_TICK(9);
-                    auto owner_of = [&](uint32_t e) -> uint32_t {   // lane whose row holds flattened element e (e < T)
-                        uint32_t lo = 0, hi = 63;
+                    for (uint32_t x = 0; x < 8; ++x) if (!big || 14 + x >= len) it[x] = EMPTY32;
+                    g8(it);
+                    for (uint32_t t = 22; __ballot(big && t < len) != 0ull; t += 8) {
 #pragma unroll
-                        for (int sd = 0; sd < 6; ++sd) { const uint32_t mid = (lo + hi) >> 1; const uint32_t v = __shfl(incl, (int)mid, 64);
-                                                          if (v > e) hi = mid; else lo = mid + 1; }
-                        return lo & 63u; };
-                    // The group's row elements are handled in batches of ROW_CACHE*64: all loads of a batch are requested
-                    // before any is consumed (one memory latency per batch, not per element).  B1 runs over every batch,
-                    // then B2; the last batch is still in registers for B2, earlier ones (only when the group holds more
-                    // than one batch of elements) are gathered again, from L1/L2 by then.
-                    constexpr int ROW_CACHE = MASKS ? 8 : 4;        // row elements per lane kept in registers per batch
-                    constexpr uint32_t BATCH = ROW_CACHE * 64;
-                    uint32_t itc[ROW_CACHE], own[ROW_CACHE / 4];   // owner lanes packed 4 x 8 bit
-                    auto gather = [&](uint32_t base0) {
+                        for (int x = 0; x < 8; ++x) it[x] = EMPTY32;
+                        if (big && t < len) { const RowVec v = *reinterpret_cast<const RowVec*>(ext + (t - 14)); it[0] = v.x; it[1] = v.y; it[2] = v.z; it[3] = v.w; }
+                        if (big && t + 4 < len) { const RowVec v = *reinterpret_cast<const RowVec*>(ext + (t - 14) + 4); it[4] = v.x; it[5] = v.y; it[6] = v.z; it[7] = v.w; }
 #pragma unroll
-                        for (int u = 0; u < ROW_CACHE; ++u) {
-                            itc[u] = EMPTY32; if ((u & 3) == 0) own[u >> 2] = 0;
-                            if (base0 + (uint32_t)u * 64 < T) {   // wave-uniform
-                                const uint32_t e = base0 + u * 64 + lane;
-                                const uint32_t lo = owner_of(e);
-                                const uint32_t ex = __shfl(excl, (int)lo, 64);
-                                const OffT ob = (OffT)__shfl(o0, (int)lo, 64);
-                                own[u >> 2] |= lo << ((u & 3) * 8);
-                                if (e < T) itc[u] = ix.row_items[(size_t)ob + (e - ex)];
-                            }
-                        } };
-                    const uint32_t nbat = (T + BATCH - 1) / BATCH;
-                    SRN_TICK(10);
-                    // steps 0..nbat-1: B1 (first-match position of every row, Q4: against the full row) on batch `step`;
-                    // then the row weights; steps nbat..2 nbat-1: B2 (accumulate), starting with the batch still cached
-                    // (sharded pipeline: stage B stops after B1 and publishes the partial positions; stage C starts at B2 with
-                    //  the all-reduced positions)
-                    int wrow = 0;
-                    constexpr bool SKIP_B1 = MASKS || STAGE == 3;   // first-match positions already known
-                    if (MASKS) { const int mp = num ? __ffs((int)num) - 1 : MINPOS_NONE;   // lowest set position = first match (Q4)
-                                 if (STAGE == 2 && g0 + lane < K) sh.minpos[(size_t)q * (p.k + 1) + g0 + lane] = mp;
-                                 wrow = (mp < 99 ? 10 - (mp + 1) : 0) * (int)wlut[num]; }
-                    else if (STAGE == 3) { const int mp = g0 + lane < K ? sh.minpos[(size_t)q * (p.k + 1) + g0 + lane] : MINPOS_NONE;
-                                           wrow = (mp < 99 ? 10 - (mp + 1) : 0) * (int)num; }
-                    const uint32_t step0 = SKIP_B1 ? nbat : 0, step1 = STAGE == 2 ? (MASKS ? 0u : nbat) : 2 * nbat;
-                    for (uint32_t step = step0; step < step1; ++step) {
-                        const bool b2 = SKIP_B1 || step >= nbat;   // (compile-time true when the first-match pass is not needed)
-                        if (!SKIP_B1 && step == nbat) {
-                            const uint32_t mp = wmin[lane];
-                            if (STAGE == 0 && g0 + lane < K && mp == 0xFFFFu) misc[S_ERR] = 1;   // inconsistent index (reference: unwrap panic, mod.rs:138)
-                            const int p1 = (int)mp + 1;
-                            wrow = (p1 < 100 ? 10 - p1 : 0) * (int)num;            // 10 * linear_score(pos) * numerator, exact (Q3)
-                            SRN_TICK(11);
-                        } else gather((SKIP_B1 ? step - nbat : (b2 ? step - nbat - 1 : step)) * BATCH);
-#pragma unroll
-                        for (int u = 0; u < ROW_CACHE; ++u) {
-                            const uint32_t owner = (own[u >> 2] >> ((u & 3) * 8)) & 63u;
-                            if (!b2) { if (itc[u] != EMPTY32) { const uint32_t mp = match_pos(itc[u]); if (mp != 0xFFFFu) atomicMin(&wmin[owner], mp); } }
-                            else { const int w = __shfl(wrow, (int)owner, 64); if (itc[u] != EMPTY32) accumulate(itc[u], w); }
-                        }
-                    }
-                    if (!MASKS && STAGE == 2 && g0 + lane < K) sh.minpos[(size_t)q * (p.k + 1) + g0 + lane] = wmin[lane] == 0xFFFFu ? MINPOS_NONE : (int)wmin[lane];
-                    num = nnum; len = nlen; o0 = no0;
-                    SRN_TICK(12);
-                }
-                fresh = wave_sum(fresh);
-                if (lane == 0) { if (fresh) atomicAdd((uint32_t*)&misc[S_ICNT], fresh); if (p.stats && part == 0 && isum) atomicAdd((uint32_t*)&misc[S_I], isum); }
-                if (ovf) misc[S_OVF] = 1;
+                        for (uint32_t x = 1; x < 8; ++x) if (t + x >= len) it[x] = EMPTY32;
+                        g8(it);
+                    } };
+                per_row(g0 + lane, num, for_row);
+                num = nnum; r = nr; a = na; b = nb;
             }
-            if constexpr (STAGE == 2) break;
-            phase_sync<GLOBAL_TABLES>();
-            SRN_TICK(13);
-            if (misc[S_OVF]) {   // block-uniform: split the item space finer and start the accumulation over
-                __syncthreads();
-                if (parts >= MAX_ITEM_PASSES || GLOBAL_TABLES || (STAGE != 3 && !nb_spill)) { failed = true; break; }
-                // phase 4 reuses the neighbour list's LDS for its candidates: keep a copy in global scratch
-                if (parts == 1 && STAGE != 3) { for (uint32_t i = tid; i < K; i += BLOCK) nb_spill[i] = nbl[i]; __threadfence(); }
-                parts *= 2; part = 0; d_total = 0;
-                if (tid == 0) { misc[S_CCNT] = 0; misc[S_HAVE_T] = 0; misc[S_I] = 0; }
-                continue;
-            }
-            if (p.stats && H) {   // debug counters only: distinct items = hash inserts + touched direct-mapped entries
-                uint32_t touched = 0; for (uint32_t i = tid; i < H; i += BLOCK) touched += hot[i] != 0;
-                touched = wave_sum(touched); if (lane == 0 && touched) atomicAdd((uint32_t*)&misc[S_ICNT], touched);
-                __syncthreads();
-            }
-            d_total += misc[S_ICNT];
+            return isum; };
+        // 10 * linear_score(first match) * numerator of lane's neighbour j (exact, Q3); publishes / reads the first-match
+        // position in the sharded stages
+        auto row_weight = [&](uint32_t j, uint32_t num, auto&& for_row) -> int {
+            const bool active = j < K;
+            if (MASKS) { const int mp = num ? __ffs((int)num) - 1 : MINPOS_NONE;   // lowest set position = first match (Q4)
+                         if (STAGE == 2 && active) sh.minpos[(size_t)q * (p.k + 1) + j] = mp;
+                         return (mp < 99 ? 10 - (mp + 1) : 0) * (int)wlut[num]; }
+            if (STAGE == 3) { const int mp = active ? sh.minpos[(size_t)q * (p.k + 1) + j] : MINPOS_NONE;
+                              return (mp < 99 ? 10 - (mp + 1) : 0) * (int)num; }
+            uint32_t mp = 0xFFFFu;   // first-match position against the FULL row (Q4)
+            for_row([&](const auto& it) {
+                constexpr int N = sizeof(it) / sizeof(it[0]);
+#pragma unroll
+                for (int x = 0; x < N; ++x) if (it[x] != EMPTY32) mp = min(mp, match_pos(it[x])); });
+            if (STAGE == 0 && active && mp == 0xFFFFu) misc[S_ERR] = 1;   // inconsistent index (reference: unwrap panic, mod.rs:138)
+            if (STAGE == 2 && active) sh.minpos[(size_t)q * (p.k + 1) + j] = mp == 0xFFFFu ? MINPOS_NONE : (int)mp;
+            const int p1 = (int)mp + 1;
+            return (p1 < 100 ? 10 - p1 : 0) * (int)num; };
+        auto nb_lds = [&](uint32_t j) -> SlotT { return STAGE == 3 ? ((const SlotT*)sh.nb)[(size_t)q * p.k + j] : nbl[j]; };
+        auto nb_glb = [&](uint32_t j) -> SlotT { return STAGE == 3 ? ((const SlotT*)sh.nb)[(size_t)q * p.k + j] : nb_spill[j]; };
 
-            // ---- phase 4: scores, business rules, top-n (per partition, one running candidate set) ----
-            // Chunks of BLOCK slots; the first chunk is a sample whose n-th best score becomes a threshold, then all
-            // the other chunks are swept in one barrier-free round (4 chunks' gathers in flight at a time) and only
-            // candidates beating the threshold are appended.  If the buffer would overflow, the round is redone
-            // chunk by chunk with a prune whenever needed (exact).
-            {
-                const uint32_t n_entries = H + c.item_slots;   // direct-mapped entries first, then the hash slots
-                const uint32_t n_chunks = (n_entries + BLOCK - 1) / BLOCK;
-                uint32_t u = 0, ru = 1;
-                while (u < n_chunks) {
-                    const uint32_t cnt0 = misc[S_CCNT];
-                    const bool have_t = misc[S_HAVE_T] != 0;
-                    const uint64_t tk = ((uint64_t)misc[S_TKEY_HI] << 32) | misc[S_TKEY_LO];
-                    const uint32_t tix = misc[S_TIDX];
-                    const bool t_pos = have_t && tk > 0x8000000000000000ull;   // threshold score > 0: non-positive accumulators cannot make it
-                    // smallest accumulator that could still reach the threshold: score <= idf_hi * acc / denom, so an item needs
-                    // acc >= thr * denom / idf_hi; shaved by a relative 1e-9 and one unit so that rounding can only keep more
-                    const int acc_floor = t_pos ? (int)fmin(2147483000.0, fmax(1.0, floor(key_score(tk) * denom / ix.idf_hi * (1.0 - 1e-9)) - 1.0)) : 0;
-                    const uint32_t u_end = min(u + ru, n_chunks);
-                    __syncthreads();   // every wave has read the round's state before any wave appends (and moves S_CCNT)
-                    // gather first (up to 4 chunks' idf loads in flight per lane), then score + append.  Once the
-                    // threshold score is positive, an item whose upper bound idf_hi * acc / denom (same operations and
-                    // rounding as the score, so monotone and safe) is below it is dropped without touching idf[].
-                    for (uint32_t ub = u; ub < u_end; ub += 2) {   // sub-batches of 2 chunks, no barrier in between
+        if constexpr (STAGE == 2) {   // stage B: first-match positions only
+            walk_rows(nb_lds, [&](uint32_t j, uint32_t num, auto&& for_row) { row_weight(j, num, for_row); });
+            continue;
+        }
+        for (uint32_t i = tid; i < H + SK; i += BLOCK) hot[i] = 0;   // direct-mapped words and the sketch are adjacent
+        if (tid == 0) { misc[S_CCNT] = 0; misc[S_HAVE_T] = 0; misc[S_SORTED] = 0; misc[S_I] = 0; misc[S_LIVE] = 0; misc[S_ICNT] = 0; }
+        phase_sync<GLOBAL_TABLES>();
+        SRN_TICK(8);
+        {   // walk A
+            const uint32_t isum = wave_sum(walk_rows(nb_lds, [&](uint32_t j, uint32_t num, auto&& for_row) {
+                const int w = row_weight(j, num, for_row);
+                const uint32_t wpos = SK ? (uint32_t)max(w, 0) : 0u, whot = (1u << SB) + (uint32_t)w;
+                // one LDS add per element: idx < H -> its direct-mapped word, anything else -> its sketch word (sketch = hot + H;
+                // without a sketch the add is + 0 into the word after the direct-mapped part)
+                for_row([&](const auto& it) {
+                    constexpr int N = sizeof(it) / sizeof(it[0]);
+#pragma unroll
+                    for (int x = 0; x < N; ++x) {
+                        const bool is_hot = it[x] < H;
+                        if (it[x] != EMPTY32) atomicAdd(&hot[is_hot ? it[x] : H + sketch_hash(it[x], SKSH)], is_hot ? whot : wpos);
+                    } }); }));
+            if (lane == 0 && p.stats && isum) atomicAdd((uint32_t*)&misc[S_I], isum);
+        }
+        phase_sync<GLOBAL_TABLES>();
+        SRN_TICK(9);
+        uint32_t d_total = 0;
+        if (p.stats && H) {   // debug counters only: distinct items = touched direct-mapped entries + hash inserts
+            uint32_t touched = 0; for (uint32_t i = tid; i < H; i += BLOCK) touched += hot[i] != 0;
+            touched = wave_sum(touched); if (lane == 0 && touched) atomicAdd((uint32_t*)&misc[S_ICNT], touched);
+            __syncthreads();
+            d_total = misc[S_ICNT];
+            __syncthreads();
+        }
+
+        // ---- phase 4: scores, business rules, top-n (one running candidate set) -------------
+        // harvest(e_lo, e_hi): entries [e_lo, e_hi) of (direct-mapped words | hash slots) in chunks of BLOCK; the first
+        // chunk without a threshold is a sample whose n-th best score becomes one, then all other chunks are swept in
+        // one barrier-free round and only candidates beating the threshold are appended.  If the buffer would overflow,
+        // the round is redone chunk by chunk with a prune whenever needed (exact).  Leaves the best min(cnt, n) sorted.
+        auto acc_floor_of = [&](uint64_t tk) -> int {
+            // smallest accumulator that could still reach the threshold: score <= idf_hi * acc / denom, so an item needs
+            // acc >= thr * denom / idf_hi; shaved by a relative 1e-9 and one unit so that rounding can only keep more
+            return (int)fmin(2147483000.0, fmax(1.0, floor(key_score(tk) * denom / ix.idf_hi * (1.0 - 1e-9)) - 1.0)); };
+        auto harvest = [&](uint32_t e_lo, uint32_t e_hi) {
+            const uint32_t n_chunks = (e_hi - e_lo + BLOCK - 1) / BLOCK;
+            uint32_t u = 0, ru = (misc[S_HAVE_T] && misc[S_CCNT] * 2 <= CAND_CAP) ? n_chunks : 1u;
+            while (u < n_chunks) {
+                const uint32_t cnt0 = misc[S_CCNT];
+                const bool have_t = misc[S_HAVE_T] != 0;
+                const uint64_t tk = ((uint64_t)misc[S_TKEY_HI] << 32) | misc[S_TKEY_LO];
+                const uint32_t tix = misc[S_TIDX];
+                const bool t_pos = have_t && tk > 0x8000000000000000ull;   // threshold score > 0: non-positive accumulators cannot make it
+                const int acc_floor = t_pos ? acc_floor_of(tk) : 0;
+                const uint32_t u_end = min(u + ru, n_chunks);
+                __syncthreads();   // every wave has read the round's state before any wave appends (and moves S_CCNT)
+                // gather first (2 chunks' idf loads in flight per lane), then score + append.  Once the
+                // threshold score is positive, an item whose upper bound idf_hi * acc / denom (same operations and
+                // rounding as the score, so monotone and safe) is below it is dropped without touching meta[].
+                for (uint32_t ub = u; ub < u_end; ub += 2) {   // sub-batches of 2 chunks, no barrier in between
                     uint32_t its[2]; int accs[2]; ItemMeta metas[2];
 #pragma unroll
                     for (int x = 0; x < 2; ++x) {
                         its[x] = EMPTY32; accs[x] = 0; metas[x] = ItemMeta{0.0, 0u, 0u};
-                        const uint32_t i = (ub + x) * BLOCK + tid;
-                        if (ub + x < u_end && i < n_entries) {
+                        const uint32_t i = e_lo + (ub + x) * BLOCK + tid;
+                        if (ub + x < u_end && i < e_hi) {
                             uint32_t it = EMPTY32; int acc = 0;
                             if (i < H) { const uint32_t v = hot[i]; if (v) { it = i; acc = (int)(v - (((v + (1u << (SB - 1))) >> SB) << SB)); } }
                             else { it = ikeys[i - H]; acc = iacc[i - H]; }
@@ -760,62 +764,114 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                             if (take) { if (at < CAND_CAP) { ckey[at] = sk; cidx[at] = tie; } else misc[S_COVF] = 1; }
                         }
                     }
+                }
+                __syncthreads();
+                if (misc[S_COVF]) {   // block-uniform: too many survivors for one optimistic round
+                    __syncthreads();
+                    if (tid == 0) { misc[S_CCNT] = cnt0; misc[S_COVF] = 0; }
+                    ru = 1;
+                    __syncthreads();
+                    continue;
+                }
+                u = u_end;
+                const uint32_t cnt = misc[S_CCNT];
+                const bool last = u >= n_chunks;
+                // before a single-chunk round the buffer must have room for BLOCK appends (exact path);
+                // also sort once as soon as n candidates exist, to get a threshold
+                const bool must_prune = cnt + BLOCK > CAND_CAP || (!have_t && cnt >= n_out && cnt > 1);
+                if ((must_prune && !last) || (last && cnt > 1 && cnt != misc[S_SORTED])) {
+                    if (n_out <= 64) block_top64<BLOCK>(ckey, cidx, cnt);   // leaves the best min(cnt, 64) sorted at the front
+                    else {
+                        uint32_t n2 = 2; while (n2 < cnt) n2 <<= 1;
+                        for (uint32_t t = cnt + tid; t < n2; t += BLOCK) { ckey[t] = 0; cidx[t] = EMPTY32; }
+                        __syncthreads();
+                        block_sort_candidates<BLOCK>(ckey, cidx, n2);
+                    }
+                    if (tid == 0) {
+                        misc[S_SORTED] = min(cnt, n_out);
+                        if (cnt >= n_out) { misc[S_CCNT] = n_out; misc[S_HAVE_T] = 1; misc[S_TIDX] = cidx[n_out - 1];
+                                            misc[S_TKEY_LO] = (uint32_t)ckey[n_out - 1]; misc[S_TKEY_HI] = (uint32_t)(ckey[n_out - 1] >> 32); }
                     }
                     __syncthreads();
-                    if (misc[S_COVF]) {   // block-uniform: too many survivors for one optimistic round
-                        __syncthreads();
-                        if (tid == 0) { misc[S_CCNT] = cnt0; misc[S_COVF] = 0; }
-                        ru = 1;
-                        __syncthreads();
-                        continue;
-                    }
-                    u = u_end;
-                    const uint32_t cnt = misc[S_CCNT];
-                    const bool last = u >= n_chunks && part + 1 == parts;
-                    // before a single-chunk round the buffer must have room for BLOCK appends (exact path);
-                    // also sort once as soon as n candidates exist, to get a threshold
-                    const bool must_prune = cnt + BLOCK > CAND_CAP || (!have_t && cnt >= n_out && cnt > 1);
-                    SRN_TICK(14);
-                    if ((must_prune && !last) || (last && cnt > 1)) {
-                        if (n_out <= 64) block_top64<BLOCK>(ckey, cidx, cnt);   // leaves the best min(cnt, 64) sorted at the front
-                        else {
-                            uint32_t n2 = 2; while (n2 < cnt) n2 <<= 1;
-                            for (uint32_t t = cnt + tid; t < n2; t += BLOCK) { ckey[t] = 0; cidx[t] = EMPTY32; }
-                            __syncthreads();
-                            block_sort_candidates<BLOCK>(ckey, cidx, n2);
-                        }
-                        if (tid == 0 && cnt >= n_out) {
-                            misc[S_CCNT] = n_out; misc[S_HAVE_T] = 1; misc[S_TIDX] = cidx[n_out - 1];
-                            misc[S_TKEY_LO] = (uint32_t)ckey[n_out - 1]; misc[S_TKEY_HI] = (uint32_t)(ckey[n_out - 1] >> 32);
-                        }
-                        __syncthreads();
-                    }
-                    SRN_TICK(15);
-                    // once a threshold exists and the buffer is at most half full: ONE optimistic round over all the
-                    // remaining chunks (a round that overflows the buffer is redone chunk by chunk, see above)
-                    ru = (misc[S_HAVE_T] && misc[S_CCNT] * 2 <= CAND_CAP) ? n_chunks : 1u;
                 }
+                // once a threshold exists and the buffer is at most half full: ONE optimistic round over all the
+                // remaining chunks (a round that overflows the buffer is redone chunk by chunk, see above)
+                ru = (misc[S_HAVE_T] && misc[S_CCNT] * 2 <= CAND_CAP) ? n_chunks : 1u;
             }
-            SRN_TICK(6);
+            __syncthreads(); };
+
+        if (H) harvest(0, H);   // phase 4a: the direct-mapped items, exactly -> threshold
+        SRN_TICK(10);
+
+        // ---- walk B + phase 4b, per item partition ------------------------------------------
+        uint32_t parts = 1, part = 0;
+        bool failed = false;
+        for (;;) {
+            // what the threshold lets through (block-uniform; all waves read it before anyone can move it again)
+            const bool have_t = misc[S_HAVE_T] != 0;
+            const uint64_t tk = ((uint64_t)misc[S_TKEY_HI] << 32) | misc[S_TKEY_LO];
+            const bool filt = use_filter && have_t && tk > 0x8000000000000000ull;
+            const uint32_t floor_b = filt ? (uint32_t)acc_floor_of(tk) : 0u;
+            if (filt && part == 0 && parts == 1) {   // no sketch word reaches the floor: no other item can make the top n
+                uint32_t live = 0;
+                for (uint32_t i = tid; i < SK; i += BLOCK) live += sketch[i] >= floor_b;
+                live = wave_sum(live);
+                if (lane == 0 && live) atomicAdd((uint32_t*)&misc[S_LIVE], live);
+                __syncthreads();
+                if (misc[S_LIVE] == 0) break;
+            }
+            for (uint32_t i = tid; i < c.item_slots; i += BLOCK) { ikeys[i] = EMPTY32; iacc[i] = 0; }
+            if (tid == 0) { misc[S_OVF] = 0; misc[S_ICNT] = 0; }
+            phase_sync<GLOBAL_TABLES>();
+            SRN_TICK(11);
+            {
+                uint32_t fresh = 0; bool ovf = false;
+                walk_rows(nb_glb, [&](uint32_t j, uint32_t num, auto&& for_row) {
+                    const int w = row_weight(j, num, for_row);
+                    for_row([&](const auto& it) {
+                        constexpr int N = sizeof(it) / sizeof(it[0]);
+                        bool go[N];
+#pragma unroll
+                        for (int x = 0; x < N; ++x) {
+                            go[x] = it[x] != EMPTY32 && it[x] >= H && (parts == 1 || hash_part(it[x], parts) == part);
+                            if (filt) { const uint32_t ub = go[x] ? sketch[sketch_hash(it[x], SKSH)] : 0u; go[x] = go[x] & (ub >= floor_b); }
+                        }
+#pragma unroll
+                        for (int x = 0; x < N; ++x) {
+                            if (go[x]) { const int res = item_insert(ikeys, iacc, inb, it[x], w); if (res < 0) ovf = true; else fresh += (uint32_t)res; }
+                        } }); });
+                fresh = wave_sum(fresh);
+                if (lane == 0 && fresh) atomicAdd((uint32_t*)&misc[S_ICNT], fresh);
+                if (ovf) misc[S_OVF] = 1;
+            }
+            phase_sync<GLOBAL_TABLES>();
+            SRN_TICK(12);
+            if (misc[S_OVF]) {   // block-uniform: split the item space finer; partitions already harvested stay as they are
+                __syncthreads();   // (hash_part(it, 2 * parts) is 2 * hash_part(it, parts) or that + 1: a refinement)
+                if (parts >= MAX_ITEM_PASSES || GLOBAL_TABLES) { failed = true; break; }
+                parts *= 2; part *= 2;
+                continue;
+            }
+            d_total += misc[S_ICNT];
+            harvest(H, H + c.item_slots);
+            SRN_TICK(13);
             if (++part >= parts) break;
-            __syncthreads();
         }
-        if constexpr (STAGE == 2) continue;
         if (failed) {
             if (GLOBAL_TABLES || STAGE == 3) { if (tid == 0) { p.out_counts[q] = 0xFFFFFFFFu; if (p.stats) p.stats[(size_t)q * 8 + 7] = 3; } }
             else if (tid == 0) retry_list[atomicAdd(retry_cnt, 1u)] = q;
             continue;
         }
-        const uint32_t H = min(misc[S_CCNT], n_out);
-        if (tid < H) {
+        const uint32_t n_res = min(misc[S_CCNT], n_out);
+        if (tid < n_res) {
             p.out_ids[(size_t)q * n_out + tid] = ix.id_sorted[cidx[tid]];
             p.out_scores[(size_t)q * n_out + tid] = key_score(ckey[tid]);
         }
         if (tid == 0) {
-            p.out_counts[q] = H;
+            p.out_counts[q] = n_res;
             if (p.nb_cnt) p.nb_cnt[q] = K;
             if (p.stats) { uint32_t* st = p.stats + (size_t)q * 8;
-                st[0] = P; st[1] = Cm; st[2] = K; st[3] = misc[S_I]; st[4] = d_total; st[5] = H; st[6] = L;
+                st[0] = P; st[1] = Cm; st[2] = K; st[3] = misc[S_I]; st[4] = d_total; st[5] = n_res; st[6] = L;
                 st[7] = misc[S_ERR] ? 4u : (GLOBAL_TABLES ? 1u : (parts > 1 ? 0x100u * parts : 0u)); }
         }
     }
@@ -843,7 +899,6 @@ struct DeviceState {
     std::vector<void*> allocs; uint64_t bytes = 0;
     DeviceIndex di{};
     ItemMeta* d_meta = nullptr;
-    bool off64 = false;
     int n_cu = 256;
     int lds_per_block_max = 65536;
     std::mutex mu; std::vector<Workspace*> free_ws; std::vector<Workspace*> all_ws;
@@ -853,8 +908,8 @@ struct DeviceState {
 };
 
 namespace {
-template <typename T> const T* upload(DeviceState* d, const std::vector<T>& v, bool& ok) {
-    void* p = nullptr; const size_t n = std::max<size_t>(v.size() * sizeof(T), 16);
+template <typename T> const T* upload(DeviceState* d, const std::vector<T>& v, bool& ok, size_t pad = 0, size_t = 0) {   // (hipMalloc is 256-byte aligned)
+    void* p = nullptr; const size_t n = std::max<size_t>(v.size() * sizeof(T), 16) + pad;
     if (!ok) return nullptr;
     if (hipMalloc(&p, n) != hipSuccess) { ok = false; set_error("hipMalloc failed for index array"); return nullptr; }
     d->allocs.push_back(p); d->bytes += n;
@@ -876,10 +931,27 @@ DeviceState* device_attach(const FlatIndex& ix, int device) {
       for (size_t i = 0; i < ix.n_items; ++i) { meta[i] = ItemMeta{ix.idf[i], ix.id_rank[i], ix.attr[i]}; id_sorted[ix.id_rank[i]] = ix.item_id[i]; }
       d->d_meta = (ItemMeta*)upload(d, meta, ok); d->di.meta = d->d_meta; d->di.id_sorted = upload(d, id_sorted, ok); }
     d->di.post_off = upload(d, ix.post_off, ok); d->di.post_rank = upload(d, ix.post_rank, ok);
-    d->off64 = ix.nnz_rows >= 0xFFFFFFFFull;
-    if (d->off64) d->di.row_off = upload(d, ix.row_off, ok);
-    else { std::vector<uint32_t> o32(ix.row_off.begin(), ix.row_off.end()); d->di.row_off = upload(d, o32, ok); }
-    d->di.row_items = upload(d, ix.row_items, ok);
+    {   // rows -> 64-byte slots (+ overflow area), see DeviceIndex
+        const size_t n = ix.n_kept;
+        std::vector<uint32_t> slots((n + 1) * 16, EMPTY32), ext(16, EMPTY32);   // slot n: the empty row idle lanes read; ext[0..15]: what short rows read
+        uint64_t ext_total = 16;
+        for (size_t r = 0; r < n; ++r) { const uint64_t len = ix.row_off[r + 1] - ix.row_off[r]; if (len > 15) ext_total += len - 14; }
+        if (ext_total >= 0xFFFFFFF0ull) { set_error("row overflow area exceeds 2^32 items"); device_release(d); return nullptr; }
+        ext.reserve(ext_total + 16);
+        slots[n * 16] = 0;
+        for (size_t r = 0; r < n; ++r) {
+            const uint64_t o = ix.row_off[r], len = ix.row_off[r + 1] - o;
+            uint32_t* sl = &slots[r * 16];
+            sl[0] = (uint32_t)len;
+            if (len <= 15) for (uint64_t i = 0; i < len; ++i) sl[1 + i] = ix.row_items[o + i];
+            else { sl[1] = (uint32_t)ext.size();
+                   for (uint64_t i = 0; i < 14; ++i) sl[2 + i] = ix.row_items[o + i];
+                   ext.insert(ext.end(), ix.row_items.begin() + o + 14, ix.row_items.begin() + o + len); }
+        }
+        ext.resize(ext.size() + 16, EMPTY32);   // 4-item loads may run past the last row
+        d->di.row_slots = (const RowQuad*)upload(d, slots, ok);
+        d->di.row_ext = upload(d, ext, ok);
+    }
     d->di.n_items = (uint32_t)ix.n_items; d->di.n_kept = (uint32_t)ix.n_kept;
     double hi = 1.0, lo = 1.0; bool any = false;   // bounds of idf_eff = (idf > 0 ? idf : 1) for the top-n pre-filter
     for (double v : ix.idf) { const double e = v > 0.0 ? v : 1.0; if (!any) { hi = lo = e; any = true; } else { hi = std::max(hi, e); lo = std::min(lo, e); } }
@@ -954,22 +1026,20 @@ static inline uint32_t round_up(uint32_t v, uint32_t a) { return (v + a - 1) / a
 static inline int bits_host(uint64_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
 
 template <int BLOCK, bool GLOBAL_TABLES, int STAGE = 0, bool MASKS = false>
-static hipError_t launch_variant(bool slot64, bool off64, dim3 grid, size_t lds, hipStream_t st, const DeviceIndex& di,
+static hipError_t launch_variant(bool slot64, dim3 grid, size_t lds, hipStream_t st, const DeviceIndex& di,
                                  const LaunchParams& p, const KernelCfg& c, const uint32_t* qlist, const uint32_t* qn,
                                  uint32_t* retry_list, uint32_t* retry_cnt, char* gs, unsigned long long gstride, char* spill,
                                  const ShardIO& sh = ShardIO{}) {
-#define SRN_LAUNCH(SLOT, OFF)                                                                                             \
+#define SRN_LAUNCH(SLOT)                                                                                             \
     do {                                                                                                                  \
-        auto kern = vmis_predict_kernel<BLOCK, SLOT, OFF, GLOBAL_TABLES, STAGE, MASKS>;                                                 \
+        auto kern = vmis_predict_kernel<BLOCK, SLOT, GLOBAL_TABLES, STAGE, MASKS>;                                                      \
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
         if (e != hipSuccess) return e;                                                                                    \
         hipLaunchKernelGGL(kern, grid, dim3(BLOCK), lds, st, di, p, c, qlist, qn, retry_list, retry_cnt, gs, gstride, spill, sh); \
         return hipGetLastError();                                                                                         \
     } while (0)
-    if (!slot64 && !off64) SRN_LAUNCH(uint32_t, uint32_t);
-    if (!slot64 && off64) SRN_LAUNCH(uint32_t, unsigned long long);
-    if (slot64 && !off64) SRN_LAUNCH(unsigned long long, uint32_t);
-    SRN_LAUNCH(unsigned long long, unsigned long long);
+    if (!slot64) SRN_LAUNCH(uint32_t);
+    SRN_LAUNCH(unsigned long long);
 #undef SRN_LAUNCH
 }
 
@@ -1003,7 +1073,7 @@ static int make_geometry(const DeviceState* d, const FlatIndex& ix, const Launch
     c.q_cap = round_up((uint32_t)Lmax + 1, 4);
     c.off_q = MISC_WORDS * 4 + 1024;
     c.off_wave = round_up(c.off_q + c.q_cap * 24 + (c.q_cap + 4) * 4, 16);
-    c.off_b = c.off_wave + (kBlock / 64) * 256;
+    c.off_b = c.off_wave;   // (no per-wave scratch any more)
     const uint32_t region_b = round_up(std::max<uint32_t>(std::max<uint32_t>(p.k * slot_bytes, CAND_CAP * 12), min_region_b), 16);
     c.off_a = c.off_b + region_b;
     const uint32_t lds_max = (uint32_t)std::min(d->lds_per_block_max, 160 * 1024);
@@ -1021,10 +1091,15 @@ static int make_geometry(const DeviceState* d, const FlatIndex& ix, const Launch
     if (const char* e = getenv("SRN_HOT_SLOTS")) hot = sbits + cbits <= 32 ? (uint32_t)atoi(e) : 0u;   // test knob
     hot = std::min<uint32_t>(std::min<uint32_t>(hot, a_max / 8), round_up((uint32_t)std::min<uint64_t>(ix.n_items, 1u << 20), 4)) / 4 * 4;
     c.hot_slots = hot; c.sum_bits = (uint32_t)sbits;
+    // sketch: upper-bound words for all other items (needs the direct-mapped part: its top n give the threshold)
+    uint32_t sk = hot ? 8192u : 0u;
+    if (const char* e = getenv("SRN_SKETCH_SLOTS")) sk = hot ? floor_pow2((uint64_t)std::max(0, atoi(e))) * (atoi(e) > 0) : 0u;   // test knob
+    while (sk && (uint64_t)sk * 4 * 8 > (uint64_t)(a_max - hot * 4) * 5) sk >>= 1;   // leave >= 3/8 of the room to the exact table
+    c.sketch_slots = sk; c.sketch_shift = sk ? 32u - (uint32_t)(bits_host(sk) - 1) : 31u;
     const uint64_t want_buckets = std::max<uint64_t>(61, g.need_item / 2 + 8);          // load <= 0.5 at the worst case
-    c.item_buckets = prime_at_most((uint32_t)std::min<uint64_t>((a_max - hot * 4) / 32, want_buckets));
+    c.item_buckets = prime_at_most((uint32_t)std::min<uint64_t>((a_max - hot * 4 - sk * 4) / 32, want_buckets));
     c.item_slots = c.item_buckets * 4;
-    const uint32_t region_a = std::max<uint32_t>(hot * 4 + c.item_slots * 8, c.sess_slots * slot_bytes);
+    const uint32_t region_a = std::max<uint32_t>(hot * 4 + sk * 4 + c.item_slots * 8, c.sess_slots * slot_bytes);
     g.lds = (size_t)c.off_a + region_a;
     // tables at least twice the worst case cannot exhaust the probe budget: no retry machinery needed
     g.sess_may_overflow = (uint64_t)c.sess_slots < g.need_sess * 2; g.item_may_overflow = (uint64_t)c.item_slots < g.need_item * 2;
@@ -1078,7 +1153,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
             HIP_TRY(hipMalloc((void**)&w->retry_list, (size_t)p.nq * 4 + 64)); w->retry_cap = p.nq; }
         cg.sess_slots = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(256, ceil_pow2(need_sess * 2)));
         cg.item_buckets = prime_at_least(need_item / 2 + 64); cg.item_slots = cg.item_buckets * 4;
-        g_stride = std::max<uint64_t>((uint64_t)cg.sess_slots * slot_bytes, (uint64_t)cg.hot_slots * 4 + (uint64_t)cg.item_slots * 8);
+        g_stride = std::max<uint64_t>((uint64_t)cg.sess_slots * slot_bytes, (uint64_t)cg.hot_slots * 4 + (uint64_t)cg.sketch_slots * 4 + (uint64_t)cg.item_slots * 8);
         g_stride = (g_stride + 255) / 256 * 256;
         retry_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)d->n_cu, (2ull << 30) / g_stride));
         int rc = ensure(&w->gscratch, &w->gscratch_bytes, g_stride * retry_blocks); if (rc) return rc;
@@ -1088,24 +1163,22 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     // ---- launches ----------------------------------------------------------------------
     const uint32_t blocks_per_cu = std::max<uint32_t>(1, (160 * 1024) / (uint32_t)lds);
     const uint32_t grid = (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * std::min<uint32_t>(blocks_per_cu, 2048 / kBlock) * 4);
-    char* spill = nullptr;
-    if (item_may_overflow) {
-        int rc = ensure(&w->spill, &w->spill_bytes, (size_t)grid * p.k * slot_bytes); if (rc) return rc;
-        spill = w->spill;
-    }
+    // per-block global copy of the neighbour list (walk B reads it after phase 4a has reused the LDS)
+    { int rc = ensure(&w->spill, &w->spill_bytes, (size_t)std::max<uint32_t>(grid, (uint32_t)retry_blocks) * p.k * slot_bytes); if (rc) return rc; }
+    char* spill = w->spill;
     hipEvent_t* ev = w->ev[w->calls % Workspace::RING];
     HIP_TRY(hipEventRecord(ev[0], st));
-    if (geo.masks) HIP_TRY((launch_variant<kBlock, false, 0, true>(slot64, d->off64, dim3(grid), lds, st, d->di, p, c, nullptr, nullptr,
+    if (geo.masks) HIP_TRY((launch_variant<kBlock, false, 0, true>(slot64, dim3(grid), lds, st, d->di, p, c, nullptr, nullptr,
                                                                    w->retry_list, w->retry_cnt, nullptr, 0, spill)));
-    else HIP_TRY((launch_variant<kBlock, false, 0, false>(slot64, d->off64, dim3(grid), lds, st, d->di, p, c, nullptr, nullptr,
+    else HIP_TRY((launch_variant<kBlock, false, 0, false>(slot64, dim3(grid), lds, st, d->di, p, c, nullptr, nullptr,
                                                            w->retry_list, w->retry_cnt, nullptr, 0, spill)));
     HIP_TRY(hipEventRecord(ev[1], st));
     if (may_overflow) {
         const size_t lds_g = c.off_a;
-        if (geo.masks) HIP_TRY((launch_variant<kBlock, true, 0, true>(slot64, d->off64, dim3(retry_blocks), lds_g, st, d->di, p, cg, w->retry_list,
-                                                                      w->retry_cnt, nullptr, nullptr, w->gscratch, g_stride, nullptr)));
-        else HIP_TRY((launch_variant<kBlock, true, 0, false>(slot64, d->off64, dim3(retry_blocks), lds_g, st, d->di, p, cg, w->retry_list,
-                                                              w->retry_cnt, nullptr, nullptr, w->gscratch, g_stride, nullptr)));
+        if (geo.masks) HIP_TRY((launch_variant<kBlock, true, 0, true>(slot64, dim3(retry_blocks), lds_g, st, d->di, p, cg, w->retry_list,
+                                                                      w->retry_cnt, nullptr, nullptr, w->gscratch, g_stride, spill)));
+        else HIP_TRY((launch_variant<kBlock, true, 0, false>(slot64, dim3(retry_blocks), lds_g, st, d->di, p, cg, w->retry_list,
+                                                              w->retry_cnt, nullptr, nullptr, w->gscratch, g_stride, spill)));
         HIP_TRY(hipMemcpyAsync(w->h_retry, w->retry_cnt, 4, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipEventRecord(ev[2], st));
@@ -1139,7 +1212,7 @@ int device_shard_stage(DeviceState* d, const FlatIndex& ix, int stage, const Lau
     const uint32_t grid = (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * std::min<uint32_t>(blocks_per_cu, 2048 / kBlock) * 4);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;
-#define SRN_STAGE(N, M) launch_variant<kBlock, false, N, M>(geo.slot64, d->off64, dim3(grid), geo.lds, st, d->di, p, geo.c, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, sh)
+#define SRN_STAGE(N, M) launch_variant<kBlock, false, N, M>(geo.slot64, dim3(grid), geo.lds, st, d->di, p, geo.c, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, sh)
     if (stage == 1) e = geo.masks ? SRN_STAGE(1, true) : SRN_STAGE(1, false);
     else if (stage == 2) e = geo.masks ? SRN_STAGE(2, true) : SRN_STAGE(2, false);
     else if (stage == 3) e = geo.masks ? SRN_STAGE(3, true) : SRN_STAGE(3, false);

@@ -31,6 +31,10 @@ def _check_batch(gix, oix, queries, k, m, how_many, business=False, check_neighb
         assert np.array_equal(res["ids"][q, :n], ref["ids"][q, :n]), (q, queries[q], res["ids"][q, :n], ref["ids"][q, :n])
         np.testing.assert_allclose(res["scores"][q, :n], ref["scores"][q, :n], rtol=SCORE_RTOL, atol=0)
     assert np.array_equal(res["stats"][:, :7].astype(np.uint64), ref["stats"]), "P,C,K,I,D,H,L counters differ"
+    # the product call: the debug counters switch the sketch pre-filter off (they need every scored item), this one has it on
+    ids, scores, counts = sa.predict_batch(gix, queries, k, m, how_many, business)
+    assert np.array_equal(counts, res["counts"]) and np.array_equal(ids, res["ids"]) and np.array_equal(scores, res["scores"]), \
+        "filtered (product) path differs from the unfiltered (debug) path"
     if check_neighbours:
         for q in range(len(queries)):
             sid, num, _U = oix.neighbors_canonical(queries[q], k, m)
@@ -56,10 +60,11 @@ def test_kat1_should_train_and_predict():
         assert r.score == pytest.approx(1.751319134149782, rel=1e-12)
 
 
-@pytest.fixture(params=["default", "no_masks", "no_hot", "hot64"])
+@pytest.fixture(params=["default", "no_masks", "no_hot", "hot64", "no_sketch", "sketch64"])
 def kernel_path(request, monkeypatch):
     """The kernel picks code paths per launch: position-set slots (sessions <= 8 items) vs numerator slots + first-match
-    pass; direct-mapped accumulators for popular items vs hash only.  The knobs force each combination."""
+    pass; direct-mapped accumulators for popular items vs hash only; sketch pre-filter on / off / tiny.  The knobs force
+    each combination."""
     if request.param == "no_masks":
         monkeypatch.setenv("SRN_NO_MASKS", "1")
     elif request.param == "no_hot":
@@ -67,6 +72,11 @@ def kernel_path(request, monkeypatch):
     elif request.param == "hot64":
         monkeypatch.setenv("SRN_HOT_SLOTS", "64")
         monkeypatch.setenv("SRN_NO_MASKS", "1")
+    elif request.param == "no_sketch":
+        monkeypatch.setenv("SRN_SKETCH_SLOTS", "0")
+    elif request.param == "sketch64":          # heavy collisions in the upper-bound words: the filter must stay exact
+        monkeypatch.setenv("SRN_SKETCH_SLOTS", "64")
+        monkeypatch.setenv("SRN_HOT_SLOTS", "32")
     return request.param
 
 
@@ -273,8 +283,9 @@ def test_baseline_configs_full_size(config, n_check, monkeypatch):
     np.testing.assert_allclose(res["scores"], ref["scores"], rtol=SCORE_RTOL, atol=0)
     assert np.array_equal(res["stats"][:, :7].astype(np.uint64), ref["stats"])
     assert (res["stats"][:, 1] == m).any() and (res["stats"][:, 2] == k).any()      # both cuts are exercised at this size
-    a = sa.predict_batch(gix, (qi, qo), k, m, synth.HOW_MANY)
-    monkeypatch.setenv("SRN_NO_MASKS", "1")
+    a = sa.predict_batch(gix, (qi, qo), k, m, synth.HOW_MANY)     # product path: sketch pre-filter on
+    assert np.array_equal(a[0][:n_check], res["ids"]) and np.array_equal(a[1][:n_check], res["scores"])
+    monkeypatch.setenv("SRN_NO_MASKS", "1")                        # no direct-mapped part => no threshold => nothing filtered
     monkeypatch.setenv("SRN_HOT_SLOTS", "0")
     b = sa.predict_batch(gix, (qi, qo), k, m, synth.HOW_MANY)
     for x, y in zip(a, b):

@@ -18,10 +18,11 @@ capi.FLAG_BUSINESS_LOGIC = FL
 for rep in range(2):
     sa.predict_batch(ix, (qi, qo), k, m, 21, bool(FL))
 ix.debug_phase_cycles(True)
-t0 = time.time(); r = sa.predict_batch_debug(ix, (qi, qo), k, m, 21, bool(FL), neighbours=False); dt = time.time() - t0
+t0 = time.time(); sa.predict_batch(ix, (qi, qo), k, m, 21, bool(FL)); dt = time.time() - t0
 cyc = ix.debug_phase_cycles(False).astype(np.float64)
 ms, msr, _ = ix.last_kernel_ms()
-names = ["0 prep+clear", "1 postings->sess", "2 m-cut select", "3 k-cut select", "4 compact+clear", "5 (unused)", "6 score+topn", "7", "8 p5 clear+sync", "9 p5 group load+scan", "10 p5 gather", "11 p5 B1", "12 p5 B2", "13 p5 flush+wait", "14 p6 scan+append", "15 p6 sorts"]
+r = sa.predict_batch_debug(ix, (qi, qo), k, m, 21, bool(FL), neighbours=False)
+names = ["0 prep+clear", "1 postings->sess", "2 m-cut select", "3 k-cut select", "4 compact+clear", "5 wA: issue+weight", "6 wA: head adds", "7 wA: tail loop", "8 clear hot+sketch", "9 walk A", "10 harvest hot", "11 live check+clear", "12 walk B", "13 harvest exact", "14 wA: prologue", "15"]
 print("main %.2f ms retry %.2f ms  total cycles %.3g" % (ms, msr, cyc.sum()))
 for n, c in zip(names, cyc):
     print("  %-18s %6.2f%%  %.0f cyc/query" % (n, 100 * c / cyc.sum(), c / B))
