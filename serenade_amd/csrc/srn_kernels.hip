@@ -57,11 +57,12 @@ struct KernelCfg {
     uint32_t num_bits;                 // low bits of a session slot that hold the numerator
     uint32_t q_cap;                    // capacity of the per-query item arrays (>= max_len, multiple of 4)
     uint32_t off_q, off_wave, off_b, off_a;   // LDS byte offsets: query arrays, per-wave scratch, region B, region A
+    uint32_t region_a_bytes;                  // size of region A in LDS (0 when the tables live in global memory)
 };
 
 // LDS scalar slots
 enum { S_CNT = 0, S_OVF, S_XLO, S_RMAX, S_U, S_P, S_SUMW, S_SELD, S_SELR, S_NB, S_ICNT, S_CCNT, S_I, S_HAVE_T, S_TIDX,
-       S_ERR, S_TKEY_LO, S_TKEY_HI, S_COVF, S_SORTED, S_LIVE };
+       S_ERR, S_TKEY_LO, S_TKEY_HI, S_COVF, S_SORTED, S_LIVE, S_L1, S_L2, S_NK };
 
 template <typename T> struct SlotTraits;
 template <> struct SlotTraits<uint32_t> { static constexpr uint32_t EMPTY = 0xFFFFFFFFu; };
@@ -127,6 +128,47 @@ static constexpr int SEL_BITS = 11, SEL_BINS = 1 << SEL_BITS;
 // one-word skew all 64 lanes would read the same LDS bank (64-way conflict on each of the 32 reads)
 static constexpr int SEL_WORDS = SEL_BINS + SEL_BINS / 32;
 __device__ __forceinline__ uint32_t sel_word(uint32_t bin) { return bin + (bin >> 5); }
+// The bin (bins counted from the top) that holds the `remain`-th largest entry of a 2048-bin histogram: wave 0 searches
+// (lane owns bins [32 lane, 32 lane + 32), suffix sums from the top bin down), writes misc[S_SELD] = bin and
+// misc[S_SELR] = rank of the wanted entry inside that bin, and clears the histogram.  The histogram must be complete
+// (barrier) on entry; ends with a barrier.
+template <int BLOCK>
+__device__ void hist_search(uint32_t* hist, uint32_t remain, volatile uint32_t* misc) {
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        constexpr int PER = SEL_BINS / 64;   // 32 bins per lane, kept as 4 group sums of 8 (not 32 registers)
+        uint32_t g[4];
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) { uint32_t t = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t += hist[sel_word(PER * tid + gi * 8 + j)];
+            g[gi] = t; }
+        const uint32_t s = g[0] + g[1] + g[2] + g[3];
+        uint32_t inc = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_down(inc, d, 64); if (tid + d < 64) inc += t; }
+        uint32_t above = inc - s;   // entries in bins owned by higher lanes
+        if (above < remain && remain <= above + s) {   // the target bin is one of mine: find the group of 8, then the bin
+            int gsel = -1; uint32_t ab = above;
+#pragma unroll
+            for (int gi = 3; gi >= 0; --gi) {
+                if (gsel < 0 && ab < remain && remain <= ab + g[gi]) { gsel = gi; above = ab; }
+                ab += g[gi];
+            }
+            uint32_t cj[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cj[j] = hist[sel_word(PER * tid + gsel * 8 + j)];
+#pragma unroll
+            for (int j = 7; j >= 0; --j) {
+                if (above < remain && remain <= above + cj[j]) { misc[S_SELD] = PER * tid + gsel * 8 + j; misc[S_SELR] = remain - above; }
+                above += cj[j];
+            }
+        }
+#pragma unroll 8
+        for (int j = 0; j < PER; ++j) hist[sel_word(PER * tid + j)] = 0;
+    }
+    __syncthreads();
+}
 template <int BLOCK, typename KeyT, typename F>
 __device__ KeyT block_select_desc(F keyfn, uint32_t n, int nbits, uint32_t r, uint32_t* hist, volatile uint32_t* misc) {
     const int tid = threadIdx.x;
@@ -146,39 +188,7 @@ __device__ KeyT block_select_desc(F keyfn, uint32_t n, int nbits, uint32_t r, ui
             }
         }
         __syncthreads();
-        if (tid < 64) {   // lane owns bins [32 lane, 32 lane + 32); suffix sums from the top bin down
-            constexpr int PER = SEL_BINS / 64;   // 32 bins per lane, kept as 4 group sums of 8 (not 32 registers)
-            uint32_t g[4];
-#pragma unroll
-            for (int gi = 0; gi < 4; ++gi) { uint32_t t = 0;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) t += hist[sel_word(PER * tid + gi * 8 + j)];
-                g[gi] = t; }
-            const uint32_t s = g[0] + g[1] + g[2] + g[3];
-            uint32_t inc = s;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_down(inc, d, 64); if (tid + d < 64) inc += t; }
-            uint32_t above = inc - s;   // entries in bins owned by higher lanes
-            if (above < remain && remain <= above + s) {   // the target bin is one of mine: find the group of 8, then the bin
-                int gsel = -1; uint32_t ab = above;
-#pragma unroll
-                for (int gi = 3; gi >= 0; --gi) {
-                    if (gsel < 0 && ab < remain && remain <= ab + g[gi]) { gsel = gi; above = ab; }
-                    ab += g[gi];
-                }
-                uint32_t cj[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) cj[j] = hist[sel_word(PER * tid + gsel * 8 + j)];
-#pragma unroll
-                for (int j = 7; j >= 0; --j) {
-                    if (above < remain && remain <= above + cj[j]) { misc[S_SELD] = PER * tid + gsel * 8 + j; misc[S_SELR] = remain - above; }
-                    above += cj[j];
-                }
-            }
-#pragma unroll 8
-            for (int j = 0; j < PER; ++j) hist[sel_word(PER * tid + j)] = 0;
-        }
-        __syncthreads();
+        hist_search<BLOCK>(hist, remain, misc);
         prefix = (KeyT)((prefix << w) | (KeyT)misc[S_SELD]);
         remain = misc[S_SELR];
         rem = shift;
@@ -480,6 +490,10 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
         } else {
             uint32_t fresh = 0, pos = 0;
             bool ovf = false;
+            // if an m-cut is possible, count the distinct sessions per top-11-bit bin of (rank - x_lo) as they are inserted:
+            // the first pass of the m-cut select comes for free
+            const bool want_h1 = !GLOBAL_TABLES && P > p.m;
+            const int sh1 = max(bits_for(r_max - x_lo) - SEL_BITS, 0);
             for (uint32_t e0 = tid; e0 < P; e0 += 4 * BLOCK) {
                 uint32_t r[4], w[4];
 #pragma unroll
@@ -496,7 +510,8 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                 for (int u = 0; u < 4; ++u) {
                     if (w[u] && r[u] >= x_lo) {
                         const int res = sess_insert<SlotT, MASKS>(stab, smask, NB, r[u], w[u]);
-                        if (res < 0) ovf = true; else fresh += (uint32_t)res;
+                        if (res < 0) ovf = true;
+                        else if (res) { ++fresh; if (want_h1) atomicAdd(&hist[sel_word((r[u] - x_lo) >> sh1)], 1u); }
                     }
                 }
             }
@@ -517,13 +532,119 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
         const uint32_t x_lo2 = STAGE == 2 ? (Call ? misc[S_XLO] : 0u) : x_lo, r_max2 = STAGE == 2 ? misc[S_RMAX] : r_max;
 
         // ---- phase 2: m-cut, k-cut, compaction -------------------------------------------
+        // ONE scan of the (sparse) session table, everything else on dense lists.  m-cut: the histogram of phase 1 gives
+        // the top-11-bit rank bin of the m-th most recent session; the scan moves every session above that bin to the
+        // dense list D and the bin's own few sessions to S1, whose r1 most recent join D.  k-cut: histogram of D by the
+        // top 11 bits of the composite (numerator, rank), the bin of the k-th best; D's sessions above that bin go to
+        // the neighbour list, the bin's own to S2, whose r2 best follow.  The session table is dead after the scan, so
+        // the second histogram and the lists of the k-cut live in its LDS.  Lists that do not fit (very large m, k or
+        // boundary bins) and the global-table pass fall back to radix selects over the table.
+        const bool mcut = Call > p.m, kcut = STAGE != 1 && Cm > p.k;
         uint32_t tau = x_lo2;
+        bool legacy = STAGE == 2 || GLOBAL_TABLES;   // (stage B learns the rank range only while inserting: no phase-1 histogram)
+        if constexpr (STAGE != 2 && !GLOBAL_TABLES) {
+            const uint32_t rb_slots = (c.off_a - c.off_b) / (uint32_t)sizeof(SlotT);
+            SlotT* dl = (SlotT*)region_b;                       // D (becomes the neighbour list)
+            const uint32_t CAP_S1 = rb_slots > p.m ? rb_slots - p.m : 0u, CAP_S2 = p.m;   // S2 cannot overflow (<= |D| <= m)
+            SlotT* s1 = dl + p.m;
+            uint32_t* hist2 = (uint32_t*)region_a;              // after the scan
+            SlotT* tmp = (SlotT*)(region_a + SEL_WORDS * 4);
+            SlotT* s2 = tmp + p.k;
+            if (CAP_S1 < 64 || c.region_a_bytes < SEL_WORDS * 4 + (p.k + CAP_S2) * (uint32_t)sizeof(SlotT)) legacy = true;   // launch-uniform
+            if (!legacy) {
+                const int rb_all = bits_for(r_max2 - x_lo2), sh1 = max(rb_all - SEL_BITS, 0);
+                const int sh2 = max(bits_for(misc[S_SUMW]) + rb_all - SEL_BITS, 0);
+                auto comp_of = [&](SlotT s) -> unsigned long long { return ((unsigned long long)num_of(s) << rb_all) | (unsigned long long)((uint32_t)(s >> NB) - x_lo2); };
+                uint32_t b1 = 0, r1 = 0;
+                if (mcut) { hist_search<BLOCK>(hist, p.m, misc); b1 = misc[S_SELD]; r1 = misc[S_SELR]; }
+                for (uint32_t i0 = 0; i0 < sslots; i0 += 8 * BLOCK) {   // the scan
+                    SlotT sv[8]; unsigned long long bm[8]; uint32_t total = 0;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { const uint32_t i = i0 + u * BLOCK + tid; sv[u] = i < sslots ? stab[i] : SEMPTY; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const bool valid = sv[u] != SEMPTY;
+                        const uint32_t rb = ((uint32_t)(sv[u] >> NB) - x_lo2) >> sh1;
+                        bm[u] = __ballot(valid && (!mcut || rb > b1)); total += (uint32_t)__popcll(bm[u]);
+                        const bool edge = mcut && valid && rb == b1;
+                        const uint32_t at = wave_append(edge, (uint32_t*)&misc[S_L1]);
+                        if (edge && at < CAP_S1) s1[at] = sv[u];
+                    }
+                    uint32_t base = 0;
+                    if (total) { if (lane == 0) base = atomicAdd((uint32_t*)&misc[S_NB], total); base = __shfl(base, 0, 64); }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if ((bm[u] >> lane) & 1ull) dl[base + (uint32_t)__popcll(bm[u] & ((1ull << lane) - 1ull))] = sv[u];
+                        base += (uint32_t)__popcll(bm[u]);
+                    }
+                }
+                __syncthreads();
+                SRN_TICK(2);
+                const uint32_t n1 = misc[S_L1];
+                if (n1 > CAP_S1) legacy = true;   // block-uniform
+                else {
+                    for (uint32_t t = tid; t < n1; t += BLOCK) {   // the r1 most recent sessions of the boundary bin
+                        const SlotT v = s1[t]; const uint32_t my = (uint32_t)(v >> NB); uint32_t above = 0;
+                        for (uint32_t j = 0; j < n1; ++j) above += (uint32_t)(s1[j] >> NB) > my;
+                        if (above < r1) dl[atomicAdd((uint32_t*)&misc[S_NB], 1u)] = v;
+                    }
+                    if (kcut) for (uint32_t i = tid; i < SEL_WORDS; i += BLOCK) hist2[i] = 0;   // (the table is dead)
+                    __syncthreads();
+                    const uint32_t nd = misc[S_NB];   // == Cm
+                    uint32_t b2 = 0, r2 = 0;
+                    if (kcut) {
+                        for (uint32_t i = tid; i < nd; i += BLOCK) atomicAdd(&hist2[sel_word((uint32_t)(comp_of(dl[i]) >> sh2))], 1u);
+                        __syncthreads();
+                        hist_search<BLOCK>(hist2, p.k, misc); b2 = misc[S_SELD]; r2 = misc[S_SELR];
+                        SRN_TICK(3);
+                        for (uint32_t i0 = 0; i0 < nd; i0 += BLOCK) {
+                            const uint32_t i = i0 + tid; const SlotT v = i < nd ? dl[i] : SEMPTY;
+                            const uint32_t bb = i < nd ? (uint32_t)(comp_of(v) >> sh2) : 0u;
+                            const uint32_t at = wave_append(i < nd && bb > b2, (uint32_t*)&misc[S_NK]);   // (own counter: S_NB is still being read as |D|)
+                            if (i < nd && bb > b2) tmp[at] = v;
+                            const uint32_t at2 = wave_append(i < nd && bb == b2, (uint32_t*)&misc[S_L2]);
+                            if (i < nd && bb == b2 && at2 < CAP_S2) s2[at2] = v;
+                        }
+                        __syncthreads();
+                        const uint32_t n2 = misc[S_L2];
+                        if (n2 <= 128) {
+                            for (uint32_t t = tid; t < n2; t += BLOCK) {   // the r2 best of the boundary bin
+                                const SlotT v = s2[t]; const unsigned long long my = comp_of(v); uint32_t above = 0;
+                                for (uint32_t j = 0; j < n2; ++j) above += comp_of(s2[j]) > my;
+                                if (above < r2) tmp[atomicAdd((uint32_t*)&misc[S_NK], 1u)] = v;
+                            }
+                        } else {   // a crowded bin: radix select on the composite's remaining low bits (dense list: cheap passes)
+                            const unsigned long long low = (1ull << sh2) - 1ull;
+                            const unsigned long long thr = block_select_desc<BLOCK, unsigned long long>(
+                                [&](uint32_t i, unsigned long long& key) { key = comp_of(s2[i]) & low; return true; }, n2, sh2, r2, hist2, misc);
+                            for (uint32_t t = tid; t < n2; t += BLOCK) { const SlotT v = s2[t]; if ((comp_of(v) & low) >= thr) tmp[atomicAdd((uint32_t*)&misc[S_NK], 1u)] = v; }
+                        }
+                        __syncthreads();
+                    }
+                    if (!legacy) {   // publish: D (no k-cut) or tmp -> neighbour list in region B, its global copy, debug dump
+                        const uint32_t kk = kcut ? misc[S_NK] : misc[S_NB];
+                        for (uint32_t i = tid; i < kk; i += BLOCK) {
+                            const SlotT v = kcut ? tmp[i] : dl[i];
+                            if (STAGE == 1) ((SlotT*)sh.cand)[(size_t)q * p.m + i] = v; else { if (kcut) nbl[i] = v; if (STAGE == 0) nb_spill[i] = v; }
+                            if (STAGE == 0 && p.nb_rank) { p.nb_rank[(size_t)q * p.k + i] = (uint32_t)(v >> NB); p.nb_num[(size_t)q * p.k + i] = num_of(v); }
+                        }
+                        if (kcut) { __syncthreads(); if (tid == 0) misc[S_NB] = kk; }   // every thread has read |D| long ago
+                    }
+                }
+            }
+            if (legacy) {   // start over with the radix selects
+                __syncthreads();
+                for (uint32_t i = tid; i < SEL_WORDS; i += BLOCK) hist[i] = 0;
+                if (tid == 0) misc[S_NB] = 0;
+                __syncthreads();
+            }
+        }
+        if (legacy) {
         if (Call > p.m) {
             tau = x_lo2 + block_select_desc<BLOCK, uint32_t>(
                 [&](uint32_t i, uint32_t& key) { const SlotT s = stab[i]; key = (uint32_t)(s >> NB) - x_lo2; return s != SEMPTY; },
                 sslots, bits_for(r_max2 - x_lo2), p.m, hist, misc);
         }
-        SRN_TICK(2);
         const int rbits = bits_for(r_max2 - tau);
         unsigned long long kappa = 0;   // composite threshold: (num << rbits) | (rank - tau)
         if (STAGE != 1 && Cm > p.k) {   // (a shard's stage A keeps all of its <= m candidates: the k-cut is global)
@@ -535,7 +656,6 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
             if (nbits <= 32) kappa = block_select_desc<BLOCK, uint32_t>(comp, sslots, nbits, p.k, hist, misc);
             else kappa = block_select_desc<BLOCK, unsigned long long>(comp, sslots, nbits, p.k, hist, misc);
         }
-        SRN_TICK(3);
         for (uint32_t i0 = 0; i0 < sslots; i0 += 8 * BLOCK) {
             SlotT sv[8]; unsigned long long bm[8]; uint32_t total = 0;
 #pragma unroll
@@ -557,6 +677,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                 }
                 base += (uint32_t)__popcll(bm[u]);
             }
+        }
         }
         __syncthreads();
         K = misc[S_NB];
@@ -1100,6 +1221,7 @@ static int make_geometry(const DeviceState* d, const FlatIndex& ix, const Launch
     c.item_buckets = prime_at_most((uint32_t)std::min<uint64_t>((a_max - hot * 4 - sk * 4) / 32, want_buckets));
     c.item_slots = c.item_buckets * 4;
     const uint32_t region_a = std::max<uint32_t>(hot * 4 + sk * 4 + c.item_slots * 8, c.sess_slots * slot_bytes);
+    c.region_a_bytes = region_a;
     g.lds = (size_t)c.off_a + region_a;
     // tables at least twice the worst case cannot exhaust the probe budget: no retry machinery needed
     g.sess_may_overflow = (uint64_t)c.sess_slots < g.need_sess * 2; g.item_may_overflow = (uint64_t)c.item_slots < g.need_item * 2;
