@@ -494,8 +494,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
             // the first pass of the m-cut select comes for free
             const bool want_h1 = !GLOBAL_TABLES && P > p.m;
             const int sh1 = max(bits_for(r_max - x_lo) - SEL_BITS, 0);
-            for (uint32_t e0 = tid; e0 < P; e0 += 4 * BLOCK) {
-                uint32_t r[4], w[4];
+            auto fetch = [&](uint32_t e0, uint32_t (&r)[4], uint32_t (&w)[4]) {   // 4 list entries of this lane (coalesced across lanes)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t e = e0 + u * BLOCK;
@@ -505,15 +504,22 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                         r[u] = ix.post_rank[l_base[pos] + (e - l_pre[pos])];
                         w[u] = MASKS ? (1u << pos) : L - pos;
                     }
-                }
+                } };
+            auto note_fresh = [&](uint32_t rank) { ++fresh; if (want_h1) atomicAdd(&hist[sel_word((rank - x_lo) >> sh1)], 1u); };
+            auto insert4 = [&](uint32_t (&r)[4], uint32_t (&w)[4]) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     if (w[u] && r[u] >= x_lo) {
                         const int res = sess_insert<SlotT, MASKS>(stab, smask, NB, r[u], w[u]);
-                        if (res < 0) ovf = true;
-                        else if (res) { ++fresh; if (want_h1) atomicAdd(&hist[sel_word((r[u] - x_lo) >> sh1)], 1u); }
+                        if (res < 0) ovf = true; else if (res) note_fresh(r[u]);
                     }
-                }
+                } };
+            // (measured: neither prefetching the next batch's entries nor probing the 4 buckets of a batch together helps --
+            //  the loop is bound by instruction issue, not by the list loads or the LDS round trips)
+            for (uint32_t e0 = tid; e0 < P; e0 += 4 * BLOCK) {
+                uint32_t r[4], w[4];
+                fetch(e0, r, w);
+                insert4(r, w);
             }
             fresh = wave_sum(fresh);
             if (lane == 0 && fresh) atomicAdd((uint32_t*)&misc[S_CNT], fresh);
@@ -558,7 +564,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                 uint32_t b1 = 0, r1 = 0;
                 if (mcut) { hist_search<BLOCK>(hist, p.m, misc); b1 = misc[S_SELD]; r1 = misc[S_SELR]; }
                 for (uint32_t i0 = 0; i0 < sslots; i0 += 8 * BLOCK) {   // the scan
-                    SlotT sv[8]; unsigned long long bm[8]; uint32_t total = 0;
+                    SlotT sv[8]; unsigned long long bm[8]; uint32_t total = 0, edges = 0;
 #pragma unroll
                     for (int u = 0; u < 8; ++u) { const uint32_t i = i0 + u * BLOCK + tid; sv[u] = i < sslots ? stab[i] : SEMPTY; }
 #pragma unroll
@@ -566,9 +572,15 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                         const bool valid = sv[u] != SEMPTY;
                         const uint32_t rb = ((uint32_t)(sv[u] >> NB) - x_lo2) >> sh1;
                         bm[u] = __ballot(valid && (!mcut || rb > b1)); total += (uint32_t)__popcll(bm[u]);
-                        const bool edge = mcut && valid && rb == b1;
-                        const uint32_t at = wave_append(edge, (uint32_t*)&misc[S_L1]);
-                        if (edge && at < CAP_S1) s1[at] = sv[u];
+                        edges |= (mcut && valid && rb == b1) ? 1u << u : 0u;
+                    }
+                    if (__ballot(edges != 0) != 0ull) {   // rare: some slot of this batch lies in the boundary bin
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const bool edge = (edges >> u) & 1u;
+                            const uint32_t at = wave_append(edge, (uint32_t*)&misc[S_L1]);
+                            if (edge && at < CAP_S1) s1[at] = sv[u];
+                        }
                     }
                     uint32_t base = 0;
                     if (total) { if (lane == 0) base = atomicAdd((uint32_t*)&misc[S_NB], total); base = __shfl(base, 0, 64); }
@@ -597,13 +609,26 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                         __syncthreads();
                         hist_search<BLOCK>(hist2, p.k, misc); b2 = misc[S_SELD]; r2 = misc[S_SELR];
                         SRN_TICK(3);
-                        for (uint32_t i0 = 0; i0 < nd; i0 += BLOCK) {
-                            const uint32_t i = i0 + tid; const SlotT v = i < nd ? dl[i] : SEMPTY;
-                            const uint32_t bb = i < nd ? (uint32_t)(comp_of(v) >> sh2) : 0u;
-                            const uint32_t at = wave_append(i < nd && bb > b2, (uint32_t*)&misc[S_NK]);   // (own counter: S_NB is still being read as |D|)
-                            if (i < nd && bb > b2) tmp[at] = v;
-                            const uint32_t at2 = wave_append(i < nd && bb == b2, (uint32_t*)&misc[S_L2]);
-                            if (i < nd && bb == b2 && at2 < CAP_S2) s2[at2] = v;
+                        for (uint32_t i0 = 0; i0 < nd; i0 += 8 * BLOCK) {   // 8 per lane, one atomic per wave and list
+                            SlotT sv[8]; unsigned long long ba[8], be[8]; uint32_t ta = 0, te = 0;
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) { const uint32_t i = i0 + u * BLOCK + tid; sv[u] = i < nd ? dl[i] : SEMPTY; }
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                const bool in = i0 + u * BLOCK + tid < nd;
+                                const uint32_t bb = (uint32_t)(comp_of(sv[u]) >> sh2);
+                                ba[u] = __ballot(in && bb > b2); be[u] = __ballot(in && bb == b2);
+                                ta += (uint32_t)__popcll(ba[u]); te += (uint32_t)__popcll(be[u]);
+                            }
+                            uint32_t basea = 0, basee = 0;
+                            if (lane == 0) { if (ta) basea = atomicAdd((uint32_t*)&misc[S_NK], ta); if (te) basee = atomicAdd((uint32_t*)&misc[S_L2], te); }   // (S_NK: S_NB is still being read as |D|)
+                            basea = __shfl(basea, 0, 64); basee = __shfl(basee, 0, 64);
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                if ((ba[u] >> lane) & 1ull) tmp[basea + (uint32_t)__popcll(ba[u] & ((1ull << lane) - 1ull))] = sv[u];
+                                if ((be[u] >> lane) & 1ull) { const uint32_t at2 = basee + (uint32_t)__popcll(be[u] & ((1ull << lane) - 1ull)); if (at2 < CAP_S2) s2[at2] = sv[u]; }
+                                basea += (uint32_t)__popcll(ba[u]); basee += (uint32_t)__popcll(be[u]);
+                            }
                         }
                         __syncthreads();
                         const uint32_t n2 = misc[S_L2];
@@ -807,18 +832,92 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
         phase_sync<GLOBAL_TABLES>();
         SRN_TICK(8);
         {   // walk A
-            const uint32_t isum = wave_sum(walk_rows(nb_lds, [&](uint32_t j, uint32_t num, auto&& for_row) {
-                const int w = row_weight(j, num, for_row);
-                const uint32_t wpos = SK ? (uint32_t)max(w, 0) : 0u, whot = (1u << SB) + (uint32_t)w;
-                // one LDS add per element: idx < H -> its direct-mapped word, anything else -> its sketch word (sketch = hot + H;
-                // without a sketch the add is + 0 into the word after the direct-mapped part)
-                for_row([&](const auto& it) {
-                    constexpr int N = sizeof(it) / sizeof(it[0]);
+            // one LDS add per element: idx < H -> its direct-mapped word, anything else -> its sketch word (sketch = hot + H;
+            // without a sketch the add is + 0 into the word after the direct-mapped part)
+            auto add_items = [&](const auto& it, uint32_t whot, uint32_t wpos) {
+                constexpr int N = sizeof(it) / sizeof(it[0]);
 #pragma unroll
-                    for (int x = 0; x < N; ++x) {
-                        const bool is_hot = it[x] < H;
-                        if (it[x] != EMPTY32) atomicAdd(&hot[is_hot ? it[x] : H + sketch_hash(it[x], SKSH)], is_hot ? whot : wpos);
-                    } }); }));
+                for (int x = 0; x < N; ++x) {
+                    const bool is_hot = it[x] < H;
+                    if (it[x] != EMPTY32) atomicAdd(&hot[is_hot ? it[x] : H + sketch_hash(it[x], SKSH)], is_hot ? whot : wpos);
+                } };
+            uint32_t isum = 0;
+            if constexpr (MASKS && STAGE == 0) {
+                // Rows differ in length and a wave pays for its longest lane, so the rows are walked in three rounds of
+                // like work: (i) every neighbour's first 7 items; neighbours with more are queued, (ii) items 7..14 of the
+                // queued rows; rows that continue in the overflow area are queued again, (iii) those.  A wave queues into
+                // the neighbour-list slots of its own groups that it has already consumed: no extra LDS.  (The row weight
+                // is a function of the slot's position set, so a queued slot carries everything.)
+                constexpr uint32_t GSTEP = NWAVES * 64;
+                auto qpos = [&](uint32_t pq) -> uint32_t { return ((wave + NWAVES * (pq >> 6)) << 6) + (pq & 63u); };
+                auto weight_of = [&](uint32_t num, uint32_t& whot, uint32_t& wpos) {
+                    const int mp = num ? __ffs((int)num) - 1 : MINPOS_NONE;
+                    const int w = (mp < 99 ? 10 - (mp + 1) : 0) * (int)wlut[num];
+                    whot = (1u << SB) + (uint32_t)w; wpos = SK ? (uint32_t)max(w, 0) : 0u; };
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                uint32_t qn = 0;
+                if ((uint32_t)wave * 64 < K) {
+                    SlotT sv = nbl[min((uint32_t)(wave * 64 + lane), K - 1)], nsv = 0;
+                    size_t r = (uint32_t)(wave * 64 + lane) < K ? (size_t)(uint32_t)(sv >> NB) : (size_t)ix.n_kept;
+                    RowQuad a = ix.row_slots[4 * r], b = ix.row_slots[4 * r + 1], na, nb;
+                    for (uint32_t g0 = wave * 64; g0 < K; g0 += GSTEP) {   // (i)
+                        const uint32_t jn = g0 + GSTEP + lane;
+                        nsv = nbl[min(jn, K - 1)];
+                        const size_t nr = jn < K ? (size_t)(uint32_t)(nsv >> NB) : (size_t)ix.n_kept;
+                        na = ix.row_slots[4 * nr]; nb = ix.row_slots[4 * nr + 1];
+                        const uint32_t len = a.x;   // (0 for the idle lanes' empty slot)
+                        uint32_t whot, wpos; weight_of((uint32_t)(sv & num_mask), whot, wpos);
+                        isum += len;
+                        const uint32_t it7[7] = {len > 15 ? EMPTY32 : a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                        add_items(it7, whot, wpos);
+                        const bool more = len > 7;
+                        const unsigned long long bm = __ballot(more);
+                        if (more) nbl[qpos(qn + (uint32_t)__popcll(bm & lt))] = sv;   // (all lanes hold their slot in a register by now)
+                        qn += (uint32_t)__popcll(bm);
+                        sv = nsv; a = na; b = nb;
+                    }
+                }
+                uint32_t qn2 = 0;
+                for (uint32_t p0 = 0; p0 < qn; p0 += 64) {   // (ii)
+                    const bool act = p0 + lane < qn;
+                    const SlotT sv = nbl[qpos(min(p0 + lane, qn - 1))];
+                    const size_t r = act ? (size_t)(uint32_t)(sv >> NB) : (size_t)ix.n_kept;
+                    const RowQuad c4 = ix.row_slots[4 * r + 2], d4 = ix.row_slots[4 * r + 3];
+                    const uint32_t len = ix.row_slots[4 * r].x;
+                    uint32_t whot, wpos; weight_of((uint32_t)(sv & num_mask), whot, wpos);
+                    const uint32_t it8[8] = {c4.x, c4.y, c4.z, c4.w, d4.x, d4.y, d4.z, d4.w};
+                    add_items(it8, whot, wpos);
+                    const bool more = len > 15;
+                    const unsigned long long bm = __ballot(more);
+                    if (more) nbl[qpos(qn2 + (uint32_t)__popcll(bm & lt))] = sv;
+                    qn2 += (uint32_t)__popcll(bm);
+                }
+                for (uint32_t p0 = 0; p0 < qn2; p0 += 64) {   // (iii)
+                    const bool act = p0 + lane < qn2;
+                    const SlotT sv = nbl[qpos(min(p0 + lane, qn2 - 1))];
+                    const size_t r = act ? (size_t)(uint32_t)(sv >> NB) : (size_t)ix.n_kept;
+                    const RowQuad a = ix.row_slots[4 * r];
+                    const uint32_t len = a.x; const bool big = len > 15;
+                    const uint32_t* ext = ix.row_ext + (big ? a.y : 0u);
+                    uint32_t whot, wpos; weight_of((uint32_t)(sv & num_mask), whot, wpos);
+                    for (uint32_t t = 14; __ballot(big && t < len) != 0ull; t += 8) {
+                        uint32_t it8[8];
+#pragma unroll
+                        for (int x = 0; x < 8; ++x) it8[x] = EMPTY32;
+                        if (big && t < len) { const RowVec v = *reinterpret_cast<const RowVec*>(ext + (t - 14)); it8[0] = v.x; it8[1] = v.y; it8[2] = v.z; it8[3] = v.w; }
+                        if (big && t + 4 < len) { const RowVec v = *reinterpret_cast<const RowVec*>(ext + (t - 14) + 4); it8[4] = v.x; it8[5] = v.y; it8[6] = v.z; it8[7] = v.w; }
+#pragma unroll
+                        for (uint32_t x = 1; x < 8; ++x) if (t + x >= len) it8[x] = EMPTY32;
+                        add_items(it8, whot, wpos);
+                    }
+                }
+            } else {
+                isum = walk_rows(nb_lds, [&](uint32_t j, uint32_t num, auto&& for_row) {
+                    const int w = row_weight(j, num, for_row);
+                    const uint32_t wpos = SK ? (uint32_t)max(w, 0) : 0u, whot = (1u << SB) + (uint32_t)w;
+                    for_row([&](const auto& it) { add_items(it, whot, wpos); }); });
+            }
+            isum = wave_sum(isum);
             if (lane == 0 && p.stats && isum) atomicAdd((uint32_t*)&misc[S_I], isum);
         }
         phase_sync<GLOBAL_TABLES>();
