@@ -96,6 +96,7 @@ struct LaunchParams {
     uint32_t* stats;      // [nq*8] or null
     uint32_t* nb_rank; uint32_t* nb_num; uint32_t* nb_cnt;   // debug neighbour dump or null
     unsigned long long* phase_cycles;                       // [16] per-phase shader cycles (debug) or null
+    const char* prep; uint32_t prep_stride;                 // per-query records of the prep kernel (or null: translate in the main kernel)
 };
 
 struct Workspace;   // per-call device scratch + events, owned by the index handle's pool

@@ -362,6 +362,46 @@ __device__ void block_sort_slots(SlotT* a, uint32_t n) {
 }
 
 // optional per-phase cycle accounting (debug; p.phase_cycles == nullptr in normal operation)
+// -------------------------------------------------------------------------------------
+// Prep kernel: one thread per evolving session does the dependent look-ups of phase 0 (public id -> dense idx ->
+// posting list bounds -> first / m-th rank) so that the main kernel, where a whole workgroup would wait on that
+// chain, reads one record.  Record = PrepHead + max_len * PrepItem, positions counted from the most recent item.
+// -------------------------------------------------------------------------------------
+struct PrepHead { uint32_t U, rmax, xlo, sumw, P, pad[3]; };          // S_U, S_RMAX, S_XLO, S_SUMW, S_P of the query
+struct PrepItem { uint32_t idx, len, pre, pad; unsigned long long base; };   // dense idx | kNone, truncated list length, prefix of len, list start
+__global__ __launch_bounds__(256) void vmis_prep_kernel(DeviceIndex ix, const uint64_t* __restrict__ items_flat, const uint32_t* __restrict__ q_off,
+                                                        uint32_t nq, uint32_t m, uint32_t max_len, char* out, uint32_t stride) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const uint32_t qb = q_off[q], L = q_off[q + 1] - qb;
+    PrepHead h{0u, 0u, 0u, 0u, 0u, {0u, 0u, 0u}};
+    PrepItem* items = (PrepItem*)(out + (size_t)q * stride + sizeof(PrepHead));
+    if (L != 0 && L <= max_len) {
+        for (uint32_t pos = 0; pos < L; ++pos) {
+            const uint64_t raw = items_flat[qb + (L - 1 - pos)];   // pos 0 = most recent item
+            bool first = true;
+            for (uint32_t j = 0; j < pos; ++j) first = first && (items_flat[qb + (L - 1 - j)] != raw);   // Q2: most recent occurrence only
+            uint32_t idx = kNone;
+            { uint32_t hh = (uint32_t)dev_mix64(raw) & ix.id_mask;
+              for (;;) { const IdSlot s = ix.id_table[hh]; if (s.idx == kNone) break; if (s.key == raw) { idx = s.idx; break; } hh = (hh + 1) & ix.id_mask; } }
+            uint32_t len = 0; unsigned long long base = 0;
+            if (first) ++h.U;   // Q1: distinct raw ids, known or not
+            if (first && idx != kNone) {
+                const unsigned long long o0 = ix.post_off[idx], o1 = ix.post_off[idx + 1];
+                len = (uint32_t)min((unsigned long long)m, o1 - o0); base = o0;
+                if (len) {
+                    h.rmax = max(h.rmax, ix.post_rank[o0]);
+                    if (len >= m) h.xlo = max(h.xlo, ix.post_rank[o0 + m - 1]);
+                    h.sumw += L - pos;
+                }
+            }
+            items[pos] = PrepItem{idx, len, h.P, 0u, base};
+            h.P += len;
+        }
+    }
+    *(PrepHead*)(out + (size_t)q * stride) = h;
+}
+
 #define SRN_TICK(ph)                                                                                         \
     do { if (p.phase_cycles && tid == 0) { const long long t_ = clock64(); atomicAdd(&p.phase_cycles[ph], (unsigned long long)(t_ - t_prev)); t_prev = t_; } } while (0)
 
@@ -423,8 +463,17 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
         long long t_prev = p.phase_cycles ? clock64() : 0;
         if (tid < MISC_WORDS) misc[tid] = 0;
         for (uint32_t i = tid; i < SEL_WORDS; i += BLOCK) hist[i] = 0;
-        for (uint32_t i = tid; i < L; i += BLOCK) q_raw[i] = p.items_flat[qb + (L - 1 - i)];   // pos 0 = most recent item
         if (MASKS && tid < 256) { uint32_t acc = 0; for (uint32_t b = 0; b < L; ++b) if ((tid >> b) & 1) acc += L - b; wlut[tid] = (uint8_t)acc; }
+        uint32_t x_lo, r_max, U, P, cur_idx;
+        if (STAGE == 0 && p.prep) {   // the look-ups were done by the prep kernel: one record per query, no barrier needed here
+            const char* rec = p.prep + (size_t)q * p.prep_stride;
+            const PrepHead hd = *(const PrepHead*)rec;   // (uniform address)
+            const PrepItem* pit = (const PrepItem*)(rec + sizeof(PrepHead));
+            x_lo = hd.xlo; r_max = hd.rmax; U = hd.U; P = hd.P; cur_idx = pit[0].idx;
+            for (uint32_t pos = tid; pos < L; pos += BLOCK) { const PrepItem x = pit[pos]; q_idx[pos] = x.idx; l_len[pos] = x.len; l_pre[pos] = x.pre; l_base[pos] = x.base; }
+            if (tid == 0) { l_pre[L] = hd.P; misc[S_U] = hd.U; misc[S_RMAX] = hd.rmax; misc[S_XLO] = hd.xlo; misc[S_SUMW] = hd.sumw; misc[S_P] = hd.P; }   // (same wave zeroed them)
+        } else {
+        for (uint32_t i = tid; i < L; i += BLOCK) q_raw[i] = p.items_flat[qb + (L - 1 - i)];   // pos 0 = most recent item
         __syncthreads();
         for (uint32_t pos = tid; pos < L; pos += BLOCK) {
             const uint64_t raw = q_raw[pos];
@@ -454,8 +503,8 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                 uint32_t tot = 0; for (uint32_t g = 0; g < sh.n_shards; ++g) tot += sh.gathered_cnt[(size_t)g * p.nq + q];
                 misc[S_P] = tot; misc[S_XLO] = 0xFFFFFFFFu; misc[S_RMAX] = 0; } }
         phase_sync<GLOBAL_TABLES>();
-        const uint32_t x_lo = misc[S_XLO], r_max = misc[S_RMAX], U = misc[S_U], P = misc[S_P];
-        const uint32_t cur_idx = q_idx[0];
+        x_lo = misc[S_XLO]; r_max = misc[S_RMAX]; U = misc[S_U]; P = misc[S_P]; cur_idx = q_idx[0];
+        }
         // session table sized to this query: at most P entries are inserted, keep the load <= 2/3
         uint32_t sslots = 256; while (sslots < c.sess_slots && sslots * 2 < P * 3) sslots <<= 1;
         const uint32_t smask = sslots / 4 - 1;   // bucket mask (4 slots per bucket)
@@ -1108,7 +1157,8 @@ struct Workspace {
     // device scratch
     uint32_t* retry_list = nullptr; size_t retry_cap = 0; uint32_t* retry_cnt = nullptr;
     char* gscratch = nullptr; size_t gscratch_bytes = 0;
-    char* spill = nullptr; size_t spill_bytes = 0;   // per-block neighbour-list copies for multi-partition item passes
+    char* spill = nullptr; size_t spill_bytes = 0;   // per-block global copies of the neighbour lists
+    char* prep = nullptr; size_t prep_bytes = 0;     // per-query records of the prep kernel
     // staging for host-pointer calls
     char* stage = nullptr; size_t stage_bytes = 0;
     uint32_t* h_retry = nullptr;   // pinned
@@ -1187,6 +1237,7 @@ static void ws_free(Workspace* w) {
     if (w->retry_cnt) hipFree(w->retry_cnt);
     if (w->gscratch) hipFree(w->gscratch);
     if (w->spill) hipFree(w->spill);
+    if (w->prep) hipFree(w->prep);
     if (w->stage) hipFree(w->stage);
     if (w->h_retry) hipHostFree(w->h_retry);
     for (auto& t : w->ev) for (auto& e : t) if (e) hipEventDestroy(e);
@@ -1387,8 +1438,13 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     // per-block global copy of the neighbour list (walk B reads it after phase 4a has reused the LDS)
     { int rc = ensure(&w->spill, &w->spill_bytes, (size_t)std::max<uint32_t>(grid, (uint32_t)retry_blocks) * p.k * slot_bytes); if (rc) return rc; }
     char* spill = w->spill;
+    const uint32_t prep_stride = (uint32_t)(sizeof(PrepHead) + (size_t)p.max_len * sizeof(PrepItem));
+    { int rc = ensure(&w->prep, &w->prep_bytes, (size_t)p.nq * prep_stride); if (rc) return rc; }
     hipEvent_t* ev = w->ev[w->calls % Workspace::RING];
     HIP_TRY(hipEventRecord(ev[0], st));
+    hipLaunchKernelGGL(vmis_prep_kernel, dim3((p.nq + 255) / 256), dim3(256), 0, st, d->di, p.items_flat, p.q_off, p.nq, p.m, p.max_len, w->prep, prep_stride);
+    HIP_TRY(hipGetLastError());
+    p.prep = w->prep; p.prep_stride = prep_stride;
     if (geo.masks) HIP_TRY((launch_variant<kBlock, false, 0, true>(slot64, dim3(grid), lds, st, d->di, p, c, nullptr, nullptr,
                                                                    w->retry_list, w->retry_cnt, nullptr, 0, spill)));
     else HIP_TRY((launch_variant<kBlock, false, 0, false>(slot64, dim3(grid), lds, st, d->di, p, c, nullptr, nullptr,
