@@ -1151,8 +1151,8 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
 // =====================================================================================
 struct Workspace {
     hipStream_t stream = nullptr;   // own stream for host-pointer calls
-    static constexpr int RING = 64;               // per-call event triples (start, after main kernel, after retry pass)
-    hipEvent_t ev[RING][3] = {};
+    static constexpr int RING = 64;               // per-call events: start, after main kernel, after retry pass, after prep kernel
+    hipEvent_t ev[RING][4] = {};
     uint64_t calls = 0; uint32_t last_retry = 0;
     // device scratch
     uint32_t* retry_list = nullptr; size_t retry_cap = 0; uint32_t* retry_cnt = nullptr;
@@ -1445,6 +1445,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     hipLaunchKernelGGL(vmis_prep_kernel, dim3((p.nq + 255) / 256), dim3(256), 0, st, d->di, p.items_flat, p.q_off, p.nq, p.m, p.max_len, w->prep, prep_stride);
     HIP_TRY(hipGetLastError());
     p.prep = w->prep; p.prep_stride = prep_stride;
+    HIP_TRY(hipEventRecord(ev[3], st));
     if (geo.masks) HIP_TRY((launch_variant<kBlock, false, 0, true>(slot64, dim3(grid), lds, st, d->di, p, c, nullptr, nullptr,
                                                                    w->retry_list, w->retry_cnt, nullptr, 0, spill)));
     else HIP_TRY((launch_variant<kBlock, false, 0, false>(slot64, dim3(grid), lds, st, d->di, p, c, nullptr, nullptr,
@@ -1511,7 +1512,7 @@ int device_last_kernel_ms(DeviceState* d, double* ms_main, double* ms_retry, uin
     hipEvent_t* ev = w->ev[(w->calls - 1) % Workspace::RING];
     HIP_TRY(hipEventSynchronize(ev[2]));
     float a = 0, b = 0;
-    HIP_TRY(hipEventElapsedTime(&a, ev[0], ev[1]));
+    HIP_TRY(hipEventElapsedTime(&a, ev[3], ev[1]));   // the predict kernel alone (the prep kernel runs between ev[0] and ev[3])
     HIP_TRY(hipEventElapsedTime(&b, ev[1], ev[2]));
     if (ms_main) *ms_main = a;
     if (ms_retry) *ms_retry = b;
@@ -1541,7 +1542,7 @@ int device_kernel_times(DeviceState* d, uint32_t max_n, double* ms_main, double*
     for (uint64_t i = 0; i < n; ++i) {
         hipEvent_t* ev = w->ev[(w->calls - n + i) % Workspace::RING];
         float a = 0, b = 0;
-        HIP_TRY(hipEventElapsedTime(&a, ev[0], ev[1]));
+        HIP_TRY(hipEventElapsedTime(&a, ev[3], ev[1]));
         HIP_TRY(hipEventElapsedTime(&b, ev[1], ev[2]));
         if (ms_main) ms_main[i] = a;
         if (ms_retry) ms_retry[i] = b;
