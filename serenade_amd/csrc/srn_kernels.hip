@@ -363,6 +363,42 @@ __device__ void block_sort_slots(SlotT* a, uint32_t n) {
 
 // optional per-phase cycle accounting (debug; p.phase_cycles == nullptr in normal operation)
 // -------------------------------------------------------------------------------------
+// Row layout kernel (attach time): CSR rows -> 64-byte slots + overflow area (see DeviceIndex).  One thread per row, 1024
+// consecutive rows per block; the overflow offsets are a block-local exclusive scan on top of the block's base (computed
+// on the host from the row lengths), so the layout is the sequential one.  Slot n is the empty row.
+// -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void rows_to_slots_kernel(const uint64_t* __restrict__ row_off, const uint32_t* __restrict__ row_items, uint64_t n,
+                                                             const uint32_t* __restrict__ block_base, uint32_t* __restrict__ slots, uint32_t* __restrict__ ext) {
+    __shared__ uint32_t wave_tot[16];
+    const uint64_t r = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t o = 0, len = 0;
+    if (r < n) { o = row_off[r]; len = row_off[r + 1] - o; }
+    const uint32_t e = len > 15 ? (uint32_t)(len - 14) : 0u;
+    uint32_t inc = e;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t base = block_base[blockIdx.x];
+    for (int w = 0; w < wave; ++w) base += wave_tot[w];
+    const uint32_t eoff = base + inc - e;
+    if (r > n) return;
+    uint32_t sl[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sl[i] = EMPTY32;
+    sl[0] = (uint32_t)len;   // (0 for the empty row r == n)
+    if (len <= 15) { for (uint32_t i = 0; i < (uint32_t)len; ++i) sl[1 + i] = row_items[o + i]; }
+    else { sl[1] = eoff;
+#pragma unroll
+           for (int i = 0; i < 14; ++i) sl[2 + i] = row_items[o + i];
+           for (uint64_t i = 14; i < len; ++i) ext[eoff + (i - 14)] = row_items[o + i]; }
+    uint4* dst = reinterpret_cast<uint4*>(slots + r * 16);
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) dst[qd] = make_uint4(sl[4 * qd], sl[4 * qd + 1], sl[4 * qd + 2], sl[4 * qd + 3]);
+}
+
+// -------------------------------------------------------------------------------------
 // Prep kernel: one thread per evolving session does the dependent look-ups of phase 0 (public id -> dense idx ->
 // posting list bounds -> first / m-th rank) so that the main kernel, where a whole workgroup would wait on that
 // chain, reads one record.  Record = PrepHead + max_len * PrepItem, positions counted from the most recent item.
@@ -1201,26 +1237,32 @@ DeviceState* device_attach(const FlatIndex& ix, int device) {
       for (size_t i = 0; i < ix.n_items; ++i) { meta[i] = ItemMeta{ix.idf[i], ix.id_rank[i], ix.attr[i]}; id_sorted[ix.id_rank[i]] = ix.item_id[i]; }
       d->d_meta = (ItemMeta*)upload(d, meta, ok); d->di.meta = d->d_meta; d->di.id_sorted = upload(d, id_sorted, ok); }
     d->di.post_off = upload(d, ix.post_off, ok); d->di.post_rank = upload(d, ix.post_rank, ok);
-    {   // rows -> 64-byte slots (+ overflow area), see DeviceIndex
-        const size_t n = ix.n_kept;
-        std::vector<uint32_t> slots((n + 1) * 16, EMPTY32), ext(16, EMPTY32);   // slot n: the empty row idle lanes read; ext[0..15]: what short rows read
-        uint64_t ext_total = 16;
-        for (size_t r = 0; r < n; ++r) { const uint64_t len = ix.row_off[r + 1] - ix.row_off[r]; if (len > 15) ext_total += len - 14; }
-        if (ext_total >= 0xFFFFFFF0ull) { set_error("row overflow area exceeds 2^32 items"); device_release(d); return nullptr; }
-        ext.reserve(ext_total + 16);
-        slots[n * 16] = 0;
-        for (size_t r = 0; r < n; ++r) {
-            const uint64_t o = ix.row_off[r], len = ix.row_off[r + 1] - o;
-            uint32_t* sl = &slots[r * 16];
-            sl[0] = (uint32_t)len;
-            if (len <= 15) for (uint64_t i = 0; i < len; ++i) sl[1 + i] = ix.row_items[o + i];
-            else { sl[1] = (uint32_t)ext.size();
-                   for (uint64_t i = 0; i < 14; ++i) sl[2 + i] = ix.row_items[o + i];
-                   ext.insert(ext.end(), ix.row_items.begin() + o + 14, ix.row_items.begin() + o + len); }
+    if (ok) {   // rows -> 64-byte slots (+ overflow area) on the device, see DeviceIndex and rows_to_slots_kernel
+        const size_t n = ix.n_kept, nblocks = (n + 1 + 1023) / 1024;
+        std::vector<uint32_t> block_base(nblocks);
+        uint64_t ext_total = 16;   // ext[0..15] = EMPTY32: what short rows read
+        for (size_t b0 = 0; b0 < nblocks; ++b0) {
+            block_base[b0] = (uint32_t)ext_total;
+            const size_t hi = std::min(n, (b0 + 1) * 1024);
+            for (size_t r = b0 * 1024; r < hi; ++r) { const uint64_t len = ix.row_off[r + 1] - ix.row_off[r]; if (len > 15) ext_total += len - 14; }
+            if (ext_total >= 0xFFFFFFF0ull) { set_error("row overflow area exceeds 2^32 items"); device_release(d); return nullptr; }
         }
-        ext.resize(ext.size() + 16, EMPTY32);   // 4-item loads may run past the last row
-        d->di.row_slots = (const RowQuad*)upload(d, slots, ok);
-        d->di.row_ext = upload(d, ext, ok);
+        void *d_off = nullptr, *d_items = nullptr, *d_base = nullptr, *d_slots = nullptr, *d_ext = nullptr;
+        const size_t ext_words = ext_total + 16;   // (4-item loads may run past the last row)
+        bool good = hipMalloc(&d_off, (n + 1) * 8) == hipSuccess && hipMalloc(&d_items, std::max<size_t>(ix.row_items.size() * 4, 16)) == hipSuccess &&
+                    hipMalloc(&d_base, nblocks * 4) == hipSuccess && hipMalloc(&d_slots, (n + 1) * 64) == hipSuccess && hipMalloc(&d_ext, ext_words * 4) == hipSuccess;
+        good = good && hipMemcpy(d_off, ix.row_off.data(), (n + 1) * 8, hipMemcpyHostToDevice) == hipSuccess &&
+               (ix.row_items.empty() || hipMemcpy(d_items, ix.row_items.data(), ix.row_items.size() * 4, hipMemcpyHostToDevice) == hipSuccess) &&
+               hipMemcpy(d_base, block_base.data(), nblocks * 4, hipMemcpyHostToDevice) == hipSuccess &&
+               hipMemset(d_ext, 0xFF, ext_words * 4) == hipSuccess;
+        if (good) { hipLaunchKernelGGL(rows_to_slots_kernel, dim3((unsigned)nblocks), dim3(1024), 0, 0, (const uint64_t*)d_off, (const uint32_t*)d_items, (uint64_t)n,
+                                       (const uint32_t*)d_base, (uint32_t*)d_slots, (uint32_t*)d_ext);
+                    good = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess; }
+        if (d_off) hipFree(d_off); if (d_items) hipFree(d_items); if (d_base) hipFree(d_base);
+        if (d_slots) { d->allocs.push_back(d_slots); d->bytes += (n + 1) * 64; }
+        if (d_ext) { d->allocs.push_back(d_ext); d->bytes += ext_words * 4; }
+        if (!good) { ok = false; set_error("row slot layout on the device failed"); }
+        d->di.row_slots = (const RowQuad*)d_slots; d->di.row_ext = (const uint32_t*)d_ext;
     }
     d->di.n_items = (uint32_t)ix.n_items; d->di.n_kept = (uint32_t)ix.n_kept;
     double hi = 1.0, lo = 1.0; bool any = false;   // bounds of idf_eff = (idf > 0 ? idf : 1) for the top-n pre-filter
