@@ -1025,7 +1025,26 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
             // smallest accumulator that could still reach the threshold: score <= idf_hi * acc / denom, so an item needs
             // acc >= thr * denom / idf_hi; shaved by a relative 1e-9 and one unit so that rounding can only keep more
             return (int)fmin(2147483000.0, fmax(1.0, floor(key_score(tk) * denom / ix.idf_hi * (1.0 - 1e-9)) - 1.0)); };
-        auto harvest = [&](uint32_t e_lo, uint32_t e_hi) {
+        // leaves the best min(cnt, n) candidates sorted at the front of the buffer, sets the threshold if n exist
+        auto sort_candidates = [&](uint32_t cnt) {
+            if (n_out <= 64 && cnt <= 64) {   // one wave sorts in registers, no merge levels
+                if (wave == 0) { uint64_t kk = lane < (int)cnt ? ckey[lane] : 0; uint32_t ii = lane < (int)cnt ? cidx[lane] : EMPTY32;
+                                 wave_sort_desc(kk, ii, lane); ckey[lane] = kk; cidx[lane] = ii; }
+                __syncthreads();
+            } else if (n_out <= 64) block_top64<BLOCK>(ckey, cidx, cnt);   // leaves the best min(cnt, 64) sorted at the front
+            else {
+                uint32_t n2 = 2; while (n2 < cnt) n2 <<= 1;
+                for (uint32_t t = cnt + tid; t < n2; t += BLOCK) { ckey[t] = 0; cidx[t] = EMPTY32; }
+                __syncthreads();
+                block_sort_candidates<BLOCK>(ckey, cidx, n2);
+            }
+            if (tid == 0) {
+                misc[S_SORTED] = min(cnt, n_out);
+                if (cnt >= n_out) { misc[S_CCNT] = n_out; misc[S_HAVE_T] = 1; misc[S_TIDX] = cidx[n_out - 1];
+                                    misc[S_TKEY_LO] = (uint32_t)ckey[n_out - 1]; misc[S_TKEY_HI] = (uint32_t)(ckey[n_out - 1] >> 32); }
+            }
+            __syncthreads(); };
+        auto harvest = [&](uint32_t e_lo, uint32_t e_hi, bool sort_at_end) {
             const uint32_t n_chunks = (e_hi - e_lo + BLOCK - 1) / BLOCK;
             uint32_t u = 0, ru = (misc[S_HAVE_T] && misc[S_CCNT] * 2 <= CAND_CAP) ? n_chunks : 1u;
             while (u < n_chunks) {
@@ -1084,28 +1103,50 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                 // before a single-chunk round the buffer must have room for BLOCK appends (exact path);
                 // also sort once as soon as n candidates exist, to get a threshold
                 const bool must_prune = cnt + BLOCK > CAND_CAP || (!have_t && cnt >= n_out && cnt > 1);
-                if ((must_prune && !last) || (last && cnt > 1 && cnt != misc[S_SORTED])) {
-                    if (n_out <= 64) block_top64<BLOCK>(ckey, cidx, cnt);   // leaves the best min(cnt, 64) sorted at the front
-                    else {
-                        uint32_t n2 = 2; while (n2 < cnt) n2 <<= 1;
-                        for (uint32_t t = cnt + tid; t < n2; t += BLOCK) { ckey[t] = 0; cidx[t] = EMPTY32; }
-                        __syncthreads();
-                        block_sort_candidates<BLOCK>(ckey, cidx, n2);
-                    }
-                    if (tid == 0) {
-                        misc[S_SORTED] = min(cnt, n_out);
-                        if (cnt >= n_out) { misc[S_CCNT] = n_out; misc[S_HAVE_T] = 1; misc[S_TIDX] = cidx[n_out - 1];
-                                            misc[S_TKEY_LO] = (uint32_t)ckey[n_out - 1]; misc[S_TKEY_HI] = (uint32_t)(ckey[n_out - 1] >> 32); }
-                    }
-                    __syncthreads();
-                }
+                if ((must_prune && !last) || (last && sort_at_end && cnt > 1 && cnt != misc[S_SORTED])) sort_candidates(cnt);
                 // once a threshold exists and the buffer is at most half full: ONE optimistic round over all the
                 // remaining chunks (a round that overflows the buffer is redone chunk by chunk, see above)
                 ru = (misc[S_HAVE_T] && misc[S_CCNT] * 2 <= CAND_CAP) ? n_chunks : 1u;
             }
             __syncthreads(); };
 
-        if (H) harvest(0, H);   // phase 4a: the direct-mapped items, exactly -> threshold
+        // phase 4a: the direct-mapped items, exactly -> threshold.
+        if (H >= (uint32_t)BLOCK && n_out <= 3 * NWAVES) {
+            // First chunk (the 512 most popular items) without a block-wide sort: every wave sorts its 64 scores in registers;
+            // the worst of the waves' 3rd-best scores has >= 3 * NWAVES >= n candidates at or above it, so it is a valid
+            // (and tight) threshold.  Only candidates at or above it are kept at all.
+            uint64_t sk = 0; uint32_t tie = EMPTY32; bool valid = false;
+            { const uint32_t e = (uint32_t)lane * NWAVES + (uint32_t)wave;   // entries dealt round-robin: every wave sees the same mix of popularity
+              const uint32_t v = hot[e];
+              if (v && e != cur_idx) {
+                  const int acc = (int)(v - (((v + (1u << (SB - 1))) >> SB) << SB));
+                  const ItemMeta mt = ix.meta[e];
+                  if (!business || business_ok(cur_attr, mt.attr)) { sk = score_key((mt.idf > 0.0 ? mt.idf : 1.0) * (double)acc / denom); tie = mt.id_rank; valid = true; }
+              } }
+            // the wave's 3rd largest key, on the top 32 bits of the score key (a monotone truncation: still a valid bound)
+            const uint32_t k32 = valid ? (uint32_t)(sk >> 32) : 0u;
+            { uint32_t v = k32, third = 0;
+#pragma unroll
+              for (int t = 0; t < 3; ++t) {
+                  uint32_t mx = v;
+#pragma unroll
+                  for (int dd = 32; dd > 0; dd >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, dd, 64));
+                  third = mx;
+                  const unsigned long long bal = __ballot(v == mx);
+                  if (lane == __ffsll((long long)bal) - 1) v = 0;   // take one holder of the maximum out
+              }
+              if (lane == 0) cidx[CAND_CAP - NWAVES + wave] = third; }   // (0 if the wave has < 3 candidates)
+            __syncthreads();
+            uint32_t t32 = 0xFFFFFFFFu;
+#pragma unroll
+            for (int w = 0; w < NWAVES; ++w) t32 = min(t32, cidx[CAND_CAP - NWAVES + w]);
+            const bool take = valid && k32 >= t32;   // at or above the threshold (everything, if there is none)
+            const uint32_t at = wave_append(take, (uint32_t*)&misc[S_CCNT]);
+            if (take) { ckey[at] = sk; cidx[at] = tie; }
+            if (tid == 0 && t32) { misc[S_HAVE_T] = 1; misc[S_TIDX] = EMPTY32; misc[S_TKEY_LO] = 0u; misc[S_TKEY_HI] = t32; }
+            __syncthreads();
+            if (H > (uint32_t)BLOCK) harvest(BLOCK, H, false);   // (no sort yet: the sample's threshold serves walk B, one sort at the very end)
+        } else if (H) harvest(0, H, true);
         SRN_TICK(10);
 
         // ---- walk B + phase 4b, per item partition ------------------------------------------
@@ -1158,9 +1199,13 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                 continue;
             }
             d_total += misc[S_ICNT];
-            harvest(H, H + c.item_slots);
+            harvest(H, H + c.item_slots, true);
             SRN_TICK(13);
             if (++part >= parts) break;
+        }
+        if (!failed) {   // (walk B skipped, or nothing came of it: the candidates may still be unsorted)
+            const uint32_t cnt = misc[S_CCNT];
+            if (cnt > 1 && cnt != misc[S_SORTED]) sort_candidates(cnt);
         }
         if (failed) {
             if (GLOBAL_TABLES || STAGE == 3) { if (tid == 0) { p.out_counts[q] = 0xFFFFFFFFu; if (p.stats) p.stats[(size_t)q * 8 + 7] = 3; } }
