@@ -908,6 +908,82 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
         auto nb_lds = [&](uint32_t j) -> SlotT { return STAGE == 3 ? ((const SlotT*)sh.nb)[(size_t)q * p.k + j] : nbl[j]; };
         auto nb_glb = [&](uint32_t j) -> SlotT { return STAGE == 3 ? ((const SlotT*)sh.nb)[(size_t)q * p.k + j] : nb_spill[j]; };
 
+        // Rows differ in length and a wave pays for its longest lane, so (MASKS, fused kernel) the rows are walked in three
+        // rounds of like work: (i) every neighbour's first 7 items; neighbours with more are queued, (ii) items 7..14 of the
+        // queued rows; rows that continue in the overflow area are queued again, (iii) those.  `queue` has one slot per
+        // neighbour (rounded up to whole groups of 64); a wave only writes queue slots of its own groups that it has already
+        // consumed, so the queue may be the neighbour list itself.  (The row weight is a function of the slot's position
+        // set, so a queued slot carries everything.)  elem(it[N], w) sees N row elements of one lane's row.
+        auto walk_rounds = [&](auto nb_at, SlotT* queue, auto&& elem) -> uint32_t {
+            uint32_t isum = 0;
+                // Rows differ in length and a wave pays for its longest lane, so the rows are walked in three rounds of
+            // like work: (i) every neighbour's first 7 items; neighbours with more are queued, (ii) items 7..14 of the
+            // queued rows; rows that continue in the overflow area are queued again, (iii) those.  A wave queues into
+            // the neighbour-list slots of its own groups that it has already consumed: no extra LDS.  (The row weight
+            // is a function of the slot's position set, so a queued slot carries everything.)
+            constexpr uint32_t GSTEP = NWAVES * 64;
+            auto qpos = [&](uint32_t pq) -> uint32_t { return ((wave + NWAVES * (pq >> 6)) << 6) + (pq & 63u); };
+            auto weight_of = [&](uint32_t num) -> int {
+                const int mp = num ? __ffs((int)num) - 1 : MINPOS_NONE;
+                return (mp < 99 ? 10 - (mp + 1) : 0) * (int)wlut[num]; };
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            uint32_t qn = 0;
+            if ((uint32_t)wave * 64 < K) {
+                SlotT sv = nb_at(min((uint32_t)(wave * 64 + lane), K - 1)), nsv = 0;
+                size_t r = (uint32_t)(wave * 64 + lane) < K ? (size_t)(uint32_t)(sv >> NB) : (size_t)ix.n_kept;
+                RowQuad a = ix.row_slots[4 * r], b = ix.row_slots[4 * r + 1], na, nb;
+                for (uint32_t g0 = wave * 64; g0 < K; g0 += GSTEP) {   // (i)
+                    const uint32_t jn = g0 + GSTEP + lane;
+                    nsv = nb_at(min(jn, K - 1));
+                    const size_t nr = jn < K ? (size_t)(uint32_t)(nsv >> NB) : (size_t)ix.n_kept;
+                    na = ix.row_slots[4 * nr]; nb = ix.row_slots[4 * nr + 1];
+                    const uint32_t len = a.x;   // (0 for the idle lanes' empty slot)
+                    const int w = weight_of((uint32_t)(sv & num_mask));
+                    isum += len;
+                    const uint32_t it7[7] = {len > 15 ? EMPTY32 : a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                    elem(it7, w);
+                    const bool more = len > 7;
+                    const unsigned long long bm = __ballot(more);
+                    if (more) queue[qpos(qn + (uint32_t)__popcll(bm & lt))] = sv;   // (all lanes hold their slot in a register by now)
+                    qn += (uint32_t)__popcll(bm);
+                    sv = nsv; a = na; b = nb;
+                }
+            }
+            uint32_t qn2 = 0;
+            for (uint32_t p0 = 0; p0 < qn; p0 += 64) {   // (ii)
+                const bool act = p0 + lane < qn;
+                const SlotT sv = queue[qpos(min(p0 + lane, qn - 1))];
+                const size_t r = act ? (size_t)(uint32_t)(sv >> NB) : (size_t)ix.n_kept;
+                const RowQuad c4 = ix.row_slots[4 * r + 2], d4 = ix.row_slots[4 * r + 3];
+                const uint32_t len = ix.row_slots[4 * r].x;
+                const int w = weight_of((uint32_t)(sv & num_mask));
+                const uint32_t it8[8] = {c4.x, c4.y, c4.z, c4.w, d4.x, d4.y, d4.z, d4.w};
+                elem(it8, w);
+                const bool more = len > 15;
+                const unsigned long long bm = __ballot(more);
+                if (more) queue[qpos(qn2 + (uint32_t)__popcll(bm & lt))] = sv;
+                qn2 += (uint32_t)__popcll(bm);
+            }
+            for (uint32_t p0 = 0; p0 < qn2; p0 += 64) {   // (iii)
+                const bool act = p0 + lane < qn2;
+                const SlotT sv = queue[qpos(min(p0 + lane, qn2 - 1))];
+                const size_t r = act ? (size_t)(uint32_t)(sv >> NB) : (size_t)ix.n_kept;
+                const RowQuad a = ix.row_slots[4 * r];
+                const uint32_t len = a.x; const bool big = len > 15;
+                const uint32_t* ext = ix.row_ext + (big ? a.y : 0u);
+                const int w = weight_of((uint32_t)(sv & num_mask));
+                for (uint32_t t = 14; __ballot(big && t < len) != 0ull; t += 8) {
+                    uint32_t it8[8];
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) it8[x] = EMPTY32;
+                    if (big && t < len) { const RowVec v = *reinterpret_cast<const RowVec*>(ext + (t - 14)); it8[0] = v.x; it8[1] = v.y; it8[2] = v.z; it8[3] = v.w; }
+                    if (big && t + 4 < len) { const RowVec v = *reinterpret_cast<const RowVec*>(ext + (t - 14) + 4); it8[4] = v.x; it8[5] = v.y; it8[6] = v.z; it8[7] = v.w; }
+#pragma unroll
+                    for (uint32_t x = 1; x < 8; ++x) if (t + x >= len) it8[x] = EMPTY32;
+                    elem(it8, w);
+                }
+            }
+            return isum; };
         if constexpr (STAGE == 2) {   // stage B: first-match positions only
             walk_rows(nb_lds, [&](uint32_t j, uint32_t num, auto&& for_row) { row_weight(j, num, for_row); });
             continue;
@@ -928,74 +1004,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                 } };
             uint32_t isum = 0;
             if constexpr (MASKS && STAGE == 0) {
-                // Rows differ in length and a wave pays for its longest lane, so the rows are walked in three rounds of
-                // like work: (i) every neighbour's first 7 items; neighbours with more are queued, (ii) items 7..14 of the
-                // queued rows; rows that continue in the overflow area are queued again, (iii) those.  A wave queues into
-                // the neighbour-list slots of its own groups that it has already consumed: no extra LDS.  (The row weight
-                // is a function of the slot's position set, so a queued slot carries everything.)
-                constexpr uint32_t GSTEP = NWAVES * 64;
-                auto qpos = [&](uint32_t pq) -> uint32_t { return ((wave + NWAVES * (pq >> 6)) << 6) + (pq & 63u); };
-                auto weight_of = [&](uint32_t num, uint32_t& whot, uint32_t& wpos) {
-                    const int mp = num ? __ffs((int)num) - 1 : MINPOS_NONE;
-                    const int w = (mp < 99 ? 10 - (mp + 1) : 0) * (int)wlut[num];
-                    whot = (1u << SB) + (uint32_t)w; wpos = SK ? (uint32_t)max(w, 0) : 0u; };
-                const unsigned long long lt = (1ull << lane) - 1ull;
-                uint32_t qn = 0;
-                if ((uint32_t)wave * 64 < K) {
-                    SlotT sv = nbl[min((uint32_t)(wave * 64 + lane), K - 1)], nsv = 0;
-                    size_t r = (uint32_t)(wave * 64 + lane) < K ? (size_t)(uint32_t)(sv >> NB) : (size_t)ix.n_kept;
-                    RowQuad a = ix.row_slots[4 * r], b = ix.row_slots[4 * r + 1], na, nb;
-                    for (uint32_t g0 = wave * 64; g0 < K; g0 += GSTEP) {   // (i)
-                        const uint32_t jn = g0 + GSTEP + lane;
-                        nsv = nbl[min(jn, K - 1)];
-                        const size_t nr = jn < K ? (size_t)(uint32_t)(nsv >> NB) : (size_t)ix.n_kept;
-                        na = ix.row_slots[4 * nr]; nb = ix.row_slots[4 * nr + 1];
-                        const uint32_t len = a.x;   // (0 for the idle lanes' empty slot)
-                        uint32_t whot, wpos; weight_of((uint32_t)(sv & num_mask), whot, wpos);
-                        isum += len;
-                        const uint32_t it7[7] = {len > 15 ? EMPTY32 : a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-                        add_items(it7, whot, wpos);
-                        const bool more = len > 7;
-                        const unsigned long long bm = __ballot(more);
-                        if (more) nbl[qpos(qn + (uint32_t)__popcll(bm & lt))] = sv;   // (all lanes hold their slot in a register by now)
-                        qn += (uint32_t)__popcll(bm);
-                        sv = nsv; a = na; b = nb;
-                    }
-                }
-                uint32_t qn2 = 0;
-                for (uint32_t p0 = 0; p0 < qn; p0 += 64) {   // (ii)
-                    const bool act = p0 + lane < qn;
-                    const SlotT sv = nbl[qpos(min(p0 + lane, qn - 1))];
-                    const size_t r = act ? (size_t)(uint32_t)(sv >> NB) : (size_t)ix.n_kept;
-                    const RowQuad c4 = ix.row_slots[4 * r + 2], d4 = ix.row_slots[4 * r + 3];
-                    const uint32_t len = ix.row_slots[4 * r].x;
-                    uint32_t whot, wpos; weight_of((uint32_t)(sv & num_mask), whot, wpos);
-                    const uint32_t it8[8] = {c4.x, c4.y, c4.z, c4.w, d4.x, d4.y, d4.z, d4.w};
-                    add_items(it8, whot, wpos);
-                    const bool more = len > 15;
-                    const unsigned long long bm = __ballot(more);
-                    if (more) nbl[qpos(qn2 + (uint32_t)__popcll(bm & lt))] = sv;
-                    qn2 += (uint32_t)__popcll(bm);
-                }
-                for (uint32_t p0 = 0; p0 < qn2; p0 += 64) {   // (iii)
-                    const bool act = p0 + lane < qn2;
-                    const SlotT sv = nbl[qpos(min(p0 + lane, qn2 - 1))];
-                    const size_t r = act ? (size_t)(uint32_t)(sv >> NB) : (size_t)ix.n_kept;
-                    const RowQuad a = ix.row_slots[4 * r];
-                    const uint32_t len = a.x; const bool big = len > 15;
-                    const uint32_t* ext = ix.row_ext + (big ? a.y : 0u);
-                    uint32_t whot, wpos; weight_of((uint32_t)(sv & num_mask), whot, wpos);
-                    for (uint32_t t = 14; __ballot(big && t < len) != 0ull; t += 8) {
-                        uint32_t it8[8];
-#pragma unroll
-                        for (int x = 0; x < 8; ++x) it8[x] = EMPTY32;
-                        if (big && t < len) { const RowVec v = *reinterpret_cast<const RowVec*>(ext + (t - 14)); it8[0] = v.x; it8[1] = v.y; it8[2] = v.z; it8[3] = v.w; }
-                        if (big && t + 4 < len) { const RowVec v = *reinterpret_cast<const RowVec*>(ext + (t - 14) + 4); it8[4] = v.x; it8[5] = v.y; it8[6] = v.z; it8[7] = v.w; }
-#pragma unroll
-                        for (uint32_t x = 1; x < 8; ++x) if (t + x >= len) it8[x] = EMPTY32;
-                        add_items(it8, whot, wpos);
-                    }
-                }
+                isum = walk_rounds(nb_lds, nbl, [&](const auto& it, int w) { add_items(it, (1u << SB) + (uint32_t)w, SK ? (uint32_t)max(w, 0) : 0u); });
             } else {
                 isum = walk_rows(nb_lds, [&](uint32_t j, uint32_t num, auto&& for_row) {
                     const int w = row_weight(j, num, for_row);
@@ -1172,20 +1181,24 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
             SRN_TICK(11);
             {
                 uint32_t fresh = 0; bool ovf = false;
-                walk_rows(nb_glb, [&](uint32_t j, uint32_t num, auto&& for_row) {
+                auto insert_items = [&](const auto& it, int w) {
+                    constexpr int N = sizeof(it) / sizeof(it[0]);
+                    bool go[N];
+#pragma unroll
+                    for (int x = 0; x < N; ++x) {
+                        go[x] = it[x] != EMPTY32 && it[x] >= H && (parts == 1 || hash_part(it[x], parts) == part);
+                        if (filt) { const uint32_t ub = go[x] ? sketch[sketch_hash(it[x], SKSH)] : 0u; go[x] = go[x] & (ub >= floor_b); }
+                    }
+#pragma unroll
+                    for (int x = 0; x < N; ++x) {
+                        if (go[x]) { const int res = item_insert(ikeys, iacc, inb, it[x], w); if (res < 0) ovf = true; else fresh += (uint32_t)res; }
+                    } };
+                bool rounds = false;
+                if constexpr (MASKS && STAGE == 0 && !GLOBAL_TABLES) rounds = (size_t)(K + 64) * sizeof(SlotT) <= (size_t)H * 4;   // the direct-mapped words are dead: queue there
+                if (rounds) { if constexpr (MASKS && STAGE == 0 && !GLOBAL_TABLES) walk_rounds(nb_glb, (SlotT*)hot, insert_items); }
+                else walk_rows(nb_glb, [&](uint32_t j, uint32_t num, auto&& for_row) {
                     const int w = row_weight(j, num, for_row);
-                    for_row([&](const auto& it) {
-                        constexpr int N = sizeof(it) / sizeof(it[0]);
-                        bool go[N];
-#pragma unroll
-                        for (int x = 0; x < N; ++x) {
-                            go[x] = it[x] != EMPTY32 && it[x] >= H && (parts == 1 || hash_part(it[x], parts) == part);
-                            if (filt) { const uint32_t ub = go[x] ? sketch[sketch_hash(it[x], SKSH)] : 0u; go[x] = go[x] & (ub >= floor_b); }
-                        }
-#pragma unroll
-                        for (int x = 0; x < N; ++x) {
-                            if (go[x]) { const int res = item_insert(ikeys, iacc, inb, it[x], w); if (res < 0) ovf = true; else fresh += (uint32_t)res; }
-                        } }); });
+                    for_row([&](const auto& it) { insert_items(it, w); }); });
                 fresh = wave_sum(fresh);
                 if (lane == 0 && fresh) atomicAdd((uint32_t*)&misc[S_ICNT], fresh);
                 if (ovf) misc[S_OVF] = 1;

@@ -93,6 +93,21 @@ def test_small_random_vs_oracle(tied, kernel_path):
             _check_batch(gix, oix, qs, k, m, n)
 
 
+def test_long_rows_and_large_cuts(kernel_path):
+    """Rows of up to 34 items (the 64-byte row slots keep 14-15 inline, the rest lives in the overflow area and is walked in
+    further rounds) and cuts that do not fit the dense phase-2 lists (m = 4000 > what region B holds next to the boundary-bin
+    list: the radix selects over the session table take over), with posting lists long enough for both cuts to bite."""
+    import serenade_amd as sa
+    O = _oracle()
+    off, items, ts, ids = small_dataset(21, n_sessions=30000, n_items=90, max_len=34)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, 5000, 34, 1.0)
+    oix = O.OracleIndex(off, items, ts, 5000, 34, 1.0)
+    qs = random_queries(8, ids, 80, max_len=5, unknown_rate=0.02, dup_rate=0.1)
+    for (k, m, n) in [(700, 1500, 21), (2500, 4000, 21), (100, 4500, 40)]:
+        res = _check_batch(gix, oix, qs, k, m, n, check_neighbours=(k <= 700))
+        assert (res["stats"][:, 1] == m).any() and (res["stats"][:, 2] == k).any(), "both cuts should be exercised"
+
+
 def test_long_sessions_negative_weights_and_duplicates(kernel_path):
     """L up to 14: linear_score goes to 0 at position 10 and negative beyond (Q3); duplicates (Q1/Q2)."""
     import serenade_amd as sa
