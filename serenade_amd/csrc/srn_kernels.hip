@@ -481,7 +481,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
     // first-match position (lowest set bit) come from it and phase 3 needs no first-match pass over the rows.
     uint8_t* wlut = (uint8_t*)(smem + MISC_WORDS * 4);                        // 256 B: numerator of each position set
     auto num_of = [&](SlotT sl) -> uint32_t { return MASKS ? (uint32_t)wlut[(uint32_t)(sl & num_mask)] : (uint32_t)(sl & num_mask); };
-    const uint32_t inb = c.item_buckets, H = c.hot_slots, SB = c.sum_bits, SK = c.sketch_slots, SKSH = c.sketch_shift;
+    const uint32_t inb = c.item_buckets, H = c.hot_slots, SB = c.sum_bits, SK = c.sketch_slots, SKM = c.sketch_slots - 1u;
     const uint32_t nq_eff = qlist ? *qlist_n : p.nq;
 
     for (uint32_t qi = blockIdx.x; qi < nq_eff; qi += gridDim.x) {
@@ -993,23 +993,32 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
         phase_sync<GLOBAL_TABLES>();
         SRN_TICK(8);
         {   // walk A
-            // one LDS add per element: idx < H -> its direct-mapped word, anything else -> its sketch word (sketch = hot + H;
-            // without a sketch the add is + 0 into the word after the direct-mapped part)
-            auto add_items = [&](const auto& it, uint32_t whot, uint32_t wpos) {
+            // one LDS add per element: idx < H -> its direct-mapped word, anything else -> sketch word idx mod SK (sketch = hot + H).
+            // A sketch word sums max(w, 0) of everything that lands in it: an upper bound of each of its items.  A direct-mapped
+            // word is the exact sum; where weights can be <= 0 (no MASKS) it also carries a touch count above bit SB so that a
+            // touched item with sum 0 is still seen.  Without a sketch only idx < H adds.
+            auto add_items = [&](const auto& it, uint32_t whot, uint32_t wsk) {
                 constexpr int N = sizeof(it) / sizeof(it[0]);
 #pragma unroll
                 for (int x = 0; x < N; ++x) {
                     const bool is_hot = it[x] < H;
-                    if (it[x] != EMPTY32) atomicAdd(&hot[is_hot ? it[x] : H + sketch_hash(it[x], SKSH)], is_hot ? whot : wpos);
+                    if (it[x] != EMPTY32 && (is_hot || SK)) atomicAdd(&hot[min(it[x], H + (it[x] & SKM))], is_hot ? whot : wsk);
                 } };
+            // The word index needs no select: min(idx, H + idx mod SK) is idx itself below H and a word of the sketch otherwise
+            // (idx in [H, H + SK) keeps its own position).  MASKS: weights are positive, plain sums everywhere, one value for both kinds
+            auto add_items_pos = [&](const auto& it, uint32_t wv) {
+                constexpr int N = sizeof(it) / sizeof(it[0]);
+#pragma unroll
+                for (int x = 0; x < N; ++x) if (it[x] != EMPTY32) atomicAdd(&hot[min(it[x], H + (it[x] & SKM))], wv); };
             uint32_t isum = 0;
             if constexpr (MASKS && STAGE == 0) {
-                isum = walk_rounds(nb_lds, nbl, [&](const auto& it, int w) { add_items(it, (1u << SB) + (uint32_t)w, SK ? (uint32_t)max(w, 0) : 0u); });
+                if (SK) isum = walk_rounds(nb_lds, nbl, [&](const auto& it, int w) { add_items_pos(it, (uint32_t)w); });
+                else isum = walk_rounds(nb_lds, nbl, [&](const auto& it, int w) { add_items(it, (uint32_t)w, 0u); });
             } else {
                 isum = walk_rows(nb_lds, [&](uint32_t j, uint32_t num, auto&& for_row) {
                     const int w = row_weight(j, num, for_row);
-                    const uint32_t wpos = SK ? (uint32_t)max(w, 0) : 0u, whot = (1u << SB) + (uint32_t)w;
-                    for_row([&](const auto& it) { add_items(it, whot, wpos); }); });
+                    const uint32_t wsk = (uint32_t)max(w, 0), whot = MASKS ? (uint32_t)w : (1u << SB) + (uint32_t)w;
+                    for_row([&](const auto& it) { add_items(it, whot, wsk); }); });
             }
             isum = wave_sum(isum);
             if (lane == 0 && p.stats && isum) atomicAdd((uint32_t*)&misc[S_I], isum);
@@ -1076,7 +1085,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                         const uint32_t i = e_lo + (ub + x) * BLOCK + tid;
                         if (ub + x < u_end && i < e_hi) {
                             uint32_t it = EMPTY32; int acc = 0;
-                            if (i < H) { const uint32_t v = hot[i]; if (v) { it = i; acc = (int)(v - (((v + (1u << (SB - 1))) >> SB) << SB)); } }
+                            if (i < H) { const uint32_t v = hot[i]; if (v) { it = i; acc = MASKS ? (int)v : (int)(v - (((v + (1u << (SB - 1))) >> SB) << SB)); } }
                             else { it = ikeys[i - H]; acc = iacc[i - H]; }
                             if (it != EMPTY32 && it != cur_idx) {   // Q6
                                 const bool hopeless = t_pos & (acc < acc_floor);   // branch-free on purpose (see DESIGN.md hazards)
@@ -1128,7 +1137,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
             { const uint32_t e = (uint32_t)lane * NWAVES + (uint32_t)wave;   // entries dealt round-robin: every wave sees the same mix of popularity
               const uint32_t v = hot[e];
               if (v && e != cur_idx) {
-                  const int acc = (int)(v - (((v + (1u << (SB - 1))) >> SB) << SB));
+                  const int acc = MASKS ? (int)v : (int)(v - (((v + (1u << (SB - 1))) >> SB) << SB));
                   const ItemMeta mt = ix.meta[e];
                   if (!business || business_ok(cur_attr, mt.attr)) { sk = score_key((mt.idf > 0.0 ? mt.idf : 1.0) * (double)acc / denom); tie = mt.id_rank; valid = true; }
               } }
@@ -1187,7 +1196,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
 #pragma unroll
                     for (int x = 0; x < N; ++x) {
                         go[x] = it[x] != EMPTY32 && it[x] >= H && (parts == 1 || hash_part(it[x], parts) == part);
-                        if (filt) { const uint32_t ub = go[x] ? sketch[sketch_hash(it[x], SKSH)] : 0u; go[x] = go[x] & (ub >= floor_b); }
+                        if (filt) { const uint32_t ub = go[x] ? hot[min(it[x], H + (it[x] & SKM))] : 0u; go[x] = go[x] & (ub >= floor_b); }
                     }
 #pragma unroll
                     for (int x = 0; x < N; ++x) {
