@@ -58,6 +58,7 @@ struct KernelCfg {
     uint32_t q_cap;                    // capacity of the per-query item arrays (>= max_len, multiple of 4)
     uint32_t off_q, off_wave, off_b, off_a;   // LDS byte offsets: query arrays, per-wave scratch, region B, region A
     uint32_t region_a_bytes;                  // size of region A in LDS (0 when the tables live in global memory)
+    uint32_t no_merge;                        // test knob: candidate sessions through the hash table even where the merge tree applies
 };
 
 // LDS scalar slots
@@ -194,6 +195,22 @@ __device__ KeyT block_select_desc(F keyfn, uint32_t n, int nbits, uint32_t r, ui
         rem = shift;
     }
     return prefix;
+}
+
+// exclusive prefix sum of one value per thread over the block (thread order); `scratch` = NWAVES words of LDS that nobody
+// else touches until the next barrier after the call; one barrier inside.  total = sum over the block.
+template <int BLOCK>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, volatile uint32_t* scratch, uint32_t& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+    if (lane == 63) scratch[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0; total = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) { const uint32_t t = scratch[w]; total += t; if (w < wave) base += t; }
+    return base + inc - v;
 }
 
 // Barrier between phases.  With the tables in global memory (retry pass) the CU's vector L1 may hold
@@ -500,12 +517,13 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
         if (tid < MISC_WORDS) misc[tid] = 0;
         for (uint32_t i = tid; i < SEL_WORDS; i += BLOCK) hist[i] = 0;
         if (MASKS && tid < 256) { uint32_t acc = 0; for (uint32_t b = 0; b < L; ++b) if ((tid >> b) & 1) acc += L - b; wlut[tid] = (uint8_t)acc; }
-        uint32_t x_lo, r_max, U, P, cur_idx;
+        uint32_t x_lo, r_max, U, P, cur_idx, sumw = 0, nruns = 0;
         if (STAGE == 0 && p.prep) {   // the look-ups were done by the prep kernel: one record per query, no barrier needed here
             const char* rec = p.prep + (size_t)q * p.prep_stride;
             const PrepHead hd = *(const PrepHead*)rec;   // (uniform address)
             const PrepItem* pit = (const PrepItem*)(rec + sizeof(PrepHead));
-            x_lo = hd.xlo; r_max = hd.rmax; U = hd.U; P = hd.P; cur_idx = pit[0].idx;
+            x_lo = hd.xlo; r_max = hd.rmax; U = hd.U; P = hd.P; cur_idx = pit[0].idx; sumw = hd.sumw;
+            for (uint32_t pos = 0; pos < L && pos < 16; ++pos) nruns += pit[pos].len != 0;   // (uniform)
             for (uint32_t pos = tid; pos < L; pos += BLOCK) { const PrepItem x = pit[pos]; q_idx[pos] = x.idx; l_len[pos] = x.len; l_pre[pos] = x.pre; l_base[pos] = x.base; }
             if (tid == 0) { l_pre[L] = hd.P; misc[S_U] = hd.U; misc[S_RMAX] = hd.rmax; misc[S_XLO] = hd.xlo; misc[S_SUMW] = hd.sumw; misc[S_P] = hd.P; }   // (same wave zeroed them)
         } else {
@@ -541,14 +559,196 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
         phase_sync<GLOBAL_TABLES>();
         x_lo = misc[S_XLO]; r_max = misc[S_RMAX]; U = misc[S_U]; P = misc[S_P]; cur_idx = q_idx[0];
         }
+        // Merge mode (the fused kernel's normal case): the posting lists are sorted, so the candidate sessions come out of a
+        // merge tree over the lists staged in LDS -- no session hash table, no selects (see phases 1-2 below).  It needs two
+        // buffers of P words in regions B + A (contiguous), u32 slots, <= 8 lists and <= 63 numerator classes.
+        bool merge_mode = false;
+        uint32_t* const wb = (uint32_t*)region_b;
+        const uint32_t wwords = ((c.off_a - c.off_b) + c.region_a_bytes) / 4;
+        if constexpr (STAGE == 0 && !GLOBAL_TABLES && sizeof(SlotT) == 4)
+            merge_mode = p.prep != nullptr && L <= 16 && nruns <= 8 && sumw <= 63 && (size_t)2 * P + 64 <= wwords && !c.no_merge;
         // session table sized to this query: at most P entries are inserted, keep the load <= 2/3
         uint32_t sslots = 256; while (sslots < c.sess_slots && sslots * 2 < P * 3) sslots <<= 1;
         const uint32_t smask = sslots / 4 - 1;   // bucket mask (4 slots per bucket)
-        for (uint32_t i = tid; i < sslots; i += BLOCK) stab[i] = SEMPTY;
+        if (!merge_mode) for (uint32_t i = tid; i < sslots; i += BLOCK) stab[i] = SEMPTY;
+        else if (tid < 64) {   // run table 0 (start, valid length of every active list) and the numerator class counters
+            wb[wwords - 64 + tid] = 0;
+            if (tid < 8) { uint32_t seen = 0, start = 0; const PrepItem* pit = (const PrepItem*)(p.prep + (size_t)q * p.prep_stride + sizeof(PrepHead));
+                           for (uint32_t pos = 0; pos < L; ++pos) { const uint32_t ln = pit[pos].len; if (ln) { if (seen == (uint32_t)tid) start = pit[pos].pre; ++seen; } }
+                           misc[32 + tid] = start; misc[40 + tid] = 0; }
+        }
         phase_sync<GLOBAL_TABLES>();
         SRN_TICK(0);
 
         uint32_t K = 0, Cm = 0;
+        if (merge_mode) {
+        if constexpr (STAGE == 0 && !GLOBAL_TABLES && sizeof(SlotT) == 4) {
+            // ---- phases 1-2, merge mode ------------------------------------------------------
+            // stage: every list entry >= x_lo as a packed slot (rank << NB | payload) at its list's offset -- each list is
+            //        sorted by rank, so the kept entries are a prefix and the staged list is a sorted run;
+            // merge: ceil(log2(#lists)) levels of pairwise merges (merge path: a binary search on the thread's diagonal,
+            //        then g = ceil(n / 512) sequential steps), ping-pong between two buffers of P words;
+            // m-cut: in the merged run a session's copies (one per list that holds it) are adjacent: flag the first of each
+            //        group, block prefix sum = index among the distinct sessions, the first m are the candidates D, payloads
+            //        of a group combined (OR of position bits / sum of weights);
+            // k-cut: D is ordered by recency, so inside one numerator class the order is already right: count the classes,
+            //        find the class n* that holds the k-th best and how many r* of it are wanted, prefix-count that class.
+            uint32_t* bufx = wb; uint32_t* bufy = wb + P;
+            const uint32_t nlv = nruns <= 1 ? 0u : (uint32_t)bits_for(nruns - 1);
+            uint32_t* in = (nlv & 1u) ? bufy : bufx; uint32_t* out = (nlv & 1u) ? bufx : bufy;   // the final run lands in bufx
+            {   // stage (lane <-> list element, coalesced, up to 10 loads in flight per lane: one memory latency for a typical query)
+                uint32_t pos = 0, run = 0;
+                for (uint32_t e0 = tid; e0 < P; e0 += 10 * BLOCK) {
+                    uint32_t r4[10], w4[10], run4[10], start4[10], end4[10];
+#pragma unroll
+                    for (int u = 0; u < 10; ++u) {
+                        const uint32_t e = e0 + u * BLOCK; r4[u] = 0; w4[u] = 0; run4[u] = 0; start4[u] = 0; end4[u] = 0;
+                        if (e < P) {
+                            while (e >= l_pre[pos + 1]) { run += l_len[pos] != 0; ++pos; }
+                            r4[u] = ix.post_rank[l_base[pos] + (e - l_pre[pos])];
+                            w4[u] = MASKS ? (1u << pos) : L - pos;
+                            run4[u] = run; start4[u] = l_pre[pos]; end4[u] = l_pre[pos + 1];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 10; ++u) {
+                        const uint32_t e = e0 + u * BLOCK;
+                        const bool keep = w4[u] && r4[u] >= x_lo;
+                        if (keep) in[e] = (r4[u] << NB) | w4[u];
+                        // the kept entries of a list are a prefix: its length is written by the lane that holds the last one
+                        // (the next entry belongs to the next lane; the last lane of a wave cannot see it and reports itself)
+                        const uint32_t rnext = (uint32_t)__shfl_down((int)r4[u], 1, 64);
+                        if (keep && (lane == 63 || e + 1 >= end4[u] || rnext < x_lo)) atomicMax((uint32_t*)&misc[40 + run4[u]], e + 1 - start4[u]);
+                    }
+                }
+            }
+            __syncthreads();
+            SRN_TICK(1);
+            // merge tree: level l merges runs pairwise (<= 4 pairs at level 0).  Merge path: thread t produces outputs
+            // [t g, (t + 1) g) of every pair -- a binary search on its diagonal (all pairs of the level searched together: their
+            // LDS round trips overlap), then g sequential steps.  Run tables (start x8 | length x8) ping-pong in misc[32..63].
+            const uint32_t nl = nruns <= 1 ? 0u : (uint32_t)bits_for(nruns - 1);
+            for (uint32_t lev = 0; lev < nl; ++lev) {
+                const uint32_t tb = 32 + 16 * (lev & 1u), tn = 32 + 16 * ((lev + 1) & 1u);
+                const uint32_t nr = (nruns + (1u << lev) - 1) >> lev, np = (nr + 1) >> 1;
+                uint32_t sa[4], la[4], sb[4], lb[4], d0[4], d1[4], lo[4], hi[4];
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {
+                    sa[pr] = la[pr] = sb[pr] = lb[pr] = d0[pr] = d1[pr] = lo[pr] = hi[pr] = 0;
+                    if ((uint32_t)pr < np) {
+                        sa[pr] = misc[tb + 2 * pr]; la[pr] = misc[tb + 8 + 2 * pr];
+                        if (2u * pr + 1 < nr) { sb[pr] = misc[tb + 2 * pr + 1]; lb[pr] = misc[tb + 8 + 2 * pr + 1]; }
+                        const uint32_t total = la[pr] + lb[pr], g = (total + BLOCK - 1) / BLOCK;
+                        d0[pr] = min((uint32_t)tid * g, total); d1[pr] = min(d0[pr] + g, total);
+                        lo[pr] = d0[pr] > lb[pr] ? d0[pr] - lb[pr] : 0u; hi[pr] = min(d0[pr], la[pr]);
+                        if (tid == 0) { misc[tn + pr] = sa[pr]; misc[tn + 8 + pr] = total; }
+                    }
+                }
+                for (int step = 0; step < 13; ++step) {   // (lists hold <= m <= 2^13 entries... any length: loop until every range is empty)
+                    bool any = false;
+#pragma unroll
+                    for (int pr = 0; pr < 4; ++pr) {
+                        if (lo[pr] < hi[pr]) {
+                            const uint32_t mid = (lo[pr] + hi[pr]) >> 1;
+                            if (in[sa[pr] + mid] > in[sb[pr] + d0[pr] - mid - 1]) lo[pr] = mid + 1; else hi[pr] = mid;
+                            any = any || lo[pr] < hi[pr];
+                        }
+                    }
+                    if (__ballot(any) == 0ull) break;
+                    if (step == 12) step = 0;   // (ranges wider than 2^13: keep going)
+                }
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {
+                    if ((uint32_t)pr < np && d0[pr] < d1[pr]) {
+                        const uint32_t* A = in + sa[pr]; const uint32_t* B = in + sb[pr]; uint32_t* Cc = out + sa[pr];
+                        const uint32_t a = la[pr], b = lb[pr];
+                        uint32_t i = lo[pr], j = d0[pr] - lo[pr];
+                        uint32_t va = i < a ? A[i] : 0u, vb = j < b ? B[j] : 0u;   // (a staged slot is never 0: its payload is >= 1)
+                        for (uint32_t o = d0[pr]; o < d1[pr]; ++o) {
+                            const bool ta = va > vb;
+                            Cc[o] = ta ? va : vb;
+                            if (ta) { ++i; va = i < a ? A[i] : 0u; } else { ++j; vb = j < b ? B[j] : 0u; }
+                        }
+                    }
+                }
+                __syncthreads();
+                uint32_t* t = in; in = out; out = t;
+            }
+            const uint32_t n = nruns ? misc[32 + 16 * (nl & 1u) + 8] : 0u;
+            // `in` == bufx holds the merged run F[0, n)
+            const uint32_t* F = bufx; uint32_t* D = bufy;
+            uint32_t Call;
+            {   // m-cut.  Every copy of a session ORs (adds) itself into D[index of its group]: no look-ahead over the group
+                const uint32_t g = (n + BLOCK - 1) / BLOCK, o0 = min((uint32_t)tid * g, n), o1 = min(o0 + g, n);
+                uint32_t firsts = 0;
+                uint32_t prev = o0 > 0 && o0 < o1 ? F[o0 - 1] >> NB : 0xFFFFFFFFu;
+                const uint32_t prev0 = prev;
+                for (uint32_t o = o0; o < o1; ++o) { const uint32_t r = F[o] >> NB; firsts += o == 0 || r != prev; prev = r; }
+                for (uint32_t i = tid; i < min(n, p.m); i += BLOCK) D[i] = 0;   // (the last merge level has read bufy: barrier above)
+                uint32_t idx = block_excl_scan<BLOCK>(firsts, misc + 32, Call);   // (the run tables in misc[32..63] are dead: scan scratch; barrier inside)
+                prev = prev0;
+                for (uint32_t o = o0; o < o1; ++o) {
+                    const uint32_t v = F[o], r = v >> NB;
+                    const bool first = o == 0 || r != prev; prev = r;
+                    idx += first;      // idx - 1 = index of v's group among the distinct sessions
+                    if (idx - 1 < p.m) { if (MASKS) atomicOr(&D[idx - 1], v); else atomicAdd(&D[idx - 1], (v & (uint32_t)num_mask) + (first ? r << NB : 0u)); }
+                }
+            }
+            Cm = min(Call, p.m);
+            __syncthreads();
+            SRN_TICK(2);
+            auto publish = [&](uint32_t at, uint32_t v) {
+                nbl[at] = v; nb_spill[at] = v;
+                if (p.nb_rank) { p.nb_rank[(size_t)q * p.k + at] = v >> NB; p.nb_num[(size_t)q * p.k + at] = num_of(v); } };
+            if (Cm <= p.k) {   // every candidate is a neighbour (F in bufx is dead: the neighbour list overwrites it)
+                for (uint32_t e = tid; e < Cm; e += BLOCK) publish(e, D[e]);
+                if (tid == 0) misc[S_NB] = Cm;
+            } else {   // k-cut
+                uint32_t* cls = wb + (wwords - 64);
+                {   // lane v counts class v (ballots), one scattered atomic per lane at the end: no same-address pile-up
+                    uint32_t mycnt = 0;
+                    for (uint32_t e0 = 0; e0 < Cm; e0 += BLOCK) {
+                        const uint32_t e = e0 + tid; const uint32_t nm = e < Cm ? num_of(D[e]) : 0xFFFFFFFFu;
+                        for (uint32_t v = 0; v <= sumw; ++v) { const uint32_t cv = (uint32_t)__popcll(__ballot(nm == v)); if ((uint32_t)lane == v) mycnt += cv; }
+                    }
+                    if (mycnt) atomicAdd(&cls[lane], mycnt);
+                }
+                __syncthreads();
+                uint32_t nstar, rstar;
+                {   // lane v holds class v: suffix sums from the best class down, the boundary class is the highest one whose suffix reaches k
+                    const uint32_t cv = cls[lane]; uint32_t suf = cv;
+#pragma unroll
+                    for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t t = __shfl_down(suf, dd, 64); if (lane + dd < 64) suf += t; }
+                    const unsigned long long reach = __ballot(suf >= p.k);
+                    nstar = 63u - (uint32_t)__clzll((long long)reach);
+                    rstar = p.k - ((uint32_t)__shfl((int)suf, (int)nstar, 64) - (uint32_t)__shfl((int)cv, (int)nstar, 64));
+                }
+                SRN_TICK(3);
+                const uint32_t g = (Cm + BLOCK - 1) / BLOCK, o0 = min((uint32_t)tid * g, Cm), o1 = min(o0 + g, Cm);
+                uint32_t mine = 0;
+                for (uint32_t o = o0; o < o1; ++o) mine += num_of(D[o]) == nstar;
+                uint32_t tot_star;
+                uint32_t before = block_excl_scan<BLOCK>(mine, misc + 40, tot_star);
+                uint32_t sel = 0;
+                for (uint32_t o = o0; o < o1; ++o) { const uint32_t nm = num_of(D[o]); sel += nm > nstar || (nm == nstar && before < rstar); before += nm == nstar; }
+                uint32_t at;   // output slots: a wave's selected entries are contiguous, waves in any order (the order of the list is free)
+                { uint32_t inc = sel;
+#pragma unroll
+                  for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t t = __shfl_up(inc, dd, 64); if (lane >= dd) inc += t; }
+                  uint32_t base = 0; if (lane == 63 && inc) base = atomicAdd((uint32_t*)&misc[S_NB], inc);
+                  at = (uint32_t)__shfl((int)base, 63, 64) + inc - sel; }
+                before = before - mine;   // back to this thread's start
+                for (uint32_t o = o0; o < o1; ++o) {
+                    const uint32_t v = D[o], nm = num_of(v);
+                    if (nm > nstar || (nm == nstar && before < rstar)) publish(at++, v);
+                    before += nm == nstar;
+                }
+            }
+            __syncthreads();
+            K = misc[S_NB];
+            SRN_TICK(4);
+        }
+        } else
         if constexpr (STAGE != 3) {
         // ---- phase 1: posting lists -> session table -------------------------------------
         // All <= U lists are walked as one flattened range (lane <-> list element, coalesced).  Entries
@@ -1481,6 +1681,7 @@ static int make_geometry(const DeviceState* d, const FlatIndex& ix, const Launch
     c.item_slots = c.item_buckets * 4;
     const uint32_t region_a = std::max<uint32_t>(hot * 4 + sk * 4 + c.item_slots * 8, c.sess_slots * slot_bytes);
     c.region_a_bytes = region_a;
+    c.no_merge = getenv("SRN_NO_MERGE") ? 1u : 0u;
     g.lds = (size_t)c.off_a + region_a;
     // tables at least twice the worst case cannot exhaust the probe budget: no retry machinery needed
     g.sess_may_overflow = (uint64_t)c.sess_slots < g.need_sess * 2; g.item_may_overflow = (uint64_t)c.item_slots < g.need_item * 2;

@@ -60,11 +60,11 @@ def test_kat1_should_train_and_predict():
         assert r.score == pytest.approx(1.751319134149782, rel=1e-12)
 
 
-@pytest.fixture(params=["default", "no_masks", "no_hot", "hot64", "no_sketch", "sketch64"])
+@pytest.fixture(params=["default", "no_masks", "no_hot", "hot64", "no_sketch", "sketch64", "no_merge"])
 def kernel_path(request, monkeypatch):
     """The kernel picks code paths per launch: position-set slots (sessions <= 8 items) vs numerator slots + first-match
-    pass; direct-mapped accumulators for popular items vs hash only; sketch pre-filter on / off / tiny.  The knobs force
-    each combination."""
+    pass; direct-mapped accumulators for popular items vs hash only; sketch pre-filter on / off / tiny; candidate sessions by
+    merge tree vs session hash table.  The knobs force each combination."""
     if request.param == "no_masks":
         monkeypatch.setenv("SRN_NO_MASKS", "1")
     elif request.param == "no_hot":
@@ -74,6 +74,8 @@ def kernel_path(request, monkeypatch):
         monkeypatch.setenv("SRN_NO_MASKS", "1")
     elif request.param == "no_sketch":
         monkeypatch.setenv("SRN_SKETCH_SLOTS", "0")
+    elif request.param == "no_merge":          # candidate sessions through the LDS hash table + selects instead of the merge tree
+        monkeypatch.setenv("SRN_NO_MERGE", "1")
     elif request.param == "sketch64":          # heavy collisions in the upper-bound words: the filter must stay exact
         monkeypatch.setenv("SRN_SKETCH_SLOTS", "64")
         monkeypatch.setenv("SRN_HOT_SLOTS", "32")
@@ -300,6 +302,10 @@ def test_baseline_configs_full_size(config, n_check, monkeypatch):
     assert (res["stats"][:, 1] == m).any() and (res["stats"][:, 2] == k).any()      # both cuts are exercised at this size
     a = sa.predict_batch(gix, (qi, qo), k, m, synth.HOW_MANY)     # product path: sketch pre-filter on
     assert np.array_equal(a[0][:n_check], res["ids"]) and np.array_equal(a[1][:n_check], res["scores"])
+    monkeypatch.setenv("SRN_NO_MERGE", "1")                        # session hash table + selects instead of the merge tree
+    c = sa.predict_batch(gix, (qi, qo), k, m, synth.HOW_MANY)
+    for x, y in zip(a, c):
+        assert np.array_equal(x, y)
     monkeypatch.setenv("SRN_NO_MASKS", "1")                        # no direct-mapped part => no threshold => nothing filtered
     monkeypatch.setenv("SRN_HOT_SLOTS", "0")
     b = sa.predict_batch(gix, (qi, qo), k, m, synth.HOW_MANY)
