@@ -420,14 +420,14 @@ __global__ __launch_bounds__(1024) void rows_to_slots_kernel(const uint64_t* __r
 // posting list bounds -> first / m-th rank) so that the main kernel, where a whole workgroup would wait on that
 // chain, reads one record.  Record = PrepHead + max_len * PrepItem, positions counted from the most recent item.
 // -------------------------------------------------------------------------------------
-struct PrepHead { uint32_t U, rmax, xlo, sumw, P, pad[3]; };          // S_U, S_RMAX, S_XLO, S_SUMW, S_P of the query
+struct PrepHead { uint32_t U, rmax, xlo, sumw, P, nruns, pad[2], run_start[8]; };   // S_U, S_RMAX, S_XLO, S_SUMW, S_P of the query; number of non-empty lists and where the first 8 start
 struct PrepItem { uint32_t idx, len, pre, pad; unsigned long long base; };   // dense idx | kNone, truncated list length, prefix of len, list start
 __global__ __launch_bounds__(256) void vmis_prep_kernel(DeviceIndex ix, const uint64_t* __restrict__ items_flat, const uint32_t* __restrict__ q_off,
                                                         uint32_t nq, uint32_t m, uint32_t max_len, char* out, uint32_t stride) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     const uint32_t qb = q_off[q], L = q_off[q + 1] - qb;
-    PrepHead h{0u, 0u, 0u, 0u, 0u, {0u, 0u, 0u}};
+    PrepHead h{0u, 0u, 0u, 0u, 0u, 0u, {0u, 0u}, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}};
     PrepItem* items = (PrepItem*)(out + (size_t)q * stride + sizeof(PrepHead));
     if (L != 0 && L <= max_len) {
         for (uint32_t pos = 0; pos < L; ++pos) {
@@ -448,6 +448,7 @@ __global__ __launch_bounds__(256) void vmis_prep_kernel(DeviceIndex ix, const ui
                     h.sumw += L - pos;
                 }
             }
+            if (len) { if (h.nruns < 8) h.run_start[h.nruns] = h.P; ++h.nruns; }
             items[pos] = PrepItem{idx, len, h.P, 0u, base};
             h.P += len;
         }
@@ -523,7 +524,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
             const PrepHead hd = *(const PrepHead*)rec;   // (uniform address)
             const PrepItem* pit = (const PrepItem*)(rec + sizeof(PrepHead));
             x_lo = hd.xlo; r_max = hd.rmax; U = hd.U; P = hd.P; cur_idx = pit[0].idx; sumw = hd.sumw;
-            for (uint32_t pos = 0; pos < L && pos < 16; ++pos) nruns += pit[pos].len != 0;   // (uniform)
+            nruns = hd.nruns;
             for (uint32_t pos = tid; pos < L; pos += BLOCK) { const PrepItem x = pit[pos]; q_idx[pos] = x.idx; l_len[pos] = x.len; l_pre[pos] = x.pre; l_base[pos] = x.base; }
             if (tid == 0) { l_pre[L] = hd.P; misc[S_U] = hd.U; misc[S_RMAX] = hd.rmax; misc[S_XLO] = hd.xlo; misc[S_SUMW] = hd.sumw; misc[S_P] = hd.P; }   // (same wave zeroed them)
         } else {
@@ -566,16 +567,14 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
         uint32_t* const wb = (uint32_t*)region_b;
         const uint32_t wwords = ((c.off_a - c.off_b) + c.region_a_bytes) / 4;
         if constexpr (STAGE == 0 && !GLOBAL_TABLES && sizeof(SlotT) == 4)
-            merge_mode = p.prep != nullptr && L <= 16 && nruns <= 8 && sumw <= 63 && (size_t)2 * P + 64 <= wwords && !c.no_merge;
+            merge_mode = p.prep != nullptr && nruns <= 8 && sumw <= 63 && (size_t)2 * P + 64 <= wwords && !c.no_merge;
         // session table sized to this query: at most P entries are inserted, keep the load <= 2/3
         uint32_t sslots = 256; while (sslots < c.sess_slots && sslots * 2 < P * 3) sslots <<= 1;
         const uint32_t smask = sslots / 4 - 1;   // bucket mask (4 slots per bucket)
         if (!merge_mode) for (uint32_t i = tid; i < sslots; i += BLOCK) stab[i] = SEMPTY;
         else if (tid < 64) {   // run table 0 (start, valid length of every active list) and the numerator class counters
             wb[wwords - 64 + tid] = 0;
-            if (tid < 8) { uint32_t seen = 0, start = 0; const PrepItem* pit = (const PrepItem*)(p.prep + (size_t)q * p.prep_stride + sizeof(PrepHead));
-                           for (uint32_t pos = 0; pos < L; ++pos) { const uint32_t ln = pit[pos].len; if (ln) { if (seen == (uint32_t)tid) start = pit[pos].pre; ++seen; } }
-                           misc[32 + tid] = start; misc[40 + tid] = 0; }
+            if (tid < 8) { misc[32 + tid] = ((const PrepHead*)(p.prep + (size_t)q * p.prep_stride))->run_start[tid]; misc[40 + tid] = 0; }
         }
         phase_sync<GLOBAL_TABLES>();
         SRN_TICK(0);
@@ -596,30 +595,29 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
             uint32_t* bufx = wb; uint32_t* bufy = wb + P;
             const uint32_t nlv = nruns <= 1 ? 0u : (uint32_t)bits_for(nruns - 1);
             uint32_t* in = (nlv & 1u) ? bufy : bufx; uint32_t* out = (nlv & 1u) ? bufx : bufy;   // the final run lands in bufx
-            {   // stage (lane <-> list element, coalesced, up to 10 loads in flight per lane: one memory latency for a typical query)
-                uint32_t pos = 0, run = 0;
-                for (uint32_t e0 = tid; e0 < P; e0 += 10 * BLOCK) {
-                    uint32_t r4[10], w4[10], run4[10], start4[10], end4[10];
+            {   // stage, list by list (uniform base and weight: no per-element list look-up), 4 loads in flight per lane
+                uint32_t run = 0;
+                for (uint32_t pos = 0; pos < L; ++pos) {
+                    const uint32_t len = l_len[pos];   // (uniform)
+                    if (len == 0) continue;
+                    const uint32_t* __restrict__ src = ix.post_rank + l_base[pos];
+                    uint32_t* dst = in + l_pre[pos];
+                    const uint32_t w = MASKS ? (1u << pos) : L - pos;
+                    uint32_t kept = 0;
+                    for (uint32_t e0 = tid; e0 < len; e0 += 4 * BLOCK) {
+                        uint32_t r4[4];
 #pragma unroll
-                    for (int u = 0; u < 10; ++u) {
-                        const uint32_t e = e0 + u * BLOCK; r4[u] = 0; w4[u] = 0; run4[u] = 0; start4[u] = 0; end4[u] = 0;
-                        if (e < P) {
-                            while (e >= l_pre[pos + 1]) { run += l_len[pos] != 0; ++pos; }
-                            r4[u] = ix.post_rank[l_base[pos] + (e - l_pre[pos])];
-                            w4[u] = MASKS ? (1u << pos) : L - pos;
-                            run4[u] = run; start4[u] = l_pre[pos]; end4[u] = l_pre[pos + 1];
+                        for (int u = 0; u < 4; ++u) { const uint32_t e = e0 + u * BLOCK; r4[u] = e < len ? src[e] : 0u; }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const uint32_t e = e0 + u * BLOCK;
+                            const bool keep = e < len && r4[u] >= x_lo;   // (the list is sorted: the kept entries are a prefix)
+                            if (keep) dst[e] = (r4[u] << NB) | w;
+                            kept += (uint32_t)__popcll(__ballot(keep));
                         }
                     }
-#pragma unroll
-                    for (int u = 0; u < 10; ++u) {
-                        const uint32_t e = e0 + u * BLOCK;
-                        const bool keep = w4[u] && r4[u] >= x_lo;
-                        if (keep) in[e] = (r4[u] << NB) | w4[u];
-                        // the kept entries of a list are a prefix: its length is written by the lane that holds the last one
-                        // (the next entry belongs to the next lane; the last lane of a wave cannot see it and reports itself)
-                        const uint32_t rnext = (uint32_t)__shfl_down((int)r4[u], 1, 64);
-                        if (keep && (lane == 63 || e + 1 >= end4[u] || rnext < x_lo)) atomicMax((uint32_t*)&misc[40 + run4[u]], e + 1 - start4[u]);
-                    }
+                    if (lane == 0 && kept) atomicAdd((uint32_t*)&misc[40 + run], kept);
+                    ++run;
                 }
             }
             __syncthreads();
