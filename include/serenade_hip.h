@@ -205,6 +205,20 @@ int srn_kernel_times(const srn_index_t* idx, uint32_t max_n, double* out_ms_main
 int srn_debug_phase_cycles(const srn_index_t* idx, int enable, uint64_t* out16);
 
 /* ---- misc ------------------------------------------------------------------------------- */
+/* ---- dynamic batching: the serving-side caller ------------------------------------------------------------------
+ * The reference answers every /v1/recommend call with its own vmisknn::predict on an actix worker
+ * (src/endpoints/recommend_resource.rs:56-62; workers share one Arc<VMISIndex>, src/bin/serving.rs:62-94).
+ * srn_batcher_predict has predict()'s shape -- one evolving session in, <= how_many (id, score) pairs out, blocking --
+ * and may be called from any number of threads; a dispatcher thread folds what is waiting (up to max_batch requests, or
+ * whatever has arrived max_wait_us after the first one) into ONE srn_predict_batch launch.  k, m, how_many and the
+ * business-logic switch are fixed per batcher, like the serving binary's configuration (src/config.rs). */
+typedef struct srn_batcher srn_batcher_t;
+int srn_batcher_create(const srn_index_t* idx, size_t max_batch, unsigned max_wait_us, size_t k, size_t m, size_t how_many,
+                       int enable_business_logic, srn_batcher_t** out);
+int srn_batcher_predict(srn_batcher_t* b, const uint64_t* evolving, size_t len, uint64_t* out_ids, double* out_scores, size_t* out_n);
+int srn_batcher_stats(srn_batcher_t* b, uint64_t* n_requests, uint64_t* n_batches, uint64_t* max_batch_seen);
+void srn_batcher_free(srn_batcher_t* b);   /* serves what is still queued, then stops the dispatcher */
+
 int srn_device_count(int* out);
 void srn_limits(srn_limits_t* out);
 const char* srn_last_error(void);

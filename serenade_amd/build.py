@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libserenade_hip.so")
 SYNTH_LIB = os.path.join(HERE, "libsrn_synth.so")
-SOURCES = ["srn_index.cpp", "srn_capi.cpp", "srn_kernels.hip", "srn_build_gpu.hip"]
+SOURCES = ["srn_index.cpp", "srn_capi.cpp", "srn_batcher.cpp", "srn_kernels.hip", "srn_build_gpu.hip"]
 HEADERS = ["srn_internal.h", os.path.join("..", "..", "include", "serenade_hip.h")]
 
 
@@ -69,10 +69,24 @@ def build_evaluator(force=False):
     return EVALUATOR
 
 
+SERVE_BENCH = os.path.join(HERE, "bin", "serve_bench")
+
+
+def build_serve_bench(force=False):
+    """Closed-loop load generator for the dynamic batcher (host program over the C ABI)."""
+    src = os.path.join(CSRC, "host", "serve_bench.cpp")
+    if force or _stale(SERVE_BENCH, [src, LIB]):
+        os.makedirs(os.path.dirname(SERVE_BENCH), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", SERVE_BENCH, src, "-L" + HERE, "-lserenade_hip",
+                               "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"])
+    return SERVE_BENCH
+
+
 def build_all(force=False, verbose=False):
     build_hip(force, verbose)
     build_synth(force)
     build_evaluator(force)
+    build_serve_bench(force)
 
 
 if __name__ == "__main__":

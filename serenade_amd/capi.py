@@ -54,6 +54,10 @@ SYMBOLS = {
     "srn_index_free": (None, [_vp]),
     "srn_predict": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _i, _vp, _vp, C.POINTER(_sz)]),
     "srn_predict_batch": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint, _vp, _vp, _vp]),
+    "srn_batcher_create": (_i, [_vp, _sz, C.c_uint, _sz, _sz, _sz, _i, C.POINTER(_vp)]),
+    "srn_batcher_predict": (_i, [_vp, _vp, _sz, _vp, _vp, C.POINTER(_sz)]),
+    "srn_batcher_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
+    "srn_batcher_free": (None, [_vp]),
     "srn_predict_batch_device": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, C.c_uint, _vp, _vp, _vp, _vp]),
     "srn_predict_batch_debug": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "srn_last_kernel_ms": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),

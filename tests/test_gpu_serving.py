@@ -1,0 +1,58 @@
+"""Dynamic batching (srn_batcher_*): many threads call predict() concurrently, the library folds them into shared launches;
+every caller must get exactly what a call of its own would have returned."""
+import threading
+
+import numpy as np
+import pytest
+
+from helpers import random_queries, small_dataset
+
+pytestmark = pytest.mark.gpu
+
+
+def test_batcher_matches_direct_predict_under_concurrency():
+    import serenade_amd as sa
+    from serenade_amd.serving import Batcher
+    off, items, ts, ids = small_dataset(31, n_sessions=4000, n_items=500)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, 300, 12, 1.0)
+    qs = random_queries(4, ids, 600, max_len=6)
+    want = [sa.predict(gix, q, 100, 300, 21, False) for q in qs]
+    b = Batcher(gix, 100, 300, 21, False, max_batch=64, max_wait_us=2000)
+    got = [None] * len(qs)
+    errs = []
+
+    def worker(lo, hi):
+        try:
+            for i in range(lo, hi):
+                got[i] = b.predict(qs[i])
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    n_threads = 24
+    step = (len(qs) + n_threads - 1) // n_threads
+    threads = [threading.Thread(target=worker, args=(t * step, min(len(qs), (t + 1) * step))) for t in range(n_threads)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errs, errs
+    assert got == want
+    st = b.stats
+    assert st["requests"] == len(qs) and st["batches"] < len(qs) and 1 < st["max_batch_seen"] <= 64, st
+    # a bad request fails alone (same code and message class as srn_predict), the batcher keeps serving
+    with pytest.raises(sa.SerenadeError) as e:
+        b.predict([])
+    assert e.value.code == -1
+    with pytest.raises(sa.SerenadeError) as e:
+        b.predict([1] * 300)
+    assert e.value.code == -4
+    assert b.predict(qs[0]) == want[0]
+    b.close()
+
+
+def test_batcher_rejects_bad_configuration():
+    import serenade_amd as sa
+    from serenade_amd.serving import Batcher
+    off, items, ts, ids = small_dataset(32, n_sessions=200, n_items=50)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, 50, 12, 1.0)
+    for kw in (dict(k=0, m=10, how_many=5), dict(k=10, m=10, how_many=100000), dict(k=10, m=10, how_many=5, max_batch=0)):
+        with pytest.raises(sa.SerenadeError):
+            Batcher(gix, kw["k"], kw["m"], kw["how_many"], max_batch=kw.get("max_batch", 16))
