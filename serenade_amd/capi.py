@@ -44,6 +44,7 @@ SYMBOLS = {
     "srn_sessions_length_quantile": (_i, [_vp, C.c_double, C.POINTER(_u64)]),
     "srn_sessions_free": (None, [_vp]),
     "srn_index_build": (_i, [C.POINTER(SessionsView), _sz, _sz, C.c_double, _i, C.POINTER(_vp)]),
+    "srn_index_new_from_avro": (_i, [C.c_char_p, _i, C.POINTER(_vp)]),
     "srn_index_build_gpu": (_i, [C.POINTER(SessionsView), _sz, _sz, C.c_double, _i, C.POINTER(_vp)]),
     "srn_index_new_from_csv": (_i, [C.c_char_p, _sz, C.c_double, _sz, _i, C.POINTER(_vp)]),
     "srn_index_save": (_i, [_vp, C.c_char_p]),

@@ -127,6 +127,17 @@ int srn_index_new_from_csv(const char* path, size_t m_most_recent_sessions, doub
                    : srn_index_build(&v, m_most_recent_sessions, max_session_len, idf_weighting, device, out); });
 }
 
+int srn_index_new_from_avro(const char* base_path, int device, srn_index_t** out) {
+    return guarded([&]() -> int {
+        if (!base_path || !out) return fail(SRN_EINVAL, "null argument");
+        *out = nullptr;
+        srn_index* ix = new srn_index();
+        int rc = build_flat_index_from_avro(base_path, ix->flat);
+        if (rc == SRN_OK && device >= 0) { ix->dev = device_attach(ix->flat, device); ix->device = device; if (!ix->dev) rc = SRN_EHIP; }
+        if (rc) { delete ix; return rc; }
+        *out = ix; return SRN_OK; });
+}
+
 int srn_index_save(const srn_index_t* idx, const char* path) {
     if (!idx || !path) return fail(SRN_EINVAL, "null argument");
     return guarded([&]() -> int { return save_flat_index(idx->flat, path); });

@@ -65,6 +65,7 @@ int build_flat_index(const srn_sessions_view_t& v, size_t m_index, size_t max_se
 static inline uint32_t item_owner(uint64_t id, uint32_t n_shards) { return (uint32_t)(mix64(id ^ 0x9E3779B97F4A7C15ull) % n_shards); }
 int build_flat_index_gpu(const srn_sessions_view_t& v, size_t m_index, size_t max_session_len, double idf_weighting, int device,
                          FlatIndex& out);   // same result, built with rocPRIM sorts on the GPU (srn_build_gpu.hip)
+int build_flat_index_from_avro(const char* base_path, FlatIndex& out);   // <base>/itemindex/*.avro + <base>/sessionindex/*.avro (srn_avro.cpp)
 int save_flat_index(const FlatIndex& ix, const char* path);
 int load_flat_index(const char* path, FlatIndex& ix);
 

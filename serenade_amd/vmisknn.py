@@ -54,6 +54,13 @@ class VMISIndex:
         return cls(h)
 
     @classmethod
+    def new_from_avro(cls, base_path, device=0):
+        """VMISIndex::new(base_path) (vmis_index.rs:85-314): pre-built index from <base>/itemindex and <base>/sessionindex Avro files."""
+        h = C.c_void_p()
+        capi.check(capi.lib().srn_index_new_from_avro(str(base_path).encode(), int(device), C.byref(h)))
+        return cls(h)
+
+    @classmethod
     def load(cls, path, device=0):
         h = C.c_void_p()
         capi.check(capi.lib().srn_index_load(str(path).encode(), int(device), C.byref(h)))
