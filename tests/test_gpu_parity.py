@@ -108,6 +108,9 @@ def test_long_rows_and_large_cuts(kernel_path):
     for (k, m, n) in [(700, 1500, 21), (2500, 4000, 21), (100, 4500, 40)]:
         res = _check_batch(gix, oix, qs, k, m, n, check_neighbours=(k <= 700))
         assert (res["stats"][:, 1] == m).any() and (res["stats"][:, 2] == k).any(), "both cuts should be exercised"
+    # the ABI's limits: k = SRN_MAX_K neighbours (the neighbour list alone takes 32 KB of LDS: one workgroup per CU), how_many = 512
+    res = _check_batch(gix, oix, qs[:30], 8192, 5000, 512, check_neighbours=False)
+    assert (res["stats"][:, 2] > 4000).any()
 
 
 def test_long_sessions_negative_weights_and_duplicates(kernel_path):
