@@ -118,8 +118,8 @@ int srn_index_new_from_csv(const char* path, size_t m_most_recent_sessions, doub
                            size_t max_session_len, int device, srn_index_t** out);
 /* VMISIndex::new(base_path) (src/vmisknn/vmis_index.rs:85-314): the pre-built production index, two directories of Avro
  * object-container files (codec null or snappy):
- *   <base>/itemindex/*.avro     {ItemId: long, session_indices_time_ordered: array<int>, idf: double, ForSale, IsAdult: boolean}
- *   <base>/sessionindex/*.avro  {SessionIndex: int, item_ids_asc: array<long>, Time: int}
+ *   <base>/itemindex/[files].avro     {ItemId: long, session_indices_time_ordered: array<int>, idf: double, ForSale, IsAdult: boolean}
+ *   <base>/sessionindex/[files].avro  {SessionIndex: int, item_ids_asc: array<long>, Time: int}
  * Posting lists, idf and the product flags are taken from the files as they are (nothing is recomputed); the lists must be
  * what their name says -- each item's most recent sessions -- or the call fails with SRN_EINVAL.  device < 0: host only. */
 int srn_index_new_from_avro(const char* base_path, int device, srn_index_t** out);

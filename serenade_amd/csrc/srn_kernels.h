@@ -1,0 +1,46 @@
+// Internal interface between the kernels (srn_kernels.hip) and the device runtime (srn_runtime.hip): LDS geometry, the
+// prep record layout and the launchers.  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "srn_internal.h"
+
+namespace srn {
+
+static constexpr uint32_t EMPTY32 = 0xFFFFFFFFu;
+static constexpr int CAND_CAP = 1024;       // candidate buffer of the final top-n (entries)
+static constexpr int MISC_WORDS = 64;       // scalar words at the head of LDS
+static constexpr int kBlock = 512;            // threads per workgroup of the predict kernel
+static constexpr int SEL_BITS = 11, SEL_BINS = 1 << SEL_BITS;   // radix-select histogram: 11 bits per pass
+static constexpr int SEL_WORDS = SEL_BINS + SEL_BINS / 32;
+
+// launch-time geometry, identical for every block of a launch (all LDS offsets multiples of 16)
+struct KernelCfg {
+    uint32_t sess_slots, item_slots;   // session table: power of two; item hash table: 4 * item_buckets slots
+    uint32_t item_buckets;             // prime number of 4-slot buckets (double hashing needs a full cycle)
+    uint32_t hot_slots;                // direct-mapped accumulators for dense idx < hot_slots (idx = popularity order)
+    uint32_t sketch_slots, sketch_shift;   // power-of-two upper-bound words for every other item (0 = none); 32 - log2
+    uint32_t sum_bits;                 // hot accumulator = (touch count << sum_bits) + signed weight sum
+    uint32_t num_bits;                 // low bits of a session slot that hold the numerator
+    uint32_t q_cap;                    // capacity of the per-query item arrays (>= max_len, multiple of 4)
+    uint32_t off_q, off_wave, off_b, off_a;   // LDS byte offsets: query arrays, per-wave scratch, region B, region A
+    uint32_t region_a_bytes;                  // size of region A in LDS (0 when the tables live in global memory)
+    uint32_t no_merge;                        // test knob: candidate sessions through the hash table even where the merge tree applies
+};
+
+// record written by the prep kernel for every query: PrepHead + max_len * PrepItem, positions counted from the most recent item
+struct PrepHead { uint32_t U, rmax, xlo, sumw, P, nruns, pad[2], run_start[8]; };   // S_U, S_RMAX, S_XLO, S_SUMW, S_P of the query; number of non-empty lists and where the first 8 start
+struct PrepItem { uint32_t idx, len, pre, pad; unsigned long long base; };   // dense idx | kNone, truncated list length, prefix of len, list start
+
+// ---- launchers (srn_kernels.hip) -------------------------------------------------------------
+// the predict kernel: stage 0 = fused, 1..3 = the item-sharded pipeline's stages A..C; global_tables = the retry pass with its
+// tables in a global-memory arena (stage 0 only)
+hipError_t launch_predict(bool masks, bool slot64, bool global_tables, int stage, dim3 grid, size_t lds, hipStream_t st, const DeviceIndex& di,
+                          const LaunchParams& p, const KernelCfg& c, const uint32_t* qlist, const uint32_t* qn, uint32_t* retry_list,
+                          uint32_t* retry_cnt, char* gscratch, unsigned long long gscratch_stride, char* nb_spill, const ShardIO& sh);
+hipError_t launch_prep(hipStream_t st, const DeviceIndex& di, const uint64_t* items_flat, const uint32_t* q_off, uint32_t nq, uint32_t m,
+                       uint32_t max_len, char* out, uint32_t stride);
+hipError_t launch_rows_to_slots(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base,
+                                uint32_t* slots, uint32_t* ext);   // grid = ceil((n_rows + 1) / 1024) blocks of 1024
+
+}  // namespace srn

@@ -1,0 +1,405 @@
+// =====================================================================================
+// Device runtime of libserenade_hip.so: index upload (row slots laid out on the device), per-call workspaces (own stream,
+// staging buffers, event ring), LDS geometry of a launch, the predict launches (prep kernel, predict kernel, global-table
+// retry pass), the item-sharded pipeline's stages, timing and debug counters.  The kernels live in srn_kernels.hip.
+// =====================================================================================
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "srn_kernels.h"
+
+namespace srn {
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(SRN_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct Workspace {
+    hipStream_t stream = nullptr;   // own stream for host-pointer calls
+    static constexpr int RING = 64;               // per-call events: start, after main kernel, after retry pass, after prep kernel
+    hipEvent_t ev[RING][4] = {};
+    uint64_t calls = 0; uint32_t last_retry = 0;
+    // device scratch
+    uint32_t* retry_list = nullptr; size_t retry_cap = 0; uint32_t* retry_cnt = nullptr;
+    char* gscratch = nullptr; size_t gscratch_bytes = 0;
+    char* spill = nullptr; size_t spill_bytes = 0;   // per-block global copies of the neighbour lists
+    char* prep = nullptr; size_t prep_bytes = 0;     // per-query records of the prep kernel
+    // staging for host-pointer calls
+    char* stage = nullptr; size_t stage_bytes = 0;
+    uint32_t* h_retry = nullptr;   // pinned
+};
+
+struct DeviceState {
+    int device = 0;
+    std::vector<void*> allocs; uint64_t bytes = 0;
+    DeviceIndex di{};
+    ItemMeta* d_meta = nullptr;
+    int n_cu = 256;
+    int lds_per_block_max = 65536;
+    std::mutex mu; std::vector<Workspace*> free_ws; std::vector<Workspace*> all_ws;
+    std::vector<std::pair<void*, Workspace*>> stream_ws;   // device-pointer calls: one workspace per user stream
+    Workspace* last_ws = nullptr;   // for srn_last_kernel_ms (single-threaded measurement use)
+    unsigned long long* d_phase = nullptr; bool phase_on = false;   // debug per-phase cycle counters
+};
+
+namespace {
+template <typename T> const T* upload(DeviceState* d, const std::vector<T>& v, bool& ok, size_t pad = 0, size_t = 0) {   // (hipMalloc is 256-byte aligned)
+    void* p = nullptr; const size_t n = std::max<size_t>(v.size() * sizeof(T), 16) + pad;
+    if (!ok) return nullptr;
+    if (hipMalloc(&p, n) != hipSuccess) { ok = false; set_error("hipMalloc failed for index array"); return nullptr; }
+    d->allocs.push_back(p); d->bytes += n;
+    if (!v.empty() && hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { ok = false; set_error("hipMemcpy H2D failed"); }
+    return (const T*)p;
+}
+}  // namespace
+
+DeviceState* device_attach(const FlatIndex& ix, int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) { set_error("no such HIP device"); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice failed"); return nullptr; }
+    DeviceState* d = new DeviceState(); d->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) { d->n_cu = prop.multiProcessorCount; d->lds_per_block_max = (int)prop.sharedMemPerBlock; }
+    bool ok = true;
+    d->di.id_table = upload(d, ix.id_table, ok); d->di.id_mask = ix.id_mask;
+    { std::vector<ItemMeta> meta(ix.n_items); std::vector<uint64_t> id_sorted(ix.n_items);
+      for (size_t i = 0; i < ix.n_items; ++i) { meta[i] = ItemMeta{ix.idf[i], ix.id_rank[i], ix.attr[i]}; id_sorted[ix.id_rank[i]] = ix.item_id[i]; }
+      d->d_meta = (ItemMeta*)upload(d, meta, ok); d->di.meta = d->d_meta; d->di.id_sorted = upload(d, id_sorted, ok); }
+    d->di.post_off = upload(d, ix.post_off, ok); d->di.post_rank = upload(d, ix.post_rank, ok);
+    if (ok) {   // rows -> 64-byte slots (+ overflow area) on the device, see DeviceIndex and rows_to_slots_kernel
+        const size_t n = ix.n_kept, nblocks = (n + 1 + 1023) / 1024;
+        std::vector<uint32_t> block_base(nblocks);
+        uint64_t ext_total = 16;   // ext[0..15] = EMPTY32: what short rows read
+        for (size_t b0 = 0; b0 < nblocks; ++b0) {
+            block_base[b0] = (uint32_t)ext_total;
+            const size_t hi = std::min(n, (b0 + 1) * 1024);
+            for (size_t r = b0 * 1024; r < hi; ++r) { const uint64_t len = ix.row_off[r + 1] - ix.row_off[r]; if (len > 15) ext_total += len - 14; }
+            if (ext_total >= 0xFFFFFFF0ull) { set_error("row overflow area exceeds 2^32 items"); device_release(d); return nullptr; }
+        }
+        void *d_off = nullptr, *d_items = nullptr, *d_base = nullptr, *d_slots = nullptr, *d_ext = nullptr;
+        const size_t ext_words = ext_total + 16;   // (4-item loads may run past the last row)
+        bool good = hipMalloc(&d_off, (n + 1) * 8) == hipSuccess && hipMalloc(&d_items, std::max<size_t>(ix.row_items.size() * 4, 16)) == hipSuccess &&
+                    hipMalloc(&d_base, nblocks * 4) == hipSuccess && hipMalloc(&d_slots, (n + 1) * 64) == hipSuccess && hipMalloc(&d_ext, ext_words * 4) == hipSuccess;
+        good = good && hipMemcpy(d_off, ix.row_off.data(), (n + 1) * 8, hipMemcpyHostToDevice) == hipSuccess &&
+               (ix.row_items.empty() || hipMemcpy(d_items, ix.row_items.data(), ix.row_items.size() * 4, hipMemcpyHostToDevice) == hipSuccess) &&
+               hipMemcpy(d_base, block_base.data(), nblocks * 4, hipMemcpyHostToDevice) == hipSuccess &&
+               hipMemset(d_ext, 0xFF, ext_words * 4) == hipSuccess;
+        good = good && launch_rows_to_slots(nullptr, (const uint64_t*)d_off, (const uint32_t*)d_items, (uint64_t)n, (const uint32_t*)d_base, (uint32_t*)d_slots, (uint32_t*)d_ext) == hipSuccess &&
+               hipDeviceSynchronize() == hipSuccess;
+        if (d_off) hipFree(d_off); if (d_items) hipFree(d_items); if (d_base) hipFree(d_base);
+        if (d_slots) { d->allocs.push_back(d_slots); d->bytes += (n + 1) * 64; }
+        if (d_ext) { d->allocs.push_back(d_ext); d->bytes += ext_words * 4; }
+        if (!good) { ok = false; set_error("row slot layout on the device failed"); }
+        d->di.row_slots = (const RowQuad*)d_slots; d->di.row_ext = (const uint32_t*)d_ext;
+    }
+    d->di.n_items = (uint32_t)ix.n_items; d->di.n_kept = (uint32_t)ix.n_kept;
+    double hi = 1.0, lo = 1.0; bool any = false;   // bounds of idf_eff = (idf > 0 ? idf : 1) for the top-n pre-filter
+    for (double v : ix.idf) { const double e = v > 0.0 ? v : 1.0; if (!any) { hi = lo = e; any = true; } else { hi = std::max(hi, e); lo = std::min(lo, e); } }
+    d->di.idf_hi = hi; d->di.idf_lo = lo;
+    if (getenv("SRN_DEBUG")) fprintf(stderr, "[srn] idf_hi=%g idf_lo=%g n_items=%zu\n", hi, lo, (size_t)ix.n_items);
+    if (!ok) { device_release(d); return nullptr; }
+    return d;
+}
+
+static void ws_free(Workspace* w) {
+    if (!w) return;
+    if (w->retry_list) hipFree(w->retry_list);
+    if (w->retry_cnt) hipFree(w->retry_cnt);
+    if (w->gscratch) hipFree(w->gscratch);
+    if (w->spill) hipFree(w->spill);
+    if (w->prep) hipFree(w->prep);
+    if (w->stage) hipFree(w->stage);
+    if (w->h_retry) hipHostFree(w->h_retry);
+    for (auto& t : w->ev) for (auto& e : t) if (e) hipEventDestroy(e);
+    if (w->stream) hipStreamDestroy(w->stream);
+    delete w;
+}
+
+void device_release(DeviceState* d) {
+    if (!d) return;
+    hipSetDevice(d->device);
+    for (Workspace* w : d->all_ws) ws_free(w);
+    for (void* p : d->allocs) hipFree(p);
+    delete d;
+}
+
+int device_update_attr(DeviceState* d, const FlatIndex& ix) {
+    HIP_TRY(hipSetDevice(d->device));
+    std::vector<ItemMeta> meta(ix.n_items);
+    for (size_t i = 0; i < ix.n_items; ++i) meta[i] = ItemMeta{ix.idf[i], ix.id_rank[i], ix.attr[i]};
+    HIP_TRY(hipMemcpy(d->d_meta, meta.data(), meta.size() * sizeof(ItemMeta), hipMemcpyHostToDevice));
+    return SRN_OK;
+}
+uint64_t device_bytes(const DeviceState* d) { return d ? d->bytes : 0; }
+int device_count() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
+
+// Host-pointer calls borrow a workspace for the duration of the (synchronous) call.  Device-pointer
+// calls return while their work is still in flight, so their scratch stays bound to the user's stream
+// (stream order then serialises its reuse).
+static Workspace* ws_acquire(DeviceState* d, bool bind_to_stream, void* user_stream) {
+    std::lock_guard<std::mutex> lk(d->mu);
+    if (bind_to_stream) for (auto& sw : d->stream_ws) if (sw.first == user_stream) return sw.second;
+    if (!bind_to_stream && !d->free_ws.empty()) { Workspace* w = d->free_ws.back(); d->free_ws.pop_back(); return w; }
+    Workspace* w = new Workspace();
+    if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { delete w; return nullptr; }
+    for (auto& t : w->ev) for (auto& e : t) if (hipEventCreate(&e) != hipSuccess) { ws_free(w); return nullptr; }
+    if (hipMalloc((void**)&w->retry_cnt, 16) != hipSuccess || hipHostMalloc((void**)&w->h_retry, 16) != hipSuccess) { ws_free(w); return nullptr; }
+    d->all_ws.push_back(w);
+    if (bind_to_stream) d->stream_ws.emplace_back(user_stream, w);
+    return w;
+}
+static void ws_release(DeviceState* d, Workspace* w, bool bound) {
+    std::lock_guard<std::mutex> lk(d->mu);
+    if (!bound) d->free_ws.push_back(w);
+    d->last_ws = w;
+}
+
+static int ensure(char** p, size_t* have, size_t need) {
+    if (*have >= need) return SRN_OK;
+    if (*p) HIP_TRY(hipFree(*p));
+    *p = nullptr; *have = 0;
+    need = need + need / 4 + 256;
+    HIP_TRY(hipMalloc((void**)p, need));
+    *have = need; return SRN_OK;
+}
+
+static inline uint32_t round_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
+static inline int bits_host(uint64_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
+
+
+static inline uint32_t floor_pow2(uint64_t v) { uint32_t p2 = 1; while ((uint64_t)p2 * 2 <= v) p2 <<= 1; return p2; }
+static inline uint64_t ceil_pow2(uint64_t v) { uint64_t p2 = 1; while (p2 < v) p2 <<= 1; return p2; }
+static inline bool is_prime(uint32_t n) { if (n < 2) return false; for (uint32_t d = 2; (uint64_t)d * d <= n; ++d) if (n % d == 0) return false; return true; }
+static inline uint32_t prime_at_most(uint32_t n) { while (n > 2 && !is_prime(n)) --n; return std::max<uint32_t>(n, 2); }
+static inline uint32_t prime_at_least(uint64_t n) { uint32_t v = (uint32_t)std::min<uint64_t>(n, 0x3FFFFFFFull); while (!is_prime(v)) ++v; return v; }
+
+struct Geometry {
+    KernelCfg c{}; bool slot64 = false, masks = false; uint32_t slot_bytes = 4; size_t lds = 0;
+    uint64_t need_sess = 0, need_item = 0; bool sess_may_overflow = false, item_may_overflow = false;
+};
+// LDS layout + table sizes for one launch (all blocks alike).  min_region_b: extra room the caller needs in region B.
+static int make_geometry(const DeviceState* d, const FlatIndex& ix, const LaunchParams& p, uint32_t min_region_b, Geometry& g) {
+    const uint64_t Lmax = p.max_len;
+    // position-set slots (no first-match pass over the rows) need <= 8 evolving items and lists complete above x_lo
+    g.masks = Lmax <= 8 && p.m <= ix.m_index && !getenv("SRN_NO_MASKS");
+    const int num_bits = g.masks ? (int)Lmax : std::max(1, bits_host(Lmax * (Lmax + 1) / 2));
+    const int rank_bits = std::max(1, bits_host(ix.n_kept ? ix.n_kept - 1 : 0));
+    g.slot64 = rank_bits + num_bits > 32 || ix.n_kept >= 0xFFFFFFF0ull;
+    g.slot_bytes = g.slot64 ? 8 : 4;
+    const uint32_t slot_bytes = g.slot_bytes;
+    // what the query set could need at most
+    const uint64_t m_eff = std::min<uint64_t>(p.m, ix.m_index);
+    g.need_sess = std::max<uint64_t>(1, std::min<uint64_t>(Lmax * m_eff, ix.n_kept));
+    g.need_item = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)p.k * std::max<uint64_t>(1, ix.max_row_len), ix.n_items));
+    KernelCfg& c = g.c;
+    c.num_bits = (uint32_t)num_bits;
+    c.q_cap = round_up((uint32_t)Lmax + 1, 4);
+    c.off_q = MISC_WORDS * 4 + 1024;
+    c.off_wave = round_up(c.off_q + c.q_cap * 24 + (c.q_cap + 4) * 4, 16);
+    c.off_b = c.off_wave;   // (no per-wave scratch any more)
+    const uint32_t region_b = round_up(std::max<uint32_t>(std::max<uint32_t>(p.k * slot_bytes, CAND_CAP * 12), min_region_b), 16);
+    c.off_a = c.off_b + region_b;
+    const uint32_t lds_max = (uint32_t)std::min(d->lds_per_block_max, 160 * 1024);
+    uint32_t budget = 80 * 1024;                          // two 512-thread blocks per CU
+    if (c.off_a + 32 * 1024 > budget) budget = lds_max;   // long sessions / large k: one block per CU
+    if (c.off_a + 8 * 1024 > budget) return fail(SRN_ERANGE, "k / session length too large for the LDS layout");
+    const uint32_t a_max = budget - c.off_a;
+    c.sess_slots = std::min<uint32_t>(floor_pow2(a_max / slot_bytes), (uint32_t)std::min<uint64_t>(1u << 30, ceil_pow2(g.need_sess * 2)));
+    c.sess_slots = std::max<uint32_t>(c.sess_slots, 256);
+    // item side of region A: direct-mapped accumulators for the most popular idx, the rest a hash of 4-slot buckets.
+    // A direct-mapped word packs (touch count, signed weight sum); if those do not fit 32 bits the hot part is disabled.
+    const uint64_t w_max = (uint64_t)p.k * 9 * (Lmax * (Lmax + 1) / 2) + 1;
+    const int sbits = std::max(2, bits_host(w_max) + 1), cbits = bits_host(p.k);
+    uint32_t hot = sbits + cbits <= 32 ? 2048u : 0u;
+    if (const char* e = getenv("SRN_HOT_SLOTS")) hot = sbits + cbits <= 32 ? (uint32_t)atoi(e) : 0u;   // test knob
+    hot = std::min<uint32_t>(std::min<uint32_t>(hot, a_max / 8), round_up((uint32_t)std::min<uint64_t>(ix.n_items, 1u << 20), 4)) / 4 * 4;
+    c.hot_slots = hot; c.sum_bits = (uint32_t)sbits;
+    // sketch: upper-bound words for all other items (needs the direct-mapped part: its top n give the threshold)
+    uint32_t sk = hot ? 8192u : 0u;
+    if (const char* e = getenv("SRN_SKETCH_SLOTS")) sk = hot ? floor_pow2((uint64_t)std::max(0, atoi(e))) * (atoi(e) > 0) : 0u;   // test knob
+    while (sk && (uint64_t)sk * 4 * 8 > (uint64_t)(a_max - hot * 4) * 5) sk >>= 1;   // leave >= 3/8 of the room to the exact table
+    c.sketch_slots = sk; c.sketch_shift = sk ? 32u - (uint32_t)(bits_host(sk) - 1) : 31u;
+    const uint64_t want_buckets = std::max<uint64_t>(61, g.need_item / 2 + 8);          // load <= 0.5 at the worst case
+    c.item_buckets = prime_at_most((uint32_t)std::min<uint64_t>((a_max - hot * 4 - sk * 4) / 32, want_buckets));
+    c.item_slots = c.item_buckets * 4;
+    const uint32_t region_a = std::max<uint32_t>(hot * 4 + sk * 4 + c.item_slots * 8, c.sess_slots * slot_bytes);
+    c.region_a_bytes = region_a;
+    c.no_merge = getenv("SRN_NO_MERGE") ? 1u : 0u;
+    g.lds = (size_t)c.off_a + region_a;
+    // tables at least twice the worst case cannot exhaust the probe budget: no retry machinery needed
+    g.sess_may_overflow = (uint64_t)c.sess_slots < g.need_sess * 2; g.item_may_overflow = (uint64_t)c.item_slots < g.need_item * 2;
+    return SRN_OK;
+}
+
+int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in, bool on_device, void* user_stream,
+                   const uint64_t* h_items, const uint32_t* h_qoff, uint64_t* h_ids, double* h_scores, uint32_t* h_counts,
+                   uint32_t* h_stats, uint32_t* h_nb_rank, uint32_t* h_nb_num, uint32_t* h_nb_cnt) {
+    HIP_TRY(hipSetDevice(d->device));
+    LaunchParams p = p_in;
+    if (p.nq == 0) return SRN_OK;
+    p.phase_cycles = d->phase_on ? d->d_phase : nullptr;
+    Workspace* w = ws_acquire(d, on_device, user_stream);
+    if (!w) return fail(SRN_EHIP, "cannot create HIP stream / events");
+    struct Rel { DeviceState* d; Workspace* w; bool b; ~Rel() { ws_release(d, w, b); } } rel{d, w, on_device};
+    hipStream_t st = on_device ? (hipStream_t)user_stream : w->stream;
+
+    // ---- geometry ----------------------------------------------------------------------
+    Geometry geo; { int rc = make_geometry(d, ix, p, 0, geo); if (rc) return rc; }
+    const KernelCfg& c = geo.c; const bool slot64 = geo.slot64; const uint32_t slot_bytes = geo.slot_bytes; const size_t lds = geo.lds;
+    const uint64_t need_sess = geo.need_sess, need_item = geo.need_item;
+    const bool may_overflow = geo.sess_may_overflow || geo.item_may_overflow;
+
+    // ---- buffers -----------------------------------------------------------------------
+    const size_t n_out = (size_t)p.nq * p.how_many;
+    size_t nitems = 0;
+    if (!on_device) {
+        nitems = h_qoff[p.nq];
+        size_t off = 0; auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+        const size_t o_items = take(nitems * 8), o_qoff = take(((size_t)p.nq + 1) * 4), o_ids = take(n_out * 8), o_sc = take(n_out * 8),
+                     o_cnt = take((size_t)p.nq * 4), o_st = take(h_stats ? (size_t)p.nq * 32 : 0),
+                     o_nr = take(h_nb_rank ? (size_t)p.nq * p.k * 4 : 0), o_nn = take(h_nb_rank ? (size_t)p.nq * p.k * 4 : 0),
+                     o_nc = take(h_nb_rank ? (size_t)p.nq * 4 : 0);
+        int rc = ensure(&w->stage, &w->stage_bytes, off); if (rc) return rc;
+        char* s = w->stage;
+        p.items_flat = (const uint64_t*)(s + o_items); p.q_off = (const uint32_t*)(s + o_qoff);
+        p.out_ids = (uint64_t*)(s + o_ids); p.out_scores = (double*)(s + o_sc); p.out_counts = (uint32_t*)(s + o_cnt);
+        p.stats = h_stats ? (uint32_t*)(s + o_st) : nullptr;
+        p.nb_rank = h_nb_rank ? (uint32_t*)(s + o_nr) : nullptr; p.nb_num = h_nb_rank ? (uint32_t*)(s + o_nn) : nullptr;
+        p.nb_cnt = h_nb_rank ? (uint32_t*)(s + o_nc) : nullptr;
+        HIP_TRY(hipMemsetAsync(p.out_ids, 0, n_out * 8, st));      // unused tail of each row reads as 0
+        HIP_TRY(hipMemsetAsync(p.out_scores, 0, n_out * 8, st));
+        HIP_TRY(hipMemcpyAsync((void*)p.items_flat, h_items, nitems * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync((void*)p.q_off, h_qoff, ((size_t)p.nq + 1) * 4, hipMemcpyHostToDevice, st));
+    }
+    uint64_t g_stride = 0; int retry_blocks = 0;
+    KernelCfg cg = c;
+    if (may_overflow) {
+        if (w->retry_cap < p.nq) { if (w->retry_list) HIP_TRY(hipFree(w->retry_list)); w->retry_list = nullptr; w->retry_cap = 0;
+            HIP_TRY(hipMalloc((void**)&w->retry_list, (size_t)p.nq * 4 + 64)); w->retry_cap = p.nq; }
+        cg.sess_slots = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(256, ceil_pow2(need_sess * 2)));
+        cg.item_buckets = prime_at_least(need_item / 2 + 64); cg.item_slots = cg.item_buckets * 4;
+        g_stride = std::max<uint64_t>((uint64_t)cg.sess_slots * slot_bytes, (uint64_t)cg.hot_slots * 4 + (uint64_t)cg.sketch_slots * 4 + (uint64_t)cg.item_slots * 8);
+        g_stride = (g_stride + 255) / 256 * 256;
+        retry_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)d->n_cu, (2ull << 30) / g_stride));
+        int rc = ensure(&w->gscratch, &w->gscratch_bytes, g_stride * retry_blocks); if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(w->retry_cnt, 0, 4, st));
+    }
+
+    // ---- launches ----------------------------------------------------------------------
+    const uint32_t blocks_per_cu = std::max<uint32_t>(1, (160 * 1024) / (uint32_t)lds);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * std::min<uint32_t>(blocks_per_cu, 2048 / kBlock) * 4);
+    // per-block global copy of the neighbour list (walk B reads it after phase 4a has reused the LDS)
+    { int rc = ensure(&w->spill, &w->spill_bytes, (size_t)std::max<uint32_t>(grid, (uint32_t)retry_blocks) * p.k * slot_bytes); if (rc) return rc; }
+    char* spill = w->spill;
+    const uint32_t prep_stride = (uint32_t)(sizeof(PrepHead) + (size_t)p.max_len * sizeof(PrepItem));
+    { int rc = ensure(&w->prep, &w->prep_bytes, (size_t)p.nq * prep_stride); if (rc) return rc; }
+    hipEvent_t* ev = w->ev[w->calls % Workspace::RING];
+    HIP_TRY(hipEventRecord(ev[0], st));
+    HIP_TRY(launch_prep(st, d->di, p.items_flat, p.q_off, p.nq, p.m, p.max_len, w->prep, prep_stride));
+    p.prep = w->prep; p.prep_stride = prep_stride;
+    HIP_TRY(hipEventRecord(ev[3], st));
+    HIP_TRY(launch_predict(geo.masks, slot64, false, 0, dim3(grid), lds, st, d->di, p, c, nullptr, nullptr, w->retry_list, w->retry_cnt, nullptr, 0, spill, ShardIO{}));
+    HIP_TRY(hipEventRecord(ev[1], st));
+    if (may_overflow) {
+        const size_t lds_g = c.off_a;
+        HIP_TRY(launch_predict(geo.masks, slot64, true, 0, dim3(retry_blocks), lds_g, st, d->di, p, cg, w->retry_list, w->retry_cnt, nullptr, nullptr,
+                               w->gscratch, g_stride, spill, ShardIO{}));
+        HIP_TRY(hipMemcpyAsync(w->h_retry, w->retry_cnt, 4, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipEventRecord(ev[2], st));
+    ++w->calls; w->last_retry = may_overflow ? 1 : 0;
+
+    if (!on_device) {
+        HIP_TRY(hipMemcpyAsync(h_ids, p.out_ids, n_out * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h_scores, p.out_scores, n_out * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h_counts, p.out_counts, (size_t)p.nq * 4, hipMemcpyDeviceToHost, st));
+        if (h_stats) HIP_TRY(hipMemcpyAsync(h_stats, p.stats, (size_t)p.nq * 32, hipMemcpyDeviceToHost, st));
+        if (h_nb_rank) {
+            HIP_TRY(hipMemcpyAsync(h_nb_rank, p.nb_rank, (size_t)p.nq * p.k * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(h_nb_num, p.nb_num, (size_t)p.nq * p.k * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(h_nb_cnt, p.nb_cnt, (size_t)p.nq * 4, hipMemcpyDeviceToHost, st));
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return SRN_OK;
+}
+
+// One stage of the item-sharded pipeline (device buffers, asynchronous on `stream`); see ShardIO.
+int device_shard_stage(DeviceState* d, const FlatIndex& ix, int stage, const LaunchParams& p_in, const ShardIO& sh, void* stream) {
+    HIP_TRY(hipSetDevice(d->device));
+    LaunchParams p = p_in;
+    if (p.nq == 0) return SRN_OK;
+    p.phase_cycles = nullptr;
+    Geometry geo;
+    const uint32_t sort_room = stage == 2 ? (uint32_t)ceil_pow2(std::max<uint32_t>(p.k, 2)) * 8 : 0;   // stage B sorts the neighbour list in region B
+    int rc = make_geometry(d, ix, p, sort_room, geo); if (rc) return rc;
+    const uint32_t blocks_per_cu = std::max<uint32_t>(1, (160 * 1024) / (uint32_t)geo.lds);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * std::min<uint32_t>(blocks_per_cu, 2048 / kBlock) * 4);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e;
+    if (stage < 1 || stage > 3) return fail(SRN_EINVAL, "bad stage");
+    e = launch_predict(geo.masks, geo.slot64, false, stage, dim3(grid), geo.lds, st, d->di, p, geo.c, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, sh);
+    if (e != hipSuccess) return fail(SRN_EHIP, std::string("shard stage launch: ") + hipGetErrorString(e));
+    return SRN_OK;
+}
+int device_slot_bytes(DeviceState* d, const FlatIndex& ix, uint32_t max_len) {   // element size of the packed candidate / neighbour buffers
+    LaunchParams p{}; p.max_len = max_len; p.k = 1; p.m = 1; Geometry g;
+    return make_geometry(d, ix, p, 0, g) == SRN_OK ? (int)g.slot_bytes : -1;
+}
+
+int device_last_kernel_ms(DeviceState* d, double* ms_main, double* ms_retry, uint32_t* retried) {
+    HIP_TRY(hipSetDevice(d->device));
+    Workspace* w;
+    { std::lock_guard<std::mutex> lk(d->mu); w = d->last_ws; }
+    if (!w || !w->calls) return fail(SRN_EINVAL, "no timed predict call yet");
+    hipEvent_t* ev = w->ev[(w->calls - 1) % Workspace::RING];
+    HIP_TRY(hipEventSynchronize(ev[2]));
+    float a = 0, b = 0;
+    HIP_TRY(hipEventElapsedTime(&a, ev[3], ev[1]));   // the predict kernel alone (the prep kernel runs between ev[0] and ev[3])
+    HIP_TRY(hipEventElapsedTime(&b, ev[1], ev[2]));
+    if (ms_main) *ms_main = a;
+    if (ms_retry) *ms_retry = b;
+    if (retried) *retried = w->last_retry ? *w->h_retry : 0;
+    return SRN_OK;
+}
+
+int device_phase_cycles(DeviceState* d, int enable, unsigned long long* out16) {
+    HIP_TRY(hipSetDevice(d->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (!d->d_phase) { HIP_TRY(hipMalloc((void**)&d->d_phase, 16 * 8)); d->allocs.push_back(d->d_phase); HIP_TRY(hipMemset(d->d_phase, 0, 16 * 8)); }
+    if (out16) HIP_TRY(hipMemcpy(out16, d->d_phase, 16 * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(d->d_phase, 0, 16 * 8));
+    d->phase_on = enable != 0;
+    return SRN_OK;
+}
+
+// durations of the most recent min(max_n, calls, RING) predict launches of the last-used workspace, oldest first
+int device_kernel_times(DeviceState* d, uint32_t max_n, double* ms_main, double* ms_retry, uint32_t* out_n) {
+    HIP_TRY(hipSetDevice(d->device));
+    Workspace* w;
+    { std::lock_guard<std::mutex> lk(d->mu); w = d->last_ws; }
+    *out_n = 0;
+    if (!w || !w->calls) return SRN_OK;
+    const uint64_t n = std::min<uint64_t>(std::min<uint64_t>(max_n, w->calls), Workspace::RING);
+    HIP_TRY(hipEventSynchronize(w->ev[(w->calls - 1) % Workspace::RING][2]));
+    for (uint64_t i = 0; i < n; ++i) {
+        hipEvent_t* ev = w->ev[(w->calls - n + i) % Workspace::RING];
+        float a = 0, b = 0;
+        HIP_TRY(hipEventElapsedTime(&a, ev[3], ev[1]));
+        HIP_TRY(hipEventElapsedTime(&b, ev[1], ev[2]));
+        if (ms_main) ms_main[i] = a;
+        if (ms_retry) ms_retry[i] = b;
+    }
+    *out_n = (uint32_t)n;
+    return SRN_OK;
+}
+
+}  // namespace srn
