@@ -1,25 +1,27 @@
 // =====================================================================================
-// VMIS-kNN predict_next on gfx950 (MI355X).  One workgroup per evolving session; the whole of
-// find_neighbors (src/vmisknn/vmis_index.rs:325-415) and predict (src/vmisknn/mod.rs:118-215)
-// runs inside one kernel with all per-query state in LDS:
+// VMIS-kNN predict_next on gfx950 (MI355X): the kernels.  find_neighbors (src/vmisknn/vmis_index.rs:325-415) and
+// predict (src/vmisknn/mod.rs:118-215) for a batch of evolving sessions, one workgroup (8 waves) per session with all
+// per-query state in LDS (DESIGN.md section 4 has the full story and the measurements):
 //
-//   phase 0  translate the evolving items (u64 -> dense idx), de-duplicate, position weights
-//   phase 1  walk the <= U posting lists (coalesced, rank-descending), insert-or-add
-//            (rank, weight) into an LDS open-addressing table  -> integer similarity numerators
-//   phase 2  m-cut: radix-select the m-th largest recency rank;  k-cut: radix-select the k-th
-//            largest (numerator, rank) composite;  compact the neighbours
-//   phase 3  walk the neighbours' rows (sub-wave groups of lanes per row), first-match position
-//            against the FULL row, insert-or-add w10*num into the LDS item table
-//   phase 4  score = idf_eff * acc / (10 U) in f64, business rules, filtered top-n with an
-//            in-LDS bitonic sort on (score desc, item idx asc)
+//   vmis_prep_kernel      one THREAD per session: public id -> dense idx, posting-list bounds, first / m-th rank
+//   vmis_predict_kernel
+//     phase 0   the session's prep record -> per-list arrays
+//     phase 1-2 candidate sessions.  Merge mode (default): the posting lists are sorted by recency, so they are staged
+//               in LDS and merged (merge path); the first m distinct sessions are the candidates, the k-cut counts the
+//               few numerator classes.  Hash mode (what does not fit): packed session hash table, one scan, histograms
+//     phase 3a  walk A: one neighbour row (64-byte slot) per lane; popular items -> exact direct-mapped accumulators,
+//               everything else -> a sketch of upper bounds.  One fire-and-forget LDS add per row item
+//     phase 4a  exact top-n of the direct-mapped items -> threshold score
+//     phase 3b  walk B: only items whose sketch word can still beat the threshold reach the exact hash table
+//     phase 4b  f64 score = idf_eff * acc / (10 U), business rules, top-n by (score desc, public id asc)
+//   rows_to_slots_kernel  CSR rows -> 64-byte row slots when an index is attached to a device
 //
-// Everything up to the final f64 multiply/divide is integer arithmetic, so (neighbours,
-// numerators, accumulators) are bit-identical to the canonical CPU oracle by construction.
-// No MFMA: this is sparse gather/scatter, bounded by HBM/L2 traffic and LDS atomics.
+// Everything up to the final f64 multiply/divide is integer arithmetic, so (neighbours, numerators, accumulators) are
+// bit-identical to the canonical CPU oracle by construction.  No MFMA: this is sparse gather/scatter.
 //
-// Queries whose candidate or item sets do not fit the LDS tables are queued on a device-side
-// retry list and served by the same kernel instantiated with its tables in a global scratch
-// arena (GLOBAL_TABLES = true) -- still on the GPU, never on the CPU.
+// Queries whose candidate or item sets do not fit the LDS tables are queued on a device-side retry list and served by
+// the same kernel instantiated with its tables in a global scratch arena (GLOBAL_TABLES = true) -- still on the GPU,
+// never on the CPU.  STAGE 1..3 are the cuts of the item-sharded pipeline (stages A..C).
 // =====================================================================================
 #include <hip/hip_runtime.h>
 
