@@ -442,12 +442,22 @@ __global__ __launch_bounds__(256) void vmis_prep_kernel(DeviceIndex ix, const ui
     do { if (p.phase_cycles && tid == 0) { const long long t_ = clock64(); atomicAdd(&p.phase_cycles[ph], (unsigned long long)(t_ - t_prev)); t_prev = t_; } } while (0)
 
 template <int BLOCK, typename SlotT, bool GLOBAL_TABLES, int STAGE = 0, bool MASKS = false>
-__global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(DeviceIndex ix, LaunchParams p, KernelCfg c,
+__global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(DeviceIndex ix_arg, LaunchParams p_arg, KernelCfg c_arg,
                                                              const uint32_t* __restrict__ qlist, const uint32_t* __restrict__ qlist_n,
                                                              uint32_t* retry_list, uint32_t* retry_cnt,
                                                              char* gscratch, unsigned long long gscratch_stride, char* nb_spill_base,
                                                              ShardIO sh) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // The three parameter blocks (the first three arguments, packed in order with their natural alignment) are read where they
+    // are needed, straight from the kernel-argument segment -- constant memory, scalar loads.  Used as by-value arguments the
+    // compiler keeps all ~60 words live in SGPRs for the whole kernel and spills them to VGPR lanes (-39 % spill moves this way).
+    typedef const __attribute__((address_space(4))) char* KArg;
+    const KArg ka = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr size_t OFF_P = (sizeof(DeviceIndex) + alignof(LaunchParams) - 1) / alignof(LaunchParams) * alignof(LaunchParams);
+    constexpr size_t OFF_C = (OFF_P + sizeof(LaunchParams) + alignof(KernelCfg) - 1) / alignof(KernelCfg) * alignof(KernelCfg);
+    const __attribute__((address_space(4))) DeviceIndex& ix = *(const __attribute__((address_space(4))) DeviceIndex*)ka;
+    const __attribute__((address_space(4))) LaunchParams& p = *(const __attribute__((address_space(4))) LaunchParams*)(ka + OFF_P);
+    const __attribute__((address_space(4))) KernelCfg& c = *(const __attribute__((address_space(4))) KernelCfg*)(ka + OFF_C);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NWAVES = BLOCK / 64;
     constexpr SlotT SEMPTY = SlotTraits<SlotT>::EMPTY;
