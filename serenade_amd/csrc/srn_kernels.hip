@@ -442,13 +442,9 @@ __global__ __launch_bounds__(256) void vmis_prep_kernel(DeviceIndex ix, const ui
     do { if (p.phase_cycles && tid == 0) { const long long t_ = clock64(); atomicAdd(&p.phase_cycles[ph], (unsigned long long)(t_ - t_prev)); t_prev = t_; } } while (0)
 
 template <int BLOCK, typename SlotT, bool GLOBAL_TABLES, int STAGE = 0, bool MASKS = false>
-__global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(DeviceIndex ix_arg, LaunchParams p_arg, KernelCfg c_arg,
-                                                             const uint32_t* __restrict__ qlist, const uint32_t* __restrict__ qlist_n,
-                                                             uint32_t* retry_list, uint32_t* retry_cnt,
-                                                             char* gscratch, unsigned long long gscratch_stride, char* nb_spill_base,
-                                                             ShardIO sh) {
+__global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(DeviceIndex ix_arg, LaunchParams p_arg, KernelCfg c_arg, LaunchAux aux_arg, ShardIO sh_arg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // The three parameter blocks (the first three arguments, packed in order with their natural alignment) are read where they
+    // The parameter blocks (the arguments, packed in order with their natural alignment) are read where they
     // are needed, straight from the kernel-argument segment -- constant memory, scalar loads.  Used as by-value arguments the
     // compiler keeps all ~60 words live in SGPRs for the whole kernel and spills them to VGPR lanes (-39 % spill moves this way).
     typedef const __attribute__((address_space(4))) char* KArg;
@@ -458,6 +454,10 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
     const __attribute__((address_space(4))) DeviceIndex& ix = *(const __attribute__((address_space(4))) DeviceIndex*)ka;
     const __attribute__((address_space(4))) LaunchParams& p = *(const __attribute__((address_space(4))) LaunchParams*)(ka + OFF_P);
     const __attribute__((address_space(4))) KernelCfg& c = *(const __attribute__((address_space(4))) KernelCfg*)(ka + OFF_C);
+    constexpr size_t OFF_X = (OFF_C + sizeof(KernelCfg) + alignof(LaunchAux) - 1) / alignof(LaunchAux) * alignof(LaunchAux);
+    constexpr size_t OFF_S = (OFF_X + sizeof(LaunchAux) + alignof(ShardIO) - 1) / alignof(ShardIO) * alignof(ShardIO);
+    const __attribute__((address_space(4))) LaunchAux& aux = *(const __attribute__((address_space(4))) LaunchAux*)(ka + OFF_X);
+    const __attribute__((address_space(4))) ShardIO& sh = *(const __attribute__((address_space(4))) ShardIO*)(ka + OFF_S);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NWAVES = BLOCK / 64;
     constexpr SlotT SEMPTY = SlotTraits<SlotT>::EMPTY;
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
     uint32_t* l_pre = l_len + c.q_cap;                                        // q_cap+4 exclusive prefix of l_len
     char* region_b = smem + c.off_b;
     uint32_t* hist = (uint32_t*)region_b;                                     // 2048-bin select histogram (phase 2 only)
-    char* region_a = GLOBAL_TABLES ? (gscratch + (size_t)blockIdx.x * gscratch_stride) : (smem + c.off_a);
+    char* region_a = GLOBAL_TABLES ? (aux.gscratch + (size_t)blockIdx.x * aux.gscratch_stride) : (smem + c.off_a);
 
     SlotT* stab = (SlotT*)region_a;                                           // phase 1-2
     uint32_t* hot = (uint32_t*)region_a;                                      // phase 3-4: direct-mapped accumulators (idx < hot_slots)
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
     uint32_t* ikeys = sketch + c.sketch_slots;                                //            exact hash table keys (buckets of 4), then accumulators
     int* iacc = (int*)(ikeys + c.item_slots);
     SlotT* nbl = (SlotT*)region_b;                                            // neighbours (phase 2-3)
-    SlotT* nb_spill = nb_spill_base ? (SlotT*)nb_spill_base + (size_t)blockIdx.x * p.k : nullptr;   // global copy: phase 4a reuses the LDS
+    SlotT* nb_spill = aux.nb_spill ? (SlotT*)aux.nb_spill + (size_t)blockIdx.x * p.k : nullptr;   // global copy: phase 4a reuses the LDS
     uint64_t* ckey = (uint64_t*)region_b;                                     // candidates (phase 4)
     uint32_t* cidx = (uint32_t*)(region_b + CAND_CAP * 8);
 
@@ -492,10 +492,10 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
     uint8_t* wlut = (uint8_t*)(smem + MISC_WORDS * 4);                        // 256 B: numerator of each position set
     auto num_of = [&](SlotT sl) -> uint32_t { return MASKS ? (uint32_t)wlut[(uint32_t)(sl & num_mask)] : (uint32_t)(sl & num_mask); };
     const uint32_t inb = c.item_buckets, H = c.hot_slots, SB = c.sum_bits, SK = c.sketch_slots, SKM = c.sketch_slots - 1u;
-    const uint32_t nq_eff = qlist ? *qlist_n : p.nq;
+    const uint32_t nq_eff = aux.qlist ? *aux.qlist_n : p.nq;
 
     for (uint32_t qi = blockIdx.x; qi < nq_eff; qi += gridDim.x) {
-        const uint32_t q = qlist ? qlist[qi] : qi;
+        const uint32_t q = aux.qlist ? aux.qlist[qi] : qi;
         const uint32_t qb = p.q_off[q];
         const uint32_t L = p.q_off[q + 1] - qb;
         if (L == 0 || L > p.max_len) {   // block-uniform
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
         if (misc[S_OVF]) {   // block-uniform: hand the query to the global-table pass
             if (STAGE != 0) { if (tid == 0) { if (STAGE == 1) sh.cand_cnt[q] = 0xFFFFFFFFu; else sh.nb_cnt[q] = 0xFFFFFFFFu; } }
             else if (GLOBAL_TABLES) { if (tid == 0) { p.out_counts[q] = 0xFFFFFFFFu; if (p.stats) p.stats[(size_t)q * 8 + 7] = 3; } }
-            else if (tid == 0) retry_list[atomicAdd(retry_cnt, 1u)] = q;
+            else if (tid == 0) aux.retry_list[atomicAdd(aux.retry_cnt, 1u)] = q;
             continue;
         }
         SRN_TICK(1);
@@ -1421,7 +1421,7 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
         }
         if (failed) {
             if (GLOBAL_TABLES || STAGE == 3) { if (tid == 0) { p.out_counts[q] = 0xFFFFFFFFu; if (p.stats) p.stats[(size_t)q * 8 + 7] = 3; } }
-            else if (tid == 0) retry_list[atomicAdd(retry_cnt, 1u)] = q;
+            else if (tid == 0) aux.retry_list[atomicAdd(aux.retry_cnt, 1u)] = q;
             continue;
         }
         const uint32_t n_res = min(misc[S_CCNT], n_out);
@@ -1453,7 +1453,7 @@ static hipError_t launch_variant(bool slot64, dim3 grid, size_t lds, hipStream_t
         auto kern = vmis_predict_kernel<BLOCK, SLOT, GLOBAL_TABLES, STAGE, MASKS>;                                                      \
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
         if (e != hipSuccess) return e;                                                                                    \
-        hipLaunchKernelGGL(kern, grid, dim3(BLOCK), lds, st, di, p, c, qlist, qn, retry_list, retry_cnt, gs, gstride, spill, sh); \
+        hipLaunchKernelGGL(kern, grid, dim3(BLOCK), lds, st, di, p, c, LaunchAux{qlist, qn, retry_list, retry_cnt, gs, gstride, spill}, sh); \
         return hipGetLastError();                                                                                         \
     } while (0)
     if (!slot64) SRN_LAUNCH(uint32_t);
