@@ -1196,13 +1196,16 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                 } };
             // The word index needs no select: min(idx, H + idx mod SK) is idx itself below H and a word of the sketch otherwise
             // (idx in [H, H + SK) keeps its own position).  MASKS: weights are positive, plain sums everywhere, one value for both kinds
+            // Empty element slots are not masked out (that costs an exec save / restore and two taken branches per element): they
+            // add into a per-lane scratch word instead -- the last 64 words of region A, which nobody reads before they are cleared.
+            uint32_t* const idle_word = wb + (wwords - 64) + lane;
             auto add_items_pos = [&](const auto& it, uint32_t wv) {
                 constexpr int N = sizeof(it) / sizeof(it[0]);
 #pragma unroll
-                for (int x = 0; x < N; ++x) if (it[x] != EMPTY32) atomicAdd(&hot[min(it[x], H + (it[x] & SKM))], wv); };
+                for (int x = 0; x < N; ++x) { uint32_t* at = &hot[min(it[x], H + (it[x] & SKM))]; atomicAdd(it[x] != EMPTY32 ? at : idle_word, wv); } };
             uint32_t isum = 0;
             if constexpr (MASKS && STAGE == 0) {
-                if (SK) isum = walk_rounds(nb_lds, nbl, [&](const auto& it, int w) { add_items_pos(it, (uint32_t)w); });
+                if (SK && !GLOBAL_TABLES) isum = walk_rounds(nb_lds, nbl, [&](const auto& it, int w) { add_items_pos(it, (uint32_t)w); });   // (region A in LDS)
                 else isum = walk_rounds(nb_lds, nbl, [&](const auto& it, int w) { add_items(it, (uint32_t)w, 0u); });
             } else {
                 isum = walk_rows(nb_lds, [&](uint32_t j, uint32_t num, auto&& for_row) {
