@@ -1385,12 +1385,14 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
                 uint32_t fresh = 0; bool ovf = false;
                 auto insert_items = [&](const auto& it, int w) {
                     constexpr int N = sizeof(it) / sizeof(it[0]);
-                    bool go[N];
+                    bool go[N]; bool any = false;
 #pragma unroll
-                    for (int x = 0; x < N; ++x) {
-                        go[x] = it[x] != EMPTY32 && it[x] >= H && (parts == 1 || hash_part(it[x], parts) == part);
-                        if (filt) { const uint32_t ub = go[x] ? hot[min(it[x], H + (it[x] & SKM))] : 0u; go[x] = go[x] & (ub >= floor_b); }
+                    for (int x = 0; x < N; ++x) {   // (the sketch word is read for every slot, empty or not: no exec juggling; the index is always in range)
+                        const uint32_t ub = filt ? hot[min(it[x], H + (it[x] & SKM))] : 0xFFFFFFFFu;
+                        go[x] = (it[x] != EMPTY32) & (it[x] >= H) & (ub >= floor_b) & (parts == 1 || hash_part(it[x], parts) == part);
+                        any |= go[x];
                     }
+                    if (__ballot(any) == 0ull) return;   // the usual case: nothing of these 8 slots can reach the top n
 #pragma unroll
                     for (int x = 0; x < N; ++x) {
                         if (go[x]) { const int res = item_insert(ikeys, iacc, inb, it[x], w); if (res < 0) ovf = true; else fresh += (uint32_t)res; }
