@@ -650,14 +650,18 @@ __global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(
 #pragma unroll
                 for (int pr = 0; pr < 4; ++pr) {
                     if ((uint32_t)pr < np && d0[pr] < d1[pr]) {
-                        const uint32_t* A = in + sa[pr]; const uint32_t* B = in + sb[pr]; uint32_t* Cc = out + sa[pr];
                         const uint32_t a = la[pr], b = lb[pr];
+                        uint32_t* Cc = out + sa[pr];
                         uint32_t i = lo[pr], j = d0[pr] - lo[pr];
-                        uint32_t va = i < a ? A[i] : 0u, vb = j < b ? B[j] : 0u;   // (a staged slot is never 0: its payload is >= 1)
-                        for (uint32_t o = d0[pr]; o < d1[pr]; ++o) {
+                        uint32_t va = i < a ? in[sa[pr] + i] : 0u, vb = j < b ? in[sb[pr] + j] : 0u;   // (a staged slot is never 0: its payload is >= 1)
+                        for (uint32_t o = d0[pr]; o < d1[pr]; ++o) {   // branch-free step: one LDS read, one LDS write
                             const bool ta = va > vb;
                             Cc[o] = ta ? va : vb;
-                            if (ta) { ++i; va = i < a ? A[i] : 0u; } else { ++j; vb = j < b ? B[j] : 0u; }
+                            i += ta; j += !ta;
+                            const bool more = ta ? i < a : j < b;
+                            const uint32_t nxt = in[ta ? sa[pr] + i : sb[pr] + j];   // (past a run's end this reads a neighbour's entry or scratch: discarded)
+                            const uint32_t nv = more ? nxt : 0u;
+                            va = ta ? nv : va; vb = ta ? vb : nv;
                         }
                     }
                 }
