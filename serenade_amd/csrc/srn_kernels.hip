@@ -442,7 +442,10 @@ __global__ __launch_bounds__(256) void vmis_prep_kernel(DeviceIndex ix, const ui
     do { if (p.phase_cycles && tid == 0) { const long long t_ = clock64(); atomicAdd(&p.phase_cycles[ph], (unsigned long long)(t_ - t_prev)); t_prev = t_; } } while (0)
 
 template <int BLOCK, typename SlotT, bool GLOBAL_TABLES, int STAGE = 0, bool MASKS = false>
-__global__ __launch_bounds__(BLOCK, (2 * BLOCK) / 256) void vmis_predict_kernel(DeviceIndex ix_arg, LaunchParams p_arg, KernelCfg c_arg, LaunchAux aux_arg, ShardIO sh_arg) {
+#ifndef SRN_MIN_WAVES_PER_SIMD
+#define SRN_MIN_WAVES_PER_SIMD ((2 * BLOCK) / 256)   // 2 workgroups of 8 waves per CU: 4 waves per SIMD, <= 128 VGPRs
+#endif
+__global__ __launch_bounds__(BLOCK, SRN_MIN_WAVES_PER_SIMD) void vmis_predict_kernel(DeviceIndex ix_arg, LaunchParams p_arg, KernelCfg c_arg, LaunchAux aux_arg, ShardIO sh_arg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // The parameter blocks (the arguments, packed in order with their natural alignment) are read where they
     // are needed, straight from the kernel-argument segment -- constant memory, scalar loads.  Used as by-value arguments the

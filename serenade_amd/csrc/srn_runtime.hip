@@ -209,6 +209,7 @@ static int make_geometry(const DeviceState* d, const FlatIndex& ix, const Launch
     c.off_a = c.off_b + region_b;
     const uint32_t lds_max = (uint32_t)std::min(d->lds_per_block_max, 160 * 1024);
     uint32_t budget = 80 * 1024;                          // two 512-thread blocks per CU
+    if (const char* e = getenv("SRN_LDS_BUDGET_KB")) budget = (uint32_t)atoi(e) * 1024;   // experiment knob (occupancy studies)
     if (c.off_a + 32 * 1024 > budget) budget = lds_max;   // long sessions / large k: one block per CU
     if (c.off_a + 8 * 1024 > budget) return fail(SRN_ERANGE, "k / session length too large for the LDS layout");
     const uint32_t a_max = budget - c.off_a;
