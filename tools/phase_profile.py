@@ -1,7 +1,7 @@
 """Scratch experiment driver (GPU box): phase-cycle breakdown at a given config. Not part of the product."""
 import sys, time, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import serenade_amd as sa
 from serenade_amd import synth
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
