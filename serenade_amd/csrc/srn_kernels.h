@@ -40,7 +40,7 @@ struct PrepItem { uint32_t idx, len, pre, pad; unsigned long long base; };   // 
 // tables in a global-memory arena (stage 0 only)
 hipError_t launch_predict(bool masks, bool slot64, bool global_tables, int stage, dim3 grid, size_t lds, hipStream_t st, const DeviceIndex& di,
                           const LaunchParams& p, const KernelCfg& c, const uint32_t* qlist, const uint32_t* qn, uint32_t* retry_list,
-                          uint32_t* retry_cnt, char* gscratch, unsigned long long gscratch_stride, char* nb_spill, const ShardIO& sh);
+                          uint32_t* retry_cnt, char* gscratch, unsigned long long gscratch_stride, char* nb_spill, const ShardIO& sh, int wg_per_cu = 2);
 hipError_t launch_prep(hipStream_t st, const DeviceIndex& di, const uint64_t* items_flat, const uint32_t* q_off, uint32_t nq, uint32_t m,
                        uint32_t max_len, char* out, uint32_t stride);
 hipError_t launch_rows_to_slots(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base,

@@ -441,11 +441,10 @@ __global__ __launch_bounds__(256) void vmis_prep_kernel(DeviceIndex ix, const ui
 #define SRN_TICK(ph)                                                                                         \
     do { if (p.phase_cycles && tid == 0) { const long long t_ = clock64(); atomicAdd(&p.phase_cycles[ph], (unsigned long long)(t_ - t_prev)); t_prev = t_; } } while (0)
 
-template <int BLOCK, typename SlotT, bool GLOBAL_TABLES, int STAGE = 0, bool MASKS = false>
-#ifndef SRN_MIN_WAVES_PER_SIMD
-#define SRN_MIN_WAVES_PER_SIMD ((2 * BLOCK) / 256)   // 2 workgroups of 8 waves per CU: 4 waves per SIMD, <= 128 VGPRs
-#endif
-__global__ __launch_bounds__(BLOCK, SRN_MIN_WAVES_PER_SIMD) void vmis_predict_kernel(DeviceIndex ix_arg, LaunchParams p_arg, KernelCfg c_arg, LaunchAux aux_arg, ShardIO sh_arg) {
+// WG_PER_CU = workgroups the build is meant to co-reside with: 2 (4 waves per SIMD, <= 128 VGPRs) or 3 (6 waves, <= 80 VGPRs: more
+// latency hiding for the price of spills; used with the small LDS geometry when the queries are large, see device_predict)
+template <int BLOCK, typename SlotT, bool GLOBAL_TABLES, int STAGE = 0, bool MASKS = false, int WG_PER_CU = 2>
+__global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict_kernel(DeviceIndex ix_arg, LaunchParams p_arg, KernelCfg c_arg, LaunchAux aux_arg, ShardIO sh_arg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // The parameter blocks (the arguments, packed in order with their natural alignment) are read where they
     // are needed, straight from the kernel-argument segment -- constant memory, scalar loads.  Used as by-value arguments the
@@ -1455,14 +1454,14 @@ __global__ __launch_bounds__(BLOCK, SRN_MIN_WAVES_PER_SIMD) void vmis_predict_ke
 // =====================================================================================
 // launchers
 // =====================================================================================
-template <int BLOCK, bool GLOBAL_TABLES, int STAGE = 0, bool MASKS = false>
+template <int BLOCK, bool GLOBAL_TABLES, int STAGE = 0, bool MASKS = false, int WG_PER_CU = 2>
 static hipError_t launch_variant(bool slot64, dim3 grid, size_t lds, hipStream_t st, const DeviceIndex& di,
                                  const LaunchParams& p, const KernelCfg& c, const uint32_t* qlist, const uint32_t* qn,
                                  uint32_t* retry_list, uint32_t* retry_cnt, char* gs, unsigned long long gstride, char* spill,
                                  const ShardIO& sh = ShardIO{}) {
 #define SRN_LAUNCH(SLOT)                                                                                             \
     do {                                                                                                                  \
-        auto kern = vmis_predict_kernel<BLOCK, SLOT, GLOBAL_TABLES, STAGE, MASKS>;                                                      \
+        auto kern = vmis_predict_kernel<BLOCK, SLOT, GLOBAL_TABLES, STAGE, MASKS, WG_PER_CU>;                                           \
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
         if (e != hipSuccess) return e;                                                                                    \
         hipLaunchKernelGGL(kern, grid, dim3(BLOCK), lds, st, di, p, c, LaunchAux{qlist, qn, retry_list, retry_cnt, gs, gstride, spill}, sh); \
@@ -1475,7 +1474,12 @@ static hipError_t launch_variant(bool slot64, dim3 grid, size_t lds, hipStream_t
 
 hipError_t launch_predict(bool masks, bool slot64, bool global_tables, int stage, dim3 grid, size_t lds, hipStream_t st, const DeviceIndex& di,
                           const LaunchParams& p, const KernelCfg& c, const uint32_t* qlist, const uint32_t* qn, uint32_t* retry_list,
-                          uint32_t* retry_cnt, char* gscratch, unsigned long long gscratch_stride, char* nb_spill, const ShardIO& sh) {
+                          uint32_t* retry_cnt, char* gscratch, unsigned long long gscratch_stride, char* nb_spill, const ShardIO& sh, int wg_per_cu) {
+    if (wg_per_cu == 3) {   // the 80-VGPR build exists for the fused kernel with u32 slots and LDS tables only
+        if (global_tables || stage != 0 || slot64) return hipErrorInvalidValue;
+        return masks ? launch_variant<kBlock, false, 0, true, 3>(false, grid, lds, st, di, p, c, qlist, qn, retry_list, retry_cnt, gscratch, gscratch_stride, nb_spill, sh)
+                     : launch_variant<kBlock, false, 0, false, 3>(false, grid, lds, st, di, p, c, qlist, qn, retry_list, retry_cnt, gscratch, gscratch_stride, nb_spill, sh);
+    }
 #define SRN_V(G, S, M) launch_variant<kBlock, G, S, M>(slot64, grid, lds, st, di, p, c, qlist, qn, retry_list, retry_cnt, gscratch, gscratch_stride, nb_spill, sh)
     if (global_tables) return stage != 0 ? hipErrorInvalidValue : (masks ? SRN_V(true, 0, true) : SRN_V(true, 0, false));
     switch (stage) {

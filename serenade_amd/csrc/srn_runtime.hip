@@ -32,6 +32,7 @@ struct Workspace {
     char* gscratch = nullptr; size_t gscratch_bytes = 0;
     char* spill = nullptr; size_t spill_bytes = 0;   // per-block global copies of the neighbour lists
     char* prep = nullptr; size_t prep_bytes = 0;     // per-query records of the prep kernel
+    uint32_t* retry_list2 = nullptr; size_t retry_cap2 = 0; uint32_t* retry_cnt2 = nullptr;   // what the second LDS tier could not hold either
     // staging for host-pointer calls
     char* stage = nullptr; size_t stage_bytes = 0;
     uint32_t* h_retry = nullptr;   // pinned
@@ -116,6 +117,8 @@ static void ws_free(Workspace* w) {
     if (w->gscratch) hipFree(w->gscratch);
     if (w->spill) hipFree(w->spill);
     if (w->prep) hipFree(w->prep);
+    if (w->retry_list2) hipFree(w->retry_list2);
+    if (w->retry_cnt2) hipFree(w->retry_cnt2);
     if (w->stage) hipFree(w->stage);
     if (w->h_retry) hipHostFree(w->h_retry);
     for (auto& t : w->ev) for (auto& e : t) if (e) hipEventDestroy(e);
@@ -151,7 +154,7 @@ static Workspace* ws_acquire(DeviceState* d, bool bind_to_stream, void* user_str
     Workspace* w = new Workspace();
     if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { delete w; return nullptr; }
     for (auto& t : w->ev) for (auto& e : t) if (hipEventCreate(&e) != hipSuccess) { ws_free(w); return nullptr; }
-    if (hipMalloc((void**)&w->retry_cnt, 16) != hipSuccess || hipHostMalloc((void**)&w->h_retry, 16) != hipSuccess) { ws_free(w); return nullptr; }
+    if (hipMalloc((void**)&w->retry_cnt, 16) != hipSuccess || hipMalloc((void**)&w->retry_cnt2, 16) != hipSuccess || hipHostMalloc((void**)&w->h_retry, 16) != hipSuccess) { ws_free(w); return nullptr; }
     d->all_ws.push_back(w);
     if (bind_to_stream) d->stream_ws.emplace_back(user_stream, w);
     return w;
@@ -186,7 +189,7 @@ struct Geometry {
     uint64_t need_sess = 0, need_item = 0; bool sess_may_overflow = false, item_may_overflow = false;
 };
 // LDS layout + table sizes for one launch (all blocks alike).  min_region_b: extra room the caller needs in region B.
-static int make_geometry(const DeviceState* d, const FlatIndex& ix, const LaunchParams& p, uint32_t min_region_b, Geometry& g) {
+static int make_geometry(const DeviceState* d, const FlatIndex& ix, const LaunchParams& p, uint32_t min_region_b, Geometry& g, uint32_t budget_bytes = 0) {
     const uint64_t Lmax = p.max_len;
     // position-set slots (no first-match pass over the rows) need <= 8 evolving items and lists complete above x_lo
     g.masks = Lmax <= 8 && p.m <= ix.m_index && !getenv("SRN_NO_MASKS");
@@ -208,7 +211,7 @@ static int make_geometry(const DeviceState* d, const FlatIndex& ix, const Launch
     const uint32_t region_b = round_up(std::max<uint32_t>(std::max<uint32_t>(p.k * slot_bytes, CAND_CAP * 12), min_region_b), 16);
     c.off_a = c.off_b + region_b;
     const uint32_t lds_max = (uint32_t)std::min(d->lds_per_block_max, 160 * 1024);
-    uint32_t budget = 80 * 1024;                          // two 512-thread blocks per CU
+    uint32_t budget = budget_bytes ? budget_bytes : 80 * 1024;   // default: two 512-thread blocks per CU
     if (const char* e = getenv("SRN_LDS_BUDGET_KB")) budget = (uint32_t)atoi(e) * 1024;   // experiment knob (occupancy studies)
     if (c.off_a + 32 * 1024 > budget) budget = lds_max;   // long sessions / large k: one block per CU
     if (c.off_a + 8 * 1024 > budget) return fail(SRN_ERANGE, "k / session length too large for the LDS layout");
@@ -280,9 +283,15 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         HIP_TRY(hipMemcpyAsync((void*)p.items_flat, h_items, nitems * 8, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync((void*)p.q_off, h_qoff, ((size_t)p.nq + 1) * 4, hipMemcpyHostToDevice, st));
     }
+    // Opt-in (SRN_DENSE=1): THREE workgroups per CU -- the 80-VGPR build of the kernel with a 52 KB LDS geometry -- and what that
+    // geometry cannot hold goes through the normal one (second tier) before the global-table pass.  Measured on config 3 / 4:
+    // +5.8 % / +3.6 % queries/s, but the 80-VGPR build's register spills double the memory traffic (16 -> 31 GB per launch), so it
+    // stays off until the build fits without spilling.
+    Geometry g3; bool dense = !slot64 && getenv("SRN_DENSE") && !getenv("SRN_LDS_BUDGET_KB");
+    if (dense && (make_geometry(d, ix, p, 0, g3, 52 * 1024) != SRN_OK || g3.slot64 || g3.masks != geo.masks)) dense = false;
     uint64_t g_stride = 0; int retry_blocks = 0;
     KernelCfg cg = c;
-    if (may_overflow) {
+    if (may_overflow || dense) {
         if (w->retry_cap < p.nq) { if (w->retry_list) HIP_TRY(hipFree(w->retry_list)); w->retry_list = nullptr; w->retry_cap = 0;
             HIP_TRY(hipMalloc((void**)&w->retry_list, (size_t)p.nq * 4 + 64)); w->retry_cap = p.nq; }
         cg.sess_slots = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(256, ceil_pow2(need_sess * 2)));
@@ -292,13 +301,19 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         retry_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)d->n_cu, (2ull << 30) / g_stride));
         int rc = ensure(&w->gscratch, &w->gscratch_bytes, g_stride * retry_blocks); if (rc) return rc;
         HIP_TRY(hipMemsetAsync(w->retry_cnt, 0, 4, st));
+        if (dense) {
+            if (w->retry_cap2 < p.nq) { if (w->retry_list2) HIP_TRY(hipFree(w->retry_list2)); w->retry_list2 = nullptr; w->retry_cap2 = 0;
+                HIP_TRY(hipMalloc((void**)&w->retry_list2, (size_t)p.nq * 4 + 64)); w->retry_cap2 = p.nq; }
+            HIP_TRY(hipMemsetAsync(w->retry_cnt2, 0, 4, st));
+        }
     }
 
     // ---- launches ----------------------------------------------------------------------
     const uint32_t blocks_per_cu = std::max<uint32_t>(1, (160 * 1024) / (uint32_t)lds);
     const uint32_t grid = (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * std::min<uint32_t>(blocks_per_cu, 2048 / kBlock) * 4);
     // per-block global copy of the neighbour list (walk B reads it after phase 4a has reused the LDS)
-    { int rc = ensure(&w->spill, &w->spill_bytes, (size_t)std::max<uint32_t>(grid, (uint32_t)retry_blocks) * p.k * slot_bytes); if (rc) return rc; }
+    const uint32_t grid3 = dense ? (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * std::min<uint32_t>(std::max<uint32_t>(1, (160 * 1024) / (uint32_t)g3.lds), 2048 / kBlock) * 4) : 0u;
+    { int rc = ensure(&w->spill, &w->spill_bytes, (size_t)std::max<uint32_t>(std::max(grid, grid3), (uint32_t)retry_blocks) * p.k * slot_bytes); if (rc) return rc; }
     char* spill = w->spill;
     const uint32_t prep_stride = (uint32_t)(sizeof(PrepHead) + (size_t)p.max_len * sizeof(PrepItem));
     { int rc = ensure(&w->prep, &w->prep_bytes, (size_t)p.nq * prep_stride); if (rc) return rc; }
@@ -307,16 +322,22 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     HIP_TRY(launch_prep(st, d->di, p.items_flat, p.q_off, p.nq, p.m, p.max_len, w->prep, prep_stride));
     p.prep = w->prep; p.prep_stride = prep_stride;
     HIP_TRY(hipEventRecord(ev[3], st));
-    HIP_TRY(launch_predict(geo.masks, slot64, false, 0, dim3(grid), lds, st, d->di, p, c, nullptr, nullptr, w->retry_list, w->retry_cnt, nullptr, 0, spill, ShardIO{}));
+    const uint32_t* final_list = w->retry_list; uint32_t* final_cnt = w->retry_cnt;
+    if (dense) {
+        HIP_TRY(launch_predict(geo.masks, false, false, 0, dim3(grid3), g3.lds, st, d->di, p, g3.c, nullptr, nullptr, w->retry_list, w->retry_cnt, nullptr, 0, spill, ShardIO{}, 3));
+        HIP_TRY(launch_predict(geo.masks, false, false, 0, dim3(grid), lds, st, d->di, p, c, w->retry_list, w->retry_cnt, w->retry_list2, w->retry_cnt2, nullptr, 0, spill, ShardIO{}));
+        final_list = w->retry_list2; final_cnt = w->retry_cnt2;
+    } else
+        HIP_TRY(launch_predict(geo.masks, slot64, false, 0, dim3(grid), lds, st, d->di, p, c, nullptr, nullptr, w->retry_list, w->retry_cnt, nullptr, 0, spill, ShardIO{}));
     HIP_TRY(hipEventRecord(ev[1], st));
-    if (may_overflow) {
+    if (may_overflow || dense) {
         const size_t lds_g = c.off_a;
-        HIP_TRY(launch_predict(geo.masks, slot64, true, 0, dim3(retry_blocks), lds_g, st, d->di, p, cg, w->retry_list, w->retry_cnt, nullptr, nullptr,
+        HIP_TRY(launch_predict(geo.masks, slot64, true, 0, dim3(retry_blocks), lds_g, st, d->di, p, cg, final_list, final_cnt, nullptr, nullptr,
                                w->gscratch, g_stride, spill, ShardIO{}));
-        HIP_TRY(hipMemcpyAsync(w->h_retry, w->retry_cnt, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(w->h_retry, final_cnt, 4, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipEventRecord(ev[2], st));
-    ++w->calls; w->last_retry = may_overflow ? 1 : 0;
+    ++w->calls; w->last_retry = (may_overflow || dense) ? 1 : 0;
 
     if (!on_device) {
         HIP_TRY(hipMemcpyAsync(h_ids, p.out_ids, n_out * 8, hipMemcpyDeviceToHost, st));

@@ -60,7 +60,7 @@ def test_kat1_should_train_and_predict():
         assert r.score == pytest.approx(1.751319134149782, rel=1e-12)
 
 
-@pytest.fixture(params=["default", "no_masks", "no_hot", "hot64", "no_sketch", "sketch64", "no_merge"])
+@pytest.fixture(params=["default", "no_masks", "no_hot", "hot64", "no_sketch", "sketch64", "no_merge", "dense"])
 def kernel_path(request, monkeypatch):
     """The kernel picks code paths per launch: position-set slots (sessions <= 8 items) vs numerator slots + first-match
     pass; direct-mapped accumulators for popular items vs hash only; sketch pre-filter on / off / tiny; candidate sessions by
@@ -74,6 +74,8 @@ def kernel_path(request, monkeypatch):
         monkeypatch.setenv("SRN_NO_MASKS", "1")
     elif request.param == "no_sketch":
         monkeypatch.setenv("SRN_SKETCH_SLOTS", "0")
+    elif request.param == "dense":             # three workgroups per CU: the 80-VGPR build + small LDS geometry, second LDS tier behind it
+        monkeypatch.setenv("SRN_DENSE", "1")
     elif request.param == "no_merge":          # candidate sessions through the LDS hash table + selects instead of the merge tree
         monkeypatch.setenv("SRN_NO_MERGE", "1")
     elif request.param == "sketch64":          # heavy collisions in the upper-bound words: the filter must stay exact

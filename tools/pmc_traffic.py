@@ -10,7 +10,10 @@ def per_launch(d, counter, min_grid_wg=1024):
                     and int(r["Grid_Size"]) >= min_grid_wg * int(r["Workgroup_Size"]):
                 vals.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
     vals.sort()
-    return [v for _, v in vals[:-1]]   # the last full-size launch is bench.py's stats pass (debug counters on), not a timed step
+    top = max(v for _, v in vals)
+    big = [v for _, v in vals if v >= 0.1 * top][:-1]     # the last full-size launch is bench.py's stats pass (debug counters on), not a timed step
+    small = [v for _, v in vals if v < 0.1 * top][:-1]    # second-tier launches (what the small LDS geometry could not hold), one per step
+    return [b + (sum(small) / len(small) if small else 0.0) for b in big]
 
 fetch, write = per_launch(sys.argv[1], "FETCH_SIZE"), per_launch(sys.argv[2], "WRITE_SIZE")
 f, w = sum(fetch) / len(fetch), sum(write) / len(write)
