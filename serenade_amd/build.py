@@ -34,7 +34,12 @@ def build_hip(force=False, verbose=False):
     for name in SOURCES:
         src, obj = os.path.join(CSRC, name), os.path.join(objdir, name + ".o")
         if force or extra or _stale(obj, [src] + headers):
-            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-value"] + extra + ["-c", "-o", obj, src]
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-value"]
+            if name == "srn_kernels.hip":
+                # hoisting loop invariants out of the per-query loop keeps them live for ~100 K cycles: a third fewer SGPR spill
+                # moves and half the scratch accesses without it, +5..6 % queries/s
+                cmd += ["-mllvm", "-disable-machine-licm"]
+            cmd += extra + ["-c", "-o", obj, src]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
