@@ -1245,8 +1245,18 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
         // leaves the best min(cnt, n) candidates sorted at the front of the buffer, sets the threshold if n exist
         auto sort_candidates = [&](uint32_t cnt) {
             if (n_out <= 64 && cnt <= 64) {   // one wave sorts in registers, no merge levels
-                if (wave == 0) { uint64_t kk = lane < (int)cnt ? ckey[lane] : 0; uint32_t ii = lane < (int)cnt ? cidx[lane] : EMPTY32;
-                                 wave_sort_desc(kk, ii, lane); ckey[lane] = kk; cidx[lane] = ii; }
+                if (wave == 0) {   // rank by counting: lane j's candidate is broadcast with v_readlane (no LDS crossbar round trips, unlike a
+                                   // shuffle network); (key, id rank) pairs are distinct, so the ranks are a permutation
+                    const uint64_t kk = lane < (int)cnt ? ckey[lane] : 0; const uint32_t ii = lane < (int)cnt ? cidx[lane] : EMPTY32;
+                    const int klo = (int)(uint32_t)kk, khi = (int)(uint32_t)(kk >> 32);
+                    uint32_t rank = 0;
+                    for (uint32_t j = 0; j < cnt; ++j) {
+                        const uint64_t kj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(khi, (int)j) << 32) | (uint32_t)__builtin_amdgcn_readlane(klo, (int)j);
+                        const uint32_t ij = (uint32_t)__builtin_amdgcn_readlane((int)ii, (int)j);
+                        rank += cand_better(kj, ij, kk, ii);
+                    }
+                    if (lane < (int)cnt) { ckey[rank] = kk; cidx[rank] = ii; }
+                }
                 __syncthreads();
             } else if (n_out <= 64) block_top64<BLOCK>(ckey, cidx, cnt);   // leaves the best min(cnt, 64) sorted at the front
             else {
