@@ -224,7 +224,35 @@ int srn_batcher_create(const srn_index_t* idx, size_t max_batch, unsigned max_wa
                        int enable_business_logic, srn_batcher_t** out);
 int srn_batcher_predict(srn_batcher_t* b, const uint64_t* evolving, size_t len, uint64_t* out_ids, double* out_scores, size_t* out_n);
 int srn_batcher_stats(srn_batcher_t* b, uint64_t* n_requests, uint64_t* n_batches, uint64_t* max_batch_seen);
+int srn_batcher_how_many(const srn_batcher_t* b, size_t* out);   /* the result capacity a caller's buffers need */
 void srn_batcher_free(srn_batcher_t* b);   /* serves what is still queued, then stops the dispatcher */
+
+/* ---- evolving-session store + the /v1/recommend handler body --------------------------------------------------------
+ * Replaces RocksDBSessionStore (src/sessions/mod.rs:7-77) and the body of v1_recommend
+ * (src/endpoints/recommend_resource.rs:20-65) between the web framework and predict.  The store is in memory (a visitor
+ * is pinned to one pod by session_id affinity; nothing has to survive the process).  Keys are the reference's: the MD5
+ * digest of the session_id string read as a big-endian u128 (recommend_resource.rs:27-28), here as (hi, lo).
+ * A session idle for more than idle_secs reads as empty (mod.rs:46-52; 0 = the reference's 20 minutes); entries older than
+ * ttl_secs are dropped (RocksDB TTL, src/bin/serving.rs:55-56; 0 = the reference's 30 minutes).  now_secs = 0 means the
+ * system clock (seconds since the epoch, mod.rs:74-76); tests pass explicit times. */
+typedef struct srn_session_store srn_session_store_t;
+int srn_session_key(const char* session_id, size_t len, uint64_t* key_hi, uint64_t* key_lo);
+int srn_session_store_create(uint64_t ttl_secs, uint64_t idle_secs, srn_session_store_t** out);
+void srn_session_store_free(srn_session_store_t* s);
+/* get_session_items (mod.rs:37-57): unknown or idle session -> *out_n = 0 */
+int srn_session_store_get(srn_session_store_t* s, uint64_t key_hi, uint64_t key_lo, uint64_t now_secs,
+                          uint64_t* out_items, size_t cap, size_t* out_n);
+/* update_session_items (mod.rs:59-72) */
+int srn_session_store_update(srn_session_store_t* s, uint64_t key_hi, uint64_t key_lo, uint64_t now_secs,
+                             const uint64_t* items, size_t n);
+/* drops every entry older than ttl_secs now (also done incrementally by updates); *n_live = entries kept */
+int srn_session_store_sweep(srn_session_store_t* s, uint64_t now_secs, uint64_t* n_live);
+/* v1_recommend's body: with user_consent, session := stored items; append item_id unless it repeats the last one; drop the
+ * oldest beyond max_items_in_session; store; without consent the session is [item_id] and the store is untouched.  Then
+ * predict through the batcher.  out_ids (and out_scores, may be NULL: the endpoint returns ids only) hold how_many entries. */
+int srn_recommend(srn_batcher_t* b, srn_session_store_t* s, const char* session_id, size_t session_id_len, uint64_t item_id,
+                  int user_consent, size_t max_items_in_session, uint64_t now_secs, uint64_t* out_ids, double* out_scores,
+                  size_t* out_n);
 
 int srn_device_count(int* out);
 void srn_limits(srn_limits_t* out);

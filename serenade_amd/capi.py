@@ -59,6 +59,14 @@ SYMBOLS = {
     "srn_batcher_predict": (_i, [_vp, _vp, _sz, _vp, _vp, C.POINTER(_sz)]),
     "srn_batcher_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
     "srn_batcher_free": (None, [_vp]),
+    "srn_batcher_how_many": (_i, [_vp, C.POINTER(_sz)]),
+    "srn_session_key": (_i, [C.c_char_p, _sz, C.POINTER(_u64), C.POINTER(_u64)]),
+    "srn_session_store_create": (_i, [_u64, _u64, C.POINTER(_vp)]),
+    "srn_session_store_free": (None, [_vp]),
+    "srn_session_store_get": (_i, [_vp, _u64, _u64, _u64, _vp, _sz, C.POINTER(_sz)]),
+    "srn_session_store_update": (_i, [_vp, _u64, _u64, _u64, _vp, _sz]),
+    "srn_session_store_sweep": (_i, [_vp, _u64, C.POINTER(_u64)]),
+    "srn_recommend": (_i, [_vp, _vp, C.c_char_p, _sz, _u64, _i, _sz, _u64, _vp, _vp, C.POINTER(_sz)]),
     "srn_predict_batch_device": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, C.c_uint, _vp, _vp, _vp, _vp]),
     "srn_predict_batch_debug": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "srn_last_kernel_ms": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),

@@ -126,6 +126,12 @@ int srn_batcher_stats(srn_batcher_t* b, uint64_t* n_requests, uint64_t* n_batche
     return SRN_OK;
 }
 
+int srn_batcher_how_many(const srn_batcher_t* b, size_t* out) {
+    if (!b || !out) return fail(SRN_EINVAL, "null argument");
+    *out = b->how_many;
+    return SRN_OK;
+}
+
 void srn_batcher_free(srn_batcher_t* b) {
     if (!b) return;
     { std::lock_guard<std::mutex> lk(b->mu); b->stop = true; }

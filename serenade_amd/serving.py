@@ -39,3 +39,50 @@ class Batcher:
             self._h = None
 
     __del__ = close
+
+
+def session_key(session_id):
+    """u128 key of a session_id string, as the reference builds it (MD5 digest read big-endian, recommend_resource.rs:27-28)."""
+    raw = session_id.encode() if isinstance(session_id, str) else bytes(session_id)
+    hi, lo = C.c_uint64(), C.c_uint64()
+    capi.check(capi.lib().srn_session_key(raw, len(raw), C.byref(hi), C.byref(lo)))
+    return (hi.value << 64) | lo.value
+
+
+class SessionStore:
+    """In-memory stand-in for RocksDBSessionStore (src/sessions/mod.rs): same get / update calls, same idle and TTL clocks."""
+
+    def __init__(self, ttl_secs=30 * 60, idle_secs=20 * 60):
+        h = C.c_void_p()
+        capi.check(capi.lib().srn_session_store_create(int(ttl_secs), int(idle_secs), C.byref(h)))
+        self._h = h
+
+    def get_session_items(self, key, now=0, cap=256):
+        out, n = np.zeros(cap, np.uint64), C.c_size_t()
+        capi.check(capi.lib().srn_session_store_get(self._h, key >> 64, key & (2**64 - 1), int(now), capi.ptr(out), cap, C.byref(n)))
+        return [int(x) for x in out[:n.value]]
+
+    def update_session_items(self, key, items, now=0):
+        it = capi.as_u64(items)
+        capi.check(capi.lib().srn_session_store_update(self._h, key >> 64, key & (2**64 - 1), int(now), capi.ptr(it), len(it)))
+
+    def sweep(self, now=0):
+        n = C.c_uint64()
+        capi.check(capi.lib().srn_session_store_sweep(self._h, int(now), C.byref(n)))
+        return n.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            capi.lib().srn_session_store_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+def recommend(batcher, store, session_id, item_id, user_consent=True, max_items_in_session=2, now=0):
+    """Body of the reference's /v1/recommend handler (recommend_resource.rs:20-65) -> recommended item ids, best first."""
+    raw = session_id.encode() if isinstance(session_id, str) else bytes(session_id)
+    ids, n = np.zeros(batcher.how_many, np.uint64), C.c_size_t()
+    capi.check(capi.lib().srn_recommend(batcher._h, store._h if store is not None else None, raw, len(raw), int(item_id),
+                                        int(bool(user_consent)), int(max_items_in_session), int(now), capi.ptr(ids), None, C.byref(n)))
+    return [int(i) for i in ids[:n.value]]

@@ -56,3 +56,44 @@ def test_batcher_rejects_bad_configuration():
     for kw in (dict(k=0, m=10, how_many=5), dict(k=10, m=10, how_many=100000), dict(k=10, m=10, how_many=5, max_batch=0)):
         with pytest.raises(sa.SerenadeError):
             Batcher(gix, kw["k"], kw["m"], kw["how_many"], max_batch=kw.get("max_batch", 16))
+
+
+def test_recommend_follows_the_reference_handler():
+    """srn_recommend == the body of v1_recommend (recommend_resource.rs:20-65) replayed in Python over direct predict calls:
+    session read with the idle rule, append unless the click repeats the last item, drop the oldest beyond the limit."""
+    import serenade_amd as sa
+    from serenade_amd.serving import Batcher, SessionStore, recommend, session_key
+    off, items, ts, ids = small_dataset(33, n_sessions=3000, n_items=300)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, 200, 12, 1.0)
+    b = Batcher(gix, 50, 200, 21, False, max_batch=32, max_wait_us=100)
+    store = SessionStore(ttl_secs=1800, idle_secs=1200)
+    rng = np.random.default_rng(5)
+    model, now, max_items = {}, 10_000, 3
+    for step in range(400):
+        now += int(rng.integers(0, 500))
+        sid = "visitor-%d" % rng.integers(0, 12)
+        item = int(ids[rng.integers(0, len(ids))]) if rng.random() < 0.9 else 999_999_999   # sometimes unknown to the index
+        consent = rng.random() < 0.85
+        if consent:
+            sess, t = model.get(sid, ([], 0))
+            if now - t > 1200:
+                sess = []
+            sess = list(sess)
+            if not sess:
+                sess.append(item)
+            elif sess[-1] != item:
+                sess.append(item)
+                if len(sess) > max_items:
+                    sess.pop(0)
+            model[sid] = (sess, now)
+        else:
+            sess = [item]
+        want = [r.id for r in sa.predict(gix, sess, 50, 200, 21, False)]
+        assert recommend(b, store, sid, item, consent, max_items, now=now) == want, (step, sid, sess)
+        if consent:
+            assert store.get_session_items(session_key(sid), now=now) == sess
+    with pytest.raises(sa.SerenadeError):
+        recommend(b, None, "x", 1, True, 3)           # consent needs a store
+    assert recommend(b, None, "x", int(ids[0]), False, 3) == [r.id for r in sa.predict(gix, [int(ids[0])], 50, 200, 21, False)]
+    b.close()
+    store.close()
