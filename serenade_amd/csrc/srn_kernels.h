@@ -32,7 +32,7 @@ struct KernelCfg {
 struct LaunchAux { const uint32_t* qlist; const uint32_t* qlist_n; uint32_t* retry_list; uint32_t* retry_cnt; char* gscratch; unsigned long long gscratch_stride; char* nb_spill; };
 
 // record written by the prep kernel for every query: PrepHead + max_len * PrepItem, positions counted from the most recent item
-struct PrepHead { uint32_t U, rmax, xlo, sumw, P, nruns, pad[2], run_start[8]; };   // S_U, S_RMAX, S_XLO, S_SUMW, S_P of the query; number of non-empty lists and where the first 8 start
+struct PrepHead { uint32_t U, rmax, xlo, sumw, P, nruns, L, pad, run_start[8]; };   // S_U, S_RMAX, S_XLO, S_SUMW, S_P of the query; number of non-empty lists, session length as given, where the first 8 lists start
 struct PrepItem { uint32_t idx, len, pre, pad; unsigned long long base; };   // dense idx | kNone, truncated list length, prefix of len, list start
 
 // ---- launchers (srn_kernels.hip) -------------------------------------------------------------

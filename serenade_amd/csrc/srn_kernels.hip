@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void vmis_prep_kernel(DeviceIndex ix, const ui
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     const uint32_t qb = q_off[q], L = q_off[q + 1] - qb;
-    PrepHead h{0u, 0u, 0u, 0u, 0u, 0u, {0u, 0u}, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}};
+    PrepHead h{0u, 0u, 0u, 0u, 0u, 0u, L, 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}};
     PrepItem* items = (PrepItem*)(out + (size_t)q * stride + sizeof(PrepHead));
     if (L != 0 && L <= max_len) {
         for (uint32_t pos = 0; pos < L; ++pos) {
@@ -498,8 +498,17 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
 
     for (uint32_t qi = blockIdx.x; qi < nq_eff; qi += gridDim.x) {
         const uint32_t q = aux.qlist ? aux.qlist[qi] : qi;
-        const uint32_t qb = p.q_off[q];
-        const uint32_t L = p.q_off[q + 1] - qb;
+        // with a prep record every global read of this phase is issued here, in one round: the head (uniform), the first
+        // 8 item entries and the run starts (lanes 0..7) -- the session length comes with the head, not from q_off
+        const bool use_prep = STAGE == 0 && p.prep != nullptr;
+        const char* const rec = use_prep ? p.prep + (size_t)q * p.prep_stride : nullptr;
+        PrepHead hd; PrepItem x0{kNone, 0u, 0u, 0u, 0ull}; uint32_t rs0 = 0;
+        uint32_t qb = 0, L;
+        if (use_prep) {
+            hd = *(const PrepHead*)rec;   // (uniform address)
+            if (lane < 8) { if ((uint32_t)lane < p.max_len) x0 = ((const PrepItem*)(rec + sizeof(PrepHead)))[lane]; rs0 = ((const PrepHead*)rec)->run_start[lane]; }   // (every wave: all need entry 0)
+            L = hd.L;
+        } else { qb = p.q_off[q]; L = p.q_off[q + 1] - qb; }
         if (L == 0 || L > p.max_len) {   // block-uniform
             if (tid == 0) { p.out_counts[q] = 0xFFFFFFFFu;
                 if (p.stats) { for (int i = 0; i < 8; ++i) p.stats[(size_t)q * 8 + i] = 0; p.stats[(size_t)q * 8 + 7] = 2; }
@@ -513,13 +522,12 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
         for (uint32_t i = tid; i < SEL_WORDS; i += BLOCK) hist[i] = 0;
         if (MASKS && tid < 256) { uint32_t acc = 0; for (uint32_t b = 0; b < L; ++b) if ((tid >> b) & 1) acc += L - b; wlut[tid] = (uint8_t)acc; }
         uint32_t x_lo, r_max, U, P, cur_idx, sumw = 0, nruns = 0;
-        if (STAGE == 0 && p.prep) {   // the look-ups were done by the prep kernel: one record per query, no barrier needed here
-            const char* rec = p.prep + (size_t)q * p.prep_stride;
-            const PrepHead hd = *(const PrepHead*)rec;   // (uniform address)
+        if (use_prep) {   // the look-ups were done by the prep kernel: one record per query, no barrier needed here
             const PrepItem* pit = (const PrepItem*)(rec + sizeof(PrepHead));
-            x_lo = hd.xlo; r_max = hd.rmax; U = hd.U; P = hd.P; cur_idx = pit[0].idx; sumw = hd.sumw;
+            x_lo = hd.xlo; r_max = hd.rmax; U = hd.U; P = hd.P; sumw = hd.sumw;
             nruns = hd.nruns;
-            for (uint32_t pos = tid; pos < L; pos += BLOCK) { const PrepItem x = pit[pos]; q_idx[pos] = x.idx; l_len[pos] = x.len; l_pre[pos] = x.pre; l_base[pos] = x.base; }
+            cur_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)x0.idx);
+            for (uint32_t pos = tid; pos < L; pos += BLOCK) { const PrepItem x = pos < 8 ? x0 : pit[pos]; q_idx[pos] = x.idx; l_len[pos] = x.len; l_pre[pos] = x.pre; l_base[pos] = x.base; }
             if (tid == 0) { l_pre[L] = hd.P; misc[S_U] = hd.U; misc[S_RMAX] = hd.rmax; misc[S_XLO] = hd.xlo; misc[S_SUMW] = hd.sumw; misc[S_P] = hd.P; }   // (same wave zeroed them)
         } else {
         for (uint32_t i = tid; i < L; i += BLOCK) q_raw[i] = p.items_flat[qb + (L - 1 - i)];   // pos 0 = most recent item
@@ -568,7 +576,7 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
         if (!merge_mode) for (uint32_t i = tid; i < sslots; i += BLOCK) stab[i] = SEMPTY;
         else if (tid < 64) {   // run table 0 (start, valid length of every active list) and the numerator class counters
             wb[wwords - 64 + tid] = 0;
-            if (tid < 8) { misc[32 + tid] = ((const PrepHead*)(p.prep + (size_t)q * p.prep_stride))->run_start[tid]; misc[40 + tid] = 0; }
+            if (tid < 8) { misc[32 + tid] = rs0; misc[40 + tid] = 0; }
         }
         phase_sync<GLOBAL_TABLES>();
         SRN_TICK(0);
