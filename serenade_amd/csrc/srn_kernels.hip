@@ -87,10 +87,30 @@ __device__ __forceinline__ bool business_ok(uint32_t cur, uint32_t reco) {
     return false;
 }
 
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+// Wave-wide scans and reductions on the VALU's data-parallel-primitive path (row_shr inside the rows of 16 lanes, then
+// row_bcast 15 / 31 across them): ~12 VALU instructions.  The __shfl_* forms compile to ds_bpermute_b32, i.e. six DEPENDENT
+// LDS round trips per scan, on a kernel whose LDS pipe is the busiest unit.
+#define SRN_DPP(v, ctrl, rmask, bctl) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rmask, 0xf, bctl)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {   // lane i <- v[0] + ... + v[i]
+    v += SRN_DPP(v, 0x111, 0xf, true);    // row_shr:1 (0 shifted in at the row start)
+    v += SRN_DPP(v, 0x112, 0xf, true);    // row_shr:2
+    v += SRN_DPP(v, 0x114, 0xf, true);    // row_shr:4
+    v += SRN_DPP(v, 0x118, 0xf, true);    // row_shr:8
+    v += SRN_DPP(v, 0x142, 0xa, false);   // row_bcast:15 -> rows 1 and 3
+    v += SRN_DPP(v, 0x143, 0xc, false);   // row_bcast:31 -> rows 2 and 3
     return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {   // (uniform result)
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v), 63);
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {   // (uniform result)
+    v = max(v, SRN_DPP(v, 0x111, 0xf, true));
+    v = max(v, SRN_DPP(v, 0x112, 0xf, true));
+    v = max(v, SRN_DPP(v, 0x114, 0xf, true));
+    v = max(v, SRN_DPP(v, 0x118, 0xf, true));
+    v = max(v, SRN_DPP(v, 0x142, 0xa, false));
+    v = max(v, SRN_DPP(v, 0x143, 0xc, false));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 // one LDS atomic per wave: returns this lane's slot in a shared append buffer (only meaningful if pred)
 __device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
@@ -100,7 +120,7 @@ __device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
     const int leader = __ffsll((long long)mask) - 1;
     uint32_t base = 0;
     if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader, 64);
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
@@ -129,10 +149,8 @@ __device__ void hist_search(uint32_t* hist, uint32_t remain, volatile uint32_t* 
             for (int j = 0; j < 8; ++j) t += hist[sel_word(PER * tid + gi * 8 + j)];
             g[gi] = t; }
         const uint32_t s = g[0] + g[1] + g[2] + g[3];
-        uint32_t inc = s;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_down(inc, d, 64); if (tid + d < 64) inc += t; }
-        uint32_t above = inc - s;   // entries in bins owned by higher lanes
+        const uint32_t pre = wave_incl_scan(s);
+        uint32_t above = (uint32_t)__builtin_amdgcn_readlane((int)pre, 63) - pre;   // entries in bins owned by higher lanes
         if (above < remain && remain <= above + s) {   // the target bin is one of mine: find the group of 8, then the bin
             int gsel = -1; uint32_t ab = above;
 #pragma unroll
@@ -186,9 +204,7 @@ __device__ KeyT block_select_desc(F keyfn, uint32_t n, int nbits, uint32_t r, ui
 template <int BLOCK>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, volatile uint32_t* scratch, uint32_t& total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+    const uint32_t inc = wave_incl_scan(v);
     if (lane == 63) scratch[wave] = inc;
     __syncthreads();
     uint32_t base = 0; total = 0;
@@ -720,12 +736,11 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
                 __syncthreads();
                 uint32_t nstar, rstar;
                 {   // lane v holds class v: suffix sums from the best class down, the boundary class is the highest one whose suffix reaches k
-                    const uint32_t cv = cls[lane]; uint32_t suf = cv;
-#pragma unroll
-                    for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t t = __shfl_down(suf, dd, 64); if (lane + dd < 64) suf += t; }
+                    const uint32_t cv = cls[lane]; const uint32_t pre = wave_incl_scan(cv);
+                    const uint32_t suf = (uint32_t)__builtin_amdgcn_readlane((int)pre, 63) - pre + cv;
                     const unsigned long long reach = __ballot(suf >= p.k);
                     nstar = 63u - (uint32_t)__clzll((long long)reach);
-                    rstar = p.k - ((uint32_t)__shfl((int)suf, (int)nstar, 64) - (uint32_t)__shfl((int)cv, (int)nstar, 64));
+                    rstar = p.k - ((uint32_t)__builtin_amdgcn_readlane((int)suf, (int)nstar) - (uint32_t)__builtin_amdgcn_readlane((int)cv, (int)nstar));
                 }
                 SRN_TICK(3);
                 const uint32_t g = (Cm + BLOCK - 1) / BLOCK, o0 = min((uint32_t)tid * g, Cm), o1 = min(o0 + g, Cm);
@@ -736,11 +751,9 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
                 uint32_t sel = 0;
                 for (uint32_t o = o0; o < o1; ++o) { const uint32_t nm = num_of(D[o]); sel += nm > nstar || (nm == nstar && before < rstar); before += nm == nstar; }
                 uint32_t at;   // output slots: a wave's selected entries are contiguous, waves in any order (the order of the list is free)
-                { uint32_t inc = sel;
-#pragma unroll
-                  for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t t = __shfl_up(inc, dd, 64); if (lane >= dd) inc += t; }
+                { const uint32_t inc = wave_incl_scan(sel);
                   uint32_t base = 0; if (lane == 63 && inc) base = atomicAdd((uint32_t*)&misc[S_NB], inc);
-                  at = (uint32_t)__shfl((int)base, 63, 64) + inc - sel; }
+                  at = (uint32_t)__builtin_amdgcn_readlane((int)base, 63) + inc - sel; }
                 before = before - mine;   // back to this thread's start
                 for (uint32_t o = o0; o < o1; ++o) {
                     const uint32_t v = D[o], nm = num_of(v);
@@ -872,7 +885,7 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
                         }
                     }
                     uint32_t base = 0;
-                    if (total) { if (lane == 0) base = atomicAdd((uint32_t*)&misc[S_NB], total); base = __shfl(base, 0, 64); }
+                    if (total) { if (lane == 0) base = atomicAdd((uint32_t*)&misc[S_NB], total); base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base); }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         if ((bm[u] >> lane) & 1ull) dl[base + (uint32_t)__popcll(bm[u] & ((1ull << lane) - 1ull))] = sv[u];
@@ -911,7 +924,7 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
                             }
                             uint32_t basea = 0, basee = 0;
                             if (lane == 0) { if (ta) basea = atomicAdd((uint32_t*)&misc[S_NK], ta); if (te) basee = atomicAdd((uint32_t*)&misc[S_L2], te); }   // (S_NK: S_NB is still being read as |D|)
-                            basea = __shfl(basea, 0, 64); basee = __shfl(basee, 0, 64);
+                            basea = (uint32_t)__builtin_amdgcn_readfirstlane((int)basea); basee = (uint32_t)__builtin_amdgcn_readfirstlane((int)basee);
 #pragma unroll
                             for (int u = 0; u < 8; ++u) {
                                 if ((ba[u] >> lane) & 1ull) tmp[basea + (uint32_t)__popcll(ba[u] & ((1ull << lane) - 1ull))] = sv[u];
@@ -981,7 +994,7 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
                 bm[u] = __ballot(sel); total += (uint32_t)__popcll(bm[u]);
             }
             uint32_t base = 0;
-            if (total) { if (lane == 0) base = atomicAdd((uint32_t*)&misc[S_NB], total); base = __shfl(base, 0, 64); }
+            if (total) { if (lane == 0) base = atomicAdd((uint32_t*)&misc[S_NB], total); base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base); }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 if ((bm[u] >> lane) & 1ull) {
@@ -1363,9 +1376,7 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
             { uint32_t v = k32, third = 0;
 #pragma unroll
               for (int t = 0; t < 3; ++t) {
-                  uint32_t mx = v;
-#pragma unroll
-                  for (int dd = 32; dd > 0; dd >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, dd, 64));
+                  const uint32_t mx = wave_max(v);
                   third = mx;
                   const unsigned long long bal = __ballot(v == mx);
                   if (lane == __ffsll((long long)bal) - 1) v = 0;   // take one holder of the maximum out
