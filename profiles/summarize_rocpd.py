@@ -19,8 +19,12 @@ if rows:
         print("\n# second-tier launches (what the small LDS geometry could not hold): %d, avg %.3f ms" % (len(small), sum(r[6] for r in small) / len(small)))
     rows = [r for r in rows if r[6] >= 0.1 * big]
     ms = [r[6] for r in rows]
-    print("\n# (the last launch is bench.py's stats pass -- debug counters on, sketch pre-filter off -- not a timed step: %.3f ms)" % ms[-1])
-    ms = ms[:-1]
+    med = sorted(ms)[len(ms) // 2]
+    cut = next((i for i, v in enumerate(ms) if v > 2.0 * med), len(ms))   # bench.py's stats pass: debug counters on, sketch pre-filter off
+    if cut < len(ms):
+        print("\n# (launch %d is bench.py's stats pass, not a timed step: %.3f ms; the %d launches after it are the host-buffer batch calls "
+              "of the latency section: %s)" % (cut + 1, ms[cut], len(ms) - cut - 1, " ".join("%.3f" % v for v in ms[cut + 1:])))
+    ms = ms[:cut]
     print("# timed and warm-up launches of vmis_predict_kernel<..., GLOBAL_TABLES=false, ...>: %d" % len(ms))
     print("grid_threads=%d workgroup=%d lds_bytes=%d vgpr=%d sgpr=%d scratch=%d" % rows[0][:6])
     print("duration_ms: " + " ".join("%.3f" % v for v in ms))

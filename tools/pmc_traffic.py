@@ -1,5 +1,5 @@
 """HBM traffic of the predict kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over `bench.py --steps 2 --warmup 1`
-(tools/pmc_bench.sh fetch FETCH_SIZE; tools/pmc_bench.sh write WRITE_SIZE):  python tools/pmc_traffic.py <fetch_dir> <write_dir> <config> <batch> > profiles/rNN_traffic_<config>.json"""
+(tools/pmc_bench.sh fetch FETCH_SIZE; tools/pmc_bench.sh write WRITE_SIZE):  python tools/pmc_traffic.py <fetch_dir> <write_dir> <config> <batch> [launches = warm-up + steps, default 3] > profiles/rNN_traffic_<config>.json"""
 import csv, glob, json, sys
 
 def per_launch(d, counter, min_grid_wg=1024):
@@ -11,8 +11,9 @@ def per_launch(d, counter, min_grid_wg=1024):
                 vals.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
     vals.sort()
     top = max(v for _, v in vals)
-    big = [v for _, v in vals if v >= 0.1 * top][:-1]     # the last full-size launch is bench.py's stats pass (debug counters on), not a timed step
-    small = [v for _, v in vals if v < 0.1 * top][:-1]    # second-tier launches (what the small LDS geometry could not hold), one per step
+    n_timed = int(sys.argv[5]) if len(sys.argv) > 5 else 3   # warm-up + timed steps of the profiled command; then come the stats pass and the host-buffer batch calls
+    big = [v for _, v in vals if v >= 0.1 * top][:n_timed]
+    small = [v for _, v in vals if v < 0.1 * top][:n_timed]    # second-tier launches (what the small LDS geometry could not hold), one per step
     return [b + (sum(small) / len(small) if small else 0.0) for b in big]
 
 fetch, write = per_launch(sys.argv[1], "FETCH_SIZE"), per_launch(sys.argv[2], "WRITE_SIZE")
