@@ -454,8 +454,12 @@ __global__ __launch_bounds__(256) void vmis_prep_kernel(DeviceIndex ix, const ui
     *(PrepHead*)(out + (size_t)q * stride) = h;
 }
 
+#ifndef SRN_STOP_AT
+#define SRN_STOP_AT (-1)   // experiments only (tools/phase_insts.sh): leave the query after phase tick N (0..4, 8..10) to count instructions per phase
+#endif
 #define SRN_TICK(ph)                                                                                         \
-    do { if (p.phase_cycles && tid == 0) { const long long t_ = clock64(); atomicAdd(&p.phase_cycles[ph], (unsigned long long)(t_ - t_prev)); t_prev = t_; } } while (0)
+    do { if (p.phase_cycles && tid == 0) { const long long t_ = clock64(); atomicAdd(&p.phase_cycles[ph], (unsigned long long)(t_ - t_prev)); t_prev = t_; } } while (0); \
+    if (SRN_STOP_AT == (ph)) continue
 
 // WG_PER_CU = workgroups the build is meant to co-reside with: 2 (4 waves per SIMD, <= 128 VGPRs) or 3 (6 waves, <= 80 VGPRs: more
 // latency hiding for the price of spills; used with the small LDS geometry when the queries are large, see device_predict)
@@ -725,7 +729,26 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
                 if (tid == 0) misc[S_NB] = Cm;
             } else {   // k-cut
                 uint32_t* cls = wb + (wwords - 64);
-                {   // lane v counts class v (ballots), one scattered atomic per lane at the end: no same-address pile-up
+                if (sumw <= 15 && Cm <= 15 * BLOCK) {
+                    // <= 16 classes, <= 15 candidates per thread: count in packed fields.  A thread adds 1 << 4 class into a 64-bit
+                    // word (16 fields of 4 bits), the word is spread over 4 x 64 bits with 16-bit fields (class c -> word c & 3, field
+                    // c >> 2; a wave's sum is <= 64 * 15 per field), 8 DPP wave sums, lane c picks its class.  ~100 VALU
+                    // instructions per wave where a compare + ballot per class and batch costs 4 * (sumw + 1) per batch.
+                    unsigned long long acc = 0;
+                    for (uint32_t e = tid; e < Cm; e += BLOCK) acc += 1ull << (4u * num_of(D[e]));
+                    uint32_t tot[8];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const unsigned long long t = (acc >> (4 * jj)) & 0x000F000F000F000Full;
+                        tot[2 * jj] = wave_sum((uint32_t)t); tot[2 * jj + 1] = wave_sum((uint32_t)(t >> 32));
+                    }
+                    const uint32_t dw = ((uint32_t)lane & 3u) * 2u + ((uint32_t)lane >> 3);   // class = lane: word lane & 3, field lane >> 2
+                    uint32_t pick = tot[0];
+#pragma unroll
+                    for (int x = 1; x < 8; ++x) pick = dw == (uint32_t)x ? tot[x] : pick;
+                    const uint32_t mycnt = lane < 16 ? (pick >> (16u * (((uint32_t)lane >> 2) & 1u))) & 0xFFFFu : 0u;
+                    if (mycnt) atomicAdd(&cls[lane], mycnt);
+                } else {   // lane v counts class v (ballots), one scattered atomic per lane at the end: no same-address pile-up
                     uint32_t mycnt = 0;
                     for (uint32_t e0 = 0; e0 < Cm; e0 += BLOCK) {
                         const uint32_t e = e0 + tid; const uint32_t nm = e < Cm ? num_of(D[e]) : 0xFFFFFFFFu;
