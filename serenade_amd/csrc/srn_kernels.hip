@@ -767,6 +767,30 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
                 }
                 SRN_TICK(3);
                 const uint32_t g = (Cm + BLOCK - 1) / BLOCK, o0 = min((uint32_t)tid * g, Cm), o1 = min(o0 + g, Cm);
+                if (g <= 6) {   // (m <= 3072) the thread's candidates and their classes stay in registers: read once, all loads in flight together
+                    uint32_t dv[6], nmv[6];
+#pragma unroll
+                    for (int x = 0; x < 6; ++x) dv[x] = o0 + x < o1 ? D[o0 + x] : 0u;
+#pragma unroll
+                    for (int x = 0; x < 6; ++x) nmv[x] = o0 + x < o1 ? num_of(dv[x]) : 0u;   // (class 0 does not exist: a candidate matched something)
+                    uint32_t mine = 0;
+#pragma unroll
+                    for (int x = 0; x < 6; ++x) mine += o0 + x < o1 && nmv[x] == nstar;
+                    uint32_t tot_star;
+                    uint32_t before = block_excl_scan<BLOCK>(mine, misc + 40, tot_star);
+                    uint32_t sel = 0; bool take[6];
+#pragma unroll
+                    for (int x = 0; x < 6; ++x) {
+                        const bool in_r = o0 + x < o1, eq = nmv[x] == nstar;
+                        take[x] = in_r && (nmv[x] > nstar || (eq && before < rstar));
+                        sel += take[x]; before += in_r && eq;
+                    }
+                    const uint32_t inc = wave_incl_scan(sel);
+                    uint32_t base = 0; if (lane == 63 && inc) base = atomicAdd((uint32_t*)&misc[S_NB], inc);
+                    uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)base, 63) + inc - sel;
+#pragma unroll
+                    for (int x = 0; x < 6; ++x) if (take[x]) publish(at++, dv[x]);
+                } else {
                 uint32_t mine = 0;
                 for (uint32_t o = o0; o < o1; ++o) mine += num_of(D[o]) == nstar;
                 uint32_t tot_star;
@@ -782,6 +806,7 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
                     const uint32_t v = D[o], nm = num_of(v);
                     if (nm > nstar || (nm == nstar && before < rstar)) publish(at++, v);
                     before += nm == nstar;
+                }
                 }
             }
             __syncthreads();
