@@ -289,9 +289,10 @@ __device__ void block_top64(uint64_t* ckey, uint32_t* cidx, uint32_t cnt) {
     ckey[wave * 64 + lane] = rk; cidx[wave * 64 + lane] = ri;
     __syncthreads();
 #pragma unroll
-    for (int half = NW / 2; half >= 1; half >>= 1) {
-        if (wave < half) {
-            wave_fold(rk, ri, ckey[(wave + half) * 64 + lane], cidx[(wave + half) * 64 + lane], lane);
+    for (int n = NW; n > 1; n = (n + 1) / 2) {   // (any number of waves: fold the upper half onto the lower)
+        const int up = (n + 1) / 2;
+        if (wave + up < n) {
+            wave_fold(rk, ri, ckey[(wave + up) * 64 + lane], cidx[(wave + up) * 64 + lane], lane);
             ckey[wave * 64 + lane] = rk; cidx[wave * 64 + lane] = ri;
         }
         __syncthreads();
