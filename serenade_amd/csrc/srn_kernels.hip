@@ -138,7 +138,7 @@ __device__ __forceinline__ uint32_t sel_word(uint32_t bin) { return bin + (bin >
 // misc[S_SELR] = rank of the wanted entry inside that bin, and clears the histogram.  The histogram must be complete
 // (barrier) on entry; ends with a barrier.
 template <int BLOCK>
-__device__ void hist_search(uint32_t* hist, uint32_t remain, volatile uint32_t* misc) {
+__device__ void hist_search(uint32_t* hist, uint32_t remain, uint32_t* misc) {
     const int tid = threadIdx.x;
     if (tid < 64) {
         constexpr int PER = SEL_BINS / 64;   // 32 bins per lane, kept as 4 group sums of 8 (not 32 registers)
@@ -173,7 +173,7 @@ __device__ void hist_search(uint32_t* hist, uint32_t remain, volatile uint32_t* 
     __syncthreads();
 }
 template <int BLOCK, typename KeyT, typename F>
-__device__ KeyT block_select_desc(F keyfn, uint32_t n, int nbits, uint32_t r, uint32_t* hist, volatile uint32_t* misc) {
+__device__ KeyT block_select_desc(F keyfn, uint32_t n, int nbits, uint32_t r, uint32_t* hist, uint32_t* misc) {
     const int tid = threadIdx.x;
     KeyT prefix = 0;   // value of the bits above `rem`
     uint32_t remain = r;
@@ -202,7 +202,7 @@ __device__ KeyT block_select_desc(F keyfn, uint32_t n, int nbits, uint32_t r, ui
 // exclusive prefix sum of one value per thread over the block (thread order); `scratch` = NWAVES words of LDS that nobody
 // else touches until the next barrier after the call; one barrier inside.  total = sum over the block.
 template <int BLOCK>
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, volatile uint32_t* scratch, uint32_t& total) {
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* scratch, uint32_t& total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t inc = wave_incl_scan(v);
     if (lane == 63) scratch[wave] = inc;
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
     constexpr SlotT SEMPTY = SlotTraits<SlotT>::EMPTY;
 
     // ---- LDS carve-up ------------------------------------------------------------------
-    volatile uint32_t* misc = (volatile uint32_t*)smem;                       // MISC_WORDS
+    uint32_t* misc = (uint32_t*)smem;                       // MISC_WORDS
     uint64_t* q_raw = (uint64_t*)(smem + c.off_q);                            // q_cap   raw ids, pos 0 = most recent
     unsigned long long* l_base = (unsigned long long*)(q_raw + c.q_cap);      // q_cap   posting list start
     uint32_t* q_idx = (uint32_t*)(l_base + c.q_cap);                          // q_cap   dense idx or kNone
