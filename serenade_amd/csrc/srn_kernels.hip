@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void vmis_prep_kernel(DeviceIndex ix, const ui
 #define SRN_STOP_AT (-1)   // experiments only (tools/phase_insts.sh): leave the query after phase tick N (0..4, 8..10) to count instructions per phase
 #endif
 #define SRN_TICK(ph)                                                                                         \
-    do { if (p.phase_cycles && tid == 0) { const long long t_ = clock64(); atomicAdd(&p.phase_cycles[ph], (unsigned long long)(t_ - t_prev)); t_prev = t_; } } while (0); \
+    do { if (ticking && tid == 0) { const long long t_ = clock64(); atomicAdd(&p.phase_cycles[ph], (unsigned long long)(t_ - t_prev)); t_prev = t_; } } while (0); \
     if (SRN_STOP_AT == (ph)) continue
 
 // WG_PER_CU = workgroups the build is meant to co-reside with: 2 (4 waves per SIMD, <= 128 VGPRs) or 3 (6 waves, <= 80 VGPRs: more
@@ -517,6 +517,11 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
     const uint32_t inb = c.item_buckets, H = c.hot_slots, SB = c.sum_bits, SK = c.sketch_slots, SKM = c.sketch_slots - 1u;
     const uint32_t nq_eff = aux.qlist ? *aux.qlist_n : p.nq;
 
+    // Read once what the inner loops keep asking for: with machine LICM off (build flag) a kernel-argument field used inside a
+    // loop is re-read there -- an s_load plus a wait that also drains the LDS queue -- every iteration.
+    const uint32_t n_kept = ix.n_kept;
+    const bool dump_nb = p.nb_rank != nullptr, ticking = p.phase_cycles != nullptr;
+    const double idf_hi = ix.idf_hi;
     for (uint32_t qi = blockIdx.x; qi < nq_eff; qi += gridDim.x) {
         const uint32_t q = aux.qlist ? aux.qlist[qi] : qi;
         // with a prep record every global read of this phase is issued here, in one round: the head (uniform), the first
@@ -538,7 +543,7 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
         }
         // ---- phase 0: reset, translate items ---------------------------------------------
         __syncthreads();   // previous query's LDS reads are done
-        long long t_prev = p.phase_cycles ? clock64() : 0;
+        long long t_prev = ticking ? clock64() : 0;
         if (tid < MISC_WORDS) misc[tid] = 0;
         for (uint32_t i = tid; i < SEL_WORDS; i += BLOCK) hist[i] = 0;
         if (MASKS && tid < 256) { uint32_t acc = 0; for (uint32_t b = 0; b < L; ++b) if ((tid >> b) & 1) acc += L - b; wlut[tid] = (uint8_t)acc; }
@@ -724,7 +729,7 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
             SRN_TICK(2);
             auto publish = [&](uint32_t at, uint32_t v) {
                 nbl[at] = v; nb_spill[at] = v;
-                if (p.nb_rank) { p.nb_rank[(size_t)q * p.k + at] = v >> NB; p.nb_num[(size_t)q * p.k + at] = num_of(v); } };
+                if (dump_nb) { p.nb_rank[(size_t)q * p.k + at] = v >> NB; p.nb_num[(size_t)q * p.k + at] = num_of(v); } };
             if (Cm <= p.k) {   // every candidate is a neighbour (F in bufx is dead: the neighbour list overwrites it)
                 for (uint32_t e = tid; e < Cm; e += BLOCK) publish(e, D[e]);
                 if (tid == 0) misc[S_NB] = Cm;
@@ -1002,7 +1007,7 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
                         for (uint32_t i = tid; i < kk; i += BLOCK) {
                             const SlotT v = kcut ? tmp[i] : dl[i];
                             if (STAGE == 1) ((SlotT*)sh.cand)[(size_t)q * p.m + i] = v; else { if (kcut) nbl[i] = v; if (STAGE == 0) nb_spill[i] = v; }
-                            if (STAGE == 0 && p.nb_rank) { p.nb_rank[(size_t)q * p.k + i] = (uint32_t)(v >> NB); p.nb_num[(size_t)q * p.k + i] = num_of(v); }
+                            if (STAGE == 0 && dump_nb) { p.nb_rank[(size_t)q * p.k + i] = (uint32_t)(v >> NB); p.nb_num[(size_t)q * p.k + i] = num_of(v); }
                         }
                         if (kcut) { __syncthreads(); if (tid == 0) misc[S_NB] = kk; }   // every thread has read |D| long ago
                     }
@@ -1049,7 +1054,7 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
                 if ((bm[u] >> lane) & 1ull) {
                     const uint32_t at = base + (uint32_t)__popcll(bm[u] & ((1ull << lane) - 1ull));
                     if (STAGE == 1) ((SlotT*)sh.cand)[(size_t)q * p.m + at] = sv[u]; else { nbl[at] = sv[u]; if (STAGE == 0) nb_spill[at] = sv[u]; }
-                    if (STAGE == 0 && p.nb_rank) { p.nb_rank[(size_t)q * p.k + at] = (uint32_t)(sv[u] >> NB); p.nb_num[(size_t)q * p.k + at] = num_of(sv[u]); }
+                    if (STAGE == 0 && dump_nb) { p.nb_rank[(size_t)q * p.k + at] = (uint32_t)(sv[u] >> NB); p.nb_num[(size_t)q * p.k + at] = num_of(sv[u]); }
                 }
                 base += (uint32_t)__popcll(bm[u]);
             }
@@ -1112,7 +1117,7 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
             auto slot_of = [&](uint32_t j, uint32_t& num) -> size_t {   // lanes past the last neighbour read the all-EMPTY slot n_kept
                 const SlotT s = nb_at(min(j, K - 1));
                 num = j < K ? (uint32_t)(s & num_mask) : 0u;
-                return j < K ? (size_t)(uint32_t)(s >> NB) : (size_t)ix.n_kept; };
+                return j < K ? (size_t)(uint32_t)(s >> NB) : (size_t)n_kept; };
             constexpr uint32_t GSTEP = NWAVES * 64;
             uint32_t num, nnum;
             size_t r = slot_of(wave * 64 + lane, num), nr;
@@ -1196,12 +1201,12 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
             uint32_t qn = 0;
             if ((uint32_t)wave * 64 < K) {
                 SlotT sv = nb_at(min((uint32_t)(wave * 64 + lane), K - 1)), nsv = 0;
-                size_t r = (uint32_t)(wave * 64 + lane) < K ? (size_t)(uint32_t)(sv >> NB) : (size_t)ix.n_kept;
+                size_t r = (uint32_t)(wave * 64 + lane) < K ? (size_t)(uint32_t)(sv >> NB) : (size_t)n_kept;
                 RowQuad a = ix.row_slots[4 * r], b = ix.row_slots[4 * r + 1], na, nb;
                 for (uint32_t g0 = wave * 64; g0 < K; g0 += GSTEP) {   // (i)
                     const uint32_t jn = g0 + GSTEP + lane;
                     nsv = nb_at(min(jn, K - 1));
-                    const size_t nr = jn < K ? (size_t)(uint32_t)(nsv >> NB) : (size_t)ix.n_kept;
+                    const size_t nr = jn < K ? (size_t)(uint32_t)(nsv >> NB) : (size_t)n_kept;
                     na = ix.row_slots[4 * nr]; nb = ix.row_slots[4 * nr + 1];
                     const uint32_t len = a.x;   // (0 for the idle lanes' empty slot)
                     const int w = weight_of((uint32_t)(sv & num_mask));
@@ -1219,7 +1224,7 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
             for (uint32_t p0 = 0; p0 < qn; p0 += 64) {   // (ii)
                 const bool act = p0 + lane < qn;
                 const SlotT sv = queue[qpos(min(p0 + lane, qn - 1))];
-                const size_t r = act ? (size_t)(uint32_t)(sv >> NB) : (size_t)ix.n_kept;
+                const size_t r = act ? (size_t)(uint32_t)(sv >> NB) : (size_t)n_kept;
                 const RowQuad c4 = ix.row_slots[4 * r + 2], d4 = ix.row_slots[4 * r + 3];
                 const uint32_t len = ix.row_slots[4 * r].x;
                 const int w = weight_of((uint32_t)(sv & num_mask));
@@ -1233,7 +1238,7 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
             for (uint32_t p0 = 0; p0 < qn2; p0 += 64) {   // (iii)
                 const bool act = p0 + lane < qn2;
                 const SlotT sv = queue[qpos(min(p0 + lane, qn2 - 1))];
-                const size_t r = act ? (size_t)(uint32_t)(sv >> NB) : (size_t)ix.n_kept;
+                const size_t r = act ? (size_t)(uint32_t)(sv >> NB) : (size_t)n_kept;
                 const RowQuad a = ix.row_slots[4 * r];
                 const uint32_t len = a.x; const bool big = len > 15;
                 const uint32_t* ext = ix.row_ext + (big ? a.y : 0u);
@@ -1311,7 +1316,7 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
         auto acc_floor_of = [&](uint64_t tk) -> int {
             // smallest accumulator that could still reach the threshold: score <= idf_hi * acc / denom, so an item needs
             // acc >= thr * denom / idf_hi; shaved by a relative 1e-9 and one unit so that rounding can only keep more
-            return (int)fmin(2147483000.0, fmax(1.0, floor(key_score(tk) * denom / ix.idf_hi * (1.0 - 1e-9)) - 1.0)); };
+            return (int)fmin(2147483000.0, fmax(1.0, floor(key_score(tk) * denom / idf_hi * (1.0 - 1e-9)) - 1.0)); };
         // leaves the best min(cnt, n) candidates sorted at the front of the buffer, sets the threshold if n exist
         auto sort_candidates = [&](uint32_t cnt) {
             if (n_out <= 64 && cnt <= 64) {   // one wave sorts in registers, no merge levels
