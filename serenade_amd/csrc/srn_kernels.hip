@@ -1243,7 +1243,25 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
                 const uint32_t len = a.x; const bool big = len > 15;
                 const uint32_t* ext = ix.row_ext + (big ? a.y : 0u);
                 const int w = weight_of((uint32_t)(sv & num_mask));
-                for (uint32_t t = 14; __ballot(big && t < len) != 0ull; t += 8) {
+                // the first 24 overflow items (rows of <= 38) are requested together: one HBM latency for the round, not one per
+                // 8 items -- few rows come here, so the round is nothing but latency
+                constexpr int MAXV = 6;
+                RowVec pv[MAXV];
+#pragma unroll
+                for (int x = 0; x < MAXV; ++x) {
+                    pv[x] = RowVec{EMPTY32, EMPTY32, EMPTY32, EMPTY32};
+                    if (big && 14u + 4u * x < len) pv[x] = *reinterpret_cast<const RowVec*>(ext + 4 * x);
+                }
+#pragma unroll
+                for (int x = 0; x < MAXV; x += 2) {
+                    const uint32_t t = 14u + 4u * x;
+                    if (__ballot(big && t < len) == 0ull) break;
+                    uint32_t it8[8] = {pv[x].x, pv[x].y, pv[x].z, pv[x].w, pv[x + 1].x, pv[x + 1].y, pv[x + 1].z, pv[x + 1].w};
+#pragma unroll
+                    for (uint32_t y = 0; y < 8; ++y) if (!big || t + y >= len) it8[y] = EMPTY32;
+                    elem(it8, w);
+                }
+                for (uint32_t t = 14 + 4 * MAXV; __ballot(big && t < len) != 0ull; t += 8) {
                     uint32_t it8[8];
 #pragma unroll
                     for (int x = 0; x < 8; ++x) it8[x] = EMPTY32;
