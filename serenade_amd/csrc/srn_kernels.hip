@@ -623,7 +623,7 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
             uint32_t* bufx = wb; uint32_t* bufy = wb + P;
             const uint32_t nlv = nruns <= 1 ? 0u : (uint32_t)bits_for(nruns - 1);
             uint32_t* in = (nlv & 1u) ? bufy : bufx; uint32_t* out = (nlv & 1u) ? bufx : bufy;   // the final run lands in bufx
-            {   // stage, list by list (uniform base and weight: no per-element list look-up), 4 loads in flight per lane
+            {   // stage, list by list (uniform base and weight: no per-element list look-up), 5 loads in flight per lane
                 uint32_t run = 0;
                 for (uint32_t pos = 0; pos < L; ++pos) {
                     const uint32_t len = l_len[pos];   // (uniform)
@@ -632,12 +632,13 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
                     uint32_t* dst = in + l_pre[pos];
                     const uint32_t w = MASKS ? (1u << pos) : L - pos;
                     uint32_t kept = 0;
-                    for (uint32_t e0 = tid; e0 < len; e0 += 4 * BLOCK) {
-                        uint32_t r4[4];
+                    constexpr int SU = 5;   // 5 * 512 entries per trip: a full list of m = 2500 is one trip, one HBM latency
+                    for (uint32_t e0 = tid; e0 < len; e0 += SU * BLOCK) {
+                        uint32_t r4[SU];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) { const uint32_t e = e0 + u * BLOCK; r4[u] = e < len ? src[e] : 0u; }
+                        for (int u = 0; u < SU; ++u) { const uint32_t e = e0 + u * BLOCK; r4[u] = e < len ? src[e] : 0u; }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                        for (int u = 0; u < SU; ++u) {
                             const uint32_t e = e0 + u * BLOCK;
                             const bool keep = e < len && r4[u] >= x_lo;   // (the list is sorted: the kept entries are a prefix)
                             if (keep) dst[e] = (r4[u] << NB) | w;
