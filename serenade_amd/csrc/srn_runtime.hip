@@ -285,7 +285,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     }
     // Opt-in (SRN_DENSE=1): THREE workgroups per CU -- the 80-VGPR build of the kernel with a 52 KB LDS geometry -- and what that
     // geometry cannot hold goes through the normal one (second tier) before the global-table pass.  Measured on config 3 / 4:
-    // +8.6 % / +4.7 % queries/s (+2 % / 0 with the end-of-round kernel), but the 80-VGPR build's register spills double the memory traffic (14.5 -> 31.8 GB per launch), so it
+    // +8.6 % / +4.7 % queries/s (-1 % / -2 % with the end-of-round kernel), but the 80-VGPR build's register spills double the memory traffic (14.5 -> 31.8 GB per launch), so it
     // stays off until the build fits without spilling.
     Geometry g3; bool dense = !slot64 && getenv("SRN_DENSE") && !getenv("SRN_LDS_BUDGET_KB");
     if (dense && (make_geometry(d, ix, p, 0, g3, 52 * 1024) != SRN_OK || g3.slot64 || g3.masks != geo.masks)) dense = false;
