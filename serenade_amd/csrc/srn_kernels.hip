@@ -64,9 +64,6 @@ __device__ __forceinline__ uint64_t dev_mix64(uint64_t x) {
 __device__ __forceinline__ uint32_t hash_start(uint32_t key, uint32_t mask) { return ((key * 0x9E3779B1u) >> 7) & mask; }
 __device__ __forceinline__ uint32_t hash_step(uint32_t key, uint32_t mask) { return (((key * 0x85EBCA6Bu) >> 9) | 1u) & mask; }
 __device__ __forceinline__ uint32_t hash_part(uint32_t key, uint32_t parts) { return __umulhi(key * 0xC2B2AE35u, parts); }
-// sketch word of a non-hot item: full-rate 24-bit multiply (items that differ only above bit 23 share a word -- still an upper bound)
-// (hipcc's __umul24 yields a signed int: without the cast the shift is arithmetic and half the indices go negative)
-__device__ __forceinline__ uint32_t sketch_hash(uint32_t it, uint32_t shift) { return (uint32_t)__umul24(it, 0x9E3779u) >> shift; }
 __device__ __forceinline__ int bits_for(uint32_t v) { return v ? 32 - __clz((int)v) : 0; }
 
 __device__ __forceinline__ uint64_t score_key(double s) {   // order-preserving f64 -> u64
