@@ -672,6 +672,7 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
                     bool any = false;
 #pragma unroll
                     for (int pr = 0; pr < 4; ++pr) {
+                        if ((uint32_t)pr >= np) break;   // (uniform: no per-lane test for the pairs that do not exist)
                         if (lo[pr] < hi[pr]) {
                             const uint32_t mid = (lo[pr] + hi[pr]) >> 1;
                             if (in[sa[pr] + mid] > in[sb[pr] + d0[pr] - mid - 1]) lo[pr] = mid + 1; else hi[pr] = mid;
