@@ -211,6 +211,17 @@ int srn_kernel_times(const srn_index_t* idx, uint32_t max_n, double* out_ms_main
  * switches the accounting on (enable != 0) or off.  Not for production use. */
 int srn_debug_phase_cycles(const srn_index_t* idx, int enable, uint64_t* out16);
 
+/* How the queries of the most recent predict call on this handle were served: *out_nq queries in all, *out_general of them by
+ * the general kernel (the fast kernel hands over what does not fit its query shape; == nq when the launch was not eligible for
+ * the fast kernel at all), *out_global_pass through the global-table retry pass.  Waits for that call to finish. */
+int srn_last_path_counts(const srn_index_t* idx, uint32_t* out_nq, uint32_t* out_general, uint32_t* out_global_pass);
+
+/* Test / experiment knobs (environment variables SRN_NO_FAST, SRN_NO_MASKS, SRN_NO_MERGE, SRN_DENSE, SRN_HOT_SLOTS,
+ * SRN_SKETCH_SLOTS, SRN_LDS_BUDGET_KB, SRN_GRID_MULT, SRN_DEBUG) force individual kernel code paths.  They are read ONCE,
+ * when the library is first used -- never on the launch path; this call re-reads them (the parity tests switch paths
+ * between calls).  Not for production use: make sure no predict call is in flight. */
+void srn_debug_reload_knobs(void);
+
 /* ---- misc ------------------------------------------------------------------------------- */
 /* ---- dynamic batching: the serving-side caller ------------------------------------------------------------------
  * The reference answers every /v1/recommend call with its own vmisknn::predict on an actix worker

@@ -77,6 +77,8 @@ SYMBOLS = {
     "srn_shard_stage_c": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, C.c_uint, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "srn_kernel_times": (_i, [_vp, C.c_uint32, _vp, _vp, C.POINTER(C.c_uint32)]),
     "srn_debug_phase_cycles": (_i, [_vp, _i, _vp]),
+    "srn_debug_reload_knobs": (None, []),
+    "srn_last_path_counts": (_i, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "srn_device_count": (_i, [C.POINTER(_i)]),
     "srn_limits": (None, [C.POINTER(Limits)]),
     "srn_last_error": (C.c_char_p, []),
@@ -120,6 +122,11 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = L
     return _lib
+
+
+def reload_knobs():
+    """Re-read the SRN_* test knobs from the environment (the library reads them once, at first use)."""
+    lib().srn_debug_reload_knobs()
 
 
 def check(rc):

@@ -301,4 +301,11 @@ int srn_debug_phase_cycles(const srn_index_t* idx, int enable, uint64_t* out16) 
     return guarded([&]() -> int { return device_phase_cycles(idx->dev, enable, (unsigned long long*)out16); });
 }
 
+int srn_last_path_counts(const srn_index_t* idx, uint32_t* out_nq, uint32_t* out_general, uint32_t* out_global_pass) {
+    if (!idx || !idx->dev) return fail(SRN_ENODEV, "index has no device attached");
+    return guarded([&]() -> int { return device_last_path_counts(idx->dev, out_nq, out_general, out_global_pass); });
+}
+
+void srn_debug_reload_knobs(void) { reload_knobs(); }
+
 }  // extern "C"

@@ -1,0 +1,86 @@
+// Device-side primitives shared by the predict kernels (srn_kernels.hip, srn_fast.hip): DPP wave scans, one-atomic-per-wave
+// appends, the block scan and the exact item hash table.  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "srn_kernels.h"
+
+namespace srn {
+
+static constexpr int MAX_PROBES = 48;       // bucket probes (4 slots each) before a table is declared full
+
+// Wave-wide scans and reductions on the VALU's data-parallel-primitive path (row_shr inside the rows of 16 lanes, then
+// row_bcast 15 / 31 across them): ~12 VALU instructions.  The __shfl_* forms compile to ds_bpermute_b32, i.e. six DEPENDENT
+// LDS round trips per scan, on a kernel whose LDS pipe is the busiest unit.
+#define SRN_DPP(v, ctrl, rmask, bctl) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rmask, 0xf, bctl)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {   // lane i <- v[0] + ... + v[i]
+    v += SRN_DPP(v, 0x111, 0xf, true);    // row_shr:1 (0 shifted in at the row start)
+    v += SRN_DPP(v, 0x112, 0xf, true);    // row_shr:2
+    v += SRN_DPP(v, 0x114, 0xf, true);    // row_shr:4
+    v += SRN_DPP(v, 0x118, 0xf, true);    // row_shr:8
+    v += SRN_DPP(v, 0x142, 0xa, false);   // row_bcast:15 -> rows 1 and 3
+    v += SRN_DPP(v, 0x143, 0xc, false);   // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {   // (uniform result)
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v), 63);
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {   // (uniform result)
+    v = max(v, SRN_DPP(v, 0x111, 0xf, true));
+    v = max(v, SRN_DPP(v, 0x112, 0xf, true));
+    v = max(v, SRN_DPP(v, 0x114, 0xf, true));
+    v = max(v, SRN_DPP(v, 0x118, 0xf, true));
+    v = max(v, SRN_DPP(v, 0x142, 0xa, false));
+    v = max(v, SRN_DPP(v, 0x143, 0xc, false));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// one LDS atomic per wave: returns this lane's slot in a shared append buffer (only meaningful if pred)
+__device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0) return 0;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// exclusive prefix sum of one value per thread over the block (thread order); `scratch` = NWAVES words of LDS that nobody
+// else touches until the next barrier after the call; one barrier inside.  total = sum over the block.
+template <int BLOCK>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* scratch, uint32_t& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t inc = wave_incl_scan(v);
+    if (lane == 63) scratch[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0; total = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) { const uint32_t t = scratch[w]; total += t; if (w < wave) base += t; }
+    return base + inc - v;
+}
+
+// insert-or-add into the exact item table: 4-slot buckets (one ds_read_b128 per probe), double hashing over a prime number of
+// buckets, separate key / accumulator arrays; accumulators are signed.  Returns 1 if the item was new, 0 if it existed, -1 = table full
+__device__ __forceinline__ int item_insert(uint32_t* ikeys, int* iacc, uint32_t nb, uint32_t it, int w) {
+    uint32_t b = __umulhi(it * 0x9E3779B1u, nb);                       // nb is prime: any step in [1, nb) cycles through all buckets
+    const uint32_t step = 1u + __umulhi(it * 0x85EBCA6Bu, nb - 1u);
+    for (int probe = 0; probe < MAX_PROBES;) {
+        const uint4 v = *reinterpret_cast<const uint4*>(&ikeys[4 * b]);
+        const int hit = v.x == it ? 0 : v.y == it ? 1 : v.z == it ? 2 : v.w == it ? 3 : -1;
+        if (hit >= 0) { atomicAdd(&iacc[4 * b + hit], w); return 0; }
+        const int empty = v.x == EMPTY32 ? 0 : v.y == EMPTY32 ? 1 : v.z == EMPTY32 ? 2 : v.w == EMPTY32 ? 3 : -1;
+        if (empty >= 0) {
+            const uint32_t old = atomicCAS(&ikeys[4 * b + empty], EMPTY32, it);
+            if (old == EMPTY32) { atomicAdd(&iacc[4 * b + empty], w); return 1; }
+            if (old == it) { atomicAdd(&iacc[4 * b + empty], w); return 0; }
+            continue;   // another item took that slot meanwhile: look at this bucket again
+        }
+        b += step; if (b >= nb) b -= nb;
+        ++probe;
+    }
+    return -1;
+}
+
+
+}  // namespace srn

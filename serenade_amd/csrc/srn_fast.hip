@@ -1,0 +1,599 @@
+// =====================================================================================
+// VMIS-kNN predict_next on gfx950 (MI355X): the FAST kernel -- the lean instantiation of the path for the query shape a
+// production workload consists of: evolving sessions of <= 8 items of which <= 4 distinct known ones
+// have a non-empty posting list above x_lo, position-set slots (MASKS), 32-bit slots, k <= 1536, m <= 2560, how_many <= 24,
+// no business rules, no debug outputs.  Everything else -- and every query this kernel meets that does not fit -- is
+// queued on a device-side list and served by vmis_predict_kernel (srn_kernels.hip) in a second launch: still on the GPU,
+// same results, bit for bit.  Same algorithm as the general kernel (find_neighbors src/vmisknn/vmis_index.rs:325-415,
+// predict src/vmisknn/mod.rs:118-215, canonical semantics of DESIGN.md section 1); what differs:
+//
+//   * the posting lists are staged with the lengths the prep kernel found (entries >= x_lo), every load of every list
+//     in flight at once, and the run tables of the merge tree live in SGPRs (<= 4 runs, 2 levels);
+//   * rows come from a second row array: 64-byte slots of 16-BIT LDS BYTE OFFSETS (30 items per slot), the offset of
+//     an item's accumulator word -- direct-mapped for the 4096 most popular items, a sketch word for the rest -- so the
+//     row walks cost one extract + one ds_add per item; unused positions hold offsets into a dump area (rows of
+//     different lengths need no masking);
+//   * a wave's first-round row quads stay in registers between walk A and walk B; walk B only reads sketch words,
+//     and an element whose word could still reach the threshold fetches its item id from the general row slots;
+//   * the top-n runs in x = idf * acc space (one f64 multiply per candidate, the divide by 10 U only for the <= 160
+//     final candidates), with per-chunk integer floors (popular items have small idf), survivors compacted before they
+//     are scored, and a final rank-by-counting instead of a sort.
+// =====================================================================================
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+#include "srn_device.h"
+#include "srn_kernels.h"
+
+namespace srn {
+
+// scalar words at the head of LDS
+enum { FS_NB = 0, FS_FAIL, FS_SURV, FS_CCNT, FS_HITS, FS_SCAN_A = 8, FS_SCAN_B = 8, FS_W3 = 8, FS_CLS = 16, FS_TACC = 32 };   // (the three scratch areas are never live together; words 32..63: debug counters)
+static constexpr uint32_t F_TOTAL = F_LDS_BYTES;
+static constexpr uint32_t F_MERGE_WORDS = F_WORK_WORDS;
+
+// per-phase cycle accounting (debug): summed per workgroup in LDS, flushed once at the end -- one global atomic per phase and
+// query (as the general kernel does) serialises on 16 addresses and distorts what it measures
+#define FAST_TICK(ph) \
+    do { if (ticking && tid == 0) { const long long t_ = clock64(); tacc[ph] += (unsigned long long)(t_ - t_prev); t_prev = t_; } } while (0)
+
+// -------------------------------------------------------------------------------------
+// Row layout kernel (attach time): CSR rows -> 64-byte slots of 16-bit LDS byte offsets (relative to F_HOT) + overflow
+// blocks.  halfword 0 = row length, 1 = 0, 2..31 = items 0..29; rows longer than 30: halfwords 2..29 = items 0..27, word
+// 15 = index of the row's first 16-byte overflow block (8 items each, items 28..).  Unused positions hold offsets
+// into the dump area, spread by a hash of (row, position).  Slot n is the empty row.
+// -------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fast_offset_of(uint32_t idx) {
+    return idx < F_HOT_WORDS ? idx * 4u : (F_SKETCH - F_HOT) + (idx & (F_SK_WORDS - 1u)) * 4u;
+}
+__device__ __forceinline__ uint32_t fast_phantom(uint64_t r, uint32_t j) {
+    return (F_DUMP - F_HOT) + ((((uint32_t)r * 0x9E3779B1u + j * 0x85EBCA6Bu) >> 21) & (F_DUMP_WORDS - 1u)) * 4u;
+}
+__global__ __launch_bounds__(1024) void rows_to_packed_kernel(const uint64_t* __restrict__ row_off, const uint32_t* __restrict__ row_items, uint64_t n,
+                                                              const uint32_t* __restrict__ block_base, uint32_t* __restrict__ packed, uint32_t* __restrict__ ext16) {
+    __shared__ uint32_t wave_tot[16];
+    const uint64_t r = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t o = 0, len = 0;
+    if (r < n) { o = row_off[r]; len = row_off[r + 1] - o; }
+    const uint32_t e = len > 30 ? (uint32_t)((len - 28 + 7) / 8) : 0u;   // overflow blocks of this row
+    const uint32_t inc = wave_incl_scan(e);
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t base = block_base[blockIdx.x];
+    for (int w = 0; w < wave; ++w) base += wave_tot[w];
+    const uint32_t eblk = base + inc - e;
+    if (r > n) return;
+    const uint32_t inl = len > 30 ? 28u : (uint32_t)len;
+    uint32_t sl[16];
+    auto half = [&](uint32_t j) -> uint32_t { return j < inl ? fast_offset_of(row_items[o + j]) : fast_phantom(r, j); };
+    sl[0] = (uint32_t)(len > 0xFFFFu ? 0xFFFFu : len);
+#pragma unroll
+    for (uint32_t wd = 1; wd < 16; ++wd) sl[wd] = half(2 * wd - 2) | (half(2 * wd - 1) << 16);
+    if (len > 30) {
+        sl[15] = eblk;
+        for (uint32_t b = 0; b < e; ++b) {
+            uint32_t wv[4];
+#pragma unroll
+            for (uint32_t x = 0; x < 4; ++x) {
+                const uint64_t j0 = 28 + 8ull * b + 2 * x;
+                const uint32_t lo = j0 < len ? fast_offset_of(row_items[o + j0]) : fast_phantom(r, (uint32_t)j0);
+                const uint32_t hi = j0 + 1 < len ? fast_offset_of(row_items[o + j0 + 1]) : fast_phantom(r, (uint32_t)j0 + 1);
+                wv[x] = lo | (hi << 16);
+            }
+            reinterpret_cast<uint4*>(ext16)[(size_t)eblk + b] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+        }
+    }
+    uint4* dst = reinterpret_cast<uint4*>(packed + r * 16);
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) dst[qd] = make_uint4(sl[4 * qd], sl[4 * qd + 1], sl[4 * qd + 2], sl[4 * qd + 3]);
+}
+
+// -------------------------------------------------------------------------------------
+// merge path over two adjacent sorted (descending) runs A = in[sa, sa + la), B = in[sa + la, sa + la + lb) -> out[sa, ...):
+// thread t produces outputs [t g, (t + 1) g).  All values are distinct (the position bit differs between lists).
+// -------------------------------------------------------------------------------------
+__device__ __forceinline__ void merge_pair(const uint32_t* in, uint32_t* out, uint32_t sa, uint32_t la, uint32_t lb, uint32_t tid) {
+    const uint32_t sb = sa + la, total = la + lb, g = (total + 511u) >> 9;
+    const uint32_t d0 = min(tid * g, total), d1 = min(d0 + g, total);
+    if (d0 >= d1) return;
+    uint32_t lo = d0 > lb ? d0 - lb : 0u, hi = min(d0, la);
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (in[sa + mid] > in[sb + d0 - 1 - mid]) lo = mid + 1; else hi = mid;
+    }
+    uint32_t i = lo, j = d0 - lo;
+    uint32_t va = i < la ? in[sa + i] : 0u, vb = j < lb ? in[sb + j] : 0u;   // (a staged slot is never 0)
+    uint32_t* C = out + sa;
+    for (uint32_t o = d0; o < d1; ++o) {
+        const bool ta = va > vb;
+        C[o] = ta ? va : vb;
+        i += ta; j += !ta;
+        const bool more = ta ? i < la : j < lb;
+        const uint32_t nxt = in[ta ? sa + i : sb + j];   // (past a run's end: a neighbour's entry or scratch, discarded)
+        const uint32_t nv = more ? nxt : 0u;
+        va = ta ? nv : va; vb = ta ? vb : nv;
+    }
+}
+
+template <int WG_PER_CU>
+#ifndef SRN_FAST_WAVES
+#define SRN_FAST_WAVES (WG_PER_CU * 2)
+#endif
+__global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIndex ix_arg, LaunchParams p_arg, FastParams f_arg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef const __attribute__((address_space(4))) char* KArg;
+    const KArg ka = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr size_t OFF_P = (sizeof(DeviceIndex) + alignof(LaunchParams) - 1) / alignof(LaunchParams) * alignof(LaunchParams);
+    constexpr size_t OFF_F = (OFF_P + sizeof(LaunchParams) + alignof(FastParams) - 1) / alignof(FastParams) * alignof(FastParams);
+    const __attribute__((address_space(4))) DeviceIndex& ix = *(const __attribute__((address_space(4))) DeviceIndex*)ka;
+    const __attribute__((address_space(4))) LaunchParams& p = *(const __attribute__((address_space(4))) LaunchParams*)(ka + OFF_P);
+    const __attribute__((address_space(4))) FastParams& f = *(const __attribute__((address_space(4))) FastParams*)(ka + OFF_F);
+    constexpr int BLOCK = 512, NW = 8;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+
+    uint32_t* misc = (uint32_t*)(smem + F_MISC);
+    uint8_t* wlut = (uint8_t*)(smem + F_WLUT);            // numerator of each position set
+    uint16_t* w10t = (uint16_t*)(smem + F_W10);           // 10 * linear_score(first match) * numerator of each position set
+    uint32_t* nbl = (uint32_t*)(smem + F_NBL);            // neighbours; in the walks also the waves' row queues
+    unsigned long long* ckey = (unsigned long long*)(smem + F_CAND);   // candidates: x = idf_eff * acc (f64 bits), then the score
+    uint32_t* cidx = (uint32_t*)(smem + F_CAND + F_CAND_CAP * 8);      //             id rank (tie-break key)
+    char* const acc_base = smem + F_HOT;
+    uint32_t* hot = (uint32_t*)(smem + F_HOT);
+    uint32_t* ikeys = (uint32_t*)(smem + F_TABLE);
+    int* iacc = (int*)(smem + F_TABLE + F_TABLE_WORDS * 4);
+    uint2* hits = (uint2*)(smem + F_HITS);
+    uint32_t* surv = (uint32_t*)(smem + F_SURV);
+    constexpr uint32_t SURV_CAP = F_SURV_WORDS - 256u;
+    uint32_t* thist = surv + SURV_CAP;                    // 256 bins: the sample's candidates by the top 16 bits of x, relative to the first threshold
+
+    unsigned long long* tacc = (unsigned long long*)(smem + F_MISC + FS_TACC * 4);   // 16 debug counters, kept across the queries
+    if (tid < 16u) tacc[tid] = 0ull;
+    const uint32_t NB = f.nb, NBM = (1u << NB) - 1u;
+    const bool ticking = p.phase_cycles != nullptr;
+    const uint32_t n_kept = ix.n_kept;
+    auto qpos = [&](uint32_t pq) -> uint32_t { return ((wave + NW * (pq >> 6)) << 6) + (pq & 63u); };   // the wave's own neighbour-list slots
+
+    for (uint32_t q = blockIdx.x; q < p.nq; q += gridDim.x) {
+        // ---- phase 0: the query's prep record -> run descriptors in SGPRs ------------------------------
+        const char* const rec = p.prep + (size_t)q * p.prep_stride;
+        const PrepHead hd = *(const PrepHead*)rec;   // (uniform address)
+        PrepItem x0{kNone, 0u, 0u, 0u, 0ull};
+        if (lane < 8u && lane < hd.L) x0 = ((const PrepItem*)(rec + sizeof(PrepHead)))[lane];
+        const uint32_t L = hd.L, n = hd.n_staged, U = hd.U;
+        unsigned long long rm = __ballot(x0.kept > 0u);
+        const uint32_t nr = (uint32_t)__popcll(rm);
+        const bool fits = L >= 1u && L <= 8u && L <= p.max_len && hd.sumw <= 15u && nr <= 4u && 2u * n + 8u <= F_MERGE_WORDS;
+        if (!fits) {   // block-uniform: the general kernel takes it
+            if (tid == 0) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q;
+            continue;
+        }
+        if (n == 0u) { if (tid == 0) p.out_counts[q] = 0u; continue; }   // no known item (vmis_index.rs:350): empty result
+        uint32_t kp[4], ps[4]; const uint32_t* src[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int l = rm ? __ffsll((long long)rm) - 1 : 0;
+            kp[r] = rm ? (uint32_t)__builtin_amdgcn_readlane((int)x0.kept, l) : 0u;
+            const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x0.base, l), bhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x0.base >> 32), l);
+            src[r] = ix.post_rank + (((unsigned long long)bhi << 32) | blo);
+            ps[r] = (uint32_t)l;
+            rm &= rm - 1ull;
+        }
+        const uint32_t cur_idx = (uint32_t)__builtin_amdgcn_readlane((int)x0.idx, 0);
+        const uint32_t s1 = kp[0], s2 = s1 + kp[1], s3 = s2 + kp[2];
+
+        __syncthreads();   // previous query's LDS reads are done
+        long long t_prev = ticking ? clock64() : 0;
+        if (tid < (uint32_t)FS_TACC) misc[tid] = 0;
+        if (tid < (1u << L)) {
+            uint32_t num = 0;
+            for (uint32_t b = 0; b < L; ++b) if ((tid >> b) & 1u) num += L - b;
+            const uint32_t mp = tid ? (uint32_t)__ffs((int)tid) - 1u : 0u;   // lowest set position = first match (Q4)
+            wlut[tid] = (uint8_t)num; w10t[tid] = (uint16_t)((9u - mp) * num);
+        }
+        // ---- phase 1: stage the lists' kept prefixes as packed slots (rank << NB | position bit) ---------
+        uint32_t* const B0 = (uint32_t*)(smem + F_WORK); uint32_t* const B1 = B0 + n;
+        const uint32_t nl = (nr > 1u) + (nr > 2u);
+        {
+            uint32_t v[4][5];   // every load of every list in flight at once (uniform skips; past a list's end the lanes re-read its last entry)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) { v[r][j] = 0u; if ((uint32_t)j * BLOCK < kp[r]) v[r][j] = src[r][min(tid + j * BLOCK, kp[r] - 1u)]; }
+            uint32_t* const d01 = nl == 1u ? B1 : B0; uint32_t* const d2 = nr == 3u ? B1 : B0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                uint32_t* const dst = (r < 2 ? d01 : r == 2 ? d2 : B0) + (r == 0 ? 0u : r == 1 ? s1 : r == 2 ? s2 : s3);
+#pragma unroll
+                for (int j = 0; j < 5; ++j) { const uint32_t e = tid + j * BLOCK; if ((uint32_t)j * BLOCK < kp[r] && e < kp[r]) dst[e] = (v[r][j] << NB) | (1u << ps[r]); }
+            }
+        }
+        __syncthreads();
+        FAST_TICK(1);
+        // ---- merge tree: <= 2 levels, the final run lands in B0 ------------------------------------------
+        if (nr == 2u) { merge_pair(B1, B0, 0u, kp[0], kp[1], tid); __syncthreads(); }
+        else if (nr == 3u) { merge_pair(B0, B1, 0u, kp[0], kp[1], tid); __syncthreads(); merge_pair(B1, B0, 0u, s2, kp[2], tid); __syncthreads(); }
+        else if (nr == 4u) { merge_pair(B0, B1, 0u, kp[0], kp[1], tid); merge_pair(B0, B1, s2, kp[2], kp[3], tid); __syncthreads();
+                             merge_pair(B1, B0, 0u, s2, kp[2] + kp[3], tid); __syncthreads(); }
+        const uint32_t* F = B0; uint32_t* D = B1;
+        // ---- m-cut: the copies of a session are adjacent in F; the first m distinct sessions, position sets OR-ed ----
+        uint32_t Call, Cm;
+        {
+            const uint32_t g = (n + BLOCK - 1) / BLOCK, o0 = min(tid * g, n), o1 = min(o0 + g, n);
+            uint32_t firsts = 0;
+            uint32_t prev = o0 > 0u && o0 < o1 ? F[o0 - 1] >> NB : 0xFFFFFFFFu;
+            const uint32_t prev0 = prev;
+            for (uint32_t o = o0; o < o1; ++o) { const uint32_t r = F[o] >> NB; firsts += o == 0u || r != prev; prev = r; }
+            for (uint32_t i = tid; i < min(n, p.m); i += BLOCK) D[i] = 0;
+            uint32_t idx = block_excl_scan<BLOCK>(firsts, misc + FS_SCAN_A, Call);   // (barrier inside)
+            prev = prev0;
+            for (uint32_t o = o0; o < o1; ++o) {
+                const uint32_t v = F[o], r = v >> NB;
+                const bool first = o == 0u || r != prev; prev = r;
+                idx += first;
+                if (idx - 1u < p.m) atomicOr(&D[idx - 1u], v);
+            }
+            Cm = min(Call, p.m);
+        }
+        __syncthreads();
+        FAST_TICK(2);
+        // ---- k-cut: D is ordered by recency, so inside one numerator class the order is already the wanted one ----
+        if (Cm <= p.k) {
+            for (uint32_t e = tid; e < Cm; e += BLOCK) nbl[e] = D[e];
+            if (tid == 0) misc[FS_NB] = Cm;
+        } else {
+            uint32_t* cls = misc + FS_CLS;
+            const uint32_t g = (Cm + BLOCK - 1) / BLOCK, o0 = min(tid * g, Cm), o1 = min(o0 + g, Cm);   // g <= 5
+            uint32_t dv[5], nmv[5];
+#pragma unroll
+            for (int x = 0; x < 5; ++x) dv[x] = o0 + x < o1 ? D[o0 + x] : 0u;
+#pragma unroll
+            for (int x = 0; x < 5; ++x) nmv[x] = o0 + x < o1 ? (uint32_t)wlut[dv[x] & NBM] : 0u;   // (class 0 does not exist)
+            {   // class counts: 16 fields of 4 bits per thread, spread over 4 x 64 bits with 16-bit fields, 8 DPP wave sums
+                unsigned long long acc = 0;
+#pragma unroll
+                for (int x = 0; x < 5; ++x) acc += o0 + x < o1 ? 1ull << (4u * nmv[x]) : 0ull;
+                uint32_t tot[8];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const unsigned long long t = (acc >> (4 * jj)) & 0x000F000F000F000Full;
+                    tot[2 * jj] = wave_sum((uint32_t)t); tot[2 * jj + 1] = wave_sum((uint32_t)(t >> 32));
+                }
+                const uint32_t dw = (lane & 3u) * 2u + (lane >> 3);   // class = lane: word lane & 3, field lane >> 2
+                uint32_t pick = tot[0];
+#pragma unroll
+                for (int x = 1; x < 8; ++x) pick = dw == (uint32_t)x ? tot[x] : pick;
+                const uint32_t mycnt = lane < 16u ? (pick >> (16u * ((lane >> 2) & 1u))) & 0xFFFFu : 0u;
+                if (mycnt) atomicAdd(&cls[lane], mycnt);
+            }
+            __syncthreads();
+            uint32_t nstar, rstar;
+            {   // lane v holds class v: suffix sums from the best class down; the boundary class is the highest one whose suffix reaches k
+                const uint32_t cv = lane < 16u ? cls[lane] : 0u; const uint32_t pre = wave_incl_scan(cv);
+                const uint32_t suf = (uint32_t)__builtin_amdgcn_readlane((int)pre, 63) - pre + cv;
+                const unsigned long long reach = __ballot(suf >= p.k);
+                nstar = 63u - (uint32_t)__clzll((long long)reach);
+                rstar = p.k - ((uint32_t)__builtin_amdgcn_readlane((int)suf, (int)nstar) - (uint32_t)__builtin_amdgcn_readlane((int)cv, (int)nstar));
+            }
+            uint32_t mine = 0;
+#pragma unroll
+            for (int x = 0; x < 5; ++x) mine += o0 + x < o1 && nmv[x] == nstar;
+            uint32_t tot_star;
+            uint32_t before = block_excl_scan<BLOCK>(mine, misc + FS_SCAN_B, tot_star);
+            uint32_t sel = 0; bool take[5];
+#pragma unroll
+            for (int x = 0; x < 5; ++x) {
+                const bool in_r = o0 + x < o1, eq = nmv[x] == nstar;
+                take[x] = in_r && (nmv[x] > nstar || (eq && before < rstar));
+                sel += take[x]; before += in_r && eq;
+            }
+            const uint32_t inc = wave_incl_scan(sel);
+            uint32_t base = 0; if (lane == 63u && inc) base = atomicAdd(&misc[FS_NB], inc);
+            uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)base, 63) + inc - sel;
+#pragma unroll
+            for (int x = 0; x < 5; ++x) if (take[x]) nbl[at++] = dv[x];
+        }
+        __syncthreads();
+        const uint32_t K = misc[FS_NB];
+        FAST_TICK(4);
+
+        // ---- walk A: one neighbour row per lane, the first 32 bytes (14 items) of all the wave's rows requested at once ---------
+        uint32_t svr[3]; uint4 rq[3], rq1[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const uint32_t j = wave * 64u + lane + (uint32_t)t * BLOCK;
+            svr[t] = K ? nbl[min(j, K - 1u)] : 0u;   // (all loads unconditional: a load inside a branch is waited for at the branch's end)
+            const size_t r = K ? (size_t)(svr[t] >> NB) : (size_t)n_kept;   // (idle lanes re-read the last neighbour's row)
+            rq[t] = *reinterpret_cast<const uint4*>(&f.row_packed[r * 4]);
+            rq1[t] = *reinterpret_cast<const uint4*>(&f.row_packed[r * 4 + 1]);
+        }
+        {   // clear: accumulators + sketch + dump, exact table (keys EMPTY32, sums 0)
+            uint4* z = reinterpret_cast<uint4*>(smem + F_HOT);
+            for (uint32_t i = tid; i < (F_TABLE - F_HOT) / 16u; i += BLOCK) z[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (tid < 64u) reinterpret_cast<uint4*>(thist)[tid] = make_uint4(0u, 0u, 0u, 0u);
+            if (tid < F_TABLE_WORDS / 4u) { reinterpret_cast<uint4*>(ikeys)[tid] = make_uint4(EMPTY32, EMPTY32, EMPTY32, EMPTY32);
+                                            reinterpret_cast<uint4*>(iacc)[tid] = make_uint4(0u, 0u, 0u, 0u); }
+        }
+        __syncthreads();   // (also: every wave holds its neighbour slots in registers, the list's LDS is free for the queue)
+        FAST_TICK(8);
+        auto add2 = [&](uint32_t wd, uint32_t w) {
+            atomicAdd((uint32_t*)(acc_base + (wd & 0xFFFFu)), w); atomicAdd((uint32_t*)(acc_base + (wd >> 16)), w); };
+        // rows of > 14 items queue for round (ii) in the wave's own 192 list slots (their session slots are in registers by now)
+        uint32_t cnt3 = 0;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const bool m3 = wave * 64u + lane + (uint32_t)t * BLOCK < K && (rq[t].x & 0xFFFFu) > 14u;
+            const unsigned long long b3 = __ballot(m3);
+            if (m3) nbl[qpos(cnt3 + (uint32_t)__popcll(b3 & lt))] = svr[t];
+            cnt3 += (uint32_t)__popcll(b3);
+        }
+        // round (ii)'s first batch is requested BEFORE round (i)'s adds, which hide its latency (L2 hits: the lines came with round (i))
+        auto q3_load = [&](uint32_t p0, uint32_t& sv, uint32_t& hdr, uint4& c4, uint4& d4) {
+            sv = nbl[qpos(min(p0 + lane, cnt3 - 1u))];
+            const RowQuad* rowp = f.row_packed + (size_t)(sv >> NB) * 4;
+            hdr = *reinterpret_cast<const uint32_t*>(rowp); c4 = *reinterpret_cast<const uint4*>(rowp + 2); d4 = *reinterpret_cast<const uint4*>(rowp + 3); };
+        uint32_t sv3 = 0, hdr3 = 0; uint4 c43 = make_uint4(0u, 0u, 0u, 0u), d43 = c43;
+        if (cnt3) q3_load(0u, sv3, hdr3, c43, d43);   // (wave-uniform)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {   // (i) items 0..13
+            if (wave * 64u + (uint32_t)t * BLOCK < K) {
+                const bool act = wave * 64u + lane + (uint32_t)t * BLOCK < K;
+                const uint32_t w = w10t[svr[t] & NBM], len = rq[t].x & 0xFFFFu;
+                if (act) { add2(rq[t].y, w); add2(rq[t].z, w); add2(rq[t].w, w); }
+                if (act && len > 6u) { add2(rq1[t].x, w); add2(rq1[t].y, w); add2(rq1[t].z, w); add2(rq1[t].w, w); }
+            }
+        }
+        auto add_tail = [&](uint32_t p0, uint32_t sv, uint32_t hdr, const uint4& c4, const uint4& d4) {   // items 14..29, then the overflow blocks
+            const bool act = p0 + lane < cnt3;
+            const uint32_t len = hdr & 0xFFFFu, w = w10t[sv & NBM];
+            if (act) {
+                add2(c4.x, w); add2(c4.y, w); add2(c4.z, w); add2(c4.w, w);
+                add2(d4.x, w); add2(d4.y, w); add2(d4.z, w);
+                if (len <= 30u) add2(d4.w, w);
+            }
+            for (uint32_t t8 = 28u; __ballot(act && len > 30u && t8 < len) != 0ull; t8 += 8u) {
+                if (act && len > 30u && t8 < len) {
+                    const uint4 e4 = reinterpret_cast<const uint4*>(f.row_ext16)[(size_t)d4.w + ((t8 - 28u) >> 3)];
+                    add2(e4.x, w); add2(e4.y, w); add2(e4.z, w); add2(e4.w, w);
+                }
+            } };
+        if (cnt3) add_tail(0u, sv3, hdr3, c43, d43);
+        for (uint32_t p0 = 64u; p0 < cnt3; p0 += 64u) { uint32_t sv, hdr; uint4 c4, d4; q3_load(p0, sv, hdr, c4, d4); add_tail(p0, sv, hdr, c4, d4); }
+        __syncthreads();
+        FAST_TICK(9);
+
+        // ---- phase 4a: the direct-mapped items, exactly -> threshold, candidates ----------------------------
+        // Sample = the 512 most popular items, dealt round-robin to the waves: every wave takes the 3rd largest of its 64 values
+        // of x = idf_eff * acc (top 32 bits of the f64: a monotone truncation); the smallest of the 8 has >= 24 >= n items at or
+        // above it.  Everything is kept down to one step (2^-20 relative) BELOW it, so that what is dropped is strictly smaller
+        // after the division by 10 U as well (ties at the cut included).
+        uint32_t t32m1; uint32_t floor_b;
+        {
+            const uint32_t e = lane * NW + wave;
+            const uint32_t v = hot[e];
+            hot[e] = 0u;   // (walk B reads the accumulator words of popular items as "cannot reach the floor" ...
+            for (uint32_t i = tid; i < F_DUMP_WORDS; i += BLOCK) ((uint32_t*)(smem + F_DUMP))[i] = 0u;   // ... and the dump words, where the positions past a row's end point)
+            const bool valid = v != 0u && e != cur_idx;
+            double x = 0.0; uint32_t tie = 0;
+            { const ItemMeta mt = f.meta_sample[tid]; if (valid) { x = (mt.idf > 0.0 ? mt.idf : 1.0) * (double)v; tie = mt.id_rank; } }   // (coalesced, unconditional)
+            const uint32_t k32 = (uint32_t)((unsigned long long)__double_as_longlong(x) >> 32);
+            {
+                uint32_t vv = k32, third = 0;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const uint32_t mx = wave_max(vv);
+                    third = mx;
+                    const unsigned long long bal = __ballot(vv == mx);
+                    if ((int)lane == __ffsll((long long)bal) - 1) vv = 0;   // take one holder of the maximum out
+                }
+                if (lane == 0u) misc[FS_W3 + wave] = third;   // (0 if the wave has < 3 valid items)
+            }
+            __syncthreads();
+            uint32_t t32 = 0xFFFFFFFFu;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t32 = min(t32, misc[FS_W3 + w]);
+            if (t32 < 2u) {   // block-uniform: no threshold from the sample (a small query) -- the general kernel takes it
+                if (tid == 0) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q;
+                continue;
+            }
+            t32m1 = t32 - 1u;
+            const bool take = valid && k32 >= t32m1;
+            const uint32_t at = wave_append(take, &misc[FS_CCNT]);
+            if (take) { if (at < F_CAND_CAP) { ckey[at] = (unsigned long long)__double_as_longlong(x); cidx[at] = tie; } else misc[FS_FAIL] = 1;
+                        const uint32_t hb = k32 >> 16, tb = t32 >> 16; atomicAdd(&thist[hb > tb ? min(hb - tb, 255u) : 0u], 1u); }   // (>= 24 entries, few more: no pile-up)
+            // integer floors: an item needs idf * acc >= x_lo, i.e. acc >= x_lo / (largest idf of its chunk); shaved so that rounding
+            // can only keep more.  Lane c computes chunk c's floor (lane 8: the sketch words'), broadcast by v_readlane.
+            const double x_lo = __longlong_as_double((long long)((unsigned long long)t32m1 << 32));
+            const double inv = lane < 8u ? f.inv_idf_hot[lane & 7u] : f.inv_idf_hi;
+            const uint32_t my_floor = (uint32_t)fmin(4.0e9, fmax(1.0, floor(x_lo * inv * (1.0 - 1e-9)) - 1.0));
+            floor_b = (uint32_t)__builtin_amdgcn_readlane((int)my_floor, 8);
+#pragma unroll
+            for (int c = 1; c < (int)(F_HOT_WORDS / BLOCK); ++c) {   // the other direct-mapped words: survivors of the chunk's floor are compacted, scored below
+                const uint32_t fl = (uint32_t)__builtin_amdgcn_readlane((int)my_floor, c);
+                const uint32_t e2 = (uint32_t)c * BLOCK + tid;
+                const uint32_t v2 = hot[e2];
+                hot[e2] = 0u;
+                const bool pass = v2 >= fl && e2 != cur_idx;
+                const uint32_t at2 = wave_append(pass, &misc[FS_SURV]);
+                if (pass) { if (at2 < SURV_CAP) surv[at2] = (e2 << 20) | v2; else misc[FS_FAIL] = 1; }
+            }
+        }
+        __syncthreads();
+        {   // The first threshold is loose (a wave whose 3rd-best is weak drags it down) and the sketch floor with it.  Second, tight one:
+            // the bin (top 16 bits of x: 1/16 octave) of the n-th best of the sample's candidates -- at least n valid items sit at
+            // or above its lower edge.  Every wave scans the 256 bins itself (4 per lane, suffix sums from the top): no extra barrier.
+            const uint4 h4 = reinterpret_cast<const uint4*>(thist)[lane];
+            const uint32_t sum4 = h4.x + h4.y + h4.z + h4.w, pre = wave_incl_scan(sum4);
+            uint32_t above = (uint32_t)__builtin_amdgcn_readlane((int)pre, 63) - pre;   // entries in bins owned by higher lanes
+            const uint32_t need = p.how_many;
+            const bool mine = above < need && need <= above + sum4;
+            uint32_t bin = 4u * lane + 3u;
+            if (above + h4.w < need) { above += h4.w; bin = 4u * lane + 2u;
+                if (above + h4.z < need) { above += h4.z; bin = 4u * lane + 1u;
+                    if (above + h4.y < need) bin = 4u * lane; } }
+            const unsigned long long mb = __ballot(mine);   // (exactly one lane: the histogram holds >= 24 >= n entries)
+            const uint32_t bsel = mb ? (uint32_t)__builtin_amdgcn_readlane((int)bin, __ffsll((long long)mb) - 1) : 0u;
+            if (bsel) {
+                const uint32_t t32b = (((t32m1 + 1u) >> 16) + bsel) << 16;
+                t32m1 = t32b - 1u;
+                const double x_lo = __longlong_as_double((long long)((unsigned long long)t32m1 << 32));
+                floor_b = (uint32_t)fmin(4.0e9, fmax(1.0, floor(x_lo * f.inv_idf_hi * (1.0 - 1e-9)) - 1.0));
+            }
+        }
+        if (ticking && tid == 0) { tacc[15] += floor_b; tacc[3] += t32m1 >> 16; }
+        FAST_TICK(10);
+        {
+            const uint32_t ns = min(misc[FS_SURV], SURV_CAP);
+            for (uint32_t i = tid; i < ns; i += BLOCK) {
+                const uint32_t sv = surv[i], e = sv >> 20, v = sv & 0xFFFFFu;
+                const ItemMeta mt = ix.meta[e];
+                const double x = (mt.idf > 0.0 ? mt.idf : 1.0) * (double)v;
+                const bool take = (uint32_t)((unsigned long long)__double_as_longlong(x) >> 32) >= t32m1;
+                const uint32_t at = wave_append(take, &misc[FS_CCNT]);
+                if (take) { if (at < F_CAND_CAP) { ckey[at] = (unsigned long long)__double_as_longlong(x); cidx[at] = mt.id_rank; } else misc[FS_FAIL] = 1; }
+            }
+        }
+        // ---- walk B: an element reaches the exact table only if its sketch word can still reach the floor -----------
+        // (all elements of an item share the word, so an item is accumulated completely or not at all; the accumulator words of
+        // the popular items read 0 by now; a dump word that happens to reach the floor belongs to a position past its row's end).
+        // The walk itself touches no global memory in round (i): it only LISTS the elements whose word is live, as (session slot,
+        // row position) pairs; the list is resolved afterwards, one element per thread, all item-id fetches in flight together.
+        {
+            uint32_t dbg_hits = 0;
+            auto chk2 = [&](uint32_t hm, uint32_t wd) -> uint32_t {   // two more positions, most recent in bit 0 ... appended at the top
+                const uint32_t a = *(const uint32_t*)(acc_base + (wd & 0xFFFFu)), b = *(const uint32_t*)(acc_base + (wd >> 16));
+                return (hm << 2) | (a >= floor_b ? 2u : 0u) | (b >= floor_b ? 1u : 0u); };   // (bit (n - 1 - i) = position i of the n checked)
+            auto list_hits = [&](uint32_t hm, uint32_t npos, uint32_t sv, uint32_t j0) {   // hm: bit (npos - 1 - i) = position j0 + i
+                const uint32_t c = (uint32_t)__popc(hm);
+                if (__ballot(c != 0u) == 0ull) return;
+                dbg_hits += c;
+                const uint32_t inc = wave_incl_scan(c);
+                uint32_t base = 0; if (lane == 63u) base = atomicAdd(&misc[FS_HITS], inc);
+                uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)base, 63) + inc - c;
+                while (hm) {
+                    const uint32_t b = 31u - (uint32_t)__clz((int)hm); hm &= ~(1u << b);
+                    if (at < F_HIT_CAP) hits[at] = make_uint2(sv, j0 + (npos - 1u - b)); else misc[FS_FAIL] = 1;
+                    ++at;
+                }
+            };
+            uint32_t sv3b = 0, hdr3b = 0; uint4 c43b = make_uint4(0u, 0u, 0u, 0u), d43b = c43b;
+            if (cnt3) q3_load(0u, sv3b, hdr3b, c43b, d43b);   // requested before round (i), which needs no memory
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {   // (i) from the registers
+                if (wave * 64u + (uint32_t)t * BLOCK < K) {
+                    const bool act = wave * 64u + lane + (uint32_t)t * BLOCK < K;
+                    uint32_t hm = 0;
+                    if (act) {
+                        hm = chk2(chk2(chk2(0u, rq[t].y), rq[t].z), rq[t].w) << 8;
+                        if ((rq[t].x & 0xFFFFu) > 6u) hm = chk2(chk2(chk2(chk2(hm >> 8, rq1[t].x), rq1[t].y), rq1[t].z), rq1[t].w);
+                    }
+                    list_hits(hm, 14u, svr[t], 0u);
+                }
+            }
+            auto chk_tail = [&](uint32_t p0, uint32_t sv, uint32_t hdr, const uint4& c4, const uint4& d4) {
+                const bool act = p0 + lane < cnt3;
+                const uint32_t len = hdr & 0xFFFFu;
+                uint32_t hm = 0;
+                if (act) {
+                    hm = chk2(chk2(chk2(chk2(chk2(chk2(chk2(0u, c4.x), c4.y), c4.z), c4.w), d4.x), d4.y), d4.z);
+                    if (len > 30u) hm <<= 2; else hm = chk2(hm, d4.w);
+                }
+                list_hits(hm, 16u, sv, 14u);
+                for (uint32_t t8 = 28u; __ballot(act && len > 30u && t8 < len) != 0ull; t8 += 8u) {
+                    uint32_t hm2 = 0;
+                    if (act && len > 30u && t8 < len) {
+                        const uint4 e4 = reinterpret_cast<const uint4*>(f.row_ext16)[(size_t)d4.w + ((t8 - 28u) >> 3)];
+                        hm2 = chk2(chk2(chk2(chk2(0u, e4.x), e4.y), e4.z), e4.w);
+                    }
+                    list_hits(hm2, 8u, sv, t8);
+                } };
+            if (cnt3) chk_tail(0u, sv3b, hdr3b, c43b, d43b);
+            for (uint32_t p0 = 64u; p0 < cnt3; p0 += 64u) { uint32_t sv, hdr; uint4 c4, d4; q3_load(p0, sv, hdr, c4, d4); chk_tail(p0, sv, hdr, c4, d4); }
+            if (ticking) { const uint32_t hs = wave_sum(dbg_hits); if (lane == 0u && hs) atomicAdd(&tacc[5], (unsigned long long)hs); }
+        }
+        __syncthreads();
+        FAST_TICK(11);
+        {   // resolve the listed elements: item id from the general row slot (its word 0 = the row's length: a position past the
+            // end was a dump word), weight from the slot's position set, exact sums in the table
+            const uint32_t nh = min(misc[FS_HITS], F_HIT_CAP);
+            bool ovf = false;
+            for (uint32_t i = tid; i < nh; i += BLOCK) {
+                const uint2 h = hits[i];
+                const uint32_t* os = reinterpret_cast<const uint32_t*>(ix.row_slots + (size_t)(h.x >> NB) * 4);
+                const uint32_t len = os[0], j = h.y;
+                uint32_t it = EMPTY32;
+                if (j < len) it = len <= 15u ? os[1 + j] : (j < 14u ? os[2 + j] : ix.row_ext[os[1] + (j - 14u)]);
+                if (it != EMPTY32 && it >= F_HOT_WORDS && item_insert(ikeys, iacc, F_TABLE_BUCKETS, it, (int)w10t[h.x & NBM]) < 0) ovf = true;
+            }
+            if (ovf) misc[FS_FAIL] = 1;
+        }
+        __syncthreads();
+        FAST_TICK(12);
+        if (misc[FS_FAIL]) { if (tid == 0) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q; continue; }   // block-uniform
+        // ---- phase 4b + final ranking: wave 0 alone (the others go on to the next query's record and wait at its first barrier) ----
+        // the exact table's items join the candidates; score = x / (10 U) (the reference's multiply-then-divide, mod.rs:146-152); rank by counting
+        if (wave != 0u) continue;
+        bool fail0 = false;
+#pragma unroll
+        for (uint32_t b0 = 0; b0 < (F_TABLE_BUCKETS + 63u) / 64u; ++b0) {
+            const uint32_t bk = b0 * 64u + lane;
+            uint4 kq = make_uint4(EMPTY32, EMPTY32, EMPTY32, EMPTY32);
+            if (bk < F_TABLE_BUCKETS) kq = reinterpret_cast<const uint4*>(ikeys)[bk];
+            const uint32_t kk[4] = {kq.x, kq.y, kq.z, kq.w};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const uint32_t it = kk[s4];
+                if (__ballot(it != EMPTY32) == 0ull) continue;
+                bool take = false; double x = 0.0; uint32_t tie = 0;
+                if (it != EMPTY32 && it != cur_idx) {   // (few: divergence is cheap here)
+                    const ItemMeta mt = ix.meta[it];
+                    x = (mt.idf > 0.0 ? mt.idf : 1.0) * (double)iacc[4 * bk + s4]; tie = mt.id_rank;
+                    take = (uint32_t)((unsigned long long)__double_as_longlong(x) >> 32) >= t32m1;
+                }
+                const uint32_t at = wave_append(take, &misc[FS_CCNT]);
+                if (take) { if (at < F_CAND_CAP) { ckey[at] = (unsigned long long)__double_as_longlong(x); cidx[at] = tie; } else fail0 = true; }
+            }
+        }
+        const uint32_t cnt = misc[FS_CCNT];   // (this wave's own LDS traffic is ordered; the other waves' appends are behind the barrier above)
+        if (__ballot(fail0) != 0ull || cnt > F_CAND_CAP) { if (lane == 0u) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q; continue; }
+        if (ticking && lane == 0u) { tacc[6] += cnt; tacc[7] += misc[FS_SURV]; tacc[14] += 1ull; }
+        const double denom = (double)(10u * U);
+        // x -> score is monotone and what was dropped is strictly below every kept score, but two kept x may round to the same score:
+        // the ranks are counted on the scores themselves (positive doubles order like their bit patterns)
+        for (uint32_t i = lane; i < cnt; i += 64u) ckey[i] = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)ckey[i]) / denom);
+        for (uint32_t c0 = 0; c0 < cnt; c0 += 64u) {   // candidates c0 + lane; candidate j is read from LDS at a uniform address (broadcast)
+            const uint32_t i = c0 + lane;
+            unsigned long long mk = 0; uint32_t tie = EMPTY32; unsigned long long pid = 0;
+            if (i < cnt) { tie = cidx[i]; pid = ix.id_sorted[tie]; mk = ckey[i]; }   // (the id arrives while the ranks are counted)
+            uint32_t rank = 0;
+#pragma unroll 4
+            for (uint32_t j = 0; j < cnt; ++j) { const unsigned long long kj = ckey[j]; const uint32_t ij = cidx[j]; rank += kj > mk || (kj == mk && ij < tie); }
+            if (i < cnt && rank < p.how_many) { p.out_ids[(size_t)q * p.how_many + rank] = pid; p.out_scores[(size_t)q * p.how_many + rank] = __longlong_as_double((long long)mk); }
+        }
+        if (lane == 0u) p.out_counts[q] = min(cnt, p.how_many);
+        FAST_TICK(13);
+    }
+    if (ticking) { __syncthreads(); if (tid < 16u && tacc[tid]) atomicAdd(&p.phase_cycles[tid], tacc[tid]); }
+}
+
+hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f) {
+    auto kern = vmis_fast_kernel<(int)F_WG_PER_CU>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_TOTAL);
+    if (e != hipSuccess) return e;
+    static bool told = false;
+    if (!told && getenv("SRN_DEBUG")) { told = true; int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 512, F_TOTAL);
+        fprintf(stderr, "[srn] vmis_fast_kernel: %u bytes of LDS, %d workgroups per CU (occupancy API)\n", F_TOTAL, nb); }
+    hipLaunchKernelGGL(kern, grid, dim3(512), F_TOTAL, st, di, p, f);
+    return hipGetLastError();
+}
+
+hipError_t launch_rows_to_packed(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base,
+                                 uint32_t* packed, uint32_t* ext16) {
+    hipLaunchKernelGGL(rows_to_packed_kernel, dim3((unsigned)((n_rows + 1 + 1023) / 1024)), dim3(1024), 0, st, row_off, row_items, n_rows, block_base, packed, ext16);
+    return hipGetLastError();
+}
+
+}  // namespace srn

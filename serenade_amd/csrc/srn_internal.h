@@ -106,6 +106,8 @@ struct DeviceState;  // uploaded arrays + workspace pool
 DeviceState* device_attach(const FlatIndex& ix, int device);   // nullptr on failure (error set)
 void device_release(DeviceState* d);
 int device_update_attr(DeviceState* d, const FlatIndex& ix);
+void device_refresh_fast_bounds(DeviceState* d, const FlatIndex& ix);   // idf bounds of the fast kernel's integer floors (srn_runtime.hip)
+void reload_knobs();                                                     // re-read the SRN_* test / experiment knobs from the environment
 uint64_t device_bytes(const DeviceState* d);
 int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p, bool buffers_on_device, void* stream,
                    // host-pointer mode: these are host buffers copied in/out by the call
@@ -120,7 +122,8 @@ struct ShardIO {
 int device_shard_stage(DeviceState* d, const FlatIndex& ix, int stage, const LaunchParams& p, const ShardIO& sh, void* stream);
 int device_slot_bytes(DeviceState* d, const FlatIndex& ix, uint32_t max_len);
 int device_last_kernel_ms(DeviceState* d, double* ms_main, double* ms_retry, uint32_t* retried);
-int device_phase_cycles(DeviceState* d, int enable, unsigned long long* out16);   // debug profiling aid
+int device_phase_cycles(DeviceState* d, int enable, unsigned long long* out16);
+int device_last_path_counts(DeviceState* d, uint32_t* nq, uint32_t* general, uint32_t* global_pass);   // debug profiling aid
 int device_kernel_times(DeviceState* d, uint32_t max_n, double* ms_main, double* ms_retry, uint32_t* out_n);
 
 }  // namespace srn

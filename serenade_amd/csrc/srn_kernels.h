@@ -32,8 +32,37 @@ struct KernelCfg {
 struct LaunchAux { const uint32_t* qlist; const uint32_t* qlist_n; uint32_t* retry_list; uint32_t* retry_cnt; char* gscratch; unsigned long long gscratch_stride; char* nb_spill; };
 
 // record written by the prep kernel for every query: PrepHead + max_len * PrepItem, positions counted from the most recent item
-struct PrepHead { uint32_t U, rmax, xlo, sumw, P, nruns, L, pad, run_start[8]; };   // S_U, S_RMAX, S_XLO, S_SUMW, S_P of the query; number of non-empty lists, session length as given, where the first 8 lists start
-struct PrepItem { uint32_t idx, len, pre, pad; unsigned long long base; };   // dense idx | kNone, truncated list length, prefix of len, list start
+struct PrepHead { uint32_t U, rmax, xlo, sumw, P, nruns, L, n_staged, run_start[8]; };   // S_U, S_RMAX, S_XLO, S_SUMW, S_P of the query; number of non-empty lists, session length as given, sum of the lists' kept counts, where the first 8 lists start
+struct PrepItem { uint32_t idx, len, pre, kept; unsigned long long base; };   // dense idx | kNone, truncated list length, prefix of len, entries >= x_lo (a prefix of the list), list start
+
+// ---- fast path (srn_fast.hip): the lean kernel for the common query shape; everything else goes to vmis_predict_kernel ----
+// LDS map of vmis_fast_kernel, bytes.  The row slots of the fast path hold 16-bit byte offsets relative to F_HOT, so the layout is fixed.
+#ifndef SRN_FAST_SMALL
+#define SRN_FAST_SMALL 1
+#endif
+#if SRN_FAST_SMALL   // 52 KB: three workgroups per CU
+static constexpr uint32_t F_HOT_WORDS = 4096, F_SK_WORDS = 4096, F_DUMP_WORDS = 256, F_TABLE_BUCKETS = 127, F_TABLE_WORDS = 512, F_HIT_CAP = 512, F_SURV_WORDS = 512, F_WG_PER_CU = 3;
+#else                // 80 KB: two workgroups per CU
+static constexpr uint32_t F_HOT_WORDS = 4096, F_SK_WORDS = 8192, F_DUMP_WORDS = 1024, F_TABLE_BUCKETS = 127, F_TABLE_WORDS = 512, F_HIT_CAP = 1536, F_SURV_WORDS = 768, F_WG_PER_CU = 2;
+#endif
+static constexpr uint32_t F_MISC = 0, F_WLUT = 256, F_W10 = 512, F_NBL = 1024, F_K_MAX = 1536, F_CAND = F_NBL + F_K_MAX * 4, F_CAND_CAP = 160;
+static constexpr uint32_t F_HOT = 9216, F_SKETCH = F_HOT + F_HOT_WORDS * 4, F_DUMP = F_SKETCH + F_SK_WORDS * 4, F_TABLE = F_DUMP + F_DUMP_WORDS * 4;
+static constexpr uint32_t F_HITS = F_TABLE + F_TABLE_WORDS * 8;          // walk B's hit list: (session slot, row position) pairs; exact table: prime number of 4-slot buckets, keys then sums
+static constexpr uint32_t F_SURV = F_HITS + F_HIT_CAP * 8;               // survivors of the integer floors, packed (idx << 20 | acc)
+static constexpr uint32_t F_LDS_BYTES = F_SURV + F_SURV_WORDS * 4;
+static constexpr uint32_t F_WORK = F_NBL, F_WORK_WORDS = (F_LDS_BYTES - F_WORK) / 4;   // merge buffers: 2 * n_staged words
+static constexpr uint32_t F_M_MAX = 2560;
+static_assert(F_CAND + F_CAND_CAP * 12 <= F_HOT, "candidate buffer overlaps the accumulators");
+static_assert(F_LDS_BYTES * F_WG_PER_CU <= 160 * 1024, "LDS budget");
+static_assert(F_DUMP + F_DUMP_WORDS * 4 - F_HOT <= 65536, "16-bit row offsets");
+struct FastParams {
+    const RowQuad* row_packed; const uint32_t* row_ext16;   // 64-byte slots of 16-bit LDS offsets + overflow blocks (8 items per 16 bytes)
+    const ItemMeta* meta_sample;   // meta[] of the 512 most popular items in the order the threshold sample reads them: entry 64 w + l = item 8 l + w
+    double inv_idf_hot[8];      // 1 / max idf_eff over the dense idx [512 c, 512 c + 512): popular items have small idf, so their integer floor is much tighter
+    double inv_idf_hi;          // 1 / max idf_eff over all items
+    uint32_t* slow_list; uint32_t* slow_cnt;   // queries the fast kernel hands to vmis_predict_kernel
+    uint32_t nb;                // low bits of a session slot that hold the position set
+};
 
 // ---- launchers (srn_kernels.hip) -------------------------------------------------------------
 // the predict kernel: stage 0 = fused, 1..3 = the item-sharded pipeline's stages A..C; global_tables = the retry pass with its
@@ -43,6 +72,9 @@ hipError_t launch_predict(bool masks, bool slot64, bool global_tables, int stage
                           uint32_t* retry_cnt, char* gscratch, unsigned long long gscratch_stride, char* nb_spill, const ShardIO& sh, int wg_per_cu = 2);
 hipError_t launch_prep(hipStream_t st, const DeviceIndex& di, const uint64_t* items_flat, const uint32_t* q_off, uint32_t nq, uint32_t m,
                        uint32_t max_len, char* out, uint32_t stride);
+hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f);
+hipError_t launch_rows_to_packed(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base,
+                                 uint32_t* packed, uint32_t* ext16);   // grid = ceil((n_rows + 1) / 1024) blocks of 1024; block_base in 16-byte blocks
 hipError_t launch_rows_to_slots(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base,
                                 uint32_t* slots, uint32_t* ext);   // grid = ceil((n_rows + 1) / 1024) blocks of 1024
 

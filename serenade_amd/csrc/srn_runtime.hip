@@ -22,17 +22,39 @@ namespace srn {
         if (e_ != hipSuccess) return fail(SRN_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// Test / experiment knobs (environment variables SRN_*): read ONCE, when the library is first used, never on the launch path;
+// srn_debug_reload_knobs() re-reads them (the tests switch kernel paths between calls).  All defaults = production behaviour.
+struct Knobs {
+    bool no_masks = false, no_merge = false, dense = false, no_fast = false, debug = false;
+    int hot_slots = -1, sketch_slots = -1, lds_budget_kb = 0, grid_mult = 16;
+    bool geometry_default() const { return !no_masks && !no_merge && !dense && hot_slots < 0 && sketch_slots < 0 && lds_budget_kb == 0; }
+};
+static Knobs g_knobs; static std::once_flag g_knobs_once; static std::mutex g_knobs_mu;
+static void knobs_read() {
+    Knobs k;
+    k.no_masks = getenv("SRN_NO_MASKS") != nullptr; k.no_merge = getenv("SRN_NO_MERGE") != nullptr; k.dense = getenv("SRN_DENSE") != nullptr;
+    k.no_fast = getenv("SRN_NO_FAST") != nullptr; k.debug = getenv("SRN_DEBUG") != nullptr;
+    if (const char* e = getenv("SRN_HOT_SLOTS")) k.hot_slots = std::max(0, atoi(e));
+    if (const char* e = getenv("SRN_SKETCH_SLOTS")) k.sketch_slots = std::max(0, atoi(e));
+    if (const char* e = getenv("SRN_LDS_BUDGET_KB")) k.lds_budget_kb = std::max(0, atoi(e));
+    if (const char* e = getenv("SRN_GRID_MULT")) k.grid_mult = std::max(1, atoi(e));
+    std::lock_guard<std::mutex> lk(g_knobs_mu); g_knobs = k;
+}
+static Knobs knobs() { std::call_once(g_knobs_once, knobs_read); std::lock_guard<std::mutex> lk(g_knobs_mu); return g_knobs; }
+void reload_knobs() { std::call_once(g_knobs_once, knobs_read); knobs_read(); }
+
 struct Workspace {
     hipStream_t stream = nullptr;   // own stream for host-pointer calls
     static constexpr int RING = 64;               // per-call events: start, after main kernel, after retry pass, after prep kernel
     hipEvent_t ev[RING][4] = {};
-    uint64_t calls = 0; uint32_t last_retry = 0;
+    uint64_t calls = 0; uint32_t last_retry = 0, last_nq = 0;
     // device scratch
     uint32_t* retry_list = nullptr; size_t retry_cap = 0; uint32_t* retry_cnt = nullptr;
     char* gscratch = nullptr; size_t gscratch_bytes = 0;
     char* spill = nullptr; size_t spill_bytes = 0;   // per-block global copies of the neighbour lists
     char* prep = nullptr; size_t prep_bytes = 0;     // per-query records of the prep kernel
     uint32_t* retry_list2 = nullptr; size_t retry_cap2 = 0; uint32_t* retry_cnt2 = nullptr;   // what the second LDS tier could not hold either
+    uint32_t* slow_list = nullptr; size_t slow_cap = 0; uint32_t* slow_cnt = nullptr;          // what the fast kernel hands to the general one
     // staging for host-pointer calls
     char* stage = nullptr; size_t stage_bytes = 0;
     uint32_t* h_retry = nullptr;   // pinned
@@ -43,6 +65,8 @@ struct DeviceState {
     std::vector<void*> allocs; uint64_t bytes = 0;
     DeviceIndex di{};
     ItemMeta* d_meta = nullptr;
+    FastParams fast{};            // packed row slots + idf bounds of the fast kernel (row_packed == nullptr: no fast path for this index)
+    uint32_t host_max_row_len = 0;
     int n_cu = 256;
     int lds_per_block_max = 65536;
     std::mutex mu; std::vector<Workspace*> free_ws; std::vector<Workspace*> all_ws;
@@ -73,7 +97,10 @@ DeviceState* device_attach(const FlatIndex& ix, int device) {
     d->di.id_table = upload(d, ix.id_table, ok); d->di.id_mask = ix.id_mask;
     { std::vector<ItemMeta> meta(ix.n_items); std::vector<uint64_t> id_sorted(ix.n_items);
       for (size_t i = 0; i < ix.n_items; ++i) { meta[i] = ItemMeta{ix.idf[i], ix.id_rank[i], ix.attr[i]}; id_sorted[ix.id_rank[i]] = ix.item_id[i]; }
-      d->d_meta = (ItemMeta*)upload(d, meta, ok); d->di.meta = d->d_meta; d->di.id_sorted = upload(d, id_sorted, ok); }
+      d->d_meta = (ItemMeta*)upload(d, meta, ok); d->di.meta = d->d_meta; d->di.id_sorted = upload(d, id_sorted, ok);
+      std::vector<ItemMeta> ms(512, ItemMeta{0.0, 0u, 0u});   // the fast kernel's threshold sample: one coalesced read per wave
+      for (uint32_t w8 = 0; w8 < 8; ++w8) for (uint32_t l = 0; l < 64; ++l) if (8 * l + w8 < ix.n_items) ms[64 * w8 + l] = meta[8 * l + w8];
+      d->fast.meta_sample = upload(d, ms, ok); }
     d->di.post_off = upload(d, ix.post_off, ok); d->di.post_rank = upload(d, ix.post_rank, ok);
     if (ok) {   // rows -> 64-byte slots (+ overflow area) on the device, see DeviceIndex and rows_to_slots_kernel
         const size_t n = ix.n_kept, nblocks = (n + 1 + 1023) / 1024;
@@ -95,6 +122,23 @@ DeviceState* device_attach(const FlatIndex& ix, int device) {
                hipMemset(d_ext, 0xFF, ext_words * 4) == hipSuccess;
         good = good && launch_rows_to_slots(nullptr, (const uint64_t*)d_off, (const uint32_t*)d_items, (uint64_t)n, (const uint32_t*)d_base, (uint32_t*)d_slots, (uint32_t*)d_ext) == hipSuccess &&
                hipDeviceSynchronize() == hipSuccess;
+        if (good && ix.n_shards == 1) {   // the fast kernel's rows: 64-byte slots of 16-bit LDS offsets (+ overflow blocks of 8 items), srn_fast.hip
+            std::vector<uint32_t> bb(nblocks); uint64_t blocks = 1;   // (block 0: what a stray read finds)
+            for (size_t b0 = 0; b0 < nblocks; ++b0) {
+                bb[b0] = (uint32_t)blocks;
+                const size_t hi = std::min(n, (b0 + 1) * 1024);
+                for (size_t r = b0 * 1024; r < hi; ++r) { const uint64_t len = ix.row_off[r + 1] - ix.row_off[r]; if (len > 30) blocks += (len - 28 + 7) / 8; }
+            }
+            void *d_pk = nullptr, *d_e16 = nullptr;
+            bool g2 = blocks < 0xFFFFFFF0ull && hipMalloc(&d_pk, (n + 1) * 64) == hipSuccess && hipMalloc(&d_e16, (blocks + 1) * 16) == hipSuccess &&
+                      hipMemcpy(d_base, bb.data(), nblocks * 4, hipMemcpyHostToDevice) == hipSuccess && hipMemset(d_e16, 0, (blocks + 1) * 16) == hipSuccess &&
+                      launch_rows_to_packed(nullptr, (const uint64_t*)d_off, (const uint32_t*)d_items, (uint64_t)n, (const uint32_t*)d_base, (uint32_t*)d_pk, (uint32_t*)d_e16) == hipSuccess &&
+                      hipDeviceSynchronize() == hipSuccess;
+            if (d_pk) { d->allocs.push_back(d_pk); d->bytes += (n + 1) * 64; }
+            if (d_e16) { d->allocs.push_back(d_e16); d->bytes += (blocks + 1) * 16; }
+            if (g2) { d->fast.row_packed = (const RowQuad*)d_pk; d->fast.row_ext16 = (const uint32_t*)d_e16; }
+            else { good = false; }
+        }
         if (d_off) hipFree(d_off); if (d_items) hipFree(d_items); if (d_base) hipFree(d_base);
         if (d_slots) { d->allocs.push_back(d_slots); d->bytes += (n + 1) * 64; }
         if (d_ext) { d->allocs.push_back(d_ext); d->bytes += ext_words * 4; }
@@ -105,9 +149,22 @@ DeviceState* device_attach(const FlatIndex& ix, int device) {
     double hi = 1.0, lo = 1.0; bool any = false;   // bounds of idf_eff = (idf > 0 ? idf : 1) for the top-n pre-filter
     for (double v : ix.idf) { const double e = v > 0.0 ? v : 1.0; if (!any) { hi = lo = e; any = true; } else { hi = std::max(hi, e); lo = std::min(lo, e); } }
     d->di.idf_hi = hi; d->di.idf_lo = lo;
-    if (getenv("SRN_DEBUG")) fprintf(stderr, "[srn] idf_hi=%g idf_lo=%g n_items=%zu\n", hi, lo, (size_t)ix.n_items);
+    device_refresh_fast_bounds(d, ix);
+    if (knobs().debug) fprintf(stderr, "[srn] idf_hi=%g idf_lo=%g n_items=%zu\n", hi, lo, (size_t)ix.n_items);
     if (!ok) { device_release(d); return nullptr; }
     return d;
+}
+
+// idf bounds of the fast kernel's integer floors: the largest idf_eff of each chunk of 512 direct-mapped items, and of all items
+void device_refresh_fast_bounds(DeviceState* d, const FlatIndex& ix) {
+    double hi_all = 1.0; bool any = false;
+    for (double v : ix.idf) { const double e = v > 0.0 ? v : 1.0; hi_all = any ? std::max(hi_all, e) : e; any = true; }
+    for (uint32_t c = 0; c < 8; ++c) {
+        double hi = 0.0;
+        for (uint64_t i = (uint64_t)c * 512; i < std::min<uint64_t>(ix.n_items, (uint64_t)c * 512 + 512); ++i) hi = std::max(hi, ix.idf[i] > 0.0 ? ix.idf[i] : 1.0);
+        d->fast.inv_idf_hot[c] = hi > 0.0 ? 1.0 / hi : 1.0;
+    }
+    d->fast.inv_idf_hi = 1.0 / hi_all;
 }
 
 static void ws_free(Workspace* w) {
@@ -119,6 +176,8 @@ static void ws_free(Workspace* w) {
     if (w->prep) hipFree(w->prep);
     if (w->retry_list2) hipFree(w->retry_list2);
     if (w->retry_cnt2) hipFree(w->retry_cnt2);
+    if (w->slow_list) hipFree(w->slow_list);
+    if (w->slow_cnt) hipFree(w->slow_cnt);
     if (w->stage) hipFree(w->stage);
     if (w->h_retry) hipHostFree(w->h_retry);
     for (auto& t : w->ev) for (auto& e : t) if (e) hipEventDestroy(e);
@@ -154,7 +213,7 @@ static Workspace* ws_acquire(DeviceState* d, bool bind_to_stream, void* user_str
     Workspace* w = new Workspace();
     if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { delete w; return nullptr; }
     for (auto& t : w->ev) for (auto& e : t) if (hipEventCreate(&e) != hipSuccess) { ws_free(w); return nullptr; }
-    if (hipMalloc((void**)&w->retry_cnt, 16) != hipSuccess || hipMalloc((void**)&w->retry_cnt2, 16) != hipSuccess || hipHostMalloc((void**)&w->h_retry, 16) != hipSuccess) { ws_free(w); return nullptr; }
+    if (hipMalloc((void**)&w->retry_cnt, 16) != hipSuccess || hipMalloc((void**)&w->retry_cnt2, 16) != hipSuccess || hipMalloc((void**)&w->slow_cnt, 16) != hipSuccess || hipHostMalloc((void**)&w->h_retry, 16) != hipSuccess) { ws_free(w); return nullptr; }
     d->all_ws.push_back(w);
     if (bind_to_stream) d->stream_ws.emplace_back(user_stream, w);
     return w;
@@ -190,9 +249,10 @@ struct Geometry {
 };
 // LDS layout + table sizes for one launch (all blocks alike).  min_region_b: extra room the caller needs in region B.
 static int make_geometry(const DeviceState* d, const FlatIndex& ix, const LaunchParams& p, uint32_t min_region_b, Geometry& g, uint32_t budget_bytes = 0) {
+    const Knobs kn = knobs();
     const uint64_t Lmax = p.max_len;
     // position-set slots (no first-match pass over the rows) need <= 8 evolving items and lists complete above x_lo
-    g.masks = Lmax <= 8 && p.m <= ix.m_index && !getenv("SRN_NO_MASKS");
+    g.masks = Lmax <= 8 && p.m <= ix.m_index && !kn.no_masks;
     const int num_bits = g.masks ? (int)Lmax : std::max(1, bits_host(Lmax * (Lmax + 1) / 2));
     const int rank_bits = std::max(1, bits_host(ix.n_kept ? ix.n_kept - 1 : 0));
     g.slot64 = rank_bits + num_bits > 32 || ix.n_kept >= 0xFFFFFFF0ull;
@@ -212,7 +272,7 @@ static int make_geometry(const DeviceState* d, const FlatIndex& ix, const Launch
     c.off_a = c.off_b + region_b;
     const uint32_t lds_max = (uint32_t)std::min(d->lds_per_block_max, 160 * 1024);
     uint32_t budget = budget_bytes ? budget_bytes : 80 * 1024;   // default: two 512-thread blocks per CU
-    if (const char* e = getenv("SRN_LDS_BUDGET_KB")) budget = (uint32_t)atoi(e) * 1024;   // experiment knob (occupancy studies)
+    if (kn.lds_budget_kb) budget = (uint32_t)kn.lds_budget_kb * 1024;   // experiment knob (occupancy studies)
     if (c.off_a + 32 * 1024 > budget) budget = lds_max;   // long sessions / large k: one block per CU
     if (c.off_a + 8 * 1024 > budget) return fail(SRN_ERANGE, "k / session length too large for the LDS layout");
     const uint32_t a_max = budget - c.off_a;
@@ -225,12 +285,12 @@ static int make_geometry(const DeviceState* d, const FlatIndex& ix, const Launch
     // exact words for the 2048 most popular items, 4096 where a query walks many rows (measured with the end-of-round kernel, 2048 -> 4096:
     // config 3 / 4 (k = 1500) +2.6 % / +2.3 %, config 2 (k = 500) -2.6 %: clearing and harvesting the extra words costs more than they save there)
     uint32_t hot = sbits + cbits <= 32 ? (p.k >= 1024 ? 4096u : 2048u) : 0u;
-    if (const char* e = getenv("SRN_HOT_SLOTS")) hot = sbits + cbits <= 32 ? (uint32_t)atoi(e) : 0u;   // test knob
+    if (kn.hot_slots >= 0) hot = sbits + cbits <= 32 ? (uint32_t)kn.hot_slots : 0u;   // test knob
     hot = std::min<uint32_t>(std::min<uint32_t>(hot, a_max / 8), round_up((uint32_t)std::min<uint64_t>(ix.n_items, 1u << 20), 4)) / 4 * 4;
     c.hot_slots = hot; c.sum_bits = (uint32_t)sbits;
     // sketch: upper-bound words for all other items (needs the direct-mapped part: its top n give the threshold)
     uint32_t sk = hot ? 8192u : 0u;
-    if (const char* e = getenv("SRN_SKETCH_SLOTS")) sk = hot ? floor_pow2((uint64_t)std::max(0, atoi(e))) * (atoi(e) > 0) : 0u;   // test knob
+    if (kn.sketch_slots >= 0) sk = hot && kn.sketch_slots > 0 ? floor_pow2((uint64_t)kn.sketch_slots) : 0u;   // test knob
     while (sk && (uint64_t)sk * 4 * 8 > (uint64_t)(a_max - hot * 4) * 5) sk >>= 1;   // leave >= 3/8 of the room to the exact table
     c.sketch_slots = sk; c.sketch_shift = sk ? 32u - (uint32_t)(bits_host(sk) - 1) : 31u;
     const uint64_t want_buckets = std::max<uint64_t>(61, g.need_item / 2 + 8);          // load <= 0.5 at the worst case
@@ -238,7 +298,7 @@ static int make_geometry(const DeviceState* d, const FlatIndex& ix, const Launch
     c.item_slots = c.item_buckets * 4;
     const uint32_t region_a = std::max<uint32_t>(hot * 4 + sk * 4 + c.item_slots * 8, c.sess_slots * slot_bytes);
     c.region_a_bytes = region_a;
-    c.no_merge = getenv("SRN_NO_MERGE") ? 1u : 0u;
+    c.no_merge = kn.no_merge ? 1u : 0u;
     g.lds = (size_t)c.off_a + region_a;
     // tables at least twice the worst case cannot exhaust the probe budget: no retry machinery needed
     g.sess_may_overflow = (uint64_t)c.sess_slots < g.need_sess * 2; g.item_may_overflow = (uint64_t)c.item_slots < g.need_item * 2;
@@ -289,7 +349,8 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     // geometry cannot hold goes through the normal one (second tier) before the global-table pass.  Measured on config 3 / 4:
     // +8.6 % / +4.7 % queries/s (-1 % / -2 % with the end-of-round kernel), but the 80-VGPR build's register spills double the memory traffic (14.5 -> 31.8 GB per launch), so it
     // stays off until the build fits without spilling.
-    Geometry g3; bool dense = !slot64 && getenv("SRN_DENSE") && !getenv("SRN_LDS_BUDGET_KB");
+    const Knobs kn = knobs();
+    Geometry g3; bool dense = !slot64 && kn.dense && !kn.lds_budget_kb;
     if (dense && (make_geometry(d, ix, p, 0, g3, 52 * 1024) != SRN_OK || g3.slot64 || g3.masks != geo.masks)) dense = false;
     uint64_t g_stride = 0; int retry_blocks = 0;
     KernelCfg cg = c;
@@ -314,7 +375,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     const uint32_t blocks_per_cu = std::max<uint32_t>(1, (160 * 1024) / (uint32_t)lds);
     // 16 workgroups per resident slot: the hardware hands out workgroups as slots free up, so smaller chunks of queries shorten the
     // tail of a launch (measured on config 3: x1 10.62 ms, x4 10.50, x16 10.35, x32 10.32)
-    const uint32_t grid_mult = getenv("SRN_GRID_MULT") ? (uint32_t)std::max(1, atoi(getenv("SRN_GRID_MULT"))) : 16u;
+    const uint32_t grid_mult = (uint32_t)kn.grid_mult;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * std::min<uint32_t>(blocks_per_cu, 2048 / kBlock) * grid_mult);
     // per-block global copy of the neighbour list (walk B reads it after phase 4a has reused the LDS)
     const uint32_t grid3 = dense ? (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * std::min<uint32_t>(std::max<uint32_t>(1, (160 * 1024) / (uint32_t)g3.lds), 2048 / kBlock) * grid_mult) : 0u;
@@ -328,6 +389,19 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     p.prep = w->prep; p.prep_stride = prep_stride;
     HIP_TRY(hipEventRecord(ev[3], st));
     const uint32_t* final_list = w->retry_list; uint32_t* final_cnt = w->retry_cnt;
+    // The fast kernel (srn_fast.hip) serves the common query shape; what it cannot take -- decided per query, on the device -- is
+    // queued on slow_list and served by the general kernel right behind it.
+    const bool fast = d->fast.row_packed != nullptr && geo.masks && !slot64 && kn.geometry_default() && !kn.no_fast && p.k <= F_K_MAX && p.m <= F_M_MAX &&
+                      p.how_many <= 24 && p.flags == 0 && p.stats == nullptr && p.nb_rank == nullptr && p.max_len <= 8 && c.num_bits <= 8;
+    if (fast) {
+        if (w->slow_cap < p.nq) { if (w->slow_list) HIP_TRY(hipFree(w->slow_list)); w->slow_list = nullptr; w->slow_cap = 0;
+            HIP_TRY(hipMalloc((void**)&w->slow_list, (size_t)p.nq * 4 + 64)); w->slow_cap = p.nq; }
+        HIP_TRY(hipMemsetAsync(w->slow_cnt, 0, 4, st));
+        FastParams fp = d->fast; fp.slow_list = w->slow_list; fp.slow_cnt = w->slow_cnt; fp.nb = c.num_bits;
+        const uint32_t grid_f = (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * F_WG_PER_CU * grid_mult);
+        HIP_TRY(launch_fast(dim3(grid_f), st, d->di, p, fp));
+        HIP_TRY(launch_predict(geo.masks, slot64, false, 0, dim3(grid), lds, st, d->di, p, c, w->slow_list, w->slow_cnt, w->retry_list, w->retry_cnt, nullptr, 0, spill, ShardIO{}));
+    } else
     if (dense) {
         HIP_TRY(launch_predict(geo.masks, false, false, 0, dim3(grid3), g3.lds, st, d->di, p, g3.c, nullptr, nullptr, w->retry_list, w->retry_cnt, nullptr, 0, spill, ShardIO{}, 3));
         HIP_TRY(launch_predict(geo.masks, false, false, 0, dim3(grid), lds, st, d->di, p, c, w->retry_list, w->retry_cnt, w->retry_list2, w->retry_cnt2, nullptr, 0, spill, ShardIO{}));
@@ -341,8 +415,10 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
                                w->gscratch, g_stride, spill, ShardIO{}));
         HIP_TRY(hipMemcpyAsync(w->h_retry, final_cnt, 4, hipMemcpyDeviceToHost, st));
     }
+    if (fast) HIP_TRY(hipMemcpyAsync(w->h_retry + 1, w->slow_cnt, 4, hipMemcpyDeviceToHost, st));
+    else w->h_retry[1] = p.nq;
     HIP_TRY(hipEventRecord(ev[2], st));
-    ++w->calls; w->last_retry = (may_overflow || dense) ? 1 : 0;
+    ++w->calls; w->last_retry = (may_overflow || dense) ? 1 : 0; w->last_nq = p.nq;
 
     if (!on_device) {
         HIP_TRY(hipMemcpyAsync(h_ids, p.out_ids, n_out * 8, hipMemcpyDeviceToHost, st));
@@ -395,6 +471,19 @@ int device_last_kernel_ms(DeviceState* d, double* ms_main, double* ms_retry, uin
     if (ms_main) *ms_main = a;
     if (ms_retry) *ms_retry = b;
     if (retried) *retried = w->last_retry ? *w->h_retry : 0;
+    return SRN_OK;
+}
+
+// how the last call's queries were served: by the fast kernel / handed to the general kernel / through the global-table pass
+int device_last_path_counts(DeviceState* d, uint32_t* nq, uint32_t* general, uint32_t* global_pass) {
+    HIP_TRY(hipSetDevice(d->device));
+    Workspace* w;
+    { std::lock_guard<std::mutex> lk(d->mu); w = d->last_ws; }
+    if (!w || !w->calls) return fail(SRN_EINVAL, "no predict call yet");
+    HIP_TRY(hipEventSynchronize(w->ev[(w->calls - 1) % Workspace::RING][2]));
+    if (nq) *nq = w->last_nq;
+    if (general) *general = w->h_retry[1];
+    if (global_pass) *global_pass = w->last_retry ? w->h_retry[0] : 0;
     return SRN_OK;
 }
 

@@ -104,6 +104,12 @@ class VMISIndex:
         return a.value, b.value, r.value
 
 
+    def last_path_counts(self):
+        """(queries of the last call, served by the general kernel, served through the global-table pass)."""
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        capi.check(capi.lib().srn_last_path_counts(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def kernel_times(self, max_n=64):
         """Per-call (main kernel ms, retry pass ms) of the most recent predict calls, oldest first (HIP events
         recorded on the launch stream around each launch)."""

@@ -60,7 +60,7 @@ def test_kat1_should_train_and_predict():
         assert r.score == pytest.approx(1.751319134149782, rel=1e-12)
 
 
-@pytest.fixture(params=["default", "no_masks", "no_hot", "hot64", "no_sketch", "sketch64", "no_merge", "dense"])
+@pytest.fixture(params=["default", "no_fast", "no_masks", "no_hot", "hot64", "no_sketch", "sketch64", "no_merge", "dense"])
 def kernel_path(request, monkeypatch):
     """The kernel picks code paths per launch: position-set slots (sessions <= 8 items) vs numerator slots + first-match
     pass; direct-mapped accumulators for popular items vs hash only; sketch pre-filter on / off / tiny; candidate sessions by
@@ -81,7 +81,13 @@ def kernel_path(request, monkeypatch):
     elif request.param == "sketch64":          # heavy collisions in the upper-bound words: the filter must stay exact
         monkeypatch.setenv("SRN_SKETCH_SLOTS", "64")
         monkeypatch.setenv("SRN_HOT_SLOTS", "32")
-    return request.param
+    elif request.param == "no_fast":           # the general kernel alone (the fast kernel hands it single queries otherwise)
+        monkeypatch.setenv("SRN_NO_FAST", "1")
+    from serenade_amd import capi
+    capi.reload_knobs()                        # the library reads its knobs once; tests switch paths between calls
+    yield request.param
+    monkeypatch.undo()
+    capi.reload_knobs()
 
 
 @pytest.mark.parametrize("tied", [False, True])
@@ -307,15 +313,27 @@ def test_baseline_configs_full_size(config, n_check, monkeypatch):
     assert (res["stats"][:, 1] == m).any() and (res["stats"][:, 2] == k).any()      # both cuts are exercised at this size
     a = sa.predict_batch(gix, (qi, qo), k, m, synth.HOW_MANY)     # product path: sketch pre-filter on
     assert np.array_equal(a[0][:n_check], res["ids"]) and np.array_equal(a[1][:n_check], res["scores"])
-    monkeypatch.setenv("SRN_NO_MERGE", "1")                        # session hash table + selects instead of the merge tree
-    c = sa.predict_batch(gix, (qi, qo), k, m, synth.HOW_MANY)
-    for x, y in zip(a, c):
-        assert np.array_equal(x, y)
-    monkeypatch.setenv("SRN_NO_MASKS", "1")                        # no direct-mapped part => no threshold => nothing filtered
-    monkeypatch.setenv("SRN_HOT_SLOTS", "0")
-    b = sa.predict_batch(gix, (qi, qo), k, m, synth.HOW_MANY)
-    for x, y in zip(a, b):
-        assert np.array_equal(x, y)
+    from serenade_amd import capi
+    try:
+        monkeypatch.setenv("SRN_NO_FAST", "1")                     # the general kernel alone (merge tree, position sets, sketch filter)
+        capi.reload_knobs()
+        g = sa.predict_batch(gix, (qi, qo), k, m, synth.HOW_MANY)
+        for x, y in zip(a, g):
+            assert np.array_equal(x, y)
+        monkeypatch.setenv("SRN_NO_MERGE", "1")                    # session hash table + selects instead of the merge tree
+        capi.reload_knobs()
+        c = sa.predict_batch(gix, (qi, qo), k, m, synth.HOW_MANY)
+        for x, y in zip(a, c):
+            assert np.array_equal(x, y)
+        monkeypatch.setenv("SRN_NO_MASKS", "1")                    # no direct-mapped part => no threshold => nothing filtered
+        monkeypatch.setenv("SRN_HOT_SLOTS", "0")
+        capi.reload_knobs()
+        b = sa.predict_batch(gix, (qi, qo), k, m, synth.HOW_MANY)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    finally:
+        monkeypatch.undo()
+        capi.reload_knobs()
     assert nq > 30000
 
 

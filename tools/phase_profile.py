@@ -21,11 +21,15 @@ ix.debug_phase_cycles(True)
 t0 = time.time(); sa.predict_batch(ix, (qi, qo), k, m, 21, bool(FL)); dt = time.time() - t0
 cyc = ix.debug_phase_cycles(False).astype(np.float64)
 ms, msr, _ = ix.last_kernel_ms()
+print("path counts (nq, general kernel, global pass):", ix.last_path_counts())
 r = sa.predict_batch_debug(ix, (qi, qo), k, m, 21, bool(FL), neighbours=False)
-names = ["0 prep+clear", "1 stage lists", "2 merges+m-cut", "3 class count", "4 k-cut scans+publish", "5", "6", "7", "8 clear hot+sketch", "9 walk A", "10 harvest hot", "11 live check+clear", "12 walk B", "13 harvest exact", "14", "15"]
+names = ["0 prep+clear", "1 stage lists", "2 merges+m-cut", "3 class count", "4 k-cut scans+publish", "5", "6", "7", "8 clear hot+sketch", "9 walk A", "10 harvest hot", "11 live check+clear", "12 walk B (+surv)", "13 harvest exact/final", "14", "15"]
 print("main %.2f ms retry %.2f ms  total cycles %.3g" % (ms, msr, cyc.sum()))
 for n, c in zip(names, cyc):
     print("  %-18s %6.2f%%  %.0f cyc/query" % (n, 100 * c / cyc.sum(), c / B))
+print("dbg: sum floor_b %d  sum t32>>16 %d  B %d" % (cyc[15], cyc[3], B))
+if cyc[14]:
+    print("fast kernel: queries %d, walk-B hit elements/query %.1f, candidates/query %.1f, floor survivors/query %.1f" % (cyc[14], cyc[5] / cyc[14], cyc[6] / cyc[14], cyc[7] / cyc[14]))
 st = r["stats"].astype(np.float64)
 print("mean P,C,K,I,D,H,L", st[:, :7].mean(0).round(1), "retry frac", (st[:, 7] == 1).mean())
 print("D pct", np.percentile(st[:, 4], [50, 90, 99, 100]), "I pct", np.percentile(st[:, 3], [50, 90, 99, 100]), "P pct", np.percentile(st[:,0],[50,90,99,100]))
