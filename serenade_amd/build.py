@@ -42,6 +42,9 @@ def build_hip(force=False, verbose=False):
                 # hoisting loop invariants out of the per-query loop keeps them live for ~100 K cycles: a third fewer SGPR spill
                 # moves and half the scratch accesses without it, +5..6 % queries/s
                 cmd += ["-mllvm", "-disable-machine-licm"]
+            if name == "srn_fast.hip":
+                # same reason: invariants hoisted out of the per-query loop get spilled (11 -> 4 VGPR spills at the 80-register cap of three workgroups per CU)
+                cmd += ["-mllvm", "-disable-machine-licm"]
             cmd += extra + ["-c", "-o", obj, src]
             if verbose:
                 print(" ".join(cmd))

@@ -36,8 +36,12 @@ static constexpr uint32_t F_MERGE_WORDS = F_WORK_WORDS;
 
 // per-phase cycle accounting (debug): summed per workgroup in LDS, flushed once at the end -- one global atomic per phase and
 // query (as the general kernel does) serialises on 16 addresses and distorts what it measures
+#ifndef SRN_FAST_STOP
+#define SRN_FAST_STOP (-1)   // experiments only (tools/fast_phase_insts.sh): every query leaves after phase tick N, to count instructions per phase
+#endif
 #define FAST_TICK(ph) \
-    do { if (ticking && tid == 0) { const long long t_ = clock64(); tacc[ph] += (unsigned long long)(t_ - t_prev); t_prev = t_; } } while (0)
+    do { if (ticking && tid == 0) { const long long t_ = clock64(); tacc[ph] += (unsigned long long)(t_ - t_prev); t_prev = t_; } } while (0); \
+    if (SRN_FAST_STOP == (ph)) continue
 
 // -------------------------------------------------------------------------------------
 // Row layout kernel (attach time): CSR rows -> 64-byte slots of 16-bit LDS byte offsets (relative to F_HOT) + overflow
@@ -93,11 +97,15 @@ __global__ __launch_bounds__(1024) void rows_to_packed_kernel(const uint64_t* __
 
 // -------------------------------------------------------------------------------------
 // merge path over two adjacent sorted (descending) runs A = in[sa, sa + la), B = in[sa + la, sa + la + lb) -> out[sa, ...):
-// thread t produces outputs [t g, (t + 1) g).  All values are distinct (the position bit differs between lists).
+// team thread t (of nthr) produces outputs [t g, (t + 1) g).  All values are distinct (the position bit differs between lists).
+// A thread's binary search on its diagonal costs ~11 round trips whatever g is, so a pair is merged by only as many waves as give
+// every thread ~8 outputs (merge_team): the searches of the other waves would be pure overhead.
 // -------------------------------------------------------------------------------------
-__device__ __forceinline__ void merge_pair(const uint32_t* in, uint32_t* out, uint32_t sa, uint32_t la, uint32_t lb, uint32_t tid) {
-    const uint32_t sb = sa + la, total = la + lb, g = (total + 511u) >> 9;
-    const uint32_t d0 = min(tid * g, total), d1 = min(d0 + g, total);
+__device__ __forceinline__ uint32_t merge_team(uint32_t total) { return min(512u, max(64u, (((total + 7u) >> 3) + 63u) & ~63u)); }
+__device__ __forceinline__ void merge_pair(const uint32_t* in, uint32_t* out, uint32_t sa, uint32_t la, uint32_t lb, uint32_t ttid, uint32_t nthr) {
+    if (ttid >= nthr) return;   // (whole waves)
+    const uint32_t sb = sa + la, total = la + lb, g = (total + nthr - 1u) / nthr;
+    const uint32_t d0 = min(ttid * g, total), d1 = min(d0 + g, total);
     if (d0 >= d1) return;
     uint32_t lo = d0 > lb ? d0 - lb : 0u, hi = min(d0, la);
     while (lo < hi) {
@@ -158,6 +166,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
     auto qpos = [&](uint32_t pq) -> uint32_t { return ((wave + NW * (pq >> 6)) << 6) + (pq & 63u); };   // the wave's own neighbour-list slots
 
     for (uint32_t q = blockIdx.x; q < p.nq; q += gridDim.x) {
+        long long t_prev = ticking ? clock64() : 0;
         // ---- phase 0: the query's prep record -> run descriptors in SGPRs ------------------------------
         const char* const rec = p.prep + (size_t)q * p.prep_stride;
         const PrepHead hd = *(const PrepHead*)rec;   // (uniform address)
@@ -185,8 +194,15 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         const uint32_t cur_idx = (uint32_t)__builtin_amdgcn_readlane((int)x0.idx, 0);
         const uint32_t s1 = kp[0], s2 = s1 + kp[1], s3 = s2 + kp[2];
 
+        // The stage loads go out BEFORE the barrier that ends the previous query: waves 1..7 get here while wave 0 still ranks that
+        // query's candidates, and their share of the posting lists is in flight meanwhile.
+        uint32_t v[4][5];   // every load of every list in flight at once (uniform skips; past a list's end the lanes re-read its last entry)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) { v[r][j] = 0u; if ((uint32_t)j * BLOCK < kp[r]) v[r][j] = src[r][min(tid + j * BLOCK, kp[r] - 1u)]; }
         __syncthreads();   // previous query's LDS reads are done
-        long long t_prev = ticking ? clock64() : 0;
+        FAST_TICK(0);
         if (tid < (uint32_t)FS_TACC) misc[tid] = 0;
         if (tid < (1u << L)) {
             uint32_t num = 0;
@@ -198,11 +214,6 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         uint32_t* const B0 = (uint32_t*)(smem + F_WORK); uint32_t* const B1 = B0 + n;
         const uint32_t nl = (nr > 1u) + (nr > 2u);
         {
-            uint32_t v[4][5];   // every load of every list in flight at once (uniform skips; past a list's end the lanes re-read its last entry)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int j = 0; j < 5; ++j) { v[r][j] = 0u; if ((uint32_t)j * BLOCK < kp[r]) v[r][j] = src[r][min(tid + j * BLOCK, kp[r] - 1u)]; }
             uint32_t* const d01 = nl == 1u ? B1 : B0; uint32_t* const d2 = nr == 3u ? B1 : B0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -214,10 +225,11 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         __syncthreads();
         FAST_TICK(1);
         // ---- merge tree: <= 2 levels, the final run lands in B0 ------------------------------------------
-        if (nr == 2u) { merge_pair(B1, B0, 0u, kp[0], kp[1], tid); __syncthreads(); }
-        else if (nr == 3u) { merge_pair(B0, B1, 0u, kp[0], kp[1], tid); __syncthreads(); merge_pair(B1, B0, 0u, s2, kp[2], tid); __syncthreads(); }
-        else if (nr == 4u) { merge_pair(B0, B1, 0u, kp[0], kp[1], tid); merge_pair(B0, B1, s2, kp[2], kp[3], tid); __syncthreads();
-                             merge_pair(B1, B0, 0u, s2, kp[2] + kp[3], tid); __syncthreads(); }
+        // (level 0 of four runs: the first pair's team counts threads from 0 up, the second pair's from 511 down -- on disjoint waves when both are small)
+        if (nr == 2u) { merge_pair(B1, B0, 0u, kp[0], kp[1], tid, merge_team(s2)); __syncthreads(); }
+        else if (nr == 3u) { merge_pair(B0, B1, 0u, kp[0], kp[1], tid, merge_team(s2)); __syncthreads(); merge_pair(B1, B0, 0u, s2, kp[2], tid, merge_team(n)); __syncthreads(); }
+        else if (nr == 4u) { merge_pair(B0, B1, 0u, kp[0], kp[1], tid, merge_team(s2)); merge_pair(B0, B1, s2, kp[2], kp[3], 511u - tid, merge_team(n - s2)); __syncthreads();
+                             merge_pair(B1, B0, 0u, s2, kp[2] + kp[3], tid, merge_team(n)); __syncthreads(); }
         const uint32_t* F = B0; uint32_t* D = B1;
         // ---- m-cut: the copies of a session are adjacent in F; the first m distinct sessions, position sets OR-ed ----
         uint32_t Call, Cm;
@@ -395,15 +407,13 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             uint32_t t32 = 0xFFFFFFFFu;
 #pragma unroll
             for (int w = 0; w < NW; ++w) t32 = min(t32, misc[FS_W3 + w]);
-            if (t32 < 2u) {   // block-uniform: no threshold from the sample (a small query) -- the general kernel takes it
-                if (tid == 0) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q;
-                continue;
-            }
-            t32m1 = t32 - 1u;
+            // no threshold from the sample (t32 == 0: a small query): everything valid is a candidate, every element of a non-popular
+            // item is listed; the caps of the lists decide whether the query fits (the general kernel takes it otherwise)
+            t32m1 = t32 ? t32 - 1u : 0u;
             const bool take = valid && k32 >= t32m1;
             const uint32_t at = wave_append(take, &misc[FS_CCNT]);
             if (take) { if (at < F_CAND_CAP) { ckey[at] = (unsigned long long)__double_as_longlong(x); cidx[at] = tie; } else misc[FS_FAIL] = 1;
-                        const uint32_t hb = k32 >> 16, tb = t32 >> 16; atomicAdd(&thist[hb > tb ? min(hb - tb, 255u) : 0u], 1u); }   // (>= 24 entries, few more: no pile-up)
+                        const uint32_t hb = k32 >> 16, tb = t32 >> 16; if (t32) atomicAdd(&thist[hb > tb ? min(hb - tb, 255u) : 0u], 1u); }   // (>= 24 entries, few more: no pile-up)
             // integer floors: an item needs idf * acc >= x_lo, i.e. acc >= x_lo / (largest idf of its chunk); shaved so that rounding
             // can only keep more.  Lane c computes chunk c's floor (lane 8: the sketch words'), broadcast by v_readlane.
             const double x_lo = __longlong_as_double((long long)((unsigned long long)t32m1 << 32));
@@ -443,7 +453,6 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
                 floor_b = (uint32_t)fmin(4.0e9, fmax(1.0, floor(x_lo * f.inv_idf_hi * (1.0 - 1e-9)) - 1.0));
             }
         }
-        if (ticking && tid == 0) { tacc[15] += floor_b; tacc[3] += t32m1 >> 16; }
         FAST_TICK(10);
         {
             const uint32_t ns = min(misc[FS_SURV], SURV_CAP);
@@ -479,36 +488,47 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
                     ++at;
                 }
             };
+            // the usual case costs one v_max3 per two positions: the largest word of the lane's row; only a wave that sees a word at the
+            // floor looks again, position by position
+            auto mx2 = [&](uint32_t mx, uint32_t wd) -> uint32_t {
+                const uint32_t a = *(const uint32_t*)(acc_base + (wd & 0xFFFFu)), b = *(const uint32_t*)(acc_base + (wd >> 16));
+                return max(max(mx, a), b); };
             uint32_t sv3b = 0, hdr3b = 0; uint4 c43b = make_uint4(0u, 0u, 0u, 0u), d43b = c43b;
             if (cnt3) q3_load(0u, sv3b, hdr3b, c43b, d43b);   // requested before round (i), which needs no memory
 #pragma unroll
             for (int t = 0; t < 3; ++t) {   // (i) from the registers
                 if (wave * 64u + (uint32_t)t * BLOCK < K) {
-                    const bool act = wave * 64u + lane + (uint32_t)t * BLOCK < K;
-                    uint32_t hm = 0;
-                    if (act) {
-                        hm = chk2(chk2(chk2(0u, rq[t].y), rq[t].z), rq[t].w) << 8;
-                        if ((rq[t].x & 0xFFFFu) > 6u) hm = chk2(chk2(chk2(chk2(hm >> 8, rq1[t].x), rq1[t].y), rq1[t].z), rq1[t].w);
+                    const bool act = wave * 64u + lane + (uint32_t)t * BLOCK < K, two = (rq[t].x & 0xFFFFu) > 6u;
+                    uint32_t mx = 0;
+                    if (act) { mx = mx2(mx2(mx2(0u, rq[t].y), rq[t].z), rq[t].w); if (two) mx = mx2(mx2(mx2(mx2(mx, rq1[t].x), rq1[t].y), rq1[t].z), rq1[t].w); }
+                    if (__ballot(mx >= floor_b) != 0ull) {
+                        uint32_t hm = 0;
+                        if (act) {
+                            hm = chk2(chk2(chk2(0u, rq[t].y), rq[t].z), rq[t].w) << 8;
+                            if (two) hm = chk2(chk2(chk2(chk2(hm >> 8, rq1[t].x), rq1[t].y), rq1[t].z), rq1[t].w);
+                        }
+                        list_hits(hm, 14u, svr[t], 0u);
                     }
-                    list_hits(hm, 14u, svr[t], 0u);
                 }
             }
             auto chk_tail = [&](uint32_t p0, uint32_t sv, uint32_t hdr, const uint4& c4, const uint4& d4) {
                 const bool act = p0 + lane < cnt3;
                 const uint32_t len = hdr & 0xFFFFu;
-                uint32_t hm = 0;
+                uint32_t hm = 0, mx = 0;
+                if (act) { mx = mx2(mx2(mx2(mx2(mx2(mx2(mx2(0u, c4.x), c4.y), c4.z), c4.w), d4.x), d4.y), d4.z); if (len <= 30u) mx = mx2(mx, d4.w); }
+                if (__ballot(mx >= floor_b) != 0ull) {
                 if (act) {
                     hm = chk2(chk2(chk2(chk2(chk2(chk2(chk2(0u, c4.x), c4.y), c4.z), c4.w), d4.x), d4.y), d4.z);
                     if (len > 30u) hm <<= 2; else hm = chk2(hm, d4.w);
                 }
-                list_hits(hm, 16u, sv, 14u);
+                list_hits(hm, 16u, sv, 14u); }
                 for (uint32_t t8 = 28u; __ballot(act && len > 30u && t8 < len) != 0ull; t8 += 8u) {
                     uint32_t hm2 = 0;
                     if (act && len > 30u && t8 < len) {
                         const uint4 e4 = reinterpret_cast<const uint4*>(f.row_ext16)[(size_t)d4.w + ((t8 - 28u) >> 3)];
                         hm2 = chk2(chk2(chk2(chk2(0u, e4.x), e4.y), e4.z), e4.w);
                     }
-                    list_hits(hm2, 8u, sv, t8);
+                    list_hits(hm2, 8u, sv, t8);   // (rows of > 30 items are few: no fast path)
                 } };
             if (cnt3) chk_tail(0u, sv3b, hdr3b, c43b, d43b);
             for (uint32_t p0 = 64u; p0 < cnt3; p0 += 64u) { uint32_t sv, hdr; uint4 c4, d4; q3_load(p0, sv, hdr, c4, d4); chk_tail(p0, sv, hdr, c4, d4); }
@@ -537,46 +557,94 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         // the exact table's items join the candidates; score = x / (10 U) (the reference's multiply-then-divide, mod.rs:146-152); rank by counting
         if (wave != 0u) continue;
         bool fail0 = false;
+        {   // the table's contenders (exact sum at the floor: the others were collisions in their sketch word) are compacted first, so that
+            // their idf comes with ONE gather, all lanes at once, instead of one round trip per bucket slot
+            uint2* tl = hits;   // (the hit list is dead)
+            uint32_t nt = 0;
 #pragma unroll
-        for (uint32_t b0 = 0; b0 < (F_TABLE_BUCKETS + 63u) / 64u; ++b0) {
-            const uint32_t bk = b0 * 64u + lane;
-            uint4 kq = make_uint4(EMPTY32, EMPTY32, EMPTY32, EMPTY32);
-            if (bk < F_TABLE_BUCKETS) kq = reinterpret_cast<const uint4*>(ikeys)[bk];
-            const uint32_t kk[4] = {kq.x, kq.y, kq.z, kq.w};
+            for (uint32_t b0 = 0; b0 < (F_TABLE_BUCKETS + 63u) / 64u; ++b0) {
+                const uint32_t bk = b0 * 64u + lane;
+                uint4 kq = make_uint4(EMPTY32, EMPTY32, EMPTY32, EMPTY32), aq = make_uint4(0u, 0u, 0u, 0u);
+                if (bk < F_TABLE_BUCKETS) { kq = reinterpret_cast<const uint4*>(ikeys)[bk]; aq = reinterpret_cast<const uint4*>(iacc)[bk]; }
+                const uint32_t kk[4] = {kq.x, kq.y, kq.z, kq.w}, aa[4] = {aq.x, aq.y, aq.z, aq.w};
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const uint32_t it = kk[s4];
-                if (__ballot(it != EMPTY32) == 0ull) continue;
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const bool in = kk[s4] != EMPTY32 && kk[s4] != cur_idx && aa[s4] >= floor_b;
+                    const unsigned long long bm = __ballot(in);
+                    if (in) tl[nt + (uint32_t)__popcll(bm & lt)] = make_uint2(kk[s4], aa[s4]);
+                    nt += (uint32_t)__popcll(bm);
+                }
+            }
+            FAST_TICK(3);
+            for (uint32_t i0 = 0; i0 < nt; i0 += 64u) {
+                const uint32_t i = i0 + lane;
                 bool take = false; double x = 0.0; uint32_t tie = 0;
-                if (it != EMPTY32 && it != cur_idx) {   // (few: divergence is cheap here)
-                    const ItemMeta mt = ix.meta[it];
-                    x = (mt.idf > 0.0 ? mt.idf : 1.0) * (double)iacc[4 * bk + s4]; tie = mt.id_rank;
+                if (i < nt) {
+                    const uint2 e = tl[i]; const ItemMeta mt = ix.meta[e.x];
+                    x = (mt.idf > 0.0 ? mt.idf : 1.0) * (double)e.y; tie = mt.id_rank;
                     take = (uint32_t)((unsigned long long)__double_as_longlong(x) >> 32) >= t32m1;
                 }
                 const uint32_t at = wave_append(take, &misc[FS_CCNT]);
                 if (take) { if (at < F_CAND_CAP) { ckey[at] = (unsigned long long)__double_as_longlong(x); cidx[at] = tie; } else fail0 = true; }
             }
         }
+        FAST_TICK(15);
         const uint32_t cnt = misc[FS_CCNT];   // (this wave's own LDS traffic is ordered; the other waves' appends are behind the barrier above)
         if (__ballot(fail0) != 0ull || cnt > F_CAND_CAP) { if (lane == 0u) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q; continue; }
-        if (ticking && lane == 0u) { tacc[6] += cnt; tacc[7] += misc[FS_SURV]; tacc[14] += 1ull; }
+        if (ticking && lane == 0u) { tacc[6] += cnt; tacc[14] += 1ull; }
         const double denom = (double)(10u * U);
         // x -> score is monotone and what was dropped is strictly below every kept score, but two kept x may round to the same score:
         // the ranks are counted on the scores themselves (positive doubles order like their bit patterns)
         for (uint32_t i = lane; i < cnt; i += 64u) ckey[i] = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)ckey[i]) / denom);
-        for (uint32_t c0 = 0; c0 < cnt; c0 += 64u) {   // candidates c0 + lane; candidate j is read from LDS at a uniform address (broadcast)
-            const uint32_t i = c0 + lane;
-            unsigned long long mk = 0; uint32_t tie = EMPTY32; unsigned long long pid = 0;
-            if (i < cnt) { tie = cidx[i]; pid = ix.id_sorted[tie]; mk = ckey[i]; }   // (the id arrives while the ranks are counted)
+        FAST_TICK(7);
+        if (cnt <= 64u) {   // candidate j is broadcast by v_readlane: no LDS round trip, no branch per comparison
+            unsigned long long mk = 0; uint32_t tie = EMPTY32;
+            if (lane < cnt) { tie = cidx[lane]; mk = ckey[lane]; }
+            const int klo = (int)(uint32_t)mk, khi = (int)(uint32_t)(mk >> 32);
             uint32_t rank = 0;
-#pragma unroll 4
-            for (uint32_t j = 0; j < cnt; ++j) { const unsigned long long kj = ckey[j]; const uint32_t ij = cidx[j]; rank += kj > mk || (kj == mk && ij < tie); }
-            if (i < cnt && rank < p.how_many) { p.out_ids[(size_t)q * p.how_many + rank] = pid; p.out_scores[(size_t)q * p.how_many + rank] = __longlong_as_double((long long)mk); }
+            for (uint32_t j = 0; j < cnt; ++j) {
+                const uint32_t jl = (uint32_t)__builtin_amdgcn_readlane(klo, (int)j), jh = (uint32_t)__builtin_amdgcn_readlane(khi, (int)j), ij = (uint32_t)__builtin_amdgcn_readlane((int)tie, (int)j);
+                const unsigned long long kj = ((unsigned long long)jh << 32) | jl;
+                rank += (uint32_t)(kj > mk) | ((uint32_t)(kj == mk) & (uint32_t)(ij < tie));
+            }
+            if (lane < cnt && rank < p.how_many) { p.out_ids[(size_t)q * p.how_many + rank] = tie; p.out_scores[(size_t)q * p.how_many + rank] = __longlong_as_double((long long)mk); }   // (id rank: vmis_translate_kernel turns it into the public id)
+        } else
+        for (uint32_t c0 = 0; c0 < cnt; c0 += 64u) {   // candidates c0 + lane; candidate j is read from LDS at a uniform address (broadcast), four per round trip
+            const uint32_t i = c0 + lane;
+            unsigned long long mk = 0; uint32_t tie = EMPTY32;
+            if (i < cnt) { tie = cidx[i]; mk = ckey[i]; }
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < cnt; j += 4u) {
+                unsigned long long kj[4]; uint32_t ij[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) { const uint32_t jj = min(j + u, cnt - 1u); kj[u] = ckey[jj]; ij[u] = cidx[jj]; }
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) rank += (uint32_t)(j + u < cnt) & ((uint32_t)(kj[u] > mk) | ((uint32_t)(kj[u] == mk) & (uint32_t)(ij[u] < tie)));
+            }
+            if (i < cnt && rank < p.how_many) { p.out_ids[(size_t)q * p.how_many + rank] = tie; p.out_scores[(size_t)q * p.how_many + rank] = __longlong_as_double((long long)mk); }
         }
-        if (lane == 0u) p.out_counts[q] = min(cnt, p.how_many);
+        if (lane == 0u) p.out_counts[q] = min(cnt, p.how_many) | 0x80000000u;   // (flag: the ids of this row are still id ranks)
         FAST_TICK(13);
     }
     if (ticking) { __syncthreads(); if (tid < 16u && tacc[tid]) atomicAdd(&p.phase_cycles[tid], tacc[tid]); }
+}
+
+// The fast kernel returns id ranks (the final tie-break key it already holds) instead of public ids: looking the id up at the end
+// of every query puts an HBM round trip on each workgroup's serial path; here it is one gather per returned item, all in flight.
+__global__ __launch_bounds__(256) void vmis_translate_kernel(const uint64_t* __restrict__ id_sorted, uint64_t* __restrict__ out_ids, uint32_t* __restrict__ out_counts,
+                                                             uint32_t nq, uint32_t how_many) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const uint32_t c = out_counts[q];
+    if (c == 0xFFFFFFFFu || !(c & 0x80000000u)) return;   // (not served, or served by the general kernel: public ids already)
+    const uint32_t n = c & 0x7FFFFFFFu;
+    uint64_t* row = out_ids + (size_t)q * how_many;
+    for (uint32_t j = 0; j < n; ++j) row[j] = id_sorted[row[j]];
+    out_counts[q] = n;
+}
+hipError_t launch_translate(hipStream_t st, const DeviceIndex& di, uint64_t* out_ids, uint32_t* out_counts, uint32_t nq, uint32_t how_many) {
+    hipLaunchKernelGGL(vmis_translate_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, di.id_sorted, out_ids, out_counts, nq, how_many);
+    return hipGetLastError();
 }
 
 hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f) {

@@ -72,6 +72,7 @@ hipError_t launch_predict(bool masks, bool slot64, bool global_tables, int stage
                           uint32_t* retry_cnt, char* gscratch, unsigned long long gscratch_stride, char* nb_spill, const ShardIO& sh, int wg_per_cu = 2);
 hipError_t launch_prep(hipStream_t st, const DeviceIndex& di, const uint64_t* items_flat, const uint32_t* q_off, uint32_t nq, uint32_t m,
                        uint32_t max_len, char* out, uint32_t stride);
+hipError_t launch_translate(hipStream_t st, const DeviceIndex& di, uint64_t* out_ids, uint32_t* out_counts, uint32_t nq, uint32_t how_many);   // id ranks -> public ids for the rows the fast kernel served
 hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f);
 hipError_t launch_rows_to_packed(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base,
                                  uint32_t* packed, uint32_t* ext16);   // grid = ceil((n_rows + 1) / 1024) blocks of 1024; block_base in 16-byte blocks

@@ -401,6 +401,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         const uint32_t grid_f = (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * F_WG_PER_CU * grid_mult);
         HIP_TRY(launch_fast(dim3(grid_f), st, d->di, p, fp));
         HIP_TRY(launch_predict(geo.masks, slot64, false, 0, dim3(grid), lds, st, d->di, p, c, w->slow_list, w->slow_cnt, w->retry_list, w->retry_cnt, nullptr, 0, spill, ShardIO{}));
+        HIP_TRY(launch_translate(st, d->di, p.out_ids, p.out_counts, p.nq, p.how_many));
     } else
     if (dense) {
         HIP_TRY(launch_predict(geo.masks, false, false, 0, dim3(grid3), g3.lds, st, d->di, p, g3.c, nullptr, nullptr, w->retry_list, w->retry_cnt, nullptr, 0, spill, ShardIO{}, 3));

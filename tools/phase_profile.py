@@ -27,7 +27,6 @@ names = ["0 prep+clear", "1 stage lists", "2 merges+m-cut", "3 class count", "4 
 print("main %.2f ms retry %.2f ms  total cycles %.3g" % (ms, msr, cyc.sum()))
 for n, c in zip(names, cyc):
     print("  %-18s %6.2f%%  %.0f cyc/query" % (n, 100 * c / cyc.sum(), c / B))
-print("dbg: sum floor_b %d  sum t32>>16 %d  B %d" % (cyc[15], cyc[3], B))
 if cyc[14]:
     print("fast kernel: queries %d, walk-B hit elements/query %.1f, candidates/query %.1f, floor survivors/query %.1f" % (cyc[14], cyc[5] / cyc[14], cyc[6] / cyc[14], cyc[7] / cyc[14]))
 st = r["stats"].astype(np.float64)
