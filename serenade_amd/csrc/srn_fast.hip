@@ -36,6 +36,9 @@ static constexpr uint32_t F_MERGE_WORDS = F_WORK_WORDS;
 
 // per-phase cycle accounting (debug): summed per workgroup in LDS, flushed once at the end -- one global atomic per phase and
 // query (as the general kernel does) serialises on 16 addresses and distorts what it measures
+#ifndef SRN_FAST_RELOAD_ROWS
+#define SRN_FAST_RELOAD_ROWS 0
+#endif
 #ifndef SRN_FAST_STOP
 #define SRN_FAST_STOP (-1)   // experiments only (tools/fast_phase_insts.sh): every query leaves after phase tick N, to count instructions per phase
 #endif
@@ -165,6 +168,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
     const uint32_t n_kept = ix.n_kept;
     auto qpos = [&](uint32_t pq) -> uint32_t { return ((wave + NW * (pq >> 6)) << 6) + (pq & 63u); };   // the wave's own neighbour-list slots
 
+    uint32_t fin_used = 0;   // (wave 0) units of this workgroup's arena slice in use
     for (uint32_t q = blockIdx.x; q < p.nq; q += gridDim.x) {
         long long t_prev = ticking ? clock64() : 0;
         // ---- phase 0: the query's prep record -> run descriptors in SGPRs ------------------------------
@@ -494,7 +498,17 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
                 const uint32_t a = *(const uint32_t*)(acc_base + (wd & 0xFFFFu)), b = *(const uint32_t*)(acc_base + (wd >> 16));
                 return max(max(mx, a), b); };
             uint32_t sv3b = 0, hdr3b = 0; uint4 c43b = make_uint4(0u, 0u, 0u, 0u), d43b = c43b;
-            if (cnt3) q3_load(0u, sv3b, hdr3b, c43b, d43b);   // requested before round (i), which needs no memory
+#if SRN_FAST_RELOAD_ROWS
+            // the rows' first 32 bytes again (L2 hits), all requested at once: keeping them in registers since walk A costs 24 VGPRs
+            // across phase 4a -- at the 80-register cap of three workgroups per CU that means scratch spills on the serial paths
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const size_t r = K ? (size_t)(svr[t] >> NB) : (size_t)n_kept;
+                rq[t] = *reinterpret_cast<const uint4*>(&f.row_packed[r * 4]);
+                rq1[t] = *reinterpret_cast<const uint4*>(&f.row_packed[r * 4 + 1]);
+            }
+#endif
+            if (cnt3) q3_load(0u, sv3b, hdr3b, c43b, d43b);   // requested before round (i)
 #pragma unroll
             for (int t = 0; t < 3; ++t) {   // (i) from the registers
                 if (wave * 64u + (uint32_t)t * BLOCK < K) {
@@ -553,97 +567,116 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         __syncthreads();
         FAST_TICK(12);
         if (misc[FS_FAIL]) { if (tid == 0) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q; continue; }   // block-uniform
-        // ---- phase 4b + final ranking: wave 0 alone (the others go on to the next query's record and wait at its first barrier) ----
-        // the exact table's items join the candidates; score = x / (10 U) (the reference's multiply-then-divide, mod.rs:146-152); rank by counting
+        // ---- hand-off: wave 0 alone (the others go on to the next query's record and wait at its first barrier) ---------------
+        // What is left -- the idf of the exact table's contenders, score = x / (10 U), the ranking, the public ids -- is a chain of
+        // dependent gathers and a serial loop: on this workgroup's path it would cost 10 K cycles per query with seven waves idle.
+        // The candidates and the table's contenders (exact sum at the floor; the others were collisions in their sketch word) are
+        // written to a per-query record instead, and vmis_finish_kernel ranks all queries of the batch, one wave each.
         if (wave != 0u) continue;
-        bool fail0 = false;
-        {   // the table's contenders (exact sum at the floor: the others were collisions in their sketch word) are compacted first, so that
-            // their idf comes with ONE gather, all lanes at once, instead of one round trip per bucket slot
-            uint2* tl = hits;   // (the hit list is dead)
-            uint32_t nt = 0;
+        // (every lane-derived value of this tail is recomputed from an opaque copy of the lane id: hoisted out of the query loop, such
+        //  values stay live through all phases, get spilled at the 80-register cap and come back from scratch right here, on the serial path)
+        uint32_t ln = lane; asm volatile("" : "+v"(ln));
+        const unsigned long long ltl = (1ull << ln) - 1ull;
+        uint2* tl = hits;   // (the hit list is dead)
+        uint32_t nt = 0;
 #pragma unroll
-            for (uint32_t b0 = 0; b0 < (F_TABLE_BUCKETS + 63u) / 64u; ++b0) {
-                const uint32_t bk = b0 * 64u + lane;
-                uint4 kq = make_uint4(EMPTY32, EMPTY32, EMPTY32, EMPTY32), aq = make_uint4(0u, 0u, 0u, 0u);
-                if (bk < F_TABLE_BUCKETS) { kq = reinterpret_cast<const uint4*>(ikeys)[bk]; aq = reinterpret_cast<const uint4*>(iacc)[bk]; }
-                const uint32_t kk[4] = {kq.x, kq.y, kq.z, kq.w}, aa[4] = {aq.x, aq.y, aq.z, aq.w};
+        for (uint32_t b0 = 0; b0 < (F_TABLE_BUCKETS + 63u) / 64u; ++b0) {
+            const uint32_t bk = b0 * 64u + ln;
+            uint4 kq = make_uint4(EMPTY32, EMPTY32, EMPTY32, EMPTY32), aq = make_uint4(0u, 0u, 0u, 0u);
+            if (bk < F_TABLE_BUCKETS) { kq = reinterpret_cast<const uint4*>(ikeys)[bk]; aq = reinterpret_cast<const uint4*>(iacc)[bk]; }
+            const uint32_t kk[4] = {kq.x, kq.y, kq.z, kq.w}, aa[4] = {aq.x, aq.y, aq.z, aq.w};
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    const bool in = kk[s4] != EMPTY32 && kk[s4] != cur_idx && aa[s4] >= floor_b;
-                    const unsigned long long bm = __ballot(in);
-                    if (in) tl[nt + (uint32_t)__popcll(bm & lt)] = make_uint2(kk[s4], aa[s4]);
-                    nt += (uint32_t)__popcll(bm);
-                }
-            }
-            FAST_TICK(3);
-            for (uint32_t i0 = 0; i0 < nt; i0 += 64u) {
-                const uint32_t i = i0 + lane;
-                bool take = false; double x = 0.0; uint32_t tie = 0;
-                if (i < nt) {
-                    const uint2 e = tl[i]; const ItemMeta mt = ix.meta[e.x];
-                    x = (mt.idf > 0.0 ? mt.idf : 1.0) * (double)e.y; tie = mt.id_rank;
-                    take = (uint32_t)((unsigned long long)__double_as_longlong(x) >> 32) >= t32m1;
-                }
-                const uint32_t at = wave_append(take, &misc[FS_CCNT]);
-                if (take) { if (at < F_CAND_CAP) { ckey[at] = (unsigned long long)__double_as_longlong(x); cidx[at] = tie; } else fail0 = true; }
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const bool in = kk[s4] != EMPTY32 && kk[s4] != cur_idx && aa[s4] >= floor_b;
+                const unsigned long long bm = __ballot(in);
+                if (in) tl[nt + (uint32_t)__popcll(bm & ltl)] = make_uint2(kk[s4], aa[s4]);
+                nt += (uint32_t)__popcll(bm);
             }
         }
-        FAST_TICK(15);
         const uint32_t cnt = misc[FS_CCNT];   // (this wave's own LDS traffic is ordered; the other waves' appends are behind the barrier above)
-        if (__ballot(fail0) != 0ull || cnt > F_CAND_CAP) { if (lane == 0u) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q; continue; }
-        if (ticking && lane == 0u) { tacc[6] += cnt; tacc[14] += 1ull; }
-        const double denom = (double)(10u * U);
-        // x -> score is monotone and what was dropped is strictly below every kept score, but two kept x may round to the same score:
-        // the ranks are counted on the scores themselves (positive doubles order like their bit patterns)
-        for (uint32_t i = lane; i < cnt; i += 64u) ckey[i] = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)ckey[i]) / denom);
-        FAST_TICK(7);
-        if (cnt <= 64u) {   // candidate j is broadcast by v_readlane: no LDS round trip, no branch per comparison
-            unsigned long long mk = 0; uint32_t tie = EMPTY32;
-            if (lane < cnt) { tie = cidx[lane]; mk = ckey[lane]; }
-            const int klo = (int)(uint32_t)mk, khi = (int)(uint32_t)(mk >> 32);
-            uint32_t rank = 0;
-            for (uint32_t j = 0; j < cnt; ++j) {
-                const uint32_t jl = (uint32_t)__builtin_amdgcn_readlane(klo, (int)j), jh = (uint32_t)__builtin_amdgcn_readlane(khi, (int)j), ij = (uint32_t)__builtin_amdgcn_readlane((int)tie, (int)j);
-                const unsigned long long kj = ((unsigned long long)jh << 32) | jl;
-                rank += (uint32_t)(kj > mk) | ((uint32_t)(kj == mk) & (uint32_t)(ij < tie));
-            }
-            if (lane < cnt && rank < p.how_many) { p.out_ids[(size_t)q * p.how_many + rank] = tie; p.out_scores[(size_t)q * p.how_many + rank] = __longlong_as_double((long long)mk); }   // (id rank: vmis_translate_kernel turns it into the public id)
-        } else
-        for (uint32_t c0 = 0; c0 < cnt; c0 += 64u) {   // candidates c0 + lane; candidate j is read from LDS at a uniform address (broadcast), four per round trip
-            const uint32_t i = c0 + lane;
-            unsigned long long mk = 0; uint32_t tie = EMPTY32;
-            if (i < cnt) { tie = cidx[i]; mk = ckey[i]; }
-            uint32_t rank = 0;
-            for (uint32_t j = 0; j < cnt; j += 4u) {
-                unsigned long long kj[4]; uint32_t ij[4];
-#pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) { const uint32_t jj = min(j + u, cnt - 1u); kj[u] = ckey[jj]; ij[u] = cidx[jj]; }
-#pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) rank += (uint32_t)(j + u < cnt) & ((uint32_t)(kj[u] > mk) | ((uint32_t)(kj[u] == mk) & (uint32_t)(ij[u] < tie)));
-            }
-            if (i < cnt && rank < p.how_many) { p.out_ids[(size_t)q * p.how_many + rank] = tie; p.out_scores[(size_t)q * p.how_many + rank] = __longlong_as_double((long long)mk); }
+        // record: {cnt, nt, U, 0} | x[cnt] f64 bits | (item, sum)[nt] | id rank[cnt], in 16-byte units from a bump allocator
+        // (no atomic: a returning global atomic would put its round trip right back on this path.  Every workgroup owns a slice of the
+        //  arena, sized for its share of the queries at 1 KB each -- ~2.5x what a query writes --, and fills it front to back.)
+        const uint32_t units = 1u + (cnt * 12u + nt * 8u + 15u) / 16u;
+        const uint32_t off = blockIdx.x * f.fin_units_per_block + fin_used;
+        if (cnt > F_CAND_CAP || fin_used + units > f.fin_units_per_block) {   // (wave-uniform) no room: the general kernel redoes the query
+            if (ln == 0u) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q;
+            continue;
         }
-        if (lane == 0u) p.out_counts[q] = min(cnt, p.how_many) | 0x80000000u;   // (flag: the ids of this row are still id ranks)
+        {
+            char* rec = f.fin + (size_t)off * 16u;
+            unsigned long long* rx = (unsigned long long*)(rec + 16); uint2* rc = (uint2*)(rec + 16 + (size_t)cnt * 8u); uint32_t* rt = (uint32_t*)(rec + 16 + (size_t)cnt * 8u + (size_t)nt * 8u);
+            if (ln == 0u) { *(uint4*)rec = make_uint4(cnt, nt, U, t32m1); f.fin_index[q] = off; p.out_counts[q] = 0x80000000u; }   // (flag: vmis_finish_kernel completes the row)
+            for (uint32_t i = ln; i < cnt; i += 64u) { rx[i] = ckey[i]; rt[i] = cidx[i]; }
+            for (uint32_t i = ln; i < nt; i += 64u) rc[i] = tl[i];
+        }
+        fin_used += units;
+        if (ticking && ln == 0u) { tacc[6] += cnt; tacc[7] += nt; tacc[14] += 1ull; }
         FAST_TICK(13);
     }
     if (ticking) { __syncthreads(); if (tid < 16u && tacc[tid]) atomicAdd(&p.phase_cycles[tid], tacc[tid]); }
 }
 
-// The fast kernel returns id ranks (the final tie-break key it already holds) instead of public ids: looking the id up at the end
-// of every query puts an HBM round trip on each workgroup's serial path; here it is one gather per returned item, all in flight.
-__global__ __launch_bounds__(256) void vmis_translate_kernel(const uint64_t* __restrict__ id_sorted, uint64_t* __restrict__ out_ids, uint32_t* __restrict__ out_counts,
-                                                             uint32_t nq, uint32_t how_many) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+// -------------------------------------------------------------------------------------
+// The tail of predict (mod.rs:156-214) for the queries the fast kernel served, one wave per query: idf of the exact table's
+// contenders, score = idf_eff * acc / (10 U) (one multiply, one divide, in that order), top-n by (score desc, public id asc)
+// -- ranks counted on the scores themselves --, public ids.  Rows of other queries are left alone.
+// -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vmis_finish_kernel(DeviceIndex ix, const char* __restrict__ fin, const uint32_t* __restrict__ fin_index,
+                                                          uint64_t* __restrict__ out_ids, double* __restrict__ out_scores, uint32_t* __restrict__ out_counts,
+                                                          uint32_t nq, uint32_t how_many) {
+    constexpr uint32_t CAP = F_CAND_CAP + F_TABLE_BUCKETS * 4u;   // candidates + every slot of the exact table
+    __shared__ unsigned long long s_key[4][CAP];
+    __shared__ uint32_t s_tie[4][CAP];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t q = blockIdx.x * 4u + wv;
     if (q >= nq) return;
-    const uint32_t c = out_counts[q];
-    if (c == 0xFFFFFFFFu || !(c & 0x80000000u)) return;   // (not served, or served by the general kernel: public ids already)
-    const uint32_t n = c & 0x7FFFFFFFu;
-    uint64_t* row = out_ids + (size_t)q * how_many;
-    for (uint32_t j = 0; j < n; ++j) row[j] = id_sorted[row[j]];
-    out_counts[q] = n;
+    if (out_counts[q] != 0x80000000u) return;   // (wave-uniform: not served by the fast kernel)
+    const char* rec = fin + (size_t)fin_index[q] * 16u;
+    const uint4 hd = *(const uint4*)rec;
+    const uint32_t cnt = hd.x, nt = hd.y, M = cnt + nt;
+    const unsigned long long* rx = (const unsigned long long*)(rec + 16); const uint2* rc = (const uint2*)(rec + 16 + (size_t)cnt * 8u);
+    const uint32_t* rt = (const uint32_t*)(rec + 16 + (size_t)cnt * 8u + (size_t)nt * 8u);
+    const double denom = (double)(10u * hd.z);
+    unsigned long long* key = s_key[wv]; uint32_t* tieb = s_tie[wv];
+    for (uint32_t e = lane; e < M; e += 64u) {
+        double x; uint32_t tie;
+        if (e < cnt) { x = __longlong_as_double((long long)rx[e]); tie = rt[e]; }
+        else { const uint2 c = rc[e - cnt]; const ItemMeta mt = ix.meta[c.x]; x = (mt.idf > 0.0 ? mt.idf : 1.0) * (double)c.y; tie = mt.id_rank; }
+        key[e] = (unsigned long long)__double_as_longlong(x / denom); tieb[e] = tie;   // (positive doubles order like their bit patterns)
+    }
+    // (one wave: its own LDS traffic is ordered)
+    if (M <= 64u) {   // entry j is broadcast by v_readlane: no LDS round trip per comparison
+        unsigned long long mk = 0; uint32_t tie = EMPTY32;
+        if (lane < M) { mk = key[lane]; tie = tieb[lane]; }
+        const unsigned long long pid = lane < M ? ix.id_sorted[tie] : 0ull;   // (arrives while the ranks are counted)
+        const int klo = (int)(uint32_t)mk, khi = (int)(uint32_t)(mk >> 32);
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < M; ++j) {
+            const uint32_t jl = (uint32_t)__builtin_amdgcn_readlane(klo, (int)j), jh = (uint32_t)__builtin_amdgcn_readlane(khi, (int)j), ij = (uint32_t)__builtin_amdgcn_readlane((int)tie, (int)j);
+            const unsigned long long kj = ((unsigned long long)jh << 32) | jl;
+            rank += (uint32_t)(kj > mk) | ((uint32_t)(kj == mk) & (uint32_t)(ij < tie));
+        }
+        if (lane < M && rank < how_many) { out_ids[(size_t)q * how_many + rank] = pid; out_scores[(size_t)q * how_many + rank] = __longlong_as_double((long long)mk); }
+    } else {
+        for (uint32_t i = lane; i < M; i += 64u) {
+            const unsigned long long mk = key[i]; const uint32_t tie = tieb[i];
+            const unsigned long long pid = ix.id_sorted[tie];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < M; j += 4u) {
+                unsigned long long kj[4]; uint32_t ij[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) { const uint32_t jj = min(j + u, M - 1u); kj[u] = key[jj]; ij[u] = tieb[jj]; }
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) rank += (uint32_t)(j + u < M) & ((uint32_t)(kj[u] > mk) | ((uint32_t)(kj[u] == mk) & (uint32_t)(ij[u] < tie)));
+            }
+            if (rank < how_many) { out_ids[(size_t)q * how_many + rank] = pid; out_scores[(size_t)q * how_many + rank] = __longlong_as_double((long long)mk); }
+        }
+    }
+    if (lane == 0u) out_counts[q] = min(M, how_many);
 }
-hipError_t launch_translate(hipStream_t st, const DeviceIndex& di, uint64_t* out_ids, uint32_t* out_counts, uint32_t nq, uint32_t how_many) {
-    hipLaunchKernelGGL(vmis_translate_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, di.id_sorted, out_ids, out_counts, nq, how_many);
+hipError_t launch_finish(hipStream_t st, const DeviceIndex& di, const FastParams& f, uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint32_t nq, uint32_t how_many) {
+    hipLaunchKernelGGL(vmis_finish_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, di, (const char*)f.fin, (const uint32_t*)f.fin_index, out_ids, out_scores, out_counts, nq, how_many);
     return hipGetLastError();
 }
 

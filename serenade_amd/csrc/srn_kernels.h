@@ -61,6 +61,7 @@ struct FastParams {
     double inv_idf_hot[8];      // 1 / max idf_eff over the dense idx [512 c, 512 c + 512): popular items have small idf, so their integer floor is much tighter
     double inv_idf_hi;          // 1 / max idf_eff over all items
     uint32_t* slow_list; uint32_t* slow_cnt;   // queries the fast kernel hands to vmis_predict_kernel
+    char* fin; uint32_t* fin_index; uint32_t fin_units_per_block;   // per-query records for vmis_finish_kernel: arena (16-byte units, one slice per workgroup), record of each query
     uint32_t nb;                // low bits of a session slot that hold the position set
 };
 
@@ -72,7 +73,7 @@ hipError_t launch_predict(bool masks, bool slot64, bool global_tables, int stage
                           uint32_t* retry_cnt, char* gscratch, unsigned long long gscratch_stride, char* nb_spill, const ShardIO& sh, int wg_per_cu = 2);
 hipError_t launch_prep(hipStream_t st, const DeviceIndex& di, const uint64_t* items_flat, const uint32_t* q_off, uint32_t nq, uint32_t m,
                        uint32_t max_len, char* out, uint32_t stride);
-hipError_t launch_translate(hipStream_t st, const DeviceIndex& di, uint64_t* out_ids, uint32_t* out_counts, uint32_t nq, uint32_t how_many);   // id ranks -> public ids for the rows the fast kernel served
+hipError_t launch_finish(hipStream_t st, const DeviceIndex& di, const FastParams& f, uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint32_t nq, uint32_t how_many);   // scores, ranking, public ids of the rows the fast kernel served
 hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f);
 hipError_t launch_rows_to_packed(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base,
                                  uint32_t* packed, uint32_t* ext16);   // grid = ceil((n_rows + 1) / 1024) blocks of 1024; block_base in 16-byte blocks

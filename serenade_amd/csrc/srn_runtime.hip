@@ -55,6 +55,7 @@ struct Workspace {
     char* prep = nullptr; size_t prep_bytes = 0;     // per-query records of the prep kernel
     uint32_t* retry_list2 = nullptr; size_t retry_cap2 = 0; uint32_t* retry_cnt2 = nullptr;   // what the second LDS tier could not hold either
     uint32_t* slow_list = nullptr; size_t slow_cap = 0; uint32_t* slow_cnt = nullptr;          // what the fast kernel hands to the general one
+    char* fin = nullptr; size_t fin_bytes = 0; char* fin_index = nullptr; size_t fin_index_bytes = 0;   // records for vmis_finish_kernel
     // staging for host-pointer calls
     char* stage = nullptr; size_t stage_bytes = 0;
     uint32_t* h_retry = nullptr;   // pinned
@@ -178,6 +179,8 @@ static void ws_free(Workspace* w) {
     if (w->retry_cnt2) hipFree(w->retry_cnt2);
     if (w->slow_list) hipFree(w->slow_list);
     if (w->slow_cnt) hipFree(w->slow_cnt);
+    if (w->fin) hipFree(w->fin);
+    if (w->fin_index) hipFree(w->fin_index);
     if (w->stage) hipFree(w->stage);
     if (w->h_retry) hipHostFree(w->h_retry);
     for (auto& t : w->ev) for (auto& e : t) if (e) hipEventDestroy(e);
@@ -397,11 +400,17 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         if (w->slow_cap < p.nq) { if (w->slow_list) HIP_TRY(hipFree(w->slow_list)); w->slow_list = nullptr; w->slow_cap = 0;
             HIP_TRY(hipMalloc((void**)&w->slow_list, (size_t)p.nq * 4 + 64)); w->slow_cap = p.nq; }
         HIP_TRY(hipMemsetAsync(w->slow_cnt, 0, 4, st));
-        FastParams fp = d->fast; fp.slow_list = w->slow_list; fp.slow_cnt = w->slow_cnt; fp.nb = c.num_bits;
         const uint32_t grid_f = (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * F_WG_PER_CU * grid_mult);
+        // record arena of vmis_finish_kernel: one slice per workgroup, 64 units (1 KB) per query of its share -- ~2.5x what a query writes;
+        // a query that finds its workgroup's slice full goes to the general kernel
+        const uint32_t fin_upb = (uint32_t)(((uint64_t)p.nq + grid_f - 1) / grid_f) * 64u + 448u;
+        { int rc = ensure(&w->fin, &w->fin_bytes, (size_t)fin_upb * grid_f * 16); if (rc) return rc; }
+        { int rc = ensure(&w->fin_index, &w->fin_index_bytes, (size_t)p.nq * 4); if (rc) return rc; }
+        FastParams fp = d->fast; fp.slow_list = w->slow_list; fp.slow_cnt = w->slow_cnt; fp.nb = c.num_bits;
+        fp.fin = w->fin; fp.fin_index = (uint32_t*)w->fin_index; fp.fin_units_per_block = fin_upb;
         HIP_TRY(launch_fast(dim3(grid_f), st, d->di, p, fp));
         HIP_TRY(launch_predict(geo.masks, slot64, false, 0, dim3(grid), lds, st, d->di, p, c, w->slow_list, w->slow_cnt, w->retry_list, w->retry_cnt, nullptr, 0, spill, ShardIO{}));
-        HIP_TRY(launch_translate(st, d->di, p.out_ids, p.out_counts, p.nq, p.how_many));
+        HIP_TRY(launch_finish(st, d->di, fp, p.out_ids, p.out_scores, p.out_counts, p.nq, p.how_many));
     } else
     if (dense) {
         HIP_TRY(launch_predict(geo.masks, false, false, 0, dim3(grid3), g3.lds, st, d->di, p, g3.c, nullptr, nullptr, w->retry_list, w->retry_cnt, nullptr, 0, spill, ShardIO{}, 3));
