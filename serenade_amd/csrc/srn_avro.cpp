@@ -6,8 +6,10 @@
 // -> the flat index.  Self-contained reader: Avro container framing, codecs "null" and "snappy" (what avro-rs writes with the
 // reference's Cargo features), records decoded in the WRITER schema's field order and picked by name.  Unlike the TSV path
 // nothing is computed: posting lists, idf and the product flags are taken from the files (:201-228); the lists are re-ordered
-// by this library's canonical recency (Time, then SessionIndex) and checked to be most-recent prefixes, which is what
-// "time ordered, top m" lists are and what the position-set kernel path relies on.
+// by this library's canonical recency (Time, then SessionIndex).  If every list is a most-recent prefix under that order -- what
+// "time ordered, top m" lists are unless the producer broke timestamp ties differently -- the position-set kernel path applies
+// (FlatIndex::lists_complete); otherwise the lists are used as given, like the reference does, with the first-match position
+// taken from the rows.  Snappy blocks are checked against their CRC-32 trailer.
 // =====================================================================================
 #include <dirent.h>
 
@@ -69,6 +71,15 @@ std::vector<uint8_t> snappy_uncompress(const uint8_t* p, size_t n) {
     }
     if (out.size() != len) bad("snappy: length mismatch");
     return out;
+}
+
+// CRC-32 (ISO 3309 / zlib) of the uncompressed block: the 4-byte big-endian trailer of a snappy-coded Avro block
+uint32_t crc32_of(const uint8_t* p, size_t n) {
+    struct Table { uint32_t t[256]; Table() { for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; t[i] = c; } } };
+    static const Table table;   // (thread-safe initialisation)
+    uint32_t c = 0xFFFFFFFFu;
+    for (size_t i = 0; i < n; ++i) c = table.t[(c ^ p[i]) & 0xFF] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
 }
 
 // ---- the little JSON needed for a schema -----------------------------------------------------
@@ -164,7 +175,12 @@ template <typename F> void read_container(const std::string& path, const std::ve
         const int64_t count = c.zz(), size = c.zz();
         if (count < 0 || size < 0) bad(path + ": bad block header"); c.need((size_t)size);
         std::vector<uint8_t> raw; Cur b{c.p, c.p + size};
-        if (codec == "snappy") { if (size < 4) bad(path + ": short snappy block"); raw = snappy_uncompress(c.p, (size_t)size - 4); b = Cur{raw.data(), raw.data() + raw.size()}; }   // (4-byte CRC32 trailer)
+        if (codec == "snappy") {   // raw snappy + 4-byte big-endian CRC-32 of the uncompressed data
+            if (size < 4) bad(path + ": short snappy block");
+            raw = snappy_uncompress(c.p, (size_t)size - 4); b = Cur{raw.data(), raw.data() + raw.size()};
+            const uint8_t* t = c.p + size - 4; const uint32_t want_crc = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3];
+            if (crc32_of(raw.data(), raw.size()) != want_crc) bad(path + ": CRC mismatch in a snappy block");
+        }
         for (int64_t r = 0; r < count; ++r) {
             for (auto& v : vals) v = Value();
             for (size_t f = 0; f < types.size(); ++f) { Value tmp; read_value(b, types[f], slot[f] >= 0 ? vals[(size_t)slot[f]] : tmp); }
@@ -243,8 +259,9 @@ int build_flat_index_from_avro(const char* base_path, FlatIndex& ix) {
         { std::vector<uint32_t> newer(ix.n_items, 0), total(ix.n_items, 0);
           for (size_t r = 0; r < ns; ++r) for (uint64_t j = ix.row_off[r]; j < ix.row_off[r + 1]; ++j) { const uint32_t it = ix.row_items[j]; ++total[it]; newer[it] += oldest[it] != 0xFFFFFFFFu && r >= oldest[it]; }
           for (uint32_t i = 0; i < ix.n_items; ++i) { const uint64_t len = ix.post_off[i + 1] - ix.post_off[i];
-              if (newer[i] != len || (len < ix.m_index && len != total[i]))
-                  bad("the session list of item " + std::to_string(ix.item_id[i]) + " is not the list of its most recent sessions (unsupported index)"); } }
+              // (an index built elsewhere may break ties between equal timestamps differently, or truncate by another rule: the reference
+              //  uses the lists as given, vmis_index.rs:201-228 -- so do we, without the position-set shortcut that relies on complete lists)
+              if (newer[i] != len || (len < ix.m_index && len != total[i])) ix.lists_complete = false; } }
         size_t tcap = 16; while (tcap < ix.n_items * 2) tcap <<= 1;
         ix.id_table.assign(tcap, IdSlot{0, kNone, 0}); ix.id_mask = (uint32_t)(tcap - 1);
         for (uint32_t i = 0; i < ix.n_items; ++i) { uint32_t h = (uint32_t)mix64(ix.item_id[i]) & ix.id_mask; while (ix.id_table[h].idx != kNone) h = (h + 1) & ix.id_mask; ix.id_table[h] = IdSlot{ix.item_id[i], i, 0}; }

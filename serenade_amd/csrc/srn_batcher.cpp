@@ -63,11 +63,15 @@ struct srn_batcher {
             while (!queue.empty() && batch.size() < max_batch) { batch.push_back(queue.front()); queue.pop_front(); }
             lk.unlock();
             const size_t nq = batch.size();
-            off.assign(nq + 1, 0); items.clear();
-            for (size_t i = 0; i < nq; ++i) { items.insert(items.end(), batch[i]->evolving, batch[i]->evolving + batch[i]->len); off[i + 1] = (uint32_t)items.size(); }
-            ids.assign(nq * how_many, 0); scores.assign(nq * how_many, 0.0); counts.assign(nq, 0);
-            const int rc = srn_predict_batch(idx, items.data(), off.data(), nq, k, m, how_many, flags, ids.data(), scores.data(), counts.data());
-            const std::string err = rc ? srn_last_error() : "";
+            int rc = SRN_OK; std::string err;
+            try {   // an allocation failure here must fail this batch's requests, not terminate the host process
+                off.assign(nq + 1, 0); items.clear();
+                for (size_t i = 0; i < nq; ++i) { items.insert(items.end(), batch[i]->evolving, batch[i]->evolving + batch[i]->len); off[i + 1] = (uint32_t)items.size(); }
+                ids.assign(nq * how_many, 0); scores.assign(nq * how_many, 0.0); counts.assign(nq, 0);
+                rc = srn_predict_batch(idx, items.data(), off.data(), nq, k, m, how_many, flags, ids.data(), scores.data(), counts.data());
+                if (rc) err = srn_last_error();
+            } catch (const std::bad_alloc&) { rc = SRN_ENOMEM; err = "out of host memory in the batch dispatcher"; }
+            catch (const std::exception& e) { rc = SRN_EINVAL; err = std::string("internal error in the batch dispatcher: ") + e.what(); }
             for (size_t i = 0; i < nq; ++i) {
                 Request* r = batch[i];
                 if (rc == SRN_OK) { const size_t n = counts[i]; std::memcpy(r->out_ids, &ids[i * how_many], n * 8); std::memcpy(r->out_scores, &scores[i * how_many], n * 8); *r->out_n = n; }
@@ -92,7 +96,8 @@ int srn_batcher_create(const srn_index_t* idx, size_t max_batch, unsigned max_wa
         if (!idx->dev) return fail(SRN_ENODEV, "index has no device attached; there is no CPU fallback behind this ABI");
         if (k == 0 || m == 0 || how_many == 0) return fail(SRN_EINVAL, "k, m and how_many must be > 0");
         if (how_many > SRN_MAX_HOW_MANY || k > SRN_MAX_K || m > 0x7FFFFFFFull) return fail(SRN_ERANGE, "k, m or how_many above the limits (srn_limits)");
-        if (max_batch == 0 || max_batch > 0x7FFFFFFFull) return fail(SRN_EINVAL, "max_batch must be in [1, 2^31)");
+        // (q_off is 32-bit: max_batch sessions of SRN_MAX_SESSION_LEN items must not wrap it)
+        if (max_batch == 0 || max_batch * (unsigned long long)SRN_MAX_SESSION_LEN >= 0xFFFFFFFFull) return fail(SRN_EINVAL, "max_batch must be in [1, 2^32 / SRN_MAX_SESSION_LEN)");
         srn_batcher* b = new srn_batcher();
         b->idx = idx; b->max_batch = max_batch; b->max_wait_us = max_wait_us; b->k = k; b->m = m; b->how_many = how_many;
         b->flags = enable_business_logic ? SRN_FLAG_BUSINESS_LOGIC : 0;

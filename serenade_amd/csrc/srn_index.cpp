@@ -213,7 +213,7 @@ int build_flat_index(const srn_sessions_view_t& v, size_t m_index, size_t max_se
 }
 
 // ---------------------------------------------------------------------------------------------
-// binary save / load ("SRNFLAT3": header of u64 fields, then raw arrays)
+// binary save / load ("SRNFLAT4": header of u64 fields, then raw arrays; "SRNFLAT3" files -- no flags word -- still load)
 // ---------------------------------------------------------------------------------------------
 namespace {
 template <typename T> bool wr(FILE* f, const std::vector<T>& v) {
@@ -222,39 +222,72 @@ template <typename T> bool wr(FILE* f, const std::vector<T>& v) {
 }
 template <typename T> bool rd(FILE* f, std::vector<T>& v) {
     uint64_t n = 0; if (fread(&n, 8, 1, f) != 1) return false;
+    const long at = ftell(f); if (at < 0 || fseek(f, 0, SEEK_END) != 0) return false;   // (a corrupted length must not turn into a huge allocation)
+    const long end = ftell(f); if (end < at || fseek(f, at, SEEK_SET) != 0 || n > (uint64_t)(end - at) / sizeof(T)) return false;
     v.resize(n); return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
 }
 }  // namespace
 
 int save_flat_index(const FlatIndex& ix, const char* path) {
     FILE* f = fopen(path, "wb"); if (!f) return fail(SRN_EIO, std::string("cannot create ") + path);
-    const char magic[8] = {'S', 'R', 'N', 'F', 'L', 'A', 'T', '3'};
-    uint64_t hdr[12] = {ix.n_items, ix.n_sessions_total, ix.n_kept, ix.nnz_rows, ix.nnz_post, ix.m_index, ix.max_session_len, ix.max_row_len, ix.id_mask,
-                        ix.shard, ix.n_shards, ix.total_pairs};
-    bool ok = fwrite(magic, 8, 1, f) == 1 && fwrite(hdr, 8, 12, f) == 12 && fwrite(&ix.idf_weighting, 8, 1, f) == 1 &&
+    const char magic[8] = {'S', 'R', 'N', 'F', 'L', 'A', 'T', '4'};
+    uint64_t hdr[13] = {ix.n_items, ix.n_sessions_total, ix.n_kept, ix.nnz_rows, ix.nnz_post, ix.m_index, ix.max_session_len, ix.max_row_len, ix.id_mask,
+                        ix.shard, ix.n_shards, ix.total_pairs, ix.lists_complete ? 1ull : 0ull};
+    bool ok = fwrite(magic, 8, 1, f) == 1 && fwrite(hdr, 8, 13, f) == 13 && fwrite(&ix.idf_weighting, 8, 1, f) == 1 &&
               wr(f, ix.item_id) && wr(f, ix.id_rank) && wr(f, ix.idf) && wr(f, ix.attr) && wr(f, ix.post_off) && wr(f, ix.post_rank) &&
               wr(f, ix.row_off) && wr(f, ix.row_items) && wr(f, ix.rank_to_session) && wr(f, ix.id_table);
     ok = (fclose(f) == 0) && ok;
     return ok ? SRN_OK : fail(SRN_EIO, std::string("short write to ") + path);
 }
 
+// One O(nnz) pass over a loaded index: a truncated or corrupted file must come back as SRN_EIO, not as out-of-bounds device reads
+// or a probe loop that never ends.
+static const char* validate_flat_index(const FlatIndex& ix) {
+    if (ix.n_shards == 0 || ix.shard >= ix.n_shards) return "bad shard header";
+    if (ix.id_table.empty() || (ix.id_table.size() & (ix.id_table.size() - 1)) != 0) return "id table size is not a power of two";
+    if (ix.n_items >= 0xFFFFFFF0ull || ix.n_kept >= 0xFFFFFFF0ull) return "too many items or sessions";
+    if (ix.post_off[0] != 0 || ix.post_off[ix.n_items] != ix.nnz_post || ix.row_off[0] != 0 || ix.row_off[ix.n_kept] != ix.nnz_rows) return "offsets do not span the arrays";
+    for (uint64_t i = 0; i < ix.n_items; ++i) {
+        const uint64_t a = ix.post_off[i], b = ix.post_off[i + 1];
+        if (b < a || b > ix.nnz_post || b - a > ix.m_index) return "posting offsets not monotone / list longer than m_index";
+        for (uint64_t j = a; j < b; ++j) { if (ix.post_rank[j] >= ix.n_kept) return "posting entry out of range"; if (j > a && ix.post_rank[j] >= ix.post_rank[j - 1]) return "posting list not strictly descending"; }
+        if (ix.id_rank[i] >= ix.n_items) return "id rank out of range";
+    }
+    uint64_t max_len = 0;
+    for (uint64_t r = 0; r < ix.n_kept; ++r) {
+        const uint64_t a = ix.row_off[r], b = ix.row_off[r + 1];
+        if (b < a || b > ix.nnz_rows) return "row offsets not monotone";
+        max_len = std::max(max_len, b - a);
+        for (uint64_t j = a; j < b; ++j) if (ix.row_items[j] >= ix.n_items) return "row item out of range";
+    }
+    if (max_len > ix.max_row_len) return "row longer than max_row_len";
+    uint64_t used = 0;
+    for (const IdSlot& sl : ix.id_table) { if (sl.idx == kNone) continue; ++used; if (sl.idx >= ix.n_items || ix.item_id[sl.idx] != sl.key) return "id table entry does not match its item"; }
+    if (used != ix.n_items || used >= ix.id_table.size()) return "id table has no empty slot or misses items";
+    return nullptr;
+}
+
 int load_flat_index(const char* path, FlatIndex& ix) {
     FILE* f = fopen(path, "rb"); if (!f) return fail(SRN_EIO, std::string("cannot open ") + path);
-    char magic[8]; uint64_t hdr[12]; ix = FlatIndex();
-    bool ok = fread(magic, 8, 1, f) == 1 && memcmp(magic, "SRNFLAT3", 8) == 0 && fread(hdr, 8, 12, f) == 12 &&
-              fread(&ix.idf_weighting, 8, 1, f) == 1;
+    char magic[8]; uint64_t hdr[13] = {0}; ix = FlatIndex();
+    bool ok = fread(magic, 8, 1, f) == 1 && (memcmp(magic, "SRNFLAT4", 8) == 0 || memcmp(magic, "SRNFLAT3", 8) == 0);
+    const bool v3 = ok && magic[7] == '3';
+    hdr[12] = 1;   // (format 3 had no flags word: every index it could hold has complete lists)
+    ok = ok && fread(hdr, 8, v3 ? 12 : 13, f) == (v3 ? 12u : 13u) && fread(&ix.idf_weighting, 8, 1, f) == 1;
+    const char* why = nullptr;
     if (ok) {
         ix.n_items = hdr[0]; ix.n_sessions_total = hdr[1]; ix.n_kept = hdr[2]; ix.nnz_rows = hdr[3]; ix.nnz_post = hdr[4];
         ix.m_index = hdr[5]; ix.max_session_len = hdr[6]; ix.max_row_len = hdr[7]; ix.id_mask = (uint32_t)hdr[8];
-        ix.shard = (uint32_t)hdr[9]; ix.n_shards = (uint32_t)hdr[10]; ix.total_pairs = hdr[11];
+        ix.shard = (uint32_t)hdr[9]; ix.n_shards = (uint32_t)hdr[10]; ix.total_pairs = hdr[11]; ix.lists_complete = (hdr[12] & 1) != 0;
         ok = rd(f, ix.item_id) && rd(f, ix.id_rank) && rd(f, ix.idf) && rd(f, ix.attr) && rd(f, ix.post_off) && rd(f, ix.post_rank) &&
              rd(f, ix.row_off) && rd(f, ix.row_items) && rd(f, ix.rank_to_session) && rd(f, ix.id_table);
         ok = ok && ix.item_id.size() == ix.n_items && ix.id_rank.size() == ix.n_items && ix.idf.size() == ix.n_items && ix.attr.size() == ix.n_items &&
              ix.post_off.size() == ix.n_items + 1 && ix.post_rank.size() == ix.nnz_post && ix.row_off.size() == ix.n_kept + 1 &&
              ix.row_items.size() == ix.nnz_rows && ix.rank_to_session.size() == ix.n_kept && ix.id_table.size() == (size_t)ix.id_mask + 1;
+        if (ok) { why = validate_flat_index(ix); ok = why == nullptr; }
     }
     fclose(f);
-    return ok ? SRN_OK : fail(SRN_EIO, std::string("not a valid SRNFLAT3 index: ") + path);
+    return ok ? SRN_OK : fail(SRN_EIO, std::string("not a valid SRNFLAT index: ") + path + (why ? std::string(" (") + why + ")" : std::string()));
 }
 
 }  // namespace srn

@@ -41,6 +41,9 @@ struct FlatIndex {
     uint64_t n_items = 0, n_sessions_total = 0, n_kept = 0, nnz_rows = 0, nnz_post = 0;
     uint64_t m_index = 0, max_session_len = 0, max_row_len = 0;
     double idf_weighting = 1.0;
+    bool lists_complete = true;             // every posting list holds ALL sessions of its item that are at least as recent as its last entry (and is complete if
+                                            // shorter than m_index): true for every index built here; a pre-built (Avro) index may not satisfy it -- then the
+                                            // first-match position comes from the rows (the reference's contains() test), not from posting-list membership
     uint32_t shard = 0, n_shards = 1;       // item-sharded index: this shard holds the items with owner(id) == shard
     uint64_t total_pairs = 0;               // (session,item) pairs of ALL kept sessions = idf numerator (== nnz_rows when unsharded)
     std::vector<uint64_t> item_id;          // [n_items]   public id of each dense idx; idx = popularity order (count desc, id asc)

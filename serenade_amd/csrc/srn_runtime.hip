@@ -255,7 +255,7 @@ static int make_geometry(const DeviceState* d, const FlatIndex& ix, const Launch
     const Knobs kn = knobs();
     const uint64_t Lmax = p.max_len;
     // position-set slots (no first-match pass over the rows) need <= 8 evolving items and lists complete above x_lo
-    g.masks = Lmax <= 8 && p.m <= ix.m_index && !kn.no_masks;
+    g.masks = Lmax <= 8 && p.m <= ix.m_index && ix.lists_complete && !kn.no_masks;
     const int num_bits = g.masks ? (int)Lmax : std::max(1, bits_host(Lmax * (Lmax + 1) / 2));
     const int rank_bits = std::max(1, bits_host(ix.n_kept ? ix.n_kept - 1 : 0));
     g.slot64 = rank_bits + num_bits > 32 || ix.n_kept >= 0xFFFFFFF0ull;
@@ -283,7 +283,10 @@ static int make_geometry(const DeviceState* d, const FlatIndex& ix, const Launch
     c.sess_slots = std::max<uint32_t>(c.sess_slots, 256);
     // item side of region A: direct-mapped accumulators for the most popular idx, the rest a hash of 4-slot buckets.
     // A direct-mapped word packs (touch count, signed weight sum); if those do not fit 32 bits the hot part is disabled.
-    const uint64_t w_max = (uint64_t)p.k * 9 * (Lmax * (Lmax + 1) / 2) + 1;
+    // |10 * linear_score| is 9 at the first position but reaches 89 at position 99 (negative weights beyond position 10, Q3): without
+    // position sets a session of >= 20 items can see weights up to min(Lmax, 99) - 10
+    const uint64_t w_abs = g.masks ? 9 : std::max<uint64_t>(9, std::min<uint64_t>(Lmax, 99) > 10 ? std::min<uint64_t>(Lmax, 99) - 10 : 0);
+    const uint64_t w_max = (uint64_t)p.k * w_abs * (Lmax * (Lmax + 1) / 2) + 1;
     const int sbits = std::max(2, bits_host(w_max) + 1), cbits = bits_host(p.k);
     // exact words for the 2048 most popular items, 4096 where a query walks many rows (measured with the end-of-round kernel, 2048 -> 4096:
     // config 3 / 4 (k = 1500) +2.6 % / +2.3 %, config 2 (k = 500) -2.6 %: clearing and harvesting the extra words costs more than they save there)

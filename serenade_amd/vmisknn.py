@@ -126,7 +126,11 @@ class VMISIndex:
 
 
 def _flatten(sessions):
-    if isinstance(sessions, tuple) and len(sessions) == 2:
+    # CSR input is a tuple of two numpy arrays (items_flat, q_off) with q_off a 32-bit offset array starting at 0 and ending at
+    # len(items_flat); a tuple of two evolving sessions (lists, or arrays that are not such a pair) is two queries
+    if isinstance(sessions, tuple) and len(sessions) == 2 and all(isinstance(a, np.ndarray) for a in sessions) \
+            and sessions[1].dtype in (np.uint32, np.int32) and len(sessions[1]) >= 1 and int(sessions[1][0]) == 0 \
+            and int(sessions[1][-1]) == len(sessions[0]):
         return capi.as_u64(sessions[0]), capi.as_u32(sessions[1])
     off = np.zeros(len(sessions) + 1, np.uint32)
     off[1:] = np.cumsum([len(s) for s in sessions])

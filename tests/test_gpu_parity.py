@@ -95,7 +95,8 @@ def test_small_random_vs_oracle(tied, kernel_path):
     import serenade_amd as sa
     O = _oracle()
     off, items, ts, ids = small_dataset(11 + tied, n_sessions=3000, n_items=400, tied_timestamps=tied)
-    for (m_index, max_len, idfw) in [(200, 12, 1.0), (40, 8, 2.0)]:
+    # idf_weighting = 0 switches every item to the un-weighted branch (idf <= 0: score += w * sim, mod.rs:146-152, Q5)
+    for (m_index, max_len, idfw) in [(200, 12, 1.0), (40, 8, 2.0), (200, 12, 0.0)]:
         gix = sa.VMISIndex.from_sessions(off, items, ts, m_index, max_len, idfw)
         oix = O.OracleIndex(off, items, ts, m_index, max_len, idfw)
         qs = random_queries(5, ids, 300, max_len=6)
@@ -135,6 +136,24 @@ def test_long_sessions_negative_weights_and_duplicates(kernel_path):
     deep = [[int(x) for x in ids[rng.choice(len(ids), size=3)]] + [7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17] for _ in range(50)]
     res = _check_batch(gix, oix, deep, 100, 300, 512)
     assert (res["scores"] < 0).any() and (res["scores"] == 0).any(), "expected zero and negative scores (Q3)"
+
+
+def test_very_long_sessions_keep_the_accumulators_exact():
+    """Evolving sessions of 100+ items whose neighbours match only OLD positions: |10 * linear_score| reaches 89 at position 99
+    (the direct-mapped accumulator's sum field must be sized for that, not for 9)."""
+    import serenade_amd as sa
+    O = _oracle()
+    off, items, ts, ids = small_dataset(17, n_sessions=4000, n_items=60, max_len=6)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, 2000, 10, 1.0)
+    oix = O.OracleIndex(off, items, ts, 2000, 10, 1.0)
+    rng = np.random.default_rng(2)
+    qs = []
+    for _ in range(12):
+        old = [int(x) for x in ids[rng.choice(len(ids), size=6)]]                  # known items, far back in the session
+        pad = [int(5 + j) for j in range(int(rng.integers(60, 110)))]              # unknown recent items: first matches at 60..110
+        qs.append(old + pad)
+    res = _check_batch(gix, oix, qs, 1500, 2000, 40, check_neighbours=False)
+    assert (res["scores"] < 0).any(), "expected negative scores (positions beyond 10)"
 
 
 def test_unknown_items_and_single_predict():
@@ -300,7 +319,7 @@ def test_baseline_configs_full_size(config, n_check, monkeypatch):
     O = _oracle()
     inter, n_items, k, m, idfw = synth.CONFIGS[config]
     off, items, ts = synth.training_sessions(inter, n_items)
-    gix = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw, builder="gpu")   # the index bench.py times: built on the GPU
     qi, qo = synth.queries(12000, n_items)
     nq = len(qo) - 1
     oix = O.OracleIndex(off, items, ts, m, 34, idfw, fast=True)
@@ -335,6 +354,46 @@ def test_baseline_configs_full_size(config, n_check, monkeypatch):
         monkeypatch.undo()
         capi.reload_knobs()
     assert nq > 30000
+
+
+def test_config4_full_size(monkeypatch):
+    """BASELINE.json configs[3]: 582 M interactions / 6.5 M items (~10 GB of index in HBM), k=1500 m=2500, index built on the
+    GPU.  A 1 000-query sample against the canonical oracle (ids, order, counters exact; scores 1e-12), and the path-equivalence
+    properties on > 30 000 queries: fast kernel == general kernel (merge tree) == session hash table + selects.
+    SRN_SKIP_CFG4=1 skips it (needs ~60 GB of host memory for the generator's sessions and the oracle's index)."""
+    import os
+    if os.environ.get("SRN_SKIP_CFG4"):
+        pytest.skip("SRN_SKIP_CFG4 set")
+    import serenade_amd as sa
+    from serenade_amd import capi, synth
+    O = _oracle()
+    inter, n_items, k, m, idfw = synth.CONFIGS["cfg4"]
+    off, items, ts = synth.training_sessions(inter, n_items)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw, builder="gpu")
+    qi, qo = synth.queries(12000, n_items)
+    nq = len(qo) - 1
+    assert nq > 30000
+    a = sa.predict_batch(gix, (qi, qo), k, m, synth.HOW_MANY)
+    assert gix.last_path_counts()[1] < nq // 4, "most queries should have been served by the fast kernel"
+    try:
+        monkeypatch.setenv("SRN_NO_FAST", "1"); capi.reload_knobs()
+        b = sa.predict_batch(gix, (qi, qo), k, m, synth.HOW_MANY)
+        monkeypatch.setenv("SRN_NO_MERGE", "1"); capi.reload_knobs()
+        c = sa.predict_batch(gix, (qi, qo), k, m, synth.HOW_MANY)
+    finally:
+        monkeypatch.undo(); capi.reload_knobs()
+    for x, y, z in zip(a, b, c):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
+    n_check = 1000
+    res = sa.predict_batch_debug(gix, (qi[:qo[n_check]], qo[:n_check + 1]), k, m, synth.HOW_MANY, neighbours=False)
+    assert np.array_equal(a[0][:n_check], res["ids"]) and np.array_equal(a[1][:n_check], res["scores"])
+    del gix
+    oix = O.OracleIndex(off, items, ts, m, 34, idfw, fast=True)
+    ref = oix.predict_batch("canonical", qi[:qo[n_check]], qo[:n_check + 1], k, m, synth.HOW_MANY, threads=32, want_stats=True)
+    assert np.array_equal(res["counts"], ref["counts"])
+    assert np.array_equal(res["ids"], ref["ids"])
+    np.testing.assert_allclose(res["scores"], ref["scores"], rtol=SCORE_RTOL, atol=0)
+    assert np.array_equal(res["stats"][:, :7].astype(np.uint64), ref["stats"])
 
 
 def test_concurrent_host_threads_share_one_index():

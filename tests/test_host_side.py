@@ -133,11 +133,39 @@ def test_save_load_roundtrip(tmp_path):
         a, ia = ix.postings(int(it))
         b, ib = ix2.postings(int(it))
         assert (a is None and b is None) or (np.array_equal(a, b) and ia == ib)
-    with open(p, "r+b") as f:
-        f.write(b"garbage!")
-    with pytest.raises(sa.SerenadeError) as e:
-        sa.VMISIndex.load(p, device=-1)
-    assert e.value.code == capi.SRN_EIO
+    good = open(p, "rb").read()
+    # a damaged file must come back as SRN_EIO -- never as out-of-range indices on the device or a probe loop that does not end:
+    # bad magic, truncation, a length field that exceeds the file, and single corrupted words in every array
+    rng = np.random.default_rng(5)
+    damaged = [b"garbage!" + good[8:], good[:len(good) // 2], good[:120] + (2 ** 62).to_bytes(8, "little") + good[128:]]
+    for _ in range(40):
+        at = int(rng.integers(8 + 13 * 8 + 8, len(good) - 4)) & ~3
+        damaged.append(good[:at] + b"\xff\xff\xff\x7f" + good[at + 4:])
+    rejected = 0
+    for blob in damaged:
+        with open(p, "wb") as f:
+            f.write(blob)
+        try:
+            ix3 = sa.VMISIndex.load(p, device=-1)
+        except sa.SerenadeError as e:
+            assert e.code == capi.SRN_EIO
+            rejected += 1
+            continue
+        # what still loads (e.g. a changed idf double or attribute byte) must at least be structurally sound
+        assert ix3.info["n_items"] == ix.info["n_items"]
+    assert rejected >= 20, rejected
+
+
+def test_predict_batch_takes_a_tuple_of_two_sessions_as_two_queries():
+    """(items_flat, q_off) is recognised by its shape -- two numpy arrays, 32-bit offsets from 0 to len(items_flat) -- not by being
+    a 2-tuple: a tuple of two evolving sessions is two queries."""
+    from serenade_amd import vmisknn
+    flat, off = vmisknn._flatten(([11, 12, 13], [14, 15]))
+    assert flat.tolist() == [11, 12, 13, 14, 15] and off.tolist() == [0, 3, 5]
+    flat, off = vmisknn._flatten((np.array([11, 12, 13], np.uint64), np.array([14, 15], np.uint64)))
+    assert flat.tolist() == [11, 12, 13, 14, 15] and off.tolist() == [0, 3, 5]
+    flat, off = vmisknn._flatten((np.array([11, 12, 13, 14, 15], np.uint64), np.array([0, 3, 5], np.uint32)))
+    assert flat.tolist() == [11, 12, 13, 14, 15] and off.tolist() == [0, 3, 5]
 
 
 def test_error_codes_without_a_device():
