@@ -206,6 +206,12 @@ int srn_shard_stage_c(const srn_index_t* idx, const uint64_t* d_items_flat, cons
  * launch.  This is what bench.py reports as the kernel's live-measured launch duration. */
 int srn_kernel_times(const srn_index_t* idx, uint32_t max_n, double* out_ms_main, double* out_ms_retry, uint32_t* out_n);
 
+/* The same with the launches of a call told apart: prep kernel | fast kernel alone (vmis_fast_kernel, the dominant kernel;
+ * 0 when the call was not eligible for it) | all predict launches (fast kernel + general kernel over the handed-over
+ * queries + finish kernel: == out_ms_main of srn_kernel_times) | global-table retry pass.  Any output may be null. */
+int srn_kernel_times_detail(const srn_index_t* idx, uint32_t max_n, double* out_ms_prep, double* out_ms_fast, double* out_ms_predict,
+                            double* out_ms_retry, uint32_t* out_n);
+
 /* Profiling aid: returns (and clears) 16 counters of shader cycles summed over workgroups, one per
  * kernel phase (DESIGN.md "Kernel phases"), accumulated by predict calls made while enabled; then
  * switches the accounting on (enable != 0) or off.  Not for production use. */

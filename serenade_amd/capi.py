@@ -76,6 +76,7 @@ SYMBOLS = {
     "srn_shard_stage_b": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "srn_shard_stage_c": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, C.c_uint, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "srn_kernel_times": (_i, [_vp, C.c_uint32, _vp, _vp, C.POINTER(C.c_uint32)]),
+    "srn_kernel_times_detail": (_i, [_vp, C.c_uint32, _vp, _vp, _vp, _vp, C.POINTER(C.c_uint32)]),
     "srn_debug_phase_cycles": (_i, [_vp, _i, _vp]),
     "srn_debug_reload_knobs": (None, []),
     "srn_last_path_counts": (_i, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),

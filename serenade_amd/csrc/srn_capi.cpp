@@ -296,6 +296,13 @@ int srn_kernel_times(const srn_index_t* idx, uint32_t max_n, double* out_ms_main
     return guarded([&]() -> int { return device_kernel_times(idx->dev, max_n, out_ms_main, out_ms_retry, out_n); });
 }
 
+int srn_kernel_times_detail(const srn_index_t* idx, uint32_t max_n, double* out_ms_prep, double* out_ms_fast, double* out_ms_predict,
+                            double* out_ms_retry, uint32_t* out_n) {
+    if (!idx || !idx->dev) return fail(SRN_ENODEV, "index has no device attached");
+    if (!out_n) return fail(SRN_EINVAL, "null argument");
+    return guarded([&]() -> int { return device_kernel_times(idx->dev, max_n, out_ms_predict, out_ms_retry, out_n, out_ms_prep, out_ms_fast); });
+}
+
 int srn_debug_phase_cycles(const srn_index_t* idx, int enable, uint64_t* out16) {
     if (!idx || !idx->dev) return fail(SRN_ENODEV, "index has no device attached");
     return guarded([&]() -> int { return device_phase_cycles(idx->dev, enable, (unsigned long long*)out16); });

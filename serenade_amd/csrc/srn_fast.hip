@@ -168,7 +168,6 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
     const uint32_t n_kept = ix.n_kept;
     auto qpos = [&](uint32_t pq) -> uint32_t { return ((wave + NW * (pq >> 6)) << 6) + (pq & 63u); };   // the wave's own neighbour-list slots
 
-    uint32_t fin_used = 0;   // (wave 0) units of this workgroup's arena slice in use
     for (uint32_t q = blockIdx.x; q < p.nq; q += gridDim.x) {
         long long t_prev = ticking ? clock64() : 0;
         // ---- phase 0: the query's prep record -> run descriptors in SGPRs ------------------------------
@@ -181,7 +180,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         const uint32_t nr = (uint32_t)__popcll(rm);
         const bool fits = L >= 1u && L <= 8u && L <= p.max_len && hd.sumw <= 15u && nr <= 4u && 2u * n + 8u <= F_MERGE_WORDS;
         if (!fits) {   // block-uniform: the general kernel takes it
-            if (tid == 0) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q;
+            if (tid == 0) { f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q; if (ticking) tacc[3] += 1ull; }
             continue;
         }
         if (n == 0u) { if (tid == 0) p.out_counts[q] = 0u; continue; }   // no known item (vmis_index.rs:350): empty result
@@ -390,8 +389,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         {
             const uint32_t e = lane * NW + wave;
             const uint32_t v = hot[e];
-            hot[e] = 0u;   // (walk B reads the accumulator words of popular items as "cannot reach the floor" ...
-            for (uint32_t i = tid; i < F_DUMP_WORDS; i += BLOCK) ((uint32_t*)(smem + F_DUMP))[i] = 0u;   // ... and the dump words, where the positions past a row's end point)
+            for (uint32_t i = tid; i < F_DUMP_WORDS; i += BLOCK) ((uint32_t*)(smem + F_DUMP))[i] = 0u;   // (walk B reads the dump words, where the positions past a row's end point, as "cannot reach the floor")
             const bool valid = v != 0u && e != cur_idx;
             double x = 0.0; uint32_t tie = 0;
             { const ItemMeta mt = f.meta_sample[tid]; if (valid) { x = (mt.idf > 0.0 ? mt.idf : 1.0) * (double)v; tie = mt.id_rank; } }   // (coalesced, unconditional)
@@ -416,7 +414,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             t32m1 = t32 ? t32 - 1u : 0u;
             const bool take = valid && k32 >= t32m1;
             const uint32_t at = wave_append(take, &misc[FS_CCNT]);
-            if (take) { if (at < F_CAND_CAP) { ckey[at] = (unsigned long long)__double_as_longlong(x); cidx[at] = tie; } else misc[FS_FAIL] = 1;
+            if (take) { if (at < F_CAND_CAP) { ckey[at] = (unsigned long long)__double_as_longlong(x); cidx[at] = tie; } else misc[FS_FAIL] = 1;   // (FS_FAIL: 1 candidates, 2 floor survivors, 4 hit list, 8 exact table)
                         const uint32_t hb = k32 >> 16, tb = t32 >> 16; if (t32) atomicAdd(&thist[hb > tb ? min(hb - tb, 255u) : 0u], 1u); }   // (>= 24 entries, few more: no pile-up)
             // integer floors: an item needs idf * acc >= x_lo, i.e. acc >= x_lo / (largest idf of its chunk); shaved so that rounding
             // can only keep more.  Lane c computes chunk c's floor (lane 8: the sketch words'), broadcast by v_readlane.
@@ -429,10 +427,10 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
                 const uint32_t fl = (uint32_t)__builtin_amdgcn_readlane((int)my_floor, c);
                 const uint32_t e2 = (uint32_t)c * BLOCK + tid;
                 const uint32_t v2 = hot[e2];
-                hot[e2] = 0u;
+                if (e2 == F_HOT_WORDS - 1u) hot[e2] = 0u;   // (the word walk B reads for every popular item)
                 const bool pass = v2 >= fl && e2 != cur_idx;
                 const uint32_t at2 = wave_append(pass, &misc[FS_SURV]);
-                if (pass) { if (at2 < SURV_CAP) surv[at2] = (e2 << 20) | v2; else misc[FS_FAIL] = 1; }
+                if (pass) { if (at2 < SURV_CAP) surv[at2] = (e2 << 20) | v2; else atomicOr(&misc[FS_FAIL], 2u); }
             }
         }
         __syncthreads();
@@ -476,8 +474,10 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         // row position) pairs; the list is resolved afterwards, one element per thread, all item-id fetches in flight together.
         {
             uint32_t dbg_hits = 0;
+            // (offsets below the sketch -- popular items -- are mapped to the last direct-mapped word, which reads 0: one v_max per position
+            //  buys the whole direct-mapped area for the hit list)
             auto chk2 = [&](uint32_t hm, uint32_t wd) -> uint32_t {   // two more positions, most recent in bit 0 ... appended at the top
-                const uint32_t a = *(const uint32_t*)(acc_base + (wd & 0xFFFFu)), b = *(const uint32_t*)(acc_base + (wd >> 16));
+                const uint32_t a = *(const uint32_t*)(acc_base + max(wd & 0xFFFFu, F_ZERO_OFF)), b = *(const uint32_t*)(acc_base + max(wd >> 16, F_ZERO_OFF));
                 return (hm << 2) | (a >= floor_b ? 2u : 0u) | (b >= floor_b ? 1u : 0u); };   // (bit (n - 1 - i) = position i of the n checked)
             auto list_hits = [&](uint32_t hm, uint32_t npos, uint32_t sv, uint32_t j0) {   // hm: bit (npos - 1 - i) = position j0 + i
                 const uint32_t c = (uint32_t)__popc(hm);
@@ -488,14 +488,14 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
                 uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)base, 63) + inc - c;
                 while (hm) {
                     const uint32_t b = 31u - (uint32_t)__clz((int)hm); hm &= ~(1u << b);
-                    if (at < F_HIT_CAP) hits[at] = make_uint2(sv, j0 + (npos - 1u - b)); else misc[FS_FAIL] = 1;
+                    if (at < F_HIT_CAP) hits[at] = make_uint2(sv, j0 + (npos - 1u - b)); else atomicOr(&misc[FS_FAIL], 4u);
                     ++at;
                 }
             };
             // the usual case costs one v_max3 per two positions: the largest word of the lane's row; only a wave that sees a word at the
             // floor looks again, position by position
             auto mx2 = [&](uint32_t mx, uint32_t wd) -> uint32_t {
-                const uint32_t a = *(const uint32_t*)(acc_base + (wd & 0xFFFFu)), b = *(const uint32_t*)(acc_base + (wd >> 16));
+                const uint32_t a = *(const uint32_t*)(acc_base + max(wd & 0xFFFFu, F_ZERO_OFF)), b = *(const uint32_t*)(acc_base + max(wd >> 16, F_ZERO_OFF));
                 return max(max(mx, a), b); };
             uint32_t sv3b = 0, hdr3b = 0; uint4 c43b = make_uint4(0u, 0u, 0u, 0u), d43b = c43b;
 #if SRN_FAST_RELOAD_ROWS
@@ -562,11 +562,14 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
                 if (j < len) it = len <= 15u ? os[1 + j] : (j < 14u ? os[2 + j] : ix.row_ext[os[1] + (j - 14u)]);
                 if (it != EMPTY32 && it >= F_HOT_WORDS && item_insert(ikeys, iacc, F_TABLE_BUCKETS, it, (int)w10t[h.x & NBM]) < 0) ovf = true;
             }
-            if (ovf) misc[FS_FAIL] = 1;
+            if (ovf) atomicOr(&misc[FS_FAIL], 8u);
         }
         __syncthreads();
         FAST_TICK(12);
-        if (misc[FS_FAIL]) { if (tid == 0) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q; continue; }   // block-uniform
+        if (misc[FS_FAIL]) {   // block-uniform
+            if (tid == 0) { f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q; if (ticking) { const uint32_t c = misc[FS_FAIL]; tacc[15] += (c & 1u) + ((unsigned long long)((c >> 1) & 1u) << 16) + ((unsigned long long)((c >> 2) & 1u) << 32) + ((unsigned long long)((c >> 3) & 1u) << 48); } }
+            continue;
+        }
         // ---- hand-off: wave 0 alone (the others go on to the next query's record and wait at its first barrier) ---------------
         // What is left -- the idf of the exact table's contenders, score = x / (10 U), the ranking, the public ids -- is a chain of
         // dependent gathers and a serial loop: on this workgroup's path it would cost 10 K cycles per query with seven waves idle.
@@ -594,23 +597,34 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             }
         }
         const uint32_t cnt = misc[FS_CCNT];   // (this wave's own LDS traffic is ordered; the other waves' appends are behind the barrier above)
-        // record: {cnt, nt, U, 0} | x[cnt] f64 bits | (item, sum)[nt] | id rank[cnt], in 16-byte units from a bump allocator
-        // (no atomic: a returning global atomic would put its round trip right back on this path.  Every workgroup owns a slice of the
-        //  arena, sized for its share of the queries at 1 KB each -- ~2.5x what a query writes --, and fills it front to back.)
-        const uint32_t units = 1u + (cnt * 12u + nt * 8u + 15u) / 16u;
-        const uint32_t off = blockIdx.x * f.fin_units_per_block + fin_used;
-        if (cnt > F_CAND_CAP || fin_used + units > f.fin_units_per_block) {   // (wave-uniform) no room: the general kernel redoes the query
-            if (ln == 0u) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q;
-            continue;
+        // record of query q: 1 KB at a FIXED place (vmis_finish_kernel then needs no index look-up before it can ask for the entries):
+        // {M, U, 0, 0} | M <= 63 entries of 16 bytes: {x (f64 bits), id rank, 0} for a candidate, {sum, item, 1} for a contender of the table
+        // A query with more entries (no threshold: a small query) puts the rest in an overflow arena and itself on the list of
+        // vmis_finish_big_kernel: one 64-bit atomic hands out the list slot (high word) and the arena space (low word, entries).
+        const uint32_t M = cnt + nt;
+        uint32_t ovf_at = 0;
+        if (M > F_FIN_ENTRIES) {   // (wave-uniform, rare: the atomic's round trip is paid by these queries only)
+            unsigned long long tk = 0;
+            if (ln == 0u) tk = atomicAdd(f.big_ticket, (1ull << 32) | (unsigned long long)(M - F_FIN_ENTRIES));
+            const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(tk >> 32), 0);
+            ovf_at = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tk, 0);
+            if (cnt > F_CAND_CAP || (unsigned long long)ovf_at + (M - F_FIN_ENTRIES) > f.big_cap_entries) {   // no room: the general kernel redoes the query
+                if (ln == 0u) { f.big_list[slot] = 0xFFFFFFFFu; f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q; }
+                continue;
+            }
+            if (ln == 0u) f.big_list[slot] = q;
         }
         {
-            char* rec = f.fin + (size_t)off * 16u;
-            unsigned long long* rx = (unsigned long long*)(rec + 16); uint2* rc = (uint2*)(rec + 16 + (size_t)cnt * 8u); uint32_t* rt = (uint32_t*)(rec + 16 + (size_t)cnt * 8u + (size_t)nt * 8u);
-            if (ln == 0u) { *(uint4*)rec = make_uint4(cnt, nt, U, t32m1); f.fin_index[q] = off; p.out_counts[q] = 0x80000000u; }   // (flag: vmis_finish_kernel completes the row)
-            for (uint32_t i = ln; i < cnt; i += 64u) { rx[i] = ckey[i]; rt[i] = cidx[i]; }
-            for (uint32_t i = ln; i < nt; i += 64u) rc[i] = tl[i];
+            uint4* rec = reinterpret_cast<uint4*>(f.fin + (size_t)q * F_FIN_BYTES);
+            uint4* ovf = reinterpret_cast<uint4*>(f.big_arena) + ovf_at;
+            if (ln == 0u) { rec[0] = make_uint4(M, U, ovf_at, 0u); p.out_counts[q] = M > F_FIN_ENTRIES ? 0x80000001u : 0x80000000u; }   // (flags: a finish kernel completes the row)
+            for (uint32_t i = ln; i < M; i += 64u) {
+                uint4 e;
+                if (i < cnt) { const unsigned long long x = ckey[i]; e = make_uint4((uint32_t)x, (uint32_t)(x >> 32), cidx[i], 0u); }
+                else { const uint2 c = tl[i - cnt]; e = make_uint4(c.y, 0u, c.x, 1u); }
+                if (i < F_FIN_ENTRIES) rec[1 + i] = e; else ovf[i - F_FIN_ENTRIES] = e;
+            }
         }
-        fin_used += units;
         if (ticking && ln == 0u) { tacc[6] += cnt; tacc[7] += nt; tacc[14] += 1ull; }
         FAST_TICK(13);
     }
@@ -622,61 +636,118 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
 // contenders, score = idf_eff * acc / (10 U) (one multiply, one divide, in that order), top-n by (score desc, public id asc)
 // -- ranks counted on the scores themselves --, public ids.  Rows of other queries are left alone.
 // -------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void vmis_finish_kernel(DeviceIndex ix, const char* __restrict__ fin, const uint32_t* __restrict__ fin_index,
-                                                          uint64_t* __restrict__ out_ids, double* __restrict__ out_scores, uint32_t* __restrict__ out_counts,
-                                                          uint32_t nq, uint32_t how_many) {
-    constexpr uint32_t CAP = F_CAND_CAP + F_TABLE_BUCKETS * 4u;   // candidates + every slot of the exact table
-    __shared__ unsigned long long s_key[4][CAP];
-    __shared__ uint32_t s_tie[4][CAP];
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t q = blockIdx.x * 4u + wv;
+__global__ __launch_bounds__(256) void vmis_finish_kernel(DeviceIndex ix, const char* __restrict__ fin, uint64_t* __restrict__ out_ids, double* __restrict__ out_scores,
+                                                          uint32_t* __restrict__ out_counts, uint32_t nq, uint32_t how_many) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t q = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (q >= nq) return;
-    if (out_counts[q] != 0x80000000u) return;   // (wave-uniform: not served by the fast kernel)
-    const char* rec = fin + (size_t)fin_index[q] * 16u;
-    const uint4 hd = *(const uint4*)rec;
-    const uint32_t cnt = hd.x, nt = hd.y, M = cnt + nt;
-    const unsigned long long* rx = (const unsigned long long*)(rec + 16); const uint2* rc = (const uint2*)(rec + 16 + (size_t)cnt * 8u);
-    const uint32_t* rt = (const uint32_t*)(rec + 16 + (size_t)cnt * 8u + (size_t)nt * 8u);
-    const double denom = (double)(10u * hd.z);
-    unsigned long long* key = s_key[wv]; uint32_t* tieb = s_tie[wv];
-    for (uint32_t e = lane; e < M; e += 64u) {
-        double x; uint32_t tie;
-        if (e < cnt) { x = __longlong_as_double((long long)rx[e]); tie = rt[e]; }
-        else { const uint2 c = rc[e - cnt]; const ItemMeta mt = ix.meta[c.x]; x = (mt.idf > 0.0 ? mt.idf : 1.0) * (double)c.y; tie = mt.id_rank; }
-        key[e] = (unsigned long long)__double_as_longlong(x / denom); tieb[e] = tie;   // (positive doubles order like their bit patterns)
+    // the record sits at a fixed place: flag, header and this lane's entry are requested together (three dependent round trips in
+    // all: these, the contenders' idf, the public ids)
+    const uint4* rec = reinterpret_cast<const uint4*>(fin + (size_t)q * F_FIN_BYTES);
+    const uint32_t flag = out_counts[q];
+    const uint4 hd = rec[0];
+    const uint4 e = rec[1 + min(lane, F_FIN_ENTRIES - 1u)];
+    if (flag != 0x80000000u) return;   // (wave-uniform: not served by the fast kernel -- what was read is stale, and unused)
+    const uint32_t M = hd.x;
+    const bool valid = lane < M;
+    double x = 0.0; uint32_t tie = EMPTY32;
+    if (valid) {
+        if (e.w == 0u) { x = __longlong_as_double((long long)(((unsigned long long)e.y << 32) | e.x)); tie = e.z; }
+        else { const ItemMeta mt = ix.meta[e.z]; x = (mt.idf > 0.0 ? mt.idf : 1.0) * (double)e.x; tie = mt.id_rank; }
     }
-    // (one wave: its own LDS traffic is ordered)
-    if (M <= 64u) {   // entry j is broadcast by v_readlane: no LDS round trip per comparison
-        unsigned long long mk = 0; uint32_t tie = EMPTY32;
-        if (lane < M) { mk = key[lane]; tie = tieb[lane]; }
-        const unsigned long long pid = lane < M ? ix.id_sorted[tie] : 0ull;   // (arrives while the ranks are counted)
-        const int klo = (int)(uint32_t)mk, khi = (int)(uint32_t)(mk >> 32);
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < M; ++j) {
-            const uint32_t jl = (uint32_t)__builtin_amdgcn_readlane(klo, (int)j), jh = (uint32_t)__builtin_amdgcn_readlane(khi, (int)j), ij = (uint32_t)__builtin_amdgcn_readlane((int)tie, (int)j);
-            const unsigned long long kj = ((unsigned long long)jh << 32) | jl;
-            rank += (uint32_t)(kj > mk) | ((uint32_t)(kj == mk) & (uint32_t)(ij < tie));
-        }
-        if (lane < M && rank < how_many) { out_ids[(size_t)q * how_many + rank] = pid; out_scores[(size_t)q * how_many + rank] = __longlong_as_double((long long)mk); }
-    } else {
+    const unsigned long long pid = valid ? ix.id_sorted[tie] : 0ull;   // (arrives while the ranks are counted)
+    const double sc = valid ? x / (double)(10u * hd.y) : 0.0;
+    const unsigned long long mk = (unsigned long long)__double_as_longlong(sc);   // (positive doubles order like their bit patterns)
+    const int klo = (int)(uint32_t)mk, khi = (int)(uint32_t)(mk >> 32);
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < M; ++j) {   // entry j is broadcast by v_readlane: no LDS, no memory
+        const uint32_t jl = (uint32_t)__builtin_amdgcn_readlane(klo, (int)j), jh = (uint32_t)__builtin_amdgcn_readlane(khi, (int)j), ij = (uint32_t)__builtin_amdgcn_readlane((int)tie, (int)j);
+        const unsigned long long kj = ((unsigned long long)jh << 32) | jl;
+        rank += (uint32_t)(kj > mk) | ((uint32_t)(kj == mk) & (uint32_t)(ij < tie));
+    }
+    if (valid && rank < how_many) { out_ids[(size_t)q * how_many + rank] = pid; out_scores[(size_t)q * how_many + rank] = sc; }
+    if (lane == 0u) out_counts[q] = min(M, how_many);
+}
+// The same for the few queries with more than 63 entries (no threshold from the sample: small queries whose every scored item is a
+// candidate): one wave per listed query, entries staged in LDS; a threshold first -- 256-bin histogram of the scores' top 16 bits
+// relative to the maximum, the bin of the n-th best -- then the ranks of what is at or above it.
+__global__ __launch_bounds__(64) void vmis_finish_big_kernel(DeviceIndex ix, const char* __restrict__ fin, const uint4* __restrict__ arena, const uint32_t* __restrict__ big_list,
+                                                             const unsigned long long* __restrict__ big_ticket, uint64_t* __restrict__ out_ids, double* __restrict__ out_scores,
+                                                             uint32_t* __restrict__ out_counts, uint32_t how_many) {
+    constexpr uint32_t CAP = F_CAND_CAP + F_TABLE_BUCKETS * 4u;
+    __shared__ unsigned long long key[CAP];
+    __shared__ uint32_t tieb[CAP];
+    __shared__ uint32_t hist[256];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t nbig = (uint32_t)(*big_ticket >> 32);
+    for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x) {
+        const uint32_t q = big_list[b];
+        if (q == 0xFFFFFFFFu) continue;   // (handed to the general kernel)
+        const uint4* rec = reinterpret_cast<const uint4*>(fin + (size_t)q * F_FIN_BYTES);
+        const uint4 hd = rec[0];
+        const uint32_t M = min(hd.x, CAP);
+        const double denom = (double)(10u * hd.y);
+        for (uint32_t i = lane; i < 256u; i += 64u) hist[i] = 0;
+        uint32_t kmax = 0;
         for (uint32_t i = lane; i < M; i += 64u) {
+            const uint4 e = i < F_FIN_ENTRIES ? rec[1 + i] : arena[hd.z + (i - F_FIN_ENTRIES)];
+            double x; uint32_t tie;
+            if (e.w == 0u) { x = __longlong_as_double((long long)(((unsigned long long)e.y << 32) | e.x)); tie = e.z; }
+            else { const ItemMeta mt = ix.meta[e.z]; x = (mt.idf > 0.0 ? mt.idf : 1.0) * (double)e.x; tie = mt.id_rank; }
+            const unsigned long long kb = (unsigned long long)__double_as_longlong(x / denom);
+            key[i] = kb; tieb[i] = tie; kmax = max(kmax, (uint32_t)(kb >> 48));
+        }
+        kmax = wave_max(kmax);
+        __syncthreads();   // (one wave; orders the LDS traffic)
+        for (uint32_t i = lane; i < M; i += 64u) { const uint32_t hb = (uint32_t)(key[i] >> 48); atomicAdd(&hist[kmax - hb < 255u ? kmax - hb : 255u], 1u); }   // bin 0 = the best 1/16 octave
+        __syncthreads();
+        uint32_t cut = 255;   // first bin (from the best) at which the running count reaches n: everything in bins <= cut stays
+        {
+            const uint4 h4 = reinterpret_cast<const uint4*>(hist)[lane];
+            const uint32_t s4 = h4.x + h4.y + h4.z + h4.w, inc = wave_incl_scan(s4);
+            const uint32_t before = inc - s4;
+            uint32_t mybin = 0xFFFFFFFFu;
+            if (before < how_many && how_many <= inc) { mybin = 4u * lane; uint32_t c = before + h4.x; if (c < how_many) { ++mybin; c += h4.y; if (c < how_many) { ++mybin; c += h4.z; if (c < how_many) ++mybin; } } }
+            const unsigned long long mb = __ballot(mybin != 0xFFFFFFFFu);
+            if (mb) cut = (uint32_t)__builtin_amdgcn_readlane((int)mybin, __ffsll((long long)mb) - 1);
+        }
+        const uint32_t kcut = kmax >= cut && cut < 255u ? kmax - cut : 0u;   // keep entries whose top 16 bits are >= kcut (bin 255 collects everything below: keep all)
+        uint32_t nk = 0;
+        for (uint32_t i0 = 0; i0 < M; i0 += 64u) {   // compact the kept entries to the front (in place: the write index never passes the read index)
+            const uint32_t i = i0 + lane;
+            unsigned long long kb = 0; uint32_t tie = 0; bool keep = false;
+            if (i < M) { kb = key[i]; tie = tieb[i]; keep = (uint32_t)(kb >> 48) >= kcut; }
+            const unsigned long long bm = __ballot(keep);
+            __syncthreads();
+            if (keep) { const uint32_t at = nk + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull)); key[at] = kb; tieb[at] = tie; }
+            nk += (uint32_t)__popcll(bm);
+            __syncthreads();
+        }
+        for (uint32_t i = lane; i < nk; i += 64u) {
             const unsigned long long mk = key[i]; const uint32_t tie = tieb[i];
             const unsigned long long pid = ix.id_sorted[tie];
             uint32_t rank = 0;
-            for (uint32_t j = 0; j < M; j += 4u) {
+            for (uint32_t j = 0; j < nk; j += 4u) {
                 unsigned long long kj[4]; uint32_t ij[4];
 #pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) { const uint32_t jj = min(j + u, M - 1u); kj[u] = key[jj]; ij[u] = tieb[jj]; }
+                for (uint32_t u = 0; u < 4u; ++u) { const uint32_t jj = min(j + u, nk - 1u); kj[u] = key[jj]; ij[u] = tieb[jj]; }
 #pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) rank += (uint32_t)(j + u < M) & ((uint32_t)(kj[u] > mk) | ((uint32_t)(kj[u] == mk) & (uint32_t)(ij[u] < tie)));
+                for (uint32_t u = 0; u < 4u; ++u) rank += (uint32_t)(j + u < nk) & ((uint32_t)(kj[u] > mk) | ((uint32_t)(kj[u] == mk) & (uint32_t)(ij[u] < tie)));
             }
             if (rank < how_many) { out_ids[(size_t)q * how_many + rank] = pid; out_scores[(size_t)q * how_many + rank] = __longlong_as_double((long long)mk); }
         }
+        if (lane == 0u) out_counts[q] = min(nk, how_many);
+        __syncthreads();
     }
-    if (lane == 0u) out_counts[q] = min(M, how_many);
 }
+hipError_t launch_finish_big(hipStream_t st, const DeviceIndex& di, const FastParams& f, uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint32_t how_many, uint32_t grid) {
+    hipLaunchKernelGGL(vmis_finish_big_kernel, dim3(grid), dim3(64), 0, st, di, (const char*)f.fin, (const uint4*)f.big_arena, (const uint32_t*)f.big_list, (const unsigned long long*)f.big_ticket,
+                       out_ids, out_scores, out_counts, how_many);
+    return hipGetLastError();
+}
+
 hipError_t launch_finish(hipStream_t st, const DeviceIndex& di, const FastParams& f, uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint32_t nq, uint32_t how_many) {
-    hipLaunchKernelGGL(vmis_finish_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, di, (const char*)f.fin, (const uint32_t*)f.fin_index, out_ids, out_scores, out_counts, nq, how_many);
+    hipLaunchKernelGGL(vmis_finish_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, di, (const char*)f.fin, out_ids, out_scores, out_counts, nq, how_many);
     return hipGetLastError();
 }
 

@@ -40,18 +40,21 @@ struct PrepItem { uint32_t idx, len, pre, kept; unsigned long long base; };   //
 #ifndef SRN_FAST_SMALL
 #define SRN_FAST_SMALL 1
 #endif
-#if SRN_FAST_SMALL   // 52 KB: three workgroups per CU
-static constexpr uint32_t F_HOT_WORDS = 4096, F_SK_WORDS = 4096, F_DUMP_WORDS = 256, F_TABLE_BUCKETS = 127, F_TABLE_WORDS = 512, F_HIT_CAP = 512, F_SURV_WORDS = 512, F_WG_PER_CU = 3;
+#if SRN_FAST_SMALL   // 48 KB: three workgroups per CU
+static constexpr uint32_t F_HOT_WORDS = 4096, F_SK_WORDS = 4096, F_DUMP_WORDS = 256, F_TABLE_BUCKETS = 127, F_TABLE_WORDS = 512, F_SURV_WORDS = 512, F_WG_PER_CU = 3;
 #else                // 80 KB: two workgroups per CU
-static constexpr uint32_t F_HOT_WORDS = 4096, F_SK_WORDS = 8192, F_DUMP_WORDS = 1024, F_TABLE_BUCKETS = 127, F_TABLE_WORDS = 512, F_HIT_CAP = 1536, F_SURV_WORDS = 768, F_WG_PER_CU = 2;
+static constexpr uint32_t F_HOT_WORDS = 4096, F_SK_WORDS = 8192, F_DUMP_WORDS = 1024, F_TABLE_BUCKETS = 127, F_TABLE_WORDS = 512, F_SURV_WORDS = 768, F_WG_PER_CU = 2;
 #endif
 static constexpr uint32_t F_MISC = 0, F_WLUT = 256, F_W10 = 512, F_NBL = 1024, F_K_MAX = 1536, F_CAND = F_NBL + F_K_MAX * 4, F_CAND_CAP = 160;
 static constexpr uint32_t F_HOT = 9216, F_SKETCH = F_HOT + F_HOT_WORDS * 4, F_DUMP = F_SKETCH + F_SK_WORDS * 4, F_TABLE = F_DUMP + F_DUMP_WORDS * 4;
-static constexpr uint32_t F_HITS = F_TABLE + F_TABLE_WORDS * 8;          // walk B's hit list: (session slot, row position) pairs; exact table: prime number of 4-slot buckets, keys then sums
-static constexpr uint32_t F_SURV = F_HITS + F_HIT_CAP * 8;               // survivors of the integer floors, packed (idx << 20 | acc)
+// walk B's hit list -- (session slot, row position) pairs -- lives in the direct-mapped words, which are dead by then (walk B maps every
+// offset below the sketch to the LAST direct-mapped word, kept 0); exact table: prime number of 4-slot buckets, keys then sums
+static constexpr uint32_t F_HITS = F_HOT, F_HIT_CAP = F_HOT_WORDS / 2 - 1, F_ZERO_OFF = (F_HOT_WORDS - 1) * 4;
+static constexpr uint32_t F_SURV = F_TABLE + F_TABLE_WORDS * 8;          // survivors of the integer floors, packed (idx << 20 | acc), then the threshold histogram
 static constexpr uint32_t F_LDS_BYTES = F_SURV + F_SURV_WORDS * 4;
 static constexpr uint32_t F_WORK = F_NBL, F_WORK_WORDS = (F_LDS_BYTES - F_WORK) / 4;   // merge buffers: 2 * n_staged words
 static constexpr uint32_t F_M_MAX = 2560;
+static constexpr uint32_t F_FIN_BYTES = 1024, F_FIN_ENTRIES = F_FIN_BYTES / 16 - 1;   // a query's record: header + 63 entries
 static_assert(F_CAND + F_CAND_CAP * 12 <= F_HOT, "candidate buffer overlaps the accumulators");
 static_assert(F_LDS_BYTES * F_WG_PER_CU <= 160 * 1024, "LDS budget");
 static_assert(F_DUMP + F_DUMP_WORDS * 4 - F_HOT <= 65536, "16-bit row offsets");
@@ -61,7 +64,9 @@ struct FastParams {
     double inv_idf_hot[8];      // 1 / max idf_eff over the dense idx [512 c, 512 c + 512): popular items have small idf, so their integer floor is much tighter
     double inv_idf_hi;          // 1 / max idf_eff over all items
     uint32_t* slow_list; uint32_t* slow_cnt;   // queries the fast kernel hands to vmis_predict_kernel
-    char* fin; uint32_t* fin_index; uint32_t fin_units_per_block;   // per-query records for vmis_finish_kernel: arena (16-byte units, one slice per workgroup), record of each query
+    char* fin;                  // per-query records for vmis_finish_kernel: F_FIN_BYTES each, at q * F_FIN_BYTES
+    char* big_arena; uint32_t* big_list; unsigned long long* big_ticket; uint32_t big_cap_entries;   // queries with > 63 entries: overflow entries, list for vmis_finish_big_kernel,
+                                                                                                      // ticket = (list length << 32 | arena entries in use)
     uint32_t nb;                // low bits of a session slot that hold the position set
 };
 
@@ -73,6 +78,7 @@ hipError_t launch_predict(bool masks, bool slot64, bool global_tables, int stage
                           uint32_t* retry_cnt, char* gscratch, unsigned long long gscratch_stride, char* nb_spill, const ShardIO& sh, int wg_per_cu = 2);
 hipError_t launch_prep(hipStream_t st, const DeviceIndex& di, const uint64_t* items_flat, const uint32_t* q_off, uint32_t nq, uint32_t m,
                        uint32_t max_len, char* out, uint32_t stride);
+hipError_t launch_finish_big(hipStream_t st, const DeviceIndex& di, const FastParams& f, uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint32_t how_many, uint32_t grid);
 hipError_t launch_finish(hipStream_t st, const DeviceIndex& di, const FastParams& f, uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint32_t nq, uint32_t how_many);   // scores, ranking, public ids of the rows the fast kernel served
 hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f);
 hipError_t launch_rows_to_packed(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base,

@@ -46,7 +46,7 @@ void reload_knobs() { std::call_once(g_knobs_once, knobs_read); knobs_read(); }
 struct Workspace {
     hipStream_t stream = nullptr;   // own stream for host-pointer calls
     static constexpr int RING = 64;               // per-call events: start, after main kernel, after retry pass, after prep kernel
-    hipEvent_t ev[RING][4] = {};
+    hipEvent_t ev[RING][5] = {};                  // ... [4] = after the fast kernel (== [3] when the launch did not use it)
     uint64_t calls = 0; uint32_t last_retry = 0, last_nq = 0;
     // device scratch
     uint32_t* retry_list = nullptr; size_t retry_cap = 0; uint32_t* retry_cnt = nullptr;
@@ -55,7 +55,8 @@ struct Workspace {
     char* prep = nullptr; size_t prep_bytes = 0;     // per-query records of the prep kernel
     uint32_t* retry_list2 = nullptr; size_t retry_cap2 = 0; uint32_t* retry_cnt2 = nullptr;   // what the second LDS tier could not hold either
     uint32_t* slow_list = nullptr; size_t slow_cap = 0; uint32_t* slow_cnt = nullptr;          // what the fast kernel hands to the general one
-    char* fin = nullptr; size_t fin_bytes = 0; char* fin_index = nullptr; size_t fin_index_bytes = 0;   // records for vmis_finish_kernel
+    char* fin = nullptr; size_t fin_bytes = 0;   // records for vmis_finish_kernel
+    char* big = nullptr; size_t big_bytes = 0;   // overflow entries + list for vmis_finish_big_kernel
     // staging for host-pointer calls
     char* stage = nullptr; size_t stage_bytes = 0;
     uint32_t* h_retry = nullptr;   // pinned
@@ -180,7 +181,7 @@ static void ws_free(Workspace* w) {
     if (w->slow_list) hipFree(w->slow_list);
     if (w->slow_cnt) hipFree(w->slow_cnt);
     if (w->fin) hipFree(w->fin);
-    if (w->fin_index) hipFree(w->fin_index);
+    if (w->big) hipFree(w->big);
     if (w->stage) hipFree(w->stage);
     if (w->h_retry) hipHostFree(w->h_retry);
     for (auto& t : w->ev) for (auto& e : t) if (e) hipEventDestroy(e);
@@ -404,16 +405,18 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
             HIP_TRY(hipMalloc((void**)&w->slow_list, (size_t)p.nq * 4 + 64)); w->slow_cap = p.nq; }
         HIP_TRY(hipMemsetAsync(w->slow_cnt, 0, 4, st));
         const uint32_t grid_f = (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * F_WG_PER_CU * grid_mult);
-        // record arena of vmis_finish_kernel: one slice per workgroup, 64 units (1 KB) per query of its share -- ~2.5x what a query writes;
-        // a query that finds its workgroup's slice full goes to the general kernel
-        const uint32_t fin_upb = (uint32_t)(((uint64_t)p.nq + grid_f - 1) / grid_f) * 64u + 448u;
-        { int rc = ensure(&w->fin, &w->fin_bytes, (size_t)fin_upb * grid_f * 16); if (rc) return rc; }
-        { int rc = ensure(&w->fin_index, &w->fin_index_bytes, (size_t)p.nq * 4); if (rc) return rc; }
-        FastParams fp = d->fast; fp.slow_list = w->slow_list; fp.slow_cnt = w->slow_cnt; fp.nb = c.num_bits;
-        fp.fin = w->fin; fp.fin_index = (uint32_t*)w->fin_index; fp.fin_units_per_block = fin_upb;
+        { int rc = ensure(&w->fin, &w->fin_bytes, (size_t)p.nq * F_FIN_BYTES + 1024); if (rc) return rc; }   // one record per query for vmis_finish_kernel
+        // queries with more than 63 entries: a list + an overflow arena (room for 1/8 of the queries at 128 entries each; what finds no room goes to the general kernel)
+        const uint64_t big_entries = std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)p.nq * 16 + 4096);
+        { int rc = ensure(&w->big, &w->big_bytes, big_entries * 16 + (size_t)p.nq * 4 + 64); if (rc) return rc; }
+        HIP_TRY(hipMemsetAsync(w->slow_cnt + 2, 0, 8, st));   // (slow_cnt[2..3] = the 64-bit ticket)
+        FastParams fp = d->fast; fp.slow_list = w->slow_list; fp.slow_cnt = w->slow_cnt; fp.nb = c.num_bits; fp.fin = w->fin;
+        fp.big_arena = w->big; fp.big_list = (uint32_t*)(w->big + big_entries * 16); fp.big_ticket = (unsigned long long*)(w->slow_cnt + 2); fp.big_cap_entries = (uint32_t)big_entries;
         HIP_TRY(launch_fast(dim3(grid_f), st, d->di, p, fp));
+        HIP_TRY(hipEventRecord(ev[4], st));
         HIP_TRY(launch_predict(geo.masks, slot64, false, 0, dim3(grid), lds, st, d->di, p, c, w->slow_list, w->slow_cnt, w->retry_list, w->retry_cnt, nullptr, 0, spill, ShardIO{}));
         HIP_TRY(launch_finish(st, d->di, fp, p.out_ids, p.out_scores, p.out_counts, p.nq, p.how_many));
+        HIP_TRY(launch_finish_big(st, d->di, fp, p.out_ids, p.out_scores, p.out_counts, p.how_many, (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * 16)));
     } else
     if (dense) {
         HIP_TRY(launch_predict(geo.masks, false, false, 0, dim3(grid3), g3.lds, st, d->di, p, g3.c, nullptr, nullptr, w->retry_list, w->retry_cnt, nullptr, 0, spill, ShardIO{}, 3));
@@ -421,6 +424,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         final_list = w->retry_list2; final_cnt = w->retry_cnt2;
     } else
         HIP_TRY(launch_predict(geo.masks, slot64, false, 0, dim3(grid), lds, st, d->di, p, c, nullptr, nullptr, w->retry_list, w->retry_cnt, nullptr, 0, spill, ShardIO{}));
+    if (!fast) HIP_TRY(hipEventRecord(ev[4], st));
     HIP_TRY(hipEventRecord(ev[1], st));
     if (may_overflow || dense) {
         const size_t lds_g = c.off_a;
@@ -511,7 +515,7 @@ int device_phase_cycles(DeviceState* d, int enable, unsigned long long* out16) {
 }
 
 // durations of the most recent min(max_n, calls, RING) predict launches of the last-used workspace, oldest first
-int device_kernel_times(DeviceState* d, uint32_t max_n, double* ms_main, double* ms_retry, uint32_t* out_n) {
+int device_kernel_times(DeviceState* d, uint32_t max_n, double* ms_main, double* ms_retry, uint32_t* out_n, double* ms_prep, double* ms_fast) {
     HIP_TRY(hipSetDevice(d->device));
     Workspace* w;
     { std::lock_guard<std::mutex> lk(d->mu); w = d->last_ws; }
@@ -526,6 +530,8 @@ int device_kernel_times(DeviceState* d, uint32_t max_n, double* ms_main, double*
         HIP_TRY(hipEventElapsedTime(&b, ev[1], ev[2]));
         if (ms_main) ms_main[i] = a;
         if (ms_retry) ms_retry[i] = b;
+        if (ms_prep) { float c2 = 0; HIP_TRY(hipEventElapsedTime(&c2, ev[0], ev[3])); ms_prep[i] = c2; }
+        if (ms_fast) { float c2 = 0; HIP_TRY(hipEventElapsedTime(&c2, ev[3], ev[4])); ms_fast[i] = c2; }
     }
     *out_n = (uint32_t)n;
     return SRN_OK;

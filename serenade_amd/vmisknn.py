@@ -118,6 +118,12 @@ class VMISIndex:
         return a[:n.value].copy(), b[:n.value].copy()
 
 
+    def kernel_times_detail(self, max_n=64):
+        """Per-call ms of (prep kernel, fast kernel alone, all predict launches, global-table retry pass), oldest first."""
+        a, b, c, d, n = np.zeros(max_n), np.zeros(max_n), np.zeros(max_n), np.zeros(max_n), C.c_uint32()
+        capi.check(capi.lib().srn_kernel_times_detail(self._h, max_n, capi.ptr(a), capi.ptr(b), capi.ptr(c), capi.ptr(d), C.byref(n)))
+        return tuple(x[:n.value].copy() for x in (a, b, c, d))
+
     def debug_phase_cycles(self, enable):
         """Profiling aid: fetch-and-clear the per-phase shader-cycle counters, then switch accounting on/off."""
         out = np.zeros(16, np.uint64)
