@@ -134,7 +134,13 @@ template <int WG_PER_CU>
 #define SRN_FAST_WAVES (WG_PER_CU * 2)
 #endif
 __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIndex ix_arg, LaunchParams p_arg, FastParams f_arg) {
+#if SRN_FAST_SMALL
+    // static allocation: the compiler then knows every LDS address and folds the region offsets into the instructions' offset fields
+    // (with a dynamic allocation each computed address pays a v_add of the -- zero -- base: two per row item in the walks)
+    __shared__ __attribute__((aligned(16))) char smem[F_TOTAL];
+#else
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#endif
     typedef const __attribute__((address_space(4))) char* KArg;
     const KArg ka = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr size_t OFF_P = (sizeof(DeviceIndex) + alignof(LaunchParams) - 1) / alignof(LaunchParams) * alignof(LaunchParams);
@@ -753,12 +759,12 @@ hipError_t launch_finish(hipStream_t st, const DeviceIndex& di, const FastParams
 
 hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f) {
     auto kern = vmis_fast_kernel<(int)F_WG_PER_CU>;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_TOTAL);
-    if (e != hipSuccess) return e;
+    constexpr size_t dyn = SRN_FAST_SMALL ? 0 : F_TOTAL;
+    if (dyn) { hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); if (e != hipSuccess) return e; }
     static bool told = false;
-    if (!told && getenv("SRN_DEBUG")) { told = true; int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 512, F_TOTAL);
+    if (!told && getenv("SRN_DEBUG")) { told = true; int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 512, dyn);
         fprintf(stderr, "[srn] vmis_fast_kernel: %u bytes of LDS, %d workgroups per CU (occupancy API)\n", F_TOTAL, nb); }
-    hipLaunchKernelGGL(kern, grid, dim3(512), F_TOTAL, st, di, p, f);
+    hipLaunchKernelGGL(kern, grid, dim3(512), dyn, st, di, p, f);
     return hipGetLastError();
 }
 
