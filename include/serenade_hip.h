@@ -186,6 +186,17 @@ int srn_last_kernel_ms(const srn_index_t* idx, double* out_ms_main, double* out_
 int srn_index_build_shard(const srn_sessions_view_t* sessions, size_t m_index, size_t max_session_len,
                           double idf_weighting, uint32_t shard, uint32_t n_shards, int device, srn_index_t** out);
 int srn_shard_slot_bytes(const srn_index_t* idx, size_t max_len_hint, uint32_t* out);
+/* width of a packed entry and of its low payload field: rank = entry >> *out_num_bits (the host compacts the candidate lists by rank) */
+int srn_shard_slot_info(const srn_index_t* idx, size_t max_len_hint, uint32_t* out_bytes, uint32_t* out_num_bits);
+/* Shard `shard` of n_shards cut out of an UNSHARDED index -- built by srn_index_build_gpu or read by srn_index_load; the same bytes
+ * srn_index_build_shard builds from the sessions, in one O(nnz) pass (an item-sharded deployment builds or loads ONE index and
+ * every rank cuts its own shard out of it; the reference loads its production index: src/vmisknn/vmis_index.rs:85-314).
+ * srn_index_build_shard_gpu = srn_index_build_gpu + srn_index_shard without ever attaching the full index to the device;
+ * srn_index_load_shard reads a saved index (unsharded: cut; already that shard: as is). */
+int srn_index_shard(const srn_index_t* full, uint32_t shard, uint32_t n_shards, int device, srn_index_t** out);
+int srn_index_build_shard_gpu(const srn_sessions_view_t* sessions, size_t m_index, size_t max_session_len, double idf_weighting,
+                              uint32_t shard, uint32_t n_shards, int device, srn_index_t** out);
+int srn_index_load_shard(const char* path, uint32_t shard, uint32_t n_shards, int device, srn_index_t** out);
 /* A: this shard's candidates of every query: d_cand [nq * m] packed (rank, partial numerator), d_cand_cnt [nq] */
 int srn_shard_stage_a(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq,
                       size_t max_len_hint, size_t k, size_t m, void* d_cand, uint32_t* d_cand_cnt, void* stream);
@@ -195,6 +206,11 @@ int srn_shard_stage_a(const srn_index_t* idx, const uint64_t* d_items_flat, cons
 int srn_shard_stage_b(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq,
                       size_t max_len_hint, size_t k, size_t m, uint32_t n_shards, const void* d_gathered,
                       const uint32_t* d_gathered_cnt, void* d_nb, uint32_t* d_nb_cnt, int32_t* d_minpos, void* stream);
+/* B with the gathered lists `gathered_stride` entries apart per query and shard instead of m (the host ships only the entries at or
+ * above the global m-th rank, serenade_amd/sharded.py) */
+int srn_shard_stage_b_strided(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq,
+                              size_t max_len_hint, size_t k, size_t m, uint32_t n_shards, size_t gathered_stride, const void* d_gathered,
+                              const uint32_t* d_gathered_cnt, void* d_nb, uint32_t* d_nb_cnt, int32_t* d_minpos, void* stream);
 /* C: d_minpos after all-reduce(min) -> exact top-how_many among the items this shard owns */
 int srn_shard_stage_c(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq,
                       size_t max_len_hint, size_t k, size_t m, size_t how_many, unsigned flags, const void* d_nb,

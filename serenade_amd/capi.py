@@ -72,6 +72,11 @@ SYMBOLS = {
     "srn_last_kernel_ms": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     "srn_index_build_shard": (_i, [C.POINTER(SessionsView), _sz, _sz, C.c_double, C.c_uint32, C.c_uint32, _i, C.POINTER(_vp)]),
     "srn_shard_slot_bytes": (_i, [_vp, _sz, C.POINTER(C.c_uint32)]),
+    "srn_shard_slot_info": (_i, [_vp, _sz, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "srn_index_shard": (_i, [_vp, C.c_uint32, C.c_uint32, _i, C.POINTER(_vp)]),
+    "srn_index_build_shard_gpu": (_i, [C.POINTER(SessionsView), _sz, _sz, C.c_double, C.c_uint32, C.c_uint32, _i, C.POINTER(_vp)]),
+    "srn_index_load_shard": (_i, [C.c_char_p, C.c_uint32, C.c_uint32, _i, C.POINTER(_vp)]),
+    "srn_shard_stage_b_strided": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint32, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     "srn_shard_stage_a": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp]),
     "srn_shard_stage_b": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "srn_shard_stage_c": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, C.c_uint, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -248,6 +248,51 @@ int srn_index_build_shard(const srn_sessions_view_t* sessions, size_t m_index, s
         if (rc) { delete ix; return rc; }
         *out = ix; return SRN_OK; });
 }
+int srn_index_shard(const srn_index_t* full, uint32_t shard, uint32_t n_shards, int device, srn_index_t** out) {
+    return guarded([&]() -> int {
+        if (!full || !out) return fail(SRN_EINVAL, "null argument");
+        *out = nullptr;
+        srn_index* ix = new srn_index();
+        int rc = shard_flat_index(full->flat, shard, n_shards, ix->flat);
+        if (rc == SRN_OK && device >= 0) { ix->dev = device_attach(ix->flat, device); ix->device = device; if (!ix->dev) rc = SRN_EHIP; }
+        if (rc) { delete ix; return rc; }
+        *out = ix; return SRN_OK; });
+}
+int srn_index_build_shard_gpu(const srn_sessions_view_t* sessions, size_t m_index, size_t max_session_len, double idf_weighting,
+                              uint32_t shard, uint32_t n_shards, int device, srn_index_t** out) {
+    return guarded([&]() -> int {
+        if (!sessions || !out) return fail(SRN_EINVAL, "null argument");
+        if (device < 0) return fail(SRN_ENODEV, "the GPU index builder needs a device");
+        *out = nullptr;
+        FlatIndex full;   // built on the GPU, never attached: only the shard goes to HBM
+        int rc = build_flat_index_gpu(*sessions, m_index, max_session_len, idf_weighting, device, full);
+        if (rc) return rc;
+        srn_index* ix = new srn_index();
+        rc = shard_flat_index(full, shard, n_shards, ix->flat);
+        if (rc == SRN_OK) { ix->dev = device_attach(ix->flat, device); ix->device = device; if (!ix->dev) rc = SRN_EHIP; }
+        if (rc) { delete ix; return rc; }
+        *out = ix; return SRN_OK; });
+}
+int srn_index_load_shard(const char* path, uint32_t shard, uint32_t n_shards, int device, srn_index_t** out) {
+    return guarded([&]() -> int {
+        if (!path || !out) return fail(SRN_EINVAL, "null argument");
+        *out = nullptr;
+        FlatIndex full;
+        int rc = load_flat_index(path, full);
+        if (rc) return rc;
+        srn_index* ix = new srn_index();
+        rc = full.n_shards == 1 ? shard_flat_index(full, shard, n_shards, ix->flat)
+                                : (full.shard == shard && full.n_shards == n_shards ? (ix->flat = std::move(full), SRN_OK) : fail(SRN_EINVAL, "the file holds another shard"));
+        if (rc == SRN_OK && device >= 0) { ix->dev = device_attach(ix->flat, device); ix->device = device; if (!ix->dev) rc = SRN_EHIP; }
+        if (rc) { delete ix; return rc; }
+        *out = ix; return SRN_OK; });
+}
+int srn_shard_slot_info(const srn_index_t* idx, size_t max_len_hint, uint32_t* out_bytes, uint32_t* out_num_bits) {
+    if (!idx || !idx->dev || !out_bytes || !out_num_bits) return fail(SRN_ENODEV, "index has no device attached");
+    const int b = device_slot_bytes(idx->dev, idx->flat, (uint32_t)max_len_hint, out_num_bits);
+    if (b < 0) return SRN_ERANGE;
+    *out_bytes = (uint32_t)b; return SRN_OK;
+}
 int srn_shard_slot_bytes(const srn_index_t* idx, size_t max_len_hint, uint32_t* out) {
     if (!idx || !idx->dev || !out) return fail(SRN_ENODEV, "index has no device attached");
     const int b = device_slot_bytes(idx->dev, idx->flat, (uint32_t)max_len_hint);
@@ -280,6 +325,13 @@ int srn_shard_stage_b(const srn_index_t* idx, const uint64_t* d_items_flat, cons
                       void* d_nb, uint32_t* d_nb_cnt, int32_t* d_minpos, void* stream) {
     if (!d_gathered || !d_gathered_cnt || !d_nb || !d_nb_cnt || !d_minpos || n_shards == 0) return fail(SRN_EINVAL, "null buffer");
     ShardIO sh{}; sh.gathered = d_gathered; sh.gathered_cnt = d_gathered_cnt; sh.n_shards = n_shards; sh.nb = d_nb; sh.nb_cnt = d_nb_cnt; sh.minpos = d_minpos;
+    return shard_stage(idx, 2, d_items_flat, d_q_off, nq, max_len_hint, k, m, 0, 0, sh, nullptr, nullptr, nullptr, stream);
+}
+int srn_shard_stage_b_strided(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq, size_t max_len_hint,
+                              size_t k, size_t m, uint32_t n_shards, size_t gathered_stride, const void* d_gathered, const uint32_t* d_gathered_cnt,
+                              void* d_nb, uint32_t* d_nb_cnt, int32_t* d_minpos, void* stream) {
+    if (!d_gathered || !d_gathered_cnt || !d_nb || !d_nb_cnt || !d_minpos || n_shards == 0 || gathered_stride == 0 || gathered_stride > 0xFFFFFFFFull) return fail(SRN_EINVAL, "null buffer");
+    ShardIO sh{}; sh.gathered = d_gathered; sh.gathered_cnt = d_gathered_cnt; sh.n_shards = n_shards; sh.gathered_stride = (uint32_t)gathered_stride; sh.nb = d_nb; sh.nb_cnt = d_nb_cnt; sh.minpos = d_minpos;
     return shard_stage(idx, 2, d_items_flat, d_q_off, nq, max_len_hint, k, m, 0, 0, sh, nullptr, nullptr, nullptr, stream);
 }
 int srn_shard_stage_c(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq, size_t max_len_hint,

@@ -213,6 +213,54 @@ int build_flat_index(const srn_sessions_view_t& v, size_t m_index, size_t max_se
 }
 
 // ---------------------------------------------------------------------------------------------
+// Shard g of an UNSHARDED flat index: the items with item_owner(id) == g, everything else restated for them -- the same bytes
+// build_flat_index(..., g, n_shards) produces from the sessions (tests compare the saved files), in one O(nnz) pass instead of a
+// rebuild.  The full index comes from the GPU builder or from disk, so an item-sharded deployment builds ONE index and every rank
+// cuts its own shard out of it (the reference loads its production index, it does not rebuild it: vmis_index.rs:85-314).
+// ---------------------------------------------------------------------------------------------
+int shard_flat_index(const FlatIndex& full, uint32_t shard, uint32_t n_shards, FlatIndex& ix) {
+    if (n_shards == 0 || shard >= n_shards) return fail(SRN_EINVAL, "shard must be < n_shards");
+    if (full.n_shards != 1) return fail(SRN_EINVAL, "the source index is already a shard");
+    ix = FlatIndex();
+    ix.n_sessions_total = full.n_sessions_total; ix.n_kept = full.n_kept; ix.m_index = full.m_index; ix.max_session_len = full.max_session_len;
+    ix.idf_weighting = full.idf_weighting; ix.total_pairs = full.total_pairs; ix.shard = shard; ix.n_shards = n_shards; ix.lists_complete = full.lists_complete;
+    ix.rank_to_session = full.rank_to_session;
+    // owned items keep their relative (popularity) order; remap[full idx] = shard idx
+    std::vector<uint32_t> remap(full.n_items, kNone);
+    for (uint64_t i = 0; i < full.n_items; ++i)
+        if (n_shards == 1 || item_owner(full.item_id[i], n_shards) == shard) { remap[i] = (uint32_t)ix.item_id.size(); ix.item_id.push_back(full.item_id[i]); }
+    ix.n_items = ix.item_id.size();
+    ix.idf.resize(ix.n_items); ix.attr.resize(ix.n_items); ix.post_off.assign(ix.n_items + 1, 0);
+    for (uint64_t i = 0; i < full.n_items; ++i) { const uint32_t j = remap[i]; if (j == kNone) continue;
+        ix.idf[j] = full.idf[i]; ix.attr[j] = full.attr[i]; ix.post_off[j + 1] = full.post_off[i + 1] - full.post_off[i]; }
+    for (uint64_t j = 0; j < ix.n_items; ++j) ix.post_off[j + 1] += ix.post_off[j];
+    ix.nnz_post = ix.post_off[ix.n_items]; ix.post_rank.resize(ix.nnz_post);
+    for (uint64_t i = 0; i < full.n_items; ++i) { const uint32_t j = remap[i]; if (j == kNone) continue;
+        std::copy(full.post_rank.begin() + full.post_off[i], full.post_rank.begin() + full.post_off[i + 1], ix.post_rank.begin() + ix.post_off[j]); }
+    // id_rank: rank of the public id among the owned items = order of the full index's id ranks
+    { std::vector<uint32_t> by(ix.n_items); std::iota(by.begin(), by.end(), 0u);
+      std::sort(by.begin(), by.end(), [&](uint32_t a, uint32_t b) { return ix.item_id[a] < ix.item_id[b]; });
+      ix.id_rank.resize(ix.n_items); for (uint32_t r = 0; r < ix.n_items; ++r) ix.id_rank[by[r]] = r; }
+    // row fragments, in the rows' own order
+    ix.row_off.assign(ix.n_kept + 1, 0);
+    uint64_t w = 0;
+    for (uint64_t r = 0; r < full.n_kept; ++r) { for (uint64_t j = full.row_off[r]; j < full.row_off[r + 1]; ++j) w += remap[full.row_items[j]] != kNone; ix.row_off[r + 1] = w; }
+    ix.nnz_rows = w; ix.row_items.resize(w); w = 0;
+    for (uint64_t r = 0; r < full.n_kept; ++r) {
+        for (uint64_t j = full.row_off[r]; j < full.row_off[r + 1]; ++j) { const uint32_t m = remap[full.row_items[j]]; if (m != kNone) ix.row_items[w++] = m; }
+        ix.max_row_len = std::max<uint64_t>(ix.max_row_len, ix.row_off[r + 1] - ix.row_off[r]);
+    }
+    size_t tcap = 16; while (tcap < ix.n_items * 2) tcap <<= 1;
+    ix.id_table.assign(tcap, IdSlot{0, kNone, 0}); ix.id_mask = (uint32_t)(tcap - 1);
+    for (uint32_t i = 0; i < ix.n_items; ++i) {
+        uint32_t h = (uint32_t)mix64(ix.item_id[i]) & ix.id_mask;
+        while (ix.id_table[h].idx != kNone) h = (h + 1) & ix.id_mask;
+        ix.id_table[h] = IdSlot{ix.item_id[i], i, 0};
+    }
+    return SRN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // binary save / load ("SRNFLAT4": header of u64 fields, then raw arrays; "SRNFLAT3" files -- no flags word -- still load)
 // ---------------------------------------------------------------------------------------------
 namespace {

@@ -69,6 +69,7 @@ static inline uint32_t item_owner(uint64_t id, uint32_t n_shards) { return (uint
 int build_flat_index_gpu(const srn_sessions_view_t& v, size_t m_index, size_t max_session_len, double idf_weighting, int device,
                          FlatIndex& out);   // same result, built with rocPRIM sorts on the GPU (srn_build_gpu.hip)
 int build_flat_index_from_avro(const char* base_path, FlatIndex& out);   // <base>/itemindex/*.avro + <base>/sessionindex/*.avro (srn_avro.cpp)
+int shard_flat_index(const FlatIndex& full, uint32_t shard, uint32_t n_shards, FlatIndex& out);   // shard `shard` of an unsharded index (same bytes as build_flat_index(..., shard, n_shards))
 int save_flat_index(const FlatIndex& ix, const char* path);
 int load_flat_index(const char* path, FlatIndex& ix);
 
@@ -118,12 +119,13 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p, b
                    uint32_t* h_counts, uint32_t* h_stats, uint32_t* h_nb_rank, uint32_t* h_nb_num, uint32_t* h_nb_cnt);
 struct ShardIO {
     void* cand; uint32_t* cand_cnt;                                       // A out: [nq * m] packed slots, [nq]
-    const void* gathered; const uint32_t* gathered_cnt; uint32_t n_shards;   // B in: [G][nq * m], [G][nq]
+    const void* gathered; const uint32_t* gathered_cnt; uint32_t n_shards;   // B in: [G][nq * gathered_stride], [G][nq]
+    uint32_t gathered_stride;                                                // entries per query and shard in `gathered` (0 = m)
     void* nb; uint32_t* nb_cnt; int* minpos;                             // B out / C in: [nq * k], [nq], [nq * (k + 1)]
 };
 
 int device_shard_stage(DeviceState* d, const FlatIndex& ix, int stage, const LaunchParams& p, const ShardIO& sh, void* stream);
-int device_slot_bytes(DeviceState* d, const FlatIndex& ix, uint32_t max_len);
+int device_slot_bytes(DeviceState* d, const FlatIndex& ix, uint32_t max_len, uint32_t* num_bits = nullptr);
 int device_last_kernel_ms(DeviceState* d, double* ms_main, double* ms_retry, uint32_t* retried);
 int device_phase_cycles(DeviceState* d, int enable, unsigned long long* out16);
 int device_last_path_counts(DeviceState* d, uint32_t* nq, uint32_t* general, uint32_t* global_pass);   // debug profiling aid

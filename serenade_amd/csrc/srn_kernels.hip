@@ -766,7 +766,7 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
             uint32_t fresh = 0, rmin = 0xFFFFFFFFu, rmax = 0;
             bool ovf = false;
             for (uint32_t g = 0; g < sh.n_shards; ++g) {
-                const SlotT* list = (const SlotT*)sh.gathered + ((size_t)g * p.nq + q) * p.m;
+                const SlotT* list = (const SlotT*)sh.gathered + ((size_t)g * p.nq + q) * (sh.gathered_stride ? sh.gathered_stride : p.m);
                 const uint32_t cnt = sh.gathered_cnt[(size_t)g * p.nq + q];
                 for (uint32_t e = tid; e < cnt; e += BLOCK) {
                     const SlotT v = list[e]; const uint32_t r = (uint32_t)(v >> NB);

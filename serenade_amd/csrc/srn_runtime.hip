@@ -470,9 +470,11 @@ int device_shard_stage(DeviceState* d, const FlatIndex& ix, int stage, const Lau
     if (e != hipSuccess) return fail(SRN_EHIP, std::string("shard stage launch: ") + hipGetErrorString(e));
     return SRN_OK;
 }
-int device_slot_bytes(DeviceState* d, const FlatIndex& ix, uint32_t max_len) {   // element size of the packed candidate / neighbour buffers
+int device_slot_bytes(DeviceState* d, const FlatIndex& ix, uint32_t max_len, uint32_t* num_bits) {   // element size of the packed candidate / neighbour buffers
     LaunchParams p{}; p.max_len = max_len; p.k = 1; p.m = 1; Geometry g;
-    return make_geometry(d, ix, p, 0, g) == SRN_OK ? (int)g.slot_bytes : -1;
+    if (make_geometry(d, ix, p, 0, g) != SRN_OK) return -1;
+    if (num_bits) *num_bits = g.c.num_bits;
+    return (int)g.slot_bytes;
 }
 
 int device_last_kernel_ms(DeviceState* d, double* ms_main, double* ms_retry, uint32_t* retried) {

@@ -28,15 +28,43 @@ MINPOS_NONE = 0x7FFFFFFF
 
 
 class ShardedVMISIndex:
-    """One shard (srn_index_build_shard).  Every rank passes the SAME training sessions and its own shard number."""
+    """One shard.  Every rank passes the SAME training sessions (or the same unsharded index) and its own shard number.
+    builder="gpu" (default when the shard is attached to a device): the unsharded index is built with rocPRIM sorts on this
+    rank's GPU and the shard is cut out of it in one pass -- seconds at BASELINE config 4/5 scale; builder="host": the
+    single-threaded host builder restricted to the shard's items (same bytes)."""
 
-    def __init__(self, sess_off, items, max_ts, m_index, max_session_len, idf_weighting, shard, n_shards, device=0):
+    def __init__(self, sess_off, items, max_ts, m_index, max_session_len, idf_weighting, shard, n_shards, device=0, builder=None):
         sess_off, items, max_ts = capi.as_u64(sess_off), capi.as_u64(items), capi.as_u32(max_ts)
         v = capi.SessionsView(sess_off.ctypes.data, items.ctypes.data, max_ts.ctypes.data, len(max_ts))
         h = C.c_void_p()
-        capi.check(capi.lib().srn_index_build_shard(C.byref(v), int(m_index), int(max_session_len), float(idf_weighting),
-                                                    int(shard), int(n_shards), int(device), C.byref(h)))
+        if builder is None:
+            builder = "gpu" if device >= 0 and len(max_ts) < 0xFFFFFFFF and len(items) < 0xFFFFFFFF else "host"
+        fn = capi.lib().srn_index_build_shard_gpu if builder == "gpu" else capi.lib().srn_index_build_shard
+        capi.check(fn(C.byref(v), int(m_index), int(max_session_len), float(idf_weighting), int(shard), int(n_shards), int(device), C.byref(h)))
         self._h, self.shard, self.n_shards, self.device = h, int(shard), int(n_shards), int(device)
+
+    @classmethod
+    def _wrap(cls, h, shard, n_shards, device):
+        self = cls.__new__(cls)
+        self._h, self.shard, self.n_shards, self.device = h, int(shard), int(n_shards), int(device)
+        return self
+
+    @classmethod
+    def from_full(cls, full_index, shard, n_shards, device=0):
+        """Cut shard `shard` out of an unsharded VMISIndex (srn_index_shard)."""
+        h = C.c_void_p()
+        capi.check(capi.lib().srn_index_shard(full_index._h, int(shard), int(n_shards), int(device), C.byref(h)))
+        return cls._wrap(h, shard, n_shards, device)
+
+    @classmethod
+    def load(cls, path, shard, n_shards, device=0):
+        """From a saved index (VMISIndex.save): an unsharded file is cut, a file that already holds this shard is taken as is."""
+        h = C.c_void_p()
+        capi.check(capi.lib().srn_index_load_shard(str(path).encode(), int(shard), int(n_shards), int(device), C.byref(h)))
+        return cls._wrap(h, shard, n_shards, device)
+
+    def save(self, path):
+        capi.check(capi.lib().srn_index_save(self._h, str(path).encode()))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -55,6 +83,12 @@ class ShardedVMISIndex:
         out = C.c_uint32()
         capi.check(capi.lib().srn_shard_slot_bytes(self._h, int(max_len), C.byref(out)))
         return out.value
+
+    def slot_info(self, max_len):
+        """(bytes per packed entry, low payload bits): rank = entry >> bits."""
+        a, b = C.c_uint32(), C.c_uint32()
+        capi.check(capi.lib().srn_shard_slot_info(self._h, int(max_len), C.byref(a), C.byref(b)))
+        return a.value, b.value
 
 
 class DistComm:
@@ -85,6 +119,16 @@ class DistComm:
         return t
 
 
+    def all_reduce_max(self, t):
+        if self.staged:
+            h = t.cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.MAX, group=self.group)
+            t.copy_(h)
+        else:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return t
+
+
 class SoloComm:
     """world size 1 (single shard): the collectives degenerate."""
     world = 1
@@ -94,6 +138,45 @@ class SoloComm:
 
     def all_reduce_min(self, t):
         return t
+
+    def all_reduce_max(self, t):
+        return t
+
+
+def _local_mth_rank(cand, cand_cnt, nq, m, slot_bytes, num_bits):
+    """Per query: the rank of this shard's m-th most recent candidate, 0 if it holds fewer than m."""
+    import torch
+    c2 = cand.view(nq, m)
+    u = (c2.to(torch.int64) & 0xFFFFFFFF) if slot_bytes == 4 else c2            # packed value, unsigned
+    rank = u >> num_bits
+    cnt = cand_cnt.to(torch.int64)
+    valid = torch.arange(m, device=cand.device).view(1, m) < cnt.clamp(min=0).view(nq, 1)
+    mth = torch.where(cnt == m, rank.masked_fill(~valid, torch.iinfo(torch.int64).max).min(dim=1).values, torch.zeros_like(cnt))
+    return mth, rank, valid
+
+
+def _keep_at_or_above(cand, cand_cnt, rank, valid, tau, nq, m):
+    """Entries with rank >= tau moved to the front of each query's list (in their order) -> (packed [nq, m], counts [nq])."""
+    import torch
+    keep = valid & (rank >= tau.view(nq, 1))
+    order = torch.argsort((~keep).to(torch.int8), dim=1, stable=True)
+    packed = torch.gather(cand.view(nq, m), 1, order)
+    new_cnt = keep.sum(dim=1)
+    return packed, torch.where(cand_cnt < 0, cand_cnt, new_cnt.to(cand_cnt.dtype))   # (the overflow marker travels)
+
+
+def compact_candidates(cand, cand_cnt, nq, m, slot_bytes, num_bits, reduce_max):
+    """all-gather #1 is the bandwidth-relevant exchange (m entries per query and shard).  A tiny all-reduce(max)
+    of the shards' local m-th ranks gives, per query, a rank below which no entry can be among the m most recent distinct
+    sessions of the union (the shard that attains the maximum alone holds m sessions at or above it); only the entries at or
+    above it are shipped, in slabs as wide as the fullest list (a second, scalar all-reduce(max)).
+    cand [nq * m] packed (rank << num_bits | payload), cand_cnt [nq] (-1 = overflow on this shard) -> (slab [nq, w], cnt [nq], w)."""
+    mth, rank, valid = _local_mth_rank(cand, cand_cnt, nq, m, slot_bytes, num_bits)
+    tau = reduce_max(mth)
+    packed, cnt = _keep_at_or_above(cand, cand_cnt, rank, valid, tau, nq, m)
+    w = int(reduce_max(cnt.clamp(min=0).max().to(mth.dtype).view(1)).item())
+    w = min(m, (max(1, w) + 63) // 64 * 64)
+    return packed[:, :w].contiguous(), cnt, w
 
 
 def _ptr(t):
@@ -108,14 +191,14 @@ def _stage_a(ix, d_flat, d_off, nq, max_len, k, m, dtype, stream):
     return cand, cnt
 
 
-def _stage_b(ix, d_flat, d_off, nq, max_len, k, m, gathered, gathered_cnt, dtype, stream):
+def _stage_b(ix, d_flat, d_off, nq, max_len, k, m, gathered, gathered_cnt, dtype, stream, stride=None):
     import torch
     dev = d_flat.device
     nb = torch.zeros(nq * k, dtype=dtype, device=dev)
     nb_cnt = torch.empty(nq, dtype=torch.int32, device=dev)
     minpos = torch.full((nq * (k + 1),), MINPOS_NONE, dtype=torch.int32, device=dev)
-    capi.check(capi.lib().srn_shard_stage_b(ix._h, _ptr(d_flat), _ptr(d_off), nq, max_len, k, m, gathered.shape[0],
-                                            _ptr(gathered), _ptr(gathered_cnt), _ptr(nb), _ptr(nb_cnt), _ptr(minpos), C.c_void_p(stream)))
+    capi.check(capi.lib().srn_shard_stage_b_strided(ix._h, _ptr(d_flat), _ptr(d_off), nq, max_len, k, m, gathered.shape[0], int(stride or m),
+                                                    _ptr(gathered), _ptr(gathered_cnt), _ptr(nb), _ptr(nb_cnt), _ptr(minpos), C.c_void_p(stream)))
     return nb, nb_cnt, minpos
 
 
@@ -163,10 +246,14 @@ def predict_batch_sharded(index, comm, d_items_flat, d_q_off, nq, max_len, k, m,
         stream = torch.cuda.current_stream(d_items_flat.device).cuda_stream
     dtype = torch.int32 if index.slot_bytes(max_len) == 4 else torch.int64
     cand, cand_cnt = _stage_a(index, d_items_flat, d_q_off, nq, max_len, k, m, dtype, stream)
+    sbytes, nbits = index.slot_info(max_len)
+    stride = m
+    if comm.world > 1:   # ship only what can still be among the m most recent sessions of the union
+        cand, cand_cnt, stride = compact_candidates(cand, cand_cnt, nq, m, sbytes, nbits, comm.all_reduce_max)
     gathered, gathered_cnt = comm.all_gather(cand), comm.all_gather(cand_cnt)
     if bool((gathered_cnt == -1).any()):
         raise capi.SerenadeError(capi.SRN_ERANGE, "a query exceeded the session-table limits on some shard")
-    nb, nb_cnt, minpos = _stage_b(index, d_items_flat, d_q_off, nq, max_len, k, m, gathered.contiguous(), gathered_cnt.contiguous(), dtype, stream)
+    nb, nb_cnt, minpos = _stage_b(index, d_items_flat, d_q_off, nq, max_len, k, m, gathered.contiguous(), gathered_cnt.contiguous(), dtype, stream, stride)
     comm.all_reduce_min(minpos)
     ids, sc, cnt = _stage_c(index, d_items_flat, d_q_off, nq, max_len, k, m, how_many, enable_business_logic, nb, nb_cnt, minpos, stream)
     g_ids = comm.all_gather(ids.view(nq, how_many))
@@ -175,16 +262,24 @@ def predict_batch_sharded(index, comm, d_items_flat, d_q_off, nq, max_len, k, m,
     return merge_topn(g_ids, g_sc, g_cnt, how_many)
 
 
-def predict_batch_sharded_local(shards, d_items_flat, d_q_off, nq, max_len, k, m, how_many, enable_business_logic=False):
+def predict_batch_sharded_local(shards, d_items_flat, d_q_off, nq, max_len, k, m, how_many, enable_business_logic=False, compact=True):
     """All shards in ONE process on one GPU (tests, debugging): the collectives become tensor ops."""
     import torch
     stream = torch.cuda.current_stream(d_items_flat.device).cuda_stream
     dtype = torch.int32 if shards[0].slot_bytes(max_len) == 4 else torch.int64
     a = [_stage_a(ix, d_items_flat, d_q_off, nq, max_len, k, m, dtype, stream) for ix in shards]
+    stride = m
+    if compact and len(shards) > 1:   # compact_candidates with its two all-reduce(max) steps as tensor ops over the shards
+        sbytes, nbits = shards[0].slot_info(max_len)
+        loc = [_local_mth_rank(x[0], x[1], nq, m, sbytes, nbits) for x in a]
+        tau = torch.stack([l[0] for l in loc]).max(dim=0).values
+        kept = [_keep_at_or_above(x[0], x[1], l[1], l[2], tau, nq, m) for x, l in zip(a, loc)]
+        stride = min(m, (max(1, max(int(kc.clamp(min=0).max().item()) for _, kc in kept)) + 63) // 64 * 64)
+        a = [(kp[:, :stride].contiguous().view(-1), kc) for kp, kc in kept]
     gathered, gathered_cnt = torch.stack([x[0] for x in a]).contiguous(), torch.stack([x[1] for x in a]).contiguous()
     if bool((gathered_cnt == -1).any()):
         raise capi.SerenadeError(capi.SRN_ERANGE, "a query exceeded the session-table limits on some shard")
-    b = [_stage_b(ix, d_items_flat, d_q_off, nq, max_len, k, m, gathered, gathered_cnt, dtype, stream) for ix in shards]
+    b = [_stage_b(ix, d_items_flat, d_q_off, nq, max_len, k, m, gathered, gathered_cnt, dtype, stream, stride) for ix in shards]
     for x in b[1:]:   # stage B computes the same neighbour list on every shard
         assert torch.equal(x[0], b[0][0]) and torch.equal(x[1], b[0][1]), "shards disagree on the neighbour list"
     minpos = torch.stack([x[2] for x in b]).min(dim=0).values.contiguous()

@@ -16,6 +16,7 @@ CONFIGS = {
     "cfg3": (60_000_000, 1_760_000, 1500, 2500, 2.0),  # "Synthetic 60M / 1.76M items, k=1500 m=2500 idf=2"
     "cfg4": (582_000_000, 6_500_000, 1500, 2500, 1.0),
     "cfg5": (2_300_000_000, 20_000_000, 1500, 2500, 1.0),
+    "cfg5_8th": (287_500_000, 2_500_000, 1500, 2500, 1.0),   # config 5's shape at 1/8 scale: what one GPU of the 8 would see of the sessions if they were split too
 }
 ZIPF_ALPHA = 1.05
 LAST_ITEMS = 4

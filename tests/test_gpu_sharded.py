@@ -44,7 +44,7 @@ def test_local_shards_match_unsharded(n_shards):
     d_flat, d_off = _to_dev(flat, qoff)
     for (m_index, k, m, n) in [(200, 50, 200, 21), (60, 20, 40, 64), (200, 500, 500, 100)]:
         ref = _unsharded(off, items, ts, m_index, 12, 1.0, flat, qoff, k, m, n, False)
-        shards = [sharded.ShardedVMISIndex(off, items, ts, m_index, 12, 1.0, g, n_shards) for g in range(n_shards)]
+        shards = [sharded.ShardedVMISIndex(off, items, ts, m_index, 12, 1.0, g, n_shards) for g in range(n_shards)]   # built on the GPU, cut per shard
         infos = [s.info for s in shards]
         assert sum(i["n_items"] for i in infos) == len(np.unique(items[np.repeat(np.diff(off.astype(np.int64)) <= 12, np.diff(off.astype(np.int64)))]))
         _check(sharded.predict_batch_sharded_local(shards, d_flat, d_off, len(qs), 6, k, m, n), ref)
@@ -74,6 +74,112 @@ def test_local_shards_business_rules_and_synthetic():
     ref = _unsharded(off, items, ts, m, 34, idfw, qi, qo, k, m, 21, False)
     shards = [sharded.ShardedVMISIndex(off, items, ts, m, 34, idfw, g, 4) for g in range(4)]
     _check(sharded.predict_batch_sharded_local(shards, d_flat, d_off, len(qo) - 1, 4, k, m, 21), ref)
+
+
+def test_gpu_built_shards_equal_host_built_shards_and_load_from_one_file(tmp_path):
+    """The three ways to a shard give the same bytes: the host builder restricted to the shard's items (srn_index_build_shard), the
+    unsharded index built on the GPU and cut (srn_index_build_shard_gpu), an unsharded index saved to disk and cut on load
+    (srn_index_load_shard) -- the last is how an 8-GPU node would start: build or ship ONE index, every rank cuts its own part."""
+    import serenade_amd as sa
+    from serenade_amd import sharded
+    off, items, ts, ids = small_dataset(54, n_sessions=6000, n_items=500, tied_timestamps=True)
+    full = sa.VMISIndex.from_sessions(off, items, ts, 120, 10, 2.0, device=0, builder="gpu")
+    full.save(tmp_path / "full.srn")
+    for G in (2, 5):
+        for g in range(G):
+            a = sharded.ShardedVMISIndex(off, items, ts, 120, 10, 2.0, g, G, device=-1, builder="host")
+            b = sharded.ShardedVMISIndex(off, items, ts, 120, 10, 2.0, g, G, device=0, builder="gpu")
+            c = sharded.ShardedVMISIndex.load(tmp_path / "full.srn", g, G, device=-1)
+            d = sharded.ShardedVMISIndex.from_full(full, g, G, device=-1)
+            blobs = []
+            for nm, ix in (("a", a), ("b", b), ("c", c), ("d", d)):
+                ix.save(tmp_path / ("%s.srn" % nm))
+                blobs.append(open(tmp_path / ("%s.srn" % nm), "rb").read())
+            assert blobs[0] == blobs[1] == blobs[2] == blobs[3], (G, g)
+
+
+def test_candidate_compaction_ships_less_and_changes_nothing():
+    """All-gather #1 compacted to the entries at or above the global m-th rank: same results with and without, and
+    the slabs are narrower than m when the shards' lists overlap in recency."""
+    import torch
+    from serenade_amd import sharded, synth
+    inter, n_items, k, m, idfw = synth.CONFIGS["tiny"]
+    off, items, ts = synth.training_sessions(inter, n_items)
+    qi, qo = synth.queries(400, n_items)
+    d_flat, d_off = _to_dev(qi, qo)
+    nq = len(qo) - 1
+    shards = [sharded.ShardedVMISIndex(off, items, ts, m, 34, idfw, g, 4) for g in range(4)]
+    a = sharded.predict_batch_sharded_local(shards, d_flat, d_off, nq, 4, k, m, 21, compact=True)
+    b = sharded.predict_batch_sharded_local(shards, d_flat, d_off, nq, 4, k, m, 21, compact=False)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    ref = _unsharded(off, items, ts, m, 34, idfw, qi, qo, k, m, 21, False)
+    _check(a, ref)
+    stream = torch.cuda.current_stream().cuda_stream
+    sbytes, nbits = shards[0].slot_info(4)
+    dtype = torch.int32 if sbytes == 4 else torch.int64
+    st = [sharded._stage_a(ix, d_flat, d_off, nq, 4, k, m, dtype, stream) for ix in shards]
+    loc = [sharded._local_mth_rank(x[0], x[1], nq, m, sbytes, nbits) for x in st]
+    tau = torch.stack([l[0] for l in loc]).max(dim=0).values
+    kept = [sharded._keep_at_or_above(x[0], x[1], l[1], l[2], tau, nq, m)[1] for x, l in zip(st, loc)]
+    before = sum(int(x[1].clamp(min=0).sum()) for x in st)
+    after = sum(int(kc.clamp(min=0).sum()) for kc in kept)
+    assert after < before, (before, after)
+
+
+def _nccl_worker(port, q):
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    try:
+        import torch
+        import torch.distributed as dist
+        from serenade_amd import sharded
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)       # RCCL, one rank: the device_id= init path
+        comm = sharded.DistComm()
+        assert comm.world == 1 and not comm.staged                                  # device tensors go straight to RCCL
+        off, items, ts, ids = small_dataset(55, n_sessions=3000, n_items=300)
+        qs = random_queries(9, ids, 200, max_len=5)
+        flat, qoff = flatten(qs)
+        d_flat, d_off = _to_dev(flat, qoff)
+        ix = sharded.ShardedVMISIndex(off, items, ts, 150, 12, 1.0, 0, 1, device=0)
+        res = sharded.predict_batch_sharded(ix, comm, d_flat, d_off, len(qs), 5, 40, 150, 21)
+        # and the exchange steps of a multi-rank run on device buffers: all-reduce(max), all-reduce(min), all-gather
+        t = torch.arange(1000, dtype=torch.int64, device=dev)
+        assert torch.equal(comm.all_reduce_max(t.clone()), t) and torch.equal(comm.all_reduce_min(t.to(torch.int32).clone()), t.to(torch.int32))
+        assert torch.equal(comm.all_gather(t)[0], t)
+        sb, nb = ix.slot_info(5)
+        c, cc, w = sharded.compact_candidates(*sharded._stage_a(ix, d_flat, d_off, len(qs), 5, 40, 150, torch.int32 if sb == 4 else torch.int64,
+                                                                torch.cuda.current_stream().cuda_stream), len(qs), 150, sb, nb, comm.all_reduce_max)
+        assert c.shape == (len(qs), w) and w <= 150
+        torch.cuda.synchronize()
+        q.put([x.cpu().numpy() for x in res])
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put("error: %r\n%s" % (e, traceback.format_exc()))
+
+
+def test_single_rank_nccl_group_runs_the_rccl_code_path():
+    """backend "nccl" IS RCCL on ROCm.  With one GPU on the test box a 1-rank group is what can run: process-group init with
+    device_id=, all_gather_into_tensor / all_reduce(MIN | MAX) on device buffers through DistComm's non-staged branch, and the
+    whole sharded pipeline over it -- bit-identical to the unsharded result."""
+    mp = pytest.importorskip("torch.multiprocessing")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(port, q))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(timeout=120)
+    assert not isinstance(res, str), res
+    off, items, ts, ids = small_dataset(55, n_sessions=3000, n_items=300)
+    qs = random_queries(9, ids, 200, max_len=5)
+    flat, qoff = flatten(qs)
+    ref = _unsharded(off, items, ts, 150, 12, 1.0, flat, qoff, 40, 150, 21, False)
+    assert np.array_equal(res[2].view(np.uint32), ref[2]) and np.array_equal(res[0].view(np.uint64), ref[0]) and np.array_equal(res[1], ref[1])
 
 
 def _worker(rank, world, port, q):
