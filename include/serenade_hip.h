@@ -170,6 +170,11 @@ int srn_predict_batch_debug(const srn_index_t* idx, const uint64_t* items_flat, 
                             double* out_scores, uint32_t* out_counts, uint32_t* out_stats,
                             uint32_t* out_nb_sessions, uint32_t* out_nb_num, uint32_t* out_nb_counts);
 
+/* Sizes the per-stream workspace of srn_predict_batch_device for calls of up to nq queries with these parameters: after it, such
+ * calls on `stream` allocate nothing (hipMalloc / hipFree synchronise the device, so a serving process reserves once at start-up).
+ * Without it the workspace grows on demand, the first time a larger batch arrives. */
+int srn_index_reserve(const srn_index_t* idx, size_t nq, size_t max_len_hint, size_t k, size_t m, size_t how_many, unsigned flags, void* stream);
+
 /* Average duration in milliseconds of the predict kernel launches enqueued by the most recent
  * srn_predict_batch* call on this thread, measured with HIP events on the launch stream (blocks
  * until that work has finished); *out_launches = number of kernel launches it covered. */

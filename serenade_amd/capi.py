@@ -69,6 +69,7 @@ SYMBOLS = {
     "srn_recommend": (_i, [_vp, _vp, C.c_char_p, _sz, _u64, _i, _sz, _u64, _vp, _vp, C.POINTER(_sz)]),
     "srn_predict_batch_device": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, C.c_uint, _vp, _vp, _vp, _vp]),
     "srn_predict_batch_debug": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "srn_index_reserve": (_i, [_vp, _sz, _sz, _sz, _sz, _sz, C.c_uint, _vp]),
     "srn_last_kernel_ms": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     "srn_index_build_shard": (_i, [C.POINTER(SessionsView), _sz, _sz, C.c_double, C.c_uint32, C.c_uint32, _i, C.POINTER(_vp)]),
     "srn_shard_slot_bytes": (_i, [_vp, _sz, C.POINTER(C.c_uint32)]),

@@ -231,6 +231,16 @@ int srn_predict_batch_device(const srn_index_t* idx, const uint64_t* d_items_fla
                               nullptr, nullptr); });
 }
 
+int srn_index_reserve(const srn_index_t* idx, size_t nq, size_t max_len_hint, size_t k, size_t m, size_t how_many, unsigned flags, void* stream) {
+    return guarded([&]() -> int {
+        int rc = check_predict_args(idx, k, m, how_many); if (rc) return rc;
+        if (nq == 0 || nq > 0x7FFFFFFFull) return fail(SRN_ERANGE, "nq out of range");
+        if (max_len_hint == 0 || max_len_hint > SRN_MAX_SESSION_LEN) return fail(SRN_ERANGE, "max_len_hint out of range");
+        LaunchParams p{};
+        p.nq = (uint32_t)nq; p.k = (uint32_t)k; p.m = (uint32_t)m; p.how_many = (uint32_t)how_many; p.flags = flags; p.max_len = (uint32_t)max_len_hint;
+        return device_reserve(idx->dev, idx->flat, p, stream); });
+}
+
 int srn_last_kernel_ms(const srn_index_t* idx, double* out_ms_main, double* out_ms_retry, uint32_t* out_retried) {
     if (!idx || !idx->dev) return fail(SRN_ENODEV, "index has no device attached");
     return guarded([&]() -> int { return device_last_kernel_ms(idx->dev, out_ms_main, out_ms_retry, out_retried); });

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -57,6 +58,7 @@ struct Workspace {
     uint32_t* slow_list = nullptr; size_t slow_cap = 0; uint32_t* slow_cnt = nullptr;          // what the fast kernel hands to the general one
     char* fin = nullptr; size_t fin_bytes = 0;   // records for vmis_finish_kernel
     char* big = nullptr; size_t big_bytes = 0;   // overflow entries + list for vmis_finish_big_kernel
+    char* pin = nullptr; size_t pin_bytes = 0;   // pinned, device-mapped staging of the latency path (a handful of queries on host pointers)
     // staging for host-pointer calls
     char* stage = nullptr; size_t stage_bytes = 0;
     uint32_t* h_retry = nullptr;   // pinned
@@ -182,6 +184,7 @@ static void ws_free(Workspace* w) {
     if (w->slow_cnt) hipFree(w->slow_cnt);
     if (w->fin) hipFree(w->fin);
     if (w->big) hipFree(w->big);
+    if (w->pin) hipHostFree(w->pin);
     if (w->stage) hipFree(w->stage);
     if (w->h_retry) hipHostFree(w->h_retry);
     for (auto& t : w->ev) for (auto& e : t) if (e) hipEventDestroy(e);
@@ -312,6 +315,53 @@ static int make_geometry(const DeviceState* d, const FlatIndex& ix, const Launch
     return SRN_OK;
 }
 
+// Latency path: a handful of evolving sessions on host pointers (srn_predict: the reference's call shape, one session per call).
+// No copies, no memsets, no events: the queries are written into pinned, device-mapped memory that the kernels read directly, the
+// results come back the same way; two launches (prep kernel + general kernel, one workgroup per query) and one stream synchronise.
+// Returns 1 if a query needs the global-table pass (the caller then takes the normal path).
+static int device_predict_tiny(DeviceState* d, Workspace* w, const Geometry& geo, LaunchParams p, const uint64_t* h_items, const uint32_t* h_qoff,
+                               uint64_t* h_ids, double* h_scores, uint32_t* h_counts) {
+    const size_t nitems = h_qoff[p.nq], n_out = (size_t)p.nq * p.how_many;
+    size_t off = 0; auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 63) / 64 * 64; return o; };
+    const size_t o_items = take(nitems * 8), o_qoff = take(((size_t)p.nq + 1) * 4), o_ids = take(n_out * 8), o_sc = take(n_out * 8), o_cnt = take((size_t)p.nq * 4),
+                 o_rc = take(4), o_rl = take((size_t)p.nq * 4 + 4);
+    if (w->pin_bytes < off) {
+        if (w->pin) HIP_TRY(hipHostFree(w->pin));
+        w->pin = nullptr; w->pin_bytes = 0;
+        const size_t want = std::max<size_t>(off * 2, 64 * 1024);
+        HIP_TRY(hipHostMalloc((void**)&w->pin, want, hipHostMallocMapped));
+        w->pin_bytes = want;
+    }
+    char* dp = nullptr; HIP_TRY(hipHostGetDevicePointer((void**)&dp, w->pin, 0));
+    memcpy(w->pin + o_items, h_items, nitems * 8); memcpy(w->pin + o_qoff, h_qoff, ((size_t)p.nq + 1) * 4);
+    *(volatile uint32_t*)(w->pin + o_rc) = 0;
+    p.items_flat = (const uint64_t*)(dp + o_items); p.q_off = (const uint32_t*)(dp + o_qoff);
+    p.out_ids = (uint64_t*)(dp + o_ids); p.out_scores = (double*)(dp + o_sc); p.out_counts = (uint32_t*)(dp + o_cnt);
+    p.stats = nullptr; p.nb_rank = p.nb_num = p.nb_cnt = nullptr; p.phase_cycles = nullptr;
+    hipStream_t st = w->stream;
+    { int rc = ensure(&w->spill, &w->spill_bytes, (size_t)p.nq * p.k * geo.slot_bytes); if (rc) return rc; }
+    const uint32_t prep_stride = (uint32_t)(sizeof(PrepHead) + (size_t)p.max_len * sizeof(PrepItem));
+    { int rc = ensure(&w->prep, &w->prep_bytes, (size_t)p.nq * prep_stride); if (rc) return rc; }
+    HIP_TRY(launch_prep(st, d->di, p.items_flat, p.q_off, p.nq, p.m, p.max_len, w->prep, prep_stride));
+    p.prep = w->prep; p.prep_stride = prep_stride;
+    HIP_TRY(launch_predict(geo.masks, geo.slot64, false, 0, dim3(p.nq), geo.lds, st, d->di, p, geo.c, nullptr, nullptr, (uint32_t*)(dp + o_rl), (uint32_t*)(dp + o_rc), nullptr, 0,
+                           w->spill, ShardIO{}));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (*(volatile uint32_t*)(w->pin + o_rc) != 0) return 1;   // (rare: tables too small for some query)
+    const uint64_t* r_ids = (const uint64_t*)(w->pin + o_ids); const double* r_sc = (const double*)(w->pin + o_sc); const uint32_t* r_cnt = (const uint32_t*)(w->pin + o_cnt);
+    for (uint32_t q = 0; q < p.nq; ++q) {
+        const uint32_t n = r_cnt[q] == 0xFFFFFFFFu ? 0u : std::min<uint32_t>(r_cnt[q], p.how_many);
+        h_counts[q] = r_cnt[q];
+        memcpy(h_ids + (size_t)q * p.how_many, r_ids + (size_t)q * p.how_many, (size_t)n * 8);
+        memcpy(h_scores + (size_t)q * p.how_many, r_sc + (size_t)q * p.how_many, (size_t)n * 8);
+        std::fill(h_ids + (size_t)q * p.how_many + n, h_ids + (size_t)(q + 1) * p.how_many, 0ull);      // the unused tail of each row reads as 0
+        std::fill(h_scores + (size_t)q * p.how_many + n, h_scores + (size_t)(q + 1) * p.how_many, 0.0);
+    }
+    return SRN_OK;
+}
+
+static thread_local bool t_reserve_only = false;   // device_reserve: size the workspace of a call, launch nothing
+
 int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in, bool on_device, void* user_stream,
                    const uint64_t* h_items, const uint32_t* h_qoff, uint64_t* h_ids, double* h_scores, uint32_t* h_counts,
                    uint32_t* h_stats, uint32_t* h_nb_rank, uint32_t* h_nb_num, uint32_t* h_nb_cnt) {
@@ -330,6 +380,10 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     const uint64_t need_sess = geo.need_sess, need_item = geo.need_item;
     const bool may_overflow = geo.sess_may_overflow || geo.item_may_overflow;
 
+    if (!on_device && p.nq <= 16 && !h_stats && !h_nb_rank && !d->phase_on && !knobs().dense) {
+        const int rc = device_predict_tiny(d, w, geo, p, h_items, h_qoff, h_ids, h_scores, h_counts);
+        if (rc != 1) return rc;   // (1: some query needs the global-table pass -- the normal path below has it)
+    }
     // ---- buffers -----------------------------------------------------------------------
     const size_t n_out = (size_t)p.nq * p.how_many;
     size_t nitems = 0;
@@ -390,6 +444,16 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     char* spill = w->spill;
     const uint32_t prep_stride = (uint32_t)(sizeof(PrepHead) + (size_t)p.max_len * sizeof(PrepItem));
     { int rc = ensure(&w->prep, &w->prep_bytes, (size_t)p.nq * prep_stride); if (rc) return rc; }
+    const bool fast = d->fast.row_packed != nullptr && geo.masks && !slot64 && kn.geometry_default() && !kn.no_fast && p.k <= F_K_MAX && p.m <= F_M_MAX &&
+                      p.how_many <= 24 && p.flags == 0 && p.stats == nullptr && p.nb_rank == nullptr && p.max_len <= 8 && c.num_bits <= 8;
+    if (fast) {   // (all allocations of a call happen before its first launch)
+        if (w->slow_cap < p.nq) { if (w->slow_list) HIP_TRY(hipFree(w->slow_list)); w->slow_list = nullptr; w->slow_cap = 0;
+            HIP_TRY(hipMalloc((void**)&w->slow_list, (size_t)p.nq * 4 + 64)); w->slow_cap = p.nq; }
+        { int rc = ensure(&w->fin, &w->fin_bytes, (size_t)p.nq * F_FIN_BYTES + 1024); if (rc) return rc; }   // one record per query for vmis_finish_kernel
+        const uint64_t big_entries = std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)p.nq * 16 + 4096);
+        { int rc = ensure(&w->big, &w->big_bytes, big_entries * 16 + (size_t)p.nq * 4 + 64); if (rc) return rc; }
+    }
+    if (t_reserve_only) return SRN_OK;
     hipEvent_t* ev = w->ev[w->calls % Workspace::RING];
     HIP_TRY(hipEventRecord(ev[0], st));
     HIP_TRY(launch_prep(st, d->di, p.items_flat, p.q_off, p.nq, p.m, p.max_len, w->prep, prep_stride));
@@ -398,18 +462,10 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     const uint32_t* final_list = w->retry_list; uint32_t* final_cnt = w->retry_cnt;
     // The fast kernel (srn_fast.hip) serves the common query shape; what it cannot take -- decided per query, on the device -- is
     // queued on slow_list and served by the general kernel right behind it.
-    const bool fast = d->fast.row_packed != nullptr && geo.masks && !slot64 && kn.geometry_default() && !kn.no_fast && p.k <= F_K_MAX && p.m <= F_M_MAX &&
-                      p.how_many <= 24 && p.flags == 0 && p.stats == nullptr && p.nb_rank == nullptr && p.max_len <= 8 && c.num_bits <= 8;
     if (fast) {
-        if (w->slow_cap < p.nq) { if (w->slow_list) HIP_TRY(hipFree(w->slow_list)); w->slow_list = nullptr; w->slow_cap = 0;
-            HIP_TRY(hipMalloc((void**)&w->slow_list, (size_t)p.nq * 4 + 64)); w->slow_cap = p.nq; }
-        HIP_TRY(hipMemsetAsync(w->slow_cnt, 0, 4, st));
+        HIP_TRY(hipMemsetAsync(w->slow_cnt, 0, 16, st));   // (slow_cnt[0] = handed-over queries, [2..3] = the 64-bit ticket of vmis_finish_big_kernel's list)
         const uint32_t grid_f = (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * F_WG_PER_CU * grid_mult);
-        { int rc = ensure(&w->fin, &w->fin_bytes, (size_t)p.nq * F_FIN_BYTES + 1024); if (rc) return rc; }   // one record per query for vmis_finish_kernel
-        // queries with more than 63 entries: a list + an overflow arena (room for 1/8 of the queries at 128 entries each; what finds no room goes to the general kernel)
         const uint64_t big_entries = std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)p.nq * 16 + 4096);
-        { int rc = ensure(&w->big, &w->big_bytes, big_entries * 16 + (size_t)p.nq * 4 + 64); if (rc) return rc; }
-        HIP_TRY(hipMemsetAsync(w->slow_cnt + 2, 0, 8, st));   // (slow_cnt[2..3] = the 64-bit ticket)
         FastParams fp = d->fast; fp.slow_list = w->slow_list; fp.slow_cnt = w->slow_cnt; fp.nb = c.num_bits; fp.fin = w->fin;
         fp.big_arena = w->big; fp.big_list = (uint32_t*)(w->big + big_entries * 16); fp.big_ticket = (unsigned long long*)(w->slow_cnt + 2); fp.big_cap_entries = (uint32_t)big_entries;
         HIP_TRY(launch_fast(dim3(grid_f), st, d->di, p, fp));
@@ -494,6 +550,15 @@ int device_last_kernel_ms(DeviceState* d, double* ms_main, double* ms_retry, uin
 }
 
 // how the last call's queries were served: by the fast kernel / handed to the general kernel / through the global-table pass
+// Sizes the workspace bound to `stream` for device-pointer calls of up to nq queries with these parameters, so that
+// srn_predict_batch_device allocates nothing (hipMalloc / hipFree synchronise the device) once traffic starts.
+int device_reserve(DeviceState* d, const FlatIndex& ix, const LaunchParams& p, void* stream) {
+    t_reserve_only = true;
+    const int rc = device_predict(d, ix, p, true, stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    t_reserve_only = false;
+    return rc;
+}
+
 int device_last_path_counts(DeviceState* d, uint32_t* nq, uint32_t* general, uint32_t* global_pass) {
     HIP_TRY(hipSetDevice(d->device));
     Workspace* w;

@@ -182,6 +182,12 @@ def predict_batch_debug(index, sessions, k, m, how_many, enable_business_logic=F
     return dict(ids=ids, scores=sc, counts=cnt, stats=stats, nb_sessions=nb_s, nb_num=nb_n, nb_counts=nb_c)
 
 
+def reserve(index, nq, max_len, k, m, how_many, enable_business_logic=False, stream=0):
+    """srn_index_reserve: size the workspace bound to `stream` so that predict_batch_device calls of up to nq queries allocate nothing."""
+    capi.check(capi.lib().srn_index_reserve(index._h, int(nq), int(max_len), int(k), int(m), int(how_many),
+                                            capi.FLAG_BUSINESS_LOGIC if enable_business_logic else 0, C.c_void_p(stream)))
+
+
 def predict_batch_device(index, d_items_flat, d_q_off, nq, max_len, k, m, how_many, enable_business_logic,
                          d_out_ids, d_out_scores, d_out_counts, stream=0):
     """Device-resident variant: arguments are raw device addresses (e.g. torch.Tensor.data_ptr()) on the

@@ -257,6 +257,7 @@ def test_device_pointer_entry_point_matches_host_entry_point():
     d_sc = torch.zeros(len(qs) * n, dtype=torch.float64, device=dev)
     d_cnt = torch.zeros(len(qs), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream()
+    sa.reserve(gix, 4 * len(qs), 5, k, m, n, False, stream.cuda_stream)          # the workspace of this stream is sized up front: the call below allocates nothing
     sa.predict_batch_device(gix, d_flat.data_ptr(), d_off.data_ptr(), len(qs), 5, k, m, n, False,
                             d_ids.data_ptr(), d_sc.data_ptr(), d_cnt.data_ptr(), stream.cuda_stream)
     stream.synchronize()
