@@ -104,10 +104,13 @@ __global__ __launch_bounds__(1024) void rows_to_packed_kernel(const uint64_t* __
 // A thread's binary search on its diagonal costs ~11 round trips whatever g is, so a pair is merged by only as many waves as give
 // every thread ~8 outputs (merge_team): the searches of the other waves would be pure overhead.
 // -------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t merge_team(uint32_t total) { return min(512u, max(64u, (((total + 7u) >> 3) + 63u) & ~63u)); }
-__device__ __forceinline__ void merge_pair(const uint32_t* in, uint32_t* out, uint32_t sa, uint32_t la, uint32_t lb, uint32_t ttid, uint32_t nthr) {
-    if (ttid >= nthr) return;   // (whole waves)
-    const uint32_t sb = sa + la, total = la + lb, g = (total + nthr - 1u) / nthr;
+__device__ __forceinline__ uint32_t merge_team(uint32_t total) {   // log2 of the team size: 64 .. 512 threads, >= total / 8
+    const uint32_t want = (total + 7u) >> 3;
+    return want <= 64u ? 6u : want <= 128u ? 7u : want <= 256u ? 8u : 9u;
+}
+__device__ __forceinline__ void merge_pair(const uint32_t* in, uint32_t* out, uint32_t sa, uint32_t la, uint32_t lb, uint32_t ttid, uint32_t lg_nthr) {
+    if ((ttid >> lg_nthr) != 0u) return;   // (whole waves)
+    const uint32_t sb = sa + la, total = la + lb, g = (total + (1u << lg_nthr) - 1u) >> lg_nthr;
     const uint32_t d0 = min(ttid * g, total), d1 = min(d0 + g, total);
     if (d0 >= d1) return;
     uint32_t lo = d0 > lb ? d0 - lb : 0u, hi = min(d0, la);
@@ -115,16 +118,19 @@ __device__ __forceinline__ void merge_pair(const uint32_t* in, uint32_t* out, ui
         const uint32_t mid = (lo + hi) >> 1;
         if (in[sa + mid] > in[sb + d0 - 1 - mid]) lo = mid + 1; else hi = mid;
     }
-    uint32_t i = lo, j = d0 - lo;
-    uint32_t va = i < la ? in[sa + i] : 0u, vb = j < lb ? in[sb + j] : 0u;   // (a staged slot is never 0)
-    uint32_t* C = out + sa;
-    for (uint32_t o = d0; o < d1; ++o) {
+    // sequential steps on two read pointers: one compare, one max, one dependent LDS read per output (12 VALU instructions; the index
+    // form with its per-step bound checks on both runs compiled to ~20)
+    const uint32_t* pa = in + sa + lo; const uint32_t* pb = in + sb + (d0 - lo);
+    const uint32_t* const ea = in + sb; const uint32_t* const eb = in + sb + lb;
+    uint32_t va = pa < ea ? *pa : 0u, vb = pb < eb ? *pb : 0u;   // (a staged slot is never 0)
+    uint32_t* c = out + sa + d0; uint32_t* const ce = out + sa + d1;
+    for (; c < ce; ++c) {
         const bool ta = va > vb;
-        C[o] = ta ? va : vb;
-        i += ta; j += !ta;
-        const bool more = ta ? i < la : j < lb;
-        const uint32_t nxt = in[ta ? sa + i : sb + j];   // (past a run's end: a neighbour's entry or scratch, discarded)
-        const uint32_t nv = more ? nxt : 0u;
+        *c = max(va, vb);
+        const uint32_t* q = (ta ? pa : pb) + 1;
+        pa = ta ? q : pa; pb = ta ? pb : q;
+        const uint32_t nxt = *q;   // (past a run's end: a neighbour's entry or scratch, discarded)
+        const uint32_t nv = q < (ta ? ea : eb) ? nxt : 0u;
         va = ta ? nv : va; vb = ta ? vb : nv;
     }
 }
@@ -219,6 +225,16 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             const uint32_t mp = tid ? (uint32_t)__ffs((int)tid) - 1u : 0u;   // lowest set position = first match (Q4)
             wlut[tid] = (uint8_t)num; w10t[tid] = (uint16_t)((9u - mp) * num);
         }
+        uint32_t K;
+        if (nr == 1u) {
+            // ONE list (a quarter of the queries): its entries are distinct sessions in recency order, all of one numerator class -- the candidates are
+            // its first min(n, m) entries, the neighbours the first k of those.  No merge, no m-cut, no k-cut: the list goes straight into the neighbour list.
+            K = min(kp[0], p.k);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { const uint32_t e = tid + j * BLOCK; if ((uint32_t)j * BLOCK < K && e < K) nbl[e] = (v[0][j] << NB) | (1u << ps[0]); }
+            __syncthreads();
+            FAST_TICK(1);
+        } else {
         // ---- phase 1: stage the lists' kept prefixes as packed slots (rank << NB | position bit) ---------
         uint32_t* const B0 = (uint32_t*)(smem + F_WORK); uint32_t* const B1 = B0 + n;
         const uint32_t nl = (nr > 1u) + (nr > 2u);
@@ -318,7 +334,9 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             for (int x = 0; x < 5; ++x) if (take[x]) nbl[at++] = dv[x];
         }
         __syncthreads();
-        const uint32_t K = misc[FS_NB];
+        K = misc[FS_NB];
+        }
+
         FAST_TICK(4);
 
         // ---- walk A: one neighbour row per lane, the first 32 bytes (14 items) of all the wave's rows requested at once ---------
