@@ -30,7 +30,7 @@
 namespace srn {
 
 // scalar words at the head of LDS
-enum { FS_NB = 0, FS_FAIL, FS_SURV, FS_CCNT, FS_HITS, FS_SCAN_A = 8, FS_SCAN_B = 8, FS_W3 = 8, FS_CLS = 16, FS_TACC = 32 };   // (the three scratch areas are never live together; words 32..63: debug counters)
+enum { FS_NB = 0, FS_FAIL, FS_SURV, FS_CCNT, FS_HITS, FS_LIVE, FS_SCAN_A = 8, FS_SCAN_B = 8, FS_W3 = 8, FS_CLS = 16, FS_TACC = 32 };   // (the three scratch areas are never live together; words 32..63: debug counters)
 static constexpr uint32_t F_TOTAL = F_LDS_BYTES;
 static constexpr uint32_t F_MERGE_WORDS = F_WORK_WORDS;
 
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         const uint32_t nr = (uint32_t)__popcll(rm);
         const bool fits = L >= 1u && L <= 8u && L <= p.max_len && hd.sumw <= 15u && nr <= 4u && 2u * n + 8u <= F_MERGE_WORDS;
         if (!fits) {   // block-uniform: the general kernel takes it
-            if (tid == 0) { f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q; if (ticking) tacc[3] += 1ull; }
+            if (tid == 0) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q;
             continue;
         }
         if (n == 0u) { if (tid == 0) p.out_counts[q] = 0u; continue; }   // no known item (vmis_index.rs:350): empty result
@@ -491,6 +491,17 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
                 if (take) { if (at < F_CAND_CAP) { ckey[at] = (unsigned long long)__double_as_longlong(x); cidx[at] = mt.id_rank; } else misc[FS_FAIL] = 1; }
             }
         }
+        // Is any sketch word at the floor at all?  (config 3: for 84 % of the queries none is -- no item outside the direct-mapped range can
+        // make the top n -- and walk B, the resolve pass and the table scan are skipped: one 16-byte read and a v_max3 per 4 words.)
+        {
+            const uint4* sk4 = reinterpret_cast<const uint4*>(smem + F_SKETCH);
+            uint32_t mx = 0;
+            for (uint32_t i = tid; i < F_SK_WORDS / 4u; i += BLOCK) { const uint4 w4 = sk4[i]; mx = max(max(mx, w4.x), max(max(w4.y, w4.z), w4.w)); }
+            if (__ballot(mx >= floor_b) != 0ull && lane == 0u) misc[FS_LIVE] = 1u;
+        }
+        __syncthreads();
+        const bool live = misc[FS_LIVE] != 0u;   // block-uniform
+        if (live) {
         // ---- walk B: an element reaches the exact table only if its sketch word can still reach the floor -----------
         // (all elements of an item share the word, so an item is accumulated completely or not at all; the accumulator words of
         // the popular items read 0 by now; a dump word that happens to reach the floor belongs to a position past its row's end).
@@ -577,6 +588,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         {   // resolve the listed elements: item id from the general row slot (its word 0 = the row's length: a position past the
             // end was a dump word), weight from the slot's position set, exact sums in the table
             const uint32_t nh = min(misc[FS_HITS], F_HIT_CAP);
+            if (ticking && tid == 0 && nh == 0u) tacc[7] += 1ull;
             bool ovf = false;
             for (uint32_t i = tid; i < nh; i += BLOCK) {
                 const uint2 h = hits[i];
@@ -589,6 +601,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             if (ovf) atomicOr(&misc[FS_FAIL], 8u);
         }
         __syncthreads();
+        }
         FAST_TICK(12);
         if (misc[FS_FAIL]) {   // block-uniform
             if (tid == 0) { f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q; if (ticking) { const uint32_t c = misc[FS_FAIL]; tacc[15] += (c & 1u) + ((unsigned long long)((c >> 1) & 1u) << 16) + ((unsigned long long)((c >> 2) & 1u) << 32) + ((unsigned long long)((c >> 3) & 1u) << 48); } }
@@ -606,6 +619,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         const unsigned long long ltl = (1ull << ln) - 1ull;
         uint2* tl = hits;   // (the hit list is dead)
         uint32_t nt = 0;
+        if (live)
 #pragma unroll
         for (uint32_t b0 = 0; b0 < (F_TABLE_BUCKETS + 63u) / 64u; ++b0) {
             const uint32_t bk = b0 * 64u + ln;
@@ -649,7 +663,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
                 if (i < F_FIN_ENTRIES) rec[1 + i] = e; else ovf[i - F_FIN_ENTRIES] = e;
             }
         }
-        if (ticking && ln == 0u) { tacc[6] += cnt; tacc[7] += nt; tacc[14] += 1ull; }
+        if (ticking && ln == 0u) { tacc[6] += cnt; tacc[14] += 1ull; }
         FAST_TICK(13);
     }
     if (ticking) { __syncthreads(); if (tid < 16u && tacc[tid]) atomicAdd(&p.phase_cycles[tid], tacc[tid]); }

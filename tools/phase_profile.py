@@ -28,7 +28,8 @@ print("main %.2f ms retry %.2f ms  total cycles %.3g" % (ms, msr, cyc.sum()))
 for n, c in zip(names, cyc):
     print("  %-18s %6.2f%%  %.0f cyc/query" % (n, 100 * c / cyc.sum(), c / B))
 c15 = int(cyc[15])
-print("handed over: shape does not fit %d | candidate list %d, floor survivors %d, hit list %d, exact table %d" % (cyc[3], c15 & 0xFFFF, (c15 >> 16) & 0xFFFF, (c15 >> 32) & 0xFFFF, (c15 >> 48) & 0xFFFF))
+print("queries whose walk B listed nothing: %d" % cyc[7])
+print("handed over after a list overflowed: candidate list %d, floor survivors %d, hit list %d, exact table %d" % (c15 & 0xFFFF, (c15 >> 16) & 0xFFFF, (c15 >> 32) & 0xFFFF, (c15 >> 48) & 0xFFFF))
 if cyc[14]:
     print("fast kernel: queries %d, walk-B hit elements/query %.1f, candidates/query %.1f, floor survivors/query %.1f" % (cyc[14], cyc[5] / cyc[14], cyc[6] / cyc[14], cyc[7] / cyc[14]))
 st = r["stats"].astype(np.float64)
