@@ -27,11 +27,16 @@ int check_predict_args(const srn_index_t* idx, size_t k, size_t m, size_t how_ma
     if (m > 0x7FFFFFFFull) return fail(SRN_ERANGE, "m too large");
     return SRN_OK;
 }
+// an item shard answers only through the three stages: its rows are fragments (DeviceIndex::row_frag) and its lists a subset
+static int check_not_a_shard(const srn_index_t* idx) {
+    return idx && idx->flat.n_shards > 1 ? fail(SRN_EINVAL, "this index is one item shard of several: predictions go through srn_shard_stage_a/b/c") : SRN_OK;
+}
 
 int predict_host(const srn_index_t* idx, const uint64_t* items_flat, const uint32_t* q_off, size_t nq, size_t k, size_t m,
                  size_t how_many, unsigned flags, uint64_t* out_ids, double* out_scores, uint32_t* out_counts,
                  uint32_t* out_stats, uint32_t* out_nb_sessions, uint32_t* out_nb_num, uint32_t* out_nb_counts) {
     int rc = check_predict_args(idx, k, m, how_many); if (rc) return rc;
+    rc = check_not_a_shard(idx); if (rc) return rc;
     if (nq == 0) return SRN_OK;
     if (!items_flat || !q_off || !out_ids || !out_scores || !out_counts) return fail(SRN_EINVAL, "null buffer");
     if (nq > 0x7FFFFFFFull) return fail(SRN_ERANGE, "too many queries in one batch");
@@ -219,6 +224,7 @@ int srn_predict_batch_device(const srn_index_t* idx, const uint64_t* d_items_fla
                              double* d_out_scores, uint32_t* d_out_counts, void* stream) {
     return guarded([&]() -> int {
         int rc = check_predict_args(idx, k, m, how_many); if (rc) return rc;
+        rc = check_not_a_shard(idx); if (rc) return rc;
         if (nq == 0) return SRN_OK;
         if (!d_items_flat || !d_q_off || !d_out_ids || !d_out_scores || !d_out_counts) return fail(SRN_EINVAL, "null buffer");
         if (nq > 0x7FFFFFFFull) return fail(SRN_ERANGE, "too many queries in one batch");

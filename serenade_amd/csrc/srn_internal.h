@@ -91,6 +91,8 @@ struct DeviceIndex {  // pointers into HBM; passed by value to the kernels
     const RowQuad* row_slots;   // 4 quads per slot
     const uint32_t* row_ext;
     uint32_t n_items, n_kept;
+    uint32_t row_frag;       // item shards (n_shards > 1): row_slots holds 16-byte FRAGMENT slots instead -- {len, i0, i1, i2}, or {len, offset in row_ext, i0, i1} with
+                             // items 2.. in row_ext when the fragment has > 3 items: a shard sees ~len / n_shards items of a row, so its row memory is 16 B per session, not 64
     double idf_hi, idf_lo;   // max / min over items of (idf > 0 ? idf : 1)
 };
 

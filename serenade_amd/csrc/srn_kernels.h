@@ -83,6 +83,8 @@ hipError_t launch_finish(hipStream_t st, const DeviceIndex& di, const FastParams
 hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f);
 hipError_t launch_rows_to_packed(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base,
                                  uint32_t* packed, uint32_t* ext16);   // grid = ceil((n_rows + 1) / 1024) blocks of 1024; block_base in 16-byte blocks
+hipError_t launch_rows_to_frags(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base,
+                                uint32_t* slots, uint32_t* ext);   // 16-byte fragment slots of an item shard; block_base in items
 hipError_t launch_rows_to_slots(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base,
                                 uint32_t* slots, uint32_t* ext);   // grid = ceil((n_rows + 1) / 1024) blocks of 1024
 

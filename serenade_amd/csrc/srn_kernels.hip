@@ -342,6 +342,29 @@ __global__ __launch_bounds__(1024) void rows_to_slots_kernel(const uint64_t* __r
     for (int qd = 0; qd < 4; ++qd) dst[qd] = make_uint4(sl[4 * qd], sl[4 * qd + 1], sl[4 * qd + 2], sl[4 * qd + 3]);
 }
 
+// the same for an item shard's row FRAGMENTS: 16-byte slots {len, i0, i1, i2}; > 3 items: {len, offset of items 2.. in ext, i0, i1}
+__global__ __launch_bounds__(1024) void rows_to_frags_kernel(const uint64_t* __restrict__ row_off, const uint32_t* __restrict__ row_items, uint64_t n,
+                                                             const uint32_t* __restrict__ block_base, uint32_t* __restrict__ slots, uint32_t* __restrict__ ext) {
+    __shared__ uint32_t wave_tot[16];
+    const uint64_t r = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t o = 0, len = 0;
+    if (r < n) { o = row_off[r]; len = row_off[r + 1] - o; }
+    const uint32_t e = len > 3 ? (uint32_t)(len - 2) : 0u;
+    const uint32_t inc = wave_incl_scan(e);
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t base = block_base[blockIdx.x];
+    for (int w = 0; w < wave; ++w) base += wave_tot[w];
+    const uint32_t eoff = base + inc - e;
+    if (r > n) return;
+    uint32_t sl[4] = {(uint32_t)len, EMPTY32, EMPTY32, EMPTY32};   // (0 items for the empty row r == n)
+    if (len <= 3) { for (uint32_t i = 0; i < (uint32_t)len; ++i) sl[1 + i] = row_items[o + i]; }
+    else { sl[1] = eoff; sl[2] = row_items[o]; sl[3] = row_items[o + 1];
+           for (uint64_t i = 2; i < len; ++i) ext[eoff + (i - 2)] = row_items[o + i]; }
+    reinterpret_cast<uint4*>(slots)[r] = make_uint4(sl[0], sl[1], sl[2], sl[3]);
+}
+
 // -------------------------------------------------------------------------------------
 // Prep kernel: one thread per evolving session does the dependent look-ups of phase 0 (public id -> dense idx ->
 // posting list bounds -> first / m-th rank) so that the main kernel, where a whole workgroup would wait on that
@@ -1057,36 +1080,43 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
                 return j < K ? (size_t)(uint32_t)(s >> NB) : (size_t)n_kept; };
             constexpr uint32_t GSTEP = NWAVES * 64;
             uint32_t num, nnum;
+            // Item shards keep 16-byte FRAGMENT slots (DeviceIndex::row_frag): one quad {len, i0, i1, i2}, or {len, offset, i0, i1} + items 2.. in row_ext.
+            // They walk through the same code as a 64-byte slot whose words 4..15 are empty: `inl` items inline before the overflow area.
+            const bool frag = ix.row_frag != 0u;   // (launch-uniform)
+            const uint32_t qs = frag ? 1u : 4u, inl = frag ? 2u : 14u;
+            const RowQuad EQ{EMPTY32, EMPTY32, EMPTY32, EMPTY32};
             size_t r = slot_of(wave * 64 + lane, num), nr;
-            RowQuad a = ix.row_slots[4 * r], b = ix.row_slots[4 * r + 1], na, nb;
+            RowQuad a = ix.row_slots[qs * r], b = frag ? EQ : ix.row_slots[4 * r + 1], na, nb;
             for (uint32_t g0 = wave * 64; g0 < K; g0 += GSTEP) {
                 // unused slot words are EMPTY32 in memory, so only a long row's word 1 (its overflow offset) needs masking;
                 // short rows read the EMPTY32 words at the start of row_ext
                 const uint32_t len = a.x;
-                const bool big = len > 15;                       // word 1 = offset of items 14.. in row_ext, items 0..13 in words 2..15
-                const RowQuad c4 = ix.row_slots[4 * r + 2], d4 = ix.row_slots[4 * r + 3];
+                const bool big = len > inl + 1u;                 // word 1 = offset of items inl.. in row_ext, items 0..inl-1 in the words from 2 on
+                const RowQuad c4 = frag ? EQ : ix.row_slots[4 * r + 2], d4 = frag ? EQ : ix.row_slots[4 * r + 3];
                 const uint32_t* ext = ix.row_ext + (big ? a.y : 0u);
                 const RowVec e0 = *reinterpret_cast<const RowVec*>(ext), e1 = *reinterpret_cast<const RowVec*>(ext + 4);
                 nr = slot_of(g0 + GSTEP + lane, nnum);
-                na = ix.row_slots[4 * nr]; nb = ix.row_slots[4 * nr + 1];
+                na = ix.row_slots[qs * nr]; nb = frag ? EQ : ix.row_slots[4 * nr + 1];
                 isum += len;
                 auto for_row = [&](auto&& g8) {
                     { const uint32_t it7[7] = {big ? EMPTY32 : a.y, a.z, a.w, b.x, b.y, b.z, b.w};   // words 1..7
                       g8(it7); }
-                    if (__ballot(len > 7) == 0ull) return;
                     uint32_t it[8];
-                    it[0] = c4.x; it[1] = c4.y; it[2] = c4.z; it[3] = c4.w; it[4] = d4.x; it[5] = d4.y; it[6] = d4.z; it[7] = d4.w;   // words 8..15
-                    g8(it);
+                    if (!frag) {
+                        if (__ballot(len > 7) == 0ull) return;
+                        it[0] = c4.x; it[1] = c4.y; it[2] = c4.z; it[3] = c4.w; it[4] = d4.x; it[5] = d4.y; it[6] = d4.z; it[7] = d4.w;   // words 8..15
+                        g8(it);
+                    }
                     if (__ballot(big) == 0ull) return;
-                    it[0] = e0.x; it[1] = e0.y; it[2] = e0.z; it[3] = e0.w; it[4] = e1.x; it[5] = e1.y; it[6] = e1.z; it[7] = e1.w;   // items 14..21
+                    it[0] = e0.x; it[1] = e0.y; it[2] = e0.z; it[3] = e0.w; it[4] = e1.x; it[5] = e1.y; it[6] = e1.z; it[7] = e1.w;   // items inl .. inl + 7
 #pragma unroll
-                    for (uint32_t x = 0; x < 8; ++x) if (!big || 14 + x >= len) it[x] = EMPTY32;
+                    for (uint32_t x = 0; x < 8; ++x) if (!big || inl + x >= len) it[x] = EMPTY32;
                     g8(it);
-                    for (uint32_t t = 22; __ballot(big && t < len) != 0ull; t += 8) {
+                    for (uint32_t t = inl + 8u; __ballot(big && t < len) != 0ull; t += 8) {
 #pragma unroll
                         for (int x = 0; x < 8; ++x) it[x] = EMPTY32;
-                        if (big && t < len) { const RowVec v = *reinterpret_cast<const RowVec*>(ext + (t - 14)); it[0] = v.x; it[1] = v.y; it[2] = v.z; it[3] = v.w; }
-                        if (big && t + 4 < len) { const RowVec v = *reinterpret_cast<const RowVec*>(ext + (t - 14) + 4); it[4] = v.x; it[5] = v.y; it[6] = v.z; it[7] = v.w; }
+                        if (big && t < len) { const RowVec v = *reinterpret_cast<const RowVec*>(ext + (t - inl)); it[0] = v.x; it[1] = v.y; it[2] = v.z; it[3] = v.w; }
+                        if (big && t + 4 < len) { const RowVec v = *reinterpret_cast<const RowVec*>(ext + (t - inl) + 4); it[4] = v.x; it[5] = v.y; it[6] = v.z; it[7] = v.w; }
 #pragma unroll
                         for (uint32_t x = 1; x < 8; ++x) if (t + x >= len) it[x] = EMPTY32;
                         g8(it);
@@ -1533,6 +1563,12 @@ hipError_t launch_predict(bool masks, bool slot64, bool global_tables, int stage
 hipError_t launch_prep(hipStream_t st, const DeviceIndex& di, const uint64_t* items_flat, const uint32_t* q_off, uint32_t nq, uint32_t m,
                        uint32_t max_len, char* out, uint32_t stride) {
     hipLaunchKernelGGL(vmis_prep_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, di, items_flat, q_off, nq, m, max_len, out, stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_rows_to_frags(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base,
+                                uint32_t* slots, uint32_t* ext) {
+    hipLaunchKernelGGL(rows_to_frags_kernel, dim3((unsigned)((n_rows + 1 + 1023) / 1024)), dim3(1024), 0, st, row_off, row_items, n_rows, block_base, slots, ext);
     return hipGetLastError();
 }
 

@@ -107,24 +107,29 @@ DeviceState* device_attach(const FlatIndex& ix, int device) {
       d->fast.meta_sample = upload(d, ms, ok); }
     d->di.post_off = upload(d, ix.post_off, ok); d->di.post_rank = upload(d, ix.post_rank, ok);
     if (ok) {   // rows -> 64-byte slots (+ overflow area) on the device, see DeviceIndex and rows_to_slots_kernel
+        // item shards: 16-byte FRAGMENT slots (a shard holds ~1/n_shards of a row's items), DeviceIndex::row_frag
+        const bool frag = ix.n_shards > 1;
+        const uint64_t inl = frag ? 2 : 14;            // items inline in a slot that also carries an overflow offset
+        const size_t slot_bytes = frag ? 16 : 64;
         const size_t n = ix.n_kept, nblocks = (n + 1 + 1023) / 1024;
         std::vector<uint32_t> block_base(nblocks);
         uint64_t ext_total = 16;   // ext[0..15] = EMPTY32: what short rows read
         for (size_t b0 = 0; b0 < nblocks; ++b0) {
             block_base[b0] = (uint32_t)ext_total;
             const size_t hi = std::min(n, (b0 + 1) * 1024);
-            for (size_t r = b0 * 1024; r < hi; ++r) { const uint64_t len = ix.row_off[r + 1] - ix.row_off[r]; if (len > 15) ext_total += len - 14; }
+            for (size_t r = b0 * 1024; r < hi; ++r) { const uint64_t len = ix.row_off[r + 1] - ix.row_off[r]; if (len > inl + 1) ext_total += len - inl; }
             if (ext_total >= 0xFFFFFFF0ull) { set_error("row overflow area exceeds 2^32 items"); device_release(d); return nullptr; }
         }
         void *d_off = nullptr, *d_items = nullptr, *d_base = nullptr, *d_slots = nullptr, *d_ext = nullptr;
         const size_t ext_words = ext_total + 16;   // (4-item loads may run past the last row)
         bool good = hipMalloc(&d_off, (n + 1) * 8) == hipSuccess && hipMalloc(&d_items, std::max<size_t>(ix.row_items.size() * 4, 16)) == hipSuccess &&
-                    hipMalloc(&d_base, nblocks * 4) == hipSuccess && hipMalloc(&d_slots, (n + 1) * 64) == hipSuccess && hipMalloc(&d_ext, ext_words * 4) == hipSuccess;
+                    hipMalloc(&d_base, nblocks * 4) == hipSuccess && hipMalloc(&d_slots, (n + 1) * slot_bytes) == hipSuccess && hipMalloc(&d_ext, ext_words * 4) == hipSuccess;
         good = good && hipMemcpy(d_off, ix.row_off.data(), (n + 1) * 8, hipMemcpyHostToDevice) == hipSuccess &&
                (ix.row_items.empty() || hipMemcpy(d_items, ix.row_items.data(), ix.row_items.size() * 4, hipMemcpyHostToDevice) == hipSuccess) &&
                hipMemcpy(d_base, block_base.data(), nblocks * 4, hipMemcpyHostToDevice) == hipSuccess &&
                hipMemset(d_ext, 0xFF, ext_words * 4) == hipSuccess;
-        good = good && launch_rows_to_slots(nullptr, (const uint64_t*)d_off, (const uint32_t*)d_items, (uint64_t)n, (const uint32_t*)d_base, (uint32_t*)d_slots, (uint32_t*)d_ext) == hipSuccess &&
+        good = good && (frag ? launch_rows_to_frags : launch_rows_to_slots)(nullptr, (const uint64_t*)d_off, (const uint32_t*)d_items, (uint64_t)n, (const uint32_t*)d_base,
+                                                                             (uint32_t*)d_slots, (uint32_t*)d_ext) == hipSuccess &&
                hipDeviceSynchronize() == hipSuccess;
         if (good && ix.n_shards == 1) {   // the fast kernel's rows: 64-byte slots of 16-bit LDS offsets (+ overflow blocks of 8 items), srn_fast.hip
             std::vector<uint32_t> bb(nblocks); uint64_t blocks = 1;   // (block 0: what a stray read finds)
@@ -144,7 +149,8 @@ DeviceState* device_attach(const FlatIndex& ix, int device) {
             else { good = false; }
         }
         if (d_off) hipFree(d_off); if (d_items) hipFree(d_items); if (d_base) hipFree(d_base);
-        if (d_slots) { d->allocs.push_back(d_slots); d->bytes += (n + 1) * 64; }
+        if (d_slots) { d->allocs.push_back(d_slots); d->bytes += (n + 1) * slot_bytes; }
+        d->di.row_frag = frag ? 1u : 0u;
         if (d_ext) { d->allocs.push_back(d_ext); d->bytes += ext_words * 4; }
         if (!good) { ok = false; set_error("row slot layout on the device failed"); }
         d->di.row_slots = (const RowQuad*)d_slots; d->di.row_ext = (const uint32_t*)d_ext;

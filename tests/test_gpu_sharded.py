@@ -50,6 +50,29 @@ def test_local_shards_match_unsharded(n_shards):
         _check(sharded.predict_batch_sharded_local(shards, d_flat, d_off, len(qs), 6, k, m, n), ref)
 
 
+def test_row_fragments_of_every_length_and_shard_row_memory():
+    """A shard keeps each session's FRAGMENT (the items it owns) in a 16-byte slot, longer fragments continue in an overflow
+    area: rows of up to 80 items over 2 and 5 shards put fragments of 0..40+ items through every branch of that walk.  The
+    shard's HBM footprint must be well under the unsharded index's 64-byte row slots, and a shard refuses plain predictions."""
+    import serenade_amd as sa
+    from serenade_amd import sharded, capi
+    off, items, ts, ids = small_dataset(57, n_sessions=3000, n_items=500, max_len=80)
+    qs = random_queries(17, ids, 300, max_len=8)
+    flat, qoff = flatten(qs)
+    d_flat, d_off = _to_dev(flat, qoff)
+    full = sa.VMISIndex.from_sessions(off, items, ts, 300, 80, 1.0)
+    for n_shards in (2, 5):
+        shards = [sharded.ShardedVMISIndex(off, items, ts, 300, 80, 1.0, g, n_shards) for g in range(n_shards)]
+        for (k, m, n) in [(100, 300, 21), (500, 500, 50)]:
+            ref = sa.predict_batch(full, (flat, qoff), k, m, n, False)
+            _check(sharded.predict_batch_sharded_local(shards, d_flat, d_off, len(qs), 8, k, m, n), ref)
+        assert max(s.info["device_bytes"] for s in shards) < full.info["device_bytes"] / 2
+        with pytest.raises(capi.SerenadeError):
+            out = np.zeros(21, np.uint64); sc = np.zeros(21); cnt = np.zeros(1, np.uint32)
+            capi.check(capi.lib().srn_predict_batch(shards[0]._h, flat.ctypes.data, qoff.ctypes.data, 1, 100, 300, 21, 0,
+                                                    out.ctypes.data, sc.ctypes.data, cnt.ctypes.data))
+
+
 def test_local_shards_business_rules_and_synthetic():
     from serenade_amd import sharded, synth
     off, items, ts, ids = small_dataset(52, n_sessions=3000, n_items=300)
