@@ -222,6 +222,36 @@ int srn_shard_stage_c(const srn_index_t* idx, const uint64_t* d_items_flat, cons
                       const uint32_t* d_nb_cnt, const int32_t* d_minpos, uint64_t* d_out_ids, double* d_out_scores,
                       uint32_t* d_out_counts, void* stream);
 
+/* ---- item-sharded index, LISTS mode: two exchanges instead of three, and the unsharded kernels between them ----
+ * The posting lists of a query are small, so the shards exchange the LISTS (their entries at or above the global cut) instead of
+ * candidates: after one all-gather every rank holds all lists of the batch and runs the unsharded kernels unchanged, scoring the
+ * items it owns from its row fragments; a last all-gather of the per-shard top-n and a merge by (score desc, id asc) finish.
+ * Valid for position-set geometry (sessions of <= 8 items, m <= m_index, complete lists) without business rules:
+ * srn_shard_lists_supported says which; everything else takes stages A/B/C above.  All buffers are device memory, all calls
+ * asynchronous on `stream`.  The sequence on every rank (serenade_amd/sharded.py predict_batch_sharded_lists):
+ *   head     -> d_pos [nq * max_len] x 16 B (this shard's view of every evolving position), d_head [nq][2] int32 = local (x_lo, r_max)
+ *   all-reduce(max) of d_head
+ *   count    -> d_kept [nq * max_len] u32 (entries >= x_lo of every owned list), d_tot [nq] int32
+ *   d_off = exclusive prefix sum of d_tot (int64) -- the host's job
+ *   copy     -> d_out[d_off[q] ...]: the query's kept list prefixes, back to back in position order
+ *   all-gather of d_kept, d_off and the flat buffers (padded to a common `shard_stride`, in entries)
+ *   predict  -> prep records against the gathered buffer (d_records: nq * srn_shard_lists_record_bytes(max_len) scratch), then the
+ *               unsharded launch sequence: per-query top-how_many among the items this shard owns
+ * Reference: the reference has no sharded mode (one VMISIndex per process, vmis_index.rs:28-35); this serves the north star's
+ * "index sharded by item id across the GPUs". */
+int srn_shard_lists_supported(const srn_index_t* idx, size_t max_len_hint, size_t k, size_t m, size_t how_many, unsigned flags, int* out);
+size_t srn_shard_lists_record_bytes(size_t max_len_hint);
+int srn_shard_lists_head(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq, size_t max_len_hint, size_t m,
+                         void* d_pos, int32_t* d_head, void* stream);
+int srn_shard_lists_count(const srn_index_t* idx, const uint32_t* d_q_off, size_t nq, size_t max_len_hint, const void* d_pos, const int32_t* d_head,
+                          uint32_t* d_kept, int32_t* d_tot, void* stream);
+int srn_shard_lists_copy(const srn_index_t* idx, size_t nq, size_t max_len_hint, const void* d_pos, const uint32_t* d_kept, const int64_t* d_off,
+                         uint32_t* d_out, void* stream);
+int srn_shard_lists_predict(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq, size_t max_len_hint, size_t k, size_t m,
+                            size_t how_many, unsigned flags, uint32_t n_shards, const uint32_t* d_kept_g, const int64_t* d_off_g, uint64_t shard_stride,
+                            const uint32_t* d_lists_g, const int32_t* d_head, const void* d_pos_local, void* d_records,
+                            uint64_t* d_out_ids, double* d_out_scores, uint32_t* d_out_counts, void* stream);
+
 /* The same for the most recent min(max_n, 64) predict calls (oldest first): per-call duration in ms of
  * the main kernel and of the retry pass, from HIP events recorded on the launch stream around each
  * launch.  This is what bench.py reports as the kernel's live-measured launch duration. */

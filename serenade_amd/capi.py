@@ -81,6 +81,12 @@ SYMBOLS = {
     "srn_shard_stage_a": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp]),
     "srn_shard_stage_b": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "srn_shard_stage_c": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, C.c_uint, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "srn_shard_lists_supported": (_i, [_vp, _sz, _sz, _sz, _sz, C.c_uint, C.POINTER(_i)]),
+    "srn_shard_lists_record_bytes": (_sz, [_sz]),
+    "srn_shard_lists_head": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp, _vp]),
+    "srn_shard_lists_count": (_i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "srn_shard_lists_copy": (_i, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "srn_shard_lists_predict": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, C.c_uint, C.c_uint32, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "srn_kernel_times": (_i, [_vp, C.c_uint32, _vp, _vp, C.POINTER(C.c_uint32)]),
     "srn_kernel_times_detail": (_i, [_vp, C.c_uint32, _vp, _vp, _vp, _vp, C.POINTER(C.c_uint32)]),
     "srn_debug_phase_cycles": (_i, [_vp, _i, _vp]),

@@ -358,6 +358,62 @@ int srn_shard_stage_c(const srn_index_t* idx, const uint64_t* d_items_flat, cons
     return shard_stage(idx, 3, d_items_flat, d_q_off, nq, max_len_hint, k, m, how_many, flags, sh, d_out_ids, d_out_scores, d_out_counts, stream);
 }
 
+// ---- item-sharded index, lists mode (srn_shard.hip) ----
+static int lists_params(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq, size_t max_len_hint, size_t k, size_t m, size_t how_many,
+                        unsigned flags, LaunchParams& p) {
+    int rc = check_predict_args(idx, k, m, how_many); if (rc) return rc;
+    if (!d_items_flat || !d_q_off) return fail(SRN_EINVAL, "null buffer");
+    if (nq > 0x7FFFFFFFull) return fail(SRN_ERANGE, "too many queries in one batch");
+    if (max_len_hint == 0 || max_len_hint > SRN_MAX_SESSION_LEN) return fail(SRN_ERANGE, "max_len_hint out of range");
+    p = LaunchParams{};
+    p.nq = (uint32_t)nq; p.k = (uint32_t)k; p.m = (uint32_t)m; p.how_many = (uint32_t)how_many; p.flags = flags; p.max_len = (uint32_t)max_len_hint;
+    p.items_flat = d_items_flat; p.q_off = d_q_off;
+    return SRN_OK;
+}
+int srn_shard_lists_supported(const srn_index_t* idx, size_t max_len_hint, size_t k, size_t m, size_t how_many, unsigned flags, int* out) {
+    if (!out) return fail(SRN_EINVAL, "null argument");
+    return guarded([&]() -> int {
+        LaunchParams p; const uint64_t dummy = 0; const uint32_t dq = 0;
+        int rc = lists_params(idx, &dummy, &dq, 1, max_len_hint, k, m, how_many, flags, p); if (rc) return rc;
+        *out = device_shard_lists_supported(idx->dev, idx->flat, p) ? 1 : 0;
+        return SRN_OK; });
+}
+size_t srn_shard_lists_record_bytes(size_t max_len_hint) { return device_prep_stride((uint32_t)max_len_hint); }
+int srn_shard_lists_head(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq, size_t max_len_hint, size_t m,
+                         void* d_pos, int32_t* d_head, void* stream) {
+    return guarded([&]() -> int {
+        LaunchParams p; int rc = lists_params(idx, d_items_flat, d_q_off, nq, max_len_hint, 1, m, 1, 0, p); if (rc) return rc;
+        if (!d_pos || !d_head) return fail(SRN_EINVAL, "null buffer");
+        return device_shard_lists_head(idx->dev, p, d_pos, d_head, stream); });
+}
+int srn_shard_lists_count(const srn_index_t* idx, const uint32_t* d_q_off, size_t nq, size_t max_len_hint, const void* d_pos, const int32_t* d_head,
+                          uint32_t* d_kept, int32_t* d_tot, void* stream) {
+    return guarded([&]() -> int {
+        const uint64_t dummy = 0;
+        LaunchParams p; int rc = lists_params(idx, &dummy, d_q_off, nq, max_len_hint, 1, 1, 1, 0, p); if (rc) return rc;
+        if (!d_pos || !d_head || !d_kept || !d_tot) return fail(SRN_EINVAL, "null buffer");
+        return device_shard_lists_count(idx->dev, p, d_pos, d_head, d_kept, d_tot, stream); });
+}
+int srn_shard_lists_copy(const srn_index_t* idx, size_t nq, size_t max_len_hint, const void* d_pos, const uint32_t* d_kept, const int64_t* d_off, uint32_t* d_out, void* stream) {
+    return guarded([&]() -> int {
+        const uint64_t dummy = 0; const uint32_t dq = 0;
+        LaunchParams p; int rc = lists_params(idx, &dummy, &dq, nq, max_len_hint, 1, 1, 1, 0, p); if (rc) return rc;
+        if (!d_pos || !d_kept || !d_off || !d_out) return fail(SRN_EINVAL, "null buffer");
+        return device_shard_lists_copy(idx->dev, p, d_pos, d_kept, (const long long*)d_off, d_out, stream); });
+}
+int srn_shard_lists_predict(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq, size_t max_len_hint, size_t k, size_t m,
+                            size_t how_many, unsigned flags, uint32_t n_shards, const uint32_t* d_kept_g, const int64_t* d_off_g, uint64_t shard_stride,
+                            const uint32_t* d_lists_g, const int32_t* d_head, const void* d_pos_local, void* d_records,
+                            uint64_t* d_out_ids, double* d_out_scores, uint32_t* d_out_counts, void* stream) {
+    return guarded([&]() -> int {
+        LaunchParams p; int rc = lists_params(idx, d_items_flat, d_q_off, nq, max_len_hint, k, m, how_many, flags, p); if (rc) return rc;
+        if (n_shards == 0 || !d_kept_g || !d_off_g || !d_lists_g || !d_head || !d_pos_local || !d_records || !d_out_ids || !d_out_scores || !d_out_counts)
+            return fail(SRN_EINVAL, "null buffer");
+        p.out_ids = d_out_ids; p.out_scores = d_out_scores; p.out_counts = d_out_counts;
+        return device_shard_lists_predict(idx->dev, idx->flat, p, n_shards, d_kept_g, (const long long*)d_off_g, shard_stride, d_lists_g, d_head, d_pos_local,
+                                          (char*)d_records, stream); });
+}
+
 int srn_kernel_times(const srn_index_t* idx, uint32_t max_n, double* out_ms_main, double* out_ms_retry, uint32_t* out_n) {
     if (!idx || !idx->dev) return fail(SRN_ENODEV, "index has no device attached");
     if (!out_n) return fail(SRN_EINVAL, "null argument");

@@ -9,6 +9,12 @@ namespace srn {
 
 static constexpr int MAX_PROBES = 48;       // bucket probes (4 slots each) before a table is declared full
 
+__device__ __forceinline__ uint64_t dev_mix64(uint64_t x) {   // the id table's hash (srn_index.cpp mix64)
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33; return x;
+}
+
 // Wave-wide scans and reductions on the VALU's data-parallel-primitive path (row_shr inside the rows of 16 lanes, then
 // row_bcast 15 / 31 across them): ~12 VALU instructions.  The __shfl_* forms compile to ds_bpermute_b32, i.e. six DEPENDENT
 // LDS round trips per scan, on a kernel whose LDS pipe is the busiest unit.

@@ -98,6 +98,46 @@ __global__ __launch_bounds__(1024) void rows_to_packed_kernel(const uint64_t* __
     for (int qd = 0; qd < 4; ++qd) dst[qd] = make_uint4(sl[4 * qd], sl[4 * qd + 1], sl[4 * qd + 2], sl[4 * qd + 3]);
 }
 
+// The same for an item shard's row FRAGMENTS: 16-byte slots -- halfword 0 = length, 1 = 0, 2..7 = items 0..5; fragments of > 6 items: halfwords 2..5 =
+// items 0..3, word 3 = index of the fragment's first overflow block (items 4..).
+__global__ __launch_bounds__(1024) void rows_to_packed_frag_kernel(const uint64_t* __restrict__ row_off, const uint32_t* __restrict__ row_items, uint64_t n,
+                                                                   const uint32_t* __restrict__ block_base, uint32_t* __restrict__ packed, uint32_t* __restrict__ ext16) {
+    __shared__ uint32_t wave_tot[16];
+    const uint64_t r = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t o = 0, len = 0;
+    if (r < n) { o = row_off[r]; len = row_off[r + 1] - o; }
+    const uint32_t e = len > 6 ? (uint32_t)((len - 4 + 7) / 8) : 0u;   // overflow blocks of this fragment
+    const uint32_t inc = wave_incl_scan(e);
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t base = block_base[blockIdx.x];
+    for (int w = 0; w < wave; ++w) base += wave_tot[w];
+    const uint32_t eblk = base + inc - e;
+    if (r > n) return;
+    const uint32_t inl = len > 6 ? 4u : (uint32_t)len;
+    auto half = [&](uint32_t j) -> uint32_t { return j < inl ? fast_offset_of(row_items[o + j]) : fast_phantom(r, j); };
+    uint32_t sl[4];
+    sl[0] = (uint32_t)(len > 0xFFFFu ? 0xFFFFu : len);
+#pragma unroll
+    for (uint32_t wd = 1; wd < 4; ++wd) sl[wd] = half(2 * wd - 2) | (half(2 * wd - 1) << 16);
+    if (len > 6) {
+        sl[3] = eblk;
+        for (uint32_t b = 0; b < e; ++b) {
+            uint32_t wv[4];
+#pragma unroll
+            for (uint32_t x = 0; x < 4; ++x) {
+                const uint64_t j0 = 4 + 8ull * b + 2 * x;
+                const uint32_t lo = j0 < len ? fast_offset_of(row_items[o + j0]) : fast_phantom(r, (uint32_t)j0);
+                const uint32_t hi = j0 + 1 < len ? fast_offset_of(row_items[o + j0 + 1]) : fast_phantom(r, (uint32_t)j0 + 1);
+                wv[x] = lo | (hi << 16);
+            }
+            reinterpret_cast<uint4*>(ext16)[(size_t)eblk + b] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+        }
+    }
+    reinterpret_cast<uint4*>(packed)[r] = make_uint4(sl[0], sl[1], sl[2], sl[3]);
+}
+
 // -------------------------------------------------------------------------------------
 // merge path over two adjacent sorted (descending) runs A = in[sa, sa + la), B = in[sa + la, sa + la + lb) -> out[sa, ...):
 // team thread t (of nthr) produces outputs [t g, (t + 1) g).  All values are distinct (the position bit differs between lists).
@@ -135,7 +175,10 @@ __device__ __forceinline__ void merge_pair(const uint32_t* in, uint32_t* out, ui
     }
 }
 
-template <int WG_PER_CU>
+// FRAG (an item shard in lists mode): the row slots are 16-byte FRAGMENT slots -- halfword 0 = length, halfwords 2..7 = items 0..5; fragments of > 6 items:
+// halfwords 2..5 = items 0..3, word 3 = the fragment's first overflow block (8 items each, items 4..) -- see rows_to_packed_frag_kernel; the general slots the
+// hits are resolved from are the 16-byte fragments of DeviceIndex::row_frag.
+template <int WG_PER_CU, bool FRAG>
 #ifndef SRN_FAST_WAVES
 #define SRN_FAST_WAVES (WG_PER_CU * 2)
 #endif
@@ -346,8 +389,8 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             const uint32_t j = wave * 64u + lane + (uint32_t)t * BLOCK;
             svr[t] = K ? nbl[min(j, K - 1u)] : 0u;   // (all loads unconditional: a load inside a branch is waited for at the branch's end)
             const size_t r = K ? (size_t)(svr[t] >> NB) : (size_t)n_kept;   // (idle lanes re-read the last neighbour's row)
-            rq[t] = *reinterpret_cast<const uint4*>(&f.row_packed[r * 4]);
-            rq1[t] = *reinterpret_cast<const uint4*>(&f.row_packed[r * 4 + 1]);
+            if constexpr (FRAG) { rq[t] = *reinterpret_cast<const uint4*>(&f.row_packed[r]); rq1[t] = make_uint4(0u, 0u, 0u, 0u); }
+            else { rq[t] = *reinterpret_cast<const uint4*>(&f.row_packed[r * 4]); rq1[t] = *reinterpret_cast<const uint4*>(&f.row_packed[r * 4 + 1]); }
         }
         {   // clear: accumulators + sketch + dump, exact table (keys EMPTY32, sums 0)
             uint4* z = reinterpret_cast<uint4*>(smem + F_HOT);
@@ -360,47 +403,64 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         FAST_TICK(8);
         auto add2 = [&](uint32_t wd, uint32_t w) {
             atomicAdd((uint32_t*)(acc_base + (wd & 0xFFFFu)), w); atomicAdd((uint32_t*)(acc_base + (wd >> 16)), w); };
+        constexpr uint32_t INL1 = FRAG ? 6u : 14u, INL2 = FRAG ? 20u : 28u;   // items served by round (i) / before the overflow loop
         // rows of > 14 items queue for round (ii) in the wave's own 192 list slots (their session slots are in registers by now)
         uint32_t cnt3 = 0;
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-            const bool m3 = wave * 64u + lane + (uint32_t)t * BLOCK < K && (rq[t].x & 0xFFFFu) > 14u;
+            const bool m3 = wave * 64u + lane + (uint32_t)t * BLOCK < K && (rq[t].x & 0xFFFFu) > INL1;
             const unsigned long long b3 = __ballot(m3);
             if (m3) nbl[qpos(cnt3 + (uint32_t)__popcll(b3 & lt))] = svr[t];
             cnt3 += (uint32_t)__popcll(b3);
         }
         // round (ii)'s first batch is requested BEFORE round (i)'s adds, which hide its latency (L2 hits: the lines came with round (i))
-        auto q3_load = [&](uint32_t p0, uint32_t& sv, uint32_t& hdr, uint4& c4, uint4& d4) {
+        // (FRAG: the queued fragments continue in their overflow blocks: c4 = items 4..11, d4 = items 12..19 if the fragment has that many; blk = the block the
+        //  overflow loop starts at)
+        auto q3_load = [&](uint32_t p0, uint32_t& sv, uint32_t& hdr, uint4& c4, uint4& d4, uint32_t& blk) {
             sv = nbl[qpos(min(p0 + lane, cnt3 - 1u))];
-            const RowQuad* rowp = f.row_packed + (size_t)(sv >> NB) * 4;
-            hdr = *reinterpret_cast<const uint32_t*>(rowp); c4 = *reinterpret_cast<const uint4*>(rowp + 2); d4 = *reinterpret_cast<const uint4*>(rowp + 3); };
-        uint32_t sv3 = 0, hdr3 = 0; uint4 c43 = make_uint4(0u, 0u, 0u, 0u), d43 = c43;
-        if (cnt3) q3_load(0u, sv3, hdr3, c43, d43);   // (wave-uniform)
+            if constexpr (FRAG) {
+                const uint4 s4 = *reinterpret_cast<const uint4*>(f.row_packed + (size_t)(sv >> NB));
+                hdr = s4.x;
+                const uint4* eb = reinterpret_cast<const uint4*>(f.row_ext16) + ((hdr & 0xFFFFu) > 6u ? (size_t)s4.w : (size_t)0);   // (an idle lane's slot may be a short one)
+                c4 = eb[0]; d4 = eb[1]; blk = s4.w + 2u;
+            } else {
+                const RowQuad* rowp = f.row_packed + (size_t)(sv >> NB) * 4;
+                hdr = *reinterpret_cast<const uint32_t*>(rowp); c4 = *reinterpret_cast<const uint4*>(rowp + 2); d4 = *reinterpret_cast<const uint4*>(rowp + 3); blk = d4.w;
+            } };
+        uint32_t sv3 = 0, hdr3 = 0, blk3 = 0; uint4 c43 = make_uint4(0u, 0u, 0u, 0u), d43 = c43;
+        if (cnt3) q3_load(0u, sv3, hdr3, c43, d43, blk3);   // (wave-uniform)
 #pragma unroll
         for (int t = 0; t < 3; ++t) {   // (i) items 0..13
             if (wave * 64u + (uint32_t)t * BLOCK < K) {
                 const bool act = wave * 64u + lane + (uint32_t)t * BLOCK < K;
                 const uint32_t w = w10t[svr[t] & NBM], len = rq[t].x & 0xFFFFu;
+                if constexpr (FRAG) { if (act) { add2(rq[t].y, w); add2(rq[t].z, w); if (len <= 6u) add2(rq[t].w, w); } }
+                else {
                 if (act) { add2(rq[t].y, w); add2(rq[t].z, w); add2(rq[t].w, w); }
                 if (act && len > 6u) { add2(rq1[t].x, w); add2(rq1[t].y, w); add2(rq1[t].z, w); add2(rq1[t].w, w); }
+                }
             }
         }
-        auto add_tail = [&](uint32_t p0, uint32_t sv, uint32_t hdr, const uint4& c4, const uint4& d4) {   // items 14..29, then the overflow blocks
+        auto add_tail = [&](uint32_t p0, uint32_t sv, uint32_t hdr, const uint4& c4, const uint4& d4, uint32_t blk) {   // items 14..29 (FRAG: 4..19), then the overflow blocks
             const bool act = p0 + lane < cnt3;
             const uint32_t len = hdr & 0xFFFFu, w = w10t[sv & NBM];
-            if (act) {
+            const bool more = FRAG ? true : len > 30u;   // (a slot without overflow blocks keeps items in the words the others use for the block index)
+            if constexpr (FRAG) {
+                if (act) { add2(c4.x, w); add2(c4.y, w); add2(c4.z, w); add2(c4.w, w); }
+                if (act && len > 12u) { add2(d4.x, w); add2(d4.y, w); add2(d4.z, w); add2(d4.w, w); }   // (a fragment of <= 12 items has one block: the next belongs to another row)
+            } else if (act) {
                 add2(c4.x, w); add2(c4.y, w); add2(c4.z, w); add2(c4.w, w);
                 add2(d4.x, w); add2(d4.y, w); add2(d4.z, w);
                 if (len <= 30u) add2(d4.w, w);
             }
-            for (uint32_t t8 = 28u; __ballot(act && len > 30u && t8 < len) != 0ull; t8 += 8u) {
-                if (act && len > 30u && t8 < len) {
-                    const uint4 e4 = reinterpret_cast<const uint4*>(f.row_ext16)[(size_t)d4.w + ((t8 - 28u) >> 3)];
+            for (uint32_t t8 = INL2; __ballot(act && more && t8 < len) != 0ull; t8 += 8u) {
+                if (act && more && t8 < len) {
+                    const uint4 e4 = reinterpret_cast<const uint4*>(f.row_ext16)[(size_t)blk + ((t8 - INL2) >> 3)];
                     add2(e4.x, w); add2(e4.y, w); add2(e4.z, w); add2(e4.w, w);
                 }
             } };
-        if (cnt3) add_tail(0u, sv3, hdr3, c43, d43);
-        for (uint32_t p0 = 64u; p0 < cnt3; p0 += 64u) { uint32_t sv, hdr; uint4 c4, d4; q3_load(p0, sv, hdr, c4, d4); add_tail(p0, sv, hdr, c4, d4); }
+        if (cnt3) add_tail(0u, sv3, hdr3, c43, d43, blk3);
+        for (uint32_t p0 = 64u; p0 < cnt3; p0 += 64u) { uint32_t sv, hdr, blk; uint4 c4, d4; q3_load(p0, sv, hdr, c4, d4, blk); add_tail(p0, sv, hdr, c4, d4, blk); }
         __syncthreads();
         FAST_TICK(9);
 
@@ -532,7 +592,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             auto mx2 = [&](uint32_t mx, uint32_t wd) -> uint32_t {
                 const uint32_t a = *(const uint32_t*)(acc_base + max(wd & 0xFFFFu, F_ZERO_OFF)), b = *(const uint32_t*)(acc_base + max(wd >> 16, F_ZERO_OFF));
                 return max(max(mx, a), b); };
-            uint32_t sv3b = 0, hdr3b = 0; uint4 c43b = make_uint4(0u, 0u, 0u, 0u), d43b = c43b;
+            uint32_t sv3b = 0, hdr3b = 0, blk3b = 0; uint4 c43b = make_uint4(0u, 0u, 0u, 0u), d43b = c43b;
 #if SRN_FAST_RELOAD_ROWS
             // the rows' first 32 bytes again (L2 hits), all requested at once: keeping them in registers since walk A costs 24 VGPRs
             // across phase 4a -- at the 80-register cap of three workgroups per CU that means scratch spills on the serial paths
@@ -543,12 +603,20 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
                 rq1[t] = *reinterpret_cast<const uint4*>(&f.row_packed[r * 4 + 1]);
             }
 #endif
-            if (cnt3) q3_load(0u, sv3b, hdr3b, c43b, d43b);   // requested before round (i)
+            if (cnt3) q3_load(0u, sv3b, hdr3b, c43b, d43b, blk3b);   // requested before round (i)
 #pragma unroll
             for (int t = 0; t < 3; ++t) {   // (i) from the registers
                 if (wave * 64u + (uint32_t)t * BLOCK < K) {
                     const bool act = wave * 64u + lane + (uint32_t)t * BLOCK < K, two = (rq[t].x & 0xFFFFu) > 6u;
                     uint32_t mx = 0;
+                    if constexpr (FRAG) {   // positions 0..5; a fragment of > 6 items keeps only 0..3 here (word 3 = its first overflow block)
+                        if (act) { mx = mx2(mx2(0u, rq[t].y), rq[t].z); if (!two) mx = mx2(mx, rq[t].w); }
+                        if (__ballot(mx >= floor_b) != 0ull) {
+                            uint32_t hm = 0;
+                            if (act) { hm = chk2(chk2(0u, rq[t].y), rq[t].z); hm = two ? hm << 2 : chk2(hm, rq[t].w); }
+                            list_hits(hm, 6u, svr[t], 0u);
+                        }
+                    } else {
                     if (act) { mx = mx2(mx2(mx2(0u, rq[t].y), rq[t].z), rq[t].w); if (two) mx = mx2(mx2(mx2(mx2(mx, rq1[t].x), rq1[t].y), rq1[t].z), rq1[t].w); }
                     if (__ballot(mx >= floor_b) != 0ull) {
                         uint32_t hm = 0;
@@ -558,12 +626,23 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
                         }
                         list_hits(hm, 14u, svr[t], 0u);
                     }
+                    }
                 }
             }
-            auto chk_tail = [&](uint32_t p0, uint32_t sv, uint32_t hdr, const uint4& c4, const uint4& d4) {
+            auto chk_tail = [&](uint32_t p0, uint32_t sv, uint32_t hdr, const uint4& c4, const uint4& d4, uint32_t blk) {
                 const bool act = p0 + lane < cnt3;
                 const uint32_t len = hdr & 0xFFFFu;
+                const bool more = FRAG ? true : len > 30u;
                 uint32_t hm = 0, mx = 0;
+                if constexpr (FRAG) {   // positions 4..11, then 12..19 if the fragment has a second block
+                    const bool two = len > 12u;
+                    if (act) { mx = mx2(mx2(mx2(mx2(0u, c4.x), c4.y), c4.z), c4.w); if (two) mx = mx2(mx2(mx2(mx2(mx, d4.x), d4.y), d4.z), d4.w); }
+                    if (__ballot(mx >= floor_b) != 0ull) {
+                        uint32_t hmd = 0;
+                        if (act) { hm = chk2(chk2(chk2(chk2(0u, c4.x), c4.y), c4.z), c4.w); if (two) hmd = chk2(chk2(chk2(chk2(0u, d4.x), d4.y), d4.z), d4.w); }
+                        list_hits(hm, 8u, sv, 4u); list_hits(hmd, 8u, sv, 12u);
+                    }
+                } else {
                 if (act) { mx = mx2(mx2(mx2(mx2(mx2(mx2(mx2(0u, c4.x), c4.y), c4.z), c4.w), d4.x), d4.y), d4.z); if (len <= 30u) mx = mx2(mx, d4.w); }
                 if (__ballot(mx >= floor_b) != 0ull) {
                 if (act) {
@@ -571,16 +650,17 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
                     if (len > 30u) hm <<= 2; else hm = chk2(hm, d4.w);
                 }
                 list_hits(hm, 16u, sv, 14u); }
-                for (uint32_t t8 = 28u; __ballot(act && len > 30u && t8 < len) != 0ull; t8 += 8u) {
+                }
+                for (uint32_t t8 = INL2; __ballot(act && more && t8 < len) != 0ull; t8 += 8u) {
                     uint32_t hm2 = 0;
-                    if (act && len > 30u && t8 < len) {
-                        const uint4 e4 = reinterpret_cast<const uint4*>(f.row_ext16)[(size_t)d4.w + ((t8 - 28u) >> 3)];
+                    if (act && more && t8 < len) {
+                        const uint4 e4 = reinterpret_cast<const uint4*>(f.row_ext16)[(size_t)blk + ((t8 - INL2) >> 3)];
                         hm2 = chk2(chk2(chk2(chk2(0u, e4.x), e4.y), e4.z), e4.w);
                     }
                     list_hits(hm2, 8u, sv, t8);   // (rows of > 30 items are few: no fast path)
                 } };
-            if (cnt3) chk_tail(0u, sv3b, hdr3b, c43b, d43b);
-            for (uint32_t p0 = 64u; p0 < cnt3; p0 += 64u) { uint32_t sv, hdr; uint4 c4, d4; q3_load(p0, sv, hdr, c4, d4); chk_tail(p0, sv, hdr, c4, d4); }
+            if (cnt3) chk_tail(0u, sv3b, hdr3b, c43b, d43b, blk3b);
+            for (uint32_t p0 = 64u; p0 < cnt3; p0 += 64u) { uint32_t sv, hdr, blk; uint4 c4, d4; q3_load(p0, sv, hdr, c4, d4, blk); chk_tail(p0, sv, hdr, c4, d4, blk); }
             if (ticking) { const uint32_t hs = wave_sum(dbg_hits); if (lane == 0u && hs) atomicAdd(&tacc[5], (unsigned long long)hs); }
         }
         __syncthreads();
@@ -592,9 +672,11 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             bool ovf = false;
             for (uint32_t i = tid; i < nh; i += BLOCK) {
                 const uint2 h = hits[i];
-                const uint32_t* os = reinterpret_cast<const uint32_t*>(ix.row_slots + (size_t)(h.x >> NB) * 4);
+                const uint32_t* os = reinterpret_cast<const uint32_t*>(ix.row_slots + (size_t)(h.x >> NB) * (FRAG ? 1 : 4));
                 const uint32_t len = os[0], j = h.y;
                 uint32_t it = EMPTY32;
+                if constexpr (FRAG) { if (j < len) it = len <= 3u ? os[1 + j] : (j < 2u ? os[2 + j] : ix.row_ext[os[1] + (j - 2u)]); }
+                else
                 if (j < len) it = len <= 15u ? os[1 + j] : (j < 14u ? os[2 + j] : ix.row_ext[os[1] + (j - 14u)]);
                 if (it != EMPTY32 && it >= F_HOT_WORDS && item_insert(ikeys, iacc, F_TABLE_BUCKETS, it, (int)w10t[h.x & NBM]) < 0) ovf = true;
             }
@@ -790,7 +872,7 @@ hipError_t launch_finish(hipStream_t st, const DeviceIndex& di, const FastParams
 }
 
 hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f) {
-    auto kern = vmis_fast_kernel<(int)F_WG_PER_CU>;
+    auto kern = di.row_frag ? vmis_fast_kernel<(int)F_WG_PER_CU, true> : vmis_fast_kernel<(int)F_WG_PER_CU, false>;
     constexpr size_t dyn = SRN_FAST_SMALL ? 0 : F_TOTAL;
     if (dyn) { hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); if (e != hipSuccess) return e; }
     static bool told = false;
@@ -801,7 +883,9 @@ hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const L
 }
 
 hipError_t launch_rows_to_packed(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base,
-                                 uint32_t* packed, uint32_t* ext16) {
+                                 uint32_t* packed, uint32_t* ext16, bool frag) {
+    if (frag) hipLaunchKernelGGL(rows_to_packed_frag_kernel, dim3((unsigned)((n_rows + 1 + 1023) / 1024)), dim3(1024), 0, st, row_off, row_items, n_rows, block_base, packed, ext16);
+    else
     hipLaunchKernelGGL(rows_to_packed_kernel, dim3((unsigned)((n_rows + 1 + 1023) / 1024)), dim3(1024), 0, st, row_off, row_items, n_rows, block_base, packed, ext16);
     return hipGetLastError();
 }

@@ -115,10 +115,12 @@ int device_update_attr(DeviceState* d, const FlatIndex& ix);
 void device_refresh_fast_bounds(DeviceState* d, const FlatIndex& ix);   // idf bounds of the fast kernel's integer floors (srn_runtime.hip)
 void reload_knobs();                                                     // re-read the SRN_* test / experiment knobs from the environment
 uint64_t device_bytes(const DeviceState* d);
+// item-sharded index, lists mode: prep records (PrepHead + max_len * PrepItem per query) written against a gathered posting buffer
+struct ExtLists { const char* prep; uint32_t prep_stride; const uint32_t* post_rank; };
 int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p, bool buffers_on_device, void* stream,
                    // host-pointer mode: these are host buffers copied in/out by the call
                    const uint64_t* h_items, const uint32_t* h_qoff, uint64_t* h_ids, double* h_scores,
-                   uint32_t* h_counts, uint32_t* h_stats, uint32_t* h_nb_rank, uint32_t* h_nb_num, uint32_t* h_nb_cnt);
+                   uint32_t* h_counts, uint32_t* h_stats, uint32_t* h_nb_rank, uint32_t* h_nb_num, uint32_t* h_nb_cnt, const ExtLists* ext = nullptr);
 struct ShardIO {
     void* cand; uint32_t* cand_cnt;                                       // A out: [nq * m] packed slots, [nq]
     const void* gathered; const uint32_t* gathered_cnt; uint32_t n_shards;   // B in: [G][nq * gathered_stride], [G][nq]
@@ -126,6 +128,13 @@ struct ShardIO {
     void* nb; uint32_t* nb_cnt; int* minpos;                             // B out / C in: [nq * k], [nq], [nq * (k + 1)]
 };
 
+bool device_shard_lists_supported(DeviceState* d, const FlatIndex& ix, const LaunchParams& p);
+uint32_t device_prep_stride(uint32_t max_len);
+int device_shard_lists_head(DeviceState* d, const LaunchParams& p, void* pos, int* head, void* stream);
+int device_shard_lists_count(DeviceState* d, const LaunchParams& p, const void* pos, const int* head, uint32_t* kept, int* tot, void* stream);
+int device_shard_lists_copy(DeviceState* d, const LaunchParams& p, const void* pos, const uint32_t* kept, const long long* off, uint32_t* out, void* stream);
+int device_shard_lists_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p, uint32_t n_shards, const uint32_t* kept_g, const long long* off_g,
+                               unsigned long long shard_stride, const uint32_t* lists_g, const int* head, const void* pos_local, char* records, void* stream);
 int device_shard_stage(DeviceState* d, const FlatIndex& ix, int stage, const LaunchParams& p, const ShardIO& sh, void* stream);
 int device_slot_bytes(DeviceState* d, const FlatIndex& ix, uint32_t max_len, uint32_t* num_bits = nullptr);
 int device_last_kernel_ms(DeviceState* d, double* ms_main, double* ms_retry, uint32_t* retried);

@@ -35,6 +35,9 @@ struct LaunchAux { const uint32_t* qlist; const uint32_t* qlist_n; uint32_t* ret
 struct PrepHead { uint32_t U, rmax, xlo, sumw, P, nruns, L, n_staged, run_start[8]; };   // S_U, S_RMAX, S_XLO, S_SUMW, S_P of the query; number of non-empty lists, session length as given, sum of the lists' kept counts, where the first 8 lists start
 struct PrepItem { uint32_t idx, len, pre, kept; unsigned long long base; };   // dense idx | kNone, truncated list length, prefix of len, entries >= x_lo (a prefix of the list), list start
 
+// item-sharded index, lists mode (srn_shard.hip): what a shard knows about one evolving position of a query
+struct ShardPos { uint32_t idx, len; unsigned long long base; };   // dense idx | kNone; list length truncated to m (0: not this shard's item, unknown, or an older duplicate); list start
+
 // ---- fast path (srn_fast.hip): the lean kernel for the common query shape; everything else goes to vmis_predict_kernel ----
 // LDS map of vmis_fast_kernel, bytes.  The row slots of the fast path hold 16-bit byte offsets relative to F_HOT, so the layout is fixed.
 #ifndef SRN_FAST_SMALL
@@ -80,9 +83,17 @@ hipError_t launch_prep(hipStream_t st, const DeviceIndex& di, const uint64_t* it
                        uint32_t max_len, char* out, uint32_t stride);
 hipError_t launch_finish_big(hipStream_t st, const DeviceIndex& di, const FastParams& f, uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint32_t how_many, uint32_t grid);
 hipError_t launch_finish(hipStream_t st, const DeviceIndex& di, const FastParams& f, uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint32_t nq, uint32_t how_many);   // scores, ranking, public ids of the rows the fast kernel served
+hipError_t launch_shard_lists_head(hipStream_t st, const DeviceIndex& di, const uint64_t* items_flat, const uint32_t* q_off, uint32_t nq, uint32_t m, uint32_t max_len,
+                                   ShardPos* pos_out, int* head);
+hipError_t launch_shard_lists_count(hipStream_t st, const DeviceIndex& di, const uint32_t* q_off, uint32_t nq, uint32_t max_len, const ShardPos* pos_in, const int* head,
+                                    uint32_t* kept, int* tot);
+hipError_t launch_shard_lists_copy(hipStream_t st, const DeviceIndex& di, uint32_t nq, uint32_t max_len, const ShardPos* pos_in, const uint32_t* kept, const long long* off,
+                                   uint32_t* out);
+hipError_t launch_shard_prep(hipStream_t st, const uint64_t* items_flat, const uint32_t* q_off, uint32_t nq, uint32_t max_len, uint32_t n_shards, const uint32_t* kept_g,
+                             const long long* off_g, unsigned long long shard_stride, const int* head, const ShardPos* pos_local, char* out, uint32_t stride);
 hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f);
 hipError_t launch_rows_to_packed(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base,
-                                 uint32_t* packed, uint32_t* ext16);   // grid = ceil((n_rows + 1) / 1024) blocks of 1024; block_base in 16-byte blocks
+                                 uint32_t* packed, uint32_t* ext16, bool frag = false);   // grid = ceil((n_rows + 1) / 1024) blocks of 1024; block_base in 16-byte blocks
 hipError_t launch_rows_to_frags(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base,
                                 uint32_t* slots, uint32_t* ext);   // 16-byte fragment slots of an item shard; block_base in items
 hipError_t launch_rows_to_slots(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base,

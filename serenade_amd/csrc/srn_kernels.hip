@@ -56,11 +56,6 @@ template <typename T> struct SlotTraits;
 template <> struct SlotTraits<uint32_t> { static constexpr uint32_t EMPTY = 0xFFFFFFFFu; };
 template <> struct SlotTraits<unsigned long long> { static constexpr unsigned long long EMPTY = ~0ull; };
 
-__device__ __forceinline__ uint64_t dev_mix64(uint64_t x) {
-    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
-    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
-    x ^= x >> 33; return x;
-}
 // double hashing over a power-of-two table: start slot from the high product bits, odd stride
 __device__ __forceinline__ uint32_t hash_start(uint32_t key, uint32_t mask) { return ((key * 0x9E3779B1u) >> 7) & mask; }
 __device__ __forceinline__ uint32_t hash_step(uint32_t key, uint32_t mask) { return (((key * 0x85EBCA6Bu) >> 9) | 1u) & mask; }
@@ -1270,15 +1265,17 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
 #pragma unroll
                 for (int x = 0; x < N; ++x) { uint32_t* at = &hot[min(it[x], H + (it[x] & SKM))]; atomicAdd(it[x] != EMPTY32 ? at : idle_word, wv); } };
             uint32_t isum = 0;
-            if constexpr (MASKS && STAGE == 0) {
-                if (SK && !GLOBAL_TABLES) isum = walk_rounds(nb_lds, nbl, [&](const auto& it, int w) { add_items_pos(it, (uint32_t)w); });   // (region A in LDS)
-                else isum = walk_rounds(nb_lds, nbl, [&](const auto& it, int w) { add_items(it, (uint32_t)w, 0u); });
-            } else {
-                isum = walk_rows(nb_lds, [&](uint32_t j, uint32_t num, auto&& for_row) {
+            auto walk_a_rows = [&]() -> uint32_t {
+                return walk_rows(nb_lds, [&](uint32_t j, uint32_t num, auto&& for_row) {
                     const int w = row_weight(j, num, for_row);
                     const uint32_t wsk = (uint32_t)max(w, 0), whot = MASKS ? (uint32_t)w : (1u << SB) + (uint32_t)w;
-                    for_row([&](const auto& it) { add_items(it, whot, wsk); }); });
-            }
+                    for_row([&](const auto& it) { add_items(it, whot, wsk); }); }); };
+            if constexpr (MASKS && STAGE == 0) {
+                if (ix.row_frag != 0u) isum = walk_a_rows();   // (an item shard in lists mode: 16-byte fragment slots, walk_rows reads both kinds)
+                else
+                if (SK && !GLOBAL_TABLES) isum = walk_rounds(nb_lds, nbl, [&](const auto& it, int w) { add_items_pos(it, (uint32_t)w); });   // (region A in LDS)
+                else isum = walk_rounds(nb_lds, nbl, [&](const auto& it, int w) { add_items(it, (uint32_t)w, 0u); });
+            } else isum = walk_a_rows();
             isum = wave_sum(isum);
             if (lane == 0 && p.stats && isum) atomicAdd((uint32_t*)&misc[S_I], isum);
         }
@@ -1472,7 +1469,7 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
                         if (go[x]) { const int res = item_insert(ikeys, iacc, inb, it[x], w); if (res < 0) ovf = true; else fresh += (uint32_t)res; }
                     } };
                 bool rounds = false;
-                if constexpr (MASKS && STAGE == 0 && !GLOBAL_TABLES) rounds = (size_t)(K + 64) * sizeof(SlotT) <= (size_t)H * 4;   // the direct-mapped words are dead: queue there
+                if constexpr (MASKS && STAGE == 0 && !GLOBAL_TABLES) rounds = ix.row_frag == 0u && (size_t)(K + 64) * sizeof(SlotT) <= (size_t)H * 4;   // the direct-mapped words are dead: queue there
                 if (rounds) { if constexpr (MASKS && STAGE == 0 && !GLOBAL_TABLES) walk_rounds(nb_glb, (SlotT*)hot, insert_items); }
                 else walk_rows(nb_glb, [&](uint32_t j, uint32_t num, auto&& for_row) {
                     const int w = row_weight(j, num, for_row);

@@ -131,20 +131,21 @@ DeviceState* device_attach(const FlatIndex& ix, int device) {
         good = good && (frag ? launch_rows_to_frags : launch_rows_to_slots)(nullptr, (const uint64_t*)d_off, (const uint32_t*)d_items, (uint64_t)n, (const uint32_t*)d_base,
                                                                              (uint32_t*)d_slots, (uint32_t*)d_ext) == hipSuccess &&
                hipDeviceSynchronize() == hipSuccess;
-        if (good && ix.n_shards == 1) {   // the fast kernel's rows: 64-byte slots of 16-bit LDS offsets (+ overflow blocks of 8 items), srn_fast.hip
+        if (good) {   // the fast kernel's rows: 64-byte slots of 16-bit LDS offsets (+ overflow blocks of 8 items); item shards: 16-byte fragment slots, srn_fast.hip
             std::vector<uint32_t> bb(nblocks); uint64_t blocks = 1;   // (block 0: what a stray read finds)
             for (size_t b0 = 0; b0 < nblocks; ++b0) {
                 bb[b0] = (uint32_t)blocks;
                 const size_t hi = std::min(n, (b0 + 1) * 1024);
-                for (size_t r = b0 * 1024; r < hi; ++r) { const uint64_t len = ix.row_off[r + 1] - ix.row_off[r]; if (len > 30) blocks += (len - 28 + 7) / 8; }
+                for (size_t r = b0 * 1024; r < hi; ++r) { const uint64_t len = ix.row_off[r + 1] - ix.row_off[r];
+                    if (frag) { if (len > 6) blocks += (len - 4 + 7) / 8; } else if (len > 30) blocks += (len - 28 + 7) / 8; }
             }
             void *d_pk = nullptr, *d_e16 = nullptr;
-            bool g2 = blocks < 0xFFFFFFF0ull && hipMalloc(&d_pk, (n + 1) * 64) == hipSuccess && hipMalloc(&d_e16, (blocks + 1) * 16) == hipSuccess &&
-                      hipMemcpy(d_base, bb.data(), nblocks * 4, hipMemcpyHostToDevice) == hipSuccess && hipMemset(d_e16, 0, (blocks + 1) * 16) == hipSuccess &&
-                      launch_rows_to_packed(nullptr, (const uint64_t*)d_off, (const uint32_t*)d_items, (uint64_t)n, (const uint32_t*)d_base, (uint32_t*)d_pk, (uint32_t*)d_e16) == hipSuccess &&
+            bool g2 = blocks < 0xFFFFFFF0ull && hipMalloc(&d_pk, (n + 1) * slot_bytes) == hipSuccess && hipMalloc(&d_e16, (blocks + 2) * 16) == hipSuccess &&
+                      hipMemcpy(d_base, bb.data(), nblocks * 4, hipMemcpyHostToDevice) == hipSuccess && hipMemset(d_e16, 0, (blocks + 2) * 16) == hipSuccess &&
+                      launch_rows_to_packed(nullptr, (const uint64_t*)d_off, (const uint32_t*)d_items, (uint64_t)n, (const uint32_t*)d_base, (uint32_t*)d_pk, (uint32_t*)d_e16, frag) == hipSuccess &&
                       hipDeviceSynchronize() == hipSuccess;
-            if (d_pk) { d->allocs.push_back(d_pk); d->bytes += (n + 1) * 64; }
-            if (d_e16) { d->allocs.push_back(d_e16); d->bytes += (blocks + 1) * 16; }
+            if (d_pk) { d->allocs.push_back(d_pk); d->bytes += (n + 1) * slot_bytes; }
+            if (d_e16) { d->allocs.push_back(d_e16); d->bytes += (blocks + 2) * 16; }
             if (g2) { d->fast.row_packed = (const RowQuad*)d_pk; d->fast.row_ext16 = (const uint32_t*)d_e16; }
             else { good = false; }
         }
@@ -370,10 +371,14 @@ static thread_local bool t_reserve_only = false;   // device_reserve: size the w
 
 int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in, bool on_device, void* user_stream,
                    const uint64_t* h_items, const uint32_t* h_qoff, uint64_t* h_ids, double* h_scores, uint32_t* h_counts,
-                   uint32_t* h_stats, uint32_t* h_nb_rank, uint32_t* h_nb_num, uint32_t* h_nb_cnt) {
+                   uint32_t* h_stats, uint32_t* h_nb_rank, uint32_t* h_nb_num, uint32_t* h_nb_cnt, const ExtLists* ext) {
     HIP_TRY(hipSetDevice(d->device));
     LaunchParams p = p_in;
     if (p.nq == 0) return SRN_OK;
+    // item-sharded index, lists mode (device_shard_lists_*): the posting lists of ALL shards for this batch arrive in one gathered
+    // buffer with the prep records already written against it; everything below runs unchanged on "an index whose postings live there"
+    DeviceIndex di = d->di;
+    if (ext) di.post_rank = ext->post_rank;
     p.phase_cycles = d->phase_on ? d->d_phase : nullptr;
     Workspace* w = ws_acquire(d, on_device, user_stream);
     if (!w) return fail(SRN_EHIP, "cannot create HIP stream / events");
@@ -449,7 +454,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     { int rc = ensure(&w->spill, &w->spill_bytes, (size_t)std::max<uint32_t>(std::max(grid, grid3), (uint32_t)retry_blocks) * p.k * slot_bytes); if (rc) return rc; }
     char* spill = w->spill;
     const uint32_t prep_stride = (uint32_t)(sizeof(PrepHead) + (size_t)p.max_len * sizeof(PrepItem));
-    { int rc = ensure(&w->prep, &w->prep_bytes, (size_t)p.nq * prep_stride); if (rc) return rc; }
+    if (!ext) { int rc = ensure(&w->prep, &w->prep_bytes, (size_t)p.nq * prep_stride); if (rc) return rc; }
     const bool fast = d->fast.row_packed != nullptr && geo.masks && !slot64 && kn.geometry_default() && !kn.no_fast && p.k <= F_K_MAX && p.m <= F_M_MAX &&
                       p.how_many <= 24 && p.flags == 0 && p.stats == nullptr && p.nb_rank == nullptr && p.max_len <= 8 && c.num_bits <= 8;
     if (fast) {   // (all allocations of a call happen before its first launch)
@@ -462,8 +467,8 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     if (t_reserve_only) return SRN_OK;
     hipEvent_t* ev = w->ev[w->calls % Workspace::RING];
     HIP_TRY(hipEventRecord(ev[0], st));
-    HIP_TRY(launch_prep(st, d->di, p.items_flat, p.q_off, p.nq, p.m, p.max_len, w->prep, prep_stride));
-    p.prep = w->prep; p.prep_stride = prep_stride;
+    if (ext) { if (ext->prep_stride != prep_stride) return fail(SRN_EINVAL, "prep record stride mismatch"); p.prep = ext->prep; p.prep_stride = prep_stride; }
+    else { HIP_TRY(launch_prep(st, di, p.items_flat, p.q_off, p.nq, p.m, p.max_len, w->prep, prep_stride)); p.prep = w->prep; p.prep_stride = prep_stride; }
     HIP_TRY(hipEventRecord(ev[3], st));
     const uint32_t* final_list = w->retry_list; uint32_t* final_cnt = w->retry_cnt;
     // The fast kernel (srn_fast.hip) serves the common query shape; what it cannot take -- decided per query, on the device -- is
@@ -474,23 +479,23 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         const uint64_t big_entries = std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)p.nq * 16 + 4096);
         FastParams fp = d->fast; fp.slow_list = w->slow_list; fp.slow_cnt = w->slow_cnt; fp.nb = c.num_bits; fp.fin = w->fin;
         fp.big_arena = w->big; fp.big_list = (uint32_t*)(w->big + big_entries * 16); fp.big_ticket = (unsigned long long*)(w->slow_cnt + 2); fp.big_cap_entries = (uint32_t)big_entries;
-        HIP_TRY(launch_fast(dim3(grid_f), st, d->di, p, fp));
+        HIP_TRY(launch_fast(dim3(grid_f), st, di, p, fp));
         HIP_TRY(hipEventRecord(ev[4], st));
-        HIP_TRY(launch_predict(geo.masks, slot64, false, 0, dim3(grid), lds, st, d->di, p, c, w->slow_list, w->slow_cnt, w->retry_list, w->retry_cnt, nullptr, 0, spill, ShardIO{}));
-        HIP_TRY(launch_finish(st, d->di, fp, p.out_ids, p.out_scores, p.out_counts, p.nq, p.how_many));
-        HIP_TRY(launch_finish_big(st, d->di, fp, p.out_ids, p.out_scores, p.out_counts, p.how_many, (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * 16)));
+        HIP_TRY(launch_predict(geo.masks, slot64, false, 0, dim3(grid), lds, st, di, p, c, w->slow_list, w->slow_cnt, w->retry_list, w->retry_cnt, nullptr, 0, spill, ShardIO{}));
+        HIP_TRY(launch_finish(st, di, fp, p.out_ids, p.out_scores, p.out_counts, p.nq, p.how_many));
+        HIP_TRY(launch_finish_big(st, di, fp, p.out_ids, p.out_scores, p.out_counts, p.how_many, (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * 16)));
     } else
     if (dense) {
-        HIP_TRY(launch_predict(geo.masks, false, false, 0, dim3(grid3), g3.lds, st, d->di, p, g3.c, nullptr, nullptr, w->retry_list, w->retry_cnt, nullptr, 0, spill, ShardIO{}, 3));
-        HIP_TRY(launch_predict(geo.masks, false, false, 0, dim3(grid), lds, st, d->di, p, c, w->retry_list, w->retry_cnt, w->retry_list2, w->retry_cnt2, nullptr, 0, spill, ShardIO{}));
+        HIP_TRY(launch_predict(geo.masks, false, false, 0, dim3(grid3), g3.lds, st, di, p, g3.c, nullptr, nullptr, w->retry_list, w->retry_cnt, nullptr, 0, spill, ShardIO{}, 3));
+        HIP_TRY(launch_predict(geo.masks, false, false, 0, dim3(grid), lds, st, di, p, c, w->retry_list, w->retry_cnt, w->retry_list2, w->retry_cnt2, nullptr, 0, spill, ShardIO{}));
         final_list = w->retry_list2; final_cnt = w->retry_cnt2;
     } else
-        HIP_TRY(launch_predict(geo.masks, slot64, false, 0, dim3(grid), lds, st, d->di, p, c, nullptr, nullptr, w->retry_list, w->retry_cnt, nullptr, 0, spill, ShardIO{}));
+        HIP_TRY(launch_predict(geo.masks, slot64, false, 0, dim3(grid), lds, st, di, p, c, nullptr, nullptr, w->retry_list, w->retry_cnt, nullptr, 0, spill, ShardIO{}));
     if (!fast) HIP_TRY(hipEventRecord(ev[4], st));
     HIP_TRY(hipEventRecord(ev[1], st));
     if (may_overflow || dense) {
         const size_t lds_g = c.off_a;
-        HIP_TRY(launch_predict(geo.masks, slot64, true, 0, dim3(retry_blocks), lds_g, st, d->di, p, cg, final_list, final_cnt, nullptr, nullptr,
+        HIP_TRY(launch_predict(geo.masks, slot64, true, 0, dim3(retry_blocks), lds_g, st, di, p, cg, final_list, final_cnt, nullptr, nullptr,
                                w->gscratch, g_stride, spill, ShardIO{}));
         HIP_TRY(hipMemcpyAsync(w->h_retry, final_cnt, 4, hipMemcpyDeviceToHost, st));
     }
@@ -532,6 +537,41 @@ int device_shard_stage(DeviceState* d, const FlatIndex& ix, int stage, const Lau
     if (e != hipSuccess) return fail(SRN_EHIP, std::string("shard stage launch: ") + hipGetErrorString(e));
     return SRN_OK;
 }
+// ---- item-sharded index, lists mode (srn_shard.hip): the steps either side of the exchanges; device buffers, asynchronous on `stream` ----
+bool device_shard_lists_supported(DeviceState* d, const FlatIndex& ix, const LaunchParams& p) {
+    Geometry g;
+    return make_geometry(d, ix, p, 0, g) == SRN_OK && g.masks && p.flags == 0 && p.stats == nullptr && p.nb_rank == nullptr;
+}
+uint32_t device_prep_stride(uint32_t max_len) { return (uint32_t)(sizeof(PrepHead) + (size_t)max_len * sizeof(PrepItem)); }
+int device_shard_lists_head(DeviceState* d, const LaunchParams& p, void* pos, int* head, void* stream) {
+    HIP_TRY(hipSetDevice(d->device));
+    if (p.nq == 0) return SRN_OK;
+    HIP_TRY(launch_shard_lists_head((hipStream_t)stream, d->di, p.items_flat, p.q_off, p.nq, p.m, p.max_len, (ShardPos*)pos, head));
+    return SRN_OK;
+}
+int device_shard_lists_count(DeviceState* d, const LaunchParams& p, const void* pos, const int* head, uint32_t* kept, int* tot, void* stream) {
+    HIP_TRY(hipSetDevice(d->device));
+    if (p.nq == 0) return SRN_OK;
+    HIP_TRY(launch_shard_lists_count((hipStream_t)stream, d->di, p.q_off, p.nq, p.max_len, (const ShardPos*)pos, head, kept, tot));
+    return SRN_OK;
+}
+int device_shard_lists_copy(DeviceState* d, const LaunchParams& p, const void* pos, const uint32_t* kept, const long long* off, uint32_t* out, void* stream) {
+    HIP_TRY(hipSetDevice(d->device));
+    if (p.nq == 0) return SRN_OK;
+    HIP_TRY(launch_shard_lists_copy((hipStream_t)stream, d->di, p.nq, p.max_len, (const ShardPos*)pos, kept, off, out));
+    return SRN_OK;
+}
+int device_shard_lists_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p, uint32_t n_shards, const uint32_t* kept_g, const long long* off_g,
+                               unsigned long long shard_stride, const uint32_t* lists_g, const int* head, const void* pos_local, char* records, void* stream) {
+    HIP_TRY(hipSetDevice(d->device));
+    if (p.nq == 0) return SRN_OK;
+    if (!device_shard_lists_supported(d, ix, p)) return fail(SRN_EINVAL, "lists mode needs position-set slots (sessions of <= 8 items, complete lists) and no business rules: use the three-stage pipeline");
+    const uint32_t stride = device_prep_stride(p.max_len);
+    HIP_TRY(launch_shard_prep((hipStream_t)stream, p.items_flat, p.q_off, p.nq, p.max_len, n_shards, kept_g, off_g, shard_stride, head, (const ShardPos*)pos_local, records, stride));
+    ExtLists ext{records, stride, lists_g};
+    return device_predict(d, ix, p, true, stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &ext);
+}
+
 int device_slot_bytes(DeviceState* d, const FlatIndex& ix, uint32_t max_len, uint32_t* num_bits) {   // element size of the packed candidate / neighbour buffers
     LaunchParams p{}; p.max_len = max_len; p.k = 1; p.m = 1; Geometry g;
     if (make_geometry(d, ix, p, 0, g) != SRN_OK) return -1;
