@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--mode", default="replicas", choices=["replicas", "item-sharded"],
                     help="replicas: every GPU holds the index and serves its own queries (default, no data-path collective); "
                          "item-sharded: the north-star capacity mode, index split by item over the GPUs, 3 RCCL collectives per batch")
+    ap.add_argument("--shard-pipeline", default="auto", choices=["auto", "lists", "stages"],
+                    help="item-sharded mode: exchange the posting lists and run the unsharded kernels (lists), or the three-stage pipeline (stages)")
     ap.add_argument("--builder", default="gpu", choices=["gpu", "host"], help="index construction: rocPRIM sorts on the GPU, or the host builder (same bytes)")
     ap.add_argument("--parity", type=int, default=2048, help="queries of batch 0 checked against the canonical oracle before anything is timed (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -100,7 +102,7 @@ def main():
     how_many, last_items = synth.HOW_MANY, synth.LAST_ITEMS
     sharded_mode = args.mode == "item-sharded"
     if sharded_mode and args.batch == 1 << 20:
-        args.batch = 16384          # the exchange buffers are per query and shard
+        args.batch = 16384 if args.shard_pipeline == "stages" else 1 << 18          # the exchange buffers are per query and shard
     t0 = time.time()
     off, items, ts = synth.training_sessions(inter, n_items)
     t_gen = time.time() - t0
@@ -140,7 +142,7 @@ def main():
     def step(i, nq=None):
         d_flat, d_off, _, _ = batches[i % args.pool]
         if sharded_mode:
-            res = SH.predict_batch_sharded(index, comm, d_flat, d_off, B, last_items, k, m, how_many, False, stream.cuda_stream)
+            res = SH.predict_batch_sharded(index, comm, d_flat, d_off, B, last_items, k, m, how_many, False, stream.cuda_stream, args.shard_pipeline)
             out_cnt.copy_(res[2])
         else:
             sa.predict_batch_device(index, d_flat.data_ptr(), d_off.data_ptr(), B if nq is None else nq, last_items, k, m, how_many, False,
@@ -157,7 +159,7 @@ def main():
         pf, po = flat0[:qo0[n_par]], qo0[:n_par + 1]
         ref = oix.predict_batch("canonical", pf, po, k, m, how_many, False, threads=usable_cores())
         if sharded_mode:
-            res = SH.predict_batch_sharded(index, comm, batches[0][0], batches[0][1], B, last_items, k, m, how_many, False, stream.cuda_stream)
+            res = SH.predict_batch_sharded(index, comm, batches[0][0], batches[0][1], B, last_items, k, m, how_many, False, stream.cuda_stream, args.shard_pipeline)
             torch.cuda.synchronize()
             g_ids = res[0].cpu().numpy().view(np.uint64).reshape(B, how_many)[:n_par]
             g_sc = res[1].cpu().numpy().reshape(B, how_many)[:n_par]
@@ -177,7 +179,7 @@ def main():
             os._exit(1)
         parity_checked = n_par
     elif rank != 0 and sharded_mode and args.parity > 0:
-        SH.predict_batch_sharded(index, comm, batches[0][0], batches[0][1], B, last_items, k, m, how_many, False, stream.cuda_stream)   # rank 0's check is a collective call
+        SH.predict_batch_sharded(index, comm, batches[0][0], batches[0][1], B, last_items, k, m, how_many, False, stream.cuda_stream, args.shard_pipeline)   # rank 0's check is a collective call
 
     barrier = D.barrier
     for i in range(args.warmup):
@@ -204,7 +206,8 @@ def main():
     if sharded_mode:
         if rank == 0:
             # roofline of the capacity mode: the same algorithmic bytes (every datum is touched once, on the shard that owns it) against
-            # the whole step (three stage launches + three collectives): the stages are the general kernel cut at its exchange points
+            # the whole step (lists pipeline: 4 small kernels + the unsharded launch sequence + 2 exchanges; stages: 3 launches + 3 collectives)
+            lists = args.shard_pipeline == "lists" or (args.shard_pipeline == "auto" and SH.lists_supported(index, last_items, k, m, how_many, False))
             nstat = min(B, 8192)
             bq_mean = None
             try:
@@ -218,7 +221,7 @@ def main():
             roof = None
             if bq_mean is not None:
                 ach = bq_mean * B / (ms_step * 1e-3) / 1e9
-                roof = {"bound": "hbm", "kernel": "item-sharded step (stages A, B, C + 3 collectives)", "achieved": ach, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                roof = {"bound": "hbm", "kernel": "item-sharded step (%s)" % ("lists exchange + unsharded kernels over row fragments" if lists else "stages A, B, C + 3 collectives"), "achieved": ach, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                         "frac": ach / (HBM_PEAK_GBS * world), "traffic": None, "algorithmic_bytes_per_query": bq_mean, "queries_per_launch": B}
             cpu = None
             if world == 1 and not args.no_cpu_baseline and oix is not None:
@@ -230,7 +233,8 @@ def main():
             out = dict(common)
             out.update({"value": args.steps * B / elapsed, "ms_per_step": ms_step, "scaling": "strong",
                         "config": {"workload": "synth.CONFIGS[%s], index item-sharded over %d GPU(s), every rank sees the whole batch" % (args.config, world),
-                                   "name": args.config, "batch": B, "parallelism": "item-sharded x%d: all-gather + all-reduce(min) + all-gather per batch" % world,
+                                   "name": args.config, "batch": B, "parallelism": "item-sharded x%d, %s" % (world, "lists pipeline: all-reduce(max) + all-gather of the posting lists + all-gather of the top-n per batch" if lists
+                                                                                else "three-stage pipeline: all-gather + all-reduce(min) + all-gather per batch"),
                                    "items_on_rank0": int(info["n_items"]), "index_bytes_hbm_rank0": int(info["device_bytes"])},
                         "roofline": roof, "cpu_baseline": cpu, "parity_checked": parity_checked, "queries_served_last_step": served,
                         "note": "capacity mode; the headline bench line is --mode replicas"})

@@ -67,7 +67,7 @@ class ShardedVMISIndex:
         capi.check(capi.lib().srn_index_save(self._h, str(path).encode()))
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and capi is not None and getattr(capi, "lib", None) is not None:   # (None at interpreter shutdown)
             capi.lib().srn_index_free(self._h)
             self._h = None
 
