@@ -219,7 +219,9 @@ def _nccl_worker(port, q):
         flat, qoff = flatten(qs)
         d_flat, d_off = _to_dev(flat, qoff)
         ix = sharded.ShardedVMISIndex(off, items, ts, 150, 12, 1.0, 0, 1, device=0)
-        res = sharded.predict_batch_sharded(ix, comm, d_flat, d_off, len(qs), 5, 40, 150, 21)
+        res = sharded.predict_batch_sharded(ix, comm, d_flat, d_off, len(qs), 5, 40, 150, 21, mode="lists")
+        res2 = sharded.predict_batch_sharded(ix, comm, d_flat, d_off, len(qs), 5, 40, 150, 21, mode="stages")
+        assert all(torch.equal(a, b) for a, b in zip(res, res2)), "the two pipelines disagree"
         # and the exchange steps of a multi-rank run on device buffers: all-reduce(max), all-reduce(min), all-gather
         t = torch.arange(1000, dtype=torch.int64, device=dev)
         assert torch.equal(comm.all_reduce_max(t.clone()), t) and torch.equal(comm.all_reduce_min(t.to(torch.int32).clone()), t.to(torch.int32))
@@ -271,8 +273,11 @@ def _worker(rank, world, port, q):
         flat, qoff = flatten(qs)
         d_flat, d_off = _to_dev(flat, qoff)
         ix = sharded.ShardedVMISIndex(off, items, ts, 150, 12, 1.0, rank, world, device=0)
-        res = sharded.predict_batch_sharded(ix, sharded.DistComm(), d_flat, d_off, len(qs), 5, 40, 150, 21)
+        assert sharded.lists_supported(ix, 5, 40, 150, 21)
+        res = sharded.predict_batch_sharded(ix, sharded.DistComm(), d_flat, d_off, len(qs), 5, 40, 150, 21)                       # (auto: the lists pipeline)
+        res2 = sharded.predict_batch_sharded(ix, sharded.DistComm(), d_flat, d_off, len(qs), 5, 40, 150, 21, mode="stages")
         torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(res, res2)), "the two pipelines disagree"
         q.put((rank, [x.cpu().numpy() for x in res]))
         D.barrier()
         dist.destroy_process_group()
