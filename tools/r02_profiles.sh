@@ -7,6 +7,8 @@ python bench.py > $O/bench_cfg3.json 2> $O/bench_cfg3.err
 python bench.py --config cfg2 --no-cpu-baseline > $O/bench_cfg2.json 2>/dev/null
 python bench.py --config cfg4 --no-cpu-baseline > $O/bench_cfg4.json 2>/dev/null
 python bench.py --mode item-sharded --steps 10 > $O/bench_sharded_g1_cfg3.json 2>/dev/null
+python bench.py --mode item-sharded --shard-pipeline stages --steps 10 --no-cpu-baseline > $O/bench_sharded_stages_g1_cfg3.json 2>/dev/null
+( python tools/shard_lists_rank_time.py cfg3 8; python tools/shard_lists_rank_time.py cfg3 2; python tools/shard_lists_rank_time.py cfg5_8th 8 65536 ) 2>&1 | grep -v "^  File\|Error\|Exception ignored\|Traceback\|amdgpu.ids" > $O/shard_lists_rank_time.txt
 python tools/latency_probe.py cfg3 > $O/latency_cfg3.txt 2>&1
 python tools/phase_profile.py cfg3 131072 > $O/phase_cfg3.log 2>&1
 cd /tmp && export TMPDIR=/tmp
