@@ -233,7 +233,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         const uint32_t L = hd.L, n = hd.n_staged, U = hd.U;
         unsigned long long rm = __ballot(x0.kept > 0u);
         const uint32_t nr = (uint32_t)__popcll(rm);
-        const bool fits = L >= 1u && L <= 8u && L <= p.max_len && hd.sumw <= 15u && nr <= 4u && 2u * n + 8u <= F_MERGE_WORDS;
+        const bool fits = L >= 1u && L <= 8u && L <= p.max_len && hd.sumw <= 15u && nr <= f.max_runs && 2u * n + 8u <= F_MERGE_WORDS;
         if (!fits) {   // block-uniform: the general kernel takes it
             if (tid == 0) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q;
             continue;
@@ -262,10 +262,12 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         __syncthreads();   // previous query's LDS reads are done
         FAST_TICK(0);
         if (tid < (uint32_t)FS_TACC) misc[tid] = 0;
-        if (tid < (1u << L)) {
-            uint32_t num = 0;
-            for (uint32_t b = 0; b < L; ++b) if ((tid >> b) & 1u) num += L - b;
-            const uint32_t mp = tid ? (uint32_t)__ffs((int)tid) - 1u : 0u;   // lowest set position = first match (Q4)
+        // A slot's low bits are the set of RUNS (not evolving positions) that hold the session: <= 4 runs, so 4 bits (3 with f.max_runs == 3) whatever the
+        // session length, and 28 (29) bits for the rank.  Runs are numbered in position order, so the lowest set run is the first match (Q4).
+        if (tid < (1u << nr)) {
+            const uint32_t num = ((tid & 1u) ? L - ps[0] : 0u) + ((tid & 2u) ? L - ps[1] : 0u) + ((tid & 4u) ? L - ps[2] : 0u) + ((tid & 8u) ? L - ps[3] : 0u);
+            const uint32_t lo = tid ? (uint32_t)__ffs((int)tid) - 1u : 0u;
+            const uint32_t mp = lo == 0u ? ps[0] : lo == 1u ? ps[1] : lo == 2u ? ps[2] : ps[3];
             wlut[tid] = (uint8_t)num; w10t[tid] = (uint16_t)((9u - mp) * num);
         }
         uint32_t K;
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             // its first min(n, m) entries, the neighbours the first k of those.  No merge, no m-cut, no k-cut: the list goes straight into the neighbour list.
             K = min(kp[0], p.k);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { const uint32_t e = tid + j * BLOCK; if ((uint32_t)j * BLOCK < K && e < K) nbl[e] = (v[0][j] << NB) | (1u << ps[0]); }
+            for (int j = 0; j < 3; ++j) { const uint32_t e = tid + j * BLOCK; if ((uint32_t)j * BLOCK < K && e < K) nbl[e] = (v[0][j] << NB) | 1u; }
             __syncthreads();
             FAST_TICK(1);
         } else {
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             for (int r = 0; r < 4; ++r) {
                 uint32_t* const dst = (r < 2 ? d01 : r == 2 ? d2 : B0) + (r == 0 ? 0u : r == 1 ? s1 : r == 2 ? s2 : s3);
 #pragma unroll
-                for (int j = 0; j < 5; ++j) { const uint32_t e = tid + j * BLOCK; if ((uint32_t)j * BLOCK < kp[r] && e < kp[r]) dst[e] = (v[r][j] << NB) | (1u << ps[r]); }
+                for (int j = 0; j < 5; ++j) { const uint32_t e = tid + j * BLOCK; if ((uint32_t)j * BLOCK < kp[r] && e < kp[r]) dst[e] = (v[r][j] << NB) | (1u << r); }
             }
         }
         __syncthreads();

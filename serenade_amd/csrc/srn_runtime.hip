@@ -27,7 +27,7 @@ namespace srn {
 // srn_debug_reload_knobs() re-reads them (the tests switch kernel paths between calls).  All defaults = production behaviour.
 struct Knobs {
     bool no_masks = false, no_merge = false, dense = false, no_fast = false, debug = false;
-    int hot_slots = -1, sketch_slots = -1, lds_budget_kb = 0, grid_mult = 16;
+    int hot_slots = -1, sketch_slots = -1, lds_budget_kb = 0, grid_mult = 16, fast_runs = 0;
     bool geometry_default() const { return !no_masks && !no_merge && !dense && hot_slots < 0 && sketch_slots < 0 && lds_budget_kb == 0; }
 };
 static Knobs g_knobs; static std::once_flag g_knobs_once; static std::mutex g_knobs_mu;
@@ -39,6 +39,7 @@ static void knobs_read() {
     if (const char* e = getenv("SRN_SKETCH_SLOTS")) k.sketch_slots = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_LDS_BUDGET_KB")) k.lds_budget_kb = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_GRID_MULT")) k.grid_mult = std::max(1, atoi(e));
+    if (const char* e = getenv("SRN_FAST_RUNS")) k.fast_runs = atoi(e) == 3 ? 3 : 0;   // tests: the fast kernel's 29-bit-rank form (3 lists per query) on a small index
     std::lock_guard<std::mutex> lk(g_knobs_mu); g_knobs = k;
 }
 static Knobs knobs() { std::call_once(g_knobs_once, knobs_read); std::lock_guard<std::mutex> lk(g_knobs_mu); return g_knobs; }
@@ -455,8 +456,12 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     char* spill = w->spill;
     const uint32_t prep_stride = (uint32_t)(sizeof(PrepHead) + (size_t)p.max_len * sizeof(PrepItem));
     if (!ext) { int rc = ensure(&w->prep, &w->prep_bytes, (size_t)p.nq * prep_stride); if (rc) return rc; }
-    const bool fast = d->fast.row_packed != nullptr && geo.masks && !slot64 && kn.geometry_default() && !kn.no_fast && p.k <= F_K_MAX && p.m <= F_M_MAX &&
-                      p.how_many <= 24 && p.flags == 0 && p.stats == nullptr && p.nb_rank == nullptr && p.max_len <= 8 && c.num_bits <= 8;
+    // the fast kernel packs (rank, set of <= 4 lists) into 32 bits whatever the general kernel's slots look like: up to 2^28 sessions with 4 lists per query,
+    // up to 2^29 with 3 (queries with more go to the general kernel)
+    const int rank_bits_f = std::max(1, bits_host(ix.n_kept ? ix.n_kept - 1 : 0));
+    const uint32_t nb_fast = kn.fast_runs == 3 && rank_bits_f <= 29 ? 3u : rank_bits_f <= 28 ? 4u : rank_bits_f <= 29 ? 3u : 0u;
+    const bool fast = d->fast.row_packed != nullptr && geo.masks && nb_fast != 0 && kn.geometry_default() && !kn.no_fast && p.k <= F_K_MAX && p.m <= F_M_MAX &&
+                      p.how_many <= 24 && p.flags == 0 && p.stats == nullptr && p.nb_rank == nullptr && p.max_len <= 8;
     if (fast) {   // (all allocations of a call happen before its first launch)
         if (w->slow_cap < p.nq) { if (w->slow_list) HIP_TRY(hipFree(w->slow_list)); w->slow_list = nullptr; w->slow_cap = 0;
             HIP_TRY(hipMalloc((void**)&w->slow_list, (size_t)p.nq * 4 + 64)); w->slow_cap = p.nq; }
@@ -477,7 +482,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         HIP_TRY(hipMemsetAsync(w->slow_cnt, 0, 16, st));   // (slow_cnt[0] = handed-over queries, [2..3] = the 64-bit ticket of vmis_finish_big_kernel's list)
         const uint32_t grid_f = (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * F_WG_PER_CU * grid_mult);
         const uint64_t big_entries = std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)p.nq * 16 + 4096);
-        FastParams fp = d->fast; fp.slow_list = w->slow_list; fp.slow_cnt = w->slow_cnt; fp.nb = c.num_bits; fp.fin = w->fin;
+        FastParams fp = d->fast; fp.slow_list = w->slow_list; fp.slow_cnt = w->slow_cnt; fp.nb = nb_fast; fp.max_runs = nb_fast; fp.fin = w->fin;
         fp.big_arena = w->big; fp.big_list = (uint32_t*)(w->big + big_entries * 16); fp.big_ticket = (unsigned long long*)(w->slow_cnt + 2); fp.big_cap_entries = (uint32_t)big_entries;
         HIP_TRY(launch_fast(dim3(grid_f), st, di, p, fp));
         HIP_TRY(hipEventRecord(ev[4], st));

@@ -60,7 +60,7 @@ def test_kat1_should_train_and_predict():
         assert r.score == pytest.approx(1.751319134149782, rel=1e-12)
 
 
-@pytest.fixture(params=["default", "no_fast", "no_masks", "no_hot", "hot64", "no_sketch", "sketch64", "no_merge", "dense"])
+@pytest.fixture(params=["default", "no_fast", "fast_runs3", "no_masks", "no_hot", "hot64", "no_sketch", "sketch64", "no_merge", "dense"])
 def kernel_path(request, monkeypatch):
     """The kernel picks code paths per launch: position-set slots (sessions <= 8 items) vs numerator slots + first-match
     pass; direct-mapped accumulators for popular items vs hash only; sketch pre-filter on / off / tiny; candidate sessions by
@@ -81,6 +81,8 @@ def kernel_path(request, monkeypatch):
     elif request.param == "sketch64":          # heavy collisions in the upper-bound words: the filter must stay exact
         monkeypatch.setenv("SRN_SKETCH_SLOTS", "64")
         monkeypatch.setenv("SRN_HOT_SLOTS", "32")
+    elif request.param == "fast_runs3":        # the fast kernel's form for > 2^28 sessions: 29 rank bits + 3 list bits, queries with 4 lists handed over
+        monkeypatch.setenv("SRN_FAST_RUNS", "3")
     elif request.param == "no_fast":           # the general kernel alone (the fast kernel hands it single queries otherwise)
         monkeypatch.setenv("SRN_NO_FAST", "1")
     from serenade_amd import capi
