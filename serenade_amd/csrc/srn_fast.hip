@@ -178,7 +178,8 @@ __device__ __forceinline__ void merge_pair(const uint32_t* in, uint32_t* out, ui
 // FRAG (an item shard in lists mode): the row slots are 16-byte FRAGMENT slots -- halfword 0 = length, halfwords 2..7 = items 0..5; fragments of > 6 items:
 // halfwords 2..5 = items 0..3, word 3 = the fragment's first overflow block (8 items each, items 4..) -- see rows_to_packed_frag_kernel; the general slots the
 // hits are resolved from are the 16-byte fragments of DeviceIndex::row_frag.
-template <int WG_PER_CU, bool FRAG>
+// WIDE (an index of > 2^28 sessions): 29 rank bits + 3 list bits per slot, see NB in the kernel.
+template <int WG_PER_CU, bool FRAG, bool WIDE>
 #ifndef SRN_FAST_WAVES
 #define SRN_FAST_WAVES (WG_PER_CU * 2)
 #endif
@@ -218,7 +219,6 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
 
     unsigned long long* tacc = (unsigned long long*)(smem + F_MISC + FS_TACC * 4);   // 16 debug counters, kept across the queries
     if (tid < 16u) tacc[tid] = 0ull;
-    const uint32_t NB = f.nb, NBM = (1u << NB) - 1u;
     const bool ticking = p.phase_cycles != nullptr;
     const uint32_t n_kept = ix.n_kept;
     auto qpos = [&](uint32_t pq) -> uint32_t { return ((wave + NW * (pq >> 6)) << 6) + (pq & 63u); };   // the wave's own neighbour-list slots
@@ -233,7 +233,11 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         const uint32_t L = hd.L, n = hd.n_staged, U = hd.U;
         unsigned long long rm = __ballot(x0.kept > 0u);
         const uint32_t nr = (uint32_t)__popcll(rm);
-        const bool fits = L >= 1u && L <= 8u && L <= p.max_len && hd.sumw <= 15u && nr <= f.max_runs && 2u * n + 8u <= F_MERGE_WORDS;
+        // Slot = (rank - base) << NB | set of lists.  Normally NB = 4 (WIDE, above 2^28 sessions: 3) and base = 0.  A query with MORE lists than bits
+        // (4 lists on an index of > 2^28 sessions) takes NB = 4 with the ranks counted from the cut x_lo -- every staged entry is >= x_lo -- if that fits 28 bits.
+        const bool rel = WIDE && nr > 3u;   // (block-uniform)
+        const uint32_t NB = WIDE && !rel ? 3u : 4u, NBM = (1u << NB) - 1u, base = rel ? hd.xlo : 0u;
+        const bool fits = L >= 1u && L <= 8u && L <= p.max_len && hd.sumw <= 15u && nr <= 4u && 2u * n + 8u <= F_MERGE_WORDS && (!rel || hd.rmax - hd.xlo < (1u << 28));
         if (!fits) {   // block-uniform: the general kernel takes it
             if (tid == 0) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q;
             continue;
@@ -260,9 +264,15 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
 #pragma unroll
             for (int j = 0; j < 5; ++j) { v[r][j] = 0u; if ((uint32_t)j * BLOCK < kp[r]) v[r][j] = src[r][min(tid + j * BLOCK, kp[r] - 1u)]; }
         __syncthreads();   // previous query's LDS reads are done
+        // (opaque copies: with a compile-time shift the packing of a staged entry is otherwise hoisted into the conditional block of its load, which then
+        //  ends in s_waitcnt vmcnt(0) -- the lists' loads would go out one HBM round trip after the other instead of all together)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) asm volatile("" : "+v"(v[r][j]));
         FAST_TICK(0);
         if (tid < (uint32_t)FS_TACC) misc[tid] = 0;
-        // A slot's low bits are the set of RUNS (not evolving positions) that hold the session: <= 4 runs, so 4 bits (3 with f.max_runs == 3) whatever the
+        // A slot's low bits are the set of RUNS (not evolving positions) that hold the session: <= 4 runs, so 4 bits (3 above 2^28 sessions, see NB above) whatever the
         // session length, and 28 (29) bits for the rank.  Runs are numbered in position order, so the lowest set run is the first match (Q4).
         if (tid < (1u << nr)) {
             const uint32_t num = ((tid & 1u) ? L - ps[0] : 0u) + ((tid & 2u) ? L - ps[1] : 0u) + ((tid & 4u) ? L - ps[2] : 0u) + ((tid & 8u) ? L - ps[3] : 0u);
@@ -276,7 +286,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             // its first min(n, m) entries, the neighbours the first k of those.  No merge, no m-cut, no k-cut: the list goes straight into the neighbour list.
             K = min(kp[0], p.k);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { const uint32_t e = tid + j * BLOCK; if ((uint32_t)j * BLOCK < K && e < K) nbl[e] = (v[0][j] << NB) | 1u; }
+            for (int j = 0; j < 3; ++j) { const uint32_t e = tid + j * BLOCK; if ((uint32_t)j * BLOCK < K && e < K) nbl[e] = ((v[0][j] - base) << NB) | 1u; }
             __syncthreads();
             FAST_TICK(1);
         } else {
@@ -289,7 +299,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             for (int r = 0; r < 4; ++r) {
                 uint32_t* const dst = (r < 2 ? d01 : r == 2 ? d2 : B0) + (r == 0 ? 0u : r == 1 ? s1 : r == 2 ? s2 : s3);
 #pragma unroll
-                for (int j = 0; j < 5; ++j) { const uint32_t e = tid + j * BLOCK; if ((uint32_t)j * BLOCK < kp[r] && e < kp[r]) dst[e] = (v[r][j] << NB) | (1u << r); }
+                for (int j = 0; j < 5; ++j) { const uint32_t e = tid + j * BLOCK; if ((uint32_t)j * BLOCK < kp[r] && e < kp[r]) dst[e] = ((v[r][j] - base) << NB) | (1u << r); }
             }
         }
         __syncthreads();
@@ -390,7 +400,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         for (int t = 0; t < 3; ++t) {
             const uint32_t j = wave * 64u + lane + (uint32_t)t * BLOCK;
             svr[t] = K ? nbl[min(j, K - 1u)] : 0u;   // (all loads unconditional: a load inside a branch is waited for at the branch's end)
-            const size_t r = K ? (size_t)(svr[t] >> NB) : (size_t)n_kept;   // (idle lanes re-read the last neighbour's row)
+            const size_t r = K ? (size_t)(base + (svr[t] >> NB)) : (size_t)n_kept;   // (idle lanes re-read the last neighbour's row)
             if constexpr (FRAG) { rq[t] = *reinterpret_cast<const uint4*>(&f.row_packed[r]); rq1[t] = make_uint4(0u, 0u, 0u, 0u); }
             else { rq[t] = *reinterpret_cast<const uint4*>(&f.row_packed[r * 4]); rq1[t] = *reinterpret_cast<const uint4*>(&f.row_packed[r * 4 + 1]); }
         }
@@ -421,12 +431,12 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         auto q3_load = [&](uint32_t p0, uint32_t& sv, uint32_t& hdr, uint4& c4, uint4& d4, uint32_t& blk) {
             sv = nbl[qpos(min(p0 + lane, cnt3 - 1u))];
             if constexpr (FRAG) {
-                const uint4 s4 = *reinterpret_cast<const uint4*>(f.row_packed + (size_t)(sv >> NB));
+                const uint4 s4 = *reinterpret_cast<const uint4*>(f.row_packed + (size_t)(base + (sv >> NB)));
                 hdr = s4.x;
                 const uint4* eb = reinterpret_cast<const uint4*>(f.row_ext16) + ((hdr & 0xFFFFu) > 6u ? (size_t)s4.w : (size_t)0);   // (an idle lane's slot may be a short one)
                 c4 = eb[0]; d4 = eb[1]; blk = s4.w + 2u;
             } else {
-                const RowQuad* rowp = f.row_packed + (size_t)(sv >> NB) * 4;
+                const RowQuad* rowp = f.row_packed + (size_t)(base + (sv >> NB)) * 4;
                 hdr = *reinterpret_cast<const uint32_t*>(rowp); c4 = *reinterpret_cast<const uint4*>(rowp + 2); d4 = *reinterpret_cast<const uint4*>(rowp + 3); blk = d4.w;
             } };
         uint32_t sv3 = 0, hdr3 = 0, blk3 = 0; uint4 c43 = make_uint4(0u, 0u, 0u, 0u), d43 = c43;
@@ -600,7 +610,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             // across phase 4a -- at the 80-register cap of three workgroups per CU that means scratch spills on the serial paths
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
-                const size_t r = K ? (size_t)(svr[t] >> NB) : (size_t)n_kept;
+                const size_t r = K ? (size_t)(base + (svr[t] >> NB)) : (size_t)n_kept;
                 rq[t] = *reinterpret_cast<const uint4*>(&f.row_packed[r * 4]);
                 rq1[t] = *reinterpret_cast<const uint4*>(&f.row_packed[r * 4 + 1]);
             }
@@ -674,7 +684,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             bool ovf = false;
             for (uint32_t i = tid; i < nh; i += BLOCK) {
                 const uint2 h = hits[i];
-                const uint32_t* os = reinterpret_cast<const uint32_t*>(ix.row_slots + (size_t)(h.x >> NB) * (FRAG ? 1 : 4));
+                const uint32_t* os = reinterpret_cast<const uint32_t*>(ix.row_slots + (size_t)(base + (h.x >> NB)) * (FRAG ? 1 : 4));
                 const uint32_t len = os[0], j = h.y;
                 uint32_t it = EMPTY32;
                 if constexpr (FRAG) { if (j < len) it = len <= 3u ? os[1 + j] : (j < 2u ? os[2 + j] : ix.row_ext[os[1] + (j - 2u)]); }
@@ -874,7 +884,8 @@ hipError_t launch_finish(hipStream_t st, const DeviceIndex& di, const FastParams
 }
 
 hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f) {
-    auto kern = di.row_frag ? vmis_fast_kernel<(int)F_WG_PER_CU, true> : vmis_fast_kernel<(int)F_WG_PER_CU, false>;
+    auto kern = f.nb == 3u ? (di.row_frag ? vmis_fast_kernel<(int)F_WG_PER_CU, true, true> : vmis_fast_kernel<(int)F_WG_PER_CU, false, true>)
+                           : (di.row_frag ? vmis_fast_kernel<(int)F_WG_PER_CU, true, false> : vmis_fast_kernel<(int)F_WG_PER_CU, false, false>);
     constexpr size_t dyn = SRN_FAST_SMALL ? 0 : F_TOTAL;
     if (dyn) { hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); if (e != hipSuccess) return e; }
     static bool told = false;

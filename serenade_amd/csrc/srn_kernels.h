@@ -71,7 +71,7 @@ struct FastParams {
     char* big_arena; uint32_t* big_list; unsigned long long* big_ticket; uint32_t big_cap_entries;   // queries with > 63 entries: overflow entries, list for vmis_finish_big_kernel,
                                                                                                       // ticket = (list length << 32 | arena entries in use)
     uint32_t nb;                // low bits of a session slot that hold the set of runs (lists) with the session: 4, or 3 when the ranks need 29 bits
-    uint32_t max_runs;          // = nb: queries with more non-empty lists go to the general kernel
+    uint32_t max_runs;          // = nb (a query with more lists than that takes 4 bits and ranks relative to its cut x_lo, if they fit 28 bits)
 };
 
 // ---- launchers (srn_kernels.hip) -------------------------------------------------------------

@@ -1274,7 +1274,7 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
                 if (ix.row_frag != 0u) isum = walk_a_rows();   // (an item shard in lists mode: 16-byte fragment slots, walk_rows reads both kinds)
                 else
                 if (SK && !GLOBAL_TABLES) isum = walk_rounds(nb_lds, nbl, [&](const auto& it, int w) { add_items_pos(it, (uint32_t)w); });   // (region A in LDS)
-                else isum = walk_rounds(nb_lds, nbl, [&](const auto& it, int w) { add_items(it, (uint32_t)w, 0u); });
+                else isum = walk_rounds(nb_lds, nbl, [&](const auto& it, int w) { add_items(it, (uint32_t)w, (uint32_t)w); });   // (global-table pass: the sketch words need their sums too)
             } else isum = walk_a_rows();
             isum = wave_sum(isum);
             if (lane == 0 && p.stats && isum) atomicAdd((uint32_t*)&misc[S_I], isum);

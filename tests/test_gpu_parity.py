@@ -226,6 +226,37 @@ def test_retry_path_with_global_tables():
     assert (res["stats"][6:, 7] == 0).all()
 
 
+def test_global_table_pass_with_position_sets_and_sketch_filter():
+    """The global-table pass in its production form: sessions of <= 8 items (position-set slots), the sketch pre-filter ON (no debug
+    outputs) and most scored items outside the direct-mapped range.  Heavy items with lists of ~30 K sessions make L * m overflow the LDS
+    session table; the pass must still feed the sketch words (found on config 5: it added 0 there and lost every non-popular item)."""
+    import serenade_amd as sa
+    O = _oracle()
+    rng = np.random.default_rng(21)
+    n_heavy, n_tail, n_sessions = 10, 30000, 200000
+    heavy = (np.arange(n_heavy, dtype=np.uint64) + 1) * 7
+    tail = (np.arange(n_tail, dtype=np.uint64) + 1) * 1000 + 3
+    off, items = [0], []
+    for s in range(n_sessions):
+        row = np.unique(np.concatenate([heavy[rng.choice(n_heavy, size=int(rng.integers(1, 3)))], tail[rng.choice(n_tail, size=int(rng.integers(2, 6)))]]))
+        items.extend(row.tolist()); off.append(len(items))
+    ts = (1 + rng.permutation(n_sessions)).astype(np.uint32)
+    off, items = np.array(off, np.uint64), np.array(items, np.uint64)
+    m, k, n = 40000, 1500, 21
+    gix = sa.VMISIndex.from_sessions(off, items, ts, m, 12, 1.0)
+    oix = O.OracleIndex(off, items, ts, m, 12, 1.0, fast=True)
+    qs = [heavy[rng.permutation(n_heavy)[:int(rng.integers(4, 9))]].tolist() for _ in range(12)] + [[int(heavy[0])], [int(tail[5]), int(heavy[2])]]
+    flat, qoff = flatten(qs)
+    ids, sc, cnt = sa.predict_batch(gix, (flat, qoff), k, m, n)            # 8 items at most: position sets; no debug outputs: the filter is on
+    nq, general, global_pass = gix.last_path_counts()
+    assert global_pass >= 8, "the heavy queries should have been served by the global-table pass"
+    ref = oix.predict_batch("canonical", flat, qoff, k, m, n, threads=4)
+    assert np.array_equal(cnt, ref["counts"])
+    assert np.array_equal(ids, ref["ids"])
+    np.testing.assert_allclose(sc, ref["scores"], rtol=SCORE_RTOL, atol=0)
+    assert (np.isin(ids[:12], tail).sum(axis=1) > 0).all(), "the case needs non-popular items among the results"
+
+
 def test_synthetic_tiny_config_matches_oracle(kernel_path):
     """The bench generator's `tiny` config end to end (u64 hashed ids, unique timestamps, k/m cuts hit)."""
     import serenade_amd as sa

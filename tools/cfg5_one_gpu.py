@@ -41,6 +41,23 @@ e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 5
 say("unsharded, %d queries per call, resident: %.2f ms per call = %.2f M queries/s; path counts (nq, general, global pass) %s" % (B, ms, B / ms / 1e3, full.last_path_counts()))
 ref_ids = out_ids.cpu().numpy().view(np.uint64).reshape(B, n).copy(); ref_sc = out_sc.cpu().numpy().reshape(B, n).copy(); ref_cnt = out_cnt.cpu().numpy().view(np.uint32).copy()
+# path equivalence: the general kernel alone (u64 slots at this size) must give the same bytes as fast kernel + hand-overs
+from serenade_amd import capi
+os.environ["SRN_NO_FAST"] = "1"; capi.reload_knobs()
+run(); torch.cuda.synchronize()
+e0.record(); run(); e1.record(); torch.cuda.synchronize()
+same_paths = np.array_equal(out_ids.cpu().numpy().view(np.uint64).reshape(B, n), ref_ids) and np.array_equal(out_sc.cpu().numpy().reshape(B, n), ref_sc) and np.array_equal(out_cnt.cpu().numpy().view(np.uint32), ref_cnt)
+say("general kernel alone: %.2f ms per call = %.2f M queries/s; identical to the fast path's results: %s" % (e0.elapsed_time(e1), B / e0.elapsed_time(e1) / 1e3, same_paths))
+del os.environ["SRN_NO_FAST"]; capi.reload_knobs()
+if not same_paths:
+    gi = out_ids.cpu().numpy().view(np.uint64).reshape(B, n); gs = out_sc.cpu().numpy().reshape(B, n); gc = out_cnt.cpu().numpy().view(np.uint32)
+    bad = np.nonzero((gi != ref_ids).any(1) | (gs != ref_sc).any(1) | (gc != ref_cnt))[0]
+    say("differing queries: %d of %d; first: %s" % (len(bad), B, bad[:8]))
+    for q in bad[:4]:
+        say(" q", q, "L", qo[q + 1] - qo[q], "items", qi[qo[q]:qo[q + 1]], "counts fast/general", ref_cnt[q], gc[q])
+        say("   fast   ", ref_ids[q][:8], ref_sc[q][:8])
+        say("   general", gi[q][:8], gs[q][:8])
+    if "--stop-on-diff" in sys.argv: sys.exit(1)
 
 # ---- 8 shards, all on this GPU ----
 G = 8
