@@ -9,6 +9,15 @@ namespace srn {
 
 static constexpr int MAX_PROBES = 48;       // bucket probes (4 slots each) before a table is declared full
 
+// passes_business_rules, src/vmisknn/mod.rs:162-182; attribute byte SRN_ATTR_NONE = None
+__device__ __forceinline__ bool business_ok(uint32_t cur, uint32_t reco) {
+    if (reco == SRN_ATTR_NONE) return false;
+    if (reco & SRN_ATTR_FOR_SALE) {
+        if (reco & SRN_ATTR_ADULT) return cur != SRN_ATTR_NONE && (cur & SRN_ATTR_ADULT);
+        return true;
+    }
+    return false;
+}
 __device__ __forceinline__ uint64_t dev_mix64(uint64_t x) {   // the id table's hash (srn_index.cpp mix64)
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
     x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;

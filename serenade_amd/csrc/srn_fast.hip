@@ -2,7 +2,7 @@
 // VMIS-kNN predict_next on gfx950 (MI355X): the FAST kernel -- the lean instantiation of the path for the query shape a
 // production workload consists of: evolving sessions of <= 8 items of which <= 4 distinct known ones
 // have a non-empty posting list above x_lo, position-set slots (MASKS), 32-bit slots, k <= 1536, m <= 2560, how_many <= 24,
-// no business rules, no debug outputs.  Everything else -- and every query this kernel meets that does not fit -- is
+// business rules on or off, no debug outputs.  Everything else -- and every query this kernel meets that does not fit -- is
 // queued on a device-side list and served by vmis_predict_kernel (srn_kernels.hip) in a second launch: still on the GPU,
 // same results, bit for bit.  Same algorithm as the general kernel (find_neighbors src/vmisknn/vmis_index.rs:325-415,
 // predict src/vmisknn/mod.rs:118-215, canonical semantics of DESIGN.md section 1); what differs:
@@ -220,6 +220,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
     unsigned long long* tacc = (unsigned long long*)(smem + F_MISC + FS_TACC * 4);   // 16 debug counters, kept across the queries
     if (tid < 16u) tacc[tid] = 0ull;
     const bool ticking = p.phase_cycles != nullptr;
+    const bool business = (p.flags & SRN_FLAG_BUSINESS_LOGIC) != 0u;   // (launch-uniform)
     const uint32_t n_kept = ix.n_kept;
     auto qpos = [&](uint32_t pq) -> uint32_t { return ((wave + NW * (pq >> 6)) << 6) + (pq & 63u); };   // the wave's own neighbour-list slots
 
@@ -254,6 +255,9 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             rm &= rm - 1ull;
         }
         const uint32_t cur_idx = (uint32_t)__builtin_amdgcn_readlane((int)x0.idx, 0);
+        // business rules (mod.rs:162-182): the current item's attribute byte, one more uniform look-up that travels with the list loads
+        uint32_t cur_attr = SRN_ATTR_NONE;
+        if (business && cur_idx != kNone) cur_attr = ix.meta[cur_idx].attr;
         const uint32_t s1 = kp[0], s2 = s1 + kp[1], s3 = s2 + kp[2];
 
         // The stage loads go out BEFORE the barrier that ends the previous query: waves 1..7 get here while wave 0 still ranks that
@@ -486,9 +490,11 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             const uint32_t e = lane * NW + wave;
             const uint32_t v = hot[e];
             for (uint32_t i = tid; i < F_DUMP_WORDS; i += BLOCK) ((uint32_t*)(smem + F_DUMP))[i] = 0u;   // (walk B reads the dump words, where the positions past a row's end point, as "cannot reach the floor")
-            const bool valid = v != 0u && e != cur_idx;
+            bool valid = v != 0u && e != cur_idx;
             double x = 0.0; uint32_t tie = 0;
-            { const ItemMeta mt = f.meta_sample[tid]; if (valid) { x = (mt.idf > 0.0 ? mt.idf : 1.0) * (double)v; tie = mt.id_rank; } }   // (coalesced, unconditional)
+            { const ItemMeta mt = f.meta_sample[tid];   // (coalesced, unconditional)
+              if (business) valid = valid && business_ok(cur_attr, mt.attr);   // an item the rules exclude is no candidate and sets no threshold
+              if (valid) { x = (mt.idf > 0.0 ? mt.idf : 1.0) * (double)v; tie = mt.id_rank; } }
             const uint32_t k32 = (uint32_t)((unsigned long long)__double_as_longlong(x) >> 32);
             {
                 uint32_t vv = k32, third = 0;
@@ -558,7 +564,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
                 const uint32_t sv = surv[i], e = sv >> 20, v = sv & 0xFFFFFu;
                 const ItemMeta mt = ix.meta[e];
                 const double x = (mt.idf > 0.0 ? mt.idf : 1.0) * (double)v;
-                const bool take = (uint32_t)((unsigned long long)__double_as_longlong(x) >> 32) >= t32m1;
+                const bool take = (uint32_t)((unsigned long long)__double_as_longlong(x) >> 32) >= t32m1 && (!business || business_ok(cur_attr, mt.attr));
                 const uint32_t at = wave_append(take, &misc[FS_CCNT]);
                 if (take) { if (at < F_CAND_CAP) { ckey[at] = (unsigned long long)__double_as_longlong(x); cidx[at] = mt.id_rank; } else misc[FS_FAIL] = 1; }
             }
@@ -690,6 +696,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
                 if constexpr (FRAG) { if (j < len) it = len <= 3u ? os[1 + j] : (j < 2u ? os[2 + j] : ix.row_ext[os[1] + (j - 2u)]); }
                 else
                 if (j < len) it = len <= 15u ? os[1 + j] : (j < 14u ? os[2 + j] : ix.row_ext[os[1] + (j - 14u)]);
+                if (business && it != EMPTY32 && it >= F_HOT_WORDS && !business_ok(cur_attr, ix.meta[it].attr)) it = EMPTY32;   // (one more gather per listed element, all in flight together)
                 if (it != EMPTY32 && it >= F_HOT_WORDS && item_insert(ikeys, iacc, F_TABLE_BUCKETS, it, (int)w10t[h.x & NBM]) < 0) ovf = true;
             }
             if (ovf) atomicOr(&misc[FS_FAIL], 8u);

@@ -70,15 +70,6 @@ __device__ __forceinline__ double key_score(uint64_t k) {
     uint64_t b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
     return __longlong_as_double((long long)b);
 }
-// passes_business_rules, src/vmisknn/mod.rs:162-182; attribute byte SRN_ATTR_NONE = None
-__device__ __forceinline__ bool business_ok(uint32_t cur, uint32_t reco) {
-    if (reco == SRN_ATTR_NONE) return false;
-    if (reco & SRN_ATTR_FOR_SALE) {
-        if (reco & SRN_ATTR_ADULT) return cur != SRN_ATTR_NONE && (cur & SRN_ATTR_ADULT);
-        return true;
-    }
-    return false;
-}
 
 // -------------------------------------------------------------------------------------
 // r-th largest key among the valid entries of `n` slots (keys distinct and < 2^nbits, 1 <= r <= #valid):

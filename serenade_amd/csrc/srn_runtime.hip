@@ -213,6 +213,11 @@ int device_update_attr(DeviceState* d, const FlatIndex& ix) {
     std::vector<ItemMeta> meta(ix.n_items);
     for (size_t i = 0; i < ix.n_items; ++i) meta[i] = ItemMeta{ix.idf[i], ix.id_rank[i], ix.attr[i]};
     HIP_TRY(hipMemcpy(d->d_meta, meta.data(), meta.size() * sizeof(ItemMeta), hipMemcpyHostToDevice));
+    if (d->fast.meta_sample) {   // the fast kernel's copy of the 512 most popular items' records (same order as at attach)
+        std::vector<ItemMeta> ms(512, ItemMeta{0.0, 0u, 0u});
+        for (uint32_t w8 = 0; w8 < 8; ++w8) for (uint32_t l = 0; l < 64; ++l) if (8 * l + w8 < ix.n_items) ms[64 * w8 + l] = meta[8 * l + w8];
+        HIP_TRY(hipMemcpy((void*)d->fast.meta_sample, ms.data(), ms.size() * sizeof(ItemMeta), hipMemcpyHostToDevice));
+    }
     return SRN_OK;
 }
 uint64_t device_bytes(const DeviceState* d) { return d ? d->bytes : 0; }
@@ -461,7 +466,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     const int rank_bits_f = std::max(1, bits_host(ix.n_kept ? ix.n_kept - 1 : 0));
     const uint32_t nb_fast = kn.fast_runs == 3 && rank_bits_f <= 29 ? 3u : rank_bits_f <= 28 ? 4u : rank_bits_f <= 29 ? 3u : 0u;
     const bool fast = d->fast.row_packed != nullptr && geo.masks && nb_fast != 0 && kn.geometry_default() && !kn.no_fast && p.k <= F_K_MAX && p.m <= F_M_MAX &&
-                      p.how_many <= 24 && p.flags == 0 && p.stats == nullptr && p.nb_rank == nullptr && p.max_len <= 8;
+                      p.how_many <= 24 && (p.flags & ~(unsigned)SRN_FLAG_BUSINESS_LOGIC) == 0 && p.stats == nullptr && p.nb_rank == nullptr && p.max_len <= 8;
     if (fast) {   // (all allocations of a call happen before its first launch)
         if (w->slow_cap < p.nq) { if (w->slow_list) HIP_TRY(hipFree(w->slow_list)); w->slow_list = nullptr; w->slow_cap = 0;
             HIP_TRY(hipMalloc((void**)&w->slow_list, (size_t)p.nq * 4 + 64)); w->slow_cap = p.nq; }

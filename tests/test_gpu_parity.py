@@ -274,6 +274,29 @@ def test_synthetic_tiny_config_matches_oracle(kernel_path):
     assert (st[:, 1] == m).any() and (st[:, 2] == k).any(), "workload should hit both the m-cut and the k-cut"
 
 
+def test_business_rules_synthetic_tiny(kernel_path):
+    """Business rules (mod.rs:162-182) on the generator's tiny config: 20 K items, so that scored items lie outside the direct-mapped
+    range as well -- the fast kernel applies the rules to its threshold sample, to the floor survivors and to the elements it lists."""
+    import serenade_amd as sa
+    from serenade_amd import synth
+    O = _oracle()
+    inter, n_items, k, m, idfw = synth.CONFIGS["tiny"]
+    off, items, ts = synth.training_sessions(inter, n_items)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw)
+    oix = O.OracleIndex(off, items, ts, m, 34, idfw, fast=True)
+    rng = np.random.default_rng(44)
+    known = np.unique(items)
+    flags = rng.choice(np.array([0, 1, 2, 3, 0xFF], np.uint8), size=len(known), p=[0.15, 0.05, 0.5, 0.2, 0.1])
+    gix.set_attributes(known, flags)
+    oix.set_attributes(known, flags)
+    qi, qo = synth.queries(500, n_items)
+    nq = len(qo) - 1
+    qs = [qi[qo[i]:qo[i + 1]].tolist() for i in range(nq)]
+    _check_batch(gix, oix, qs, k, m, synth.HOW_MANY, business=True, check_neighbours=False)
+    if kernel_path == "default":
+        assert gix.last_path_counts()[1] < nq // 2, "with business rules on, most queries should still be served by the fast kernel"
+
+
 def test_device_pointer_entry_point_matches_host_entry_point():
     torch = pytest.importorskip("torch")
     import serenade_amd as sa
