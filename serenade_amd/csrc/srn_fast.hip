@@ -405,8 +405,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             const uint32_t j = wave * 64u + lane + (uint32_t)t * BLOCK;
             svr[t] = K ? nbl[min(j, K - 1u)] : 0u;   // (all loads unconditional: a load inside a branch is waited for at the branch's end)
             const size_t r = K ? (size_t)(base + (svr[t] >> NB)) : (size_t)n_kept;   // (idle lanes re-read the last neighbour's row)
-            if constexpr (FRAG) { rq[t] = *reinterpret_cast<const uint4*>(&f.row_packed[r]); rq1[t] = make_uint4(0u, 0u, 0u, 0u); }
-            else { rq[t] = *reinterpret_cast<const uint4*>(&f.row_packed[r * 4]); rq1[t] = *reinterpret_cast<const uint4*>(&f.row_packed[r * 4 + 1]); }
+            rq[t] = *reinterpret_cast<const uint4*>(&f.row_packed[r * (FRAG ? 1 : 4)]); rq1[t] = make_uint4(0u, 0u, 0u, 0u);
         }
         {   // clear: accumulators + sketch + dump, exact table (keys EMPTY32, sums 0)
             uint4* z = reinterpret_cast<uint4*>(smem + F_HOT);
@@ -428,6 +427,16 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             const unsigned long long b3 = __ballot(m3);
             if (m3) nbl[qpos(cnt3 + (uint32_t)__popcll(b3 & lt))] = svr[t];
             cnt3 += (uint32_t)__popcll(b3);
+        }
+        // The second 16 bytes (items 6..13) are asked for only now, and only by the rows that have them (1 in 4): the other lanes all read the empty
+        // slot's -- one line for the lot -- so the address unit sees a quarter of the requests; the lines themselves came with the first 16 bytes.
+        if constexpr (!FRAG) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const bool more6 = wave * 64u + lane + (uint32_t)t * BLOCK < K && (rq[t].x & 0xFFFFu) > 6u;
+                const size_t r1 = more6 ? (size_t)(base + (svr[t] >> NB)) : (size_t)n_kept;
+                rq1[t] = *reinterpret_cast<const uint4*>(&f.row_packed[r1 * 4 + 1]);
+            }
         }
         // round (ii)'s first batch is requested BEFORE round (i)'s adds, which hide its latency (L2 hits: the lines came with round (i))
         // (FRAG: the queued fragments continue in their overflow blocks: c4 = items 4..11, d4 = items 12..19 if the fragment has that many; blk = the block the
