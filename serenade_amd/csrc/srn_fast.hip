@@ -224,13 +224,28 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
     const uint32_t n_kept = ix.n_kept;
     auto qpos = [&](uint32_t pq) -> uint32_t { return ((wave + NW * (pq >> 6)) << 6) + (pq & 63u); };   // the wave's own neighbour-list slots
 
+    // The NEXT query's record is fetched during this one (wave 1, between walk A and the end of phase 4a) and parked in LDS: a query's critical path then starts
+    // with the list loads, not with the record's HBM round trip followed by theirs.  The record's first 256 bytes go from global memory STRAIGHT into LDS
+    // (global_load_lds: one dword per lane, no registers held): words 0..15 = PrepHead, words 16 + 6 l .. = item l.  (The 448 bytes behind the 16 entries
+    // the weight table uses are free.)
+    uint32_t* const pre = (uint32_t*)(smem + F_W10 + 64);
+    bool have_pre = false;   // block-uniform
     for (uint32_t q = blockIdx.x; q < p.nq; q += gridDim.x) {
         long long t_prev = ticking ? clock64() : 0;
         // ---- phase 0: the query's prep record -> run descriptors in SGPRs ------------------------------
         const char* const rec = p.prep + (size_t)q * p.prep_stride;
-        const PrepHead hd = *(const PrepHead*)rec;   // (uniform address)
-        PrepItem x0{kNone, 0u, 0u, 0u, 0ull};
-        if (lane < 8u && lane < hd.L) x0 = ((const PrepItem*)(rec + sizeof(PrepHead)))[lane];
+        struct { uint32_t U, rmax, xlo, sumw, L, n_staged; } hd;
+        struct { uint32_t idx, kept; unsigned long long base; } x0{kNone, 0u, 0ull};
+        if (have_pre) {
+            auto uni = [&](uint32_t w) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)pre[w]); };   // (SGPRs: the branches on these stay scalar)
+            hd.U = uni(0); hd.rmax = uni(1); hd.xlo = uni(2); hd.sumw = uni(3); hd.L = uni(6); hd.n_staged = uni(7);
+            if (lane < 8u && lane < hd.L) { const uint32_t* it = pre + 16 + 6u * lane; x0.idx = it[0]; x0.kept = it[3]; x0.base = ((unsigned long long)it[5] << 32) | it[4]; }
+        } else {
+            const PrepHead h0 = *(const PrepHead*)rec;   // (uniform address)
+            hd.U = h0.U; hd.rmax = h0.rmax; hd.xlo = h0.xlo; hd.sumw = h0.sumw; hd.L = h0.L; hd.n_staged = h0.n_staged;
+            if (lane < 8u && lane < hd.L) { const PrepItem pi = ((const PrepItem*)(rec + sizeof(PrepHead)))[lane]; x0.idx = pi.idx; x0.kept = pi.kept; x0.base = pi.base; }
+        }
+        have_pre = false;
         const uint32_t L = hd.L, n = hd.n_staged, U = hd.U;
         unsigned long long rm = __ballot(x0.kept > 0u);
         const uint32_t nr = (uint32_t)__popcll(rm);
@@ -454,6 +469,14 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             } };
         uint32_t sv3 = 0, hdr3 = 0, blk3 = 0; uint4 c43 = make_uint4(0u, 0u, 0u, 0u), d43 = c43;
         if (cnt3) q3_load(0u, sv3, hdr3, c43, d43, blk3);   // (wave-uniform)
+        // the next query's record: requested by wave 1 HERE -- behind its own row requests, with no other load of the wave due for thousands of cycles (loads return
+        // in order: anywhere else the record's HBM round trip would sit in front of data the wave needs at once); it lands in LDS by itself, the wave
+        // waits for it at the end of phase 4a, before the barrier that everybody passes on the way to the next query
+        const uint32_t qn = q + gridDim.x;
+        if (wave == 1u && qn < p.nq && lane * 4u < min(p.prep_stride, 256u)) {
+            const char* const rn = p.prep + (size_t)qn * p.prep_stride + lane * 4u;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)rn, (__attribute__((address_space(3))) void*)pre, 4, 0, 0);
+        }
 #pragma unroll
         for (int t = 0; t < 3; ++t) {   // (i) items 0..13
             if (wave * 64u + (uint32_t)t * BLOCK < K) {
@@ -488,7 +511,6 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         for (uint32_t p0 = 64u; p0 < cnt3; p0 += 64u) { uint32_t sv, hdr, blk; uint4 c4, d4; q3_load(p0, sv, hdr, c4, d4, blk); add_tail(p0, sv, hdr, c4, d4, blk); }
         __syncthreads();
         FAST_TICK(9);
-
         // ---- phase 4a: the direct-mapped items, exactly -> threshold, candidates ----------------------------
         // Sample = the 512 most popular items, dealt round-robin to the waves: every wave takes the 3rd largest of its 64 values
         // of x = idf_eff * acc (top 32 bits of the f64: a monotone truncation); the smallest of the 8 has >= 24 >= n items at or
@@ -566,6 +588,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
                 floor_b = (uint32_t)fmin(4.0e9, fmax(1.0, floor(x_lo * f.inv_idf_hi * (1.0 - 1e-9)) - 1.0));
             }
         }
+        if (wave == 1u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the record has landed
         FAST_TICK(10);
         {
             const uint32_t ns = min(misc[FS_SURV], SURV_CAP);
@@ -587,6 +610,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             if (__ballot(mx >= floor_b) != 0ull && lane == 0u) misc[FS_LIVE] = 1u;
         }
         __syncthreads();
+        have_pre = qn < p.nq;   // (the barrier above orders wave 1's writes before anybody's next look)
         const bool live = misc[FS_LIVE] != 0u;   // block-uniform
         if (live) {
         // ---- walk B: an element reaches the exact table only if its sketch word can still reach the floor -----------
