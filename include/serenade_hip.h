@@ -226,10 +226,10 @@ int srn_shard_stage_c(const srn_index_t* idx, const uint64_t* d_items_flat, cons
  * The posting lists of a query are small, so the shards exchange the LISTS (their entries at or above the global cut) instead of
  * candidates: after one all-gather every rank holds all lists of the batch and runs the unsharded kernels unchanged, scoring the
  * items it owns from its row fragments; a last all-gather of the per-shard top-n and a merge by (score desc, id asc) finish.
- * Valid for position-set geometry (sessions of <= 8 items, m <= m_index, complete lists) without business rules:
+ * Valid for position-set geometry (sessions of <= 8 items, m <= m_index, complete lists), business rules on or off:
  * srn_shard_lists_supported says which; everything else takes stages A/B/C above.  All buffers are device memory, all calls
  * asynchronous on `stream`.  The sequence on every rank (serenade_amd/sharded.py predict_batch_sharded_lists):
- *   head     -> d_pos [nq * max_len] x 16 B (this shard's view of every evolving position), d_head [nq][2] int32 = local (x_lo, r_max)
+ *   head     -> d_pos [nq * max_len] x 16 B (this shard's view of every evolving position), d_head [nq][3] int32 = local (x_lo, r_max, the current item's attribute byte or -1)
  *   all-reduce(max) of d_head
  *   count    -> d_kept [nq * max_len] u32 (entries >= x_lo of every owned list), d_tot [nq] int32
  *   d_off = exclusive prefix sum of d_tot (int64) -- the host's job

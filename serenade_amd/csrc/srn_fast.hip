@@ -226,7 +226,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
 
     // The NEXT query's record is fetched during this one (wave 1, between walk A and the end of phase 4a) and parked in LDS: a query's critical path then starts
     // with the list loads, not with the record's HBM round trip followed by theirs.  The record's first 256 bytes go from global memory STRAIGHT into LDS
-    // (global_load_lds: one dword per lane, no registers held): words 0..15 = PrepHead, words 16 + 6 l .. = item l.  (The 448 bytes behind the 16 entries
+    // (global_load_lds: one dword per lane, no registers held): words 0..17 = PrepHead, words 18 + 6 l .. = item l.  (The 448 bytes behind the 16 entries
     // the weight table uses are free.)
     uint32_t* const pre = (uint32_t*)(smem + F_W10 + 64);
     bool have_pre = false;   // block-uniform
@@ -234,15 +234,16 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         long long t_prev = ticking ? clock64() : 0;
         // ---- phase 0: the query's prep record -> run descriptors in SGPRs ------------------------------
         const char* const rec = p.prep + (size_t)q * p.prep_stride;
-        struct { uint32_t U, rmax, xlo, sumw, L, n_staged; } hd;
+        struct { uint32_t U, rmax, xlo, sumw, L, n_staged, cur_attr; } hd;
+        constexpr uint32_t HW = (uint32_t)sizeof(PrepHead) / 4u;   // record words before the items
         struct { uint32_t idx, kept; unsigned long long base; } x0{kNone, 0u, 0ull};
         if (have_pre) {
             auto uni = [&](uint32_t w) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)pre[w]); };   // (SGPRs: the branches on these stay scalar)
-            hd.U = uni(0); hd.rmax = uni(1); hd.xlo = uni(2); hd.sumw = uni(3); hd.L = uni(6); hd.n_staged = uni(7);
-            if (lane < 8u && lane < hd.L) { const uint32_t* it = pre + 16 + 6u * lane; x0.idx = it[0]; x0.kept = it[3]; x0.base = ((unsigned long long)it[5] << 32) | it[4]; }
+            hd.U = uni(0); hd.rmax = uni(1); hd.xlo = uni(2); hd.sumw = uni(3); hd.L = uni(6); hd.n_staged = uni(7); hd.cur_attr = uni(16);
+            if (lane < 8u && lane < hd.L) { const uint32_t* it = pre + HW + 6u * lane; x0.idx = it[0]; x0.kept = it[3]; x0.base = ((unsigned long long)it[5] << 32) | it[4]; }
         } else {
             const PrepHead h0 = *(const PrepHead*)rec;   // (uniform address)
-            hd.U = h0.U; hd.rmax = h0.rmax; hd.xlo = h0.xlo; hd.sumw = h0.sumw; hd.L = h0.L; hd.n_staged = h0.n_staged;
+            hd.U = h0.U; hd.rmax = h0.rmax; hd.xlo = h0.xlo; hd.sumw = h0.sumw; hd.L = h0.L; hd.n_staged = h0.n_staged; hd.cur_attr = h0.cur_attr;
             if (lane < 8u && lane < hd.L) { const PrepItem pi = ((const PrepItem*)(rec + sizeof(PrepHead)))[lane]; x0.idx = pi.idx; x0.kept = pi.kept; x0.base = pi.base; }
         }
         have_pre = false;
@@ -270,9 +271,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             rm &= rm - 1ull;
         }
         const uint32_t cur_idx = (uint32_t)__builtin_amdgcn_readlane((int)x0.idx, 0);
-        // business rules (mod.rs:162-182): the current item's attribute byte, one more uniform look-up that travels with the list loads
-        uint32_t cur_attr = SRN_ATTR_NONE;
-        if (business && cur_idx != kNone) cur_attr = ix.meta[cur_idx].attr;
+        const uint32_t cur_attr = hd.cur_attr;   // business rules (mod.rs:162-182): the current item's attribute byte, looked up by the prep kernel
         const uint32_t s1 = kp[0], s2 = s1 + kp[1], s3 = s2 + kp[2];
 
         // The stage loads go out BEFORE the barrier that ends the previous query: waves 1..7 get here while wave 0 still ranks that
@@ -473,9 +472,10 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         // in order: anywhere else the record's HBM round trip would sit in front of data the wave needs at once); it lands in LDS by itself, the wave
         // waits for it at the end of phase 4a, before the barrier that everybody passes on the way to the next query
         const uint32_t qn = q + gridDim.x;
-        if (wave == 1u && qn < p.nq && lane * 4u < min(p.prep_stride, 256u)) {
+        if (wave == 1u && qn < p.nq) {   // (a record is at most 72 + 8 * 24 = 264 bytes: two rounds of a dword per lane)
             const char* const rn = p.prep + (size_t)qn * p.prep_stride + lane * 4u;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)rn, (__attribute__((address_space(3))) void*)pre, 4, 0, 0);
+            if (lane * 4u < p.prep_stride) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)rn, (__attribute__((address_space(3))) void*)pre, 4, 0, 0);
+            if (256u + lane * 4u < min(p.prep_stride, 320u)) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rn + 256), (__attribute__((address_space(3))) void*)(pre + 64), 4, 0, 0);
         }
 #pragma unroll
         for (int t = 0; t < 3; ++t) {   // (i) items 0..13

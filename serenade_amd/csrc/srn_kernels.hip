@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void vmis_prep_kernel(DeviceIndex ix, const ui
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     const uint32_t qb = q_off[q], L = q_off[q + 1] - qb;
-    PrepHead h{0u, 0u, 0u, 0u, 0u, 0u, L, 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}};
+    PrepHead h{0u, 0u, 0u, 0u, 0u, 0u, L, 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, SRN_ATTR_NONE, 0u};
     PrepItem* items = (PrepItem*)(out + (size_t)q * stride + sizeof(PrepHead));
     if (L != 0 && L <= max_len) {
         for (uint32_t pos = 0; pos < L; ++pos) {
@@ -383,6 +383,7 @@ __global__ __launch_bounds__(256) void vmis_prep_kernel(DeviceIndex ix, const ui
                 }
             }
             if (len) { if (h.nruns < 8) h.run_start[h.nruns] = h.P; ++h.nruns; }
+            if (pos == 0 && idx != kNone) h.cur_attr = ix.meta[idx].attr;   // business rules look at the current item's attributes (mod.rs:162-182)
             items[pos] = PrepItem{idx, len, h.P, 0u, base};
             h.P += len;
         }
@@ -1041,6 +1042,7 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
         uint32_t cur_attr = SRN_ATTR_NONE;
         if (business) {
             if (STAGE == 3) { const int v = sh.minpos[(size_t)q * (p.k + 1) + p.k]; if (v != MINPOS_NONE) cur_attr = (uint32_t)v; }   // owner shard's byte, all-reduced
+            else if (use_prep) cur_attr = hd.cur_attr;   // (looked up by the prep kernel; item-sharded lists mode: the owner shard's byte)
             else if (cur_idx != kNone) cur_attr = ix.meta[cur_idx].attr;
         }
         const uint32_t n_out = p.how_many;

@@ -550,7 +550,7 @@ int device_shard_stage(DeviceState* d, const FlatIndex& ix, int stage, const Lau
 // ---- item-sharded index, lists mode (srn_shard.hip): the steps either side of the exchanges; device buffers, asynchronous on `stream` ----
 bool device_shard_lists_supported(DeviceState* d, const FlatIndex& ix, const LaunchParams& p) {
     Geometry g;
-    return make_geometry(d, ix, p, 0, g) == SRN_OK && g.masks && p.flags == 0 && p.stats == nullptr && p.nb_rank == nullptr;
+    return make_geometry(d, ix, p, 0, g) == SRN_OK && g.masks && (p.flags & ~(unsigned)SRN_FLAG_BUSINESS_LOGIC) == 0 && p.stats == nullptr && p.nb_rank == nullptr;
 }
 uint32_t device_prep_stride(uint32_t max_len) { return (uint32_t)(sizeof(PrepHead) + (size_t)max_len * sizeof(PrepItem)); }
 int device_shard_lists_head(DeviceState* d, const LaunchParams& p, void* pos, int* head, void* stream) {
@@ -575,7 +575,7 @@ int device_shard_lists_predict(DeviceState* d, const FlatIndex& ix, const Launch
                                unsigned long long shard_stride, const uint32_t* lists_g, const int* head, const void* pos_local, char* records, void* stream) {
     HIP_TRY(hipSetDevice(d->device));
     if (p.nq == 0) return SRN_OK;
-    if (!device_shard_lists_supported(d, ix, p)) return fail(SRN_EINVAL, "lists mode needs position-set slots (sessions of <= 8 items, complete lists) and no business rules: use the three-stage pipeline");
+    if (!device_shard_lists_supported(d, ix, p)) return fail(SRN_EINVAL, "lists mode needs position-set slots (sessions of <= 8 items, m <= m_index, complete lists): use the three-stage pipeline");
     const uint32_t stride = device_prep_stride(p.max_len);
     HIP_TRY(launch_shard_prep((hipStream_t)stream, p.items_flat, p.q_off, p.nq, p.max_len, n_shards, kept_g, off_g, shard_stride, head, (const ShardPos*)pos_local, records, stride));
     ExtLists ext{records, stride, lists_g};

@@ -8,16 +8,17 @@
 // rows are local -- each rank scores the items it owns from its row fragments, its top-n is exact for those items
 // (an item's whole score lives on its owner), and a final all-gather + merge by (score desc, id asc) gives the result.
 //
-//   shard_lists_head_kernel    one thread per query: id -> dense idx of the items this shard owns, list bounds, local x_lo / r_max
-//        all-reduce(max) of (x_lo, r_max)
+//   shard_lists_head_kernel    one thread per query: id -> dense idx of the items this shard owns, list bounds, local x_lo / r_max, the current item's
+//                              attribute byte if this shard owns it (-1 otherwise)
+//        all-reduce(max) of (x_lo, r_max, attribute)
 //   shard_lists_count_kernel   one thread per query: entries >= x_lo of every owned list (a prefix), the query's total
 //        exclusive scan of the totals (host side: torch.cumsum)
 //   shard_lists_copy_kernel    one wave per query: the kept prefixes -> the shard's flat buffer
 //        all-gather of (kept counts, offsets, flat buffers)
 //   shard_prep_kernel          one thread per query: the prep record (PrepHead + PrepItems) against the gathered buffer
 //
-// Valid where the position sets give the first-match position (MASKS geometry: sessions of <= 8 items, complete lists) and
-// without business rules (the current item's attributes live on its owner); everything else takes the three-stage pipeline.
+// Valid where the position sets give the first-match position (MASKS geometry: sessions of <= 8 items, complete lists), with or without
+// business rules (the current item's attribute byte travels with the first all-reduce); everything else takes the three-stage pipeline.
 #include <hip/hip_runtime.h>
 
 #include "srn_device.h"
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(256) void shard_lists_head_kernel(DeviceIndex ix, c
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     const uint32_t qb = q_off[q], L = q_off[q + 1] - qb;
-    uint32_t xlo = 0, rmax = 0;
+    uint32_t xlo = 0, rmax = 0; int attr = -1;
     ShardPos* const out = pos_out + (size_t)q * max_len;
     if (L != 0 && L <= max_len) {
         for (uint32_t pos = 0; pos < L; ++pos) {
@@ -46,10 +47,11 @@ __global__ __launch_bounds__(256) void shard_lists_head_kernel(DeviceIndex ix, c
                 len = (uint32_t)min((unsigned long long)m, o1 - o0); base = o0;
                 if (len) { rmax = max(rmax, ix.post_rank[o0]); if (len >= m) xlo = max(xlo, ix.post_rank[o0 + m - 1]); }
             }
+            if (pos == 0 && idx != kNone) attr = (int)ix.meta[idx].attr;   // (an item has one owner: every other shard says -1)
             out[pos] = ShardPos{idx, len, base};
         }
     }
-    head[2 * (size_t)q] = (int)xlo; head[2 * (size_t)q + 1] = (int)rmax;   // (ranks are < 2^31: they index sessions)
+    head[3 * (size_t)q] = (int)xlo; head[3 * (size_t)q + 1] = (int)rmax; head[3 * (size_t)q + 2] = attr;   // (ranks are < 2^31: they index sessions)
 }
 
 __global__ __launch_bounds__(256) void shard_lists_count_kernel(DeviceIndex ix, const uint32_t* __restrict__ q_off, uint32_t nq, uint32_t max_len,
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256) void shard_lists_count_kernel(DeviceIndex ix, 
                                                                 uint32_t* __restrict__ kept, int* __restrict__ tot) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
-    const uint32_t L = q_off[q + 1] - q_off[q], xlo = (uint32_t)head[2 * (size_t)q];
+    const uint32_t L = q_off[q + 1] - q_off[q], xlo = (uint32_t)head[3 * (size_t)q];
     uint32_t total = 0;
     for (uint32_t pos = 0; pos < max_len; ++pos) {
         uint32_t lo = 0;
@@ -95,10 +97,11 @@ __global__ __launch_bounds__(256) void shard_prep_kernel(const uint64_t* __restr
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     const uint32_t qb = q_off[q], L = q_off[q + 1] - qb;
-    PrepHead h{0u, 0u, 0u, 0u, 0u, 0u, L, 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}};
+    PrepHead h{0u, 0u, 0u, 0u, 0u, 0u, L, 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, SRN_ATTR_NONE, 0u};
     PrepItem* items = (PrepItem*)(out + (size_t)q * stride + sizeof(PrepHead));
     if (L != 0 && L <= max_len) {
-        h.xlo = (uint32_t)head[2 * (size_t)q]; h.rmax = (uint32_t)head[2 * (size_t)q + 1];
+        h.xlo = (uint32_t)head[3 * (size_t)q]; h.rmax = (uint32_t)head[3 * (size_t)q + 1];
+        if (head[3 * (size_t)q + 2] >= 0) h.cur_attr = (uint32_t)head[3 * (size_t)q + 2];
         for (uint32_t pos = 0; pos < L; ++pos) {
             const uint64_t raw = items_flat[qb + (L - 1 - pos)];
             bool first = true;

@@ -239,7 +239,7 @@ def merge_topn(ids, scores, counts, how_many):
 
 # ---- lists mode: the shards exchange the posting LISTS of the batch, then every rank runs the unsharded kernels (srn_shard.hip) ----
 def lists_supported(index, max_len, k, m, how_many, enable_business_logic=False):
-    """True where the lists mode applies: position-set geometry (sessions of <= 8 items, m <= m_index, complete lists), no business rules."""
+    """True where the lists mode applies: position-set geometry (sessions of <= 8 items, m <= m_index, complete lists), business rules on or off."""
     out = C.c_int(0)
     capi.check(capi.lib().srn_shard_lists_supported(index._h, max_len, k, m, how_many, capi.FLAG_BUSINESS_LOGIC if enable_business_logic else 0, C.byref(out)))
     return bool(out.value)
@@ -249,7 +249,7 @@ def _lists_head(ix, d_flat, d_off, nq, max_len, m, stream):
     import torch
     dev = d_flat.device
     pos = torch.empty(nq * max_len * 2, dtype=torch.int64, device=dev)          # 16 bytes per (query, position)
-    head = torch.empty((nq, 2), dtype=torch.int32, device=dev)                  # local (x_lo, r_max)
+    head = torch.empty((nq, 3), dtype=torch.int32, device=dev)                  # local (x_lo, r_max, attribute byte of the current item | -1)
     capi.check(capi.lib().srn_shard_lists_head(ix._h, _ptr(d_flat), _ptr(d_off), nq, max_len, m, _ptr(pos), _ptr(head), C.c_void_p(stream)))
     return pos, head
 
@@ -273,19 +273,19 @@ def _lists_copy(ix, nq, max_len, pos, kept, off, stride, stream):
     return flat
 
 
-def _lists_predict(ix, d_flat, d_off, nq, max_len, k, m, how_many, kept_g, off_g, lists_g, head, pos, stream):
+def _lists_predict(ix, d_flat, d_off, nq, max_len, k, m, how_many, kept_g, off_g, lists_g, head, pos, stream, business=False):
     import torch
     dev = d_flat.device
     rec = torch.empty(nq * int(capi.lib().srn_shard_lists_record_bytes(max_len)), dtype=torch.uint8, device=dev)
     ids = torch.zeros(nq * how_many, dtype=torch.int64, device=dev)
     sc = torch.zeros(nq * how_many, dtype=torch.float64, device=dev)
     cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
-    capi.check(capi.lib().srn_shard_lists_predict(ix._h, _ptr(d_flat), _ptr(d_off), nq, max_len, k, m, how_many, 0, kept_g.shape[0], _ptr(kept_g), _ptr(off_g),
+    capi.check(capi.lib().srn_shard_lists_predict(ix._h, _ptr(d_flat), _ptr(d_off), nq, max_len, k, m, how_many, capi.FLAG_BUSINESS_LOGIC if business else 0, kept_g.shape[0], _ptr(kept_g), _ptr(off_g),
                                                   lists_g.shape[1], _ptr(lists_g), _ptr(head), _ptr(pos), _ptr(rec), _ptr(ids), _ptr(sc), _ptr(cnt), C.c_void_p(stream)))
     return ids, sc, cnt
 
 
-def predict_batch_sharded_lists(index, comm, d_items_flat, d_q_off, nq, max_len, k, m, how_many, stream=None):
+def predict_batch_sharded_lists(index, comm, d_items_flat, d_q_off, nq, max_len, k, m, how_many, stream=None, enable_business_logic=False):
     """One batch through the LISTS pipeline on this rank (see srn_shard.hip): all-reduce(max) of the cuts, all-gather of the kept list
     prefixes, the unsharded kernels over this shard's row fragments, all-gather + merge of the per-shard top-n.  Same arguments
     and results as predict_batch_sharded; one host synchronisation per batch (the size of the exchange buffer)."""
@@ -298,13 +298,13 @@ def predict_batch_sharded_lists(index, comm, d_items_flat, d_q_off, nq, max_len,
     stride = (max(1, int(comm.all_reduce_max(total).item())) + 63) // 64 * 64
     flat = _lists_copy(index, nq, max_len, pos, kept, off, stride, stream)
     kept_g, off_g, lists_g = comm.all_gather(kept).contiguous(), comm.all_gather(off).contiguous(), comm.all_gather(flat).contiguous()
-    ids, sc, cnt = _lists_predict(index, d_items_flat, d_q_off, nq, max_len, k, m, how_many, kept_g, off_g, lists_g, head, pos, stream)
+    ids, sc, cnt = _lists_predict(index, d_items_flat, d_q_off, nq, max_len, k, m, how_many, kept_g, off_g, lists_g, head, pos, stream, enable_business_logic)
     if comm.world == 1:
         return ids.view(nq, how_many), sc.view(nq, how_many), cnt
     return merge_topn(comm.all_gather(ids.view(nq, how_many)), comm.all_gather(sc.view(nq, how_many)), comm.all_gather(cnt), how_many)
 
 
-def predict_batch_sharded_lists_local(shards, d_items_flat, d_q_off, nq, max_len, k, m, how_many):
+def predict_batch_sharded_lists_local(shards, d_items_flat, d_q_off, nq, max_len, k, m, how_many, enable_business_logic=False):
     """The lists pipeline with all shards in ONE process on one GPU (tests): the collectives become tensor ops."""
     import torch
     stream = torch.cuda.current_stream(d_items_flat.device).cuda_stream
@@ -314,16 +314,16 @@ def predict_batch_sharded_lists_local(shards, d_items_flat, d_q_off, nq, max_len
     stride = (max(1, max(int(x[2].item()) for x in c)) + 63) // 64 * 64
     flats = [_lists_copy(ix, nq, max_len, x[0], y[0], y[1], stride, stream) for ix, x, y in zip(shards, h, c)]
     kept_g, off_g, lists_g = torch.stack([y[0] for y in c]).contiguous(), torch.stack([y[1] for y in c]).contiguous(), torch.stack(flats).contiguous()
-    r = [_lists_predict(ix, d_items_flat, d_q_off, nq, max_len, k, m, how_many, kept_g, off_g, lists_g, head, x[0], stream) for ix, x in zip(shards, h)]
+    r = [_lists_predict(ix, d_items_flat, d_q_off, nq, max_len, k, m, how_many, kept_g, off_g, lists_g, head, x[0], stream, enable_business_logic) for ix, x in zip(shards, h)]
     return merge_topn(torch.stack([x[0].view(nq, how_many) for x in r]), torch.stack([x[1].view(nq, how_many) for x in r]),
                       torch.stack([x[2] for x in r]), how_many)
 
 
 def predict_batch_sharded(index, comm, d_items_flat, d_q_off, nq, max_len, k, m, how_many, enable_business_logic=False, stream=None, mode="auto"):
     """One batch through the item-sharded index on this rank: the lists pipeline where it applies (mode "auto" / "lists"), the
-    three-stage pipeline otherwise (mode "stages": business rules, sessions of > 8 items, truncated lists)."""
+    three-stage pipeline otherwise (mode "stages": sessions of > 8 items, truncated lists)."""
     if mode == "lists" or (mode == "auto" and lists_supported(index, max_len, k, m, how_many, enable_business_logic)):
-        return predict_batch_sharded_lists(index, comm, d_items_flat, d_q_off, nq, max_len, k, m, how_many, stream)
+        return predict_batch_sharded_lists(index, comm, d_items_flat, d_q_off, nq, max_len, k, m, how_many, stream, enable_business_logic)
     return predict_batch_sharded_stages(index, comm, d_items_flat, d_q_off, nq, max_len, k, m, how_many, enable_business_logic, stream)
 
 

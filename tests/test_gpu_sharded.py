@@ -108,8 +108,31 @@ def test_lists_pipeline_matches_unsharded(n_shards, lists_kernel_path):
         _check(sharded.predict_batch_sharded_lists_local(shards, d_flat, d_off, len(qs), 8, k, m, n), ref)
     if n_shards == 1:   # the one-rank pipeline as a rank runs it (SoloComm: no merge step)
         _check(sharded.predict_batch_sharded(shards[0], sharded.SoloComm(), d_flat, d_off, len(qs), 8, 100, 400, 21), sa.predict_batch(full, (flat, qoff), 100, 400, 21, False))
-    assert not sharded.lists_supported(shards[0], 8, 100, 400, 21, True)      # business rules: the three-stage pipeline
+    assert sharded.lists_supported(shards[0], 8, 100, 400, 21, True)          # business rules: the current item's attribute byte travels with the first all-reduce
     assert not sharded.lists_supported(shards[0], 12, 100, 400, 21)           # sessions of > 8 items: no position sets
+
+
+def test_lists_pipeline_business_rules():
+    """Business rules in lists mode: the current item's attributes live on its owner shard and reach the others with the first all-reduce."""
+    import serenade_amd as sa
+    from serenade_amd import sharded, synth, capi
+    inter, n_items, k, m, idfw = synth.CONFIGS["tiny"]
+    off, items, ts = synth.training_sessions(inter, n_items)
+    flat, qoff = synth.queries(1500, n_items)
+    d_flat, d_off = _to_dev(flat, qoff)
+    rng = np.random.default_rng(45)
+    known = np.unique(items)
+    flags = rng.choice(np.array([0, 1, 2, 3, 0xFF], np.uint8), size=len(known), p=[0.15, 0.05, 0.5, 0.2, 0.1])
+    full = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw)
+    full.set_attributes(known, flags)
+    ref = sa.predict_batch(full, (flat, qoff), k, m, 21, True)
+    assert not np.array_equal(ref[0], sa.predict_batch(full, (flat, qoff), k, m, 21, False)[0]), "the rules should change something"
+    shards = [sharded.ShardedVMISIndex.from_full(full, g, 3) for g in range(3)]
+    for s in shards:
+        capi.check(capi.lib().srn_index_set_attributes(s._h, capi.ptr(capi.as_u64(known)), capi.ptr(flags), len(known)))
+    nq = len(qoff) - 1
+    _check(sharded.predict_batch_sharded_lists_local(shards, d_flat, d_off, nq, 4, k, m, 21, True), ref)
+    _check(sharded.predict_batch_sharded_local(shards, d_flat, d_off, nq, 4, k, m, 21, True), ref)       # (the three-stage pipeline agrees)
 
 
 def test_lists_pipeline_synthetic_shape():
