@@ -808,37 +808,68 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
 // contenders, score = idf_eff * acc / (10 U) (one multiply, one divide, in that order), top-n by (score desc, public id asc)
 // -- ranks counted on the scores themselves --, public ids.  Rows of other queries are left alone.
 // -------------------------------------------------------------------------------------
+constexpr uint32_t FIN_QPW = 4;   // queries per wave: the three dependent round trips (record, contenders' idf, public ids) of FIN_QPW queries overlap
 __global__ __launch_bounds__(256) void vmis_finish_kernel(DeviceIndex ix, const char* __restrict__ fin, uint64_t* __restrict__ out_ids, double* __restrict__ out_scores,
                                                           uint32_t* __restrict__ out_counts, uint32_t nq, uint32_t how_many) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t q = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (q >= nq) return;
-    // the record sits at a fixed place: flag, header and this lane's entry are requested together (three dependent round trips in
-    // all: these, the contenders' idf, the public ids)
-    const uint4* rec = reinterpret_cast<const uint4*>(fin + (size_t)q * F_FIN_BYTES);
-    const uint32_t flag = out_counts[q];
-    const uint4 hd = rec[0];
-    const uint4 e = rec[1 + min(lane, F_FIN_ENTRIES - 1u)];
-    if (flag != 0x80000000u) return;   // (wave-uniform: not served by the fast kernel -- what was read is stale, and unused)
-    const uint32_t M = hd.x;
-    const bool valid = lane < M;
-    double x = 0.0; uint32_t tie = EMPTY32;
-    if (valid) {
-        if (e.w == 0u) { x = __longlong_as_double((long long)(((unsigned long long)e.y << 32) | e.x)); tie = e.z; }
-        else { const ItemMeta mt = ix.meta[e.z]; x = (mt.idf > 0.0 ? mt.idf : 1.0) * (double)e.x; tie = mt.id_rank; }
+    const uint32_t q0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * FIN_QPW;
+    if (q0 >= nq) return;
+    // the records sit at fixed places: flag, header and this lane's entry of every query are requested together
+    uint32_t flag[FIN_QPW]; uint4 hd[FIN_QPW], e[FIN_QPW];
+#pragma unroll
+    for (uint32_t u = 0; u < FIN_QPW; ++u) {
+        const uint32_t q = min(q0 + u, nq - 1u);
+        const uint4* rec = reinterpret_cast<const uint4*>(fin + (size_t)q * F_FIN_BYTES);
+        flag[u] = q0 + u < nq ? out_counts[q] : 0u;
+        hd[u] = rec[0];
+        e[u] = rec[1 + min(lane, 30u)];   // the record's first 512 bytes: most queries have <= 31 entries (lanes past 30 re-read entry 30: same line)
     }
-    const unsigned long long pid = valid ? ix.id_sorted[tie] : 0ull;   // (arrives while the ranks are counted)
-    const double sc = valid ? x / (double)(10u * hd.y) : 0.0;
-    const unsigned long long mk = (unsigned long long)__double_as_longlong(sc);   // (positive doubles order like their bit patterns)
-    const int klo = (int)(uint32_t)mk, khi = (int)(uint32_t)(mk >> 32);
-    uint32_t rank = 0;
-    for (uint32_t j = 0; j < M; ++j) {   // entry j is broadcast by v_readlane: no LDS, no memory
-        const uint32_t jl = (uint32_t)__builtin_amdgcn_readlane(klo, (int)j), jh = (uint32_t)__builtin_amdgcn_readlane(khi, (int)j), ij = (uint32_t)__builtin_amdgcn_readlane((int)tie, (int)j);
-        const unsigned long long kj = ((unsigned long long)jh << 32) | jl;
-        rank += (uint32_t)(kj > mk) | ((uint32_t)(kj == mk) & (uint32_t)(ij < tie));
+#pragma unroll
+    for (uint32_t u = 0; u < FIN_QPW; ++u)   // (wave-uniform, rare: the second half of a long record)
+        if (flag[u] == 0x80000000u && hd[u].x > 31u) { const uint4* rec = reinterpret_cast<const uint4*>(fin + (size_t)(q0 + u) * F_FIN_BYTES); e[u] = rec[1 + min(lane, F_FIN_ENTRIES - 1u)]; }
+    bool valid[FIN_QPW]; double x[FIN_QPW]; uint32_t tie[FIN_QPW]; ItemMeta mt[FIN_QPW];
+#pragma unroll
+    for (uint32_t u = 0; u < FIN_QPW; ++u) {   // (flag != 0x80000000: not served by the fast kernel -- what was read is stale, and unused)
+        valid[u] = flag[u] == 0x80000000u && lane < hd[u].x;
+        mt[u] = ix.meta[valid[u] && e[u].w != 0u ? e[u].z : 0u];   // (unconditional: a load inside a branch is waited for at its end)
     }
-    if (valid && rank < how_many) { out_ids[(size_t)q * how_many + rank] = pid; out_scores[(size_t)q * how_many + rank] = sc; }
-    if (lane == 0u) out_counts[q] = min(M, how_many);
+#pragma unroll
+    for (uint32_t u = 0; u < FIN_QPW; ++u) {
+        x[u] = 0.0; tie[u] = EMPTY32;
+        if (valid[u]) {
+            if (e[u].w == 0u) { x[u] = __longlong_as_double((long long)(((unsigned long long)e[u].y << 32) | e[u].x)); tie[u] = e[u].z; }
+            else { x[u] = (mt[u].idf > 0.0 ? mt[u].idf : 1.0) * (double)e[u].x; tie[u] = mt[u].id_rank; }
+        }
+    }
+    unsigned long long pid[FIN_QPW];
+#pragma unroll
+    for (uint32_t u = 0; u < FIN_QPW; ++u) pid[u] = ix.id_sorted[valid[u] ? tie[u] : 0u];   // (arrive while the ranks are counted)
+#pragma unroll
+    for (uint32_t u = 0; u < FIN_QPW; ++u) {
+        if (flag[u] != 0x80000000u) continue;   // (wave-uniform)
+        const uint32_t q = q0 + u, M = hd[u].x;
+        const double sc = valid[u] ? x[u] / (double)(10u * hd[u].y) : 0.0;
+        const unsigned long long mk = (unsigned long long)__double_as_longlong(sc);   // (positive doubles order like their bit patterns)
+        const int klo = (int)(uint32_t)mk, khi = (int)(uint32_t)(mk >> 32);
+        // ranks: this kernel's time is this loop (2^20 queries x ~30 entries), so it first runs on the scores' top 32 bits alone -- entry j broadcast by
+        // v_readlane, a compare and an add-with-carry each for "greater" and "equal" -- and only a wave in which two entries share those bits (near ties)
+        // counts again on the full keys (score, then id rank)
+        uint32_t rank = 0, same = 0;
+        for (uint32_t j = 0; j < M; ++j) {
+            const uint32_t jh = (uint32_t)__builtin_amdgcn_readlane(khi, (int)j);
+            rank += (uint32_t)(jh > (uint32_t)khi); same += (uint32_t)(jh == (uint32_t)khi);
+        }
+        if (__ballot(valid[u] && same > 1u) != 0ull) {   // (wave-uniform)
+            rank = 0;
+            for (uint32_t j = 0; j < M; ++j) {
+                const uint32_t jl = (uint32_t)__builtin_amdgcn_readlane(klo, (int)j), jh = (uint32_t)__builtin_amdgcn_readlane(khi, (int)j), ij = (uint32_t)__builtin_amdgcn_readlane((int)tie[u], (int)j);
+                const unsigned long long kj = ((unsigned long long)jh << 32) | jl;
+                rank += (uint32_t)(kj > mk) | ((uint32_t)(kj == mk) & (uint32_t)(ij < tie[u]));
+            }
+        }
+        if (valid[u] && rank < how_many) { out_ids[(size_t)q * how_many + rank] = pid[u]; out_scores[(size_t)q * how_many + rank] = sc; }
+        if (lane == 0u) out_counts[q] = min(M, how_many);
+    }
 }
 // The same for the few queries with more than 63 entries (no threshold from the sample: small queries whose every scored item is a
 // candidate): one wave per listed query, entries staged in LDS; a threshold first -- 256-bin histogram of the scores' top 16 bits
@@ -919,7 +950,7 @@ hipError_t launch_finish_big(hipStream_t st, const DeviceIndex& di, const FastPa
 }
 
 hipError_t launch_finish(hipStream_t st, const DeviceIndex& di, const FastParams& f, uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint32_t nq, uint32_t how_many) {
-    hipLaunchKernelGGL(vmis_finish_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, di, (const char*)f.fin, out_ids, out_scores, out_counts, nq, how_many);
+    hipLaunchKernelGGL(vmis_finish_kernel, dim3((nq + 4 * FIN_QPW - 1) / (4 * FIN_QPW)), dim3(256), 0, st, di, (const char*)f.fin, out_ids, out_scores, out_counts, nq, how_many);
     return hipGetLastError();
 }
 

@@ -393,6 +393,7 @@ __global__ __launch_bounds__(256) void vmis_prep_kernel(DeviceIndex ix, const ui
             if (len == 0) continue;
             const uint32_t* __restrict__ lst = ix.post_rank + items[pos].base;
             uint32_t lo = 0, hi = len;   // first index whose entry is < x_lo
+            if (h.xlo == 0u || lst[len - 1] >= h.xlo) lo = len;   // (the usual case: the whole list is kept -- one look instead of ~11 dependent ones)
             while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (lst[mid] >= h.xlo) lo = mid + 1; else hi = mid; }
             items[pos].kept = lo; h.n_staged += lo;
         }
