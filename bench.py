@@ -58,7 +58,7 @@ def usable_cores():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="cfg3", help="tiny | cfg2 | cfg3 | cfg4 (synth.CONFIGS)")
     ap.add_argument("--batch", type=int, default=1 << 20, help="evolving sessions per step and per GPU")
