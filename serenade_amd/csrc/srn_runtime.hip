@@ -28,6 +28,7 @@ namespace srn {
 struct Knobs {
     bool no_masks = false, no_merge = false, dense = false, no_fast = false, debug = false;
     int hot_slots = -1, sketch_slots = -1, lds_budget_kb = 0, grid_mult = 16, fast_runs = 0;
+    bool grid_mult_set = false;
     bool geometry_default() const { return !no_masks && !no_merge && !dense && hot_slots < 0 && sketch_slots < 0 && lds_budget_kb == 0; }
 };
 static Knobs g_knobs; static std::once_flag g_knobs_once; static std::mutex g_knobs_mu;
@@ -38,7 +39,7 @@ static void knobs_read() {
     if (const char* e = getenv("SRN_HOT_SLOTS")) k.hot_slots = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_SKETCH_SLOTS")) k.sketch_slots = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_LDS_BUDGET_KB")) k.lds_budget_kb = std::max(0, atoi(e));
-    if (const char* e = getenv("SRN_GRID_MULT")) k.grid_mult = std::max(1, atoi(e));
+    if (const char* e = getenv("SRN_GRID_MULT")) { k.grid_mult = std::max(1, atoi(e)); k.grid_mult_set = true; }
     if (const char* e = getenv("SRN_FAST_RUNS")) k.fast_runs = atoi(e) == 3 ? 3 : 0;   // tests: the fast kernel's 29-bit-rank form (3 lists per query) on a small index
     std::lock_guard<std::mutex> lk(g_knobs_mu); g_knobs = k;
 }
@@ -485,7 +486,12 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     // queued on slow_list and served by the general kernel right behind it.
     if (fast) {
         HIP_TRY(hipMemsetAsync(w->slow_cnt, 0, 16, st));   // (slow_cnt[0] = handed-over queries, [2..3] = the 64-bit ticket of vmis_finish_big_kernel's list)
-        const uint32_t grid_f = (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * F_WG_PER_CU * grid_mult);
+        // The fast kernel's workgroups walk their queries in a pipeline (the next record is fetched during the current query), so they want ~12 queries each;
+        // beyond that, more and smaller workgroups shorten the tail of the launch.  Measured on config 3 (ms per launch at 8 / 16 / 32 / 64 resident sets): 2^20 queries
+        // 26.29 / 26.06 / 25.85 / 25.81; 2^18: - / 6.62 / 6.57 / 6.63; 2^16: - / 1.70 / 1.72 / 1.78.
+        const uint64_t resident = (uint64_t)d->n_cu * F_WG_PER_CU;
+        const uint32_t grid_f = kn.grid_mult_set ? (uint32_t)std::min<uint64_t>(p.nq, resident * grid_mult)
+                                                 : (uint32_t)std::min<uint64_t>(p.nq, std::min<uint64_t>(resident * 64, std::max<uint64_t>(resident * 16, p.nq / 12)));
         const uint64_t big_entries = std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)p.nq * 16 + 4096);
         FastParams fp = d->fast; fp.slow_list = w->slow_list; fp.slow_cnt = w->slow_cnt; fp.nb = nb_fast; fp.max_runs = nb_fast; fp.fin = w->fin;
         fp.big_arena = w->big; fp.big_list = (uint32_t*)(w->big + big_entries * 16); fp.big_ticket = (unsigned long long*)(w->slow_cnt + 2); fp.big_cap_entries = (uint32_t)big_entries;
