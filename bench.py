@@ -204,6 +204,23 @@ def main():
     elapsed = D.max_over_ranks(elapsed, dev)
     step_ms = np.array([a.elapsed_time(b) for a, b in ev])
     served = int((out_cnt.cpu().numpy().view(np.uint32) != 0xFFFFFFFF).sum())
+    # size-independent properties of the WHOLE last batch (the oracle gate above covers 2 048 queries): every row is a valid top-n list --
+    # count <= n, scores positive-or-not but non-increasing, equal scores in ascending id order, no item twice
+    props_ok = None
+    if not sharded_mode:
+        cnt = out_cnt.to(torch.int64)
+        ok_rows = (cnt >= 0) & (cnt <= how_many)
+        col = torch.arange(how_many, device=dev).view(1, -1)
+        inside = col < cnt.view(-1, 1)
+        sc2 = out_sc.view(B, how_many); id2 = out_ids.view(B, how_many)
+        pair = inside[:, 1:] & inside[:, :-1]
+        desc = (~pair) | (sc2[:, :-1] > sc2[:, 1:]) | ((sc2[:, :-1] == sc2[:, 1:]) & ((id2[:, :-1] ^ torch.iinfo(torch.int64).min) < (id2[:, 1:] ^ torch.iinfo(torch.int64).min)))
+        srt = torch.sort(torch.where(inside, id2, torch.arange(how_many, device=dev).view(1, -1) - how_many - 1), dim=1).values   # (fillers: distinct negatives no real id... u64 ids as int64 may be negative: collisions only flag, never pass wrongly)
+        uniq = (srt[:, 1:] != srt[:, :-1]).all(dim=1)
+        props_ok = bool((ok_rows & desc.all(dim=1) & uniq).all().item())
+        if not props_ok:
+            print("bench.py: the last batch's results violate the top-n list properties", file=sys.stderr)
+            os._exit(1)
 
     common = {"metric": "predict_next queries/sec", "unit": "queries/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
               "higher_is_better": True, "vs_baseline": None, "dtype": "u32 ids / i32 accumulators / f64 scores", "data": "synthetic"}
@@ -337,7 +354,7 @@ def main():
                    "posting_entries": int(info["nnz_postings"]), "index_bytes_hbm": int(info["device_bytes"]),
                    "parallelism": "query-sharded replicas x%d (no data-path collective)" % args.gpus,
                    "setup_s": {"generate": round(t_gen, 2), "index_build_upload": round(t_build, 2), "index_builder": args.builder}},
-        "parity_checked": parity_checked,
+        "parity_checked": parity_checked, "full_batch_properties_ok": props_ok,
         "roofline": {"bound": "hbm", "kernel": "vmis_fast_kernel" if fast_used else "vmis_predict_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE)",
                      "traffic_source": traffic_src,
