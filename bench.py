@@ -187,6 +187,9 @@ def main():
         SH.predict_batch_sharded(index, comm, batches[0][0], batches[0][1], B, last_items, k, m, how_many, False, stream.cuda_stream, args.shard_pipeline)   # rank 0's check is a collective call
 
     barrier = D.barrier
+    if sharded_mode:   # prime both lanes' allocator pools and workspaces (setup, not one of the W warm-up steps)
+        step(0); step(1)
+        torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
