@@ -190,6 +190,8 @@ def main():
     if sharded_mode:   # prime both lanes' allocator pools and workspaces (setup, not one of the W warm-up steps)
         step(0); step(1)
         torch.cuda.synchronize()
+    else:              # size the stream's workspace up front (srn_index_reserve): no call of the run allocates, warm-up or not
+        sa.reserve(index, B, last_items, k, m, how_many, False, stream.cuda_stream)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
