@@ -135,6 +135,34 @@ def test_lists_pipeline_business_rules():
     _check(sharded.predict_batch_sharded_local(shards, d_flat, d_off, nq, 4, k, m, 21, True), ref)       # (the three-stage pipeline agrees)
 
 
+def test_lists_entry_points_reject_misuse():
+    """The lists-mode ABI fails loudly: null buffers, zero shards, and a geometry it does not serve (sessions of > 8 items) give error codes, not launches."""
+    import torch
+    from serenade_amd import sharded, capi
+    import ctypes as C
+    off, items, ts, ids = small_dataset(59, n_sessions=800, n_items=100)
+    ix = sharded.ShardedVMISIndex(off, items, ts, 100, 12, 1.0, 0, 2)
+    qs = random_queries(19, ids, 16, max_len=4)
+    flat, qoff = flatten(qs)
+    d_flat, d_off = _to_dev(flat, qoff)
+    nq = len(qs)
+    L = capi.lib()
+    assert L.srn_shard_lists_head(ix._h, C.c_void_p(d_flat.data_ptr()), C.c_void_p(d_off.data_ptr()), nq, 4, 100, None, None, None) == capi.SRN_EINVAL
+    pos, head = sharded._lists_head(ix, d_flat, d_off, nq, 4, 100, 0)
+    kept, offs, total = sharded._lists_count(ix, d_off, nq, 4, pos, head, 0)
+    assert L.srn_shard_lists_copy(ix._h, nq, 4, C.c_void_p(pos.data_ptr()), C.c_void_p(kept.data_ptr()), None, None, None) == capi.SRN_EINVAL
+    out = torch.zeros(nq * 21, dtype=torch.int64, device=d_flat.device); sc = torch.zeros(nq * 21, dtype=torch.float64, device=d_flat.device); cnt = torch.zeros(nq, dtype=torch.int32, device=d_flat.device)
+    rec = torch.empty(nq * int(L.srn_shard_lists_record_bytes(12)), dtype=torch.uint8, device=d_flat.device)
+    flat_l = torch.zeros(64, dtype=torch.int32, device=d_flat.device)
+    args = lambda max_len, n_shards: (ix._h, C.c_void_p(d_flat.data_ptr()), C.c_void_p(d_off.data_ptr()), nq, max_len, 20, 100, 21, 0, n_shards, C.c_void_p(kept.data_ptr()),
+                                      C.c_void_p(offs.data_ptr()), 64, C.c_void_p(flat_l.data_ptr()), C.c_void_p(head.data_ptr()), C.c_void_p(pos.data_ptr()), C.c_void_p(rec.data_ptr()),
+                                      C.c_void_p(out.data_ptr()), C.c_void_p(sc.data_ptr()), C.c_void_p(cnt.data_ptr()), None)
+    assert L.srn_shard_lists_predict(*args(4, 0)) == capi.SRN_EINVAL                       # zero shards
+    assert L.srn_shard_lists_predict(*args(12, 1)) == capi.SRN_EINVAL                      # sessions of > 8 items: no position sets, the three-stage pipeline serves them
+    assert b"three-stage" in L.srn_last_error()
+    torch.cuda.synchronize()
+
+
 def test_lists_pipeline_synthetic_shape():
     """The production-shaped generator (long lists, popular items, m-cut and k-cut both active) through the lists pipeline on 3 shards."""
     import serenade_amd as sa
