@@ -43,7 +43,9 @@ def build_hip(force=False, verbose=False):
                 # moves and half the scratch accesses without it, +5..6 % queries/s
                 cmd += ["-mllvm", "-disable-machine-licm"]
             if name == "srn_fast.hip":
-                # same reason: invariants hoisted out of the per-query loop get spilled (11 -> 4 VGPR spills at the 80-register cap of three workgroups per CU)
+                # same reason: invariants hoisted out of the per-query loop get spilled (11 -> 4 VGPR spills at the 80-register cap of three workgroups per CU);
+                # -Os: 25.77 / 25.82 ms against 25.88 / 25.86 with -O3 (same box, alternating)
+                cmd[2] = "-Os"
                 cmd += ["-mllvm", "-disable-machine-licm"]
             cmd += extra + ["-c", "-o", obj, src]
             if verbose:
