@@ -31,7 +31,10 @@ namespace srn {
 
 // scalar words at the head of LDS
 enum { FS_NB = 0, FS_FAIL, FS_SURV, FS_CCNT, FS_HITS, FS_LIVE, FS_SCAN_A = 8, FS_SCAN_B = 8, FS_W3 = 8, FS_CLS = 16, FS_TACC = 32 };   // (the three scratch areas are never live together; words 32..63: debug counters)
-static constexpr uint32_t F_TOTAL = F_LDS_BYTES;
+// behind the per-query areas: every thread's own sample constants (idf_eff of the popular item it samples in phase 4a, and its attribute byte), read from global
+// memory ONCE per workgroup -- hand-made register spills into the 5 KB of LDS that three workgroups per CU leave over
+static constexpr uint32_t F_SIDF = F_LDS_BYTES, F_SATTR = F_SIDF + 512 * 8, F_TOTAL = F_SATTR + 512;
+static_assert(F_TOTAL * F_WG_PER_CU <= 160 * 1024, "LDS budget with the sample constants");
 static constexpr uint32_t F_MERGE_WORDS = F_WORK_WORDS;
 
 // per-phase cycle accounting (debug): summed per workgroup in LDS, flushed once at the end -- one global atomic per phase and
@@ -230,6 +233,8 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
     // the weight table uses are free.)
     uint32_t* const pre = (uint32_t*)(smem + F_W10 + 64);
     bool have_pre = false;   // block-uniform
+    { const ItemMeta m0 = f.meta_sample[tid];
+      ((double*)(smem + F_SIDF))[tid] = m0.idf > 0.0 ? m0.idf : 1.0; ((uint8_t*)(smem + F_SATTR))[tid] = (uint8_t)m0.attr; }   // (own slot only: no barrier)
     for (uint32_t q = blockIdx.x; q < p.nq; q += gridDim.x) {
         long long t_prev = ticking ? clock64() : 0;
         // ---- phase 0: the query's prep record -> run descriptors in SGPRs ------------------------------
@@ -523,9 +528,11 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             for (uint32_t i = tid; i < F_DUMP_WORDS; i += BLOCK) ((uint32_t*)(smem + F_DUMP))[i] = 0u;   // (walk B reads the dump words, where the positions past a row's end point, as "cannot reach the floor")
             bool valid = v != 0u && e != cur_idx;
             double x = 0.0; uint32_t tie = 0;
-            { const ItemMeta mt = f.meta_sample[tid];   // (coalesced, unconditional)
-              if (business) valid = valid && business_ok(cur_attr, mt.attr);   // an item the rules exclude is no candidate and sets no threshold
-              if (valid) { x = (mt.idf > 0.0 ? mt.idf : 1.0) * (double)v; tie = mt.id_rank; } }
+            // idf_eff and the attribute byte come from the thread's LDS slot; only the id rank (wanted after the barrier below, for the few candidates) is a
+            // global load -- nothing on the way to the wave reductions waits for memory
+            tie = f.meta_sample[tid].id_rank;   // (coalesced, unconditional)
+            if (business) valid = valid && business_ok(cur_attr, (uint32_t)((const uint8_t*)(smem + F_SATTR))[tid]);   // an item the rules exclude is no candidate and sets no threshold
+            if (valid) x = ((const double*)(smem + F_SIDF))[tid] * (double)v;
             const uint32_t k32 = (uint32_t)((unsigned long long)__double_as_longlong(x) >> 32);
             {
                 uint32_t vv = k32, third = 0;
