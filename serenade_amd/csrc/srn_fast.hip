@@ -33,7 +33,7 @@ namespace srn {
 enum { FS_NB = 0, FS_FAIL, FS_SURV, FS_CCNT, FS_HITS, FS_LIVE, FS_SCAN_A = 8, FS_SCAN_B = 8, FS_W3 = 8, FS_CLS = 16, FS_TACC = 32 };   // (the three scratch areas are never live together; words 32..63: debug counters)
 // behind the per-query areas: every thread's own sample constants (idf_eff of the popular item it samples in phase 4a, and its attribute byte), read from global
 // memory ONCE per workgroup -- hand-made register spills into the 5 KB of LDS that three workgroups per CU leave over
-static constexpr uint32_t F_SIDF = F_LDS_BYTES, F_SATTR = F_SIDF + 512 * 8, F_TOTAL = F_SATTR + 512;
+static constexpr uint32_t F_SIDF = F_LDS_BYTES, F_SATTR = F_SIDF + 512 * 8, F_TOTAL = F_SATTR + 512, F_SINV = F_W10 + 384;   // (F_SINV: 1 / max idf of the 8 chunks, then of all items -- 128 bytes behind the parked record in the weight table's unused tail; 53 760 bytes in all: one more allocation granule and only two workgroups fit a CU)
 static_assert(F_TOTAL * F_WG_PER_CU <= 160 * 1024, "LDS budget with the sample constants");
 static constexpr uint32_t F_MERGE_WORDS = F_WORK_WORDS;
 
@@ -234,7 +234,8 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
     uint32_t* const pre = (uint32_t*)(smem + F_W10 + 64);
     bool have_pre = false;   // block-uniform
     { const ItemMeta m0 = f.meta_sample[tid];
-      ((double*)(smem + F_SIDF))[tid] = m0.idf > 0.0 ? m0.idf : 1.0; ((uint8_t*)(smem + F_SATTR))[tid] = (uint8_t)m0.attr; }   // (own slot only: no barrier)
+      ((double*)(smem + F_SIDF))[tid] = m0.idf > 0.0 ? m0.idf : 1.0; ((uint8_t*)(smem + F_SATTR))[tid] = (uint8_t)m0.attr;   // (own slot only: no barrier)
+      if (tid < 16u) ((double*)(smem + F_SINV))[tid] = tid < 8u ? f.inv_idf_hot[tid] : f.inv_idf_hi; }   // (read in phase 4a: barriers in between)
     for (uint32_t q = blockIdx.x; q < p.nq; q += gridDim.x) {
         long long t_prev = ticking ? clock64() : 0;
         // ---- phase 0: the query's prep record -> run descriptors in SGPRs ------------------------------
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             // integer floors: an item needs idf * acc >= x_lo, i.e. acc >= x_lo / (largest idf of its chunk); shaved so that rounding
             // can only keep more.  Lane c computes chunk c's floor (lane 8: the sketch words'), broadcast by v_readlane.
             const double x_lo = __longlong_as_double((long long)((unsigned long long)t32m1 << 32));
-            const double inv = lane < 8u ? f.inv_idf_hot[lane & 7u] : f.inv_idf_hi;
+            const double inv = ((const double*)(smem + F_SINV))[min(lane, 8u)];
             const uint32_t my_floor = (uint32_t)fmin(4.0e9, fmax(1.0, floor(x_lo * inv * (1.0 - 1e-9)) - 1.0));
             floor_b = (uint32_t)__builtin_amdgcn_readlane((int)my_floor, 8);
 #pragma unroll
@@ -592,7 +593,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
                 const uint32_t t32b = (((t32m1 + 1u) >> 16) + bsel) << 16;
                 t32m1 = t32b - 1u;
                 const double x_lo = __longlong_as_double((long long)((unsigned long long)t32m1 << 32));
-                floor_b = (uint32_t)fmin(4.0e9, fmax(1.0, floor(x_lo * f.inv_idf_hi * (1.0 - 1e-9)) - 1.0));
+                floor_b = (uint32_t)fmin(4.0e9, fmax(1.0, floor(x_lo * ((const double*)(smem + F_SINV))[8] * (1.0 - 1e-9)) - 1.0));
             }
         }
         if (wave == 1u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the record has landed
