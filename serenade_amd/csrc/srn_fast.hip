@@ -1,7 +1,7 @@
 // =====================================================================================
 // VMIS-kNN predict_next on gfx950 (MI355X): the FAST kernel -- the lean instantiation of the path for the query shape a
 // production workload consists of: evolving sessions of <= 8 items of which <= 4 distinct known ones
-// have a non-empty posting list above x_lo, position-set slots (MASKS), 32-bit slots, k <= 1536, m <= 2560, how_many <= 24,
+// have a non-empty posting list above x_lo, list-set slots of 32 bits (28 rank bits + 4 list bits; 29 + 3 above 2^28 sessions), k <= 1536, m <= 2560, how_many <= 24,
 // business rules on or off, no debug outputs.  Everything else -- and every query this kernel meets that does not fit -- is
 // queued on a device-side list and served by vmis_predict_kernel (srn_kernels.hip) in a second launch: still on the GPU,
 // same results, bit for bit.  Same algorithm as the general kernel (find_neighbors src/vmisknn/vmis_index.rs:325-415,
@@ -13,6 +13,8 @@
 //     an item's accumulator word -- direct-mapped for the 4096 most popular items, a sketch word for the rest -- so the
 //     row walks cost one extract + one ds_add per item; unused positions hold offsets into a dump area (rows of
 //     different lengths need no masking);
+//   * the next query's prep record is fetched into LDS during the current query (global_load_lds), the threshold sample's constants sit in per-thread LDS
+//     slots: a query's critical path has one HBM round trip in front of the merges (its lists) and none in front of the top-n;
 //   * a wave's first-round row quads stay in registers between walk A and walk B; walk B only reads sketch words,
 //     and an element whose word could still reach the threshold fetches its item id from the general row slots;
 //   * the top-n runs in x = idf * acc space (one f64 multiply per candidate, the divide by 10 U only for the <= 160
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
 
         FAST_TICK(4);
 
-        // ---- walk A: one neighbour row per lane, the first 32 bytes (14 items) of all the wave's rows requested at once ---------
+        // ---- walk A: one neighbour row per lane; the first 16 bytes (6 items) of all the wave's rows requested at once, the next 16 only where a row has them ----
         uint32_t svr[3]; uint4 rq[3], rq1[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
