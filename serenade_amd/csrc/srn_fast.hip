@@ -964,13 +964,13 @@ hipError_t launch_finish(hipStream_t st, const DeviceIndex& di, const FastParams
     return hipGetLastError();
 }
 
-hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f) {
+hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f, bool debug) {
     auto kern = f.nb == 3u ? (di.row_frag ? vmis_fast_kernel<(int)F_WG_PER_CU, true, true> : vmis_fast_kernel<(int)F_WG_PER_CU, false, true>)
                            : (di.row_frag ? vmis_fast_kernel<(int)F_WG_PER_CU, true, false> : vmis_fast_kernel<(int)F_WG_PER_CU, false, false>);
     constexpr size_t dyn = SRN_FAST_SMALL ? 0 : F_TOTAL;
     if (dyn) { hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); if (e != hipSuccess) return e; }
     static bool told = false;
-    if (!told && getenv("SRN_DEBUG")) { told = true; int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 512, dyn);
+    if (!told && debug) { told = true; int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 512, dyn);
         fprintf(stderr, "[srn] vmis_fast_kernel: %u bytes of LDS, %d workgroups per CU (occupancy API)\n", F_TOTAL, nb); }
     hipLaunchKernelGGL(kern, grid, dim3(512), dyn, st, di, p, f);
     return hipGetLastError();

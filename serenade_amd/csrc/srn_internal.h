@@ -120,7 +120,8 @@ struct ExtLists { const char* prep; uint32_t prep_stride; const uint32_t* post_r
 int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p, bool buffers_on_device, void* stream,
                    // host-pointer mode: these are host buffers copied in/out by the call
                    const uint64_t* h_items, const uint32_t* h_qoff, uint64_t* h_ids, double* h_scores,
-                   uint32_t* h_counts, uint32_t* h_stats, uint32_t* h_nb_rank, uint32_t* h_nb_num, uint32_t* h_nb_cnt, const ExtLists* ext = nullptr);
+                   uint32_t* h_counts, uint32_t* h_stats, uint32_t* h_nb_rank, uint32_t* h_nb_num, uint32_t* h_nb_cnt, const ExtLists* ext = nullptr,
+                   bool reserve_only = false);   // reserve_only (srn_index_reserve): size the call's workspace, enqueue nothing
 struct ShardIO {
     void* cand; uint32_t* cand_cnt;                                       // A out: [nq * m] packed slots, [nq]
     const void* gathered; const uint32_t* gathered_cnt; uint32_t n_shards;   // B in: [G][nq * gathered_stride], [G][nq]

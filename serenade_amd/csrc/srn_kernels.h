@@ -92,7 +92,7 @@ hipError_t launch_shard_lists_copy(hipStream_t st, const DeviceIndex& di, uint32
                                    uint32_t* out);
 hipError_t launch_shard_prep(hipStream_t st, const uint64_t* items_flat, const uint32_t* q_off, uint32_t nq, uint32_t max_len, uint32_t n_shards, const uint32_t* kept_g,
                              const long long* off_g, unsigned long long shard_stride, const int* head, const ShardPos* pos_local, char* out, uint32_t stride);
-hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f);
+hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f, bool debug = false);   // debug: say the occupancy once (the SRN_DEBUG knob, read by the runtime)
 hipError_t launch_rows_to_packed(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base,
                                  uint32_t* packed, uint32_t* ext16, bool frag = false);   // grid = ceil((n_rows + 1) / 1024) blocks of 1024; block_base in 16-byte blocks
 hipError_t launch_rows_to_frags(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base,

@@ -50,7 +50,9 @@ struct Workspace {
     hipStream_t stream = nullptr;   // own stream for host-pointer calls
     static constexpr int RING = 64;               // per-call events: start, after main kernel, after retry pass, after prep kernel
     hipEvent_t ev[RING][5] = {};                  // ... [4] = after the fast kernel (== [3] when the launch did not use it)
-    uint64_t calls = 0; uint32_t last_retry = 0, last_nq = 0;
+    uint64_t calls = 0, untimed_calls = 0; uint32_t last_retry = 0, last_nq = 0;
+    bool last_fast = false;      // the last call went through the fast kernel: h_retry[1] = what it handed to the general kernel (otherwise: all of last_nq)
+    bool last_untimed = false;   // the last call took the latency path: no events were recorded for it
     // device scratch
     uint32_t* retry_list = nullptr; size_t retry_cap = 0; uint32_t* retry_cnt = nullptr;
     char* gscratch = nullptr; size_t gscratch_bytes = 0;
@@ -146,10 +148,16 @@ DeviceState* device_attach(const FlatIndex& ix, int device) {
                       hipMemcpy(d_base, bb.data(), nblocks * 4, hipMemcpyHostToDevice) == hipSuccess && hipMemset(d_e16, 0, (blocks + 2) * 16) == hipSuccess &&
                       launch_rows_to_packed(nullptr, (const uint64_t*)d_off, (const uint32_t*)d_items, (uint64_t)n, (const uint32_t*)d_base, (uint32_t*)d_pk, (uint32_t*)d_e16, frag) == hipSuccess &&
                       hipDeviceSynchronize() == hipSuccess;
-            if (d_pk) { d->allocs.push_back(d_pk); d->bytes += (n + 1) * slot_bytes; }
-            if (d_e16) { d->allocs.push_back(d_e16); d->bytes += (blocks + 2) * 16; }
-            if (g2) { d->fast.row_packed = (const RowQuad*)d_pk; d->fast.row_ext16 = (const uint32_t*)d_e16; }
-            else { good = false; }
+            // The packed rows are OPTIONAL (row_packed == nullptr: every query takes the general kernel): they cost another (n + 1) * slot_bytes of HBM
+            // next to row_slots, and an index that fits without them must still attach when they do not.
+            if (g2) { d->allocs.push_back(d_pk); d->bytes += (n + 1) * slot_bytes; d->allocs.push_back(d_e16); d->bytes += (blocks + 2) * 16;
+                      d->fast.row_packed = (const RowQuad*)d_pk; d->fast.row_ext16 = (const uint32_t*)d_e16; }
+            else {
+                (void)hipGetLastError();   // (clear the sticky allocation error)
+                if (d_pk) hipFree(d_pk); if (d_e16) hipFree(d_e16);
+                d->fast.row_packed = nullptr; d->fast.row_ext16 = nullptr;
+                if (knobs().debug) fprintf(stderr, "[srn] no room for the fast kernel's packed rows (%zu bytes): general kernel only\n", (size_t)((n + 1) * slot_bytes + (blocks + 2) * 16));
+            }
         }
         if (d_off) hipFree(d_off); if (d_items) hipFree(d_items); if (d_base) hipFree(d_base);
         if (d_slots) { d->allocs.push_back(d_slots); d->bytes += (n + 1) * slot_bytes; }
@@ -266,7 +274,7 @@ static inline uint32_t prime_at_least(uint64_t n) { uint32_t v = (uint32_t)std::
 
 struct Geometry {
     KernelCfg c{}; bool slot64 = false, masks = false; uint32_t slot_bytes = 4; size_t lds = 0;
-    uint64_t need_sess = 0, need_item = 0; bool sess_may_overflow = false, item_may_overflow = false;
+    uint64_t need_sess = 0, need_item = 0; bool sess_may_overflow = false, item_may_overflow = false, sketch_may_wrap = false;
 };
 // LDS layout + table sizes for one launch (all blocks alike).  min_region_b: extra room the caller needs in region B.
 static int make_geometry(const DeviceState* d, const FlatIndex& ix, const LaunchParams& p, uint32_t min_region_b, Geometry& g, uint32_t budget_bytes = 0) {
@@ -305,6 +313,20 @@ static int make_geometry(const DeviceState* d, const FlatIndex& ix, const Launch
     // position sets a session of >= 20 items can see weights up to min(Lmax, 99) - 10
     const uint64_t w_abs = g.masks ? 9 : std::max<uint64_t>(9, std::min<uint64_t>(Lmax, 99) > 10 ? std::min<uint64_t>(Lmax, 99) - 10 : 0);
     const uint64_t w_max = (uint64_t)p.k * w_abs * (Lmax * (Lmax + 1) / 2) + 1;
+    // The exact accumulators (item table, direct-mapped words) are 32-bit integers: |acc(item)| <= k * max over first-match positions q of
+    // |10 - q| * num_max(q), where a neighbour whose first match is at position q holds no more recent evolving item: num_max(q) = sum of (L - pos) over
+    // pos >= q - 1 = (L - q + 1)(L - q + 2) / 2.  Beyond 2^31 the sums would wrap silently: refuse the call instead (k = 8192 with sessions of ~90+ items).
+    {
+        uint64_t wn_max = 0;
+        for (uint64_t q = 1; q <= std::min<uint64_t>(Lmax, 99); ++q) {
+            const uint64_t wq = q <= 10 ? 10 - q : q - 10, nq_ = (Lmax - q + 1) * (Lmax - q + 2) / 2;
+            wn_max = std::max(wn_max, wq * nq_);
+        }
+        if ((uint64_t)p.k * wn_max >= (1ull << 31))
+            return fail(SRN_ERANGE, "k * |10 * linear_score| * similarity numerator can exceed the 32-bit item accumulators at this k and session length: lower k or max_items_in_session");
+        // a sketch word sums max(w, 0) * num over ALL elements that share it (<= k rows of <= max_row_len items): if even that could wrap, no sketch
+        g.sketch_may_wrap = (uint64_t)p.k * std::max<uint64_t>(1, ix.max_row_len) * 9ull * (Lmax * (Lmax + 1) / 2) >= (1ull << 32);
+    }
     const int sbits = std::max(2, bits_host(w_max) + 1), cbits = bits_host(p.k);
     // exact words for the 2048 most popular items, 4096 where a query walks many rows (measured with the end-of-round kernel, 2048 -> 4096:
     // config 3 / 4 (k = 1500) +2.6 % / +2.3 %, config 2 (k = 500) -2.6 %: clearing and harvesting the extra words costs more than they save there)
@@ -313,8 +335,8 @@ static int make_geometry(const DeviceState* d, const FlatIndex& ix, const Launch
     hot = std::min<uint32_t>(std::min<uint32_t>(hot, a_max / 8), round_up((uint32_t)std::min<uint64_t>(ix.n_items, 1u << 20), 4)) / 4 * 4;
     c.hot_slots = hot; c.sum_bits = (uint32_t)sbits;
     // sketch: upper-bound words for all other items (needs the direct-mapped part: its top n give the threshold)
-    uint32_t sk = hot ? 8192u : 0u;
-    if (kn.sketch_slots >= 0) sk = hot && kn.sketch_slots > 0 ? floor_pow2((uint64_t)kn.sketch_slots) : 0u;   // test knob
+    uint32_t sk = hot && !g.sketch_may_wrap ? 8192u : 0u;
+    if (kn.sketch_slots >= 0) sk = hot && !g.sketch_may_wrap && kn.sketch_slots > 0 ? floor_pow2((uint64_t)kn.sketch_slots) : 0u;   // test knob
     while (sk && (uint64_t)sk * 4 * 8 > (uint64_t)(a_max - hot * 4) * 5) sk >>= 1;   // leave >= 3/8 of the room to the exact table
     c.sketch_slots = sk; c.sketch_shift = sk ? 32u - (uint32_t)(bits_host(sk) - 1) : 31u;
     const uint64_t want_buckets = std::max<uint64_t>(61, g.need_item / 2 + 8);          // load <= 0.5 at the worst case
@@ -362,6 +384,9 @@ static int device_predict_tiny(DeviceState* d, Workspace* w, const Geometry& geo
                            w->spill, ShardIO{}));
     HIP_TRY(hipStreamSynchronize(st));
     if (*(volatile uint32_t*)(w->pin + o_rc) != 0) return 1;   // (rare: tables too small for some query)
+    // what the timing / path-count APIs report after this call: its query count, all through the general kernel, not timed (the stream is idle here:
+    // nothing of an earlier call is still writing the pinned words)
+    ++w->untimed_calls; w->last_nq = p.nq; w->last_retry = 0; w->last_fast = false; w->last_untimed = true;   // (`calls` indexes the event ring: timed calls only)
     const uint64_t* r_ids = (const uint64_t*)(w->pin + o_ids); const double* r_sc = (const double*)(w->pin + o_sc); const uint32_t* r_cnt = (const uint32_t*)(w->pin + o_cnt);
     for (uint32_t q = 0; q < p.nq; ++q) {
         const uint32_t n = r_cnt[q] == 0xFFFFFFFFu ? 0u : std::min<uint32_t>(r_cnt[q], p.how_many);
@@ -374,11 +399,9 @@ static int device_predict_tiny(DeviceState* d, Workspace* w, const Geometry& geo
     return SRN_OK;
 }
 
-static thread_local bool t_reserve_only = false;   // device_reserve: size the workspace of a call, launch nothing
-
 int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in, bool on_device, void* user_stream,
                    const uint64_t* h_items, const uint32_t* h_qoff, uint64_t* h_ids, double* h_scores, uint32_t* h_counts,
-                   uint32_t* h_stats, uint32_t* h_nb_rank, uint32_t* h_nb_num, uint32_t* h_nb_cnt, const ExtLists* ext) {
+                   uint32_t* h_stats, uint32_t* h_nb_rank, uint32_t* h_nb_num, uint32_t* h_nb_cnt, const ExtLists* ext, bool reserve_only) {
     HIP_TRY(hipSetDevice(d->device));
     LaunchParams p = p_in;
     if (p.nq == 0) return SRN_OK;
@@ -398,7 +421,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     const uint64_t need_sess = geo.need_sess, need_item = geo.need_item;
     const bool may_overflow = geo.sess_may_overflow || geo.item_may_overflow;
 
-    if (!on_device && p.nq <= 16 && !h_stats && !h_nb_rank && !d->phase_on && !knobs().dense) {
+    if (!on_device && !reserve_only && p.nq <= 16 && !h_stats && !h_nb_rank && !d->phase_on && !knobs().dense) {
         const int rc = device_predict_tiny(d, w, geo, p, h_items, h_qoff, h_ids, h_scores, h_counts);
         if (rc != 1) return rc;   // (1: some query needs the global-table pass -- the normal path below has it)
     }
@@ -442,11 +465,9 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         g_stride = (g_stride + 255) / 256 * 256;
         retry_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)d->n_cu, (2ull << 30) / g_stride));
         int rc = ensure(&w->gscratch, &w->gscratch_bytes, g_stride * retry_blocks); if (rc) return rc;
-        HIP_TRY(hipMemsetAsync(w->retry_cnt, 0, 4, st));
         if (dense) {
             if (w->retry_cap2 < p.nq) { if (w->retry_list2) HIP_TRY(hipFree(w->retry_list2)); w->retry_list2 = nullptr; w->retry_cap2 = 0;
                 HIP_TRY(hipMalloc((void**)&w->retry_list2, (size_t)p.nq * 4 + 64)); w->retry_cap2 = p.nq; }
-            HIP_TRY(hipMemsetAsync(w->retry_cnt2, 0, 4, st));
         }
     }
 
@@ -466,7 +487,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     // up to 2^29 with 3 (queries with more go to the general kernel)
     const int rank_bits_f = std::max(1, bits_host(ix.n_kept ? ix.n_kept - 1 : 0));
     const uint32_t nb_fast = kn.fast_runs == 3 && rank_bits_f <= 29 ? 3u : rank_bits_f <= 28 ? 4u : rank_bits_f <= 29 ? 3u : 0u;
-    const bool fast = d->fast.row_packed != nullptr && geo.masks && nb_fast != 0 && kn.geometry_default() && !kn.no_fast && p.k <= F_K_MAX && p.m <= F_M_MAX &&
+    const bool fast = d->fast.row_packed != nullptr && geo.masks && !geo.sketch_may_wrap && nb_fast != 0 && kn.geometry_default() && !kn.no_fast && p.k <= F_K_MAX && p.m <= F_M_MAX &&
                       p.how_many <= 24 && (p.flags & ~(unsigned)SRN_FLAG_BUSINESS_LOGIC) == 0 && p.stats == nullptr && p.nb_rank == nullptr && p.max_len <= 8;
     if (fast) {   // (all allocations of a call happen before its first launch)
         if (w->slow_cap < p.nq) { if (w->slow_list) HIP_TRY(hipFree(w->slow_list)); w->slow_list = nullptr; w->slow_cap = 0;
@@ -475,7 +496,8 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         const uint64_t big_entries = std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)p.nq * 16 + 4096);
         { int rc = ensure(&w->big, &w->big_bytes, big_entries * 16 + (size_t)p.nq * 4 + 64); if (rc) return rc; }
     }
-    if (t_reserve_only) return SRN_OK;
+    if (reserve_only) return SRN_OK;   // (srn_index_reserve: the workspace is sized, nothing was enqueued)
+    if (may_overflow || dense) { HIP_TRY(hipMemsetAsync(w->retry_cnt, 0, 4, st)); if (dense) HIP_TRY(hipMemsetAsync(w->retry_cnt2, 0, 4, st)); }
     hipEvent_t* ev = w->ev[w->calls % Workspace::RING];
     HIP_TRY(hipEventRecord(ev[0], st));
     if (ext) { if (ext->prep_stride != prep_stride) return fail(SRN_EINVAL, "prep record stride mismatch"); p.prep = ext->prep; p.prep_stride = prep_stride; }
@@ -495,7 +517,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         const uint64_t big_entries = std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)p.nq * 16 + 4096);
         FastParams fp = d->fast; fp.slow_list = w->slow_list; fp.slow_cnt = w->slow_cnt; fp.nb = nb_fast; fp.max_runs = nb_fast; fp.fin = w->fin;
         fp.big_arena = w->big; fp.big_list = (uint32_t*)(w->big + big_entries * 16); fp.big_ticket = (unsigned long long*)(w->slow_cnt + 2); fp.big_cap_entries = (uint32_t)big_entries;
-        HIP_TRY(launch_fast(dim3(grid_f), st, di, p, fp));
+        HIP_TRY(launch_fast(dim3(grid_f), st, di, p, fp, kn.debug));
         HIP_TRY(hipEventRecord(ev[4], st));
         HIP_TRY(launch_predict(geo.masks, slot64, false, 0, dim3(grid), lds, st, di, p, c, w->slow_list, w->slow_cnt, w->retry_list, w->retry_cnt, nullptr, 0, spill, ShardIO{}));
         HIP_TRY(launch_finish(st, di, fp, p.out_ids, p.out_scores, p.out_counts, p.nq, p.how_many));
@@ -515,10 +537,10 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
                                w->gscratch, g_stride, spill, ShardIO{}));
         HIP_TRY(hipMemcpyAsync(w->h_retry, final_cnt, 4, hipMemcpyDeviceToHost, st));
     }
-    if (fast) HIP_TRY(hipMemcpyAsync(w->h_retry + 1, w->slow_cnt, 4, hipMemcpyDeviceToHost, st));
-    else w->h_retry[1] = p.nq;
+    if (fast) HIP_TRY(hipMemcpyAsync(w->h_retry + 1, w->slow_cnt, 4, hipMemcpyDeviceToHost, st));   // (not fast: last_fast = false says "all of last_nq" -- no host write into a
+                                                                                                   //  pinned word that an earlier call's copy on this stream may still be writing)
     HIP_TRY(hipEventRecord(ev[2], st));
-    ++w->calls; w->last_retry = (may_overflow || dense) ? 1 : 0; w->last_nq = p.nq;
+    ++w->calls; w->last_retry = (may_overflow || dense) ? 1 : 0; w->last_nq = p.nq; w->last_fast = fast; w->last_untimed = false;
 
     if (!on_device) {
         HIP_TRY(hipMemcpyAsync(h_ids, p.out_ids, n_out * 8, hipMemcpyDeviceToHost, st));
@@ -581,6 +603,7 @@ int device_shard_lists_predict(DeviceState* d, const FlatIndex& ix, const Launch
                                unsigned long long shard_stride, const uint32_t* lists_g, const int* head, const void* pos_local, char* records, void* stream) {
     HIP_TRY(hipSetDevice(d->device));
     if (p.nq == 0) return SRN_OK;
+    if (n_shards != ix.n_shards) return fail(SRN_EINVAL, "n_shards differs from the number of shards this index was cut into");
     if (!device_shard_lists_supported(d, ix, p)) return fail(SRN_EINVAL, "lists mode needs position-set slots (sessions of <= 8 items, m <= m_index, complete lists): use the three-stage pipeline");
     const uint32_t stride = device_prep_stride(p.max_len);
     HIP_TRY(launch_shard_prep((hipStream_t)stream, p.items_flat, p.q_off, p.nq, p.max_len, n_shards, kept_g, off_g, shard_stride, head, (const ShardPos*)pos_local, records, stride));
@@ -599,7 +622,8 @@ int device_last_kernel_ms(DeviceState* d, double* ms_main, double* ms_retry, uin
     HIP_TRY(hipSetDevice(d->device));
     Workspace* w;
     { std::lock_guard<std::mutex> lk(d->mu); w = d->last_ws; }
-    if (!w || !w->calls) return fail(SRN_EINVAL, "no timed predict call yet");
+    if (!w || !(w->calls + w->untimed_calls)) return fail(SRN_EINVAL, "no timed predict call yet");
+    if (w->last_untimed) return fail(SRN_EINVAL, "the last call took the latency path (<= 16 sessions on host pointers): it records no events");
     hipEvent_t* ev = w->ev[(w->calls - 1) % Workspace::RING];
     HIP_TRY(hipEventSynchronize(ev[2]));
     float a = 0, b = 0;
@@ -615,20 +639,17 @@ int device_last_kernel_ms(DeviceState* d, double* ms_main, double* ms_retry, uin
 // Sizes the workspace bound to `stream` for device-pointer calls of up to nq queries with these parameters, so that
 // srn_predict_batch_device allocates nothing (hipMalloc / hipFree synchronise the device) once traffic starts.
 int device_reserve(DeviceState* d, const FlatIndex& ix, const LaunchParams& p, void* stream) {
-    t_reserve_only = true;
-    const int rc = device_predict(d, ix, p, true, stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-    t_reserve_only = false;
-    return rc;
+    return device_predict(d, ix, p, true, stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, /*reserve_only=*/true);
 }
 
 int device_last_path_counts(DeviceState* d, uint32_t* nq, uint32_t* general, uint32_t* global_pass) {
     HIP_TRY(hipSetDevice(d->device));
     Workspace* w;
     { std::lock_guard<std::mutex> lk(d->mu); w = d->last_ws; }
-    if (!w || !w->calls) return fail(SRN_EINVAL, "no predict call yet");
-    HIP_TRY(hipEventSynchronize(w->ev[(w->calls - 1) % Workspace::RING][2]));
+    if (!w || !(w->calls + w->untimed_calls)) return fail(SRN_EINVAL, "no predict call yet");
+    if (!w->last_untimed) HIP_TRY(hipEventSynchronize(w->ev[(w->calls - 1) % Workspace::RING][2]));   // (the latency path returns with its stream idle)
     if (nq) *nq = w->last_nq;
-    if (general) *general = w->h_retry[1];
+    if (general) *general = w->last_fast ? w->h_retry[1] : w->last_nq;
     if (global_pass) *global_pass = w->last_retry ? w->h_retry[0] : 0;
     return SRN_OK;
 }

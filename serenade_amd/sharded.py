@@ -290,6 +290,10 @@ def predict_batch_sharded_lists(index, comm, d_items_flat, d_q_off, nq, max_len,
     prefixes, the unsharded kernels over this shard's row fragments, all-gather + merge of the per-shard top-n.  Same arguments
     and results as predict_batch_sharded; one host synchronisation per batch (the size of the exchange buffer)."""
     import torch
+    if nq == 0:   # (the C side returns SRN_OK for an empty batch; `off[-1:]` of nothing has no .item())
+        dev = d_items_flat.device
+        return (torch.zeros((0, how_many), dtype=torch.int64, device=dev), torch.zeros((0, how_many), dtype=torch.float64, device=dev),
+                torch.zeros(0, dtype=torch.int32, device=dev))
     if stream is None:
         stream = torch.cuda.current_stream(d_items_flat.device).cuda_stream
     pos, head = _lists_head(index, d_items_flat, d_q_off, nq, max_len, m, stream)

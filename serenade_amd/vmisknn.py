@@ -131,12 +131,23 @@ class VMISIndex:
         return out
 
 
+def _is_csr_pair(sessions):
+    """(items_flat, q_off): two 1-D numpy arrays, q_off of ANY integer dtype (np.cumsum hands back int64), starting at 0, non-decreasing and
+    ending at len(items_flat)."""
+    if not (isinstance(sessions, tuple) and len(sessions) == 2 and all(isinstance(a, np.ndarray) and a.ndim == 1 for a in sessions)):
+        return False
+    flat, off = sessions
+    if not np.issubdtype(off.dtype, np.integer) or len(off) < 1:
+        return False
+    return int(off[0]) == 0 and int(off[-1]) == len(flat) and (len(off) < 2 or bool((off[1:] >= off[:-1]).all()))
+
+
 def _flatten(sessions):
-    # CSR input is a tuple of two numpy arrays (items_flat, q_off) with q_off a 32-bit offset array starting at 0 and ending at
-    # len(items_flat); a tuple of two evolving sessions (lists, or arrays that are not such a pair) is two queries
-    if isinstance(sessions, tuple) and len(sessions) == 2 and all(isinstance(a, np.ndarray) for a in sessions) \
-            and sessions[1].dtype in (np.uint32, np.int32) and len(sessions[1]) >= 1 and int(sessions[1][0]) == 0 \
-            and int(sessions[1][-1]) == len(sessions[0]):
+    # CSR input is a tuple of two numpy arrays (items_flat, q_off), see _is_csr_pair; a tuple of two evolving sessions (lists, or arrays
+    # that are not such a pair) is two queries
+    if _is_csr_pair(sessions):
+        if len(sessions[0]) > 0xFFFFFFFF:
+            raise ValueError("more than 2^32 - 1 items in one batch: q_off is 32-bit in the C ABI")
         return capi.as_u64(sessions[0]), capi.as_u32(sessions[1])
     off = np.zeros(len(sessions) + 1, np.uint32)
     off[1:] = np.cumsum([len(s) for s in sessions])

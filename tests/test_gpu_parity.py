@@ -158,6 +158,31 @@ def test_very_long_sessions_keep_the_accumulators_exact():
     assert (res["scores"] < 0).any(), "expected negative scores (positions beyond 10)"
 
 
+def test_accumulator_range_guard_at_the_abi_limits():
+    """The exact accumulators are 32-bit: k = SRN_MAX_K with sessions whose first matches sit near position 90+ could push
+    k * |10 * linear_score| * numerator past 2^31.  Such a call is refused with SRN_ERANGE instead of wrapping; the
+    same k with sessions the bound allows still matches the oracle."""
+    import serenade_amd as sa
+    from serenade_amd import capi
+    O = _oracle()
+    off, items, ts, ids = small_dataset(19, n_sessions=3000, n_items=60, max_len=6)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, 3000, 10, 1.0)
+    oix = O.OracleIndex(off, items, ts, 3000, 10, 1.0)
+    rng = np.random.default_rng(3)
+    long_q = [int(x) for x in ids[rng.choice(len(ids), size=6)]] + [int(5 + j) for j in range(249)]     # 255 items: the ABI limit
+    with pytest.raises(sa.SerenadeError) as e:
+        sa.predict_batch(gix, [long_q], capi.MAX_K, 3000, 21, False)
+    assert e.value.code == capi.SRN_ERANGE
+    with pytest.raises(sa.SerenadeError) as e:
+        sa.predict(gix, long_q, capi.MAX_K, 3000, 21, False)
+    assert e.value.code == capi.SRN_ERANGE
+    # k * 1.11 M < 2^31 for k = 1900 at L = 255: allowed, and exact
+    _check_batch(gix, oix, [long_q, long_q[3:200]], 1900, 3000, 40, check_neighbours=False)
+    # k = 8192 with sessions of <= 60 items (8192 * 50 * 11 * 12 / 2 ... well inside): allowed, and exact
+    qs = [[int(x) for x in ids[rng.choice(len(ids), size=5)]] + [int(5 + j) for j in range(int(rng.integers(20, 55)))] for _ in range(6)]
+    _check_batch(gix, oix, qs, capi.MAX_K, 3000, 40, check_neighbours=False)
+
+
 def test_unknown_items_and_single_predict():
     import serenade_amd as sa
     off, items, ts, ids = small_dataset(5)
