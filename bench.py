@@ -306,7 +306,7 @@ def main():
     lat_single = None
     if not args.no_sweep:
         d_flat, d_off, _, _ = batches[0]
-        for s in [1, 64, 4096, 65536, 1 << 20]:
+        for s in [1, 16, 64, 256, 4096, 65536, 1 << 20]:
             if s > B:
                 continue
             reps = 30 if s <= 65536 else 10
@@ -319,12 +319,12 @@ def main():
             torch.cuda.synchronize()
             dms = np.array([a.elapsed_time(b) for a, b in es])
             hf, ho = flat0[:qo0[s]], qo0[:s + 1]
-            hms = []
-            for _ in range(reps // 3 + 2):
+            hms, hout = [], None
+            for _ in range(reps // 3 + 3):   # (the host keeps its result buffers between calls, like a serving / evaluator process: first call allocates, untimed)
                 t1 = time.perf_counter()
-                sa.predict_batch(index, (hf, ho), k, m, how_many, False)
+                hout = sa.predict_batch(index, (hf, ho), k, m, how_many, False, out=hout)
                 hms.append((time.perf_counter() - t1) * 1e3)
-            hms = np.array(hms[1:])
+            hms = np.array(hms[2:])
             sweep.append({"batch": s, "device_resident": {"queries_per_s": s / (float(np.median(dms)) * 1e-3), "ms_p50": float(np.median(dms)), "ms_p90": float(np.percentile(dms, 90))},
                           "host_inclusive": {"queries_per_s": s / (float(np.median(hms)) * 1e-3), "ms_p50": float(np.median(hms)), "ms_p90": float(np.percentile(hms, 90))}})
         lat = []
@@ -377,8 +377,9 @@ def main():
                     "single_query_us_p50": float(np.percentile(lat_single, 50)) if lat_single is not None else None,
                     "single_query_us_p90": float(np.percentile(lat_single, 90)) if lat_single is not None else None,
                     "batch_sweep": sweep,
-                    "note": "batch_sweep: srn_predict_batch_device on resident buffers (HIP events) vs srn_predict_batch on host buffers (pageable numpy arrays: "
-                            "upload + launches + download, wall clock); single_query = srn_predict (host pointers, one evolving session per call, PCIe-inclusive)"},
+                    "note": "batch_sweep: srn_predict_batch_device on resident buffers (HIP events) vs srn_predict_batch on host buffers (pageable numpy arrays, result buffers "
+                            "reused between calls: upload + launches + download, wall clock; <= 256 sessions: zero-copy latency path, above: chunked pipeline); "
+                            "single_query = srn_predict (host pointers, one evolving session per call, PCIe-inclusive)"},
         "queries_served_last_step": served,
     })
 

@@ -142,9 +142,17 @@ void srn_index_free(srn_index_t* idx);
 int srn_predict(const srn_index_t* idx, const uint64_t* evolving, size_t len, size_t k, size_t m,
                 size_t how_many, int enable_business_logic, uint64_t* out_ids, double* out_scores,
                 size_t* out_n);
+/* srn_predict is re-entrant on one handle from any number of host threads, like predict() on the Arc<VMISIndex> the actix workers
+ * share (src/bin/serving.rs:62-94).  Concurrent calls with the same (k, m, how_many, business flag) COMBINE into rounds: one batch
+ * launch serves every call that arrived while the previous rounds ran (a lone caller runs alone, at once; environment
+ * SRN_PREDICT_LANES = rounds in flight side by side, default 4, 0 = never combine).  Counters since the handle was created: */
+int srn_predict_stats(const srn_index_t* idx, uint64_t* out_rounds, uint64_t* out_requests, uint64_t* out_max_round);
 
 /* nq sessions in CSR form: session q = items_flat[q_off[q] .. q_off[q+1]).  Host pointers.
- * out_ids / out_scores are [nq * how_many] (row q at q * how_many), out_counts [nq]. */
+ * out_ids / out_scores are [nq * how_many] (row q at q * how_many), out_counts [nq].
+ * Up to 256 sessions take the zero-copy latency path (pinned, device-mapped staging: two launches, no copies); larger batches are cut into
+ * chunks whose uploads, kernels and downloads overlap on separate streams, the results landing in the caller's buffers while
+ * the next chunks run (srn_hostpipe.hip).  The buffers may be pageable. */
 int srn_predict_batch(const srn_index_t* idx, const uint64_t* items_flat, const uint32_t* q_off, size_t nq,
                       size_t k, size_t m, size_t how_many, unsigned flags, uint64_t* out_ids,
                       double* out_scores, uint32_t* out_counts);

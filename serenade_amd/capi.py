@@ -54,6 +54,7 @@ SYMBOLS = {
     "srn_index_postings": (_i, [_vp, _u64, _vp, _sz, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "srn_index_free": (None, [_vp]),
     "srn_predict": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _i, _vp, _vp, C.POINTER(_sz)]),
+    "srn_predict_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
     "srn_predict_batch": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint, _vp, _vp, _vp]),
     "srn_batcher_create": (_i, [_vp, _sz, C.c_uint, _sz, _sz, _sz, _i, C.POINTER(_vp)]),
     "srn_batcher_predict": (_i, [_vp, _vp, _sz, _vp, _vp, C.POINTER(_sz)]),

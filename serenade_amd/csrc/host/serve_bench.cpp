@@ -54,7 +54,7 @@ int main(int argc, char** argv) {
     std::vector<float> all; for (auto& v : lat) all.insert(all.end(), v.begin(), v.end());
     std::sort(all.begin(), all.end());
     auto pct = [&](double p) { return all.empty() ? 0.f : all[std::min(all.size() - 1, (size_t)(p * all.size()))]; };
-    uint64_t nr = 0, nb = 0, mx = 0; if (b) srn_batcher_stats(b, &nr, &nb, &mx);
+    uint64_t nr = 0, nb = 0, mx = 0; if (b) srn_batcher_stats(b, &nr, &nb, &mx); else srn_predict_stats(idx, &nb, &nr, &mx);   // (direct: the rounds concurrent srn_predict calls combined into)
     printf("{\"mode\": \"%s\", \"threads\": %d, \"seconds\": %.2f, \"requests\": %zu, \"requests_per_s\": %.1f, \"errors\": %llu, "
            "\"latency_us\": {\"p50\": %.1f, \"p90\": %.1f, \"p99\": %.1f, \"p99_5\": %.1f, \"max\": %.1f}, \"batches\": %llu, \"mean_batch\": %.1f, \"max_batch_seen\": %llu, "
            "\"max_batch\": %zu, \"max_wait_us\": %u}\n",

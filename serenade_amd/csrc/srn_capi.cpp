@@ -101,7 +101,7 @@ int srn_index_build(const srn_sessions_view_t* sessions, size_t m_index, size_t 
         *out = nullptr;
         srn_index* ix = new srn_index();
         int rc = build_flat_index(*sessions, m_index, max_session_len, idf_weighting, 0, 1, ix->flat);
-        if (rc == SRN_OK && device >= 0) { ix->dev = device_attach(ix->flat, device); ix->device = device; if (!ix->dev) rc = SRN_EHIP; }
+        if (rc == SRN_OK && device >= 0) { ix->dev = device_attach(ix->flat, device); ix->device = device; if (!ix->dev) rc = SRN_EHIP; else ix->comb = combiner_create(); }
         if (rc) { delete ix; return rc; }
         *out = ix; return SRN_OK; });
 }
@@ -114,7 +114,7 @@ int srn_index_build_gpu(const srn_sessions_view_t* sessions, size_t m_index, siz
         *out = nullptr;
         srn_index* ix = new srn_index();
         int rc = build_flat_index_gpu(*sessions, m_index, max_session_len, idf_weighting, device, ix->flat);
-        if (rc == SRN_OK) { ix->dev = device_attach(ix->flat, device); ix->device = device; if (!ix->dev) rc = SRN_EHIP; }
+        if (rc == SRN_OK) { ix->dev = device_attach(ix->flat, device); ix->device = device; if (!ix->dev) rc = SRN_EHIP; else ix->comb = combiner_create(); }
         if (rc) { delete ix; return rc; }
         *out = ix; return SRN_OK; });
 }
@@ -138,7 +138,7 @@ int srn_index_new_from_avro(const char* base_path, int device, srn_index_t** out
         *out = nullptr;
         srn_index* ix = new srn_index();
         int rc = build_flat_index_from_avro(base_path, ix->flat);
-        if (rc == SRN_OK && device >= 0) { ix->dev = device_attach(ix->flat, device); ix->device = device; if (!ix->dev) rc = SRN_EHIP; }
+        if (rc == SRN_OK && device >= 0) { ix->dev = device_attach(ix->flat, device); ix->device = device; if (!ix->dev) rc = SRN_EHIP; else ix->comb = combiner_create(); }
         if (rc) { delete ix; return rc; }
         *out = ix; return SRN_OK; });
 }
@@ -153,7 +153,7 @@ int srn_index_load(const char* path, int device, srn_index_t** out) {
         *out = nullptr;
         srn_index* ix = new srn_index();
         int rc = load_flat_index(path, ix->flat);
-        if (rc == SRN_OK && device >= 0) { ix->dev = device_attach(ix->flat, device); ix->device = device; if (!ix->dev) rc = SRN_EHIP; }
+        if (rc == SRN_OK && device >= 0) { ix->dev = device_attach(ix->flat, device); ix->device = device; if (!ix->dev) rc = SRN_EHIP; else ix->comb = combiner_create(); }
         if (rc) { delete ix; return rc; }
         *out = ix; return SRN_OK; });
 }
@@ -189,6 +189,7 @@ int srn_index_postings(const srn_index_t* idx, uint64_t item_id, uint32_t* out_s
 void srn_index_free(srn_index_t* idx) {
     if (!idx) return;
     device_release(idx->dev);
+    if (idx->comb) combiner_free(idx->comb);
     delete idx;
 }
 
@@ -199,11 +200,26 @@ int srn_predict(const srn_index_t* idx, const uint64_t* evolving, size_t len, si
         *out_n = 0;
         if (!evolving || len == 0) return fail(SRN_EINVAL, "empty evolving session (the reference panics: src/vmisknn/mod.rs:157)");
         if (len > SRN_MAX_SESSION_LEN) return fail(SRN_ERANGE, "evolving session longer than SRN_MAX_SESSION_LEN");
+        // concurrent calls on one handle share launches (srn_combine.cpp); a lone caller runs its own round of one at once
+        const int lanes = knob_predict_lanes();
+        if (lanes > 0 && idx && idx->comb) {
+            int rc = check_predict_args(idx, k, m, how_many); if (rc) return rc;
+            rc = check_not_a_shard(idx); if (rc) return rc;
+            if (!out_ids || !out_scores) return fail(SRN_EINVAL, "null buffer");
+            return combiner_predict(idx->comb, idx, evolving, len, k, m, how_many, enable_business_logic ? SRN_FLAG_BUSINESS_LOGIC : 0, out_ids, out_scores, out_n,
+                                    lanes, knob_tiny_max());
+        }
         const uint32_t q_off[2] = {0, (uint32_t)len}; uint32_t cnt = 0;
         int rc = predict_host(idx, evolving, q_off, 1, k, m, how_many, enable_business_logic ? SRN_FLAG_BUSINESS_LOGIC : 0, out_ids,
                               out_scores, &cnt, nullptr, nullptr, nullptr, nullptr);
         if (rc == SRN_OK) *out_n = cnt;
         return rc; });
+}
+
+int srn_predict_stats(const srn_index_t* idx, uint64_t* out_rounds, uint64_t* out_requests, uint64_t* out_max_round) {
+    if (!idx || !idx->comb) return fail(SRN_ENODEV, "index has no device attached");
+    combiner_stats(idx->comb, out_rounds, out_requests, out_max_round);
+    return SRN_OK;
 }
 
 int srn_predict_batch(const srn_index_t* idx, const uint64_t* items_flat, const uint32_t* q_off, size_t nq, size_t k, size_t m,
@@ -260,7 +276,7 @@ int srn_index_build_shard(const srn_sessions_view_t* sessions, size_t m_index, s
         *out = nullptr;
         srn_index* ix = new srn_index();
         int rc = build_flat_index(*sessions, m_index, max_session_len, idf_weighting, shard, n_shards, ix->flat);
-        if (rc == SRN_OK && device >= 0) { ix->dev = device_attach(ix->flat, device); ix->device = device; if (!ix->dev) rc = SRN_EHIP; }
+        if (rc == SRN_OK && device >= 0) { ix->dev = device_attach(ix->flat, device); ix->device = device; if (!ix->dev) rc = SRN_EHIP; else ix->comb = combiner_create(); }
         if (rc) { delete ix; return rc; }
         *out = ix; return SRN_OK; });
 }
@@ -270,7 +286,7 @@ int srn_index_shard(const srn_index_t* full, uint32_t shard, uint32_t n_shards, 
         *out = nullptr;
         srn_index* ix = new srn_index();
         int rc = shard_flat_index(full->flat, shard, n_shards, ix->flat);
-        if (rc == SRN_OK && device >= 0) { ix->dev = device_attach(ix->flat, device); ix->device = device; if (!ix->dev) rc = SRN_EHIP; }
+        if (rc == SRN_OK && device >= 0) { ix->dev = device_attach(ix->flat, device); ix->device = device; if (!ix->dev) rc = SRN_EHIP; else ix->comb = combiner_create(); }
         if (rc) { delete ix; return rc; }
         *out = ix; return SRN_OK; });
 }
@@ -285,7 +301,7 @@ int srn_index_build_shard_gpu(const srn_sessions_view_t* sessions, size_t m_inde
         if (rc) return rc;
         srn_index* ix = new srn_index();
         rc = shard_flat_index(full, shard, n_shards, ix->flat);
-        if (rc == SRN_OK) { ix->dev = device_attach(ix->flat, device); ix->device = device; if (!ix->dev) rc = SRN_EHIP; }
+        if (rc == SRN_OK) { ix->dev = device_attach(ix->flat, device); ix->device = device; if (!ix->dev) rc = SRN_EHIP; else ix->comb = combiner_create(); }
         if (rc) { delete ix; return rc; }
         *out = ix; return SRN_OK; });
 }
@@ -299,7 +315,7 @@ int srn_index_load_shard(const char* path, uint32_t shard, uint32_t n_shards, in
         srn_index* ix = new srn_index();
         rc = full.n_shards == 1 ? shard_flat_index(full, shard, n_shards, ix->flat)
                                 : (full.shard == shard && full.n_shards == n_shards ? (ix->flat = std::move(full), SRN_OK) : fail(SRN_EINVAL, "the file holds another shard"));
-        if (rc == SRN_OK && device >= 0) { ix->dev = device_attach(ix->flat, device); ix->device = device; if (!ix->dev) rc = SRN_EHIP; }
+        if (rc == SRN_OK && device >= 0) { ix->dev = device_attach(ix->flat, device); ix->device = device; if (!ix->dev) rc = SRN_EHIP; else ix->comb = combiner_create(); }
         if (rc) { delete ix; return rc; }
         *out = ix; return SRN_OK; });
 }

@@ -1,0 +1,107 @@
+// =====================================================================================
+// srn_predict from MANY host threads on one index: combining rounds.
+//
+// The reference's serving binary calls vmisknn::predict once per HTTP request on `num_workers` actix threads that share one Arc<VMISIndex>
+// (src/bin/serving.rs:62-94, src/endpoints/recommend_resource.rs:56).  On a GPU a call is two launches and a stream synchronise: 16 threads doing that
+// side by side reach 91 K requests/s, 64 threads fall to 26 K with a 75 ms p99 (64 streams, 64 spinning waits on 16 cores: round 2's
+// profiles/r02_serving_cfg3.json).  So concurrent srn_predict calls on one handle COMBINE: a caller that finds an open round joins it and sleeps on
+// the round's futex; a caller that finds none opens one, waits for one of a few lanes (SRN_PREDICT_LANES, default 4: that many rounds run side by side),
+// closes the round and runs it as ONE batch on the zero-copy latency path; every member copies its own rows out.  A lone caller opens, closes and
+// runs its own round at once -- the latency path of before plus one uncontended mutex.  No dispatcher thread, no timer: a round is as large as
+// the load that arrived while the lanes were busy.  (srn_batcher_* remains the explicit queue for hosts that want max_batch / max_wait control.)
+// =====================================================================================
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <climits>
+#include <condition_variable>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "srn_internal.h"
+
+namespace srn {
+
+namespace {
+struct Round {
+    size_t k, m, how_many; unsigned flags;
+    std::vector<const uint64_t*> ev; std::vector<uint32_t> len;          // members' evolving sessions (borrowed: the members are blocked in their calls)
+    std::vector<uint64_t> ids; std::vector<double> scores; std::vector<uint32_t> counts;
+    int rc = SRN_OK; std::string err;
+    std::atomic<uint32_t> done{0};
+    bool closed = false;
+};
+void futex_wait(std::atomic<uint32_t>* w) {
+    while (w->load(std::memory_order_acquire) == 0) syscall(SYS_futex, reinterpret_cast<uint32_t*>(w), FUTEX_WAIT_PRIVATE, 0u, nullptr, nullptr, 0);
+}
+void futex_wake_all(std::atomic<uint32_t>* w) {
+    w->store(1, std::memory_order_release);
+    syscall(SYS_futex, reinterpret_cast<uint32_t*>(w), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+}
+}  // namespace
+
+struct Combiner {
+    std::mutex mu; std::condition_variable cv_lane;
+    std::vector<std::shared_ptr<Round>> open;   // joinable rounds (one per parameter set in use: a serving process has one)
+    int lanes_busy = 0;
+    std::atomic<uint64_t> n_rounds{0}, n_requests{0}, max_round{0};
+};
+Combiner* combiner_create() { return new Combiner(); }
+void combiner_free(Combiner* c) { delete c; }
+void combiner_stats(const Combiner* c, uint64_t* rounds, uint64_t* requests, uint64_t* max_round) {
+    if (rounds) *rounds = c->n_rounds.load(); if (requests) *requests = c->n_requests.load(); if (max_round) *max_round = c->max_round.load();
+}
+
+// One evolving session through the index's combiner.  Arguments are validated by the caller (srn_predict).
+int combiner_predict(Combiner* c, const srn_index* idx, const uint64_t* evolving, size_t len, size_t k, size_t m, size_t how_many, unsigned flags,
+                     uint64_t* out_ids, double* out_scores, size_t* out_n, int lanes, size_t round_cap) {
+    std::shared_ptr<Round> r; size_t me = 0; bool leader = false;
+    {
+        std::unique_lock<std::mutex> lk(c->mu);
+        for (auto& o : c->open)
+            if (!o->closed && o->k == k && o->m == m && o->how_many == how_many && o->flags == flags && o->ev.size() < round_cap) { r = o; break; }
+        if (r) { me = r->ev.size(); r->ev.push_back(evolving); r->len.push_back((uint32_t)len); }
+        else {
+            r = std::make_shared<Round>(); r->k = k; r->m = m; r->how_many = how_many; r->flags = flags;
+            r->ev.push_back(evolving); r->len.push_back((uint32_t)len);
+            c->open.push_back(r); leader = true;
+            c->cv_lane.wait(lk, [&] { return c->lanes_busy < lanes; });   // (the round stays open meanwhile: the load that arrives now rides along)
+            ++c->lanes_busy; r->closed = true;
+            c->open.erase(std::find(c->open.begin(), c->open.end(), r));
+        }
+    }
+    if (leader) {
+        const size_t nq = r->ev.size();
+        try {
+            std::vector<uint64_t> flat; std::vector<uint32_t> off(nq + 1, 0); uint32_t max_len = 0;
+            for (size_t i = 0; i < nq; ++i) { flat.insert(flat.end(), r->ev[i], r->ev[i] + r->len[i]); off[i + 1] = (uint32_t)flat.size(); max_len = std::max(max_len, r->len[i]); }
+            r->ids.assign(nq * how_many, 0); r->scores.assign(nq * how_many, 0.0); r->counts.assign(nq, 0);
+            LaunchParams p{};
+            p.nq = (uint32_t)nq; p.k = (uint32_t)k; p.m = (uint32_t)m; p.how_many = (uint32_t)how_many; p.flags = flags; p.max_len = max_len;
+            r->rc = device_predict(idx->dev, idx->flat, p, false, nullptr, flat.data(), off.data(), r->ids.data(), r->scores.data(), r->counts.data(), nullptr, nullptr, nullptr, nullptr);
+            if (r->rc) r->err = last_error_string();
+        } catch (const std::bad_alloc&) { r->rc = SRN_ENOMEM; r->err = "out of host memory in a combining round"; }
+        catch (const std::exception& e) { r->rc = SRN_EINVAL; r->err = std::string("internal error in a combining round: ") + e.what(); }
+        c->n_rounds.fetch_add(1, std::memory_order_relaxed); c->n_requests.fetch_add(nq, std::memory_order_relaxed);
+        uint64_t mx = c->max_round.load(std::memory_order_relaxed); while (nq > mx && !c->max_round.compare_exchange_weak(mx, nq)) {}
+        futex_wake_all(&r->done);
+        { std::lock_guard<std::mutex> lk(c->mu); --c->lanes_busy; }
+        c->cv_lane.notify_one();
+    } else futex_wait(&r->done);
+    *out_n = 0;
+    if (r->rc) return fail(r->rc, r->err);
+    const uint32_t cnt = r->counts[me];
+    if (cnt == 0xFFFFFFFFu) return fail(SRN_ERANGE, "a query exceeded the kernel's table limits");   // (this member's query only: the others' rows are complete)
+    const size_t n = std::min<size_t>(cnt, how_many);
+    std::memcpy(out_ids, &r->ids[me * how_many], n * 8); std::memcpy(out_scores, &r->scores[me * how_many], n * 8);
+    *out_n = n;
+    return SRN_OK;
+}
+
+}  // namespace srn

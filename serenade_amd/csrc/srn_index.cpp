@@ -20,6 +20,7 @@ static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 const char* last_error_cstr() { return g_err.c_str(); }
+std::string last_error_string() { return g_err; }
 
 // ---------------------------------------------------------------------------------------------
 // TSV loader

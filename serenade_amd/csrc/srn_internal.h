@@ -12,6 +12,7 @@ namespace srn {
 // ---- error plumbing (thread-local message behind srn_last_error) ---------------------------
 void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);
+std::string last_error_string();   // this thread's message (copied: a combining round hands its leader's error to every member)
 
 // ---- u64 item id -> dense item index: open addressing, 16-byte slots (one load per probe) ----
 struct IdSlot {
@@ -146,10 +147,23 @@ int device_kernel_times(DeviceState* d, uint32_t max_n, double* ms_main, double*
 
 }  // namespace srn
 
+namespace srn {
+// concurrent srn_predict calls on one handle combine into rounds (srn_combine.cpp)
+struct Combiner;
+Combiner* combiner_create();
+void combiner_free(Combiner* c);
+void combiner_stats(const Combiner* c, uint64_t* rounds, uint64_t* requests, uint64_t* max_round);
+int combiner_predict(Combiner* c, const srn_index* idx, const uint64_t* evolving, size_t len, size_t k, size_t m, size_t how_many, unsigned flags,
+                     uint64_t* out_ids, double* out_scores, size_t* out_n, int lanes, size_t round_cap);
+int knob_predict_lanes();   // SRN_PREDICT_LANES (0 = no combining: every call runs by itself, as in round 2)
+size_t knob_tiny_max();     // SRN_TINY_MAX: largest host batch on the zero-copy latency path = largest round
+}  // namespace srn
+
 struct srn_index {
     srn::FlatIndex flat;
     srn::DeviceState* dev = nullptr;
     int device = -1;
+    srn::Combiner* comb = nullptr;   // created with the device state
 };
 struct srn_sessions {
     srn::Sessions s;

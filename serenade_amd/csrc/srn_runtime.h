@@ -1,0 +1,83 @@
+// Private to the device runtime (srn_runtime.hip, srn_hostpipe.hip, srn_group.hip): the per-index device state, per-call workspaces and the
+// test / experiment knobs.  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "srn_kernels.h"
+
+namespace srn {
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(SRN_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// Test / experiment knobs (environment variables SRN_*): read ONCE, when the library is first used, never on the launch path;
+// srn_debug_reload_knobs() re-reads them (the tests switch kernel paths between calls).  All defaults = production behaviour.
+struct Knobs {
+    bool no_masks = false, no_merge = false, dense = false, no_fast = false, debug = false;
+    int hot_slots = -1, sketch_slots = -1, lds_budget_kb = 0, grid_mult = 16, fast_runs = 0;
+    bool grid_mult_set = false;
+    int host_chunks = 0;      // SRN_HOST_CHUNKS: number of chunks a host-pointer batch is cut into (0 = by size, srn_hostpipe.hip)
+    int tiny_max = 256;       // SRN_TINY_MAX: host-pointer batches of up to this many sessions take the zero-copy latency path
+    int lanes = 4;            // SRN_PREDICT_LANES: concurrent rounds of the srn_predict combiner (srn_combine.cpp)
+    bool geometry_default() const { return !no_masks && !no_merge && !dense && hot_slots < 0 && sketch_slots < 0 && lds_budget_kb == 0; }
+};
+Knobs knobs();   // (a copy: the tests re-read the environment between calls)
+
+struct HostPipe;   // srn_hostpipe.hip: staging rings + streams of the chunked host-pointer path
+
+struct Workspace {
+    hipStream_t stream = nullptr;   // own stream for host-pointer calls
+    static constexpr int RING = 64;               // per-call events: start, after main kernel, after retry pass, after prep kernel
+    hipEvent_t ev[RING][5] = {};                  // ... [4] = after the fast kernel (== [3] when the launch did not use it)
+    uint64_t calls = 0, untimed_calls = 0; uint32_t last_retry = 0, last_nq = 0;
+    bool last_fast = false;      // the last call went through the fast kernel: h_retry[1] = what it handed to the general kernel (otherwise: all of last_nq)
+    bool last_untimed = false;   // the last call took the latency path: no events were recorded for it
+    // device scratch
+    uint32_t* retry_list = nullptr; size_t retry_cap = 0; uint32_t* retry_cnt = nullptr;
+    char* gscratch = nullptr; size_t gscratch_bytes = 0;
+    char* spill = nullptr; size_t spill_bytes = 0;   // per-block global copies of the neighbour lists
+    char* prep = nullptr; size_t prep_bytes = 0;     // per-query records of the prep kernel
+    uint32_t* retry_list2 = nullptr; size_t retry_cap2 = 0; uint32_t* retry_cnt2 = nullptr;   // what the second LDS tier could not hold either
+    uint32_t* slow_list = nullptr; size_t slow_cap = 0; uint32_t* slow_cnt = nullptr;          // what the fast kernel hands to the general one
+    char* fin = nullptr; size_t fin_bytes = 0;   // records for vmis_finish_kernel
+    char* big = nullptr; size_t big_bytes = 0;   // overflow entries + list for vmis_finish_big_kernel
+    char* pin = nullptr; size_t pin_bytes = 0;   // pinned, device-mapped staging of the latency path (a handful of queries on host pointers)
+    // staging for host-pointer calls
+    char* stage = nullptr; size_t stage_bytes = 0;
+    uint32_t* h_retry = nullptr;   // pinned
+};
+
+struct DeviceState {
+    int device = 0;
+    std::vector<void*> allocs; uint64_t bytes = 0;
+    DeviceIndex di{};
+    ItemMeta* d_meta = nullptr;
+    FastParams fast{};            // packed row slots + idf bounds of the fast kernel (row_packed == nullptr: no fast path for this index)
+    uint32_t host_max_row_len = 0;
+    int n_cu = 256;
+    int lds_per_block_max = 65536;
+    std::mutex mu; std::vector<Workspace*> free_ws; std::vector<Workspace*> all_ws;
+    std::vector<std::pair<void*, Workspace*>> stream_ws;   // device-pointer calls: one workspace per user stream
+    Workspace* last_ws = nullptr;   // for srn_last_kernel_ms (single-threaded measurement use)
+    std::vector<HostPipe*> free_pipes, all_pipes;   // chunked host-pointer batches (srn_hostpipe.hip), pooled like the workspaces
+    unsigned long long* d_phase = nullptr; bool phase_on = false;   // debug per-phase cycle counters
+};
+
+// ---- shared helpers (srn_runtime.hip) ----
+int ensure(char** p, size_t* have, size_t need);   // grow-only device scratch
+Workspace* ws_acquire(DeviceState* d, bool bind_to_stream, void* user_stream);
+void ws_release(DeviceState* d, Workspace* w, bool bound);
+void hostpipes_free(DeviceState* d);   // srn_hostpipe.hip
+int device_predict_host_pipelined(DeviceState* d, const FlatIndex& ix, const LaunchParams& p, const uint64_t* h_items, const uint32_t* h_qoff,
+                                  uint64_t* h_ids, double* h_scores, uint32_t* h_counts);
+uint32_t hostpipe_chunks(uint32_t nq, uint32_t how_many);
+
+}  // namespace srn

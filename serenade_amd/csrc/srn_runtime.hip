@@ -13,24 +13,10 @@
 #include <string>
 #include <vector>
 
-#include "srn_kernels.h"
+#include "srn_runtime.h"
 
 namespace srn {
 
-#define HIP_TRY(expr)                                                                                   \
-    do {                                                                                                \
-        hipError_t e_ = (expr);                                                                         \
-        if (e_ != hipSuccess) return fail(SRN_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-    } while (0)
-
-// Test / experiment knobs (environment variables SRN_*): read ONCE, when the library is first used, never on the launch path;
-// srn_debug_reload_knobs() re-reads them (the tests switch kernel paths between calls).  All defaults = production behaviour.
-struct Knobs {
-    bool no_masks = false, no_merge = false, dense = false, no_fast = false, debug = false;
-    int hot_slots = -1, sketch_slots = -1, lds_budget_kb = 0, grid_mult = 16, fast_runs = 0;
-    bool grid_mult_set = false;
-    bool geometry_default() const { return !no_masks && !no_merge && !dense && hot_slots < 0 && sketch_slots < 0 && lds_budget_kb == 0; }
-};
 static Knobs g_knobs; static std::once_flag g_knobs_once; static std::mutex g_knobs_mu;
 static void knobs_read() {
     Knobs k;
@@ -40,48 +26,16 @@ static void knobs_read() {
     if (const char* e = getenv("SRN_SKETCH_SLOTS")) k.sketch_slots = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_LDS_BUDGET_KB")) k.lds_budget_kb = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_GRID_MULT")) { k.grid_mult = std::max(1, atoi(e)); k.grid_mult_set = true; }
+    if (const char* e = getenv("SRN_HOST_CHUNKS")) k.host_chunks = std::max(0, atoi(e));
+    if (const char* e = getenv("SRN_TINY_MAX")) k.tiny_max = std::max(0, atoi(e));
+    if (const char* e = getenv("SRN_PREDICT_LANES")) k.lanes = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_FAST_RUNS")) k.fast_runs = atoi(e) == 3 ? 3 : 0;   // tests: the fast kernel's 29-bit-rank form (3 lists per query) on a small index
     std::lock_guard<std::mutex> lk(g_knobs_mu); g_knobs = k;
 }
-static Knobs knobs() { std::call_once(g_knobs_once, knobs_read); std::lock_guard<std::mutex> lk(g_knobs_mu); return g_knobs; }
+Knobs knobs() { std::call_once(g_knobs_once, knobs_read); std::lock_guard<std::mutex> lk(g_knobs_mu); return g_knobs; }
+int knob_predict_lanes() { return knobs().lanes; }
+size_t knob_tiny_max() { return (size_t)std::max(1, knobs().tiny_max); }
 void reload_knobs() { std::call_once(g_knobs_once, knobs_read); knobs_read(); }
-
-struct Workspace {
-    hipStream_t stream = nullptr;   // own stream for host-pointer calls
-    static constexpr int RING = 64;               // per-call events: start, after main kernel, after retry pass, after prep kernel
-    hipEvent_t ev[RING][5] = {};                  // ... [4] = after the fast kernel (== [3] when the launch did not use it)
-    uint64_t calls = 0, untimed_calls = 0; uint32_t last_retry = 0, last_nq = 0;
-    bool last_fast = false;      // the last call went through the fast kernel: h_retry[1] = what it handed to the general kernel (otherwise: all of last_nq)
-    bool last_untimed = false;   // the last call took the latency path: no events were recorded for it
-    // device scratch
-    uint32_t* retry_list = nullptr; size_t retry_cap = 0; uint32_t* retry_cnt = nullptr;
-    char* gscratch = nullptr; size_t gscratch_bytes = 0;
-    char* spill = nullptr; size_t spill_bytes = 0;   // per-block global copies of the neighbour lists
-    char* prep = nullptr; size_t prep_bytes = 0;     // per-query records of the prep kernel
-    uint32_t* retry_list2 = nullptr; size_t retry_cap2 = 0; uint32_t* retry_cnt2 = nullptr;   // what the second LDS tier could not hold either
-    uint32_t* slow_list = nullptr; size_t slow_cap = 0; uint32_t* slow_cnt = nullptr;          // what the fast kernel hands to the general one
-    char* fin = nullptr; size_t fin_bytes = 0;   // records for vmis_finish_kernel
-    char* big = nullptr; size_t big_bytes = 0;   // overflow entries + list for vmis_finish_big_kernel
-    char* pin = nullptr; size_t pin_bytes = 0;   // pinned, device-mapped staging of the latency path (a handful of queries on host pointers)
-    // staging for host-pointer calls
-    char* stage = nullptr; size_t stage_bytes = 0;
-    uint32_t* h_retry = nullptr;   // pinned
-};
-
-struct DeviceState {
-    int device = 0;
-    std::vector<void*> allocs; uint64_t bytes = 0;
-    DeviceIndex di{};
-    ItemMeta* d_meta = nullptr;
-    FastParams fast{};            // packed row slots + idf bounds of the fast kernel (row_packed == nullptr: no fast path for this index)
-    uint32_t host_max_row_len = 0;
-    int n_cu = 256;
-    int lds_per_block_max = 65536;
-    std::mutex mu; std::vector<Workspace*> free_ws; std::vector<Workspace*> all_ws;
-    std::vector<std::pair<void*, Workspace*>> stream_ws;   // device-pointer calls: one workspace per user stream
-    Workspace* last_ws = nullptr;   // for srn_last_kernel_ms (single-threaded measurement use)
-    unsigned long long* d_phase = nullptr; bool phase_on = false;   // debug per-phase cycle counters
-};
 
 namespace {
 template <typename T> const T* upload(DeviceState* d, const std::vector<T>& v, bool& ok, size_t pad = 0, size_t = 0) {   // (hipMalloc is 256-byte aligned)
@@ -212,6 +166,7 @@ static void ws_free(Workspace* w) {
 void device_release(DeviceState* d) {
     if (!d) return;
     hipSetDevice(d->device);
+    hostpipes_free(d);
     for (Workspace* w : d->all_ws) ws_free(w);
     for (void* p : d->allocs) hipFree(p);
     delete d;
@@ -235,7 +190,7 @@ int device_count() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n :
 // Host-pointer calls borrow a workspace for the duration of the (synchronous) call.  Device-pointer
 // calls return while their work is still in flight, so their scratch stays bound to the user's stream
 // (stream order then serialises its reuse).
-static Workspace* ws_acquire(DeviceState* d, bool bind_to_stream, void* user_stream) {
+Workspace* ws_acquire(DeviceState* d, bool bind_to_stream, void* user_stream) {
     std::lock_guard<std::mutex> lk(d->mu);
     if (bind_to_stream) for (auto& sw : d->stream_ws) if (sw.first == user_stream) return sw.second;
     if (!bind_to_stream && !d->free_ws.empty()) { Workspace* w = d->free_ws.back(); d->free_ws.pop_back(); return w; }
@@ -247,13 +202,13 @@ static Workspace* ws_acquire(DeviceState* d, bool bind_to_stream, void* user_str
     if (bind_to_stream) d->stream_ws.emplace_back(user_stream, w);
     return w;
 }
-static void ws_release(DeviceState* d, Workspace* w, bool bound) {
+void ws_release(DeviceState* d, Workspace* w, bool bound) {
     std::lock_guard<std::mutex> lk(d->mu);
     if (!bound) d->free_ws.push_back(w);
     d->last_ws = w;
 }
 
-static int ensure(char** p, size_t* have, size_t need) {
+int ensure(char** p, size_t* have, size_t need) {
     if (*have >= need) return SRN_OK;
     if (*p) HIP_TRY(hipFree(*p));
     *p = nullptr; *have = 0;
@@ -412,7 +367,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     p.phase_cycles = d->phase_on ? d->d_phase : nullptr;
     Workspace* w = ws_acquire(d, on_device, user_stream);
     if (!w) return fail(SRN_EHIP, "cannot create HIP stream / events");
-    struct Rel { DeviceState* d; Workspace* w; bool b; ~Rel() { ws_release(d, w, b); } } rel{d, w, on_device};
+    struct Rel { DeviceState* d; Workspace* w; bool b; ~Rel() { if (w) ws_release(d, w, b); } } rel{d, w, on_device};
     hipStream_t st = on_device ? (hipStream_t)user_stream : w->stream;
 
     // ---- geometry ----------------------------------------------------------------------
@@ -421,9 +376,16 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     const uint64_t need_sess = geo.need_sess, need_item = geo.need_item;
     const bool may_overflow = geo.sess_may_overflow || geo.item_may_overflow;
 
-    if (!on_device && !reserve_only && p.nq <= 16 && !h_stats && !h_nb_rank && !d->phase_on && !knobs().dense) {
-        const int rc = device_predict_tiny(d, w, geo, p, h_items, h_qoff, h_ids, h_scores, h_counts);
-        if (rc != 1) return rc;   // (1: some query needs the global-table pass -- the normal path below has it)
+    if (!on_device && !reserve_only && !h_stats && !h_nb_rank) {
+        const Knobs kn0 = knobs();
+        if (p.nq <= (uint32_t)kn0.tiny_max && !d->phase_on && !kn0.dense) {
+            const int rc = device_predict_tiny(d, w, geo, p, h_items, h_qoff, h_ids, h_scores, h_counts);
+            if (rc != 1) return rc;   // (1: some query needs the global-table pass -- the paths below have it)
+        }
+        // everything larger: chunks through pinned staging, uploads / kernels / downloads overlapped (srn_hostpipe.hip); each chunk comes back here as a
+        // device-pointer call on one of the pipeline's kernel streams.  (This call's own workspace goes back to the pool first.)
+        ws_release(d, w, false); rel.w = nullptr;
+        return device_predict_host_pipelined(d, ix, p, h_items, h_qoff, h_ids, h_scores, h_counts);
     }
     // ---- buffers -----------------------------------------------------------------------
     const size_t n_out = (size_t)p.nq * p.how_many;

@@ -164,12 +164,19 @@ def predict(index, evolving_session, k, m, how_many, enable_business_logic):
     return [ItemScore(int(i), float(s)) for i, s in zip(ids[:n.value], sc[:n.value])]
 
 
-def predict_batch(index, sessions, k, m, how_many, enable_business_logic=False):
+def predict_batch(index, sessions, k, m, how_many, enable_business_logic=False, out=None):
     """Many evolving sessions in one call (list of sequences, or (items_flat, q_off)).
-    -> (ids u64[nq, how_many], scores f64[nq, how_many], counts u32[nq])."""
+    -> (ids u64[nq, how_many], scores f64[nq, how_many], counts u32[nq]).  out = (ids, scores, counts) of an earlier call of the same
+    shape: the result buffers are reused (what a serving / evaluator host does) instead of freshly allocated."""
     flat, off = _flatten(sessions)
     nq = len(off) - 1
-    ids, sc, cnt = np.zeros((nq, how_many), np.uint64), np.zeros((nq, how_many)), np.zeros(nq, np.uint32)
+    if out is not None:
+        ids, sc, cnt = out
+        if ids.shape != (nq, how_many) or sc.shape != (nq, how_many) or cnt.shape != (nq,) or ids.dtype != np.uint64 or sc.dtype != np.float64 or cnt.dtype != np.uint32 \
+                or not (ids.flags.c_contiguous and sc.flags.c_contiguous and cnt.flags.c_contiguous):
+            raise ValueError("out must be (u64[nq, how_many], f64[nq, how_many], u32[nq]), C-contiguous")
+    else:
+        ids, sc, cnt = np.zeros((nq, how_many), np.uint64), np.zeros((nq, how_many)), np.zeros(nq, np.uint32)
     capi.check(capi.lib().srn_predict_batch(index._h, capi.ptr(flat), capi.ptr(off), nq, int(k), int(m), int(how_many),
                                             capi.FLAG_BUSINESS_LOGIC if enable_business_logic else 0,
                                             capi.ptr(ids), capi.ptr(sc), capi.ptr(cnt)))

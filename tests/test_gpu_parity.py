@@ -512,3 +512,83 @@ def test_concurrent_host_threads_share_one_index():
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+def test_sixty_four_host_threads_combine_into_rounds():
+    """64 threads calling srn_predict on one handle (the reference's actix workers, src/bin/serving.rs:62-94) fell off a
+    cliff in round 2 (64 streams, 64 spinning waits).  Concurrent calls now combine into rounds (srn_combine.cpp): every answer still equals the
+    oracle's, and the rounds are fewer than the requests."""
+    import threading
+    import serenade_amd as sa
+    from serenade_amd import capi
+    import ctypes as C
+    O = _oracle()
+    off, items, ts, ids = small_dataset(67, n_sessions=4000, n_items=500)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, 200, 12, 1.0)
+    oix = O.OracleIndex(off, items, ts, 200, 12, 1.0)
+    qs = random_queries(17, ids, 512, max_len=5, unknown_rate=0.02)
+    flat, qoff = flatten(qs)
+    ref = oix.predict_batch("canonical", flat, qoff, 50, 200, 21, threads=4)
+    errors = []
+
+    def worker(t):
+        try:
+            for rep in range(6):
+                for q in range(t, len(qs), 64):
+                    recs = sa.predict(gix, qs[q], 50, 200, 21, False)
+                    n = int(ref["counts"][q])
+                    assert [r.id for r in recs] == ref["ids"][q, :n].tolist(), (q, qs[q])
+                    np.testing.assert_allclose([r.score for r in recs], ref["scores"][q, :n], rtol=SCORE_RTOL, atol=0)
+        except Exception as e:  # pragma: no cover
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(64)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]
+    rounds, requests, biggest = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    capi.check(capi.lib().srn_predict_stats(gix._h, C.byref(rounds), C.byref(requests), C.byref(biggest)))
+    assert requests.value == 6 * len(qs)
+    assert rounds.value <= requests.value and biggest.value >= 1
+    # an empty session fails alone; a call with other parameters gets its own round
+    with pytest.raises(sa.SerenadeError):
+        sa.predict(gix, [], 50, 200, 21, False)
+    f1, o1 = flatten([qs[0]])
+    ref1 = oix.predict_batch("canonical", f1, o1, 10, 30, 5)
+    assert [r.id for r in sa.predict(gix, qs[0], 10, 30, 5, False)] == ref1["ids"][0, :int(ref1["counts"][0])].tolist()
+
+
+@pytest.mark.parametrize("chunks", [0, 1, 3, 7])
+def test_host_pointer_batches_through_the_chunked_pipeline(chunks, monkeypatch):
+    """srn_predict_batch on host buffers: <= 256 sessions take the zero-copy latency path, larger batches are cut into chunks whose uploads,
+    kernels and downloads overlap (srn_hostpipe.hip).  Every size -- chunk boundaries that do not divide the batch included -- gives the oracle's
+    rows, and the reused-buffer form writes the same bytes."""
+    import serenade_amd as sa
+    from serenade_amd import capi
+    O = _oracle()
+    off, items, ts, ids = small_dataset(71, n_sessions=6000, n_items=700)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, 300, 12, 1.0)
+    oix = O.OracleIndex(off, items, ts, 300, 12, 1.0)
+    qs = random_queries(19, ids, 9000, max_len=6, unknown_rate=0.02)
+    flat, qoff = flatten(qs)
+    ref = oix.predict_batch("canonical", flat, qoff, 60, 300, 21, threads=4)
+    try:
+        if chunks:
+            monkeypatch.setenv("SRN_HOST_CHUNKS", str(chunks))
+        capi.reload_knobs()
+        out = None
+        for nq in (1, 16, 17, 256, 257, 1000, 4097, 9000):
+            f, o = flat[:qoff[nq]], qoff[:nq + 1]
+            got = sa.predict_batch(gix, (f, o), 60, 300, 21)
+            mask = np.arange(21)[None, :] < ref["counts"][:nq, None].astype(np.int64)
+            assert np.array_equal(got[2], ref["counts"][:nq]), nq
+            assert np.array_equal(got[0][mask], ref["ids"][:nq][mask]), nq
+            np.testing.assert_allclose(got[1][mask], ref["scores"][:nq][mask], rtol=SCORE_RTOL, atol=0)
+            assert not got[0][~mask].any() and not got[1][~mask].any(), "the unused tail of a row reads as 0"
+            if nq == 9000:
+                out = sa.predict_batch(gix, (f, o), 60, 300, 21, out=got)          # same buffers again
+                assert out[0] is got[0] and np.array_equal(out[0][mask], ref["ids"][:nq][mask])
+    finally:
+        monkeypatch.undo(); capi.reload_knobs()
