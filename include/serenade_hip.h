@@ -260,6 +260,53 @@ int srn_shard_lists_predict(const srn_index_t* idx, const uint64_t* d_items_flat
                             const uint32_t* d_lists_g, const int32_t* d_head, const void* d_pos_local, void* d_records,
                             uint64_t* d_out_ids, double* d_out_scores, uint32_t* d_out_counts, void* stream);
 
+/* ---- the shard group: the whole item-sharded batch in ONE call, collectives inside (srn_group.hip) ---------------------------------------
+ * What a reference-side host (serving / evaluator, src/endpoints/recommend_resource.rs:56, src/bin/evaluator.rs:58) calls to drive an index
+ * sharded over the GPUs of a node: one process (or thread group) per GPU creates its rank of the group around its shard, then every rank calls
+ * srn_shard_group_predict_batch with the SAME batch; the call runs the LISTS pipeline above -- head, all-reduce(max), count, all-gather of the
+ * counts, variable-length exchange of the kept list prefixes, the unsharded kernels over the rank's row fragments, all-gather of the per-shard
+ * top-n, merge by (score desc, id asc) -- with RCCL called from inside the library.  Results (identical on every rank, bit-identical to the
+ * unsharded index) are written to the caller's device buffers, asynchronously on `stream`; the call itself blocks the host for one short
+ * synchronisation on the group's own exchange stream (the per-shard list totals size the exchange).  With SRN_FLAG_INPUTS_RESIDENT a batch's
+ * exchange phase overlaps the previous batch's kernels.  Valid where srn_shard_lists_supported says so (sessions of <= 8 items, m <= m_index).
+ *
+ *   rank 0:   srn_shard_group_unique_id(id, sizeof id)      -- 256 opaque bytes; hand them to the other ranks (your own control plane)
+ *   rank r:   srn_index_load_shard(path, r, world, device_r, &shard);  srn_shard_group_create(shard, id, r, world, &group)
+ *   per batch, every rank:   srn_shard_group_predict_batch(group, d_items, d_q_off, nq, ...)
+ */
+#define SRN_SHARD_GROUP_ID_BYTES 256
+#define SRN_FLAG_INPUTS_RESIDENT 2u /* srn_shard_group_predict_batch: d_items_flat / d_q_off are complete in device memory at call time (not pending on `stream`) */
+typedef struct srn_shard_group srn_shard_group_t;
+int srn_shard_group_unique_id(void* out, size_t bytes);
+int srn_shard_group_create(const srn_index_t* shard, const void* unique_id, int rank, int world, srn_shard_group_t** out);
+/* The same group over the APPLICATION's transport instead of RCCL (MPI, sockets, a test harness): three collectives on device buffers.  Each
+ * callback must order itself after the work already enqueued on `stream` and complete (or be enqueued on `stream`) before it returns;
+ * channel 0 / 1 = the group's two independent sequences of collectives (exchange stream / caller's stream).  Non-zero return = failure.
+ *   all_reduce_max_i32(user, channel, d_buf, count, stream)                 element-wise maximum over the ranks, in place
+ *   all_gather(user, channel, d_buf, block_bytes, stream)                   d_buf = world blocks; block `rank` holds this rank's data
+ *   all_gather_v(user, channel, d_buf, byte_off[world], byte_cnt[world], stream)    segment r = d_buf[byte_off[r] .. + byte_cnt[r]); this rank's is in place */
+typedef struct {
+    void* user;
+    int (*all_reduce_max_i32)(void* user, int channel, int32_t* d_buf, size_t count, void* stream);
+    int (*all_gather)(void* user, int channel, void* d_buf, size_t block_bytes, void* stream);
+    int (*all_gather_v)(void* user, int channel, void* d_buf, const uint64_t* byte_off, const uint64_t* byte_cnt, void* stream);
+} srn_shard_comm_t;
+int srn_shard_group_create_with_comm(const srn_index_t* shard, int rank, int world, const srn_shard_comm_t* comm, srn_shard_group_t** out);
+/* All shards of the group in THIS process on one device (tests; capacity experiments on one GPU): the collectives degenerate to kernels. */
+int srn_shard_group_create_local(const srn_index_t* const* shards, int n_shards, srn_shard_group_t** out);
+int srn_shard_group_predict_batch(srn_shard_group_t* g, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq, size_t max_len_hint,
+                                  size_t k, size_t m, size_t how_many, unsigned flags, uint64_t* d_out_ids, double* d_out_scores,
+                                  uint32_t* d_out_counts, void* stream);
+typedef struct {
+    uint64_t n_shards, batches, queries;
+    uint64_t bytes_head, bytes_counts, bytes_lists, bytes_results; /* what THIS rank contributed to each exchange, summed over the batches */
+    uint64_t bytes_lists_max_rank;                                 /* the fullest rank's list segment, summed over the batches (what a padded all-gather would ship per rank) */
+    uint32_t transport;                                            /* 0 in-process, 1 RCCL, 2 application callbacks */
+    uint32_t overlapped;                                           /* the exchange phase runs on the group's own stream */
+} srn_shard_group_stats_t;
+int srn_shard_group_stats(const srn_shard_group_t* g, srn_shard_group_stats_t* out);
+void srn_shard_group_free(srn_shard_group_t* g);
+
 /* The same for the most recent min(max_n, 64) predict calls (oldest first): per-call duration in ms of
  * the main kernel and of the retry pass, from HIP events recorded on the launch stream around each
  * launch.  This is what bench.py reports as the kernel's live-measured launch duration. */

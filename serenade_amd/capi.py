@@ -32,6 +32,25 @@ class IndexInfo(C.Structure):
                [("device", C.c_int32), ("offsets_64bit", C.c_int32), ("idf_weighting", C.c_double)]
 
 
+class ShardGroupStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_shards", "batches", "queries", "bytes_head", "bytes_counts", "bytes_lists", "bytes_results", "bytes_lists_max_rank")] + \
+               [("transport", C.c_uint32), ("overlapped", C.c_uint32)]
+
+
+# srn_shard_comm_t: the application's transport for a shard group (three collectives on device buffers)
+ALL_REDUCE_MAX_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
+ALL_GATHER_V_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p)
+
+
+class ShardComm(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("all_reduce_max_i32", ALL_REDUCE_MAX_FN), ("all_gather", ALL_GATHER_FN), ("all_gather_v", ALL_GATHER_V_FN)]
+
+
+SHARD_GROUP_ID_BYTES = 256
+FLAG_INPUTS_RESIDENT = 2
+
+
 class Limits(C.Structure):
     _fields_ = [("max_how_many", C.c_uint32), ("max_session_len", C.c_uint32), ("max_k", C.c_uint32), ("reserved", C.c_uint32)]
 
@@ -88,6 +107,13 @@ SYMBOLS = {
     "srn_shard_lists_count": (_i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp]),
     "srn_shard_lists_copy": (_i, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp]),
     "srn_shard_lists_predict": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, C.c_uint, C.c_uint32, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "srn_shard_group_unique_id": (_i, [_vp, _sz]),
+    "srn_shard_group_create": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
+    "srn_shard_group_create_with_comm": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
+    "srn_shard_group_create_local": (_i, [C.POINTER(_vp), _i, C.POINTER(_vp)]),
+    "srn_shard_group_predict_batch": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, C.c_uint, _vp, _vp, _vp, _vp]),
+    "srn_shard_group_stats": (_i, [_vp, _vp]),
+    "srn_shard_group_free": (None, [_vp]),
     "srn_kernel_times": (_i, [_vp, C.c_uint32, _vp, _vp, C.POINTER(C.c_uint32)]),
     "srn_kernel_times_detail": (_i, [_vp, C.c_uint32, _vp, _vp, _vp, _vp, C.POINTER(C.c_uint32)]),
     "srn_debug_phase_cycles": (_i, [_vp, _i, _vp]),
@@ -117,6 +143,10 @@ def _preload_hip_runtime():
             p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
             if os.path.exists(p):
                 C.CDLL(p, mode=C.RTLD_GLOBAL)
+            # and ONE RCCL: the shard group (srn_group.hip) looks for a librccl already in the process before it loads /opt/rocm's
+            r = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
+            if os.path.exists(r) and os.environ.get("SRN_RCCL_LIB", "") == "":
+                os.environ["SRN_RCCL_LIB"] = r
     except Exception:
         pass
 

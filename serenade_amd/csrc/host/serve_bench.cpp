@@ -12,6 +12,8 @@
 #include <thread>
 #include <vector>
 
+#include <sys/resource.h>
+
 #include "../../../include/serenade_hip.h"
 
 int main(int argc, char** argv) {
@@ -30,6 +32,9 @@ int main(int argc, char** argv) {
     if (!direct && srn_batcher_create(idx, max_batch, wait_us, k, m, n, 0, &b)) { fprintf(stderr, "batcher: %s\n", srn_last_error()); return 1; }
     { std::vector<uint64_t> ids(n); std::vector<double> sc(n); size_t cnt;   // warm-up: first launch, workspace allocation
       for (int i = 0; i < 20; ++i) srn_predict(idx, &items[off[i]], off[i + 1] - off[i], k, m, n, 0, ids.data(), sc.data(), &cnt); }
+    auto cpu_s = [] { rusage ru; getrusage(RUSAGE_SELF, &ru); return ru.ru_utime.tv_sec + ru.ru_stime.tv_sec + 1e-6 * (ru.ru_utime.tv_usec + ru.ru_stime.tv_usec); };
+    auto throttled = [] { unsigned long long n = 0, us = 0; if (FILE* c = fopen("/sys/fs/cgroup/cpu.stat", "r")) { char key[64]; unsigned long long v; while (fscanf(c, "%63s %llu", key, &v) == 2) { if (!strcmp(key, "nr_throttled")) n = v; if (!strcmp(key, "throttled_usec")) us = v; } fclose(c); } return std::make_pair(n, us); };
+    const double cpu0 = cpu_s(); const auto thr0 = throttled();
     std::atomic<bool> stop{false}; std::atomic<uint64_t> errors{0};
     std::vector<std::vector<float>> lat(T);
     std::vector<std::thread> th;
@@ -57,9 +62,10 @@ int main(int argc, char** argv) {
     uint64_t nr = 0, nb = 0, mx = 0; if (b) srn_batcher_stats(b, &nr, &nb, &mx); else srn_predict_stats(idx, &nb, &nr, &mx);   // (direct: the rounds concurrent srn_predict calls combined into)
     printf("{\"mode\": \"%s\", \"threads\": %d, \"seconds\": %.2f, \"requests\": %zu, \"requests_per_s\": %.1f, \"errors\": %llu, "
            "\"latency_us\": {\"p50\": %.1f, \"p90\": %.1f, \"p99\": %.1f, \"p99_5\": %.1f, \"max\": %.1f}, \"batches\": %llu, \"mean_batch\": %.1f, \"max_batch_seen\": %llu, "
-           "\"max_batch\": %zu, \"max_wait_us\": %u}\n",
+           "\"max_batch\": %zu, \"max_wait_us\": %u, \"host_cpu_cores_used\": %.2f, \"cgroup_throttled_periods\": %llu, \"cgroup_throttled_ms\": %.1f}\n",
            direct ? "direct srn_predict per thread" : "srn_batcher", T, el, all.size(), all.size() / el, (unsigned long long)errors.load(),
-           pct(0.5), pct(0.9), pct(0.99), pct(0.995), all.empty() ? 0.f : all.back(), (unsigned long long)nb, nb ? (double)nr / nb : 0.0, (unsigned long long)mx, max_batch, wait_us);
+           pct(0.5), pct(0.9), pct(0.99), pct(0.995), all.empty() ? 0.f : all.back(), (unsigned long long)nb, nb ? (double)nr / nb : 0.0, (unsigned long long)mx, max_batch, wait_us,
+           (cpu_s() - cpu0) / el, throttled().first - thr0.first, (throttled().second - thr0.second) / 1e3);
     if (b) srn_batcher_free(b);
     srn_index_free(idx);
     return errors ? 1 : 0;

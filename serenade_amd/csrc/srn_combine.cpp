@@ -84,7 +84,9 @@ int combiner_predict(Combiner* c, const srn_index* idx, const uint64_t* evolving
             r->ids.assign(nq * how_many, 0); r->scores.assign(nq * how_many, 0.0); r->counts.assign(nq, 0);
             LaunchParams p{};
             p.nq = (uint32_t)nq; p.k = (uint32_t)k; p.m = (uint32_t)m; p.how_many = (uint32_t)how_many; p.flags = flags; p.max_len = max_len;
-            r->rc = device_predict(idx->dev, idx->flat, p, false, nullptr, flat.data(), off.data(), r->ids.data(), r->scores.data(), r->counts.data(), nullptr, nullptr, nullptr, nullptr);
+            // a lone caller spins on its result (lowest latency); a shared round sleeps on an interrupt: its members' cores are better spent on their next requests
+            r->rc = device_predict(idx->dev, idx->flat, p, false, nullptr, flat.data(), off.data(), r->ids.data(), r->scores.data(), r->counts.data(), nullptr, nullptr, nullptr, nullptr,
+                                   nullptr, false, /*blocking_wait=*/nq > 1);
             if (r->rc) r->err = last_error_string();
         } catch (const std::bad_alloc&) { r->rc = SRN_ENOMEM; r->err = "out of host memory in a combining round"; }
         catch (const std::exception& e) { r->rc = SRN_EINVAL; r->err = std::string("internal error in a combining round: ") + e.what(); }

@@ -1,0 +1,367 @@
+// =====================================================================================
+// The item-sharded index behind the C ABI: srn_shard_group_* (include/serenade_hip.h).
+//
+// North star (BASELINE.json): "the index shards by item-id hash across the 8 GPUs of one node with per-query partial top-k merged over RCCL
+// all-gather on xGMI ... host side stays Rust".  Round 2 drove the shards from Python: the collectives went through torch.distributed and the
+// scan / merge steps through the host's tensor library, so a Rust `serving` / `evaluator` host (src/endpoints/recommend_resource.rs:56,
+// src/bin/evaluator.rs:58) bound to this library could not drive more than one GPU.  Here the whole LISTS pipeline of srn_shard.hip runs inside
+// one call, RCCL called from C++ (dlopen: whichever librccl the process already has, else /opt/rocm's):
+//
+//   exchange stream (its own communicator, overlaps the previous batch's kernels on the caller's stream)
+//     head kernel -> all-reduce(max) of (x_lo, r_max, attribute)                        12 B per query
+//     count kernel -> all-gather of the kept counts -> offsets + per-shard totals        4 * max_len B per query and shard
+//     ONE short host synchronisation: the totals size the next step                       (the GPU keeps running the previous batch meanwhile)
+//     copy kernel -> variable-length exchange of the kept list prefixes                   grouped send / recv: every rank ships exactly what it holds
+//   caller's stream (second communicator)
+//     prep records against the gathered lists -> the unsharded launch sequence over this shard's row fragments
+//     all-gather of the per-shard top-n -> merge kernel (score desc, item id asc)         (16 n + 4) B per query and shard
+//
+// Three transports behind one interface: RCCL (one process per GPU), host callbacks (an application's own transport; the tests drive two
+// processes over gloo with it), and an in-process group (all shards of the group on this process's device: collectives degenerate to kernels --
+// tests, and capacity experiments on one GPU).  Same kernels, same bytes in all three.
+// =====================================================================================
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "srn_runtime.h"
+
+namespace srn {
+
+namespace {
+template <typename F> int guarded(F f) {   // never let an exception cross the C boundary
+    try { return f(); }
+    catch (const std::bad_alloc&) { return fail(SRN_ENOMEM, "out of host memory"); }
+    catch (const std::exception& e) { return fail(SRN_EINVAL, std::string("internal error: ") + e.what()); }
+    catch (...) { return fail(SRN_EINVAL, "internal error"); }
+}
+
+// ---- RCCL through dlopen: no link-time dependency, and ONE RCCL per process (a host that already loaded librccl -- torch does -- shares it) ----
+struct RcclApi {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    std::string err;
+};
+RcclApi* rccl() {
+    static RcclApi api; static std::once_flag once;
+    std::call_once(once, [] {
+        const char* env = getenv("SRN_RCCL_LIB");
+        void* h = env ? dlopen(env, RTLD_NOW | RTLD_GLOBAL) : nullptr;
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);   // already in the process (torch's bundled copy, or the host's own)
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) { api.err = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?"); return; }
+        api.h = h;
+        auto sym = [&](const char* n) -> void* { void* p = dlsym(h, n); if (!p && api.err.empty()) api.err = std::string("librccl lacks ") + n; return p; };
+        api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId"); api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+        api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy"); api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+        api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce"); api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+        api.Send = (decltype(api.Send))sym("ncclSend"); api.Recv = (decltype(api.Recv))sym("ncclRecv");
+        api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart"); api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+    });
+    return &api;
+}
+#define NCCL_TRY(expr)                                                                                                              \
+    do {                                                                                                                            \
+        ncclResult_t r_ = (expr);                                                                                                   \
+        if (r_ != ncclSuccess) return fail(SRN_EHIP, std::string(#expr) + ": " + (rccl()->GetErrorString ? rccl()->GetErrorString(r_) : "rccl error")); \
+    } while (0)
+
+struct Slot {   // everything one batch in flight needs (grow-only); two slots: batch i + 1's exchange overlaps batch i's kernels
+    std::vector<char*> pos; std::vector<size_t> pos_bytes;   // per local shard
+    char* head = nullptr; size_t head_bytes = 0;             // [nq][3] int32 (in-process group: + one scratch copy behind it)
+    char* kept = nullptr; size_t kept_bytes = 0;             // [G][nq * max_len] u32
+    char* tot = nullptr; size_t tot_bytes = 0;               // [nq] int32 (the count kernel's per-query totals; unused here)
+    char* off = nullptr; size_t off_bytes = 0;               // [G][nq] int64
+    char* small = nullptr; size_t small_bytes = 0;           // tot_dev [G] u64 | base_dev [G] u64
+    unsigned long long* tot_host = nullptr;                  // pinned, device-mapped: [G] totals | [G] bases
+    char* lists = nullptr; size_t lists_bytes = 0;           // the gathered list prefixes, segment g at base[g]
+    char* records = nullptr; size_t records_bytes = 0;
+    char* part = nullptr; size_t part_bytes = 0;             // [G] blocks: ids | scores | counts
+    hipEvent_t e_done = nullptr;
+};
+}  // namespace
+
+}  // namespace srn
+
+using namespace srn;
+
+struct srn_shard_group {
+    enum Kind { RCCL, CALLBACKS, LOCAL } kind = LOCAL;
+    int rank = 0, world = 1, device = 0;
+    std::vector<const srn_index*> shards;   // LOCAL: all of them; otherwise this rank's one
+    ncclComm_t comm[2] = {nullptr, nullptr};   // [0] exchange stream, [1] caller's stream: operations on one communicator serialise in issue order
+    srn_shard_comm_t cb{};
+    hipStream_t s_x = nullptr; hipEvent_t e_in = nullptr, e_x = nullptr;
+    bool overlap = true;
+    Slot slot[2];
+    uint64_t calls = 0;
+    uint64_t st_queries = 0, st_bytes_head = 0, st_bytes_kept = 0, st_bytes_lists = 0, st_bytes_results = 0, st_lists_max = 0;
+    std::mutex mu;   // one batch is issued at a time per group (the collectives must be issued in the same order on every rank anyway)
+};
+
+namespace {
+uint32_t G_of(const srn_shard_group* g) { return g->kind == srn_shard_group::LOCAL ? (uint32_t)g->shards.size() : (uint32_t)g->world; }
+
+// ---- the three collectives.  channel 0 = exchange stream, 1 = caller's stream ----
+int all_reduce_max_i32(srn_shard_group* g, int channel, int* buf, size_t count, hipStream_t st) {
+    if (g->kind == srn_shard_group::RCCL) NCCL_TRY(rccl()->AllReduce(buf, buf, count, ncclInt32, ncclMax, g->comm[channel], st));
+    else if (g->kind == srn_shard_group::CALLBACKS) { const int rc = g->cb.all_reduce_max_i32(g->cb.user, channel, buf, count, st); if (rc) return fail(rc, "the application's all-reduce callback failed"); }
+    return SRN_OK;
+}
+int all_gather_blocks(srn_shard_group* g, int channel, char* buf, size_t block_bytes, hipStream_t st) {   // block `rank` in place
+    if (g->kind == srn_shard_group::RCCL) NCCL_TRY(rccl()->AllGather(buf + (size_t)g->rank * block_bytes, buf, block_bytes, ncclChar, g->comm[channel], st));
+    else if (g->kind == srn_shard_group::CALLBACKS) { const int rc = g->cb.all_gather(g->cb.user, channel, buf, block_bytes, st); if (rc) return fail(rc, "the application's all-gather callback failed"); }
+    return SRN_OK;
+}
+int all_gather_v(srn_shard_group* g, int channel, char* buf, const unsigned long long* byte_off, const unsigned long long* byte_cnt, hipStream_t st) {   // segment `rank` in place
+    if (g->kind == srn_shard_group::RCCL) {
+        // every rank ships exactly the entries it holds: grouped point-to-point pairs (xGMI is point-to-point: 7 links per GPU, one per peer)
+        NCCL_TRY(rccl()->GroupStart());
+        for (int p = 0; p < g->world; ++p) {
+            if (p == g->rank) continue;
+            if (byte_cnt[g->rank]) NCCL_TRY(rccl()->Send(buf + byte_off[g->rank], byte_cnt[g->rank], ncclChar, p, g->comm[channel], st));
+            if (byte_cnt[p]) NCCL_TRY(rccl()->Recv(buf + byte_off[p], byte_cnt[p], ncclChar, p, g->comm[channel], st));
+        }
+        NCCL_TRY(rccl()->GroupEnd());
+    } else if (g->kind == srn_shard_group::CALLBACKS) {
+        const int rc = g->cb.all_gather_v(g->cb.user, channel, buf, (const uint64_t*)byte_off, (const uint64_t*)byte_cnt, st);
+        if (rc) return fail(rc, "the application's all-gather-v callback failed");
+    }
+    return SRN_OK;
+}
+
+void slot_free(Slot& s) {
+    for (char* p : s.pos) if (p) hipFree(p);
+    for (char* p : {s.head, s.kept, s.tot, s.off, s.small, s.lists, s.records, s.part}) if (p) hipFree(p);
+    if (s.tot_host) hipHostFree(s.tot_host);
+    if (s.e_done) hipEventDestroy(s.e_done);
+    s = Slot();
+}
+
+int group_init_common(srn_shard_group* g) {
+    HIP_TRY(hipSetDevice(g->device));
+    HIP_TRY(hipStreamCreateWithFlags(&g->s_x, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&g->e_in, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&g->e_x, hipEventDisableTiming));
+    const uint32_t G = G_of(g);
+    for (Slot& s : g->slot) {
+        HIP_TRY(hipEventCreateWithFlags(&s.e_done, hipEventDisableTiming));
+        HIP_TRY(hipHostMalloc((void**)&s.tot_host, (size_t)G * 16, hipHostMallocMapped));
+        s.pos.assign(g->shards.size(), nullptr); s.pos_bytes.assign(g->shards.size(), 0);
+    }
+    if (const char* e = getenv("SRN_GROUP_OVERLAP")) g->overlap = atoi(e) != 0;
+    return SRN_OK;
+}
+
+int check_shard(const srn_index* ix, uint32_t want_shard, uint32_t n_shards) {
+    if (!ix) return fail(SRN_EINVAL, "null shard");
+    if (!ix->dev) return fail(SRN_ENODEV, "shard has no device attached; there is no CPU fallback behind this ABI");
+    if (ix->flat.n_shards != n_shards || ix->flat.shard != want_shard) return fail(SRN_EINVAL, "the index is not shard " + std::to_string(want_shard) + " of " + std::to_string(n_shards));
+    return SRN_OK;
+}
+
+int group_predict(srn_shard_group* g, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq_, size_t max_len_hint, size_t k, size_t m, size_t how_many,
+                  unsigned flags, uint64_t* d_out_ids, double* d_out_scores, uint32_t* d_out_counts, hipStream_t user) {
+    std::lock_guard<std::mutex> lk(g->mu);
+    HIP_TRY(hipSetDevice(g->device));
+    const uint32_t G = G_of(g), nq = (uint32_t)nq_, ML = (uint32_t)max_len_hint, n = (uint32_t)how_many;
+    const bool local = g->kind == srn_shard_group::LOCAL;
+    LaunchParams p{};
+    const bool resident = (flags & SRN_FLAG_INPUTS_RESIDENT) != 0u;   // the inputs do not hang on the caller's stream: this batch's exchange may start while the previous batch still runs there
+    flags &= ~(unsigned)SRN_FLAG_INPUTS_RESIDENT;
+    p.nq = nq; p.k = (uint32_t)k; p.m = (uint32_t)m; p.how_many = n; p.flags = flags; p.max_len = ML; p.items_flat = d_items_flat; p.q_off = d_q_off;
+    for (const srn_index* ix : g->shards)
+        if (!device_shard_lists_supported(ix->dev, ix->flat, p))
+            return fail(SRN_EINVAL, "the shard group runs the LISTS pipeline: sessions of <= 8 items, m <= m_index, complete posting lists (everything else: stages A/B/C, srn_shard_stage_*)");
+    Slot& s = g->slot[g->calls & 1u];
+    const bool overlap = g->overlap && !local;
+    hipStream_t sx = overlap ? g->s_x : user;
+    // ---- buffers (grow-only; growing synchronises the device, like every hipFree) ----
+    const uint32_t rec_stride = device_prep_stride(ML);
+    const size_t block_bytes = ((size_t)nq * n * 16 + (size_t)nq * 4 + 255) / 256 * 256;
+    {
+        int rc = SRN_OK;
+        for (size_t i = 0; i < g->shards.size() && !rc; ++i) rc = ensure(&s.pos[i], &s.pos_bytes[i], (size_t)nq * ML * 16);
+        if (!rc) rc = ensure(&s.head, &s.head_bytes, (size_t)nq * 12 * 2);
+        if (!rc) rc = ensure(&s.kept, &s.kept_bytes, (size_t)G * nq * ML * 4);
+        if (!rc) rc = ensure(&s.tot, &s.tot_bytes, (size_t)nq * 4);
+        if (!rc) rc = ensure(&s.off, &s.off_bytes, (size_t)G * nq * 8);
+        if (!rc) rc = ensure(&s.small, &s.small_bytes, (size_t)G * 16);
+        if (!rc) rc = ensure(&s.records, &s.records_bytes, (size_t)nq * rec_stride);
+        if (!rc) rc = ensure(&s.part, &s.part_bytes, (size_t)G * block_bytes);
+        if (rc) return rc;
+    }
+    int* head = (int*)s.head; uint32_t* kept_g = (uint32_t*)s.kept; long long* off_g = (long long*)s.off;
+    unsigned long long* tot_dev = (unsigned long long*)s.small; unsigned long long* base_dev = tot_dev + G;
+    unsigned long long* tot_host_dev = nullptr; HIP_TRY(hipHostGetDevicePointer((void**)&tot_host_dev, s.tot_host, 0));
+    // ---- exchange stream: ordered behind the caller's inputs and behind the batch that used this slot two calls ago ----
+    if (overlap) {
+        if (!resident) { HIP_TRY(hipEventRecord(g->e_in, user)); HIP_TRY(hipStreamWaitEvent(sx, g->e_in, 0)); }   // (behind everything on the caller's stream: correct, but no overlap)
+        if (g->calls >= 2) HIP_TRY(hipStreamWaitEvent(sx, s.e_done, 0));
+    }
+    // head: every shard's view of the evolving positions, the local cuts -> global cuts
+    for (size_t i = 0; i < g->shards.size(); ++i) {
+        int* h_i = i == 0 ? head : head + (size_t)nq * 3;
+        int rc = device_shard_lists_head(g->shards[i]->dev, p, s.pos[i], h_i, sx); if (rc) return rc;
+        if (i > 0) HIP_TRY(launch_shard_max(sx, head, h_i, (size_t)nq * 3));
+    }
+    { int rc = all_reduce_max_i32(g, 0, head, (size_t)nq * 3, sx); if (rc) return rc; }
+    // count: the entries at or above the cut, per owned list -> every rank knows every shard's counts
+    for (size_t i = 0; i < g->shards.size(); ++i) {
+        const uint32_t gi = local ? (uint32_t)i : (uint32_t)g->rank;
+        int rc = device_shard_lists_count(g->shards[i]->dev, p, s.pos[i], head, kept_g + (size_t)gi * nq * ML, (int*)s.tot, sx); if (rc) return rc;
+    }
+    { int rc = all_gather_blocks(g, 0, s.kept, (size_t)nq * ML * 4, sx); if (rc) return rc; }
+    HIP_TRY(launch_shard_offsets(sx, kept_g, nq, ML, G, off_g, tot_dev, tot_host_dev));
+    HIP_TRY(hipStreamSynchronize(sx));   // the batch's one host synchronisation (with the exchange stream: only this batch's small kernels are waited for)
+    unsigned long long base[64], cnt_b[64], off_b[64], total = 0;
+    if (G > 64) return fail(SRN_ERANGE, "more than 64 shards");
+    for (uint32_t i = 0; i < G; ++i) { base[i] = total; total += (s.tot_host[i] + 63ull) / 64ull * 64ull; }   // (segments start on 256-byte boundaries)
+    for (uint32_t i = 0; i < G; ++i) { s.tot_host[G + i] = base[i]; off_b[i] = base[i] * 4ull; cnt_b[i] = s.tot_host[i] * 4ull; }
+    if (s.lists_bytes < total * 4 + 256) { int rc = ensure(&s.lists, &s.lists_bytes, (size_t)(total * 4 + total / 2 + 4096)); if (rc) return rc; }   // (head room: the totals of like batches differ by a per cent or two)
+    HIP_TRY(hipMemcpyAsync(base_dev, s.tot_host + G, (size_t)G * 8, hipMemcpyHostToDevice, sx));
+    uint32_t* lists_g = (uint32_t*)s.lists;
+    for (size_t i = 0; i < g->shards.size(); ++i) {
+        const uint32_t gi = local ? (uint32_t)i : (uint32_t)g->rank;
+        int rc = device_shard_lists_copy(g->shards[i]->dev, p, s.pos[i], kept_g + (size_t)gi * nq * ML, off_g + (size_t)gi * nq, lists_g + base[gi], sx); if (rc) return rc;
+    }
+    { int rc = all_gather_v(g, 0, s.lists, off_b, cnt_b, sx); if (rc) return rc; }
+    if (overlap) { HIP_TRY(hipEventRecord(g->e_x, sx)); HIP_TRY(hipStreamWaitEvent(user, g->e_x, 0)); }
+    // ---- caller's stream: the unsharded launch sequence over every local shard's row fragments ----
+    for (size_t i = 0; i < g->shards.size(); ++i) {
+        const uint32_t gi = local ? (uint32_t)i : (uint32_t)g->rank;
+        char* blk = s.part + (size_t)gi * block_bytes;
+        LaunchParams pi = p;
+        const bool direct = G == 1;   // one shard: its top-n IS the result
+        pi.out_ids = direct ? d_out_ids : (uint64_t*)blk; pi.out_scores = direct ? d_out_scores : (double*)(blk + (size_t)nq * n * 8); pi.out_counts = direct ? d_out_counts : (uint32_t*)(blk + (size_t)nq * n * 16);
+        HIP_TRY(hipMemsetAsync(pi.out_ids, 0, (size_t)nq * n * 8, user)); HIP_TRY(hipMemsetAsync(pi.out_scores, 0, (size_t)nq * n * 8, user));
+        int rc = device_shard_lists_predict(g->shards[i]->dev, g->shards[i]->flat, pi, G, kept_g, off_g, 0ull, lists_g, head, s.pos[i], s.records, user, base_dev); if (rc) return rc;
+    }
+    if (G > 1) {
+        int rc = all_gather_blocks(g, 1, s.part, block_bytes, user); if (rc) return rc;
+        HIP_TRY(launch_shard_merge_topn(user, s.part, block_bytes, G, nq, n, d_out_ids, d_out_scores, d_out_counts));
+    }
+    HIP_TRY(hipEventRecord(s.e_done, user));
+    ++g->calls;
+    const uint32_t me = local ? 0u : (uint32_t)g->rank;
+    g->st_queries += nq; g->st_bytes_head += (uint64_t)nq * 12; g->st_bytes_kept += (uint64_t)nq * ML * 4 * (local ? G : 1);
+    { uint64_t mine = 0, mx = 0; for (uint32_t i = 0; i < G; ++i) { mx = std::max<uint64_t>(mx, s.tot_host[i]); if (local || i == me) mine += s.tot_host[i]; }
+      g->st_bytes_lists += mine * 4; g->st_lists_max += mx * 4; }
+    g->st_bytes_results += G > 1 ? (uint64_t)block_bytes * (local ? G : 1) : 0;
+    return SRN_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int srn_shard_group_unique_id(void* out, size_t bytes) {
+    return guarded([&]() -> int {
+        if (!out || bytes < SRN_SHARD_GROUP_ID_BYTES) return fail(SRN_EINVAL, "the id buffer must hold SRN_SHARD_GROUP_ID_BYTES");
+        RcclApi* r = rccl();
+        if (!r->h || !r->err.empty()) return fail(SRN_ENODEV, r->err.empty() ? "librccl is not available" : r->err);
+        static_assert(SRN_SHARD_GROUP_ID_BYTES == 2 * sizeof(ncclUniqueId), "two communicators per group");
+        ncclUniqueId id[2];
+        NCCL_TRY(r->GetUniqueId(&id[0])); NCCL_TRY(r->GetUniqueId(&id[1]));
+        memcpy(out, id, sizeof id);
+        return SRN_OK; });
+}
+
+int srn_shard_group_create(const srn_index_t* shard, const void* unique_id, int rank, int world, srn_shard_group_t** out) {
+    return guarded([&]() -> int {
+        if (!out) return fail(SRN_EINVAL, "null argument");
+        *out = nullptr;
+        if (!unique_id || world < 1 || world > 64 || rank < 0 || rank >= world) return fail(SRN_EINVAL, "bad rank / world / id");
+        int rc = check_shard(shard, (uint32_t)rank, (uint32_t)world); if (rc) return rc;
+        RcclApi* r = rccl();
+        if (!r->h || !r->err.empty()) return fail(SRN_ENODEV, r->err.empty() ? "librccl is not available" : r->err);
+        srn_shard_group* g = new srn_shard_group();
+        g->kind = srn_shard_group::RCCL; g->rank = rank; g->world = world; g->device = shard->device; g->shards = {shard};
+        rc = group_init_common(g);
+        if (!rc) {
+            ncclUniqueId id[2]; memcpy(id, unique_id, sizeof id);
+            auto init = [&]() -> int { NCCL_TRY(r->CommInitRank(&g->comm[0], world, id[0], rank)); NCCL_TRY(r->CommInitRank(&g->comm[1], world, id[1], rank)); return SRN_OK; };
+            rc = init();
+        }
+        if (rc) { srn_shard_group_free(g); return rc; }
+        *out = g; return SRN_OK; });
+}
+
+int srn_shard_group_create_with_comm(const srn_index_t* shard, int rank, int world, const srn_shard_comm_t* comm, srn_shard_group_t** out) {
+    return guarded([&]() -> int {
+        if (!out) return fail(SRN_EINVAL, "null argument");
+        *out = nullptr;
+        if (!comm || !comm->all_reduce_max_i32 || !comm->all_gather || !comm->all_gather_v || world < 1 || world > 64 || rank < 0 || rank >= world) return fail(SRN_EINVAL, "bad rank / world / callbacks");
+        int rc = check_shard(shard, (uint32_t)rank, (uint32_t)world); if (rc) return rc;
+        srn_shard_group* g = new srn_shard_group();
+        g->kind = srn_shard_group::CALLBACKS; g->rank = rank; g->world = world; g->device = shard->device; g->shards = {shard}; g->cb = *comm;
+        rc = group_init_common(g);
+        if (rc) { srn_shard_group_free(g); return rc; }
+        *out = g; return SRN_OK; });
+}
+
+int srn_shard_group_create_local(const srn_index_t* const* shards, int n_shards, srn_shard_group_t** out) {
+    return guarded([&]() -> int {
+        if (!out) return fail(SRN_EINVAL, "null argument");
+        *out = nullptr;
+        if (!shards || n_shards < 1 || n_shards > 64) return fail(SRN_EINVAL, "bad shard list");
+        for (int i = 0; i < n_shards; ++i) {
+            int rc = check_shard(shards[i], (uint32_t)i, (uint32_t)n_shards); if (rc) return rc;
+            if (shards[i]->device != shards[0]->device) return fail(SRN_EINVAL, "an in-process group keeps all its shards on one device (one process per GPU otherwise: srn_shard_group_create)");
+        }
+        srn_shard_group* g = new srn_shard_group();
+        g->kind = srn_shard_group::LOCAL; g->rank = 0; g->world = 1; g->device = shards[0]->device; g->shards.assign(shards, shards + n_shards);
+        int rc = group_init_common(g);
+        if (rc) { srn_shard_group_free(g); return rc; }
+        *out = g; return SRN_OK; });
+}
+
+void srn_shard_group_free(srn_shard_group_t* g) {
+    if (!g) return;
+    hipSetDevice(g->device);
+    hipDeviceSynchronize();
+    for (auto& c : g->comm) if (c && rccl()->CommDestroy) rccl()->CommDestroy(c);
+    for (Slot& s : g->slot) slot_free(s);
+    if (g->s_x) hipStreamDestroy(g->s_x);
+    if (g->e_in) hipEventDestroy(g->e_in); if (g->e_x) hipEventDestroy(g->e_x);
+    delete g;
+}
+
+int srn_shard_group_predict_batch(srn_shard_group_t* g, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq, size_t max_len_hint, size_t k, size_t m,
+                                  size_t how_many, unsigned flags, uint64_t* d_out_ids, double* d_out_scores, uint32_t* d_out_counts, void* stream) {
+    return guarded([&]() -> int {
+        if (!g) return fail(SRN_EINVAL, "null group");
+        if (k == 0 || m == 0 || how_many == 0) return fail(SRN_EINVAL, "k, m and how_many must be > 0");
+        if (how_many > SRN_MAX_HOW_MANY || k > SRN_MAX_K || m > 0x7FFFFFFFull) return fail(SRN_ERANGE, "k, m or how_many above the limits (srn_limits)");
+        if (nq == 0) return SRN_OK;
+        if (!d_items_flat || !d_q_off || !d_out_ids || !d_out_scores || !d_out_counts) return fail(SRN_EINVAL, "null buffer");
+        if (nq > 0x7FFFFFFFull) return fail(SRN_ERANGE, "too many queries in one batch");
+        if (max_len_hint == 0 || max_len_hint > SRN_MAX_SESSION_LEN) return fail(SRN_ERANGE, "max_len_hint out of range");
+        return group_predict(g, d_items_flat, d_q_off, nq, max_len_hint, k, m, how_many, flags, d_out_ids, d_out_scores, d_out_counts, (hipStream_t)stream); });
+}
+
+int srn_shard_group_stats(const srn_shard_group_t* g, srn_shard_group_stats_t* out) {
+    if (!g || !out) return fail(SRN_EINVAL, "null argument");
+    *out = srn_shard_group_stats_t{(uint64_t)G_of(g), g->calls, g->st_queries, g->st_bytes_head, g->st_bytes_kept, g->st_bytes_lists, g->st_bytes_results, g->st_lists_max,
+                                   g->kind == srn_shard_group::RCCL ? 1u : g->kind == srn_shard_group::CALLBACKS ? 2u : 0u, g->overlap && g->kind != srn_shard_group::LOCAL ? 1u : 0u};
+    return SRN_OK;
+}
+
+}  // extern "C"

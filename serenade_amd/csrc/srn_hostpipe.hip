@@ -12,6 +12,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -30,10 +32,10 @@ struct CopyTask { void* dst; const void* src; size_t n; std::atomic<int>* pendin
 class CopyPool {
 public:
     static CopyPool& get() { static CopyPool* p = new CopyPool(); return *p; }   // (leaked on purpose: no static destructor racing with threads at exit)
-    void submit(void* dst, const void* src, size_t n, std::atomic<int>* pending) {
+    void submit(void* dst, const void* src, size_t n, std::atomic<int>* pending, int slices = 0) {
         if (n == 0) return;
-        const size_t nthr = threads_.size();
-        if (nthr == 0 || n < (1u << 20)) { memcpy(dst, src, n); return; }   // small: the wake-up costs more than the copy
+        const size_t nthr = slices > 0 ? (size_t)slices : threads_.size();
+        if (threads_.empty() || n < (1u << 20)) { memcpy(dst, src, n); return; }   // small: the wake-up costs more than the copy
         const size_t per = ((n + nthr - 1) / nthr + 4095) / 4096 * 4096;
         std::vector<CopyTask> ts;
         for (size_t o = 0; o < n; o += per) ts.push_back(CopyTask{(char*)dst + o, (const char*)src + o, std::min(per, n - o), pending});
@@ -130,6 +132,10 @@ int device_predict_host_pipelined(DeviceState* d, const FlatIndex& ix, const Lau
         if (*good) pipe_release(d, hp);
         else { hipStreamSynchronize(hp->s_in); hipStreamSynchronize(hp->s_k[0]); hipStreamSynchronize(hp->s_k[1]); hipStreamSynchronize(hp->s_out); pipe_release(d, hp); } } } rel{d, hp, &good};
     const uint32_t nq = p_in.nq, n = p_in.how_many;
+    const Knobs kn = knobs();
+    const auto t_start = std::chrono::steady_clock::now();
+    auto now_us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count(); };
+    double tr_in = 0, tr_enq = 0, tr_wait_out = 0, tr_wait_copy = 0, tr_submit = 0;
     const uint32_t nchunks = hostpipe_chunks(nq, n);
     const uint32_t csz = (uint32_t)(((uint64_t)nq + nchunks - 1) / nchunks);
     CopyPool& pool = CopyPool::get();
@@ -137,11 +143,16 @@ int device_predict_host_pipelined(DeviceState* d, const FlatIndex& ix, const Lau
     auto flush = [&](uint32_t c) -> int {   // chunk c's results: pinned staging -> the caller's buffers (asynchronous: the copy threads)
         const int o = (int)(c % HostPipe::NOUT);
         const uint32_t q0 = c * csz, cq = std::min(csz, nq - q0);
+        double t0 = now_us();
         HIP_TRY(hipEventSynchronize(hp->e_out[o]));
+        tr_wait_out += now_us() - t0; t0 = now_us();
         const char* src = hp->pin_out[o];
-        pool.submit(h_ids + (size_t)q0 * n, src, (size_t)cq * n * 8, &hp->pending[o]);
-        pool.submit(h_scores + (size_t)q0 * n, src + (size_t)cq * n * 8, (size_t)cq * n * 8, &hp->pending[o]);
+        if (!kn.host_nocopy) {
+            pool.submit(h_ids + (size_t)q0 * n, src, (size_t)cq * n * 8, &hp->pending[o], kn.copy_slices);
+            pool.submit(h_scores + (size_t)q0 * n, src + (size_t)cq * n * 8, (size_t)cq * n * 8, &hp->pending[o], kn.copy_slices);
+        }
         memcpy(h_counts + q0, src + (size_t)cq * n * 16, (size_t)cq * 4);
+        tr_submit += now_us() - t0;
         return SRN_OK;
     };
     for (uint32_t c = 0; c < nchunks; ++c) {
@@ -150,10 +161,12 @@ int device_predict_host_pipelined(DeviceState* d, const FlatIndex& ix, const Lau
         if (q0 >= nq) break;
         const size_t it0 = h_qoff[q0], it1 = h_qoff[q0 + cq], in_items = (it1 - it0) * 8, in_off = ((size_t)cq + 1) * 4, in_bytes = (in_items + 255) / 256 * 256 + in_off;
         // input staging of chunk c - 2 has been read by its upload
+        double t0 = now_us();
         if (c >= 2) HIP_TRY(hipEventSynchronize(hp->e_in[i]));
         { int rc = ensure_pinned(&hp->pin_in[i], &hp->pin_in_bytes[i], in_bytes); if (rc) return rc; }
         memcpy(hp->pin_in[i], h_items + it0, in_items);
         memcpy(hp->pin_in[i] + (in_items + 255) / 256 * 256, h_qoff + q0, in_off);
+        tr_in += now_us() - t0; t0 = now_us();
         if (c >= 2) HIP_TRY(hipStreamWaitEvent(hp->s_in, hp->e_k[i], 0));   // device input slot: chunk c - 2's kernels are done with it
         if (hp->dev_in_bytes[i] < in_bytes) { if (c >= 2) HIP_TRY(hipEventSynchronize(hp->e_k[i])); int rc = ensure(&hp->dev_in[i], &hp->dev_in_bytes[i], in_bytes); if (rc) return rc; }
         HIP_TRY(hipMemcpyAsync(hp->dev_in[i], hp->pin_in[i], in_bytes, hipMemcpyHostToDevice, hp->s_in));
@@ -172,15 +185,20 @@ int device_predict_host_pipelined(DeviceState* d, const FlatIndex& ix, const Lau
         { int rc = device_predict(d, ix, p, true, hp->s_k[i], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr); if (rc) return rc; }
         HIP_TRY(hipEventRecord(hp->e_k[i], hp->s_k[i]));
         // download: the pinned slot's previous contents (chunk c - NOUT) must have reached the caller's buffers
+        tr_enq += now_us() - t0; t0 = now_us();
         CopyPool::wait(&hp->pending[o]);
+        tr_wait_copy += now_us() - t0; t0 = now_us();
         { int rc = ensure_pinned(&hp->pin_out[o], &hp->pin_out_bytes[o], ob); if (rc) return rc; }
         HIP_TRY(hipStreamWaitEvent(hp->s_out, hp->e_k[i], 0));
         HIP_TRY(hipMemcpyAsync(hp->pin_out[o], hp->dev_out[i], ob, hipMemcpyDeviceToHost, hp->s_out));
         HIP_TRY(hipEventRecord(hp->e_out[o], hp->s_out));
+        tr_enq += now_us() - t0;
         if (c >= 1) { int rc = flush(c - 1); if (rc) return rc; }
     }
     { const uint32_t last = (nq + csz - 1) / csz - 1; int rc = flush(last); if (rc) return rc; }
-    for (auto& pnd : hp->pending) CopyPool::wait(&pnd);
+    { const double t0 = now_us(); for (auto& pnd : hp->pending) CopyPool::wait(&pnd); tr_wait_copy += now_us() - t0; }
+    if (kn.host_trace) fprintf(stderr, "[srn] host pipe: nq %u, %u chunks of %u: total %.0f us = input staging %.0f + enqueue %.0f + wait downloads %.0f + wait copy threads %.0f + submit %.0f\n",
+                               nq, nchunks, csz, now_us(), tr_in, tr_enq, tr_wait_out, tr_wait_copy, tr_submit);
     good = true;
     return SRN_OK;
 }

@@ -122,7 +122,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p, b
                    // host-pointer mode: these are host buffers copied in/out by the call
                    const uint64_t* h_items, const uint32_t* h_qoff, uint64_t* h_ids, double* h_scores,
                    uint32_t* h_counts, uint32_t* h_stats, uint32_t* h_nb_rank, uint32_t* h_nb_num, uint32_t* h_nb_cnt, const ExtLists* ext = nullptr,
-                   bool reserve_only = false);   // reserve_only (srn_index_reserve): size the call's workspace, enqueue nothing
+                   bool reserve_only = false, bool blocking_wait = false);   // reserve_only (srn_index_reserve): size the call's workspace, enqueue nothing; blocking_wait: the latency path sleeps on an interrupt instead of spinning
 struct ShardIO {
     void* cand; uint32_t* cand_cnt;                                       // A out: [nq * m] packed slots, [nq]
     const void* gathered; const uint32_t* gathered_cnt; uint32_t n_shards;   // B in: [G][nq * gathered_stride], [G][nq]
@@ -136,7 +136,8 @@ int device_shard_lists_head(DeviceState* d, const LaunchParams& p, void* pos, in
 int device_shard_lists_count(DeviceState* d, const LaunchParams& p, const void* pos, const int* head, uint32_t* kept, int* tot, void* stream);
 int device_shard_lists_copy(DeviceState* d, const LaunchParams& p, const void* pos, const uint32_t* kept, const long long* off, uint32_t* out, void* stream);
 int device_shard_lists_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p, uint32_t n_shards, const uint32_t* kept_g, const long long* off_g,
-                               unsigned long long shard_stride, const uint32_t* lists_g, const int* head, const void* pos_local, char* records, void* stream);
+                               unsigned long long shard_stride, const uint32_t* lists_g, const int* head, const void* pos_local, char* records, void* stream,
+                               const unsigned long long* shard_base = nullptr);   // shard_base [n_shards] (device): the shards' segment starts (null: g * shard_stride)
 int device_shard_stage(DeviceState* d, const FlatIndex& ix, int stage, const LaunchParams& p, const ShardIO& sh, void* stream);
 int device_slot_bytes(DeviceState* d, const FlatIndex& ix, uint32_t max_len, uint32_t* num_bits = nullptr);
 int device_last_kernel_ms(DeviceState* d, double* ms_main, double* ms_retry, uint32_t* retried);

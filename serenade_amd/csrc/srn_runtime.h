@@ -25,6 +25,9 @@ struct Knobs {
     int hot_slots = -1, sketch_slots = -1, lds_budget_kb = 0, grid_mult = 16, fast_runs = 0;
     bool grid_mult_set = false;
     int host_chunks = 0;      // SRN_HOST_CHUNKS: number of chunks a host-pointer batch is cut into (0 = by size, srn_hostpipe.hip)
+    int copy_slices = 0;      // SRN_COPY_SLICES: slices a result block is cut into for the copy threads (0 = one per thread)
+    bool host_nocopy = false; // SRN_HOST_NOCOPY (experiments): the chunked host path leaves the results in its pinned staging
+    bool host_trace = false;  // SRN_HOST_TRACE (experiments): per-call timeline of the chunked host path on stderr
     int tiny_max = 256;       // SRN_TINY_MAX: host-pointer batches of up to this many sessions take the zero-copy latency path
     int lanes = 4;            // SRN_PREDICT_LANES: concurrent rounds of the srn_predict combiner (srn_combine.cpp)
     bool geometry_default() const { return !no_masks && !no_merge && !dense && hot_slots < 0 && sketch_slots < 0 && lds_budget_kb == 0; }
@@ -53,6 +56,7 @@ struct Workspace {
     // staging for host-pointer calls
     char* stage = nullptr; size_t stage_bytes = 0;
     uint32_t* h_retry = nullptr;   // pinned
+    hipEvent_t ev_block = nullptr; // blocking-sync event of the latency path (rounds shared by several callers)
 };
 
 struct DeviceState {

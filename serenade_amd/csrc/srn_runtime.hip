@@ -27,6 +27,8 @@ static void knobs_read() {
     if (const char* e = getenv("SRN_LDS_BUDGET_KB")) k.lds_budget_kb = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_GRID_MULT")) { k.grid_mult = std::max(1, atoi(e)); k.grid_mult_set = true; }
     if (const char* e = getenv("SRN_HOST_CHUNKS")) k.host_chunks = std::max(0, atoi(e));
+    if (const char* e = getenv("SRN_COPY_SLICES")) k.copy_slices = std::max(0, atoi(e));
+    k.host_nocopy = getenv("SRN_HOST_NOCOPY") != nullptr; k.host_trace = getenv("SRN_HOST_TRACE") != nullptr;
     if (const char* e = getenv("SRN_TINY_MAX")) k.tiny_max = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_PREDICT_LANES")) k.lanes = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_FAST_RUNS")) k.fast_runs = atoi(e) == 3 ? 3 : 0;   // tests: the fast kernel's 29-bit-rank form (3 lists per query) on a small index
@@ -158,6 +160,7 @@ static void ws_free(Workspace* w) {
     if (w->pin) hipHostFree(w->pin);
     if (w->stage) hipFree(w->stage);
     if (w->h_retry) hipHostFree(w->h_retry);
+    if (w->ev_block) hipEventDestroy(w->ev_block);
     for (auto& t : w->ev) for (auto& e : t) if (e) hipEventDestroy(e);
     if (w->stream) hipStreamDestroy(w->stream);
     delete w;
@@ -311,7 +314,7 @@ static int make_geometry(const DeviceState* d, const FlatIndex& ix, const Launch
 // results come back the same way; two launches (prep kernel + general kernel, one workgroup per query) and one stream synchronise.
 // Returns 1 if a query needs the global-table pass (the caller then takes the normal path).
 static int device_predict_tiny(DeviceState* d, Workspace* w, const Geometry& geo, LaunchParams p, const uint64_t* h_items, const uint32_t* h_qoff,
-                               uint64_t* h_ids, double* h_scores, uint32_t* h_counts) {
+                               uint64_t* h_ids, double* h_scores, uint32_t* h_counts, bool blocking_wait) {
     const size_t nitems = h_qoff[p.nq], n_out = (size_t)p.nq * p.how_many;
     size_t off = 0; auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 63) / 64 * 64; return o; };
     const size_t o_items = take(nitems * 8), o_qoff = take(((size_t)p.nq + 1) * 4), o_ids = take(n_out * 8), o_sc = take(n_out * 8), o_cnt = take((size_t)p.nq * 4),
@@ -319,7 +322,7 @@ static int device_predict_tiny(DeviceState* d, Workspace* w, const Geometry& geo
     if (w->pin_bytes < off) {
         if (w->pin) HIP_TRY(hipHostFree(w->pin));
         w->pin = nullptr; w->pin_bytes = 0;
-        const size_t want = std::max<size_t>(off * 2, 64 * 1024);
+        const size_t want = std::max<size_t>(off * 2, 256 * 1024);   // (room for a full round of the combiner at once: growing a pinned buffer stalls every lane)
         HIP_TRY(hipHostMalloc((void**)&w->pin, want, hipHostMallocMapped));
         w->pin_bytes = want;
     }
@@ -330,14 +333,19 @@ static int device_predict_tiny(DeviceState* d, Workspace* w, const Geometry& geo
     p.out_ids = (uint64_t*)(dp + o_ids); p.out_scores = (double*)(dp + o_sc); p.out_counts = (uint32_t*)(dp + o_cnt);
     p.stats = nullptr; p.nb_rank = p.nb_num = p.nb_cnt = nullptr; p.phase_cycles = nullptr;
     hipStream_t st = w->stream;
-    { int rc = ensure(&w->spill, &w->spill_bytes, (size_t)p.nq * p.k * geo.slot_bytes); if (rc) return rc; }
+    const size_t cap_q = std::max<size_t>(p.nq, (size_t)std::max(1, knobs().tiny_max));   // (sized once for the largest round: hipFree / hipMalloc synchronise the device)
+    { int rc = ensure(&w->spill, &w->spill_bytes, cap_q * p.k * geo.slot_bytes); if (rc) return rc; }
     const uint32_t prep_stride = (uint32_t)(sizeof(PrepHead) + (size_t)p.max_len * sizeof(PrepItem));
-    { int rc = ensure(&w->prep, &w->prep_bytes, (size_t)p.nq * prep_stride); if (rc) return rc; }
+    { int rc = ensure(&w->prep, &w->prep_bytes, cap_q * prep_stride); if (rc) return rc; }
     HIP_TRY(launch_prep(st, d->di, p.items_flat, p.q_off, p.nq, p.m, p.max_len, w->prep, prep_stride));
     p.prep = w->prep; p.prep_stride = prep_stride;
     HIP_TRY(launch_predict(geo.masks, geo.slot64, false, 0, dim3(p.nq), geo.lds, st, d->di, p, geo.c, nullptr, nullptr, (uint32_t*)(dp + o_rl), (uint32_t*)(dp + o_rc), nullptr, 0,
                            w->spill, ShardIO{}));
-    HIP_TRY(hipStreamSynchronize(st));
+    if (blocking_wait) {   // a round several callers share: sleep on an interrupt instead of spinning on the signal (the host's cores belong to the callers)
+        if (!w->ev_block) HIP_TRY(hipEventCreateWithFlags(&w->ev_block, hipEventBlockingSync | hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(w->ev_block, st));
+        HIP_TRY(hipEventSynchronize(w->ev_block));
+    } else HIP_TRY(hipStreamSynchronize(st));
     if (*(volatile uint32_t*)(w->pin + o_rc) != 0) return 1;   // (rare: tables too small for some query)
     // what the timing / path-count APIs report after this call: its query count, all through the general kernel, not timed (the stream is idle here:
     // nothing of an earlier call is still writing the pinned words)
@@ -356,7 +364,7 @@ static int device_predict_tiny(DeviceState* d, Workspace* w, const Geometry& geo
 
 int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in, bool on_device, void* user_stream,
                    const uint64_t* h_items, const uint32_t* h_qoff, uint64_t* h_ids, double* h_scores, uint32_t* h_counts,
-                   uint32_t* h_stats, uint32_t* h_nb_rank, uint32_t* h_nb_num, uint32_t* h_nb_cnt, const ExtLists* ext, bool reserve_only) {
+                   uint32_t* h_stats, uint32_t* h_nb_rank, uint32_t* h_nb_num, uint32_t* h_nb_cnt, const ExtLists* ext, bool reserve_only, bool blocking_wait) {
     HIP_TRY(hipSetDevice(d->device));
     LaunchParams p = p_in;
     if (p.nq == 0) return SRN_OK;
@@ -379,7 +387,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     if (!on_device && !reserve_only && !h_stats && !h_nb_rank) {
         const Knobs kn0 = knobs();
         if (p.nq <= (uint32_t)kn0.tiny_max && !d->phase_on && !kn0.dense) {
-            const int rc = device_predict_tiny(d, w, geo, p, h_items, h_qoff, h_ids, h_scores, h_counts);
+            const int rc = device_predict_tiny(d, w, geo, p, h_items, h_qoff, h_ids, h_scores, h_counts, blocking_wait);
             if (rc != 1) return rc;   // (1: some query needs the global-table pass -- the paths below have it)
         }
         // everything larger: chunks through pinned staging, uploads / kernels / downloads overlapped (srn_hostpipe.hip); each chunk comes back here as a
@@ -562,13 +570,14 @@ int device_shard_lists_copy(DeviceState* d, const LaunchParams& p, const void* p
     return SRN_OK;
 }
 int device_shard_lists_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p, uint32_t n_shards, const uint32_t* kept_g, const long long* off_g,
-                               unsigned long long shard_stride, const uint32_t* lists_g, const int* head, const void* pos_local, char* records, void* stream) {
+                               unsigned long long shard_stride, const uint32_t* lists_g, const int* head, const void* pos_local, char* records, void* stream,
+                               const unsigned long long* shard_base) {
     HIP_TRY(hipSetDevice(d->device));
     if (p.nq == 0) return SRN_OK;
     if (n_shards != ix.n_shards) return fail(SRN_EINVAL, "n_shards differs from the number of shards this index was cut into");
     if (!device_shard_lists_supported(d, ix, p)) return fail(SRN_EINVAL, "lists mode needs position-set slots (sessions of <= 8 items, m <= m_index, complete lists): use the three-stage pipeline");
     const uint32_t stride = device_prep_stride(p.max_len);
-    HIP_TRY(launch_shard_prep((hipStream_t)stream, p.items_flat, p.q_off, p.nq, p.max_len, n_shards, kept_g, off_g, shard_stride, head, (const ShardPos*)pos_local, records, stride));
+    HIP_TRY(launch_shard_prep((hipStream_t)stream, p.items_flat, p.q_off, p.nq, p.max_len, n_shards, kept_g, off_g, shard_stride, head, (const ShardPos*)pos_local, records, stride, shard_base));
     ExtLists ext{records, stride, lists_g};
     return device_predict(d, ix, p, true, stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &ext);
 }

@@ -92,8 +92,8 @@ __global__ __launch_bounds__(256) void shard_lists_copy_kernel(DeviceIndex ix, u
 
 __global__ __launch_bounds__(256) void shard_prep_kernel(const uint64_t* __restrict__ items_flat, const uint32_t* __restrict__ q_off, uint32_t nq, uint32_t max_len,
                                                          uint32_t n_shards, const uint32_t* __restrict__ kept_g, const long long* __restrict__ off_g,
-                                                         unsigned long long shard_stride, const int* __restrict__ head, const ShardPos* __restrict__ pos_local,
-                                                         char* __restrict__ out, uint32_t stride) {
+                                                         unsigned long long shard_stride, const unsigned long long* __restrict__ shard_base, const int* __restrict__ head,
+                                                         const ShardPos* __restrict__ pos_local, char* __restrict__ out, uint32_t stride) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     const uint32_t qb = q_off[q], L = q_off[q + 1] - qb;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void shard_prep_kernel(const uint64_t* __restr
                 if (kq[pos] == 0) continue;
                 unsigned long long before = 0;
                 for (uint32_t j = 0; j < pos; ++j) before += kq[j];
-                kp = kq[pos]; base = (unsigned long long)g * shard_stride + (unsigned long long)off_g[(size_t)g * nq + q] + before;
+                kp = kq[pos]; base = (shard_base ? shard_base[g] : (unsigned long long)g * shard_stride) + (unsigned long long)off_g[(size_t)g * nq + q] + before;   // (shard_base: segments of different lengths, back to back)
                 break;
             }
             if (kp) { h.sumw += L - pos; if (h.nruns < 8) h.run_start[h.nruns] = h.P; ++h.nruns; }
@@ -141,9 +141,97 @@ hipError_t launch_shard_lists_copy(hipStream_t st, const DeviceIndex& di, uint32
     return hipGetLastError();
 }
 hipError_t launch_shard_prep(hipStream_t st, const uint64_t* items_flat, const uint32_t* q_off, uint32_t nq, uint32_t max_len, uint32_t n_shards, const uint32_t* kept_g,
-                             const long long* off_g, unsigned long long shard_stride, const int* head, const ShardPos* pos_local, char* out, uint32_t stride) {
-    hipLaunchKernelGGL(shard_prep_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, items_flat, q_off, nq, max_len, n_shards, kept_g, off_g, shard_stride, head, pos_local,
+                             const long long* off_g, unsigned long long shard_stride, const int* head, const ShardPos* pos_local, char* out, uint32_t stride,
+                             const unsigned long long* shard_base) {
+    hipLaunchKernelGGL(shard_prep_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, items_flat, q_off, nq, max_len, n_shards, kept_g, off_g, shard_stride, shard_base, head, pos_local,
                        out, stride);
+    return hipGetLastError();
+}
+
+// ---- the shard group's own steps (srn_group.hip): what round 2 left to the host's tensor library ------------------------------------------
+
+// elementwise maximum of G int32 arrays (the all-reduce(max) of the heads when all shards live in one process)
+__global__ __launch_bounds__(256) void shard_max_kernel(int* __restrict__ dst, const int* __restrict__ src, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = max(dst[i], src[i]);
+}
+hipError_t launch_shard_max(hipStream_t st, int* dst, const int* src, size_t n) {
+    if (n) hipLaunchKernelGGL(shard_max_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dst, src, n);
+    return hipGetLastError();
+}
+
+// Where every query's kept prefixes start inside its shard's segment, for ALL shards at once, from the all-gathered kept counts: block g scans shard g's
+// queries (off_g[g][q] = number of entries of shard g before query q) and leaves the shard's total in tot[g] -- device memory, and a pinned word the
+// host reads after the one short synchronisation of a batch (the totals size the variable-length exchange).
+__global__ __launch_bounds__(1024) void shard_offsets_kernel(const uint32_t* __restrict__ kept_g, uint32_t nq, uint32_t max_len, long long* __restrict__ off_g,
+                                                             unsigned long long* __restrict__ tot_dev, unsigned long long* __restrict__ tot_host) {
+    __shared__ unsigned long long part[1024];
+    const uint32_t g = blockIdx.x, t = threadIdx.x;
+    const uint32_t per = (nq + 1023u) / 1024u, q0 = min(t * per, nq), q1 = min(q0 + per, nq);
+    const uint32_t* kq = kept_g + (size_t)g * nq * max_len;
+    unsigned long long sum = 0;
+    for (uint32_t q = q0; q < q1; ++q) for (uint32_t j = 0; j < max_len; ++j) sum += kq[(size_t)q * max_len + j];
+    part[t] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {   // (Hillis-Steele over 1024 partial sums: 10 steps)
+        const unsigned long long v = t >= d ? part[t - d] : 0ull;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    unsigned long long run = part[t] - sum;
+    for (uint32_t q = q0; q < q1; ++q) {
+        off_g[(size_t)g * nq + q] = (long long)run;
+        for (uint32_t j = 0; j < max_len; ++j) run += kq[(size_t)q * max_len + j];
+    }
+    if (t == 1023u) { tot_dev[g] = part[1023]; if (tot_host) tot_host[g] = part[1023]; }
+}
+hipError_t launch_shard_offsets(hipStream_t st, const uint32_t* kept_g, uint32_t nq, uint32_t max_len, uint32_t n_shards, long long* off_g, unsigned long long* tot_dev,
+                                unsigned long long* tot_host) {
+    hipLaunchKernelGGL(shard_offsets_kernel, dim3(n_shards), dim3(1024), 0, st, kept_g, nq, max_len, off_g, tot_dev, tot_host);
+    return hipGetLastError();
+}
+
+// The last step of a sharded batch: the G per-shard top-n lists of a query -> its global top-n by (score desc, item id asc).  An item's whole score lives on its
+// owner, so no item appears twice; every list is already in that order.  One wave per query; an entry's global rank is its own position plus, for every other
+// list, the number of that list's entries that come before it (binary search: <= 9 steps for n <= 512).  Replaces two argsorts and four gathers of the host's
+// tensor library (round 2: sharded.py merge_topn).  part = G blocks of block_bytes: ids [nq * n] u64 | scores [nq * n] f64 | counts [nq] u32.
+__global__ __launch_bounds__(256) void shard_merge_topn_kernel(const char* __restrict__ part, size_t block_bytes, uint32_t G, uint32_t nq, uint32_t n,
+                                                               uint64_t* __restrict__ out_ids, double* __restrict__ out_scores, uint32_t* __restrict__ out_counts) {
+    const uint32_t q = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (q >= nq) return;
+    auto ids_of = [&](uint32_t g) { return reinterpret_cast<const uint64_t*>(part + (size_t)g * block_bytes) + (size_t)q * n; };
+    auto sc_of = [&](uint32_t g) { return reinterpret_cast<const double*>(part + (size_t)g * block_bytes + (size_t)nq * n * 8) + (size_t)q * n; };
+    auto cnt_of = [&](uint32_t g) { return reinterpret_cast<const uint32_t*>(part + (size_t)g * block_bytes + (size_t)nq * n * 16)[q]; };
+    uint32_t total = 0; bool bad = false;
+    for (uint32_t g = 0; g < G; ++g) { const uint32_t c = cnt_of(g); if (c == 0xFFFFFFFFu) bad = true; else total += min(c, n); }
+    if (bad) { if (lane == 0u) out_counts[q] = 0xFFFFFFFFu; return; }   // (a query some shard could not serve: the caller sees the marker, as in the unsharded path)
+    const uint32_t keep = min(total, n);
+    for (uint32_t e = lane; e < G * n; e += 64u) {
+        const uint32_t g = e / n, j = e - g * n;
+        if (j >= min(cnt_of(g), n)) continue;
+        const double s = sc_of(g)[j]; const uint64_t id = ids_of(g)[j];
+        uint32_t rank = j;
+        for (uint32_t h = 0; h < G && rank < keep; ++h) {
+            if (h == g) continue;
+            const double* sh = sc_of(h); const uint64_t* ih = ids_of(h);
+            uint32_t lo = 0, hi = min(cnt_of(h), n);
+            while (lo < hi) {   // first entry of list h that does NOT come before (s, id)
+                const uint32_t mid = (lo + hi) >> 1;
+                const double sm = sh[mid];
+                const bool before = sm > s || (sm == s && ih[mid] < id);
+                if (before) lo = mid + 1; else hi = mid;
+            }
+            rank += lo;
+        }
+        if (rank < keep) { out_ids[(size_t)q * n + rank] = id; out_scores[(size_t)q * n + rank] = s; }
+    }
+    for (uint32_t r = keep + lane; r < n; r += 64u) { out_ids[(size_t)q * n + r] = 0ull; out_scores[(size_t)q * n + r] = 0.0; }   // the unused tail of a row reads as 0
+    if (lane == 0u) out_counts[q] = keep;
+}
+hipError_t launch_shard_merge_topn(hipStream_t st, const char* part, size_t block_bytes, uint32_t n_shards, uint32_t nq, uint32_t how_many, uint64_t* out_ids, double* out_scores,
+                                   uint32_t* out_counts) {
+    hipLaunchKernelGGL(shard_merge_topn_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, part, block_bytes, n_shards, nq, how_many, out_ids, out_scores, out_counts);
     return hipGetLastError();
 }
 

@@ -380,3 +380,132 @@ def predict_batch_sharded_local(shards, d_items_flat, d_q_off, nq, max_len, k, m
     c = [_stage_c(ix, d_items_flat, d_q_off, nq, max_len, k, m, how_many, enable_business_logic, b[0][0], b[0][1], minpos, stream) for ix in shards]
     return merge_topn(torch.stack([x[0].view(nq, how_many) for x in c]), torch.stack([x[1].view(nq, how_many) for x in c]),
                       torch.stack([x[2] for x in c]), how_many)
+
+
+# ---- the shard group: the whole sharded batch in ONE C call, collectives inside the library (srn_group.hip) ----------------------------------
+class ShardGroup:
+    """srn_shard_group_*: this rank's end of an item-sharded index.  Three transports, one pipeline:
+    ShardGroup.rccl(shard, rank, world)      RCCL called from inside the library (one process per GPU); the 256-byte id travels over torch.distributed
+    ShardGroup.over(shard, rank, world, comm)  the collectives as callbacks into a DistComm (gloo in the tests: two processes sharing one GPU)
+    ShardGroup.local(shards)                 all shards in this process on one device: collectives degenerate to kernels"""
+
+    def __init__(self, h, keep=()):
+        self._h, self._keep = h, keep
+
+    @classmethod
+    def rccl(cls, shard, rank, world, group=None):
+        import torch
+        import torch.distributed as dist
+        buf = (C.c_uint8 * capi.SHARD_GROUP_ID_BYTES)()
+        if rank == 0:
+            capi.check(capi.lib().srn_shard_group_unique_id(buf, capi.SHARD_GROUP_ID_BYTES))
+        if world > 1:   # the id reaches the other ranks over whatever control plane the host has: here the process group
+            t = torch.tensor(list(bytes(buf)), dtype=torch.uint8)
+            if dist.get_backend(group) == "nccl":
+                t = t.cuda()
+            dist.broadcast(t, src=0, group=group)
+            buf = (C.c_uint8 * capi.SHARD_GROUP_ID_BYTES)(*t.cpu().tolist())
+        h = C.c_void_p()
+        capi.check(capi.lib().srn_shard_group_create(shard._h, buf, int(rank), int(world), C.byref(h)))
+        return cls(h, (shard,))
+
+    @classmethod
+    def local(cls, shards):
+        arr = (C.c_void_p * len(shards))(*[s._h for s in shards])
+        h = C.c_void_p()
+        capi.check(capi.lib().srn_shard_group_create_local(arr, len(shards), C.byref(h)))
+        return cls(h, tuple(shards))
+
+    @classmethod
+    def over(cls, shard, rank, world, comm):
+        """Collectives through `comm` (a DistComm): device buffers are wrapped as torch tensors by address; with a host-staged backend (gloo) each
+        callback synchronises the stream, moves the bytes through host memory and back."""
+        import torch
+
+        dev = torch.device("cuda", shard.device)
+
+        def as_tensor(ptr, nbytes):
+            # a torch view of raw device memory: through the __cuda_array_interface__ protocol
+            class _Raw:
+                pass
+            raw = _Raw()
+            raw.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+            return torch.as_tensor(raw, device=dev)
+
+        def sync(stream):
+            torch.cuda.synchronize(dev)   # (test transport: everything enqueued so far is done before the bytes leave)
+
+        def arm(user, channel, d_buf, count, stream):
+            try:
+                sync(stream)
+                t = as_tensor(d_buf, count * 4).view(torch.int32)
+                comm.all_reduce_max(t)
+                torch.cuda.synchronize(dev)
+                return 0
+            except Exception:   # pragma: no cover
+                import traceback; traceback.print_exc()
+                return capi.SRN_EHIP
+
+        def ag(user, channel, d_buf, block_bytes, stream):
+            try:
+                sync(stream)
+                t = as_tensor(d_buf, block_bytes * world).view(world, block_bytes)
+                g = comm.all_gather(t[rank].clone())
+                t.copy_(g.view(world, block_bytes))
+                torch.cuda.synchronize(dev)
+                return 0
+            except Exception:   # pragma: no cover
+                import traceback; traceback.print_exc()
+                return capi.SRN_EHIP
+
+        def agv(user, channel, d_buf, byte_off, byte_cnt, stream):
+            try:
+                sync(stream)
+                offs = [int(byte_off[i]) for i in range(world)]; cnts = [int(byte_cnt[i]) for i in range(world)]
+                width = max(1, max(cnts))
+                mine = torch.zeros(width, dtype=torch.uint8, device=dev)
+                if cnts[rank]:
+                    mine[:cnts[rank]] = as_tensor(d_buf + offs[rank], cnts[rank])
+                g = comm.all_gather(mine).view(world, width)
+                for r in range(world):
+                    if r != rank and cnts[r]:
+                        as_tensor(d_buf + offs[r], cnts[r]).copy_(g[r, :cnts[r]])
+                torch.cuda.synchronize(dev)
+                return 0
+            except Exception:   # pragma: no cover
+                import traceback; traceback.print_exc()
+                return capi.SRN_EHIP
+
+        cbs = (capi.ALL_REDUCE_MAX_FN(arm), capi.ALL_GATHER_FN(ag), capi.ALL_GATHER_V_FN(agv))
+        sc = capi.ShardComm(None, *cbs)
+        h = C.c_void_p()
+        capi.check(capi.lib().srn_shard_group_create_with_comm(shard._h, int(rank), int(world), C.byref(sc), C.byref(h)))
+        return cls(h, (shard, cbs, sc, comm))
+
+    def predict_batch(self, d_items_flat, d_q_off, nq, max_len, k, m, how_many, enable_business_logic=False, stream=None, resident=False, out=None):
+        """d_items_flat (int64 view of the u64 ids) / d_q_off (int32): torch tensors on the group's GPU holding the SAME batch on every rank.
+        -> (ids int64 [nq, n], scores f64 [nq, n], counts int32 [nq]) torch tensors, identical on every rank; asynchronous on `stream`."""
+        import torch
+        dev = d_items_flat.device
+        if stream is None:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        if out is None:
+            out = (torch.empty((nq, how_many), dtype=torch.int64, device=dev), torch.empty((nq, how_many), dtype=torch.float64, device=dev),
+                   torch.empty(nq, dtype=torch.int32, device=dev))
+        flags = (capi.FLAG_BUSINESS_LOGIC if enable_business_logic else 0) | (capi.FLAG_INPUTS_RESIDENT if resident else 0)
+        capi.check(capi.lib().srn_shard_group_predict_batch(self._h, _ptr(d_items_flat), _ptr(d_q_off), int(nq), int(max_len), int(k), int(m), int(how_many), flags,
+                                                            _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), C.c_void_p(stream)))
+        return out
+
+    @property
+    def stats(self):
+        st = capi.ShardGroupStats()
+        capi.check(capi.lib().srn_shard_group_stats(self._h, C.byref(st)))
+        return {n: getattr(st, n) for n, _ in capi.ShardGroupStats._fields_}
+
+    def close(self):
+        if getattr(self, "_h", None) and capi is not None and getattr(capi, "lib", None) is not None:
+            capi.lib().srn_shard_group_free(self._h)
+            self._h = None
+
+    __del__ = close

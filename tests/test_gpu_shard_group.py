@@ -1,0 +1,216 @@
+"""The shard group (srn_shard_group_*, srn_group.hip): the whole item-sharded batch in ONE C call, collectives inside the library.
+Checked against the CANONICAL ORACLE directly (the sharded tests used to compare HIP-sharded with HIP-unsharded only),
+against the unsharded HIP path bit for bit, and over all three transports: in-process (1, 2, 3, 5 shards on one GPU), RCCL (a 1-rank
+communicator is what one GPU allows: every RCCL call of a multi-rank run is made), and application callbacks (two processes over gloo
+sharing the GPU: the rank-major control flow of a real multi-GPU run)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from helpers import flatten, random_queries, small_dataset
+
+pytestmark = pytest.mark.gpu
+SCORE_RTOL = 1e-12
+
+
+def _to_dev(flat, qoff):
+    import torch
+    dev = torch.device("cuda:0")
+    return torch.from_numpy(flat.view(np.int64).copy()).to(dev), torch.from_numpy(qoff.view(np.int32).copy()).to(dev)
+
+
+def _np(res):
+    import torch
+    torch.cuda.synchronize()
+    return res[0].cpu().numpy().view(np.uint64), res[1].cpu().numpy(), res[2].cpu().numpy().view(np.uint32)
+
+
+def _check_oracle(res, ref, n):
+    ids, sc, cnt = res
+    assert np.array_equal(cnt, ref["counts"]), "result counts differ from the oracle"
+    mask = np.arange(n)[None, :] < ref["counts"][:, None].astype(np.int64)
+    assert np.array_equal(ids[mask], ref["ids"][mask]), "ranked item lists differ from the oracle"
+    np.testing.assert_allclose(sc[mask], ref["scores"][mask], rtol=SCORE_RTOL, atol=0)
+    assert not ids[~mask].any() and not sc[~mask].any(), "the unused tail of a row reads as 0"
+
+
+@pytest.mark.parametrize("n_shards", [1, 2, 3, 5])
+def test_local_group_matches_the_oracle_and_the_unsharded_path(n_shards):
+    import serenade_amd as sa
+    from serenade_amd import sharded
+    from oracle import oracle as O
+    off, items, ts, ids = small_dataset(81, n_sessions=6000, n_items=500, max_len=80)          # rows of up to 80 items: fragments of every length
+    qs = random_queries(23, ids, 700, max_len=8, unknown_rate=0.03, dup_rate=0.1)
+    flat, qoff = flatten(qs)
+    d_flat, d_off = _to_dev(flat, qoff)
+    full = sa.VMISIndex.from_sessions(off, items, ts, 400, 80, 1.0)
+    oix = O.OracleIndex(off, items, ts, 400, 80, 1.0)
+    shards = [sharded.ShardedVMISIndex.from_full(full, g, n_shards) for g in range(n_shards)]
+    grp = sharded.ShardGroup.local(shards)
+    for (k, m, n) in [(100, 400, 21), (500, 300, 21), (30, 60, 5), (200, 400, 100)]:
+        ref = oix.predict_batch("canonical", flat, qoff, k, m, n, False, threads=4)
+        got = _np(grp.predict_batch(d_flat, d_off, len(qs), 8, k, m, n))
+        _check_oracle(got, ref, n)                                                             # the sharded path against the ORACLE
+        u = sa.predict_batch(full, (flat, qoff), k, m, n, False)
+        assert np.array_equal(got[0], u[0]) and np.array_equal(got[1], u[1]) and np.array_equal(got[2], u[2])     # and bit-identical to the unsharded HIP path
+    st = grp.stats
+    assert st["n_shards"] == n_shards and st["batches"] == 4 and st["queries"] == 4 * len(qs) and st["transport"] == 0
+    assert st["bytes_lists"] > 0 and st["bytes_lists_max_rank"] * n_shards >= st["bytes_lists"]
+    # two batches back to back on one stream (the group alternates two buffer slots) and the reused-output form
+    out = grp.predict_batch(d_flat, d_off, len(qs), 8, 100, 400, 21)
+    out2 = grp.predict_batch(d_flat, d_off, len(qs), 8, 100, 400, 21, out=out)
+    _check_oracle(_np(out2), oix.predict_batch("canonical", flat, qoff, 100, 400, 21, False, threads=4), 21)
+
+
+def test_local_group_business_rules_against_the_oracle():
+    """Real product flags incl. None: the current item's attribute byte lives on its owner shard and reaches the others with the first all-reduce."""
+    import serenade_amd as sa
+    from serenade_amd import sharded, synth, capi
+    from oracle import oracle as O
+    inter, n_items, k, m, idfw = synth.CONFIGS["tiny"]
+    off, items, ts = synth.training_sessions(inter, n_items)
+    flat, qoff = synth.queries(1500, n_items)
+    d_flat, d_off = _to_dev(flat, qoff)
+    rng = np.random.default_rng(46)
+    known = np.unique(items)
+    flags = rng.choice(np.array([0, 1, 2, 3, 0xFF], np.uint8), size=len(known), p=[0.15, 0.05, 0.5, 0.2, 0.1])
+    full = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw)
+    full.set_attributes(known, flags)
+    oix = O.OracleIndex(off, items, ts, m, 34, idfw, fast=True)
+    oix.set_attributes(known, flags)
+    shards = [sharded.ShardedVMISIndex.from_full(full, g, 4) for g in range(4)]
+    for s in shards:
+        capi.check(capi.lib().srn_index_set_attributes(s._h, capi.ptr(capi.as_u64(known)), capi.ptr(flags), len(known)))
+    grp = sharded.ShardGroup.local(shards)
+    nq = len(qoff) - 1
+    for business in (True, False):
+        ref = oix.predict_batch("canonical", flat, qoff, k, m, 21, business, threads=4)
+        _check_oracle(_np(grp.predict_batch(d_flat, d_off, nq, 4, k, m, 21, business)), ref, 21)
+
+
+def test_group_rejects_misuse():
+    import ctypes as C
+    import serenade_amd as sa
+    from serenade_amd import sharded, capi
+    off, items, ts, ids = small_dataset(82, n_sessions=800, n_items=100)
+    full = sa.VMISIndex.from_sessions(off, items, ts, 100, 12, 1.0)
+    shards = [sharded.ShardedVMISIndex.from_full(full, g, 2) for g in range(2)]
+    with pytest.raises(capi.SerenadeError):          # shards out of order
+        sharded.ShardGroup.local([shards[1], shards[0]])
+    with pytest.raises(capi.SerenadeError):          # an unsharded index is not shard 0 of 2
+        h = C.c_void_p(); arr = (C.c_void_p * 2)(full._h, shards[1]._h)
+        capi.check(capi.lib().srn_shard_group_create_local(arr, 2, C.byref(h)))
+    grp = sharded.ShardGroup.local(shards)
+    qs = random_queries(3, ids, 16, max_len=4)
+    flat, qoff = flatten(qs)
+    d_flat, d_off = _to_dev(flat, qoff)
+    with pytest.raises(capi.SerenadeError) as e:     # sessions of > 8 items: the lists pipeline does not serve them
+        grp.predict_batch(d_flat, d_off, len(qs), 12, 20, 100, 21)
+    assert e.value.code == capi.SRN_EINVAL
+    with pytest.raises(capi.SerenadeError) as e:
+        grp.predict_batch(d_flat, d_off, len(qs), 4, 0, 100, 21)
+    assert e.value.code == capi.SRN_EINVAL
+    buf = (C.c_uint8 * 16)()
+    assert capi.lib().srn_shard_group_unique_id(buf, 16) == capi.SRN_EINVAL     # id buffer too small
+
+
+def _rccl_worker(q):
+    try:
+        import torch
+        import serenade_amd as sa
+        from serenade_amd import sharded
+        torch.cuda.set_device(0)
+        off, items, ts, ids = small_dataset(83, n_sessions=4000, n_items=400, max_len=40)
+        qs = random_queries(29, ids, 500, max_len=6)
+        flat, qoff = flatten(qs)
+        d_flat, d_off = _to_dev(flat, qoff)
+        full = sa.VMISIndex.from_sessions(off, items, ts, 300, 40, 1.0)
+        ix = sharded.ShardedVMISIndex.from_full(full, 0, 1)
+        grp = sharded.ShardGroup.rccl(ix, 0, 1)          # ncclGetUniqueId + 2 x ncclCommInitRank inside the library
+        res = []
+        for rep in range(3):                             # three batches: both buffer slots, the overlapped exchange stream, resident inputs
+            res.append(_np(grp.predict_batch(d_flat, d_off, len(qs), 6, 80, 300, 21, resident=(rep > 0))))
+        st = grp.stats
+        u = sa.predict_batch(full, (flat, qoff), 80, 300, 21, False)
+        q.put((res, st, u))
+        grp.close()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put("error: %r\n%s" % (e, traceback.format_exc()))
+
+
+def test_single_rank_rccl_group_through_the_c_abi():
+    """RCCL called from C++ (dlopen'd librccl): ncclCommInitRank on two communicators, ncclAllReduce(max), ncclAllGather (in place), the grouped
+    ncclSend / ncclRecv exchange (no peers at world 1) -- every call a multi-rank run makes, on the 1-rank communicators one GPU allows; results
+    bit-identical to the unsharded path, over both buffer slots and with the exchange on the group's own stream."""
+    mp = pytest.importorskip("torch.multiprocessing")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(q,))
+    p.start()
+    out = q.get(timeout=600)
+    p.join(timeout=120)
+    assert not isinstance(out, str), out
+    res, st, u = out
+    assert st["transport"] == 1 and st["overlapped"] == 1 and st["batches"] == 3
+    for r in res:
+        assert np.array_equal(r[0], u[0]) and np.array_equal(r[1], u[1]) and np.array_equal(r[2], u[2])
+
+
+def _cb_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    try:
+        import torch
+        import torch.distributed as dist
+        import serenade_amd as sa
+        from serenade_amd import distributed as D
+        from serenade_amd import sharded
+        D.init("gloo")
+        off, items, ts, ids = small_dataset(84, n_sessions=5000, n_items=400, max_len=40)
+        qs = random_queries(31, ids, 400, max_len=7, unknown_rate=0.02)
+        flat, qoff = flatten(qs)
+        d_flat, d_off = _to_dev(flat, qoff)
+        full = sa.VMISIndex.from_sessions(off, items, ts, 300, 40, 1.0)
+        ix = sharded.ShardedVMISIndex.from_full(full, rank, world)
+        grp = sharded.ShardGroup.over(ix, rank, world, sharded.DistComm())
+        res = [_np(grp.predict_batch(d_flat, d_off, len(qs), 7, k, m, n)) for (k, m, n) in [(80, 300, 21), (400, 200, 50)]]
+        st = grp.stats
+        q.put((rank, res, st))
+        D.barrier()
+        grp.close()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "error: %r\n%s" % (e, traceback.format_exc()), None))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_rank_group_over_application_callbacks(world):
+    """Two / three PROCESSES, one shard each (all on the test box's one GPU), the group's collectives as callbacks into torch.distributed (gloo): the
+    rank-major control flow of a real multi-GPU run -- in-place all-gather of the counts, offsets from every rank's counts, the variable-length
+    list exchange, the merge of the per-shard top-n -- against the oracle."""
+    mp = pytest.importorskip("torch.multiprocessing")
+    from oracle import oracle as O
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cb_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=900) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+    off, items, ts, ids = small_dataset(84, n_sessions=5000, n_items=400, max_len=40)
+    qs = random_queries(31, ids, 400, max_len=7, unknown_rate=0.02)
+    flat, qoff = flatten(qs)
+    oix = O.OracleIndex(off, items, ts, 300, 40, 1.0)
+    refs = [oix.predict_batch("canonical", flat, qoff, k, m, n, False, threads=4) for (k, m, n) in [(80, 300, 21), (400, 200, 50)]]
+    for rank, res, st in out:
+        assert not isinstance(res, str), res
+        assert st["transport"] == 2 and st["n_shards"] == world
+        for r, ref, n in zip(res, refs, (21, 50)):
+            _check_oracle(r, ref, n)

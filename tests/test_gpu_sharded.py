@@ -158,7 +158,9 @@ def test_lists_entry_points_reject_misuse():
                                       C.c_void_p(offs.data_ptr()), 64, C.c_void_p(flat_l.data_ptr()), C.c_void_p(head.data_ptr()), C.c_void_p(pos.data_ptr()), C.c_void_p(rec.data_ptr()),
                                       C.c_void_p(out.data_ptr()), C.c_void_p(sc.data_ptr()), C.c_void_p(cnt.data_ptr()), None)
     assert L.srn_shard_lists_predict(*args(4, 0)) == capi.SRN_EINVAL                       # zero shards
-    assert L.srn_shard_lists_predict(*args(12, 1)) == capi.SRN_EINVAL                      # sessions of > 8 items: no position sets, the three-stage pipeline serves them
+    assert L.srn_shard_lists_predict(*args(4, 1)) == capi.SRN_EINVAL                       # not the number of shards this index was cut into
+    assert b"n_shards" in L.srn_last_error()
+    assert L.srn_shard_lists_predict(*args(12, 2)) == capi.SRN_EINVAL                      # sessions of > 8 items: no position sets, the three-stage pipeline serves them
     assert b"three-stage" in L.srn_last_error()
     torch.cuda.synchronize()
 
