@@ -1,24 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- VMIS-kNN predict_next throughput on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path (libserenade_hip.so: srn_predict_batch_device) over one batch of synthetic evolving
-sessions, with the index and the query / result buffers already resident in HBM.  At N=1 the workload is BASELINE.json
-configs[2] -- the 60 M-interaction / 1.76 M-item synthetic index the metric's target is quoted on (k=1500, m=2500,
-idf_weighting=2); a batch is 2^20 evolving sessions, so that the 20 steps the driver asks for time ~1 s of GPU work.  With N>1
-(launched by torch.distributed.run, one rank per GPU) every rank holds the full index and serves its own slice of the query
-stream: queries are independent, so the path shards by query with no data-path collective (weak scaling, DESIGN.md "Multi-GPU");
-`--mode item-sharded` runs the north star's capacity mode instead (index split by item, three RCCL collectives per batch).
+A "step" is one pass of the hot path (libserenade_hip.so) over one batch of synthetic evolving sessions, with the index and the
+query / result buffers already resident in HBM.  The workload is BASELINE.json configs[2] -- the 60 M-interaction / 1.76 M-item
+synthetic index the metric's target is quoted on (k=1500, m=2500, idf_weighting=2).
+
+  N = 1   srn_predict_batch_device on the whole index; a batch is 2^20 evolving sessions (20 steps time ~0.5 s of GPU work).
+  N > 1   one process per GPU (launched by torch.distributed.run -- or by this script itself when started bare with --gpus N), and
+          BOTH multi-GPU modes in one line:
+            value      the north star's partitioning: the index ITEM-SHARDED over the N GPUs (owner = hash of the item id), every rank
+                       sees the whole batch, srn_shard_group_predict_batch exchanges the posting lists and merges the per-shard top-n
+                       over RCCL (called from inside the library); "scaling": "strong"
+            replicas   the ceiling: every GPU holds the whole index and serves its own slice of the query stream, no data-path
+                       collective (how the reference scales: replicas + session affinity, src/endpoints/recommend_resource.rs:17-19)
+          --mode replicas | item-sharded runs one of them alone (item-sharded works at N = 1 too: the group's overhead over the fused path).
 
 Order of events (no timing counts before parity):
-  1. PARITY GATE  the first `--parity` queries of batch 0 through the product call, against the canonical CPU oracle: item ids and
-                  order exact, scores to 1e-12 relative; a mismatch aborts the run with exit code 1
+  1. PARITY GATE  the first `--parity` queries of batch 0 through the product call of every mode that is timed, against the canonical
+                  CPU oracle: item ids and order exact, scores to 1e-12 relative; a mismatch aborts the run with exit code 1
   2. warm-up, then K timed steps between barrier + synchronize on both sides, max over ranks
-  3. (N=1) batch-size sweep {1, 64, 4096, 65536, 2^20}: queries/s and p90 latency, device-resident and host-inclusive
+  3. (N=1) batch-size sweep {1, 16, 64, 256, 4096, 65536, 2^20}: queries/s and p90 latency, device-resident and host-inclusive
   4. (N=1) CPU baseline: the oracle's literal restatement of the reference loops on the host cores, bounded sample
 
 Prints ONE JSON line on rank 0:
-  value         whole-job predict_next queries/s = N * K * batch / max-over-ranks wall time of the K timed steps
-  roofline      dominant kernel (vmis_fast_kernel): algorithmic bytes of the queries it served / its HIP-event duration
+  value         whole-job predict_next queries/s of the K timed steps (max-over-ranks wall time)
+  roofline      N=1: dominant kernel (vmis_fast_kernel): algorithmic bytes of the queries it served / its HIP-event duration, `frac` against
+                8 TB/s and `frac_counter` = measured HBM traffic / time / 8 TB/s; N>1: the item-sharded step against N x 8 TB/s
   cpu_baseline  see 4.
 """
 import argparse
@@ -63,11 +70,12 @@ def main():
     ap.add_argument("--config", default="cfg3", help="tiny | cfg2 | cfg3 | cfg4 (synth.CONFIGS)")
     ap.add_argument("--batch", type=int, default=1 << 20, help="evolving sessions per step and per GPU")
     ap.add_argument("--pool", type=int, default=2, help="distinct query batches cycled through")
-    ap.add_argument("--mode", default="replicas", choices=["replicas", "item-sharded"],
-                    help="replicas: every GPU holds the index and serves its own queries (default, no data-path collective); "
-                         "item-sharded: the north-star capacity mode, index split by item over the GPUs, 3 RCCL collectives per batch")
-    ap.add_argument("--shard-pipeline", default="auto", choices=["auto", "lists", "stages"],
-                    help="item-sharded mode: exchange the posting lists and run the unsharded kernels (lists), or the three-stage pipeline (stages)")
+    ap.add_argument("--mode", default="auto", choices=["auto", "replicas", "item-sharded"],
+                    help="auto: N=1 the whole index on the GPU; N>1 BOTH modes in one line (value = item-sharded over RCCL, replicas = the ceiling). "
+                         "replicas: every GPU holds the index and serves its own queries (no data-path collective); "
+                         "item-sharded: the north star's partitioning, index split by item over the GPUs, srn_shard_group_predict_batch")
+    ap.add_argument("--shard-batch", type=int, default=1 << 18, help="evolving sessions per item-sharded step (every rank sees the whole batch)")
+    ap.add_argument("--selftest-launch", action="store_true", help="CPU check of the launcher and the control plane (gloo): no GPU, no timing")
     ap.add_argument("--builder", default="gpu", choices=["gpu", "host"], help="index construction: rocPRIM sorts on the GPU, or the host builder (same bytes)")
     ap.add_argument("--parity", type=int, default=2048, help="queries of batch 0 checked against the canonical oracle before anything is timed (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -76,14 +84,39 @@ def main():
     ap.add_argument("--traffic-file", default=None, help="profiles/*_traffic_<config>.json from the PMC passes (default: newest match)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started bare (`python bench.py --gpus N ...`): launch the N ranks ourselves -- one process per GPU under torch.distributed.run, rendezvous on
+        # 127.0.0.1 -- and hand their exit code back; rank 0 prints the one JSON line
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus), file=sys.stderr)
-            sys.exit(2)
-        args.gpus = world
+    args.gpus = world
+    if args.selftest_launch:
+        # the launcher + control plane on CPU: process group over gloo, barrier, the max-over-ranks reduction of the timing, the broadcast that carries
+        # the shard group's 256-byte id to the other ranks
+        import torch
+        import torch.distributed as dist
+        from serenade_amd import distributed as D
+        D.init("gloo")
+        D.barrier()
+        mx = D.max_over_ranks(1.0 + rank)
+        t = torch.tensor([7 * (i + 1) % 251 for i in range(256)] if rank == 0 else [0] * 256, dtype=torch.uint8)
+        if world > 1:
+            dist.broadcast(t, src=0)
+        ok = mx == float(world) and int(t.sum()) == sum(7 * (i + 1) % 251 for i in range(256))
+        if rank == 0:
+            print(json.dumps({"selftest_launch": True, "world": world, "max_over_ranks": mx, "id_broadcast_ok": bool(ok)}))
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(0 if ok else 1)
 
     import torch
     import torch.distributed as dist
@@ -100,180 +133,202 @@ def main():
 
     inter, n_items, k, m, idfw = synth.CONFIGS[args.config]
     how_many, last_items = synth.HOW_MANY, synth.LAST_ITEMS
-    sharded_mode = args.mode == "item-sharded"
-    if sharded_mode and args.batch == 1 << 20:
-        args.batch = 16384 if args.shard_pipeline == "stages" else 1 << 18          # the exchange buffers are per query and shard
+    mode = args.mode if args.mode != "auto" else ("replicas" if world == 1 else "both")
+    do_rep, do_shard = mode in ("replicas", "both"), mode in ("item-sharded", "both")
     t0 = time.time()
     off, items, ts = synth.training_sessions(inter, n_items)
     t_gen = time.time() - t0
     t0 = time.time()
-    if sharded_mode:
-        from serenade_amd import sharded as SH
-        index = SH.ShardedVMISIndex(off, items, ts, m, 34, idfw, rank, world, device=local_rank)
-        comm = SH.DistComm() if world > 1 else SH.SoloComm()
-    else:
-        index = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw, device=local_rank, builder=args.builder)
+    # the whole index: what the replicas serve from, and (rank 0) where the per-query counters of the roofline come from
+    index = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw, device=local_rank, builder=args.builder) if (do_rep or rank == 0) else None
     t_build = time.time() - t0
-    info = index.info
-
-    # ---- this rank's slice of the query stream: `pool` distinct batches of `batch` evolving sessions ----
-    B = args.batch
-    need = B * args.pool
-    n_sess = max(1024, int(need / 3.2) + 4096)
-    while True:
-        # replicas: every rank draws its own slice of the query stream; item-sharded: all ranks see the same batch
-        q_items, q_off = synth.queries(n_sess, n_items, seed=synth.SEED + 7919 * ((0 if sharded_mode else rank) + 1), max_items=last_items)
-        if len(q_off) - 1 >= need:
-            break
-        n_sess = int(n_sess * 1.5)
-    batches = []
-    for b in range(args.pool):
-        lo, hi = b * B, (b + 1) * B
-        fo = q_off[lo:hi + 1].astype(np.int64)
-        flat = q_items[fo[0]:fo[-1]]
-        qo = (fo - fo[0]).astype(np.uint32)
-        batches.append((torch.from_numpy(flat.view(np.int64).copy()).to(dev), torch.from_numpy(qo.view(np.int32).copy()).to(dev), flat, qo))
-    out_ids = torch.zeros(B * how_many, dtype=torch.int64, device=dev)
-    out_sc = torch.zeros(B * how_many, dtype=torch.float64, device=dev)
-    out_cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    shard = group = None
+    t_shard = None
+    if do_shard:
+        from serenade_amd import sharded as SH
+        t0 = time.time()
+        # every rank cuts ITS shard out of one unsharded index (built on its GPU or -- a production start -- loaded from one file: srn_index_load_shard)
+        shard = SH.ShardedVMISIndex.from_full(index, rank, world, device=local_rank) if index is not None else \
+            SH.ShardedVMISIndex(off, items, ts, m, 34, idfw, rank, world, device=local_rank)
+        group = SH.ShardGroup.rccl(shard, rank, world)      # RCCL communicators created inside the library; the id travels over the process group
+        t_shard = time.time() - t0
+    info = (index if index is not None else shard).info
     stream = torch.cuda.current_stream()
-    _, _, flat0, qo0 = batches[0]
+    common = {"metric": "predict_next queries/sec", "unit": "queries/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+              "higher_is_better": True, "vs_baseline": None, "dtype": "u32 ids / i32 accumulators / f64 scores", "data": "synthetic"}
 
-    # item-sharded mode keeps TWO batches in flight on two streams: the lists pipeline synchronises the host once per batch (the size of the
-    # exchange buffer), and the other stream's kernels keep the GPU busy meanwhile
-    lanes = [torch.cuda.Stream(), torch.cuda.Stream()] if sharded_mode else None
+    def draw_batches(B, pool, seed_rank):
+        need = B * pool
+        n_sess = max(1024, int(need / 3.2) + 4096)
+        while True:
+            q_items, q_off = synth.queries(n_sess, n_items, seed=synth.SEED + 7919 * (seed_rank + 1), max_items=last_items)
+            if len(q_off) - 1 >= need:
+                break
+            n_sess = int(n_sess * 1.5)
+        out = []
+        for b in range(pool):
+            lo, hi = b * B, (b + 1) * B
+            fo = q_off[lo:hi + 1].astype(np.int64)
+            flat = q_items[fo[0]:fo[-1]]
+            qo = (fo - fo[0]).astype(np.uint32)
+            out.append((torch.from_numpy(flat.view(np.int64).copy()).to(dev), torch.from_numpy(qo.view(np.int32).copy()).to(dev), flat, qo))
+        return out
 
-    def step(i, nq=None):
-        d_flat, d_off, _, _ = batches[i % args.pool]
-        if sharded_mode:
-            with torch.cuda.stream(lanes[i % 2]):
-                res = SH.predict_batch_sharded(index, comm, d_flat, d_off, B, last_items, k, m, how_many, False, lanes[i % 2].cuda_stream, args.shard_pipeline)
-                out_cnt.copy_(res[2])
-        else:
-            sa.predict_batch_device(index, d_flat.data_ptr(), d_off.data_ptr(), B if nq is None else nq, last_items, k, m, how_many, False,
-                                    out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), stream.cuda_stream)
+    oracle_box = {"oix": None, "t_build": None}
 
-    # ---- 1. parity gate (rank 0; the other ranks wait at the barrier below) --------------------------------------------
-    parity_checked, oix, t_obuild = 0, None, None
-    if rank == 0 and args.parity > 0:
-        from oracle import oracle as O   # the CPU oracle is the checker here (and the timed baseline at the end), never the thing measured
-        t1 = time.time()
-        oix = O.OracleIndex(off, items, ts, m, 34, idfw, fast=True)
-        t_obuild = time.time() - t1
-        n_par = int(min(B, args.parity))
-        pf, po = flat0[:qo0[n_par]], qo0[:n_par + 1]
-        ref = oix.predict_batch("canonical", pf, po, k, m, how_many, False, threads=usable_cores())
-        if sharded_mode:
-            res = SH.predict_batch_sharded(index, comm, batches[0][0], batches[0][1], B, last_items, k, m, how_many, False, stream.cuda_stream, args.shard_pipeline)
-            torch.cuda.synchronize()
-            g_ids = res[0].cpu().numpy().view(np.uint64).reshape(B, how_many)[:n_par]
-            g_sc = res[1].cpu().numpy().reshape(B, how_many)[:n_par]
-            g_cnt = res[2].cpu().numpy().view(np.uint32)[:n_par]
-        else:
-            step(0, n_par)
-            torch.cuda.synchronize()
-            g_ids = out_ids.cpu().numpy().view(np.uint64).reshape(B, how_many)[:n_par]
-            g_sc = out_sc.cpu().numpy().reshape(B, how_many)[:n_par]
-            g_cnt = out_cnt.cpu().numpy().view(np.uint32)[:n_par]
+    def oracle_index():
+        if oracle_box["oix"] is None:
+            from oracle import oracle as O   # the CPU oracle is the checker here (and the timed baseline at the end), never the thing measured
+            t1 = time.time()
+            oracle_box["oix"] = O.OracleIndex(off, items, ts, m, 34, idfw, fast=True)
+            oracle_box["t_build"] = time.time() - t1
+        return oracle_box["oix"]
+
+    def gate(g_ids, g_sc, g_cnt, flat0, qo0, n_par, what):
+        ref = oracle_index().predict_batch("canonical", flat0[:qo0[n_par]], qo0[:n_par + 1], k, m, how_many, False, threads=usable_cores())
         ok = np.array_equal(g_cnt, ref["counts"])
         if ok:
             mask = np.arange(how_many)[None, :] < ref["counts"][:, None].astype(np.int64)
             ok = np.array_equal(g_ids[mask], ref["ids"][mask]) and np.allclose(g_sc[mask], ref["scores"][mask], rtol=SCORE_RTOL, atol=0)
         if not ok:
-            print("bench.py: PARITY GATE FAILED on the first %d queries of batch 0 -- nothing is timed" % n_par, file=sys.stderr)
+            print("bench.py: PARITY GATE FAILED (%s) on the first %d queries of batch 0 -- nothing is timed" % (what, n_par), file=sys.stderr)
             os._exit(1)
-        parity_checked = n_par
-    elif rank != 0 and sharded_mode and args.parity > 0:
-        SH.predict_batch_sharded(index, comm, batches[0][0], batches[0][1], B, last_items, k, m, how_many, False, stream.cuda_stream, args.shard_pipeline)   # rank 0's check is a collective call
+        return n_par
 
-    barrier = D.barrier
-    if sharded_mode:   # prime both lanes' allocator pools and workspaces (setup, not one of the W warm-up steps)
-        step(0); step(1)
+    def timed(step_fn):
+        for i in range(args.warmup):
+            step_fn(i)
         torch.cuda.synchronize()
-    else:              # size the stream's workspace up front (srn_index_reserve): no call of the run allocates, warm-up or not
-        sa.reserve(index, B, last_items, k, m, how_many, False, stream.cuda_stream)
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record(stream)
-        step(args.warmup + i)
-        ev[i][1].record(stream)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = D.max_over_ranks(elapsed, dev)
-    step_ms = np.array([a.elapsed_time(b) for a, b in ev])
+        D.barrier()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            ev[i][0].record(stream)
+            step_fn(args.warmup + i)
+            ev[i][1].record(stream)
+        torch.cuda.synchronize()
+        D.barrier()
+        elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+        return elapsed, np.array([a.elapsed_time(b) for a, b in ev])
+
+    # =========================== item-sharded index over the N GPUs (srn_shard_group_*, RCCL inside the library) ===========================
+    shard_line = None
+    if do_shard:
+        Bs = args.shard_batch
+        sbatches = draw_batches(Bs, args.pool, 0)                     # every rank sees the SAME batches
+        s_out = (torch.empty((Bs, how_many), dtype=torch.int64, device=dev), torch.empty((Bs, how_many), dtype=torch.float64, device=dev),
+                 torch.empty(Bs, dtype=torch.int32, device=dev))
+
+        def sstep(i):
+            d_flat, d_off, _, _ = sbatches[i % args.pool]
+            group.predict_batch(d_flat, d_off, Bs, last_items, k, m, how_many, False, stream.cuda_stream, resident=True, out=s_out)
+
+        s_parity = 0
+        if args.parity > 0:                                           # (a collective call: every rank runs it, rank 0 checks)
+            sstep(0)
+            torch.cuda.synchronize()
+            if rank == 0:
+                n_par = int(min(Bs, args.parity))
+                s_parity = gate(s_out[0].cpu().numpy().view(np.uint64)[:n_par], s_out[1].cpu().numpy()[:n_par], s_out[2].cpu().numpy().view(np.uint32)[:n_par],
+                                sbatches[0][2], sbatches[0][3], n_par, "item-sharded")
+        sstep(0); sstep(1)                                            # both buffer slots sized (setup, not one of the W warm-up steps)
+        torch.cuda.synchronize()
+        st0 = group.stats
+        s_elapsed, s_step_ms = timed(sstep)
+        st1 = group.stats
+        s_served = int((s_out[2].cpu().numpy().view(np.uint32) != 0xFFFFFFFF).sum())
+        if rank == 0:
+            nb, nqs = st1["batches"] - st0["batches"], max(1, st1["queries"] - st0["queries"])
+            per_q = {kk: (st1[kk] - st0[kk]) / nqs for kk in ("bytes_head", "bytes_counts", "bytes_lists", "bytes_results", "bytes_lists_max_rank")}
+            nstat = min(Bs, 8192)
+            dbg = sa.predict_batch_debug(index, (sbatches[0][2][:sbatches[0][3][nstat]], sbatches[0][3][:nstat + 1]), k, m, how_many, False, neighbours=False)
+            bq_mean = float(algorithmic_bytes(dbg["stats"]).mean())
+            ms_step = s_elapsed / args.steps * 1e3
+            ach = bq_mean * Bs / (ms_step * 1e-3) / 1e9
+            shard_line = dict(common)
+            shard_line.update({
+                "value": args.steps * Bs / s_elapsed, "ms_per_step": ms_step, "scaling": "strong",
+                "config": {"workload": ("BASELINE configs[2]: synthetic %d interactions / %d items, k=%d m=%d idf_weighting=%g last_items=%d how_many=%d" % (inter, n_items, k, m, idfw, last_items, how_many)
+                                        if args.config == "cfg3" else "synth.CONFIGS[%s]" % args.config) + "; index item-sharded over %d GPU(s), every rank sees the whole batch" % world,
+                           "name": args.config, "batch": Bs, "query_pool_batches": args.pool,
+                           "parallelism": "item-sharded x%d (owner = hash of the item id): all-reduce(max) of the cuts + all-gather of the kept counts + variable-length exchange of "
+                                          "the posting-list prefixes + all-gather of the per-shard top-n per batch, RCCL called from inside libserenade_hip.so (srn_shard_group_predict_batch)" % world,
+                           "rccl_ranks": int(dist.get_world_size()) if world > 1 else 1, "transport": {0: "in-process", 1: "rccl", 2: "callbacks"}[st1["transport"]],
+                           "exchange_overlapped_with_previous_batch": bool(st1["overlapped"]),
+                           "items_on_rank0": int(shard.info["n_items"]), "index_bytes_hbm_rank0": int(shard.info["device_bytes"]),
+                           "setup_s": {"generate": round(t_gen, 2), "index_build_upload": round(t_build, 2), "shard_cut_attach_group": round(t_shard, 2)}},
+                "roofline": {"bound": "hbm", "kernel": "item-sharded step: list exchange + unsharded kernels over the rank's row fragments + top-n merge", "achieved": ach,
+                             "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": ach / (HBM_PEAK_GBS * world), "traffic": None,
+                             "algorithmic_bytes_per_query": bq_mean, "queries_per_launch": Bs,
+                             "note": "the same algorithmic bytes as the unsharded path (every datum is touched once, on the shard that owns it) against the whole step and N x 8 TB/s"},
+                "exchange_bytes_per_query_rank0": {"cuts_all_reduce": per_q["bytes_head"], "kept_counts_all_gather": per_q["bytes_counts"], "list_prefixes_sent": per_q["bytes_lists"],
+                                                   "list_prefixes_fullest_rank": per_q["bytes_lists_max_rank"], "topn_all_gather": per_q["bytes_results"]},
+                "latency": {"step_ms_p50": float(np.percentile(s_step_ms, 50)), "step_ms_p90": float(np.percentile(s_step_ms, 90))},
+                "parity_checked": s_parity, "queries_served_last_step": s_served, "timed_batches": int(nb)})
+        if not do_rep:
+            if rank == 0:
+                cpu = None
+                if world == 1 and not args.no_cpu_baseline:
+                    cores = usable_cores()
+                    n_cpu = int(min(Bs, 4096))
+                    r = oracle_index().predict_batch("literal", sbatches[0][2][:sbatches[0][3][n_cpu]], sbatches[0][3][:n_cpu + 1], k, m, how_many, False, threads=cores, want_results=False)
+                    cpu = {"value": n_cpu / r["elapsed"], "unit": "queries/s", "cores": cores, "kind": "port",
+                           "sample": "first %d queries of the same batch, %d threads (%.1f s); oracle/vmis_oracle.cpp literal restatement" % (n_cpu, cores, r["elapsed"])}
+                shard_line["cpu_baseline"] = cpu
+                print(json.dumps(shard_line))
+            group.close()
+            if world > 1:
+                dist.destroy_process_group()
+            return
+        del sbatches, s_out
+
+    # =========================== the whole index on every GPU: replicas, query-sharded (N = 1: THE bench line) ===========================
+    B = args.batch
+    batches = draw_batches(B, args.pool, rank)                        # every rank draws its own slice of the query stream
+    out_ids = torch.zeros(B * how_many, dtype=torch.int64, device=dev)
+    out_sc = torch.zeros(B * how_many, dtype=torch.float64, device=dev)
+    out_cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    _, _, flat0, qo0 = batches[0]
+
+    def step(i, nq=None):
+        d_flat, d_off, _, _ = batches[i % args.pool]
+        sa.predict_batch_device(index, d_flat.data_ptr(), d_off.data_ptr(), B if nq is None else nq, last_items, k, m, how_many, False,
+                                out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), stream.cuda_stream)
+
+    # ---- 1. parity gate (rank 0; the other ranks wait at the barrier below) --------------------------------------------
+    parity_checked = 0
+    if rank == 0 and args.parity > 0:
+        n_par = int(min(B, args.parity))
+        step(0, n_par)
+        torch.cuda.synchronize()
+        parity_checked = gate(out_ids.cpu().numpy().view(np.uint64).reshape(B, how_many)[:n_par], out_sc.cpu().numpy().reshape(B, how_many)[:n_par],
+                              out_cnt.cpu().numpy().view(np.uint32)[:n_par], flat0, qo0, n_par, "whole index")
+    sa.reserve(index, B, last_items, k, m, how_many, False, stream.cuda_stream)   # size the stream's workspace up front (srn_index_reserve): no call of the run allocates
+    elapsed, step_ms = timed(step)
     served = int((out_cnt.cpu().numpy().view(np.uint32) != 0xFFFFFFFF).sum())
     # size-independent properties of the WHOLE last batch (the oracle gate above covers 2 048 queries): every row is a valid top-n list --
     # count <= n, scores positive-or-not but non-increasing, equal scores in ascending id order, no item twice
-    props_ok = None
-    if not sharded_mode:
-        cnt = out_cnt.to(torch.int64)
-        ok_rows = (cnt >= 0) & (cnt <= how_many)
-        col = torch.arange(how_many, device=dev).view(1, -1)
-        inside = col < cnt.view(-1, 1)
-        sc2 = out_sc.view(B, how_many); id2 = out_ids.view(B, how_many)
-        pair = inside[:, 1:] & inside[:, :-1]
-        desc = (~pair) | (sc2[:, :-1] > sc2[:, 1:]) | ((sc2[:, :-1] == sc2[:, 1:]) & ((id2[:, :-1] ^ torch.iinfo(torch.int64).min) < (id2[:, 1:] ^ torch.iinfo(torch.int64).min)))
-        srt = torch.sort(torch.where(inside, id2, torch.arange(how_many, device=dev).view(1, -1) - how_many - 1), dim=1).values   # (fillers: distinct negatives no real id... u64 ids as int64 may be negative: collisions only flag, never pass wrongly)
-        uniq = (srt[:, 1:] != srt[:, :-1]).all(dim=1)
-        props_ok = bool((ok_rows & desc.all(dim=1) & uniq).all().item())
-        if not props_ok:
-            print("bench.py: the last batch's results violate the top-n list properties", file=sys.stderr)
-            os._exit(1)
-
-    common = {"metric": "predict_next queries/sec", "unit": "queries/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
-              "higher_is_better": True, "vs_baseline": None, "dtype": "u32 ids / i32 accumulators / f64 scores", "data": "synthetic"}
-
-    if sharded_mode:
-        if rank == 0:
-            # roofline of the capacity mode: the same algorithmic bytes (every datum is touched once, on the shard that owns it) against
-            # the whole step (lists pipeline: 4 small kernels + the unsharded launch sequence + 2 exchanges; stages: 3 launches + 3 collectives)
-            lists = args.shard_pipeline == "lists" or (args.shard_pipeline == "auto" and SH.lists_supported(index, last_items, k, m, how_many, False))
-            nstat = min(B, 8192)
-            bq_mean = None
-            try:
-                full = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw, device=local_rank, builder=args.builder) if world == 1 else None
-                if full is not None:
-                    dbg = sa.predict_batch_debug(full, (flat0[:qo0[nstat]], qo0[:nstat + 1]), k, m, how_many, False, neighbours=False)
-                    bq_mean = float(algorithmic_bytes(dbg["stats"]).mean())
-            except Exception:
-                pass
-            ms_step = elapsed / args.steps * 1e3
-            roof = None
-            if bq_mean is not None:
-                ach = bq_mean * B / (ms_step * 1e-3) / 1e9
-                roof = {"bound": "hbm", "kernel": "item-sharded step (%s)" % ("lists exchange + unsharded kernels over row fragments" if lists else "stages A, B, C + 3 collectives"), "achieved": ach, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
-                        "frac": ach / (HBM_PEAK_GBS * world), "traffic": None, "algorithmic_bytes_per_query": bq_mean, "queries_per_launch": B}
-            cpu = None
-            if world == 1 and not args.no_cpu_baseline and oix is not None:
-                cores = usable_cores()
-                n_cpu = int(min(B, 4096))
-                r = oix.predict_batch("literal", flat0[:qo0[n_cpu]], qo0[:n_cpu + 1], k, m, how_many, False, threads=cores, want_results=False)
-                cpu = {"value": n_cpu / r["elapsed"], "unit": "queries/s", "cores": cores, "kind": "port",
-                       "sample": "first %d queries of the same batch, %d threads (%.1f s); oracle/vmis_oracle.cpp literal restatement" % (n_cpu, cores, r["elapsed"])}
-            out = dict(common)
-            out.update({"value": args.steps * B / elapsed, "ms_per_step": ms_step, "scaling": "strong",
-                        "config": {"workload": "synth.CONFIGS[%s], index item-sharded over %d GPU(s), every rank sees the whole batch" % (args.config, world),
-                                   "name": args.config, "batch": B, "parallelism": "item-sharded x%d, %s" % (world, "lists pipeline: all-reduce(max) + all-gather of the posting lists + all-gather of the top-n per batch" if lists
-                                                                                else "three-stage pipeline: all-gather + all-reduce(min) + all-gather per batch"),
-                                   "items_on_rank0": int(info["n_items"]), "index_bytes_hbm_rank0": int(info["device_bytes"])},
-                        "roofline": roof, "cpu_baseline": cpu, "parity_checked": parity_checked, "queries_served_last_step": served,
-                        "batches_in_flight": 2, "note": "capacity mode; the headline bench line is --mode replicas"})
-            print(json.dumps(out))
-        if world > 1:
-            dist.destroy_process_group()
-        return
+    cnt = out_cnt.to(torch.int64)
+    ok_rows = (cnt >= 0) & (cnt <= how_many)
+    col = torch.arange(how_many, device=dev).view(1, -1)
+    inside = col < cnt.view(-1, 1)
+    sc2 = out_sc.view(B, how_many); id2 = out_ids.view(B, how_many)
+    pair = inside[:, 1:] & inside[:, :-1]
+    desc = (~pair) | (sc2[:, :-1] > sc2[:, 1:]) | ((sc2[:, :-1] == sc2[:, 1:]) & ((id2[:, :-1] ^ torch.iinfo(torch.int64).min) < (id2[:, 1:] ^ torch.iinfo(torch.int64).min)))
+    srt = torch.sort(torch.where(inside, id2, torch.arange(how_many, device=dev).view(1, -1) - how_many - 1), dim=1).values   # (fillers: distinct negatives no real id... u64 ids as int64 may be negative: collisions only flag, never pass wrongly)
+    uniq = (srt[:, 1:] != srt[:, :-1]).all(dim=1)
+    props_ok = bool((ok_rows & desc.all(dim=1) & uniq).all().item())
+    if not props_ok:
+        print("bench.py: the last batch's results violate the top-n list properties", file=sys.stderr)
+        os._exit(1)
 
     t_prep, t_fast, t_pred, t_retry = index.kernel_times_detail(min(64, args.steps))
     nq_last, general_last, global_last = index.last_path_counts()
 
     if rank != 0:
+        if group is not None:
+            group.close()
         if world > 1:
             dist.destroy_process_group()
         return
@@ -304,7 +359,7 @@ def main():
     # ---- 3. batch-size sweep: queries/s and p90 latency per batch size -----------------
     sweep = []
     lat_single = None
-    if not args.no_sweep:
+    if not args.no_sweep and world == 1:
         d_flat, d_off, _, _ = batches[0]
         for s in [1, 16, 64, 256, 4096, 65536, 1 << 20]:
             if s > B:
@@ -340,7 +395,7 @@ def main():
     traffic, traffic_src = None, None
     try:
         import glob
-        cand = [args.traffic_file] if args.traffic_file else sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*traffic_%s.json" % args.config)))
+        cand = [args.traffic_file] if args.traffic_file else sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*traffic_%s.json" % args.config)))
         if cand:
             tj = json.load(open(cand[-1]))
             if tj.get("config") == args.config and tj.get("batch_per_gpu") == B:
@@ -362,6 +417,8 @@ def main():
         "parity_checked": parity_checked, "full_batch_properties_ok": props_ok,
         "roofline": {"bound": "hbm", "kernel": "vmis_fast_kernel" if fast_used else "vmis_predict_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE)",
+                     "frac_counter": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                     "frac_counter_note": "measured HBM traffic of the launch / its duration / 8 TB/s: what the memory system really moves (frac prices the contract's algorithmic bytes)",
                      "traffic_source": traffic_src,
                      "measured_copy_gbs": copy_gbs, "frac_measured_copy": achieved / copy_gbs,
                      "algorithmic_bytes_per_query": float(bq.mean()), "queries_per_launch": B,
@@ -385,11 +442,8 @@ def main():
 
     if args.gpus == 1 and not args.no_cpu_baseline:
         # 4. the oracle is used here ONLY as the timed CPU baseline (literal restatement of the reference loops)
-        from oracle import oracle as O
-        if oix is None:
-            t1 = time.time()
-            oix = O.OracleIndex(off, items, ts, m, 34, idfw, fast=True)
-            t_obuild = time.time() - t1
+        oix = oracle_index()
+        t_obuild = oracle_box["t_build"]
         cores = usable_cores()
         probe_n = min(B, 64 * cores)
         r = oix.predict_batch("literal", flat0[:qo0[probe_n]], qo0[:probe_n + 1], k, m, how_many, False, threads=cores, want_results=False)
@@ -407,7 +461,18 @@ def main():
             "index_build_s": round(t_obuild, 2)}
     else:
         result["cpu_baseline"] = None
+    if shard_line is not None:
+        # N > 1, both modes: the line IS the north star's mode (item-sharded over RCCL); the replicas run is its ceiling
+        line = dict(shard_line)
+        line["replicas"] = {"value": result["value"], "ms_per_step": result["ms_per_step"], "scaling": "weak", "batch_per_gpu": B, "parallelism": result["config"]["parallelism"],
+                            "parity_checked": parity_checked, "full_batch_properties_ok": props_ok,
+                            "kernel": {kk: result["roofline"][kk] for kk in ("kernel", "achieved", "frac", "kernel_ms_avg", "algorithmic_bytes_per_query")},
+                            "note": "every GPU holds the whole index and serves its own slice of the query stream: no data-path collective, the throughput ceiling of any index that fits 288 GB"}
+        line["cpu_baseline"] = result["cpu_baseline"]
+        result = line
     print(json.dumps(result))
+    if group is not None:
+        group.close()
     if world > 1:
         dist.destroy_process_group()
 
