@@ -36,6 +36,8 @@ def lib():
     sz, vp = C.c_size_t, C.c_void_p
     L.orc_index_build.restype = vp
     L.orc_index_build.argtypes = [u64p, u64p, u32p, sz, sz, sz, C.c_double, C.c_int]
+    L.orc_index_build_restricted.restype = vp
+    L.orc_index_build_restricted.argtypes = [u64p, u64p, u32p, sz, sz, sz, C.c_double, u64p, sz, C.c_int, sz]
     L.orc_index_free.argtypes = [vp]
     L.orc_sessions_read_tsv.restype = vp
     L.orc_sessions_read_tsv.argtypes = [C.c_char_p]
@@ -98,9 +100,18 @@ def read_tsv(path):
 class OracleIndex:
     """Restatement of VMISIndex (src/vmisknn/vmis_index.rs:28-35) built by prepare_hashmap (:422-528)."""
 
-    def __init__(self, sess_off, items, ts, m_index, max_len, idf_weighting=1.0, fast=False):
+    def __init__(self, sess_off, items, ts, m_index, max_len, idf_weighting=1.0, fast=False, wanted=None, threads=1, items_hint=0):
+        """wanted = item ids: the RESTRICTED index for a query sample (prepare_hashmap_restricted: posting lists only for these items, idf of all, built
+        on `threads` threads; queries naming other known items are refused; items_hint = an upper bound of the number of distinct items, sizes the count table).  The session arrays are then borrowed, not copied."""
         self.L = lib()
         self.sess_off, self.items, self.ts = _u64(sess_off), _u64(items), np.ascontiguousarray(ts, np.uint32)
+        if wanted is not None:
+            w = _u64(np.unique(np.asarray(wanted, dtype=np.uint64)))
+            self.h = self.L.orc_index_build_restricted(self.sess_off, self.items, self.ts, len(self.ts), int(m_index), int(max_len), float(idf_weighting),
+                                                       w, len(w), int(threads), int(items_hint))
+            if not self.h:
+                raise MemoryError("restricted oracle index: item table overflow")
+            return
         self.h = self.L.orc_index_build(self.sess_off, self.items, self.ts, len(self.ts), int(m_index),
                                         int(max_len), float(idf_weighting), int(bool(fast)))
 
@@ -178,6 +189,8 @@ class OracleIndex:
         lat = np.zeros(nq) if want_latency else None
         el = self.L.orc_predict_batch(self.h, 0 if which == "literal" else 1, items_flat, q_off, nq, k, m, how_many,
                                       int(business), int(threads), _ptr(ids), _ptr(sc), _ptr(cnt), _ptr(st), _ptr(lat))
+        if el < 0:
+            raise ValueError("a restricted oracle index was asked about an item outside its `wanted` set")
         return dict(elapsed=el, ids=ids, scores=sc, counts=cnt, stats=st, lat_us=lat)
 
 

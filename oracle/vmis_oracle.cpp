@@ -34,6 +34,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <numeric>
 #include <string>
 #include <thread>
@@ -186,8 +187,17 @@ struct Index {
     std::vector<uint64_t> sess_off; std::vector<uint64_t> sess_items;
     FlatMap<uint64_t, uint8_t> item_to_product_attributes;  // bit0 is_adult, bit1 is_for_sale
     size_t total_pairs = 0;
+    // (the session arrays may be BORROWED from the caller instead of copied -- at 2.3 B interactions the copy alone is 18 GB: off_p / items_p are what row() reads)
+    const uint64_t* off_p = nullptr; const uint64_t* items_p = nullptr;
+    // A RESTRICTED index (prepare_hashmap_restricted) holds posting lists only for the items in `wanted`: a query that names another KNOWN item must be refused, not answered
+    bool restricted = false; FlatMap<uint64_t, uint8_t> wanted;
     const uint64_t* row(uint32_t s, size_t* len) const {
-        *len = (size_t)(sess_off[s + 1] - sess_off[s]); return sess_items.data() + sess_off[s];
+        *len = (size_t)(off_p[s + 1] - off_p[s]); return items_p + off_p[s];
+    }
+    bool serves(const uint64_t* ev, size_t len) const {   // (restricted index: every evolving item is wanted or unknown to the training data)
+        if (!restricted) return true;
+        for (size_t i = 0; i < len; ++i) if (!wanted.get(ev[i]) && item_to_idf_score.get(ev[i])) return false;
+        return true;
     }
 };
 
@@ -249,7 +259,7 @@ static void prepare_hashmap_fast(Index& ix, size_t m_most_recent_sessions,
     const size_t n_sessions = ix.session_to_max_time_stamp.size();
     std::vector<uint32_t> kept;
     for (size_t s = 0; s < n_sessions; ++s)
-        if (ix.sess_off[s + 1] - ix.sess_off[s] <= max_training_session_length) kept.push_back((uint32_t)s);
+        if (ix.off_p[s + 1] - ix.off_p[s] <= max_training_session_length) kept.push_back((uint32_t)s);
     // most recent first; ties -> larger session index first (stable ascending sort, then reversed)
     std::stable_sort(kept.begin(), kept.end(), [&](uint32_t a, uint32_t b) {
         return ix.session_to_max_time_stamp[a] < ix.session_to_max_time_stamp[b]; });
@@ -275,6 +285,107 @@ static void prepare_hashmap_fast(Index& ix, size_t m_most_recent_sessions,
         *ix.item_to_idf_score.insert_slot(ids[i]) = std::log((double)total / (double)cnt[i]) * idf_weighting;
         *ix.item_to_product_attributes.insert_slot(ids[i]) = 2;
     }
+}
+
+// The same index as prepare_hashmap_fast -- idf and attributes of EVERY item, total pairs -- but posting lists only for the items in `wanted`, built in
+// parallel: what a parity check of a query SAMPLE needs at BASELINE configs[4] scale (2.3 B interactions: the full single-threaded build takes ~7 minutes,
+// almost all of it hash-map probes for posting lists no sampled query ever reads).  find_neighbors reads postings of evolving items only
+// (vmis_index.rs:350), so for queries whose items are all wanted (or unknown) the answers are those of the full index; anything else is refused (Index::serves).
+// Pass 1, all threads: session-length filter (vmis_index.rs:452), per-item session counts in a lock-free open-addressing table, and for every wanted item a
+// bounded min-heap of its m most recent sessions by (timestamp, session index) -- the order prepare_hashmap gives its lists (:497-504).  Then the heaps of the
+// threads are merged per item.  Checked equal to prepare_hashmap_fast in tests/test_oracle_pins.py.
+static bool prepare_hashmap_restricted(Index& ix, size_t m_most_recent_sessions, size_t max_training_session_length, double idf_weighting,
+                                       const uint64_t* wanted, size_t n_wanted, int threads, size_t items_hint) {
+    const size_t n_sessions = ix.session_to_max_time_stamp.size();
+    if (threads < 1) threads = 1;
+    const uint64_t nnz = ix.off_p[n_sessions];
+    size_t cap = 1024; while (cap < 2 * std::min<uint64_t>(items_hint ? items_hint + 1 : nnz + 1, 1ull << 27)) cap <<= 1;   // (<= 2^28 slots: up to ~180 M distinct items; items_hint = an upper bound of the distinct items, 0 = unknown)
+    const uint64_t EMPTYK = ~0ull;
+    // (default-initialised, i.e. untouched, arrays: the threads of "table init" below fault the pages in -- value-initialising 2^27..2^28 atomics on one thread cost seconds)
+    std::unique_ptr<std::atomic<uint64_t>[]> keys(new std::atomic<uint64_t>[cap]); std::unique_ptr<std::atomic<uint32_t>[]> cnts(new std::atomic<uint32_t>[cap]);
+    const bool dbg = getenv("ORC_DEBUG") != nullptr; auto tp0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (dbg) { auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[oracle] restricted build: %s %.2f s\n", what, std::chrono::duration<double>(n - tp0).count()); tp0 = n; } };
+    {
+        std::vector<std::thread> pool;
+        auto init = [&](int t) { for (size_t i = cap * (size_t)t / threads; i < cap * (size_t)(t + 1) / threads; ++i) { keys[i].store(EMPTYK, std::memory_order_relaxed); cnts[i].store(0, std::memory_order_relaxed); } };
+        for (int t = 1; t < threads; ++t) pool.emplace_back(init, t);
+        init(0);
+        for (auto& th : pool) th.join();
+    }
+    lap("table init");
+    ix.wanted = FlatMap<uint64_t, uint8_t>(n_wanted);
+    FlatMap<uint64_t, uint32_t> widx(n_wanted); std::vector<uint64_t> wids;
+    for (size_t i = 0; i < n_wanted; ++i) { bool fresh; uint32_t* d = widx.insert_slot(wanted[i], &fresh); if (fresh) { *d = (uint32_t)wids.size(); wids.push_back(wanted[i]); *ix.wanted.insert_slot(wanted[i]) = 1; } }
+    const size_t m = m_most_recent_sessions;
+    std::vector<std::vector<std::vector<uint64_t>>> heaps(threads, std::vector<std::vector<uint64_t>>(wids.size()));   // [thread][wanted item] min-heap of (ts << 32 | session)
+    std::vector<uint64_t> pairs(threads, 0); std::atomic<bool> overflow{false};
+    auto work = [&](int t) {
+        const size_t lo = n_sessions * (size_t)t / threads, hi = n_sessions * (size_t)(t + 1) / threads;
+        auto& hp = heaps[t]; uint64_t tot = 0;
+        // counts go through a thread-local direct-mapped cache first: the popular items (a Zipf head holds a third of all interactions) would otherwise be
+        // atomic increments of the same few cache lines from every thread
+        constexpr size_t LC = 1u << 16;
+        std::vector<uint64_t> lk(LC, EMPTYK); std::vector<uint32_t> lc(LC, 0);
+        auto flush = [&](uint64_t id, uint32_t c) -> bool {
+            size_t i = mix64(id) & (cap - 1);
+            for (size_t probes = 0;; ++probes) {
+                uint64_t cur = keys[i].load(std::memory_order_relaxed);
+                if (cur == id) break;
+                if (cur == EMPTYK) { if (keys[i].compare_exchange_strong(cur, id, std::memory_order_relaxed) || cur == id) break; }
+                i = (i + 1) & (cap - 1);
+                if (probes > cap) { overflow = true; return false; }
+            }
+            cnts[i].fetch_add(c, std::memory_order_relaxed);
+            return true;
+        };
+        for (size_t s = lo; s < hi; ++s) {
+            size_t len; const uint64_t* r = ix.row((uint32_t)s, &len);
+            if (len > max_training_session_length) continue;
+            tot += len;
+            const uint64_t key = ((uint64_t)ix.session_to_max_time_stamp[s] << 32) | (uint64_t)s;
+            for (size_t j = 0; j < len; ++j) {
+                const uint64_t id = r[j];
+                const size_t ls = (mix64(id) >> 40) & (LC - 1);
+                if (lk[ls] == id) ++lc[ls];
+                else { if (lk[ls] != EMPTYK && !flush(lk[ls], lc[ls])) return; lk[ls] = id; lc[ls] = 1; }
+                if (const uint32_t* w = widx.get(id)) {
+                    auto& h = hp[*w];
+                    if (h.size() < m) { h.push_back(key); std::push_heap(h.begin(), h.end(), std::greater<uint64_t>()); }
+                    else if (key > h.front()) { std::pop_heap(h.begin(), h.end(), std::greater<uint64_t>()); h.back() = key; std::push_heap(h.begin(), h.end(), std::greater<uint64_t>()); }
+                }
+            }
+        }
+        for (size_t ls = 0; ls < LC; ++ls) if (lk[ls] != EMPTYK && !flush(lk[ls], lc[ls])) return;
+        pairs[t] = tot;
+    };
+    { std::vector<std::thread> pool; for (int t = 1; t < threads; ++t) pool.emplace_back(work, t); work(0); for (auto& th : pool) th.join(); }
+    lap("counting + heaps pass");
+    if (overflow) return false;
+    size_t total = 0; for (uint64_t v : pairs) total += v;
+    ix.total_pairs = total;
+    size_t n_items = 0; for (size_t i = 0; i < cap; ++i) n_items += keys[i].load(std::memory_order_relaxed) != EMPTYK;
+    ix.item_to_idf_score = FlatMap<uint64_t, double>(n_items);
+    ix.item_to_product_attributes = FlatMap<uint64_t, uint8_t>(n_items);
+    for (size_t i = 0; i < cap; ++i) {
+        const uint64_t id = keys[i].load(std::memory_order_relaxed); if (id == EMPTYK) continue;
+        *ix.item_to_idf_score.insert_slot(id) = std::log((double)total / (double)cnts[i].load(std::memory_order_relaxed)) * idf_weighting;   // :509-512
+        *ix.item_to_product_attributes.insert_slot(id) = 2;                                                                              // :514-517
+    }
+    lap("idf / attribute maps");
+    ix.item_to_top_sessions_ordered = FlatMap<uint64_t, Postings>(wids.size());
+    for (size_t w = 0; w < wids.size(); ++w) {
+        std::vector<uint64_t> all;
+        for (int t = 0; t < threads; ++t) all.insert(all.end(), heaps[t][w].begin(), heaps[t][w].end());
+        if (all.empty()) continue;                                             // (a wanted id the training data never saw)
+        std::sort(all.begin(), all.end(), std::greater<uint64_t>());           // most recent first; ties -> larger session index first
+        if (all.size() > m) all.resize(m);
+        Postings p{ix.postings.size(), (uint32_t)all.size()};
+        for (uint64_t v : all) ix.postings.push_back((uint32_t)v);
+        *ix.item_to_top_sessions_ordered.insert_slot(wids[w]) = p;
+    }
+    lap("list merge");
+    ix.restricted = true;
+    return true;
 }
 
 // ---------------------------------------------------------------------------------
@@ -515,6 +626,7 @@ static Index* index_from_sessions(const uint64_t* off, const uint64_t* items, co
                                   size_t m_index, size_t max_len, double idf_w, bool fast) {
     Index* ix = new Index();
     ix->sess_off.assign(off, off + n + 1); ix->sess_items.assign(items, items + off[n]);
+    ix->off_p = ix->sess_off.data(); ix->items_p = ix->sess_items.data();
     ix->session_to_max_time_stamp.assign(ts, ts + n);
     if (fast) prepare_hashmap_fast(*ix, m_index, max_len, idf_w);
     else prepare_hashmap_literal(*ix, m_index, max_len, idf_w);
@@ -531,6 +643,15 @@ extern "C" {
 void* orc_index_build(const uint64_t* sess_off, const uint64_t* items, const uint32_t* ts, size_t n_sessions,
                       size_t m_index, size_t max_len, double idf_weighting, int fast) {
     return index_from_sessions(sess_off, items, ts, n_sessions, m_index, max_len, idf_weighting, fast != 0);
+}
+// The restricted index for a query sample (prepare_hashmap_restricted).  The session arrays are BORROWED: the caller keeps them alive as long as the index.
+void* orc_index_build_restricted(const uint64_t* sess_off, const uint64_t* items, const uint32_t* ts, size_t n_sessions, size_t m_index, size_t max_len,
+                                 double idf_weighting, const uint64_t* wanted, size_t n_wanted, int threads, size_t items_hint) {
+    Index* ix = new Index();
+    ix->off_p = sess_off; ix->items_p = items;
+    ix->session_to_max_time_stamp.assign(ts, ts + n_sessions);
+    if (!prepare_hashmap_restricted(*ix, m_index, max_len, idf_weighting, wanted, n_wanted, threads, items_hint)) { delete ix; return nullptr; }
+    return ix;
 }
 void orc_index_free(void* h) { delete (Index*)h; }
 
@@ -614,7 +735,7 @@ double orc_predict_batch(void* h, int which, const uint64_t* items_flat, const u
                          uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint64_t* stats, double* lat_us) {
     const Index& ix = *(Index*)h;
     if (threads < 1) threads = 1;
-    std::atomic<size_t> next{0};
+    std::atomic<size_t> next{0}, refused{0};
     auto t0 = std::chrono::steady_clock::now();
     auto work = [&]() {
         std::vector<ItemScore> rl; std::vector<Scored> rc;
@@ -622,6 +743,7 @@ double orc_predict_batch(void* h, int which, const uint64_t* items_flat, const u
             size_t q0 = next.fetch_add(64); if (q0 >= nq) break;
             for (size_t q = q0; q < std::min(nq, q0 + 64); ++q) {
                 const uint64_t* ev = items_flat + q_off[q]; size_t len = q_off[q + 1] - q_off[q];
+                if (!ix.serves(ev, len)) { refused.fetch_add(1); if (out_counts) out_counts[q] = 0xFFFFFFFFu; continue; }
                 auto c0 = std::chrono::steady_clock::now();
                 size_t n = 0;
                 if (which == 0) { predict_literal(ix, ev, len, k, m, how_many, business != 0, rl); n = rl.size(); }
@@ -640,6 +762,7 @@ double orc_predict_batch(void* h, int which, const uint64_t* items_flat, const u
     for (int t = 1; t < threads; ++t) pool.emplace_back(work);
     work();
     for (auto& t : pool) t.join();
+    if (refused.load()) return -1.0;   // a restricted index was asked about an item it holds no list for
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 

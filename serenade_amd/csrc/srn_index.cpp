@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstring>
 #include <numeric>
+#include <thread>
+#include <cstdlib>
 
 #include "srn_internal.h"
 
@@ -219,9 +221,24 @@ int build_flat_index(const srn_sessions_view_t& v, size_t m_index, size_t max_se
 // rebuild.  The full index comes from the GPU builder or from disk, so an item-sharded deployment builds ONE index and every rank
 // cuts its own shard out of it (the reference loads its production index, it does not rebuild it: vmis_index.rs:85-314).
 // ---------------------------------------------------------------------------------------------
+// chunks of [0, n) on up to `threads` host threads (the shard cut below walks 2.3 B row items and as many posting entries at BASELINE configs[4] scale)
+template <typename F> static void parallel_chunks(uint64_t n, unsigned threads, F f) {
+    threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(threads, n / 65536 + 1));
+    if (threads == 1) { f(0u, 0ull, n); return; }
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < threads; ++t) pool.emplace_back([&, t] { f(t, n * t / threads, n * (t + 1) / threads); });
+    f(0u, 0ull, n / threads);
+    for (auto& th : pool) th.join();
+}
+static unsigned cut_threads() {
+    if (const char* e = getenv("SRN_BUILD_THREADS")) return (unsigned)std::max(1, atoi(e));
+    return std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+}
+
 int shard_flat_index(const FlatIndex& full, uint32_t shard, uint32_t n_shards, FlatIndex& ix) {
     if (n_shards == 0 || shard >= n_shards) return fail(SRN_EINVAL, "shard must be < n_shards");
     if (full.n_shards != 1) return fail(SRN_EINVAL, "the source index is already a shard");
+    const unsigned T = cut_threads();
     ix = FlatIndex();
     ix.n_sessions_total = full.n_sessions_total; ix.n_kept = full.n_kept; ix.m_index = full.m_index; ix.max_session_len = full.max_session_len;
     ix.idf_weighting = full.idf_weighting; ix.total_pairs = full.total_pairs; ix.shard = shard; ix.n_shards = n_shards; ix.lists_complete = full.lists_complete;
@@ -236,21 +253,22 @@ int shard_flat_index(const FlatIndex& full, uint32_t shard, uint32_t n_shards, F
         ix.idf[j] = full.idf[i]; ix.attr[j] = full.attr[i]; ix.post_off[j + 1] = full.post_off[i + 1] - full.post_off[i]; }
     for (uint64_t j = 0; j < ix.n_items; ++j) ix.post_off[j + 1] += ix.post_off[j];
     ix.nnz_post = ix.post_off[ix.n_items]; ix.post_rank.resize(ix.nnz_post);
-    for (uint64_t i = 0; i < full.n_items; ++i) { const uint32_t j = remap[i]; if (j == kNone) continue;
-        std::copy(full.post_rank.begin() + full.post_off[i], full.post_rank.begin() + full.post_off[i + 1], ix.post_rank.begin() + ix.post_off[j]); }
+    parallel_chunks(full.n_items, T, [&](unsigned, uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; ++i) { const uint32_t j = remap[i]; if (j == kNone) continue;
+            std::copy(full.post_rank.begin() + full.post_off[i], full.post_rank.begin() + full.post_off[i + 1], ix.post_rank.begin() + ix.post_off[j]); } });
     // id_rank: rank of the public id among the owned items = order of the full index's id ranks
     { std::vector<uint32_t> by(ix.n_items); std::iota(by.begin(), by.end(), 0u);
       std::sort(by.begin(), by.end(), [&](uint32_t a, uint32_t b) { return ix.item_id[a] < ix.item_id[b]; });
       ix.id_rank.resize(ix.n_items); for (uint32_t r = 0; r < ix.n_items; ++r) ix.id_rank[by[r]] = r; }
-    // row fragments, in the rows' own order
+    // row fragments, in the rows' own order: count per row (parallel), prefix, fill (parallel)
     ix.row_off.assign(ix.n_kept + 1, 0);
-    uint64_t w = 0;
-    for (uint64_t r = 0; r < full.n_kept; ++r) { for (uint64_t j = full.row_off[r]; j < full.row_off[r + 1]; ++j) w += remap[full.row_items[j]] != kNone; ix.row_off[r + 1] = w; }
-    ix.nnz_rows = w; ix.row_items.resize(w); w = 0;
-    for (uint64_t r = 0; r < full.n_kept; ++r) {
-        for (uint64_t j = full.row_off[r]; j < full.row_off[r + 1]; ++j) { const uint32_t m = remap[full.row_items[j]]; if (m != kNone) ix.row_items[w++] = m; }
-        ix.max_row_len = std::max<uint64_t>(ix.max_row_len, ix.row_off[r + 1] - ix.row_off[r]);
-    }
+    parallel_chunks(full.n_kept, T, [&](unsigned, uint64_t lo, uint64_t hi) {
+        for (uint64_t r = lo; r < hi; ++r) { uint64_t w = 0; for (uint64_t j = full.row_off[r]; j < full.row_off[r + 1]; ++j) w += remap[full.row_items[j]] != kNone; ix.row_off[r + 1] = w; } });
+    for (uint64_t r = 0; r < full.n_kept; ++r) { ix.max_row_len = std::max<uint64_t>(ix.max_row_len, ix.row_off[r + 1]); ix.row_off[r + 1] += ix.row_off[r]; }
+    ix.nnz_rows = ix.row_off[ix.n_kept]; ix.row_items.resize(ix.nnz_rows);
+    parallel_chunks(full.n_kept, T, [&](unsigned, uint64_t lo, uint64_t hi) {
+        for (uint64_t r = lo; r < hi; ++r) { uint64_t w = ix.row_off[r];
+            for (uint64_t j = full.row_off[r]; j < full.row_off[r + 1]; ++j) { const uint32_t m = remap[full.row_items[j]]; if (m != kNone) ix.row_items[w++] = m; } } });
     size_t tcap = 16; while (tcap < ix.n_items * 2) tcap <<= 1;
     ix.id_table.assign(tcap, IdSlot{0, kNone, 0}); ix.id_mask = (uint32_t)(tcap - 1);
     for (uint32_t i = 0; i < ix.n_items; ++i) {

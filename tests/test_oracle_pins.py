@@ -164,3 +164,31 @@ def test_reference_example_readme_vectors(tmp_path):
         a, _ = ix2.find_neighbors_literal(q, 288, 1502)
         b, _, _ = ix2.neighbors_canonical(q, 288, 1502)
         assert set(a.tolist()) == set(b.tolist())
+
+
+def test_restricted_parallel_builder_equals_prepare_hashmap():
+    """prepare_hashmap_restricted (posting lists only for a query sample's items, idf of every item, built on several threads -- what makes an oracle check of
+    BASELINE configs[4], 2.3 B interactions, fit a test) against prepare_hashmap_fast, which the tests above pin on the literal builder: same lists (tied
+    timestamps included), same idf, same total, same answers from both restatements; and it refuses a query about a known item it holds no list for."""
+    from helpers import flatten, random_queries, small_dataset
+    off, items, ts, ids = small_dataset(91, n_sessions=5000, n_items=300, tied_timestamps=True, max_len=20)
+    qs = random_queries(5, ids, 300, max_len=6)
+    flat, qoff = flatten(qs)
+    full = O.OracleIndex(off, items, ts, 60, 12, 2.0, fast=True)
+    lit = O.OracleIndex(off, items, ts, 60, 12, 2.0, fast=False)
+    for thr in (1, 3, 8):
+        r = O.OracleIndex(off, items, ts, 60, 12, 2.0, wanted=flat, threads=thr)
+        assert r.num_items == full.num_items == lit.num_items and r.total_pairs == full.total_pairs
+        for it in np.unique(flat):
+            a, b, c = full.postings(int(it)), r.postings(int(it)), lit.postings(int(it))
+            if a[0] is None:
+                assert b[0] is None
+                continue
+            assert np.array_equal(a[0], b[0]) and np.array_equal(c[0], b[0]) and a[1] == b[1] == c[1]
+        for which in ("canonical", "literal"):
+            x, y = full.predict_batch(which, flat, qoff, 50, 60, 21, threads=2), r.predict_batch(which, flat, qoff, 50, 60, 21, threads=2)
+            assert np.array_equal(x["ids"], y["ids"]) and np.array_equal(x["scores"], y["scores"]) and np.array_equal(x["counts"], y["counts"])
+    seen = set(flat.tolist())
+    other = next(int(i) for i in ids if int(i) not in seen)
+    with pytest.raises(ValueError):
+        r.predict_batch("canonical", np.array([other], np.uint64), np.array([0, 1], np.uint32), 50, 60, 21)
