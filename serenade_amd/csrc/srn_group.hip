@@ -111,7 +111,7 @@ struct srn_shard_group {
     ncclComm_t comm[2] = {nullptr, nullptr};   // [0] exchange stream, [1] caller's stream: operations on one communicator serialise in issue order
     srn_shard_comm_t cb{};
     hipStream_t s_x = nullptr; hipEvent_t e_in = nullptr, e_x = nullptr;
-    bool overlap = true;
+    bool overlap = true, no_direct = false;
     Slot slot[2];
     uint64_t calls = 0;
     uint64_t st_queries = 0, st_bytes_head = 0, st_bytes_kept = 0, st_bytes_lists = 0, st_bytes_results = 0, st_lists_max = 0;
@@ -168,6 +168,7 @@ int group_init_common(srn_shard_group* g) {
         s.pos.assign(g->shards.size(), nullptr); s.pos_bytes.assign(g->shards.size(), 0);
     }
     if (const char* e = getenv("SRN_GROUP_OVERLAP")) g->overlap = atoi(e) != 0;
+    g->no_direct = getenv("SRN_GROUP_NO_DIRECT") != nullptr;
     return SRN_OK;
 }
 
@@ -204,7 +205,7 @@ int group_predict(srn_shard_group* g, const uint64_t* d_items_flat, const uint32
         if (!rc) rc = ensure(&s.kept, &s.kept_bytes, (size_t)G * nq * ML * 4);
         if (!rc) rc = ensure(&s.tot, &s.tot_bytes, (size_t)nq * 4);
         if (!rc) rc = ensure(&s.off, &s.off_bytes, (size_t)G * nq * 8);
-        if (!rc) rc = ensure(&s.small, &s.small_bytes, (size_t)G * 16);
+        if (!rc) rc = ensure(&s.small, &s.small_bytes, (size_t)G * 16 + (size_t)G * ((nq + 1023) / 1024) * 8);
         if (!rc) rc = ensure(&s.records, &s.records_bytes, (size_t)nq * rec_stride);
         if (!rc) rc = ensure(&s.part, &s.part_bytes, (size_t)G * block_bytes);
         if (rc) return rc;
@@ -230,20 +231,26 @@ int group_predict(srn_shard_group* g, const uint64_t* d_items_flat, const uint32
         int rc = device_shard_lists_count(g->shards[i]->dev, p, s.pos[i], head, kept_g + (size_t)gi * nq * ML, (int*)s.tot, sx); if (rc) return rc;
     }
     { int rc = all_gather_blocks(g, 0, s.kept, (size_t)nq * ML * 4, sx); if (rc) return rc; }
-    HIP_TRY(launch_shard_offsets(sx, kept_g, nq, ML, G, off_g, tot_dev, tot_host_dev));
+    HIP_TRY(launch_shard_offsets(sx, kept_g, nq, ML, G, off_g, tot_dev, tot_host_dev, base_dev + G));
     HIP_TRY(hipStreamSynchronize(sx));   // the batch's one host synchronisation (with the exchange stream: only this batch's small kernels are waited for)
     unsigned long long base[64], cnt_b[64], off_b[64], total = 0;
     if (G > 64) return fail(SRN_ERANGE, "more than 64 shards");
     for (uint32_t i = 0; i < G; ++i) { base[i] = total; total += (s.tot_host[i] + 63ull) / 64ull * 64ull; }   // (segments start on 256-byte boundaries)
     for (uint32_t i = 0; i < G; ++i) { s.tot_host[G + i] = base[i]; off_b[i] = base[i] * 4ull; cnt_b[i] = s.tot_host[i] * 4ull; }
-    if (s.lists_bytes < total * 4 + 256) { int rc = ensure(&s.lists, &s.lists_bytes, (size_t)(total * 4 + total / 2 + 4096)); if (rc) return rc; }   // (head room: the totals of like batches differ by a per cent or two)
-    HIP_TRY(hipMemcpyAsync(base_dev, s.tot_host + G, (size_t)G * 8, hipMemcpyHostToDevice, sx));
-    uint32_t* lists_g = (uint32_t*)s.lists;
-    for (size_t i = 0; i < g->shards.size(); ++i) {
-        const uint32_t gi = local ? (uint32_t)i : (uint32_t)g->rank;
-        int rc = device_shard_lists_copy(g->shards[i]->dev, p, s.pos[i], kept_g + (size_t)gi * nq * ML, off_g + (size_t)gi * nq, lists_g + base[gi], sx); if (rc) return rc;
+    // A group of ONE shard ships nothing: its kept prefixes are read where they lie in the shard's posting array (no copy, no exchange buffer).  SRN_GROUP_NO_DIRECT
+    // keeps the copy + exchange steps even then (tests: every RCCL call of a multi-rank run on the 1-rank communicator one GPU allows).
+    const bool direct = G == 1 && !g->no_direct;
+    uint32_t* lists_g = nullptr;
+    if (!direct) {
+        if (s.lists_bytes < total * 4 + 256) { int rc = ensure(&s.lists, &s.lists_bytes, (size_t)(total * 4 + total / 2 + 4096)); if (rc) return rc; }   // (head room: the totals of like batches differ by a per cent or two)
+        HIP_TRY(hipMemcpyAsync(base_dev, s.tot_host + G, (size_t)G * 8, hipMemcpyHostToDevice, sx));
+        lists_g = (uint32_t*)s.lists;
+        for (size_t i = 0; i < g->shards.size(); ++i) {
+            const uint32_t gi = local ? (uint32_t)i : (uint32_t)g->rank;
+            int rc = device_shard_lists_copy(g->shards[i]->dev, p, s.pos[i], kept_g + (size_t)gi * nq * ML, off_g + (size_t)gi * nq, lists_g + base[gi], sx); if (rc) return rc;
+        }
+        { int rc = all_gather_v(g, 0, s.lists, off_b, cnt_b, sx); if (rc) return rc; }
     }
-    { int rc = all_gather_v(g, 0, s.lists, off_b, cnt_b, sx); if (rc) return rc; }
     if (overlap) { HIP_TRY(hipEventRecord(g->e_x, sx)); HIP_TRY(hipStreamWaitEvent(user, g->e_x, 0)); }
     // ---- caller's stream: the unsharded launch sequence over every local shard's row fragments ----
     for (size_t i = 0; i < g->shards.size(); ++i) {
@@ -253,7 +260,7 @@ int group_predict(srn_shard_group* g, const uint64_t* d_items_flat, const uint32
         const bool direct = G == 1;   // one shard: its top-n IS the result
         pi.out_ids = direct ? d_out_ids : (uint64_t*)blk; pi.out_scores = direct ? d_out_scores : (double*)(blk + (size_t)nq * n * 8); pi.out_counts = direct ? d_out_counts : (uint32_t*)(blk + (size_t)nq * n * 16);
         HIP_TRY(hipMemsetAsync(pi.out_ids, 0, (size_t)nq * n * 8, user)); HIP_TRY(hipMemsetAsync(pi.out_scores, 0, (size_t)nq * n * 8, user));
-        int rc = device_shard_lists_predict(g->shards[i]->dev, g->shards[i]->flat, pi, G, kept_g, off_g, 0ull, lists_g, head, s.pos[i], s.records, user, base_dev); if (rc) return rc;
+        int rc = device_shard_lists_predict(g->shards[i]->dev, g->shards[i]->flat, pi, G, kept_g, off_g, 0ull, lists_g, head, s.pos[i], s.records, user, base_dev, direct); if (rc) return rc;
     }
     if (G > 1) {
         int rc = all_gather_blocks(g, 1, s.part, block_bytes, user); if (rc) return rc;
@@ -264,7 +271,7 @@ int group_predict(srn_shard_group* g, const uint64_t* d_items_flat, const uint32
     const uint32_t me = local ? 0u : (uint32_t)g->rank;
     g->st_queries += nq; g->st_bytes_head += (uint64_t)nq * 12; g->st_bytes_kept += (uint64_t)nq * ML * 4 * (local ? G : 1);
     { uint64_t mine = 0, mx = 0; for (uint32_t i = 0; i < G; ++i) { mx = std::max<uint64_t>(mx, s.tot_host[i]); if (local || i == me) mine += s.tot_host[i]; }
-      g->st_bytes_lists += mine * 4; g->st_lists_max += mx * 4; }
+      if (!direct) { g->st_bytes_lists += mine * 4; g->st_lists_max += mx * 4; } }
     g->st_bytes_results += G > 1 ? (uint64_t)block_bytes * (local ? G : 1) : 0;
     return SRN_OK;
 }

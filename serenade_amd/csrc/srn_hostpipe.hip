@@ -66,18 +66,20 @@ private:
 };
 }  // namespace
 
-// Slots: two chunks' kernels run side by side (two kernel streams), so a result slot must outlive its chunk by two more chunks -- with only two device result
-// slots chunk c + 2 waited for chunk c's download and the pipeline fell into lockstep pairs [kernels c, c+1][downloads c, c+1][kernels c+2, c+3] (rocprofv3
-// timeline, profiles/r03_hostpipe_timeline.txt: the downloads are blit kernels of ~0.45 ms per 64 K queries and never overlapped the compute).  Four slots on
-// the device and in pinned memory: chunk c + 2 starts when chunk c's KERNELS are done, its download runs beside chunks c + 1 and c + 2.
+// Streams: the runtime maps HIP streams onto a few hardware queues, and its device-to-host copies into pinned memory are blit KERNELS (rocprofv3 timeline,
+// profiles/r03_hostpipe_timeline.txt: __amd_rocclr_copyBuffer, ~0.45 ms per 64 K queries' results).  A download enqueued on a stream of its own landed in the
+// same hardware queue as one of the two kernel streams, BEHIND the next chunk's kernels: the pipeline ran [kernels c, c+1][downloads c, c+1][kernels c+2, c+3] and
+// no download ever overlapped compute.  So a chunk is one in-order sequence on ONE stream -- upload, kernels, download -- and the overlap comes from the two kernel
+// streams: chunk c's download runs beside chunk c + 1's kernels.  Device staging is per stream (stream order protects it), pinned result staging has four slots
+// (the copy threads lag the GPU).
 struct HostPipe {
     static constexpr int NOUT = 4;
-    hipStream_t s_in = nullptr, s_out = nullptr, s_k[2] = {nullptr, nullptr};
-    hipEvent_t e_in[2] = {}, e_k[NOUT] = {}, e_out[NOUT] = {};
+    hipStream_t s_k[2] = {nullptr, nullptr};
+    hipEvent_t e_in[2] = {}, e_out[NOUT] = {};
     char* pin_in[2] = {}; size_t pin_in_bytes[2] = {};
     char* pin_out[NOUT] = {}; size_t pin_out_bytes[NOUT] = {};
     char* dev_in[2] = {}; size_t dev_in_bytes[2] = {};
-    char* dev_out[NOUT] = {}; size_t dev_out_bytes[NOUT] = {};
+    char* dev_out[2] = {}; size_t dev_out_bytes[2] = {};
     std::atomic<int> pending[NOUT];
     HostPipe() { for (auto& p : pending) p.store(0); }
 };
@@ -85,11 +87,9 @@ struct HostPipe {
 static void pipe_free(HostPipe* hp) {
     if (!hp) return;
     for (auto& p : hp->pending) CopyPool::wait(&p);
-    for (int i = 0; i < 2; ++i) { if (hp->pin_in[i]) hipHostFree(hp->pin_in[i]); if (hp->dev_in[i]) hipFree(hp->dev_in[i]);
+    for (int i = 0; i < 2; ++i) { if (hp->pin_in[i]) hipHostFree(hp->pin_in[i]); if (hp->dev_in[i]) hipFree(hp->dev_in[i]); if (hp->dev_out[i]) hipFree(hp->dev_out[i]);
                                   if (hp->e_in[i]) hipEventDestroy(hp->e_in[i]); if (hp->s_k[i]) hipStreamDestroy(hp->s_k[i]); }
-    for (int i = 0; i < HostPipe::NOUT; ++i) { if (hp->pin_out[i]) hipHostFree(hp->pin_out[i]); if (hp->e_out[i]) hipEventDestroy(hp->e_out[i]);
-                                               if (hp->dev_out[i]) hipFree(hp->dev_out[i]); if (hp->e_k[i]) hipEventDestroy(hp->e_k[i]); }
-    if (hp->s_in) hipStreamDestroy(hp->s_in); if (hp->s_out) hipStreamDestroy(hp->s_out);
+    for (int i = 0; i < HostPipe::NOUT; ++i) { if (hp->pin_out[i]) hipHostFree(hp->pin_out[i]); if (hp->e_out[i]) hipEventDestroy(hp->e_out[i]); }
     delete hp;
 }
 void hostpipes_free(DeviceState* d) { for (HostPipe* hp : d->all_pipes) pipe_free(hp); d->all_pipes.clear(); d->free_pipes.clear(); }
@@ -97,9 +97,9 @@ void hostpipes_free(DeviceState* d) { for (HostPipe* hp : d->all_pipes) pipe_fre
 static HostPipe* pipe_acquire(DeviceState* d) {
     { std::lock_guard<std::mutex> lk(d->mu); if (!d->free_pipes.empty()) { HostPipe* hp = d->free_pipes.back(); d->free_pipes.pop_back(); return hp; } }
     HostPipe* hp = new HostPipe();
-    bool ok = hipStreamCreateWithFlags(&hp->s_in, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&hp->s_out, hipStreamNonBlocking) == hipSuccess;
+    bool ok = true;
     for (int i = 0; i < 2 && ok; ++i) ok = hipStreamCreateWithFlags(&hp->s_k[i], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&hp->e_in[i], hipEventDisableTiming) == hipSuccess;
-    for (int i = 0; i < HostPipe::NOUT && ok; ++i) ok = hipEventCreateWithFlags(&hp->e_out[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&hp->e_k[i], hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < HostPipe::NOUT && ok; ++i) ok = hipEventCreateWithFlags(&hp->e_out[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) { pipe_free(hp); return nullptr; }
     std::lock_guard<std::mutex> lk(d->mu); d->all_pipes.push_back(hp);
     return hp;
@@ -115,14 +115,15 @@ static int ensure_pinned(char** p, size_t* have, size_t need) {
     *have = need; return SRN_OK;
 }
 
-// how a host batch is cut: chunks of >= 2048 queries, at least 4 of them where the batch allows it (the copies of one chunk hide behind the kernels of the
-// next), and no chunk's results above ~32 MB of pinned staging
+// how a host batch is cut: one chunk up to 8192 queries (a second chunk's launches cost more than its overlap buys), then chunks of ~16 K queries, at most
+// 64 K (and no chunk's results above ~32 MB of pinned staging): measured on config 3, profiles/r03_host_pipe_probe.txt
 uint32_t hostpipe_chunks(uint32_t nq, uint32_t how_many) {
     const Knobs kn = knobs();
     if (kn.host_chunks > 0) return (uint32_t)std::min<uint64_t>(nq, (uint64_t)kn.host_chunks);
+    if (nq <= 8192) return 1;
     const uint64_t chunk_max = std::min<uint64_t>(65536, std::max<uint64_t>(1024, (32ull << 20) / ((uint64_t)how_many * 16 + 4)));
-    const uint64_t by_max = (nq + chunk_max - 1) / chunk_max, by_min = (nq + 2047) / 2048;
-    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(by_min, std::max<uint64_t>(4, by_max)));
+    const uint64_t by_max = (nq + chunk_max - 1) / chunk_max, by_16k = (nq + 16383) / 16384;
+    return (uint32_t)std::max<uint64_t>(2, std::min<uint64_t>(by_16k, std::max<uint64_t>(4, by_max)));
 }
 
 int device_predict_host_pipelined(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in, const uint64_t* h_items, const uint32_t* h_qoff,
@@ -134,7 +135,7 @@ int device_predict_host_pipelined(DeviceState* d, const FlatIndex& ix, const Lau
     struct Rel { DeviceState* d; HostPipe* hp; bool* good; ~Rel() {
         for (auto& pnd : hp->pending) CopyPool::wait(&pnd);
         if (*good) pipe_release(d, hp);
-        else { hipStreamSynchronize(hp->s_in); hipStreamSynchronize(hp->s_k[0]); hipStreamSynchronize(hp->s_k[1]); hipStreamSynchronize(hp->s_out); pipe_release(d, hp); } } } rel{d, hp, &good};
+        else { hipStreamSynchronize(hp->s_k[0]); hipStreamSynchronize(hp->s_k[1]); pipe_release(d, hp); } } } rel{d, hp, &good};
     const uint32_t nq = p_in.nq, n = p_in.how_many;
     const Knobs kn = knobs();
     const auto t_start = std::chrono::steady_clock::now();
@@ -159,13 +160,12 @@ int device_predict_host_pipelined(DeviceState* d, const FlatIndex& ix, const Lau
         tr_submit += now_us() - t0;
         return SRN_OK;
     };
-    const bool one = nchunks == 1;   // a single chunk: everything in order on ONE stream (no cross-stream events: each hop costs ~10 us of a ~0.3 ms call)
     constexpr uint32_t LAG = 2;      // the host collects chunk c - LAG after it has enqueued chunk c: two chunks stay queued on the GPU while it waits
     for (uint32_t c = 0; c < nchunks; ++c) {
         const int i = (int)(c & 1u), o = (int)(c % HostPipe::NOUT);
         const uint32_t q0 = c * csz, cq = std::min(csz, nq - q0);
         if (q0 >= nq) break;
-        hipStream_t sk = hp->s_k[i], sin = one ? sk : hp->s_in, sout = one ? sk : hp->s_out;
+        hipStream_t sk = hp->s_k[i];   // the chunk's ONE stream: upload, kernels, download in order
         const size_t it0 = h_qoff[q0], it1 = h_qoff[q0 + cq], in_items = (it1 - it0) * 8, in_off = ((size_t)cq + 1) * 4, in_bytes = (in_items + 255) / 256 * 256 + in_off;
         // input staging of chunk c - 2 has been read by its upload
         double t0 = now_us();
@@ -174,31 +174,28 @@ int device_predict_host_pipelined(DeviceState* d, const FlatIndex& ix, const Lau
         memcpy(hp->pin_in[i], h_items + it0, in_items);
         memcpy(hp->pin_in[i] + (in_items + 255) / 256 * 256, h_qoff + q0, in_off);
         tr_in += now_us() - t0; t0 = now_us();
-        if (c >= 2) HIP_TRY(hipStreamWaitEvent(sin, hp->e_k[(c - 2) % HostPipe::NOUT], 0));   // device input slot: chunk c - 2's kernels are done with it
-        if (hp->dev_in_bytes[i] < in_bytes) { if (c >= 2) HIP_TRY(hipEventSynchronize(hp->e_k[(c - 2) % HostPipe::NOUT])); int rc = ensure(&hp->dev_in[i], &hp->dev_in_bytes[i], in_bytes); if (rc) return rc; }
-        HIP_TRY(hipMemcpyAsync(hp->dev_in[i], hp->pin_in[i], in_bytes, hipMemcpyHostToDevice, sin));
-        if (!one) HIP_TRY(hipEventRecord(hp->e_in[i], sin));
-        // kernels
         const size_t ob = out_bytes(cq);
-        if (hp->dev_out_bytes[o] < ob) { if (c >= (uint32_t)HostPipe::NOUT) HIP_TRY(hipEventSynchronize(hp->e_out[o])); int rc = ensure(&hp->dev_out[o], &hp->dev_out_bytes[o], ob); if (rc) return rc; }
-        if (!one) HIP_TRY(hipStreamWaitEvent(sk, hp->e_in[i], 0));
-        if (c >= (uint32_t)HostPipe::NOUT) HIP_TRY(hipStreamWaitEvent(sk, hp->e_out[o], 0));   // device result slot: chunk c - NOUT's download is done
+        if (hp->dev_in_bytes[i] < in_bytes || hp->dev_out_bytes[i] < ob) {   // (growing frees: the stream that uses the buffers must be idle)
+            HIP_TRY(hipStreamSynchronize(sk));
+            int rc = ensure(&hp->dev_in[i], &hp->dev_in_bytes[i], in_bytes); if (rc) return rc;
+            rc = ensure(&hp->dev_out[i], &hp->dev_out_bytes[i], ob); if (rc) return rc;
+        }
+        HIP_TRY(hipMemcpyAsync(hp->dev_in[i], hp->pin_in[i], in_bytes, hipMemcpyHostToDevice, sk));
+        HIP_TRY(hipEventRecord(hp->e_in[i], sk));
         LaunchParams p = p_in;
         p.nq = cq;
         p.items_flat = (const uint64_t*)hp->dev_in[i] - it0;   // (the chunk's offsets stay global: the base is shifted instead)
         p.q_off = (const uint32_t*)(hp->dev_in[i] + (in_items + 255) / 256 * 256);
-        p.out_ids = (uint64_t*)hp->dev_out[o]; p.out_scores = (double*)(hp->dev_out[o] + (size_t)cq * n * 8); p.out_counts = (uint32_t*)(hp->dev_out[o] + (size_t)cq * n * 16);
-        HIP_TRY(hipMemsetAsync(hp->dev_out[o], 0, (size_t)cq * n * 16, sk));   // the unused tail of each row reads as 0
+        p.out_ids = (uint64_t*)hp->dev_out[i]; p.out_scores = (double*)(hp->dev_out[i] + (size_t)cq * n * 8); p.out_counts = (uint32_t*)(hp->dev_out[i] + (size_t)cq * n * 16);
+        HIP_TRY(hipMemsetAsync(hp->dev_out[i], 0, (size_t)cq * n * 16, sk));   // the unused tail of each row reads as 0
         { int rc = device_predict(d, ix, p, true, sk, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr); if (rc) return rc; }
-        if (!one) HIP_TRY(hipEventRecord(hp->e_k[o], sk));
         // download: the pinned slot's previous contents (chunk c - NOUT) must have reached the caller's buffers
         tr_enq += now_us() - t0; t0 = now_us();
         CopyPool::wait(&hp->pending[o]);
         tr_wait_copy += now_us() - t0; t0 = now_us();
         { int rc = ensure_pinned(&hp->pin_out[o], &hp->pin_out_bytes[o], ob); if (rc) return rc; }
-        if (!one) HIP_TRY(hipStreamWaitEvent(sout, hp->e_k[o], 0));
-        HIP_TRY(hipMemcpyAsync(hp->pin_out[o], hp->dev_out[o], ob, hipMemcpyDeviceToHost, sout));
-        HIP_TRY(hipEventRecord(hp->e_out[o], sout));
+        HIP_TRY(hipMemcpyAsync(hp->pin_out[o], hp->dev_out[i], ob, hipMemcpyDeviceToHost, sk));
+        HIP_TRY(hipEventRecord(hp->e_out[o], sk));
         tr_enq += now_us() - t0;
         if (c >= LAG) { int rc = flush(c - LAG); if (rc) return rc; }
     }

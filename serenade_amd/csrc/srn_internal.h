@@ -137,7 +137,7 @@ int device_shard_lists_count(DeviceState* d, const LaunchParams& p, const void* 
 int device_shard_lists_copy(DeviceState* d, const LaunchParams& p, const void* pos, const uint32_t* kept, const long long* off, uint32_t* out, void* stream);
 int device_shard_lists_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p, uint32_t n_shards, const uint32_t* kept_g, const long long* off_g,
                                unsigned long long shard_stride, const uint32_t* lists_g, const int* head, const void* pos_local, char* records, void* stream,
-                               const unsigned long long* shard_base = nullptr);   // shard_base [n_shards] (device): the shards' segment starts (null: g * shard_stride)
+                               const unsigned long long* shard_base = nullptr, bool direct = false);   // shard_base [n_shards] (device): the shards' segment starts (null: g * shard_stride); direct: a group of one shard reads its lists in place (lists_g = null)
 int device_shard_stage(DeviceState* d, const FlatIndex& ix, int stage, const LaunchParams& p, const ShardIO& sh, void* stream);
 int device_slot_bytes(DeviceState* d, const FlatIndex& ix, uint32_t max_len, uint32_t* num_bits = nullptr);
 int device_last_kernel_ms(DeviceState* d, double* ms_main, double* ms_retry, uint32_t* retried);

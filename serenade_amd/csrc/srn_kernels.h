@@ -92,10 +92,10 @@ hipError_t launch_shard_lists_copy(hipStream_t st, const DeviceIndex& di, uint32
                                    uint32_t* out);
 hipError_t launch_shard_prep(hipStream_t st, const uint64_t* items_flat, const uint32_t* q_off, uint32_t nq, uint32_t max_len, uint32_t n_shards, const uint32_t* kept_g,
                              const long long* off_g, unsigned long long shard_stride, const int* head, const ShardPos* pos_local, char* out, uint32_t stride,
-                             const unsigned long long* shard_base = nullptr);   // shard_base [n_shards] (device): where each shard's segment starts in the gathered buffer (null: g * shard_stride)
+                             const unsigned long long* shard_base = nullptr, bool direct = false);   // shard_base [n_shards] (device): where each shard's segment starts in the gathered buffer (null: g * shard_stride); direct: one shard, lists read in place
 hipError_t launch_shard_max(hipStream_t st, int* dst, const int* src, size_t n);
 hipError_t launch_shard_offsets(hipStream_t st, const uint32_t* kept_g, uint32_t nq, uint32_t max_len, uint32_t n_shards, long long* off_g, unsigned long long* tot_dev,
-                                unsigned long long* tot_host);
+                                unsigned long long* tot_host, unsigned long long* chunk_scratch);
 hipError_t launch_shard_merge_topn(hipStream_t st, const char* part, size_t block_bytes, uint32_t n_shards, uint32_t nq, uint32_t how_many, uint64_t* out_ids, double* out_scores,
                                    uint32_t* out_counts);
 hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f, bool debug = false);   // debug: say the occupancy once (the SRN_DEBUG knob, read by the runtime)

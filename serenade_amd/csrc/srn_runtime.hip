@@ -571,14 +571,14 @@ int device_shard_lists_copy(DeviceState* d, const LaunchParams& p, const void* p
 }
 int device_shard_lists_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p, uint32_t n_shards, const uint32_t* kept_g, const long long* off_g,
                                unsigned long long shard_stride, const uint32_t* lists_g, const int* head, const void* pos_local, char* records, void* stream,
-                               const unsigned long long* shard_base) {
+                               const unsigned long long* shard_base, bool direct) {
     HIP_TRY(hipSetDevice(d->device));
     if (p.nq == 0) return SRN_OK;
     if (n_shards != ix.n_shards) return fail(SRN_EINVAL, "n_shards differs from the number of shards this index was cut into");
     if (!device_shard_lists_supported(d, ix, p)) return fail(SRN_EINVAL, "lists mode needs position-set slots (sessions of <= 8 items, m <= m_index, complete lists): use the three-stage pipeline");
     const uint32_t stride = device_prep_stride(p.max_len);
-    HIP_TRY(launch_shard_prep((hipStream_t)stream, p.items_flat, p.q_off, p.nq, p.max_len, n_shards, kept_g, off_g, shard_stride, head, (const ShardPos*)pos_local, records, stride, shard_base));
-    ExtLists ext{records, stride, lists_g};
+    HIP_TRY(launch_shard_prep((hipStream_t)stream, p.items_flat, p.q_off, p.nq, p.max_len, n_shards, kept_g, off_g, shard_stride, head, (const ShardPos*)pos_local, records, stride, shard_base, direct));
+    ExtLists ext{records, stride, direct ? d->di.post_rank : lists_g};
     return device_predict(d, ix, p, true, stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &ext);
 }
 

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void shard_lists_copy_kernel(DeviceIndex ix, u
 __global__ __launch_bounds__(256) void shard_prep_kernel(const uint64_t* __restrict__ items_flat, const uint32_t* __restrict__ q_off, uint32_t nq, uint32_t max_len,
                                                          uint32_t n_shards, const uint32_t* __restrict__ kept_g, const long long* __restrict__ off_g,
                                                          unsigned long long shard_stride, const unsigned long long* __restrict__ shard_base, const int* __restrict__ head,
-                                                         const ShardPos* __restrict__ pos_local, char* __restrict__ out, uint32_t stride) {
+                                                         const ShardPos* __restrict__ pos_local, char* __restrict__ out, uint32_t stride, bool direct) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     const uint32_t qb = q_off[q], L = q_off[q + 1] - qb;
@@ -113,7 +113,9 @@ __global__ __launch_bounds__(256) void shard_prep_kernel(const uint64_t* __restr
                 if (kq[pos] == 0) continue;
                 unsigned long long before = 0;
                 for (uint32_t j = 0; j < pos; ++j) before += kq[j];
-                kp = kq[pos]; base = (shard_base ? shard_base[g] : (unsigned long long)g * shard_stride) + (unsigned long long)off_g[(size_t)g * nq + q] + before;   // (shard_base: segments of different lengths, back to back)
+                kp = kq[pos];
+                if (direct) base = pos_local[(size_t)q * max_len + pos].base;   // (a group of ONE shard: nothing travels, the kept prefix is read where it lies in the shard's own posting array)
+                else base = (shard_base ? shard_base[g] : (unsigned long long)g * shard_stride) + (unsigned long long)off_g[(size_t)g * nq + q] + before;   // (shard_base: segments of different lengths, back to back)
                 break;
             }
             if (kp) { h.sumw += L - pos; if (h.nruns < 8) h.run_start[h.nruns] = h.P; ++h.nruns; }
@@ -142,9 +144,9 @@ hipError_t launch_shard_lists_copy(hipStream_t st, const DeviceIndex& di, uint32
 }
 hipError_t launch_shard_prep(hipStream_t st, const uint64_t* items_flat, const uint32_t* q_off, uint32_t nq, uint32_t max_len, uint32_t n_shards, const uint32_t* kept_g,
                              const long long* off_g, unsigned long long shard_stride, const int* head, const ShardPos* pos_local, char* out, uint32_t stride,
-                             const unsigned long long* shard_base) {
+                             const unsigned long long* shard_base, bool direct) {
     hipLaunchKernelGGL(shard_prep_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, items_flat, q_off, nq, max_len, n_shards, kept_g, off_g, shard_stride, shard_base, head, pos_local,
-                       out, stride);
+                       out, stride, direct);
     return hipGetLastError();
 }
 
@@ -160,35 +162,57 @@ hipError_t launch_shard_max(hipStream_t st, int* dst, const int* src, size_t n) 
     return hipGetLastError();
 }
 
-// Where every query's kept prefixes start inside its shard's segment, for ALL shards at once, from the all-gathered kept counts: block g scans shard g's
-// queries (off_g[g][q] = number of entries of shard g before query q) and leaves the shard's total in tot[g] -- device memory, and a pinned word the
-// host reads after the one short synchronisation of a batch (the totals size the variable-length exchange).
-__global__ __launch_bounds__(1024) void shard_offsets_kernel(const uint32_t* __restrict__ kept_g, uint32_t nq, uint32_t max_len, long long* __restrict__ off_g,
-                                                             unsigned long long* __restrict__ tot_dev, unsigned long long* __restrict__ tot_host) {
+// Where every query's kept prefixes start inside its shard's segment, for ALL shards at once, from the all-gathered kept counts: off_g[g][q] = number of
+// entries of shard g before query q, tot[g] = the shard's total -- in device memory, and in a pinned word the host reads after the one short synchronisation
+// of a batch (the totals size the variable-length exchange).  Three small launches (a query per thread, coalesced): chunk sums, a scan of the chunk sums
+// per shard, offsets.  (A first version scanned a whole shard with ONE workgroup: 0.3 ms per 2^18 queries on a chip with 256 CUs.)
+constexpr uint32_t OFFS_CHUNK = 1024;   // queries per workgroup
+__device__ __forceinline__ unsigned long long row_sum(const uint32_t* __restrict__ kq, uint32_t max_len) {
+    unsigned long long v = 0; for (uint32_t j = 0; j < max_len; ++j) v += kq[j]; return v;
+}
+__global__ __launch_bounds__(1024) void shard_offsets_sum_kernel(const uint32_t* __restrict__ kept_g, uint32_t nq, uint32_t max_len, uint32_t nchunks,
+                                                                 unsigned long long* __restrict__ chunk_tot) {
+    __shared__ unsigned long long wsum[16];
+    const uint32_t g = blockIdx.y, c = blockIdx.x, q = c * OFFS_CHUNK + threadIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned long long v = q < nq ? row_sum(kept_g + ((size_t)g * nq + q) * max_len, max_len) : 0ull;
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if (lane == 0u) wsum[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned long long t = 0; for (int w = 0; w < 16; ++w) t += wsum[w]; chunk_tot[(size_t)g * nchunks + c] = t; }
+}
+__global__ __launch_bounds__(1024) void shard_offsets_scan_kernel(unsigned long long* __restrict__ chunk_tot, uint32_t nchunks, unsigned long long* __restrict__ tot_dev,
+                                                                  unsigned long long* __restrict__ tot_host) {   // one workgroup per shard: exclusive scan of its chunk sums, in place
     __shared__ unsigned long long part[1024];
     const uint32_t g = blockIdx.x, t = threadIdx.x;
-    const uint32_t per = (nq + 1023u) / 1024u, q0 = min(t * per, nq), q1 = min(q0 + per, nq);
-    const uint32_t* kq = kept_g + (size_t)g * nq * max_len;
-    unsigned long long sum = 0;
-    for (uint32_t q = q0; q < q1; ++q) for (uint32_t j = 0; j < max_len; ++j) sum += kq[(size_t)q * max_len + j];
+    unsigned long long* ct = chunk_tot + (size_t)g * nchunks;
+    const uint32_t per = (nchunks + 1023u) / 1024u, c0 = min(t * per, nchunks), c1 = min(c0 + per, nchunks);
+    unsigned long long sum = 0; for (uint32_t c = c0; c < c1; ++c) sum += ct[c];
     part[t] = sum;
     __syncthreads();
-    for (uint32_t d = 1; d < 1024u; d <<= 1) {   // (Hillis-Steele over 1024 partial sums: 10 steps)
-        const unsigned long long v = t >= d ? part[t - d] : 0ull;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
+    for (uint32_t d = 1; d < 1024u; d <<= 1) { const unsigned long long v = t >= d ? part[t - d] : 0ull; __syncthreads(); part[t] += v; __syncthreads(); }
     unsigned long long run = part[t] - sum;
-    for (uint32_t q = q0; q < q1; ++q) {
-        off_g[(size_t)g * nq + q] = (long long)run;
-        for (uint32_t j = 0; j < max_len; ++j) run += kq[(size_t)q * max_len + j];
-    }
+    for (uint32_t c = c0; c < c1; ++c) { const unsigned long long v = ct[c]; ct[c] = run; run += v; }
     if (t == 1023u) { tot_dev[g] = part[1023]; if (tot_host) tot_host[g] = part[1023]; }
 }
+__global__ __launch_bounds__(1024) void shard_offsets_write_kernel(const uint32_t* __restrict__ kept_g, uint32_t nq, uint32_t max_len, uint32_t nchunks,
+                                                                   const unsigned long long* __restrict__ chunk_base, long long* __restrict__ off_g) {
+    __shared__ unsigned long long wsum[16];
+    const uint32_t g = blockIdx.y, c = blockIdx.x, q = c * OFFS_CHUNK + threadIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long v = q < nq ? row_sum(kept_g + ((size_t)g * nq + q) * max_len, max_len) : 0ull;
+    unsigned long long inc = v;   // inclusive scan inside the wave, then over the 16 waves
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long o = __shfl_up(inc, d); if ((int)lane >= d) inc += o; }
+    if (lane == 63u) wsum[wave] = inc;
+    __syncthreads();
+    unsigned long long before = chunk_base[(size_t)g * nchunks + c];
+    for (uint32_t w = 0; w < wave; ++w) before += wsum[w];
+    if (q < nq) off_g[(size_t)g * nq + q] = (long long)(before + inc - v);
+}
 hipError_t launch_shard_offsets(hipStream_t st, const uint32_t* kept_g, uint32_t nq, uint32_t max_len, uint32_t n_shards, long long* off_g, unsigned long long* tot_dev,
-                                unsigned long long* tot_host) {
-    hipLaunchKernelGGL(shard_offsets_kernel, dim3(n_shards), dim3(1024), 0, st, kept_g, nq, max_len, off_g, tot_dev, tot_host);
+                                unsigned long long* tot_host, unsigned long long* chunk_scratch) {   // chunk_scratch: n_shards * ceil(nq / 1024) words
+    const uint32_t nchunks = (nq + OFFS_CHUNK - 1) / OFFS_CHUNK;
+    hipLaunchKernelGGL(shard_offsets_sum_kernel, dim3(nchunks, n_shards), dim3(1024), 0, st, kept_g, nq, max_len, nchunks, chunk_scratch);
+    hipLaunchKernelGGL(shard_offsets_scan_kernel, dim3(n_shards), dim3(1024), 0, st, chunk_scratch, nchunks, tot_dev, tot_host);
+    hipLaunchKernelGGL(shard_offsets_write_kernel, dim3(nchunks, n_shards), dim3(1024), 0, st, kept_g, nq, max_len, nchunks, (const unsigned long long*)chunk_scratch, off_g);
     return hipGetLastError();
 }
 

@@ -128,14 +128,19 @@ def _rccl_worker(q):
         d_flat, d_off = _to_dev(flat, qoff)
         full = sa.VMISIndex.from_sessions(off, items, ts, 300, 40, 1.0)
         ix = sharded.ShardedVMISIndex.from_full(full, 0, 1)
+        os.environ["SRN_GROUP_NO_DIRECT"] = "1"          # a group of one shard reads its lists in place; this keeps the copy + grouped send / recv steps of a multi-rank run
         grp = sharded.ShardGroup.rccl(ix, 0, 1)          # ncclGetUniqueId + 2 x ncclCommInitRank inside the library
         res = []
         for rep in range(3):                             # three batches: both buffer slots, the overlapped exchange stream, resident inputs
             res.append(_np(grp.predict_batch(d_flat, d_off, len(qs), 6, 80, 300, 21, resident=(rep > 0))))
         st = grp.stats
+        del os.environ["SRN_GROUP_NO_DIRECT"]
+        grp2 = sharded.ShardGroup.rccl(ix, 0, 1)         # and the production form of a one-shard group: lists read in place, nothing exchanged
+        res.append(_np(grp2.predict_batch(d_flat, d_off, len(qs), 6, 80, 300, 21)))
+        assert grp2.stats["bytes_lists"] == 0 and st["bytes_lists"] > 0
         u = sa.predict_batch(full, (flat, qoff), 80, 300, 21, False)
         q.put((res, st, u))
-        grp.close()
+        grp.close(); grp2.close()
     except Exception as e:  # pragma: no cover
         import traceback
         q.put("error: %r\n%s" % (e, traceback.format_exc()))
