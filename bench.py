@@ -50,6 +50,27 @@ def algorithmic_bytes(stats):
     return 4 * s[:, 0] + 4 * s[:, 1] + 8 * s[:, 2] + 4 * s[:, 3] + 8 * s[:, 4] + 16 * s[:, 5] + 8 * s[:, 6]
 
 
+class c_stdout_to_stderr:
+    """RCCL prints a version banner through C stdio when a communicator is created; the contract of this script is ONE JSON line on stdout.  Inside the block
+    file descriptor 1 points at stderr, and the C library's buffers are flushed before it is restored."""
+
+    def __enter__(self):
+        import ctypes
+        sys.stdout.flush()
+        self.libc = ctypes.CDLL(None)
+        self.libc.fflush(None)
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        self.libc.fflush(None)
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def usable_cores():
     """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -129,7 +150,8 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    D.init("nccl", dev)   # RCCL; control plane only (barrier + max-over-ranks) unless --mode item-sharded
+    with c_stdout_to_stderr():
+        D.init("nccl", dev)   # RCCL; the process group is the control plane (barrier, max-over-ranks, the shard group's id); the data-path collectives are the library's own
 
     inter, n_items, k, m, idfw = synth.CONFIGS[args.config]
     how_many, last_items = synth.HOW_MANY, synth.LAST_ITEMS
@@ -150,7 +172,8 @@ def main():
         # every rank cuts ITS shard out of one unsharded index (built on its GPU or -- a production start -- loaded from one file: srn_index_load_shard)
         shard = SH.ShardedVMISIndex.from_full(index, rank, world, device=local_rank) if index is not None else \
             SH.ShardedVMISIndex(off, items, ts, m, 34, idfw, rank, world, device=local_rank)
-        group = SH.ShardGroup.rccl(shard, rank, world)      # RCCL communicators created inside the library; the id travels over the process group
+        with c_stdout_to_stderr():
+            group = SH.ShardGroup.rccl(shard, rank, world)  # RCCL communicators created inside the library; the id travels over the process group
         t_shard = time.time() - t0
     info = (index if index is not None else shard).info
     stream = torch.cuda.current_stream()
@@ -277,9 +300,10 @@ def main():
                            "sample": "first %d queries of the same batch, %d threads (%.1f s); oracle/vmis_oracle.cpp literal restatement" % (n_cpu, cores, r["elapsed"])}
                 shard_line["cpu_baseline"] = cpu
                 print(json.dumps(shard_line))
-            group.close()
-            if world > 1:
-                dist.destroy_process_group()
+            with c_stdout_to_stderr():
+                group.close()
+                if world > 1:
+                    dist.destroy_process_group()
             return
         del sbatches, s_out
 
@@ -327,10 +351,11 @@ def main():
     nq_last, general_last, global_last = index.last_path_counts()
 
     if rank != 0:
-        if group is not None:
-            group.close()
-        if world > 1:
-            dist.destroy_process_group()
+        with c_stdout_to_stderr():
+            if group is not None:
+                group.close()
+            if world > 1:
+                dist.destroy_process_group()
         return
 
     # ---- roofline of the dominant kernel: algorithmic bytes per launch / measured launch duration -------
@@ -471,10 +496,11 @@ def main():
         line["cpu_baseline"] = result["cpu_baseline"]
         result = line
     print(json.dumps(result))
-    if group is not None:
-        group.close()
-    if world > 1:
-        dist.destroy_process_group()
+    with c_stdout_to_stderr():
+        if group is not None:
+            group.close()
+        if world > 1:
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -66,16 +66,19 @@ private:
 };
 }  // namespace
 
-// Streams: the runtime maps HIP streams onto a few hardware queues, and its device-to-host copies into pinned memory are blit KERNELS (rocprofv3 timeline,
-// profiles/r03_hostpipe_timeline.txt: __amd_rocclr_copyBuffer, ~0.45 ms per 64 K queries' results).  A download enqueued on a stream of its own landed in the
-// same hardware queue as one of the two kernel streams, BEHIND the next chunk's kernels: the pipeline ran [kernels c, c+1][downloads c, c+1][kernels c+2, c+3] and
-// no download ever overlapped compute.  So a chunk is one in-order sequence on ONE stream -- upload, kernels, download -- and the overlap comes from the two kernel
-// streams: chunk c's download runs beside chunk c + 1's kernels.  Device staging is per stream (stream order protects it), pinned result staging has four slots
-// (the copy threads lag the GPU).
+// What the rocprofv3 timelines of three designs showed (profiles/r03_hostpipe_timeline.txt), and why the pipeline looks the way it does:
+//   * the runtime maps HIP streams onto a few hardware queues, and a download on a stream of its own may land in the SAME hardware queue as a kernel stream,
+//     behind the next chunk's kernels: with four streams (upload, two kernel streams, download) no download ever overlapped compute;
+//   * two kernel streams with equal chunks lock in phase -- a stream alone on the GPU runs faster and catches up with the other -- so both compute for ~3 ms and
+//     then both download for ~0.75 ms while no kernel runs; a staggered start re-synchronises within two chunks;
+//   * a batch cut into equal small chunks pays the launch sequence's fixed cost and its tail 16 times: 16 x 1.89 ms against 26.7 ms for one 2^20-query launch.
+// So: ONE kernel stream runs the chunks back to back, ONE other stream carries the downloads (two streams in all: two hardware queues), and the chunks SHRINK
+// geometrically -- half the batch, a quarter, an eighth ... -- so that the big launches run at the resident rate, every download and every copy into the caller's
+// buffers hides behind the kernels of the chunks that follow, and what is left exposed at the end is the smallest chunk's download and copy.
 struct HostPipe {
-    static constexpr int NOUT = 4;
-    hipStream_t s_k[2] = {nullptr, nullptr};
-    hipEvent_t e_in[2] = {}, e_out[NOUT] = {};
+    static constexpr int NOUT = 3;
+    hipStream_t s_k = nullptr, s_out = nullptr;
+    hipEvent_t e_in[2] = {}, e_k[2] = {}, e_out[NOUT] = {};
     char* pin_in[2] = {}; size_t pin_in_bytes[2] = {};
     char* pin_out[NOUT] = {}; size_t pin_out_bytes[NOUT] = {};
     char* dev_in[2] = {}; size_t dev_in_bytes[2] = {};
@@ -88,8 +91,9 @@ static void pipe_free(HostPipe* hp) {
     if (!hp) return;
     for (auto& p : hp->pending) CopyPool::wait(&p);
     for (int i = 0; i < 2; ++i) { if (hp->pin_in[i]) hipHostFree(hp->pin_in[i]); if (hp->dev_in[i]) hipFree(hp->dev_in[i]); if (hp->dev_out[i]) hipFree(hp->dev_out[i]);
-                                  if (hp->e_in[i]) hipEventDestroy(hp->e_in[i]); if (hp->s_k[i]) hipStreamDestroy(hp->s_k[i]); }
+                                  if (hp->e_in[i]) hipEventDestroy(hp->e_in[i]); if (hp->e_k[i]) hipEventDestroy(hp->e_k[i]); }
     for (int i = 0; i < HostPipe::NOUT; ++i) { if (hp->pin_out[i]) hipHostFree(hp->pin_out[i]); if (hp->e_out[i]) hipEventDestroy(hp->e_out[i]); }
+    if (hp->s_k) hipStreamDestroy(hp->s_k); if (hp->s_out) hipStreamDestroy(hp->s_out);
     delete hp;
 }
 void hostpipes_free(DeviceState* d) { for (HostPipe* hp : d->all_pipes) pipe_free(hp); d->all_pipes.clear(); d->free_pipes.clear(); }
@@ -97,8 +101,8 @@ void hostpipes_free(DeviceState* d) { for (HostPipe* hp : d->all_pipes) pipe_fre
 static HostPipe* pipe_acquire(DeviceState* d) {
     { std::lock_guard<std::mutex> lk(d->mu); if (!d->free_pipes.empty()) { HostPipe* hp = d->free_pipes.back(); d->free_pipes.pop_back(); return hp; } }
     HostPipe* hp = new HostPipe();
-    bool ok = true;
-    for (int i = 0; i < 2 && ok; ++i) ok = hipStreamCreateWithFlags(&hp->s_k[i], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&hp->e_in[i], hipEventDisableTiming) == hipSuccess;
+    bool ok = hipStreamCreateWithFlags(&hp->s_k, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&hp->s_out, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 2 && ok; ++i) ok = hipEventCreateWithFlags(&hp->e_in[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&hp->e_k[i], hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < HostPipe::NOUT && ok; ++i) ok = hipEventCreateWithFlags(&hp->e_out[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) { pipe_free(hp); return nullptr; }
     std::lock_guard<std::mutex> lk(d->mu); d->all_pipes.push_back(hp);
@@ -115,16 +119,28 @@ static int ensure_pinned(char** p, size_t* have, size_t need) {
     *have = need; return SRN_OK;
 }
 
-// how a host batch is cut: one chunk up to 8192 queries (a second chunk's launches cost more than its overlap buys), then chunks of ~16 K queries, at most
-// 64 K (and no chunk's results above ~32 MB of pinned staging): measured on config 3, profiles/r03_host_pipe_probe.txt
-uint32_t hostpipe_chunks(uint32_t nq, uint32_t how_many) {
+// How a host batch is cut (boundaries, in queries).  Up to 8192 queries: one chunk (a second launch sequence costs more than its overlap buys).  Above: half the
+// batch, then half of the rest (three quarters once fewer than 256 K queries are left) ... down to 8..16 K queries; no chunk's results above ~192 MB of pinned staging (large how_many).  SRN_HOST_CHUNKS = n forces n
+// equal chunks (experiments).
+std::vector<uint32_t> hostpipe_cuts(uint32_t nq, uint32_t how_many) {
     const Knobs kn = knobs();
-    if (kn.host_chunks > 0) return (uint32_t)std::min<uint64_t>(nq, (uint64_t)kn.host_chunks);
-    if (nq <= 8192) return 1;
-    const uint64_t chunk_max = std::min<uint64_t>(65536, std::max<uint64_t>(1024, (32ull << 20) / ((uint64_t)how_many * 16 + 4)));
-    const uint64_t by_max = (nq + chunk_max - 1) / chunk_max, by_16k = (nq + 16383) / 16384;
-    return (uint32_t)std::max<uint64_t>(2, std::min<uint64_t>(by_16k, std::max<uint64_t>(4, by_max)));
+    std::vector<uint32_t> starts{0};
+    if (kn.host_chunks > 0) {
+        const uint32_t nc = (uint32_t)std::min<uint64_t>(nq, (uint64_t)kn.host_chunks), csz = (nq + nc - 1) / nc;
+        for (uint64_t q = csz; q < nq; q += csz) starts.push_back((uint32_t)q);
+    } else if (nq > 8192) {
+        const uint64_t chunk_max = std::max<uint64_t>(4096, (192ull << 20) / ((uint64_t)how_many * 16 + 4));
+        uint64_t at = 0;
+        while (nq - at > 16384) {   // (below 256 K queries left: three quarters at a time -- few launches matter more than a short tail there)
+            const uint64_t left = nq - at;
+            const uint64_t take = std::min<uint64_t>(chunk_max, std::max<uint64_t>(8192, left >= 262144 ? left / 2 : left * 3 / 4));
+            at += take; starts.push_back((uint32_t)at);
+        }
+    }
+    starts.push_back(nq);
+    return starts;
 }
+uint32_t hostpipe_chunks(uint32_t nq, uint32_t how_many) { return (uint32_t)hostpipe_cuts(nq, how_many).size() - 1; }
 
 int device_predict_host_pipelined(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in, const uint64_t* h_items, const uint32_t* h_qoff,
                                   uint64_t* h_ids, double* h_scores, uint32_t* h_counts) {
@@ -134,20 +150,21 @@ int device_predict_host_pipelined(DeviceState* d, const FlatIndex& ix, const Lau
     bool good = false;
     struct Rel { DeviceState* d; HostPipe* hp; bool* good; ~Rel() {
         for (auto& pnd : hp->pending) CopyPool::wait(&pnd);
-        if (*good) pipe_release(d, hp);
-        else { hipStreamSynchronize(hp->s_k[0]); hipStreamSynchronize(hp->s_k[1]); pipe_release(d, hp); } } } rel{d, hp, &good};
+        if (!*good) { hipStreamSynchronize(hp->s_k); hipStreamSynchronize(hp->s_out); }
+        pipe_release(d, hp); } } rel{d, hp, &good};
     const uint32_t nq = p_in.nq, n = p_in.how_many;
     const Knobs kn = knobs();
     const auto t_start = std::chrono::steady_clock::now();
     auto now_us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count(); };
     double tr_in = 0, tr_enq = 0, tr_wait_out = 0, tr_wait_copy = 0, tr_submit = 0;
-    const uint32_t nchunks = hostpipe_chunks(nq, n);
-    const uint32_t csz = (uint32_t)(((uint64_t)nq + nchunks - 1) / nchunks);
+    const std::vector<uint32_t> starts = hostpipe_cuts(nq, n);
+    const uint32_t nchunks = (uint32_t)starts.size() - 1;
+    const bool one = nchunks == 1;   // a single chunk: everything in order on the kernel stream (no cross-stream hop: each costs ~10 us of a ~0.35 ms call)
     CopyPool& pool = CopyPool::get();
     auto out_bytes = [&](uint32_t cq) { return (size_t)cq * n * 16 + (size_t)cq * 4; };
     auto flush = [&](uint32_t c) -> int {   // chunk c's results: pinned staging -> the caller's buffers (asynchronous: the copy threads)
         const int o = (int)(c % HostPipe::NOUT);
-        const uint32_t q0 = c * csz, cq = std::min(csz, nq - q0);
+        const uint32_t q0 = starts[c], cq = starts[c + 1] - q0;
         double t0 = now_us();
         HIP_TRY(hipEventSynchronize(hp->e_out[o]));
         tr_wait_out += now_us() - t0; t0 = now_us();
@@ -160,28 +177,27 @@ int device_predict_host_pipelined(DeviceState* d, const FlatIndex& ix, const Lau
         tr_submit += now_us() - t0;
         return SRN_OK;
     };
-    constexpr uint32_t LAG = 2;      // the host collects chunk c - LAG after it has enqueued chunk c: two chunks stay queued on the GPU while it waits
+    hipStream_t sk = hp->s_k, sout = one ? hp->s_k : hp->s_out;
     for (uint32_t c = 0; c < nchunks; ++c) {
         const int i = (int)(c & 1u), o = (int)(c % HostPipe::NOUT);
-        const uint32_t q0 = c * csz, cq = std::min(csz, nq - q0);
-        if (q0 >= nq) break;
-        hipStream_t sk = hp->s_k[i];   // the chunk's ONE stream: upload, kernels, download in order
+        const uint32_t q0 = starts[c], cq = starts[c + 1] - q0;
         const size_t it0 = h_qoff[q0], it1 = h_qoff[q0 + cq], in_items = (it1 - it0) * 8, in_off = ((size_t)cq + 1) * 4, in_bytes = (in_items + 255) / 256 * 256 + in_off;
-        // input staging of chunk c - 2 has been read by its upload
+        const size_t ob = out_bytes(cq);
         double t0 = now_us();
+        // staging this chunk overwrites: the pinned input slot of chunk c - 2 (read by its upload), the device slots of chunk c - 2 (its kernels and its download)
         if (c >= 2) HIP_TRY(hipEventSynchronize(hp->e_in[i]));
         { int rc = ensure_pinned(&hp->pin_in[i], &hp->pin_in_bytes[i], in_bytes); if (rc) return rc; }
         memcpy(hp->pin_in[i], h_items + it0, in_items);
         memcpy(hp->pin_in[i] + (in_items + 255) / 256 * 256, h_qoff + q0, in_off);
         tr_in += now_us() - t0; t0 = now_us();
-        const size_t ob = out_bytes(cq);
-        if (hp->dev_in_bytes[i] < in_bytes || hp->dev_out_bytes[i] < ob) {   // (growing frees: the stream that uses the buffers must be idle)
-            HIP_TRY(hipStreamSynchronize(sk));
+        if (hp->dev_in_bytes[i] < in_bytes || hp->dev_out_bytes[i] < ob) {   // (growing frees: whatever uses the buffers must be idle)
+            HIP_TRY(hipStreamSynchronize(sk)); HIP_TRY(hipStreamSynchronize(sout));
             int rc = ensure(&hp->dev_in[i], &hp->dev_in_bytes[i], in_bytes); if (rc) return rc;
             rc = ensure(&hp->dev_out[i], &hp->dev_out_bytes[i], ob); if (rc) return rc;
         }
-        HIP_TRY(hipMemcpyAsync(hp->dev_in[i], hp->pin_in[i], in_bytes, hipMemcpyHostToDevice, sk));
+        HIP_TRY(hipMemcpyAsync(hp->dev_in[i], hp->pin_in[i], in_bytes, hipMemcpyHostToDevice, sk));   // (stream order: chunk c - 2's kernels are done with the slot)
         HIP_TRY(hipEventRecord(hp->e_in[i], sk));
+        if (!one && c >= 2) HIP_TRY(hipStreamWaitEvent(sk, hp->e_out[(c - 2) % HostPipe::NOUT], 0));   // device result slot: chunk c - 2's download is done
         LaunchParams p = p_in;
         p.nq = cq;
         p.items_flat = (const uint64_t*)hp->dev_in[i] - it0;   // (the chunk's offsets stay global: the base is shifted instead)
@@ -189,20 +205,22 @@ int device_predict_host_pipelined(DeviceState* d, const FlatIndex& ix, const Lau
         p.out_ids = (uint64_t*)hp->dev_out[i]; p.out_scores = (double*)(hp->dev_out[i] + (size_t)cq * n * 8); p.out_counts = (uint32_t*)(hp->dev_out[i] + (size_t)cq * n * 16);
         HIP_TRY(hipMemsetAsync(hp->dev_out[i], 0, (size_t)cq * n * 16, sk));   // the unused tail of each row reads as 0
         { int rc = device_predict(d, ix, p, true, sk, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr); if (rc) return rc; }
+        if (!one) HIP_TRY(hipEventRecord(hp->e_k[i], sk));
         // download: the pinned slot's previous contents (chunk c - NOUT) must have reached the caller's buffers
         tr_enq += now_us() - t0; t0 = now_us();
         CopyPool::wait(&hp->pending[o]);
         tr_wait_copy += now_us() - t0; t0 = now_us();
         { int rc = ensure_pinned(&hp->pin_out[o], &hp->pin_out_bytes[o], ob); if (rc) return rc; }
-        HIP_TRY(hipMemcpyAsync(hp->pin_out[o], hp->dev_out[i], ob, hipMemcpyDeviceToHost, sk));
-        HIP_TRY(hipEventRecord(hp->e_out[o], sk));
+        if (!one) HIP_TRY(hipStreamWaitEvent(sout, hp->e_k[i], 0));
+        HIP_TRY(hipMemcpyAsync(hp->pin_out[o], hp->dev_out[i], ob, hipMemcpyDeviceToHost, sout));
+        HIP_TRY(hipEventRecord(hp->e_out[o], sout));
         tr_enq += now_us() - t0;
-        if (c >= LAG) { int rc = flush(c - LAG); if (rc) return rc; }
+        if (c >= 1) { int rc = flush(c - 1); if (rc) return rc; }   // (chunk c is queued behind chunk c - 1's kernels: the GPU has work while the host waits here)
     }
-    { const uint32_t done = (nq + csz - 1) / csz; for (uint32_t c = done > LAG ? done - LAG : 0; c < done; ++c) { int rc = flush(c); if (rc) return rc; } }
+    { int rc = flush(nchunks - 1); if (rc) return rc; }
     { const double t0 = now_us(); for (auto& pnd : hp->pending) CopyPool::wait(&pnd); tr_wait_copy += now_us() - t0; }
-    if (kn.host_trace) fprintf(stderr, "[srn] host pipe: nq %u, %u chunks of %u: total %.0f us = input staging %.0f + enqueue %.0f + wait downloads %.0f + wait copy threads %.0f + submit %.0f\n",
-                               nq, nchunks, csz, now_us(), tr_in, tr_enq, tr_wait_out, tr_wait_copy, tr_submit);
+    if (kn.host_trace) fprintf(stderr, "[srn] host pipe: nq %u, %u chunks (first %u, last %u): total %.0f us = input staging %.0f + enqueue %.0f + wait downloads %.0f + wait copy threads %.0f + submit %.0f\n",
+                               nq, nchunks, starts[1], nq - starts[nchunks - 1], now_us(), tr_in, tr_enq, tr_wait_out, tr_wait_copy, tr_submit);
     good = true;
     return SRN_OK;
 }

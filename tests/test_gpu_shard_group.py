@@ -57,7 +57,8 @@ def test_local_group_matches_the_oracle_and_the_unsharded_path(n_shards):
         assert np.array_equal(got[0], u[0]) and np.array_equal(got[1], u[1]) and np.array_equal(got[2], u[2])     # and bit-identical to the unsharded HIP path
     st = grp.stats
     assert st["n_shards"] == n_shards and st["batches"] == 4 and st["queries"] == 4 * len(qs) and st["transport"] == 0
-    assert st["bytes_lists"] > 0 and st["bytes_lists_max_rank"] * n_shards >= st["bytes_lists"]
+    if n_shards > 1:                                   # (a group of ONE shard reads its lists in place: nothing is exchanged)
+        assert st["bytes_lists"] > 0 and st["bytes_lists_max_rank"] * n_shards >= st["bytes_lists"]
     # two batches back to back on one stream (the group alternates two buffer slots) and the reused-output form
     out = grp.predict_batch(d_flat, d_off, len(qs), 8, 100, 400, 21)
     out2 = grp.predict_batch(d_flat, d_off, len(qs), 8, 100, 400, 21, out=out)

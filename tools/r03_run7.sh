@@ -1,0 +1,4 @@
+#!/bin/bash
+R=$PWD; O=$R/gpurun_out/r03; mkdir -p $O
+timeout 600 python tools/host_pipe_probe.py cfg3 > $O/host_pipe_probe4.txt 2>&1
+grep -v "^\[srn\]" $O/host_pipe_probe4.txt | grep -v "slices"
