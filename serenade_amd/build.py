@@ -61,6 +61,29 @@ def build_hip(force=False, verbose=False):
     return LIB
 
 
+def build_variant(name, cflags, sources=("srn_fast.hip",)):
+    """Experiments: the library with `sources` recompiled under extra flags (e.g. -DSRN_FAST_REPLICAS=0), linked with the standard objects of everything else,
+    as serenade_amd/variants/libserenade_hip_<name>.so; SRN_LIB_PATH=<that file> makes capi load it.  A/B runs of kernel variants in ONE GPU call."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    build_hip()
+    objdir, vdir = os.path.join(CSRC, "_obj"), os.path.join(HERE, "variants")
+    os.makedirs(vdir, exist_ok=True)
+    objs = []
+    for n in SOURCES:
+        if n in sources:
+            obj = os.path.join(vdir, "%s.%s.o" % (n, name))
+            cmd = [hipcc, "--offload-arch=gfx950", "-Os" if n in ("srn_fast.hip", "srn_kernels.hip") else "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-value"]
+            if n in ("srn_fast.hip", "srn_kernels.hip"):
+                cmd += ["-mllvm", "-disable-machine-licm"]
+            subprocess.check_call(cmd + list(cflags) + ["-c", "-o", obj, os.path.join(CSRC, n)])
+            objs.append(obj)
+        else:
+            objs.append(os.path.join(objdir, n + ".o"))
+    out = os.path.join(vdir, "libserenade_hip_%s.so" % name)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out] + objs)
+    return out
+
+
 def build_synth(force=False):
     src = os.path.join(CSRC, "srn_synth.cpp")
     if force or _stale(SYNTH_LIB, [src]):

@@ -155,7 +155,7 @@ def lib():
     """Load the in-tree HIP library.  Fails loudly if it is missing: there is no fallback path."""
     global _lib
     if _lib is None:
-        path = _build.LIB
+        path = os.environ.get("SRN_LIB_PATH") or _build.LIB          # (SRN_LIB_PATH: a kernel variant built by build.build_variant, experiments only)
         if not os.path.exists(path):
             raise ImportError("libserenade_hip.so is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(there is no CPU fallback for the predict path)")

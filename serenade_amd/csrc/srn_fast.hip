@@ -57,8 +57,9 @@ static constexpr uint32_t F_MERGE_WORDS = F_WORK_WORDS;
 // 15 = index of the row's first 16-byte overflow block (8 items each, items 28..).  Unused positions hold offsets
 // into the dump area, spread by a hash of (row, position).  Slot n is the empty row.
 // -------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t fast_offset_of(uint32_t idx) {
-    return idx < F_HOT_WORDS ? idx * 4u : (F_SKETCH - F_HOT) + (idx & (F_SK_WORDS - 1u)) * 4u;
+__device__ __forceinline__ uint32_t fast_offset_of(uint32_t idx, uint64_t r) {   // r: the row (recency rank) -- picks the replica of a replicated item
+    if (idx < F_REP_ITEMS) return (F_DIRECT + idx * F_REP + ((uint32_t)r & (F_REP - 1u))) * 4u;
+    return idx < F_DIRECT ? idx * 4u : (F_SKETCH - F_HOT) + (idx & (F_SK_WORDS - 1u)) * 4u;
 }
 __device__ __forceinline__ uint32_t fast_phantom(uint64_t r, uint32_t j) {
     return (F_DUMP - F_HOT) + ((((uint32_t)r * 0x9E3779B1u + j * 0x85EBCA6Bu) >> 21) & (F_DUMP_WORDS - 1u)) * 4u;
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(1024) void rows_to_packed_kernel(const uint64_t* __
     if (r > n) return;
     const uint32_t inl = len > 30 ? 28u : (uint32_t)len;
     uint32_t sl[16];
-    auto half = [&](uint32_t j) -> uint32_t { return j < inl ? fast_offset_of(row_items[o + j]) : fast_phantom(r, j); };
+    auto half = [&](uint32_t j) -> uint32_t { return j < inl ? fast_offset_of(row_items[o + j], r) : fast_phantom(r, j); };
     sl[0] = (uint32_t)(len > 0xFFFFu ? 0xFFFFu : len);
 #pragma unroll
     for (uint32_t wd = 1; wd < 16; ++wd) sl[wd] = half(2 * wd - 2) | (half(2 * wd - 1) << 16);
@@ -91,8 +92,8 @@ __global__ __launch_bounds__(1024) void rows_to_packed_kernel(const uint64_t* __
 #pragma unroll
             for (uint32_t x = 0; x < 4; ++x) {
                 const uint64_t j0 = 28 + 8ull * b + 2 * x;
-                const uint32_t lo = j0 < len ? fast_offset_of(row_items[o + j0]) : fast_phantom(r, (uint32_t)j0);
-                const uint32_t hi = j0 + 1 < len ? fast_offset_of(row_items[o + j0 + 1]) : fast_phantom(r, (uint32_t)j0 + 1);
+                const uint32_t lo = j0 < len ? fast_offset_of(row_items[o + j0], r) : fast_phantom(r, (uint32_t)j0);
+                const uint32_t hi = j0 + 1 < len ? fast_offset_of(row_items[o + j0 + 1], r) : fast_phantom(r, (uint32_t)j0 + 1);
                 wv[x] = lo | (hi << 16);
             }
             reinterpret_cast<uint4*>(ext16)[(size_t)eblk + b] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(1024) void rows_to_packed_frag_kernel(const uint64_
     const uint32_t eblk = base + inc - e;
     if (r > n) return;
     const uint32_t inl = len > 6 ? 4u : (uint32_t)len;
-    auto half = [&](uint32_t j) -> uint32_t { return j < inl ? fast_offset_of(row_items[o + j]) : fast_phantom(r, j); };
+    auto half = [&](uint32_t j) -> uint32_t { return j < inl ? fast_offset_of(row_items[o + j], r) : fast_phantom(r, j); };
     uint32_t sl[4];
     sl[0] = (uint32_t)(len > 0xFFFFu ? 0xFFFFu : len);
 #pragma unroll
@@ -133,8 +134,8 @@ __global__ __launch_bounds__(1024) void rows_to_packed_frag_kernel(const uint64_
 #pragma unroll
             for (uint32_t x = 0; x < 4; ++x) {
                 const uint64_t j0 = 4 + 8ull * b + 2 * x;
-                const uint32_t lo = j0 < len ? fast_offset_of(row_items[o + j0]) : fast_phantom(r, (uint32_t)j0);
-                const uint32_t hi = j0 + 1 < len ? fast_offset_of(row_items[o + j0 + 1]) : fast_phantom(r, (uint32_t)j0 + 1);
+                const uint32_t lo = j0 < len ? fast_offset_of(row_items[o + j0], r) : fast_phantom(r, (uint32_t)j0);
+                const uint32_t hi = j0 + 1 < len ? fast_offset_of(row_items[o + j0 + 1], r) : fast_phantom(r, (uint32_t)j0 + 1);
                 wv[x] = lo | (hi << 16);
             }
             reinterpret_cast<uint4*>(ext16)[(size_t)eblk + b] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
@@ -527,7 +528,12 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         uint32_t t32m1; uint32_t floor_b;
         {
             const uint32_t e = lane * NW + wave;
-            const uint32_t v = hot[e];
+            uint32_t v = hot[e];
+            if (F_REP_ITEMS && e < F_REP_ITEMS) {   // a replicated item: its sum is spread over F_REP words (its own word stays 0)
+                const uint4* rp = reinterpret_cast<const uint4*>(hot + F_DIRECT + e * F_REP);
+                const uint4 a = rp[0], b = rp[1];
+                v = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+            }
             for (uint32_t i = tid; i < F_DUMP_WORDS; i += BLOCK) ((uint32_t*)(smem + F_DUMP))[i] = 0u;   // (walk B reads the dump words, where the positions past a row's end point, as "cannot reach the floor")
             bool valid = v != 0u && e != cur_idx;
             double x = 0.0; uint32_t tie = 0;
@@ -571,7 +577,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
                 const uint32_t e2 = (uint32_t)c * BLOCK + tid;
                 const uint32_t v2 = hot[e2];
                 if (e2 == F_HOT_WORDS - 1u) hot[e2] = 0u;   // (the word walk B reads for every popular item)
-                const bool pass = v2 >= fl && e2 != cur_idx;
+                const bool pass = v2 >= fl && e2 != cur_idx && e2 < F_DIRECT;   // (the words from F_DIRECT up are the replicas of the hottest items, already in the sample)
                 const uint32_t at2 = wave_append(pass, &misc[FS_SURV]);
                 if (pass) { if (at2 < SURV_CAP) surv[at2] = (e2 << 20) | v2; else atomicOr(&misc[FS_FAIL], 2u); }
             }
@@ -739,8 +745,8 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
                 if constexpr (FRAG) { if (j < len) it = len <= 3u ? os[1 + j] : (j < 2u ? os[2 + j] : ix.row_ext[os[1] + (j - 2u)]); }
                 else
                 if (j < len) it = len <= 15u ? os[1 + j] : (j < 14u ? os[2 + j] : ix.row_ext[os[1] + (j - 14u)]);
-                if (business && it != EMPTY32 && it >= F_HOT_WORDS && !business_ok(cur_attr, ix.meta[it].attr)) it = EMPTY32;   // (one more gather per listed element, all in flight together)
-                if (it != EMPTY32 && it >= F_HOT_WORDS && item_insert(ikeys, iacc, F_TABLE_BUCKETS, it, (int)w10t[h.x & NBM]) < 0) ovf = true;
+                if (business && it != EMPTY32 && it >= F_DIRECT && !business_ok(cur_attr, ix.meta[it].attr)) it = EMPTY32;   // (one more gather per listed element, all in flight together)
+                if (it != EMPTY32 && it >= F_DIRECT && item_insert(ikeys, iacc, F_TABLE_BUCKETS, it, (int)w10t[h.x & NBM]) < 0) ovf = true;
             }
             if (ovf) atomicOr(&misc[FS_FAIL], 8u);
         }

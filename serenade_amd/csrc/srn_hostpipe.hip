@@ -75,6 +75,13 @@ private:
 // So: ONE kernel stream runs the chunks back to back, ONE other stream carries the downloads (two streams in all: two hardware queues), and the chunks SHRINK
 // geometrically -- half the batch, a quarter, an eighth ... -- so that the big launches run at the resident rate, every download and every copy into the caller's
 // buffers hides behind the kernels of the chunks that follow, and what is left exposed at the end is the smallest chunk's download and copy.
+// An own download kernel with a FEW workgroups (experiment, SRN_D2H_BLOCKS = n): the runtime's device-to-host copy on the second stream is a blit kernel whose
+// grid fills the chip, and the next chunk's small launches wait for its waves to drain.  Measured, not kept as the default: 16..256 workgroups of plain 16-byte
+// stores into pinned memory reach 34..35 ms per 2^20 queries against 29.3 ms with hipMemcpyAsync (profiles/r03_host_pipe_probe.txt) -- the blit is the faster mover.
+__global__ __launch_bounds__(256) void d2h_copy_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 struct HostPipe {
     static constexpr int NOUT = 3;
     hipStream_t s_k = nullptr, s_out = nullptr;
@@ -115,7 +122,7 @@ static int ensure_pinned(char** p, size_t* have, size_t need) {
     if (*p) HIP_TRY(hipHostFree(*p));
     *p = nullptr; *have = 0;
     need = need + need / 8 + 4096;
-    HIP_TRY(hipHostMalloc((void**)p, need, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)p, need, hipHostMallocMapped));
     *have = need; return SRN_OK;
 }
 
@@ -212,7 +219,12 @@ int device_predict_host_pipelined(DeviceState* d, const FlatIndex& ix, const Lau
         tr_wait_copy += now_us() - t0; t0 = now_us();
         { int rc = ensure_pinned(&hp->pin_out[o], &hp->pin_out_bytes[o], ob); if (rc) return rc; }
         if (!one) HIP_TRY(hipStreamWaitEvent(sout, hp->e_k[i], 0));
-        HIP_TRY(hipMemcpyAsync(hp->pin_out[o], hp->dev_out[i], ob, hipMemcpyDeviceToHost, sout));
+        if (one || kn.d2h_blocks <= 0) HIP_TRY(hipMemcpyAsync(hp->pin_out[o], hp->dev_out[i], ob, hipMemcpyDeviceToHost, sout));
+        else {
+            char* dst_dev = nullptr; HIP_TRY(hipHostGetDevicePointer((void**)&dst_dev, hp->pin_out[o], 0));
+            hipLaunchKernelGGL(d2h_copy_kernel, dim3((unsigned)kn.d2h_blocks), dim3(256), 0, sout, (uint4*)dst_dev, (const uint4*)hp->dev_out[i], (ob + 15) / 16);
+            HIP_TRY(hipGetLastError());
+        }
         HIP_TRY(hipEventRecord(hp->e_out[o], sout));
         tr_enq += now_us() - t0;
         if (c >= 1) { int rc = flush(c - 1); if (rc) return rc; }   // (chunk c is queued behind chunk c - 1's kernels: the GPU has work while the host waits here)

@@ -53,6 +53,15 @@ static constexpr uint32_t F_HOT = 9216, F_SKETCH = F_HOT + F_HOT_WORDS * 4, F_DU
 // walk B's hit list -- (session slot, row position) pairs -- lives in the direct-mapped words, which are dead by then (walk B maps every
 // offset below the sketch to the LAST direct-mapped word, kept 0); exact table: prime number of 4-slot buckets, keys then sums
 static constexpr uint32_t F_HITS = F_HOT, F_HIT_CAP = F_HOT_WORDS / 2 - 1, F_ZERO_OFF = (F_HOT_WORDS - 1) * 4;
+// REPLICATED accumulators of the hottest items.  One 64-lane ds_add of walk A takes as many LDS cycles as its fullest bank has lanes, and adds to ONE address
+// serialise: on config 3 a tenth of all row elements are the most popular item, a simulation of the walk over real neighbour lists gives 6.6 LDS cycles per add
+// instruction against ~4.1 when the F_REP_ITEMS hottest items have F_REP words each, the word chosen by the ROW (its recency rank mod F_REP: fixed at attach time,
+// baked into the row slots' offsets -- no instruction in the walk).  The replicas take the top of the direct-mapped words (items F_DIRECT.. go to the sketch
+// instead), the harvest adds them up.
+#ifndef SRN_FAST_REPLICAS
+#define SRN_FAST_REPLICAS 1
+#endif
+static constexpr uint32_t F_REP_ITEMS = SRN_FAST_REPLICAS ? 16 : 0, F_REP = 8, F_DIRECT = F_HOT_WORDS - F_REP_ITEMS * F_REP;   // items < F_DIRECT have a word of their own
 static constexpr uint32_t F_SURV = F_TABLE + F_TABLE_WORDS * 8;          // survivors of the integer floors, packed (idx << 20 | acc), then the threshold histogram
 static constexpr uint32_t F_LDS_BYTES = F_SURV + F_SURV_WORDS * 4;
 static constexpr uint32_t F_WORK = F_NBL, F_WORK_WORDS = (F_LDS_BYTES - F_WORK) / 4;   // merge buffers: 2 * n_staged words

@@ -28,6 +28,7 @@ struct Knobs {
     int copy_slices = 0;      // SRN_COPY_SLICES: slices a result block is cut into for the copy threads (0 = one per thread)
     bool host_nocopy = false; // SRN_HOST_NOCOPY (experiments): the chunked host path leaves the results in its pinned staging
     bool host_trace = false;  // SRN_HOST_TRACE (experiments): per-call timeline of the chunked host path on stderr
+    int d2h_blocks = 0;       // SRN_D2H_BLOCKS: workgroups of the chunked host path's own download kernel (0 = hipMemcpyAsync, the default: measured faster, profiles/r03_host_pipe_probe.txt)
     int tiny_max = 256;       // SRN_TINY_MAX: host-pointer batches of up to this many sessions take the zero-copy latency path
     int lanes = 4;            // SRN_PREDICT_LANES: concurrent rounds of the srn_predict combiner (srn_combine.cpp)
     bool geometry_default() const { return !no_masks && !no_merge && !dense && hot_slots < 0 && sketch_slots < 0 && lds_budget_kb == 0; }

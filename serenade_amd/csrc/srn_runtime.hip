@@ -29,6 +29,7 @@ static void knobs_read() {
     if (const char* e = getenv("SRN_HOST_CHUNKS")) k.host_chunks = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_COPY_SLICES")) k.copy_slices = std::max(0, atoi(e));
     k.host_nocopy = getenv("SRN_HOST_NOCOPY") != nullptr; k.host_trace = getenv("SRN_HOST_TRACE") != nullptr;
+    if (const char* e = getenv("SRN_D2H_BLOCKS")) k.d2h_blocks = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_TINY_MAX")) k.tiny_max = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_PREDICT_LANES")) k.lanes = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_FAST_RUNS")) k.fast_runs = atoi(e) == 3 ? 3 : 0;   // tests: the fast kernel's 29-bit-rank form (3 lists per query) on a small index

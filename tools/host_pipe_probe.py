@@ -33,5 +33,5 @@ for nq, reps in ((1 << 20, 4), (65536, 8), (4096, 10)):
     for ch in (1, 2, 4, 8, 16, 32):
         if nq // ch >= 1024:
             run(nq, reps, "chunks=%d" % ch, SRN_HOST_CHUNKS=ch)
-    for sl in (1, 2, 8):
-        run(nq, reps, "copy slices=%d" % sl, SRN_COPY_SLICES=sl)
+    for blk in (0, 16, 32, 128, 256):
+        run(nq, reps, "download kernel blocks=%d" % blk, SRN_D2H_BLOCKS=blk)
