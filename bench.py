@@ -96,6 +96,7 @@ def main():
                          "replicas: every GPU holds the index and serves its own queries (no data-path collective); "
                          "item-sharded: the north star's partitioning, index split by item over the GPUs, srn_shard_group_predict_batch")
     ap.add_argument("--shard-batch", type=int, default=1 << 18, help="evolving sessions per item-sharded step (every rank sees the whole batch)")
+    ap.add_argument("--shard-timeout", type=int, default=900, help="seconds the item-sharded phase may take before the line falls back to the replicas mode alone")
     ap.add_argument("--selftest-launch", action="store_true", help="CPU check of the launcher and the control plane (gloo): no GPU, no timing")
     ap.add_argument("--builder", default="gpu", choices=["gpu", "host"], help="index construction: rocPRIM sorts on the GPU, or the host builder (same bytes)")
     ap.add_argument("--parity", type=int, default=2048, help="queries of batch 0 checked against the canonical oracle before anything is timed (0 = skip)")
@@ -172,8 +173,6 @@ def main():
         # every rank cuts ITS shard out of one unsharded index (built on its GPU or -- a production start -- loaded from one file: srn_index_load_shard)
         shard = SH.ShardedVMISIndex.from_full(index, rank, world, device=local_rank) if index is not None else \
             SH.ShardedVMISIndex(off, items, ts, m, 34, idfw, rank, world, device=local_rank)
-        with c_stdout_to_stderr():
-            group = SH.ShardGroup.rccl(shard, rank, world)  # RCCL communicators created inside the library; the id travels over the process group
         t_shard = time.time() - t0
     info = (index if index is not None else shard).info
     stream = torch.cuda.current_stream()
@@ -236,8 +235,13 @@ def main():
         return elapsed, np.array([a.elapsed_time(b) for a, b in ev])
 
     # =========================== item-sharded index over the N GPUs (srn_shard_group_*, RCCL inside the library) ===========================
-    shard_line = None
-    if do_shard:
+    def sharded_phase():
+        nonlocal group
+        t0g = time.time()
+        with c_stdout_to_stderr():
+            group = SH.ShardGroup.rccl(shard, rank, world)  # RCCL communicators created inside the library; the id travels over the process group
+        t_group = time.time() - t0g
+        shard_line = None
         Bs = args.shard_batch
         sbatches = draw_batches(Bs, args.pool, 0)                     # every rank sees the SAME batches
         s_out = (torch.empty((Bs, how_many), dtype=torch.int64, device=dev), torch.empty((Bs, how_many), dtype=torch.float64, device=dev),
@@ -280,7 +284,7 @@ def main():
                            "rccl_ranks": int(dist.get_world_size()) if world > 1 else 1, "transport": {0: "in-process", 1: "rccl", 2: "callbacks"}[st1["transport"]],
                            "exchange_overlapped_with_previous_batch": bool(st1["overlapped"]),
                            "items_on_rank0": int(shard.info["n_items"]), "index_bytes_hbm_rank0": int(shard.info["device_bytes"]),
-                           "setup_s": {"generate": round(t_gen, 2), "index_build_upload": round(t_build, 2), "shard_cut_attach_group": round(t_shard, 2)}},
+                           "setup_s": {"generate": round(t_gen, 2), "index_build_upload": round(t_build, 2), "shard_cut_attach": round(t_shard, 2), "group_create": round(t_group, 2)}},
                 "roofline": {"bound": "hbm", "kernel": "item-sharded step: list exchange + unsharded kernels over the rank's row fragments + top-n merge", "achieved": ach,
                              "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": ach / (HBM_PEAK_GBS * world), "traffic": None,
                              "algorithmic_bytes_per_query": bq_mean, "queries_per_launch": Bs,
@@ -289,213 +293,241 @@ def main():
                                                    "list_prefixes_fullest_rank": per_q["bytes_lists_max_rank"], "topn_all_gather": per_q["bytes_results"]},
                 "latency": {"step_ms_p50": float(np.percentile(s_step_ms, 50)), "step_ms_p90": float(np.percentile(s_step_ms, 90))},
                 "parity_checked": s_parity, "queries_served_last_step": s_served, "timed_batches": int(nb)})
-        if not do_rep:
-            if rank == 0:
-                cpu = None
-                if world == 1 and not args.no_cpu_baseline:
-                    cores = usable_cores()
-                    n_cpu = int(min(Bs, 4096))
-                    r = oracle_index().predict_batch("literal", sbatches[0][2][:sbatches[0][3][n_cpu]], sbatches[0][3][:n_cpu + 1], k, m, how_many, False, threads=cores, want_results=False)
-                    cpu = {"value": n_cpu / r["elapsed"], "unit": "queries/s", "cores": cores, "kind": "port",
-                           "sample": "first %d queries of the same batch, %d threads (%.1f s); oracle/vmis_oracle.cpp literal restatement" % (n_cpu, cores, r["elapsed"])}
-                shard_line["cpu_baseline"] = cpu
-                print(json.dumps(shard_line))
-            with c_stdout_to_stderr():
-                group.close()
-                if world > 1:
-                    dist.destroy_process_group()
-            return
-        del sbatches, s_out
+        return (shard_line if rank == 0 else None), sbatches
 
     # =========================== the whole index on every GPU: replicas, query-sharded (N = 1: THE bench line) ===========================
-    B = args.batch
-    batches = draw_batches(B, args.pool, rank)                        # every rank draws its own slice of the query stream
-    out_ids = torch.zeros(B * how_many, dtype=torch.int64, device=dev)
-    out_sc = torch.zeros(B * how_many, dtype=torch.float64, device=dev)
-    out_cnt = torch.zeros(B, dtype=torch.int32, device=dev)
-    _, _, flat0, qo0 = batches[0]
+    def replicas_phase():
+        B = args.batch
+        batches = draw_batches(B, args.pool, rank)                        # every rank draws its own slice of the query stream
+        out_ids = torch.zeros(B * how_many, dtype=torch.int64, device=dev)
+        out_sc = torch.zeros(B * how_many, dtype=torch.float64, device=dev)
+        out_cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+        _, _, flat0, qo0 = batches[0]
 
-    def step(i, nq=None):
-        d_flat, d_off, _, _ = batches[i % args.pool]
-        sa.predict_batch_device(index, d_flat.data_ptr(), d_off.data_ptr(), B if nq is None else nq, last_items, k, m, how_many, False,
-                                out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), stream.cuda_stream)
+        def step(i, nq=None):
+            d_flat, d_off, _, _ = batches[i % args.pool]
+            sa.predict_batch_device(index, d_flat.data_ptr(), d_off.data_ptr(), B if nq is None else nq, last_items, k, m, how_many, False,
+                                    out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), stream.cuda_stream)
 
-    # ---- 1. parity gate (rank 0; the other ranks wait at the barrier below) --------------------------------------------
-    parity_checked = 0
-    if rank == 0 and args.parity > 0:
-        n_par = int(min(B, args.parity))
-        step(0, n_par)
+        # ---- 1. parity gate (rank 0; the other ranks wait at the barrier below) --------------------------------------------
+        parity_checked = 0
+        if rank == 0 and args.parity > 0:
+            n_par = int(min(B, args.parity))
+            step(0, n_par)
+            torch.cuda.synchronize()
+            parity_checked = gate(out_ids.cpu().numpy().view(np.uint64).reshape(B, how_many)[:n_par], out_sc.cpu().numpy().reshape(B, how_many)[:n_par],
+                                  out_cnt.cpu().numpy().view(np.uint32)[:n_par], flat0, qo0, n_par, "whole index")
+        sa.reserve(index, B, last_items, k, m, how_many, False, stream.cuda_stream)   # size the stream's workspace up front (srn_index_reserve): no call of the run allocates
+        elapsed, step_ms = timed(step)
+        served = int((out_cnt.cpu().numpy().view(np.uint32) != 0xFFFFFFFF).sum())
+        # size-independent properties of the WHOLE last batch (the oracle gate above covers 2 048 queries): every row is a valid top-n list --
+        # count <= n, scores positive-or-not but non-increasing, equal scores in ascending id order, no item twice
+        cnt = out_cnt.to(torch.int64)
+        ok_rows = (cnt >= 0) & (cnt <= how_many)
+        col = torch.arange(how_many, device=dev).view(1, -1)
+        inside = col < cnt.view(-1, 1)
+        sc2 = out_sc.view(B, how_many); id2 = out_ids.view(B, how_many)
+        pair = inside[:, 1:] & inside[:, :-1]
+        desc = (~pair) | (sc2[:, :-1] > sc2[:, 1:]) | ((sc2[:, :-1] == sc2[:, 1:]) & ((id2[:, :-1] ^ torch.iinfo(torch.int64).min) < (id2[:, 1:] ^ torch.iinfo(torch.int64).min)))
+        srt = torch.sort(torch.where(inside, id2, torch.arange(how_many, device=dev).view(1, -1) - how_many - 1), dim=1).values   # (fillers: distinct negatives no real id... u64 ids as int64 may be negative: collisions only flag, never pass wrongly)
+        uniq = (srt[:, 1:] != srt[:, :-1]).all(dim=1)
+        props_ok = bool((ok_rows & desc.all(dim=1) & uniq).all().item())
+        if not props_ok:
+            print("bench.py: the last batch's results violate the top-n list properties", file=sys.stderr)
+            os._exit(1)
+
+        t_prep, t_fast, t_pred, t_retry = index.kernel_times_detail(min(64, args.steps))
+        nq_last, general_last, global_last = index.last_path_counts()
+
+        if rank != 0:
+            return None
+
+        # ---- roofline of the dominant kernel: algorithmic bytes per launch / measured launch duration -------
+        # per-query counters come from the general kernel's stats output (validated against the oracle in tests/)
+        nstat = min(B, 32768)
+        dbg = sa.predict_batch_debug(index, (flat0[:qo0[nstat]], qo0[:nstat + 1]), k, m, how_many, False, neighbours=False)
+        bq = algorithmic_bytes(dbg["stats"])
+        bytes_per_launch = float(bq.mean()) * B
+        fast_used = len(t_fast) > 0 and float(t_fast.mean()) > 0.0
+        fast_share = (nq_last - general_last) / float(nq_last) if fast_used else 0.0
+        kernel_ms = float(t_fast.mean()) if fast_used else float(t_pred.mean())
+        kernel_bytes = bytes_per_launch * (fast_share if fast_used else 1.0)
+        achieved = kernel_bytes / (kernel_ms * 1e-3) / 1e9
+        step_achieved = bytes_per_launch / (float(np.median(step_ms)) * 1e-3) / 1e9
+        retried = int((dbg["stats"][:, 7] == 1).sum())
+        # the measured-copy denominator: a device-to-device copy of 1 GiB in this run (read + write bytes per second)
+        src = torch.empty(1 << 28, dtype=torch.float32, device=dev); dst = torch.empty_like(src)
+        dst.copy_(src); torch.cuda.synchronize()
+        ce = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+        for a, b in ce:
+            a.record(stream); dst.copy_(src); b.record(stream)
         torch.cuda.synchronize()
-        parity_checked = gate(out_ids.cpu().numpy().view(np.uint64).reshape(B, how_many)[:n_par], out_sc.cpu().numpy().reshape(B, how_many)[:n_par],
-                              out_cnt.cpu().numpy().view(np.uint32)[:n_par], flat0, qo0, n_par, "whole index")
-    sa.reserve(index, B, last_items, k, m, how_many, False, stream.cuda_stream)   # size the stream's workspace up front (srn_index_reserve): no call of the run allocates
-    elapsed, step_ms = timed(step)
-    served = int((out_cnt.cpu().numpy().view(np.uint32) != 0xFFFFFFFF).sum())
-    # size-independent properties of the WHOLE last batch (the oracle gate above covers 2 048 queries): every row is a valid top-n list --
-    # count <= n, scores positive-or-not but non-increasing, equal scores in ascending id order, no item twice
-    cnt = out_cnt.to(torch.int64)
-    ok_rows = (cnt >= 0) & (cnt <= how_many)
-    col = torch.arange(how_many, device=dev).view(1, -1)
-    inside = col < cnt.view(-1, 1)
-    sc2 = out_sc.view(B, how_many); id2 = out_ids.view(B, how_many)
-    pair = inside[:, 1:] & inside[:, :-1]
-    desc = (~pair) | (sc2[:, :-1] > sc2[:, 1:]) | ((sc2[:, :-1] == sc2[:, 1:]) & ((id2[:, :-1] ^ torch.iinfo(torch.int64).min) < (id2[:, 1:] ^ torch.iinfo(torch.int64).min)))
-    srt = torch.sort(torch.where(inside, id2, torch.arange(how_many, device=dev).view(1, -1) - how_many - 1), dim=1).values   # (fillers: distinct negatives no real id... u64 ids as int64 may be negative: collisions only flag, never pass wrongly)
-    uniq = (srt[:, 1:] != srt[:, :-1]).all(dim=1)
-    props_ok = bool((ok_rows & desc.all(dim=1) & uniq).all().item())
-    if not props_ok:
-        print("bench.py: the last batch's results violate the top-n list properties", file=sys.stderr)
-        os._exit(1)
+        copy_gbs = 2.0 * src.numel() * 4 / (min(a.elapsed_time(b) for a, b in ce) * 1e-3) / 1e9
+        del src, dst
 
-    t_prep, t_fast, t_pred, t_retry = index.kernel_times_detail(min(64, args.steps))
-    nq_last, general_last, global_last = index.last_path_counts()
-
-    if rank != 0:
-        with c_stdout_to_stderr():
-            if group is not None:
-                group.close()
-            if world > 1:
-                dist.destroy_process_group()
-        return
-
-    # ---- roofline of the dominant kernel: algorithmic bytes per launch / measured launch duration -------
-    # per-query counters come from the general kernel's stats output (validated against the oracle in tests/)
-    nstat = min(B, 32768)
-    dbg = sa.predict_batch_debug(index, (flat0[:qo0[nstat]], qo0[:nstat + 1]), k, m, how_many, False, neighbours=False)
-    bq = algorithmic_bytes(dbg["stats"])
-    bytes_per_launch = float(bq.mean()) * B
-    fast_used = len(t_fast) > 0 and float(t_fast.mean()) > 0.0
-    fast_share = (nq_last - general_last) / float(nq_last) if fast_used else 0.0
-    kernel_ms = float(t_fast.mean()) if fast_used else float(t_pred.mean())
-    kernel_bytes = bytes_per_launch * (fast_share if fast_used else 1.0)
-    achieved = kernel_bytes / (kernel_ms * 1e-3) / 1e9
-    step_achieved = bytes_per_launch / (float(np.median(step_ms)) * 1e-3) / 1e9
-    retried = int((dbg["stats"][:, 7] == 1).sum())
-    # the measured-copy denominator: a device-to-device copy of 1 GiB in this run (read + write bytes per second)
-    src = torch.empty(1 << 28, dtype=torch.float32, device=dev); dst = torch.empty_like(src)
-    dst.copy_(src); torch.cuda.synchronize()
-    ce = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
-    for a, b in ce:
-        a.record(stream); dst.copy_(src); b.record(stream)
-    torch.cuda.synchronize()
-    copy_gbs = 2.0 * src.numel() * 4 / (min(a.elapsed_time(b) for a, b in ce) * 1e-3) / 1e9
-    del src, dst
-
-    # ---- 3. batch-size sweep: queries/s and p90 latency per batch size -----------------
-    sweep = []
-    lat_single = None
-    if not args.no_sweep and world == 1:
-        d_flat, d_off, _, _ = batches[0]
-        for s in [1, 16, 64, 256, 4096, 65536, 1 << 20]:
-            if s > B:
-                continue
-            reps = 30 if s <= 65536 else 10
-            for _ in range(3):
-                step(0, s)
-            torch.cuda.synchronize()
-            es = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-            for a, b in es:
-                a.record(stream); step(0, s); b.record(stream)
-            torch.cuda.synchronize()
-            dms = np.array([a.elapsed_time(b) for a, b in es])
-            hf, ho = flat0[:qo0[s]], qo0[:s + 1]
-            hms, hout = [], None
-            for _ in range(reps // 3 + 3):   # (the host keeps its result buffers between calls, like a serving / evaluator process: first call allocates, untimed)
+        # ---- 3. batch-size sweep: queries/s and p90 latency per batch size -----------------
+        sweep = []
+        lat_single = None
+        if not args.no_sweep and world == 1:
+            d_flat, d_off, _, _ = batches[0]
+            for s in [1, 16, 64, 256, 4096, 65536, 1 << 20]:
+                if s > B:
+                    continue
+                reps = 30 if s <= 65536 else 10
+                for _ in range(3):
+                    step(0, s)
+                torch.cuda.synchronize()
+                es = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+                for a, b in es:
+                    a.record(stream); step(0, s); b.record(stream)
+                torch.cuda.synchronize()
+                dms = np.array([a.elapsed_time(b) for a, b in es])
+                hf, ho = flat0[:qo0[s]], qo0[:s + 1]
+                hms, hout = [], None
+                for _ in range(reps // 3 + 3):   # (the host keeps its result buffers between calls, like a serving / evaluator process: first call allocates, untimed)
+                    t1 = time.perf_counter()
+                    hout = sa.predict_batch(index, (hf, ho), k, m, how_many, False, out=hout)
+                    hms.append((time.perf_counter() - t1) * 1e3)
+                hms = np.array(hms[2:])
+                sweep.append({"batch": s, "device_resident": {"queries_per_s": s / (float(np.median(dms)) * 1e-3), "ms_p50": float(np.median(dms)), "ms_p90": float(np.percentile(dms, 90))},
+                              "host_inclusive": {"queries_per_s": s / (float(np.median(hms)) * 1e-3), "ms_p50": float(np.median(hms)), "ms_p90": float(np.percentile(hms, 90))}})
+            lat = []
+            for i in range(300):   # the reference's call shape: one evolving session per call, host pointers (srn_predict)
+                q = flat0[qo0[i]:qo0[i + 1]]
                 t1 = time.perf_counter()
-                hout = sa.predict_batch(index, (hf, ho), k, m, how_many, False, out=hout)
-                hms.append((time.perf_counter() - t1) * 1e3)
-            hms = np.array(hms[2:])
-            sweep.append({"batch": s, "device_resident": {"queries_per_s": s / (float(np.median(dms)) * 1e-3), "ms_p50": float(np.median(dms)), "ms_p90": float(np.percentile(dms, 90))},
-                          "host_inclusive": {"queries_per_s": s / (float(np.median(hms)) * 1e-3), "ms_p50": float(np.median(hms)), "ms_p90": float(np.percentile(hms, 90))}})
-        lat = []
-        for i in range(300):   # the reference's call shape: one evolving session per call, host pointers (srn_predict)
-            q = flat0[qo0[i]:qo0[i + 1]]
-            t1 = time.perf_counter()
-            sa.predict(index, q, k, m, how_many, False)
-            lat.append((time.perf_counter() - t1) * 1e6)
-        lat_single = np.array(lat[50:])
+                sa.predict(index, q, k, m, how_many, False)
+                lat.append((time.perf_counter() - t1) * 1e6)
+            lat_single = np.array(lat[50:])
 
-    # HBM traffic per launch comes from separate rocprofv3 --pmc passes over this same command (tools/pmc_bench.sh);
-    # the committed summary is read back here so that the line carries it (null if no summary matches the workload)
-    traffic, traffic_src = None, None
-    try:
-        import glob
-        cand = [args.traffic_file] if args.traffic_file else sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*traffic_%s.json" % args.config)))
-        if cand:
-            tj = json.load(open(cand[-1]))
-            if tj.get("config") == args.config and tj.get("batch_per_gpu") == B:
-                traffic, traffic_src = tj["traffic_bytes_per_launch"], os.path.relpath(cand[-1], ROOT)
-    except Exception:
-        pass
+        # HBM traffic per launch comes from separate rocprofv3 --pmc passes over this same command (tools/pmc_bench.sh);
+        # the committed summary is read back here so that the line carries it (null if no summary matches the workload)
+        traffic, traffic_src = None, None
+        try:
+            import glob
+            cand = [args.traffic_file] if args.traffic_file else sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*traffic_%s.json" % args.config)))
+            if cand:
+                tj = json.load(open(cand[-1]))
+                if tj.get("config") == args.config and tj.get("batch_per_gpu") == B:
+                    traffic, traffic_src = tj["traffic_bytes_per_launch"], os.path.relpath(cand[-1], ROOT)
+        except Exception:
+            pass
 
-    result = dict(common)
-    result.update({
-        "value": args.gpus * args.steps * B / elapsed, "ms_per_step": elapsed / args.steps * 1e3, "scaling": "weak",
-        "config": {"workload": "BASELINE configs[2]: synthetic %d interactions / %d items, k=%d m=%d idf_weighting=%g "
-                               "last_items=%d how_many=%d" % (inter, n_items, k, m, idfw, last_items, how_many)
-                               if args.config == "cfg3" else "synth.CONFIGS[%s]" % args.config,
-                   "name": args.config, "batch_per_gpu": B, "query_pool_batches": args.pool,
-                   "sessions": int(info["n_sessions_kept"]), "items": int(info["n_items"]), "interactions": int(info["nnz_rows"]),
-                   "posting_entries": int(info["nnz_postings"]), "index_bytes_hbm": int(info["device_bytes"]),
-                   "parallelism": "query-sharded replicas x%d (no data-path collective)" % args.gpus,
-                   "setup_s": {"generate": round(t_gen, 2), "index_build_upload": round(t_build, 2), "index_builder": args.builder}},
-        "parity_checked": parity_checked, "full_batch_properties_ok": props_ok,
-        "roofline": {"bound": "hbm", "kernel": "vmis_fast_kernel" if fast_used else "vmis_predict_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE)",
-                     "frac_counter": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                     "frac_counter_note": "measured HBM traffic of the launch / its duration / 8 TB/s: what the memory system really moves (frac prices the contract's algorithmic bytes)",
-                     "traffic_source": traffic_src,
-                     "measured_copy_gbs": copy_gbs, "frac_measured_copy": achieved / copy_gbs,
-                     "algorithmic_bytes_per_query": float(bq.mean()), "queries_per_launch": B,
-                     "queries_served_by_this_kernel": int(nq_last - general_last) if fast_used else int(nq_last),
-                     "algorithmic_bytes_per_launch": kernel_bytes,
-                     "kernel_ms_avg": kernel_ms, "kernel_ms_min": float(t_fast.min()) if fast_used else float(t_pred.min()),
-                     "other_launches_ms_avg": {"prep_kernel": float(t_prep.mean()), "general_kernel_over_handed_over_queries_plus_finish_kernel": float((t_pred - t_fast).mean()) if fast_used else 0.0,
-                                               "global_table_retry_pass": float(t_retry.mean())},
-                     "queries_handed_to_general_kernel_last_step": int(general_last), "queries_via_global_table_pass_last_step": int(global_last),
-                     "whole_step": {"achieved": step_achieved, "frac": step_achieved / HBM_PEAK_GBS, "note": "all launches of a step (prep + fast + general + finish kernels) against the same algorithmic bytes"},
-                     "queries_via_global_table_pass_in_sample": retried, "stats_sample_queries": nstat},
-        "latency": {"step_ms_p50": float(np.percentile(step_ms, 50)), "step_ms_p90": float(np.percentile(step_ms, 90)),
-                    "single_query_us_p50": float(np.percentile(lat_single, 50)) if lat_single is not None else None,
-                    "single_query_us_p90": float(np.percentile(lat_single, 90)) if lat_single is not None else None,
-                    "batch_sweep": sweep,
-                    "note": "batch_sweep: srn_predict_batch_device on resident buffers (HIP events) vs srn_predict_batch on host buffers (pageable numpy arrays, result buffers "
-                            "reused between calls: upload + launches + download, wall clock; <= 256 sessions: zero-copy latency path, above: chunked pipeline); "
-                            "single_query = srn_predict (host pointers, one evolving session per call, PCIe-inclusive)"},
-        "queries_served_last_step": served,
-    })
+        result = dict(common)
+        result.update({
+            "value": args.gpus * args.steps * B / elapsed, "ms_per_step": elapsed / args.steps * 1e3, "scaling": "weak",
+            "config": {"workload": "BASELINE configs[2]: synthetic %d interactions / %d items, k=%d m=%d idf_weighting=%g "
+                                   "last_items=%d how_many=%d" % (inter, n_items, k, m, idfw, last_items, how_many)
+                                   if args.config == "cfg3" else "synth.CONFIGS[%s]" % args.config,
+                       "name": args.config, "batch_per_gpu": B, "query_pool_batches": args.pool,
+                       "sessions": int(info["n_sessions_kept"]), "items": int(info["n_items"]), "interactions": int(info["nnz_rows"]),
+                       "posting_entries": int(info["nnz_postings"]), "index_bytes_hbm": int(info["device_bytes"]),
+                       "parallelism": "query-sharded replicas x%d (no data-path collective)" % args.gpus,
+                       "setup_s": {"generate": round(t_gen, 2), "index_build_upload": round(t_build, 2), "index_builder": args.builder}},
+            "parity_checked": parity_checked, "full_batch_properties_ok": props_ok,
+            "roofline": {"bound": "hbm", "kernel": "vmis_fast_kernel" if fast_used else "vmis_predict_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE)",
+                         "frac_counter": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "frac_counter_note": "measured HBM traffic of the launch / its duration / 8 TB/s: what the memory system really moves (frac prices the contract's algorithmic bytes)",
+                         "traffic_source": traffic_src,
+                         "measured_copy_gbs": copy_gbs, "frac_measured_copy": achieved / copy_gbs,
+                         "algorithmic_bytes_per_query": float(bq.mean()), "queries_per_launch": B,
+                         "queries_served_by_this_kernel": int(nq_last - general_last) if fast_used else int(nq_last),
+                         "algorithmic_bytes_per_launch": kernel_bytes,
+                         "kernel_ms_avg": kernel_ms, "kernel_ms_min": float(t_fast.min()) if fast_used else float(t_pred.min()),
+                         "other_launches_ms_avg": {"prep_kernel": float(t_prep.mean()), "general_kernel_over_handed_over_queries_plus_finish_kernel": float((t_pred - t_fast).mean()) if fast_used else 0.0,
+                                                   "global_table_retry_pass": float(t_retry.mean())},
+                         "queries_handed_to_general_kernel_last_step": int(general_last), "queries_via_global_table_pass_last_step": int(global_last),
+                         "whole_step": {"achieved": step_achieved, "frac": step_achieved / HBM_PEAK_GBS, "note": "all launches of a step (prep + fast + general + finish kernels) against the same algorithmic bytes"},
+                         "queries_via_global_table_pass_in_sample": retried, "stats_sample_queries": nstat},
+            "latency": {"step_ms_p50": float(np.percentile(step_ms, 50)), "step_ms_p90": float(np.percentile(step_ms, 90)),
+                        "single_query_us_p50": float(np.percentile(lat_single, 50)) if lat_single is not None else None,
+                        "single_query_us_p90": float(np.percentile(lat_single, 90)) if lat_single is not None else None,
+                        "batch_sweep": sweep,
+                        "note": "batch_sweep: srn_predict_batch_device on resident buffers (HIP events) vs srn_predict_batch on host buffers (pageable numpy arrays, result buffers "
+                                "reused between calls: upload + launches + download, wall clock; <= 256 sessions: zero-copy latency path, above: chunked pipeline); "
+                                "single_query = srn_predict (host pointers, one evolving session per call, PCIe-inclusive)"},
+            "queries_served_last_step": served,
+        })
 
-    if args.gpus == 1 and not args.no_cpu_baseline:
-        # 4. the oracle is used here ONLY as the timed CPU baseline (literal restatement of the reference loops)
-        oix = oracle_index()
-        t_obuild = oracle_box["t_build"]
-        cores = usable_cores()
-        probe_n = min(B, 64 * cores)
-        r = oix.predict_batch("literal", flat0[:qo0[probe_n]], qo0[:probe_n + 1], k, m, how_many, False, threads=cores, want_results=False)
-        rate = probe_n / max(r["elapsed"], 1e-6)
-        n_cpu = int(min(B, max(probe_n, rate * args.cpu_seconds)))
-        r = oix.predict_batch("literal", flat0[:qo0[n_cpu]], qo0[:n_cpu + 1], k, m, how_many, False, threads=cores,
-                              want_results=False, want_latency=True)
-        lat_cpu = r["lat_us"]
-        result["cpu_baseline"] = {
-            "value": n_cpu / r["elapsed"], "unit": "queries/s", "cores": cores, "kind": "port",
-            "sample": "first %d queries of the same batch, %d threads over one shared read-only index (%.1f s); "
-                      "oracle/vmis_oracle.cpp literal restatement of the reference's Rust loops, not the Rust binary"
-                      % (n_cpu, cores, r["elapsed"]),
-            "per_call_us_p50": float(np.percentile(lat_cpu, 50)), "per_call_us_p90": float(np.percentile(lat_cpu, 90)),
-            "index_build_s": round(t_obuild, 2)}
-    else:
-        result["cpu_baseline"] = None
-    if shard_line is not None:
-        # N > 1, both modes: the line IS the north star's mode (item-sharded over RCCL); the replicas run is its ceiling
-        line = dict(shard_line)
-        line["replicas"] = {"value": result["value"], "ms_per_step": result["ms_per_step"], "scaling": "weak", "batch_per_gpu": B, "parallelism": result["config"]["parallelism"],
-                            "parity_checked": parity_checked, "full_batch_properties_ok": props_ok,
-                            "kernel": {kk: result["roofline"][kk] for kk in ("kernel", "achieved", "frac", "kernel_ms_avg", "algorithmic_bytes_per_query")},
-                            "note": "every GPU holds the whole index and serves its own slice of the query stream: no data-path collective, the throughput ceiling of any index that fits 288 GB"}
-        line["cpu_baseline"] = result["cpu_baseline"]
-        result = line
-    print(json.dumps(result))
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            # 4. the oracle is used here ONLY as the timed CPU baseline (literal restatement of the reference loops)
+            oix = oracle_index()
+            t_obuild = oracle_box["t_build"]
+            cores = usable_cores()
+            probe_n = min(B, 64 * cores)
+            r = oix.predict_batch("literal", flat0[:qo0[probe_n]], qo0[:probe_n + 1], k, m, how_many, False, threads=cores, want_results=False)
+            rate = probe_n / max(r["elapsed"], 1e-6)
+            n_cpu = int(min(B, max(probe_n, rate * args.cpu_seconds)))
+            r = oix.predict_batch("literal", flat0[:qo0[n_cpu]], qo0[:n_cpu + 1], k, m, how_many, False, threads=cores,
+                                  want_results=False, want_latency=True)
+            lat_cpu = r["lat_us"]
+            result["cpu_baseline"] = {
+                "value": n_cpu / r["elapsed"], "unit": "queries/s", "cores": cores, "kind": "port",
+                "sample": "first %d queries of the same batch, %d threads over one shared read-only index (%.1f s); "
+                          "oracle/vmis_oracle.cpp literal restatement of the reference's Rust loops, not the Rust binary"
+                          % (n_cpu, cores, r["elapsed"]),
+                "per_call_us_p50": float(np.percentile(lat_cpu, 50)), "per_call_us_p90": float(np.percentile(lat_cpu, 90)),
+                "index_build_s": round(t_obuild, 2)}
+        else:
+            result["cpu_baseline"] = None
+        result["_parity_checked"] = parity_checked; result["_props_ok"] = props_ok; result["_B"] = B
+        return result
+
+    # ---- the phases.  Replicas first (no data-path collective: nothing in it can hang on a peer); the item-sharded phase runs under a watchdog, and if it
+    # fails or stalls the line that is printed is the replicas' with the reason -- a SCALE run never ends without a line. ----
+    result = replicas_phase() if do_rep else None
+    shard_line, shard_error, sb = None, None, None
+    if do_shard:
+        import threading
+
+        def give_up():
+            if rank == 0:
+                line = dict(result) if result is not None else dict(common, value=None)
+                for kk in ("_parity_checked", "_props_ok", "_B"):
+                    line.pop(kk, None)
+                line["item_sharded_error"] = "the item-sharded phase did not finish within %d s; this line is the replicas mode alone" % args.shard_timeout
+                print(json.dumps(line)); sys.stdout.flush()
+            os._exit(0 if rank == 0 else 3)
+        wd = threading.Timer(args.shard_timeout + (0 if rank == 0 else 10), give_up)
+        wd.daemon = True
+        wd.start()
+        try:
+            shard_line, sb = sharded_phase()
+        except Exception as e:   # (RCCL missing, communicator creation failed, ...): say so in the line instead of dying without one
+            import traceback
+            traceback.print_exc()
+            shard_error = repr(e)
+        wd.cancel()
+    if rank == 0:
+        if result is not None:
+            parity_checked, props_ok, B = result.pop("_parity_checked"), result.pop("_props_ok"), result.pop("_B")
+        if do_shard and not do_rep:
+            line = shard_line if shard_line is not None else dict(common, value=None, item_sharded_error=shard_error)
+            cpu = None
+            if shard_line is not None and world == 1 and not args.no_cpu_baseline:
+                cores = usable_cores()
+                Bs = args.shard_batch
+                n_cpu = int(min(Bs, 4096))
+                r = oracle_index().predict_batch("literal", sb[0][2][:sb[0][3][n_cpu]], sb[0][3][:n_cpu + 1], k, m, how_many, False, threads=cores, want_results=False)
+                cpu = {"value": n_cpu / r["elapsed"], "unit": "queries/s", "cores": cores, "kind": "port",
+                       "sample": "first %d queries of the same batch, %d threads (%.1f s); oracle/vmis_oracle.cpp literal restatement" % (n_cpu, cores, r["elapsed"])}
+            line["cpu_baseline"] = cpu
+        elif do_shard:
+            if shard_line is not None:
+                # N > 1, both modes: the line IS the north star's mode (item-sharded over RCCL); the replicas run is its ceiling
+                line = dict(shard_line)
+                line["replicas"] = {"value": result["value"], "ms_per_step": result["ms_per_step"], "scaling": "weak", "batch_per_gpu": B, "parallelism": result["config"]["parallelism"],
+                                    "parity_checked": parity_checked, "full_batch_properties_ok": props_ok,
+                                    "kernel": {kk: result["roofline"][kk] for kk in ("kernel", "achieved", "frac", "kernel_ms_avg", "algorithmic_bytes_per_query")},
+                                    "note": "every GPU holds the whole index and serves its own slice of the query stream: no data-path collective, the throughput ceiling of any index that fits 288 GB"}
+                line["cpu_baseline"] = result["cpu_baseline"]
+            else:
+                line = dict(result)
+                line["item_sharded_error"] = shard_error
+        else:
+            line = result
+        print(json.dumps(line))
+        sys.stdout.flush()
     with c_stdout_to_stderr():
         if group is not None:
             group.close()
