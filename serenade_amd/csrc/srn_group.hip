@@ -159,7 +159,8 @@ void slot_free(Slot& s) {
 
 int group_init_common(srn_shard_group* g) {
     HIP_TRY(hipSetDevice(g->device));
-    HIP_TRY(hipStreamCreateWithFlags(&g->s_x, hipStreamNonBlocking));
+    { int prio_lo = 0, prio_hi = 0; (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // the exchange stream: highest priority = a hardware queue of its own, and its small kernels and RCCL's
+      HIP_TRY(hipStreamCreateWithPriority(&g->s_x, hipStreamNonBlocking, prio_hi)); }          // are dispatched ahead of the previous batch's persistent workgroups on the caller's stream
     HIP_TRY(hipEventCreateWithFlags(&g->e_in, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&g->e_x, hipEventDisableTiming));
     const uint32_t G = G_of(g);
     for (Slot& s : g->slot) {

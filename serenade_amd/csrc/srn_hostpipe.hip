@@ -108,7 +108,12 @@ void hostpipes_free(DeviceState* d) { for (HostPipe* hp : d->all_pipes) pipe_fre
 static HostPipe* pipe_acquire(DeviceState* d) {
     { std::lock_guard<std::mutex> lk(d->mu); if (!d->free_pipes.empty()) { HostPipe* hp = d->free_pipes.back(); d->free_pipes.pop_back(); return hp; } }
     HostPipe* hp = new HostPipe();
-    bool ok = hipStreamCreateWithFlags(&hp->s_k, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&hp->s_out, hipStreamNonBlocking) == hipSuccess;
+    // The download stream gets the HIGHEST priority: priority classes have hardware queues of their own, so it cannot end up in the kernel stream's queue (where the
+    // download would wait behind the next chunk's kernels: seen in a process that had created a handful of other streams before -- 34.5 ms per 2^20 queries instead of
+    // 28.3), and its blit kernel is dispatched ahead of the fast kernel's next workgroups.
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    bool ok = hipStreamCreateWithFlags(&hp->s_k, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithPriority(&hp->s_out, hipStreamNonBlocking, prio_hi) == hipSuccess;
     for (int i = 0; i < 2 && ok; ++i) ok = hipEventCreateWithFlags(&hp->e_in[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&hp->e_k[i], hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < HostPipe::NOUT && ok; ++i) ok = hipEventCreateWithFlags(&hp->e_out[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) { pipe_free(hp); return nullptr; }
@@ -126,7 +131,8 @@ static int ensure_pinned(char** p, size_t* have, size_t need) {
     *have = need; return SRN_OK;
 }
 
-// How a host batch is cut (boundaries, in queries).  Up to 8192 queries: one chunk (a second launch sequence costs more than its overlap buys).  Above: half the
+// How a host batch is cut (boundaries, in queries).  Up to 65 536 queries: one chunk (a second launch sequence costs more than its overlap buys: 2.69 ms in one
+// chunk against 2.81 in two, profiles/r03_host_pipe_probe.txt).  Above: half the
 // batch, then half of the rest (three quarters once fewer than 256 K queries are left) ... down to 8..16 K queries; no chunk's results above ~192 MB of pinned staging (large how_many).  SRN_HOST_CHUNKS = n forces n
 // equal chunks (experiments).
 std::vector<uint32_t> hostpipe_cuts(uint32_t nq, uint32_t how_many) {
@@ -135,7 +141,7 @@ std::vector<uint32_t> hostpipe_cuts(uint32_t nq, uint32_t how_many) {
     if (kn.host_chunks > 0) {
         const uint32_t nc = (uint32_t)std::min<uint64_t>(nq, (uint64_t)kn.host_chunks), csz = (nq + nc - 1) / nc;
         for (uint64_t q = csz; q < nq; q += csz) starts.push_back((uint32_t)q);
-    } else if (nq > 8192) {
+    } else if (nq > 65536) {
         const uint64_t chunk_max = std::max<uint64_t>(4096, (192ull << 20) / ((uint64_t)how_many * 16 + 4));
         uint64_t at = 0;
         while (nq - at > 16384) {   // (below 256 K queries left: three quarters at a time -- few launches matter more than a short tail there)

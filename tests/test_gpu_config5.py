@@ -108,7 +108,7 @@ def test_config5_full_size(monkeypatch):
     assert np.array_equal(g_cnt[:nc], oref["counts"]) and np.array_equal(g_ids[:nc][mask], oref["ids"][mask])          # the sharded path against the ORACLE, directly
     np.testing.assert_allclose(g_sc[:nc][mask], oref["scores"][mask], rtol=SCORE_RTOL, atol=0)
     st8 = grp.stats
-    print("\\nconfig 5: index built on the GPU + attached %.1f s (%.1f GB in HBM), restricted oracle index %.1f s, 8 shards cut + attached %.1f s (%.1f GB each), "
+    print("\nconfig 5: index built on the GPU + attached %.1f s (%.1f GB in HBM), restricted oracle index %.1f s, 8 shards cut + attached %.1f s (%.1f GB each), "
           "lists exchanged %.0f B per query; whole test %.0f s" % (t_build, info["device_bytes"] / 1e9, t_oracle, t_cut, shards[0].info["device_bytes"] / 1e9,
                                                                    st8["bytes_lists"] / max(1, st8["queries"]), time.time() - t_all))
     grp.close()
