@@ -150,8 +150,11 @@ __global__ __launch_bounds__(1024) void rows_to_packed_frag_kernel(const uint64_
 // A thread's binary search on its diagonal costs ~11 round trips whatever g is, so a pair is merged by only as many waves as give
 // every thread ~8 outputs (merge_team): the searches of the other waves would be pure overhead.
 // -------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t merge_team(uint32_t total) {   // log2 of the team size: 64 .. 512 threads, >= total / 8
-    const uint32_t want = (total + 7u) >> 3;
+#ifndef SRN_MERGE_G
+#define SRN_MERGE_G 8   // outputs per thread a merge team is sized for
+#endif
+__device__ __forceinline__ uint32_t merge_team(uint32_t total) {   // log2 of the team size: 64 .. 512 threads, >= total / SRN_MERGE_G
+    const uint32_t want = (total + (uint32_t)SRN_MERGE_G - 1u) / (uint32_t)SRN_MERGE_G;
     return want <= 64u ? 6u : want <= 128u ? 7u : want <= 256u ? 8u : 9u;
 }
 __device__ __forceinline__ void merge_pair(const uint32_t* in, uint32_t* out, uint32_t sa, uint32_t la, uint32_t lb, uint32_t ttid, uint32_t lg_nthr) {
