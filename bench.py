@@ -96,6 +96,9 @@ def main():
                          "replicas: every GPU holds the index and serves its own queries (no data-path collective); "
                          "item-sharded: the north star's partitioning, index split by item over the GPUs, srn_shard_group_predict_batch")
     ap.add_argument("--shard-batch", type=int, default=1 << 18, help="evolving sessions per item-sharded step (every rank sees the whole batch)")
+    ap.add_argument("--resident-flag", action="store_true", help="call srn_predict_batch_device with SRN_FLAG_INPUTS_RESIDENT (a step's prep kernel then runs beside the previous "
+                    "step's kernels; measured on config 3: the prep kernel's 0.44 ms disappear from the step but the fast kernel slows down by 0.7 ms -- 40.5 M against 41.3 M queries/s -- "
+                    "so it is off by default)")
     ap.add_argument("--shard-timeout", type=int, default=900, help="seconds the item-sharded phase may take before the line falls back to the replicas mode alone")
     ap.add_argument("--selftest-launch", action="store_true", help="CPU check of the launcher and the control plane (gloo): no GPU, no timing")
     ap.add_argument("--builder", default="gpu", choices=["gpu", "host"], help="index construction: rocPRIM sorts on the GPU, or the host builder (same bytes)")
@@ -307,7 +310,7 @@ def main():
         def step(i, nq=None):
             d_flat, d_off, _, _ = batches[i % args.pool]
             sa.predict_batch_device(index, d_flat.data_ptr(), d_off.data_ptr(), B if nq is None else nq, last_items, k, m, how_many, False,
-                                    out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), stream.cuda_stream)
+                                    out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), stream.cuda_stream, resident=args.resident_flag)
 
         # ---- 1. parity gate (rank 0; the other ranks wait at the barrier below) --------------------------------------------
         parity_checked = 0

@@ -160,7 +160,9 @@ int srn_predict_batch(const srn_index_t* idx, const uint64_t* items_flat, const 
 /* Same with every buffer already resident in the index's device memory, enqueued on `stream`
  * (a hipStream_t; NULL = the null stream) without host synchronisation.  max_len_hint must be
  * >= the longest session in the batch (<= SRN_MAX_SESSION_LEN).  A query the kernel cannot serve
- * (empty or over-long session) gets out_counts[q] = 0xFFFFFFFF. */
+ * (empty or over-long session) gets out_counts[q] = 0xFFFFFFFF.  flags: SRN_FLAG_BUSINESS_LOGIC, SRN_FLAG_INPUTS_RESIDENT
+ * (the prep kernel of this call then runs beside the previous call's kernels; for back-to-back full batches that was measured as a LOSS -- the prep kernel's
+ * 0.44 ms per 2^20 queries disappear but the concurrent random look-ups slow vmis_fast_kernel by 0.7 ms -- it pays where the previous call leaves the GPU idle). */
 int srn_predict_batch_device(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off,
                              size_t nq, size_t max_len_hint, size_t k, size_t m, size_t how_many,
                              unsigned flags, uint64_t* d_out_ids, double* d_out_scores,
@@ -275,7 +277,8 @@ int srn_shard_lists_predict(const srn_index_t* idx, const uint64_t* d_items_flat
  *   per batch, every rank:   srn_shard_group_predict_batch(group, d_items, d_q_off, nq, ...)
  */
 #define SRN_SHARD_GROUP_ID_BYTES 256
-#define SRN_FLAG_INPUTS_RESIDENT 2u /* srn_shard_group_predict_batch: d_items_flat / d_q_off are complete in device memory at call time (not pending on `stream`) */
+#define SRN_FLAG_INPUTS_RESIDENT 2u /* srn_shard_group_predict_batch, srn_predict_batch_device: d_items_flat / d_q_off are complete in device memory at call time (not pending on `stream`):
+                                     * the call's first small kernels may then run on a stream of the library's own, beside the previous call's kernels */
 typedef struct srn_shard_group srn_shard_group_t;
 int srn_shard_group_unique_id(void* out, size_t bytes);
 int srn_shard_group_create(const srn_index_t* shard, const void* unique_id, int rank, int world, srn_shard_group_t** out);

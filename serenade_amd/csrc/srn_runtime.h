@@ -58,6 +58,8 @@ struct Workspace {
     char* stage = nullptr; size_t stage_bytes = 0;
     uint32_t* h_retry = nullptr;   // pinned
     hipEvent_t ev_block = nullptr; // blocking-sync event of the latency path (rounds shared by several callers)
+    // SRN_FLAG_INPUTS_RESIDENT: this call's prep kernel on a side stream, beside the previous call's kernels (two sets of prep records)
+    hipStream_t side = nullptr; hipEvent_t ev_prep[2] = {}, ev_done[2] = {}; char* prep2 = nullptr; size_t prep2_bytes = 0; uint64_t resident_calls = 0;
 };
 
 struct DeviceState {

@@ -162,6 +162,9 @@ static void ws_free(Workspace* w) {
     if (w->stage) hipFree(w->stage);
     if (w->h_retry) hipHostFree(w->h_retry);
     if (w->ev_block) hipEventDestroy(w->ev_block);
+    if (w->prep2) hipFree(w->prep2);
+    for (int i = 0; i < 2; ++i) { if (w->ev_prep[i]) hipEventDestroy(w->ev_prep[i]); if (w->ev_done[i]) hipEventDestroy(w->ev_done[i]); }
+    if (w->side) hipStreamDestroy(w->side);
     for (auto& t : w->ev) for (auto& e : t) if (e) hipEventDestroy(e);
     if (w->stream) hipStreamDestroy(w->stream);
     delete w;
@@ -369,6 +372,10 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     HIP_TRY(hipSetDevice(d->device));
     LaunchParams p = p_in;
     if (p.nq == 0) return SRN_OK;
+    // SRN_FLAG_INPUTS_RESIDENT (device-pointer calls): the query buffers are complete in device memory at call time, so the prep kernel of THIS call may run on a side
+    // stream while the previous call's kernels still occupy the caller's stream (see below); the kernels never see the flag
+    const bool resident = on_device && !ext && (p.flags & SRN_FLAG_INPUTS_RESIDENT) != 0u;
+    p.flags &= ~(unsigned)SRN_FLAG_INPUTS_RESIDENT;
     // item-sharded index, lists mode (device_shard_lists_*): the posting lists of ALL shards for this batch arrive in one gathered
     // buffer with the prep records already written against it; everything below runs unchanged on "an index whose postings live there"
     DeviceIndex di = d->di;
@@ -454,6 +461,14 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     char* spill = w->spill;
     const uint32_t prep_stride = (uint32_t)(sizeof(PrepHead) + (size_t)p.max_len * sizeof(PrepItem));
     if (!ext) { int rc = ensure(&w->prep, &w->prep_bytes, (size_t)p.nq * prep_stride); if (rc) return rc; }
+    if (resident) {   // a second set of prep records: call i + 1's prep kernel runs while call i's kernels still read theirs
+        int rc = ensure(&w->prep2, &w->prep2_bytes, (size_t)p.nq * prep_stride); if (rc) return rc;
+        if (!w->side) {
+            int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            HIP_TRY(hipStreamCreateWithPriority(&w->side, hipStreamNonBlocking, hi));   // (highest priority: a hardware queue of its own, dispatched ahead of the running call's persistent workgroups)
+            for (int i = 0; i < 2; ++i) { HIP_TRY(hipEventCreateWithFlags(&w->ev_prep[i], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&w->ev_done[i], hipEventDisableTiming)); }
+        }
+    }
     // the fast kernel packs (rank, set of <= 4 lists) into 32 bits whatever the general kernel's slots look like: up to 2^28 sessions with 4 lists per query,
     // up to 2^29 with 3 (queries with more go to the general kernel)
     const int rank_bits_f = std::max(1, bits_host(ix.n_kept ? ix.n_kept - 1 : 0));
@@ -472,6 +487,16 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     hipEvent_t* ev = w->ev[w->calls % Workspace::RING];
     HIP_TRY(hipEventRecord(ev[0], st));
     if (ext) { if (ext->prep_stride != prep_stride) return fail(SRN_EINVAL, "prep record stride mismatch"); p.prep = ext->prep; p.prep_stride = prep_stride; }
+    else if (resident) {
+        // prep of this call on the side stream: behind the call that used this set of records two calls ago, beside the previous call's kernels
+        const int par = (int)(w->resident_calls & 1u);
+        char* rec = par ? w->prep2 : w->prep;
+        if (w->resident_calls >= 2) HIP_TRY(hipStreamWaitEvent(w->side, w->ev_done[par], 0));
+        HIP_TRY(launch_prep(w->side, di, p.items_flat, p.q_off, p.nq, p.m, p.max_len, rec, prep_stride));
+        HIP_TRY(hipEventRecord(w->ev_prep[par], w->side));
+        HIP_TRY(hipStreamWaitEvent(st, w->ev_prep[par], 0));
+        p.prep = rec; p.prep_stride = prep_stride;
+    }
     else { HIP_TRY(launch_prep(st, di, p.items_flat, p.q_off, p.nq, p.m, p.max_len, w->prep, prep_stride)); p.prep = w->prep; p.prep_stride = prep_stride; }
     HIP_TRY(hipEventRecord(ev[3], st));
     const uint32_t* final_list = w->retry_list; uint32_t* final_cnt = w->retry_cnt;
@@ -511,6 +536,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     if (fast) HIP_TRY(hipMemcpyAsync(w->h_retry + 1, w->slow_cnt, 4, hipMemcpyDeviceToHost, st));   // (not fast: last_fast = false says "all of last_nq" -- no host write into a
                                                                                                    //  pinned word that an earlier call's copy on this stream may still be writing)
     HIP_TRY(hipEventRecord(ev[2], st));
+    if (resident) { HIP_TRY(hipEventRecord(w->ev_done[w->resident_calls & 1u], st)); ++w->resident_calls; }
     ++w->calls; w->last_retry = (may_overflow || dense) ? 1 : 0; w->last_nq = p.nq; w->last_fast = fast; w->last_untimed = false;
 
     if (!on_device) {

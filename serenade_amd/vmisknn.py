@@ -207,11 +207,12 @@ def reserve(index, nq, max_len, k, m, how_many, enable_business_logic=False, str
 
 
 def predict_batch_device(index, d_items_flat, d_q_off, nq, max_len, k, m, how_many, enable_business_logic,
-                         d_out_ids, d_out_scores, d_out_counts, stream=0):
+                         d_out_ids, d_out_scores, d_out_counts, stream=0, resident=False):
     """Device-resident variant: arguments are raw device addresses (e.g. torch.Tensor.data_ptr()) on the
-    index's GPU and a hipStream_t handle (e.g. torch.cuda.current_stream().cuda_stream); asynchronous."""
+    index's GPU and a hipStream_t handle (e.g. torch.cuda.current_stream().cuda_stream); asynchronous.  resident=True (SRN_FLAG_INPUTS_RESIDENT):
+    the query buffers are complete in device memory now, not pending on `stream`."""
     capi.check(capi.lib().srn_predict_batch_device(index._h, C.c_void_p(d_items_flat), C.c_void_p(d_q_off), int(nq),
                                                    int(max_len), int(k), int(m), int(how_many),
-                                                   capi.FLAG_BUSINESS_LOGIC if enable_business_logic else 0,
+                                                   (capi.FLAG_BUSINESS_LOGIC if enable_business_logic else 0) | (capi.FLAG_INPUTS_RESIDENT if resident else 0),
                                                    C.c_void_p(d_out_ids), C.c_void_p(d_out_scores),
                                                    C.c_void_p(d_out_counts), C.c_void_p(stream)))

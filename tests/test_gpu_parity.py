@@ -352,6 +352,40 @@ def test_device_pointer_entry_point_matches_host_entry_point():
         assert np.array_equal(sc_d[q, :c], sc_h[q, :c])
 
 
+def test_resident_inputs_flag_overlaps_prep_and_changes_nothing():
+    """SRN_FLAG_INPUTS_RESIDENT on srn_predict_batch_device: the call's prep kernel runs on the library's own stream beside the previous call's kernels (two sets of prep
+    records alternate).  Many calls back to back without a host synchronisation, three different batches in rotation, each into its own result buffers: every call's
+    rows equal the flag-less call's."""
+    torch = pytest.importorskip("torch")
+    import serenade_amd as sa
+    from serenade_amd import synth
+    inter, n_items, k, m, idfw = synth.CONFIGS["tiny"]
+    off, items, ts = synth.training_sessions(inter, n_items)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw)
+    dev = torch.device("cuda:0")
+    n = synth.HOW_MANY
+    batches = []
+    for b in range(3):
+        qi, qo = synth.queries(2500, n_items, seed=synth.SEED + 101 * (b + 1))
+        nq = len(qo) - 1
+        ref = sa.predict_batch(gix, (qi, qo), k, m, n)
+        batches.append((torch.from_numpy(qi.view(np.int64).copy()).to(dev), torch.from_numpy(qo.view(np.int32).copy()).to(dev), nq, ref))
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream()
+    outs = []
+    for rep in range(9):
+        d_flat, d_off, nq, _ = batches[rep % 3]
+        o = (torch.zeros(nq * n, dtype=torch.int64, device=dev), torch.zeros(nq * n, dtype=torch.float64, device=dev), torch.zeros(nq, dtype=torch.int32, device=dev))
+        sa.predict_batch_device(gix, d_flat.data_ptr(), d_off.data_ptr(), nq, synth.LAST_ITEMS, k, m, n, False, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(),
+                                stream.cuda_stream, resident=True)
+        outs.append(o)
+    stream.synchronize()
+    for rep, o in enumerate(outs):
+        nq, ref = batches[rep % 3][2], batches[rep % 3][3]
+        assert np.array_equal(o[2].cpu().numpy().view(np.uint32), ref[2]), rep
+        assert np.array_equal(o[0].cpu().numpy().view(np.uint64).reshape(nq, n), ref[0]) and np.array_equal(o[1].cpu().numpy().reshape(nq, n), ref[1]), rep
+
+
 def test_evaluator_binary_on_reference_example(tmp_path):
     """The drop-in `evaluator <config.toml>` host program (mirror of src/bin/evaluator.rs) on the reference's example data,
     rebuilt from the golden fixture: 931 evaluations, HitRate@20 0.6402, the README's metric line (README.md:170-172)."""
