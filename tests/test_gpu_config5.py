@@ -67,8 +67,12 @@ def test_config5_full_size(monkeypatch):
         return out_ids.cpu().numpy().view(np.uint64).reshape(B, n).copy(), out_sc.cpu().numpy().reshape(B, n).copy(), out_cnt.cpu().numpy().view(np.uint32).copy()
 
     ref = run()
-    nq_, general, _glob = full.last_path_counts()
+    nq_, general, glob = full.last_path_counts()
     assert nq_ == B and general < B // 4, "most queries should have been served by the fast kernel (%d of %d went to the general one)" % (general, B)
+    assert glob > 0, "at this size a few queries need the global-table pass (64-bit slots halve the LDS session table)"
+    again = run()          # the second call on the stream knows that queries get retried: the global-table pass is forked beside the finish kernels
+    for a, b in zip(ref, again):
+        assert np.array_equal(a, b), "the forked global-table pass changed a result"
     # ---- path equivalence on 262 144 queries: the general kernel alone (u64 slots at this size) ----
     try:
         monkeypatch.setenv("SRN_NO_FAST", "1"); capi.reload_knobs()
