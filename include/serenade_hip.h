@@ -270,7 +270,9 @@ int srn_shard_lists_predict(const srn_index_t* idx, const uint64_t* d_items_flat
  * top-n, merge by (score desc, id asc) -- with RCCL called from inside the library.  Results (identical on every rank, bit-identical to the
  * unsharded index) are written to the caller's device buffers, asynchronously on `stream`; the call itself blocks the host for one short
  * synchronisation on the group's own exchange stream (the per-shard list totals size the exchange).  With SRN_FLAG_INPUTS_RESIDENT a batch's
- * exchange phase overlaps the previous batch's kernels.  Valid where srn_shard_lists_supported says so (sessions of <= 8 items, m <= m_index).
+ * exchange phase overlaps the previous batch's kernels.  Batches the lists pipeline does not serve (srn_shard_lists_supported: sessions of > 8 items,
+ * m > m_index, incomplete posting lists) take the three-stage pipeline inside the same call: stage A -> all-gather of the candidates -> stage B ->
+ * all-reduce(min) of the first-match positions -> stage C -> all-gather of the per-shard top-n -> merge (no host synchronisation at all).
  *
  *   rank 0:   srn_shard_group_unique_id(id, sizeof id)      -- 256 opaque bytes; hand them to the other ranks (your own control plane)
  *   rank r:   srn_index_load_shard(path, r, world, device_r, &shard);  srn_shard_group_create(shard, id, r, world, &group)
@@ -285,7 +287,7 @@ int srn_shard_group_create(const srn_index_t* shard, const void* unique_id, int 
 /* The same group over the APPLICATION's transport instead of RCCL (MPI, sockets, a test harness): three collectives on device buffers.  Each
  * callback must order itself after the work already enqueued on `stream` and complete (or be enqueued on `stream`) before it returns;
  * channel 0 / 1 = the group's two independent sequences of collectives (exchange stream / caller's stream).  Non-zero return = failure.
- *   all_reduce_max_i32(user, channel, d_buf, count, stream)                 element-wise maximum over the ranks, in place
+ *   all_reduce_max_i32 / all_reduce_min_i32(user, channel, d_buf, count, stream)   element-wise maximum / minimum over the ranks, in place
  *   all_gather(user, channel, d_buf, block_bytes, stream)                   d_buf = world blocks; block `rank` holds this rank's data
  *   all_gather_v(user, channel, d_buf, byte_off[world], byte_cnt[world], stream)    segment r = d_buf[byte_off[r] .. + byte_cnt[r]); this rank's is in place */
 typedef struct {
@@ -293,6 +295,7 @@ typedef struct {
     int (*all_reduce_max_i32)(void* user, int channel, int32_t* d_buf, size_t count, void* stream);
     int (*all_gather)(void* user, int channel, void* d_buf, size_t block_bytes, void* stream);
     int (*all_gather_v)(void* user, int channel, void* d_buf, const uint64_t* byte_off, const uint64_t* byte_cnt, void* stream);
+    int (*all_reduce_min_i32)(void* user, int channel, int32_t* d_buf, size_t count, void* stream);   /* may be NULL: the group then serves the lists pipeline only */
 } srn_shard_comm_t;
 int srn_shard_group_create_with_comm(const srn_index_t* shard, int rank, int world, const srn_shard_comm_t* comm, srn_shard_group_t** out);
 /* All shards of the group in THIS process on one device (tests; capacity experiments on one GPU): the collectives degenerate to kernels. */
@@ -306,6 +309,7 @@ typedef struct {
     uint64_t bytes_lists_max_rank;                                 /* the fullest rank's list segment, summed over the batches (what a padded all-gather would ship per rank) */
     uint32_t transport;                                            /* 0 in-process, 1 RCCL, 2 application callbacks */
     uint32_t overlapped;                                           /* the exchange phase runs on the group's own stream */
+    uint64_t stage_batches, bytes_stage_candidates, bytes_stage_minpos; /* batches that took the three-stage pipeline, and what this rank contributed to its two big exchanges */
 } srn_shard_group_stats_t;
 int srn_shard_group_stats(const srn_shard_group_t* g, srn_shard_group_stats_t* out);
 void srn_shard_group_free(srn_shard_group_t* g);

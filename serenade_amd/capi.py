@@ -34,7 +34,7 @@ class IndexInfo(C.Structure):
 
 class ShardGroupStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_shards", "batches", "queries", "bytes_head", "bytes_counts", "bytes_lists", "bytes_results", "bytes_lists_max_rank")] + \
-               [("transport", C.c_uint32), ("overlapped", C.c_uint32)]
+               [("transport", C.c_uint32), ("overlapped", C.c_uint32)] + [(n, C.c_uint64) for n in ("stage_batches", "bytes_stage_candidates", "bytes_stage_minpos")]
 
 
 # srn_shard_comm_t: the application's transport for a shard group (three collectives on device buffers)
@@ -44,7 +44,8 @@ ALL_GATHER_V_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTE
 
 
 class ShardComm(C.Structure):
-    _fields_ = [("user", C.c_void_p), ("all_reduce_max_i32", ALL_REDUCE_MAX_FN), ("all_gather", ALL_GATHER_FN), ("all_gather_v", ALL_GATHER_V_FN)]
+    _fields_ = [("user", C.c_void_p), ("all_reduce_max_i32", ALL_REDUCE_MAX_FN), ("all_gather", ALL_GATHER_FN), ("all_gather_v", ALL_GATHER_V_FN),
+                ("all_reduce_min_i32", ALL_REDUCE_MAX_FN)]
 
 
 SHARD_GROUP_ID_BYTES = 256

@@ -96,6 +96,9 @@ struct Slot {   // everything one batch in flight needs (grow-only); two slots: 
     char* lists = nullptr; size_t lists_bytes = 0;           // the gathered list prefixes, segment g at base[g]
     char* records = nullptr; size_t records_bytes = 0;
     char* part = nullptr; size_t part_bytes = 0;             // [G] blocks: ids | scores | counts
+    // three-stage pipeline: [G] candidate blocks + [G][nq] counts, the neighbour list, first-match positions (+ one scratch copy for an in-process group), overflow flags
+    char* cand = nullptr; size_t cand_bytes = 0; char* cand_cnt = nullptr; size_t cand_cnt_bytes = 0;
+    char* nb = nullptr; size_t nb_bytes = 0; char* nb_cnt = nullptr; size_t nb_cnt_bytes = 0; char* minpos = nullptr; size_t minpos_bytes = 0; char* flagq = nullptr; size_t flagq_bytes = 0;
     hipEvent_t e_done = nullptr;
 };
 }  // namespace
@@ -115,6 +118,7 @@ struct srn_shard_group {
     Slot slot[2];
     uint64_t calls = 0;
     uint64_t st_queries = 0, st_bytes_head = 0, st_bytes_kept = 0, st_bytes_lists = 0, st_bytes_results = 0, st_lists_max = 0;
+    uint64_t st_stage_batches = 0, st_bytes_stage_cand = 0, st_bytes_stage_minpos = 0;   // batches that took the three-stage pipeline
     std::mutex mu;   // one batch is issued at a time per group (the collectives must be issued in the same order on every rank anyway)
 };
 
@@ -125,6 +129,11 @@ uint32_t G_of(const srn_shard_group* g) { return g->kind == srn_shard_group::LOC
 int all_reduce_max_i32(srn_shard_group* g, int channel, int* buf, size_t count, hipStream_t st) {
     if (g->kind == srn_shard_group::RCCL) NCCL_TRY(rccl()->AllReduce(buf, buf, count, ncclInt32, ncclMax, g->comm[channel], st));
     else if (g->kind == srn_shard_group::CALLBACKS) { const int rc = g->cb.all_reduce_max_i32(g->cb.user, channel, buf, count, st); if (rc) return fail(rc, "the application's all-reduce callback failed"); }
+    return SRN_OK;
+}
+int all_reduce_min_i32(srn_shard_group* g, int channel, int* buf, size_t count, hipStream_t st) {
+    if (g->kind == srn_shard_group::RCCL) NCCL_TRY(rccl()->AllReduce(buf, buf, count, ncclInt32, ncclMin, g->comm[channel], st));
+    else if (g->kind == srn_shard_group::CALLBACKS) { const int rc = g->cb.all_reduce_min_i32(g->cb.user, channel, buf, count, st); if (rc) return fail(rc, "the application's all-reduce(min) callback failed"); }
     return SRN_OK;
 }
 int all_gather_blocks(srn_shard_group* g, int channel, char* buf, size_t block_bytes, hipStream_t st) {   // block `rank` in place
@@ -151,7 +160,7 @@ int all_gather_v(srn_shard_group* g, int channel, char* buf, const unsigned long
 
 void slot_free(Slot& s) {
     for (char* p : s.pos) if (p) hipFree(p);
-    for (char* p : {s.head, s.kept, s.tot, s.off, s.small, s.lists, s.records, s.part}) if (p) hipFree(p);
+    for (char* p : {s.head, s.kept, s.tot, s.off, s.small, s.lists, s.records, s.part, s.cand, s.cand_cnt, s.nb, s.nb_cnt, s.minpos, s.flagq}) if (p) hipFree(p);
     if (s.tot_host) hipHostFree(s.tot_host);
     if (s.e_done) hipEventDestroy(s.e_done);
     s = Slot();
@@ -180,6 +189,77 @@ int check_shard(const srn_index* ix, uint32_t want_shard, uint32_t n_shards) {
     return SRN_OK;
 }
 
+// The three-stage pipeline (round 1's kernels, `STAGE` instantiations of vmis_predict_kernel) for what the lists pipeline does not serve -- sessions of > 8 items,
+// m > m_index, incomplete posting lists: stage A (this shard's candidates, locally cut to m) -> all-gather -> stage B (global cuts: the neighbour list, identical on every
+// rank; partial first-match positions over the evolving items this shard owns) -> all-reduce(min) -> stage C (accumulate over the shard's row fragments, exact top-n among
+// the items it owns) -> all-gather -> merge.  Everything on the caller's stream, no host synchronisation; a query whose session table overflowed on some shard comes back
+// with out_counts = 0xFFFFFFFF like on the unsharded path.  (serenade_amd/sharded.py drove these stages from Python until round 3, with a compaction of the candidate slabs
+// that is not repeated here: the lists pipeline is the fast path, this is the complete one.)
+int group_predict_stages(srn_shard_group* g, const LaunchParams& p, uint64_t* d_out_ids, double* d_out_scores, uint32_t* d_out_counts, hipStream_t user) {
+    const uint32_t G = G_of(g), nq = p.nq, n = p.how_many;
+    const bool local = g->kind == srn_shard_group::LOCAL;
+    if (g->kind == srn_shard_group::CALLBACKS && !g->cb.all_reduce_min_i32) return fail(SRN_EINVAL, "this batch needs the three-stage pipeline, and the group's transport has no all_reduce_min_i32");
+    Slot& s = g->slot[g->calls & 1u];
+    uint32_t num_bits = 0;
+    const int sb = device_slot_bytes(g->shards[0]->dev, g->shards[0]->flat, p.max_len, &num_bits);
+    if (sb < 0) return SRN_ERANGE;
+    const size_t cand_block = (size_t)nq * p.m * (size_t)sb /* exactly [nq][m] slots: stage B indexes the gathered buffer as [G][nq][m] */, block_bytes = ((size_t)nq * n * 16 + (size_t)nq * 4 + 255) / 256 * 256;
+    const size_t mp_count = (size_t)nq * ((size_t)p.k + 1);
+    {
+        int rc = ensure(&s.cand, &s.cand_bytes, (size_t)G * cand_block);
+        if (!rc) rc = ensure(&s.cand_cnt, &s.cand_cnt_bytes, (size_t)G * nq * 4);
+        if (!rc) rc = ensure(&s.nb, &s.nb_bytes, (size_t)nq * p.k * (size_t)sb);
+        if (!rc) rc = ensure(&s.nb_cnt, &s.nb_cnt_bytes, (size_t)nq * 4);
+        if (!rc) rc = ensure(&s.minpos, &s.minpos_bytes, mp_count * 4 * 2);
+        if (!rc) rc = ensure(&s.flagq, &s.flagq_bytes, (size_t)nq * 4);
+        if (!rc) rc = ensure(&s.part, &s.part_bytes, (size_t)G * block_bytes);
+        if (rc) return rc;
+    }
+    uint32_t* cnt_g = (uint32_t*)s.cand_cnt; int* minpos = (int*)s.minpos;
+    if (g->calls >= 2 && g->overlap && !local) HIP_TRY(hipStreamWaitEvent(user, s.e_done, 0));   // (a lists batch may still be using this slot's buffers on the exchange stream: order behind it)
+    // stage A
+    for (size_t i = 0; i < g->shards.size(); ++i) {
+        const uint32_t gi = local ? (uint32_t)i : (uint32_t)g->rank;
+        ShardIO sh{}; sh.cand = s.cand + (size_t)gi * cand_block; sh.cand_cnt = cnt_g + (size_t)gi * nq;
+        int rc = device_shard_stage(g->shards[i]->dev, g->shards[i]->flat, 1, p, sh, user); if (rc) return rc;
+    }
+    { int rc = all_gather_blocks(g, 1, s.cand, cand_block, user); if (rc) return rc; }
+    { int rc = all_gather_blocks(g, 1, s.cand_cnt, (size_t)nq * 4, user); if (rc) return rc; }
+    HIP_TRY(launch_shard_scrub_counts(user, cnt_g, G, nq, (uint32_t*)s.flagq));
+    // stage B (every rank computes the same neighbour list; its own partial first-match positions)
+    for (size_t i = 0; i < g->shards.size(); ++i) {
+        int* mp_i = i == 0 ? minpos : minpos + mp_count;
+        HIP_TRY(hipMemsetAsync(s.nb, 0, (size_t)nq * p.k * (size_t)sb, user));
+        HIP_TRY(launch_shard_fill_i32(user, mp_i, 0x7FFFFFFF, mp_count));
+        ShardIO sh{}; sh.gathered = s.cand; sh.gathered_cnt = cnt_g; sh.n_shards = G; sh.gathered_stride = 0;
+        sh.nb = s.nb; sh.nb_cnt = (uint32_t*)s.nb_cnt; sh.minpos = mp_i;
+        int rc = device_shard_stage(g->shards[i]->dev, g->shards[i]->flat, 2, p, sh, user); if (rc) return rc;
+        if (i > 0) HIP_TRY(launch_shard_min(user, minpos, mp_i, mp_count));
+    }
+    { int rc = all_reduce_min_i32(g, 1, minpos, mp_count, user); if (rc) return rc; }
+    // stage C
+    for (size_t i = 0; i < g->shards.size(); ++i) {
+        const uint32_t gi = local ? (uint32_t)i : (uint32_t)g->rank;
+        char* blk = s.part + (size_t)gi * block_bytes;
+        LaunchParams pi = p;
+        const bool direct = G == 1;
+        pi.out_ids = direct ? d_out_ids : (uint64_t*)blk; pi.out_scores = direct ? d_out_scores : (double*)(blk + (size_t)nq * n * 8); pi.out_counts = direct ? d_out_counts : (uint32_t*)(blk + (size_t)nq * n * 16);
+        HIP_TRY(hipMemsetAsync(pi.out_ids, 0, (size_t)nq * n * 8, user)); HIP_TRY(hipMemsetAsync(pi.out_scores, 0, (size_t)nq * n * 8, user)); HIP_TRY(hipMemsetAsync(pi.out_counts, 0, (size_t)nq * 4, user));
+        ShardIO sh{}; sh.nb = s.nb; sh.nb_cnt = (uint32_t*)s.nb_cnt; sh.minpos = minpos;
+        int rc = device_shard_stage(g->shards[i]->dev, g->shards[i]->flat, 3, pi, sh, user); if (rc) return rc;
+    }
+    if (G > 1) {
+        int rc = all_gather_blocks(g, 1, s.part, block_bytes, user); if (rc) return rc;
+        HIP_TRY(launch_shard_merge_topn(user, s.part, block_bytes, G, nq, n, d_out_ids, d_out_scores, d_out_counts));
+    }
+    HIP_TRY(launch_shard_mark(user, (const uint32_t*)s.flagq, nq, d_out_counts));
+    HIP_TRY(hipEventRecord(s.e_done, user));
+    ++g->calls;
+    g->st_queries += nq; g->st_bytes_stage_cand += (uint64_t)(cand_block + (size_t)nq * 4) * (local ? G : 1); g->st_bytes_stage_minpos += (uint64_t)mp_count * 4;
+    g->st_bytes_results += G > 1 ? (uint64_t)block_bytes * (local ? G : 1) : 0; ++g->st_stage_batches;
+    return SRN_OK;
+}
+
 int group_predict(srn_shard_group* g, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq_, size_t max_len_hint, size_t k, size_t m, size_t how_many,
                   unsigned flags, uint64_t* d_out_ids, double* d_out_scores, uint32_t* d_out_counts, hipStream_t user) {
     std::lock_guard<std::mutex> lk(g->mu);
@@ -190,9 +270,10 @@ int group_predict(srn_shard_group* g, const uint64_t* d_items_flat, const uint32
     const bool resident = (flags & SRN_FLAG_INPUTS_RESIDENT) != 0u;   // the inputs do not hang on the caller's stream: this batch's exchange may start while the previous batch still runs there
     flags &= ~(unsigned)SRN_FLAG_INPUTS_RESIDENT;
     p.nq = nq; p.k = (uint32_t)k; p.m = (uint32_t)m; p.how_many = n; p.flags = flags; p.max_len = ML; p.items_flat = d_items_flat; p.q_off = d_q_off;
+    p.out_ids = d_out_ids; p.out_scores = d_out_scores; p.out_counts = d_out_counts;
     for (const srn_index* ix : g->shards)
-        if (!device_shard_lists_supported(ix->dev, ix->flat, p))
-            return fail(SRN_EINVAL, "the shard group runs the LISTS pipeline: sessions of <= 8 items, m <= m_index, complete posting lists (everything else: stages A/B/C, srn_shard_stage_*)");
+        if (!device_shard_lists_supported(ix->dev, ix->flat, p)) return group_predict_stages(g, p, d_out_ids, d_out_scores, d_out_counts, user);   // (every rank holds the same index parameters: the same choice everywhere)
+    p.out_ids = nullptr; p.out_scores = nullptr; p.out_counts = nullptr;
     Slot& s = g->slot[g->calls & 1u];
     const bool overlap = g->overlap && !local;
     hipStream_t sx = overlap ? g->s_x : user;
@@ -368,7 +449,8 @@ int srn_shard_group_predict_batch(srn_shard_group_t* g, const uint64_t* d_items_
 int srn_shard_group_stats(const srn_shard_group_t* g, srn_shard_group_stats_t* out) {
     if (!g || !out) return fail(SRN_EINVAL, "null argument");
     *out = srn_shard_group_stats_t{(uint64_t)G_of(g), g->calls, g->st_queries, g->st_bytes_head, g->st_bytes_kept, g->st_bytes_lists, g->st_bytes_results, g->st_lists_max,
-                                   g->kind == srn_shard_group::RCCL ? 1u : g->kind == srn_shard_group::CALLBACKS ? 2u : 0u, g->overlap && g->kind != srn_shard_group::LOCAL ? 1u : 0u};
+                                   g->kind == srn_shard_group::RCCL ? 1u : g->kind == srn_shard_group::CALLBACKS ? 2u : 0u, g->overlap && g->kind != srn_shard_group::LOCAL ? 1u : 0u,
+                                   g->st_stage_batches, g->st_bytes_stage_cand, g->st_bytes_stage_minpos};
     return SRN_OK;
 }
 

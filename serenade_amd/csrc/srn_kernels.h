@@ -105,6 +105,10 @@ hipError_t launch_shard_prep(hipStream_t st, const uint64_t* items_flat, const u
 hipError_t launch_shard_max(hipStream_t st, int* dst, const int* src, size_t n);
 hipError_t launch_shard_offsets(hipStream_t st, const uint32_t* kept_g, uint32_t nq, uint32_t max_len, uint32_t n_shards, long long* off_g, unsigned long long* tot_dev,
                                 unsigned long long* tot_host, unsigned long long* chunk_scratch);
+hipError_t launch_shard_min(hipStream_t st, int* dst, const int* src, size_t n);
+hipError_t launch_shard_scrub_counts(hipStream_t st, uint32_t* cnt_g, uint32_t n_shards, uint32_t nq, uint32_t* flag);
+hipError_t launch_shard_mark(hipStream_t st, const uint32_t* flag, uint32_t nq, uint32_t* out_counts);
+hipError_t launch_shard_fill_i32(hipStream_t st, int* dst, int v, size_t n);
 hipError_t launch_shard_merge_topn(hipStream_t st, const char* part, size_t block_bytes, uint32_t n_shards, uint32_t nq, uint32_t how_many, uint64_t* out_ids, double* out_scores,
                                    uint32_t* out_counts);
 hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f, bool debug = false);   // debug: say the occupancy once (the SRN_DEBUG knob, read by the runtime)

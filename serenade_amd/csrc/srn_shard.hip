@@ -216,6 +216,44 @@ hipError_t launch_shard_offsets(hipStream_t st, const uint32_t* kept_g, uint32_t
     return hipGetLastError();
 }
 
+// ---- helpers of the three-stage pipeline inside the shard group (sessions the lists pipeline does not serve) ----
+__global__ __launch_bounds__(256) void shard_min_kernel(int* __restrict__ dst, const int* __restrict__ src, size_t n) {   // element-wise minimum (the all-reduce(min) of an in-process group)
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = min(dst[i], src[i]);
+}
+hipError_t launch_shard_min(hipStream_t st, int* dst, const int* src, size_t n) {
+    if (n) hipLaunchKernelGGL(shard_min_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dst, src, n);
+    return hipGetLastError();
+}
+// the gathered candidate counts: a shard whose session table overflowed says 0xFFFFFFFF for the query -- remember it (flag) and feed stage B a 0 instead
+__global__ __launch_bounds__(256) void shard_scrub_counts_kernel(uint32_t* __restrict__ cnt_g, uint32_t n_shards, uint32_t nq, uint32_t* __restrict__ flag) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    uint32_t bad = 0;
+    for (uint32_t g = 0; g < n_shards; ++g) if (cnt_g[(size_t)g * nq + q] == 0xFFFFFFFFu) { bad = 1; cnt_g[(size_t)g * nq + q] = 0u; }
+    flag[q] = bad;
+}
+hipError_t launch_shard_scrub_counts(hipStream_t st, uint32_t* cnt_g, uint32_t n_shards, uint32_t nq, uint32_t* flag) {
+    hipLaunchKernelGGL(shard_scrub_counts_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, cnt_g, n_shards, nq, flag);
+    return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void shard_mark_kernel(const uint32_t* __restrict__ flag, uint32_t nq, uint32_t* __restrict__ out_counts) {   // flagged queries: the marker the unsharded path uses
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nq && flag[q]) out_counts[q] = 0xFFFFFFFFu;
+}
+hipError_t launch_shard_mark(hipStream_t st, const uint32_t* flag, uint32_t nq, uint32_t* out_counts) {
+    hipLaunchKernelGGL(shard_mark_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, flag, nq, out_counts);
+    return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void shard_fill_i32_kernel(int* __restrict__ dst, int v, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = v;
+}
+hipError_t launch_shard_fill_i32(hipStream_t st, int* dst, int v, size_t n) {
+    if (n) hipLaunchKernelGGL(shard_fill_i32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dst, v, n);
+    return hipGetLastError();
+}
+
 // The last step of a sharded batch: the G per-shard top-n lists of a query -> its global top-n by (score desc, item id asc).  An item's whole score lives on its
 // owner, so no item appears twice; every list is already in that order.  One wave per query; an entry's global rank is its own position plus, for every other
 // list, the number of that list's entries that come before it (binary search: <= 9 steps for n <= 512).  Replaces two argsorts and four gathers of the host's

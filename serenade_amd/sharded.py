@@ -476,7 +476,18 @@ class ShardGroup:
                 import traceback; traceback.print_exc()
                 return capi.SRN_EHIP
 
-        cbs = (capi.ALL_REDUCE_MAX_FN(arm), capi.ALL_GATHER_FN(ag), capi.ALL_GATHER_V_FN(agv))
+        def armin(user, channel, d_buf, count, stream):
+            try:
+                sync(stream)
+                t = as_tensor(d_buf, count * 4).view(torch.int32)
+                comm.all_reduce_min(t)
+                torch.cuda.synchronize(dev)
+                return 0
+            except Exception:   # pragma: no cover
+                import traceback; traceback.print_exc()
+                return capi.SRN_EHIP
+
+        cbs = (capi.ALL_REDUCE_MAX_FN(arm), capi.ALL_GATHER_FN(ag), capi.ALL_GATHER_V_FN(agv), capi.ALL_REDUCE_MAX_FN(armin))
         sc = capi.ShardComm(None, *cbs)
         h = C.c_void_p()
         capi.check(capi.lib().srn_shard_group_create_with_comm(shard._h, int(rank), int(world), C.byref(sc), C.byref(h)))

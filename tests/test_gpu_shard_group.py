@@ -65,6 +65,43 @@ def test_local_group_matches_the_oracle_and_the_unsharded_path(n_shards):
     _check_oracle(_np(out2), oix.predict_batch("canonical", flat, qoff, 100, 400, 21, False, threads=4), 21)
 
 
+@pytest.mark.parametrize("n_shards", [1, 2, 3])
+def test_local_group_three_stage_pipeline_for_what_the_lists_pipeline_does_not_serve(n_shards):
+    """Sessions of > 8 items and m > m_index take stages A / B / C INSIDE the same C call (candidates all-gathered, first-match positions all-reduced(min),
+    per-shard top-n merged): against the oracle, against the unsharded path, and interleaved with lists batches on the same group."""
+    import serenade_amd as sa
+    from serenade_amd import sharded
+    from oracle import oracle as O
+    off, items, ts, ids = small_dataset(85, n_sessions=5000, n_items=450, max_len=60)
+    qs = random_queries(37, ids, 500, max_len=20, unknown_rate=0.03, dup_rate=0.1)             # evolving sessions of up to 20 items
+    flat, qoff = flatten(qs)
+    d_flat, d_off = _to_dev(flat, qoff)
+    short = random_queries(38, ids, 300, max_len=6)
+    sflat, sqoff = flatten(short)
+    d_sflat, d_soff = _to_dev(sflat, sqoff)
+    full = sa.VMISIndex.from_sessions(off, items, ts, 300, 60, 1.0)
+    oix = O.OracleIndex(off, items, ts, 300, 60, 1.0)
+    shards = [sharded.ShardedVMISIndex.from_full(full, g, n_shards) for g in range(n_shards)]
+    grp = sharded.ShardGroup.local(shards)
+    stage_batches = 0
+    for (k, m, n, business) in [(100, 300, 21, False), (400, 250, 21, False), (30, 60, 5, False), (100, 300, 50, True)]:
+        ref = oix.predict_batch("canonical", flat, qoff, k, m, n, business, threads=4)
+        got = _np(grp.predict_batch(d_flat, d_off, len(qs), 20, k, m, n, business))
+        _check_oracle(got, ref, n)
+        u = sa.predict_batch(full, (flat, qoff), k, m, n, business)
+        assert np.array_equal(got[0], u[0]) and np.array_equal(got[1], u[1]) and np.array_equal(got[2], u[2])
+        stage_batches += 1
+        assert grp.stats["stage_batches"] == stage_batches
+        # a lists batch in between: the two pipelines share the group's buffer slots
+        _check_oracle(_np(grp.predict_batch(d_sflat, d_soff, len(short), 6, k, m, n)), oix.predict_batch("canonical", sflat, sqoff, k, m, n, False, threads=4), n)
+        assert grp.stats["stage_batches"] == stage_batches
+    # m larger than the index's own cut: short sessions, but no shard's lists hold enough -> stages
+    ref = oix.predict_batch("canonical", sflat, sqoff, 100, 500, 21, False, threads=4)
+    _check_oracle(_np(grp.predict_batch(d_sflat, d_soff, len(short), 6, 100, 500, 21)), ref, 21)
+    st = grp.stats
+    assert st["stage_batches"] == stage_batches + 1 and st["bytes_stage_candidates"] > 0 and st["bytes_stage_minpos"] > 0
+
+
 def test_local_group_business_rules_against_the_oracle():
     """Real product flags incl. None: the current item's attribute byte lives on its owner shard and reaches the others with the first all-reduce."""
     import serenade_amd as sa
@@ -107,9 +144,9 @@ def test_group_rejects_misuse():
     qs = random_queries(3, ids, 16, max_len=4)
     flat, qoff = flatten(qs)
     d_flat, d_off = _to_dev(flat, qoff)
-    with pytest.raises(capi.SerenadeError) as e:     # sessions of > 8 items: the lists pipeline does not serve them
-        grp.predict_batch(d_flat, d_off, len(qs), 12, 20, 100, 21)
-    assert e.value.code == capi.SRN_EINVAL
+    with pytest.raises(capi.SerenadeError) as e:     # a session-length hint beyond the ABI's limit
+        grp.predict_batch(d_flat, d_off, len(qs), capi.MAX_SESSION_LEN + 1, 20, 100, 21)
+    assert e.value.code == capi.SRN_ERANGE
     with pytest.raises(capi.SerenadeError) as e:
         grp.predict_batch(d_flat, d_off, len(qs), 4, 0, 100, 21)
     assert e.value.code == capi.SRN_EINVAL
@@ -140,7 +177,13 @@ def _rccl_worker(q):
         res.append(_np(grp2.predict_batch(d_flat, d_off, len(qs), 6, 80, 300, 21)))
         assert grp2.stats["bytes_lists"] == 0 and st["bytes_lists"] > 0
         u = sa.predict_batch(full, (flat, qoff), 80, 300, 21, False)
-        q.put((res, st, u))
+        long_qs = random_queries(30, ids, 300, max_len=15)      # > 8 items: the three-stage pipeline (ncclAllGather x 4, ncclAllReduce(min))
+        lflat, lqoff = flatten(long_qs)
+        d_lflat, d_loff = _to_dev(lflat, lqoff)
+        lres = [_np(g.predict_batch(d_lflat, d_loff, len(long_qs), 15, 80, 300, 21)) for g in (grp, grp2)]
+        lres.append(_np(grp.predict_batch(d_flat, d_off, len(qs), 6, 80, 300, 21)))      # and a lists batch behind it on the overlapped group
+        lu = sa.predict_batch(full, (lflat, lqoff), 80, 300, 21, False)
+        q.put((res, st, u, lres, lu, grp.stats))
         grp.close(); grp2.close()
     except Exception as e:  # pragma: no cover
         import traceback
@@ -159,10 +202,13 @@ def test_single_rank_rccl_group_through_the_c_abi():
     out = q.get(timeout=600)
     p.join(timeout=120)
     assert not isinstance(out, str), out
-    res, st, u = out
+    res, st, u, lres, lu, st2 = out
     assert st["transport"] == 1 and st["overlapped"] == 1 and st["batches"] == 3
-    for r in res:
+    for r in res + lres[2:]:
         assert np.array_equal(r[0], u[0]) and np.array_equal(r[1], u[1]) and np.array_equal(r[2], u[2])
+    for r in lres[:2]:
+        assert np.array_equal(r[0], lu[0]) and np.array_equal(r[1], lu[1]) and np.array_equal(r[2], lu[2])
+    assert st2["stage_batches"] == 1
 
 
 def _cb_worker(rank, world, port, q):
@@ -182,6 +228,11 @@ def _cb_worker(rank, world, port, q):
         ix = sharded.ShardedVMISIndex.from_full(full, rank, world)
         grp = sharded.ShardGroup.over(ix, rank, world, sharded.DistComm())
         res = [_np(grp.predict_batch(d_flat, d_off, len(qs), 7, k, m, n)) for (k, m, n) in [(80, 300, 21), (400, 200, 50)]]
+        long_qs = random_queries(32, ids, 300, max_len=18, unknown_rate=0.02)      # > 8 items: the three-stage pipeline through the same callbacks (+ all_reduce_min_i32)
+        lflat, lqoff = flatten(long_qs)
+        d_lflat, d_loff = _to_dev(lflat, lqoff)
+        res.append(_np(grp.predict_batch(d_lflat, d_loff, len(long_qs), 18, 80, 300, 21)))
+        res.append(_np(grp.predict_batch(d_flat, d_off, len(qs), 7, 80, 300, 21)))   # and lists again
         st = grp.stats
         q.put((rank, res, st))
         D.barrier()
@@ -215,8 +266,12 @@ def test_multi_rank_group_over_application_callbacks(world):
     flat, qoff = flatten(qs)
     oix = O.OracleIndex(off, items, ts, 300, 40, 1.0)
     refs = [oix.predict_batch("canonical", flat, qoff, k, m, n, False, threads=4) for (k, m, n) in [(80, 300, 21), (400, 200, 50)]]
+    long_qs = random_queries(32, ids, 300, max_len=18, unknown_rate=0.02)
+    lflat, lqoff = flatten(long_qs)
+    refs.append(oix.predict_batch("canonical", lflat, lqoff, 80, 300, 21, False, threads=4))
+    refs.append(refs[0])
     for rank, res, st in out:
         assert not isinstance(res, str), res
-        assert st["transport"] == 2 and st["n_shards"] == world
-        for r, ref, n in zip(res, refs, (21, 50)):
+        assert st["transport"] == 2 and st["n_shards"] == world and st["stage_batches"] == 1
+        for r, ref, n in zip(res, refs, (21, 50, 21, 21)):
             _check_oracle(r, ref, n)
