@@ -321,6 +321,7 @@ def main():
             parity_checked = gate(out_ids.cpu().numpy().view(np.uint64).reshape(B, how_many)[:n_par], out_sc.cpu().numpy().reshape(B, how_many)[:n_par],
                                   out_cnt.cpu().numpy().view(np.uint32)[:n_par], flat0, qo0, n_par, "whole index")
         sa.reserve(index, B, last_items, k, m, how_many, False, stream.cuda_stream)   # size the stream's workspace up front (srn_index_reserve): no call of the run allocates
+        index.kernel_timing(True)      # per-kernel HIP events on the launch stream for the timed region (the roofline's launch duration); off again for the sweeps below
         elapsed, step_ms = timed(step)
         served = int((out_cnt.cpu().numpy().view(np.uint32) != 0xFFFFFFFF).sum())
         # size-independent properties of the WHOLE last batch (the oracle gate above covers 2 048 queries): every row is a valid top-n list --
@@ -340,6 +341,7 @@ def main():
             os._exit(1)
 
         t_prep, t_fast, t_pred, t_retry = index.kernel_times_detail(min(64, args.steps))
+        index.kernel_timing(False)
         nq_last, general_last, global_last = index.last_path_counts()
 
         if rank != 0:

@@ -185,9 +185,15 @@ int srn_predict_batch_debug(const srn_index_t* idx, const uint64_t* items_flat, 
  * Without it the workspace grows on demand, the first time a larger batch arrives. */
 int srn_index_reserve(const srn_index_t* idx, size_t nq, size_t max_len_hint, size_t k, size_t m, size_t how_many, unsigned flags, void* stream);
 
+/* Kernel timing on (enable != 0) or off, per index; off by default (SRN_TIMING=1 in the environment: on from the start).  When on, every batch call records HIP
+ * events between its kernels, which srn_last_kernel_ms / srn_kernel_times* read back; each event idles the launch stream for ~6 us (three per call: 18 us of the
+ * 250 us a 4 096-query batch takes), so a serving process leaves it off and a benchmark switches it on around the region it reports kernel times for. */
+int srn_kernel_timing(srn_index_t* idx, int enable);
+
 /* Average duration in milliseconds of the predict kernel launches enqueued by the most recent
  * srn_predict_batch* call on this thread, measured with HIP events on the launch stream (blocks
- * until that work has finished); *out_launches = number of kernel launches it covered. */
+ * until that work has finished); *out_launches = number of kernel launches it covered.  SRN_EINVAL if kernel timing
+ * was off for that call (srn_kernel_timing). */
 int srn_last_kernel_ms(const srn_index_t* idx, double* out_ms_main, double* out_ms_retry, uint32_t* out_retried);
 
 /* ---- item-sharded index: one shard per GPU ---------------------------------------------------
@@ -316,7 +322,8 @@ void srn_shard_group_free(srn_shard_group_t* g);
 
 /* The same for the most recent min(max_n, 64) predict calls (oldest first): per-call duration in ms of
  * the main kernel and of the retry pass, from HIP events recorded on the launch stream around each
- * launch.  This is what bench.py reports as the kernel's live-measured launch duration. */
+ * launch.  This is what bench.py reports as the kernel's live-measured launch duration.  Only the trailing run of calls
+ * made with kernel timing on (srn_kernel_timing) is reported: *out_n = 0 if the last call was not timed. */
 int srn_kernel_times(const srn_index_t* idx, uint32_t max_n, double* out_ms_main, double* out_ms_retry, uint32_t* out_n);
 
 /* The same with the launches of a call told apart: prep kernel | fast kernel alone (vmis_fast_kernel, the dominant kernel;

@@ -443,6 +443,11 @@ int srn_kernel_times_detail(const srn_index_t* idx, uint32_t max_n, double* out_
     return guarded([&]() -> int { return device_kernel_times(idx->dev, max_n, out_ms_predict, out_ms_retry, out_n, out_ms_prep, out_ms_fast); });
 }
 
+int srn_kernel_timing(srn_index_t* idx, int enable) {
+    if (!idx || !idx->dev) return fail(SRN_ENODEV, "index has no device attached");
+    return device_kernel_timing(idx->dev, enable);
+}
+
 int srn_debug_phase_cycles(const srn_index_t* idx, int enable, uint64_t* out16) {
     if (!idx || !idx->dev) return fail(SRN_ENODEV, "index has no device attached");
     return guarded([&]() -> int { return device_phase_cycles(idx->dev, enable, (unsigned long long*)out16); });

@@ -895,8 +895,12 @@ __global__ __launch_bounds__(256) void vmis_finish_kernel(DeviceIndex ix, const 
 // relative to the maximum, the bin of the n-th best -- then the ranks of what is at or above it.
 __global__ __launch_bounds__(64) void vmis_finish_big_kernel(DeviceIndex ix, const char* __restrict__ fin, const uint4* __restrict__ arena, const uint32_t* __restrict__ big_list,
                                                              const unsigned long long* __restrict__ big_ticket, uint64_t* __restrict__ out_ids, double* __restrict__ out_scores,
-                                                             uint32_t* __restrict__ out_counts, uint32_t how_many) {
+                                                             uint32_t* __restrict__ out_counts, uint32_t how_many, const uint32_t* __restrict__ cnt_retry, const uint32_t* __restrict__ cnt_slow,
+                                                             uint32_t* __restrict__ host_words) {
     constexpr uint32_t CAP = F_CAND_CAP + F_TABLE_BUCKETS * 4u;
+    // the launch sequence's two counters (queries for the global-table pass, queries handed to the general kernel: both final before this kernel starts) straight into
+    // the workspace's pinned words -- two 4-byte device-to-host copies cost 9 us of every call
+    if (host_words && blockIdx.x == 0u && threadIdx.x == 0u) { host_words[0] = cnt_retry ? *cnt_retry : 0u; host_words[1] = cnt_slow ? *cnt_slow : 0u; }
     __shared__ unsigned long long key[CAP];
     __shared__ uint32_t tieb[CAP];
     __shared__ uint32_t hist[256];
@@ -962,9 +966,10 @@ __global__ __launch_bounds__(64) void vmis_finish_big_kernel(DeviceIndex ix, con
         __syncthreads();
     }
 }
-hipError_t launch_finish_big(hipStream_t st, const DeviceIndex& di, const FastParams& f, uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint32_t how_many, uint32_t grid) {
+hipError_t launch_finish_big(hipStream_t st, const DeviceIndex& di, const FastParams& f, uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint32_t how_many, uint32_t grid,
+                             const uint32_t* cnt_retry, const uint32_t* cnt_slow, uint32_t* host_words) {
     hipLaunchKernelGGL(vmis_finish_big_kernel, dim3(grid), dim3(64), 0, st, di, (const char*)f.fin, (const uint4*)f.big_arena, (const uint32_t*)f.big_list, (const unsigned long long*)f.big_ticket,
-                       out_ids, out_scores, out_counts, how_many);
+                       out_ids, out_scores, out_counts, how_many, cnt_retry, cnt_slow, host_words);
     return hipGetLastError();
 }
 

@@ -90,8 +90,8 @@ hipError_t launch_predict(bool masks, bool slot64, bool global_tables, int stage
                           const LaunchParams& p, const KernelCfg& c, const uint32_t* qlist, const uint32_t* qn, uint32_t* retry_list,
                           uint32_t* retry_cnt, char* gscratch, unsigned long long gscratch_stride, char* nb_spill, const ShardIO& sh, int wg_per_cu = 2);
 hipError_t launch_prep(hipStream_t st, const DeviceIndex& di, const uint64_t* items_flat, const uint32_t* q_off, uint32_t nq, uint32_t m,
-                       uint32_t max_len, char* out, uint32_t stride);
-hipError_t launch_finish_big(hipStream_t st, const DeviceIndex& di, const FastParams& f, uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint32_t how_many, uint32_t grid);
+                       uint32_t max_len, char* out, uint32_t stride, uint32_t* zero_a = nullptr, uint32_t* zero_b = nullptr);   // zero_a[0..3], zero_b[0]: counters cleared by the prep kernel
+hipError_t launch_finish_big(hipStream_t st, const DeviceIndex& di, const FastParams& f, uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint32_t how_many, uint32_t grid, const uint32_t* cnt_retry = nullptr, const uint32_t* cnt_slow = nullptr, uint32_t* host_words = nullptr);
 hipError_t launch_finish(hipStream_t st, const DeviceIndex& di, const FastParams& f, uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint32_t nq, uint32_t how_many);   // scores, ranking, public ids of the rows the fast kernel served
 hipError_t launch_shard_lists_head(hipStream_t st, const DeviceIndex& di, const uint64_t* items_flat, const uint32_t* q_off, uint32_t nq, uint32_t m, uint32_t max_len,
                                    ShardPos* pos_out, int* head);

@@ -352,53 +352,100 @@ __global__ __launch_bounds__(1024) void rows_to_frags_kernel(const uint64_t* __r
 }
 
 // -------------------------------------------------------------------------------------
-// Prep kernel: one thread per evolving session does the dependent look-ups of phase 0 (public id -> dense idx ->
-// posting list bounds -> first / m-th rank) so that the main kernel, where a whole workgroup would wait on that
-// chain, reads one record.  Record = PrepHead + max_len * PrepItem, positions counted from the most recent item.
+// Prep kernel: the dependent look-ups of phase 0 (public id -> dense idx -> posting list bounds -> first / m-th rank) done ahead of the main kernel, where
+// a whole workgroup would wait on that chain; the main kernel reads one record.  Record = PrepHead + max_len * PrepItem, positions counted from the most
+// recent item.  EIGHT LANES PER SESSION, one evolving position each (sessions of > 8 items: in rounds of 8): the chain is ~5 dependent loads long and a
+// thread per session walked it once per item -- 32 us for a batch of 4 096 sessions, where the chain itself is the cost; per-session totals are 8-lane
+// shuffles.  Rounds 1-2 ran one thread per session; the records are the same byte for byte.
+// zero_a / zero_b (either may be null): the 4-word / 1-word device counters of the launch sequence that follows on the same stream (the hand-over count and
+// finish_big's ticket; the retry count), cleared here instead of by two fill kernels.
 // -------------------------------------------------------------------------------------
+static constexpr uint32_t PREP_LANES = 8;
 __global__ __launch_bounds__(256) void vmis_prep_kernel(DeviceIndex ix, const uint64_t* __restrict__ items_flat, const uint32_t* __restrict__ q_off,
-                                                        uint32_t nq, uint32_t m, uint32_t max_len, char* out, uint32_t stride) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq) return;
+                                                        uint32_t nq, uint32_t m, uint32_t max_len, char* out, uint32_t stride, uint32_t* zero_a, uint32_t* zero_b) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 4 && zero_a) zero_a[t] = 0u;
+    if (t == 4 && zero_b) *zero_b = 0u;
+    const uint32_t q = t / PREP_LANES, sub = t % PREP_LANES;
+    if (q >= nq) return;   // (nq is a multiple of nothing in particular: whole 8-lane groups leave together, the shuffles below stay within a group)
     const uint32_t qb = q_off[q], L = q_off[q + 1] - qb;
-    PrepHead h{0u, 0u, 0u, 0u, 0u, 0u, L, 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, SRN_ATTR_NONE, 0u};
-    PrepItem* items = (PrepItem*)(out + (size_t)q * stride + sizeof(PrepHead));
-    if (L != 0 && L <= max_len) {
-        for (uint32_t pos = 0; pos < L; ++pos) {
+    char* rec = out + (size_t)q * stride;
+    PrepItem* items = (PrepItem*)(rec + sizeof(PrepHead));
+    uint32_t U = 0, rmax = 0, xlo = 0, sumw = 0, P = 0, nruns = 0, n_staged = 0, cur_attr = SRN_ATTR_NONE, my_run_start = 0;
+    const bool ok = L != 0 && L <= max_len;
+    const uint32_t rounds = ok ? (L + PREP_LANES - 1) / PREP_LANES : 0;
+    uint32_t idx = kNone, len = 0, pre = 0; unsigned long long base = 0;   // this lane's item of the LAST round (a session of <= 8 items has one round: its record is written once, with `kept`)
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t pos = r * PREP_LANES + sub;
+        const bool have = pos < L;
+        idx = kNone; len = 0; base = 0;
+        uint32_t first_i = 0, head_rank = 0, mth_rank = 0;
+        if (have) {
             const uint64_t raw = items_flat[qb + (L - 1 - pos)];   // pos 0 = most recent item
             bool first = true;
             for (uint32_t j = 0; j < pos; ++j) first = first && (items_flat[qb + (L - 1 - j)] != raw);   // Q2: most recent occurrence only
-            uint32_t idx = kNone;
             { uint32_t hh = (uint32_t)dev_mix64(raw) & ix.id_mask;
               for (;;) { const IdSlot s = ix.id_table[hh]; if (s.idx == kNone) break; if (s.key == raw) { idx = s.idx; break; } hh = (hh + 1) & ix.id_mask; } }
-            uint32_t len = 0; unsigned long long base = 0;
-            if (first) ++h.U;   // Q1: distinct raw ids, known or not
+            first_i = first ? 1u : 0u;   // Q1: distinct raw ids, known or not
             if (first && idx != kNone) {
                 const unsigned long long o0 = ix.post_off[idx], o1 = ix.post_off[idx + 1];
                 len = (uint32_t)min((unsigned long long)m, o1 - o0); base = o0;
-                if (len) {
-                    h.rmax = max(h.rmax, ix.post_rank[o0]);
-                    if (len >= m) h.xlo = max(h.xlo, ix.post_rank[o0 + m - 1]);
-                    h.sumw += L - pos;
-                }
+                if (len) { head_rank = ix.post_rank[o0]; if (len >= m) mth_rank = ix.post_rank[o0 + m - 1]; }
             }
-            if (len) { if (h.nruns < 8) h.run_start[h.nruns] = h.P; ++h.nruns; }
-            if (pos == 0 && idx != kNone) h.cur_attr = ix.meta[idx].attr;   // business rules look at the current item's attributes (mod.rs:162-182)
-            items[pos] = PrepItem{idx, len, h.P, 0u, base};
-            h.P += len;
+            if (pos == 0 && idx != kNone) cur_attr = ix.meta[idx].attr;   // business rules look at the current item's attributes (mod.rs:162-182)
         }
-        // entries >= x_lo of every list (a prefix: the lists are sorted by rank, descending): what the merge-mode kernels stage
-        for (uint32_t pos = 0; pos < L; ++pos) {
-            const uint32_t len = items[pos].len;
-            if (len == 0) continue;
-            const uint32_t* __restrict__ lst = ix.post_rank + items[pos].base;
-            uint32_t lo = 0, hi = len;   // first index whose entry is < x_lo
-            if (h.xlo == 0u || lst[len - 1] >= h.xlo) lo = len;   // (the usual case: the whole list is kept -- one look instead of ~11 dependent ones)
-            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (lst[mid] >= h.xlo) lo = mid + 1; else hi = mid; }
-            items[pos].kept = lo; h.n_staged += lo;
+        // 8-lane inclusive scans of len and of (len != 0); 8-lane totals
+        uint32_t sc_len = len, sc_run = len ? 1u : 0u;
+        #pragma unroll
+        for (uint32_t d = 1; d < PREP_LANES; d <<= 1) {
+            const uint32_t a = __shfl_up(sc_len, d, PREP_LANES), b2 = __shfl_up(sc_run, d, PREP_LANES);
+            if (sub >= d) { sc_len += a; sc_run += b2; }
         }
+        uint32_t u = first_i, rm = head_rank, xl = mth_rank, sw = len ? L - pos : 0u;
+        #pragma unroll
+        for (uint32_t d = 1; d < PREP_LANES; d <<= 1) {
+            u += __shfl_xor(u, d, PREP_LANES); sw += __shfl_xor(sw, d, PREP_LANES);
+            rm = max(rm, __shfl_xor(rm, d, PREP_LANES)); xl = max(xl, __shfl_xor(xl, d, PREP_LANES));
+        }
+        pre = P + sc_len - len;
+        const uint32_t run_idx = nruns + sc_run - (len ? 1u : 0u);   // which non-empty list of the session this one is
+        #pragma unroll
+        for (uint32_t s = 0; s < PREP_LANES; ++s) {   // lane j keeps run_start[j]
+            const uint32_t rp = __shfl(pre, s, PREP_LANES), ri = __shfl(run_idx, s, PREP_LANES), rl = __shfl(len, s, PREP_LANES);
+            if (rl != 0u && ri == sub) my_run_start = rp;
+        }
+        U += u; sumw += sw; rmax = max(rmax, rm); xlo = max(xlo, xl);
+        P += __shfl(sc_len, PREP_LANES - 1, PREP_LANES); nruns += __shfl(sc_run, PREP_LANES - 1, PREP_LANES);
+        if (have && rounds > 1) items[pos] = PrepItem{idx, len, pre, 0u, base};
     }
-    *(PrepHead*)(out + (size_t)q * stride) = h;
+    // entries >= x_lo of every list (a prefix: the lists are sorted by rank, descending): what the merge-mode kernels stage
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t pos = r * PREP_LANES + sub;
+        const bool have = pos < L;
+        uint32_t kept = 0;
+        if (have) {
+            if (rounds > 1) { len = items[pos].len; base = items[pos].base; }
+            if (len != 0) {
+                const uint32_t* __restrict__ lst = ix.post_rank + base;
+                uint32_t lo = 0, hi = len;   // first index whose entry is < x_lo
+                if (xlo == 0u || lst[len - 1] >= xlo) lo = len;   // (the usual case: the whole list is kept -- one look instead of ~11 dependent ones)
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (lst[mid] >= xlo) lo = mid + 1; else hi = mid; }
+                kept = lo;
+            }
+            if (rounds > 1) items[pos].kept = kept; else items[pos] = PrepItem{idx, len, pre, kept, base};
+        }
+        uint32_t ks = kept;
+        #pragma unroll
+        for (uint32_t d = 1; d < PREP_LANES; d <<= 1) ks += __shfl_xor(ks, d, PREP_LANES);
+        n_staged += ks;
+    }
+    cur_attr = __shfl(cur_attr, 0, PREP_LANES);
+    uint32_t* hw = (uint32_t*)rec;   // PrepHead, word by word: U rmax xlo sumw | P nruns L n_staged | run_start[8] | cur_attr pad_
+    if (sub == 0) {   // (records are 8-byte aligned: 72 + 24 * max_len)
+        *(uint2*)hw = make_uint2(U, rmax); *(uint2*)(hw + 2) = make_uint2(xlo, sumw); *(uint2*)(hw + 4) = make_uint2(P, nruns); *(uint2*)(hw + 6) = make_uint2(L, n_staged);
+        *(uint2*)(hw + 16) = make_uint2(cur_attr, 0u);
+    }
+    hw[8 + sub] = sub < nruns ? my_run_start : 0u;
 }
 
 #ifndef SRN_STOP_AT
@@ -1552,8 +1599,10 @@ hipError_t launch_predict(bool masks, bool slot64, bool global_tables, int stage
 }
 
 hipError_t launch_prep(hipStream_t st, const DeviceIndex& di, const uint64_t* items_flat, const uint32_t* q_off, uint32_t nq, uint32_t m,
-                       uint32_t max_len, char* out, uint32_t stride) {
-    hipLaunchKernelGGL(vmis_prep_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, di, items_flat, q_off, nq, m, max_len, out, stride);
+                       uint32_t max_len, char* out, uint32_t stride, uint32_t* zero_a, uint32_t* zero_b) {
+    static_assert(sizeof(PrepHead) == 72 && sizeof(PrepItem) == 24, "vmis_prep_kernel writes the record word by word");
+    const uint32_t per_block = 256 / PREP_LANES;
+    hipLaunchKernelGGL(vmis_prep_kernel, dim3((nq + per_block - 1) / per_block), dim3(256), 0, st, di, items_flat, q_off, nq, m, max_len, out, stride, zero_a, zero_b);
     return hipGetLastError();
 }
 

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -28,6 +29,7 @@ struct Knobs {
     int copy_slices = 0;      // SRN_COPY_SLICES: slices a result block is cut into for the copy threads (0 = one per thread)
     bool host_nocopy = false; // SRN_HOST_NOCOPY (experiments): the chunked host path leaves the results in its pinned staging
     bool host_trace = false;  // SRN_HOST_TRACE (experiments): per-call timeline of the chunked host path on stderr
+    bool timing = false;      // SRN_TIMING: kernel timing on from the start (srn_kernel_timing switches it per index)
     int d2h_blocks = 0;       // SRN_D2H_BLOCKS: workgroups of the chunked host path's own download kernel (0 = hipMemcpyAsync, the default: measured faster, profiles/r03_host_pipe_probe.txt)
     int tiny_max = 256;       // SRN_TINY_MAX: host-pointer batches of up to this many sessions take the zero-copy latency path
     int lanes = 4;            // SRN_PREDICT_LANES: concurrent rounds of the srn_predict combiner (srn_combine.cpp)
@@ -41,6 +43,7 @@ struct Workspace {
     hipStream_t stream = nullptr;   // own stream for host-pointer calls
     static constexpr int RING = 64;               // per-call events: start, after main kernel, after retry pass, after prep kernel
     hipEvent_t ev[RING][5] = {};                  // ... [4] = after the fast kernel (== [3] when the launch did not use it)
+    bool ring_timed[RING] = {};                   // the call recorded all five (kernel timing on: srn_kernel_timing); otherwise only [2], the end of the call
     uint64_t calls = 0, untimed_calls = 0; uint32_t last_retry = 0, last_nq = 0;
     bool last_fast = false;      // the last call went through the fast kernel: h_retry[1] = what it handed to the general kernel (otherwise: all of last_nq)
     bool last_untimed = false;   // the last call took the latency path: no events were recorded for it
@@ -57,6 +60,7 @@ struct Workspace {
     // staging for host-pointer calls
     char* stage = nullptr; size_t stage_bytes = 0;
     uint32_t* h_retry = nullptr;   // pinned
+    uint32_t* h_retry_dev = nullptr;   // ... as the device sees it (vmis_finish_big_kernel writes the two counters there)
     bool h_retry_valid = false; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // the global-table pass forked beside the finish kernels (srn_runtime.hip)
     hipEvent_t ev_block = nullptr; // blocking-sync event of the latency path (rounds shared by several callers)
     // SRN_FLAG_INPUTS_RESIDENT: this call's prep kernel on a side stream, beside the previous call's kernels (two sets of prep records)
@@ -77,6 +81,7 @@ struct DeviceState {
     Workspace* last_ws = nullptr;   // for srn_last_kernel_ms (single-threaded measurement use)
     std::vector<HostPipe*> free_pipes, all_pipes;   // chunked host-pointer batches (srn_hostpipe.hip), pooled like the workspaces
     unsigned long long* d_phase = nullptr; bool phase_on = false;   // debug per-phase cycle counters
+    std::atomic<bool> timing{false};   // record the per-kernel events of every call (srn_kernel_timing; SRN_TIMING=1): each event costs ~6 us of idle stream
 };
 
 // ---- shared helpers (srn_runtime.hip) ----

@@ -28,7 +28,7 @@ static void knobs_read() {
     if (const char* e = getenv("SRN_GRID_MULT")) { k.grid_mult = std::max(1, atoi(e)); k.grid_mult_set = true; }
     if (const char* e = getenv("SRN_HOST_CHUNKS")) k.host_chunks = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_COPY_SLICES")) k.copy_slices = std::max(0, atoi(e));
-    k.host_nocopy = getenv("SRN_HOST_NOCOPY") != nullptr; k.host_trace = getenv("SRN_HOST_TRACE") != nullptr;
+    k.host_nocopy = getenv("SRN_HOST_NOCOPY") != nullptr; k.host_trace = getenv("SRN_HOST_TRACE") != nullptr; k.timing = getenv("SRN_TIMING") != nullptr && atoi(getenv("SRN_TIMING")) != 0;
     if (const char* e = getenv("SRN_D2H_BLOCKS")) k.d2h_blocks = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_TINY_MAX")) k.tiny_max = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_PREDICT_LANES")) k.lanes = std::max(0, atoi(e));
@@ -55,7 +55,7 @@ DeviceState* device_attach(const FlatIndex& ix, int device) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) { set_error("no such HIP device"); return nullptr; }
     if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice failed"); return nullptr; }
-    DeviceState* d = new DeviceState(); d->device = device;
+    DeviceState* d = new DeviceState(); d->device = device; d->timing.store(knobs().timing);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) { d->n_cu = prop.multiProcessorCount; d->lds_per_block_max = (int)prop.sharedMemPerBlock; }
     bool ok = true;
@@ -207,6 +207,7 @@ Workspace* ws_acquire(DeviceState* d, bool bind_to_stream, void* user_stream) {
     for (auto& t : w->ev) for (auto& e : t) if (hipEventCreate(&e) != hipSuccess) { ws_free(w); return nullptr; }
     if (hipMalloc((void**)&w->retry_cnt, 16) != hipSuccess || hipMalloc((void**)&w->retry_cnt2, 16) != hipSuccess || hipMalloc((void**)&w->slow_cnt, 16) != hipSuccess || hipHostMalloc((void**)&w->h_retry, 16) != hipSuccess) { ws_free(w); return nullptr; }
     memset(w->h_retry, 0, 16);
+    if (hipHostGetDevicePointer((void**)&w->h_retry_dev, w->h_retry, 0) != hipSuccess) { ws_free(w); return nullptr; }
     d->all_ws.push_back(w);
     if (bind_to_stream) d->stream_ws.emplace_back(user_stream, w);
     return w;
@@ -491,9 +492,15 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         { int rc = ensure(&w->big, &w->big_bytes, big_entries * 16 + (size_t)p.nq * 4 + 64); if (rc) return rc; }
     }
     if (reserve_only) return SRN_OK;   // (srn_index_reserve: the workspace is sized, nothing was enqueued)
-    if (may_overflow || dense) { HIP_TRY(hipMemsetAsync(w->retry_cnt, 0, 4, st)); if (dense) HIP_TRY(hipMemsetAsync(w->retry_cnt2, 0, 4, st)); }
+    // The prep kernel clears the launch sequence's counters where it runs on this stream ahead of everything that uses them (two fill kernels otherwise: 6 us each)
+    const bool prep_clears = !ext && !resident;
+    if ((may_overflow || dense) && !prep_clears) HIP_TRY(hipMemsetAsync(w->retry_cnt, 0, 4, st));
+    if (dense) HIP_TRY(hipMemsetAsync(w->retry_cnt2, 0, 4, st));
     hipEvent_t* ev = w->ev[w->calls % Workspace::RING];
-    HIP_TRY(hipEventRecord(ev[0], st));
+    // Per-kernel events only when someone asked for kernel times: an event between two kernels idles the stream for ~6 us (three of them: 18 us of a 4 096-query batch's 250)
+    const bool timed = d->timing.load(std::memory_order_relaxed);
+    w->ring_timed[w->calls % Workspace::RING] = timed;
+    if (timed) HIP_TRY(hipEventRecord(ev[0], st));
     if (ext) { if (ext->prep_stride != prep_stride) return fail(SRN_EINVAL, "prep record stride mismatch"); p.prep = ext->prep; p.prep_stride = prep_stride; }
     else if (resident) {
         // prep of this call on the side stream: behind the call that used this set of records two calls ago, beside the previous call's kernels
@@ -505,8 +512,9 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         HIP_TRY(hipStreamWaitEvent(st, w->ev_prep[par], 0));
         p.prep = rec; p.prep_stride = prep_stride;
     }
-    else { HIP_TRY(launch_prep(st, di, p.items_flat, p.q_off, p.nq, p.m, p.max_len, w->prep, prep_stride)); p.prep = w->prep; p.prep_stride = prep_stride; }
-    HIP_TRY(hipEventRecord(ev[3], st));
+    else { HIP_TRY(launch_prep(st, di, p.items_flat, p.q_off, p.nq, p.m, p.max_len, w->prep, prep_stride, fast ? w->slow_cnt : nullptr, (may_overflow || dense) ? w->retry_cnt : nullptr));
+           p.prep = w->prep; p.prep_stride = prep_stride; }
+    if (timed) HIP_TRY(hipEventRecord(ev[3], st));
     const uint32_t* final_list = w->retry_list; uint32_t* final_cnt = w->retry_cnt;
     // The global-table retry pass serves a handful of queries with one workgroup each, ~0.3 ms behind everything else on config 5.  Where earlier
     // calls on this workspace did retry queries (the pinned counter of the last finished call says so: a hint, read without synchronising) it is forked onto the side
@@ -517,7 +525,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     // The fast kernel (srn_fast.hip) serves the common query shape; what it cannot take -- decided per query, on the device -- is
     // queued on slow_list and served by the general kernel right behind it.
     if (fast) {
-        HIP_TRY(hipMemsetAsync(w->slow_cnt, 0, 16, st));   // (slow_cnt[0] = handed-over queries, [2..3] = the 64-bit ticket of vmis_finish_big_kernel's list)
+        if (!prep_clears) HIP_TRY(hipMemsetAsync(w->slow_cnt, 0, 16, st));   // (slow_cnt[0] = handed-over queries, [2..3] = the 64-bit ticket of vmis_finish_big_kernel's list)
         // The fast kernel's workgroups walk their queries in a pipeline (the next record is fetched during the current query), so they want ~12 queries each;
         // beyond that, more and smaller workgroups shorten the tail of the launch.  Measured on config 3 (ms per launch at 8 / 16 / 32 / 64 resident sets): 2^20 queries
         // 26.29 / 26.06 / 25.85 / 25.81; 2^18: - / 6.62 / 6.57 / 6.63; 2^16: - / 1.70 / 1.72 / 1.78.
@@ -528,16 +536,17 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         FastParams fp = d->fast; fp.slow_list = w->slow_list; fp.slow_cnt = w->slow_cnt; fp.nb = nb_fast; fp.max_runs = nb_fast; fp.fin = w->fin;
         fp.big_arena = w->big; fp.big_list = (uint32_t*)(w->big + big_entries * 16); fp.big_ticket = (unsigned long long*)(w->slow_cnt + 2); fp.big_cap_entries = (uint32_t)big_entries;
         HIP_TRY(launch_fast(dim3(grid_f), st, di, p, fp, kn.debug));
-        HIP_TRY(hipEventRecord(ev[4], st));
+        if (timed) HIP_TRY(hipEventRecord(ev[4], st));
         HIP_TRY(launch_predict(geo.masks, slot64, false, 0, dim3(grid), lds, st, di, p, c, w->slow_list, w->slow_cnt, w->retry_list, w->retry_cnt, nullptr, 0, spill, ShardIO{}));
         if (fork_retry) {   // the global-table pass beside the finish kernels (they touch disjoint rows: a finish kernel only completes rows flagged by the fast kernel)
             HIP_TRY(hipEventRecord(w->ev_fork, st)); HIP_TRY(hipStreamWaitEvent(w->side, w->ev_fork, 0));
             HIP_TRY(launch_predict(geo.masks, slot64, true, 0, dim3(retry_blocks), c.off_a, w->side, di, p, cg, final_list, final_cnt, nullptr, nullptr, w->gscratch, g_stride, spill, ShardIO{}));
-            HIP_TRY(hipMemcpyAsync(w->h_retry, final_cnt, 4, hipMemcpyDeviceToHost, w->side));
             HIP_TRY(hipEventRecord(w->ev_join, w->side));
         }
         HIP_TRY(launch_finish(st, di, fp, p.out_ids, p.out_scores, p.out_counts, p.nq, p.how_many));
-        HIP_TRY(launch_finish_big(st, di, fp, p.out_ids, p.out_scores, p.out_counts, p.how_many, (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * 16)));
+        // (it also writes the call's two counters -- global-table queries, handed-over queries; both final once the general kernel is done -- into the pinned words)
+        HIP_TRY(launch_finish_big(st, di, fp, p.out_ids, p.out_scores, p.out_counts, p.how_many, (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * 16),
+                                  (may_overflow || dense) ? final_cnt : nullptr, w->slow_cnt, w->h_retry_dev));
     } else
     if (dense) {
         HIP_TRY(launch_predict(geo.masks, false, false, 0, dim3(grid3), g3.lds, st, di, p, g3.c, nullptr, nullptr, w->retry_list, w->retry_cnt, nullptr, 0, spill, ShardIO{}, 3));
@@ -545,17 +554,16 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         final_list = w->retry_list2; final_cnt = w->retry_cnt2;
     } else
         HIP_TRY(launch_predict(geo.masks, slot64, false, 0, dim3(grid), lds, st, di, p, c, nullptr, nullptr, w->retry_list, w->retry_cnt, nullptr, 0, spill, ShardIO{}));
-    if (!fast) HIP_TRY(hipEventRecord(ev[4], st));
-    HIP_TRY(hipEventRecord(ev[1], st));
+    if (!fast && timed) HIP_TRY(hipEventRecord(ev[4], st));
+    if (timed) HIP_TRY(hipEventRecord(ev[1], st));
     if (fork_retry) HIP_TRY(hipStreamWaitEvent(st, w->ev_join, 0));
     else if (may_overflow || dense) {
         const size_t lds_g = c.off_a;
         HIP_TRY(launch_predict(geo.masks, slot64, true, 0, dim3(retry_blocks), lds_g, st, di, p, cg, final_list, final_cnt, nullptr, nullptr,
                                w->gscratch, g_stride, spill, ShardIO{}));
-        HIP_TRY(hipMemcpyAsync(w->h_retry, final_cnt, 4, hipMemcpyDeviceToHost, st));
+        if (!fast) HIP_TRY(hipMemcpyAsync(w->h_retry, final_cnt, 4, hipMemcpyDeviceToHost, st));   // (fast: vmis_finish_big_kernel wrote both words.  Not fast: last_fast = false says
+                                                                                                  //  "all of last_nq" -- no host write into a pinned word that an earlier call may still be writing)
     }
-    if (fast) HIP_TRY(hipMemcpyAsync(w->h_retry + 1, w->slow_cnt, 4, hipMemcpyDeviceToHost, st));   // (not fast: last_fast = false says "all of last_nq" -- no host write into a
-                                                                                                   //  pinned word that an earlier call's copy on this stream may still be writing)
     HIP_TRY(hipEventRecord(ev[2], st));
     if (resident) { HIP_TRY(hipEventRecord(w->ev_done[w->resident_calls & 1u], st)); ++w->resident_calls; }
     ++w->calls; w->last_retry = (may_overflow || dense) ? 1 : 0; w->last_nq = p.nq; w->last_fast = fast; w->last_untimed = false;
@@ -644,6 +652,7 @@ int device_last_kernel_ms(DeviceState* d, double* ms_main, double* ms_retry, uin
     { std::lock_guard<std::mutex> lk(d->mu); w = d->last_ws; }
     if (!w || !(w->calls + w->untimed_calls)) return fail(SRN_EINVAL, "no timed predict call yet");
     if (w->last_untimed) return fail(SRN_EINVAL, "the last call took the latency path (<= 16 sessions on host pointers): it records no events");
+    if (!w->ring_timed[(w->calls - 1) % Workspace::RING]) return fail(SRN_EINVAL, "kernel timing is off: srn_kernel_timing(idx, 1) before the calls to be timed");
     hipEvent_t* ev = w->ev[(w->calls - 1) % Workspace::RING];
     HIP_TRY(hipEventSynchronize(ev[2]));
     float a = 0, b = 0;
@@ -674,6 +683,8 @@ int device_last_path_counts(DeviceState* d, uint32_t* nq, uint32_t* general, uin
     return SRN_OK;
 }
 
+int device_kernel_timing(DeviceState* d, int enable) { d->timing.store(enable != 0, std::memory_order_relaxed); return SRN_OK; }
+
 int device_phase_cycles(DeviceState* d, int enable, unsigned long long* out16) {
     HIP_TRY(hipSetDevice(d->device));
     HIP_TRY(hipDeviceSynchronize());
@@ -691,7 +702,9 @@ int device_kernel_times(DeviceState* d, uint32_t max_n, double* ms_main, double*
     { std::lock_guard<std::mutex> lk(d->mu); w = d->last_ws; }
     *out_n = 0;
     if (!w || !w->calls) return SRN_OK;
-    const uint64_t n = std::min<uint64_t>(std::min<uint64_t>(max_n, w->calls), Workspace::RING);
+    uint64_t n = std::min<uint64_t>(std::min<uint64_t>(max_n, w->calls), Workspace::RING);
+    { uint64_t timed = 0; while (timed < n && w->ring_timed[(w->calls - 1 - timed) % Workspace::RING]) ++timed; n = timed; }   // the trailing run of timed calls (srn_kernel_timing)
+    if (!n) return SRN_OK;
     HIP_TRY(hipEventSynchronize(w->ev[(w->calls - 1) % Workspace::RING][2]));
     for (uint64_t i = 0; i < n; ++i) {
         hipEvent_t* ev = w->ev[(w->calls - n + i) % Workspace::RING];

@@ -97,6 +97,10 @@ class VMISIndex:
         capi.check(capi.lib().srn_index_postings(self._h, int(item_id), capi.ptr(out), n.value, C.byref(n), C.byref(idf)))
         return out[:n.value], idf.value
 
+    def kernel_timing(self, enable=True):
+        """srn_kernel_timing: per-kernel HIP events on every batch call (what last_kernel_ms / kernel_times* read); off by default -- each event idles the stream ~6 us."""
+        capi.check(capi.lib().srn_kernel_timing(self._h, 1 if enable else 0))
+
     def last_kernel_ms(self):
         """(avg ms of the main predict kernel, ms of the retry pass, #queries retried) for the last call."""
         a, b, r = C.c_double(), C.c_double(), C.c_uint32()

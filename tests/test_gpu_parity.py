@@ -322,6 +322,37 @@ def test_business_rules_synthetic_tiny(kernel_path):
         assert gix.last_path_counts()[1] < nq // 2, "with business rules on, most queries should still be served by the fast kernel"
 
 
+def test_kernel_timing_is_a_switch_and_the_path_counts_do_not_need_it():
+    """srn_kernel_timing: off by default (the per-kernel events idle the launch stream), on for a benchmark; the counters of the call -- queries handed to the
+    general kernel, queries through the global-table pass -- arrive in pinned words written by the last finish kernel either way."""
+    import serenade_amd as sa
+    from serenade_amd import synth, capi
+    inter, n_items, k, m, idfw = synth.CONFIGS["tiny"]
+    off, items, ts = synth.training_sessions(inter, n_items)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw)
+    flat, qoff = synth.queries(3000, n_items)
+    nq = len(qoff) - 1
+    a = sa.predict_batch(gix, (flat, qoff), k, m, 21, False)
+    with pytest.raises(capi.SerenadeError) as e:
+        gix.last_kernel_ms()
+    assert e.value.code == capi.SRN_EINVAL
+    assert len(gix.kernel_times(8)[0]) == 0
+    counts_off = gix.last_path_counts()
+    assert counts_off[0] == nq and counts_off[1] < nq // 4
+    gix.kernel_timing(True)
+    b = sa.predict_batch(gix, (flat, qoff), k, m, 21, False)
+    ms, _, _ = gix.last_kernel_ms()
+    assert ms > 0
+    t_prep, t_fast, t_pred, t_retry = gix.kernel_times_detail(8)
+    assert len(t_fast) >= 1 and (t_fast > 0).all() and (t_prep > 0).all()
+    assert gix.last_path_counts() == counts_off
+    gix.kernel_timing(False)
+    c = sa.predict_batch(gix, (flat, qoff), k, m, 21, False)
+    assert len(gix.kernel_times(8)[0]) == 0          # only the trailing run of timed calls is reported
+    for x in (b, c):
+        assert all(np.array_equal(u, v) for u, v in zip(a, x))
+
+
 def test_device_pointer_entry_point_matches_host_entry_point():
     torch = pytest.importorskip("torch")
     import serenade_amd as sa

@@ -9,6 +9,7 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
 inter, n_items, k, m, idfw = synth.CONFIGS[cfg]
 off, items, ts = synth.training_sessions(inter, n_items)
 ix = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw, device=0)
+ix.kernel_timing(True)
 qi, qo = synth.queries(int(B / 3) + 2048, n_items, seed=synth.SEED + 7919)
 qi, qo = qi[:qo[B]], qo[:B + 1]
 for rep in range(3):

@@ -17,6 +17,7 @@ d_flat = torch.from_numpy(qi.view(np.int64).copy()).to(dev); d_off = torch.from_
 o_ids = torch.zeros(B * n, dtype=torch.int64, device=dev); o_sc = torch.zeros(B * n, dtype=torch.float64, device=dev); o_cnt = torch.zeros(B, dtype=torch.int32, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 sa.reserve(ix, B, synth.LAST_ITEMS, k, m, n, False, st)
+ix.kernel_timing(True)
 for _ in range(11):
     sa.predict_batch_device(ix, d_flat.data_ptr(), d_off.data_ptr(), B, synth.LAST_ITEMS, k, m, n, False, o_ids.data_ptr(), o_sc.data_ptr(), o_cnt.data_ptr(), st)
 torch.cuda.synchronize()
