@@ -900,7 +900,7 @@ __global__ __launch_bounds__(64) void vmis_finish_big_kernel(DeviceIndex ix, con
     constexpr uint32_t CAP = F_CAND_CAP + F_TABLE_BUCKETS * 4u;
     // the launch sequence's two counters (queries for the global-table pass, queries handed to the general kernel: both final before this kernel starts) straight into
     // the workspace's pinned words -- two 4-byte device-to-host copies cost 9 us of every call
-    if (host_words && blockIdx.x == 0u && threadIdx.x == 0u) { host_words[0] = cnt_retry ? *cnt_retry : 0u; host_words[1] = cnt_slow ? *cnt_slow : 0u; }
+    if (host_words && blockIdx.x == 0u && threadIdx.x == 0u) { if (cnt_retry) host_words[0] = *cnt_retry; if (cnt_slow) host_words[1] = *cnt_slow; }   // (a null source: that word is someone else's)
     __shared__ unsigned long long key[CAP];
     __shared__ uint32_t tieb[CAP];
     __shared__ uint32_t hist[256];

@@ -520,6 +520,8 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     // calls on this workspace did retry queries (the pinned counter of the last finished call says so: a hint, read without synchronising) it is forked onto the side
     // stream right behind the general kernel and runs beside the finish kernels; where nothing is ever retried (configs 2-4) the two extra events would cost more
     // than the empty pass.
+    // (Tried in round 3 and dropped: the general kernel over the handed-over queries + the global-table pass on the side stream, beside the two finish kernels -- 38 + 4 us
+    //  against 17 + 10 us at 4 096 queries.  4 096 / 65 536 / 2^20 queries: 0.220 / 1.759 / 25.28 ms forked, 0.215 / 1.759 / 25.25 ms in line.)
     const bool fork_retry = fast && may_overflow && !dense && on_device && *(volatile uint32_t*)w->h_retry != 0u && w->h_retry_valid;
     if (fork_retry) { int rc = ensure_side(w); if (rc) return rc; }
     // The fast kernel (srn_fast.hip) serves the common query shape; what it cannot take -- decided per query, on the device -- is
