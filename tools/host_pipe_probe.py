@@ -27,11 +27,13 @@ def run(nq, reps, label, **env):
     ms = np.array(ms[2:])
     print("%-44s nq %8d  p50 %8.3f ms  min %8.3f ms  -> %6.2f M q/s" % (label, nq, np.median(ms), ms.min(), nq / np.median(ms) / 1e3)); sys.stdout.flush()
 os.environ["SRN_HOST_TRACE"] = "1"
-for nq, reps in ((1 << 20, 4), (65536, 8), (4096, 10)):
+SIZES = [int(x) for x in os.environ.get("PROBE_SIZES", "1048576,65536,4096").split(",")]
+QUICK = os.environ.get("PROBE_QUICK") is not None    # chunk counts only
+for nq, reps in [(s, 4 if s >= (1 << 19) else 10) for s in SIZES]:
     run(nq, reps, "default")
     run(nq, reps, "no copy to the caller's buffers", SRN_HOST_NOCOPY=1)
-    for ch in (1, 2, 4, 8, 16, 32):
+    for ch in ((1, 2, 3, 4, 6) if QUICK else (1, 2, 4, 8, 16, 32)):
         if nq // ch >= 1024:
             run(nq, reps, "chunks=%d" % ch, SRN_HOST_CHUNKS=ch)
-    for blk in (0, 16, 32, 128, 256):
+    for blk in (() if QUICK else (0, 16, 32, 128, 256)):
         run(nq, reps, "download kernel blocks=%d" % blk, SRN_D2H_BLOCKS=blk)
