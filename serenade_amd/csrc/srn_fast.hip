@@ -340,6 +340,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         else if (nr == 3u) { merge_pair(B0, B1, 0u, kp[0], kp[1], tid, merge_team(s2)); __syncthreads(); merge_pair(B1, B0, 0u, s2, kp[2], tid, merge_team(n)); __syncthreads(); }
         else if (nr == 4u) { merge_pair(B0, B1, 0u, kp[0], kp[1], tid, merge_team(s2)); merge_pair(B0, B1, s2, kp[2], kp[3], 511u - tid, merge_team(n - s2)); __syncthreads();
                              merge_pair(B1, B0, 0u, s2, kp[2] + kp[3], tid, merge_team(n)); __syncthreads(); }
+        FAST_TICK(3);
         const uint32_t* F = B0; uint32_t* D = B1;
         // ---- m-cut: the copies of a session are adjacent in F; the first m distinct sessions, position sets OR-ed ----
         uint32_t Call, Cm;
