@@ -321,7 +321,9 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             FAST_TICK(1);
         } else {
         // ---- phase 1: stage the lists' kept prefixes as packed slots (rank << NB | position bit) ---------
-        uint32_t* const B0 = (uint32_t*)(smem + F_WORK); uint32_t* const B1 = B0 + n;
+        // (B1 is the LOWER half: the m-cut's output D lands there, on top of the neighbour list's own words -- where no k-cut follows, D is the neighbour list as it stands)
+        uint32_t* const B1 = (uint32_t*)(smem + F_WORK); uint32_t* const B0 = B1 + n;
+        static_assert(F_WORK == F_NBL, "the m-cut writes the neighbour list in place");
         const uint32_t nl = (nr > 1u) + (nr > 2u);
         {
             uint32_t* const d01 = nl == 1u ? B1 : B0; uint32_t* const d2 = nr == 3u ? B1 : B0;
@@ -364,10 +366,8 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         __syncthreads();
         FAST_TICK(2);
         // ---- k-cut: D is ordered by recency, so inside one numerator class the order is already the wanted one ----
-        if (Cm <= p.k) {
-            for (uint32_t e = tid; e < Cm; e += BLOCK) nbl[e] = D[e];
-            if (tid == 0) misc[FS_NB] = Cm;
-        } else {
+        if (Cm <= p.k) K = Cm;   // (block-uniform; the m-cut wrote the neighbour list)
+        else {
             uint32_t* cls = misc + FS_CLS;
             const uint32_t g = (Cm + BLOCK - 1) / BLOCK, o0 = min(tid * g, Cm), o1 = min(o0 + g, Cm);   // g <= 5
             uint32_t dv[5], nmv[5];
@@ -418,9 +418,9 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)base, 63) + inc - sel;
 #pragma unroll
             for (int x = 0; x < 5; ++x) if (take[x]) nbl[at++] = dv[x];
+            __syncthreads();
+            K = misc[FS_NB];
         }
-        __syncthreads();
-        K = misc[FS_NB];
         }
 
         FAST_TICK(4);
