@@ -24,7 +24,7 @@ cyc = ix.debug_phase_cycles(False).astype(np.float64)
 ms, msr, _ = ix.last_kernel_ms()
 print("path counts (nq, general kernel, global pass):", ix.last_path_counts())
 r = sa.predict_batch_debug(ix, (qi, qo), k, m, 21, bool(FL), neighbours=False)
-names = ["0 prep+clear", "1 stage lists", "2 merges+m-cut", "3 class count", "4 k-cut scans+publish", "5", "6", "7", "8 clear hot+sketch", "9 walk A", "10 harvest hot", "11 live check+clear", "12 walk B (+surv)", "13 harvest exact/final", "14", "15"]
+names = ["0 prep+clear", "1 stage lists", "2 m-cut (fast kernel; general kernel: merges+m-cut)", "3 merge tree (fast kernel; general kernel: class count)", "4 k-cut scans+publish", "5", "6", "7", "8 clear hot+sketch", "9 walk A", "10 harvest hot", "11 live check+clear", "12 walk B (+surv)", "13 harvest exact/final", "14", "15"]
 print("main %.2f ms retry %.2f ms  total cycles %.3g" % (ms, msr, cyc.sum()))
 for n, c in zip(names, cyc):
     print("  %-18s %6.2f%%  %.0f cyc/query" % (n, 100 * c / cyc.sum(), c / B))

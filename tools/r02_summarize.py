@@ -103,7 +103,7 @@ def sq(da, db, nq, phase_log):
             out["phase_cycles_per_query"]["tick %s" % m.group(1)] = int(m.group(4))
         if l.startswith("fast kernel:") or l.startswith("path counts") or l.startswith("main "):
             out.setdefault("phase_profile_lines", []).append(l.strip())
-    out["phase_legend"] = {"0": "record + barrier", "1": "stage lists", "2": "merge tree + m-cut", "4": "k-cut", "8": "row requests + clears", "9": "walk A", "10": "phase 4a (threshold, floors)",
+    out["phase_legend"] = {"0": "record + barrier", "1": "stage lists", "3": "merge tree (fast kernel, since round 3)", "2": "m-cut (+ merge tree before round 3)", "4": "k-cut", "8": "row requests + clears", "9": "walk A", "10": "phase 4a (threshold, floors)",
                            "11": "walk B (list)", "12": "resolve the hit list", "13": "hand-off record"}
     print(json.dumps(out, indent=1))
 
