@@ -625,6 +625,29 @@ def test_sixty_four_host_threads_combine_into_rounds():
     assert [r.id for r in sa.predict(gix, qs[0], 10, 30, 5, False)] == ref1["ids"][0, :int(ref1["counts"][0])].tolist()
 
 
+def test_single_chunk_host_batches_download_in_pieces():
+    """A host batch of one chunk with >= 1 MB of results comes back in pieces (two, copied by the calling thread, below 4 MB; up to eight of >= 2 MB through the copy
+    threads above): the pieces cut across the ids | scores | counts layout of the staging buffer at 4 KB boundaries -- every byte must land where the one-piece path puts it."""
+    import torch
+    import serenade_amd as sa
+    from serenade_amd import synth
+    inter, n_items, k, m, idfw = synth.CONFIGS["tiny"]
+    off, items, ts = synth.training_sessions(inter, n_items)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw)
+    flat, qoff = synth.queries(60000, n_items)
+    dev = torch.device("cuda:0")
+    for nq, n in ((3500, 21), (13001, 21), (50000, 21), (50000, 5), (30011, 24)):      # 1.2 MB (2 pieces), 4.4 MB (2 through the pool), 17 MB (8), 4.2 MB, 11.6 MB (5)
+        f, o = flat[:qoff[nq]], qoff[:nq + 1]
+        got = sa.predict_batch(gix, (f, o), k, m, n, False)
+        d_f = torch.from_numpy(f.view(np.int64).copy()).to(dev); d_o = torch.from_numpy(o.view(np.int32).copy()).to(dev)
+        r_ids = torch.zeros(nq * n, dtype=torch.int64, device=dev); r_sc = torch.zeros(nq * n, dtype=torch.float64, device=dev); r_cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
+        sa.predict_batch_device(gix, d_f.data_ptr(), d_o.data_ptr(), nq, 8, k, m, n, False, r_ids.data_ptr(), r_sc.data_ptr(), r_cnt.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(got[0].reshape(-1), r_ids.cpu().numpy().view(np.uint64)), (nq, n)
+        assert np.array_equal(got[1].reshape(-1), r_sc.cpu().numpy()), (nq, n)
+        assert np.array_equal(got[2], r_cnt.cpu().numpy().view(np.uint32)), (nq, n)
+
+
 @pytest.mark.parametrize("chunks", [0, 1, 3, 7])
 def test_host_pointer_batches_through_the_chunked_pipeline(chunks, monkeypatch):
     """srn_predict_batch on host buffers: <= 256 sessions take the zero-copy latency path, larger batches are cut into chunks whose uploads,
