@@ -347,20 +347,37 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         // ---- m-cut: the copies of a session are adjacent in F; the first m distinct sessions, position sets OR-ed ----
         uint32_t Call, Cm;
         {
+            constexpr int MC_G = 6;   // chunks of <= MC_G entries (n <= 3072) are read with all LDS reads in flight together, twice; longer ones one entry per round trip
             const uint32_t g = (n + BLOCK - 1) / BLOCK, o0 = min(tid * g, n), o1 = min(o0 + g, n);
-            uint32_t firsts = 0;
-            uint32_t prev = o0 > 0u && o0 < o1 ? F[o0 - 1] >> NB : 0xFFFFFFFFu;
-            const uint32_t prev0 = prev;
-            for (uint32_t o = o0; o < o1; ++o) { const uint32_t r = F[o] >> NB; firsts += o == 0u || r != prev; prev = r; }
+            const uint32_t prev0 = o0 > 0u && o0 < o1 ? F[o0 - 1] >> NB : 0xFFFFFFFFu;   // (no rank is 0xFFFFFFFF: F[0] starts a session)
+            uint32_t firsts = 0, prev = prev0;
+            if (g <= (uint32_t)MC_G) {   // (block-uniform)
+                uint32_t fv[MC_G];
+#pragma unroll
+                for (int x = 0; x < MC_G; ++x) fv[x] = F[min(o0 + (uint32_t)x, n - 1u)];
+#pragma unroll
+                for (int x = 0; x < MC_G; ++x) { const bool in = o0 + (uint32_t)x < o1; const uint32_t r = fv[x] >> NB; firsts += in && r != prev; prev = in ? r : prev; }
+            } else
+                for (uint32_t o = o0; o < o1; ++o) { const uint32_t r = F[o] >> NB; firsts += r != prev; prev = r; }
             for (uint32_t i = tid; i < min(n, p.m); i += BLOCK) D[i] = 0;
             uint32_t idx = block_excl_scan<BLOCK>(firsts, misc + FS_SCAN_A, Call);   // (barrier inside)
             prev = prev0;
-            for (uint32_t o = o0; o < o1; ++o) {
-                const uint32_t v = F[o], r = v >> NB;
-                const bool first = o == 0u || r != prev; prev = r;
-                idx += first;
-                if (idx - 1u < p.m) atomicOr(&D[idx - 1u], v);
-            }
+            if (g <= (uint32_t)MC_G) {
+                uint32_t fv[MC_G];
+#pragma unroll
+                for (int x = 0; x < MC_G; ++x) fv[x] = F[min(o0 + (uint32_t)x, n - 1u)];
+#pragma unroll
+                for (int x = 0; x < MC_G; ++x) {
+                    const bool in = o0 + (uint32_t)x < o1; const uint32_t r = fv[x] >> NB;
+                    idx += in && r != prev; prev = in ? r : prev;
+                    if (in && idx - 1u < p.m) atomicOr(&D[idx - 1u], fv[x]);
+                }
+            } else
+                for (uint32_t o = o0; o < o1; ++o) {
+                    const uint32_t v = F[o], r = v >> NB;
+                    idx += r != prev; prev = r;
+                    if (idx - 1u < p.m) atomicOr(&D[idx - 1u], v);
+                }
             Cm = min(Call, p.m);
         }
         __syncthreads();
