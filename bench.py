@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--resident-flag", action="store_true", help="call srn_predict_batch_device with SRN_FLAG_INPUTS_RESIDENT (a step's prep kernel then runs beside the previous "
                     "step's kernels; measured on config 3: the prep kernel's 0.44 ms disappear from the step but the fast kernel slows down by 0.7 ms -- 40.5 M against 41.3 M queries/s -- "
                     "so it is off by default)")
-    ap.add_argument("--shard-timeout", type=int, default=900, help="seconds the item-sharded phase may take before the line falls back to the replicas mode alone")
+    ap.add_argument("--shard-timeout", type=int, default=420, help="seconds the item-sharded phase may take before the line falls back to the replicas mode alone")
     ap.add_argument("--selftest-launch", action="store_true", help="CPU check of the launcher and the control plane (gloo): no GPU, no timing")
     ap.add_argument("--builder", default="gpu", choices=["gpu", "host"], help="index construction: rocPRIM sorts on the GPU, or the host builder (same bytes)")
     ap.add_argument("--parity", type=int, default=2048, help="queries of batch 0 checked against the canonical oracle before anything is timed (0 = skip)")
@@ -123,6 +123,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        print("bench.py: rank %s of %d started (local rank %s)" % (os.environ.get("RANK", "0"), world, os.environ.get("LOCAL_RANK", "0")), file=sys.stderr); sys.stderr.flush()
     args.gpus = world
     if args.selftest_launch:
         # the launcher + control plane on CPU: process group over gloo, barrier, the max-over-ranks reduction of the timing, the broadcast that carries
@@ -533,6 +535,9 @@ def main():
             line = result
         print(json.dumps(line))
         sys.stdout.flush()
+    if shard_error is not None:      # (a communicator in an unknown state: its teardown may wait for peers that are gone -- the line is out, leave)
+        sys.stderr.flush()
+        os._exit(0)
     with c_stdout_to_stderr():
         if group is not None:
             group.close()

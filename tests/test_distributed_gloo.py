@@ -159,7 +159,8 @@ def test_bench_launches_its_own_ranks_when_started_bare():
     if torch.cuda.is_available():
         pytest.skip("a GPU is visible: this checks the launcher on the CPU box")
     assert r.returncode != 0
-    assert r.stderr.count("no GPU visible") >= 2, r.stderr[-2000:]          # both ranks started and reached the device check
+    assert "rank 0 of 2 started" in r.stderr and "rank 1 of 2 started" in r.stderr, r.stderr[-2000:]     # both ranks were launched with the rendezvous environment
+    assert r.stderr.count("no GPU visible") >= 1, r.stderr[-2000:]          # ... and reached the device check (the launcher stops the peers of the first rank that fails)
 
 
 def test_bench_control_plane_over_gloo_world_2():
