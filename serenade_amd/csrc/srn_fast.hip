@@ -472,6 +472,9 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             if (m3) nbl[qpos(cnt3 + (uint32_t)__popcll(b3 & lt))] = svr[t];
             cnt3 += (uint32_t)__popcll(b3);
         }
+#ifdef SRN_FAST_SUBTICKS
+        FAST_TICK(5);   // (wave 0 has its rows' first 16 bytes)
+#endif
         // The second 16 bytes (items 6..13) are asked for only now, and only by the rows that have them (1 in 4): the other lanes all read the empty
         // slot's -- one line for the lot -- so the address unit sees a quarter of the requests; the lines themselves came with the first 16 bytes.
         if constexpr (!FRAG) {
@@ -537,8 +540,14 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
                     add2(e4.x, w); add2(e4.y, w); add2(e4.z, w); add2(e4.w, w);
                 }
             } };
+#ifdef SRN_FAST_SUBTICKS
+        FAST_TICK(6);   // (round (i): second 16 bytes + adds issued)
+#endif
         if (cnt3) add_tail(0u, sv3, hdr3, c43, d43, blk3);
         for (uint32_t p0 = 64u; p0 < cnt3; p0 += 64u) { uint32_t sv, hdr, blk; uint4 c4, d4; q3_load(p0, sv, hdr, c4, d4, blk); add_tail(p0, sv, hdr, c4, d4, blk); }
+#ifdef SRN_FAST_SUBTICKS
+        FAST_TICK(7);   // (wave 0's tail rounds done; what follows is the wait for the other waves)
+#endif
         __syncthreads();
         FAST_TICK(9);
         // ---- phase 4a: the direct-mapped items, exactly -> threshold, candidates ----------------------------
