@@ -878,8 +878,9 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
         }
         phase_sync<GLOBAL_TABLES>();
         if (misc[S_OVF]) {   // block-uniform: hand the query to the global-table pass
-            if (STAGE != 0) { if (tid == 0) { if (STAGE == 1) sh.cand_cnt[q] = 0xFFFFFFFFu; else sh.nb_cnt[q] = 0xFFFFFFFFu; } }
-            else if (GLOBAL_TABLES) { if (tid == 0) { p.out_counts[q] = 0xFFFFFFFFu; if (p.stats) p.stats[(size_t)q * 8 + 7] = 3; } }
+            // (stages of the sharded pipeline: queued for the stage's own global-table pass where the caller provides a list -- device_shard_stage --, marked otherwise)
+            if (STAGE != 0 && (GLOBAL_TABLES || aux.retry_list == nullptr)) { if (tid == 0) { if (STAGE == 1) sh.cand_cnt[q] = 0xFFFFFFFFu; else sh.nb_cnt[q] = 0xFFFFFFFFu; } }
+            else if (STAGE == 0 && GLOBAL_TABLES) { if (tid == 0) { p.out_counts[q] = 0xFFFFFFFFu; if (p.stats) p.stats[(size_t)q * 8 + 7] = 3; } }
             else if (tid == 0) aux.retry_list[atomicAdd(aux.retry_cnt, 1u)] = q;
             continue;
         }
@@ -1537,7 +1538,7 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
             if (cnt > 1 && cnt != misc[S_SORTED]) sort_candidates(cnt);
         }
         if (failed) {
-            if (GLOBAL_TABLES || STAGE == 3) { if (tid == 0) { p.out_counts[q] = 0xFFFFFFFFu; if (p.stats) p.stats[(size_t)q * 8 + 7] = 3; } }
+            if (GLOBAL_TABLES || (STAGE == 3 && aux.retry_list == nullptr)) { if (tid == 0) { p.out_counts[q] = 0xFFFFFFFFu; if (p.stats) p.stats[(size_t)q * 8 + 7] = 3; } }
             else if (tid == 0) aux.retry_list[atomicAdd(aux.retry_cnt, 1u)] = q;
             continue;
         }
@@ -1587,7 +1588,10 @@ hipError_t launch_predict(bool masks, bool slot64, bool global_tables, int stage
                      : launch_variant<kBlock, false, 0, false, 3>(false, grid, lds, st, di, p, c, qlist, qn, retry_list, retry_cnt, gscratch, gscratch_stride, nb_spill, sh);
     }
 #define SRN_V(G, S, M) launch_variant<kBlock, G, S, M>(slot64, grid, lds, st, di, p, c, qlist, qn, retry_list, retry_cnt, gscratch, gscratch_stride, nb_spill, sh)
-    if (global_tables) return stage != 0 ? hipErrorInvalidValue : (masks ? SRN_V(true, 0, true) : SRN_V(true, 0, false));
+    if (global_tables) {   // (the stages' global-table passes exist for numerator slots only: with position sets the shard group takes the lists pipeline)
+        if (stage != 0) return masks ? hipErrorInvalidValue : stage == 1 ? SRN_V(true, 1, false) : stage == 2 ? SRN_V(true, 2, false) : stage == 3 ? SRN_V(true, 3, false) : hipErrorInvalidValue;
+        return masks ? SRN_V(true, 0, true) : SRN_V(true, 0, false);
+    }
     switch (stage) {
         case 0: return masks ? SRN_V(false, 0, true) : SRN_V(false, 0, false);
         case 1: return masks ? SRN_V(false, 1, true) : SRN_V(false, 1, false);

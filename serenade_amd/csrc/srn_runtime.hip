@@ -586,7 +586,9 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     return SRN_OK;
 }
 
-// One stage of the item-sharded pipeline (device buffers, asynchronous on `stream`); see ShardIO.
+// One stage of the item-sharded pipeline (device buffers, asynchronous on `stream`); see ShardIO.  Like the unsharded launch sequence, a stage has a second pass
+// with its tables in global memory for the queries whose session or item table does not fit LDS (numerator slots only: with position sets the shard group runs the
+// lists pipeline, and the stand-alone srn_shard_stage_* calls mark such a query 0xFFFFFFFF as before).
 int device_shard_stage(DeviceState* d, const FlatIndex& ix, int stage, const LaunchParams& p_in, const ShardIO& sh, void* stream) {
     HIP_TRY(hipSetDevice(d->device));
     LaunchParams p = p_in;
@@ -600,8 +602,29 @@ int device_shard_stage(DeviceState* d, const FlatIndex& ix, int stage, const Lau
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;
     if (stage < 1 || stage > 3) return fail(SRN_EINVAL, "bad stage");
-    e = launch_predict(geo.masks, geo.slot64, false, stage, dim3(grid), geo.lds, st, d->di, p, geo.c, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, sh);
+    const bool retry = !geo.masks && (geo.sess_may_overflow || geo.item_may_overflow);
+    Workspace* w = nullptr;
+    struct Rel { DeviceState* d; Workspace* w; ~Rel() { if (w) ws_release(d, w, true); } } rel{d, nullptr};
+    KernelCfg cg = geo.c; uint64_t g_stride = 0; int retry_blocks = 0;
+    if (retry) {
+        w = ws_acquire(d, true, stream); rel.w = w;
+        if (!w) return fail(SRN_EHIP, "cannot create HIP stream / events");
+        if (w->retry_cap < p.nq) { if (w->retry_list) HIP_TRY(hipFree(w->retry_list)); w->retry_list = nullptr; w->retry_cap = 0;
+            HIP_TRY(hipMalloc((void**)&w->retry_list, (size_t)p.nq * 4 + 64)); w->retry_cap = p.nq; }
+        cg.sess_slots = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(256, ceil_pow2(geo.need_sess * 2)));
+        cg.item_buckets = prime_at_least(geo.need_item / 2 + 64); cg.item_slots = cg.item_buckets * 4;
+        g_stride = std::max<uint64_t>((uint64_t)cg.sess_slots * geo.slot_bytes, (uint64_t)cg.hot_slots * 4 + (uint64_t)cg.sketch_slots * 4 + (uint64_t)cg.item_slots * 8);
+        g_stride = (g_stride + 255) / 256 * 256;
+        retry_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)d->n_cu, (2ull << 30) / g_stride));
+        rc = ensure(&w->gscratch, &w->gscratch_bytes, g_stride * retry_blocks); if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(w->retry_cnt, 0, 4, st));
+    }
+    e = launch_predict(geo.masks, geo.slot64, false, stage, dim3(grid), geo.lds, st, d->di, p, geo.c, nullptr, nullptr, w ? w->retry_list : nullptr, w ? w->retry_cnt : nullptr, nullptr, 0, nullptr, sh);
     if (e != hipSuccess) return fail(SRN_EHIP, std::string("shard stage launch: ") + hipGetErrorString(e));
+    if (retry) {
+        e = launch_predict(false, geo.slot64, true, stage, dim3(retry_blocks), geo.c.off_a, st, d->di, p, cg, w->retry_list, w->retry_cnt, nullptr, nullptr, w->gscratch, g_stride, nullptr, sh);
+        if (e != hipSuccess) return fail(SRN_EHIP, std::string("shard stage launch (global tables): ") + hipGetErrorString(e));
+    }
     return SRN_OK;
 }
 // ---- item-sharded index, lists mode (srn_shard.hip): the steps either side of the exchanges; device buffers, asynchronous on `stream` ----

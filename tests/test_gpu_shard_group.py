@@ -102,6 +102,36 @@ def test_local_group_three_stage_pipeline_for_what_the_lists_pipeline_does_not_s
     assert st["stage_batches"] == stage_batches + 1 and st["bytes_stage_candidates"] > 0 and st["bytes_stage_minpos"] > 0
 
 
+def test_three_stage_pipeline_serves_sessions_whose_tables_outgrow_lds():
+    """Sessions of up to 20 items on posting lists of 3 000 sessions: a query's candidate table (up to 60 000 sessions) does not fit LDS.  Unsharded, such a query takes the
+    global-table pass; the stages of the sharded pipeline have one of their own since round 3 (found by tools/fuzz_parity.py: they used to come back as 0xFFFFFFFF)."""
+    import serenade_amd as sa
+    from serenade_amd import sharded
+    from oracle import oracle as O
+    off, items, ts, ids = small_dataset(100099, n_sessions=30000, n_items=300, max_len=12)
+    qs = random_queries(100100, ids, 700, max_len=20, unknown_rate=0.05, dup_rate=0.2)
+    flat, qoff = flatten(qs)
+    d_flat, d_off = _to_dev(flat, qoff)
+    full = sa.VMISIndex.from_sessions(off, items, ts, 3000, 12, 5.0)
+    oix = O.OracleIndex(off, items, ts, 3000, 12, 5.0)
+    for G in (2, 5):
+        grp = sharded.ShardGroup.local([sharded.ShardedVMISIndex.from_full(full, g, G) for g in range(G)])
+        for (k, m, n) in [(100, 6000, 21), (1500, 3000, 21)]:
+            ref = oix.predict_batch("canonical", flat, qoff, k, m, n, False, threads=4)
+            got = _np(grp.predict_batch(d_flat, d_off, len(qs), 20, k, m, n))
+            assert not (got[2] == 0xFFFFFFFF).any(), "every query is served"
+            _check_oracle(got, ref, n)
+        assert grp.stats["stage_batches"] == 2
+
+
+def test_randomised_parity_soak_sixty_indices():
+    """tools/fuzz_parity.py, 60 random indices (fixed seed): every entry point against the oracle."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "600", "7", "60"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "fuzz ok: 60 index rounds" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
 def test_local_group_business_rules_against_the_oracle():
     """Real product flags incl. None: the current item's attribute byte lives on its owner shard and reaches the others with the first all-reduce."""
     import serenade_amd as sa
