@@ -124,12 +124,12 @@ def test_three_stage_pipeline_serves_sessions_whose_tables_outgrow_lds():
         assert grp.stats["stage_batches"] == 2
 
 
-def test_randomised_parity_soak_sixty_indices():
-    """tools/fuzz_parity.py, 60 random indices (fixed seed): every entry point against the oracle."""
+def test_randomised_parity_soak():
+    """tools/fuzz_parity.py, 25 random indices (fixed seed; kernel-path knobs, shard counts, parameters drawn per index): every entry point against the oracle."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "600", "7", "60"], capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "fuzz ok: 60 index rounds" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "600", "7", "25"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "fuzz ok: 25 index rounds" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
 
 
 def test_local_group_business_rules_against_the_oracle():

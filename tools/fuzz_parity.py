@@ -2,7 +2,7 @@
 host batches on both sides of the latency-path limit, device-resident batches, the shard group -- against the canonical oracle, bit for bit on ids / counts and 1e-12
 on scores.  usage: python tools/fuzz_parity.py [seconds] [seed] [max index rounds]   (prints the failing configuration and exits 1 on the first mismatch)
 Round 3: its first minute found the three-stage sharded pipeline returning 0xFFFFFFFF for sessions whose candidate table outgrows LDS (20 items x 3 000 sessions per item) --
-the stages have a global-table pass of their own since (device_shard_stage); 12 160 comparisons over 1 216 random indices pass."""
+the stages have a global-table pass of their own since (device_shard_stage); 12 160 comparisons over 1 216 random small indices pass, and 7 505 over 395 indices with the kernel-path knobs and larger indices mixed in."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -34,7 +34,15 @@ def check(got, ref, n, what, cfg):
 while time.time() < t_end and rounds < max_rounds:
     seed = seed0 * 100003 + rounds
     rng = np.random.default_rng(seed)
-    n_sessions = int(rng.choice([300, 2000, 8000, 30000])); n_items = int(rng.choice([40, 300, 2500]))
+    # kernel-path knobs (read once by the library: reloaded per round)
+    KNOBS = [{}, {}, {}, {"SRN_NO_FAST": "1"}, {"SRN_NO_MERGE": "1"}, {"SRN_NO_MASKS": "1"}, {"SRN_HOT_SLOTS": "64", "SRN_NO_MASKS": "1"}, {"SRN_SKETCH_SLOTS": "64", "SRN_HOT_SLOTS": "32"},
+             {"SRN_FAST_RUNS": "3"}, {"SRN_DENSE": "1"}, {"SRN_TINY_MAX": "1"}, {"SRN_HOST_CHUNKS": "3"}, {"SRN_SKETCH_SLOTS": "0"}, {"SRN_HOT_SLOTS": "0"}]
+    for kk in ("SRN_NO_FAST", "SRN_NO_MERGE", "SRN_NO_MASKS", "SRN_HOT_SLOTS", "SRN_SKETCH_SLOTS", "SRN_FAST_RUNS", "SRN_DENSE", "SRN_TINY_MAX", "SRN_HOST_CHUNKS"):
+        os.environ.pop(kk, None)
+    knobs = KNOBS[int(rng.integers(0, len(KNOBS)))]
+    os.environ.update(knobs); capi.reload_knobs()
+    big = rng.random() < 0.15   # now and then an index large enough for the cuts to bite on realistic list lengths
+    n_sessions = int(rng.choice([300, 2000, 8000, 30000])) if not big else int(rng.choice([120000, 300000])); n_items = int(rng.choice([40, 300, 2500])) if not big else int(rng.choice([2500, 20000]))
     row_max = int(rng.choice([4, 12, 34, 80])); tied = bool(rng.random() < 0.3)
     m_index = int(rng.choice([5, 60, 500, 3000])); idfw = float(rng.choice([0.0, 1.0, 2.0, 5.0]))
     max_q = int(rng.choice([1, 3, 4, 8, 9, 20]))
@@ -50,13 +58,19 @@ while time.time() < t_end and rounds < max_rounds:
     flat, qoff = flatten(qs)
     for rep in range(3):
         k = int(rng.choice([1, 7, 100, 500, 1500, 4000])); m = int(rng.choice([1, 20, 300, 2500, 6000])); n = int(rng.choice([1, 5, 21, 24, 100, 512]))
-        cfg = dict(seed=seed, n_sessions=n_sessions, n_items=n_items, row_max=row_max, tied=tied, m_index=m_index, idfw=idfw, max_q=max_q, business=business, nq=nq_all, k=k, m=m, n=n)
+        cfg = dict(knobs=knobs, seed=seed, n_sessions=n_sessions, n_items=n_items, row_max=row_max, tied=tied, m_index=m_index, idfw=idfw, max_q=max_q, business=business, nq=nq_all, k=k, m=m, n=n)
         try:
             ref = oix.predict_batch("canonical", flat, qoff, k, m, n, business, threads=8)
             check(sa.predict_batch(gix, (flat, qoff), k, m, n, business), ref, n, "host batch", cfg)
             sub = min(nq_all, int(rng.choice([1, 16, 200, 256])))
             refs = {kk: v[:sub] for kk, v in ref.items() if kk in ("ids", "scores", "counts")}
             check(sa.predict_batch(gix, (flat[:qoff[sub]], qoff[:sub + 1]), k, m, n, business), refs, n, "host batch <= 256", cfg)
+            for qi in rng.integers(0, nq_all, size=3):   # srn_predict: the reference's call shape
+                recs = sa.predict(gix, qs[int(qi)], k, m, n, business)
+                cnt_ref = int(ref["counts"][qi]) if ref["counts"][qi] != 0xFFFFFFFF else 0
+                if [r.id for r in recs] != ref["ids"][qi, :cnt_ref].tolist() or not np.allclose([r.score for r in recs], ref["scores"][qi, :cnt_ref], rtol=1e-12, atol=0):
+                    print("MISMATCH in srn_predict, query %d: %r" % (qi, cfg)); sys.exit(1)
+                checks += 1
             d_f = torch.from_numpy(flat.view(np.int64).copy()).to(dev); d_o = torch.from_numpy(qoff.view(np.int32).copy()).to(dev)
             r_ids = torch.zeros(nq_all * n, dtype=torch.int64, device=dev); r_sc = torch.zeros(nq_all * n, dtype=torch.float64, device=dev); r_cnt = torch.zeros(nq_all, dtype=torch.int32, device=dev)
             sa.predict_batch_device(gix, d_f.data_ptr(), d_o.data_ptr(), nq_all, max_q, k, m, n, business, r_ids.data_ptr(), r_sc.data_ptr(), r_cnt.data_ptr(), torch.cuda.current_stream().cuda_stream)
