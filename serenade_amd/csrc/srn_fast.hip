@@ -261,6 +261,9 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         have_pre = false;
         const uint32_t L = hd.L, n = hd.n_staged, U = hd.U;
         unsigned long long rm = __ballot(x0.kept > 0u);
+#ifdef SRN_FAST_EXP_ONELIST   // experiment (timing only, wrong results): every query as if it had its first list alone -- no merge, no cuts: what the walks + harvest cost by themselves
+        rm &= 0ull - rm;
+#endif
         const uint32_t nr = (uint32_t)__popcll(rm);
         // Slot = (rank - base) << NB | set of lists.  Normally NB = 4 (WIDE, above 2^28 sessions: 3) and base = 0.  A query with MORE lists than bits
         // (4 lists on an index of > 2^28 sessions) takes NB = 4 with the ranks counted from the cut x_lo -- every staged entry is >= x_lo -- if that fits 28 bits.

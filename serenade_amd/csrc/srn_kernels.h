@@ -43,7 +43,9 @@ struct ShardPos { uint32_t idx, len; unsigned long long base; };   // dense idx 
 #ifndef SRN_FAST_SMALL
 #define SRN_FAST_SMALL 1
 #endif
-#if SRN_FAST_SMALL   // 48 KB: three workgroups per CU
+#if defined(SRN_FAST_EXP_LDS40)   // experiment ("a front end of its own?"): 40 KB, four workgroups per CU -- timing runs only, the walks' layout does not survive it
+static constexpr uint32_t F_HOT_WORDS = 3840, F_SK_WORDS = 1024, F_DUMP_WORDS = 256, F_TABLE_BUCKETS = 127, F_TABLE_WORDS = 512, F_SURV_WORDS = 512, F_WG_PER_CU = 4;
+#elif SRN_FAST_SMALL   // 48 KB: three workgroups per CU
 static constexpr uint32_t F_HOT_WORDS = 4096, F_SK_WORDS = 4096, F_DUMP_WORDS = 256, F_TABLE_BUCKETS = 127, F_TABLE_WORDS = 512, F_SURV_WORDS = 512, F_WG_PER_CU = 3;
 #else                // 80 KB: two workgroups per CU
 static constexpr uint32_t F_HOT_WORDS = 4096, F_SK_WORDS = 8192, F_DUMP_WORDS = 1024, F_TABLE_BUCKETS = 127, F_TABLE_WORDS = 512, F_SURV_WORDS = 768, F_WG_PER_CU = 2;
