@@ -218,7 +218,10 @@ int srn_index_shard(const srn_index_t* full, uint32_t shard, uint32_t n_shards, 
 int srn_index_build_shard_gpu(const srn_sessions_view_t* sessions, size_t m_index, size_t max_session_len, double idf_weighting,
                               uint32_t shard, uint32_t n_shards, int device, srn_index_t** out);
 int srn_index_load_shard(const char* path, uint32_t shard, uint32_t n_shards, int device, srn_index_t** out);
-/* A: this shard's candidates of every query: d_cand [nq * m] packed (rank, partial numerator), d_cand_cnt [nq] */
+/* The three stages (srn_shard_group_predict_batch drives them itself; these are the pieces).  A query whose session or item table does not fit LDS is served by a
+ * second pass of the same stage with its tables in global memory (numerator slots; with position-set slots -- sessions of <= 8 items, m <= m_index -- such a query is
+ * marked instead: d_cand_cnt / d_nb_cnt / d_out_counts = 0xFFFFFFFF, and the lists pipeline is the path to use).
+ * A: this shard's candidates of every query: d_cand [nq * m] packed (rank, partial numerator), d_cand_cnt [nq] */
 int srn_shard_stage_a(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq,
                       size_t max_len_hint, size_t k, size_t m, void* d_cand, uint32_t* d_cand_cnt, void* stream);
 /* B: d_gathered [n_shards][nq * m] / d_gathered_cnt [n_shards][nq] (all-gathered stage-A output) -> the global
