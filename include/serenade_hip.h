@@ -159,7 +159,8 @@ int srn_predict_batch(const srn_index_t* idx, const uint64_t* items_flat, const 
 
 /* Same with every buffer already resident in the index's device memory, enqueued on `stream`
  * (a hipStream_t; NULL = the null stream) without host synchronisation.  max_len_hint must be
- * >= the longest session in the batch (<= SRN_MAX_SESSION_LEN).  A query the kernel cannot serve
+ * >= the longest session in the batch (<= SRN_MAX_SESSION_LEN).  Calls from several host threads on the SAME stream take turns inside the library (each call's
+ * launches stay contiguous in the stream: they share the workspace bound to it); different streams run side by side.  A query the kernel cannot serve
  * (empty or over-long session) gets out_counts[q] = 0xFFFFFFFF.  flags: SRN_FLAG_BUSINESS_LOGIC, SRN_FLAG_INPUTS_RESIDENT
  * (the prep kernel of this call then runs beside the previous call's kernels; for back-to-back full batches that was measured as a LOSS -- the prep kernel's
  * 0.44 ms per 2^20 queries disappear but the concurrent random look-ups slow vmis_fast_kernel by 0.7 ms -- it pays where the previous call leaves the GPU idle). */

@@ -59,6 +59,7 @@ struct Workspace {
     char* pin = nullptr; size_t pin_bytes = 0;   // pinned, device-mapped staging of the latency path (a handful of queries on host pointers)
     // staging for host-pointer calls
     char* stage = nullptr; size_t stage_bytes = 0;
+    std::mutex call_mu;            // a stream-bound workspace serves one call at a time: two host threads enqueueing on the SAME stream must not interleave their launch sequences (they share these buffers)
     uint32_t* h_retry = nullptr;   // pinned
     uint32_t* h_retry_dev = nullptr;   // ... as the device sees it (vmis_finish_big_kernel writes the two counters there)
     bool h_retry_valid = false; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // the global-table pass forked beside the finish kernels (srn_runtime.hip)

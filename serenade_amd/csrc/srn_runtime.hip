@@ -198,9 +198,12 @@ int device_count() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n :
 // Host-pointer calls borrow a workspace for the duration of the (synchronous) call.  Device-pointer
 // calls return while their work is still in flight, so their scratch stays bound to the user's stream
 // (stream order then serialises its reuse).
+// A workspace from the pool (host-pointer calls: exclusively the caller's until released) or THE workspace bound to `user_stream` (device-pointer calls).  The latter is
+// locked for the duration of the call: its buffers are reused in stream order, which holds only while every call's launches are contiguous in the stream -- two host
+// threads on one stream (found by tools/fuzz_concurrency.py with 64 threads on torch's pool of 32 streams: wrong rows, then a GPU memory fault) now take turns.
 Workspace* ws_acquire(DeviceState* d, bool bind_to_stream, void* user_stream) {
-    std::lock_guard<std::mutex> lk(d->mu);
-    if (bind_to_stream) for (auto& sw : d->stream_ws) if (sw.first == user_stream) return sw.second;
+    std::unique_lock<std::mutex> lk(d->mu);
+    if (bind_to_stream) for (auto& sw : d->stream_ws) if (sw.first == user_stream) { Workspace* w = sw.second; lk.unlock(); w->call_mu.lock(); return w; }
     if (!bind_to_stream && !d->free_ws.empty()) { Workspace* w = d->free_ws.back(); d->free_ws.pop_back(); return w; }
     Workspace* w = new Workspace();
     if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { delete w; return nullptr; }
@@ -209,13 +212,14 @@ Workspace* ws_acquire(DeviceState* d, bool bind_to_stream, void* user_stream) {
     memset(w->h_retry, 0, 16);
     if (hipHostGetDevicePointer((void**)&w->h_retry_dev, w->h_retry, 0) != hipSuccess) { ws_free(w); return nullptr; }
     d->all_ws.push_back(w);
-    if (bind_to_stream) d->stream_ws.emplace_back(user_stream, w);
+    if (bind_to_stream) { d->stream_ws.emplace_back(user_stream, w); w->call_mu.lock(); }   // (nobody else can have found it yet: d->mu is held)
     return w;
 }
 void ws_release(DeviceState* d, Workspace* w, bool bound) {
-    std::lock_guard<std::mutex> lk(d->mu);
-    if (!bound) d->free_ws.push_back(w);
-    d->last_ws = w;
+    { std::lock_guard<std::mutex> lk(d->mu);
+      if (!bound) d->free_ws.push_back(w);
+      d->last_ws = w; }
+    if (bound) w->call_mu.unlock();
 }
 
 int ensure(char** p, size_t* have, size_t need) {

@@ -625,6 +625,45 @@ def test_sixty_four_host_threads_combine_into_rounds():
     assert [r.id for r in sa.predict(gix, qs[0], 10, 30, 5, False)] == ref1["ids"][0, :int(ref1["counts"][0])].tolist()
 
 
+def test_host_threads_sharing_one_stream_take_turns():
+    """Device-pointer calls reuse the workspace bound to their stream in stream order, which holds only while a call's launches are contiguous in the stream: several host
+    threads enqueueing on ONE stream (a host whose stream pool is smaller than its thread pool -- torch hands out 32) used to interleave their launch sequences over the
+    same buffers: wrong rows, then a GPU memory fault (tools/fuzz_concurrency.py, 64 threads).  The library serialises them now."""
+    import threading
+    import torch
+    import serenade_amd as sa
+    from serenade_amd import synth
+    inter, n_items, k, m, idfw = synth.CONFIGS["tiny"]
+    off, items, ts = synth.training_sessions(inter, n_items)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw)
+    flat, qoff = synth.queries(40000, n_items)
+    nq_all = len(qoff) - 1
+    ref = sa.predict_batch(gix, (flat, qoff), k, m, 21, False)
+    dev = torch.device("cuda:0")
+    d_flat = torch.from_numpy(flat.view(np.int64).copy()).to(dev)
+    shared = torch.cuda.Stream(dev)
+    bad = []
+
+    def worker(tid):
+        rng = np.random.default_rng(900 + tid)
+        for _ in range(40):
+            size = int(rng.choice([300, 3000, 20000])); lo = int(rng.integers(0, nq_all - size)); hi = lo + size
+            d_o = torch.from_numpy((qoff[lo:hi + 1] - qoff[lo]).astype(np.int32)).to(dev)
+            r = (torch.zeros(size * 21, dtype=torch.int64, device=dev), torch.zeros(size * 21, dtype=torch.float64, device=dev), torch.zeros(size, dtype=torch.int32, device=dev))
+            torch.cuda.synchronize()                    # (the buffers above are complete: what follows runs on the shared stream only)
+            sa.predict_batch_device(gix, d_flat[int(qoff[lo]):].data_ptr(), d_o.data_ptr(), size, 8, k, m, 21, False, r[0].data_ptr(), r[1].data_ptr(), r[2].data_ptr(), shared.cuda_stream)
+            shared.synchronize()
+            if not (np.array_equal(r[0].cpu().numpy().view(np.uint64).reshape(size, 21), ref[0][lo:hi]) and np.array_equal(r[2].cpu().numpy().view(np.uint32), ref[2][lo:hi])):
+                bad.append((tid, lo, hi))
+
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not bad, bad[:3]
+
+
 def test_single_chunk_host_batches_download_in_pieces():
     """A host batch of one chunk with >= 1 MB of results comes back in pieces (two, copied by the calling thread, below 4 MB; up to eight of >= 2 MB through the copy
     threads above): the pieces cut across the ids | scores | counts layout of the staging buffer at 4 KB boundaries -- every byte must land where the one-piece path puts it."""

@@ -25,6 +25,7 @@ dev = torch.device("cuda:0")
 d_flat_all = torch.from_numpy(flat.view(np.int64).copy()).to(dev)
 shards = [sharded.ShardedVMISIndex.from_full(gix, g, 3) for g in range(3)]
 grp = sharded.ShardGroup.local(shards); grp_lock = threading.Lock()
+OPS = os.environ.get("SOAK_OPS", "predict,predict,host,host,device,group").split(",")   # (SOAK_OPS=predict,host: the library's own paths only, no torch tensors on the data path)
 fail = []; counts = {"predict": 0, "host": 0, "device": 0, "group": 0}; cl = threading.Lock()
 
 def cmp(lo, hi, ids, sc, cnt, what):
@@ -43,7 +44,7 @@ def worker(tid):
     t_end = time.time() + budget
     try:
         while time.time() < t_end and not fail:
-            op = rng.choice(["predict", "predict", "host", "host", "device", "group"])
+            op = rng.choice(OPS)
             if op == "predict":
                 q = int(rng.integers(0, NQ))
                 recs = sa.predict(gix, flat[qoff[q]:qoff[q + 1]], k, m, n, False)
