@@ -216,7 +216,7 @@ int group_predict_stages(srn_shard_group* g, const LaunchParams& p, uint64_t* d_
         if (rc) return rc;
     }
     uint32_t* cnt_g = (uint32_t*)s.cand_cnt; int* minpos = (int*)s.minpos;
-    if (g->calls >= 2 && g->overlap && !local) HIP_TRY(hipStreamWaitEvent(user, s.e_done, 0));   // (a lists batch may still be using this slot's buffers on the exchange stream: order behind it)
+    if (g->calls >= 2) HIP_TRY(hipStreamWaitEvent(user, s.e_done, 0));   // (the batch that used this slot two calls ago -- on the exchange stream, or on ANOTHER caller's stream -- is done with its buffers)
     // stage A
     for (size_t i = 0; i < g->shards.size(); ++i) {
         const uint32_t gi = local ? (uint32_t)i : (uint32_t)g->rank;
@@ -300,6 +300,7 @@ int group_predict(srn_shard_group* g, const uint64_t* d_items_flat, const uint32
         if (!resident) { HIP_TRY(hipEventRecord(g->e_in, user)); HIP_TRY(hipStreamWaitEvent(sx, g->e_in, 0)); }   // (behind everything on the caller's stream: correct, but no overlap)
         if (g->calls >= 2) HIP_TRY(hipStreamWaitEvent(sx, s.e_done, 0));
     }
+    if (g->calls >= 2) HIP_TRY(hipStreamWaitEvent(user, s.e_done, 0));   // (callers may alternate between streams: the slot's previous user may have run on another one)
     // head: every shard's view of the evolving positions, the local cuts -> global cuts
     for (size_t i = 0; i < g->shards.size(); ++i) {
         int* h_i = i == 0 ? head : head + (size_t)nq * 3;

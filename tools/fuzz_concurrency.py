@@ -69,9 +69,8 @@ def worker(tid):
                         else:
                             size = min(size, 20000); hi = lo + size
                             d_f = d_flat_all[int(qoff[lo]):int(qoff[hi])]; d_o = torch.from_numpy((qoff[lo:hi + 1] - qoff[lo]).astype(np.int32)).to(dev)
-                            with grp_lock:   # (one batch at a time per group: its two buffer slots belong to consecutive batches on ONE stream)
-                                res = grp.predict_batch(d_f, d_o, size, synth.LAST_ITEMS, k, m, n, False, stream=st.cuda_stream)
-                                st.synchronize()
+                            res = grp.predict_batch(d_f, d_o, size, synth.LAST_ITEMS, k, m, n, False, stream=st.cuda_stream)   # (the group serialises its callers; consecutive batches may come on different streams)
+                            st.synchronize()
                             cmp(lo, hi, res[0].cpu().numpy().view(np.uint64), res[1].cpu().numpy(), res[2].cpu().numpy().view(np.uint32), "shard group batch of %d" % size)
             with cl: counts[op] += 1
     except Exception as e:
