@@ -310,6 +310,9 @@ typedef struct {
 int srn_shard_group_create_with_comm(const srn_index_t* shard, int rank, int world, const srn_shard_comm_t* comm, srn_shard_group_t** out);
 /* All shards of the group in THIS process on one device (tests; capacity experiments on one GPU): the collectives degenerate to kernels. */
 int srn_shard_group_create_local(const srn_index_t* const* shards, int n_shards, srn_shard_group_t** out);
+/* Threads and streams: calls on one group are serialised inside (a mutex for the enqueue; a buffer slot is reused only behind the batch that used it, whatever stream
+ * that batch ran on).  Over a multi-rank transport every rank must issue the group's batches in the SAME order, and a rank that alternates between streams must
+ * order them itself: collectives on one communicator execute in issue order on every rank.  One stream per group is the simple way. */
 int srn_shard_group_predict_batch(srn_shard_group_t* g, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq, size_t max_len_hint,
                                   size_t k, size_t m, size_t how_many, unsigned flags, uint64_t* d_out_ids, double* d_out_scores,
                                   uint32_t* d_out_counts, void* stream);
