@@ -20,7 +20,10 @@ NQ = 150000
 flat, qoff = synth.queries(NQ, n_items)
 NQ = len(qoff) - 1
 n = 21
-ref = oix.predict_batch("canonical", flat, qoff, k, m, n, False, threads=16)
+# several parameter sets in flight at once: the workspaces are re-sized and the kernel path (fast kernel or not, position sets or not) changes from call to call
+PARAMS = [(k, m, 21), (50, 100, 5), (700, 300, 24), (k, m, 100)]
+REFS = [oix.predict_batch("canonical", flat, qoff, kk_, mm_, nn_, False, threads=16) for (kk_, mm_, nn_) in PARAMS]
+ref = REFS[0]
 dev = torch.device("cuda:0")
 d_flat_all = torch.from_numpy(flat.view(np.int64).copy()).to(dev)
 shards = [sharded.ShardedVMISIndex.from_full(gix, g, 3) for g in range(3)]
@@ -28,7 +31,8 @@ grp = sharded.ShardGroup.local(shards); grp_lock = threading.Lock()
 OPS = os.environ.get("SOAK_OPS", "predict,predict,host,host,device,group").split(",")   # (SOAK_OPS=predict,host: the library's own paths only, no torch tensors on the data path)
 fail = []; counts = {"predict": 0, "host": 0, "device": 0, "group": 0}; cl = threading.Lock()
 
-def cmp(lo, hi, ids, sc, cnt, what):
+def cmp(lo, hi, ids, sc, cnt, what, pi=0):
+    ref = REFS[pi]; n = PARAMS[pi][2]
     r_cnt = ref["counts"][lo:hi]
     ok = np.array_equal(cnt, r_cnt)
     if ok:
@@ -45,6 +49,7 @@ def worker(tid):
     try:
         while time.time() < t_end and not fail:
             op = rng.choice(OPS)
+            pi = int(rng.integers(0, len(PARAMS))); k, m, n = PARAMS[pi]; ref = REFS[pi]
             if op == "predict":
                 q = int(rng.integers(0, NQ))
                 recs = sa.predict(gix, flat[qoff[q]:qoff[q + 1]], k, m, n, False)
@@ -57,7 +62,7 @@ def worker(tid):
                 f, o = flat[qoff[lo]:qoff[hi]], (qoff[lo:hi + 1] - qoff[lo]).astype(np.uint32)
                 if op == "host":
                     ids, sc, cnt = sa.predict_batch(gix, (f, o), k, m, n, False)
-                    cmp(lo, hi, ids, sc, cnt, "host batch of %d" % size)
+                    cmp(lo, hi, ids, sc, cnt, "host batch of %d, params %r" % (size, PARAMS[pi]), pi)
                 else:
                     with torch.cuda.stream(st):
                         d_f = d_flat_all[int(qoff[lo]):int(qoff[hi])]; d_o = torch.from_numpy(o.view(np.int32).copy()).to(dev, non_blocking=False)
@@ -65,13 +70,13 @@ def worker(tid):
                             r_ids = torch.zeros(size * n, dtype=torch.int64, device=dev); r_sc = torch.zeros(size * n, dtype=torch.float64, device=dev); r_cnt = torch.zeros(size, dtype=torch.int32, device=dev)
                             sa.predict_batch_device(gix, d_f.data_ptr(), d_o.data_ptr(), size, synth.LAST_ITEMS, k, m, n, False, r_ids.data_ptr(), r_sc.data_ptr(), r_cnt.data_ptr(), st.cuda_stream)
                             st.synchronize()
-                            cmp(lo, hi, r_ids.cpu().numpy().view(np.uint64).reshape(size, n), r_sc.cpu().numpy().reshape(size, n), r_cnt.cpu().numpy().view(np.uint32), "device batch of %d" % size)
+                            cmp(lo, hi, r_ids.cpu().numpy().view(np.uint64).reshape(size, n), r_sc.cpu().numpy().reshape(size, n), r_cnt.cpu().numpy().view(np.uint32), "device batch of %d, params %r" % (size, PARAMS[pi]), pi)
                         else:
                             size = min(size, 20000); hi = lo + size
                             d_f = d_flat_all[int(qoff[lo]):int(qoff[hi])]; d_o = torch.from_numpy((qoff[lo:hi + 1] - qoff[lo]).astype(np.int32)).to(dev)
                             res = grp.predict_batch(d_f, d_o, size, synth.LAST_ITEMS, k, m, n, False, stream=st.cuda_stream)   # (the group serialises its callers; consecutive batches may come on different streams)
                             st.synchronize()
-                            cmp(lo, hi, res[0].cpu().numpy().view(np.uint64), res[1].cpu().numpy(), res[2].cpu().numpy().view(np.uint32), "shard group batch of %d" % size)
+                            cmp(lo, hi, res[0].cpu().numpy().view(np.uint64), res[1].cpu().numpy(), res[2].cpu().numpy().view(np.uint32), "shard group batch of %d, params %r" % (size, PARAMS[pi]), pi)
             with cl: counts[op] += 1
     except Exception as e:
         import traceback
