@@ -63,7 +63,10 @@ static constexpr uint32_t F_HITS = F_HOT, F_HIT_CAP = F_HOT_WORDS / 2 - 1, F_ZER
 #ifndef SRN_FAST_REPLICAS
 #define SRN_FAST_REPLICAS 1
 #endif
-static constexpr uint32_t F_REP_ITEMS = SRN_FAST_REPLICAS ? 16 : 0, F_REP = 8, F_DIRECT = F_HOT_WORDS - F_REP_ITEMS * F_REP;   // items < F_DIRECT have a word of their own
+#ifndef SRN_FAST_REP_ITEMS
+#define SRN_FAST_REP_ITEMS 16   // (32 and 48 measured in round 3: see DESIGN.md)
+#endif
+static constexpr uint32_t F_REP_ITEMS = SRN_FAST_REPLICAS ? SRN_FAST_REP_ITEMS : 0, F_REP = 8, F_DIRECT = F_HOT_WORDS - F_REP_ITEMS * F_REP;   // items < F_DIRECT have a word of their own
 static constexpr uint32_t F_SURV = F_TABLE + F_TABLE_WORDS * 8;          // survivors of the integer floors, packed (idx << 20 | acc), then the threshold histogram
 static constexpr uint32_t F_LDS_BYTES = F_SURV + F_SURV_WORDS * 4;
 static constexpr uint32_t F_WORK = F_NBL, F_WORK_WORDS = (F_LDS_BYTES - F_WORK) / 4;   // merge buffers: 2 * n_staged words
