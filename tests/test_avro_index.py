@@ -6,8 +6,15 @@ the Avro files carry that index's own posting lists and idf (i.e. the offline pr
 import numpy as np
 import pytest
 
+import avro_spec_reader as ASR
 import avro_write as AW
-from helpers import random_queries, small_dataset
+from helpers import flatten, random_queries, small_dataset
+
+
+def pyarrow_snappy(data):
+    """THIRD-PARTY compressor (Google's snappy as bundled by pyarrow): raw-format streams this repository's author did not produce."""
+    import pyarrow as pa
+    return pa.Codec("snappy").compress(bytes(data)).to_pybytes()
 
 
 def _write_index(base, off, items, ts, m_index, idf_of, attrs=None, codec="snappy", files=2, reorder_ties=False, compressor=None):
@@ -52,14 +59,70 @@ def test_snappy_writer_uses_every_element_kind_and_decodes_independently():
     assert AW.snappy_decode(AW.snappy_literal_only(data)) == data
 
 
-@pytest.mark.parametrize("codec", ["null", "snappy", "snappy-copies"])
+def test_third_party_snappy_and_the_test_writer_agree_both_ways():
+    """pyarrow's decompressor accepts the test writer's streams (all element kinds) and the test decoder accepts pyarrow's compressor's."""
+    import pyarrow as pa
+    rng = np.random.default_rng(5)
+    data = bytes(rng.integers(0, 5, size=40000, dtype=np.uint8)) + b"\x07" * 1000 + bytes(rng.integers(0, 255, size=3000, dtype=np.uint8))
+    for z in (AW.snappy_with_copies(data), AW.snappy_literal_only(data)):
+        assert pa.Codec("snappy").decompress(z, decompressed_size=len(data)).to_pybytes() == data
+    z = pyarrow_snappy(data)
+    assert len(z) < len(data) * 3 // 4 and AW.snappy_decode(z) == data           # (it really compressed: copies inside)
+
+
+@pytest.mark.parametrize("codec", ["null", "snappy", "snappy-copies", "snappy-pyarrow"])
+def test_container_files_pass_an_independent_spec_level_reader(tmp_path, codec):
+    """The files srn_avro.cpp is tested on, read back by tests/avro_spec_reader.py (generic over the header's writer schema, third-party snappy
+    inflate, CRC by zlib): header magic / metadata map / sync markers / zig-zag longs / array blocks / snappy framing are the specification's,
+    and the records are what went in (schemas: vmis_index.rs:184-192, 249-255)."""
+    off, items, ts, ids = small_dataset(46, n_sessions=700, n_items=90, tied_timestamps=True)
+    idf = _idf_like_builder(off, items, 1.0)
+    attrs = {int(ids[0]): (False, True), int(ids[1]): (True, True)}
+    compressor = {"snappy-copies": AW.snappy_with_copies, "snappy-pyarrow": pyarrow_snappy}.get(codec)
+    per_item = _write_index(str(tmp_path), off, items, ts, 40, idf, attrs, "null" if codec == "null" else "snappy", compressor=compressor)
+    got_items, got_sessions = {}, {}
+    for part in range(2):
+        schema, cdc, recs = ASR.read_container(f"{tmp_path}/itemindex/part-{part}.avro")
+        assert schema == AW.ITEM_SCHEMA and cdc == ("null" if codec == "null" else "snappy")
+        for r in recs:
+            got_items[r["ItemId"]] = r
+        schema, cdc, recs = ASR.read_container(f"{tmp_path}/sessionindex/part-{part}.avro")
+        assert schema == AW.SESSION_SCHEMA
+        for r in recs:
+            got_sessions[r["SessionIndex"]] = r
+    n = len(ts)
+    assert sorted(got_sessions) == list(range(n)) and sorted(got_items) == sorted(per_item)
+    for s in range(n):
+        assert got_sessions[s]["item_ids_asc"] == items[off[s]:off[s + 1]].tolist() and got_sessions[s]["Time"] == int(ts[s])
+    order = np.lexsort((np.arange(n), ts)); rank = np.empty(n, np.int64); rank[order] = np.arange(n)
+    for it, ss in per_item.items():
+        r = got_items[it]
+        assert r["session_indices_time_ordered"] == sorted(ss, key=lambda s: -rank[s])[:40]
+        assert r["idf"] == idf[it] and (r["ForSale"], r["IsAdult"]) == attrs.get(it, (True, False))
+    # and the reader under test sees the same index in them
+    import serenade_amd as sa
+    ix = sa.VMISIndex.new_from_avro(tmp_path, device=-1)
+    for it in list(per_item)[:40]:
+        sess, f = ix.postings(it)
+        assert sess.tolist() == got_items[it]["session_indices_time_ordered"] and f == got_items[it]["idf"]
+    # damaged files are refused by the second reader too (so "valid" above means something)
+    for how, what in (("crc", "CRC"), ("sync", "sync"), ("truncate", "truncated")):
+        if codec == "null" and how == "crc":
+            continue
+        pth = f"{tmp_path}/bad-{how}.avro"
+        AW.write_container(pth, AW.SESSION_SCHEMA, [AW.enc_session(1, [2, 3], 4)] * 30, "null" if codec == "null" else "snappy", block_records=7, compressor=compressor, corrupt=how)
+        with pytest.raises(ValueError):
+            ASR.read_container(pth)
+
+
+@pytest.mark.parametrize("codec", ["null", "snappy", "snappy-copies", "snappy-pyarrow"])
 def test_avro_index_contents_on_host(tmp_path, codec):
     import serenade_amd as sa
     off, items, ts, ids = small_dataset(41, n_sessions=900, n_items=120, tied_timestamps=True)
     idf = _idf_like_builder(off, items, 1.0)
     attrs = {int(ids[0]): (False, True), int(ids[1]): (True, True)}
-    compressor = AW.snappy_with_copies if codec == "snappy-copies" else None
-    codec = "snappy" if codec == "snappy-copies" else codec
+    compressor = {"snappy-copies": AW.snappy_with_copies, "snappy-pyarrow": pyarrow_snappy}.get(codec)
+    codec = "snappy" if codec.startswith("snappy") else codec
     per_item = _write_index(str(tmp_path), off, items, ts, 40, idf, attrs, codec, reorder_ties=True, compressor=compressor)
     ix = sa.VMISIndex.new_from_avro(tmp_path, device=-1)
     ref = sa.VMISIndex.from_sessions(off, items, ts, 40, 10**6, 1.0, device=-1)
@@ -208,17 +271,30 @@ def test_avro_index_with_a_different_tie_break_uses_the_lists_as_given(tmp_path)
 
 
 @pytest.mark.gpu
-def test_avro_index_predicts_like_the_sessions_built_index(tmp_path):
+@pytest.mark.parametrize("compressor", ["pyarrow", "copies"])
+def test_avro_index_predicts_what_the_oracle_predicts(tmp_path, compressor):
+    """VMISIndex::new(base_path) (vmis_index.rs:85-314) on files compressed by a third-party snappy (pyarrow) -> HIP predictions == the CPU ORACLE's
+    (prepare_hashmap + canonical predict on the same sessions, real product flags: mod.rs:162-182), not another HIP index's."""
     import serenade_amd as sa
+    from oracle import oracle as O
     off, items, ts, ids = small_dataset(43, n_sessions=5000, n_items=400, tied_timestamps=True)
     idf = _idf_like_builder(off, items, 2.0)
     attrs = {int(i): (bool(j % 3), bool(j % 5 == 0)) for j, i in enumerate(ids)}
-    _write_index(str(tmp_path), off, items, ts, 150, idf, attrs, "snappy")
+    _write_index(str(tmp_path), off, items, ts, 150, idf, attrs, "snappy", compressor=pyarrow_snappy if compressor == "pyarrow" else AW.snappy_with_copies)
     a = sa.VMISIndex.new_from_avro(tmp_path)
-    b = sa.VMISIndex.from_sessions(off, items, ts, 150, 10**6, 2.0)
-    b.set_attributes(list(attrs), [(1 if ad else 0) | (2 if fs else 0) for fs, ad in attrs.values()])
+    flags = [(1 if ad else 0) | (2 if fs else 0) for fs, ad in attrs.values()]
+    oix = O.OracleIndex(off, items, ts, 150, 10**6, 2.0, fast=True)
+    oix.set_attributes(list(attrs), flags)
     qs = random_queries(6, ids, 400, max_len=6)
+    flat, qo = flatten(qs)
     for business in (False, True):
-        ra, rb = sa.predict_batch(a, qs, 80, 150, 21, business), sa.predict_batch(b, qs, 80, 150, 21, business)
-        for x, y in zip(ra, rb):
+        ids_a, sc_a, cnt_a = sa.predict_batch(a, qs, 80, 150, 21, business)
+        ref = oix.predict_batch("canonical", flat, qo, 80, 150, 21, business, threads=2)
+        assert np.array_equal(cnt_a, ref["counts"]) and np.array_equal(ids_a, ref["ids"]), business
+        np.testing.assert_allclose(sc_a, ref["scores"], rtol=1e-12, atol=0)          # (the files' idf is numpy's log, the oracle's is libm's)
+    # and, as before, bit-identical to the HIP index built from the same sessions (idf from the same doubles)
+    b = sa.VMISIndex.from_sessions(off, items, ts, 150, 10**6, 2.0)
+    b.set_attributes(list(attrs), flags)
+    for business in (False, True):
+        for x, y in zip(sa.predict_batch(a, qs, 80, 150, 21, business), sa.predict_batch(b, qs, 80, 150, 21, business)):
             assert np.array_equal(x, y)

@@ -5,9 +5,24 @@ import threading
 import numpy as np
 import pytest
 
-from helpers import random_queries, small_dataset
+from helpers import flatten, random_queries, small_dataset
 
 pytestmark = pytest.mark.gpu
+
+
+def oracle_predictions(off, items, ts, m_index, max_len, idfw, queries, k, m, how_many, business=False):
+    """What vmisknn::predict (mod.rs:118-215) returns for every query, from the CPU oracle's canonical form: [[(id, score), ...], ...], best first."""
+    from oracle import oracle as O
+    oix = O.OracleIndex(off, items, ts, m_index, max_len, idfw, fast=True)
+    flat, qo = flatten(queries)
+    ref = oix.predict_batch("canonical", flat, qo, k, m, how_many, business, threads=2)
+    return [[(int(i), float(s)) for i, s in zip(ref["ids"][q, :c], ref["scores"][q, :c])] for q, c in enumerate(ref["counts"])]
+
+
+def same_predictions(got, want):
+    """ids and order identical, scores within 1e-12 relative (the bound of tests/test_gpu_parity.py)."""
+    assert [i for i, _ in got] == [i for i, _ in want], (got, want)
+    np.testing.assert_allclose([s for _, s in got], [s for _, s in want], rtol=1e-12, atol=0)
 
 
 def test_batcher_matches_direct_predict_under_concurrency():
@@ -16,7 +31,7 @@ def test_batcher_matches_direct_predict_under_concurrency():
     off, items, ts, ids = small_dataset(31, n_sessions=4000, n_items=500)
     gix = sa.VMISIndex.from_sessions(off, items, ts, 300, 12, 1.0)
     qs = random_queries(4, ids, 600, max_len=6)
-    want = [sa.predict(gix, q, 100, 300, 21, False) for q in qs]
+    want = oracle_predictions(off, items, ts, 300, 12, 1.0, qs, 100, 300, 21)      # the ORACLE's answers, not another HIP call's
     b = Batcher(gix, 100, 300, 21, False, max_batch=64, max_wait_us=2000)
     got = [None] * len(qs)
     errs = []
@@ -34,7 +49,8 @@ def test_batcher_matches_direct_predict_under_concurrency():
     [t.start() for t in threads]
     [t.join() for t in threads]
     assert not errs, errs
-    assert got == want
+    for g, w in zip(got, want):
+        same_predictions(g, w)
     st = b.stats
     assert st["requests"] == len(qs) and st["batches"] < len(qs) and 1 < st["max_batch_seen"] <= 64, st
     # a bad request fails alone (same code and message class as srn_predict), the batcher keeps serving
@@ -44,7 +60,7 @@ def test_batcher_matches_direct_predict_under_concurrency():
     with pytest.raises(sa.SerenadeError) as e:
         b.predict([1] * 300)
     assert e.value.code == -4
-    assert b.predict(qs[0]) == want[0]
+    same_predictions(b.predict(qs[0]), want[0])
     b.close()
 
 
@@ -59,12 +75,15 @@ def test_batcher_rejects_bad_configuration():
 
 
 def test_recommend_follows_the_reference_handler():
-    """srn_recommend == the body of v1_recommend (recommend_resource.rs:20-65) replayed in Python over direct predict calls:
-    session read with the idle rule, append unless the click repeats the last item, drop the oldest beyond the limit."""
+    """srn_recommend == the body of v1_recommend (recommend_resource.rs:20-65) replayed in Python over the CPU ORACLE's predict:
+    session read with the idle rule (sessions/mod.rs:37-72), append unless the click repeats the last item, drop the oldest beyond the
+    limit (recommend_resource.rs:39-54), predict on the evolving session (:56), ids of into_sorted_vec() (:58-62)."""
     import serenade_amd as sa
+    from oracle import oracle as O
     from serenade_amd.serving import Batcher, SessionStore, recommend, session_key
     off, items, ts, ids = small_dataset(33, n_sessions=3000, n_items=300)
     gix = sa.VMISIndex.from_sessions(off, items, ts, 200, 12, 1.0)
+    oix = O.OracleIndex(off, items, ts, 200, 12, 1.0, fast=True)
     b = Batcher(gix, 50, 200, 21, False, max_batch=32, max_wait_us=100)
     store = SessionStore(ttl_secs=1800, idle_secs=1200)
     rng = np.random.default_rng(5)
@@ -88,12 +107,12 @@ def test_recommend_follows_the_reference_handler():
             model[sid] = (sess, now)
         else:
             sess = [item]
-        want = [r.id for r in sa.predict(gix, sess, 50, 200, 21, False)]
+        want = [int(i) for i in oix.predict_canonical(sess, 50, 200, 21, False)[0]]
         assert recommend(b, store, sid, item, consent, max_items, now=now) == want, (step, sid, sess)
         if consent:
             assert store.get_session_items(session_key(sid), now=now) == sess
     with pytest.raises(sa.SerenadeError):
         recommend(b, None, "x", 1, True, 3)           # consent needs a store
-    assert recommend(b, None, "x", int(ids[0]), False, 3) == [r.id for r in sa.predict(gix, [int(ids[0])], 50, 200, 21, False)]
+    assert recommend(b, None, "x", int(ids[0]), False, 3) == [int(i) for i in oix.predict_canonical([int(ids[0])], 50, 200, 21, False)[0]]
     b.close()
     store.close()
