@@ -3,6 +3,6 @@
 The package holds only what that path needs: the HIP kernels + C ABI (csrc/, built into
 libserenade_hip.so), a ctypes binding (capi), the host-side mirror of the reference interface
 (vmisknn) and the synthetic workload generator used by bench.py (synth)."""
-from .vmisknn import ItemScore, VMISIndex, SerenadeError, predict, predict_batch, predict_batch_debug, predict_batch_device, reserve  # noqa: F401
+from .vmisknn import CSR, ItemScore, VMISIndex, SerenadeError, predict, predict_batch, predict_batch_debug, predict_batch_device, reserve  # noqa: F401
 
-__all__ = ["ItemScore", "VMISIndex", "SerenadeError", "predict", "predict_batch", "predict_batch_debug", "predict_batch_device", "reserve"]
+__all__ = ["CSR", "ItemScore", "VMISIndex", "SerenadeError", "predict", "predict_batch", "predict_batch_debug", "predict_batch_device", "reserve"]

@@ -34,6 +34,7 @@ struct Round {
     std::vector<const uint64_t*> ev; std::vector<uint32_t> len;          // members' evolving sessions (borrowed: the members are blocked in their calls)
     std::vector<uint64_t> ids; std::vector<double> scores; std::vector<uint32_t> counts;
     int rc = SRN_OK; std::string err;
+    std::vector<int> member_rc; std::vector<std::string> member_err;    // filled only where a failed round was re-run member by member
     std::atomic<uint32_t> done{0};
     bool closed = false;
 };
@@ -50,12 +51,21 @@ void futex_wake_all(std::atomic<uint32_t>* w) {
 // same instant.  A sleeping mutex turns that into a convoy -- every hand-over a futex wake and a context switch: 40 us of CPU per request measured, 14 cores at
 // 350 K requests/s, and with 256 callers the cgroup's CPU quota throttled the whole process (75 ms stalls) -- so: a spin lock (test-and-test-and-set, pause,
 // yield after a while), and the leaders that wait for a lane sleep on a futex of their own.
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#else
+    std::atomic_signal_fence(std::memory_order_seq_cst);
+#endif
+}
 struct SpinLock {
     std::atomic<uint32_t> v{0};
     void lock() {
         for (uint32_t spins = 0;;) {
             if (v.load(std::memory_order_relaxed) == 0 && v.exchange(1, std::memory_order_acquire) == 0) return;
-            if (++spins < 2000) __builtin_ia32_pause(); else { sched_yield(); spins = 0; }
+            if (++spins < 2000) cpu_relax(); else { sched_yield(); spins = 0; }
         }
     }
     void unlock() { v.store(0, std::memory_order_release); }
@@ -67,7 +77,9 @@ struct Combiner {
     int lanes_busy = 0, leaders_waiting = 0;
     std::atomic<uint64_t> n_rounds{0}, n_requests{0}, max_round{0};
 };
-Combiner* combiner_create() { return new Combiner(); }
+Combiner* combiner_create() { Combiner* c = new Combiner(); c->open.reserve(64); return c; }   // (no allocation under the spin lock in the common case)
+struct SpinGuard { SpinLock& l; bool held = true; explicit SpinGuard(SpinLock& x) : l(x) { l.lock(); } void unlock() { if (held) { l.unlock(); held = false; } } void lock() { if (!held) { l.lock(); held = true; } }
+                   ~SpinGuard() { if (held) l.unlock(); } };   // released on unwind too: a bad_alloc under the lock must not leave every later caller spinning
 void combiner_free(Combiner* c) { delete c; }
 void combiner_stats(const Combiner* c, uint64_t* rounds, uint64_t* requests, uint64_t* max_round) {
     if (rounds) *rounds = c->n_rounds.load(); if (requests) *requests = c->n_requests.load(); if (max_round) *max_round = c->max_round.load();
@@ -80,11 +92,11 @@ int combiner_predict(Combiner* c, const srn_index* idx, const uint64_t* evolving
     {
         std::shared_ptr<Round> fresh = std::make_shared<Round>();   // (allocated outside the lock; dropped if an open round takes this call)
         fresh->k = k; fresh->m = m; fresh->how_many = how_many; fresh->flags = flags;
-        fresh->ev.reserve(round_cap < 64 ? round_cap : 64); fresh->len.reserve(round_cap < 64 ? round_cap : 64);
-        c->mu.lock();
+        fresh->ev.reserve(round_cap); fresh->len.reserve(round_cap);   // (a round never grows beyond round_cap: the members' push_backs below do not allocate)
+        SpinGuard g(c->mu);
         for (auto& o : c->open)
             if (!o->closed && o->k == k && o->m == m && o->how_many == how_many && o->flags == flags && o->ev.size() < round_cap) { r = o; break; }
-        if (r) { me = r->ev.size(); r->ev.push_back(evolving); r->len.push_back((uint32_t)len); c->mu.unlock(); }
+        if (r) { me = r->ev.size(); r->ev.push_back(evolving); r->len.push_back((uint32_t)len); g.unlock(); }
         else {
             r = std::move(fresh);
             r->ev.push_back(evolving); r->len.push_back((uint32_t)len);
@@ -92,14 +104,14 @@ int combiner_predict(Combiner* c, const srn_index* idx, const uint64_t* evolving
             while (c->lanes_busy >= lanes) {   // (the round stays open meanwhile: the load that arrives now rides along)
                 const uint32_t seq = c->lane_seq.load(std::memory_order_relaxed);
                 ++c->leaders_waiting;
-                c->mu.unlock();
+                g.unlock();
                 syscall(SYS_futex, reinterpret_cast<uint32_t*>(&c->lane_seq), FUTEX_WAIT_PRIVATE, seq, nullptr, nullptr, 0);
-                c->mu.lock();
+                g.lock();
                 --c->leaders_waiting;
             }
             ++c->lanes_busy; r->closed = true;
             c->open.erase(std::find(c->open.begin(), c->open.end(), r));
-            c->mu.unlock();
+            g.unlock();
         }
     }
     if (leader) {
@@ -114,6 +126,19 @@ int combiner_predict(Combiner* c, const srn_index* idx, const uint64_t* evolving
             r->rc = device_predict(idx->dev, idx->flat, p, false, nullptr, flat.data(), off.data(), r->ids.data(), r->scores.data(), r->counts.data(), nullptr, nullptr, nullptr, nullptr,
                                    nullptr, false, /*blocking_wait=*/nq > 1);
             if (r->rc) r->err = last_error_string();
+            // The reference's predict() calls are independent (src/endpoints/recommend_resource.rs:56): one member's session must not fail the others'.  A round
+            // refused for its shape (a long session pushing the batch geometry over a limit) is re-run member by member, each with its own verdict.
+            if ((r->rc == SRN_EINVAL || r->rc == SRN_ERANGE) && nq > 1) {
+                r->member_rc.assign(nq, SRN_OK); r->member_err.assign(nq, std::string());
+                for (size_t i = 0; i < nq; ++i) {
+                    const uint32_t off1[2] = {0u, r->len[i]};
+                    LaunchParams p1 = p; p1.nq = 1; p1.max_len = r->len[i];
+                    r->member_rc[i] = device_predict(idx->dev, idx->flat, p1, false, nullptr, r->ev[i], off1, &r->ids[i * how_many], &r->scores[i * how_many], &r->counts[i], nullptr, nullptr,
+                                                     nullptr, nullptr, nullptr, false, /*blocking_wait=*/true);
+                    if (r->member_rc[i]) r->member_err[i] = last_error_string();
+                }
+                r->rc = SRN_OK; r->err.clear();
+            }
         } catch (const std::bad_alloc&) { r->rc = SRN_ENOMEM; r->err = "out of host memory in a combining round"; }
         catch (const std::exception& e) { r->rc = SRN_EINVAL; r->err = std::string("internal error in a combining round: ") + e.what(); }
         c->n_rounds.fetch_add(1, std::memory_order_relaxed); c->n_requests.fetch_add(nq, std::memory_order_relaxed);
@@ -127,6 +152,7 @@ int combiner_predict(Combiner* c, const srn_index* idx, const uint64_t* evolving
     } else futex_wait(&r->done);
     *out_n = 0;
     if (r->rc) return fail(r->rc, r->err);
+    if (!r->member_rc.empty() && r->member_rc[me]) return fail(r->member_rc[me], r->member_err[me]);
     const uint32_t cnt = r->counts[me];
     if (cnt == 0xFFFFFFFFu) return fail(SRN_ERANGE, "a query exceeded the kernel's table limits");   // (this member's query only: the others' rows are complete)
     const size_t n = std::min<size_t>(cnt, how_many);

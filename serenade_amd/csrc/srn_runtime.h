@@ -65,7 +65,7 @@ struct Workspace {
     bool h_retry_valid = false; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // the global-table pass forked beside the finish kernels (srn_runtime.hip)
     hipEvent_t ev_block = nullptr; // blocking-sync event of the latency path (rounds shared by several callers)
     // SRN_FLAG_INPUTS_RESIDENT: this call's prep kernel on a side stream, beside the previous call's kernels (two sets of prep records)
-    hipStream_t side = nullptr; hipEvent_t ev_prep[2] = {}, ev_done[2] = {}; char* prep2 = nullptr; size_t prep2_bytes = 0; uint64_t resident_calls = 0;
+    hipStream_t side = nullptr; hipEvent_t ev_prep[2] = {}, ev_done[2] = {}; char* prep2 = nullptr; size_t prep2_bytes = 0; uint64_t resident_calls = 0; bool rec_used[2] = {false, false};
 };
 
 struct DeviceState {

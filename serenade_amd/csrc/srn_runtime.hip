@@ -510,7 +510,9 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         // prep of this call on the side stream: behind the call that used this set of records two calls ago, beside the previous call's kernels
         const int par = (int)(w->resident_calls & 1u);
         char* rec = par ? w->prep2 : w->prep;
-        if (w->resident_calls >= 2) HIP_TRY(hipStreamWaitEvent(w->side, w->ev_done[par], 0));
+        // (ev_done[set] = the end of the LAST call that read record set `set`, resident or not: a non-resident device-pointer call on this stream reads w->prep too)
+        if (!w->rec_used[par] && w->calls > 0) { HIP_TRY(hipEventRecord(w->ev_done[par], st)); w->rec_used[par] = true; }   // (earlier calls of this workspace that left no event: everything enqueued so far)
+        if (w->rec_used[par]) HIP_TRY(hipStreamWaitEvent(w->side, w->ev_done[par], 0));
         HIP_TRY(launch_prep(w->side, di, p.items_flat, p.q_off, p.nq, p.m, p.max_len, rec, prep_stride));
         HIP_TRY(hipEventRecord(w->ev_prep[par], w->side));
         HIP_TRY(hipStreamWaitEvent(st, w->ev_prep[par], 0));
@@ -571,7 +573,8 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
                                                                                                   //  "all of last_nq" -- no host write into a pinned word that an earlier call may still be writing)
     }
     HIP_TRY(hipEventRecord(ev[2], st));
-    if (resident) { HIP_TRY(hipEventRecord(w->ev_done[w->resident_calls & 1u], st)); ++w->resident_calls; }
+    if (resident) { const int par = (int)(w->resident_calls & 1u); HIP_TRY(hipEventRecord(w->ev_done[par], st)); w->rec_used[par] = true; ++w->resident_calls; }
+    else if (!ext && w->side) { HIP_TRY(hipEventRecord(w->ev_done[0], st)); w->rec_used[0] = true; }   // (a workspace that has served resident calls: the next one's side-stream prep must not overwrite w->prep under this call's kernels)
     ++w->calls; w->last_retry = (may_overflow || dense) ? 1 : 0; w->last_nq = p.nq; w->last_fast = fast; w->last_untimed = false;
     if (may_overflow || dense) w->h_retry_valid = true;   // (from now on the pinned counter holds a finished call's count -- or is being overwritten by a newer one)
 

@@ -135,19 +135,29 @@ class VMISIndex:
         return out
 
 
+CSR = namedtuple("CSR", ["items_flat", "q_off"])
+CSR.__doc__ = "Explicit CSR batch: CSR(items_flat u64[nnz], q_off int[nq + 1]).  Unambiguous, unlike a bare tuple of two arrays."
+
+
 def _is_csr_pair(sessions):
-    """(items_flat, q_off): two 1-D numpy arrays, q_off of ANY integer dtype (np.cumsum hands back int64), starting at 0, non-decreasing and
-    ending at len(items_flat)."""
+    """A bare tuple (items_flat, q_off) is read as CSR only if it cannot be two evolving sessions of the same kind: two 1-D numpy arrays, items_flat of dtype
+    uint64 and q_off of an integer dtype OTHER than uint64 (uint32 as the C ABI takes it, or what np.cumsum hands back), starting at 0, non-decreasing and ending
+    at len(items_flat).  Two arrays of one dtype are two sessions.  `CSR(items_flat, q_off)` says it explicitly."""
+    if isinstance(sessions, CSR):
+        flat, off = np.asarray(sessions.items_flat), np.asarray(sessions.q_off)
+        if flat.ndim != 1 or off.ndim != 1 or len(off) < 1 or int(off[0]) != 0 or int(off[-1]) != len(flat) or (len(off) > 1 and not bool((off[1:] >= off[:-1]).all())):
+            raise ValueError("CSR(items_flat, q_off): q_off must start at 0, be non-decreasing and end at len(items_flat)")
+        return True
     if not (isinstance(sessions, tuple) and len(sessions) == 2 and all(isinstance(a, np.ndarray) and a.ndim == 1 for a in sessions)):
         return False
     flat, off = sessions
-    if not np.issubdtype(off.dtype, np.integer) or len(off) < 1:
+    if flat.dtype != np.uint64 or not np.issubdtype(off.dtype, np.integer) or off.dtype == np.uint64 or len(off) < 1:
         return False
     return int(off[0]) == 0 and int(off[-1]) == len(flat) and (len(off) < 2 or bool((off[1:] >= off[:-1]).all()))
 
 
 def _flatten(sessions):
-    # CSR input is a tuple of two numpy arrays (items_flat, q_off), see _is_csr_pair; a tuple of two evolving sessions (lists, or arrays
+    # CSR input is CSR(items_flat, q_off) or a tuple of two numpy arrays of different kinds, see _is_csr_pair; a tuple of two evolving sessions (lists, or arrays
     # that are not such a pair) is two queries
     if _is_csr_pair(sessions):
         if len(sessions[0]) > 0xFFFFFFFF:

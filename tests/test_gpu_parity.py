@@ -417,6 +417,42 @@ def test_resident_inputs_flag_overlaps_prep_and_changes_nothing():
         assert np.array_equal(o[0].cpu().numpy().view(np.uint64).reshape(nq, n), ref[0]) and np.array_equal(o[1].cpu().numpy().reshape(nq, n), ref[1]), rep
 
 
+def test_resident_and_plain_calls_mixed_on_one_stream():
+    """a resident call's side-stream prep must wait for the LAST call that read its record set, resident or not.  Calls with and without
+    SRN_FLAG_INPUTS_RESIDENT alternate on one stream in every pattern of three, larger batches so that a kernel is still running when the next call is enqueued."""
+    torch = pytest.importorskip("torch")
+    import serenade_amd as sa
+    from serenade_amd import synth
+    inter, n_items, k, m, idfw = synth.CONFIGS["tiny"]
+    off, items, ts = synth.training_sessions(inter, n_items)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw)
+    dev = torch.device("cuda:0")
+    n = synth.HOW_MANY
+    batches = []
+    for b in range(3):
+        qi, qo = synth.queries(30000 + 5000 * b, n_items, seed=synth.SEED + 77 * (b + 1))
+        nq = len(qo) - 1
+        ref = sa.predict_batch(gix, (qi, qo), k, m, n)
+        batches.append((torch.from_numpy(qi.view(np.int64).copy()).to(dev), torch.from_numpy(qo.view(np.int32).copy()).to(dev), nq, ref))
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream()
+    for pattern in ((0, 1, 1), (1, 0, 1), (1, 1, 0), (0, 1, 0), (1, 0, 0)):
+        outs = []
+        with torch.cuda.stream(stream):
+            for rep in range(12):
+                d_flat, d_off, nq, _ = batches[rep % 3]
+                o = (torch.zeros(nq * n, dtype=torch.int64, device=dev), torch.zeros(nq * n, dtype=torch.float64, device=dev), torch.zeros(nq, dtype=torch.int32, device=dev))
+                stream.synchronize() if rep == 0 else None
+                sa.predict_batch_device(gix, d_flat.data_ptr(), d_off.data_ptr(), nq, synth.LAST_ITEMS, k, m, n, False, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(),
+                                        stream.cuda_stream, resident=bool(pattern[rep % 3] if rep < 9 else pattern[(rep + 1) % 3]))
+                outs.append(o)
+        stream.synchronize()
+        for rep, o in enumerate(outs):
+            nq, ref = batches[rep % 3][2], batches[rep % 3][3]
+            assert np.array_equal(o[2].cpu().numpy().view(np.uint32), ref[2]), (pattern, rep)
+            assert np.array_equal(o[0].cpu().numpy().view(np.uint64).reshape(nq, n), ref[0]) and np.array_equal(o[1].cpu().numpy().reshape(nq, n), ref[1]), (pattern, rep)
+
+
 def test_evaluator_binary_on_reference_example(tmp_path):
     """The drop-in `evaluator <config.toml>` host program (mirror of src/bin/evaluator.rs) on the reference's example data,
     rebuilt from the golden fixture: 931 evaluations, HitRate@20 0.6402, the README's metric line (README.md:170-172)."""

@@ -166,12 +166,20 @@ def test_predict_batch_takes_a_tuple_of_two_sessions_as_two_queries():
     assert flat.tolist() == [11, 12, 13, 14, 15] and off.tolist() == [0, 3, 5]
     flat, off = vmisknn._flatten((np.array([11, 12, 13, 14, 15], np.uint64), np.array([0, 3, 5], np.uint32)))
     assert flat.tolist() == [11, 12, 13, 14, 15] and off.tolist() == [0, 3, 5]
-    # offsets of any integer dtype (np.cumsum returns int64; the training offsets are uint64) are offsets, not a second session
+    # offsets of an integer dtype other than the items' uint64 (np.cumsum returns int64) are offsets, not a second session ...
     for dt in (np.int64, np.uint64, np.int32):
         lens = np.array([3, 2], dt)
         q_off = np.concatenate([np.zeros(1, dt), np.cumsum(lens, dtype=dt)])
-        flat, off = vmisknn._flatten((np.array([11, 12, 13, 14, 15], np.uint64), q_off))
+        pair = (np.array([11, 12, 13, 14, 15], np.uint64), q_off)
+        flat, off = vmisknn._flatten(pair if dt != np.uint64 else vmisknn.CSR(*pair))
         assert flat.tolist() == [11, 12, 13, 14, 15] and off.tolist() == [0, 3, 5] and off.dtype == np.uint32
+    # ... but two uint64 arrays are two evolving sessions even if the second looks like offsets (item id 0 is legal): CSR() says otherwise explicitly
+    flat, off = vmisknn._flatten((np.array([5, 7, 9], np.uint64), np.array([0, 3], np.uint64)))
+    assert flat.tolist() == [5, 7, 9, 0, 3] and off.tolist() == [0, 3, 5]
+    flat, off = vmisknn._flatten(vmisknn.CSR(np.array([5, 7, 9], np.uint64), np.array([0, 3], np.uint64)))
+    assert flat.tolist() == [5, 7, 9] and off.tolist() == [0, 3]
+    with pytest.raises(ValueError):
+        vmisknn._flatten(vmisknn.CSR(np.array([5, 7, 9], np.uint64), np.array([0, 2], np.uint64)))
     # a pair that is not offsets (does not start at 0 / end at len / decreases) stays two sessions
     flat, off = vmisknn._flatten((np.array([11, 12, 13], np.uint64), np.array([0, 2, 1, 3], np.int64)))
     assert off.tolist() == [0, 3, 7]
