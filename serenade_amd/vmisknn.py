@@ -151,7 +151,14 @@ def _is_csr_pair(sessions):
     if not (isinstance(sessions, tuple) and len(sessions) == 2 and all(isinstance(a, np.ndarray) and a.ndim == 1 for a in sessions)):
         return False
     flat, off = sessions
-    if flat.dtype != np.uint64 or not np.issubdtype(off.dtype, np.integer) or off.dtype == np.uint64 or len(off) < 1:
+    if not np.issubdtype(off.dtype, np.integer) or len(off) < 1:
+        return False
+    looks = int(off[0]) == 0 and int(off[-1]) == len(flat) and (len(off) < 2 or bool((off[1:] >= off[:-1]).all()))
+    if looks and (flat.dtype != np.uint64 or off.dtype == np.uint64):
+        # two arrays of one kind whose second one also reads as offsets of the first: refuse to guess (a wrong guess answers a different question silently)
+        raise ValueError("ambiguous batch: a tuple of two arrays of the same kind that could be (items_flat, q_off) or two evolving sessions -- "
+                         "pass serenade_amd.CSR(items_flat, q_off), or the two sessions as lists")
+    if flat.dtype != np.uint64 or off.dtype == np.uint64:
         return False
     return int(off[0]) == 0 and int(off[-1]) == len(flat) and (len(off) < 2 or bool((off[1:] >= off[:-1]).all()))
 

@@ -115,3 +115,49 @@ def random_queries(seed, ids, n, max_len=6, unknown_rate=0.05, dup_rate=0.2):
                 q[j] = q[int(rng.integers(0, j))]              # repeated item
         qs.append([int(x) for x in q])
     return qs
+
+
+def big_config_unavailable(config, why):
+    """A BASELINE config that cannot run at full size on this box must not vanish quietly: the test FAILS (the driver then reports the config as
+    untested) unless SRN_ALLOW_SKIP_BIG=1 says the smaller box is intended."""
+    import pytest
+    msg = "BASELINE %s cannot run at full size here: %s" % (config, why)
+    if os.environ.get("SRN_ALLOW_SKIP_BIG") == "1":
+        pytest.skip(msg + " (SRN_ALLOW_SKIP_BIG=1)")
+    pytest.fail(msg + " -- set SRN_ALLOW_SKIP_BIG=1 to skip it on purpose")
+
+
+def eight_metrics(recommendations, next_items, training_items, length=20):
+    """The reference's evaluation report (src/metrics/evaluation_reporter.rs:12-117) restated: Mrr, Ndcg, HitRate, Popularity, Precision, Coverage, Recall,
+    F1score @length over (recommendations, next_items) pairs; training_items = the item column of the training data (popularity.rs:20-29, coverage.rs:17-25).
+    Same formulas as serenade_amd/csrc/host/evaluator.cpp (which is pinned on the reference's metric KATs); test-side only."""
+    import math
+    from collections import Counter
+    freq = Counter(int(x) for x in training_items)
+    max_freq = max(freq.values()) if freq else 1
+    n = mrr = ndcg = hit = pop = prec = rec = 0.0
+    covered = set()
+
+    def dcg(top, nxt):                                                    # ndcg.rs:13-27
+        return sum((1.0 if i == 0 else 1.0 / math.log2(i + 1.0)) for i, x in enumerate(top) if x in nxt)
+
+    for recs, nxt in zip(recommendations, next_items):
+        n += 1
+        top = [int(x) for x in recs[:length]]
+        nxt = [int(x) for x in nxt]
+        if nxt[0] in top:                                                 # mrr.rs:24-33, hitrate.rs:24-33
+            mrr += 1.0 / (top.index(nxt[0]) + 1)
+            hit += 1.0
+        nset, tset = set(nxt), set(top)
+        ndcg += dcg(top, nset) / dcg(nxt[:length], nset)                  # ndcg.rs:42-56
+        inter = len(nset & tset)
+        prec += inter / float(length)                                     # precision.rs:31-43
+        rec += inter / float(len(nxt))                                    # recall.rs:31-44
+        if tset:                                                          # popularity.rs:41-58
+            pop += sum(freq[x] / float(max_freq) for x in tset if x in freq) / len(tset)
+        covered.update(top)                                               # coverage.rs:29-38
+    n = max(n, 1.0)
+    p, r = prec / n, rec / n
+    f1 = 2.0 * p * r / (p + r) if p + r > 0 else 0.0                      # f1score.rs:27-36
+    return {"Mrr": mrr / n, "Ndcg": ndcg / n, "HitRate": hit / n, "Popularity": pop / n, "Precision": p, "Coverage": len(covered) / float(max(1, len(freq))),
+            "Recall": r, "F1score": f1}

@@ -15,6 +15,8 @@ import time
 import numpy as np
 import pytest
 
+from helpers import big_config_unavailable
+
 pytestmark = pytest.mark.gpu
 SCORE_RTOL = 1e-12
 
@@ -38,10 +40,11 @@ def test_config5_full_size(monkeypatch):
     from serenade_amd import capi, sharded, synth
     from oracle import oracle as O
     if _host_memory_gb() < 140:
-        pytest.skip("config 5 needs ~150 GB of host memory for the generator's sessions, the host copy of the index and the 8 shards (%.0f GB here)" % _host_memory_gb())
+        big_config_unavailable("configs[4] (2.3 B interactions)", "needs ~150 GB of host memory for the generator's sessions, the host copy of the index and the 8 shards (%.0f GB here)" % _host_memory_gb())
     free_hbm = torch.cuda.mem_get_info(0)[0] / 1e9
     if free_hbm < 215:
-        pytest.skip("config 5 with all 8 shards resident needs ~200 GB of HBM (%.0f GB free)" % free_hbm)
+        big_config_unavailable("configs[4] (2.3 B interactions)", "all 8 shards resident need ~200 GB of HBM (%.0f GB free)" % free_hbm)
+    print("covers BASELINE.json configs[4]: synthetic 2.3B interactions / 20M items, index item-sharded 8 ways (all shards on this one GPU)")
     t_all = time.time()
     inter, n_items, k, m, idfw = synth.CONFIGS["cfg5"]
     L, n = synth.LAST_ITEMS, synth.HOW_MANY

@@ -224,7 +224,7 @@ def test_example_golden_fixture():
     for tag in ("a", "b"):
         m, k, n, idfw, max_len = (int(x) for x in g["params_" + tag])
         gix = sa.VMISIndex.from_sessions(g["sess_off"], g["items"], g["ts"], m, max_len, float(idfw))
-        ids, sc, cnt = sa.predict_batch(gix, (g["q_items_" + tag], g["q_off_" + tag]), k, m, n, True)
+        ids, sc, cnt = sa.predict_batch(gix, sa.CSR(g["q_items_" + tag], g["q_off_" + tag]), k, m, n, True)
         assert np.array_equal(cnt, g["counts_" + tag])
         assert np.array_equal(ids, g["ids_" + tag])
         np.testing.assert_allclose(sc, g["scores_" + tag], rtol=SCORE_RTOL, atol=0)
@@ -543,10 +543,16 @@ def test_config4_full_size(monkeypatch):
     """BASELINE.json configs[3]: 582 M interactions / 6.5 M items (~10 GB of index in HBM), k=1500 m=2500, index built on the
     GPU.  A 1 000-query sample against the canonical oracle (ids, order, counters exact; scores 1e-12), and the path-equivalence
     properties on > 30 000 queries: fast kernel == general kernel (merge tree) == session hash table + selects.
-    SRN_SKIP_CFG4=1 skips it (needs ~60 GB of host memory for the generator's sessions and the oracle's index)."""
+    Needs ~60 GB of host memory for the generator's sessions and the oracle's index: a box without it FAILS the test (SRN_ALLOW_SKIP_BIG=1 skips on purpose)."""
     import os
-    if os.environ.get("SRN_SKIP_CFG4"):
-        pytest.skip("SRN_SKIP_CFG4 set")
+    from helpers import big_config_unavailable
+    try:
+        avail_gb = next(int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")) / 1e6
+    except Exception:
+        avail_gb = float("inf")
+    if os.environ.get("SRN_SKIP_CFG4") or avail_gb < 60:
+        big_config_unavailable("configs[3] (582 M interactions)", "SRN_SKIP_CFG4 set" if os.environ.get("SRN_SKIP_CFG4") else "%.0f GB of host memory available, ~60 needed" % avail_gb)
+    print("covers BASELINE.json configs[3]: synthetic 582M interactions / 6.5M items, 1 GPU, k=1500")
     import serenade_amd as sa
     from serenade_amd import capi, synth
     O = _oracle()

@@ -174,7 +174,9 @@ def test_predict_batch_takes_a_tuple_of_two_sessions_as_two_queries():
         flat, off = vmisknn._flatten(pair if dt != np.uint64 else vmisknn.CSR(*pair))
         assert flat.tolist() == [11, 12, 13, 14, 15] and off.tolist() == [0, 3, 5] and off.dtype == np.uint32
     # ... but two uint64 arrays are two evolving sessions even if the second looks like offsets (item id 0 is legal): CSR() says otherwise explicitly
-    flat, off = vmisknn._flatten((np.array([5, 7, 9], np.uint64), np.array([0, 3], np.uint64)))
+    with pytest.raises(ValueError):      # ... a pair that reads both ways is refused, not guessed
+        vmisknn._flatten((np.array([5, 7, 9], np.uint64), np.array([0, 3], np.uint64)))
+    flat, off = vmisknn._flatten(([5, 7, 9], [0, 3]))
     assert flat.tolist() == [5, 7, 9, 0, 3] and off.tolist() == [0, 3, 5]
     flat, off = vmisknn._flatten(vmisknn.CSR(np.array([5, 7, 9], np.uint64), np.array([0, 3], np.uint64)))
     assert flat.tolist() == [5, 7, 9] and off.tolist() == [0, 3]

@@ -192,3 +192,69 @@ def test_restricted_parallel_builder_equals_prepare_hashmap():
     other = next(int(i) for i in ids if int(i) not in seen)
     with pytest.raises(ValueError):
         r.predict_batch("canonical", np.array([other], np.uint64), np.array([0, 1], np.uint32), 50, 60, 21)
+
+
+def _divergence(ix_a, which_a, ix_b, which_b, qs, k, m, n, training_items):
+    """Two predict variants over one workload: share of queries whose top-n SETS differ, whose ranked lists differ, and the 8 metric deltas (b - a) @ n - 1."""
+    from helpers import eight_metrics, flatten
+    flat, qoff = flatten([q for q, _ in qs])
+    nxt = [x for _, x in qs]
+    ra = ix_a.predict_batch(which_a, flat, qoff, k, m, n, business=True, threads=4)
+    rb = ix_b.predict_batch(which_b, flat, qoff, k, m, n, business=True, threads=4)
+    la = [ra["ids"][i, :ra["counts"][i]].tolist() for i in range(len(qs))]
+    lb = [rb["ids"][i, :rb["counts"][i]].tolist() for i in range(len(qs))]
+    set_diff = sum(set(a) != set(b) for a, b in zip(la, lb)) / float(len(qs))
+    order_diff = sum(a != b for a, b in zip(la, lb)) / float(len(qs))
+    ma, mb = eight_metrics(la, nxt, training_items, n - 1), eight_metrics(lb, nxt, training_items, n - 1)
+    return set_diff, order_diff, {kk: mb[kk] - ma[kk] for kk in ma}, ma
+
+
+def _tied_workload(seed=77):
+    """Tied-timestamp synthetic set: 6 000 training sessions on 750 distinct timestamps (8 sessions share one on average), 400 held-out sessions as evaluator prefixes."""
+    from helpers import evaluator_queries, small_dataset
+    off, items, ts, ids = small_dataset(seed, n_sessions=6000, n_items=400, tied_timestamps=True, max_len=12)
+    rng = np.random.default_rng(seed + 1)
+    w = 1.0 / np.arange(1, len(ids) + 1) ** 0.9
+    w /= w.sum()
+    test = {s: [int(x) for x in ids[rng.choice(len(ids), size=int(rng.integers(2, 9)), p=w)]] for s in range(400)}
+    return off, items, ts, evaluator_queries(test, 4)
+
+
+def test_what_canonical_costs_against_the_literal_reference_on_tied_data(capsys):
+    """the canonical closed form replaces the reference's container-order-dependent behaviour at ties and
+    the t-digest p99.5 (vmis_index.rs:689-716, Q10) by the exact quantile.  How far can that move the reference's own quality numbers?  Measured here against the
+    LITERAL restatement (same loops, heaps and scan orders as vmis_index.rs:325-415 / mod.rs:118-215, with this oracle's map iteration order standing in for
+    hashbrown's) on a tied-timestamp synthetic set, and -- where /root/reference is present -- on assets/example (306 of its sessions share a timestamp).
+    The numbers are copied into DESIGN.md section 2; the asserts are the bounds that table claims."""
+    rows = []
+    off, items, ts, qs = _tied_workload()
+    for (k, m) in ((50, 500), (100, 200)):                      # (no cut hit / m-cut and k-cut both hit)
+        ix = O.OracleIndex(off, items, ts, m, 12, 1.0, fast=True)
+        sd, od, dm, base = _divergence(ix, "literal", ix, "canonical", qs, k, m, 21, items)
+        rows.append(("synthetic tied, k=%d m=%d" % (k, m), len(qs), sd, od, dm, base))
+        assert abs(dm["Mrr"]) < 0.01 and abs(dm["HitRate"]) < 0.01 and abs(dm["Ndcg"]) < 0.01 and abs(dm["Recall"]) < 0.01, dm
+    if have_reference_assets():
+        import tempfile
+        with tempfile.TemporaryDirectory() as tmp:
+            d = extract_example(tmp)
+            eoff, eitems, ets, _ = O.read_tsv(os.path.join(d, "train.txt"))
+            test = read_test_data_evolving(os.path.join(d, "test.txt"))
+            train_col = [int(l.split()[1]) for l in list(open(os.path.join(d, "train.txt")))[1:] if len(l.split()) >= 3]
+        assert len(ets) - len(np.unique(ets)) > 100                                    # (timestamps do tie in the example)
+        for (k, m, last, idfw) in ((50, 500, 2, 1.0), (288, 1502, 4, 2.0)):           # example.toml / BASELINE configs[0] (README TPE optimum)
+            eqs = evaluator_queries(test, last)
+            ix = O.OracleIndex(eoff, eitems, ets, m, 15, idfw, fast=True)
+            sd, od, dm, base = _divergence(ix, "literal", ix, "canonical", eqs, k, m, 21, train_col)
+            rows.append(("assets/example, k=%d m=%d last=%d" % (k, m, last), len(eqs), sd, od, dm, base))
+            assert sd < 0.30 and abs(dm["Mrr"]) < 0.005 and abs(dm["HitRate"]) < 0.005, (sd, dm)
+            # Q10: the reference's t-digest estimate of p99.5 may land one off the exact quantile (15): what a +-1 max_session_len does to canonical results
+            for ml in (14, 16):
+                ix2 = O.OracleIndex(eoff, eitems, ets, m, ml, idfw, fast=True)
+                sd2, od2, dm2, _ = _divergence(ix, "canonical", ix2, "canonical", eqs, k, m, 21, train_col)
+                rows.append(("assets/example, k=%d m=%d last=%d: max_session_len %d vs 15" % (k, m, last, ml), len(eqs), sd2, od2, dm2, None))
+                assert abs(dm2["Mrr"]) < 0.01 and abs(dm2["HitRate"]) < 0.01, (ml, dm2)
+    with capsys.disabled():
+        for name, nq, sd, od, dm, base in rows:
+            print("\n[canonical-vs-literal] %s: %d queries, top-21 set differs %.2f %%, ranked list differs %.2f %%; deltas %s%s" % (
+                name, nq, 100 * sd, 100 * od, " ".join("%s %+.4f" % kv for kv in dm.items()),
+                ("; literal: " + " ".join("%s %.4f" % kv for kv in base.items())) if base else ""))
