@@ -5,15 +5,19 @@ A "step" is one pass of the hot path (libserenade_hip.so) over one batch of synt
 query / result buffers already resident in HBM.  The workload is BASELINE.json configs[2] -- the 60 M-interaction / 1.76 M-item
 synthetic index the metric's target is quoted on (k=1500, m=2500, idf_weighting=2).
 
-  N = 1   srn_predict_batch_device on the whole index; a batch is 2^20 evolving sessions (20 steps time ~0.5 s of GPU work).
-  N > 1   one process per GPU (launched by torch.distributed.run -- or by this script itself when started bare with --gpus N), and
-          BOTH multi-GPU modes in one line:
-            value      the north star's partitioning: the index ITEM-SHARDED over the N GPUs (owner = hash of the item id), every rank
-                       sees the whole batch, srn_shard_group_predict_batch exchanges the posting lists and merges the per-shard top-n
-                       over RCCL (called from inside the library); "scaling": "strong"
-            replicas   the ceiling: every GPU holds the whole index and serves its own slice of the query stream, no data-path
-                       collective (how the reference scales: replicas + session affinity, src/endpoints/recommend_resource.rs:17-19)
-          --mode replicas | item-sharded runs one of them alone (item-sharded works at N = 1 too: the group's overhead over the fused path).
+  One process per GPU (launched by torch.distributed.run -- or by this script itself when started bare with --gpus N), and at EVERY N, N = 1 included,
+  BOTH modes of SURVEY.md 8(e) in one line, so that a 1/2/4/8 curve can be read mode by mode:
+    value_replicas      every GPU holds the whole index and serves its own slice of the query stream through srn_predict_batch_device (2^20 evolving sessions
+                        per step and GPU), no data-path collective (how the reference scales: replicas + session affinity, src/endpoints/recommend_resource.rs:17-19)
+    value_item_sharded  the north star's partitioning: the index ITEM-SHARDED over the N GPUs (owner = hash of the item id), every rank sees the whole
+                        batch, srn_shard_group_predict_batch exchanges the posting lists and merges the per-shard top-n over RCCL (called from inside the
+                        library); at N = 1 a group of one shard on a 1-rank communicator
+    value / value_mode  N = 1: the replicas figure (the metric's configuration on one GPU, "scaling": "weak"); N > 1: the item-sharded figure ("strong"),
+                        as BASELINE.json's north star asks -- value_mode says which, the other one is beside it
+  --mode replicas | item-sharded runs one of them alone.  --rehearse N: N processes on device 0 over the callback transport (gloo) -- the N > 1 code path,
+  line assembly included, on a one-GPU box (tests/test_gpu_bench_rehearsal.py).
+  At N > 1 the item-sharded mode is timed twice: first with the exchange of batch i + 1 NOT overlapped with batch i (one communicator busy at a time),
+  then overlapped (two communicators in flight) under a watchdog; the line says which run `value_item_sharded` comes from and carries both.
 
 Order of events (no timing counts before parity):
   1. PARITY GATE  the first `--parity` queries of batch 0 through the product call of every mode that is timed, against the canonical
@@ -23,7 +27,7 @@ Order of events (no timing counts before parity):
   4. (N=1) CPU baseline: the oracle's literal restatement of the reference loops on the host cores, bounded sample
 
 Prints ONE JSON line on rank 0:
-  value         whole-job predict_next queries/s of the K timed steps (max-over-ranks wall time)
+  value         whole-job predict_next queries/s of the K timed steps (max-over-ranks wall time); see value_mode above
   roofline      N=1: dominant kernel (vmis_fast_kernel): algorithmic bytes of the queries it served / its HIP-event duration, `frac` against
                 8 TB/s and `frac_counter` = measured HBM traffic / time / 8 TB/s; N>1: the item-sharded step against N x 8 TB/s
   cpu_baseline  see 4.
@@ -40,7 +44,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); the copy ceiling is measured in the run (~6300 GB/s)
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); the device-to-device copy rate is measured in every run (roofline.measured_copy_gbs: 5.3-5.4 TB/s on the driver's boxes)
 SCORE_RTOL = 1e-12      # north star: 1e-5; integer-exact accumulation holds 1e-12
 
 
@@ -100,6 +104,11 @@ def main():
                     "step's kernels; measured on config 3: the prep kernel's 0.44 ms disappear from the step but the fast kernel slows down by 0.7 ms -- 40.5 M against 41.3 M queries/s -- "
                     "so it is off by default)")
     ap.add_argument("--shard-timeout", type=int, default=420, help="seconds the item-sharded phase may take before the line falls back to the replicas mode alone")
+    ap.add_argument("--rehearse", type=int, default=0, help="N processes on device 0 over the callback transport (gloo): the N > 1 code path of this script on a one-GPU box")
+    ap.add_argument("--overlap-probe-timeout", type=float, default=30.0, help="seconds (plus three times the non-overlapped run's duration) the overlapped item-sharded run may take at N > 1")
+    ap.add_argument("--shard-steps", type=int, default=0, help="timed steps of the item-sharded phase (0: --steps)")
+    ap.add_argument("--measure-traffic", action="store_true", help="N=1: two extra rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this script with 2 steps, so that "
+                    "roofline.traffic is measured in this run instead of read back from profiles/")
     ap.add_argument("--selftest-launch", action="store_true", help="CPU check of the launcher and the control plane (gloo): no GPU, no timing")
     ap.add_argument("--builder", default="gpu", choices=["gpu", "host"], help="index construction: rocPRIM sorts on the GPU, or the host builder (same bytes)")
     ap.add_argument("--parity", type=int, default=2048, help="queries of batch 0 checked against the canonical oracle before anything is timed (0 = skip)")
@@ -109,6 +118,10 @@ def main():
     ap.add_argument("--traffic-file", default=None, help="profiles/*_traffic_<config>.json from the PMC passes (default: newest match)")
     args = ap.parse_args()
 
+    rehearse = args.rehearse > 1 or os.environ.get("SRN_BENCH_REHEARSE") == "1"
+    if "WORLD_SIZE" not in os.environ and args.rehearse > 1:
+        args.gpus = args.rehearse
+        os.environ["SRN_BENCH_REHEARSE"] = "1"
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # started bare (`python bench.py --gpus N ...`): launch the N ranks ourselves -- one process per GPU under torch.distributed.run, rendezvous on
         # 127.0.0.1 -- and hand their exit code back; rank 0 prints the one JSON line
@@ -154,14 +167,17 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the predict path has no CPU fallback", file=sys.stderr)
         sys.exit(2)
+    if rehearse:
+        local_rank = 0        # every rank on the one GPU of the box; process group over gloo, the shard group's collectives through application callbacks
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     with c_stdout_to_stderr():
-        D.init("nccl", dev)   # RCCL; the process group is the control plane (barrier, max-over-ranks, the shard group's id); the data-path collectives are the library's own
+        D.init("gloo" if rehearse else "nccl", dev)   # RCCL; the process group is the control plane (barrier, max-over-ranks, the shard group's id); the data-path collectives are the library's own
+    ctl_dev = "cpu" if rehearse else dev
 
     inter, n_items, k, m, idfw = synth.CONFIGS[args.config]
     how_many, last_items = synth.HOW_MANY, synth.LAST_ITEMS
-    mode = args.mode if args.mode != "auto" else ("replicas" if world == 1 else "both")
+    mode = args.mode if args.mode != "auto" else "both"
     do_rep, do_shard = mode in ("replicas", "both"), mode in ("item-sharded", "both")
     t0 = time.time()
     off, items, ts = synth.training_sessions(inter, n_items)
@@ -222,31 +238,37 @@ def main():
             os._exit(1)
         return n_par
 
-    def timed(step_fn):
+    def timed(step_fn, steps=None):
+        steps = args.steps if steps is None else steps
         for i in range(args.warmup):
             step_fn(i)
         torch.cuda.synchronize()
         D.barrier()
         torch.cuda.synchronize()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         t0 = time.perf_counter()
-        for i in range(args.steps):
+        for i in range(steps):
             ev[i][0].record(stream)
             step_fn(args.warmup + i)
             ev[i][1].record(stream)
         torch.cuda.synchronize()
         D.barrier()
-        elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+        elapsed = D.max_over_ranks(time.perf_counter() - t0, ctl_dev)
         return elapsed, np.array([a.elapsed_time(b) for a, b in ev])
 
     # =========================== item-sharded index over the N GPUs (srn_shard_group_*, RCCL inside the library) ===========================
-    def sharded_phase():
+    shard_steps = args.shard_steps or args.steps
+    pending = {"line": None}      # what the overlap watchdog prints if the overlapped run never comes back: the line built on the non-overlapped run
+
+    def sharded_phase(make_line):
         nonlocal group
         t0g = time.time()
         with c_stdout_to_stderr():
-            group = SH.ShardGroup.rccl(shard, rank, world)  # RCCL communicators created inside the library; the id travels over the process group
+            if rehearse:
+                group = SH.ShardGroup.over(shard, rank, world, SH.DistComm())   # the collectives as callbacks over gloo: every line of the N > 1 path but RCCL itself
+            else:
+                group = SH.ShardGroup.rccl(shard, rank, world)  # RCCL communicators created inside the library; the id travels over the process group
         t_group = time.time() - t0g
-        shard_line = None
         Bs = args.shard_batch
         sbatches = draw_batches(Bs, args.pool, 0)                     # every rank sees the SAME batches
         s_out = (torch.empty((Bs, how_many), dtype=torch.int64, device=dev), torch.empty((Bs, how_many), dtype=torch.float64, device=dev),
@@ -256,6 +278,8 @@ def main():
             d_flat, d_off, _, _ = sbatches[i % args.pool]
             group.predict_batch(d_flat, d_off, Bs, last_items, k, m, how_many, False, stream.cuda_stream, resident=True, out=s_out)
 
+        # the non-overlapped form first wherever there are peers: one communicator busy at a time, nothing in it that can wait on a peer's other collective
+        group.set_overlap(world == 1)
         s_parity = 0
         if args.parity > 0:                                           # (a collective call: every rank runs it, rank 0 checks)
             sstep(0)
@@ -264,30 +288,41 @@ def main():
                 n_par = int(min(Bs, args.parity))
                 s_parity = gate(s_out[0].cpu().numpy().view(np.uint64)[:n_par], s_out[1].cpu().numpy()[:n_par], s_out[2].cpu().numpy().view(np.uint32)[:n_par],
                                 sbatches[0][2], sbatches[0][3], n_par, "item-sharded")
-        sstep(0); sstep(1)                                            # both buffer slots sized (setup, not one of the W warm-up steps)
-        torch.cuda.synchronize()
-        st0 = group.stats
-        s_elapsed, s_step_ms = timed(sstep)
-        st1 = group.stats
-        s_served = int((s_out[2].cpu().numpy().view(np.uint32) != 0xFFFFFFFF).sum())
+        bq_mean = None
         if rank == 0:
-            nb, nqs = st1["batches"] - st0["batches"], max(1, st1["queries"] - st0["queries"])
-            per_q = {kk: (st1[kk] - st0[kk]) / nqs for kk in ("bytes_head", "bytes_counts", "bytes_lists", "bytes_results", "bytes_lists_max_rank")}
             nstat = min(Bs, 8192)
             dbg = sa.predict_batch_debug(index, (sbatches[0][2][:sbatches[0][3][nstat]], sbatches[0][3][:nstat + 1]), k, m, how_many, False, neighbours=False)
             bq_mean = float(algorithmic_bytes(dbg["stats"]).mean())
-            ms_step = s_elapsed / args.steps * 1e3
-            ach = bq_mean * Bs / (ms_step * 1e-3) / 1e9
-            shard_line = dict(common)
-            shard_line.update({
-                "value": args.steps * Bs / s_elapsed, "ms_per_step": ms_step, "scaling": "strong",
+
+        def one_run(overlap):
+            group.set_overlap(overlap)
+            sstep(0); sstep(1)                                        # both buffer slots sized (setup, not one of the W warm-up steps)
+            torch.cuda.synchronize()
+            st0 = group.stats
+            s_elapsed, s_step_ms = timed(sstep, shard_steps)
+            st1 = group.stats
+            served = int((s_out[2].cpu().numpy().view(np.uint32) != 0xFFFFFFFF).sum())
+            nqs = max(1, st1["queries"] - st0["queries"])
+            return {"value": shard_steps * Bs / s_elapsed, "ms_per_step": s_elapsed / shard_steps * 1e3, "elapsed_s": s_elapsed,
+                    "step_ms_p50": float(np.percentile(s_step_ms, 50)), "step_ms_p90": float(np.percentile(s_step_ms, 90)),
+                    "exchange_overlapped_with_previous_batch": bool(st1["overlapped"]), "queries_served_last_step": served, "timed_batches": int(st1["batches"] - st0["batches"]),
+                    "transport": {0: "in-process", 1: "rccl", 2: "callbacks"}[st1["transport"]],
+                    "per_q": {kk: (st1[kk] - st0[kk]) / nqs for kk in ("bytes_head", "bytes_counts", "bytes_lists", "bytes_results", "bytes_lists_max_rank")}}
+
+        def shard_line_of(run, probe):
+            ach = bq_mean * Bs / (run["ms_per_step"] * 1e-3) / 1e9
+            per_q = run["per_q"]
+            line = dict(common)
+            line.update({
+                "value": run["value"], "ms_per_step": run["ms_per_step"], "steps": shard_steps, "scaling": "strong",
                 "config": {"workload": ("BASELINE configs[2]: synthetic %d interactions / %d items, k=%d m=%d idf_weighting=%g last_items=%d how_many=%d" % (inter, n_items, k, m, idfw, last_items, how_many)
                                         if args.config == "cfg3" else "synth.CONFIGS[%s]" % args.config) + "; index item-sharded over %d GPU(s), every rank sees the whole batch" % world,
                            "name": args.config, "batch": Bs, "query_pool_batches": args.pool,
                            "parallelism": "item-sharded x%d (owner = hash of the item id): all-reduce(max) of the cuts + all-gather of the kept counts + variable-length exchange of "
                                           "the posting-list prefixes + all-gather of the per-shard top-n per batch, RCCL called from inside libserenade_hip.so (srn_shard_group_predict_batch)" % world,
-                           "rccl_ranks": int(dist.get_world_size()) if world > 1 else 1, "transport": {0: "in-process", 1: "rccl", 2: "callbacks"}[st1["transport"]],
-                           "exchange_overlapped_with_previous_batch": bool(st1["overlapped"]),
+                           "rccl_ranks": (int(dist.get_world_size()) if world > 1 else 1) if not rehearse else 0, "transport": run["transport"],
+                           "rehearsal": "%d processes on ONE GPU over gloo callbacks: control flow only, not a scaling measurement" % world if rehearse else None,
+                           "exchange_overlapped_with_previous_batch": run["exchange_overlapped_with_previous_batch"], "overlap_probe": probe,
                            "items_on_rank0": int(shard.info["n_items"]), "index_bytes_hbm_rank0": int(shard.info["device_bytes"]),
                            "setup_s": {"generate": round(t_gen, 2), "index_build_upload": round(t_build, 2), "shard_cut_attach": round(t_shard, 2), "group_create": round(t_group, 2)}},
                 "roofline": {"bound": "hbm", "kernel": "item-sharded step: list exchange + unsharded kernels over the rank's row fragments + top-n merge", "achieved": ach,
@@ -296,9 +331,66 @@ def main():
                              "note": "the same algorithmic bytes as the unsharded path (every datum is touched once, on the shard that owns it) against the whole step and N x 8 TB/s"},
                 "exchange_bytes_per_query_rank0": {"cuts_all_reduce": per_q["bytes_head"], "kept_counts_all_gather": per_q["bytes_counts"], "list_prefixes_sent": per_q["bytes_lists"],
                                                    "list_prefixes_fullest_rank": per_q["bytes_lists_max_rank"], "topn_all_gather": per_q["bytes_results"]},
-                "latency": {"step_ms_p50": float(np.percentile(s_step_ms, 50)), "step_ms_p90": float(np.percentile(s_step_ms, 90))},
-                "parity_checked": s_parity, "queries_served_last_step": s_served, "timed_batches": int(nb)})
-        return (shard_line if rank == 0 else None), sbatches
+                "latency": {"step_ms_p50": run["step_ms_p50"], "step_ms_p90": run["step_ms_p90"]},
+                "parity_checked": s_parity, "queries_served_last_step": run["queries_served_last_step"], "timed_batches": run["timed_batches"]})
+            return line
+
+        first = one_run(world == 1)
+        if world == 1:
+            return (shard_line_of(first, None) if rank == 0 else None), sbatches
+        # N > 1: the overlapped form (two communicators in flight: batch i + 1's exchange beside batch i's kernels and result gather) under a watchdog.  If it never comes
+        # back, the line of the non-overlapped run is printed from the watchdog and the process leaves: a SCALE run cannot end without a line.
+        import threading
+        limit = args.overlap_probe_timeout + 3.0 * first["elapsed_s"] * (1.0 + (args.warmup + 2.0) / max(1, shard_steps))
+        probe_off = {"non_overlapped": {"value": first["value"], "ms_per_step": first["ms_per_step"]}, "overlapped": None, "timed_run": "non-overlapped", "watchdog_s": round(limit, 1)}
+        if rank == 0:
+            pending["line"] = make_line(shard_line_of(first, dict(probe_off, overlapped="did not finish within the watchdog: this line was printed by it")))
+
+        def probe_hung():
+            if rank == 0 and pending["line"] is not None:
+                print(json.dumps(pending["line"])); sys.stdout.flush()
+            print("bench.py: rank %d: the overlapped item-sharded run did not finish within %.0f s; leaving" % (rank, limit), file=sys.stderr); sys.stderr.flush()
+            os._exit(0)
+        wd2 = threading.Timer(limit, probe_hung)
+        wd2.daemon = True
+        D.barrier()
+        wd2.start()
+        second = one_run(True)
+        wd2.cancel()
+        pending["line"] = None
+        best_is_second = second["value"] >= first["value"]
+        probe = {"non_overlapped": {"value": first["value"], "ms_per_step": first["ms_per_step"]}, "overlapped": {"value": second["value"], "ms_per_step": second["ms_per_step"]},
+                 "timed_run": "overlapped" if best_is_second else "non-overlapped", "watchdog_s": round(limit, 1)}
+        return (shard_line_of(second if best_is_second else first, probe) if rank == 0 else None), sbatches
+
+    def measure_traffic_now(B):
+        """HBM traffic of the dominant kernel, measured NOW: this script again under rocprofv3 --pmc, FETCH_SIZE and WRITE_SIZE in separate passes (kernel trace only,
+        as MI355X_MICROARCH.md prescribes), 1 warm-up + 2 timed steps, the full-batch launches averaged; FETCH_SIZE doubled (gfx950 tallies 128-byte requests as 64)."""
+        import shutil
+        import subprocess
+        import tempfile
+        exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+        if not os.path.exists(exe):
+            return None, None
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import r02_summarize as RS
+        vals = {}
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+            for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+                d = os.path.join(tmp, ctr)
+                cmd = [exe, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__), "--mode", "replicas",
+                       "--config", args.config, "--batch", str(B), "--steps", "2", "--warmup", "1", "--no-sweep", "--no-cpu-baseline", "--parity", "0", "--builder", args.builder]
+                env = dict(os.environ, TMPDIR="/tmp")
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+                if r.returncode != 0:
+                    return None, None
+                c = RS.counters(d, "vmis_fast_kernel").get(ctr, [])
+                if not c:
+                    return None, None
+                top = max(g for _, _, g in c)
+                full = [x for _, x, g in sorted(c) if g >= 0.5 * top][:3]
+                vals[ctr] = sum(full) / len(full)
+        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own passes, 3 full-batch launches each"
 
     # =========================== the whole index on every GPU: replicas, query-sharded (N = 1: THE bench line) ===========================
     def replicas_phase():
@@ -408,16 +500,20 @@ def main():
 
         # HBM traffic per launch comes from separate rocprofv3 --pmc passes over this same command (tools/pmc_bench.sh);
         # the committed summary is read back here so that the line carries it (null if no summary matches the workload)
-        traffic, traffic_src = None, None
-        try:
-            import glob
-            cand = [args.traffic_file] if args.traffic_file else sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*traffic_%s.json" % args.config)))
-            if cand:
-                tj = json.load(open(cand[-1]))
-                if tj.get("config") == args.config and tj.get("batch_per_gpu") == B:
-                    traffic, traffic_src = tj["traffic_bytes_per_launch"], os.path.relpath(cand[-1], ROOT)
-        except Exception:
-            pass
+        traffic, traffic_src, traffic_in_run = None, None, False
+        if args.measure_traffic and world == 1:
+            traffic, traffic_src = measure_traffic_now(B)
+            traffic_in_run = traffic is not None
+        if traffic is None:
+            try:
+                import glob
+                cand = [args.traffic_file] if args.traffic_file else sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*traffic_%s.json" % args.config)))
+                if cand:
+                    tj = json.load(open(cand[-1]))
+                    if tj.get("config") == args.config and tj.get("batch_per_gpu") == B:
+                        traffic, traffic_src = tj["traffic_bytes_per_launch"], os.path.relpath(cand[-1], ROOT)
+            except Exception:
+                pass
 
         result = dict(common)
         result.update({
@@ -435,7 +531,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE)",
                          "frac_counter": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "frac_counter_note": "measured HBM traffic of the launch / its duration / 8 TB/s: what the memory system really moves (frac prices the contract's algorithmic bytes)",
-                         "traffic_source": traffic_src,
+                         "traffic_source": traffic_src, "traffic_measured_in_this_run": traffic_in_run,
+                         "traffic_note": None if traffic_in_run else "read back from the committed PMC summary named in traffic_source (tools/r04_profiles.sh reproduces it; "
+                                                                     "--measure-traffic runs the two PMC passes inside this command)",
                          "measured_copy_gbs": copy_gbs, "frac_measured_copy": achieved / copy_gbs,
                          "algorithmic_bytes_per_query": float(bq.mean()), "queries_per_launch": B,
                          "queries_served_by_this_kernel": int(nq_last - general_last) if fast_used else int(nq_last),
@@ -468,7 +566,15 @@ def main():
             r = oix.predict_batch("literal", flat0[:qo0[n_cpu]], qo0[:n_cpu + 1], k, m, how_many, False, threads=cores,
                                   want_results=False, want_latency=True)
             lat_cpu = r["lat_us"]
+            # ONE thread, one query per call, per-call microseconds -- the reference evaluator's report (src/bin/evaluator.rs:82-89, src/stopwatch.rs:28-52;
+            # there: whole microseconds through a t-digest(100) estimate, here exact quantiles of the same per-call durations)
+            n_one = int(min(n_cpu, max(256, rate / cores * min(args.cpu_seconds, 6.0))))
+            r1 = oix.predict_batch("literal", flat0[:qo0[n_one]], qo0[:n_one + 1], k, m, how_many, False, threads=1, want_results=False, want_latency=True)
+            one = {"p%s" % str(q).replace(".", "_"): float(np.percentile(r1["lat_us"], q)) for q in (25, 50, 75, 90, 95, 99.5)}
+            one.update({"queries": n_one, "seconds": float(r1["elapsed"]), "queries_per_s": n_one / r1["elapsed"],
+                        "note": "one host thread, one evolving session per call like evaluator.rs:46-76; the percentiles the reference prints (p25/50/75/90/95/99.5, microseconds)"})
             result["cpu_baseline"] = {
+                "single_thread_per_call_us": one,
                 "value": n_cpu / r["elapsed"], "unit": "queries/s", "cores": cores, "kind": "port",
                 "sample": "first %d queries of the same batch, %d threads over one shared read-only index (%.1f s); "
                           "oracle/vmis_oracle.cpp literal restatement of the reference's Rust loops, not the Rust binary"
@@ -483,57 +589,71 @@ def main():
     # ---- the phases.  Replicas first (no data-path collective: nothing in it can hang on a peer); the item-sharded phase runs under a watchdog, and if it
     # fails or stalls the line that is printed is the replicas' with the reason -- a SCALE run never ends without a line. ----
     result = replicas_phase() if do_rep else None
+    rep_extra = {}
+    if rank == 0 and result is not None:
+        rep_extra = {"parity_checked": result.pop("_parity_checked"), "props_ok": result.pop("_props_ok"), "B": result.pop("_B")}
+
+    def make_line(shard_line, shard_error=None, sb=None):
+        """The ONE line (rank 0).  Every line carries value_replicas and value_item_sharded (null where a mode did not run) and value_mode = which of them `value` is:
+        N = 1 the replicas figure (BASELINE's metric on one GPU), N > 1 the item-sharded figure (the north star's partitioning)."""
+        v_rep = result["value"] if result is not None else None
+        v_sh = shard_line["value"] if shard_line is not None else None
+        if shard_line is not None and (world > 1 or result is None):
+            line = dict(shard_line)
+            line["value_mode"] = "item-sharded"
+            if result is not None:
+                line["replicas"] = {"value": result["value"], "ms_per_step": result["ms_per_step"], "scaling": "weak", "batch_per_gpu": rep_extra["B"], "parallelism": result["config"]["parallelism"],
+                                    "parity_checked": rep_extra["parity_checked"], "full_batch_properties_ok": rep_extra["props_ok"],
+                                    "kernel": {kk: result["roofline"][kk] for kk in ("kernel", "achieved", "frac", "kernel_ms_avg", "algorithmic_bytes_per_query")},
+                                    "note": "every GPU holds the whole index and serves its own slice of the query stream: no data-path collective, the throughput ceiling of any index that fits 288 GB"}
+                line["cpu_baseline"] = result["cpu_baseline"]
+            else:
+                cpu = None
+                if world == 1 and not args.no_cpu_baseline and sb is not None:
+                    cores = usable_cores()
+                    n_cpu = int(min(args.shard_batch, 4096))
+                    r = oracle_index().predict_batch("literal", sb[0][2][:sb[0][3][n_cpu]], sb[0][3][:n_cpu + 1], k, m, how_many, False, threads=cores, want_results=False)
+                    cpu = {"value": n_cpu / r["elapsed"], "unit": "queries/s", "cores": cores, "kind": "port",
+                           "sample": "first %d queries of the same batch, %d threads (%.1f s); oracle/vmis_oracle.cpp literal restatement" % (n_cpu, cores, r["elapsed"])}
+                line["cpu_baseline"] = cpu
+        elif result is not None:
+            line = dict(result)
+            line["value_mode"] = "replicas"
+            if shard_line is not None:     # N = 1, both modes: the group of one shard beside the fused path
+                line["item_sharded"] = {kk: shard_line[kk] for kk in ("value", "ms_per_step", "steps", "scaling", "parity_checked", "queries_served_last_step", "exchange_bytes_per_query_rank0", "latency")}
+                line["item_sharded"].update({"batch": shard_line["config"]["batch"], "parallelism": shard_line["config"]["parallelism"], "rccl_ranks": shard_line["config"]["rccl_ranks"],
+                                             "transport": shard_line["config"]["transport"], "exchange_overlapped_with_previous_batch": shard_line["config"]["exchange_overlapped_with_previous_batch"],
+                                             "setup_s": shard_line["config"]["setup_s"], "roofline_whole_step_frac": shard_line["roofline"]["frac"],
+                                             "ratio_to_replicas_time": (result["value"] / shard_line["value"]) if shard_line["value"] else None})
+            elif do_shard:
+                line["item_sharded_error"] = shard_error
+        else:
+            line = dict(common, value=None, value_mode=None, item_sharded_error=shard_error)
+        line["value_replicas"], line["value_item_sharded"] = v_rep, v_sh
+        return line
+
     shard_line, shard_error, sb = None, None, None
     if do_shard:
         import threading
 
         def give_up():
             if rank == 0:
-                line = dict(result) if result is not None else dict(common, value=None)
-                for kk in ("_parity_checked", "_props_ok", "_B"):
-                    line.pop(kk, None)
-                line["item_sharded_error"] = "the item-sharded phase did not finish within %d s; this line is the replicas mode alone" % args.shard_timeout
+                line = pending["line"] if pending["line"] is not None else \
+                    make_line(None, "the item-sharded phase did not finish within %d s; this line is the replicas mode alone" % args.shard_timeout)
                 print(json.dumps(line)); sys.stdout.flush()
-            os._exit(0 if rank == 0 else 3)
+            os._exit(0)
         wd = threading.Timer(args.shard_timeout + (0 if rank == 0 else 10), give_up)
         wd.daemon = True
         wd.start()
         try:
-            shard_line, sb = sharded_phase()
+            shard_line, sb = sharded_phase(make_line)
         except Exception as e:   # (RCCL missing, communicator creation failed, ...): say so in the line instead of dying without one
             import traceback
             traceback.print_exc()
             shard_error = repr(e)
         wd.cancel()
     if rank == 0:
-        if result is not None:
-            parity_checked, props_ok, B = result.pop("_parity_checked"), result.pop("_props_ok"), result.pop("_B")
-        if do_shard and not do_rep:
-            line = shard_line if shard_line is not None else dict(common, value=None, item_sharded_error=shard_error)
-            cpu = None
-            if shard_line is not None and world == 1 and not args.no_cpu_baseline:
-                cores = usable_cores()
-                Bs = args.shard_batch
-                n_cpu = int(min(Bs, 4096))
-                r = oracle_index().predict_batch("literal", sb[0][2][:sb[0][3][n_cpu]], sb[0][3][:n_cpu + 1], k, m, how_many, False, threads=cores, want_results=False)
-                cpu = {"value": n_cpu / r["elapsed"], "unit": "queries/s", "cores": cores, "kind": "port",
-                       "sample": "first %d queries of the same batch, %d threads (%.1f s); oracle/vmis_oracle.cpp literal restatement" % (n_cpu, cores, r["elapsed"])}
-            line["cpu_baseline"] = cpu
-        elif do_shard:
-            if shard_line is not None:
-                # N > 1, both modes: the line IS the north star's mode (item-sharded over RCCL); the replicas run is its ceiling
-                line = dict(shard_line)
-                line["replicas"] = {"value": result["value"], "ms_per_step": result["ms_per_step"], "scaling": "weak", "batch_per_gpu": B, "parallelism": result["config"]["parallelism"],
-                                    "parity_checked": parity_checked, "full_batch_properties_ok": props_ok,
-                                    "kernel": {kk: result["roofline"][kk] for kk in ("kernel", "achieved", "frac", "kernel_ms_avg", "algorithmic_bytes_per_query")},
-                                    "note": "every GPU holds the whole index and serves its own slice of the query stream: no data-path collective, the throughput ceiling of any index that fits 288 GB"}
-                line["cpu_baseline"] = result["cpu_baseline"]
-            else:
-                line = dict(result)
-                line["item_sharded_error"] = shard_error
-        else:
-            line = result
-        print(json.dumps(line))
+        print(json.dumps(make_line(shard_line, shard_error, sb)))
         sys.stdout.flush()
     if shard_error is not None:      # (a communicator in an unknown state: its teardown may wait for peers that are gone -- the line is out, leave)
         sys.stderr.flush()

@@ -325,6 +325,13 @@ typedef struct {
     uint64_t stage_batches, bytes_stage_candidates, bytes_stage_minpos; /* batches that took the three-stage pipeline, and what this rank contributed to its two big exchanges */
 } srn_shard_group_stats_t;
 int srn_shard_group_stats(const srn_shard_group_t* g, srn_shard_group_stats_t* out);
+/* Overlap of batch i + 1's exchange (the group's own stream and first communicator) with batch i's kernels and result gather (caller's stream, second communicator).
+ * on = 0: everything in issue order on the caller's stream, one collective of the group in flight at a time -- the conservative form (two communicators with collectives in
+ * flight at once need both collective kernels to become resident on every rank; they do here -- the predict kernels are finite -- but a host that wants no such
+ * dependence switches it off).  Default on (the environment variable SRN_GROUP_OVERLAP=0 changes the default); takes effect from the next batch; every rank must use the
+ * same setting for the same batch.  A failed srn_shard_group_predict_batch leaves the peers' collectives of that batch without their partner: the group is then unusable
+ * on every rank (free it and create a new one). */
+int srn_shard_group_set_overlap(srn_shard_group_t* g, int on);
 void srn_shard_group_free(srn_shard_group_t* g);
 
 /* The same for the most recent min(max_n, 64) predict calls (oldest first): per-call duration in ms of

@@ -114,6 +114,7 @@ SYMBOLS = {
     "srn_shard_group_create_local": (_i, [C.POINTER(_vp), _i, C.POINTER(_vp)]),
     "srn_shard_group_predict_batch": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, C.c_uint, _vp, _vp, _vp, _vp]),
     "srn_shard_group_stats": (_i, [_vp, _vp]),
+    "srn_shard_group_set_overlap": (_i, [_vp, _i]),
     "srn_shard_group_free": (None, [_vp]),
     "srn_kernel_timing": (_i, [_vp, C.c_int]),
     "srn_kernel_times": (_i, [_vp, C.c_uint32, _vp, _vp, C.POINTER(C.c_uint32)]),

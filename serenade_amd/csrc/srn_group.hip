@@ -447,6 +447,13 @@ int srn_shard_group_predict_batch(srn_shard_group_t* g, const uint64_t* d_items_
         return group_predict(g, d_items_flat, d_q_off, nq, max_len_hint, k, m, how_many, flags, d_out_ids, d_out_scores, d_out_counts, (hipStream_t)stream); });
 }
 
+int srn_shard_group_set_overlap(srn_shard_group_t* g, int on) {
+    if (!g) return fail(SRN_EINVAL, "null group");
+    std::lock_guard<std::mutex> lk(g->mu);   // (between batches: a batch in flight keeps the form it was issued in; the slots' events order the next one behind it either way)
+    g->overlap = on != 0;
+    return SRN_OK;
+}
+
 int srn_shard_group_stats(const srn_shard_group_t* g, srn_shard_group_stats_t* out) {
     if (!g || !out) return fail(SRN_EINVAL, "null argument");
     *out = srn_shard_group_stats_t{(uint64_t)G_of(g), g->calls, g->st_queries, g->st_bytes_head, g->st_bytes_kept, g->st_bytes_lists, g->st_bytes_results, g->st_lists_max,

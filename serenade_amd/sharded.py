@@ -508,6 +508,11 @@ class ShardGroup:
                                                             _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), C.c_void_p(stream)))
         return out
 
+    def set_overlap(self, on):
+        """srn_shard_group_set_overlap: batch i + 1's exchange beside batch i's kernels and result gather (two communicators in flight), or everything in
+        issue order on the caller's stream."""
+        capi.check(capi.lib().srn_shard_group_set_overlap(self._h, 1 if on else 0))
+
     @property
     def stats(self):
         st = capi.ShardGroupStats()

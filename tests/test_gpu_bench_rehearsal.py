@@ -1,0 +1,58 @@
+"""bench.py's N > 1 code path on a one-GPU box: `--rehearse N` starts N ranks under torch.distributed.run, all on device 0, process group over
+gloo, the shard group's collectives through application callbacks -- every line of the multi-GPU run except RCCL itself: shard cut, group creation, the parity gate through
+the sharded call, the non-overlapped run, the overlapped run under its watchdog, and the assembly of the ONE JSON line.  A KeyError there must not wait for an 8-GPU node."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def _run(args, timeout=600):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]          # ONE JSON line on stdout, whatever the libraries print
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rehearsal_of_the_multi_gpu_line(world):
+    line = _run(["--rehearse", str(world), "--steps", "2", "--warmup", "1", "--config", "tiny", "--batch", "8192", "--shard-batch", "4096", "--no-sweep", "--cpu-seconds", "1"])
+    for key in CONTRACT:
+        assert key in line, key
+    assert line["n_gpus"] == world and line["value_mode"] == "item-sharded" and line["scaling"] == "strong"
+    assert line["value"] == line["value_item_sharded"] > 0 and line["value_replicas"] > 0
+    cfg = line["config"]
+    assert cfg["transport"] == "callbacks" and cfg["rccl_ranks"] == 0 and "rehearsal" in cfg and cfg["rehearsal"]
+    probe = cfg["overlap_probe"]
+    assert probe["non_overlapped"]["value"] > 0 and probe["overlapped"]["value"] > 0 and probe["timed_run"] in ("overlapped", "non-overlapped")
+    assert cfg["exchange_overlapped_with_previous_batch"] == (probe["timed_run"] == "overlapped")
+    assert line["parity_checked"] > 0 and line["queries_served_last_step"] == 4096
+    rep = line["replicas"]
+    assert rep["value"] == line["value_replicas"] and rep["parity_checked"] > 0 and rep["full_batch_properties_ok"] is True and rep["kernel"]["kernel"].startswith("vmis_")
+    rf = line["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in rf, key
+    assert rf["peak"] == 8000.0 * world and 0 < rf["frac"] < 1
+    ex = line["exchange_bytes_per_query_rank0"]
+    assert ex["topn_all_gather"] > 0 and ex["list_prefixes_sent"] > 0
+
+
+def test_single_gpu_line_carries_both_modes():
+    line = _run(["--steps", "2", "--warmup", "1", "--config", "tiny", "--batch", "8192", "--shard-batch", "4096", "--no-sweep", "--cpu-seconds", "1"])
+    for key in CONTRACT:
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["value_mode"] == "replicas" and line["scaling"] == "weak" and line["value"] == line["value_replicas"] > 0
+    assert line["value_item_sharded"] == line["item_sharded"]["value"] > 0 and line["item_sharded"]["rccl_ranks"] == 1 and line["item_sharded"]["transport"] == "rccl"
+    assert line["item_sharded"]["parity_checked"] > 0
+    rf, cb = line["roofline"], line["cpu_baseline"]
+    assert rf["kernel"].startswith("vmis_") and rf["traffic_measured_in_this_run"] is False
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and set(cb["single_thread_per_call_us"]) >= {"p25", "p50", "p75", "p90", "p95", "p99_5"}
