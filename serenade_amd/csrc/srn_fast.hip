@@ -184,6 +184,106 @@ __device__ __forceinline__ void merge_pair(const uint32_t* in, uint32_t* out, ui
     }
 }
 
+// -------------------------------------------------------------------------------------
+// The two cuts of find_neighbors (vmis_index.rs:332-414) in ONE pass over the merged run (round 4; before: an m-cut pass that OR-ed the copies of a session into
+// a compacted list D with LDS atomics, then a k-cut pass that read D back).  F = n packed slots (rank << NB | list bit), descending: the <= 4 copies of a session
+// are adjacent.  A thread takes g = ceil(n / 512) <= G consecutive entries plus three beyond them into registers, ORs every group onto its first copy (backwards carry),
+// flags the firsts; block scan #1 -> index among the distinct sessions (the m most recent are kept).  No more than k of them: they ARE the neighbours, written in place.
+// Otherwise the k-cut on the registers: numerator classes (<= 15) counted in packed 4-bit fields + DPP sums, the boundary class n* and its share r*, block scan #2 over
+// that class, one atomic per wave for the output slots.  Returns K; the caller's barrier publishes nbl.
+// -------------------------------------------------------------------------------------
+#ifndef SRN_FAST_FUSED_CUT
+#define SRN_FAST_FUSED_CUT 1
+#endif
+template <int G>
+__device__ __forceinline__ uint32_t fast_cut(const uint32_t* F, uint32_t* nbl, uint32_t n, uint32_t NB, uint32_t m, uint32_t k, const uint8_t* wlut, uint32_t* misc, uint32_t tid, uint32_t lane) {
+    constexpr int BLOCK = 512;
+    const uint32_t NBM = (1u << NB) - 1u;
+    const uint32_t g = (n + BLOCK - 1) / BLOCK, o0 = min(tid * g, n), o1 = min(o0 + g, n);
+    uint32_t fv[G + 3];
+#pragma unroll
+    for (int x = 0; x < G + 3; ++x) fv[x] = F[min(o0 + (uint32_t)x, n - 1u)];
+    const uint32_t prev0 = o0 > 0u && o0 < o1 ? F[o0 - 1u] >> NB : 0xFFFFFFFFu;   // (no rank is 0xFFFFFFFF: F[0] starts a session)
+#pragma unroll
+    for (int x = 0; x < G + 3; ++x) fv[x] = o0 + (uint32_t)x < n ? fv[x] : 0u;    // (past the run's end: no entry)
+    {   // every group OR-ed onto its first copy
+        uint32_t carry = 0u, carry_r = 0xFFFFFFFFu;
+#pragma unroll
+        for (int x = G + 2; x >= 0; --x) { const uint32_t r = fv[x] >> NB; carry = r == carry_r ? carry | fv[x] : fv[x]; carry_r = r; fv[x] = carry; }
+    }
+    uint32_t fmask = 0u, firsts = 0u;   // bit x: entry x of the chunk starts a session
+    {
+        uint32_t prev = prev0;
+#pragma unroll
+        for (int x = 0; x < G; ++x) { const bool in = o0 + (uint32_t)x < o1; const uint32_t r = fv[x] >> NB; const bool f1 = in && r != prev; fmask |= f1 ? 1u << x : 0u; firsts += f1; prev = in ? r : prev; }
+    }
+    uint32_t Call;
+    const uint32_t idx0 = block_excl_scan<BLOCK>(firsts, misc + FS_SCAN_A, Call);   // (barrier inside)
+    const uint32_t Cm = min(Call, m);
+    if (Cm <= k) {   // (block-uniform) the m most recent distinct sessions are the neighbours
+        uint32_t idx = idx0;
+#pragma unroll
+        for (int x = 0; x < G; ++x) if ((fmask >> x) & 1u) { if (idx < m) nbl[idx] = fv[x]; ++idx; }
+        return Cm;
+    }
+    uint32_t inm = 0u; unsigned long long nmp = 0ull, acc = 0ull;   // bit x: a first among the m most recent; its class in nibble x; class counts in 4-bit fields
+    {
+        uint32_t idx = idx0, nmv[G];
+#pragma unroll
+        for (int x = 0; x < G; ++x) nmv[x] = (uint32_t)wlut[fv[x] & NBM];   // (class 0 does not exist; all reads in flight together)
+#pragma unroll
+        for (int x = 0; x < G; ++x) {
+            const bool f1 = (fmask >> x) & 1u, in = f1 && idx < m;
+            idx += f1;
+            inm |= in ? 1u << x : 0u;
+            nmp |= in ? (unsigned long long)nmv[x] << (4 * x) : 0ull;
+            acc += in ? 1ull << (4u * nmv[x]) : 0ull;
+        }
+    }
+    uint32_t* cls = misc + FS_CLS;
+    {   // class counts: 16 fields of 4 bits per thread, spread over 4 x 64 bits with 16-bit fields, 8 DPP wave sums
+        uint32_t tot[8];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const unsigned long long t = (acc >> (4 * jj)) & 0x000F000F000F000Full;
+            tot[2 * jj] = wave_sum((uint32_t)t); tot[2 * jj + 1] = wave_sum((uint32_t)(t >> 32));
+        }
+        const uint32_t dw = (lane & 3u) * 2u + (lane >> 3);   // class = lane: word lane & 3, field lane >> 2
+        uint32_t pick = tot[0];
+#pragma unroll
+        for (int x = 1; x < 8; ++x) pick = dw == (uint32_t)x ? tot[x] : pick;
+        const uint32_t mycnt = lane < 16u ? (pick >> (16u * ((lane >> 2) & 1u))) & 0xFFFFu : 0u;
+        if (mycnt) atomicAdd(&cls[lane], mycnt);
+    }
+    __syncthreads();
+    uint32_t nstar, rstar;
+    {   // lane v holds class v: suffix sums from the best class down; the boundary class is the highest one whose suffix reaches k
+        const uint32_t cv = lane < 16u ? cls[lane] : 0u; const uint32_t pre = wave_incl_scan(cv);
+        const uint32_t suf = (uint32_t)__builtin_amdgcn_readlane((int)pre, 63) - pre + cv;
+        const unsigned long long reach = __ballot(suf >= k);
+        nstar = 63u - (uint32_t)__clzll((long long)reach);
+        rstar = k - ((uint32_t)__builtin_amdgcn_readlane((int)suf, (int)nstar) - (uint32_t)__builtin_amdgcn_readlane((int)cv, (int)nstar));
+    }
+    uint32_t mine = 0;
+#pragma unroll
+    for (int x = 0; x < G; ++x) mine += ((inm >> x) & 1u) && (uint32_t)((nmp >> (4 * x)) & 15ull) == nstar;
+    uint32_t tot_star;
+    uint32_t before = block_excl_scan<BLOCK>(mine, misc + FS_SCAN_B, tot_star);
+    uint32_t sel = 0, tmask = 0;
+#pragma unroll
+    for (int x = 0; x < G; ++x) {
+        const bool in = (inm >> x) & 1u; const uint32_t c = (uint32_t)((nmp >> (4 * x)) & 15ull);
+        const bool eq = in && c == nstar, take = in && (c > nstar || (eq && before < rstar));
+        tmask |= take ? 1u << x : 0u; sel += take; before += eq;
+    }
+    const uint32_t inc = wave_incl_scan(sel);
+    uint32_t base = 0; if (lane == 63u && inc) base = atomicAdd(&misc[FS_NB], inc);
+    uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)base, 63) + inc - sel;
+#pragma unroll
+    for (int x = 0; x < G; ++x) if ((tmask >> x) & 1u) nbl[at++] = fv[x];
+    return 0xFFFFFFFFu;   // (K = misc[FS_NB] after the caller's barrier)
+}
+
 // FRAG (an item shard in lists mode): the row slots are 16-byte FRAGMENT slots -- halfword 0 = length, halfwords 2..7 = items 0..5; fragments of > 6 items:
 // halfwords 2..5 = items 0..3, word 3 = the fragment's first overflow block (8 items each, items 4..) -- see rows_to_packed_frag_kernel; the general slots the
 // hits are resolved from are the 16-byte fragments of DeviceIndex::row_frag.
@@ -347,6 +447,13 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
                              merge_pair(B1, B0, 0u, s2, kp[2] + kp[3], tid, merge_team(n)); __syncthreads(); }
         FAST_TICK(3);
         const uint32_t* F = B0; uint32_t* D = B1;
+        // ---- the two cuts in one pass over the merged run (fast_cut above) where a thread's chunk is <= 6 entries (n <= 3072: four queries in five); the two-pass form below otherwise ----
+        if (SRN_FAST_FUSED_CUT && n <= 6u * BLOCK) {   // (block-uniform)
+            const uint32_t kc = fast_cut<6>(F, nbl, n, NB, p.m, p.k, wlut, misc, tid, lane);
+            __syncthreads();
+            K = kc != 0xFFFFFFFFu ? kc : misc[FS_NB];
+            FAST_TICK(2);
+        } else {
         // ---- m-cut: the copies of a session are adjacent in F; the first m distinct sessions, position sets OR-ed ----
         uint32_t Call, Cm;
         {
@@ -440,6 +547,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             for (int x = 0; x < 5; ++x) if (take[x]) nbl[at++] = dv[x];
             __syncthreads();
             K = misc[FS_NB];
+        }
         }
         }
 
@@ -604,15 +712,32 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             const double inv = ((const double*)(smem + F_SINV))[min(lane, 8u)];
             const uint32_t my_floor = (uint32_t)fmin(4.0e9, fmax(1.0, floor(x_lo * inv * (1.0 - 1e-9)) - 1.0));
             floor_b = (uint32_t)__builtin_amdgcn_readlane((int)my_floor, 8);
+            // The other direct-mapped words, four per thread and read: a thread's quad lies inside one chunk of 512 words and a wave's quads inside one chunk too
+            // (quad u = 128 + tid: chunk 1 + wave / 2; quad 640 + tid: chunk 5 + wave / 2), so the chunk's floor is wave-uniform and the usual case -- no word of the
+            // quad at its floor (1.1 survivors per query on config 3) -- costs one 16-byte read, three v_max and one compare per four items.
+            {
+                const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+                const uint4* h4 = reinterpret_cast<const uint4*>(hot);
+                static_assert(F_HOT_WORDS == 4096, "quads per thread below");
+                constexpr uint32_t NQ2 = F_HOT_WORDS / 4u - 128u - (uint32_t)BLOCK;   // quads of the second round (384 for 4096 words)
+                const uint4 a4 = h4[128u + tid];
+                const uint4 b4 = tid < NQ2 ? h4[128u + (uint32_t)BLOCK + tid] : make_uint4(0u, 0u, 0u, 0u);
+                if (tid == NQ2 - 1u) hot[F_HOT_WORDS - 1u] = 0u;   // (the word walk B reads for every popular item: a replica word, summed by the sample above before the barrier)
+                const uint32_t fl1 = (uint32_t)__builtin_amdgcn_readlane((int)my_floor, (int)(1u + (wv >> 1)));          // floors of this wave's two chunks (lane c of my_floor = chunk c)
+                const uint32_t fl2 = (uint32_t)__builtin_amdgcn_readlane((int)my_floor, (int)min(5u + (wv >> 1), 7u));
+                auto quad = [&](const uint4& q4, uint32_t e0, uint32_t fl) {
+                    const uint32_t mx = max(max(q4.x, q4.y), max(q4.z, q4.w));
+                    if (__ballot(mx >= fl) == 0ull) return;
+                    const uint32_t vv[4] = {q4.x, q4.y, q4.z, q4.w};
 #pragma unroll
-            for (int c = 1; c < (int)(F_HOT_WORDS / BLOCK); ++c) {   // the other direct-mapped words: survivors of the chunk's floor are compacted, scored below
-                const uint32_t fl = (uint32_t)__builtin_amdgcn_readlane((int)my_floor, c);
-                const uint32_t e2 = (uint32_t)c * BLOCK + tid;
-                const uint32_t v2 = hot[e2];
-                if (e2 == F_HOT_WORDS - 1u) hot[e2] = 0u;   // (the word walk B reads for every popular item)
-                const bool pass = v2 >= fl && e2 != cur_idx && e2 < F_DIRECT;   // (the words from F_DIRECT up are the replicas of the hottest items, already in the sample)
-                const uint32_t at2 = wave_append(pass, &misc[FS_SURV]);
-                if (pass) { if (at2 < SURV_CAP) surv[at2] = (e2 << 20) | v2; else atomicOr(&misc[FS_FAIL], 2u); }
+                    for (uint32_t j = 0; j < 4u; ++j) {
+                        const uint32_t e2 = e0 + j;
+                        const bool pass = vv[j] >= fl && e2 != cur_idx && e2 < F_DIRECT;   // (the words from F_DIRECT up are the replicas of the hottest items, already in the sample)
+                        const uint32_t at2 = wave_append(pass, &misc[FS_SURV]);
+                        if (pass) { if (at2 < SURV_CAP) surv[at2] = (e2 << 20) | vv[j]; else atomicOr(&misc[FS_FAIL], 2u); }
+                    } };
+                quad(a4, 512u + 4u * tid, fl1);
+                quad(b4, 512u + 4u * ((uint32_t)BLOCK + tid), fl2);
             }
         }
         __syncthreads();
