@@ -323,6 +323,7 @@ typedef struct {
     uint32_t transport;                                            /* 0 in-process, 1 RCCL, 2 application callbacks */
     uint32_t overlapped;                                           /* the exchange phase runs on the group's own stream */
     uint64_t stage_batches, bytes_stage_candidates, bytes_stage_minpos; /* batches that took the three-stage pipeline, and what this rank contributed to its two big exchanges */
+    uint64_t neighbour_batches, bytes_neighbours;                      /* batches that took the neighbours pipeline, and the neighbour-list block this rank contributed to its all-gather */
 } srn_shard_group_stats_t;
 int srn_shard_group_stats(const srn_shard_group_t* g, srn_shard_group_stats_t* out);
 /* Overlap of batch i + 1's exchange (the group's own stream and first communicator) with batch i's kernels and result gather (caller's stream, second communicator).
@@ -332,6 +333,16 @@ int srn_shard_group_stats(const srn_shard_group_t* g, srn_shard_group_stats_t* o
  * same setting for the same batch.  A failed srn_shard_group_predict_batch leaves the peers' collectives of that batch without their partner: the group is then unusable
  * on every rank (free it and create a new one). */
 int srn_shard_group_set_overlap(srn_shard_group_t* g, int on);
+/* The NEIGHBOURS pipeline (round 4; SURVEY 8(e)'s replicated-postings variant, with the candidate work divided over the ranks).  The posting lists are the pruned structure
+ * (<= m_index entries per item: config 3 111 MB, config 5 ~9 GB) -- every rank keeps ALL of them beside its shard of the rows: `postings` = the unsharded index itself, or
+ * its rows-free view (srn_index_postings_view: dictionary, idf / attributes, lists), on the group's device.  Per batch, rank r then runs find_neighbors
+ * (vmis_index.rs:325-415: lists, merge, m-cut, k-cut) for the queries [r nq / G, (r + 1) nq / G) ONLY, one all-gather ships the neighbour lists ((k + 1) * 4 bytes per
+ * query, fixed-size blocks: no host synchronisation), and every rank scores ALL queries over its own row fragments (mod.rs:126-214) before the usual all-gather of the
+ * per-shard top-n and the merge.  Same integers as the unsharded index on every rank: bit-identical results.  Serves what the lists pipeline serves and the fast kernel's
+ * shape (k <= 1536, m <= 2560, how_many <= 24, no debug outputs); other batches take the lists / three-stage pipelines as before.  postings = NULL switches it off.
+ * Every rank must make the same call; the handle must outlive the group. */
+int srn_shard_group_set_postings(srn_shard_group_t* g, const srn_index_t* postings);
+int srn_index_postings_view(const srn_index_t* full, int device, srn_index_t** out);
 void srn_shard_group_free(srn_shard_group_t* g);
 
 /* The same for the most recent min(max_n, 64) predict calls (oldest first): per-call duration in ms of

@@ -34,7 +34,7 @@ class IndexInfo(C.Structure):
 
 class ShardGroupStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_shards", "batches", "queries", "bytes_head", "bytes_counts", "bytes_lists", "bytes_results", "bytes_lists_max_rank")] + \
-               [("transport", C.c_uint32), ("overlapped", C.c_uint32)] + [(n, C.c_uint64) for n in ("stage_batches", "bytes_stage_candidates", "bytes_stage_minpos")]
+               [("transport", C.c_uint32), ("overlapped", C.c_uint32)] + [(n, C.c_uint64) for n in ("stage_batches", "bytes_stage_candidates", "bytes_stage_minpos", "neighbour_batches", "bytes_neighbours")]
 
 
 # srn_shard_comm_t: the application's transport for a shard group (three collectives on device buffers)
@@ -115,6 +115,8 @@ SYMBOLS = {
     "srn_shard_group_predict_batch": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, C.c_uint, _vp, _vp, _vp, _vp]),
     "srn_shard_group_stats": (_i, [_vp, _vp]),
     "srn_shard_group_set_overlap": (_i, [_vp, _i]),
+    "srn_shard_group_set_postings": (_i, [_vp, _vp]),
+    "srn_index_postings_view": (_i, [_vp, _i, C.POINTER(_vp)]),
     "srn_shard_group_free": (None, [_vp]),
     "srn_kernel_timing": (_i, [_vp, C.c_int]),
     "srn_kernel_times": (_i, [_vp, C.c_uint32, _vp, _vp, C.POINTER(C.c_uint32)]),

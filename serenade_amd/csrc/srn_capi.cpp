@@ -20,6 +20,7 @@ template <typename F> int guarded(F f) {   // never let an exception cross the C
 int check_predict_args(const srn_index_t* idx, size_t k, size_t m, size_t how_many) {
     if (!idx) return fail(SRN_EINVAL, "null index");
     if (!idx->dev) return fail(SRN_ENODEV, "index has no device attached; there is no CPU fallback behind this ABI");
+    if (idx->flat.postings_only) return fail(SRN_EINVAL, "a postings-only view holds no rows: it serves a shard group (srn_shard_group_set_postings), not predict calls");
     // the reference panics (peek_mut().unwrap() on an empty heap) when any of these is zero
     if (k == 0 || m == 0 || how_many == 0) return fail(SRN_EINVAL, "k, m and how_many must be > 0");
     if (how_many > SRN_MAX_HOW_MANY) return fail(SRN_ERANGE, "how_many above SRN_MAX_HOW_MANY");
@@ -288,6 +289,23 @@ int srn_index_shard(const srn_index_t* full, uint32_t shard, uint32_t n_shards, 
         int rc = shard_flat_index(full->flat, shard, n_shards, ix->flat);
         if (rc == SRN_OK && device >= 0) { ix->dev = device_attach(ix->flat, device); ix->device = device; if (!ix->dev) rc = SRN_EHIP; else ix->comb = combiner_create(); }
         if (rc) { delete ix; return rc; }
+        *out = ix; return SRN_OK; });
+}
+// The replicated part of an item-sharded index: the whole index's dictionary, idf / attributes and posting lists WITHOUT its rows (config 5: ~10 GB of the 66.6 GB)
+int srn_index_postings_view(const srn_index_t* full, int device, srn_index_t** out) {
+    return guarded([&]() -> int {
+        if (!full || !out) return fail(SRN_EINVAL, "null argument");
+        *out = nullptr;
+        if (full->flat.n_shards != 1) return fail(SRN_EINVAL, "the postings view is cut from an UNSHARDED index");
+        if (device < 0) return fail(SRN_ENODEV, "a postings view lives on a device");
+        srn_index* ix = new srn_index();
+        const FlatIndex& f = full->flat; FlatIndex& g = ix->flat;
+        g.n_items = f.n_items; g.n_sessions_total = f.n_sessions_total; g.n_kept = f.n_kept; g.nnz_rows = 0; g.nnz_post = f.nnz_post; g.m_index = f.m_index;
+        g.max_session_len = f.max_session_len; g.max_row_len = 0; g.idf_weighting = f.idf_weighting; g.lists_complete = f.lists_complete; g.postings_only = true;
+        g.total_pairs = f.total_pairs; g.item_id = f.item_id; g.id_rank = f.id_rank; g.idf = f.idf; g.attr = f.attr; g.post_off = f.post_off; g.post_rank = f.post_rank;
+        g.id_table = f.id_table; g.id_mask = f.id_mask;
+        ix->dev = device_attach(ix->flat, device); ix->device = device;
+        if (!ix->dev) { delete ix; return SRN_EHIP; }
         *out = ix; return SRN_OK; });
 }
 int srn_index_build_shard_gpu(const srn_sessions_view_t* sessions, size_t m_index, size_t max_session_len, double idf_weighting,

@@ -288,7 +288,12 @@ __device__ __forceinline__ uint32_t fast_cut(const uint32_t* F, uint32_t* nbl, u
 // halfwords 2..5 = items 0..3, word 3 = the fragment's first overflow block (8 items each, items 4..) -- see rows_to_packed_frag_kernel; the general slots the
 // hits are resolved from are the 16-byte fragments of DeviceIndex::row_frag.
 // WIDE (an index of > 2^28 sessions): 29 rank bits + 3 list bits per slot, see NB in the kernel.
-template <int WG_PER_CU, bool FRAG, bool WIDE>
+// MODE (round 4, the item-sharded index with replicated postings -- srn_group.hip, the neighbours pipeline): FM_FUSED = the whole query; FM_FRONT = find_neighbors only
+// (vmis_index.rs:325-415: lists -> merge tree -> cuts), the neighbour list goes to an exchange buffer -- K, then K packed slots -- instead of into the walks, for the
+// queries [f.q_base, p.nq) this rank fronts; FM_BACK = predict's scoring (mod.rs:126-214) from a neighbour list found by ANY rank: the list is read from the exchange
+// buffer, the weight table rebuilt from the query's own prep record (same record on every rank: same table), then the fused kernel's walks unchanged.
+enum { FM_FUSED = 0, FM_FRONT = 1, FM_BACK = 2 };
+template <int WG_PER_CU, bool FRAG, bool WIDE, int MODE = FM_FUSED>
 #ifndef SRN_FAST_WAVES
 #define SRN_FAST_WAVES (WG_PER_CU * 2)
 #endif
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
     { const ItemMeta m0 = f.meta_sample[tid];
       ((double*)(smem + F_SIDF))[tid] = m0.idf > 0.0 ? m0.idf : 1.0; ((uint8_t*)(smem + F_SATTR))[tid] = (uint8_t)m0.attr;   // (own slot only: no barrier)
       if (tid < 16u) ((double*)(smem + F_SINV))[tid] = tid < 8u ? f.inv_idf_hot[tid] : f.inv_idf_hi; }   // (read in phase 4a: barriers in between)
-    for (uint32_t q = blockIdx.x; q < p.nq; q += gridDim.x) {
+    for (uint32_t q = (MODE == FM_FRONT ? f.q_base : 0u) + blockIdx.x; q < p.nq; q += gridDim.x) {
         long long t_prev = ticking ? clock64() : 0;
         // ---- phase 0: the query's prep record -> run descriptors in SGPRs ------------------------------
         const char* const rec = p.prep + (size_t)q * p.prep_stride;
@@ -370,11 +375,13 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         const bool rel = WIDE && nr > 3u;   // (block-uniform)
         const uint32_t NB = WIDE && !rel ? 3u : 4u, NBM = (1u << NB) - 1u, base = rel ? hd.xlo : 0u;
         const bool fits = L >= 1u && L <= 8u && L <= p.max_len && hd.sumw <= 15u && nr <= 4u && 2u * n + 8u <= F_MERGE_WORDS && (!rel || hd.rmax - hd.xlo < (1u << 28));
+        uint32_t* const xq = MODE == FM_FUSED ? nullptr : f.xchg + (size_t)q * f.xchg_stride;   // this query's place in the exchange buffer: K | K slots
         if (!fits) {   // block-uniform: the general kernel takes it
-            if (tid == 0) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q;
+            if constexpr (MODE == FM_FRONT) { if (tid == 0) xq[0] = 0xFFFFFFFFu; }   // (every rank's back end reads the marker and hands the query to its general kernel)
+            else if (tid == 0) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q;
             continue;
         }
-        if (n == 0u) { if (tid == 0) p.out_counts[q] = 0u; continue; }   // no known item (vmis_index.rs:350): empty result
+        if (n == 0u) { if (tid == 0) { if constexpr (MODE == FM_FRONT) xq[0] = 0u; else p.out_counts[q] = 0u; } continue; }   // no known item (vmis_index.rs:350): empty result
         uint32_t kp[4], ps[4]; const uint32_t* src[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -392,17 +399,23 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         // The stage loads go out BEFORE the barrier that ends the previous query: waves 1..7 get here while wave 0 still ranks that
         // query's candidates, and their share of the posting lists is in flight meanwhile.
         uint32_t v[4][5];   // every load of every list in flight at once (uniform skips; past a list's end the lanes re-read its last entry)
+        uint32_t K = 0;
+        if constexpr (MODE == FM_BACK) K = (uint32_t)__builtin_amdgcn_readfirstlane((int)xq[0]);   // (uniform address; requested before the barrier like the lists of the fused form)
+        else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int j = 0; j < 5; ++j) { v[r][j] = 0u; if ((uint32_t)j * BLOCK < kp[r]) v[r][j] = src[r][min(tid + j * BLOCK, kp[r] - 1u)]; }
+        }
         __syncthreads();   // previous query's LDS reads are done
         // (opaque copies: with a compile-time shift the packing of a staged entry is otherwise hoisted into the conditional block of its load, which then
         //  ends in s_waitcnt vmcnt(0) -- the lists' loads would go out one HBM round trip after the other instead of all together)
+        if constexpr (MODE != FM_BACK) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int j = 0; j < 5; ++j) asm volatile("" : "+v"(v[r][j]));
+        }
         FAST_TICK(0);
         if (tid < (uint32_t)FS_TACC) misc[tid] = 0;
         // A slot's low bits are the set of RUNS (not evolving positions) that hold the session: <= 4 runs, so 4 bits (3 above 2^28 sessions, see NB above) whatever the
@@ -413,7 +426,10 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             const uint32_t mp = lo == 0u ? ps[0] : lo == 1u ? ps[1] : lo == 2u ? ps[2] : ps[3];
             wlut[tid] = (uint8_t)num; w10t[tid] = (uint16_t)((9u - mp) * num);
         }
-        uint32_t K;
+        if constexpr (MODE == FM_BACK) {
+            if (K == 0xFFFFFFFFu) { if (tid == 0) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q; continue; }   // (the fronting rank could not take it: block-uniform)
+            if (K == 0u) { if (tid == 0) p.out_counts[q] = 0u; continue; }
+        } else
         if (nr == 1u) {
             // ONE list (a quarter of the queries): its entries are distinct sessions in recency order, all of one numerator class -- the candidates are
             // its first min(n, m) entries, the neighbours the first k of those.  No merge, no m-cut, no k-cut: the list goes straight into the neighbour list.
@@ -552,12 +568,20 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         }
 
         FAST_TICK(4);
+        if constexpr (MODE == FM_FRONT) {   // the neighbour list leaves for the exchange buffer (a barrier stands between its last write and here in every branch above)
+            if (tid == 0) xq[0] = K;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { const uint32_t e = tid + (uint32_t)j * BLOCK; if ((uint32_t)j * BLOCK < K && e < K) xq[1u + e] = nbl[e]; }
+            continue;
+        }
 
         // ---- walk A: one neighbour row per lane; the first 16 bytes (6 items) of all the wave's rows requested at once, the next 16 only where a row has them ----
         uint32_t svr[3]; uint4 rq[3], rq1[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const uint32_t j = wave * 64u + lane + (uint32_t)t * BLOCK;
+            if constexpr (MODE == FM_BACK) svr[t] = xq[1u + min(j, K - 1u)];   // (K >= 1 here)
+            else
             svr[t] = K ? nbl[min(j, K - 1u)] : 0u;   // (all loads unconditional: a load inside a branch is waited for at the branch's end)
             const size_t r = K ? (size_t)(base + (svr[t] >> NB)) : (size_t)n_kept;   // (idle lanes re-read the last neighbour's row)
             rq[t] = *reinterpret_cast<const uint4*>(&f.row_packed[r * (FRAG ? 1 : 4)]); rq1[t] = make_uint4(0u, 0u, 0u, 0u);
@@ -1133,9 +1157,15 @@ hipError_t launch_finish(hipStream_t st, const DeviceIndex& di, const FastParams
     return hipGetLastError();
 }
 
-hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f, bool debug) {
-    auto kern = f.nb == 3u ? (di.row_frag ? vmis_fast_kernel<(int)F_WG_PER_CU, true, true> : vmis_fast_kernel<(int)F_WG_PER_CU, false, true>)
-                           : (di.row_frag ? vmis_fast_kernel<(int)F_WG_PER_CU, true, false> : vmis_fast_kernel<(int)F_WG_PER_CU, false, false>);
+hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f, bool debug, int mode) {
+    constexpr int W = (int)F_WG_PER_CU;
+    const bool wide = f.nb == 3u, frag = di.row_frag != 0u;
+    void (*kern)(DeviceIndex, LaunchParams, FastParams) =
+        mode == FM_FRONT ? (wide ? vmis_fast_kernel<W, false, true, FM_FRONT> : vmis_fast_kernel<W, false, false, FM_FRONT>)
+        : mode == FM_BACK ? (wide ? (frag ? vmis_fast_kernel<W, true, true, FM_BACK> : vmis_fast_kernel<W, false, true, FM_BACK>)
+                                  : (frag ? vmis_fast_kernel<W, true, false, FM_BACK> : vmis_fast_kernel<W, false, false, FM_BACK>))
+                          : (wide ? (frag ? vmis_fast_kernel<W, true, true> : vmis_fast_kernel<W, false, true>)
+                                  : (frag ? vmis_fast_kernel<W, true, false> : vmis_fast_kernel<W, false, false>));
     constexpr size_t dyn = SRN_FAST_SMALL ? 0 : F_TOTAL;
     if (dyn) { hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); if (e != hipSuccess) return e; }
     static bool told = false;

@@ -99,6 +99,8 @@ struct Slot {   // everything one batch in flight needs (grow-only); two slots: 
     // three-stage pipeline: [G] candidate blocks + [G][nq] counts, the neighbour list, first-match positions (+ one scratch copy for an in-process group), overflow flags
     char* cand = nullptr; size_t cand_bytes = 0; char* cand_cnt = nullptr; size_t cand_cnt_bytes = 0;
     char* nb = nullptr; size_t nb_bytes = 0; char* nb_cnt = nullptr; size_t nb_cnt_bytes = 0; char* minpos = nullptr; size_t minpos_bytes = 0; char* flagq = nullptr; size_t flagq_bytes = 0;
+    // neighbours pipeline: [G * per][k + 1] words (a query's row: K | K packed slots), and every local shard's prep records of the whole batch
+    char* xchg = nullptr; size_t xchg_bytes = 0; std::vector<char*> nrec; std::vector<size_t> nrec_bytes;
     hipEvent_t e_done = nullptr;
 };
 }  // namespace
@@ -115,9 +117,11 @@ struct srn_shard_group {
     srn_shard_comm_t cb{};
     hipStream_t s_x = nullptr; hipEvent_t e_in = nullptr, e_x = nullptr;
     bool overlap = true, no_direct = false;
+    const srn_index* postings = nullptr;   // the replicated posting lists (srn_shard_group_set_postings): batches of the fast kernel's shape take the neighbours pipeline
     Slot slot[2];
     uint64_t calls = 0;
     uint64_t st_queries = 0, st_bytes_head = 0, st_bytes_kept = 0, st_bytes_lists = 0, st_bytes_results = 0, st_lists_max = 0;
+    uint64_t st_nb_batches = 0, st_bytes_nb = 0;
     uint64_t st_stage_batches = 0, st_bytes_stage_cand = 0, st_bytes_stage_minpos = 0;   // batches that took the three-stage pipeline
     std::mutex mu;   // one batch is issued at a time per group (the collectives must be issued in the same order on every rank anyway)
 };
@@ -160,6 +164,8 @@ int all_gather_v(srn_shard_group* g, int channel, char* buf, const unsigned long
 
 void slot_free(Slot& s) {
     for (char* p : s.pos) if (p) hipFree(p);
+    for (char* p : s.nrec) if (p) hipFree(p);
+    if (s.xchg) hipFree(s.xchg);
     for (char* p : {s.head, s.kept, s.tot, s.off, s.small, s.lists, s.records, s.part, s.cand, s.cand_cnt, s.nb, s.nb_cnt, s.minpos, s.flagq}) if (p) hipFree(p);
     if (s.tot_host) hipHostFree(s.tot_host);
     if (s.e_done) hipEventDestroy(s.e_done);
@@ -176,6 +182,7 @@ int group_init_common(srn_shard_group* g) {
         HIP_TRY(hipEventCreateWithFlags(&s.e_done, hipEventDisableTiming));
         HIP_TRY(hipHostMalloc((void**)&s.tot_host, (size_t)G * 16, hipHostMallocMapped));
         s.pos.assign(g->shards.size(), nullptr); s.pos_bytes.assign(g->shards.size(), 0);
+        s.nrec.assign(g->shards.size(), nullptr); s.nrec_bytes.assign(g->shards.size(), 0);
     }
     if (const char* e = getenv("SRN_GROUP_OVERLAP")) g->overlap = atoi(e) != 0;
     g->no_direct = getenv("SRN_GROUP_NO_DIRECT") != nullptr;
@@ -260,6 +267,60 @@ int group_predict_stages(srn_shard_group* g, const LaunchParams& p, uint64_t* d_
     return SRN_OK;
 }
 
+// The NEIGHBOURS pipeline (round 4): posting lists replicated (g->postings), rows sharded.  Rank r fronts the queries [r per, (r + 1) per): prep records against the
+// replicated lists, the fast kernel's front end (lists -> merge tree -> cuts) -> neighbour lists in its block of the exchange buffer; ONE all-gather of fixed-size blocks
+// (no host synchronisation anywhere in the batch); then every rank runs the fast kernel's back end (walks, thresholds) over ALL queries on its own row fragments, the
+// general kernel behind it for the few queries no front end could take (marker in the exchange row: every rank then does that query's candidate work itself, against the
+// replicated lists), the finish kernels, and the usual all-gather + merge of the per-shard top-n.  The candidate work of a batch is done ONCE per group, not once per rank.
+int group_predict_neighbours(srn_shard_group* g, const LaunchParams& p_in, bool resident, uint64_t* d_out_ids, double* d_out_scores, uint32_t* d_out_counts, hipStream_t user) {
+    const uint32_t G = G_of(g), nq = p_in.nq, n = p_in.how_many;
+    const bool local = g->kind == srn_shard_group::LOCAL;
+    LaunchParams p = p_in; p.out_ids = nullptr; p.out_scores = nullptr; p.out_counts = nullptr;
+    Slot& s = g->slot[g->calls & 1u];
+    const bool overlap = g->overlap && !local;
+    hipStream_t sx = overlap ? g->s_x : user;
+    const uint32_t rec_stride = device_prep_stride(p.max_len), xstride = p.k + 1u, per = (nq + G - 1) / G;
+    const size_t block_bytes = ((size_t)nq * n * 16 + (size_t)nq * 4 + 255) / 256 * 256, xblock = (size_t)per * xstride * 4;
+    {
+        int rc = ensure(&s.xchg, &s.xchg_bytes, (size_t)G * xblock);
+        for (size_t i = 0; i < g->shards.size() && !rc; ++i) rc = ensure(&s.nrec[i], &s.nrec_bytes[i], (size_t)nq * rec_stride);
+        if (!rc) rc = ensure(&s.part, &s.part_bytes, (size_t)G * block_bytes);
+        if (rc) return rc;
+    }
+    if (overlap) {
+        if (!resident) { HIP_TRY(hipEventRecord(g->e_in, user)); HIP_TRY(hipStreamWaitEvent(sx, g->e_in, 0)); }
+        if (g->calls >= 2) HIP_TRY(hipStreamWaitEvent(sx, s.e_done, 0));
+    }
+    if (g->calls >= 2) HIP_TRY(hipStreamWaitEvent(user, s.e_done, 0));
+    DeviceState* post = g->postings->dev;
+    for (size_t i = 0; i < g->shards.size(); ++i) {
+        const uint32_t gi = local ? (uint32_t)i : (uint32_t)g->rank;
+        int rc = device_shard_nb_prep(g->shards[i]->dev, post, p, s.nrec[i], sx); if (rc) return rc;
+        const uint32_t q_lo = std::min<uint64_t>(nq, (uint64_t)gi * per), q_hi = std::min<uint64_t>(nq, (uint64_t)q_lo + per);
+        rc = device_shard_nb_front(g->shards[i]->dev, g->shards[i]->flat, post, p, s.nrec[i], (uint32_t*)s.xchg, xstride, q_lo, q_hi, sx); if (rc) return rc;
+    }
+    { int rc = all_gather_blocks(g, 0, s.xchg, xblock, sx); if (rc) return rc; }
+    if (overlap) { HIP_TRY(hipEventRecord(g->e_x, sx)); HIP_TRY(hipStreamWaitEvent(user, g->e_x, 0)); }
+    for (size_t i = 0; i < g->shards.size(); ++i) {
+        const uint32_t gi = local ? (uint32_t)i : (uint32_t)g->rank;
+        char* blk = s.part + (size_t)gi * block_bytes;
+        LaunchParams pi = p;
+        const bool direct = G == 1;   // one shard: its top-n IS the result
+        pi.out_ids = direct ? d_out_ids : (uint64_t*)blk; pi.out_scores = direct ? d_out_scores : (double*)(blk + (size_t)nq * n * 8); pi.out_counts = direct ? d_out_counts : (uint32_t*)(blk + (size_t)nq * n * 16);
+        HIP_TRY(hipMemsetAsync(pi.out_ids, 0, (size_t)nq * n * 8, user)); HIP_TRY(hipMemsetAsync(pi.out_scores, 0, (size_t)nq * n * 8, user));
+        int rc = device_shard_nb_back(g->shards[i]->dev, g->shards[i]->flat, post, pi, s.nrec[i], (uint32_t*)s.xchg, xstride, user); if (rc) return rc;
+    }
+    if (G > 1) {
+        int rc = all_gather_blocks(g, 1, s.part, block_bytes, user); if (rc) return rc;
+        HIP_TRY(launch_shard_merge_topn(user, s.part, block_bytes, G, nq, n, d_out_ids, d_out_scores, d_out_counts));
+    }
+    HIP_TRY(hipEventRecord(s.e_done, user));
+    ++g->calls;
+    g->st_queries += nq; ++g->st_nb_batches; g->st_bytes_nb += G > 1 ? (uint64_t)xblock * (local ? G : 1) : 0;
+    g->st_bytes_results += G > 1 ? (uint64_t)block_bytes * (local ? G : 1) : 0;
+    return SRN_OK;
+}
+
 int group_predict(srn_shard_group* g, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq_, size_t max_len_hint, size_t k, size_t m, size_t how_many,
                   unsigned flags, uint64_t* d_out_ids, double* d_out_scores, uint32_t* d_out_counts, hipStream_t user) {
     std::lock_guard<std::mutex> lk(g->mu);
@@ -273,6 +334,11 @@ int group_predict(srn_shard_group* g, const uint64_t* d_items_flat, const uint32
     p.out_ids = d_out_ids; p.out_scores = d_out_scores; p.out_counts = d_out_counts;
     for (const srn_index* ix : g->shards)
         if (!device_shard_lists_supported(ix->dev, ix->flat, p)) return group_predict_stages(g, p, d_out_ids, d_out_scores, d_out_counts, user);   // (every rank holds the same index parameters: the same choice everywhere)
+    if (g->postings) {   // (the same index parameters and the same batch shape on every rank: the same choice everywhere)
+        bool all = true;
+        for (const srn_index* ix : g->shards) all = all && device_fast_eligible(ix->dev, ix->flat, p);
+        if (all) return group_predict_neighbours(g, p, resident, d_out_ids, d_out_scores, d_out_counts, user);
+    }
     p.out_ids = nullptr; p.out_scores = nullptr; p.out_counts = nullptr;
     Slot& s = g->slot[g->calls & 1u];
     const bool overlap = g->overlap && !local;
@@ -447,6 +513,23 @@ int srn_shard_group_predict_batch(srn_shard_group_t* g, const uint64_t* d_items_
         return group_predict(g, d_items_flat, d_q_off, nq, max_len_hint, k, m, how_many, flags, d_out_ids, d_out_scores, d_out_counts, (hipStream_t)stream); });
 }
 
+int srn_shard_group_set_postings(srn_shard_group_t* g, const srn_index_t* postings) {
+    if (!g) return fail(SRN_EINVAL, "null group");
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (postings) {
+        if (!postings->dev) return fail(SRN_ENODEV, "the postings index has no device attached");
+        if (postings->flat.n_shards != 1) return fail(SRN_EINVAL, "the replicated postings are those of the UNSHARDED index (the index itself, or srn_index_postings_view of it)");
+        if (postings->device != g->device) return fail(SRN_EINVAL, "the postings must live on the group's device");
+        for (const srn_index* sh : g->shards)
+            if (sh->flat.n_kept != postings->flat.n_kept || sh->flat.total_pairs != postings->flat.total_pairs || sh->flat.m_index != postings->flat.m_index ||
+                sh->flat.n_sessions_total != postings->flat.n_sessions_total)
+                return fail(SRN_EINVAL, "the postings index is not the index these shards were cut from (sessions / pairs / m_index differ)");
+        if (!postings->flat.lists_complete) return fail(SRN_EINVAL, "the neighbours pipeline needs complete posting lists");
+    }
+    g->postings = postings;
+    return SRN_OK;
+}
+
 int srn_shard_group_set_overlap(srn_shard_group_t* g, int on) {
     if (!g) return fail(SRN_EINVAL, "null group");
     std::lock_guard<std::mutex> lk(g->mu);   // (between batches: a batch in flight keeps the form it was issued in; the slots' events order the next one behind it either way)
@@ -458,7 +541,7 @@ int srn_shard_group_stats(const srn_shard_group_t* g, srn_shard_group_stats_t* o
     if (!g || !out) return fail(SRN_EINVAL, "null argument");
     *out = srn_shard_group_stats_t{(uint64_t)G_of(g), g->calls, g->st_queries, g->st_bytes_head, g->st_bytes_kept, g->st_bytes_lists, g->st_bytes_results, g->st_lists_max,
                                    g->kind == srn_shard_group::RCCL ? 1u : g->kind == srn_shard_group::CALLBACKS ? 2u : 0u, g->overlap && g->kind != srn_shard_group::LOCAL ? 1u : 0u,
-                                   g->st_stage_batches, g->st_bytes_stage_cand, g->st_bytes_stage_minpos};
+                                   g->st_stage_batches, g->st_bytes_stage_cand, g->st_bytes_stage_minpos, g->st_nb_batches, g->st_bytes_nb};
     return SRN_OK;
 }
 

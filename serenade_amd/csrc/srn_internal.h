@@ -45,6 +45,8 @@ struct FlatIndex {
     bool lists_complete = true;             // every posting list holds ALL sessions of its item that are at least as recent as its last entry (and is complete if
                                             // shorter than m_index): true for every index built here; a pre-built (Avro) index may not satisfy it -- then the
                                             // first-match position comes from the rows (the reference's contains() test), not from posting-list membership
+    bool postings_only = false;             // the REPLICATED part of an item-sharded index (srn_index_postings_view): dictionary, idf / attributes and posting lists of the whole index,
+                                            // no rows -- what every rank of a shard group keeps beside its shard for the neighbours pipeline; answers no predict call itself
     uint32_t shard = 0, n_shards = 1;       // item-sharded index: this shard holds the items with owner(id) == shard
     uint64_t total_pairs = 0;               // (session,item) pairs of ALL kept sessions = idf numerator (== nnz_rows when unsharded)
     std::vector<uint64_t> item_id;          // [n_items]   public id of each dense idx; idx = popularity order (count desc, id asc)
@@ -117,7 +119,9 @@ void device_refresh_fast_bounds(DeviceState* d, const FlatIndex& ix);   // idf b
 void reload_knobs();                                                     // re-read the SRN_* test / experiment knobs from the environment
 uint64_t device_bytes(const DeviceState* d);
 // item-sharded index, lists mode: prep records (PrepHead + max_len * PrepItem per query) written against a gathered posting buffer
-struct ExtLists { const char* prep; uint32_t prep_stride; const uint32_t* post_rank; };
+struct ExtLists { const char* prep; uint32_t prep_stride; const uint32_t* post_rank;
+                  // the shard group's neighbours pipeline: mode 1 = front end only (neighbour lists of the queries [q_lo, nq) -> xchg), 2 = back end (neighbour lists <- xchg)
+                  int mode = 0; uint32_t* xchg = nullptr; uint32_t xchg_stride = 0; uint32_t q_lo = 0; };
 int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p, bool buffers_on_device, void* stream,
                    // host-pointer mode: these are host buffers copied in/out by the call
                    const uint64_t* h_items, const uint32_t* h_qoff, uint64_t* h_ids, double* h_scores,
@@ -131,6 +135,12 @@ struct ShardIO {
 };
 
 bool device_shard_lists_supported(DeviceState* d, const FlatIndex& ix, const LaunchParams& p);
+bool device_fast_eligible(DeviceState* d, const FlatIndex& ix, const LaunchParams& p);
+// neighbours pipeline (replicated postings `post`: the whole index's dictionary + lists): prep records of ALL queries (lists looked up in `post`, dense idx in this shard's
+// table), then the front end over the queries [q_lo, q_hi) -> xchg, or the back end over all of them <- xchg
+int device_shard_nb_prep(DeviceState* d, DeviceState* post, const LaunchParams& p, char* records, void* stream);
+int device_shard_nb_front(DeviceState* d, const FlatIndex& ix, DeviceState* post, const LaunchParams& p, const char* records, uint32_t* xchg, uint32_t xchg_stride, uint32_t q_lo, uint32_t q_hi, void* stream);
+int device_shard_nb_back(DeviceState* d, const FlatIndex& ix, DeviceState* post, const LaunchParams& p, const char* records, uint32_t* xchg, uint32_t xchg_stride, void* stream);
 uint32_t device_prep_stride(uint32_t max_len);
 int device_shard_lists_head(DeviceState* d, const LaunchParams& p, void* pos, int* head, void* stream);
 int device_shard_lists_count(DeviceState* d, const LaunchParams& p, const void* pos, const int* head, uint32_t* kept, int* tot, void* stream);

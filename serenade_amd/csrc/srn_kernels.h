@@ -86,6 +86,9 @@ struct FastParams {
                                                                                                       // ticket = (list length << 32 | arena entries in use)
     uint32_t nb;                // low bits of a session slot that hold the set of runs (lists) with the session: 4, or 3 when the ranks need 29 bits
     uint32_t max_runs;          // = nb (a query with more lists than that takes 4 bits and ranks relative to its cut x_lo, if they fit 28 bits)
+    // neighbours pipeline of the shard group (launch_fast modes 1 and 2): [nq][xchg_stride] words, a query's row = K | K packed slots (K = 0xFFFFFFFF: not served by the
+    // front end -- the general kernel takes it on every rank); the front end works on the queries [q_base, p.nq)
+    uint32_t* xchg; uint32_t xchg_stride; uint32_t q_base;
 };
 
 // ---- launchers (srn_kernels.hip) -------------------------------------------------------------
@@ -95,7 +98,8 @@ hipError_t launch_predict(bool masks, bool slot64, bool global_tables, int stage
                           const LaunchParams& p, const KernelCfg& c, const uint32_t* qlist, const uint32_t* qn, uint32_t* retry_list,
                           uint32_t* retry_cnt, char* gscratch, unsigned long long gscratch_stride, char* nb_spill, const ShardIO& sh, int wg_per_cu = 2);
 hipError_t launch_prep(hipStream_t st, const DeviceIndex& di, const uint64_t* items_flat, const uint32_t* q_off, uint32_t nq, uint32_t m,
-                       uint32_t max_len, char* out, uint32_t stride, uint32_t* zero_a = nullptr, uint32_t* zero_b = nullptr);   // zero_a[0..3], zero_b[0]: counters cleared by the prep kernel
+                       uint32_t max_len, char* out, uint32_t stride, uint32_t* zero_a = nullptr, uint32_t* zero_b = nullptr,
+                       const IdSlot* loc_table = nullptr, uint32_t loc_mask = 0);   // zero_a[0..3], zero_b[0]: counters cleared by the prep kernel; loc_table: the item shard's id table (the record's idx), di = the whole index's dictionary and lists
 hipError_t launch_finish_big(hipStream_t st, const DeviceIndex& di, const FastParams& f, uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint32_t how_many, uint32_t grid, const uint32_t* cnt_retry = nullptr, const uint32_t* cnt_slow = nullptr, uint32_t* host_words = nullptr);
 hipError_t launch_finish(hipStream_t st, const DeviceIndex& di, const FastParams& f, uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint32_t nq, uint32_t how_many);   // scores, ranking, public ids of the rows the fast kernel served
 hipError_t launch_shard_lists_head(hipStream_t st, const DeviceIndex& di, const uint64_t* items_flat, const uint32_t* q_off, uint32_t nq, uint32_t m, uint32_t max_len,
@@ -116,7 +120,7 @@ hipError_t launch_shard_mark(hipStream_t st, const uint32_t* flag, uint32_t nq, 
 hipError_t launch_shard_fill_i32(hipStream_t st, int* dst, int v, size_t n);
 hipError_t launch_shard_merge_topn(hipStream_t st, const char* part, size_t block_bytes, uint32_t n_shards, uint32_t nq, uint32_t how_many, uint64_t* out_ids, double* out_scores,
                                    uint32_t* out_counts);
-hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f, bool debug = false);   // debug: say the occupancy once (the SRN_DEBUG knob, read by the runtime)
+hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f, bool debug = false, int mode = 0);   // debug: say the occupancy once (the SRN_DEBUG knob, read by the runtime); mode: 0 fused, 1 front end only (neighbour lists -> f.xchg), 2 back end only (neighbour lists <- f.xchg)
 hipError_t launch_rows_to_packed(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base,
                                  uint32_t* packed, uint32_t* ext16, bool frag = false);   // grid = ceil((n_rows + 1) / 1024) blocks of 1024; block_base in 16-byte blocks
 hipError_t launch_rows_to_frags(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base,

@@ -362,7 +362,11 @@ __global__ __launch_bounds__(1024) void rows_to_frags_kernel(const uint64_t* __r
 // -------------------------------------------------------------------------------------
 static constexpr uint32_t PREP_LANES = 8;
 __global__ __launch_bounds__(256) void vmis_prep_kernel(DeviceIndex ix, const uint64_t* __restrict__ items_flat, const uint32_t* __restrict__ q_off,
-                                                        uint32_t nq, uint32_t m, uint32_t max_len, char* out, uint32_t stride, uint32_t* zero_a, uint32_t* zero_b) {
+                                                        uint32_t nq, uint32_t m, uint32_t max_len, char* out, uint32_t stride, uint32_t* zero_a, uint32_t* zero_b,
+                                                        const IdSlot* __restrict__ loc_table, uint32_t loc_mask) {
+    // loc_table (the shard group's neighbours pipeline, srn_group.hip): `ix` is the REPLICATED dictionary + posting lists of the whole index, loc_table the id table of
+    // the item shard whose rows the record's consumer walks -- the lists are looked up in the first, the dense idx written to the record (what the kernels compare
+    // row items with: the current item) in the second.
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < 4 && zero_a) zero_a[t] = 0u;
     if (t == 4 && zero_b) *zero_b = 0u;
@@ -393,6 +397,11 @@ __global__ __launch_bounds__(256) void vmis_prep_kernel(DeviceIndex ix, const ui
                 if (len) { head_rank = ix.post_rank[o0]; if (len >= m) mth_rank = ix.post_rank[o0 + m - 1]; }
             }
             if (pos == 0 && idx != kNone) cur_attr = ix.meta[idx].attr;   // business rules look at the current item's attributes (mod.rs:162-182)
+            if (loc_table) {   // (after everything that needs the whole index's idx)
+                idx = kNone;
+                uint32_t hh = (uint32_t)dev_mix64(raw) & loc_mask;
+                for (;;) { const IdSlot s2 = loc_table[hh]; if (s2.idx == kNone) break; if (s2.key == raw) { idx = s2.idx; break; } hh = (hh + 1) & loc_mask; }
+            }
         }
         // 8-lane inclusive scans of len and of (len != 0); 8-lane totals
         uint32_t sc_len = len, sc_run = len ? 1u : 0u;
@@ -1603,10 +1612,10 @@ hipError_t launch_predict(bool masks, bool slot64, bool global_tables, int stage
 }
 
 hipError_t launch_prep(hipStream_t st, const DeviceIndex& di, const uint64_t* items_flat, const uint32_t* q_off, uint32_t nq, uint32_t m,
-                       uint32_t max_len, char* out, uint32_t stride, uint32_t* zero_a, uint32_t* zero_b) {
+                       uint32_t max_len, char* out, uint32_t stride, uint32_t* zero_a, uint32_t* zero_b, const IdSlot* loc_table, uint32_t loc_mask) {
     static_assert(sizeof(PrepHead) == 72 && sizeof(PrepItem) == 24, "vmis_prep_kernel writes the record word by word");
     const uint32_t per_block = 256 / PREP_LANES;
-    hipLaunchKernelGGL(vmis_prep_kernel, dim3((nq + per_block - 1) / per_block), dim3(256), 0, st, di, items_flat, q_off, nq, m, max_len, out, stride, zero_a, zero_b);
+    hipLaunchKernelGGL(vmis_prep_kernel, dim3((nq + per_block - 1) / per_block), dim3(256), 0, st, di, items_flat, q_off, nq, m, max_len, out, stride, zero_a, zero_b, loc_table, loc_mask);
     return hipGetLastError();
 }
 

@@ -67,7 +67,7 @@ DeviceState* device_attach(const FlatIndex& ix, int device) {
       for (uint32_t w8 = 0; w8 < 8; ++w8) for (uint32_t l = 0; l < 64; ++l) if (8 * l + w8 < ix.n_items) ms[64 * w8 + l] = meta[8 * l + w8];
       d->fast.meta_sample = upload(d, ms, ok); }
     d->di.post_off = upload(d, ix.post_off, ok); d->di.post_rank = upload(d, ix.post_rank, ok);
-    if (ok) {   // rows -> 64-byte slots (+ overflow area) on the device, see DeviceIndex and rows_to_slots_kernel
+    if (ok && !ix.postings_only) {   // rows -> 64-byte slots (+ overflow area) on the device, see DeviceIndex and rows_to_slots_kernel
         // item shards: 16-byte FRAGMENT slots (a shard holds ~1/n_shards of a row's items), DeviceIndex::row_frag
         const bool frag = ix.n_shards > 1;
         const uint64_t inl = frag ? 2 : 14;            // items inline in a slot that also carries an overflow offset
@@ -496,6 +496,21 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         { int rc = ensure(&w->big, &w->big_bytes, big_entries * 16 + (size_t)p.nq * 4 + 64); if (rc) return rc; }
     }
     if (reserve_only) return SRN_OK;   // (srn_index_reserve: the workspace is sized, nothing was enqueued)
+    if (ext && ext->mode == 1) {
+        // The shard group's neighbours pipeline, FRONT: find_neighbors alone for the queries [q_lo, nq) of the batch this rank fronts -- the fast kernel's front end against
+        // the replicated posting lists, neighbour lists into the exchange buffer.  Nothing else of the launch sequence runs (the back end of every rank follows the all-gather).
+        if (!fast) return fail(SRN_EINVAL, "the neighbours pipeline needs the fast kernel's query shape (device_fast_eligible)");
+        if (ext->prep_stride != prep_stride) return fail(SRN_EINVAL, "prep record stride mismatch");
+        if (ext->q_lo >= p.nq) return SRN_OK;
+        p.prep = ext->prep; p.prep_stride = prep_stride;
+        FastParams fp = d->fast; fp.nb = nb_fast; fp.max_runs = nb_fast; fp.slow_list = nullptr; fp.slow_cnt = nullptr; fp.fin = nullptr;
+        fp.xchg = ext->xchg; fp.xchg_stride = ext->xchg_stride; fp.q_base = ext->q_lo;
+        const uint64_t cnt = p.nq - ext->q_lo, res_wg = (uint64_t)d->n_cu * F_WG_PER_CU;
+        const uint32_t grid_front = (uint32_t)std::min<uint64_t>(cnt, std::min<uint64_t>(res_wg * 64, std::max<uint64_t>(res_wg * 16, cnt / 12)));
+        HIP_TRY(launch_fast(dim3(grid_front), st, di, p, fp, kn.debug, 1));
+        return SRN_OK;
+    }
+    if (ext && ext->mode == 2 && !fast) return fail(SRN_EINVAL, "the neighbours pipeline needs the fast kernel's query shape (device_fast_eligible)");
     // The prep kernel clears the launch sequence's counters where it runs on this stream ahead of everything that uses them (two fill kernels otherwise: 6 us each)
     const bool prep_clears = !ext && !resident;
     if ((may_overflow || dense) && !prep_clears) HIP_TRY(hipMemsetAsync(w->retry_cnt, 0, 4, st));
@@ -543,7 +558,10 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         const uint64_t big_entries = std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)p.nq * 16 + 4096);
         FastParams fp = d->fast; fp.slow_list = w->slow_list; fp.slow_cnt = w->slow_cnt; fp.nb = nb_fast; fp.max_runs = nb_fast; fp.fin = w->fin;
         fp.big_arena = w->big; fp.big_list = (uint32_t*)(w->big + big_entries * 16); fp.big_ticket = (unsigned long long*)(w->slow_cnt + 2); fp.big_cap_entries = (uint32_t)big_entries;
-        HIP_TRY(launch_fast(dim3(grid_f), st, di, p, fp, kn.debug));
+        fp.xchg = nullptr; fp.xchg_stride = 0; fp.q_base = 0;
+        const bool back = ext && ext->mode == 2;   // neighbour lists from the exchange buffer (any rank's front end), this shard's rows
+        if (back) { fp.xchg = ext->xchg; fp.xchg_stride = ext->xchg_stride; }
+        HIP_TRY(launch_fast(dim3(grid_f), st, di, p, fp, kn.debug, back ? 2 : 0));
         if (timed) HIP_TRY(hipEventRecord(ev[4], st));
         HIP_TRY(launch_predict(geo.masks, slot64, false, 0, dim3(grid), lds, st, di, p, c, w->slow_list, w->slow_cnt, w->retry_list, w->retry_cnt, nullptr, 0, spill, ShardIO{}));
         if (fork_retry) {   // the global-table pass beside the finish kernels (they touch disjoint rows: a finish kernel only completes rows flagged by the fast kernel)
@@ -639,6 +657,15 @@ bool device_shard_lists_supported(DeviceState* d, const FlatIndex& ix, const Lau
     Geometry g;
     return make_geometry(d, ix, p, 0, g) == SRN_OK && g.masks && (p.flags & ~(unsigned)SRN_FLAG_BUSINESS_LOGIC) == 0 && p.stats == nullptr && p.nb_rank == nullptr;
 }
+// the batch shape the fast kernel takes (the same test device_predict makes): what the shard group's neighbours pipeline needs on top of lists mode
+bool device_fast_eligible(DeviceState* d, const FlatIndex& ix, const LaunchParams& p) {
+    Geometry geo;
+    if (make_geometry(d, ix, p, 0, geo) != SRN_OK) return false;
+    const Knobs kn = knobs();
+    const int rank_bits_f = std::max(1, bits_host(ix.n_kept ? ix.n_kept - 1 : 0));
+    return d->fast.row_packed != nullptr && geo.masks && !geo.sketch_may_wrap && rank_bits_f <= 29 && kn.geometry_default() && !kn.no_fast && p.k <= F_K_MAX && p.m <= F_M_MAX &&
+           p.how_many <= 24 && (p.flags & ~(unsigned)SRN_FLAG_BUSINESS_LOGIC) == 0 && p.stats == nullptr && p.nb_rank == nullptr && p.max_len <= 8;
+}
 uint32_t device_prep_stride(uint32_t max_len) { return (uint32_t)(sizeof(PrepHead) + (size_t)max_len * sizeof(PrepItem)); }
 int device_shard_lists_head(DeviceState* d, const LaunchParams& p, void* pos, int* head, void* stream) {
     HIP_TRY(hipSetDevice(d->device));
@@ -668,6 +695,26 @@ int device_shard_lists_predict(DeviceState* d, const FlatIndex& ix, const Launch
     const uint32_t stride = device_prep_stride(p.max_len);
     HIP_TRY(launch_shard_prep((hipStream_t)stream, p.items_flat, p.q_off, p.nq, p.max_len, n_shards, kept_g, off_g, shard_stride, head, (const ShardPos*)pos_local, records, stride, shard_base, direct));
     ExtLists ext{records, stride, direct ? d->di.post_rank : lists_g};
+    return device_predict(d, ix, p, true, stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &ext);
+}
+
+// ---- item-sharded index, neighbours pipeline (round 4): the posting lists are replicated (`post` = the device state of the whole index or of its postings-only view),
+// the rows stay sharded.  The record of a query is the same on every rank except for the dense idx of its items (this shard's numbering).
+int device_shard_nb_prep(DeviceState* d, DeviceState* post, const LaunchParams& p, char* records, void* stream) {
+    HIP_TRY(hipSetDevice(d->device));
+    if (p.nq == 0) return SRN_OK;
+    HIP_TRY(launch_prep((hipStream_t)stream, post->di, p.items_flat, p.q_off, p.nq, p.m, p.max_len, records, device_prep_stride(p.max_len), nullptr, nullptr, d->di.id_table, d->di.id_mask));
+    return SRN_OK;
+}
+int device_shard_nb_front(DeviceState* d, const FlatIndex& ix, DeviceState* post, const LaunchParams& p_in, const char* records, uint32_t* xchg, uint32_t xchg_stride, uint32_t q_lo, uint32_t q_hi, void* stream) {
+    if (q_lo >= q_hi) return SRN_OK;
+    LaunchParams p = p_in; p.nq = q_hi;
+    ExtLists ext{records, device_prep_stride(p.max_len), post->di.post_rank, 1, xchg, xchg_stride, q_lo};
+    return device_predict(d, ix, p, true, stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &ext);
+}
+int device_shard_nb_back(DeviceState* d, const FlatIndex& ix, DeviceState* post, const LaunchParams& p, const char* records, uint32_t* xchg, uint32_t xchg_stride, void* stream) {
+    if (p.nq == 0) return SRN_OK;
+    ExtLists ext{records, device_prep_stride(p.max_len), post->di.post_rank, 2, xchg, xchg_stride, 0u};
     return device_predict(d, ix, p, true, stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &ext);
 }
 

@@ -91,6 +91,14 @@ class ShardedVMISIndex:
         return a.value, b.value
 
 
+def postings_view(full_index, device=0):
+    """srn_index_postings_view: the replicated part of an item-sharded index (dictionary, idf / attributes, posting lists of the WHOLE index, no rows)."""
+    from .vmisknn import VMISIndex
+    h = C.c_void_p()
+    capi.check(capi.lib().srn_index_postings_view(full_index._h, int(device), C.byref(h)))
+    return VMISIndex(h)
+
+
 class DistComm:
     """Collectives of the sharded pipeline over torch.distributed.  With backend "nccl" (RCCL) tensors stay on the GPU;
     with "gloo" (CPU tests) they are staged through host memory."""
@@ -507,6 +515,11 @@ class ShardGroup:
         capi.check(capi.lib().srn_shard_group_predict_batch(self._h, _ptr(d_items_flat), _ptr(d_q_off), int(nq), int(max_len), int(k), int(m), int(how_many), flags,
                                                             _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), C.c_void_p(stream)))
         return out
+
+    def set_postings(self, postings):
+        """srn_shard_group_set_postings: the NEIGHBOURS pipeline -- `postings` = the unsharded VMISIndex (or its rows-free postings_view) on this rank's device; None: off."""
+        capi.check(capi.lib().srn_shard_group_set_postings(self._h, postings._h if postings is not None else None))
+        self._postings = postings          # (must outlive the group)
 
     def set_overlap(self, on):
         """srn_shard_group_set_overlap: batch i + 1's exchange beside batch i's kernels and result gather (two communicators in flight), or everything in

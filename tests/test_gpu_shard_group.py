@@ -305,3 +305,147 @@ def test_multi_rank_group_over_application_callbacks(world):
         assert st["transport"] == 2 and st["n_shards"] == world and st["stage_batches"] == 1
         for r, ref, n in zip(res, refs, (21, 50, 21, 21)):
             _check_oracle(r, ref, n)
+
+
+# ---- the NEIGHBOURS pipeline (round 4): posting lists replicated, candidate work divided over the ranks, neighbour lists all-gathered -------------------------------
+
+@pytest.mark.parametrize("n_shards", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("view", ["full", "postings-view"])
+def test_neighbours_pipeline_matches_the_oracle(n_shards, view):
+    """srn_shard_group_set_postings: rank r runs find_neighbors (vmis_index.rs:325-415) for ITS slice of the batch against the replicated lists, the neighbour lists
+    are all-gathered, every rank scores all queries over its row fragments (mod.rs:126-214).  Against the canonical oracle and bit-identical to the unsharded path; rows
+    of up to 80 items (fragments of every length), unknown and repeated items, queries no front end takes (more than 4 lists: the general kernel on every rank), batches
+    whose shape the fast kernel does not take at all (how_many = 100: the lists pipeline), business rules with real flags."""
+    import serenade_amd as sa
+    from serenade_amd import sharded, capi
+    from oracle import oracle as O
+    off, items, ts, ids = small_dataset(181, n_sessions=9000, n_items=600, max_len=80)
+    qs = random_queries(123, ids, 1100, max_len=8, unknown_rate=0.03, dup_rate=0.1)
+    flat, qoff = flatten(qs)
+    d_flat, d_off = _to_dev(flat, qoff)
+    full = sa.VMISIndex.from_sessions(off, items, ts, 400, 80, 1.0)
+    oix = O.OracleIndex(off, items, ts, 400, 80, 1.0)
+    rng = np.random.default_rng(47)
+    known = np.unique(items)
+    flags = rng.choice(np.array([0, 1, 2, 3, 0xFF], np.uint8), size=len(known), p=[0.1, 0.05, 0.55, 0.2, 0.1])
+    full.set_attributes(known, flags)
+    oix.set_attributes(known, flags)
+    shards = [sharded.ShardedVMISIndex.from_full(full, g, n_shards) for g in range(n_shards)]
+    for s in shards:
+        capi.check(capi.lib().srn_index_set_attributes(s._h, capi.ptr(capi.as_u64(known)), capi.ptr(flags), len(known)))
+    post = full if view == "full" else sharded.postings_view(full)
+    if view != "full":
+        assert post.info["device_bytes"] < full.info["device_bytes"]
+        with pytest.raises(sa.SerenadeError):
+            sa.predict(post, [int(ids[0])], 10, 10, 5, False)                  # a view answers no predict call
+    grp = sharded.ShardGroup.local(shards)
+    grp.set_postings(post)
+    nq = len(qs)
+    served = 0
+    for (k, m, n, business) in [(100, 400, 21, False), (500, 300, 21, True), (30, 60, 5, False), (200, 400, 100, False), (1500, 400, 24, True)]:
+        ref = oix.predict_batch("canonical", flat, qoff, k, m, n, business, threads=4)
+        before = grp.stats["neighbour_batches"]
+        got = _np(grp.predict_batch(d_flat, d_off, nq, 8, k, m, n, business))
+        _check_oracle(got, ref, n)
+        u = sa.predict_batch(full, (flat, qoff), k, m, n, business)
+        assert np.array_equal(got[0], u[0]) and np.array_equal(got[1], u[1]) and np.array_equal(got[2], u[2])
+        took = grp.stats["neighbour_batches"] - before
+        assert took == (1 if n <= 24 else 0), (k, m, n, took)                   # how_many > 24: not the fast kernel's shape -> the lists pipeline, same answers
+        served += took
+    st = grp.stats
+    assert served == 4 and (st["bytes_neighbours"] > 0) == (n_shards > 1)
+    # both buffer slots, the reused-output form, and switching the pipeline off again
+    out = grp.predict_batch(d_flat, d_off, nq, 8, 100, 400, 21)
+    out2 = grp.predict_batch(d_flat, d_off, nq, 8, 100, 400, 21, out=out)
+    ref = oix.predict_batch("canonical", flat, qoff, 100, 400, 21, False, threads=4)
+    _check_oracle(_np(out2), ref, 21)
+    grp.set_postings(None)
+    nb = grp.stats["neighbour_batches"]
+    _check_oracle(_np(grp.predict_batch(d_flat, d_off, nq, 8, 100, 400, 21)), ref, 21)
+    assert grp.stats["neighbour_batches"] == nb
+
+
+def test_neighbours_pipeline_synthetic_shape_and_misuse():
+    """The generator's shape (the bench's: sessions of <= 4 items, k = 500, m = 1000) through 4 shards, and what set_postings refuses."""
+    import serenade_amd as sa
+    from serenade_amd import sharded, synth
+    from oracle import oracle as O
+    inter, n_items, k, m, idfw = synth.CONFIGS["cfg2"]
+    off, items, ts = synth.training_sessions(inter, n_items)
+    flat, qoff = synth.queries(6000, n_items)
+    nq = len(qoff) - 1
+    d_flat, d_off = _to_dev(flat, qoff)
+    full = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw, builder="gpu")
+    oix = O.OracleIndex(off, items, ts, m, 34, idfw, fast=True)
+    shards = [sharded.ShardedVMISIndex.from_full(full, g, 4) for g in range(4)]
+    grp = sharded.ShardGroup.local(shards)
+    grp.set_postings(sharded.postings_view(full))
+    ref = oix.predict_batch("canonical", flat, qoff, k, m, 21, False, threads=8)
+    for rep in range(3):
+        _check_oracle(_np(grp.predict_batch(d_flat, d_off, nq, 4, k, m, 21, resident=rep > 0)), ref, 21)
+    assert grp.stats["neighbour_batches"] == 3
+    other = sa.VMISIndex.from_sessions(off[:1001], items[:int(off[1000])], ts[:1000], m, 34, idfw)
+    with pytest.raises(sa.SerenadeError):
+        grp.set_postings(other)                                                 # not the index these shards were cut from
+    with pytest.raises(sa.SerenadeError):
+        grp.set_postings(shards[0])                                             # a shard is not the whole index's postings
+
+
+def _cb_nb_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    try:
+        import torch.distributed as dist
+        import serenade_amd as sa
+        from serenade_amd import distributed as D
+        from serenade_amd import sharded
+        D.init("gloo")
+        off, items, ts, ids = small_dataset(84, n_sessions=5000, n_items=400, max_len=40)
+        qs = random_queries(31, ids, 401, max_len=7, unknown_rate=0.02)             # (401: the last rank's slice is shorter)
+        flat, qoff = flatten(qs)
+        d_flat, d_off = _to_dev(flat, qoff)
+        full = sa.VMISIndex.from_sessions(off, items, ts, 300, 40, 1.0)
+        ix = sharded.ShardedVMISIndex.from_full(full, rank, world)
+        post = sharded.postings_view(full)
+        del full
+        grp = sharded.ShardGroup.over(ix, rank, world, sharded.DistComm())
+        grp.set_postings(post)
+        res = [_np(grp.predict_batch(d_flat, d_off, len(qs), 7, k, m, n, resident=res_flag)) for (k, m, n, res_flag) in [(80, 300, 21, False), (400, 200, 24, True), (80, 300, 21, True)]]
+        grp.set_overlap(False)
+        res.append(_np(grp.predict_batch(d_flat, d_off, len(qs), 7, 80, 300, 21)))
+        q.put((rank, res, grp.stats))
+        D.barrier()
+        grp.close()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "error: %r\n%s" % (e, traceback.format_exc()), None))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_neighbours_pipeline_over_application_callbacks(world):
+    """The rank-major form: two / three processes (one GPU), each fronting its slice, the neighbour-list all-gather and the top-n all-gather through the callback
+    transport (gloo), with and without the overlapped exchange stream; against the oracle on every rank."""
+    mp = pytest.importorskip("torch.multiprocessing")
+    from oracle import oracle as O
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cb_nb_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=900) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+    off, items, ts, ids = small_dataset(84, n_sessions=5000, n_items=400, max_len=40)
+    qs = random_queries(31, ids, 401, max_len=7, unknown_rate=0.02)
+    flat, qoff = flatten(qs)
+    oix = O.OracleIndex(off, items, ts, 300, 40, 1.0)
+    refs = [oix.predict_batch("canonical", flat, qoff, k, m, n, False, threads=4) for (k, m, n) in [(80, 300, 21), (400, 200, 24)]]
+    refs += [refs[0], refs[0]]
+    for rank, res, st in out:
+        assert not isinstance(res, str), res
+        assert st["transport"] == 2 and st["n_shards"] == world and st["neighbour_batches"] == 4 and st["bytes_neighbours"] > 0
+        for r, ref, n in zip(res, refs, (21, 24, 21, 21)):
+            _check_oracle(r, ref, n)
