@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--shard-steps", type=int, default=0, help="timed steps of the item-sharded phase (0: --steps)")
     ap.add_argument("--measure-traffic", action="store_true", help="N=1: two extra rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this script with 2 steps, so that "
                     "roofline.traffic is measured in this run instead of read back from profiles/")
+    ap.add_argument("--no-postings", action="store_true", help="N > 1: the lists pipeline (posting lists sharded too: every rank redoes all candidate work on exchanged list prefixes) instead of the neighbours pipeline")
     ap.add_argument("--selftest-launch", action="store_true", help="CPU check of the launcher and the control plane (gloo): no GPU, no timing")
     ap.add_argument("--builder", default="gpu", choices=["gpu", "host"], help="index construction: rocPRIM sorts on the GPU, or the host builder (same bytes)")
     ap.add_argument("--parity", type=int, default=2048, help="queries of batch 0 checked against the canonical oracle before anything is timed (0 = skip)")
@@ -184,7 +185,7 @@ def main():
     t_gen = time.time() - t0
     t0 = time.time()
     # the whole index: what the replicas serve from, and (rank 0) where the per-query counters of the roofline come from
-    index = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw, device=local_rank, builder=args.builder) if (do_rep or rank == 0) else None
+    index = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw, device=local_rank, builder=args.builder) if (do_rep or rank == 0 or (do_shard and world > 1 and not args.no_postings)) else None
     t_build = time.time() - t0
     shard = group = None
     t_shard = None
@@ -268,6 +269,14 @@ def main():
                 group = SH.ShardGroup.over(shard, rank, world, SH.DistComm())   # the collectives as callbacks over gloo: every line of the N > 1 path but RCCL itself
             else:
                 group = SH.ShardGroup.rccl(shard, rank, world)  # RCCL communicators created inside the library; the id travels over the process group
+        postings = None
+        if world > 1 and not args.no_postings:
+            # the NEIGHBOURS pipeline: every rank keeps the posting lists of the whole index (rows-free view) beside its shard of the rows, runs find_neighbors for its slice of
+            # the batch only, the neighbour lists are all-gathered (srn_shard_group_set_postings)
+            postings = SH.postings_view(index, device=local_rank) if index is not None else None
+            if postings is None:
+                raise RuntimeError("the neighbours pipeline needs the unsharded index on every rank (mode both)")
+            group.set_postings(postings)
         t_group = time.time() - t0g
         Bs = args.shard_batch
         sbatches = draw_batches(Bs, args.pool, 0)                     # every rank sees the SAME batches
@@ -307,7 +316,8 @@ def main():
                     "step_ms_p50": float(np.percentile(s_step_ms, 50)), "step_ms_p90": float(np.percentile(s_step_ms, 90)),
                     "exchange_overlapped_with_previous_batch": bool(st1["overlapped"]), "queries_served_last_step": served, "timed_batches": int(st1["batches"] - st0["batches"]),
                     "transport": {0: "in-process", 1: "rccl", 2: "callbacks"}[st1["transport"]],
-                    "per_q": {kk: (st1[kk] - st0[kk]) / nqs for kk in ("bytes_head", "bytes_counts", "bytes_lists", "bytes_results", "bytes_lists_max_rank")}}
+                    "neighbour_batches": int(st1["neighbour_batches"] - st0["neighbour_batches"]),
+                    "per_q": {kk: (st1[kk] - st0[kk]) / nqs for kk in ("bytes_head", "bytes_counts", "bytes_lists", "bytes_results", "bytes_lists_max_rank", "bytes_neighbours")}}
 
         def shard_line_of(run, probe):
             ach = bq_mean * Bs / (run["ms_per_step"] * 1e-3) / 1e9
@@ -318,8 +328,11 @@ def main():
                 "config": {"workload": ("BASELINE configs[2]: synthetic %d interactions / %d items, k=%d m=%d idf_weighting=%g last_items=%d how_many=%d" % (inter, n_items, k, m, idfw, last_items, how_many)
                                         if args.config == "cfg3" else "synth.CONFIGS[%s]" % args.config) + "; index item-sharded over %d GPU(s), every rank sees the whole batch" % world,
                            "name": args.config, "batch": Bs, "query_pool_batches": args.pool,
-                           "parallelism": "item-sharded x%d (owner = hash of the item id): all-reduce(max) of the cuts + all-gather of the kept counts + variable-length exchange of "
-                                          "the posting-list prefixes + all-gather of the per-shard top-n per batch, RCCL called from inside libserenade_hip.so (srn_shard_group_predict_batch)" % world,
+                           "parallelism": ("item-sharded x%d (rows, idf and top-n by owner = hash of the item id; posting lists replicated): rank r runs find_neighbors for its 1/%d of the batch, "
+                                           "all-gather of the neighbour lists + all-gather of the per-shard top-n per batch" % (world, world) if run["neighbour_batches"] else
+                                           "item-sharded x%d (owner = hash of the item id): all-reduce(max) of the cuts + all-gather of the kept counts + variable-length exchange of "
+                                           "the posting-list prefixes + all-gather of the per-shard top-n per batch" % world) + ", RCCL called from inside libserenade_hip.so (srn_shard_group_predict_batch)",
+                           "pipeline": "neighbours" if run["neighbour_batches"] else "lists",
                            "rccl_ranks": (int(dist.get_world_size()) if world > 1 else 1) if not rehearse else 0, "transport": run["transport"],
                            "rehearsal": "%d processes on ONE GPU over gloo callbacks: control flow only, not a scaling measurement" % world if rehearse else None,
                            "exchange_overlapped_with_previous_batch": run["exchange_overlapped_with_previous_batch"], "overlap_probe": probe,
@@ -330,7 +343,8 @@ def main():
                              "algorithmic_bytes_per_query": bq_mean, "queries_per_launch": Bs,
                              "note": "the same algorithmic bytes as the unsharded path (every datum is touched once, on the shard that owns it) against the whole step and N x 8 TB/s"},
                 "exchange_bytes_per_query_rank0": {"cuts_all_reduce": per_q["bytes_head"], "kept_counts_all_gather": per_q["bytes_counts"], "list_prefixes_sent": per_q["bytes_lists"],
-                                                   "list_prefixes_fullest_rank": per_q["bytes_lists_max_rank"], "topn_all_gather": per_q["bytes_results"]},
+                                                   "list_prefixes_fullest_rank": per_q["bytes_lists_max_rank"], "neighbour_lists_all_gather": per_q["bytes_neighbours"],
+                                                   "topn_all_gather": per_q["bytes_results"]},
                 "latency": {"step_ms_p50": run["step_ms_p50"], "step_ms_p90": run["step_ms_p90"]},
                 "parity_checked": s_parity, "queries_served_last_step": run["queries_served_last_step"], "timed_batches": run["timed_batches"]})
             return line

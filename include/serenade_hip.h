@@ -343,6 +343,7 @@ int srn_shard_group_set_overlap(srn_shard_group_t* g, int on);
  * Every rank must make the same call; the handle must outlive the group. */
 int srn_shard_group_set_postings(srn_shard_group_t* g, const srn_index_t* postings);
 int srn_index_postings_view(const srn_index_t* full, int device, srn_index_t** out);
+int srn_debug_shard_group_times(const srn_shard_group_t* g, double* out_ms3);   /* measurement aid (SRN_GROUP_TIMING=1 at group creation): local shard 0's prep + front end | back end | merge of the last neighbours batch */
 void srn_shard_group_free(srn_shard_group_t* g);
 
 /* The same for the most recent min(max_n, 64) predict calls (oldest first): per-call duration in ms of

@@ -116,6 +116,7 @@ SYMBOLS = {
     "srn_shard_group_stats": (_i, [_vp, _vp]),
     "srn_shard_group_set_overlap": (_i, [_vp, _i]),
     "srn_shard_group_set_postings": (_i, [_vp, _vp]),
+    "srn_debug_shard_group_times": (_i, [_vp, _vp]),
     "srn_index_postings_view": (_i, [_vp, _i, C.POINTER(_vp)]),
     "srn_shard_group_free": (None, [_vp]),
     "srn_kernel_timing": (_i, [_vp, C.c_int]),

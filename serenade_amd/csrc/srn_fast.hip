@@ -400,8 +400,14 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         // query's candidates, and their share of the posting lists is in flight meanwhile.
         uint32_t v[4][5];   // every load of every list in flight at once (uniform skips; past a list's end the lanes re-read its last entry)
         uint32_t K = 0;
-        if constexpr (MODE == FM_BACK) K = (uint32_t)__builtin_amdgcn_readfirstlane((int)xq[0]);   // (uniform address; requested before the barrier like the lists of the fused form)
-        else {
+        uint32_t xsv[3] = {0u, 0u, 0u};
+        if constexpr (MODE == FM_BACK) {   // K and this lane's <= 3 neighbour slots in ONE round trip, requested before the barrier like the lists of the fused form (slots past K: stale words of
+                                           // the query's own row of the exchange buffer, masked below)
+            const uint32_t kv = xq[0];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) xsv[t] = xq[1u + min(wave * 64u + lane + (uint32_t)t * BLOCK, f.xchg_stride - 2u)];
+            K = (uint32_t)__builtin_amdgcn_readfirstlane((int)kv);
+        } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -580,10 +586,10 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const uint32_t j = wave * 64u + lane + (uint32_t)t * BLOCK;
-            if constexpr (MODE == FM_BACK) svr[t] = xq[1u + min(j, K - 1u)];   // (K >= 1 here)
+            if constexpr (MODE == FM_BACK) svr[t] = j < K ? xsv[t] : 0u;   // (slots past K are stale words: the idle lanes read the empty row)
             else
             svr[t] = K ? nbl[min(j, K - 1u)] : 0u;   // (all loads unconditional: a load inside a branch is waited for at the branch's end)
-            const size_t r = K ? (size_t)(base + (svr[t] >> NB)) : (size_t)n_kept;   // (idle lanes re-read the last neighbour's row)
+            const size_t r = (MODE == FM_BACK ? j < K : K != 0u) ? (size_t)(base + (svr[t] >> NB)) : (size_t)n_kept;   // (idle lanes re-read the last neighbour's row)
             rq[t] = *reinterpret_cast<const uint4*>(&f.row_packed[r * (FRAG ? 1 : 4)]); rq1[t] = make_uint4(0u, 0u, 0u, 0u);
         }
         {   // clear: accumulators + sketch + dump, exact table (keys EMPTY32, sums 0)

@@ -122,6 +122,7 @@ struct srn_shard_group {
     uint64_t calls = 0;
     uint64_t st_queries = 0, st_bytes_head = 0, st_bytes_kept = 0, st_bytes_lists = 0, st_bytes_results = 0, st_lists_max = 0;
     uint64_t st_nb_batches = 0, st_bytes_nb = 0;
+    bool timing = false; hipEvent_t e_t[6] = {}; float last_ms[3] = {0, 0, 0};   // SRN_GROUP_TIMING (measurement aid): local shard 0's prep + front end | back end | merge, of the last neighbours batch
     uint64_t st_stage_batches = 0, st_bytes_stage_cand = 0, st_bytes_stage_minpos = 0;   // batches that took the three-stage pipeline
     std::mutex mu;   // one batch is issued at a time per group (the collectives must be issued in the same order on every rank anyway)
 };
@@ -186,6 +187,7 @@ int group_init_common(srn_shard_group* g) {
     }
     if (const char* e = getenv("SRN_GROUP_OVERLAP")) g->overlap = atoi(e) != 0;
     g->no_direct = getenv("SRN_GROUP_NO_DIRECT") != nullptr;
+    if (getenv("SRN_GROUP_TIMING")) { g->timing = true; for (auto& e : g->e_t) HIP_TRY(hipEventCreate(&e)); }
     return SRN_OK;
 }
 
@@ -295,9 +297,11 @@ int group_predict_neighbours(srn_shard_group* g, const LaunchParams& p_in, bool 
     DeviceState* post = g->postings->dev;
     for (size_t i = 0; i < g->shards.size(); ++i) {
         const uint32_t gi = local ? (uint32_t)i : (uint32_t)g->rank;
+        if (g->timing && i == 0) HIP_TRY(hipEventRecord(g->e_t[0], sx));
         int rc = device_shard_nb_prep(g->shards[i]->dev, post, p, s.nrec[i], sx); if (rc) return rc;
         const uint32_t q_lo = std::min<uint64_t>(nq, (uint64_t)gi * per), q_hi = std::min<uint64_t>(nq, (uint64_t)q_lo + per);
         rc = device_shard_nb_front(g->shards[i]->dev, g->shards[i]->flat, post, p, s.nrec[i], (uint32_t*)s.xchg, xstride, q_lo, q_hi, sx); if (rc) return rc;
+        if (g->timing && i == 0) HIP_TRY(hipEventRecord(g->e_t[1], sx));
     }
     { int rc = all_gather_blocks(g, 0, s.xchg, xblock, sx); if (rc) return rc; }
     if (overlap) { HIP_TRY(hipEventRecord(g->e_x, sx)); HIP_TRY(hipStreamWaitEvent(user, g->e_x, 0)); }
@@ -307,14 +311,23 @@ int group_predict_neighbours(srn_shard_group* g, const LaunchParams& p_in, bool 
         LaunchParams pi = p;
         const bool direct = G == 1;   // one shard: its top-n IS the result
         pi.out_ids = direct ? d_out_ids : (uint64_t*)blk; pi.out_scores = direct ? d_out_scores : (double*)(blk + (size_t)nq * n * 8); pi.out_counts = direct ? d_out_counts : (uint32_t*)(blk + (size_t)nq * n * 16);
+        if (g->timing && i == 0) HIP_TRY(hipEventRecord(g->e_t[2], user));
         HIP_TRY(hipMemsetAsync(pi.out_ids, 0, (size_t)nq * n * 8, user)); HIP_TRY(hipMemsetAsync(pi.out_scores, 0, (size_t)nq * n * 8, user));
         int rc = device_shard_nb_back(g->shards[i]->dev, g->shards[i]->flat, post, pi, s.nrec[i], (uint32_t*)s.xchg, xstride, user); if (rc) return rc;
+        if (g->timing && i == 0) HIP_TRY(hipEventRecord(g->e_t[3], user));
     }
     if (G > 1) {
         int rc = all_gather_blocks(g, 1, s.part, block_bytes, user); if (rc) return rc;
+        if (g->timing) HIP_TRY(hipEventRecord(g->e_t[4], user));
         HIP_TRY(launch_shard_merge_topn(user, s.part, block_bytes, G, nq, n, d_out_ids, d_out_scores, d_out_counts));
+        if (g->timing) HIP_TRY(hipEventRecord(g->e_t[5], user));
     }
     HIP_TRY(hipEventRecord(s.e_done, user));
+    if (g->timing) {   // (measurement runs only: synchronises)
+        HIP_TRY(hipEventSynchronize(s.e_done));
+        HIP_TRY(hipEventElapsedTime(&g->last_ms[0], g->e_t[0], g->e_t[1])); HIP_TRY(hipEventElapsedTime(&g->last_ms[1], g->e_t[2], g->e_t[3]));
+        g->last_ms[2] = 0.f; if (G > 1) HIP_TRY(hipEventElapsedTime(&g->last_ms[2], g->e_t[4], g->e_t[5]));
+    }
     ++g->calls;
     g->st_queries += nq; ++g->st_nb_batches; g->st_bytes_nb += G > 1 ? (uint64_t)xblock * (local ? G : 1) : 0;
     g->st_bytes_results += G > 1 ? (uint64_t)block_bytes * (local ? G : 1) : 0;
@@ -334,7 +347,8 @@ int group_predict(srn_shard_group* g, const uint64_t* d_items_flat, const uint32
     p.out_ids = d_out_ids; p.out_scores = d_out_scores; p.out_counts = d_out_counts;
     for (const srn_index* ix : g->shards)
         if (!device_shard_lists_supported(ix->dev, ix->flat, p)) return group_predict_stages(g, p, d_out_ids, d_out_scores, d_out_counts, user);   // (every rank holds the same index parameters: the same choice everywhere)
-    if (g->postings) {   // (the same index parameters and the same batch shape on every rank: the same choice everywhere)
+    if (g->postings && G > 1) {   // (the same index parameters and the same batch shape on every rank: the same choice everywhere.  A group of ONE shard gains nothing from
+                                 //  dividing the candidate work: its lists pipeline reads the lists in place and runs the fused kernel -- 23.4 against 10 + 16.7 ms per 2^20 queries)
         bool all = true;
         for (const srn_index* ix : g->shards) all = all && device_fast_eligible(ix->dev, ix->flat, p);
         if (all) return group_predict_neighbours(g, p, resident, d_out_ids, d_out_scores, d_out_counts, user);
@@ -497,6 +511,7 @@ void srn_shard_group_free(srn_shard_group_t* g) {
     for (Slot& s : g->slot) slot_free(s);
     if (g->s_x) hipStreamDestroy(g->s_x);
     if (g->e_in) hipEventDestroy(g->e_in); if (g->e_x) hipEventDestroy(g->e_x);
+    for (auto& e : g->e_t) if (e) hipEventDestroy(e);
     delete g;
 }
 
@@ -513,6 +528,11 @@ int srn_shard_group_predict_batch(srn_shard_group_t* g, const uint64_t* d_items_
         return group_predict(g, d_items_flat, d_q_off, nq, max_len_hint, k, m, how_many, flags, d_out_ids, d_out_scores, d_out_counts, (hipStream_t)stream); });
 }
 
+int srn_debug_shard_group_times(const srn_shard_group_t* g, double* out3) {   // SRN_GROUP_TIMING=1: ms of local shard 0's prep + front end, back end (incl. general + finish kernels), merge
+    if (!g || !out3 || !g->timing) return fail(SRN_EINVAL, "group timing is off (SRN_GROUP_TIMING=1 before the group is created)");
+    for (int i = 0; i < 3; ++i) out3[i] = g->last_ms[i];
+    return SRN_OK;
+}
 int srn_shard_group_set_postings(srn_shard_group_t* g, const srn_index_t* postings) {
     if (!g) return fail(SRN_EINVAL, "null group");
     std::lock_guard<std::mutex> lk(g->mu);

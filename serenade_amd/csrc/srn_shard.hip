@@ -255,45 +255,70 @@ hipError_t launch_shard_fill_i32(hipStream_t st, int* dst, int v, size_t n) {
 }
 
 // The last step of a sharded batch: the G per-shard top-n lists of a query -> its global top-n by (score desc, item id asc).  An item's whole score lives on its
-// owner, so no item appears twice; every list is already in that order.  One wave per query; an entry's global rank is its own position plus, for every other
-// list, the number of that list's entries that come before it (binary search: <= 9 steps for n <= 512).  Replaces two argsorts and four gathers of the host's
-// tensor library (round 2: sharded.py merge_topn).  part = G blocks of block_bytes: ids [nq * n] u64 | scores [nq * n] f64 | counts [nq] u32.
+// owner, so no item appears twice; every list is already in that order.  LPQ lanes per query (the power of two >= G), lane = list: a G-way merge by selection --
+// every lane holds the head of its list (and the entry behind it, requested when the head moved up: the loads stay off the critical path), the group finds the best head
+// with log2(LPQ) exchange steps, the winner writes it out and moves on; n rounds at most.  64 / LPQ queries per wave, ~70 instructions per query at G = 8.
+// (Rounds 2-3: one wave per query, every one of the G n entries found its rank with a binary search in each other list -- 1.04 ms per 131 072 queries at G = 8, as much as
+// half the back end; this form: see profiles/r04_shard_nb_rank_time.txt.)  part = G blocks of block_bytes: ids [nq * n] u64 | scores [nq * n] f64 | counts [nq] u32.
+template <int LPQ>
 __global__ __launch_bounds__(256) void shard_merge_topn_kernel(const char* __restrict__ part, size_t block_bytes, uint32_t G, uint32_t nq, uint32_t n,
                                                                uint64_t* __restrict__ out_ids, double* __restrict__ out_scores, uint32_t* __restrict__ out_counts) {
-    const uint32_t q = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    if (q >= nq) return;
-    auto ids_of = [&](uint32_t g) { return reinterpret_cast<const uint64_t*>(part + (size_t)g * block_bytes) + (size_t)q * n; };
-    auto sc_of = [&](uint32_t g) { return reinterpret_cast<const double*>(part + (size_t)g * block_bytes + (size_t)nq * n * 8) + (size_t)q * n; };
-    auto cnt_of = [&](uint32_t g) { return reinterpret_cast<const uint32_t*>(part + (size_t)g * block_bytes + (size_t)nq * n * 16)[q]; };
-    uint32_t total = 0; bool bad = false;
-    for (uint32_t g = 0; g < G; ++g) { const uint32_t c = cnt_of(g); if (c == 0xFFFFFFFFu) bad = true; else total += min(c, n); }
-    if (bad) { if (lane == 0u) out_counts[q] = 0xFFFFFFFFu; return; }   // (a query some shard could not serve: the caller sees the marker, as in the unsharded path)
-    const uint32_t keep = min(total, n);
-    for (uint32_t e = lane; e < G * n; e += 64u) {
-        const uint32_t g = e / n, j = e - g * n;
-        if (j >= min(cnt_of(g), n)) continue;
-        const double s = sc_of(g)[j]; const uint64_t id = ids_of(g)[j];
-        uint32_t rank = j;
-        for (uint32_t h = 0; h < G && rank < keep; ++h) {
-            if (h == g) continue;
-            const double* sh = sc_of(h); const uint64_t* ih = ids_of(h);
-            uint32_t lo = 0, hi = min(cnt_of(h), n);
-            while (lo < hi) {   // first entry of list h that does NOT come before (s, id)
-                const uint32_t mid = (lo + hi) >> 1;
-                const double sm = sh[mid];
-                const bool before = sm > s || (sm == s && ih[mid] < id);
-                if (before) lo = mid + 1; else hi = mid;
-            }
-            rank += lo;
+    constexpr uint32_t QPW = 64u / LPQ;
+    const uint32_t lane = threadIdx.x & 63u, sub = lane % LPQ;
+    const uint32_t q = (blockIdx.x * 4u + (threadIdx.x >> 6)) * QPW + lane / LPQ;
+    const bool live = q < nq && sub < G;
+    const uint32_t qc = min(q, nq - 1u), gc = min(sub, G - 1u);
+    const uint64_t* ids = reinterpret_cast<const uint64_t*>(part + (size_t)gc * block_bytes) + (size_t)qc * n;
+    const double* scs = reinterpret_cast<const double*>(part + (size_t)gc * block_bytes + (size_t)nq * n * 8) + (size_t)qc * n;
+    const uint32_t craw = reinterpret_cast<const uint32_t*>(part + (size_t)gc * block_bytes + (size_t)nq * n * 16)[qc];
+    uint32_t bad = live && craw == 0xFFFFFFFFu ? 1u : 0u;
+    const uint32_t cnt = live && craw != 0xFFFFFFFFu ? min(craw, n) : 0u;
+    uint32_t total = cnt;
+#pragma unroll
+    for (int d = 1; d < LPQ; d <<= 1) { total += __shfl_xor(total, d, LPQ); bad |= __shfl_xor(bad, d, LPQ); }
+    const uint32_t keep = bad ? 0u : min(total, n);
+    // head and the entry behind it (an exhausted list: -inf with the largest id, never the winner while a live entry is left)
+    const double NEG = -__builtin_huge_val();
+    double s0 = cnt > 0u ? scs[0] : NEG, s1 = cnt > 1u ? scs[1] : NEG;
+    unsigned long long i0 = cnt > 0u ? ids[0] : ~0ull, i1 = cnt > 1u ? ids[1] : ~0ull;
+    uint32_t pos = 0;
+    uint32_t rounds = keep;
+#pragma unroll
+    for (int d = LPQ; d < 64; d <<= 1) rounds = max(rounds, (uint32_t)__shfl_xor((int)rounds, d));   // (the wave's longest query)
+    for (uint32_t r = 0; r < rounds; ++r) {
+        double bs = s0; unsigned long long bi = i0; uint32_t bl = sub;
+#pragma unroll
+        for (int d = 1; d < LPQ; d <<= 1) {
+            const double os = __shfl_xor(bs, d, LPQ); const unsigned long long oi = __shfl_xor(bi, d, LPQ); const uint32_t ol = (uint32_t)__shfl_xor((int)bl, d, LPQ);
+            const bool other = os > bs || (os == bs && oi < bi);
+            bs = other ? os : bs; bi = other ? oi : bi; bl = other ? ol : bl;
         }
-        if (rank < keep) { out_ids[(size_t)q * n + rank] = id; out_scores[(size_t)q * n + rank] = s; }
+        if (r < keep && bl == sub) {   // (one lane of the group)
+            out_ids[(size_t)q * n + r] = i0; out_scores[(size_t)q * n + r] = s0;
+            ++pos; s0 = s1; i0 = i1;
+            const bool more = pos + 1u < cnt;
+            s1 = more ? scs[pos + 1u] : NEG; i1 = more ? ids[pos + 1u] : ~0ull;
+        }
     }
-    for (uint32_t r = keep + lane; r < n; r += 64u) { out_ids[(size_t)q * n + r] = 0ull; out_scores[(size_t)q * n + r] = 0.0; }   // the unused tail of a row reads as 0
-    if (lane == 0u) out_counts[q] = keep;
+    if (q < nq) {
+        if (!bad) for (uint32_t r = keep + sub; r < n; r += LPQ) { out_ids[(size_t)q * n + r] = 0ull; out_scores[(size_t)q * n + r] = 0.0; }   // the unused tail of a row reads as 0
+        if (sub == 0u) out_counts[q] = bad ? 0xFFFFFFFFu : keep;   // (a query some shard could not serve: the caller sees the marker, as in the unsharded path)
+    }
 }
 hipError_t launch_shard_merge_topn(hipStream_t st, const char* part, size_t block_bytes, uint32_t n_shards, uint32_t nq, uint32_t how_many, uint64_t* out_ids, double* out_scores,
                                    uint32_t* out_counts) {
-    hipLaunchKernelGGL(shard_merge_topn_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, part, block_bytes, n_shards, nq, how_many, out_ids, out_scores, out_counts);
+    if (n_shards == 0 || n_shards > 64) return hipErrorInvalidValue;
+    const uint32_t lpq = n_shards <= 2 ? 2u : n_shards <= 4 ? 4u : n_shards <= 8 ? 8u : n_shards <= 16 ? 16u : n_shards <= 32 ? 32u : 64u;
+    const uint32_t per_block = 4u * (64u / lpq);
+    const dim3 grid((nq + per_block - 1) / per_block), block(256);
+    switch (lpq) {
+        case 2: hipLaunchKernelGGL(shard_merge_topn_kernel<2>, grid, block, 0, st, part, block_bytes, n_shards, nq, how_many, out_ids, out_scores, out_counts); break;
+        case 4: hipLaunchKernelGGL(shard_merge_topn_kernel<4>, grid, block, 0, st, part, block_bytes, n_shards, nq, how_many, out_ids, out_scores, out_counts); break;
+        case 8: hipLaunchKernelGGL(shard_merge_topn_kernel<8>, grid, block, 0, st, part, block_bytes, n_shards, nq, how_many, out_ids, out_scores, out_counts); break;
+        case 16: hipLaunchKernelGGL(shard_merge_topn_kernel<16>, grid, block, 0, st, part, block_bytes, n_shards, nq, how_many, out_ids, out_scores, out_counts); break;
+        case 32: hipLaunchKernelGGL(shard_merge_topn_kernel<32>, grid, block, 0, st, part, block_bytes, n_shards, nq, how_many, out_ids, out_scores, out_counts); break;
+        default: hipLaunchKernelGGL(shard_merge_topn_kernel<64>, grid, block, 0, st, part, block_bytes, n_shards, nq, how_many, out_ids, out_scores, out_counts); break;
+    }
     return hipGetLastError();
 }
 

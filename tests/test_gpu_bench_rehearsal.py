@@ -43,7 +43,7 @@ def test_rehearsal_of_the_multi_gpu_line(world):
         assert key in rf, key
     assert rf["peak"] == 8000.0 * world and 0 < rf["frac"] < 1
     ex = line["exchange_bytes_per_query_rank0"]
-    assert ex["topn_all_gather"] > 0 and ex["list_prefixes_sent"] > 0
+    assert ex["topn_all_gather"] > 0 and ex["neighbour_lists_all_gather"] > 0 and cfg["pipeline"] == "neighbours"
 
 
 def test_single_gpu_line_carries_both_modes():
