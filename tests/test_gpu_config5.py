@@ -115,6 +115,17 @@ def test_config5_full_size(monkeypatch):
     assert np.array_equal(g_cnt[:nc], oref["counts"]) and np.array_equal(g_ids[:nc][mask], oref["ids"][mask])          # the sharded path against the ORACLE, directly
     np.testing.assert_allclose(g_sc[:nc][mask], oref["scores"][mask], rtol=SCORE_RTOL, atol=0)
     st8 = grp.stats
+    # ---- and through the NEIGHBOURS pipeline (round 4): posting lists replicated (here: the unsharded index's own, resident anyway), candidate work divided over the 8 ranks,
+    #      477 M sessions = the 29-bit-rank form of the front and back ends ----
+    grp.set_postings(full)
+    res2 = grp.predict_batch(ds_flat, ds_off, NS, L, k, m, n)
+    torch.cuda.synchronize()
+    assert grp.stats["neighbour_batches"] == 1
+    n_ids, n_sc, n_cnt = res2[0].cpu().numpy().view(np.uint64), res2[1].cpu().numpy(), res2[2].cpu().numpy().view(np.uint32)
+    assert np.array_equal(n_cnt, g_cnt) and np.array_equal(n_ids, g_ids) and np.array_equal(n_sc, g_sc), "the neighbours pipeline differs from the lists pipeline"
+    assert np.array_equal(n_cnt[:nc], oref["counts"]) and np.array_equal(n_ids[:nc][mask], oref["ids"][mask])          # against the ORACLE, directly
+    np.testing.assert_allclose(n_sc[:nc][mask], oref["scores"][mask], rtol=SCORE_RTOL, atol=0)
+    print("\nconfig 5, neighbours pipeline: %.0f B of neighbour lists all-gathered per query and rank" % (grp.stats["bytes_neighbours"] / 8 / NS))
     print("\nconfig 5: index built on the GPU + attached %.1f s (%.1f GB in HBM), restricted oracle index %.1f s, 8 shards cut + attached %.1f s (%.1f GB each), "
           "lists exchanged %.0f B per query; whole test %.0f s" % (t_build, info["device_bytes"] / 1e9, t_oracle, t_cut, shards[0].info["device_bytes"] / 1e9,
                                                                    st8["bytes_lists"] / max(1, st8["queries"]), time.time() - t_all))
