@@ -198,89 +198,31 @@ int srn_kernel_timing(srn_index_t* idx, int enable);
 int srn_last_kernel_ms(const srn_index_t* idx, double* out_ms_main, double* out_ms_retry, uint32_t* out_retried);
 
 /* ---- item-sharded index: one shard per GPU ---------------------------------------------------
- * For indices that outgrow one GPU (BASELINE config 5) the index is split by item: shard g holds postings, row
- * fragments and idf of the items with owner(id) == g (a fixed hash of the public id), while session recency
- * ranks stay global.  A batch then takes three kernel stages around three collectives that the HOST runs over
- * RCCL (serenade_amd/sharded.py): A -> all-gather(candidates) -> B -> all-reduce-min(first-match positions) ->
- * C -> all-gather(per-shard top-n) -> merge.  All buffers are device memory; calls are asynchronous on `stream`.
- * Packed candidate / neighbour entries are srn_shard_slot_bytes() wide (4, or 8 when rank bits + weight bits
- * exceed 32).  Results are bit-identical to the unsharded path (tests/test_gpu_sharded.py). */
-int srn_index_build_shard(const srn_sessions_view_t* sessions, size_t m_index, size_t max_session_len,
-                          double idf_weighting, uint32_t shard, uint32_t n_shards, int device, srn_index_t** out);
-int srn_shard_slot_bytes(const srn_index_t* idx, size_t max_len_hint, uint32_t* out);
-/* width of a packed entry and of its low payload field: rank = entry >> *out_num_bits (the host compacts the candidate lists by rank) */
-int srn_shard_slot_info(const srn_index_t* idx, size_t max_len_hint, uint32_t* out_bytes, uint32_t* out_num_bits);
-/* Shard `shard` of n_shards cut out of an UNSHARDED index -- built by srn_index_build_gpu or read by srn_index_load; the same bytes
+ * For indices that outgrow one GPU (BASELINE config 5), and for the north star's multi-GPU mode, the index is split by item: shard g holds postings, row
+ * fragments and idf of the items with owner(id) == g (a fixed hash of the public id), while session recency ranks stay global.  A shard answers no predict
+ * call by itself: a SHARD GROUP (below) drives the shards of all ranks through one batch call.  Results are bit-identical to the unsharded path
+ * (tests/test_gpu_shard_group.py, tests/test_gpu_sharded.py).
+ * Shard `shard` of n_shards is cut out of an UNSHARDED index -- built by srn_index_build_gpu or read by srn_index_load; the same bytes
  * srn_index_build_shard builds from the sessions, in one O(nnz) pass (an item-sharded deployment builds or loads ONE index and
  * every rank cuts its own shard out of it; the reference loads its production index: src/vmisknn/vmis_index.rs:85-314).
  * srn_index_build_shard_gpu = srn_index_build_gpu + srn_index_shard without ever attaching the full index to the device;
  * srn_index_load_shard reads a saved index (unsharded: cut; already that shard: as is). */
+int srn_index_build_shard(const srn_sessions_view_t* sessions, size_t m_index, size_t max_session_len,
+                          double idf_weighting, uint32_t shard, uint32_t n_shards, int device, srn_index_t** out);
 int srn_index_shard(const srn_index_t* full, uint32_t shard, uint32_t n_shards, int device, srn_index_t** out);
 int srn_index_build_shard_gpu(const srn_sessions_view_t* sessions, size_t m_index, size_t max_session_len, double idf_weighting,
                               uint32_t shard, uint32_t n_shards, int device, srn_index_t** out);
 int srn_index_load_shard(const char* path, uint32_t shard, uint32_t n_shards, int device, srn_index_t** out);
-/* The three stages (srn_shard_group_predict_batch drives them itself; these are the pieces).  A query whose session or item table does not fit LDS is served by a
- * second pass of the same stage with its tables in global memory (numerator slots; with position-set slots -- sessions of <= 8 items, m <= m_index -- such a query is
- * marked instead: d_cand_cnt / d_nb_cnt / d_out_counts = 0xFFFFFFFF, and the lists pipeline is the path to use).
- * A: this shard's candidates of every query: d_cand [nq * m] packed (rank, partial numerator), d_cand_cnt [nq] */
-int srn_shard_stage_a(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq,
-                      size_t max_len_hint, size_t k, size_t m, void* d_cand, uint32_t* d_cand_cnt, void* stream);
-/* B: d_gathered [n_shards][nq * m] / d_gathered_cnt [n_shards][nq] (all-gathered stage-A output) -> the global
- * neighbour list d_nb [nq * k] (identical on every shard), d_nb_cnt [nq], and this shard's partial first-match
- * positions d_minpos [nq * (k + 1)] (int32, 0x7FFFFFFF = none; last column: the current item's attribute byte) */
-int srn_shard_stage_b(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq,
-                      size_t max_len_hint, size_t k, size_t m, uint32_t n_shards, const void* d_gathered,
-                      const uint32_t* d_gathered_cnt, void* d_nb, uint32_t* d_nb_cnt, int32_t* d_minpos, void* stream);
-/* B with the gathered lists `gathered_stride` entries apart per query and shard instead of m (the host ships only the entries at or
- * above the global m-th rank, serenade_amd/sharded.py) */
-int srn_shard_stage_b_strided(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq,
-                              size_t max_len_hint, size_t k, size_t m, uint32_t n_shards, size_t gathered_stride, const void* d_gathered,
-                              const uint32_t* d_gathered_cnt, void* d_nb, uint32_t* d_nb_cnt, int32_t* d_minpos, void* stream);
-/* C: d_minpos after all-reduce(min) -> exact top-how_many among the items this shard owns */
-int srn_shard_stage_c(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq,
-                      size_t max_len_hint, size_t k, size_t m, size_t how_many, unsigned flags, const void* d_nb,
-                      const uint32_t* d_nb_cnt, const int32_t* d_minpos, uint64_t* d_out_ids, double* d_out_scores,
-                      uint32_t* d_out_counts, void* stream);
-
-/* ---- item-sharded index, LISTS mode: two exchanges instead of three, and the unsharded kernels between them ----
- * The posting lists of a query are small, so the shards exchange the LISTS (their entries at or above the global cut) instead of
- * candidates: after one all-gather every rank holds all lists of the batch and runs the unsharded kernels unchanged, scoring the
- * items it owns from its row fragments; a last all-gather of the per-shard top-n and a merge by (score desc, id asc) finish.
- * Valid for position-set geometry (sessions of <= 8 items, m <= m_index, complete lists), business rules on or off:
- * srn_shard_lists_supported says which; everything else takes stages A/B/C above.  All buffers are device memory, all calls
- * asynchronous on `stream`.  The sequence on every rank (serenade_amd/sharded.py predict_batch_sharded_lists):
- *   head     -> d_pos [nq * max_len] x 16 B (this shard's view of every evolving position), d_head [nq][3] int32 = local (x_lo, r_max, the current item's attribute byte or -1)
- *   all-reduce(max) of d_head
- *   count    -> d_kept [nq * max_len] u32 (entries >= x_lo of every owned list), d_tot [nq] int32
- *   d_off = exclusive prefix sum of d_tot (int64) -- the host's job
- *   copy     -> d_out[d_off[q] ...]: the query's kept list prefixes, back to back in position order
- *   all-gather of d_kept, d_off and the flat buffers (padded to a common `shard_stride`, in entries)
- *   predict  -> prep records against the gathered buffer (d_records: nq * srn_shard_lists_record_bytes(max_len) scratch), then the
- *               unsharded launch sequence: per-query top-how_many among the items this shard owns
- * Reference: the reference has no sharded mode (one VMISIndex per process, vmis_index.rs:28-35); this serves the north star's
- * "index sharded by item id across the GPUs". */
-int srn_shard_lists_supported(const srn_index_t* idx, size_t max_len_hint, size_t k, size_t m, size_t how_many, unsigned flags, int* out);
-size_t srn_shard_lists_record_bytes(size_t max_len_hint);
-int srn_shard_lists_head(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq, size_t max_len_hint, size_t m,
-                         void* d_pos, int32_t* d_head, void* stream);
-int srn_shard_lists_count(const srn_index_t* idx, const uint32_t* d_q_off, size_t nq, size_t max_len_hint, const void* d_pos, const int32_t* d_head,
-                          uint32_t* d_kept, int32_t* d_tot, void* stream);
-int srn_shard_lists_copy(const srn_index_t* idx, size_t nq, size_t max_len_hint, const void* d_pos, const uint32_t* d_kept, const int64_t* d_off,
-                         uint32_t* d_out, void* stream);
-int srn_shard_lists_predict(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq, size_t max_len_hint, size_t k, size_t m,
-                            size_t how_many, unsigned flags, uint32_t n_shards, const uint32_t* d_kept_g, const int64_t* d_off_g, uint64_t shard_stride,
-                            const uint32_t* d_lists_g, const int32_t* d_head, const void* d_pos_local, void* d_records,
-                            uint64_t* d_out_ids, double* d_out_scores, uint32_t* d_out_counts, void* stream);
 
 /* ---- the shard group: the whole item-sharded batch in ONE call, collectives inside (srn_group.hip) ---------------------------------------
  * What a reference-side host (serving / evaluator, src/endpoints/recommend_resource.rs:56, src/bin/evaluator.rs:58) calls to drive an index
  * sharded over the GPUs of a node: one process (or thread group) per GPU creates its rank of the group around its shard, then every rank calls
- * srn_shard_group_predict_batch with the SAME batch; the call runs the LISTS pipeline above -- head, all-reduce(max), count, all-gather of the
+ * srn_shard_group_predict_batch with the SAME batch; the call runs the LISTS pipeline -- head kernel, all-reduce(max) of the cuts, count kernel, all-gather of the
  * counts, variable-length exchange of the kept list prefixes, the unsharded kernels over the rank's row fragments, all-gather of the per-shard
  * top-n, merge by (score desc, id asc) -- with RCCL called from inside the library.  Results (identical on every rank, bit-identical to the
  * unsharded index) are written to the caller's device buffers, asynchronously on `stream`; the call itself blocks the host for one short
  * synchronisation on the group's own exchange stream (the per-shard list totals size the exchange).  With SRN_FLAG_INPUTS_RESIDENT a batch's
- * exchange phase overlaps the previous batch's kernels.  Batches the lists pipeline does not serve (srn_shard_lists_supported: sessions of > 8 items,
+ * exchange phase overlaps the previous batch's kernels.  Batches the lists pipeline does not serve (sessions of > 8 items,
  * m > m_index, incomplete posting lists) take the three-stage pipeline inside the same call: stage A -> all-gather of the candidates -> stage B ->
  * all-reduce(min) of the first-match positions -> stage C -> all-gather of the per-shard top-n -> merge (no host synchronisation at all).
  *
@@ -343,7 +285,6 @@ int srn_shard_group_set_overlap(srn_shard_group_t* g, int on);
  * Every rank must make the same call; the handle must outlive the group. */
 int srn_shard_group_set_postings(srn_shard_group_t* g, const srn_index_t* postings);
 int srn_index_postings_view(const srn_index_t* full, int device, srn_index_t** out);
-int srn_debug_shard_group_times(const srn_shard_group_t* g, double* out_ms3);   /* measurement aid (SRN_GROUP_TIMING=1 at group creation): local shard 0's prep + front end | back end | merge of the last neighbours batch */
 void srn_shard_group_free(srn_shard_group_t* g);
 
 /* The same for the most recent min(max_n, 64) predict calls (oldest first): per-call duration in ms of
@@ -358,21 +299,12 @@ int srn_kernel_times(const srn_index_t* idx, uint32_t max_n, double* out_ms_main
 int srn_kernel_times_detail(const srn_index_t* idx, uint32_t max_n, double* out_ms_prep, double* out_ms_fast, double* out_ms_predict,
                             double* out_ms_retry, uint32_t* out_n);
 
-/* Profiling aid: returns (and clears) 16 counters of shader cycles summed over workgroups, one per
- * kernel phase (DESIGN.md "Kernel phases"), accumulated by predict calls made while enabled; then
- * switches the accounting on (enable != 0) or off.  Not for production use. */
-int srn_debug_phase_cycles(const srn_index_t* idx, int enable, uint64_t* out16);
 
 /* How the queries of the most recent predict call on this handle were served: *out_nq queries in all, *out_general of them by
  * the general kernel (the fast kernel hands over what does not fit its query shape; == nq when the launch was not eligible for
  * the fast kernel at all), *out_global_pass through the global-table retry pass.  Waits for that call to finish. */
 int srn_last_path_counts(const srn_index_t* idx, uint32_t* out_nq, uint32_t* out_general, uint32_t* out_global_pass);
 
-/* Test / experiment knobs (environment variables SRN_NO_FAST, SRN_NO_MASKS, SRN_NO_MERGE, SRN_DENSE, SRN_HOT_SLOTS,
- * SRN_SKETCH_SLOTS, SRN_LDS_BUDGET_KB, SRN_GRID_MULT, SRN_DEBUG) force individual kernel code paths.  They are read ONCE,
- * when the library is first used -- never on the launch path; this call re-reads them (the parity tests switch paths
- * between calls).  Not for production use: make sure no predict call is in flight. */
-void srn_debug_reload_knobs(void);
 
 /* ---- misc ------------------------------------------------------------------------------- */
 /* ---- dynamic batching: the serving-side caller ------------------------------------------------------------------

@@ -56,7 +56,7 @@ class Limits(C.Structure):
     _fields_ = [("max_how_many", C.c_uint32), ("max_session_len", C.c_uint32), ("max_k", C.c_uint32), ("reserved", C.c_uint32)]
 
 
-# every symbol include/serenade_hip.h declares: (restype, argtypes)
+# every symbol include/serenade_hip.h and include/serenade_hip_internal.h (the srn_debug_* aids) declare: (restype, argtypes)
 _vp, _sz, _u64, _i = C.c_void_p, C.c_size_t, C.c_uint64, C.c_int
 SYMBOLS = {
     "srn_sessions_from_tsv": (_i, [C.c_char_p, C.POINTER(_vp)]),
@@ -93,21 +93,9 @@ SYMBOLS = {
     "srn_index_reserve": (_i, [_vp, _sz, _sz, _sz, _sz, _sz, C.c_uint, _vp]),
     "srn_last_kernel_ms": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     "srn_index_build_shard": (_i, [C.POINTER(SessionsView), _sz, _sz, C.c_double, C.c_uint32, C.c_uint32, _i, C.POINTER(_vp)]),
-    "srn_shard_slot_bytes": (_i, [_vp, _sz, C.POINTER(C.c_uint32)]),
-    "srn_shard_slot_info": (_i, [_vp, _sz, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "srn_index_shard": (_i, [_vp, C.c_uint32, C.c_uint32, _i, C.POINTER(_vp)]),
     "srn_index_build_shard_gpu": (_i, [C.POINTER(SessionsView), _sz, _sz, C.c_double, C.c_uint32, C.c_uint32, _i, C.POINTER(_vp)]),
     "srn_index_load_shard": (_i, [C.c_char_p, C.c_uint32, C.c_uint32, _i, C.POINTER(_vp)]),
-    "srn_shard_stage_b_strided": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint32, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "srn_shard_stage_a": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp]),
-    "srn_shard_stage_b": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "srn_shard_stage_c": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, C.c_uint, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "srn_shard_lists_supported": (_i, [_vp, _sz, _sz, _sz, _sz, C.c_uint, C.POINTER(_i)]),
-    "srn_shard_lists_record_bytes": (_sz, [_sz]),
-    "srn_shard_lists_head": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp, _vp]),
-    "srn_shard_lists_count": (_i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp]),
-    "srn_shard_lists_copy": (_i, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp]),
-    "srn_shard_lists_predict": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, C.c_uint, C.c_uint32, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "srn_shard_group_unique_id": (_i, [_vp, _sz]),
     "srn_shard_group_create": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
     "srn_shard_group_create_with_comm": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),

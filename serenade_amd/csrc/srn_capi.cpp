@@ -337,117 +337,6 @@ int srn_index_load_shard(const char* path, uint32_t shard, uint32_t n_shards, in
         if (rc) { delete ix; return rc; }
         *out = ix; return SRN_OK; });
 }
-int srn_shard_slot_info(const srn_index_t* idx, size_t max_len_hint, uint32_t* out_bytes, uint32_t* out_num_bits) {
-    if (!idx || !idx->dev || !out_bytes || !out_num_bits) return fail(SRN_ENODEV, "index has no device attached");
-    const int b = device_slot_bytes(idx->dev, idx->flat, (uint32_t)max_len_hint, out_num_bits);
-    if (b < 0) return SRN_ERANGE;
-    *out_bytes = (uint32_t)b; return SRN_OK;
-}
-int srn_shard_slot_bytes(const srn_index_t* idx, size_t max_len_hint, uint32_t* out) {
-    if (!idx || !idx->dev || !out) return fail(SRN_ENODEV, "index has no device attached");
-    const int b = device_slot_bytes(idx->dev, idx->flat, (uint32_t)max_len_hint);
-    if (b < 0) return SRN_ERANGE;
-    *out = (uint32_t)b; return SRN_OK;
-}
-static int shard_stage(const srn_index_t* idx, int stage, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq, size_t max_len_hint,
-                       size_t k, size_t m, size_t how_many, unsigned flags, const ShardIO& sh, uint64_t* d_out_ids, double* d_out_scores,
-                       uint32_t* d_out_counts, void* stream) {
-    return guarded([&]() -> int {
-        int rc = check_predict_args(idx, k, m, how_many ? how_many : 1); if (rc) return rc;
-        if (nq == 0) return SRN_OK;
-        if (!d_items_flat || !d_q_off) return fail(SRN_EINVAL, "null buffer");
-        if (nq > 0x7FFFFFFFull) return fail(SRN_ERANGE, "too many queries in one batch");
-        if (max_len_hint == 0 || max_len_hint > SRN_MAX_SESSION_LEN) return fail(SRN_ERANGE, "max_len_hint out of range");
-        LaunchParams p{};
-        p.nq = (uint32_t)nq; p.k = (uint32_t)k; p.m = (uint32_t)m; p.how_many = (uint32_t)(how_many ? how_many : 1); p.flags = flags;
-        p.max_len = (uint32_t)max_len_hint; p.items_flat = d_items_flat; p.q_off = d_q_off;
-        p.out_ids = d_out_ids; p.out_scores = d_out_scores; p.out_counts = d_out_counts;
-        return device_shard_stage(idx->dev, idx->flat, stage, p, sh, stream); });
-}
-int srn_shard_stage_a(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq, size_t max_len_hint,
-                      size_t k, size_t m, void* d_cand, uint32_t* d_cand_cnt, void* stream) {
-    if (!d_cand || !d_cand_cnt) return fail(SRN_EINVAL, "null buffer");
-    ShardIO sh{}; sh.cand = d_cand; sh.cand_cnt = d_cand_cnt;
-    return shard_stage(idx, 1, d_items_flat, d_q_off, nq, max_len_hint, k, m, 0, 0, sh, nullptr, nullptr, nullptr, stream);
-}
-int srn_shard_stage_b(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq, size_t max_len_hint,
-                      size_t k, size_t m, uint32_t n_shards, const void* d_gathered, const uint32_t* d_gathered_cnt,
-                      void* d_nb, uint32_t* d_nb_cnt, int32_t* d_minpos, void* stream) {
-    if (!d_gathered || !d_gathered_cnt || !d_nb || !d_nb_cnt || !d_minpos || n_shards == 0) return fail(SRN_EINVAL, "null buffer");
-    ShardIO sh{}; sh.gathered = d_gathered; sh.gathered_cnt = d_gathered_cnt; sh.n_shards = n_shards; sh.nb = d_nb; sh.nb_cnt = d_nb_cnt; sh.minpos = d_minpos;
-    return shard_stage(idx, 2, d_items_flat, d_q_off, nq, max_len_hint, k, m, 0, 0, sh, nullptr, nullptr, nullptr, stream);
-}
-int srn_shard_stage_b_strided(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq, size_t max_len_hint,
-                              size_t k, size_t m, uint32_t n_shards, size_t gathered_stride, const void* d_gathered, const uint32_t* d_gathered_cnt,
-                              void* d_nb, uint32_t* d_nb_cnt, int32_t* d_minpos, void* stream) {
-    if (!d_gathered || !d_gathered_cnt || !d_nb || !d_nb_cnt || !d_minpos || n_shards == 0 || gathered_stride == 0 || gathered_stride > 0xFFFFFFFFull) return fail(SRN_EINVAL, "null buffer");
-    ShardIO sh{}; sh.gathered = d_gathered; sh.gathered_cnt = d_gathered_cnt; sh.n_shards = n_shards; sh.gathered_stride = (uint32_t)gathered_stride; sh.nb = d_nb; sh.nb_cnt = d_nb_cnt; sh.minpos = d_minpos;
-    return shard_stage(idx, 2, d_items_flat, d_q_off, nq, max_len_hint, k, m, 0, 0, sh, nullptr, nullptr, nullptr, stream);
-}
-int srn_shard_stage_c(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq, size_t max_len_hint,
-                      size_t k, size_t m, size_t how_many, unsigned flags, const void* d_nb, const uint32_t* d_nb_cnt,
-                      const int32_t* d_minpos, uint64_t* d_out_ids, double* d_out_scores, uint32_t* d_out_counts, void* stream) {
-    if (!d_nb || !d_nb_cnt || !d_minpos || !d_out_ids || !d_out_scores || !d_out_counts || how_many == 0) return fail(SRN_EINVAL, "null buffer");
-    ShardIO sh{}; sh.nb = const_cast<void*>(d_nb); sh.nb_cnt = const_cast<uint32_t*>(d_nb_cnt); sh.minpos = const_cast<int32_t*>(d_minpos);
-    return shard_stage(idx, 3, d_items_flat, d_q_off, nq, max_len_hint, k, m, how_many, flags, sh, d_out_ids, d_out_scores, d_out_counts, stream);
-}
-
-// ---- item-sharded index, lists mode (srn_shard.hip) ----
-static int lists_params(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq, size_t max_len_hint, size_t k, size_t m, size_t how_many,
-                        unsigned flags, LaunchParams& p) {
-    int rc = check_predict_args(idx, k, m, how_many); if (rc) return rc;
-    if (!d_items_flat || !d_q_off) return fail(SRN_EINVAL, "null buffer");
-    if (nq > 0x7FFFFFFFull) return fail(SRN_ERANGE, "too many queries in one batch");
-    if (max_len_hint == 0 || max_len_hint > SRN_MAX_SESSION_LEN) return fail(SRN_ERANGE, "max_len_hint out of range");
-    p = LaunchParams{};
-    p.nq = (uint32_t)nq; p.k = (uint32_t)k; p.m = (uint32_t)m; p.how_many = (uint32_t)how_many; p.flags = flags; p.max_len = (uint32_t)max_len_hint;
-    p.items_flat = d_items_flat; p.q_off = d_q_off;
-    return SRN_OK;
-}
-int srn_shard_lists_supported(const srn_index_t* idx, size_t max_len_hint, size_t k, size_t m, size_t how_many, unsigned flags, int* out) {
-    if (!out) return fail(SRN_EINVAL, "null argument");
-    return guarded([&]() -> int {
-        LaunchParams p; const uint64_t dummy = 0; const uint32_t dq = 0;
-        int rc = lists_params(idx, &dummy, &dq, 1, max_len_hint, k, m, how_many, flags, p); if (rc) return rc;
-        *out = device_shard_lists_supported(idx->dev, idx->flat, p) ? 1 : 0;
-        return SRN_OK; });
-}
-size_t srn_shard_lists_record_bytes(size_t max_len_hint) { return device_prep_stride((uint32_t)max_len_hint); }
-int srn_shard_lists_head(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq, size_t max_len_hint, size_t m,
-                         void* d_pos, int32_t* d_head, void* stream) {
-    return guarded([&]() -> int {
-        LaunchParams p; int rc = lists_params(idx, d_items_flat, d_q_off, nq, max_len_hint, 1, m, 1, 0, p); if (rc) return rc;
-        if (!d_pos || !d_head) return fail(SRN_EINVAL, "null buffer");
-        return device_shard_lists_head(idx->dev, p, d_pos, d_head, stream); });
-}
-int srn_shard_lists_count(const srn_index_t* idx, const uint32_t* d_q_off, size_t nq, size_t max_len_hint, const void* d_pos, const int32_t* d_head,
-                          uint32_t* d_kept, int32_t* d_tot, void* stream) {
-    return guarded([&]() -> int {
-        const uint64_t dummy = 0;
-        LaunchParams p; int rc = lists_params(idx, &dummy, d_q_off, nq, max_len_hint, 1, 1, 1, 0, p); if (rc) return rc;
-        if (!d_pos || !d_head || !d_kept || !d_tot) return fail(SRN_EINVAL, "null buffer");
-        return device_shard_lists_count(idx->dev, p, d_pos, d_head, d_kept, d_tot, stream); });
-}
-int srn_shard_lists_copy(const srn_index_t* idx, size_t nq, size_t max_len_hint, const void* d_pos, const uint32_t* d_kept, const int64_t* d_off, uint32_t* d_out, void* stream) {
-    return guarded([&]() -> int {
-        const uint64_t dummy = 0; const uint32_t dq = 0;
-        LaunchParams p; int rc = lists_params(idx, &dummy, &dq, nq, max_len_hint, 1, 1, 1, 0, p); if (rc) return rc;
-        if (!d_pos || !d_kept || !d_off || !d_out) return fail(SRN_EINVAL, "null buffer");
-        return device_shard_lists_copy(idx->dev, p, d_pos, d_kept, (const long long*)d_off, d_out, stream); });
-}
-int srn_shard_lists_predict(const srn_index_t* idx, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq, size_t max_len_hint, size_t k, size_t m,
-                            size_t how_many, unsigned flags, uint32_t n_shards, const uint32_t* d_kept_g, const int64_t* d_off_g, uint64_t shard_stride,
-                            const uint32_t* d_lists_g, const int32_t* d_head, const void* d_pos_local, void* d_records,
-                            uint64_t* d_out_ids, double* d_out_scores, uint32_t* d_out_counts, void* stream) {
-    return guarded([&]() -> int {
-        LaunchParams p; int rc = lists_params(idx, d_items_flat, d_q_off, nq, max_len_hint, k, m, how_many, flags, p); if (rc) return rc;
-        if (n_shards == 0 || !d_kept_g || !d_off_g || !d_lists_g || !d_head || !d_pos_local || !d_records || !d_out_ids || !d_out_scores || !d_out_counts)
-            return fail(SRN_EINVAL, "null buffer");
-        p.out_ids = d_out_ids; p.out_scores = d_out_scores; p.out_counts = d_out_counts;
-        return device_shard_lists_predict(idx->dev, idx->flat, p, n_shards, d_kept_g, (const long long*)d_off_g, shard_stride, d_lists_g, d_head, d_pos_local,
-                                          (char*)d_records, stream); });
-}
-
 int srn_kernel_times(const srn_index_t* idx, uint32_t max_n, double* out_ms_main, double* out_ms_retry, uint32_t* out_n) {
     if (!idx || !idx->dev) return fail(SRN_ENODEV, "index has no device attached");
     if (!out_n) return fail(SRN_EINVAL, "null argument");

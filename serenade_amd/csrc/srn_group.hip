@@ -381,6 +381,7 @@ int group_predict(srn_shard_group* g, const uint64_t* d_items_flat, const uint32
         if (g->calls >= 2) HIP_TRY(hipStreamWaitEvent(sx, s.e_done, 0));
     }
     if (g->calls >= 2) HIP_TRY(hipStreamWaitEvent(user, s.e_done, 0));   // (callers may alternate between streams: the slot's previous user may have run on another one)
+    if (g->timing) HIP_TRY(hipEventRecord(g->e_t[0], sx));
     // head: every shard's view of the evolving positions, the local cuts -> global cuts
     for (size_t i = 0; i < g->shards.size(); ++i) {
         int* h_i = i == 0 ? head : head + (size_t)nq * 3;
@@ -414,6 +415,7 @@ int group_predict(srn_shard_group* g, const uint64_t* d_items_flat, const uint32
         }
         { int rc = all_gather_v(g, 0, s.lists, off_b, cnt_b, sx); if (rc) return rc; }
     }
+    if (g->timing) HIP_TRY(hipEventRecord(g->e_t[1], sx));
     if (overlap) { HIP_TRY(hipEventRecord(g->e_x, sx)); HIP_TRY(hipStreamWaitEvent(user, g->e_x, 0)); }
     // ---- caller's stream: the unsharded launch sequence over every local shard's row fragments ----
     for (size_t i = 0; i < g->shards.size(); ++i) {
@@ -422,14 +424,23 @@ int group_predict(srn_shard_group* g, const uint64_t* d_items_flat, const uint32
         LaunchParams pi = p;
         const bool direct = G == 1;   // one shard: its top-n IS the result
         pi.out_ids = direct ? d_out_ids : (uint64_t*)blk; pi.out_scores = direct ? d_out_scores : (double*)(blk + (size_t)nq * n * 8); pi.out_counts = direct ? d_out_counts : (uint32_t*)(blk + (size_t)nq * n * 16);
+        if (g->timing && i == 0) HIP_TRY(hipEventRecord(g->e_t[2], user));
         HIP_TRY(hipMemsetAsync(pi.out_ids, 0, (size_t)nq * n * 8, user)); HIP_TRY(hipMemsetAsync(pi.out_scores, 0, (size_t)nq * n * 8, user));
         int rc = device_shard_lists_predict(g->shards[i]->dev, g->shards[i]->flat, pi, G, kept_g, off_g, 0ull, lists_g, head, s.pos[i], s.records, user, base_dev, direct); if (rc) return rc;
+        if (g->timing && i == 0) HIP_TRY(hipEventRecord(g->e_t[3], user));
     }
     if (G > 1) {
         int rc = all_gather_blocks(g, 1, s.part, block_bytes, user); if (rc) return rc;
+        if (g->timing) HIP_TRY(hipEventRecord(g->e_t[4], user));
         HIP_TRY(launch_shard_merge_topn(user, s.part, block_bytes, G, nq, n, d_out_ids, d_out_scores, d_out_counts));
+        if (g->timing) HIP_TRY(hipEventRecord(g->e_t[5], user));
     }
     HIP_TRY(hipEventRecord(s.e_done, user));
+    if (g->timing) {   // (measurement runs only: synchronises.  [0] = head + count + copy of ALL local shards incl. the offsets kernels and the one host synchronisation)
+        HIP_TRY(hipEventSynchronize(s.e_done));
+        HIP_TRY(hipEventElapsedTime(&g->last_ms[0], g->e_t[0], g->e_t[1])); HIP_TRY(hipEventElapsedTime(&g->last_ms[1], g->e_t[2], g->e_t[3]));
+        g->last_ms[2] = 0.f; if (G > 1) HIP_TRY(hipEventElapsedTime(&g->last_ms[2], g->e_t[4], g->e_t[5]));
+    }
     ++g->calls;
     const uint32_t me = local ? 0u : (uint32_t)g->rank;
     g->st_queries += nq; g->st_bytes_head += (uint64_t)nq * 12; g->st_bytes_kept += (uint64_t)nq * ML * 4 * (local ? G : 1);

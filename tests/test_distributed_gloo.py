@@ -86,26 +86,6 @@ def test_two_rank_gloo_sharding_and_gather():
         assert g_cnt == [i % (n + 1) for i in range(nq)]
 
 
-def test_merge_topn_orders_by_score_then_unsigned_id():
-    """Final merge of the item-sharded pipeline (serenade_amd.sharded.merge_topn) on CPU tensors."""
-    torch = pytest.importorskip("torch")
-    from serenade_amd.sharded import merge_topn
-    rng = np.random.default_rng(5)
-    G, nq, n = 3, 50, 7
-    ids = rng.integers(1, 2**63, size=(G, nq, n), dtype=np.uint64) * np.uint64(2) + np.uint64(1)     # some above 2^63
-    scores = rng.choice(np.array([0.5, 1.0, 1.5, 2.0, -1.0]), size=(G, nq, n))                        # many ties
-    counts = rng.integers(0, n + 1, size=(G, nq)).astype(np.int32)
-    out_ids, out_sc, out_cnt = merge_topn(torch.from_numpy(ids.view(np.int64)), torch.from_numpy(scores), torch.from_numpy(counts), n)
-    out_ids = out_ids.numpy().view(np.uint64)
-    for q in range(nq):
-        cand = [(float(scores[g, q, j]), int(ids[g, q, j])) for g in range(G) for j in range(counts[g, q])]
-        cand.sort(key=lambda t: (-t[0], t[1]))
-        exp = cand[:n]
-        assert int(out_cnt[q]) == len(exp)
-        assert [int(x) for x in out_ids[q, :len(exp)]] == [e[1] for e in exp]
-        assert out_sc[q, :len(exp)].tolist() == [e[0] for e in exp]
-
-
 def _comm_worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch

@@ -1,24 +1,14 @@
-"""Item-sharded index (north-star multi-GPU mode): the three-stage pipeline must reproduce the unsharded result bit for bit.
-On the 1-GPU test box all shards live on cuda:0: once inside one process (collectives become tensor ops) and once as two
-processes exchanging over torch.distributed (gloo, staged through host memory -- the RCCL path is the same code with
-backend "nccl")."""
-import os
-import socket
-
+"""Item shards (srn_index_shard & co.) under the shard group: row FRAGMENTS of every length in both slot forms, every kernel path of the launch sequence that runs
+over them (fast kernel, general kernel with the merge tree, general kernel with the session hash table), the shard's memory footprint, the three ways to build a
+shard.  All predictions go through srn_shard_group_predict_batch (the stage-level entry points and the Python-driven pipelines of rounds 1-2 are gone) and are
+compared with the CPU oracle and, bit for bit, with the unsharded HIP path.  The group's pipelines and transports themselves: tests/test_gpu_shard_group.py."""
 import numpy as np
 import pytest
 
 from helpers import flatten, random_queries, small_dataset
 
 pytestmark = pytest.mark.gpu
-
-
-def _unsharded(off, items, ts, m_index, max_len, idfw, flat, qoff, k, m, n, business, attrs=None):
-    import serenade_amd as sa
-    gix = sa.VMISIndex.from_sessions(off, items, ts, m_index, max_len, idfw)
-    if attrs is not None:
-        gix.set_attributes(*attrs)
-    return sa.predict_batch(gix, (flat, qoff), k, m, n, business)
+SCORE_RTOL = 1e-12
 
 
 def _to_dev(flat, qoff):
@@ -27,56 +17,55 @@ def _to_dev(flat, qoff):
     return torch.from_numpy(flat.view(np.int64).copy()).to(dev), torch.from_numpy(qoff.view(np.int32).copy()).to(dev)
 
 
-def _check(res, ref):
-    ids, sc, cnt = (x.cpu().numpy() for x in res)
-    r_ids, r_sc, r_cnt = ref
-    assert np.array_equal(cnt.view(np.uint32), r_cnt)
-    assert np.array_equal(ids.view(np.uint64), r_ids)
-    assert np.array_equal(sc, r_sc)          # bit-identical: same integers, same f64 operations
+def _np(res):
+    import torch
+    torch.cuda.synchronize()
+    return res[0].cpu().numpy().view(np.uint64), res[1].cpu().numpy(), res[2].cpu().numpy().view(np.uint32)
 
 
-@pytest.mark.parametrize("n_shards", [2, 3])
-def test_local_shards_match_unsharded(n_shards):
-    from serenade_amd import sharded
-    off, items, ts, ids = small_dataset(51, n_sessions=4000, n_items=400)
-    qs = random_queries(7, ids, 400, max_len=6)
-    flat, qoff = flatten(qs)
-    d_flat, d_off = _to_dev(flat, qoff)
-    for (m_index, k, m, n) in [(200, 50, 200, 21), (60, 20, 40, 64), (200, 500, 500, 100)]:
-        ref = _unsharded(off, items, ts, m_index, 12, 1.0, flat, qoff, k, m, n, False)
-        shards = [sharded.ShardedVMISIndex(off, items, ts, m_index, 12, 1.0, g, n_shards) for g in range(n_shards)]   # built on the GPU, cut per shard
-        infos = [s.info for s in shards]
-        assert sum(i["n_items"] for i in infos) == len(np.unique(items[np.repeat(np.diff(off.astype(np.int64)) <= 12, np.diff(off.astype(np.int64)))]))
-        _check(sharded.predict_batch_sharded_local(shards, d_flat, d_off, len(qs), 6, k, m, n), ref)
+def _check(got, ref, unsharded):
+    ids, sc, cnt = got
+    n = ids.shape[1]
+    assert np.array_equal(cnt, ref["counts"])
+    mask = np.arange(n)[None, :] < ref["counts"][:, None].astype(np.int64)
+    assert np.array_equal(ids[mask], ref["ids"][mask])
+    np.testing.assert_allclose(sc[mask], ref["scores"][mask], rtol=SCORE_RTOL, atol=0)
+    assert np.array_equal(ids, unsharded[0]) and np.array_equal(sc, unsharded[1]) and np.array_equal(cnt, unsharded[2])     # bit-identical: same integers, same f64 operations
 
 
 def test_row_fragments_of_every_length_and_shard_row_memory():
-    """A shard keeps each session's FRAGMENT (the items it owns) in a 16-byte slot, longer fragments continue in an overflow
-    area: rows of up to 80 items over 2 and 5 shards put fragments of 0..40+ items through every branch of that walk.  The
-    shard's HBM footprint must be well under the unsharded index's 64-byte row slots, and a shard refuses plain predictions."""
+    """A shard keeps each session's FRAGMENT (the items it owns) in a 16-byte slot, longer fragments continue in an overflow area: rows of up to 80 items over 2
+    and 5 shards put fragments of 0..40+ items through every branch of the walks.  The shard's HBM footprint must be well under the unsharded index's 64-byte row
+    slots, and a shard refuses plain predictions."""
     import serenade_amd as sa
     from serenade_amd import sharded, capi
+    from oracle import oracle as O
     off, items, ts, ids = small_dataset(57, n_sessions=3000, n_items=500, max_len=80)
     qs = random_queries(17, ids, 300, max_len=8)
     flat, qoff = flatten(qs)
     d_flat, d_off = _to_dev(flat, qoff)
     full = sa.VMISIndex.from_sessions(off, items, ts, 300, 80, 1.0)
+    oix = O.OracleIndex(off, items, ts, 300, 80, 1.0)
     for n_shards in (2, 5):
-        shards = [sharded.ShardedVMISIndex(off, items, ts, 300, 80, 1.0, g, n_shards) for g in range(n_shards)]
+        shards = [sharded.ShardedVMISIndex(off, items, ts, 300, 80, 1.0, g, n_shards) for g in range(n_shards)]       # (built on the GPU, cut per shard)
+        lens = np.diff(off.astype(np.int64))
+        assert sum(s.info["n_items"] for s in shards) == len(np.unique(items[np.repeat(lens <= 80, lens)]))
+        grp = sharded.ShardGroup.local(shards)
         for (k, m, n) in [(100, 300, 21), (500, 500, 50)]:
-            ref = sa.predict_batch(full, (flat, qoff), k, m, n, False)
-            _check(sharded.predict_batch_sharded_local(shards, d_flat, d_off, len(qs), 8, k, m, n), ref)
+            ref = oix.predict_batch("canonical", flat, qoff, k, m, n, False, threads=4)
+            _check(_np(grp.predict_batch(d_flat, d_off, len(qs), 8, k, m, n)), ref, sa.predict_batch(full, (flat, qoff), k, m, n, False))
         assert max(s.info["device_bytes"] for s in shards) < full.info["device_bytes"] * (0.7 if n_shards == 2 else 0.45), (n_shards, [s.info["device_bytes"] for s in shards], full.info["device_bytes"])
         with pytest.raises(capi.SerenadeError):
             out = np.zeros(21, np.uint64); sc = np.zeros(21); cnt = np.zeros(1, np.uint32)
             capi.check(capi.lib().srn_predict_batch(shards[0]._h, flat.ctypes.data, qoff.ctypes.data, 1, 100, 300, 21, 0,
                                                     out.ctypes.data, sc.ctypes.data, cnt.ctypes.data))
+        grp.close()
 
 
 @pytest.fixture(params=["fast", "no_fast", "no_merge"])
 def lists_kernel_path(request, monkeypatch):
-    """The lists pipeline runs the unsharded launch sequence: through the fast kernel (default), the general kernel alone,
-    and the general kernel with the session hash table instead of the merge tree."""
+    """The lists / neighbours pipelines run the unsharded launch sequence over the fragments: through the fast kernel (default), the general kernel alone, and the
+    general kernel with the session hash table instead of the merge tree."""
     from serenade_amd import capi
     if request.param == "no_fast":
         monkeypatch.setenv("SRN_NO_FAST", "1")
@@ -90,119 +79,30 @@ def lists_kernel_path(request, monkeypatch):
 
 
 @pytest.mark.parametrize("n_shards", [1, 2, 5])
-def test_lists_pipeline_matches_unsharded(n_shards, lists_kernel_path):
-    """LISTS mode (srn_shard.hip): the shards exchange the batch's posting lists and every rank runs the unsharded kernels over its
-    row fragments.  Rows of up to 80 items put fragments of 0..40+ items through the 16-byte slots and their overflow blocks, in
-    the fast kernel's packed form and in the general one; m < the lists' lengths exercises the global cut x_lo."""
+def test_every_kernel_path_over_fragments(n_shards, lists_kernel_path):
+    """Rows of up to 80 items put fragments of 0..40+ items through the 16-byte slots and their overflow blocks, in the fast kernel's packed form and in the general
+    one; m < the lists' lengths exercises the global cut x_lo.  With the fast kernel available the group is also run with replicated postings (the neighbours
+    pipeline: front end + back end); without it that pipeline must stand aside (the lists pipeline answers)."""
     import serenade_amd as sa
     from serenade_amd import sharded
+    from oracle import oracle as O
     off, items, ts, ids = small_dataset(58, n_sessions=6000, n_items=500, max_len=80)
     qs = random_queries(18, ids, 600, max_len=8)
     flat, qoff = flatten(qs)
     d_flat, d_off = _to_dev(flat, qoff)
     full = sa.VMISIndex.from_sessions(off, items, ts, 400, 80, 1.0)
+    oix = O.OracleIndex(off, items, ts, 400, 80, 1.0)
     shards = [sharded.ShardedVMISIndex(off, items, ts, 400, 80, 1.0, g, n_shards) for g in range(n_shards)]
-    for (k, m, n) in [(100, 400, 21), (500, 300, 21), (30, 60, 5)]:
-        assert sharded.lists_supported(shards[0], 8, k, m, n)
-        ref = sa.predict_batch(full, (flat, qoff), k, m, n, False)
-        _check(sharded.predict_batch_sharded_lists_local(shards, d_flat, d_off, len(qs), 8, k, m, n), ref)
-    if n_shards == 1:   # the one-rank pipeline as a rank runs it (SoloComm: no merge step)
-        _check(sharded.predict_batch_sharded(shards[0], sharded.SoloComm(), d_flat, d_off, len(qs), 8, 100, 400, 21), sa.predict_batch(full, (flat, qoff), 100, 400, 21, False))
-    assert sharded.lists_supported(shards[0], 8, 100, 400, 21, True)          # business rules: the current item's attribute byte travels with the first all-reduce
-    assert not sharded.lists_supported(shards[0], 12, 100, 400, 21)           # sessions of > 8 items: no position sets
-
-
-def test_lists_pipeline_business_rules():
-    """Business rules in lists mode: the current item's attributes live on its owner shard and reach the others with the first all-reduce."""
-    import serenade_amd as sa
-    from serenade_amd import sharded, synth, capi
-    inter, n_items, k, m, idfw = synth.CONFIGS["tiny"]
-    off, items, ts = synth.training_sessions(inter, n_items)
-    flat, qoff = synth.queries(1500, n_items)
-    d_flat, d_off = _to_dev(flat, qoff)
-    rng = np.random.default_rng(45)
-    known = np.unique(items)
-    flags = rng.choice(np.array([0, 1, 2, 3, 0xFF], np.uint8), size=len(known), p=[0.15, 0.05, 0.5, 0.2, 0.1])
-    full = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw)
-    full.set_attributes(known, flags)
-    ref = sa.predict_batch(full, (flat, qoff), k, m, 21, True)
-    assert not np.array_equal(ref[0], sa.predict_batch(full, (flat, qoff), k, m, 21, False)[0]), "the rules should change something"
-    shards = [sharded.ShardedVMISIndex.from_full(full, g, 3) for g in range(3)]
-    for s in shards:
-        capi.check(capi.lib().srn_index_set_attributes(s._h, capi.ptr(capi.as_u64(known)), capi.ptr(flags), len(known)))
-    nq = len(qoff) - 1
-    _check(sharded.predict_batch_sharded_lists_local(shards, d_flat, d_off, nq, 4, k, m, 21, True), ref)
-    _check(sharded.predict_batch_sharded_local(shards, d_flat, d_off, nq, 4, k, m, 21, True), ref)       # (the three-stage pipeline agrees)
-
-
-def test_lists_entry_points_reject_misuse():
-    """The lists-mode ABI fails loudly: null buffers, zero shards, and a geometry it does not serve (sessions of > 8 items) give error codes, not launches."""
-    import torch
-    from serenade_amd import sharded, capi
-    import ctypes as C
-    off, items, ts, ids = small_dataset(59, n_sessions=800, n_items=100)
-    ix = sharded.ShardedVMISIndex(off, items, ts, 100, 12, 1.0, 0, 2)
-    qs = random_queries(19, ids, 16, max_len=4)
-    flat, qoff = flatten(qs)
-    d_flat, d_off = _to_dev(flat, qoff)
-    nq = len(qs)
-    L = capi.lib()
-    assert L.srn_shard_lists_head(ix._h, C.c_void_p(d_flat.data_ptr()), C.c_void_p(d_off.data_ptr()), nq, 4, 100, None, None, None) == capi.SRN_EINVAL
-    pos, head = sharded._lists_head(ix, d_flat, d_off, nq, 4, 100, 0)
-    kept, offs, total = sharded._lists_count(ix, d_off, nq, 4, pos, head, 0)
-    assert L.srn_shard_lists_copy(ix._h, nq, 4, C.c_void_p(pos.data_ptr()), C.c_void_p(kept.data_ptr()), None, None, None) == capi.SRN_EINVAL
-    out = torch.zeros(nq * 21, dtype=torch.int64, device=d_flat.device); sc = torch.zeros(nq * 21, dtype=torch.float64, device=d_flat.device); cnt = torch.zeros(nq, dtype=torch.int32, device=d_flat.device)
-    rec = torch.empty(nq * int(L.srn_shard_lists_record_bytes(12)), dtype=torch.uint8, device=d_flat.device)
-    flat_l = torch.zeros(64, dtype=torch.int32, device=d_flat.device)
-    args = lambda max_len, n_shards: (ix._h, C.c_void_p(d_flat.data_ptr()), C.c_void_p(d_off.data_ptr()), nq, max_len, 20, 100, 21, 0, n_shards, C.c_void_p(kept.data_ptr()),
-                                      C.c_void_p(offs.data_ptr()), 64, C.c_void_p(flat_l.data_ptr()), C.c_void_p(head.data_ptr()), C.c_void_p(pos.data_ptr()), C.c_void_p(rec.data_ptr()),
-                                      C.c_void_p(out.data_ptr()), C.c_void_p(sc.data_ptr()), C.c_void_p(cnt.data_ptr()), None)
-    assert L.srn_shard_lists_predict(*args(4, 0)) == capi.SRN_EINVAL                       # zero shards
-    assert L.srn_shard_lists_predict(*args(4, 1)) == capi.SRN_EINVAL                       # not the number of shards this index was cut into (ADVICE r2)
-    assert b"n_shards" in L.srn_last_error()
-    assert L.srn_shard_lists_predict(*args(12, 2)) == capi.SRN_EINVAL                      # sessions of > 8 items: no position sets, the three-stage pipeline serves them
-    assert b"three-stage" in L.srn_last_error()
-    torch.cuda.synchronize()
-
-
-def test_lists_pipeline_synthetic_shape():
-    """The production-shaped generator (long lists, popular items, m-cut and k-cut both active) through the lists pipeline on 3 shards."""
-    import serenade_amd as sa
-    from serenade_amd import sharded, synth
-    inter, n_items, k, m, idfw = synth.CONFIGS["tiny"]
-    off, items, ts = synth.training_sessions(inter, n_items)
-    flat, qoff = synth.queries(3000, n_items)
-    d_flat, d_off = _to_dev(flat, qoff)
-    full = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw)
-    ref = sa.predict_batch(full, (flat, qoff), k, m, 21, False)
-    shards = [sharded.ShardedVMISIndex.from_full(full, g, 3) for g in range(3)]
-    _check(sharded.predict_batch_sharded_lists_local(shards, d_flat, d_off, len(qoff) - 1, 4, k, m, 21), ref)
-
-
-def test_local_shards_business_rules_and_synthetic():
-    from serenade_amd import sharded, synth
-    off, items, ts, ids = small_dataset(52, n_sessions=3000, n_items=300)
-    rng = np.random.default_rng(3)
-    known = np.unique(items)
-    flags = rng.choice(np.array([0, 1, 2, 3, 0xFF], np.uint8), size=len(known), p=[0.1, 0.05, 0.55, 0.2, 0.1])
-    qs = random_queries(8, ids, 300, max_len=4, unknown_rate=0.0)
-    flat, qoff = flatten(qs)
-    d_flat, d_off = _to_dev(flat, qoff)
-    ref = _unsharded(off, items, ts, 150, 12, 1.0, flat, qoff, 40, 150, 21, True, attrs=(known, flags))
-    shards = [sharded.ShardedVMISIndex(off, items, ts, 150, 12, 1.0, g, 2) for g in range(2)]
-    import serenade_amd.capi as capi
-    import ctypes as C
-    for s in shards:
-        capi.check(capi.lib().srn_index_set_attributes(s._h, capi.ptr(capi.as_u64(known)), capi.ptr(flags), len(known)))
-    _check(sharded.predict_batch_sharded_local(shards, d_flat, d_off, len(qs), 4, 40, 150, 21, True), ref)
-    # the bench generator's tiny config: u64 hashed ids, k-cut and m-cut hit
-    inter, n_items, k, m, idfw = synth.CONFIGS["tiny"]
-    off, items, ts = synth.training_sessions(inter, n_items)
-    qi, qo = synth.queries(300, n_items)
-    d_flat, d_off = _to_dev(qi, qo)
-    ref = _unsharded(off, items, ts, m, 34, idfw, qi, qo, k, m, 21, False)
-    shards = [sharded.ShardedVMISIndex(off, items, ts, m, 34, idfw, g, 4) for g in range(4)]
-    _check(sharded.predict_batch_sharded_local(shards, d_flat, d_off, len(qo) - 1, 4, k, m, 21), ref)
+    grp = sharded.ShardGroup.local(shards)
+    for with_postings in (False, True):
+        grp.set_postings(full if with_postings else None)
+        for (k, m, n) in [(100, 400, 21), (500, 300, 21), (30, 60, 5)]:
+            ref = oix.predict_batch("canonical", flat, qoff, k, m, n, False, threads=4)
+            _check(_np(grp.predict_batch(d_flat, d_off, len(qs), 8, k, m, n)), ref, sa.predict_batch(full, (flat, qoff), k, m, n, False))
+    st = grp.stats
+    assert st["stage_batches"] == 0                                                       # sessions of <= 8 items, m <= m_index: never the three-stage pipeline
+    assert st["neighbour_batches"] == (3 if lists_kernel_path == "fast" and n_shards > 1 else 0)
+    grp.close()
 
 
 def test_gpu_built_shards_equal_host_built_shards_and_load_from_one_file(tmp_path):
@@ -227,138 +127,22 @@ def test_gpu_built_shards_equal_host_built_shards_and_load_from_one_file(tmp_pat
             assert blobs[0] == blobs[1] == blobs[2] == blobs[3], (G, g)
 
 
-def test_candidate_compaction_ships_less_and_changes_nothing():
-    """All-gather #1 compacted to the entries at or above the global m-th rank: same results with and without, and
-    the slabs are narrower than m when the shards' lists overlap in recency."""
-    import torch
+def test_synthetic_shape_through_four_shards_both_pipelines():
+    """The production-shaped generator (long lists, popular items, m-cut and k-cut both active; u64 hashed ids) through 4 shards: lists pipeline, then neighbours."""
+    import serenade_amd as sa
     from serenade_amd import sharded, synth
+    from oracle import oracle as O
     inter, n_items, k, m, idfw = synth.CONFIGS["tiny"]
     off, items, ts = synth.training_sessions(inter, n_items)
-    qi, qo = synth.queries(400, n_items)
-    d_flat, d_off = _to_dev(qi, qo)
-    nq = len(qo) - 1
+    flat, qoff = synth.queries(3000, n_items)
+    d_flat, d_off = _to_dev(flat, qoff)
+    full = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw)
+    oix = O.OracleIndex(off, items, ts, m, 34, idfw, fast=True)
+    ref = oix.predict_batch("canonical", flat, qoff, k, m, 21, False, threads=4)
+    u = sa.predict_batch(full, (flat, qoff), k, m, 21, False)
     shards = [sharded.ShardedVMISIndex(off, items, ts, m, 34, idfw, g, 4) for g in range(4)]
-    a = sharded.predict_batch_sharded_local(shards, d_flat, d_off, nq, 4, k, m, 21, compact=True)
-    b = sharded.predict_batch_sharded_local(shards, d_flat, d_off, nq, 4, k, m, 21, compact=False)
-    for x, y in zip(a, b):
-        assert torch.equal(x, y)
-    ref = _unsharded(off, items, ts, m, 34, idfw, qi, qo, k, m, 21, False)
-    _check(a, ref)
-    stream = torch.cuda.current_stream().cuda_stream
-    sbytes, nbits = shards[0].slot_info(4)
-    dtype = torch.int32 if sbytes == 4 else torch.int64
-    st = [sharded._stage_a(ix, d_flat, d_off, nq, 4, k, m, dtype, stream) for ix in shards]
-    loc = [sharded._local_mth_rank(x[0], x[1], nq, m, sbytes, nbits) for x in st]
-    tau = torch.stack([l[0] for l in loc]).max(dim=0).values
-    kept = [sharded._keep_at_or_above(x[0], x[1], l[1], l[2], tau, nq, m)[1] for x, l in zip(st, loc)]
-    before = sum(int(x[1].clamp(min=0).sum()) for x in st)
-    after = sum(int(kc.clamp(min=0).sum()) for kc in kept)
-    assert after < before, (before, after)
-
-
-def _nccl_worker(port, q):
-    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    try:
-        import torch
-        import torch.distributed as dist
-        from serenade_amd import sharded
-        dev = torch.device("cuda:0")
-        torch.cuda.set_device(dev)
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)       # RCCL, one rank: the device_id= init path
-        comm = sharded.DistComm()
-        assert comm.world == 1 and not comm.staged                                  # device tensors go straight to RCCL
-        off, items, ts, ids = small_dataset(55, n_sessions=3000, n_items=300)
-        qs = random_queries(9, ids, 200, max_len=5)
-        flat, qoff = flatten(qs)
-        d_flat, d_off = _to_dev(flat, qoff)
-        ix = sharded.ShardedVMISIndex(off, items, ts, 150, 12, 1.0, 0, 1, device=0)
-        res = sharded.predict_batch_sharded(ix, comm, d_flat, d_off, len(qs), 5, 40, 150, 21, mode="lists")
-        res2 = sharded.predict_batch_sharded(ix, comm, d_flat, d_off, len(qs), 5, 40, 150, 21, mode="stages")
-        assert all(torch.equal(a, b) for a, b in zip(res, res2)), "the two pipelines disagree"
-        # and the exchange steps of a multi-rank run on device buffers: all-reduce(max), all-reduce(min), all-gather
-        t = torch.arange(1000, dtype=torch.int64, device=dev)
-        assert torch.equal(comm.all_reduce_max(t.clone()), t) and torch.equal(comm.all_reduce_min(t.to(torch.int32).clone()), t.to(torch.int32))
-        assert torch.equal(comm.all_gather(t)[0], t)
-        sb, nb = ix.slot_info(5)
-        c, cc, w = sharded.compact_candidates(*sharded._stage_a(ix, d_flat, d_off, len(qs), 5, 40, 150, torch.int32 if sb == 4 else torch.int64,
-                                                                torch.cuda.current_stream().cuda_stream), len(qs), 150, sb, nb, comm.all_reduce_max)
-        assert c.shape == (len(qs), w) and w <= 150
-        torch.cuda.synchronize()
-        q.put([x.cpu().numpy() for x in res])
-        dist.destroy_process_group()
-    except Exception as e:  # pragma: no cover
-        import traceback
-        q.put("error: %r\n%s" % (e, traceback.format_exc()))
-
-
-def test_single_rank_nccl_group_runs_the_rccl_code_path():
-    """backend "nccl" IS RCCL on ROCm.  With one GPU on the test box a 1-rank group is what can run: process-group init with
-    device_id=, all_gather_into_tensor / all_reduce(MIN | MAX) on device buffers through DistComm's non-staged branch, and the
-    whole sharded pipeline over it -- bit-identical to the unsharded result."""
-    mp = pytest.importorskip("torch.multiprocessing")
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    p = ctx.Process(target=_nccl_worker, args=(port, q))
-    p.start()
-    res = q.get(timeout=600)
-    p.join(timeout=120)
-    assert not isinstance(res, str), res
-    off, items, ts, ids = small_dataset(55, n_sessions=3000, n_items=300)
-    qs = random_queries(9, ids, 200, max_len=5)
-    flat, qoff = flatten(qs)
-    ref = _unsharded(off, items, ts, 150, 12, 1.0, flat, qoff, 40, 150, 21, False)
-    assert np.array_equal(res[2].view(np.uint32), ref[2]) and np.array_equal(res[0].view(np.uint64), ref[0]) and np.array_equal(res[1], ref[1])
-
-
-def _worker(rank, world, port, q):
-    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    try:
-        import torch
-        import torch.distributed as dist
-        from serenade_amd import distributed as D
-        from serenade_amd import sharded
-        D.init("gloo")
-        off, items, ts, ids = small_dataset(53, n_sessions=3000, n_items=300)
-        qs = random_queries(9, ids, 200, max_len=5)
-        flat, qoff = flatten(qs)
-        d_flat, d_off = _to_dev(flat, qoff)
-        ix = sharded.ShardedVMISIndex(off, items, ts, 150, 12, 1.0, rank, world, device=0)
-        assert sharded.lists_supported(ix, 5, 40, 150, 21)
-        res = sharded.predict_batch_sharded(ix, sharded.DistComm(), d_flat, d_off, len(qs), 5, 40, 150, 21)                       # (auto: the lists pipeline)
-        res2 = sharded.predict_batch_sharded(ix, sharded.DistComm(), d_flat, d_off, len(qs), 5, 40, 150, 21, mode="stages")
-        torch.cuda.synchronize()
-        assert all(torch.equal(a, b) for a, b in zip(res, res2)), "the two pipelines disagree"
-        q.put((rank, [x.cpu().numpy() for x in res]))
-        D.barrier()
-        dist.destroy_process_group()
-    except Exception as e:  # pragma: no cover
-        import traceback
-        q.put((rank, "error: %r\n%s" % (e, traceback.format_exc())))
-
-
-def test_two_process_sharded_pipeline_over_torch_distributed():
-    mp = pytest.importorskip("torch.multiprocessing")
-    world = 2
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    out = [q.get(timeout=600) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=120)
-    off, items, ts, ids = small_dataset(53, n_sessions=3000, n_items=300)
-    qs = random_queries(9, ids, 200, max_len=5)
-    flat, qoff = flatten(qs)
-    ref = _unsharded(off, items, ts, 150, 12, 1.0, flat, qoff, 40, 150, 21, False)
-    for rank, res in out:
-        assert not isinstance(res, str), res
-        assert np.array_equal(res[2].view(np.uint32), ref[2])
-        assert np.array_equal(res[0].view(np.uint64), ref[0])
-        assert np.array_equal(res[1], ref[1])
+    grp = sharded.ShardGroup.local(shards)
+    _check(_np(grp.predict_batch(d_flat, d_off, len(qoff) - 1, 4, k, m, 21)), ref, u)
+    grp.set_postings(sharded.postings_view(full))
+    _check(_np(grp.predict_batch(d_flat, d_off, len(qoff) - 1, 4, k, m, 21)), ref, u)
+    assert grp.stats["neighbour_batches"] == 1 and grp.stats["bytes_lists"] > 0

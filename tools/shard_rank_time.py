@@ -1,4 +1,4 @@
-"""What ONE rank of a G-way item-sharded index does per batch in the NEIGHBOURS pipeline, measured on one GPU: all G shards of the config in this process (an
+"""What ONE rank of a G-way item-sharded index does per batch, measured on one GPU, for the LISTS pipeline (first) and the NEIGHBOURS pipeline: all G shards of the config in this process (an
 in-process group: the all-gathers degenerate), SRN_GROUP_TIMING events around shard 0's own launches -- prep records of the whole batch + the front end over its
 1 / G of the queries | the back end over ALL queries on its row fragments (fast kernel back end + general kernel over the handed-over queries + finish kernels) | the
 top-n merge.  The exchanges themselves are not in it (no second GPU here): their payload is printed.
@@ -28,9 +28,19 @@ dev = torch.device("cuda:0")
 d_flat = torch.from_numpy(qi.view(np.int64).copy()).to(dev); d_off = torch.from_numpy(qo.view(np.int32).copy()).to(dev)
 L, n = synth.LAST_ITEMS, synth.HOW_MANY
 grp = SH.ShardGroup.local(shards)
-ref = grp.predict_batch(d_flat, d_off, B, L, k, m, n)          # the lists pipeline's answers
-torch.cuda.synchronize()
+lres = []
+for it in range(4):
+    ref = grp.predict_batch(d_flat, d_off, B, L, k, m, n)          # the lists pipeline
+    torch.cuda.synchronize()
+    t3 = (C.c_double * 3)()
+    capi.check(capi.lib().srn_debug_shard_group_times(grp._h, t3))
+    lres.append(list(t3))
 ref = [x.clone() for x in ref]
+la = np.median(np.array(lres[1:]), axis=0)
+stl = grp.stats
+print("%s G=%d batch %d, LISTS pipeline, one rank: head + count + copy %.3f ms (all %d local shards' / %d) | prep + launch sequence over the gathered lists %.3f ms | merge %.3f ms -> %.3f ms per batch = %.2f M queries/s "
+      "per batch stream without the exchanges; list prefixes exchanged: %.0f B/query sent per rank" % (cfg, G, B, la[0] / G, G, G, la[1], la[2], la[0] / G + la[1] + la[2], B / (la[0] / G + la[1] + la[2]) / 1e3,
+                                                                                                      stl["bytes_lists"] / max(1, stl["queries"]) / G))
 grp.set_postings(post)
 capi.check(capi.lib().srn_kernel_timing(shards[0]._h, 1))
 res = []
