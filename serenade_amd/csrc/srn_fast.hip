@@ -748,7 +748,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             {
                 const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
                 const uint4* h4 = reinterpret_cast<const uint4*>(hot);
-                static_assert(F_HOT_WORDS == 4096, "quads per thread below");
+                static_assert(F_HOT_WORDS == 4096 || F_HOT_WORDS == 3840, "quads per thread below (3840: the 40 KB timing experiment)");
                 constexpr uint32_t NQ2 = F_HOT_WORDS / 4u - 128u - (uint32_t)BLOCK;   // quads of the second round (384 for 4096 words)
                 const uint4 a4 = h4[128u + tid];
                 const uint4 b4 = tid < NQ2 ? h4[128u + (uint32_t)BLOCK + tid] : make_uint4(0u, 0u, 0u, 0u);
@@ -994,7 +994,11 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             uint4* rec = reinterpret_cast<uint4*>(f.fin + (size_t)q * F_FIN_BYTES);
             uint4* ovf = reinterpret_cast<uint4*>(f.big_arena) + ovf_at;
             if (ln == 0u) { rec[0] = make_uint4(M, U, ovf_at, 0u); p.out_counts[q] = M > F_FIN_ENTRIES ? 0x80000001u : 0x80000000u; }   // (flags: a finish kernel completes the row)
+#ifdef SRN_FAST_EXP_NOHANDOFF   // experiment (timing only, wrong results): what the serial copy of the candidates costs
+            for (uint32_t i = ln; i < 0u; i += 64u) {
+#else
             for (uint32_t i = ln; i < M; i += 64u) {
+#endif
                 uint4 e;
                 if (i < cnt) { const unsigned long long x = ckey[i]; e = make_uint4((uint32_t)x, (uint32_t)(x >> 32), cidx[i], 0u); }
                 else { const uint2 c = tl[i - cnt]; e = make_uint4(c.y, 0u, c.x, 1u); }

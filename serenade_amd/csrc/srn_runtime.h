@@ -32,6 +32,7 @@ struct Knobs {
     bool timing = false;      // SRN_TIMING: kernel timing on from the start (srn_kernel_timing switches it per index)
     int d2h_blocks = 0;       // SRN_D2H_BLOCKS: workgroups of the chunked host path's own download kernel (0 = hipMemcpyAsync, the default: measured faster, profiles/r03_host_pipe_probe.txt)
     int tiny_max = 256;       // SRN_TINY_MAX: host-pointer batches of up to this many sessions take the zero-copy latency path
+    int row_slots16 = -1;     // SRN_ROW_SLOTS = 16 | 64: the device row layout (-1 = by index kind: 64-byte slots unsharded, 16-byte fragment slots for item shards)
     int lanes = 4;            // SRN_PREDICT_LANES: concurrent rounds of the srn_predict combiner (srn_combine.cpp)
     bool geometry_default() const { return !no_masks && !no_merge && !dense && hot_slots < 0 && sketch_slots < 0 && lds_budget_kb == 0; }
 };

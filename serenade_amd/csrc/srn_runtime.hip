@@ -22,6 +22,7 @@ static void knobs_read() {
     Knobs k;
     k.no_masks = getenv("SRN_NO_MASKS") != nullptr; k.no_merge = getenv("SRN_NO_MERGE") != nullptr; k.dense = getenv("SRN_DENSE") != nullptr;
     k.no_fast = getenv("SRN_NO_FAST") != nullptr; k.debug = getenv("SRN_DEBUG") != nullptr;
+    if (const char* e = getenv("SRN_ROW_SLOTS")) k.row_slots16 = atoi(e) == 16 ? 1 : atoi(e) == 64 ? 0 : -1;
     if (const char* e = getenv("SRN_HOT_SLOTS")) k.hot_slots = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_SKETCH_SLOTS")) k.sketch_slots = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_LDS_BUDGET_KB")) k.lds_budget_kb = std::max(0, atoi(e));
@@ -69,7 +70,8 @@ DeviceState* device_attach(const FlatIndex& ix, int device) {
     d->di.post_off = upload(d, ix.post_off, ok); d->di.post_rank = upload(d, ix.post_rank, ok);
     if (ok && !ix.postings_only) {   // rows -> 64-byte slots (+ overflow area) on the device, see DeviceIndex and rows_to_slots_kernel
         // item shards: 16-byte FRAGMENT slots (a shard holds ~1/n_shards of a row's items), DeviceIndex::row_frag
-        const bool frag = ix.n_shards > 1;
+        const int rs16 = knobs().row_slots16;
+        const bool frag = rs16 >= 0 ? rs16 == 1 : ix.n_shards > 1;   // (SRN_ROW_SLOTS=16|64 forces a form: experiments)
         const uint64_t inl = frag ? 2 : 14;            // items inline in a slot that also carries an overflow offset
         const size_t slot_bytes = frag ? 16 : 64;
         const size_t n = ix.n_kept, nblocks = (n + 1 + 1023) / 1024;
