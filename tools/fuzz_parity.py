@@ -77,7 +77,7 @@ while time.time() < t_end and rounds < max_rounds:
             torch.cuda.synchronize()
             check((r_ids.cpu().numpy().view(np.uint64).reshape(nq_all, n), r_sc.cpu().numpy().reshape(nq_all, n), r_cnt.cpu().numpy().view(np.uint32)), ref, n, "device batch", cfg)
             if rep == 0:
-                G = int(rng.choice([1, 2, 3, 5]))
+                G = int(rng.choice([1, 2, 3, 5, 8]))
                 shards = [sharded.ShardedVMISIndex.from_full(gix, g, G) for g in range(G)]
                 if business:
                     for s_ in shards:
@@ -86,6 +86,13 @@ while time.time() < t_end and rounds < max_rounds:
                 res = grp.predict_batch(d_f, d_o, nq_all, max_q, k, m, n, business)
                 torch.cuda.synchronize()
                 check((res[0].cpu().numpy().view(np.uint64), res[1].cpu().numpy(), res[2].cpu().numpy().view(np.uint32)), ref, n, "shard group x%d (stage batches %d)" % (G, grp.stats["stage_batches"]), cfg)
+                # round 4: the same group with replicated postings (the neighbours pipeline where the batch's shape allows it; the lists / three-stage pipelines otherwise)
+                post = gix if rng.random() < 0.5 else sharded.postings_view(gix)
+                grp.set_postings(post)
+                for rep2 in range(2):
+                    res = grp.predict_batch(d_f, d_o, nq_all, max_q, k, m, n, business, resident=bool(rep2))
+                    torch.cuda.synchronize()
+                    check((res[0].cpu().numpy().view(np.uint64), res[1].cpu().numpy(), res[2].cpu().numpy().view(np.uint32)), ref, n, "shard group x%d with postings (neighbour batches %d)" % (G, grp.stats["neighbour_batches"]), cfg)
                 grp.close()
         except capi.SerenadeError as e:
             if e.code != capi.SRN_ERANGE:
