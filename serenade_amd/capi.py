@@ -112,6 +112,7 @@ SYMBOLS = {
     "srn_kernel_times_detail": (_i, [_vp, C.c_uint32, _vp, _vp, _vp, _vp, C.POINTER(C.c_uint32)]),
     "srn_debug_phase_cycles": (_i, [_vp, _i, _vp]),
     "srn_debug_reload_knobs": (None, []),
+    "srn_debug_last_mid_count": (_i, [_vp, C.POINTER(C.c_uint32)]),
     "srn_last_path_counts": (_i, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "srn_device_count": (_i, [C.POINTER(_i)]),
     "srn_limits": (None, [C.POINTER(Limits)]),

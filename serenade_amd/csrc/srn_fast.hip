@@ -292,8 +292,15 @@ __device__ __forceinline__ uint32_t fast_cut(const uint32_t* F, uint32_t* nbl, u
 // (vmis_index.rs:325-415: lists -> merge tree -> cuts), the neighbour list goes to an exchange buffer -- K, then K packed slots -- instead of into the walks, for the
 // queries [f.q_base, p.nq) this rank fronts; FM_BACK = predict's scoring (mod.rs:126-214) from a neighbour list found by ANY rank: the list is read from the exchange
 // buffer, the weight table rebuilt from the query's own prep record (same record on every rank: same table), then the fused kernel's walks unchanged.
+// MID (round 4, the tier between this kernel and vmis_predict_kernel): evolving sessions of <= 10 items with <= 8 lists and numerators up to 63 -- the reference's whole
+// hyper-parameter grid of last_items_in_session (1, 2, 3, 5, 10: src/hyperparameter/hyperparamgrid.rs:93-139) instead of the <= 4 lists / numerators <= 15 of the lean
+// form.  Same LDS map, same walks; what differs: the queries come from a device-side list (f.mid_list, filled by the lean instantiation's hand-overs), slots carry as many
+// list bits as the query has lists (ranks counted from the cut x_lo), the lists are staged four at a time, a three-level merge tree with the run lengths in SGPRs, the
+// two-pass cuts with a 64-bin class histogram in LDS (lane v = class v), no record prefetch.  A session of 10 items can see weight 0 (linear_score(10), mod.rs:110-116):
+// its zero-weight neighbours add nothing, and a query whose positive-score items do not fill the top n -- the only case in which a zero-score item can be returned --
+// goes to the general kernel.
 enum { FM_FUSED = 0, FM_FRONT = 1, FM_BACK = 2 };
-template <int WG_PER_CU, bool FRAG, bool WIDE, int MODE = FM_FUSED>
+template <int WG_PER_CU, bool FRAG, bool WIDE, int MODE = FM_FUSED, bool MID = false>
 #ifndef SRN_FAST_WAVES
 #define SRN_FAST_WAVES (WG_PER_CU * 2)
 #endif
@@ -313,6 +320,9 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
     const __attribute__((address_space(4))) LaunchParams& p = *(const __attribute__((address_space(4))) LaunchParams*)(ka + OFF_P);
     const __attribute__((address_space(4))) FastParams& f = *(const __attribute__((address_space(4))) FastParams*)(ka + OFF_F);
     constexpr int BLOCK = 512, NW = 8;
+    constexpr int NL = MID ? (int)F_MID_LISTS : 4;             // lists a query may have
+    constexpr uint32_t SINV = MID ? F_SINV_MID : F_SINV;       // idf bounds of the integer floors (MID: the weight table takes all of F_W10)
+    static_assert(!MID || MODE == FM_FUSED, "MID: fused form only");
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
 
@@ -346,22 +356,24 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
     bool have_pre = false;   // block-uniform
     { const ItemMeta m0 = f.meta_sample[tid];
       ((double*)(smem + F_SIDF))[tid] = m0.idf > 0.0 ? m0.idf : 1.0; ((uint8_t*)(smem + F_SATTR))[tid] = (uint8_t)m0.attr;   // (own slot only: no barrier)
-      if (tid < 16u) ((double*)(smem + F_SINV))[tid] = tid < 8u ? f.inv_idf_hot[tid] : f.inv_idf_hi; }   // (read in phase 4a: barriers in between)
-    for (uint32_t q = (MODE == FM_FRONT ? f.q_base : 0u) + blockIdx.x; q < p.nq; q += gridDim.x) {
+      if (tid < 16u) ((double*)(smem + SINV))[tid] = tid < 8u ? f.inv_idf_hot[tid] : f.inv_idf_hi; }   // (read in phase 4a: barriers in between)
+    const uint32_t q_end = MID ? *f.mid_cnt : p.nq;   // (MID: the list is final -- the lean instantiation's launch is over)
+    for (uint32_t qi = (MODE == FM_FRONT ? f.q_base : 0u) + blockIdx.x; qi < q_end; qi += gridDim.x) {
+        const uint32_t q = MID ? f.mid_list[qi] : qi;
         long long t_prev = ticking ? clock64() : 0;
         // ---- phase 0: the query's prep record -> run descriptors in SGPRs ------------------------------
         const char* const rec = p.prep + (size_t)q * p.prep_stride;
         struct { uint32_t U, rmax, xlo, sumw, L, n_staged, cur_attr; } hd;
         constexpr uint32_t HW = (uint32_t)sizeof(PrepHead) / 4u;   // record words before the items
         struct { uint32_t idx, kept; unsigned long long base; } x0{kNone, 0u, 0ull};
-        if (have_pre) {
+        if (!MID && have_pre) {
             auto uni = [&](uint32_t w) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)pre[w]); };   // (SGPRs: the branches on these stay scalar)
             hd.U = uni(0); hd.rmax = uni(1); hd.xlo = uni(2); hd.sumw = uni(3); hd.L = uni(6); hd.n_staged = uni(7); hd.cur_attr = uni(16);
             if (lane < 8u && lane < hd.L) { const uint32_t* it = pre + HW + 6u * lane; x0.idx = it[0]; x0.kept = it[3]; x0.base = ((unsigned long long)it[5] << 32) | it[4]; }
         } else {
             const PrepHead h0 = *(const PrepHead*)rec;   // (uniform address)
             hd.U = h0.U; hd.rmax = h0.rmax; hd.xlo = h0.xlo; hd.sumw = h0.sumw; hd.L = h0.L; hd.n_staged = h0.n_staged; hd.cur_attr = h0.cur_attr;
-            if (lane < 8u && lane < hd.L) { const PrepItem pi = ((const PrepItem*)(rec + sizeof(PrepHead)))[lane]; x0.idx = pi.idx; x0.kept = pi.kept; x0.base = pi.base; }
+            if ((MID ? lane < 16u && lane < p.max_len : lane < 8u) && lane < hd.L) { const PrepItem pi = ((const PrepItem*)(rec + sizeof(PrepHead)))[lane]; x0.idx = pi.idx; x0.kept = pi.kept; x0.base = pi.base; }
         }
         have_pre = false;
         const uint32_t L = hd.L, n = hd.n_staged, U = hd.U;
@@ -372,19 +384,25 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         const uint32_t nr = (uint32_t)__popcll(rm);
         // Slot = (rank - base) << NB | set of lists.  Normally NB = 4 (WIDE, above 2^28 sessions: 3) and base = 0.  A query with MORE lists than bits
         // (4 lists on an index of > 2^28 sessions) takes NB = 4 with the ranks counted from the cut x_lo -- every staged entry is >= x_lo -- if that fits 28 bits.
-        const bool rel = WIDE && nr > 3u;   // (block-uniform)
-        const uint32_t NB = WIDE && !rel ? 3u : 4u, NBM = (1u << NB) - 1u, base = rel ? hd.xlo : 0u;
-        const bool fits = L >= 1u && L <= 8u && L <= p.max_len && hd.sumw <= 15u && nr <= 4u && 2u * n + 8u <= F_MERGE_WORDS && (!rel || hd.rmax - hd.xlo < (1u << 28));
+        const bool rel = MID || (WIDE && nr > 3u);   // (block-uniform)
+        const uint32_t NB = MID ? max(nr, 4u) : WIDE && !rel ? 3u : 4u, NBM = (1u << NB) - 1u, base = rel ? hd.xlo : 0u;
+        // (MID: the last 256 words of the merge buffers' room hold the class histogram of the k-cut)
+        const bool fits = MID ? L >= 1u && L <= F_MID_LMAX && L <= p.max_len && hd.sumw <= F_MID_CLASSES && nr <= F_MID_LISTS && 2u * n + 8u + 256u <= F_MERGE_WORDS && hd.rmax - hd.xlo < (1u << (32u - NB))
+                              : L >= 1u && L <= 8u && L <= p.max_len && hd.sumw <= 15u && nr <= 4u && 2u * n + 8u <= F_MERGE_WORDS && (!rel || hd.rmax - hd.xlo < (1u << 28));
         uint32_t* const xq = MODE == FM_FUSED ? nullptr : f.xchg + (size_t)q * f.xchg_stride;   // this query's place in the exchange buffer: K | K slots
         if (!fits) {   // block-uniform: the general kernel takes it
             if constexpr (MODE == FM_FRONT) { if (tid == 0) xq[0] = 0xFFFFFFFFu; }   // (every rank's back end reads the marker and hands the query to its general kernel)
-            else if (tid == 0) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q;
+            else if (tid == 0) {
+                // (the MID instantiation looks at the query next, if this launch sequence has one; it decides for itself)
+                if (!MID && MODE == FM_FUSED && f.mid_list != nullptr && L >= 1u && L <= F_MID_LMAX && L <= p.max_len) f.mid_list[atomicAdd(f.mid_cnt, 1u)] = q;
+                else f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q;
+            }
             continue;
         }
         if (n == 0u) { if (tid == 0) { if constexpr (MODE == FM_FRONT) xq[0] = 0u; else p.out_counts[q] = 0u; } continue; }   // no known item (vmis_index.rs:350): empty result
-        uint32_t kp[4], ps[4]; const uint32_t* src[4];
+        uint32_t kp[NL], ps[NL]; const uint32_t* src[NL];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < NL; ++r) {
             const int l = rm ? __ffsll((long long)rm) - 1 : 0;
             kp[r] = rm ? (uint32_t)__builtin_amdgcn_readlane((int)x0.kept, l) : 0u;
             const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x0.base, l), bhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x0.base >> 32), l);
@@ -426,6 +444,15 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         if (tid < (uint32_t)FS_TACC) misc[tid] = 0;
         // A slot's low bits are the set of RUNS (not evolving positions) that hold the session: <= 4 runs, so 4 bits (3 above 2^28 sessions, see NB above) whatever the
         // session length, and 28 (29) bits for the rank.  Runs are numbered in position order, so the lowest set run is the first match (Q4).
+        if constexpr (MID) {
+            if (tid < (1u << nr)) {   // (<= 256 list sets; 10 * linear_score(first match) = 9 - mp: 0 at the tenth position)
+                uint32_t num = 0u, mp = ps[0];
+                const uint32_t lo = tid ? (uint32_t)__ffs((int)tid) - 1u : 0u;
+#pragma unroll
+                for (int r = 0; r < NL; ++r) { num += ((tid >> r) & 1u) ? L - ps[r] : 0u; mp = lo == (uint32_t)r ? ps[r] : mp; }
+                wlut[tid] = (uint8_t)num; w10t[tid] = (uint16_t)((9u - mp) * num);
+            }
+        } else
         if (tid < (1u << nr)) {
             const uint32_t num = ((tid & 1u) ? L - ps[0] : 0u) + ((tid & 2u) ? L - ps[1] : 0u) + ((tid & 4u) ? L - ps[2] : 0u) + ((tid & 8u) ? L - ps[3] : 0u);
             const uint32_t lo = tid ? (uint32_t)__ffs((int)tid) - 1u : 0u;
@@ -449,6 +476,60 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         // (B1 is the LOWER half: the m-cut's output D lands there, on top of the neighbour list's own words -- where no k-cut follows, D is the neighbour list as it stands)
         uint32_t* const B1 = (uint32_t*)(smem + F_WORK); uint32_t* const B0 = B1 + n;
         static_assert(F_WORK == F_NBL, "the m-cut writes the neighbour list in place");
+        if constexpr (MID) {
+            // lists 0..3 are in flight since before the barrier; the others take one more round trip (only queries of > 4 lists pay it).  Everything is staged into ONE
+            // buffer at the lists' prefix offsets, the one from which nlev merge levels end in B0.
+            const uint32_t nlev = nr <= 2u ? 1u : nr <= 4u ? 2u : 3u;
+            uint32_t* const X = (nlev & 1u) ? B1 : B0; uint32_t* const Y = (nlev & 1u) ? B0 : B1;
+            uint32_t pre_r[NL];
+            { uint32_t a = 0u;
+#pragma unroll
+              for (int r = 0; r < NL; ++r) { pre_r[r] = a; a += kp[r]; } }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) { const uint32_t e = tid + j * BLOCK; if ((uint32_t)j * BLOCK < kp[r] && e < kp[r]) X[pre_r[r] + e] = ((v[r][j] - base) << NB) | (1u << r); }
+            if (nr > 4u) {   // (block-uniform)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) { v[r][j] = 0u; if ((uint32_t)j * BLOCK < kp[4 + r]) v[r][j] = src[4 + r][min(tid + j * BLOCK, kp[4 + r] - 1u)]; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) asm volatile("" : "+v"(v[r][j]));   // (all loads out before the first is packed, as above)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) { const uint32_t e = tid + j * BLOCK; if ((uint32_t)j * BLOCK < kp[4 + r] && e < kp[4 + r]) X[pre_r[4 + r] + e] = ((v[r][j] - base) << NB) | (16u << r); }
+            }
+            __syncthreads();
+            FAST_TICK(1);
+            // merge tree: <= 3 levels of adjacent pairs; a level's pairs go to consecutive thread teams (sized as in the lean form; teams wrap around the workgroup: a
+            // wave that belongs to two teams merges one pair after the other), a run without a partner is copied (merge with an empty run)
+            uint32_t len[NL];
+#pragma unroll
+            for (int r = 0; r < NL; ++r) len[r] = kp[r];
+            uint32_t runs = nr; const uint32_t* in = X; uint32_t* out = Y;
+#pragma unroll
+            for (int lev = 0; lev < 3; ++lev) {
+                if ((uint32_t)lev < nlev) {   // (block-uniform)
+                    uint32_t off = 0u, start = 0u;
+#pragma unroll
+                    for (int j = 0; j < (NL >> (lev + 1)); ++j) {
+                        if (2u * (uint32_t)j < runs) {
+                            const uint32_t la = len[2 * j], lb = 2u * (uint32_t)j + 1u < runs ? len[2 * j + 1] : 0u;
+                            const uint32_t lg = merge_team(la + lb);
+                            merge_pair(in, out, off, la, lb, (tid - start) & 511u, lg);
+                            start = (start + (1u << lg)) & 511u; off += la + lb; len[j] = la + lb;
+                        }
+                    }
+                    runs = (runs + 1u) >> 1;
+                    uint32_t* const t = const_cast<uint32_t*>(in); in = out; out = t;
+                    __syncthreads();
+                }
+            }
+        } else {
         const uint32_t nl = (nr > 1u) + (nr > 2u);
         {
             uint32_t* const d01 = nl == 1u ? B1 : B0; uint32_t* const d2 = nr == 3u ? B1 : B0;
@@ -467,10 +548,11 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         else if (nr == 3u) { merge_pair(B0, B1, 0u, kp[0], kp[1], tid, merge_team(s2)); __syncthreads(); merge_pair(B1, B0, 0u, s2, kp[2], tid, merge_team(n)); __syncthreads(); }
         else if (nr == 4u) { merge_pair(B0, B1, 0u, kp[0], kp[1], tid, merge_team(s2)); merge_pair(B0, B1, s2, kp[2], kp[3], 511u - tid, merge_team(n - s2)); __syncthreads();
                              merge_pair(B1, B0, 0u, s2, kp[2] + kp[3], tid, merge_team(n)); __syncthreads(); }
+        }
         FAST_TICK(3);
         const uint32_t* F = B0; uint32_t* D = B1;
         // ---- the two cuts in one pass over the merged run (fast_cut above) where a thread's chunk is <= 6 entries (n <= 3072: four queries in five); the two-pass form below otherwise ----
-        if (SRN_FAST_FUSED_CUT && n <= 6u * BLOCK) {   // (block-uniform)
+        if (!MID && SRN_FAST_FUSED_CUT && n <= 6u * BLOCK) {   // (block-uniform)
             const uint32_t kc = fast_cut<6>(F, nbl, n, NB, p.m, p.k, wlut, misc, tid, lane);
             __syncthreads();
             K = kc != 0xFFFFFFFFu ? kc : misc[FS_NB];
@@ -492,6 +574,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             } else
                 for (uint32_t o = o0; o < o1; ++o) { const uint32_t r = F[o] >> NB; firsts += r != prev; prev = r; }
             for (uint32_t i = tid; i < min(n, p.m); i += BLOCK) D[i] = 0;
+            if (MID && tid < 64u) thist[tid] = 0u;   // (the k-cut's class histogram: the tail of the merge buffers' room, see `fits`)
             uint32_t idx = block_excl_scan<BLOCK>(firsts, misc + FS_SCAN_A, Call);   // (barrier inside)
             prev = prev0;
             if (g <= (uint32_t)MC_G) {
@@ -517,13 +600,17 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         // ---- k-cut: D is ordered by recency, so inside one numerator class the order is already the wanted one ----
         if (Cm <= p.k) K = Cm;   // (block-uniform; the m-cut wrote the neighbour list)
         else {
-            uint32_t* cls = misc + FS_CLS;
+            uint32_t* cls = MID ? thist : misc + FS_CLS;
             const uint32_t g = (Cm + BLOCK - 1) / BLOCK, o0 = min(tid * g, Cm), o1 = min(o0 + g, Cm);   // g <= 5
             uint32_t dv[5], nmv[5];
 #pragma unroll
             for (int x = 0; x < 5; ++x) dv[x] = o0 + x < o1 ? D[o0 + x] : 0u;
 #pragma unroll
             for (int x = 0; x < 5; ++x) nmv[x] = o0 + x < o1 ? (uint32_t)wlut[dv[x] & NBM] : 0u;   // (class 0 does not exist)
+            if constexpr (MID) {   // <= 63 classes: a histogram in LDS (lane v of the scan below = class v)
+#pragma unroll
+                for (int x = 0; x < 5; ++x) if (o0 + x < o1) atomicAdd(&cls[nmv[x]], 1u);
+            } else
             {   // class counts: 16 fields of 4 bits per thread, spread over 4 x 64 bits with 16-bit fields, 8 DPP wave sums
                 unsigned long long acc = 0;
 #pragma unroll
@@ -544,7 +631,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             __syncthreads();
             uint32_t nstar, rstar;
             {   // lane v holds class v: suffix sums from the best class down; the boundary class is the highest one whose suffix reaches k
-                const uint32_t cv = lane < 16u ? cls[lane] : 0u; const uint32_t pre = wave_incl_scan(cv);
+                const uint32_t cv = (MID || lane < 16u) ? cls[lane] : 0u; const uint32_t pre = wave_incl_scan(cv);
                 const uint32_t suf = (uint32_t)__builtin_amdgcn_readlane((int)pre, 63) - pre + cv;
                 const unsigned long long reach = __ballot(suf >= p.k);
                 nstar = 63u - (uint32_t)__clzll((long long)reach);
@@ -596,6 +683,9 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             uint4* z = reinterpret_cast<uint4*>(smem + F_HOT);
             for (uint32_t i = tid; i < (F_TABLE - F_HOT) / 16u; i += BLOCK) z[i] = make_uint4(0u, 0u, 0u, 0u);
             if (tid < 64u) reinterpret_cast<uint4*>(thist)[tid] = make_uint4(0u, 0u, 0u, 0u);
+            // (MID: the idf bounds of the integer floors live behind the candidate buffer -- inside the merge buffers' room, so they are rewritten once the merges are over; the
+            //  lean form keeps them in the weight table's unused tail, which MID's 256 list sets fill)
+            if constexpr (MID) { if (tid < 16u) ((double*)(smem + SINV))[tid] = tid < 8u ? f.inv_idf_hot[tid] : f.inv_idf_hi; }
             if (tid < F_TABLE_WORDS / 4u) { reinterpret_cast<uint4*>(ikeys)[tid] = make_uint4(EMPTY32, EMPTY32, EMPTY32, EMPTY32);
                                             reinterpret_cast<uint4*>(iacc)[tid] = make_uint4(0u, 0u, 0u, 0u); }
         }
@@ -646,7 +736,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         // in order: anywhere else the record's HBM round trip would sit in front of data the wave needs at once); it lands in LDS by itself, the wave
         // waits for it at the end of phase 4a, before the barrier that everybody passes on the way to the next query
         const uint32_t qn = q + gridDim.x;
-        if (wave == 1u && qn < p.nq) {   // (a record is at most 72 + 8 * 24 = 264 bytes: two rounds of a dword per lane)
+        if (!MID && wave == 1u && qn < p.nq) {   // (a record is at most 72 + 8 * 24 = 264 bytes: two rounds of a dword per lane)
             const char* const rn = p.prep + (size_t)qn * p.prep_stride + lane * 4u;
             if (lane * 4u < p.prep_stride) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)rn, (__attribute__((address_space(3))) void*)pre, 4, 0, 0);
             if (256u + lane * 4u < min(p.prep_stride, 320u)) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rn + 256), (__attribute__((address_space(3))) void*)(pre + 64), 4, 0, 0);
@@ -739,7 +829,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             // integer floors: an item needs idf * acc >= x_lo, i.e. acc >= x_lo / (largest idf of its chunk); shaved so that rounding
             // can only keep more.  Lane c computes chunk c's floor (lane 8: the sketch words'), broadcast by v_readlane.
             const double x_lo = __longlong_as_double((long long)((unsigned long long)t32m1 << 32));
-            const double inv = ((const double*)(smem + F_SINV))[min(lane, 8u)];
+            const double inv = ((const double*)(smem + SINV))[min(lane, 8u)];
             const uint32_t my_floor = (uint32_t)fmin(4.0e9, fmax(1.0, floor(x_lo * inv * (1.0 - 1e-9)) - 1.0));
             floor_b = (uint32_t)__builtin_amdgcn_readlane((int)my_floor, 8);
             // The other direct-mapped words, four per thread and read: a thread's quad lies inside one chunk of 512 words and a wave's quads inside one chunk too
@@ -789,10 +879,10 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
                 const uint32_t t32b = (((t32m1 + 1u) >> 16) + bsel) << 16;
                 t32m1 = t32b - 1u;
                 const double x_lo = __longlong_as_double((long long)((unsigned long long)t32m1 << 32));
-                floor_b = (uint32_t)fmin(4.0e9, fmax(1.0, floor(x_lo * ((const double*)(smem + F_SINV))[8] * (1.0 - 1e-9)) - 1.0));
+                floor_b = (uint32_t)fmin(4.0e9, fmax(1.0, floor(x_lo * ((const double*)(smem + SINV))[8] * (1.0 - 1e-9)) - 1.0));
             }
         }
-        if (wave == 1u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the record has landed
+        if (!MID && wave == 1u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the record has landed
         FAST_TICK(10);
         {
             const uint32_t ns = min(misc[FS_SURV], SURV_CAP);
@@ -814,7 +904,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             if (__ballot(mx >= floor_b) != 0ull && lane == 0u) misc[FS_LIVE] = 1u;
         }
         __syncthreads();
-        have_pre = qn < p.nq;   // (the barrier above orders wave 1's writes before anybody's next look)
+        have_pre = !MID && qn < p.nq;   // (the barrier above orders wave 1's writes before anybody's next look)
         const bool live = misc[FS_LIVE] != 0u;   // block-uniform
         if (live) {
         // ---- walk B: an element reaches the exact table only if its sketch word can still reach the floor -----------
@@ -978,6 +1068,10 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         // A query with more entries (no threshold: a small query) puts the rest in an overflow arena and itself on the list of
         // vmis_finish_big_kernel: one 64-bit atomic hands out the list slot (high word) and the arena space (low word, entries).
         const uint32_t M = cnt + nt;
+        if (MID && L == 10u && M < p.how_many) {   // (wave-uniform) neighbours of weight 0 may exist and the positive scores do not fill the top n: an item of score 0 can be returned (mod.rs:143-153 inserts it)
+            if (ln == 0u) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q;
+            continue;
+        }
         uint32_t ovf_at = 0;
         if (M > F_FIN_ENTRIES) {   // (wave-uniform, rare: the atomic's round trip is paid by these queries only)
             unsigned long long tk = 0;
@@ -1089,7 +1183,7 @@ __global__ __launch_bounds__(64) void vmis_finish_big_kernel(DeviceIndex ix, con
     constexpr uint32_t CAP = F_CAND_CAP + F_TABLE_BUCKETS * 4u;
     // the launch sequence's two counters (queries for the global-table pass, queries handed to the general kernel: both final before this kernel starts) straight into
     // the workspace's pinned words -- two 4-byte device-to-host copies cost 9 us of every call
-    if (host_words && blockIdx.x == 0u && threadIdx.x == 0u) { if (cnt_retry) host_words[0] = *cnt_retry; if (cnt_slow) host_words[1] = *cnt_slow; }   // (a null source: that word is someone else's)
+    if (host_words && blockIdx.x == 0u && threadIdx.x == 0u) { if (cnt_retry) host_words[0] = *cnt_retry; if (cnt_slow) { host_words[1] = cnt_slow[0]; host_words[2] = cnt_slow[1]; } }   // (cnt_slow[1]: the MID instantiation's list)   // (a null source: that word is someone else's)
     __shared__ unsigned long long key[CAP];
     __shared__ uint32_t tieb[CAP];
     __shared__ uint32_t hist[256];
@@ -1167,10 +1261,12 @@ hipError_t launch_finish(hipStream_t st, const DeviceIndex& di, const FastParams
     return hipGetLastError();
 }
 
-hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f, bool debug, int mode) {
+hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f, bool debug, int mode, bool mid) {
     constexpr int W = (int)F_WG_PER_CU;
     const bool wide = f.nb == 3u, frag = di.row_frag != 0u;
+    if (mid && (mode != FM_FUSED || frag || f.mid_list == nullptr)) return hipErrorInvalidValue;
     void (*kern)(DeviceIndex, LaunchParams, FastParams) =
+        mid ? vmis_fast_kernel<W, false, false, FM_FUSED, true> :
         mode == FM_FRONT ? (wide ? vmis_fast_kernel<W, false, true, FM_FRONT> : vmis_fast_kernel<W, false, false, FM_FRONT>)
         : mode == FM_BACK ? (wide ? (frag ? vmis_fast_kernel<W, true, true, FM_BACK> : vmis_fast_kernel<W, false, true, FM_BACK>)
                                   : (frag ? vmis_fast_kernel<W, true, false, FM_BACK> : vmis_fast_kernel<W, false, false, FM_BACK>))

@@ -22,7 +22,7 @@ namespace srn {
 // Test / experiment knobs (environment variables SRN_*): read ONCE, when the library is first used, never on the launch path;
 // srn_debug_reload_knobs() re-reads them (the tests switch kernel paths between calls).  All defaults = production behaviour.
 struct Knobs {
-    bool no_masks = false, no_merge = false, dense = false, no_fast = false, debug = false;
+    bool no_masks = false, no_merge = false, dense = false, no_fast = false, no_mid = false, debug = false;   // no_mid (SRN_NO_MID): the launch sequence without the fast kernel's MID instantiation (what it would take goes to the general kernel, as before round 4)
     int hot_slots = -1, sketch_slots = -1, lds_budget_kb = 0, grid_mult = 16, fast_runs = 0;
     bool grid_mult_set = false;
     int host_chunks = 0;      // SRN_HOST_CHUNKS: number of chunks a host-pointer batch is cut into (0 = by size, srn_hostpipe.hip)
@@ -47,6 +47,7 @@ struct Workspace {
     bool ring_timed[RING] = {};                   // the call recorded all five (kernel timing on: srn_kernel_timing); otherwise only [2], the end of the call
     uint64_t calls = 0, untimed_calls = 0; uint32_t last_retry = 0, last_nq = 0;
     bool last_fast = false;      // the last call went through the fast kernel: h_retry[1] = what it handed to the general kernel (otherwise: all of last_nq)
+    bool last_mid = false;       // ... and through its MID instantiation: h_retry[2] = the queries the lean instantiation listed for it
     bool last_untimed = false;   // the last call took the latency path: no events were recorded for it
     // device scratch
     uint32_t* retry_list = nullptr; size_t retry_cap = 0; uint32_t* retry_cnt = nullptr;

@@ -21,7 +21,7 @@ static Knobs g_knobs; static std::once_flag g_knobs_once; static std::mutex g_kn
 static void knobs_read() {
     Knobs k;
     k.no_masks = getenv("SRN_NO_MASKS") != nullptr; k.no_merge = getenv("SRN_NO_MERGE") != nullptr; k.dense = getenv("SRN_DENSE") != nullptr;
-    k.no_fast = getenv("SRN_NO_FAST") != nullptr; k.debug = getenv("SRN_DEBUG") != nullptr;
+    k.no_fast = getenv("SRN_NO_FAST") != nullptr; k.no_mid = getenv("SRN_NO_MID") != nullptr; k.debug = getenv("SRN_DEBUG") != nullptr;
     if (const char* e = getenv("SRN_ROW_SLOTS")) k.row_slots16 = atoi(e) == 16 ? 1 : atoi(e) == 64 ? 0 : -1;
     if (const char* e = getenv("SRN_HOT_SLOTS")) k.hot_slots = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_SKETCH_SLOTS")) k.sketch_slots = std::max(0, atoi(e));
@@ -488,11 +488,17 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     // up to 2^29 with 3 (queries with more go to the general kernel)
     const int rank_bits_f = std::max(1, bits_host(ix.n_kept ? ix.n_kept - 1 : 0));
     const uint32_t nb_fast = kn.fast_runs == 3 && rank_bits_f <= 29 ? 3u : rank_bits_f <= 28 ? 4u : rank_bits_f <= 29 ? 3u : 0u;
-    const bool fast = d->fast.row_packed != nullptr && geo.masks && !geo.sketch_may_wrap && nb_fast != 0 && kn.geometry_default() && !kn.no_fast && p.k <= F_K_MAX && p.m <= F_M_MAX &&
-                      p.how_many <= 24 && (p.flags & ~(unsigned)SRN_FLAG_BUSINESS_LOGIC) == 0 && p.stats == nullptr && p.nb_rank == nullptr && p.max_len <= 8;
+    // What the fast kernel needs of the LAUNCH is the position-set condition (DESIGN.md "Why MASKS is exact": m <= m_index, lists complete) and sketch words that cannot wrap
+    // at ITS session lengths (<= 10 items: the admission is per query, on the device); the batch's longest session only decides which kernel serves the hand-overs -- up to
+    // round 3 one session of nine items sent the whole batch to the general kernel.
+    const bool sets_exact = p.m <= ix.m_index && ix.lists_complete && !kn.no_masks;
+    const bool fast_sketch_ok = (uint64_t)p.k * std::max<uint64_t>(1, ix.max_row_len) * 9ull * 55ull < (1ull << 32);
+    const bool mid_tier = !kn.no_mid && !ext && d->di.row_frag == 0u && p.max_len >= 5;   // (a query of <= 4 items has <= 4 lists and numerators <= 10: nothing for the MID instantiation)
+    const bool fast = d->fast.row_packed != nullptr && sets_exact && (p.max_len <= 8 ? geo.masks && !geo.sketch_may_wrap : mid_tier && fast_sketch_ok) && nb_fast != 0 && kn.geometry_default() &&
+                      !kn.no_fast && p.k <= F_K_MAX && p.m <= F_M_MAX && p.how_many <= 24 && (p.flags & ~(unsigned)SRN_FLAG_BUSINESS_LOGIC) == 0 && p.stats == nullptr && p.nb_rank == nullptr;
     if (fast) {   // (all allocations of a call happen before its first launch)
         if (w->slow_cap < p.nq) { if (w->slow_list) HIP_TRY(hipFree(w->slow_list)); w->slow_list = nullptr; w->slow_cap = 0;
-            HIP_TRY(hipMalloc((void**)&w->slow_list, (size_t)p.nq * 4 + 64)); w->slow_cap = p.nq; }
+            HIP_TRY(hipMalloc((void**)&w->slow_list, ((size_t)p.nq * 4 + 64) * 2)); w->slow_cap = p.nq; }   // (second half: the MID instantiation's list)
         { int rc = ensure(&w->fin, &w->fin_bytes, (size_t)p.nq * F_FIN_BYTES + 1024); if (rc) return rc; }   // one record per query for vmis_finish_kernel
         const uint64_t big_entries = std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)p.nq * 16 + 4096);
         { int rc = ensure(&w->big, &w->big_bytes, big_entries * 16 + (size_t)p.nq * 4 + 64); if (rc) return rc; }
@@ -505,7 +511,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         if (ext->prep_stride != prep_stride) return fail(SRN_EINVAL, "prep record stride mismatch");
         if (ext->q_lo >= p.nq) return SRN_OK;
         p.prep = ext->prep; p.prep_stride = prep_stride;
-        FastParams fp = d->fast; fp.nb = nb_fast; fp.max_runs = nb_fast; fp.slow_list = nullptr; fp.slow_cnt = nullptr; fp.fin = nullptr;
+        FastParams fp = d->fast; fp.nb = nb_fast; fp.max_runs = nb_fast; fp.slow_list = nullptr; fp.slow_cnt = nullptr; fp.fin = nullptr; fp.mid_list = nullptr; fp.mid_cnt = nullptr;
         fp.xchg = ext->xchg; fp.xchg_stride = ext->xchg_stride; fp.q_base = ext->q_lo;
         const uint64_t cnt = p.nq - ext->q_lo, res_wg = (uint64_t)d->n_cu * F_WG_PER_CU;
         const uint32_t grid_front = (uint32_t)std::min<uint64_t>(cnt, std::min<uint64_t>(res_wg * 64, std::max<uint64_t>(res_wg * 16, cnt / 12)));
@@ -561,10 +567,14 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         FastParams fp = d->fast; fp.slow_list = w->slow_list; fp.slow_cnt = w->slow_cnt; fp.nb = nb_fast; fp.max_runs = nb_fast; fp.fin = w->fin;
         fp.big_arena = w->big; fp.big_list = (uint32_t*)(w->big + big_entries * 16); fp.big_ticket = (unsigned long long*)(w->slow_cnt + 2); fp.big_cap_entries = (uint32_t)big_entries;
         fp.xchg = nullptr; fp.xchg_stride = 0; fp.q_base = 0;
+        fp.mid_list = mid_tier ? w->slow_list + (w->slow_cap + 16) : nullptr; fp.mid_cnt = mid_tier ? w->slow_cnt + 1 : nullptr;
         const bool back = ext && ext->mode == 2;   // neighbour lists from the exchange buffer (any rank's front end), this shard's rows
         if (back) { fp.xchg = ext->xchg; fp.xchg_stride = ext->xchg_stride; }
         HIP_TRY(launch_fast(dim3(grid_f), st, di, p, fp, kn.debug, back ? 2 : 0));
         if (timed) HIP_TRY(hipEventRecord(ev[4], st));
+        // The MID instantiation over what the lean one listed for it (sessions of <= 10 items, <= 8 lists); what it cannot take either joins slow_list.  The list's length
+        // is known on the device only: a fixed grid, workgroups beyond the list leave at once.
+        if (mid_tier) HIP_TRY(launch_fast(dim3((uint32_t)std::min<uint64_t>(p.nq, resident * 8)), st, di, p, fp, kn.debug, 0, true));
         HIP_TRY(launch_predict(geo.masks, slot64, false, 0, dim3(grid), lds, st, di, p, c, w->slow_list, w->slow_cnt, w->retry_list, w->retry_cnt, nullptr, 0, spill, ShardIO{}));
         if (fork_retry) {   // the global-table pass beside the finish kernels (they touch disjoint rows: a finish kernel only completes rows flagged by the fast kernel)
             HIP_TRY(hipEventRecord(w->ev_fork, st)); HIP_TRY(hipStreamWaitEvent(w->side, w->ev_fork, 0));
@@ -595,7 +605,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     HIP_TRY(hipEventRecord(ev[2], st));
     if (resident) { const int par = (int)(w->resident_calls & 1u); HIP_TRY(hipEventRecord(w->ev_done[par], st)); w->rec_used[par] = true; ++w->resident_calls; }
     else if (!ext && w->side) { HIP_TRY(hipEventRecord(w->ev_done[0], st)); w->rec_used[0] = true; }   // (a workspace that has served resident calls: the next one's side-stream prep must not overwrite w->prep under this call's kernels)
-    ++w->calls; w->last_retry = (may_overflow || dense) ? 1 : 0; w->last_nq = p.nq; w->last_fast = fast; w->last_untimed = false;
+    ++w->calls; w->last_retry = (may_overflow || dense) ? 1 : 0; w->last_nq = p.nq; w->last_fast = fast; w->last_mid = fast && mid_tier; w->last_untimed = false;
     if (may_overflow || dense) w->h_retry_valid = true;   // (from now on the pinned counter holds a finished call's count -- or is being overwritten by a newer one)
 
     if (!on_device) {
@@ -761,6 +771,15 @@ int device_last_path_counts(DeviceState* d, uint32_t* nq, uint32_t* general, uin
     if (nq) *nq = w->last_nq;
     if (general) *general = w->last_fast ? w->h_retry[1] : w->last_nq;
     if (global_pass) *global_pass = w->last_retry ? w->h_retry[0] : 0;
+    return SRN_OK;
+}
+int device_last_mid_count(DeviceState* d, uint32_t* listed) {   // queries the last call's lean fast kernel listed for the MID instantiation (0: no such tier in that call)
+    uint32_t nq = 0;
+    const int rc = device_last_path_counts(d, &nq, nullptr, nullptr);   // (waits for the call's end)
+    if (rc != SRN_OK) return rc;
+    Workspace* w;
+    { std::lock_guard<std::mutex> lk(d->mu); w = d->last_ws; }
+    if (listed) *listed = w->last_fast && w->last_mid ? w->h_retry[2] : 0u;
     return SRN_OK;
 }
 

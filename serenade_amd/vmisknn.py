@@ -114,6 +114,12 @@ class VMISIndex:
         capi.check(capi.lib().srn_last_path_counts(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def last_mid_count(self):
+        """Queries of the last call that the lean fast kernel listed for its MID instantiation (sessions of <= 10 items, 5..8 lists); measurement aid."""
+        a = C.c_uint32()
+        capi.check(capi.lib().srn_debug_last_mid_count(self._h, C.byref(a)))
+        return a.value
+
     def kernel_times(self, max_n=64):
         """Per-call (main kernel ms, retry pass ms) of the most recent predict calls, oldest first (HIP events
         recorded on the launch stream around each launch)."""

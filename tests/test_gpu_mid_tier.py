@@ -1,0 +1,174 @@
+"""The fast kernel's MID instantiation (srn_fast.hip, round 4): evolving sessions of up to 10 items with up to 8 posting lists and similarity numerators up to 63 --
+the reference's whole grid of last_items_in_session (src/hyperparameter/hyperparamgrid.rs:93-139) -- served between the lean fast kernel and the general kernel.
+
+Everything goes through the C ABI and is compared with the canonical CPU oracle (find_neighbors src/vmisknn/vmis_index.rs:325-415, predict src/vmisknn/mod.rs:118-215);
+the same batches with SRN_NO_MID=1 (the launch sequence of round 3: what the lean kernel cannot take goes straight to the general kernel) must give the same bytes.
+"""
+import numpy as np
+import pytest
+
+from helpers import flatten, random_queries, small_dataset
+
+pytestmark = pytest.mark.gpu
+
+SCORE_RTOL = 1e-12
+
+
+def _oracle():
+    from oracle import oracle
+    return oracle
+
+
+def _against_oracle(gix, oix, queries, k, m, n, business=False):
+    import serenade_amd as sa
+    ids, scores, counts = sa.predict_batch(gix, queries, k, m, n, business)
+    flat, off = flatten(queries)
+    ref = oix.predict_batch("canonical", flat, off, k, m, n, business, threads=4)
+    assert np.array_equal(counts, ref["counts"]), "result counts differ"
+    for q in range(len(queries)):
+        c = int(ref["counts"][q])
+        assert np.array_equal(ids[q, :c], ref["ids"][q, :c]), (q, queries[q], ids[q, :c], ref["ids"][q, :c])
+        np.testing.assert_allclose(scores[q, :c], ref["scores"][q, :c], rtol=SCORE_RTOL, atol=0)
+        assert not ids[q, c:].any() and not scores[q, c:].any(), "row tails must read 0"
+    return ids, scores, counts
+
+
+@pytest.fixture
+def no_mid(monkeypatch):
+    from serenade_amd import capi
+
+    def switch(off):
+        if off:
+            monkeypatch.setenv("SRN_NO_MID", "1")
+        else:
+            monkeypatch.delenv("SRN_NO_MID", raising=False)
+        capi.reload_knobs()
+    yield switch
+    monkeypatch.undo()
+    capi.reload_knobs()
+
+
+def _long_queries(seed, ids, n, lo, hi, unknown_rate=0.05, dup_rate=0.1):
+    rng = np.random.default_rng(seed)
+    w = 1.0 / np.arange(1, len(ids) + 1) ** 0.9
+    w /= w.sum()
+    qs = []
+    for _ in range(n):
+        ln = int(rng.integers(lo, hi + 1))
+        q = ids[rng.choice(len(ids), size=ln, p=w)].tolist()
+        for j in range(ln):
+            if rng.random() < unknown_rate:
+                q[j] = int(7 + rng.integers(0, 1000))
+            elif j and rng.random() < dup_rate:
+                q[j] = q[int(rng.integers(0, j))]
+        qs.append([int(x) for x in q])
+    return qs
+
+
+def test_sessions_of_five_to_ten_items_vs_oracle(no_mid):
+    """Posting lists long enough for both cuts to bite with 5..8 lists merged; k-cut classes up to 55 (L = 10)."""
+    import serenade_amd as sa
+    O = _oracle()
+    off, items, ts, ids = small_dataset(31, n_sessions=40000, n_items=150, max_len=12)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, 3000, 12, 1.0)
+    oix = O.OracleIndex(off, items, ts, 3000, 12, 1.0)
+    qs = _long_queries(13, ids, 500, 1, 10)
+    for (k, m, n) in [(100, 500, 21), (1500, 2500, 21), (50, 2560, 24), (700, 1000, 5), (1, 1, 1)]:
+        no_mid(False)
+        got = _against_oracle(gix, oix, qs, k, m, n)
+        nq, general, _glob = gix.last_path_counts()
+        mid = gix.last_mid_count()
+        assert mid >= len(qs) // 4, "sessions of 5..10 items should have been listed for the MID instantiation (%d of %d)" % (mid, nq)
+        assert general <= mid // 2 + 8, "the MID instantiation should serve most of what it is handed (%d listed, %d reached the general kernel)" % (mid, general)   # (what it passes on: merged lists beyond the LDS buffers)
+        no_mid(True)
+        ref = sa.predict_batch(gix, qs, k, m, n, False)
+        assert gix.last_mid_count() == 0
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b), "with and without the MID tier the results must be the same bytes"
+
+
+def test_tenth_position_weight_zero(no_mid):
+    """L = 10: linear_score(10) = 0 (mod.rs:110-116) -- neighbours that match only the oldest item add 0 to every item of their row, and such items are RETURNED
+    (score 0) when the positive scores do not fill the top n: the MID instantiation hands exactly those queries to the general kernel."""
+    import serenade_amd as sa
+    O = _oracle()
+    off, items, ts, ids = small_dataset(5, n_sessions=6000, n_items=200, max_len=8)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, 1000, 10, 1.0)
+    oix = O.OracleIndex(off, items, ts, 1000, 10, 1.0)
+    rng = np.random.default_rng(4)
+    qs = []
+    for i in range(400):
+        old = int(ids[rng.integers(0, len(ids))])
+        if i % 2:   # oldest item known, the nine recent ones unknown: every neighbour has weight 0
+            qs.append([old] + [int(7 + rng.integers(0, 1000)) for _ in range(9)])
+        else:       # oldest item known and rare ones behind it: a mix of zero and positive weights
+            qs.append([old] + [int(x) for x in ids[rng.integers(len(ids) // 2, len(ids), size=9)]])
+    no_mid(False)
+    for (k, m, n) in [(100, 500, 21), (1500, 1000, 24), (20, 50, 5)]:
+        ids_, scores, counts = _against_oracle(gix, oix, qs, k, m, n)
+        assert (scores[np.arange(len(qs)) % 2 == 1][:, 0] == 0).all() and (counts[1::2] > 0).any(), "all-zero-weight queries return items of score 0"
+        assert gix.last_mid_count() > 0
+
+
+def test_many_lists_business_rules_and_ties(no_mid):
+    """Business rules on (mod.rs:162-182) through the MID instantiation; tied timestamps (canonical order); idf weighting 2."""
+    import serenade_amd as sa
+    O = _oracle()
+    off, items, ts, ids = small_dataset(8, n_sessions=20000, n_items=120, tied_timestamps=True, max_len=9)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, 2500, 9, 2.0)
+    oix = O.OracleIndex(off, items, ts, 2500, 9, 2.0)
+    rng = np.random.default_rng(4)
+    known = np.unique(items)
+    flags = rng.choice(np.array([0, 1, 2, 3, 0xFF], np.uint8), size=len(known), p=[0.1, 0.05, 0.55, 0.2, 0.1])
+    gix.set_attributes(known, flags)
+    oix.set_attributes(known, flags)
+    business = True
+    qs = _long_queries(3, ids, 400, 5, 9, unknown_rate=0.02, dup_rate=0.05)
+    no_mid(False)
+    for (k, m, n) in [(1500, 2500, 21), (300, 800, 10)]:
+        _against_oracle(gix, oix, qs, k, m, n, business)
+        assert gix.last_mid_count() >= len(qs) // 2
+        if business:
+            _against_oracle(gix, oix, qs, k, m, n, False)
+
+
+def test_one_long_session_no_longer_sends_the_batch_to_the_general_kernel(no_mid):
+    """Up to round 3 the fast kernel was chosen per LAUNCH on the batch's longest session: one session of nine items and 4 095 short ones all went through the general
+    kernel.  The admission is per query now."""
+    import serenade_amd as sa
+    O = _oracle()
+    off, items, ts, ids = small_dataset(12, n_sessions=8000, n_items=400, max_len=10)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, 500, 30, 1.0)
+    oix = O.OracleIndex(off, items, ts, 500, 30, 1.0)
+    qs = random_queries(6, ids, 2000, max_len=4)
+    qs[17] = [int(x) for x in ids[:25]]            # 25 items: the general kernel's, whatever the tiers in front of it
+    qs[900] = [int(x) for x in ids[5:14]]          # 9 items
+    no_mid(False)
+    _against_oracle(gix, oix, qs, 100, 500, 21)
+    nq, general, _ = gix.last_path_counts()
+    assert general < 100, "short sessions must stay on the fast kernel (%d of %d reached the general kernel)" % (general, nq)
+
+
+def test_synthetic_tiny_long_sessions(no_mid):
+    """The generator's tiny config (20 K items: scored items lie outside the direct-mapped range, so the per-chunk integer floors, the sketch filter, walk B and the exact
+    table all run) with evaluator-style sessions of up to 10 items: oracle-exact, the same bytes with and without the tier, and the tier serves what it is handed."""
+    import serenade_amd as sa
+    from serenade_amd import synth
+    O = _oracle()
+    inter, n_items, k, m, idfw = synth.CONFIGS["tiny"]
+    off, items, ts = synth.training_sessions(inter, n_items)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw)
+    oix = O.OracleIndex(off, items, ts, m, 34, idfw, fast=True)
+    for max_items in (5, 8, 10):
+        qi, qo = synth.queries(1500, n_items, max_items=max_items)
+        nq = min(len(qo) - 1, 3000)
+        qs = [qi[qo[i]:qo[i + 1]].tolist() for i in range(nq)]
+        no_mid(False)
+        got = _against_oracle(gix, oix, qs, k, m, synth.HOW_MANY)
+        nq_, general, _ = gix.last_path_counts()
+        mid = gix.last_mid_count()
+        assert mid > 0 and general <= mid // 4 + 8, "max_items %d: %d listed for the MID instantiation, %d reached the general kernel" % (max_items, mid, general)
+        no_mid(True)
+        ref = sa.predict_batch(gix, qs, k, m, synth.HOW_MANY, False)
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b), "with and without the MID tier the results must be the same bytes"
