@@ -512,6 +512,49 @@ def main():
                 lat.append((time.perf_counter() - t1) * 1e6)
             lat_single = np.array(lat[50:])
 
+        # ---- 3b. sessions longer than the headline's last_items (the reference's hyper-parameter grid of last_items_in_session goes to 10,
+        # src/hyperparameter/hyperparamgrid.rs:93-139): the same index, evaluator-style queries keeping their last 8 / 10 items, resident batches of 2^18; each
+        # gated against the oracle on 256 queries; at 10 items also without the fast kernel's MID instantiation (SRN_NO_MID=1: the launch sequence of round 3)
+        long_sessions = None
+        if not args.no_sweep and world == 1 and args.config in ("cfg3", "cfg2", "tiny", "small"):
+            from serenade_amd import capi as _capi
+            long_sessions = []
+            BL = int(min(B, 1 << 18))
+            for mi in (8, 10):
+                n_sess = max(1024, int(BL / 2.0) + 4096)
+                while True:
+                    lq_items, lq_off = synth.queries(n_sess, n_items, seed=synth.SEED + 104729, max_items=mi)
+                    if len(lq_off) - 1 >= BL:
+                        break
+                    n_sess = int(n_sess * 1.5)
+                lq_off = lq_off[:BL + 1]; lq_items = lq_items[:lq_off[-1]]
+                l_flat = torch.from_numpy(lq_items.view(np.int64).copy()).to(dev); l_off = torch.from_numpy(lq_off.view(np.int32).copy()).to(dev)
+                lens = np.diff(lq_off.astype(np.int64))
+                entry = {"max_items_in_session": mi, "batch": BL, "mean_session_items": float(lens.mean()), "share_of_sessions_over_4_items": float((lens > 4).mean())}
+                for tag in (("mid_tier", "without_mid_tier") if mi == 10 else ("mid_tier",)):
+                    if tag == "without_mid_tier":
+                        os.environ["SRN_NO_MID"] = "1"
+                    _capi.reload_knobs()
+
+                    def lstep():
+                        sa.predict_batch_device(index, l_flat.data_ptr(), l_off.data_ptr(), BL, mi, k, m, how_many, False, out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(),
+                                                stream.cuda_stream)
+                    lstep(); torch.cuda.synchronize()
+                    if tag == "mid_tier":
+                        gate(out_ids.cpu().numpy().view(np.uint64).reshape(B, how_many)[:256], out_sc.cpu().numpy().reshape(B, how_many)[:256],
+                             out_cnt.cpu().numpy().view(np.uint32)[:256], lq_items, lq_off, 256, "sessions of up to %d items" % mi)
+                    es = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+                    for a_, b_ in es:
+                        a_.record(stream); lstep(); b_.record(stream)
+                    torch.cuda.synchronize()
+                    ms = float(np.median([a_.elapsed_time(b_) for a_, b_ in es]))
+                    _, g_last, _ = index.last_path_counts()
+                    entry[tag] = {"queries_per_s": BL / (ms * 1e-3), "ms_p50": ms, "listed_for_mid_instantiation": int(index.last_mid_count()), "reached_general_kernel": int(g_last)}
+                    os.environ.pop("SRN_NO_MID", None)
+                    _capi.reload_knobs()
+                entry["parity_checked"] = 256
+                long_sessions.append(entry)
+
         # HBM traffic per launch comes from separate rocprofv3 --pmc passes over this same command (tools/pmc_bench.sh);
         # the committed summary is read back here so that the line carries it (null if no summary matches the workload)
         traffic, traffic_src, traffic_in_run = None, None, False
@@ -562,6 +605,7 @@ def main():
                         "single_query_us_p50": float(np.percentile(lat_single, 50)) if lat_single is not None else None,
                         "single_query_us_p90": float(np.percentile(lat_single, 90)) if lat_single is not None else None,
                         "batch_sweep": sweep,
+                        "long_sessions": long_sessions,
                         "note": "batch_sweep: srn_predict_batch_device on resident buffers (HIP events) vs srn_predict_batch on host buffers (pageable numpy arrays, result buffers "
                                 "reused between calls: upload + launches + download, wall clock; <= 256 sessions: zero-copy latency path, above: chunked pipeline); "
                                 "single_query = srn_predict (host pointers, one evolving session per call, PCIe-inclusive)"},
