@@ -292,11 +292,11 @@ __device__ __forceinline__ uint32_t fast_cut(const uint32_t* F, uint32_t* nbl, u
 // (vmis_index.rs:325-415: lists -> merge tree -> cuts), the neighbour list goes to an exchange buffer -- K, then K packed slots -- instead of into the walks, for the
 // queries [f.q_base, p.nq) this rank fronts; FM_BACK = predict's scoring (mod.rs:126-214) from a neighbour list found by ANY rank: the list is read from the exchange
 // buffer, the weight table rebuilt from the query's own prep record (same record on every rank: same table), then the fused kernel's walks unchanged.
-// MID (round 4, the tier between this kernel and vmis_predict_kernel): evolving sessions of <= 10 items with <= 8 lists and numerators up to 63 -- the reference's whole
+// MID (round 4, the tier between this kernel and vmis_predict_kernel): evolving sessions of <= 10 items (so <= 10 lists) and numerators up to 63 -- the reference's whole
 // hyper-parameter grid of last_items_in_session (1, 2, 3, 5, 10: src/hyperparameter/hyperparamgrid.rs:93-139) instead of the <= 4 lists / numerators <= 15 of the lean
 // form.  Same LDS map, same walks; what differs: the queries come from a device-side list (f.mid_list, filled by the lean instantiation's hand-overs), slots carry as many
-// list bits as the query has lists (ranks counted from the cut x_lo), the lists are staged four at a time, a three-level merge tree with the run lengths in SGPRs, the
-// two-pass cuts with a 64-bin class histogram in LDS (lane v = class v), no record prefetch.  A session of 10 items can see weight 0 (linear_score(10), mod.rs:110-116):
+// list bits as the query has lists (ranks counted from the cut x_lo), the lists are staged four at a time, a merge tree of up to four levels with the run lengths in SGPRs, the
+// two-pass cuts with a 64-bin class histogram in LDS (lane v = class v), weights from two half-set tables (lists 0..4 | 5..9), no record prefetch.  A session of 10 items can see weight 0 (linear_score(10), mod.rs:110-116):
 // its zero-weight neighbours add nothing, and a query whose positive-score items do not fill the top n -- the only case in which a zero-score item can be returned --
 // goes to the general kernel.
 enum { FM_FUSED = 0, FM_FRONT = 1, FM_BACK = 2 };
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
     const __attribute__((address_space(4))) FastParams& f = *(const __attribute__((address_space(4))) FastParams*)(ka + OFF_F);
     constexpr int BLOCK = 512, NW = 8;
     constexpr int NL = MID ? (int)F_MID_LISTS : 4;             // lists a query may have
-    constexpr uint32_t SINV = MID ? F_SINV_MID : F_SINV;       // idf bounds of the integer floors (MID: the weight table takes all of F_W10)
+    constexpr uint32_t SINV = F_SINV;                           // idf bounds of the integer floors
     static_assert(!MID || MODE == FM_FUSED, "MID: fused form only");
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -340,6 +340,14 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
     uint32_t* surv = (uint32_t*)(smem + F_SURV);
     constexpr uint32_t SURV_CAP = F_SURV_WORDS - 256u;
     uint32_t* thist = surv + SURV_CAP;                    // 256 bins: the sample's candidates by the top 16 bits of x, relative to the first threshold
+    // numerator / 10 * linear_score(first match) * numerator of a slot's list set.  Lean: one table entry per set (16 sets).  MID (<= 10 lists: 1 024 sets): the set is split into
+    // lists 0..4 and 5..9 -- wlut[0..31] / [32..63] = the halves' numerators (they add), wlut[64..95] / [96..127] = the halves' first-match positions (the low half wins)
+    auto num_of = [&](uint32_t set) -> uint32_t {
+        if constexpr (MID) return (uint32_t)wlut[set & 31u] + (uint32_t)wlut[32u + (set >> 5)];
+        else return (uint32_t)wlut[set]; };
+    auto w10_of = [&](uint32_t set) -> uint32_t {
+        if constexpr (MID) { const uint32_t lo = set & 31u, hi = set >> 5; const uint32_t mp = lo ? (uint32_t)wlut[64u + lo] : (uint32_t)wlut[96u + hi]; return (9u - mp) * ((uint32_t)wlut[lo] + (uint32_t)wlut[32u + hi]); }
+        else return (uint32_t)w10t[set]; };
 
     unsigned long long* tacc = (unsigned long long*)(smem + F_MISC + FS_TACC * 4);   // 16 debug counters, kept across the queries
     if (tid < 16u) tacc[tid] = 0ull;
@@ -445,12 +453,13 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         // A slot's low bits are the set of RUNS (not evolving positions) that hold the session: <= 4 runs, so 4 bits (3 above 2^28 sessions, see NB above) whatever the
         // session length, and 28 (29) bits for the rank.  Runs are numbered in position order, so the lowest set run is the first match (Q4).
         if constexpr (MID) {
-            if (tid < (1u << nr)) {   // (<= 256 list sets; 10 * linear_score(first match) = 9 - mp: 0 at the tenth position)
-                uint32_t num = 0u, mp = ps[0];
-                const uint32_t lo = tid ? (uint32_t)__ffs((int)tid) - 1u : 0u;
+            if (tid < 64u) {   // (two halves of 5 lists; 10 * linear_score(first match) = 9 - mp: 0 at the tenth position)
+                const uint32_t half = tid >> 5, hs = tid & 31u;
+                uint32_t num = 0u, mp = 0u;
+                const uint32_t lo = hs ? (uint32_t)__ffs((int)hs) - 1u : 0u;
 #pragma unroll
-                for (int r = 0; r < NL; ++r) { num += ((tid >> r) & 1u) ? L - ps[r] : 0u; mp = lo == (uint32_t)r ? ps[r] : mp; }
-                wlut[tid] = (uint8_t)num; w10t[tid] = (uint16_t)((9u - mp) * num);
+                for (int r = 0; r < 5; ++r) { const uint32_t pr = half ? ps[5 + r] : ps[r]; num += ((hs >> r) & 1u) ? L - pr : 0u; mp = lo == (uint32_t)r ? pr : mp; }
+                wlut[tid] = (uint8_t)num; wlut[64u + tid] = (uint8_t)mp;
             }
         } else
         if (tid < (1u << nr)) {
@@ -479,7 +488,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         if constexpr (MID) {
             // lists 0..3 are in flight since before the barrier; the others take one more round trip (only queries of > 4 lists pay it).  Everything is staged into ONE
             // buffer at the lists' prefix offsets, the one from which nlev merge levels end in B0.
-            const uint32_t nlev = nr <= 2u ? 1u : nr <= 4u ? 2u : 3u;
+            const uint32_t nlev = nr <= 2u ? 1u : nr <= 4u ? 2u : nr <= 8u ? 3u : 4u;
             uint32_t* const X = (nlev & 1u) ? B1 : B0; uint32_t* const Y = (nlev & 1u) ? B0 : B1;
             uint32_t pre_r[NL];
             { uint32_t a = 0u;
@@ -489,34 +498,38 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int j = 0; j < 5; ++j) { const uint32_t e = tid + j * BLOCK; if ((uint32_t)j * BLOCK < kp[r] && e < kp[r]) X[pre_r[r] + e] = ((v[r][j] - base) << NB) | (1u << r); }
-            if (nr > 4u) {   // (block-uniform)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+            for (int b4 = 4; b4 < NL; b4 += 4) {
+                if (nr > (uint32_t)b4) {   // (block-uniform)
+                    constexpr int R4 = 4;
 #pragma unroll
-                    for (int j = 0; j < 5; ++j) { v[r][j] = 0u; if ((uint32_t)j * BLOCK < kp[4 + r]) v[r][j] = src[4 + r][min(tid + j * BLOCK, kp[4 + r] - 1u)]; }
+                    for (int r = 0; r < R4; ++r)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                        for (int j = 0; j < 5; ++j) { v[r][j] = 0u; if (b4 + r < NL) { if ((uint32_t)j * BLOCK < kp[b4 + r < NL ? b4 + r : 0]) v[r][j] = src[b4 + r < NL ? b4 + r : 0][min(tid + j * BLOCK, kp[b4 + r < NL ? b4 + r : 0] - 1u)]; } }
 #pragma unroll
-                    for (int j = 0; j < 5; ++j) asm volatile("" : "+v"(v[r][j]));   // (all loads out before the first is packed, as above)
+                    for (int r = 0; r < R4; ++r)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                        for (int j = 0; j < 5; ++j) asm volatile("" : "+v"(v[r][j]));   // (all loads out before the first is packed, as above)
 #pragma unroll
-                    for (int j = 0; j < 5; ++j) { const uint32_t e = tid + j * BLOCK; if ((uint32_t)j * BLOCK < kp[4 + r] && e < kp[4 + r]) X[pre_r[4 + r] + e] = ((v[r][j] - base) << NB) | (16u << r); }
+                    for (int r = 0; r < R4; ++r)
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) { if (b4 + r < NL) { const int rr = b4 + r < NL ? b4 + r : 0; const uint32_t e = tid + j * BLOCK; if ((uint32_t)j * BLOCK < kp[rr] && e < kp[rr]) X[pre_r[rr] + e] = ((v[r][j] - base) << NB) | (1u << rr); } }
+                }
             }
             __syncthreads();
             FAST_TICK(1);
-            // merge tree: <= 3 levels of adjacent pairs; a level's pairs go to consecutive thread teams (sized as in the lean form; teams wrap around the workgroup: a
+            // merge tree: <= 4 levels of adjacent pairs; a level's pairs go to consecutive thread teams (sized as in the lean form; teams wrap around the workgroup: a
             // wave that belongs to two teams merges one pair after the other), a run without a partner is copied (merge with an empty run)
             uint32_t len[NL];
 #pragma unroll
             for (int r = 0; r < NL; ++r) len[r] = kp[r];
             uint32_t runs = nr; const uint32_t* in = X; uint32_t* out = Y;
 #pragma unroll
-            for (int lev = 0; lev < 3; ++lev) {
+            for (int lev = 0; lev < 4; ++lev) {
                 if ((uint32_t)lev < nlev) {   // (block-uniform)
                     uint32_t off = 0u, start = 0u;
 #pragma unroll
-                    for (int j = 0; j < (NL >> (lev + 1)); ++j) {
+                    for (int j = 0; j < (((NL + (1 << lev) - 1) >> lev) + 1) / 2; ++j) {   // pairs of a level that starts with ceil(NL / 2^lev) runs
                         if (2u * (uint32_t)j < runs) {
                             const uint32_t la = len[2 * j], lb = 2u * (uint32_t)j + 1u < runs ? len[2 * j + 1] : 0u;
                             const uint32_t lg = merge_team(la + lb);
@@ -606,7 +619,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
 #pragma unroll
             for (int x = 0; x < 5; ++x) dv[x] = o0 + x < o1 ? D[o0 + x] : 0u;
 #pragma unroll
-            for (int x = 0; x < 5; ++x) nmv[x] = o0 + x < o1 ? (uint32_t)wlut[dv[x] & NBM] : 0u;   // (class 0 does not exist)
+            for (int x = 0; x < 5; ++x) nmv[x] = o0 + x < o1 ? num_of(dv[x] & NBM) : 0u;   // (class 0 does not exist)
             if constexpr (MID) {   // <= 63 classes: a histogram in LDS (lane v of the scan below = class v)
 #pragma unroll
                 for (int x = 0; x < 5; ++x) if (o0 + x < o1) atomicAdd(&cls[nmv[x]], 1u);
@@ -683,9 +696,6 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             uint4* z = reinterpret_cast<uint4*>(smem + F_HOT);
             for (uint32_t i = tid; i < (F_TABLE - F_HOT) / 16u; i += BLOCK) z[i] = make_uint4(0u, 0u, 0u, 0u);
             if (tid < 64u) reinterpret_cast<uint4*>(thist)[tid] = make_uint4(0u, 0u, 0u, 0u);
-            // (MID: the idf bounds of the integer floors live behind the candidate buffer -- inside the merge buffers' room, so they are rewritten once the merges are over; the
-            //  lean form keeps them in the weight table's unused tail, which MID's 256 list sets fill)
-            if constexpr (MID) { if (tid < 16u) ((double*)(smem + SINV))[tid] = tid < 8u ? f.inv_idf_hot[tid] : f.inv_idf_hi; }
             if (tid < F_TABLE_WORDS / 4u) { reinterpret_cast<uint4*>(ikeys)[tid] = make_uint4(EMPTY32, EMPTY32, EMPTY32, EMPTY32);
                                             reinterpret_cast<uint4*>(iacc)[tid] = make_uint4(0u, 0u, 0u, 0u); }
         }
@@ -745,7 +755,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         for (int t = 0; t < 3; ++t) {   // (i) items 0..13
             if (wave * 64u + (uint32_t)t * BLOCK < K) {
                 const bool act = wave * 64u + lane + (uint32_t)t * BLOCK < K;
-                const uint32_t w = w10t[svr[t] & NBM], len = rq[t].x & 0xFFFFu;
+                const uint32_t w = w10_of(svr[t] & NBM), len = rq[t].x & 0xFFFFu;
                 if constexpr (FRAG) { if (act) { add2(rq[t].y, w); add2(rq[t].z, w); if (len <= 6u) add2(rq[t].w, w); } }
                 else {
                 if (act) { add2(rq[t].y, w); add2(rq[t].z, w); add2(rq[t].w, w); }
@@ -755,7 +765,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         }
         auto add_tail = [&](uint32_t p0, uint32_t sv, uint32_t hdr, const uint4& c4, const uint4& d4, uint32_t blk) {   // items 14..29 (FRAG: 4..19), then the overflow blocks
             const bool act = p0 + lane < cnt3;
-            const uint32_t len = hdr & 0xFFFFu, w = w10t[sv & NBM];
+            const uint32_t len = hdr & 0xFFFFu, w = w10_of(sv & NBM);
             const bool more = FRAG ? true : len > 30u;   // (a slot without overflow blocks keeps items in the words the others use for the block index)
             if constexpr (FRAG) {
                 if (act) { add2(c4.x, w); add2(c4.y, w); add2(c4.z, w); add2(c4.w, w); }
@@ -1024,7 +1034,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
                 else
                 if (j < len) it = len <= 15u ? os[1 + j] : (j < 14u ? os[2 + j] : ix.row_ext[os[1] + (j - 14u)]);
                 if (business && it != EMPTY32 && it >= F_DIRECT && !business_ok(cur_attr, ix.meta[it].attr)) it = EMPTY32;   // (one more gather per listed element, all in flight together)
-                if (it != EMPTY32 && it >= F_DIRECT && item_insert(ikeys, iacc, F_TABLE_BUCKETS, it, (int)w10t[h.x & NBM]) < 0) ovf = true;
+                if (it != EMPTY32 && it >= F_DIRECT && item_insert(ikeys, iacc, F_TABLE_BUCKETS, it, (int)w10_of(h.x & NBM)) < 0) ovf = true;
             }
             if (ovf) atomicOr(&misc[FS_FAIL], 8u);
         }

@@ -73,9 +73,7 @@ static constexpr uint32_t F_WORK = F_NBL, F_WORK_WORDS = (F_LDS_BYTES - F_WORK) 
 static constexpr uint32_t F_M_MAX = 2560;
 static constexpr uint32_t F_FIN_BYTES = 1024, F_FIN_ENTRIES = F_FIN_BYTES / 16 - 1;   // a query's record: header + 63 entries
 static_assert(F_CAND + F_CAND_CAP * 12 <= F_HOT, "candidate buffer overlaps the accumulators");
-static constexpr uint32_t F_SINV_MID = F_HOT - 128;   // the MID instantiation's idf bounds (its weight table takes all 512 bytes of F_W10: 256 list sets)
-static_assert(F_CAND + F_CAND_CAP * 12 <= F_SINV_MID, "MID: idf bounds behind the candidate buffer");
-static constexpr uint32_t F_MID_LISTS = 8, F_MID_LMAX = 10, F_MID_CLASSES = 63;
+static constexpr uint32_t F_MID_LISTS = 10, F_MID_LMAX = 10, F_MID_CLASSES = 63;   // the MID instantiation of vmis_fast_kernel: lists per query, session length, similarity numerators
 static_assert(F_LDS_BYTES * F_WG_PER_CU <= 160 * 1024, "LDS budget");
 static_assert(F_DUMP + F_DUMP_WORDS * 4 - F_HOT <= 65536, "16-bit row offsets");
 struct FastParams {
@@ -84,7 +82,7 @@ struct FastParams {
     double inv_idf_hot[8];      // 1 / max idf_eff over the dense idx [512 c, 512 c + 512): popular items have small idf, so their integer floor is much tighter
     double inv_idf_hi;          // 1 / max idf_eff over all items
     uint32_t* slow_list; uint32_t* slow_cnt;   // queries the fast kernel hands to vmis_predict_kernel
-    uint32_t* mid_list; uint32_t* mid_cnt;     // queries of 5..8 lists / <= 10 items / numerators up to 63: the fast kernel's MID instantiation takes them before the general kernel (null: no such tier in this launch)
+    uint32_t* mid_list; uint32_t* mid_cnt;     // queries of 5..10 lists / <= 10 items / numerators up to 63: the fast kernel's MID instantiation takes them before the general kernel (null: no such tier in this launch)
     char* fin;                  // per-query records for vmis_finish_kernel: F_FIN_BYTES each, at q * F_FIN_BYTES
     char* big_arena; uint32_t* big_list; unsigned long long* big_ticket; uint32_t big_cap_entries;   // queries with > 63 entries: overflow entries, list for vmis_finish_big_kernel,
                                                                                                       // ticket = (list length << 32 | arena entries in use)
