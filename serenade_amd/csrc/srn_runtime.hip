@@ -32,6 +32,7 @@ static void knobs_read() {
     k.host_nocopy = getenv("SRN_HOST_NOCOPY") != nullptr; k.host_trace = getenv("SRN_HOST_TRACE") != nullptr; k.timing = getenv("SRN_TIMING") != nullptr && atoi(getenv("SRN_TIMING")) != 0;
     if (const char* e = getenv("SRN_D2H_BLOCKS")) k.d2h_blocks = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_TINY_MAX")) k.tiny_max = std::max(0, atoi(e));
+    if (const char* e = getenv("SRN_TINY_FAST")) k.tiny_fast = std::min(2, std::max(0, atoi(e)));
     if (const char* e = getenv("SRN_PREDICT_LANES")) k.lanes = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_FAST_RUNS")) k.fast_runs = atoi(e) == 3 ? 3 : 0;   // tests: the fast kernel's 29-bit-rank form (3 lists per query) on a small index
     std::lock_guard<std::mutex> lk(g_knobs_mu); g_knobs = k;
@@ -322,11 +323,30 @@ static int make_geometry(const DeviceState* d, const FlatIndex& ix, const Launch
     return SRN_OK;
 }
 
+// Does the fast kernel (srn_fast.hip: lean instantiation, then MID over its hand-overs, then the general kernel over what is left) serve this launch?
+// What the fast kernel needs of the LAUNCH is the position-set condition (DESIGN.md "Why MASKS is exact": m <= m_index, lists complete) and sketch words that cannot wrap
+// at ITS session lengths (<= 10 items: the admission is per query, on the device); the batch's longest session only decides which kernels serve the hand-overs -- up to
+// round 3 one session of nine items sent the whole batch to the general kernel.
+struct FastPlan { bool fast = false, mid_tier = false; uint32_t nb_fast = 0; };
+static FastPlan fast_plan(const DeviceState* d, const FlatIndex& ix, const LaunchParams& p, const Geometry& geo, const Knobs& kn, bool has_ext) {
+    FastPlan f;
+    // the fast kernel packs (rank, set of <= 4 lists) into 32 bits whatever the general kernel's slots look like: up to 2^28 sessions with 4 lists per query,
+    // up to 2^29 with 3 (queries with more go to the MID instantiation / the general kernel)
+    const int rank_bits_f = std::max(1, bits_host(ix.n_kept ? ix.n_kept - 1 : 0));
+    f.nb_fast = kn.fast_runs == 3 && rank_bits_f <= 29 ? 3u : rank_bits_f <= 28 ? 4u : rank_bits_f <= 29 ? 3u : 0u;
+    const bool sets_exact = p.m <= ix.m_index && ix.lists_complete && !kn.no_masks;
+    const bool fast_sketch_ok = (uint64_t)p.k * std::max<uint64_t>(1, ix.max_row_len) * 9ull * 55ull < (1ull << 32);
+    f.mid_tier = !kn.no_mid && !has_ext && d->di.row_frag == 0u && p.max_len >= 5;   // (a query of <= 4 items has <= 4 lists and numerators <= 10: nothing for the MID instantiation)
+    f.fast = d->fast.row_packed != nullptr && sets_exact && (p.max_len <= 8 ? geo.masks && !geo.sketch_may_wrap : f.mid_tier && fast_sketch_ok) && f.nb_fast != 0 && kn.geometry_default() &&
+             !kn.no_fast && p.k <= F_K_MAX && p.m <= F_M_MAX && p.how_many <= 24 && (p.flags & ~(unsigned)SRN_FLAG_BUSINESS_LOGIC) == 0 && p.stats == nullptr && p.nb_rank == nullptr;
+    return f;
+}
+
 // Latency path: a handful of evolving sessions on host pointers (srn_predict: the reference's call shape, one session per call).
 // No copies, no memsets, no events: the queries are written into pinned, device-mapped memory that the kernels read directly, the
 // results come back the same way; two launches (prep kernel + general kernel, one workgroup per query) and one stream synchronise.
 // Returns 1 if a query needs the global-table pass (the caller then takes the normal path).
-static int device_predict_tiny(DeviceState* d, Workspace* w, const Geometry& geo, LaunchParams p, const uint64_t* h_items, const uint32_t* h_qoff,
+static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w, const Geometry& geo, LaunchParams p, const uint64_t* h_items, const uint32_t* h_qoff,
                                uint64_t* h_ids, double* h_scores, uint32_t* h_counts, bool blocking_wait) {
     const size_t nitems = h_qoff[p.nq], n_out = (size_t)p.nq * p.how_many;
     size_t off = 0; auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 63) / 64 * 64; return o; };
@@ -350,8 +370,33 @@ static int device_predict_tiny(DeviceState* d, Workspace* w, const Geometry& geo
     { int rc = ensure(&w->spill, &w->spill_bytes, cap_q * p.k * geo.slot_bytes); if (rc) return rc; }
     const uint32_t prep_stride = (uint32_t)(sizeof(PrepHead) + (size_t)p.max_len * sizeof(PrepItem));
     { int rc = ensure(&w->prep, &w->prep_bytes, cap_q * prep_stride); if (rc) return rc; }
-    HIP_TRY(launch_prep(st, d->di, p.items_flat, p.q_off, p.nq, p.m, p.max_len, w->prep, prep_stride));
+    // The fast kernel's launch sequence on the same zero-copy buffers where it pays (round 4): a batch with a session of > 8 items puts ALL its queries on the general kernel's
+    // non-position-set build -- 143 us per call against 52 us on config 3, and one such session in a combined round of srn_predict calls slows the whole round -- while the
+    // lean / MID instantiations serve sessions of <= 10 items at the short sessions' cost.  Four more launches (~2 us each on an idle stream), no more synchronisation.
+    const Knobs kn = knobs();
+    const FastPlan plan = fast_plan(d, ix, p, geo, kn, false);
+    const bool tiny_fast = plan.fast && (kn.tiny_fast == 2 || (kn.tiny_fast == 1 && p.max_len > 8));
+    const uint64_t big_entries = (uint64_t)cap_q * 16 + 4096;
+    if (tiny_fast) {   // (sized once, for the largest round)
+        if (w->slow_cap < cap_q) { if (w->slow_list) HIP_TRY(hipFree(w->slow_list)); w->slow_list = nullptr; w->slow_cap = 0;
+            HIP_TRY(hipMalloc((void**)&w->slow_list, (cap_q * 4 + 64) * 2)); w->slow_cap = cap_q; }
+        { int rc = ensure(&w->fin, &w->fin_bytes, cap_q * F_FIN_BYTES + 1024); if (rc) return rc; }
+        { int rc = ensure(&w->big, &w->big_bytes, big_entries * 16 + cap_q * 4 + 64); if (rc) return rc; }
+    }
+    HIP_TRY(launch_prep(st, d->di, p.items_flat, p.q_off, p.nq, p.m, p.max_len, w->prep, prep_stride, tiny_fast ? w->slow_cnt : nullptr));
     p.prep = w->prep; p.prep_stride = prep_stride;
+    if (tiny_fast) {
+        FastParams fp = d->fast; fp.slow_list = w->slow_list; fp.slow_cnt = w->slow_cnt; fp.nb = plan.nb_fast; fp.max_runs = plan.nb_fast; fp.fin = w->fin;
+        fp.big_arena = w->big; fp.big_list = (uint32_t*)(w->big + big_entries * 16); fp.big_ticket = (unsigned long long*)(w->slow_cnt + 2); fp.big_cap_entries = (uint32_t)big_entries;
+        fp.xchg = nullptr; fp.xchg_stride = 0; fp.q_base = 0;
+        fp.mid_list = plan.mid_tier ? w->slow_list + (w->slow_cap + 16) : nullptr; fp.mid_cnt = plan.mid_tier ? w->slow_cnt + 1 : nullptr;
+        HIP_TRY(launch_fast(dim3(p.nq), st, d->di, p, fp, kn.debug, 0));
+        if (plan.mid_tier) HIP_TRY(launch_fast(dim3(p.nq), st, d->di, p, fp, kn.debug, 0, true));
+        HIP_TRY(launch_predict(geo.masks, geo.slot64, false, 0, dim3(p.nq), geo.lds, st, d->di, p, geo.c, w->slow_list, w->slow_cnt, (uint32_t*)(dp + o_rl), (uint32_t*)(dp + o_rc), nullptr, 0,
+                               w->spill, ShardIO{}));
+        HIP_TRY(launch_finish(st, d->di, fp, p.out_ids, p.out_scores, p.out_counts, p.nq, p.how_many));
+        HIP_TRY(launch_finish_big(st, d->di, fp, p.out_ids, p.out_scores, p.out_counts, p.how_many, (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * 16)));
+    } else
     HIP_TRY(launch_predict(geo.masks, geo.slot64, false, 0, dim3(p.nq), geo.lds, st, d->di, p, geo.c, nullptr, nullptr, (uint32_t*)(dp + o_rl), (uint32_t*)(dp + o_rc), nullptr, 0,
                            w->spill, ShardIO{}));
     if (blocking_wait) {   // a round several callers share: sleep on an interrupt instead of spinning on the signal (the host's cores belong to the callers)
@@ -414,7 +459,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     if (!on_device && !reserve_only && !h_stats && !h_nb_rank) {
         const Knobs kn0 = knobs();
         if (p.nq <= (uint32_t)kn0.tiny_max && !d->phase_on && !kn0.dense) {
-            const int rc = device_predict_tiny(d, w, geo, p, h_items, h_qoff, h_ids, h_scores, h_counts, blocking_wait);
+            const int rc = device_predict_tiny(d, ix, w, geo, p, h_items, h_qoff, h_ids, h_scores, h_counts, blocking_wait);
             if (rc != 1) return rc;   // (1: some query needs the global-table pass -- the paths below have it)
         }
         // everything larger: chunks through pinned staging, uploads / kernels / downloads overlapped (srn_hostpipe.hip); each chunk comes back here as a
@@ -484,18 +529,8 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         int rc = ensure(&w->prep2, &w->prep2_bytes, (size_t)p.nq * prep_stride); if (rc) return rc;
         rc = ensure_side(w); if (rc) return rc;
     }
-    // the fast kernel packs (rank, set of <= 4 lists) into 32 bits whatever the general kernel's slots look like: up to 2^28 sessions with 4 lists per query,
-    // up to 2^29 with 3 (queries with more go to the general kernel)
-    const int rank_bits_f = std::max(1, bits_host(ix.n_kept ? ix.n_kept - 1 : 0));
-    const uint32_t nb_fast = kn.fast_runs == 3 && rank_bits_f <= 29 ? 3u : rank_bits_f <= 28 ? 4u : rank_bits_f <= 29 ? 3u : 0u;
-    // What the fast kernel needs of the LAUNCH is the position-set condition (DESIGN.md "Why MASKS is exact": m <= m_index, lists complete) and sketch words that cannot wrap
-    // at ITS session lengths (<= 10 items: the admission is per query, on the device); the batch's longest session only decides which kernel serves the hand-overs -- up to
-    // round 3 one session of nine items sent the whole batch to the general kernel.
-    const bool sets_exact = p.m <= ix.m_index && ix.lists_complete && !kn.no_masks;
-    const bool fast_sketch_ok = (uint64_t)p.k * std::max<uint64_t>(1, ix.max_row_len) * 9ull * 55ull < (1ull << 32);
-    const bool mid_tier = !kn.no_mid && !ext && d->di.row_frag == 0u && p.max_len >= 5;   // (a query of <= 4 items has <= 4 lists and numerators <= 10: nothing for the MID instantiation)
-    const bool fast = d->fast.row_packed != nullptr && sets_exact && (p.max_len <= 8 ? geo.masks && !geo.sketch_may_wrap : mid_tier && fast_sketch_ok) && nb_fast != 0 && kn.geometry_default() &&
-                      !kn.no_fast && p.k <= F_K_MAX && p.m <= F_M_MAX && p.how_many <= 24 && (p.flags & ~(unsigned)SRN_FLAG_BUSINESS_LOGIC) == 0 && p.stats == nullptr && p.nb_rank == nullptr;
+    const FastPlan plan = fast_plan(d, ix, p, geo, kn, ext != nullptr);
+    const uint32_t nb_fast = plan.nb_fast; const bool mid_tier = plan.mid_tier, fast = plan.fast;
     if (fast) {   // (all allocations of a call happen before its first launch)
         if (w->slow_cap < p.nq) { if (w->slow_list) HIP_TRY(hipFree(w->slow_list)); w->slow_list = nullptr; w->slow_cap = 0;
             HIP_TRY(hipMalloc((void**)&w->slow_list, ((size_t)p.nq * 4 + 64) * 2)); w->slow_cap = p.nq; }   // (second half: the MID instantiation's list)

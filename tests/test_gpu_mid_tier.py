@@ -172,3 +172,34 @@ def test_synthetic_tiny_long_sessions(no_mid):
         ref = sa.predict_batch(gix, qs, k, m, synth.HOW_MANY, False)
         for a, b in zip(got, ref):
             assert np.array_equal(a, b), "with and without the MID tier the results must be the same bytes"
+
+
+def test_latency_path_runs_the_fast_launch_sequence(monkeypatch):
+    """srn_predict / host batches of <= 256 sessions (the zero-copy latency path): since round 4 the fast kernel's launch sequence (lean -> MID -> general -> finish) on the same pinned
+    buffers wherever the shape allows it (SRN_TINY_FAST=2, the default); 0 = prep + general kernel as in rounds 1-3.  Same bytes either way, equal to the oracle."""
+    import serenade_amd as sa
+    from serenade_amd import synth, capi
+    O = _oracle()
+    inter, n_items, k, m, idfw = synth.CONFIGS["tiny"]
+    off, items, ts = synth.training_sessions(inter, n_items)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw)
+    oix = O.OracleIndex(off, items, ts, m, 34, idfw, fast=True)
+    qi, qo = synth.queries(400, n_items, max_items=10)
+    qs = [qi[qo[i]:qo[i + 1]].tolist() for i in range(min(len(qo) - 1, 600))]
+    qs[3] = [int(x) for x in qi[:14]]   # 14 items: negative weights, the general kernel's whatever the path
+    got = {}
+    try:
+        for mode in ("2", "0", "1"):
+            monkeypatch.setenv("SRN_TINY_FAST", mode); capi.reload_knobs()
+            rows = []
+            for lo in range(0, len(qs), 150):          # batches of <= 256: the latency path
+                rows.append(_against_oracle(gix, oix, qs[lo:lo + 150], k, m, synth.HOW_MANY))
+            single = [sa.predict(gix, q, k, m, synth.HOW_MANY, False) for q in qs[:40]]   # the reference's call shape
+            got[mode] = (rows, [[(r.id, r.score) for r in recs] for recs in single])
+    finally:
+        monkeypatch.undo(); capi.reload_knobs()
+    for mode in ("0", "1"):
+        for (a, b) in zip(got["2"][0], got[mode][0]):
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y), "latency path: the fast launch sequence and the general kernel must give the same bytes"
+        assert got["2"][1] == got[mode][1]
