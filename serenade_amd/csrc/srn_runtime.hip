@@ -32,7 +32,7 @@ static void knobs_read() {
     k.host_nocopy = getenv("SRN_HOST_NOCOPY") != nullptr; k.host_trace = getenv("SRN_HOST_TRACE") != nullptr; k.timing = getenv("SRN_TIMING") != nullptr && atoi(getenv("SRN_TIMING")) != 0;
     if (const char* e = getenv("SRN_D2H_BLOCKS")) k.d2h_blocks = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_TINY_MAX")) k.tiny_max = std::max(0, atoi(e));
-    if (const char* e = getenv("SRN_TINY_FAST")) k.tiny_fast = std::min(2, std::max(0, atoi(e)));
+    if (const char* e = getenv("SRN_TINY_FAST")) k.tiny_fast = std::min(3, std::max(0, atoi(e)));
     if (const char* e = getenv("SRN_PREDICT_LANES")) k.lanes = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_FAST_RUNS")) k.fast_runs = atoi(e) == 3 ? 3 : 0;   // tests: the fast kernel's 29-bit-rank form (3 lists per query) on a small index
     std::lock_guard<std::mutex> lk(g_knobs_mu); g_knobs = k;
@@ -375,7 +375,7 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
     // lean / MID instantiations serve sessions of <= 10 items at the short sessions' cost.  Four more launches (~2 us each on an idle stream), no more synchronisation.
     const Knobs kn = knobs();
     const FastPlan plan = fast_plan(d, ix, p, geo, kn, false);
-    const bool tiny_fast = plan.fast && (kn.tiny_fast == 2 || (kn.tiny_fast == 1 && p.max_len > 8));
+    const bool tiny_fast = plan.fast && (kn.tiny_fast == 3 || (kn.tiny_fast >= 1 && p.max_len > 8) || (kn.tiny_fast == 2 && p.nq <= 16));
     const uint64_t big_entries = (uint64_t)cap_q * 16 + 4096;
     if (tiny_fast) {   // (sized once, for the largest round)
         if (w->slow_cap < cap_q) { if (w->slow_list) HIP_TRY(hipFree(w->slow_list)); w->slow_list = nullptr; w->slow_cap = 0;

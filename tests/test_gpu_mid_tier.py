@@ -176,7 +176,7 @@ def test_synthetic_tiny_long_sessions(no_mid):
 
 def test_latency_path_runs_the_fast_launch_sequence(monkeypatch):
     """srn_predict / host batches of <= 256 sessions (the zero-copy latency path): since round 4 the fast kernel's launch sequence (lean -> MID -> general -> finish) on the same pinned
-    buffers wherever the shape allows it (SRN_TINY_FAST=2, the default); 0 = prep + general kernel as in rounds 1-3.  Same bytes either way, equal to the oracle."""
+    buffers for calls of <= 16 sessions and for batches with a session of > 8 items (SRN_TINY_FAST=2, the default; 3 = wherever the shape allows it); 0 = prep + general kernel as in rounds 1-3.  Same bytes either way, equal to the oracle."""
     import serenade_amd as sa
     from serenade_amd import synth, capi
     O = _oracle()
@@ -189,7 +189,7 @@ def test_latency_path_runs_the_fast_launch_sequence(monkeypatch):
     qs[3] = [int(x) for x in qi[:14]]   # 14 items: negative weights, the general kernel's whatever the path
     got = {}
     try:
-        for mode in ("2", "0", "1"):
+        for mode in ("3", "0", "1", "2"):
             monkeypatch.setenv("SRN_TINY_FAST", mode); capi.reload_knobs()
             rows = []
             for lo in range(0, len(qs), 150):          # batches of <= 256: the latency path
@@ -198,8 +198,8 @@ def test_latency_path_runs_the_fast_launch_sequence(monkeypatch):
             got[mode] = (rows, [[(r.id, r.score) for r in recs] for recs in single])
     finally:
         monkeypatch.undo(); capi.reload_knobs()
-    for mode in ("0", "1"):
-        for (a, b) in zip(got["2"][0], got[mode][0]):
+    for mode in ("0", "1", "2"):
+        for (a, b) in zip(got["3"][0], got[mode][0]):
             for x, y in zip(a, b):
                 assert np.array_equal(x, y), "latency path: the fast launch sequence and the general kernel must give the same bytes"
-        assert got["2"][1] == got[mode][1]
+        assert got["3"][1] == got[mode][1]
