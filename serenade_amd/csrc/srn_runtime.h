@@ -34,8 +34,8 @@ struct Knobs {
     int tiny_max = 256;       // SRN_TINY_MAX: host-pointer batches of up to this many sessions take the zero-copy latency path
     int tiny_fast = 2;        // SRN_TINY_FAST: the latency path's kernels -- 0: prep + general kernel (rounds 1-3); 1: the fast kernel's launch sequence only where the batch has a session of > 8 items (which puts
                               // the whole batch on the general kernel's non-position-set build: 144 us against 52 us per call on config 3); 2 (default): also for calls of <= 16 sessions (one session per call,
-                              // config 3, max_items 4: p50 53.3 -> 47.8 us, p90 63.7 -> 54.1; larger rounds stay on the general kernel -- one workgroup per query runs them all at once, and the four extra
-                              // launches cost a round of 64 sessions 59 us: profiles/r04_serving_tiny_fast.txt); 3: wherever the batch's shape allows it (experiments)
+                              // config 3, max_items 4: p50 53.3 -> 47.8 us, p90 63.7 -> 54.1; larger rounds stay on the general kernel -- one workgroup per query runs them all at once: nothing to gain,
+                              // four more launches to pay: profiles/r04_serving_tiny_fast.txt); 3: wherever the batch's shape allows it (experiments)
     int row_slots16 = -1;     // SRN_ROW_SLOTS = 16 | 64: the device row layout (-1 = by index kind: 64-byte slots unsharded, 16-byte fragment slots for item shards)
     int lanes = 4;            // SRN_PREDICT_LANES: concurrent rounds of the srn_predict combiner (srn_combine.cpp)
     bool geometry_default() const { return !no_masks && !no_merge && !dense && hot_slots < 0 && sketch_slots < 0 && lds_budget_kb == 0; }
