@@ -17,7 +17,7 @@ off, items, ts = synth.training_sessions(inter, n_items)
 gix = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw)
 oix = O.OracleIndex(off, items, ts, m, 34, idfw, fast=True)
 NQ = 150000
-flat, qoff = synth.queries(NQ, n_items)
+flat, qoff = synth.queries(NQ, n_items, max_items=int(os.environ.get("SOAK_MAX_ITEMS", "10")))   # (sessions of up to 10 items since round 4: the fast kernel's MID instantiation and the latency path's fast sequence are in the mix; 4 = the headline workload)
 NQ = len(qoff) - 1
 n = 21
 # several parameter sets in flight at once: the workspaces are re-sized and the kernel path (fast kernel or not, position sets or not) changes from call to call
