@@ -44,6 +44,17 @@ static constexpr uint32_t F_MERGE_WORDS = F_WORK_WORDS;
 #ifndef SRN_FAST_RELOAD_ROWS
 #define SRN_FAST_RELOAD_ROWS 0
 #endif
+// Wave priorities by phase (s_setprio, round 4).  The kernel is held by issue-slot contention between workgroups in DIFFERENT phases (a wave is ready but cannot
+// issue 26 % of its time): the front end and the harvest are chains of dependent LDS reads -- every cycle a ready instruction of theirs waits lengthens the query -- while walk A
+// is bound by the LDS pipe's atomic throughput and loses nothing by yielding the issue slot.  SRN_FAST_PRIO_LEVELS = eight decimal digits, one level (0..3) per phase: record ->
+// first barrier | stage + merge tree | cuts | row requests + clears | walk A | phase 4a | live check .. resolve | wave 0's hand-off; 0 = no s_setprio at all (the kernel of rounds 2-3).
+// Measured on config 3 (tools/ab_variants.sh, profiles/r04_prio_ab.txt): the levels below 22.68 ms against 23.40 without; what matters is the ORDER row requests + clears < walk A <
+// front end < harvest = hand-off -- the nearer a query is to its end the higher, except that the two walk phases yield to everybody (raising either costs the whole gain).
+#ifndef SRN_FAST_PRIO_LEVELS
+#define SRN_FAST_PRIO_LEVELS 22201333
+#endif
+enum { FP_REC = 10000000, FP_FRONT = 1000000, FP_CUT = 100000, FP_REQ = 10000, FP_WALK = 1000, FP_HARV = 100, FP_WB = 10, FP_HAND = 1 };
+#define FAST_PRIO(ph) do { if (SRN_FAST_PRIO_LEVELS) __builtin_amdgcn_s_setprio((short)(((SRN_FAST_PRIO_LEVELS) / (ph)) % 10)); } while (0)
 #ifndef SRN_FAST_STOP
 #define SRN_FAST_STOP (-1)   // experiments only (tools/fast_phase_insts.sh): every query leaves after phase tick N, to count instructions per phase
 #endif
@@ -369,6 +380,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
     for (uint32_t qi = (MODE == FM_FRONT ? f.q_base : 0u) + blockIdx.x; qi < q_end; qi += gridDim.x) {
         const uint32_t q = MID ? f.mid_list[qi] : qi;
         long long t_prev = ticking ? clock64() : 0;
+        FAST_PRIO(FP_REC);
         // ---- phase 0: the query's prep record -> run descriptors in SGPRs ------------------------------
         const char* const rec = p.prep + (size_t)q * p.prep_stride;
         struct { uint32_t U, rmax, xlo, sumw, L, n_staged, cur_attr; } hd;
@@ -440,6 +452,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             for (int j = 0; j < 5; ++j) { v[r][j] = 0u; if ((uint32_t)j * BLOCK < kp[r]) v[r][j] = src[r][min(tid + j * BLOCK, kp[r] - 1u)]; }
         }
         __syncthreads();   // previous query's LDS reads are done
+        FAST_PRIO(FP_FRONT);
         // (opaque copies: with a compile-time shift the packing of a staged entry is otherwise hoisted into the conditional block of its load, which then
         //  ends in s_waitcnt vmcnt(0) -- the lists' loads would go out one HBM round trip after the other instead of all together)
         if constexpr (MODE != FM_BACK) {
@@ -563,6 +576,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
                              merge_pair(B1, B0, 0u, s2, kp[2] + kp[3], tid, merge_team(n)); __syncthreads(); }
         }
         FAST_TICK(3);
+        FAST_PRIO(FP_CUT);
         const uint32_t* F = B0; uint32_t* D = B1;
         // ---- the two cuts in one pass over the merged run (fast_cut above) where a thread's chunk is <= 6 entries (n <= 3072: four queries in five); the two-pass form below otherwise ----
         if (!MID && SRN_FAST_FUSED_CUT && n <= 6u * BLOCK) {   // (block-uniform)
@@ -674,6 +688,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         }
 
         FAST_TICK(4);
+        FAST_PRIO(FP_REQ);
         if constexpr (MODE == FM_FRONT) {   // the neighbour list leaves for the exchange buffer (a barrier stands between its last write and here in every branch above)
             if (tid == 0) xq[0] = K;
 #pragma unroll
@@ -700,6 +715,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
                                             reinterpret_cast<uint4*>(iacc)[tid] = make_uint4(0u, 0u, 0u, 0u); }
         }
         __syncthreads();   // (also: every wave holds its neighbour slots in registers, the list's LDS is free for the queue)
+        FAST_PRIO(FP_WALK);
         FAST_TICK(8);
         auto add2 = [&](uint32_t wd, uint32_t w) {
             atomicAdd((uint32_t*)(acc_base + (wd & 0xFFFFu)), w); atomicAdd((uint32_t*)(acc_base + (wd >> 16)), w); };
@@ -790,6 +806,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         FAST_TICK(7);   // (wave 0's tail rounds done; what follows is the wait for the other waves)
 #endif
         __syncthreads();
+        FAST_PRIO(FP_HARV);
         FAST_TICK(9);
         // ---- phase 4a: the direct-mapped items, exactly -> threshold, candidates ----------------------------
         // Sample = the 512 most popular items, dealt round-robin to the waves: every wave takes the 3rd largest of its 64 values
@@ -894,6 +911,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         }
         if (!MID && wave == 1u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the record has landed
         FAST_TICK(10);
+        FAST_PRIO(FP_WB);
         {
             const uint32_t ns = min(misc[FS_SURV], SURV_CAP);
             for (uint32_t i = tid; i < ns; i += BLOCK) {
@@ -1051,6 +1069,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         // The candidates and the table's contenders (exact sum at the floor; the others were collisions in their sketch word) are
         // written to a per-query record instead, and vmis_finish_kernel ranks all queries of the batch, one wave each.
         if (wave != 0u) continue;
+        FAST_PRIO(FP_HAND);
         // (every lane-derived value of this tail is recomputed from an opaque copy of the lane id: hoisted out of the query loop, such
         //  values stay live through all phases, get spilled at the 80-register cap and come back from scratch right here, on the serial path)
         uint32_t ln = lane; asm volatile("" : "+v"(ln));

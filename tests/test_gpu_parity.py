@@ -60,7 +60,7 @@ def test_kat1_should_train_and_predict():
         assert r.score == pytest.approx(1.751319134149782, rel=1e-12)
 
 
-@pytest.fixture(params=["default", "no_fast", "fast_runs3", "no_masks", "no_hot", "hot64", "no_sketch", "sketch64", "no_merge", "dense"])
+@pytest.fixture(params=["default", "no_fast", "no_mid", "fast_runs3", "no_masks", "no_hot", "hot64", "no_sketch", "sketch64", "no_merge", "dense"])
 def kernel_path(request, monkeypatch):
     """The kernel picks code paths per launch: position-set slots (sessions <= 8 items) vs numerator slots + first-match
     pass; direct-mapped accumulators for popular items vs hash only; sketch pre-filter on / off / tiny; candidate sessions by
@@ -85,6 +85,9 @@ def kernel_path(request, monkeypatch):
         monkeypatch.setenv("SRN_FAST_RUNS", "3")
     elif request.param == "no_fast":           # the general kernel alone (the fast kernel hands it single queries otherwise)
         monkeypatch.setenv("SRN_NO_FAST", "1")
+    elif request.param == "no_mid":            # round 3's launch sequence: no MID instantiation between the lean fast kernel and the general kernel ("default" has it since round 4:
+        monkeypatch.setenv("SRN_NO_MID", "1")  # sessions of 5..10 items in these tests' batches go through it), and the latency path on prep + general kernel
+        monkeypatch.setenv("SRN_TINY_FAST", "0")
     from serenade_amd import capi
     capi.reload_knobs()                        # the library reads its knobs once; tests switch paths between calls
     yield request.param

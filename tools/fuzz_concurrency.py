@@ -17,7 +17,8 @@ off, items, ts = synth.training_sessions(inter, n_items)
 gix = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw)
 oix = O.OracleIndex(off, items, ts, m, 34, idfw, fast=True)
 NQ = 150000
-flat, qoff = synth.queries(NQ, n_items, max_items=int(os.environ.get("SOAK_MAX_ITEMS", "10")))   # (sessions of up to 10 items since round 4: the fast kernel's MID instantiation and the latency path's fast sequence are in the mix; 4 = the headline workload)
+MAX_ITEMS = int(os.environ.get("SOAK_MAX_ITEMS", "10"))
+flat, qoff = synth.queries(NQ, n_items, max_items=MAX_ITEMS)   # (sessions of up to 10 items since round 4: the fast kernel's MID instantiation and the latency path's fast sequence are in the mix; 4 = the headline workload)
 NQ = len(qoff) - 1
 n = 21
 # several parameter sets in flight at once: the workspaces are re-sized and the kernel path (fast kernel or not, position sets or not) changes from call to call
@@ -68,13 +69,13 @@ def worker(tid):
                         d_f = d_flat_all[int(qoff[lo]):int(qoff[hi])]; d_o = torch.from_numpy(o.view(np.int32).copy()).to(dev, non_blocking=False)
                         if op == "device":
                             r_ids = torch.zeros(size * n, dtype=torch.int64, device=dev); r_sc = torch.zeros(size * n, dtype=torch.float64, device=dev); r_cnt = torch.zeros(size, dtype=torch.int32, device=dev)
-                            sa.predict_batch_device(gix, d_f.data_ptr(), d_o.data_ptr(), size, synth.LAST_ITEMS, k, m, n, False, r_ids.data_ptr(), r_sc.data_ptr(), r_cnt.data_ptr(), st.cuda_stream)
+                            sa.predict_batch_device(gix, d_f.data_ptr(), d_o.data_ptr(), size, MAX_ITEMS, k, m, n, False, r_ids.data_ptr(), r_sc.data_ptr(), r_cnt.data_ptr(), st.cuda_stream)
                             st.synchronize()
                             cmp(lo, hi, r_ids.cpu().numpy().view(np.uint64).reshape(size, n), r_sc.cpu().numpy().reshape(size, n), r_cnt.cpu().numpy().view(np.uint32), "device batch of %d, params %r" % (size, PARAMS[pi]), pi)
                         else:
                             size = min(size, 20000); hi = lo + size
                             d_f = d_flat_all[int(qoff[lo]):int(qoff[hi])]; d_o = torch.from_numpy((qoff[lo:hi + 1] - qoff[lo]).astype(np.int32)).to(dev)
-                            res = grp.predict_batch(d_f, d_o, size, synth.LAST_ITEMS, k, m, n, False, stream=st.cuda_stream)   # (the group serialises its callers; consecutive batches may come on different streams)
+                            res = grp.predict_batch(d_f, d_o, size, MAX_ITEMS, k, m, n, False, stream=st.cuda_stream)   # (the group serialises its callers; consecutive batches may come on different streams)
                             st.synchronize()
                             cmp(lo, hi, res[0].cpu().numpy().view(np.uint64), res[1].cpu().numpy(), res[2].cpu().numpy().view(np.uint32), "shard group batch of %d, params %r" % (size, PARAMS[pi]), pi)
             with cl: counts[op] += 1
