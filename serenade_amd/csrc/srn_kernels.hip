@@ -457,6 +457,13 @@ __global__ __launch_bounds__(256) void vmis_prep_kernel(DeviceIndex ix, const ui
     hw[8 + sub] = sub < nruns ? my_run_start : 0u;
 }
 
+// Wave priorities by phase (s_setprio), as in vmis_fast_kernel (srn_fast.hip, where the measurements are): four decimal digits = front end (record .. cuts) | clears |
+// walk A | harvest (phase 4a .. final top-n); 0 = none.  Config 3, the general kernel alone over 2^18 queries (SRN_NO_FAST=1 tools/fast_time.py): 15.65 ms without, 15.46 with 2013
+// (2003 / 2113 / 1002: 15.48-15.54) -- two workgroups per CU contend less than the fast kernel's three.
+#ifndef SRN_GEN_PRIO_LEVELS
+#define SRN_GEN_PRIO_LEVELS 2013
+#endif
+#define GEN_PRIO(ph) do { if (SRN_GEN_PRIO_LEVELS) __builtin_amdgcn_s_setprio((short)(((SRN_GEN_PRIO_LEVELS) / (ph)) % 10)); } while (0)
 #ifndef SRN_STOP_AT
 #define SRN_STOP_AT (-1)   // experiments only (tools/phase_insts.sh): leave the query after phase tick N (0..4, 8..10) to count instructions per phase
 #endif
@@ -546,6 +553,7 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
         // ---- phase 0: reset, translate items ---------------------------------------------
         __syncthreads();   // previous query's LDS reads are done
         long long t_prev = ticking ? clock64() : 0;
+        GEN_PRIO(1000);
         if (tid < MISC_WORDS) misc[tid] = 0;
         for (uint32_t i = tid; i < SEL_WORDS; i += BLOCK) hist[i] = 0;
         if (MASKS && tid < 256) { uint32_t acc = 0; for (uint32_t b = 0; b < L; ++b) if ((tid >> b) & 1) acc += L - b; wlut[tid] = (uint8_t)acc; }
@@ -1068,6 +1076,7 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
         __syncthreads();
         K = misc[S_NB];
         SRN_TICK(4);
+        GEN_PRIO(100);
         if constexpr (STAGE == 1) { if (tid == 0) sh.cand_cnt[q] = K; continue; }
         if constexpr (STAGE == 2) {   // same neighbour order on every shard: sort by the (unique) packed value, descending
             uint32_t n2 = 2; while (n2 < K) n2 <<= 1;
@@ -1293,6 +1302,7 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
         for (uint32_t i = tid; i < H + SK; i += BLOCK) hot[i] = 0;   // direct-mapped words and the sketch are adjacent
         if (tid == 0) { misc[S_CCNT] = 0; misc[S_HAVE_T] = 0; misc[S_SORTED] = 0; misc[S_I] = 0; misc[S_LIVE] = 0; misc[S_ICNT] = 0; }
         phase_sync<GLOBAL_TABLES>();
+        GEN_PRIO(10);
         SRN_TICK(8);
         {   // walk A
             // one LDS add per element: idx < H -> its direct-mapped word, anything else -> sketch word idx mod SK (sketch = hot + H).
@@ -1331,6 +1341,7 @@ __global__ __launch_bounds__(BLOCK, (WG_PER_CU * BLOCK) / 256) void vmis_predict
             if (lane == 0 && p.stats && isum) atomicAdd((uint32_t*)&misc[S_I], isum);
         }
         phase_sync<GLOBAL_TABLES>();
+        GEN_PRIO(1);
         SRN_TICK(9);
         uint32_t d_total = 0;
         if (p.stats && H) {   // debug counters only: distinct items = touched direct-mapped entries + hash inserts
