@@ -54,6 +54,12 @@ static constexpr uint32_t F_MERGE_WORDS = F_WORK_WORDS;
 #define SRN_FAST_PRIO_LEVELS 22201333
 #endif
 enum { FP_REC = 10000000, FP_FRONT = 1000000, FP_CUT = 100000, FP_REQ = 10000, FP_WALK = 1000, FP_HARV = 100, FP_WB = 10, FP_HAND = 1 };
+// (two more points -- SRN_FAST_PRIO_X = two digits, 9 = leave as is: the row REQUESTS alone (the clears behind them then take FP_REQ's level), walk A's tail rounds.  Measured: the requests at
+//  level 2 or 3: 23.05-23.10 ms against 22.75 -- they too must yield; the tail rounds (a second HBM / L2 round trip: latency, not throughput) at level 2: 22.65, at 3: 22.68)
+#ifndef SRN_FAST_PRIO_X
+#define SRN_FAST_PRIO_X 92
+#endif
+#define FAST_PRIO_X(div) do { if (SRN_FAST_PRIO_LEVELS && ((SRN_FAST_PRIO_X) / (div)) % 10 != 9) __builtin_amdgcn_s_setprio((short)(((SRN_FAST_PRIO_X) / (div)) % 10)); } while (0)
 #define FAST_PRIO(ph) do { if (SRN_FAST_PRIO_LEVELS) __builtin_amdgcn_s_setprio((short)(((SRN_FAST_PRIO_LEVELS) / (ph)) % 10)); } while (0)
 #ifndef SRN_FAST_STOP
 #define SRN_FAST_STOP (-1)   // experiments only (tools/fast_phase_insts.sh): every query leaves after phase tick N, to count instructions per phase
@@ -688,7 +694,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         }
 
         FAST_TICK(4);
-        FAST_PRIO(FP_REQ);
+        FAST_PRIO(FP_REQ); FAST_PRIO_X(10);
         if constexpr (MODE == FM_FRONT) {   // the neighbour list leaves for the exchange buffer (a barrier stands between its last write and here in every branch above)
             if (tid == 0) xq[0] = K;
 #pragma unroll
@@ -707,6 +713,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             const size_t r = (MODE == FM_BACK ? j < K : K != 0u) ? (size_t)(base + (svr[t] >> NB)) : (size_t)n_kept;   // (idle lanes re-read the last neighbour's row)
             rq[t] = *reinterpret_cast<const uint4*>(&f.row_packed[r * (FRAG ? 1 : 4)]); rq1[t] = make_uint4(0u, 0u, 0u, 0u);
         }
+        if (((SRN_FAST_PRIO_X) / 10) % 10 != 9) FAST_PRIO(FP_REQ);
         {   // clear: accumulators + sketch + dump, exact table (keys EMPTY32, sums 0)
             uint4* z = reinterpret_cast<uint4*>(smem + F_HOT);
             for (uint32_t i = tid; i < (F_TABLE - F_HOT) / 16u; i += BLOCK) z[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -800,6 +807,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
 #ifdef SRN_FAST_SUBTICKS
         FAST_TICK(6);   // (round (i): second 16 bytes + adds issued)
 #endif
+        FAST_PRIO_X(1);
         if (cnt3) add_tail(0u, sv3, hdr3, c43, d43, blk3);
         for (uint32_t p0 = 64u; p0 < cnt3; p0 += 64u) { uint32_t sv, hdr, blk; uint4 c4, d4; q3_load(p0, sv, hdr, c4, d4, blk); add_tail(p0, sv, hdr, c4, d4, blk); }
 #ifdef SRN_FAST_SUBTICKS
