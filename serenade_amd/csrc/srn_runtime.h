@@ -33,7 +33,7 @@ struct Knobs {
     int d2h_blocks = 0;       // SRN_D2H_BLOCKS: workgroups of the chunked host path's own download kernel (0 = hipMemcpyAsync, the default: measured faster, profiles/r03_host_pipe_probe.txt)
     int tiny_max = 256;       // SRN_TINY_MAX: host-pointer batches of up to this many sessions take the zero-copy latency path
     int tiny_fast = 2;        // SRN_TINY_FAST: the latency path's kernels -- 0: prep + general kernel (rounds 1-3); 1: the fast kernel's launch sequence only where the batch has a session of > 8 items (which puts
-                              // the whole batch on the general kernel's non-position-set build: 144 us against 52 us per call on config 3); 2 (default): also for calls of <= 16 sessions (one session per call,
+                              // the whole batch on the general kernel's non-position-set build: 144 us against 52 us per call on config 3); 2 (default): also for calls of <= 32 sessions (one session per call,
                               // config 3, max_items 4: p50 53.3 -> 47.8 us, p90 63.7 -> 54.1; larger rounds stay on the general kernel -- one workgroup per query runs them all at once: nothing to gain,
                               // four more launches to pay: profiles/r04_serving_tiny_fast.txt); 3: wherever the batch's shape allows it (experiments)
     int row_slots16 = -1;     // SRN_ROW_SLOTS = 16 | 64: the device row layout (-1 = by index kind: 64-byte slots unsharded, 16-byte fragment slots for item shards)

@@ -375,7 +375,7 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
     // lean / MID instantiations serve sessions of <= 10 items at the short sessions' cost.  Four more launches (~2 us each on an idle stream), no more synchronisation.
     const Knobs kn = knobs();
     const FastPlan plan = fast_plan(d, ix, p, geo, kn, false);
-    const bool tiny_fast = plan.fast && (kn.tiny_fast == 3 || (kn.tiny_fast >= 1 && p.max_len > 8) || (kn.tiny_fast == 2 && p.nq <= 16));
+    const bool tiny_fast = plan.fast && (kn.tiny_fast == 3 || (kn.tiny_fast >= 1 && p.max_len > 8) || (kn.tiny_fast == 2 && p.nq <= 32));   // (the crossover measured with tools/tiny_crossover.py: profiles/r04_serving_tiny_fast.txt)
     const uint64_t big_entries = (uint64_t)cap_q * 16 + 4096;
     if (tiny_fast) {   // (sized once, for the largest round)
         if (w->slow_cap < cap_q) { if (w->slow_list) HIP_TRY(hipFree(w->slow_list)); w->slow_list = nullptr; w->slow_cap = 0;

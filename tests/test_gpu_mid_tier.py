@@ -176,7 +176,7 @@ def test_synthetic_tiny_long_sessions(no_mid):
 
 def test_latency_path_runs_the_fast_launch_sequence(monkeypatch):
     """srn_predict / host batches of <= 256 sessions (the zero-copy latency path): since round 4 the fast kernel's launch sequence (lean -> MID -> general -> finish) on the same pinned
-    buffers for calls of <= 16 sessions and for batches with a session of > 8 items (SRN_TINY_FAST=2, the default; 3 = wherever the shape allows it); 0 = prep + general kernel as in rounds 1-3.  Same bytes either way, equal to the oracle."""
+    buffers for calls of <= 32 sessions and for batches with a session of > 8 items (SRN_TINY_FAST=2, the default; 3 = wherever the shape allows it); 0 = prep + general kernel as in rounds 1-3.  Same bytes either way, equal to the oracle."""
     import serenade_amd as sa
     from serenade_amd import synth, capi
     O = _oracle()
