@@ -777,7 +777,7 @@ int device_last_kernel_ms(DeviceState* d, double* ms_main, double* ms_retry, uin
     Workspace* w;
     { std::lock_guard<std::mutex> lk(d->mu); w = d->last_ws; }
     if (!w || !(w->calls + w->untimed_calls)) return fail(SRN_EINVAL, "no timed predict call yet");
-    if (w->last_untimed) return fail(SRN_EINVAL, "the last call took the latency path (<= 16 sessions on host pointers): it records no events");
+    if (w->last_untimed) return fail(SRN_EINVAL, "the last call took the latency path (<= 256 sessions on host pointers): it records no events");
     if (!w->ring_timed[(w->calls - 1) % Workspace::RING]) return fail(SRN_EINVAL, "kernel timing is off: srn_kernel_timing(idx, 1) before the calls to be timed");
     hipEvent_t* ev = w->ev[(w->calls - 1) % Workspace::RING];
     HIP_TRY(hipEventSynchronize(ev[2]));
