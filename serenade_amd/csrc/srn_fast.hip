@@ -313,7 +313,7 @@ __device__ __forceinline__ uint32_t fast_cut(const uint32_t* F, uint32_t* nbl, u
 // hyper-parameter grid of last_items_in_session (1, 2, 3, 5, 10: src/hyperparameter/hyperparamgrid.rs:93-139) instead of the <= 4 lists / numerators <= 15 of the lean
 // form.  Same LDS map, same walks; what differs: the queries come from a device-side list (f.mid_list, filled by the lean instantiation's hand-overs), slots carry as many
 // list bits as the query has lists (ranks counted from the cut x_lo), the lists are staged four at a time, a merge tree of up to four levels with the run lengths in SGPRs, the
-// two-pass cuts with a 64-bin class histogram in LDS (lane v = class v), weights from two half-set tables (lists 0..4 | 5..9), no record prefetch.  A session of 10 items can see weight 0 (linear_score(10), mod.rs:110-116):
+// two-pass cuts with a 64-bin class histogram in LDS (lane v = class v), weights from two half-set tables (lists 0..4 | 5..9), no record prefetch (parking the next record through the list's indirection measured flat: SRN_MID_PREFETCH).  A session of 10 items can see weight 0 (linear_score(10), mod.rs:110-116):
 // its zero-weight neighbours add nothing, and a query whose positive-score items do not fill the top n -- the only case in which a zero-score item can be returned --
 // goes to the general kernel.
 enum { FM_FUSED = 0, FM_FRONT = 1, FM_BACK = 2 };
@@ -385,6 +385,10 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
     const uint32_t q_end = MID ? *f.mid_cnt : p.nq;   // (MID: the list is final -- the lean instantiation's launch is over)
     for (uint32_t qi = (MODE == FM_FRONT ? f.q_base : 0u) + blockIdx.x; qi < q_end; qi += gridDim.x) {
         const uint32_t q = MID ? f.mid_list[qi] : qi;
+#ifndef SRN_MID_PREFETCH
+#define SRN_MID_PREFETCH 0   // (experiment, measured flat: 7.73 / 8.61 ms per 2^18 queries at max_items 8 / 10 with or without it, and 16 bytes of scratch with)
+#endif
+        const uint32_t q_after = !(MID && SRN_MID_PREFETCH) ? 0xFFFFFFFFu : qi + gridDim.x < q_end ? f.mid_list[qi + gridDim.x] : 0xFFFFFFFFu;   // (MID: the query this workgroup serves next -- its record is parked during this one, like the lean form's)
         long long t_prev = ticking ? clock64() : 0;
         FAST_PRIO(FP_REC);
         // ---- phase 0: the query's prep record -> run descriptors in SGPRs ------------------------------
@@ -392,10 +396,10 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         struct { uint32_t U, rmax, xlo, sumw, L, n_staged, cur_attr; } hd;
         constexpr uint32_t HW = (uint32_t)sizeof(PrepHead) / 4u;   // record words before the items
         struct { uint32_t idx, kept; unsigned long long base; } x0{kNone, 0u, 0ull};
-        if (!MID && have_pre) {
+        if (have_pre) {
             auto uni = [&](uint32_t w) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)pre[w]); };   // (SGPRs: the branches on these stay scalar)
             hd.U = uni(0); hd.rmax = uni(1); hd.xlo = uni(2); hd.sumw = uni(3); hd.L = uni(6); hd.n_staged = uni(7); hd.cur_attr = uni(16);
-            if (lane < 8u && lane < hd.L) { const uint32_t* it = pre + HW + 6u * lane; x0.idx = it[0]; x0.kept = it[3]; x0.base = ((unsigned long long)it[5] << 32) | it[4]; }
+            if (lane < (MID ? 16u : 8u) && lane < hd.L) { const uint32_t* it = pre + HW + 6u * lane; x0.idx = it[0]; x0.kept = it[3]; x0.base = ((unsigned long long)it[5] << 32) | it[4]; }
         } else {
             const PrepHead h0 = *(const PrepHead*)rec;   // (uniform address)
             hd.U = h0.U; hd.rmax = h0.rmax; hd.xlo = h0.xlo; hd.sumw = h0.sumw; hd.L = h0.L; hd.n_staged = h0.n_staged; hd.cur_attr = h0.cur_attr;
@@ -779,8 +783,9 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         // the next query's record: requested by wave 1 HERE -- behind its own row requests, with no other load of the wave due for thousands of cycles (loads return
         // in order: anywhere else the record's HBM round trip would sit in front of data the wave needs at once); it lands in LDS by itself, the wave
         // waits for it at the end of phase 4a, before the barrier that everybody passes on the way to the next query
-        const uint32_t qn = q + gridDim.x;
-        if (!MID && wave == 1u && qn < p.nq) {   // (a record is at most 72 + 8 * 24 = 264 bytes: two rounds of a dword per lane)
+        const uint32_t qn = MID ? q_after : q + gridDim.x;
+        const bool park = MID ? q_after != 0xFFFFFFFFu : qn < p.nq;   // (block-uniform)
+        if (wave == 1u && park) {   // (a record is at most 72 + 8 * 24 = 264 bytes -- MID: 72 + 10 * 24 = 312 --: two rounds of a dword per lane)
             const char* const rn = p.prep + (size_t)qn * p.prep_stride + lane * 4u;
             if (lane * 4u < p.prep_stride) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)rn, (__attribute__((address_space(3))) void*)pre, 4, 0, 0);
             if (256u + lane * 4u < min(p.prep_stride, 320u)) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rn + 256), (__attribute__((address_space(3))) void*)(pre + 64), 4, 0, 0);
@@ -928,7 +933,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
                 floor_b = (uint32_t)fmin(4.0e9, fmax(1.0, floor(x_lo * ((const double*)(smem + SINV))[8] * (1.0 - 1e-9)) - 1.0));
             }
         }
-        if (!MID && wave == 1u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the record has landed
+        if (wave == 1u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the record has landed
         FAST_TICK(10);
         FAST_PRIO(FP_WB);
         {
@@ -951,7 +956,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             if (__ballot(mx >= floor_b) != 0ull && lane == 0u) misc[FS_LIVE] = 1u;
         }
         __syncthreads();
-        have_pre = !MID && qn < p.nq;   // (the barrier above orders wave 1's writes before anybody's next look)
+        have_pre = park;   // (the barrier above orders wave 1's writes before anybody's next look)
         const bool live = misc[FS_LIVE] != 0u;   // block-uniform
         if (live) {
         // ---- walk B: an element reaches the exact table only if its sketch word can still reach the floor -----------
