@@ -56,3 +56,19 @@ def test_single_gpu_line_carries_both_modes():
     rf, cb = line["roofline"], line["cpu_baseline"]
     assert rf["kernel"].startswith("vmis_") and rf["traffic_measured_in_this_run"] is False
     assert cb["kind"] == "port" and cb["cores"] >= 1 and set(cb["single_thread_per_call_us"]) >= {"p25", "p50", "p75", "p90", "p95", "p99_5"}
+
+
+def test_default_bench_line_on_the_tiny_config_carries_every_block():
+    """`python bench.py` as the driver runs it (N = 1, sweeps and CPU baseline on), on the generator's tiny config so that it takes seconds: ONE line, the contract's keys, `roofline`,
+    `cpu_baseline`, the batch sweep and -- since round 4 -- `latency.long_sessions` (sessions of up to 8 / 10 items through the fast kernel's MID instantiation, oracle-gated inside the run)."""
+    line = _run(["--config", "tiny", "--batch", "16384", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1"])
+    for key in CONTRACT + ("value_replicas", "value_item_sharded", "value_mode"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["value"] > 0
+    assert line["roofline"]["bound"] == "hbm" and line["roofline"]["achieved"] > 0 and line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["kind"] == "port"
+    ls = line["latency"]["long_sessions"]
+    assert [e["max_items_in_session"] for e in ls] == [8, 10]
+    for e in ls:
+        assert e["parity_checked"] == 256 and e["mid_tier"]["queries_per_s"] > 0 and e["mid_tier"]["listed_for_mid_instantiation"] > 0
+    assert ls[1]["without_mid_tier"]["listed_for_mid_instantiation"] == 0 and ls[1]["without_mid_tier"]["reached_general_kernel"] == ls[1]["batch"]
+    assert len(line["latency"]["batch_sweep"]) >= 5 and line["latency"]["single_query_us_p50"] > 0
