@@ -368,6 +368,10 @@ int srn_debug_last_mid_count(const srn_index_t* idx, uint32_t* out_listed) {
     if (!idx || !idx->dev) return fail(SRN_ENODEV, "index has no device attached");
     return guarded([&]() -> int { return device_last_mid_count(idx->dev, out_listed); });
 }
+int srn_debug_last_big_count(const srn_index_t* idx, uint32_t* out_listed) {
+    if (!idx || !idx->dev) return fail(SRN_ENODEV, "index has no device attached");
+    return guarded([&]() -> int { return device_last_mid_count(idx->dev, nullptr, out_listed); });
+}
 
 void srn_debug_reload_knobs(void) { reload_knobs(); }
 

@@ -37,7 +37,6 @@ enum { FS_NB = 0, FS_FAIL, FS_SURV, FS_CCNT, FS_HITS, FS_LIVE, FS_SCAN_A = 8, FS
 // memory ONCE per workgroup -- hand-made register spills into the 5 KB of LDS that three workgroups per CU leave over
 static constexpr uint32_t F_SIDF = F_LDS_BYTES, F_SATTR = F_SIDF + 512 * 8, F_TOTAL = F_SATTR + 512, F_SINV = F_W10 + 384;   // (F_SINV: 1 / max idf of the 8 chunks, then of all items -- 128 bytes behind the parked record in the weight table's unused tail; 53 760 bytes in all: one more allocation granule and only two workgroups fit a CU)
 static_assert(F_TOTAL * F_WG_PER_CU <= 160 * 1024, "LDS budget with the sample constants");
-static constexpr uint32_t F_MERGE_WORDS = F_WORK_WORDS;
 
 // per-phase cycle accounting (debug): summed per workgroup in LDS, flushed once at the end -- one global atomic per phase and
 // query (as the general kernel does) serialises on 16 addresses and distorts what it measures
@@ -317,15 +316,20 @@ __device__ __forceinline__ uint32_t fast_cut(const uint32_t* F, uint32_t* nbl, u
 // its zero-weight neighbours add nothing, and a query whose positive-score items do not fill the top n -- the only case in which a zero-score item can be returned --
 // goes to the general kernel.
 enum { FM_FUSED = 0, FM_FRONT = 1, FM_BACK = 2 };
-template <int WG_PER_CU, bool FRAG, bool WIDE, int MODE = FM_FUSED, bool MID = false>
+// BIG (MID only): the same kernel with 80 KB of LDS -- the merge buffers' room grows from 12 032 to 19 072 words (the per-thread sample constants move to the end), two workgroups per CU --
+// for the queries MID passes on only because 2 n + 264 words do not fit the 53 KB layout (3-4 % of what it is handed on config 3); they come from a third device-side list.
+template <int WG_PER_CU, bool FRAG, bool WIDE, int MODE = FM_FUSED, bool MID = false, bool BIG = false>
 #ifndef SRN_FAST_WAVES
 #define SRN_FAST_WAVES (WG_PER_CU * 2)
 #endif
-__global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIndex ix_arg, LaunchParams p_arg, FastParams f_arg) {
+__global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIndex ix_arg, LaunchParams p_arg, FastParams f_arg) {
 #if SRN_FAST_SMALL
     // static allocation: the compiler then knows every LDS address and folds the region offsets into the instructions' offset fields
     // (with a dynamic allocation each computed address pays a v_add of the -- zero -- base: two per row item in the walks)
-    __shared__ __attribute__((aligned(16))) char smem[F_TOTAL];
+    static_assert(!BIG || MID, "BIG is a form of MID");
+    constexpr uint32_t SIDF = BIG ? F_BIG_TOTAL - (F_TOTAL - F_SIDF) : F_SIDF, SATTR = SIDF + 512 * 8;   // per-thread sample constants: behind the merge buffers' room
+    constexpr uint32_t MW = (SIDF - F_WORK) / 4;   // words the merge buffers may use (= F_MERGE_WORDS in the 53 KB layout)
+    __shared__ __attribute__((aligned(16))) char smem[BIG ? F_BIG_TOTAL : F_TOTAL];
 #else
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #endif
@@ -356,6 +360,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
     uint2* hits = (uint2*)(smem + F_HITS);
     uint32_t* surv = (uint32_t*)(smem + F_SURV);
     constexpr uint32_t SURV_CAP = F_SURV_WORDS - 256u;
+    uint32_t* const cls_area = BIG ? (uint32_t*)(smem + SIDF) - 256 : surv + SURV_CAP;   // MID's class histogram of the k-cut: the last 256 words of the merge buffers' room
     uint32_t* thist = surv + SURV_CAP;                    // 256 bins: the sample's candidates by the top 16 bits of x, relative to the first threshold
     // numerator / 10 * linear_score(first match) * numerator of a slot's list set.  Lean: one table entry per set (16 sets).  MID (<= 10 lists: 1 024 sets): the set is split into
     // lists 0..4 and 5..9 -- wlut[0..31] / [32..63] = the halves' numerators (they add), wlut[64..95] / [96..127] = the halves' first-match positions (the low half wins)
@@ -380,15 +385,15 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
     uint32_t* const pre = (uint32_t*)(smem + F_W10 + 64);
     bool have_pre = false;   // block-uniform
     { const ItemMeta m0 = f.meta_sample[tid];
-      ((double*)(smem + F_SIDF))[tid] = m0.idf > 0.0 ? m0.idf : 1.0; ((uint8_t*)(smem + F_SATTR))[tid] = (uint8_t)m0.attr;   // (own slot only: no barrier)
+      ((double*)(smem + SIDF))[tid] = m0.idf > 0.0 ? m0.idf : 1.0; ((uint8_t*)(smem + SATTR))[tid] = (uint8_t)m0.attr;   // (own slot only: no barrier)
       if (tid < 16u) ((double*)(smem + SINV))[tid] = tid < 8u ? f.inv_idf_hot[tid] : f.inv_idf_hi; }   // (read in phase 4a: barriers in between)
-    const uint32_t q_end = MID ? *f.mid_cnt : p.nq;   // (MID: the list is final -- the lean instantiation's launch is over)
+    const uint32_t q_end = BIG ? *f.bigq_cnt : MID ? *f.mid_cnt : p.nq;   // (MID: the list is final -- the lean instantiation's launch is over)
     for (uint32_t qi = (MODE == FM_FRONT ? f.q_base : 0u) + blockIdx.x; qi < q_end; qi += gridDim.x) {
-        const uint32_t q = MID ? f.mid_list[qi] : qi;
+        const uint32_t q = BIG ? f.bigq_list[qi] : MID ? f.mid_list[qi] : qi;
 #ifndef SRN_MID_PREFETCH
 #define SRN_MID_PREFETCH 0   // (experiment, measured flat: 7.73 / 8.61 ms per 2^18 queries at max_items 8 / 10 with or without it, and 16 bytes of scratch with)
 #endif
-        const uint32_t q_after = !(MID && SRN_MID_PREFETCH) ? 0xFFFFFFFFu : qi + gridDim.x < q_end ? f.mid_list[qi + gridDim.x] : 0xFFFFFFFFu;   // (MID: the query this workgroup serves next -- its record is parked during this one, like the lean form's)
+        const uint32_t q_after = !(MID && SRN_MID_PREFETCH) ? 0xFFFFFFFFu : qi + gridDim.x < q_end ? (BIG ? f.bigq_list : f.mid_list)[qi + gridDim.x] : 0xFFFFFFFFu;   // (MID: the query this workgroup serves next -- its record is parked during this one, like the lean form's)
         long long t_prev = ticking ? clock64() : 0;
         FAST_PRIO(FP_REC);
         // ---- phase 0: the query's prep record -> run descriptors in SGPRs ------------------------------
@@ -417,14 +422,16 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         const bool rel = MID || (WIDE && nr > 3u);   // (block-uniform)
         const uint32_t NB = MID ? max(nr, 4u) : WIDE && !rel ? 3u : 4u, NBM = (1u << NB) - 1u, base = rel ? hd.xlo : 0u;
         // (MID: the last 256 words of the merge buffers' room hold the class histogram of the k-cut)
-        const bool fits = MID ? L >= 1u && L <= F_MID_LMAX && L <= p.max_len && hd.sumw <= F_MID_CLASSES && nr <= F_MID_LISTS && 2u * n + 8u + 256u <= F_MERGE_WORDS && hd.rmax - hd.xlo < (1u << (32u - NB))
-                              : L >= 1u && L <= 8u && L <= p.max_len && hd.sumw <= 15u && nr <= 4u && 2u * n + 8u <= F_MERGE_WORDS && (!rel || hd.rmax - hd.xlo < (1u << 28));
+        const bool fits = MID ? L >= 1u && L <= F_MID_LMAX && L <= p.max_len && hd.sumw <= F_MID_CLASSES && nr <= F_MID_LISTS && 2u * n + 8u + 256u <= MW && hd.rmax - hd.xlo < (1u << (32u - NB))
+                              : L >= 1u && L <= 8u && L <= p.max_len && hd.sumw <= 15u && nr <= 4u && 2u * n + 8u <= MW && (!rel || hd.rmax - hd.xlo < (1u << 28));
         uint32_t* const xq = MODE == FM_FUSED ? nullptr : f.xchg + (size_t)q * f.xchg_stride;   // this query's place in the exchange buffer: K | K slots
         if (!fits) {   // block-uniform: the general kernel takes it
             if constexpr (MODE == FM_FRONT) { if (tid == 0) xq[0] = 0xFFFFFFFFu; }   // (every rank's back end reads the marker and hands the query to its general kernel)
             else if (tid == 0) {
                 // (the MID instantiation looks at the query next, if this launch sequence has one; it decides for itself)
                 if (!MID && MODE == FM_FUSED && f.mid_list != nullptr && L >= 1u && L <= F_MID_LMAX && L <= p.max_len) f.mid_list[atomicAdd(f.mid_cnt, 1u)] = q;
+                else if (MID && !BIG && f.bigq_list != nullptr && L >= 1u && L <= F_MID_LMAX && L <= p.max_len && hd.sumw <= F_MID_CLASSES && nr <= F_MID_LISTS && hd.rmax - hd.xlo < (1u << (32u - NB)) &&
+                         2u * n + 8u + 256u <= (F_BIG_TOTAL - (F_TOTAL - F_SIDF) - F_WORK) / 4u) f.bigq_list[atomicAdd(f.bigq_cnt, 1u)] = q;   // (only the merge buffers' room is missing: MID's BIG form has it)
                 else f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q;
             }
             continue;
@@ -622,7 +629,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             } else
                 for (uint32_t o = o0; o < o1; ++o) { const uint32_t r = F[o] >> NB; firsts += r != prev; prev = r; }
             for (uint32_t i = tid; i < min(n, p.m); i += BLOCK) D[i] = 0;
-            if (MID && tid < 64u) thist[tid] = 0u;   // (the k-cut's class histogram: the tail of the merge buffers' room, see `fits`)
+            if (MID && tid < 64u) cls_area[tid] = 0u;   // (the k-cut's class histogram: the tail of the merge buffers' room, see `fits`)
             uint32_t idx = block_excl_scan<BLOCK>(firsts, misc + FS_SCAN_A, Call);   // (barrier inside)
             prev = prev0;
             if (g <= (uint32_t)MC_G) {
@@ -648,7 +655,7 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
         // ---- k-cut: D is ordered by recency, so inside one numerator class the order is already the wanted one ----
         if (Cm <= p.k) K = Cm;   // (block-uniform; the m-cut wrote the neighbour list)
         else {
-            uint32_t* cls = MID ? thist : misc + FS_CLS;
+            uint32_t* cls = MID ? cls_area : misc + FS_CLS;
             const uint32_t g = (Cm + BLOCK - 1) / BLOCK, o0 = min(tid * g, Cm), o1 = min(o0 + g, Cm);   // g <= 5
             uint32_t dv[5], nmv[5];
 #pragma unroll
@@ -852,8 +859,8 @@ __global__ __launch_bounds__(512, SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIn
             // idf_eff and the attribute byte come from the thread's LDS slot; only the id rank (wanted after the barrier below, for the few candidates) is a
             // global load -- nothing on the way to the wave reductions waits for memory
             tie = f.meta_sample[tid].id_rank;   // (coalesced, unconditional)
-            if (business) valid = valid && business_ok(cur_attr, (uint32_t)((const uint8_t*)(smem + F_SATTR))[tid]);   // an item the rules exclude is no candidate and sets no threshold
-            if (valid) x = ((const double*)(smem + F_SIDF))[tid] * (double)v;
+            if (business) valid = valid && business_ok(cur_attr, (uint32_t)((const uint8_t*)(smem + SATTR))[tid]);   // an item the rules exclude is no candidate and sets no threshold
+            if (valid) x = ((const double*)(smem + SIDF))[tid] * (double)v;
             const uint32_t k32 = (uint32_t)((unsigned long long)__double_as_longlong(x) >> 32);
             {
                 uint32_t vv = k32, third = 0;
@@ -1236,7 +1243,7 @@ __global__ __launch_bounds__(64) void vmis_finish_big_kernel(DeviceIndex ix, con
     constexpr uint32_t CAP = F_CAND_CAP + F_TABLE_BUCKETS * 4u;
     // the launch sequence's two counters (queries for the global-table pass, queries handed to the general kernel: both final before this kernel starts) straight into
     // the workspace's pinned words -- two 4-byte device-to-host copies cost 9 us of every call
-    if (host_words && blockIdx.x == 0u && threadIdx.x == 0u) { if (cnt_retry) host_words[0] = *cnt_retry; if (cnt_slow) { host_words[1] = cnt_slow[0]; host_words[2] = cnt_slow[1]; } }   // (cnt_slow[1]: the MID instantiation's list)   // (a null source: that word is someone else's)
+    if (host_words && blockIdx.x == 0u && threadIdx.x == 0u) { if (cnt_retry) host_words[0] = *cnt_retry; if (cnt_slow) { host_words[1] = cnt_slow[0]; host_words[2] = cnt_slow[1]; host_words[3] = cnt_slow[4]; } }   // (cnt_slow[1]: the MID instantiation's list, [4]: its BIG form's)   // (a null source: that word is someone else's)
     __shared__ unsigned long long key[CAP];
     __shared__ uint32_t tieb[CAP];
     __shared__ uint32_t hist[256];
@@ -1314,11 +1321,13 @@ hipError_t launch_finish(hipStream_t st, const DeviceIndex& di, const FastParams
     return hipGetLastError();
 }
 
-hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f, bool debug, int mode, bool mid) {
+hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f, bool debug, int mode, bool mid, bool big) {
     constexpr int W = (int)F_WG_PER_CU;
     const bool wide = f.nb == 3u, frag = di.row_frag != 0u;
     if (mid && (mode != FM_FUSED || frag || f.mid_list == nullptr)) return hipErrorInvalidValue;
+    if (big && (!mid || f.bigq_list == nullptr)) return hipErrorInvalidValue;
     void (*kern)(DeviceIndex, LaunchParams, FastParams) =
+        big ? vmis_fast_kernel<W, false, false, FM_FUSED, true, true> :
         mid ? vmis_fast_kernel<W, false, false, FM_FUSED, true> :
         mode == FM_FRONT ? (wide ? vmis_fast_kernel<W, false, true, FM_FRONT> : vmis_fast_kernel<W, false, false, FM_FRONT>)
         : mode == FM_BACK ? (wide ? (frag ? vmis_fast_kernel<W, true, true, FM_BACK> : vmis_fast_kernel<W, false, true, FM_BACK>)

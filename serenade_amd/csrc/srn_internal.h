@@ -155,7 +155,7 @@ int device_phase_cycles(DeviceState* d, int enable, unsigned long long* out16);
 int device_kernel_timing(DeviceState* d, int enable);
 int device_reserve(DeviceState* d, const FlatIndex& ix, const LaunchParams& p, void* stream);
 int device_last_path_counts(DeviceState* d, uint32_t* nq, uint32_t* general, uint32_t* global_pass);   // debug profiling aid
-int device_last_mid_count(DeviceState* d, uint32_t* listed);   // queries the last call's lean fast kernel listed for its MID instantiation
+int device_last_mid_count(DeviceState* d, uint32_t* listed, uint32_t* big_listed = nullptr);   // queries the last call's lean fast kernel listed for its MID instantiation
 int device_kernel_times(DeviceState* d, uint32_t max_n, double* ms_main, double* ms_retry, uint32_t* out_n, double* ms_prep = nullptr, double* ms_fast = nullptr);
 
 }  // namespace srn

@@ -73,6 +73,7 @@ static constexpr uint32_t F_WORK = F_NBL, F_WORK_WORDS = (F_LDS_BYTES - F_WORK) 
 static constexpr uint32_t F_M_MAX = 2560;
 static constexpr uint32_t F_FIN_BYTES = 1024, F_FIN_ENTRIES = F_FIN_BYTES / 16 - 1;   // a query's record: header + 63 entries
 static_assert(F_CAND + F_CAND_CAP * 12 <= F_HOT, "candidate buffer overlaps the accumulators");
+static constexpr uint32_t F_BIG_TOTAL = 80 * 1024;   // LDS of the MID instantiation's BIG form (two workgroups per CU): the same map with the merge buffers' room grown to 19 072 words (n <= 9 404 staged entries)
 static constexpr uint32_t F_MID_LISTS = 10, F_MID_LMAX = 10, F_MID_CLASSES = 63;   // the MID instantiation of vmis_fast_kernel: lists per query, session length, similarity numerators
 static_assert(F_LDS_BYTES * F_WG_PER_CU <= 160 * 1024, "LDS budget");
 static_assert(F_DUMP + F_DUMP_WORDS * 4 - F_HOT <= 65536, "16-bit row offsets");
@@ -82,6 +83,7 @@ struct FastParams {
     double inv_idf_hot[8];      // 1 / max idf_eff over the dense idx [512 c, 512 c + 512): popular items have small idf, so their integer floor is much tighter
     double inv_idf_hi;          // 1 / max idf_eff over all items
     uint32_t* slow_list; uint32_t* slow_cnt;   // queries the fast kernel hands to vmis_predict_kernel
+    uint32_t* bigq_list; uint32_t* bigq_cnt;   // ... and what MID passes on only because its merged lists outgrow the 53 KB layout: MID's BIG form (80 KB of LDS, two workgroups per CU) takes them before the general kernel
     uint32_t* mid_list; uint32_t* mid_cnt;     // queries of 5..10 lists / <= 10 items / numerators up to 63: the fast kernel's MID instantiation takes them before the general kernel (null: no such tier in this launch)
     char* fin;                  // per-query records for vmis_finish_kernel: F_FIN_BYTES each, at q * F_FIN_BYTES
     char* big_arena; uint32_t* big_list; unsigned long long* big_ticket; uint32_t big_cap_entries;   // queries with > 63 entries: overflow entries, list for vmis_finish_big_kernel,
@@ -101,7 +103,7 @@ hipError_t launch_predict(bool masks, bool slot64, bool global_tables, int stage
                           uint32_t* retry_cnt, char* gscratch, unsigned long long gscratch_stride, char* nb_spill, const ShardIO& sh, int wg_per_cu = 2);
 hipError_t launch_prep(hipStream_t st, const DeviceIndex& di, const uint64_t* items_flat, const uint32_t* q_off, uint32_t nq, uint32_t m,
                        uint32_t max_len, char* out, uint32_t stride, uint32_t* zero_a = nullptr, uint32_t* zero_b = nullptr,
-                       const IdSlot* loc_table = nullptr, uint32_t loc_mask = 0);   // zero_a[0..3], zero_b[0]: counters cleared by the prep kernel; loc_table: the item shard's id table (the record's idx), di = the whole index's dictionary and lists
+                       const IdSlot* loc_table = nullptr, uint32_t loc_mask = 0);   // zero_a[0..7], zero_b[0]: counters cleared by the prep kernel; loc_table: the item shard's id table (the record's idx), di = the whole index's dictionary and lists
 hipError_t launch_finish_big(hipStream_t st, const DeviceIndex& di, const FastParams& f, uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint32_t how_many, uint32_t grid, const uint32_t* cnt_retry = nullptr, const uint32_t* cnt_slow = nullptr, uint32_t* host_words = nullptr);
 hipError_t launch_finish(hipStream_t st, const DeviceIndex& di, const FastParams& f, uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint32_t nq, uint32_t how_many);   // scores, ranking, public ids of the rows the fast kernel served
 hipError_t launch_shard_lists_head(hipStream_t st, const DeviceIndex& di, const uint64_t* items_flat, const uint32_t* q_off, uint32_t nq, uint32_t m, uint32_t max_len,
@@ -122,7 +124,7 @@ hipError_t launch_shard_mark(hipStream_t st, const uint32_t* flag, uint32_t nq, 
 hipError_t launch_shard_fill_i32(hipStream_t st, int* dst, int v, size_t n);
 hipError_t launch_shard_merge_topn(hipStream_t st, const char* part, size_t block_bytes, uint32_t n_shards, uint32_t nq, uint32_t how_many, uint64_t* out_ids, double* out_scores,
                                    uint32_t* out_counts);
-hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f, bool debug = false, int mode = 0, bool mid = false);   // debug: say the occupancy once (the SRN_DEBUG knob, read by the runtime); mode: 0 fused, 1 front end only (neighbour lists -> f.xchg), 2 back end only (neighbour lists <- f.xchg); mid: the MID instantiation over f.mid_list (mode 0 only)
+hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f, bool debug = false, int mode = 0, bool mid = false, bool big = false);   // debug: say the occupancy once (the SRN_DEBUG knob, read by the runtime); mode: 0 fused, 1 front end only (neighbour lists -> f.xchg), 2 back end only (neighbour lists <- f.xchg); mid: the MID instantiation over f.mid_list (mode 0 only)
 hipError_t launch_rows_to_packed(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base,
                                  uint32_t* packed, uint32_t* ext16, bool frag = false);   // grid = ceil((n_rows + 1) / 1024) blocks of 1024; block_base in 16-byte blocks
 hipError_t launch_rows_to_frags(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base,

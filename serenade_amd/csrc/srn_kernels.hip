@@ -368,8 +368,8 @@ __global__ __launch_bounds__(256) void vmis_prep_kernel(DeviceIndex ix, const ui
     // the item shard whose rows the record's consumer walks -- the lists are looked up in the first, the dense idx written to the record (what the kernels compare
     // row items with: the current item) in the second.
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < 4 && zero_a) zero_a[t] = 0u;
-    if (t == 4 && zero_b) *zero_b = 0u;
+    if (t < 8 && zero_a) zero_a[t] = 0u;
+    if (t == 8 && zero_b) *zero_b = 0u;
     const uint32_t q = t / PREP_LANES, sub = t % PREP_LANES;
     if (q >= nq) return;   // (nq is a multiple of nothing in particular: whole 8-lane groups leave together, the shuffles below stay within a group)
     const uint32_t qb = q_off[q], L = q_off[q + 1] - qb;

@@ -22,7 +22,7 @@ namespace srn {
 // Test / experiment knobs (environment variables SRN_*): read ONCE, when the library is first used, never on the launch path;
 // srn_debug_reload_knobs() re-reads them (the tests switch kernel paths between calls).  All defaults = production behaviour.
 struct Knobs {
-    bool no_masks = false, no_merge = false, dense = false, no_fast = false, no_mid = false, debug = false;   // no_mid (SRN_NO_MID): the launch sequence without the fast kernel's MID instantiation (what it would take goes to the general kernel, as before round 4)
+    bool no_masks = false, no_merge = false, dense = false, no_fast = false, no_mid = false, no_big = false, debug = false;   // no_mid (SRN_NO_MID): the launch sequence without the fast kernel's MID instantiation (what it would take goes to the general kernel, as before round 4)
     int hot_slots = -1, sketch_slots = -1, lds_budget_kb = 0, grid_mult = 16, fast_runs = 0;
     bool grid_mult_set = false;
     int host_chunks = 0;      // SRN_HOST_CHUNKS: number of chunks a host-pointer batch is cut into (0 = by size, srn_hostpipe.hip)

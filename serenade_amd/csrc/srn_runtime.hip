@@ -21,7 +21,7 @@ static Knobs g_knobs; static std::once_flag g_knobs_once; static std::mutex g_kn
 static void knobs_read() {
     Knobs k;
     k.no_masks = getenv("SRN_NO_MASKS") != nullptr; k.no_merge = getenv("SRN_NO_MERGE") != nullptr; k.dense = getenv("SRN_DENSE") != nullptr;
-    k.no_fast = getenv("SRN_NO_FAST") != nullptr; k.no_mid = getenv("SRN_NO_MID") != nullptr; k.debug = getenv("SRN_DEBUG") != nullptr;
+    k.no_fast = getenv("SRN_NO_FAST") != nullptr; k.no_mid = getenv("SRN_NO_MID") != nullptr; k.no_big = getenv("SRN_NO_BIG") != nullptr; k.debug = getenv("SRN_DEBUG") != nullptr;
     if (const char* e = getenv("SRN_ROW_SLOTS")) k.row_slots16 = atoi(e) == 16 ? 1 : atoi(e) == 64 ? 0 : -1;
     if (const char* e = getenv("SRN_HOT_SLOTS")) k.hot_slots = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_SKETCH_SLOTS")) k.sketch_slots = std::max(0, atoi(e));
@@ -211,7 +211,7 @@ Workspace* ws_acquire(DeviceState* d, bool bind_to_stream, void* user_stream) {
     Workspace* w = new Workspace();
     if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { delete w; return nullptr; }
     for (auto& t : w->ev) for (auto& e : t) if (hipEventCreate(&e) != hipSuccess) { ws_free(w); return nullptr; }
-    if (hipMalloc((void**)&w->retry_cnt, 16) != hipSuccess || hipMalloc((void**)&w->retry_cnt2, 16) != hipSuccess || hipMalloc((void**)&w->slow_cnt, 16) != hipSuccess || hipHostMalloc((void**)&w->h_retry, 16) != hipSuccess) { ws_free(w); return nullptr; }
+    if (hipMalloc((void**)&w->retry_cnt, 16) != hipSuccess || hipMalloc((void**)&w->retry_cnt2, 16) != hipSuccess || hipMalloc((void**)&w->slow_cnt, 32) != hipSuccess || hipHostMalloc((void**)&w->h_retry, 16) != hipSuccess) { ws_free(w); return nullptr; }
     memset(w->h_retry, 0, 16);
     if (hipHostGetDevicePointer((void**)&w->h_retry_dev, w->h_retry, 0) != hipSuccess) { ws_free(w); return nullptr; }
     d->all_ws.push_back(w);
@@ -379,7 +379,7 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
     const uint64_t big_entries = (uint64_t)cap_q * 16 + 4096;
     if (tiny_fast) {   // (sized once, for the largest round)
         if (w->slow_cap < cap_q) { if (w->slow_list) HIP_TRY(hipFree(w->slow_list)); w->slow_list = nullptr; w->slow_cap = 0;
-            HIP_TRY(hipMalloc((void**)&w->slow_list, (cap_q * 4 + 64) * 2)); w->slow_cap = cap_q; }
+            HIP_TRY(hipMalloc((void**)&w->slow_list, (cap_q * 4 + 64) * 3)); w->slow_cap = cap_q; }
         { int rc = ensure(&w->fin, &w->fin_bytes, cap_q * F_FIN_BYTES + 1024); if (rc) return rc; }
         { int rc = ensure(&w->big, &w->big_bytes, big_entries * 16 + cap_q * 4 + 64); if (rc) return rc; }
     }
@@ -390,6 +390,7 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
         fp.big_arena = w->big; fp.big_list = (uint32_t*)(w->big + big_entries * 16); fp.big_ticket = (unsigned long long*)(w->slow_cnt + 2); fp.big_cap_entries = (uint32_t)big_entries;
         fp.xchg = nullptr; fp.xchg_stride = 0; fp.q_base = 0;
         fp.mid_list = plan.mid_tier ? w->slow_list + (w->slow_cap + 16) : nullptr; fp.mid_cnt = plan.mid_tier ? w->slow_cnt + 1 : nullptr;
+        fp.bigq_list = nullptr; fp.bigq_cnt = nullptr;   // (no BIG tier on the latency path: one more launch for 3-4 % of the long sessions)
         HIP_TRY(launch_fast(dim3(p.nq), st, d->di, p, fp, kn.debug, 0));
         if (plan.mid_tier) HIP_TRY(launch_fast(dim3(p.nq), st, d->di, p, fp, kn.debug, 0, true));
         HIP_TRY(launch_predict(geo.masks, geo.slot64, false, 0, dim3(p.nq), geo.lds, st, d->di, p, geo.c, w->slow_list, w->slow_cnt, (uint32_t*)(dp + o_rl), (uint32_t*)(dp + o_rc), nullptr, 0,
@@ -533,7 +534,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     const uint32_t nb_fast = plan.nb_fast; const bool mid_tier = plan.mid_tier, fast = plan.fast;
     if (fast) {   // (all allocations of a call happen before its first launch)
         if (w->slow_cap < p.nq) { if (w->slow_list) HIP_TRY(hipFree(w->slow_list)); w->slow_list = nullptr; w->slow_cap = 0;
-            HIP_TRY(hipMalloc((void**)&w->slow_list, ((size_t)p.nq * 4 + 64) * 2)); w->slow_cap = p.nq; }   // (second half: the MID instantiation's list)
+            HIP_TRY(hipMalloc((void**)&w->slow_list, ((size_t)p.nq * 4 + 64) * 3)); w->slow_cap = p.nq; }   // (second and third part: the MID instantiation's list, its BIG form's)
         { int rc = ensure(&w->fin, &w->fin_bytes, (size_t)p.nq * F_FIN_BYTES + 1024); if (rc) return rc; }   // one record per query for vmis_finish_kernel
         const uint64_t big_entries = std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)p.nq * 16 + 4096);
         { int rc = ensure(&w->big, &w->big_bytes, big_entries * 16 + (size_t)p.nq * 4 + 64); if (rc) return rc; }
@@ -546,7 +547,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         if (ext->prep_stride != prep_stride) return fail(SRN_EINVAL, "prep record stride mismatch");
         if (ext->q_lo >= p.nq) return SRN_OK;
         p.prep = ext->prep; p.prep_stride = prep_stride;
-        FastParams fp = d->fast; fp.nb = nb_fast; fp.max_runs = nb_fast; fp.slow_list = nullptr; fp.slow_cnt = nullptr; fp.fin = nullptr; fp.mid_list = nullptr; fp.mid_cnt = nullptr;
+        FastParams fp = d->fast; fp.nb = nb_fast; fp.max_runs = nb_fast; fp.slow_list = nullptr; fp.slow_cnt = nullptr; fp.fin = nullptr; fp.mid_list = nullptr; fp.mid_cnt = nullptr; fp.bigq_list = nullptr; fp.bigq_cnt = nullptr;
         fp.xchg = ext->xchg; fp.xchg_stride = ext->xchg_stride; fp.q_base = ext->q_lo;
         const uint64_t cnt = p.nq - ext->q_lo, res_wg = (uint64_t)d->n_cu * F_WG_PER_CU;
         const uint32_t grid_front = (uint32_t)std::min<uint64_t>(cnt, std::min<uint64_t>(res_wg * 64, std::max<uint64_t>(res_wg * 16, cnt / 12)));
@@ -591,7 +592,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     // The fast kernel (srn_fast.hip) serves the common query shape; what it cannot take -- decided per query, on the device -- is
     // queued on slow_list and served by the general kernel right behind it.
     if (fast) {
-        if (!prep_clears) HIP_TRY(hipMemsetAsync(w->slow_cnt, 0, 16, st));   // (slow_cnt[0] = handed-over queries, [2..3] = the 64-bit ticket of vmis_finish_big_kernel's list)
+        if (!prep_clears) HIP_TRY(hipMemsetAsync(w->slow_cnt, 0, 32, st));   // (slow_cnt[0] = handed-over queries, [1] = the MID instantiation's list, [2..3] = the 64-bit ticket of vmis_finish_big_kernel's list, [4] = MID-BIG's list)
         // The fast kernel's workgroups walk their queries in a pipeline (the next record is fetched during the current query), so they want ~12 queries each;
         // beyond that, more and smaller workgroups shorten the tail of the launch.  Measured on config 3 (ms per launch at 8 / 16 / 32 / 64 resident sets): 2^20 queries
         // 26.29 / 26.06 / 25.85 / 25.81; 2^18: - / 6.62 / 6.57 / 6.63; 2^16: - / 1.70 / 1.72 / 1.78.
@@ -603,6 +604,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         fp.big_arena = w->big; fp.big_list = (uint32_t*)(w->big + big_entries * 16); fp.big_ticket = (unsigned long long*)(w->slow_cnt + 2); fp.big_cap_entries = (uint32_t)big_entries;
         fp.xchg = nullptr; fp.xchg_stride = 0; fp.q_base = 0;
         fp.mid_list = mid_tier ? w->slow_list + (w->slow_cap + 16) : nullptr; fp.mid_cnt = mid_tier ? w->slow_cnt + 1 : nullptr;
+        fp.bigq_list = mid_tier && !kn.no_big ? w->slow_list + 2 * (w->slow_cap + 16) : nullptr; fp.bigq_cnt = fp.bigq_list ? w->slow_cnt + 4 : nullptr;
         const bool back = ext && ext->mode == 2;   // neighbour lists from the exchange buffer (any rank's front end), this shard's rows
         if (back) { fp.xchg = ext->xchg; fp.xchg_stride = ext->xchg_stride; }
         HIP_TRY(launch_fast(dim3(grid_f), st, di, p, fp, kn.debug, back ? 2 : 0));
@@ -610,6 +612,8 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         // The MID instantiation over what the lean one listed for it (sessions of <= 10 items, <= 8 lists); what it cannot take either joins slow_list.  The list's length
         // is known on the device only: a fixed grid, workgroups beyond the list leave at once.
         if (mid_tier) HIP_TRY(launch_fast(dim3((uint32_t)std::min<uint64_t>(p.nq, resident * 8)), st, di, p, fp, kn.debug, 0, true));
+        // ... and MID's BIG form (80 KB of LDS, two workgroups per CU) over what MID passed on only for want of merge-buffer room
+        if (fp.bigq_list) HIP_TRY(launch_fast(dim3((uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * 2 * 4)), st, di, p, fp, kn.debug, 0, true, true));
         HIP_TRY(launch_predict(geo.masks, slot64, false, 0, dim3(grid), lds, st, di, p, c, w->slow_list, w->slow_cnt, w->retry_list, w->retry_cnt, nullptr, 0, spill, ShardIO{}));
         if (fork_retry) {   // the global-table pass beside the finish kernels (they touch disjoint rows: a finish kernel only completes rows flagged by the fast kernel)
             HIP_TRY(hipEventRecord(w->ev_fork, st)); HIP_TRY(hipStreamWaitEvent(w->side, w->ev_fork, 0));
@@ -808,13 +812,14 @@ int device_last_path_counts(DeviceState* d, uint32_t* nq, uint32_t* general, uin
     if (global_pass) *global_pass = w->last_retry ? w->h_retry[0] : 0;
     return SRN_OK;
 }
-int device_last_mid_count(DeviceState* d, uint32_t* listed) {   // queries the last call's lean fast kernel listed for the MID instantiation (0: no such tier in that call)
+int device_last_mid_count(DeviceState* d, uint32_t* listed, uint32_t* big_listed) {   // queries the last call's lean fast kernel listed for the MID instantiation (0: no such tier in that call)
     uint32_t nq = 0;
     const int rc = device_last_path_counts(d, &nq, nullptr, nullptr);   // (waits for the call's end)
     if (rc != SRN_OK) return rc;
     Workspace* w;
     { std::lock_guard<std::mutex> lk(d->mu); w = d->last_ws; }
     if (listed) *listed = w->last_fast && w->last_mid ? w->h_retry[2] : 0u;
+    if (big_listed) *big_listed = w->last_fast && w->last_mid ? w->h_retry[3] : 0u;
     return SRN_OK;
 }
 

@@ -120,6 +120,12 @@ class VMISIndex:
         capi.check(capi.lib().srn_debug_last_mid_count(self._h, C.byref(a)))
         return a.value
 
+    def last_big_count(self):
+        """... and how many of those the MID instantiation listed for its BIG form (merged lists beyond the 53 KB layout's buffers); measurement aid."""
+        a = C.c_uint32()
+        capi.check(capi.lib().srn_debug_last_big_count(self._h, C.byref(a)))
+        return a.value
+
     def kernel_times(self, max_n=64):
         """Per-call (main kernel ms, retry pass ms) of the most recent predict calls, oldest first (HIP events
         recorded on the launch stream around each launch)."""

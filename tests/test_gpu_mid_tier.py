@@ -203,3 +203,29 @@ def test_latency_path_runs_the_fast_launch_sequence(monkeypatch):
             for x, y in zip(a, b):
                 assert np.array_equal(x, y), "latency path: the fast launch sequence and the general kernel must give the same bytes"
         assert got["3"][1] == got[mode][1]
+
+
+def test_big_form_takes_what_outgrows_the_53kb_layout(monkeypatch):
+    """MID's BIG form (80 KB of LDS, two workgroups per CU): queries whose merged lists need more than the 53 KB layout's 12 032 words of merge buffers (n > 5 884 staged entries) used to go
+    on to the general kernel; with dense lists and 5..10 of them per query they are common here.  Oracle-exact, and the same bytes with SRN_NO_BIG=1."""
+    import serenade_amd as sa
+    from serenade_amd import capi
+    O = _oracle()
+    off, items, ts, ids = small_dataset(31, n_sessions=40000, n_items=150, max_len=12)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, 3000, 12, 1.0)
+    oix = O.OracleIndex(off, items, ts, 3000, 12, 1.0)
+    qs = _long_queries(13, ids, 500, 4, 10)
+    try:
+        monkeypatch.delenv("SRN_NO_BIG", raising=False); capi.reload_knobs()
+        got = _against_oracle(gix, oix, qs, 1500, 2500, 21)
+        _nq, general, _ = gix.last_path_counts()
+        mid, big = gix.last_mid_count(), gix.last_big_count()
+        assert big > 0 and big <= mid, (mid, big)
+        assert general < big, "the BIG form should serve most of what MID lists for it (%d listed for MID, %d of them for BIG, %d reached the general kernel)" % (mid, big, general)
+        monkeypatch.setenv("SRN_NO_BIG", "1"); capi.reload_knobs()
+        ref = sa.predict_batch(gix, qs, 1500, 2500, 21, False)
+        assert gix.last_big_count() == 0 and gix.last_path_counts()[1] >= big
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b), "with and without the BIG form the results must be the same bytes"
+    finally:
+        monkeypatch.undo(); capi.reload_knobs()

@@ -41,12 +41,12 @@ for max_items in lens:
         for _ in range(R):
             sa.predict_batch_device(ix, d_flat.data_ptr(), d_off.data_ptr(), B, max_items, k, m, n, False, o_ids.data_ptr(), o_sc.data_ptr(), o_cnt.data_ptr(), st)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / R
-        nq_, general, glob = ix.last_path_counts(); mid = ix.last_mid_count()
+        nq_, general, glob = ix.last_path_counts(); mid = ix.last_mid_count(); big = ix.last_big_count()
         h = hashlib.sha256(); ids_h = o_ids.cpu().numpy(); sc_h = o_sc.cpu().numpy(); cnt_h = o_cnt.cpu().numpy()
         h.update(ids_h.tobytes()); h.update(sc_h.tobytes()); h.update(cnt_h.tobytes())
         out[tag] = h.hexdigest()[:16]
-        print("max_items %2d (mean %.2f, share of sessions > 4 items %.1f %%)  %-6s  %7.3f ms per %d queries = %6.2f M queries/s;  listed for MID %d, reached the general kernel %d, global pass %d;  results %s"
-              % (max_items, L.mean(), 100.0 * (L > 4).mean(), tag, dt * 1e3, B, B / dt / 1e6, mid, general, glob, out[tag]), flush=True)
+        print("max_items %2d (mean %.2f, share of sessions > 4 items %.1f %%)  %-6s  %7.3f ms per %d queries = %6.2f M queries/s;  listed for MID %d (of them for its BIG form %d), reached the general kernel %d, global pass %d;  results %s"
+              % (max_items, L.mean(), 100.0 * (L > 4).mean(), tag, dt * 1e3, B, B / dt / 1e6, mid, big, general, glob, out[tag]), flush=True)
         if oix is not None and tag == "mid":
             nchk = 512
             ref = oix.predict_batch("canonical", qi[:qo[nchk]], qo[:nchk + 1], k, m, n, False, threads=16)
