@@ -36,8 +36,8 @@ while time.time() < t_end and rounds < max_rounds:
     rng = np.random.default_rng(seed)
     # kernel-path knobs (read once by the library: reloaded per round)
     KNOBS = [{}, {}, {}, {"SRN_NO_FAST": "1"}, {"SRN_NO_MERGE": "1"}, {"SRN_NO_MASKS": "1"}, {"SRN_HOT_SLOTS": "64", "SRN_NO_MASKS": "1"}, {"SRN_SKETCH_SLOTS": "64", "SRN_HOT_SLOTS": "32"},
-             {"SRN_FAST_RUNS": "3"}, {"SRN_NO_MID": "1"}, {}, {"SRN_DENSE": "1"}, {"SRN_TINY_MAX": "1"}, {"SRN_HOST_CHUNKS": "3"}, {"SRN_SKETCH_SLOTS": "0"}, {"SRN_HOT_SLOTS": "0"}]
-    for kk in ("SRN_NO_FAST", "SRN_NO_MID", "SRN_NO_MERGE", "SRN_NO_MASKS", "SRN_HOT_SLOTS", "SRN_SKETCH_SLOTS", "SRN_FAST_RUNS", "SRN_DENSE", "SRN_TINY_MAX", "SRN_HOST_CHUNKS"):
+             {"SRN_FAST_RUNS": "3"}, {"SRN_NO_MID": "1"}, {"SRN_NO_BIG": "1"}, {}, {"SRN_DENSE": "1"}, {"SRN_TINY_MAX": "1"}, {"SRN_HOST_CHUNKS": "3"}, {"SRN_SKETCH_SLOTS": "0"}, {"SRN_HOT_SLOTS": "0"}]
+    for kk in ("SRN_NO_FAST", "SRN_NO_MID", "SRN_NO_BIG", "SRN_NO_MERGE", "SRN_NO_MASKS", "SRN_HOT_SLOTS", "SRN_SKETCH_SLOTS", "SRN_FAST_RUNS", "SRN_DENSE", "SRN_TINY_MAX", "SRN_HOST_CHUNKS"):
         os.environ.pop(kk, None)
     knobs = KNOBS[int(rng.integers(0, len(KNOBS)))]
     os.environ.update(knobs); capi.reload_knobs()
