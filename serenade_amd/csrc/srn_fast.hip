@@ -59,7 +59,10 @@ enum { FP_REC = 10000000, FP_FRONT = 1000000, FP_CUT = 100000, FP_REQ = 10000, F
 #define SRN_FAST_PRIO_X 92
 #endif
 #define FAST_PRIO_X(div) do { if (SRN_FAST_PRIO_LEVELS && ((SRN_FAST_PRIO_X) / (div)) % 10 != 9) __builtin_amdgcn_s_setprio((short)(((SRN_FAST_PRIO_X) / (div)) % 10)); } while (0)
-#define FAST_PRIO(ph) do { if (SRN_FAST_PRIO_LEVELS) __builtin_amdgcn_s_setprio((short)(((SRN_FAST_PRIO_LEVELS) / (ph)) % 10)); } while (0)
+#ifndef SRN_MID_PRIO_LEVELS
+#define SRN_MID_PRIO_LEVELS SRN_FAST_PRIO_LEVELS   // (the MID / BIG instantiations: same levels; variants measured flat, profiles/r04_prio_ab.txt)
+#endif
+#define FAST_PRIO(ph) do { if (SRN_FAST_PRIO_LEVELS) __builtin_amdgcn_s_setprio((short)((((MID) ? (SRN_MID_PRIO_LEVELS) : (SRN_FAST_PRIO_LEVELS)) / (ph)) % 10)); } while (0)
 #ifndef SRN_FAST_STOP
 #define SRN_FAST_STOP (-1)   // experiments only (tools/fast_phase_insts.sh): every query leaves after phase tick N, to count instructions per phase
 #endif
