@@ -20,8 +20,10 @@ synthetic index the metric's target is quoted on (k=1500, m=2500, idf_weighting=
   then overlapped (two communicators in flight) under a watchdog; the line says which run `value_item_sharded` comes from and carries both.
 
 Order of events (no timing counts before parity):
-  1. PARITY GATE  the first `--parity` queries of batch 0 through the product call of every mode that is timed, against the canonical
-                  CPU oracle: item ids and order exact, scores to 1e-12 relative; a mismatch aborts the run with exit code 1
+  1. PARITY GATE  `--parity` queries drawn uniformly over batch 0 (seeded permutation; the launch's first and last 32 always among them) FROM THE ROWS THE FULL-SIZE
+                  LAUNCH WROTE, through the product call of every mode that is timed, against the canonical CPU oracle (the closed form of DESIGN.md section 1: a valid
+                  refinement of the reference, NOT its literal tie behaviour -- on the reference's own example 13-17 % of the queries differ from the literal loops in which
+                  equal-scored items close the top-21): item ids and order exact, scores to 1e-12 relative; a mismatch aborts the run with exit code 1
   2. warm-up, then K timed steps between barrier + synchronize on both sides, max over ranks
   3. (N=1) batch-size sweep {1, 16, 64, 256, 4096, 65536, 2^20}: queries/s and p90 latency, device-resident and host-inclusive
   4. (N=1) CPU baseline: the oracle's literal restatement of the reference loops on the host cores, bounded sample
@@ -107,8 +109,9 @@ def main():
     ap.add_argument("--rehearse", type=int, default=0, help="N processes on device 0 over the callback transport (gloo): the N > 1 code path of this script on a one-GPU box")
     ap.add_argument("--overlap-probe-timeout", type=float, default=30.0, help="seconds (plus three times the non-overlapped run's duration) the overlapped item-sharded run may take at N > 1")
     ap.add_argument("--shard-steps", type=int, default=0, help="timed steps of the item-sharded phase (0: --steps)")
-    ap.add_argument("--measure-traffic", action="store_true", help="N=1: two extra rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this script with 2 steps, so that "
-                    "roofline.traffic is measured in this run instead of read back from profiles/")
+    ap.add_argument("--measure-traffic", dest="measure_traffic", action="store_true", default=True, help="N=1 (default ON where rocprofv3 exists): two extra rocprofv3 --pmc passes "
+                    "(FETCH_SIZE, WRITE_SIZE) of this script with 1 + 2 steps, so that roofline.traffic is measured in this run; the committed summary under profiles/ is only a labelled fallback")
+    ap.add_argument("--no-measure-traffic", dest="measure_traffic", action="store_false")
     ap.add_argument("--no-postings", action="store_true", help="N > 1: the lists pipeline (posting lists sharded too: every rank redoes all candidate work on exchanged list prefixes) instead of the neighbours pipeline")
     ap.add_argument("--selftest-launch", action="store_true", help="CPU check of the launcher and the control plane (gloo): no GPU, no timing")
     ap.add_argument("--builder", default="gpu", choices=["gpu", "host"], help="index construction: rocPRIM sorts on the GPU, or the host builder (same bytes)")
@@ -228,16 +231,35 @@ def main():
             oracle_box["t_build"] = time.time() - t1
         return oracle_box["oix"]
 
-    def gate(g_ids, g_sc, g_cnt, flat0, qo0, n_par, what):
-        ref = oracle_index().predict_batch("canonical", flat0[:qo0[n_par]], qo0[:n_par + 1], k, m, how_many, False, threads=usable_cores())
+    def gate_positions(B, n_par):
+        """Which rows of a B-query launch the oracle checks: n_par positions drawn uniformly over the WHOLE batch (a seeded permutation), the launch's first and last 32
+        queries always among them -- a defect that depends on where a query sits in a large launch (a hand-off list that overflows late, the last workgroups) must not pass
+        because only a prefix was looked at."""
+        n_par = int(min(B, n_par))
+        if n_par >= B:
+            return np.arange(B, dtype=np.int64)
+        edge = np.unique(np.concatenate([np.arange(min(32, B)), np.arange(max(0, B - 32), B)])).astype(np.int64)
+        if len(edge) >= n_par:
+            return edge
+        perm = np.random.default_rng(0x5E4E4ADE).permutation(B).astype(np.int64)
+        rest = perm[~np.isin(perm, edge)][:n_par - len(edge)]
+        return np.sort(np.concatenate([edge, rest]))
+
+    def gate(g_ids, g_sc, g_cnt, flat0, qo0, pos, what):
+        """The rows `pos` of a FULL-SIZE launch (g_* = those rows of what it wrote) against the canonical oracle on the same queries."""
+        qo64 = qo0.astype(np.int64)
+        lens = qo64[pos + 1] - qo64[pos]
+        sub_off = np.zeros(len(pos) + 1, np.uint32); sub_off[1:] = np.cumsum(lens)
+        take = np.repeat(qo64[pos] - sub_off[:-1].astype(np.int64), lens) + np.arange(int(sub_off[-1]), dtype=np.int64)
+        ref = oracle_index().predict_batch("canonical", np.ascontiguousarray(flat0[take]), sub_off, k, m, how_many, False, threads=usable_cores())
         ok = np.array_equal(g_cnt, ref["counts"])
         if ok:
             mask = np.arange(how_many)[None, :] < ref["counts"][:, None].astype(np.int64)
             ok = np.array_equal(g_ids[mask], ref["ids"][mask]) and np.allclose(g_sc[mask], ref["scores"][mask], rtol=SCORE_RTOL, atol=0)
         if not ok:
-            print("bench.py: PARITY GATE FAILED (%s) on the first %d queries of batch 0 -- nothing is timed" % (what, n_par), file=sys.stderr)
+            print("bench.py: PARITY GATE FAILED (%s) on %d queries drawn uniformly over batch 0 -- nothing is timed" % (what, len(pos)), file=sys.stderr)
             os._exit(1)
-        return n_par
+        return int(len(pos))
 
     def timed(step_fn, steps=None):
         steps = args.steps if steps is None else steps
@@ -269,17 +291,32 @@ def main():
                 group = SH.ShardGroup.over(shard, rank, world, SH.DistComm())   # the collectives as callbacks over gloo: every line of the N > 1 path but RCCL itself
             else:
                 group = SH.ShardGroup.rccl(shard, rank, world)  # RCCL communicators created inside the library; the id travels over the process group
-        postings = None
-        if world > 1 and not args.no_postings:
-            # the NEIGHBOURS pipeline: every rank keeps the posting lists of the whole index (rows-free view) beside its shard of the rows, runs find_neighbors for its slice of
-            # the batch only, the neighbour lists are all-gathered (srn_shard_group_set_postings)
-            postings = SH.postings_view(index, device=local_rank) if index is not None else None
-            if postings is None:
-                raise RuntimeError("the neighbours pipeline needs the unsharded index on every rank (mode both)")
-            group.set_postings(postings)
-        t_group = time.time() - t0g
+        nonlocal index
         Bs = args.shard_batch
         sbatches = draw_batches(Bs, args.pool, 0)                     # every rank sees the SAME batches
+        postings = None
+        bq_mean = None
+        resident = {"shard": int(shard.info["device_bytes"]), "unsharded_index_kept_for_the_replicas_phase": int(index.info["device_bytes"]) if (index is not None and do_rep) else 0, "replicated_postings": 0}
+        if rank == 0 and index is not None:           # (the roofline's per-query byte counters come from the unsharded index: taken before it may be let go below)
+            nstat = min(Bs, 8192)
+            dbg = sa.predict_batch_debug(index, (sbatches[0][2][:sbatches[0][3][nstat]], sbatches[0][3][:nstat + 1]), k, m, how_many, False, neighbours=False)
+            bq_mean = float(algorithmic_bytes(dbg["stats"]).mean())
+        if world > 1 and not args.no_postings:
+            # the NEIGHBOURS pipeline: every rank keeps the posting lists of the whole index beside its shard of the rows, runs find_neighbors for its slice of
+            # the batch only, the neighbour lists are all-gathered (srn_shard_group_set_postings).  Where the unsharded index stays resident anyway (mode both: the
+            # replicas phase serves from it) IT is the postings -- no second copy of the lists; in item-sharded mode alone the rows-free view is cut and the unsharded
+            # index leaves HBM, so that a rank holds what an item-sharded deployment holds: its shard + the replicated lists
+            if index is None:
+                raise RuntimeError("the neighbours pipeline needs the unsharded index on every rank to cut the postings view from")
+            if do_rep:
+                postings = index
+            else:
+                postings = SH.postings_view(index, device=local_rank)
+                resident["replicated_postings"] = int(postings.info["device_bytes"])
+                index.close(); index = None
+                torch.cuda.empty_cache()
+            group.set_postings(postings)
+        t_group = time.time() - t0g
         s_out = (torch.empty((Bs, how_many), dtype=torch.int64, device=dev), torch.empty((Bs, how_many), dtype=torch.float64, device=dev),
                  torch.empty(Bs, dtype=torch.int32, device=dev))
 
@@ -294,15 +331,9 @@ def main():
             sstep(0)
             torch.cuda.synchronize()
             if rank == 0:
-                n_par = int(min(Bs, args.parity))
-                s_parity = gate(s_out[0].cpu().numpy().view(np.uint64)[:n_par], s_out[1].cpu().numpy()[:n_par], s_out[2].cpu().numpy().view(np.uint32)[:n_par],
-                                sbatches[0][2], sbatches[0][3], n_par, "item-sharded")
-        bq_mean = None
-        if rank == 0:
-            nstat = min(Bs, 8192)
-            dbg = sa.predict_batch_debug(index, (sbatches[0][2][:sbatches[0][3][nstat]], sbatches[0][3][:nstat + 1]), k, m, how_many, False, neighbours=False)
-            bq_mean = float(algorithmic_bytes(dbg["stats"]).mean())
-
+                pos = gate_positions(Bs, args.parity)
+                s_parity = gate(s_out[0].cpu().numpy().view(np.uint64)[pos], s_out[1].cpu().numpy()[pos], s_out[2].cpu().numpy().view(np.uint32)[pos],
+                                sbatches[0][2], sbatches[0][3], pos, "item-sharded")
         def one_run(overlap):
             group.set_overlap(overlap)
             sstep(0); sstep(1)                                        # both buffer slots sized (setup, not one of the W warm-up steps)
@@ -336,7 +367,7 @@ def main():
                            "rccl_ranks": (int(dist.get_world_size()) if world > 1 else 1) if not rehearse else 0, "transport": run["transport"],
                            "rehearsal": "%d processes on ONE GPU over gloo callbacks: control flow only, not a scaling measurement" % world if rehearse else None,
                            "exchange_overlapped_with_previous_batch": run["exchange_overlapped_with_previous_batch"], "overlap_probe": probe,
-                           "items_on_rank0": int(shard.info["n_items"]), "index_bytes_hbm_rank0": int(shard.info["device_bytes"]),
+                           "items_on_rank0": int(shard.info["n_items"]), "index_bytes_hbm_rank0": int(shard.info["device_bytes"]), "hbm_resident_bytes_rank0": resident,
                            "setup_s": {"generate": round(t_gen, 2), "index_build_upload": round(t_build, 2), "shard_cut_attach": round(t_shard, 2), "group_create": round(t_group, 2)}},
                 "roofline": {"bound": "hbm", "kernel": "item-sharded step: list exchange + unsharded kernels over the rank's row fragments + top-n merge", "achieved": ach,
                              "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": ach / (HBM_PEAK_GBS * world), "traffic": None,
@@ -346,7 +377,7 @@ def main():
                                                    "list_prefixes_fullest_rank": per_q["bytes_lists_max_rank"], "neighbour_lists_all_gather": per_q["bytes_neighbours"],
                                                    "topn_all_gather": per_q["bytes_results"]},
                 "latency": {"step_ms_p50": run["step_ms_p50"], "step_ms_p90": run["step_ms_p90"]},
-                "parity_checked": s_parity, "queries_served_last_step": run["queries_served_last_step"], "timed_batches": run["timed_batches"]})
+                "parity_checked": s_parity, "parity_checked_positions": "uniform over batch", "queries_served_last_step": run["queries_served_last_step"], "timed_batches": run["timed_batches"]})
             return line
 
         first = one_run(world == 1)
@@ -393,9 +424,12 @@ def main():
             for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
                 d = os.path.join(tmp, ctr)
                 cmd = [exe, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__), "--mode", "replicas",
-                       "--config", args.config, "--batch", str(B), "--steps", "2", "--warmup", "1", "--no-sweep", "--no-cpu-baseline", "--parity", "0", "--builder", args.builder]
+                       "--config", args.config, "--batch", str(B), "--steps", "2", "--warmup", "1", "--no-sweep", "--no-cpu-baseline", "--no-measure-traffic", "--parity", "0", "--builder", args.builder]
                 env = dict(os.environ, TMPDIR="/tmp")
-                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+                try:
+                    r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+                except subprocess.TimeoutExpired:
+                    return None, None
                 if r.returncode != 0:
                     return None, None
                 c = RS.counters(d, "vmis_fast_kernel").get(ctr, [])
@@ -423,11 +457,11 @@ def main():
         # ---- 1. parity gate (rank 0; the other ranks wait at the barrier below) --------------------------------------------
         parity_checked = 0
         if rank == 0 and args.parity > 0:
-            n_par = int(min(B, args.parity))
-            step(0, n_par)
+            pos = gate_positions(B, args.parity)
+            step(0)                              # the FULL-SIZE launch of batch 0, the one the timed region repeats: the checked rows are rows IT wrote
             torch.cuda.synchronize()
-            parity_checked = gate(out_ids.cpu().numpy().view(np.uint64).reshape(B, how_many)[:n_par], out_sc.cpu().numpy().reshape(B, how_many)[:n_par],
-                                  out_cnt.cpu().numpy().view(np.uint32)[:n_par], flat0, qo0, n_par, "whole index")
+            parity_checked = gate(out_ids.cpu().numpy().view(np.uint64).reshape(B, how_many)[pos], out_sc.cpu().numpy().reshape(B, how_many)[pos],
+                                  out_cnt.cpu().numpy().view(np.uint32)[pos], flat0, qo0, pos, "whole index")
         sa.reserve(index, B, last_items, k, m, how_many, False, stream.cuda_stream)   # size the stream's workspace up front (srn_index_reserve): no call of the run allocates
         index.kernel_timing(True)      # per-kernel HIP events on the launch stream for the timed region (the roofline's launch duration); off again for the sweeps below
         elapsed, step_ms = timed(step)
@@ -541,8 +575,9 @@ def main():
                                                 stream.cuda_stream)
                     lstep(); torch.cuda.synchronize()
                     if tag == "mid_tier":
-                        gate(out_ids.cpu().numpy().view(np.uint64).reshape(B, how_many)[:256], out_sc.cpu().numpy().reshape(B, how_many)[:256],
-                             out_cnt.cpu().numpy().view(np.uint32)[:256], lq_items, lq_off, 256, "sessions of up to %d items" % mi)
+                        lpos = gate_positions(BL, 256)
+                        gate(out_ids.cpu().numpy().view(np.uint64).reshape(B, how_many)[lpos], out_sc.cpu().numpy().reshape(B, how_many)[lpos],
+                             out_cnt.cpu().numpy().view(np.uint32)[lpos], lq_items, lq_off, lpos, "sessions of up to %d items" % mi)
                     es = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
                     for a_, b_ in es:
                         a_.record(stream); lstep(); b_.record(stream)
@@ -552,15 +587,21 @@ def main():
                     entry[tag] = {"queries_per_s": BL / (ms * 1e-3), "ms_p50": ms, "listed_for_mid_instantiation": int(index.last_mid_count()), "reached_general_kernel": int(g_last)}
                     os.environ.pop("SRN_NO_MID", None)
                     _capi.reload_knobs()
-                entry["parity_checked"] = 256
+                entry["parity_checked"] = int(len(gate_positions(BL, 256))); entry["parity_checked_positions"] = "uniform over batch"
                 long_sessions.append(entry)
 
         # HBM traffic per launch comes from separate rocprofv3 --pmc passes over this same command (tools/pmc_bench.sh);
         # the committed summary is read back here so that the line carries it (null if no summary matches the workload)
         traffic, traffic_src, traffic_in_run = None, None, False
         if args.measure_traffic and world == 1:
-            traffic, traffic_src = measure_traffic_now(B)
+            t_tr = time.time()
+            try:
+                traffic, traffic_src = measure_traffic_now(B)
+            except Exception as e:   # (a profiler that is absent or misbehaves must not cost the line)
+                print("bench.py: traffic passes failed: %r" % (e,), file=sys.stderr)
+                traffic, traffic_src = None, None
             traffic_in_run = traffic is not None
+            print("bench.py: HBM traffic passes (2 x rocprofv3 --pmc): %.1f s, %s" % (time.time() - t_tr, "ok" if traffic_in_run else "FAILED: falling back to the committed summary"), file=sys.stderr)
         if traffic is None:
             try:
                 import glob
@@ -583,14 +624,13 @@ def main():
                        "posting_entries": int(info["nnz_postings"]), "index_bytes_hbm": int(info["device_bytes"]),
                        "parallelism": "query-sharded replicas x%d (no data-path collective)" % args.gpus,
                        "setup_s": {"generate": round(t_gen, 2), "index_build_upload": round(t_build, 2), "index_builder": args.builder}},
-            "parity_checked": parity_checked, "full_batch_properties_ok": props_ok,
+            "parity_checked": parity_checked, "parity_checked_positions": "uniform over batch (seeded permutation of the full-size launch's rows, its first and last 32 included)", "full_batch_properties_ok": props_ok,
             "roofline": {"bound": "hbm", "kernel": "vmis_fast_kernel" if fast_used else "vmis_predict_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE)",
                          "frac_counter": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "frac_counter_note": "measured HBM traffic of the launch / its duration / 8 TB/s: what the memory system really moves (frac prices the contract's algorithmic bytes)",
                          "traffic_source": traffic_src, "traffic_measured_in_this_run": traffic_in_run,
-                         "traffic_note": None if traffic_in_run else "read back from the committed PMC summary named in traffic_source (tools/r04_profiles.sh reproduces it; "
-                                                                     "--measure-traffic runs the two PMC passes inside this command)",
+                         "traffic_note": None if traffic_in_run else "FALLBACK: read back from the committed PMC summary named in traffic_source (the in-run rocprofv3 --pmc passes were switched off or failed)",
                          "measured_copy_gbs": copy_gbs, "frac_measured_copy": achieved / copy_gbs,
                          "algorithmic_bytes_per_query": float(bq.mean()), "queries_per_launch": B,
                          "queries_served_by_this_kernel": int(nq_last - general_last) if fast_used else int(nq_last),

@@ -40,6 +40,8 @@ extern "C" {
 #define SRN_ERANGE (-4)  /* k / m / how_many / session length above the compiled kernel limits */
 #define SRN_EIO (-5)
 #define SRN_ENODEV (-6)  /* index has no device attached (built with device < 0) or no GPU present */
+#define SRN_ESTATE (-7)  /* the handle is unusable since an earlier failure (a shard group after a failed batch): free it */
+#define SRN_ETIMEOUT (-8) /* srn_shard_group_wait: the batch did not finish in time */
 
 /* compiled kernel limits (srn_limits() reports the same numbers at run time) */
 #define SRN_MAX_HOW_MANY 512
@@ -132,6 +134,19 @@ int srn_index_info(const srn_index_t* idx, srn_index_info_t* out);
  * *out_len = -1 if the item is unknown.  For index-parity tests and debugging. */
 int srn_index_postings(const srn_index_t* idx, uint64_t item_id, uint32_t* out_sessions, size_t cap,
                        int64_t* out_len, double* out_idf);
+/* The other accessors of the trait predict() is generic over (SimilarityComputationNew, src/vmisknn/similarity_indexed.rs:9-23) -- with srn_index_postings' idf they
+ * are what `impl SimilarityComputationNew for HipVMISIndex` needs:
+ *   items_for_session(&u32) -> &[u64]   (vmis_index.rs:317-319)  the row of a session by its reference index, ascending item ids; *out_len = its length (items beyond
+ *                                        `cap` are not written).  Rows are kept for the sessions that can be neighbours (len <= max_session_len, vmis_index.rs:452); any
+ *                                        other session index: SRN_ERANGE (the reference keeps those rows too, :79, but never reads them on this path)
+ *   find_attributes(&u64) -> Option<&ProductAttributes>   (vmis_index.rs:417-419)  *out_flags = SRN_ATTR_* bits, SRN_ATTR_NONE for None (unknown item or no attributes)
+ *   find_neighbors(&[u64], k, m) -> BinaryHeap<SessionScore>   (vmis_index.rs:325-415)  the neighbour sessions as (reference session index, similarity = numerator / U),
+ *                                        best first (similarity desc, ties: more recent first -- the reference's heap order is unspecified); room for k entries; runs on
+ *                                        the GPU, canonical semantics as everywhere */
+int srn_index_items_for_session(const srn_index_t* idx, uint32_t session, uint64_t* out_items, size_t cap, size_t* out_len);
+int srn_index_find_attributes(const srn_index_t* idx, uint64_t item_id, uint8_t* out_flags);
+int srn_find_neighbors(const srn_index_t* idx, const uint64_t* evolving, size_t len, size_t k, size_t m,
+                       uint32_t* out_sessions, double* out_scores, size_t* out_n);
 void srn_index_free(srn_index_t* idx);
 
 /* ---- predict ---------------------------------------------------------------------------- */
@@ -272,10 +287,16 @@ int srn_shard_group_stats(const srn_shard_group_t* g, srn_shard_group_stats_t* o
 /* Overlap of batch i + 1's exchange (the group's own stream and first communicator) with batch i's kernels and result gather (caller's stream, second communicator).
  * on = 0: everything in issue order on the caller's stream, one collective of the group in flight at a time -- the conservative form (two communicators with collectives in
  * flight at once need both collective kernels to become resident on every rank; they do here -- the predict kernels are finite -- but a host that wants no such
- * dependence switches it off).  Default on (the environment variable SRN_GROUP_OVERLAP=0 changes the default); takes effect from the next batch; every rank must use the
- * same setting for the same batch.  A failed srn_shard_group_predict_batch leaves the peers' collectives of that batch without their partner: the group is then unusable
- * on every rank (free it and create a new one). */
+ * dependence leaves it off).  Default OFF since round 5 -- the overlapped form has never run on more than one GPU; a host opts in (or SRN_GROUP_OVERLAP=1 in the environment);
+ * takes effect from the next batch; every rank must use the same setting for the same batch. */
 int srn_shard_group_set_overlap(srn_shard_group_t* g, int on);
+/* Failure of a batch.  A srn_shard_group_predict_batch that fails after its first collective was handed to the transport (or for a reason its peers do not share: a HIP
+ * error, an allocation) leaves the peers' collectives of that batch without their partner.  The group is then BROKEN on this rank: its RCCL communicators are aborted at
+ * once (nothing of this rank keeps a peer's GPU waiting), and every further call on it fails with SRN_ESTATE.  The peers learn of it from their own transport (a callback
+ * that returns non-zero breaks their group the same way) or from srn_shard_group_wait: a bounded wait for the group's most recent batch -- SRN_OK when its results are
+ * complete, SRN_ETIMEOUT after timeout_ms, which also breaks the group (a collective whose partner died never ends; a plain stream synchronise would hang with it).
+ * A broken group is freed without waiting for the device.  Refusals every rank makes alike before anything is issued (SRN_EINVAL / SRN_ERANGE) leave the group usable. */
+int srn_shard_group_wait(srn_shard_group_t* g, uint64_t timeout_ms);
 /* The NEIGHBOURS pipeline (round 4; SURVEY 8(e)'s replicated-postings variant, with the candidate work divided over the ranks).  The posting lists are the pruned structure
  * (<= m_index entries per item: config 3 111 MB, config 5 ~9 GB) -- every rank keeps ALL of them beside its shard of the rows: `postings` = the unsharded index itself, or
  * its rows-free view (srn_index_postings_view: dictionary, idf / attributes, lists), on the group's device.  Per batch, rank r then runs find_neighbors

@@ -21,6 +21,22 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _includes(src, seen=None):
+    """The quoted #include closure of a source file: an object is rebuilt when ITS headers change, not when any header does."""
+    seen = set() if seen is None else seen
+    import re
+    try:
+        text = open(src).read()
+    except OSError:
+        return []
+    for inc in re.findall(r'^\s*#include\s+"([^"]+)"', text, flags=re.M):
+        path = os.path.normpath(os.path.join(os.path.dirname(src), inc))
+        if path not in seen and os.path.exists(path):
+            seen.add(path)
+            _includes(path, seen)
+    return sorted(seen)
+
+
 def build_hip(force=False, verbose=False):
     """One object per source (rebuilt only when that source or a header changed), then one link."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -30,10 +46,10 @@ def build_hip(force=False, verbose=False):
     if not force and not extra and not _stale(LIB, [os.path.join(CSRC, n) for n in SOURCES] + headers):
         return LIB                                              # (the objects do not travel to the GPU box; the library does)
     os.makedirs(objdir, exist_ok=True)
-    objs, relink = [], force or not os.path.exists(LIB)
+    objs, relink, jobs = [], force or not os.path.exists(LIB), []
     for name in SOURCES:
         src, obj = os.path.join(CSRC, name), os.path.join(objdir, name + ".o")
-        if force or extra or _stale(obj, [src] + headers):
+        if force or extra or _stale(obj, [src] + _includes(src)):
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-value"]
             if name == "srn_kernels.hip":
                 # the predict kernel is ~130 KB of code against a 64 KB instruction cache shared by two CUs: optimising for size
@@ -48,11 +64,18 @@ def build_hip(force=False, verbose=False):
                 cmd[2] = "-Os"
                 cmd += ["-mllvm", "-disable-machine-licm"]
             cmd += extra + ["-c", "-o", obj, src]
+            jobs.append(cmd)
+            relink = True
+        objs.append(obj)
+    if jobs:   # the translation units are independent: compile them side by side (srn_build_gpu.hip -- rocPRIM -- and srn_kernels.hip take ~100 s each alone)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
-            relink = True
-        objs.append(obj)
+        with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), (os.cpu_count() or 2) - 1))) as ex:
+            list(ex.map(run, jobs))
     if relink or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + objs
         if verbose:

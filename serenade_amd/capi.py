@@ -7,13 +7,13 @@ import numpy as np
 
 from . import build as _build
 
-SRN_OK, SRN_EINVAL, SRN_ENOMEM, SRN_EHIP, SRN_ERANGE, SRN_EIO, SRN_ENODEV = 0, -1, -2, -3, -4, -5, -6
+SRN_OK, SRN_EINVAL, SRN_ENOMEM, SRN_EHIP, SRN_ERANGE, SRN_EIO, SRN_ENODEV, SRN_ESTATE, SRN_ETIMEOUT = 0, -1, -2, -3, -4, -5, -6, -7, -8
 ATTR_ADULT, ATTR_FOR_SALE, ATTR_NONE = 1, 2, 0xFF
 FLAG_BUSINESS_LOGIC = 1
 MAX_HOW_MANY, MAX_SESSION_LEN, MAX_K = 512, 255, 8192
 
 _CODES = {SRN_EINVAL: "SRN_EINVAL", SRN_ENOMEM: "SRN_ENOMEM", SRN_EHIP: "SRN_EHIP", SRN_ERANGE: "SRN_ERANGE",
-          SRN_EIO: "SRN_EIO", SRN_ENODEV: "SRN_ENODEV"}
+          SRN_EIO: "SRN_EIO", SRN_ENODEV: "SRN_ENODEV", SRN_ESTATE: "SRN_ESTATE", SRN_ETIMEOUT: "SRN_ETIMEOUT"}
 
 
 class SerenadeError(RuntimeError):
@@ -72,6 +72,9 @@ SYMBOLS = {
     "srn_index_set_attributes": (_i, [_vp, _vp, _vp, _sz]),
     "srn_index_info": (_i, [_vp, C.POINTER(IndexInfo)]),
     "srn_index_postings": (_i, [_vp, _u64, _vp, _sz, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "srn_index_items_for_session": (_i, [_vp, C.c_uint32, _vp, _sz, C.POINTER(_sz)]),
+    "srn_index_find_attributes": (_i, [_vp, _u64, C.POINTER(C.c_uint8)]),
+    "srn_find_neighbors": (_i, [_vp, _vp, _sz, _sz, _sz, _vp, _vp, C.POINTER(_sz)]),
     "srn_index_free": (None, [_vp]),
     "srn_predict": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _i, _vp, _vp, C.POINTER(_sz)]),
     "srn_predict_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
@@ -103,6 +106,7 @@ SYMBOLS = {
     "srn_shard_group_predict_batch": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, C.c_uint, _vp, _vp, _vp, _vp]),
     "srn_shard_group_stats": (_i, [_vp, _vp]),
     "srn_shard_group_set_overlap": (_i, [_vp, _i]),
+    "srn_shard_group_wait": (_i, [_vp, _u64]),
     "srn_shard_group_set_postings": (_i, [_vp, _vp]),
     "srn_debug_shard_group_times": (_i, [_vp, _vp]),
     "srn_index_postings_view": (_i, [_vp, _i, C.POINTER(_vp)]),

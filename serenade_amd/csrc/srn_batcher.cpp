@@ -94,6 +94,7 @@ int srn_batcher_create(const srn_index_t* idx, size_t max_batch, unsigned max_wa
         *out = nullptr;
         if (!idx) return fail(SRN_EINVAL, "null index");
         if (!idx->dev) return fail(SRN_ENODEV, "index has no device attached; there is no CPU fallback behind this ABI");
+        { int rc0 = check_has_rows(idx->flat, "srn_batcher_create"); if (rc0) return rc0; }
         if (k == 0 || m == 0 || how_many == 0) return fail(SRN_EINVAL, "k, m and how_many must be > 0");
         if (how_many > SRN_MAX_HOW_MANY || k > SRN_MAX_K || m > 0x7FFFFFFFull) return fail(SRN_ERANGE, "k, m or how_many above the limits (srn_limits)");
         // (q_off is 32-bit: max_batch sessions of SRN_MAX_SESSION_LEN items must not wrap it)

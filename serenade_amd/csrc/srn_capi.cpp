@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "srn_internal.h"
 
@@ -30,7 +31,7 @@ int check_predict_args(const srn_index_t* idx, size_t k, size_t m, size_t how_ma
 }
 // an item shard answers only through the three stages: its rows are fragments (DeviceIndex::row_frag) and its lists a subset
 static int check_not_a_shard(const srn_index_t* idx) {
-    return idx && idx->flat.n_shards > 1 ? fail(SRN_EINVAL, "this index is one item shard of several: predictions go through srn_shard_stage_a/b/c") : SRN_OK;
+    return idx && idx->flat.n_shards > 1 ? fail(SRN_EINVAL, "this index is one item shard of several: predictions go through its shard group (srn_shard_group_predict_batch)") : SRN_OK;
 }
 
 int predict_host(const srn_index_t* idx, const uint64_t* items_flat, const uint32_t* q_off, size_t nq, size_t k, size_t m,
@@ -146,7 +147,7 @@ int srn_index_new_from_avro(const char* base_path, int device, srn_index_t** out
 
 int srn_index_save(const srn_index_t* idx, const char* path) {
     if (!idx || !path) return fail(SRN_EINVAL, "null argument");
-    return guarded([&]() -> int { return save_flat_index(idx->flat, path); });
+    return guarded([&]() -> int { int rc = check_has_rows(idx->flat, "srn_index_save"); if (rc) return rc; return save_flat_index(idx->flat, path); });
 }
 int srn_index_load(const char* path, int device, srn_index_t** out) {
     return guarded([&]() -> int {
@@ -187,6 +188,62 @@ int srn_index_postings(const srn_index_t* idx, uint64_t item_id, uint32_t* out_s
     if (out_idf) *out_idf = f.idf[j];
     return SRN_OK;
 }
+// ---- the rest of SimilarityComputationNew (src/vmisknn/similarity_indexed.rs:9-23) at the ABI: with srn_index_postings (+ idf) above, a maintainer can write
+// `impl SimilarityComputationNew for HipVMISIndex`, not only swap the free function predict ----
+int srn_index_items_for_session(const srn_index_t* idx, uint32_t session, uint64_t* out_items, size_t cap, size_t* out_len) {
+    return guarded([&]() -> int {
+        if (!idx || !out_len) return fail(SRN_EINVAL, "null argument");
+        *out_len = 0;
+        const FlatIndex& f = idx->flat;
+        int rc = check_has_rows(f, "srn_index_items_for_session"); if (rc) return rc;
+        if (f.n_shards > 1) return fail(SRN_EINVAL, "an item shard holds row FRAGMENTS (the items it owns): ask the unsharded index");
+        if (session >= f.n_sessions_total) return fail(SRN_EINVAL, "no such session (the reference indexes out of bounds: vmis_index.rs:317-319)");
+        std::call_once(idx->s2r_once, [&] { idx->session_to_rank.assign(f.n_sessions_total, kNone); for (uint64_t r = 0; r < f.n_kept; ++r) idx->session_to_rank[f.rank_to_session[r]] = (uint32_t)r; });
+        const uint32_t r = idx->session_to_rank[session];
+        // (the reference keeps the rows of ALL sessions, vmis_index.rs:79, but only sessions of <= max_session_len items enter the posting lists, :452 -- and only those can
+        //  ever be neighbours, so only their rows are kept here)
+        if (r == kNone) return fail(SRN_ERANGE, "this session is longer than max_session_len: it is in no posting list (vmis_index.rs:452), never a neighbour, and its row is not kept");
+        const uint64_t o0 = f.row_off[r], o1 = f.row_off[r + 1];
+        *out_len = (size_t)(o1 - o0);
+        if (out_items) for (uint64_t t = o0; t < o1 && t - o0 < cap; ++t) out_items[t - o0] = f.item_id[f.row_items[t]];   // (row order = ascending public id, as the reference's item_ids_asc)
+        return SRN_OK; });
+}
+int srn_index_find_attributes(const srn_index_t* idx, uint64_t item_id, uint8_t* out_flags) {
+    if (!idx || !out_flags) return fail(SRN_EINVAL, "null argument");
+    const uint32_t j = idx->flat.lookup(item_id);
+    *out_flags = j == kNone ? (uint8_t)SRN_ATTR_NONE : idx->flat.attr[j];   // (None for an unknown item, like HashMap::get, vmis_index.rs:417-419)
+    return SRN_OK;
+}
+// find_neighbors (vmis_index.rs:325-415) by itself: the k neighbours of an evolving session as (reference session index, similarity = numerator / U), canonical
+// semantics, best first -- similarity descending, ties: the more recent session first.  The GPU does the work (the general kernel with its
+// neighbour dump); not a debug aid: same k / m / session-length limits as srn_predict, re-entrant.
+int srn_find_neighbors(const srn_index_t* idx, const uint64_t* evolving, size_t len, size_t k, size_t m, uint32_t* out_sessions, double* out_scores, size_t* out_n) {
+    return guarded([&]() -> int {
+        if (!out_n) return fail(SRN_EINVAL, "null out_n");
+        *out_n = 0;
+        if (!evolving || len == 0) return fail(SRN_EINVAL, "empty evolving session");
+        if (len > SRN_MAX_SESSION_LEN) return fail(SRN_ERANGE, "evolving session longer than SRN_MAX_SESSION_LEN");
+        int rc = check_predict_args(idx, k, m, 1); if (rc) return rc;
+        rc = check_not_a_shard(idx); if (rc) return rc;
+        if (!out_sessions || !out_scores) return fail(SRN_EINVAL, "null buffer");
+        std::vector<uint32_t> nb_rank(k), nb_num(k); uint32_t nb_cnt = 0, cnt = 0, stats[8] = {0};
+        uint64_t id1 = 0; double sc1 = 0.0;
+        const uint32_t q_off[2] = {0u, (uint32_t)len};
+        LaunchParams p{};
+        p.nq = 1; p.k = (uint32_t)k; p.m = (uint32_t)m; p.how_many = 1; p.flags = 0; p.max_len = (uint32_t)len;
+        rc = device_predict(idx->dev, idx->flat, p, false, nullptr, evolving, q_off, &id1, &sc1, &cnt, stats, nb_rank.data(), nb_num.data(), &nb_cnt);
+        if (rc) return rc;
+        if (cnt == 0xFFFFFFFFu) return fail(SRN_ERANGE, "the query exceeded the kernel's table limits");
+        size_t U = 0;   // distinct raw ids, known or not (vmis_index.rs:334-352: the decay's denominator)
+        for (size_t i = 0; i < len; ++i) { bool first = true; for (size_t j = 0; j < i; ++j) first = first && evolving[j] != evolving[i]; U += first; }
+        std::vector<uint32_t> ord(nb_cnt);
+        for (uint32_t i = 0; i < nb_cnt; ++i) ord[i] = i;
+        std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return nb_num[a] != nb_num[b] ? nb_num[a] > nb_num[b] : nb_rank[a] > nb_rank[b]; });
+        for (uint32_t i = 0; i < nb_cnt; ++i) { out_sessions[i] = idx->flat.rank_to_session[nb_rank[ord[i]]]; out_scores[i] = (double)nb_num[ord[i]] / (double)U; }
+        *out_n = nb_cnt;
+        return SRN_OK; });
+}
+
 void srn_index_free(srn_index_t* idx) {
     if (!idx) return;
     device_release(idx->dev);
@@ -285,6 +342,7 @@ int srn_index_shard(const srn_index_t* full, uint32_t shard, uint32_t n_shards, 
     return guarded([&]() -> int {
         if (!full || !out) return fail(SRN_EINVAL, "null argument");
         *out = nullptr;
+        { int rc0 = check_has_rows(full->flat, "srn_index_shard"); if (rc0) return rc0; }
         srn_index* ix = new srn_index();
         int rc = shard_flat_index(full->flat, shard, n_shards, ix->flat);
         if (rc == SRN_OK && device >= 0) { ix->dev = device_attach(ix->flat, device); ix->device = device; if (!ix->dev) rc = SRN_EHIP; else ix->comb = combiner_create(); }
@@ -297,13 +355,14 @@ int srn_index_postings_view(const srn_index_t* full, int device, srn_index_t** o
         if (!full || !out) return fail(SRN_EINVAL, "null argument");
         *out = nullptr;
         if (full->flat.n_shards != 1) return fail(SRN_EINVAL, "the postings view is cut from an UNSHARDED index");
+        { int rc0 = check_has_rows(full->flat, "srn_index_postings_view"); if (rc0) return rc0; }
         if (device < 0) return fail(SRN_ENODEV, "a postings view lives on a device");
         srn_index* ix = new srn_index();
         const FlatIndex& f = full->flat; FlatIndex& g = ix->flat;
         g.n_items = f.n_items; g.n_sessions_total = f.n_sessions_total; g.n_kept = f.n_kept; g.nnz_rows = 0; g.nnz_post = f.nnz_post; g.m_index = f.m_index;
-        g.max_session_len = f.max_session_len; g.max_row_len = 0; g.idf_weighting = f.idf_weighting; g.lists_complete = f.lists_complete; g.postings_only = true;
+        g.max_session_len = f.max_session_len; g.max_row_len = f.max_row_len /* (of the index the lists belong to: the shard group derives its choice of pipeline from it, the same on every rank) */; g.idf_weighting = f.idf_weighting; g.lists_complete = f.lists_complete; g.postings_only = true;
         g.total_pairs = f.total_pairs; g.item_id = f.item_id; g.id_rank = f.id_rank; g.idf = f.idf; g.attr = f.attr; g.post_off = f.post_off; g.post_rank = f.post_rank;
-        g.id_table = f.id_table; g.id_mask = f.id_mask;
+        g.id_table = f.id_table; g.id_mask = f.id_mask; g.rank_to_session = f.rank_to_session;   // (srn_index_postings answers in reference session indices)
         ix->dev = device_attach(ix->flat, device); ix->device = device;
         if (!ix->dev) { delete ix; return SRN_EHIP; }
         *out = ix; return SRN_OK; });

@@ -25,6 +25,8 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -50,6 +52,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;   // (optional: tears a communicator down without waiting for its peers)
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
@@ -76,6 +79,7 @@ RcclApi* rccl() {
         api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce"); api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
         api.Send = (decltype(api.Send))sym("ncclSend"); api.Recv = (decltype(api.Recv))sym("ncclRecv");
         api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart"); api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+        api.CommAbort = (decltype(api.CommAbort))dlsym(h, "ncclCommAbort");
     });
     return &api;
 }
@@ -116,8 +120,14 @@ struct srn_shard_group {
     ncclComm_t comm[2] = {nullptr, nullptr};   // [0] exchange stream, [1] caller's stream: operations on one communicator serialise in issue order
     srn_shard_comm_t cb{};
     hipStream_t s_x = nullptr; hipEvent_t e_in = nullptr, e_x = nullptr;
-    bool overlap = true, no_direct = false;
+    bool overlap = false, no_direct = false;   // overlap: opt-in (srn_shard_group_set_overlap) -- two communicators with collectives in flight at once have never been soaked on more than one GPU
+    // A batch that failed after its first collective was issued leaves the peers' collectives without their partner: the group is BROKEN on this rank from then on (every
+    // further call fails at once with SRN_ESTATE, the RCCL communicators are aborted so that nothing of this rank keeps a peer waiting), and the peers find out through their
+    // own transport's error / srn_shard_group_wait's timeout.  `issued`: a collective of the current batch has been handed to the transport.
+    bool broken = false, issued = false; std::string broken_why;
+    hipEvent_t e_last = nullptr;           // the end of the most recent batch on the caller's stream (srn_shard_group_wait)
     const srn_index* postings = nullptr;   // the replicated posting lists (srn_shard_group_set_postings): batches of the fast kernel's shape take the neighbours pipeline
+    uint64_t postings_max_row_len = 0;     // ... and the longest row of the WHOLE index: what the choice of pipeline is derived from (the same on every rank)
     Slot slot[2];
     uint64_t calls = 0;
     uint64_t st_queries = 0, st_bytes_head = 0, st_bytes_kept = 0, st_bytes_lists = 0, st_bytes_results = 0, st_lists_max = 0;
@@ -132,21 +142,25 @@ uint32_t G_of(const srn_shard_group* g) { return g->kind == srn_shard_group::LOC
 
 // ---- the three collectives.  channel 0 = exchange stream, 1 = caller's stream ----
 int all_reduce_max_i32(srn_shard_group* g, int channel, int* buf, size_t count, hipStream_t st) {
+    g->issued = true;
     if (g->kind == srn_shard_group::RCCL) NCCL_TRY(rccl()->AllReduce(buf, buf, count, ncclInt32, ncclMax, g->comm[channel], st));
     else if (g->kind == srn_shard_group::CALLBACKS) { const int rc = g->cb.all_reduce_max_i32(g->cb.user, channel, buf, count, st); if (rc) return fail(rc, "the application's all-reduce callback failed"); }
     return SRN_OK;
 }
 int all_reduce_min_i32(srn_shard_group* g, int channel, int* buf, size_t count, hipStream_t st) {
+    g->issued = true;
     if (g->kind == srn_shard_group::RCCL) NCCL_TRY(rccl()->AllReduce(buf, buf, count, ncclInt32, ncclMin, g->comm[channel], st));
     else if (g->kind == srn_shard_group::CALLBACKS) { const int rc = g->cb.all_reduce_min_i32(g->cb.user, channel, buf, count, st); if (rc) return fail(rc, "the application's all-reduce(min) callback failed"); }
     return SRN_OK;
 }
 int all_gather_blocks(srn_shard_group* g, int channel, char* buf, size_t block_bytes, hipStream_t st) {   // block `rank` in place
+    g->issued = true;
     if (g->kind == srn_shard_group::RCCL) NCCL_TRY(rccl()->AllGather(buf + (size_t)g->rank * block_bytes, buf, block_bytes, ncclChar, g->comm[channel], st));
     else if (g->kind == srn_shard_group::CALLBACKS) { const int rc = g->cb.all_gather(g->cb.user, channel, buf, block_bytes, st); if (rc) return fail(rc, "the application's all-gather callback failed"); }
     return SRN_OK;
 }
 int all_gather_v(srn_shard_group* g, int channel, char* buf, const unsigned long long* byte_off, const unsigned long long* byte_cnt, hipStream_t st) {   // segment `rank` in place
+    g->issued = true;
     if (g->kind == srn_shard_group::RCCL) {
         // every rank ships exactly the entries it holds: grouped point-to-point pairs (xGMI is point-to-point: 7 links per GPU, one per peer)
         NCCL_TRY(rccl()->GroupStart());
@@ -178,6 +192,7 @@ int group_init_common(srn_shard_group* g) {
     { int prio_lo = 0, prio_hi = 0; (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // the exchange stream: highest priority = a hardware queue of its own, and its small kernels and RCCL's
       HIP_TRY(hipStreamCreateWithPriority(&g->s_x, hipStreamNonBlocking, prio_hi)); }          // are dispatched ahead of the previous batch's persistent workgroups on the caller's stream
     HIP_TRY(hipEventCreateWithFlags(&g->e_in, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&g->e_x, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&g->e_last, hipEventDisableTiming));
     const uint32_t G = G_of(g);
     for (Slot& s : g->slot) {
         HIP_TRY(hipEventCreateWithFlags(&s.e_done, hipEventDisableTiming));
@@ -194,6 +209,7 @@ int group_init_common(srn_shard_group* g) {
 int check_shard(const srn_index* ix, uint32_t want_shard, uint32_t n_shards) {
     if (!ix) return fail(SRN_EINVAL, "null shard");
     if (!ix->dev) return fail(SRN_ENODEV, "shard has no device attached; there is no CPU fallback behind this ABI");
+    { int rc0 = check_has_rows(ix->flat, "srn_shard_group_create"); if (rc0) return rc0; }
     if (ix->flat.n_shards != n_shards || ix->flat.shard != want_shard) return fail(SRN_EINVAL, "the index is not shard " + std::to_string(want_shard) + " of " + std::to_string(n_shards));
     return SRN_OK;
 }
@@ -334,9 +350,32 @@ int group_predict_neighbours(srn_shard_group* g, const LaunchParams& p_in, bool 
     return SRN_OK;
 }
 
+int group_predict_locked(srn_shard_group* g, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq_, size_t max_len_hint, size_t k, size_t m, size_t how_many,
+                         unsigned flags, uint64_t* d_out_ids, double* d_out_scores, uint32_t* d_out_counts, hipStream_t user);
+// The group gives up: nothing of this rank may keep a peer waiting, and nothing further is issued.  RCCL: both communicators are aborted (ncclCommAbort ends their kernels
+// on this GPU; a peer blocked in the matching collective sees the connection go and fails, or runs into its own srn_shard_group_wait timeout); callbacks: the
+// application's transport is the application's to tear down -- it learns of the failure from the return code.
+void group_break(srn_shard_group* g, const std::string& why) {
+    if (g->broken) return;
+    g->broken = true; g->broken_why = why;
+    if (g->kind == srn_shard_group::RCCL)
+        for (auto& c : g->comm) if (c) { if (rccl()->CommAbort) rccl()->CommAbort(c); else if (rccl()->CommDestroy) rccl()->CommDestroy(c); c = nullptr; }
+}
 int group_predict(srn_shard_group* g, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq_, size_t max_len_hint, size_t k, size_t m, size_t how_many,
                   unsigned flags, uint64_t* d_out_ids, double* d_out_scores, uint32_t* d_out_counts, hipStream_t user) {
     std::lock_guard<std::mutex> lk(g->mu);
+    if (g->broken) return fail(SRN_ESTATE, "the shard group is unusable since an earlier batch failed (" + g->broken_why + "): free it and create a new one on every rank");
+    g->issued = false;
+    const int rc = group_predict_locked(g, d_items_flat, d_q_off, nq_, max_len_hint, k, m, how_many, flags, d_out_ids, d_out_scores, d_out_counts, user);
+    if (rc == SRN_OK) { if (g->e_last) (void)hipEventRecord(g->e_last, user); return rc; }
+    // A refusal that every rank makes alike before anything was issued (a parameter beyond a limit) leaves the group as it was; anything else -- a collective that failed,
+    // a HIP error, an allocation that failed on THIS rank -- may have left the peers in a collective of this batch, or be about to.
+    const bool peers = g->kind != srn_shard_group::LOCAL && g->world > 1;
+    if (g->issued || (peers && rc != SRN_EINVAL && rc != SRN_ERANGE)) { const std::string why = last_error_string(); group_break(g, why); set_error(why); }
+    return rc;
+}
+int group_predict_locked(srn_shard_group* g, const uint64_t* d_items_flat, const uint32_t* d_q_off, size_t nq_, size_t max_len_hint, size_t k, size_t m, size_t how_many,
+                         unsigned flags, uint64_t* d_out_ids, double* d_out_scores, uint32_t* d_out_counts, hipStream_t user) {
     HIP_TRY(hipSetDevice(g->device));
     const uint32_t G = G_of(g), nq = (uint32_t)nq_, ML = (uint32_t)max_len_hint, n = (uint32_t)how_many;
     const bool local = g->kind == srn_shard_group::LOCAL;
@@ -349,8 +388,10 @@ int group_predict(srn_shard_group* g, const uint64_t* d_items_flat, const uint32
         if (!device_shard_lists_supported(ix->dev, ix->flat, p)) return group_predict_stages(g, p, d_out_ids, d_out_scores, d_out_counts, user);   // (every rank holds the same index parameters: the same choice everywhere)
     if (g->postings && G > 1) {   // (the same index parameters and the same batch shape on every rank: the same choice everywhere.  A group of ONE shard gains nothing from
                                  //  dividing the candidate work: its lists pipeline reads the lists in place and runs the fused kernel -- 23.4 against 10 + 16.7 ms per 2^20 queries)
+        // (rank-invariant inputs only: the batch shape, the index parameters, the whole index's longest row; that every shard has its packed rows was checked by set_postings.
+        //  a choice made from rank-local state would pair one rank's all-reduce with its peers' all-gather on the same communicator)
         bool all = true;
-        for (const srn_index* ix : g->shards) all = all && device_fast_eligible(ix->dev, ix->flat, p);
+        for (const srn_index* ix : g->shards) all = all && device_fast_eligible(ix->dev, ix->flat, p, std::max<uint64_t>(1, g->postings_max_row_len));
         if (all) return group_predict_neighbours(g, p, resident, d_out_ids, d_out_scores, d_out_counts, user);
     }
     p.out_ids = nullptr; p.out_scores = nullptr; p.out_counts = nullptr;
@@ -517,11 +558,11 @@ int srn_shard_group_create_local(const srn_index_t* const* shards, int n_shards,
 void srn_shard_group_free(srn_shard_group_t* g) {
     if (!g) return;
     hipSetDevice(g->device);
-    hipDeviceSynchronize();
+    if (!g->broken) hipDeviceSynchronize();   // (a broken group's communicators were aborted; what a dead peer left on the device is not waited for)
     for (auto& c : g->comm) if (c && rccl()->CommDestroy) rccl()->CommDestroy(c);
     for (Slot& s : g->slot) slot_free(s);
     if (g->s_x) hipStreamDestroy(g->s_x);
-    if (g->e_in) hipEventDestroy(g->e_in); if (g->e_x) hipEventDestroy(g->e_x);
+    if (g->e_in) hipEventDestroy(g->e_in); if (g->e_x) hipEventDestroy(g->e_x); if (g->e_last) hipEventDestroy(g->e_last);
     for (auto& e : g->e_t) if (e) hipEventDestroy(e);
     delete g;
 }
@@ -556,8 +597,12 @@ int srn_shard_group_set_postings(srn_shard_group_t* g, const srn_index_t* postin
                 sh->flat.n_sessions_total != postings->flat.n_sessions_total)
                 return fail(SRN_EINVAL, "the postings index is not the index these shards were cut from (sessions / pairs / m_index differ)");
         if (!postings->flat.lists_complete) return fail(SRN_EINVAL, "the neighbours pipeline needs complete posting lists");
+        // the choice between the pipelines is made per batch from rank-INVARIANT inputs; what is rank-local is settled here, loudly: a shard whose packed rows did not fit
+        // its GPU (device_attach lets that allocation fail) cannot take the neighbours pipeline, and its peers must not find out in the middle of a batch
+        for (const srn_index* sh : g->shards)
+            if (!device_has_packed_rows(sh->dev)) return fail(SRN_ENOMEM, "this rank's shard has no packed rows (no room at attach time): the neighbours pipeline cannot run on this group -- leave the postings unset on EVERY rank");
     }
-    g->postings = postings;
+    g->postings = postings; g->postings_max_row_len = postings ? postings->flat.max_row_len : 0;
     return SRN_OK;
 }
 
@@ -566,6 +611,29 @@ int srn_shard_group_set_overlap(srn_shard_group_t* g, int on) {
     std::lock_guard<std::mutex> lk(g->mu);   // (between batches: a batch in flight keeps the form it was issued in; the slots' events order the next one behind it either way)
     g->overlap = on != 0;
     return SRN_OK;
+}
+
+// The host's bounded wait for the group's most recent batch: 0 when its results are complete, SRN_ETIMEOUT after timeout_ms -- a peer that died leaves this rank's
+// collective waiting on the GPU for ever, and a plain stream synchronise with it.  On a timeout the group is broken (communicators aborted): free it on every rank.
+int srn_shard_group_wait(srn_shard_group_t* g, uint64_t timeout_ms) {
+    if (!g) return fail(SRN_EINVAL, "null group");
+    return guarded([&]() -> int {
+        std::lock_guard<std::mutex> lk(g->mu);
+        if (g->broken) return fail(SRN_ESTATE, "the shard group is unusable since an earlier batch failed (" + g->broken_why + ")");
+        if (!g->calls || !g->e_last) return SRN_OK;
+        HIP_TRY(hipSetDevice(g->device));
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spin = 0;; ++spin) {
+            const hipError_t e = hipEventQuery(g->e_last);
+            if (e == hipSuccess) return SRN_OK;
+            if (e != hipErrorNotReady) { group_break(g, std::string("hipEventQuery: ") + hipGetErrorString(e)); return fail(SRN_EHIP, std::string("hipEventQuery: ") + hipGetErrorString(e)); }
+            if ((uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() >= timeout_ms) {
+                group_break(g, "a batch did not finish within " + std::to_string(timeout_ms) + " ms (a peer gone?)");
+                return fail(SRN_ETIMEOUT, "the group's last batch did not finish within " + std::to_string(timeout_ms) + " ms: the group is now unusable on this rank (free it on every rank)");
+            }
+            if (spin > 64) std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+    });
 }
 
 int srn_shard_group_stats(const srn_shard_group_t* g, srn_shard_group_stats_t* out) {

@@ -295,6 +295,9 @@ template <typename T> bool rd(FILE* f, std::vector<T>& v) {
 }
 }  // namespace
 
+int check_has_rows(const FlatIndex& ix, const char* what) {
+    return ix.postings_only ? fail(SRN_EINVAL, std::string(what) + ": a postings-only view (srn_index_postings_view) holds no rows -- it serves srn_shard_group_set_postings and nothing else") : SRN_OK;
+}
 int save_flat_index(const FlatIndex& ix, const char* path) {
     FILE* f = fopen(path, "wb"); if (!f) return fail(SRN_EIO, std::string("cannot create ") + path);
     const char magic[8] = {'S', 'R', 'N', 'F', 'L', 'A', 'T', '4'};

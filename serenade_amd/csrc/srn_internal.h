@@ -2,6 +2,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -73,6 +74,7 @@ int build_flat_index_gpu(const srn_sessions_view_t& v, size_t m_index, size_t ma
                          FlatIndex& out);   // same result, built with rocPRIM sorts on the GPU (srn_build_gpu.hip)
 int build_flat_index_from_avro(const char* base_path, FlatIndex& out);   // <base>/itemindex/*.avro + <base>/sessionindex/*.avro (srn_avro.cpp)
 int shard_flat_index(const FlatIndex& full, uint32_t shard, uint32_t n_shards, FlatIndex& out);   // shard `shard` of an unsharded index (same bytes as build_flat_index(..., shard, n_shards))
+int check_has_rows(const FlatIndex& ix, const char* what);   // SRN_EINVAL for a postings-only view (srn_index_postings_view): it has no rows to cut, save, shard or serve from
 int save_flat_index(const FlatIndex& ix, const char* path);
 int load_flat_index(const char* path, FlatIndex& ix);
 
@@ -135,7 +137,8 @@ struct ShardIO {
 };
 
 bool device_shard_lists_supported(DeviceState* d, const FlatIndex& ix, const LaunchParams& p);
-bool device_fast_eligible(DeviceState* d, const FlatIndex& ix, const LaunchParams& p);
+bool device_fast_eligible(DeviceState* d, const FlatIndex& ix, const LaunchParams& p, uint64_t max_row_len_all = 0);   // max_row_len_all != 0: from rank-invariant inputs only (srn_group.hip)
+bool device_has_packed_rows(const DeviceState* d);
 // neighbours pipeline (replicated postings `post`: the whole index's dictionary + lists): prep records of ALL queries (lists looked up in `post`, dense idx in this shard's
 // table), then the front end over the queries [q_lo, q_hi) -> xchg, or the back end over all of them <- xchg
 int device_shard_nb_prep(DeviceState* d, DeviceState* post, const LaunchParams& p, char* records, void* stream);
@@ -177,6 +180,8 @@ struct srn_index {
     srn::DeviceState* dev = nullptr;
     int device = -1;
     srn::Combiner* comb = nullptr;   // created with the device state
+    // reference session index -> recency rank (kNone: not a kept session), built at the first srn_index_items_for_session call (the index is immutable: call_once)
+    mutable std::vector<uint32_t> session_to_rank; mutable std::once_flag s2r_once;
 };
 struct srn_sessions {
     srn::Sessions s;

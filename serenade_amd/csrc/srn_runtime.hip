@@ -196,6 +196,7 @@ int device_update_attr(DeviceState* d, const FlatIndex& ix) {
     return SRN_OK;
 }
 uint64_t device_bytes(const DeviceState* d) { return d ? d->bytes : 0; }
+bool device_has_packed_rows(const DeviceState* d) { return d && d->fast.row_packed != nullptr; }
 int device_count() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
 
 // Host-pointer calls borrow a workspace for the duration of the (synchronous) call.  Device-pointer
@@ -244,6 +245,8 @@ static inline bool is_prime(uint32_t n) { if (n < 2) return false; for (uint32_t
 static inline uint32_t prime_at_most(uint32_t n) { while (n > 2 && !is_prime(n)) --n; return std::max<uint32_t>(n, 2); }
 static inline uint32_t prime_at_least(uint64_t n) { uint32_t v = (uint32_t)std::min<uint64_t>(n, 0x3FFFFFFFull); while (!is_prime(v)) ++v; return v; }
 
+// a sketch word sums max(w, 0) * num over ALL elements that share it (<= k rows of <= max_row_len items): can that pass 2^32?
+static inline bool sketch_wraps(uint64_t k, uint64_t max_row_len, uint64_t Lmax) { return k * std::max<uint64_t>(1, max_row_len) * 9ull * (Lmax * (Lmax + 1) / 2) >= (1ull << 32); }
 struct Geometry {
     KernelCfg c{}; bool slot64 = false, masks = false; uint32_t slot_bytes = 4; size_t lds = 0;
     uint64_t need_sess = 0, need_item = 0; bool sess_may_overflow = false, item_may_overflow = false, sketch_may_wrap = false;
@@ -297,7 +300,7 @@ static int make_geometry(const DeviceState* d, const FlatIndex& ix, const Launch
         if ((uint64_t)p.k * wn_max >= (1ull << 31))
             return fail(SRN_ERANGE, "k * |10 * linear_score| * similarity numerator can exceed the 32-bit item accumulators at this k and session length: lower k or max_items_in_session");
         // a sketch word sums max(w, 0) * num over ALL elements that share it (<= k rows of <= max_row_len items): if even that could wrap, no sketch
-        g.sketch_may_wrap = (uint64_t)p.k * std::max<uint64_t>(1, ix.max_row_len) * 9ull * (Lmax * (Lmax + 1) / 2) >= (1ull << 32);
+        g.sketch_may_wrap = sketch_wraps(p.k, ix.max_row_len, Lmax);
     }
     const int sbits = std::max(2, bits_host(w_max) + 1), cbits = bits_host(p.k);
     // exact words for the 2048 most popular items, 4096 where a query walks many rows (measured with the end-of-round kernel, 2048 -> 4096:
@@ -396,7 +399,9 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
         HIP_TRY(launch_predict(geo.masks, geo.slot64, false, 0, dim3(p.nq), geo.lds, st, d->di, p, geo.c, w->slow_list, w->slow_cnt, (uint32_t*)(dp + o_rl), (uint32_t*)(dp + o_rc), nullptr, 0,
                                w->spill, ShardIO{}));
         HIP_TRY(launch_finish(st, d->di, fp, p.out_ids, p.out_scores, p.out_counts, p.nq, p.how_many));
-        HIP_TRY(launch_finish_big(st, d->di, fp, p.out_ids, p.out_scores, p.out_counts, p.how_many, (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * 16)));
+        // (it also publishes the call's path counters -- handed over, listed for MID -- in the workspace's pinned words: srn_last_path_counts / srn_debug_last_mid_count after a
+        //  latency-path call used to say "all through the general kernel")
+        HIP_TRY(launch_finish_big(st, d->di, fp, p.out_ids, p.out_scores, p.out_counts, p.how_many, (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * 16), nullptr, w->slow_cnt, w->h_retry_dev));
     } else
     HIP_TRY(launch_predict(geo.masks, geo.slot64, false, 0, dim3(p.nq), geo.lds, st, d->di, p, geo.c, nullptr, nullptr, (uint32_t*)(dp + o_rl), (uint32_t*)(dp + o_rc), nullptr, 0,
                            w->spill, ShardIO{}));
@@ -406,9 +411,9 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
         HIP_TRY(hipEventSynchronize(w->ev_block));
     } else HIP_TRY(hipStreamSynchronize(st));
     if (*(volatile uint32_t*)(w->pin + o_rc) != 0) return 1;   // (rare: tables too small for some query)
-    // what the timing / path-count APIs report after this call: its query count, all through the general kernel, not timed (the stream is idle here:
-    // nothing of an earlier call is still writing the pinned words)
-    ++w->untimed_calls; w->last_nq = p.nq; w->last_retry = 0; w->last_fast = false; w->last_untimed = true;   // (`calls` indexes the event ring: timed calls only)
+    // what the timing / path-count APIs report after this call: its query count, how many of them the fast sequence handed to the general kernel (all of them where the
+    // two-launch form ran), not timed (the stream is idle here: nothing of an earlier call is still writing the pinned words)
+    ++w->untimed_calls; w->last_nq = p.nq; w->last_retry = 0; w->last_fast = tiny_fast; w->last_mid = tiny_fast && plan.mid_tier; w->last_untimed = true;   // (`calls` indexes the event ring: timed calls only)
     const uint64_t* r_ids = (const uint64_t*)(w->pin + o_ids); const double* r_sc = (const double*)(w->pin + o_sc); const uint32_t* r_cnt = (const uint32_t*)(w->pin + o_cnt);
     for (uint32_t q = 0; q < p.nq; ++q) {
         const uint32_t n = r_cnt[q] == 0xFFFFFFFFu ? 0u : std::min<uint32_t>(r_cnt[q], p.how_many);
@@ -709,12 +714,15 @@ bool device_shard_lists_supported(DeviceState* d, const FlatIndex& ix, const Lau
     return make_geometry(d, ix, p, 0, g) == SRN_OK && g.masks && (p.flags & ~(unsigned)SRN_FLAG_BUSINESS_LOGIC) == 0 && p.stats == nullptr && p.nb_rank == nullptr;
 }
 // the batch shape the fast kernel takes (the same test device_predict makes): what the shard group's neighbours pipeline needs on top of lists mode
-bool device_fast_eligible(DeviceState* d, const FlatIndex& ix, const LaunchParams& p) {
+// (the shard group's choice of pipeline must be the SAME on every rank: `max_row_len_all` = the longest row of the whole index -- a shard's own longest fragment differs from
+//  rank to rank and is never longer -- and the packed rows, which device_attach may fail to allocate on ONE rank, are checked where the postings are set, not here)
+bool device_fast_eligible(DeviceState* d, const FlatIndex& ix, const LaunchParams& p, uint64_t max_row_len_all) {
     Geometry geo;
     if (make_geometry(d, ix, p, 0, geo) != SRN_OK) return false;
     const Knobs kn = knobs();
     const int rank_bits_f = std::max(1, bits_host(ix.n_kept ? ix.n_kept - 1 : 0));
-    return d->fast.row_packed != nullptr && geo.masks && !geo.sketch_may_wrap && rank_bits_f <= 29 && kn.geometry_default() && !kn.no_fast && p.k <= F_K_MAX && p.m <= F_M_MAX &&
+    const bool wraps = max_row_len_all ? sketch_wraps(p.k, std::max<uint64_t>(max_row_len_all, ix.max_row_len), p.max_len) : geo.sketch_may_wrap;
+    return (max_row_len_all != 0 || d->fast.row_packed != nullptr) && geo.masks && !wraps && rank_bits_f <= 29 && kn.geometry_default() && !kn.no_fast && p.k <= F_K_MAX && p.m <= F_M_MAX &&
            p.how_many <= 24 && (p.flags & ~(unsigned)SRN_FLAG_BUSINESS_LOGIC) == 0 && p.stats == nullptr && p.nb_rank == nullptr && p.max_len <= 8;
 }
 uint32_t device_prep_stride(uint32_t max_len) { return (uint32_t)(sizeof(PrepHead) + (size_t)max_len * sizeof(PrepItem)); }

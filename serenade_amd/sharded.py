@@ -250,8 +250,12 @@ class ShardGroup:
 
     def set_overlap(self, on):
         """srn_shard_group_set_overlap: batch i + 1's exchange beside batch i's kernels and result gather (two communicators in flight), or everything in
-        issue order on the caller's stream."""
+        issue order on the caller's stream (the default since round 5)."""
         capi.check(capi.lib().srn_shard_group_set_overlap(self._h, 1 if on else 0))
+
+    def wait(self, timeout_ms):
+        """srn_shard_group_wait: a bounded wait for the group's most recent batch (SerenadeError with code SRN_ETIMEOUT -- and a broken group -- if a peer never shows up)."""
+        capi.check(capi.lib().srn_shard_group_wait(self._h, int(timeout_ms)))
 
     @property
     def stats(self):

@@ -97,6 +97,36 @@ class VMISIndex:
         capi.check(capi.lib().srn_index_postings(self._h, int(item_id), capi.ptr(out), n.value, C.byref(n), C.byref(idf)))
         return out[:n.value], idf.value
 
+    # the trait's other accessors (SimilarityComputationNew, src/vmisknn/similarity_indexed.rs:9-23)
+    def idf(self, item_id):
+        """idf(&u64) -> f64 (vmis_index.rs:321-323).  The reference panics on an unknown item; here: KeyError."""
+        n, idf = C.c_int64(), C.c_double()
+        capi.check(capi.lib().srn_index_postings(self._h, int(item_id), None, 0, C.byref(n), C.byref(idf)))
+        if n.value < 0:
+            raise KeyError(item_id)
+        return idf.value
+
+    def items_for_session(self, session):
+        """items_for_session(&u32) -> &[u64] (vmis_index.rs:317-319): ascending item ids of a kept session, by its reference session index."""
+        n = C.c_size_t()
+        capi.check(capi.lib().srn_index_items_for_session(self._h, int(session), None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), np.uint64)
+        capi.check(capi.lib().srn_index_items_for_session(self._h, int(session), capi.ptr(out), n.value, C.byref(n)))
+        return out[:n.value]
+
+    def find_attributes(self, item_id):
+        """find_attributes(&u64) -> Option<&ProductAttributes> (vmis_index.rs:417-419): the SRN_ATTR_* bits, or None."""
+        fl = C.c_uint8()
+        capi.check(capi.lib().srn_index_find_attributes(self._h, int(item_id), C.byref(fl)))
+        return None if fl.value == capi.ATTR_NONE else int(fl.value)
+
+    def find_neighbors(self, evolving_session, k, m):
+        """find_neighbors(&[u64], k, m) (vmis_index.rs:325-415) -> (reference session indices u32[K], similarities f64[K]), best first."""
+        ev = capi.as_u64(evolving_session)
+        ses, sc, n = np.zeros(max(int(k), 1), np.uint32), np.zeros(max(int(k), 1)), C.c_size_t()
+        capi.check(capi.lib().srn_find_neighbors(self._h, capi.ptr(ev), len(ev), int(k), int(m), capi.ptr(ses), capi.ptr(sc), C.byref(n)))
+        return ses[:n.value], sc[:n.value]
+
     def kernel_timing(self, enable=True):
         """srn_kernel_timing: per-kernel HIP events on every batch call (what last_kernel_ms / kernel_times* read); off by default -- each event idles the stream ~6 us."""
         capi.check(capi.lib().srn_kernel_timing(self._h, 1 if enable else 0))
@@ -152,9 +182,11 @@ CSR.__doc__ = "Explicit CSR batch: CSR(items_flat u64[nnz], q_off int[nq + 1]). 
 
 
 def _is_csr_pair(sessions):
-    """A bare tuple (items_flat, q_off) is read as CSR only if it cannot be two evolving sessions of the same kind: two 1-D numpy arrays, items_flat of dtype
-    uint64 and q_off of an integer dtype OTHER than uint64 (uint32 as the C ABI takes it, or what np.cumsum hands back), starting at 0, non-decreasing and ending
-    at len(items_flat).  Two arrays of one dtype are two sessions.  `CSR(items_flat, q_off)` says it explicitly."""
+    """A bare tuple (items_flat, q_off) is read as CSR only if it cannot be two evolving sessions of the same kind: two 1-D integer numpy arrays whose second one starts
+    at 0, is non-decreasing and ends at len(first), AND whose dtypes tell them apart -- q_off is uint32 (what the C ABI takes: nobody keeps item ids in it), or
+    items_flat is uint64 and q_off any other integer dtype (what np.cumsum hands back).  Two arrays of ONE dtype that also read as (items, offsets) are refused
+    (ValueError): since round 4 such a pair -- e.g. int64 items with int64 np.cumsum offsets, accepted as CSR before -- must be passed as
+    `CSR(items_flat, q_off)` (README, "Python mirror"); a wrong guess would answer a different question silently."""
     if isinstance(sessions, CSR):
         flat, off = np.asarray(sessions.items_flat), np.asarray(sessions.q_off)
         if flat.ndim != 1 or off.ndim != 1 or len(off) < 1 or int(off[0]) != 0 or int(off[-1]) != len(flat) or (len(off) > 1 and not bool((off[1:] >= off[:-1]).all())):
@@ -163,16 +195,16 @@ def _is_csr_pair(sessions):
     if not (isinstance(sessions, tuple) and len(sessions) == 2 and all(isinstance(a, np.ndarray) and a.ndim == 1 for a in sessions)):
         return False
     flat, off = sessions
-    if not np.issubdtype(off.dtype, np.integer) or len(off) < 1:
+    if not np.issubdtype(off.dtype, np.integer) or not np.issubdtype(flat.dtype, np.integer) or len(off) < 1:
         return False
     looks = int(off[0]) == 0 and int(off[-1]) == len(flat) and (len(off) < 2 or bool((off[1:] >= off[:-1]).all()))
-    if looks and (flat.dtype != np.uint64 or off.dtype == np.uint64):
-        # two arrays of one kind whose second one also reads as offsets of the first: refuse to guess (a wrong guess answers a different question silently)
-        raise ValueError("ambiguous batch: a tuple of two arrays of the same kind that could be (items_flat, q_off) or two evolving sessions -- "
-                         "pass serenade_amd.CSR(items_flat, q_off), or the two sessions as lists")
-    if flat.dtype != np.uint64 or off.dtype == np.uint64:
+    if not looks:
         return False
-    return int(off[0]) == 0 and int(off[-1]) == len(flat) and (len(off) < 2 or bool((off[1:] >= off[:-1]).all()))
+    if (off.dtype == np.uint32 and flat.dtype != np.uint32) or (flat.dtype == np.uint64 and off.dtype != np.uint64):
+        return True
+    # two arrays of one kind whose second one also reads as offsets of the first: refuse to guess
+    raise ValueError("ambiguous batch: a tuple of two %s / %s arrays that could be (items_flat, q_off) or two evolving sessions -- "
+                     "pass serenade_amd.CSR(items_flat, q_off), or q_off as uint32, or the two sessions as lists" % (flat.dtype, off.dtype))
 
 
 def _flatten(sessions):

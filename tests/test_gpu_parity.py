@@ -764,3 +764,26 @@ def test_host_pointer_batches_through_the_chunked_pipeline(chunks, monkeypatch):
                 assert out[0] is got[0] and np.array_equal(out[0][mask], ref["ids"][:nq][mask])
     finally:
         monkeypatch.undo(); capi.reload_knobs()
+
+
+def test_trait_accessors_find_neighbors_at_the_abi():
+    """srn_find_neighbors -- the non-debug find_neighbors of SimilarityComputationNew (src/vmisknn/similarity_indexed.rs:9-23, vmis_index.rs:325-415) -- against the
+    oracle's canonical neighbours: the same (session, numerator / U) pairs, best first (similarity desc, ties: the more recent session -- (timestamp, index) -- first);
+    sessions of 1..12 items with repeats and unknown items, both cuts biting, tied timestamps."""
+    import serenade_amd as sa
+    O = _oracle()
+    off, items, ts, ids = small_dataset(7, n_sessions=3000, n_items=120, max_len=12, tied_timestamps=True)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, 300, 12, 1.0)
+    oix = O.OracleIndex(off, items, ts, 300, 12, 1.0)
+    qs = random_queries(77, ids, 60, max_len=12, unknown_rate=0.05, dup_rate=0.15)
+    for (k, m) in [(50, 300), (500, 120), (1500, 300)]:
+        for q in qs:
+            ses, sc = gix.find_neighbors(q, k, m)
+            sid, num, U = oix.neighbors_canonical(q, k, m)
+            assert len(ses) == len(sid) <= k
+            assert sorted(zip(ses.tolist(), sc.tolist())) == sorted(zip(sid.tolist(), (num / float(max(U, 1))).tolist())), q
+            key = [(-float(s), -int(ts[i]), -int(i)) for i, s in zip(ses.tolist(), sc.tolist())]
+            assert key == sorted(key), "not best-first / most-recent-first at ties"
+    with pytest.raises(sa.SerenadeError):
+        gix.find_neighbors([], 10, 10)
+    assert len(gix.find_neighbors([2 ** 60 + 1], 10, 10)[0]) == 0          # an unknown item alone: no neighbours (vmis_index.rs:350)

@@ -198,6 +198,8 @@ def _rccl_worker(q):
         ix = sharded.ShardedVMISIndex.from_full(full, 0, 1)
         os.environ["SRN_GROUP_NO_DIRECT"] = "1"          # a group of one shard reads its lists in place; this keeps the copy + grouped send / recv steps of a multi-rank run
         grp = sharded.ShardGroup.rccl(ix, 0, 1)          # ncclGetUniqueId + 2 x ncclCommInitRank inside the library
+        assert grp.stats["overlapped"] == 0              # (opt-in since round 5)
+        grp.set_overlap(True)
         res = []
         for rep in range(3):                             # three batches: both buffer slots, the overlapped exchange stream, resident inputs
             res.append(_np(grp.predict_batch(d_flat, d_off, len(qs), 6, 80, 300, 21, resident=(rep > 0))))
@@ -262,6 +264,7 @@ def _cb_worker(rank, world, port, q):
         lflat, lqoff = flatten(long_qs)
         d_lflat, d_loff = _to_dev(lflat, lqoff)
         res.append(_np(grp.predict_batch(d_lflat, d_loff, len(long_qs), 18, 80, 300, 21)))
+        grp.set_overlap(True)                                                        # (opt-in since round 5: the exchange on the group's own stream)
         res.append(_np(grp.predict_batch(d_flat, d_off, len(qs), 7, 80, 300, 21)))   # and lists again
         st = grp.stats
         q.put((rank, res, st))
@@ -409,6 +412,7 @@ def _cb_nb_worker(rank, world, port, q):
         del full
         grp = sharded.ShardGroup.over(ix, rank, world, sharded.DistComm())
         grp.set_postings(post)
+        grp.set_overlap(True)
         res = [_np(grp.predict_batch(d_flat, d_off, len(qs), 7, k, m, n, resident=res_flag)) for (k, m, n, res_flag) in [(80, 300, 21, False), (400, 200, 24, True), (80, 300, 21, True)]]
         grp.set_overlap(False)
         res.append(_np(grp.predict_batch(d_flat, d_off, len(qs), 7, 80, 300, 21)))
@@ -449,3 +453,100 @@ def test_neighbours_pipeline_over_application_callbacks(world):
         assert st["transport"] == 2 and st["n_shards"] == world and st["neighbour_batches"] == 4 and st["bytes_neighbours"] > 0
         for r, ref, n in zip(res, refs, (21, 24, 21, 21)):
             _check_oracle(r, ref, n)
+
+
+# ---- a rank that dies in the middle of a run: the others get an error, not a hang --------------------------------------------------------------
+
+def _cb_kill_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    try:
+        import datetime, time
+        import torch
+        import torch.distributed as dist
+        import serenade_amd as sa
+        from serenade_amd import capi, sharded
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=40))
+        off, items, ts, ids = small_dataset(84, n_sessions=5000, n_items=400, max_len=40)
+        qs = random_queries(31, ids, 300, max_len=7, unknown_rate=0.02)
+        flat, qoff = flatten(qs)
+        d_flat, d_off = _to_dev(flat, qoff)
+        full = sa.VMISIndex.from_sessions(off, items, ts, 300, 40, 1.0)
+        ix = sharded.ShardedVMISIndex.from_full(full, rank, world)
+        grp = sharded.ShardGroup.over(ix, rank, world, sharded.DistComm())
+        grp.set_postings(sharded.postings_view(full))
+        first = _np(grp.predict_batch(d_flat, d_off, len(qs), 7, 80, 300, 21))      # a good batch on every rank
+        grp.wait(60000)                                                             # (its bounded wait: done long ago)
+        dist.barrier()
+        if rank == world - 1:
+            q.put((rank, "left", None, None, first))
+            os._exit(0)                                                             # gone before the second batch: no goodbye to anybody
+        t0 = time.time()
+        try:
+            grp.predict_batch(d_flat, d_off, len(qs), 7, 80, 300, 21)
+            outcome = ("no error", 0, time.time() - t0)
+        except sa.SerenadeError as e:
+            outcome = ("error", e.code, time.time() - t0)
+        codes = []
+        for call in (lambda: grp.predict_batch(d_flat, d_off, len(qs), 7, 80, 300, 21), lambda: grp.wait(1000)):   # the group is unusable from then on, and says so at once
+            t1 = time.time()
+            try:
+                call(); codes.append((0, time.time() - t1))
+            except sa.SerenadeError as e:
+                codes.append((e.code, time.time() - t1))
+        q.put((rank, outcome, codes, capi.SRN_ESTATE, first))
+        grp.close()                                                                 # (a broken group is freed without waiting for the device)
+        os._exit(0)                                                                 # (the process group lost a member: no orderly shutdown to wait for)
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "error: %r\n%s" % (e, traceback.format_exc()), None, None, None))
+
+
+def test_a_rank_that_dies_mid_run_fails_the_others_within_a_timeout():
+    """Three processes over the callback transport; the last one exits between two batches.  The survivors' next srn_shard_group_predict_batch must come back with an
+    error (their transport's collective fails: the callback returns non-zero) well inside the transport's timeout -- not hang in a collective --, the group is then
+    BROKEN on each of them: every further call, srn_shard_group_wait included, fails at once with SRN_ESTATE."""
+    mp = pytest.importorskip("torch.multiprocessing")
+    world = 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cb_kill_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+    firsts = []
+    for rank, outcome, codes, estate, first in out:
+        assert not (isinstance(outcome, str) and outcome.startswith("error:")), outcome
+        firsts.append(first)
+        if rank == world - 1:
+            assert outcome == "left"
+            continue
+        what, code, secs = outcome
+        assert what == "error" and code < 0, "rank %d: the batch without its peer came back with %r" % (rank, outcome)
+        assert secs < 60.0, "rank %d needed %.1f s to notice" % (rank, secs)
+        assert all(c == estate and t < 1.0 for c, t in codes), codes
+    for f in firsts[1:]:
+        assert all(np.array_equal(a, b) for a, b in zip(f, firsts[0]))             # (the good batch: identical on every rank)
+
+
+def test_group_wait_and_the_default_overlap():
+    """srn_shard_group_wait on a healthy in-process group returns 0 once the batch is done; the exchange overlap is opt-in."""
+    import serenade_amd as sa
+    from serenade_amd import sharded
+    off, items, ts, ids = small_dataset(85, n_sessions=3000, n_items=300, max_len=30)
+    qs = random_queries(33, ids, 200, max_len=6)
+    flat, qoff = flatten(qs)
+    d_flat, d_off = _to_dev(flat, qoff)
+    full = sa.VMISIndex.from_sessions(off, items, ts, 300, 30, 1.0)
+    shards = [sharded.ShardedVMISIndex.from_full(full, g, 2) for g in range(2)]
+    grp = sharded.ShardGroup.local(shards)
+    grp.wait(10)                                            # nothing issued yet
+    got = grp.predict_batch(d_flat, d_off, len(qs), 6, 80, 300, 21)
+    grp.wait(60000)
+    u = sa.predict_batch(full, (flat, qoff), 80, 300, 21, False)
+    assert np.array_equal(got[0].cpu().numpy().view(np.uint64), u[0])          # (no torch synchronise in between: wait() was the synchronisation)
+    assert grp.stats["overlapped"] == 0

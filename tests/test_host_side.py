@@ -192,6 +192,17 @@ def test_predict_batch_takes_a_tuple_of_two_sessions_as_two_queries():
     # a pair that is not offsets (does not start at 0 / end at len / decreases) stays two sessions
     flat, off = vmisknn._flatten((np.array([11, 12, 13], np.uint64), np.array([0, 2, 1, 3], np.int64)))
     assert off.tolist() == [0, 3, 7]
+    # int64 items with int64 np.cumsum offsets (accepted as CSR until round 3) read both ways: refused with a message that names the two ways out --
+    # uint32 offsets (the ABI's type: never item ids) or CSR(...) --, and both ways out work
+    it64 = np.array([11, 12, 13, 14, 15], np.int64)
+    with pytest.raises(ValueError) as e:
+        vmisknn._flatten((it64, np.array([0, 3, 5], np.int64)))
+    assert "CSR(" in str(e.value) and "uint32" in str(e.value)
+    for ok in ((it64, np.array([0, 3, 5], np.uint32)), vmisknn.CSR(it64, np.array([0, 3, 5], np.int64))):
+        flat, off = vmisknn._flatten(ok)
+        assert flat.tolist() == [11, 12, 13, 14, 15] and flat.dtype == np.uint64 and off.tolist() == [0, 3, 5]
+    flat, off = vmisknn._flatten((it64, np.array([14, 15], np.int64)))            # (two int64 sessions that do not read as offsets: two queries)
+    assert off.tolist() == [0, 5, 7]
 
 
 def test_error_codes_without_a_device():
@@ -287,3 +298,35 @@ def test_evaluate_file_reproduces_readme_metrics(tmp_path):
     tol = [0.005, 0.005, 0.0001, 0.002, 0.0005, 0.005, 0.003, 0.001]
     for got, want, t in zip(vals[1:], readme, tol):
         assert abs(got - want) <= t + 1e-9, (vals, readme)
+
+
+def test_trait_accessors_items_for_session_and_find_attributes():
+    """srn_index_items_for_session / srn_index_find_attributes / idf through srn_index_postings: the accessors of SimilarityComputationNew
+    (src/vmisknn/similarity_indexed.rs:9-23, vmis_index.rs:317-323, 417-419) on a host-only index, against the training sessions themselves."""
+    off, items, ts, ids = small_dataset(9, n_sessions=400, n_items=60, max_len=20)
+    max_len = 9                                                             # some sessions are longer: not kept (vmis_index.rs:452)
+    ix = sa.VMISIndex.from_sessions(off, items, ts, 50, max_len, 1.0, device=-1)
+    lens = np.diff(off.astype(np.int64))
+    assert (lens > max_len).any() and (lens <= max_len).any()
+    for s in range(len(ts)):
+        row = items[int(off[s]):int(off[s + 1])]
+        if lens[s] <= max_len:
+            assert np.array_equal(ix.items_for_session(s), row)
+        else:
+            with pytest.raises(sa.SerenadeError) as e:
+                ix.items_for_session(s)
+            assert e.value.code == capi.SRN_ERANGE
+    with pytest.raises(sa.SerenadeError) as e:
+        ix.items_for_session(len(ts))
+    assert e.value.code == capi.SRN_EINVAL
+    known = np.unique(items[np.repeat(lens <= max_len, lens)])
+    assert all(ix.find_attributes(int(i)) == capi.ATTR_FOR_SALE for i in known[:20])        # the CSV path's {for_sale, not adult} (vmis_index.rs:514-517)
+    assert ix.find_attributes(2 ** 61 + 5) is None
+    ix.set_attributes(known[:3], np.array([capi.ATTR_ADULT | capi.ATTR_FOR_SALE, 0, capi.ATTR_NONE], np.uint8))
+    assert [ix.find_attributes(int(i)) for i in known[:3]] == [3, 0, None]
+    total_pairs = int(lens[lens <= max_len].sum())
+    it = int(known[0])
+    n_with = sum(1 for s in range(len(ts)) if lens[s] <= max_len and it in items[int(off[s]):int(off[s + 1])])
+    assert ix.idf(it) == pytest.approx(np.log(total_pairs / n_with), rel=1e-15)             # vmis_index.rs:509-512
+    with pytest.raises(KeyError):
+        ix.idf(2 ** 61 + 5)
