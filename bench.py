@@ -418,7 +418,7 @@ def main():
         if not os.path.exists(exe):
             return None, None
         sys.path.insert(0, os.path.join(ROOT, "tools"))
-        import r02_summarize as RS
+        import rocprof_summarize as RS
         vals = {}
         with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
             for ctr in ("FETCH_SIZE", "WRITE_SIZE"):

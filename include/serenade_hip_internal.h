@@ -29,6 +29,9 @@ int srn_debug_last_mid_count(const srn_index_t* idx, uint32_t* out_listed);
 /* ... and how many of those MID listed for its BIG form (80 KB of LDS: merged lists beyond the 53 KB layout's buffers). */
 int srn_debug_last_big_count(const srn_index_t* idx, uint32_t* out_listed);
 
+/* Test aid: batches of this item shard that went through the wave-per-query back end of srn_sback.hip (the shard group's neighbours pipeline), since the shard was attached. */
+int srn_debug_sback_launches(const srn_index_t* idx, uint64_t* out_launches);
+
 /* Test / experiment knobs (environment variables SRN_NO_FAST, SRN_NO_MID, SRN_NO_MASKS, SRN_NO_MERGE, SRN_DENSE, SRN_HOT_SLOTS,
  * SRN_SKETCH_SLOTS, SRN_LDS_BUDGET_KB, SRN_GRID_MULT, SRN_DEBUG) force individual kernel code paths.  They are read ONCE,
  * when the library is first used -- never on the launch path; this call re-reads them (the parity tests switch paths

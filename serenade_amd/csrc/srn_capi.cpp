@@ -432,6 +432,11 @@ int srn_debug_last_big_count(const srn_index_t* idx, uint32_t* out_listed) {
     return guarded([&]() -> int { return device_last_mid_count(idx->dev, nullptr, out_listed); });
 }
 
+int srn_debug_sback_launches(const srn_index_t* idx, uint64_t* out_launches) {
+    if (!idx || !idx->dev || !out_launches) return fail(SRN_EINVAL, "null argument / no device");
+    *out_launches = device_sback_launches(idx->dev); return SRN_OK;
+}
+
 void srn_debug_reload_knobs(void) { reload_knobs(); }
 
 }  // extern "C"

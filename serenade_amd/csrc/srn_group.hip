@@ -105,6 +105,7 @@ struct Slot {   // everything one batch in flight needs (grow-only); two slots: 
     char* nb = nullptr; size_t nb_bytes = 0; char* nb_cnt = nullptr; size_t nb_cnt_bytes = 0; char* minpos = nullptr; size_t minpos_bytes = 0; char* flagq = nullptr; size_t flagq_bytes = 0;
     // neighbours pipeline: [G * per][k + 1] words (a query's row: K | K packed slots), and every local shard's prep records of the whole batch
     char* xchg = nullptr; size_t xchg_bytes = 0; std::vector<char*> nrec; std::vector<size_t> nrec_bytes;
+    std::vector<char*> nord; std::vector<size_t> nord_bytes; std::vector<const unsigned long long*> nord_ptr;   // ... and the batch's serving order (keys, sorted keys, scratch)
     hipEvent_t e_done = nullptr;
 };
 }  // namespace
@@ -180,6 +181,7 @@ int all_gather_v(srn_shard_group* g, int channel, char* buf, const unsigned long
 void slot_free(Slot& s) {
     for (char* p : s.pos) if (p) hipFree(p);
     for (char* p : s.nrec) if (p) hipFree(p);
+    for (char* p : s.nord) if (p) hipFree(p);
     if (s.xchg) hipFree(s.xchg);
     for (char* p : {s.head, s.kept, s.tot, s.off, s.small, s.lists, s.records, s.part, s.cand, s.cand_cnt, s.nb, s.nb_cnt, s.minpos, s.flagq}) if (p) hipFree(p);
     if (s.tot_host) hipHostFree(s.tot_host);
@@ -199,6 +201,7 @@ int group_init_common(srn_shard_group* g) {
         HIP_TRY(hipHostMalloc((void**)&s.tot_host, (size_t)G * 16, hipHostMallocMapped));
         s.pos.assign(g->shards.size(), nullptr); s.pos_bytes.assign(g->shards.size(), 0);
         s.nrec.assign(g->shards.size(), nullptr); s.nrec_bytes.assign(g->shards.size(), 0);
+        s.nord.assign(g->shards.size(), nullptr); s.nord_bytes.assign(g->shards.size(), 0); s.nord_ptr.assign(g->shards.size(), nullptr);
     }
     if (const char* e = getenv("SRN_GROUP_OVERLAP")) g->overlap = atoi(e) != 0;
     g->no_direct = getenv("SRN_GROUP_NO_DIRECT") != nullptr;
@@ -314,7 +317,7 @@ int group_predict_neighbours(srn_shard_group* g, const LaunchParams& p_in, bool 
     for (size_t i = 0; i < g->shards.size(); ++i) {
         const uint32_t gi = local ? (uint32_t)i : (uint32_t)g->rank;
         if (g->timing && i == 0) HIP_TRY(hipEventRecord(g->e_t[0], sx));
-        int rc = device_shard_nb_prep(g->shards[i]->dev, post, p, s.nrec[i], sx); if (rc) return rc;
+        int rc = device_shard_nb_prep(g->shards[i]->dev, post, p, s.nrec[i], sx, &s.nord[i], &s.nord_bytes[i], &s.nord_ptr[i]); if (rc) return rc;
         const uint32_t q_lo = std::min<uint64_t>(nq, (uint64_t)gi * per), q_hi = std::min<uint64_t>(nq, (uint64_t)q_lo + per);
         rc = device_shard_nb_front(g->shards[i]->dev, g->shards[i]->flat, post, p, s.nrec[i], (uint32_t*)s.xchg, xstride, q_lo, q_hi, sx); if (rc) return rc;
         if (g->timing && i == 0) HIP_TRY(hipEventRecord(g->e_t[1], sx));
@@ -329,7 +332,7 @@ int group_predict_neighbours(srn_shard_group* g, const LaunchParams& p_in, bool 
         pi.out_ids = direct ? d_out_ids : (uint64_t*)blk; pi.out_scores = direct ? d_out_scores : (double*)(blk + (size_t)nq * n * 8); pi.out_counts = direct ? d_out_counts : (uint32_t*)(blk + (size_t)nq * n * 16);
         if (g->timing && i == 0) HIP_TRY(hipEventRecord(g->e_t[2], user));
         HIP_TRY(hipMemsetAsync(pi.out_ids, 0, (size_t)nq * n * 8, user)); HIP_TRY(hipMemsetAsync(pi.out_scores, 0, (size_t)nq * n * 8, user));
-        int rc = device_shard_nb_back(g->shards[i]->dev, g->shards[i]->flat, post, pi, s.nrec[i], (uint32_t*)s.xchg, xstride, user); if (rc) return rc;
+        int rc = device_shard_nb_back(g->shards[i]->dev, g->shards[i]->flat, post, pi, s.nrec[i], (uint32_t*)s.xchg, xstride, user, s.nord_ptr[i]); if (rc) return rc;
         if (g->timing && i == 0) HIP_TRY(hipEventRecord(g->e_t[3], user));
     }
     if (G > 1) {

@@ -93,7 +93,27 @@ struct FastParams {
     // neighbours pipeline of the shard group (launch_fast modes 1 and 2): [nq][xchg_stride] words, a query's row = K | K packed slots (K = 0xFFFFFFFF: not served by the
     // front end -- the general kernel takes it on every rank); the front end works on the queries [q_base, p.nq)
     uint32_t* xchg; uint32_t xchg_stride; uint32_t q_base;
+    // the order the batch is served in (round 5; null: query index order): the batch's queries sorted by their most popular item, low word of entry i = the i-th query.
+    // Workgroup b serves positions of the (b % 8)-th eighth of the order -- block b runs on XCD b % 8: what one XCD's L2 sees is a window of like queries
+    const unsigned long long* order;
 };
+// the batch's order keys (written by the prep kernel) -> sorted (srn_build_gpu.hip: rocPRIM radix sort on the key bits); temp == nullptr: only *temp_bytes is set
+hipError_t sort_order_keys(hipStream_t st, const unsigned long long* in, unsigned long long* out, size_t n, void* temp, size_t* temp_bytes);
+
+// ---- the item-sharded index's own back end (srn_sback.hip, round 5): one WAVE per query over a shard's row fragments -------------------------------------------------
+// Geometry of a wave's accumulators (words): SB_H direct-mapped (the shard's most popular items; the top SB_REP_ITEMS * SB_REP of them are the replicated words of the
+// SB_REP_ITEMS hottest), SB_S sketch words, SB_DUMP dump words -- baked into the frag8 slots' 16-bit LDS byte offsets at attach time.
+static constexpr uint32_t SB_H = 1024, SB_S = 1024, SB_DUMP = 64, SB_REP_ITEMS = 16, SB_REP = 8, SB_DIRECT = SB_H - SB_REP_ITEMS * SB_REP;
+struct SBackParams {
+    const uint2* frag8;        // [n_kept + 1] 8-byte fragment slots by recency rank: four 16-bit offsets, or {0xFFFF, len, overflow block index} for a fragment of > 4 items
+    const uint4* ext8;         // overflow blocks: 8 offsets per 16 bytes, ALL items of a long fragment
+    const uint32_t* present;   // one bit per session: the fragment is not empty (null: not consulted)
+    const ItemMeta* sample;    // meta[] of the shard's 256 most popular items, zero-padded
+    double inv_idf_chunk[SB_H / 256];   // 1 / max idf_eff over the dense idx [256 c, 256 c + 256)
+    double inv_idf_all;        // 1 / max idf_eff over all items of the shard
+};
+hipError_t launch_rows_to_frag8(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base, uint2* frag8, uint4* ext8, uint32_t* present);   // block_base in 16-byte blocks
+hipError_t launch_shard_back(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f, const SBackParams& sb, bool debug = false);
 
 // ---- launchers (srn_kernels.hip) -------------------------------------------------------------
 // the predict kernel: stage 0 = fused, 1..3 = the item-sharded pipeline's stages A..C; global_tables = the retry pass with its
@@ -103,7 +123,7 @@ hipError_t launch_predict(bool masks, bool slot64, bool global_tables, int stage
                           uint32_t* retry_cnt, char* gscratch, unsigned long long gscratch_stride, char* nb_spill, const ShardIO& sh, int wg_per_cu = 2);
 hipError_t launch_prep(hipStream_t st, const DeviceIndex& di, const uint64_t* items_flat, const uint32_t* q_off, uint32_t nq, uint32_t m,
                        uint32_t max_len, char* out, uint32_t stride, uint32_t* zero_a = nullptr, uint32_t* zero_b = nullptr,
-                       const IdSlot* loc_table = nullptr, uint32_t loc_mask = 0);   // zero_a[0..7], zero_b[0]: counters cleared by the prep kernel; loc_table: the item shard's id table (the record's idx), di = the whole index's dictionary and lists
+                       const IdSlot* loc_table = nullptr, uint32_t loc_mask = 0, unsigned long long* okeys = nullptr);   // zero_a[0..7], zero_b[0]: counters cleared by the prep kernel; loc_table: the item shard's id table (the record's idx), di = the whole index's dictionary and lists
 hipError_t launch_finish_big(hipStream_t st, const DeviceIndex& di, const FastParams& f, uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint32_t how_many, uint32_t grid, const uint32_t* cnt_retry = nullptr, const uint32_t* cnt_slow = nullptr, uint32_t* host_words = nullptr);
 hipError_t launch_finish(hipStream_t st, const DeviceIndex& di, const FastParams& f, uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint32_t nq, uint32_t how_many);   // scores, ranking, public ids of the rows the fast kernel served
 hipError_t launch_shard_lists_head(hipStream_t st, const DeviceIndex& di, const uint64_t* items_flat, const uint32_t* q_off, uint32_t nq, uint32_t m, uint32_t max_len,

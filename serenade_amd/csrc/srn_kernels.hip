@@ -363,7 +363,10 @@ __global__ __launch_bounds__(1024) void rows_to_frags_kernel(const uint64_t* __r
 static constexpr uint32_t PREP_LANES = 8;
 __global__ __launch_bounds__(256) void vmis_prep_kernel(DeviceIndex ix, const uint64_t* __restrict__ items_flat, const uint32_t* __restrict__ q_off,
                                                         uint32_t nq, uint32_t m, uint32_t max_len, char* out, uint32_t stride, uint32_t* zero_a, uint32_t* zero_b,
-                                                        const IdSlot* __restrict__ loc_table, uint32_t loc_mask) {
+                                                        const IdSlot* __restrict__ loc_table, uint32_t loc_mask, unsigned long long* __restrict__ okeys) {
+    // okeys (round 5, or null): one 64-bit sort key per query -- (dense idx of its MOST POPULAR known item, clamped to 16 bits) << 32 | q.  Queries that share their most
+    // popular item share most of their posting-list entries and neighbour rows; the launch sequence sorts the batch by this key and serves it in that order, an eighth of
+    // the order per XCD, so that the second of two such queries finds the first one's lines in its XCD's L2 (the dense idx is the popularity rank).
     // loc_table (the shard group's neighbours pipeline, srn_group.hip): `ix` is the REPLICATED dictionary + posting lists of the whole index, loc_table the id table of
     // the item shard whose rows the record's consumer walks -- the lists are looked up in the first, the dense idx written to the record (what the kernels compare
     // row items with: the current item) in the second.
@@ -378,6 +381,7 @@ __global__ __launch_bounds__(256) void vmis_prep_kernel(DeviceIndex ix, const ui
     uint32_t U = 0, rmax = 0, xlo = 0, sumw = 0, P = 0, nruns = 0, n_staged = 0, cur_attr = SRN_ATTR_NONE, my_run_start = 0;
     const bool ok = L != 0 && L <= max_len;
     const uint32_t rounds = ok ? (L + PREP_LANES - 1) / PREP_LANES : 0;
+    uint32_t hot_key = kNone;   // smallest dense idx (of the index the lists come from) among this lane's known items
     uint32_t idx = kNone, len = 0, pre = 0; unsigned long long base = 0;   // this lane's item of the LAST round (a session of <= 8 items has one round: its record is written once, with `kept`)
     for (uint32_t r = 0; r < rounds; ++r) {
         const uint32_t pos = r * PREP_LANES + sub;
@@ -390,6 +394,7 @@ __global__ __launch_bounds__(256) void vmis_prep_kernel(DeviceIndex ix, const ui
             for (uint32_t j = 0; j < pos; ++j) first = first && (items_flat[qb + (L - 1 - j)] != raw);   // Q2: most recent occurrence only
             { uint32_t hh = (uint32_t)dev_mix64(raw) & ix.id_mask;
               for (;;) { const IdSlot s = ix.id_table[hh]; if (s.idx == kNone) break; if (s.key == raw) { idx = s.idx; break; } hh = (hh + 1) & ix.id_mask; } }
+            hot_key = min(hot_key, idx);
             first_i = first ? 1u : 0u;   // Q1: distinct raw ids, known or not
             if (first && idx != kNone) {
                 const unsigned long long o0 = ix.post_off[idx], o1 = ix.post_off[idx + 1];
@@ -449,6 +454,9 @@ __global__ __launch_bounds__(256) void vmis_prep_kernel(DeviceIndex ix, const ui
         n_staged += ks;
     }
     cur_attr = __shfl(cur_attr, 0, PREP_LANES);
+    #pragma unroll
+    for (uint32_t d = 1; d < PREP_LANES; d <<= 1) hot_key = min(hot_key, (uint32_t)__shfl_xor((int)hot_key, d, PREP_LANES));
+    if (okeys && sub == 0) okeys[q] = ((unsigned long long)min(hot_key, 0xFFFFu) << 32) | q;   // (16 key bits: beyond the 65 535 most popular items there is nothing to group -- two radix passes instead of three)
     uint32_t* hw = (uint32_t*)rec;   // PrepHead, word by word: U rmax xlo sumw | P nruns L n_staged | run_start[8] | cur_attr pad_
     if (sub == 0) {   // (records are 8-byte aligned: 72 + 24 * max_len)
         *(uint2*)hw = make_uint2(U, rmax); *(uint2*)(hw + 2) = make_uint2(xlo, sumw); *(uint2*)(hw + 4) = make_uint2(P, nruns); *(uint2*)(hw + 6) = make_uint2(L, n_staged);
@@ -1623,10 +1631,10 @@ hipError_t launch_predict(bool masks, bool slot64, bool global_tables, int stage
 }
 
 hipError_t launch_prep(hipStream_t st, const DeviceIndex& di, const uint64_t* items_flat, const uint32_t* q_off, uint32_t nq, uint32_t m,
-                       uint32_t max_len, char* out, uint32_t stride, uint32_t* zero_a, uint32_t* zero_b, const IdSlot* loc_table, uint32_t loc_mask) {
+                       uint32_t max_len, char* out, uint32_t stride, uint32_t* zero_a, uint32_t* zero_b, const IdSlot* loc_table, uint32_t loc_mask, unsigned long long* okeys) {
     static_assert(sizeof(PrepHead) == 72 && sizeof(PrepItem) == 24, "vmis_prep_kernel writes the record word by word");
     const uint32_t per_block = 256 / PREP_LANES;
-    hipLaunchKernelGGL(vmis_prep_kernel, dim3((nq + per_block - 1) / per_block), dim3(256), 0, st, di, items_flat, q_off, nq, m, max_len, out, stride, zero_a, zero_b, loc_table, loc_mask);
+    hipLaunchKernelGGL(vmis_prep_kernel, dim3((nq + per_block - 1) / per_block), dim3(256), 0, st, di, items_flat, q_off, nq, m, max_len, out, stride, zero_a, zero_b, loc_table, loc_mask, okeys);
     return hipGetLastError();
 }
 

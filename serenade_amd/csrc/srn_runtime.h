@@ -37,6 +37,11 @@ struct Knobs {
                               // config 3, max_items 4: p50 53.3 -> 47.8 us, p90 63.7 -> 54.1; larger rounds stay on the general kernel -- one workgroup per query runs them all at once: nothing to gain,
                               // four more launches to pay: profiles/r04_serving_tiny_fast.txt); 3: wherever the batch's shape allows it (experiments)
     int row_slots16 = -1;     // SRN_ROW_SLOTS = 16 | 64: the device row layout (-1 = by index kind: 64-byte slots unsharded, 16-byte fragment slots for item shards)
+    int order_min = 131072;    // SRN_ORDER_MIN: batches of at least this many queries are served in the order of their most popular item, an eighth of the order per XCD (0 = never); the ordering
+                              // pass is one radix sort of the batch's keys behind the prep kernel
+    bool no_sback = false;    // SRN_NO_SBACK: the shard group's back end through vmis_fast_kernel's FM_BACK instantiation (rounds 4) instead of the wave-per-query kernel of srn_sback.hip
+    bool sback_nobitmap = false;   // SRN_SBACK_NOBITMAP (experiments): that kernel without its presence bitmap (every neighbour costs a fragment fetch)
+    int sback_min_shards = 4; // SRN_SBACK_MIN_SHARDS: shards of an index cut in at least this many get the frag8 rows (below: fragments of > 4 items are common, the geometry too small)
     int lanes = 4;            // SRN_PREDICT_LANES: concurrent rounds of the srn_predict combiner (srn_combine.cpp)
     bool geometry_default() const { return !no_masks && !no_merge && !dense && hot_slots < 0 && sketch_slots < 0 && lds_budget_kb == 0; }
 };
@@ -58,6 +63,7 @@ struct Workspace {
     char* gscratch = nullptr; size_t gscratch_bytes = 0;
     char* spill = nullptr; size_t spill_bytes = 0;   // per-block global copies of the neighbour lists
     char* prep = nullptr; size_t prep_bytes = 0;     // per-query records of the prep kernel
+    char* order = nullptr; size_t order_bytes = 0;   // the batch's order keys as the prep kernel wrote them | sorted | the sort's scratch
     uint32_t* retry_list2 = nullptr; size_t retry_cap2 = 0; uint32_t* retry_cnt2 = nullptr;   // what the second LDS tier could not hold either
     uint32_t* slow_list = nullptr; size_t slow_cap = 0; uint32_t* slow_cnt = nullptr;          // what the fast kernel hands to the general one
     char* fin = nullptr; size_t fin_bytes = 0;   // records for vmis_finish_kernel
@@ -80,6 +86,8 @@ struct DeviceState {
     DeviceIndex di{};
     ItemMeta* d_meta = nullptr;
     FastParams fast{};            // packed row slots + idf bounds of the fast kernel (row_packed == nullptr: no fast path for this index)
+    std::atomic<uint64_t> sback_launches{0};
+    SBackParams sback{};          // item shards: frag8 rows + presence bitmap of the wave-per-query back end (frag8 == nullptr: the FM_BACK form of the fast kernel serves)
     uint32_t host_max_row_len = 0;
     int n_cu = 256;
     int lds_per_block_max = 65536;

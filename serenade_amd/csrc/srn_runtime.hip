@@ -34,6 +34,9 @@ static void knobs_read() {
     if (const char* e = getenv("SRN_TINY_MAX")) k.tiny_max = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_TINY_FAST")) k.tiny_fast = std::min(3, std::max(0, atoi(e)));
     if (const char* e = getenv("SRN_PREDICT_LANES")) k.lanes = std::max(0, atoi(e));
+    if (const char* e = getenv("SRN_ORDER_MIN")) k.order_min = std::max(0, atoi(e));
+    k.no_sback = getenv("SRN_NO_SBACK") != nullptr; k.sback_nobitmap = getenv("SRN_SBACK_NOBITMAP") != nullptr;
+    if (const char* e = getenv("SRN_SBACK_MIN_SHARDS")) k.sback_min_shards = std::max(2, atoi(e));
     if (const char* e = getenv("SRN_FAST_RUNS")) k.fast_runs = atoi(e) == 3 ? 3 : 0;   // tests: the fast kernel's 29-bit-rank form (3 lists per query) on a small index
     std::lock_guard<std::mutex> lk(g_knobs_mu); g_knobs = k;
 }
@@ -119,6 +122,27 @@ DeviceState* device_attach(const FlatIndex& ix, int device) {
                 if (knobs().debug) fprintf(stderr, "[srn] no room for the fast kernel's packed rows (%zu bytes): general kernel only\n", (size_t)((n + 1) * slot_bytes + (blocks + 2) * 16));
             }
         }
+        if (good && frag && ix.n_shards >= (uint32_t)knobs().sback_min_shards) {   // the wave-per-query back end's rows (srn_sback.hip): 8-byte slots + overflow blocks + presence bitmap; optional like the packed rows
+            std::vector<uint32_t> bb(nblocks); uint64_t blocks = 1;
+            for (size_t b0 = 0; b0 < nblocks; ++b0) {
+                bb[b0] = (uint32_t)blocks;
+                const size_t hi = std::min(n, (b0 + 1) * 1024);
+                for (size_t r = b0 * 1024; r < hi; ++r) { const uint64_t len = ix.row_off[r + 1] - ix.row_off[r]; if (len > 4) blocks += (len + 7) / 8; }
+            }
+            const size_t pwords = (n + 1 + 31) / 32 + 32;
+            void *d_f8 = nullptr, *d_e8 = nullptr, *d_pr = nullptr, *d_sm = nullptr;
+            std::vector<ItemMeta> sm(256, ItemMeta{0.0, 0u, 0u});
+            for (size_t i = 0; i < std::min<size_t>(256, ix.n_items); ++i) sm[i] = ItemMeta{ix.idf[i], ix.id_rank[i], ix.attr[i]};
+            const bool g3 = blocks < 0xFFFFFFF0ull && hipMalloc(&d_f8, (n + 1) * 8) == hipSuccess && hipMalloc(&d_e8, (blocks + 2) * 16) == hipSuccess && hipMalloc(&d_pr, pwords * 4) == hipSuccess &&
+                            hipMalloc(&d_sm, 256 * sizeof(ItemMeta)) == hipSuccess && hipMemcpy(d_sm, sm.data(), 256 * sizeof(ItemMeta), hipMemcpyHostToDevice) == hipSuccess &&
+                            hipMemcpy(d_base, bb.data(), nblocks * 4, hipMemcpyHostToDevice) == hipSuccess && hipMemset(d_e8, 0, (blocks + 2) * 16) == hipSuccess && hipMemset(d_pr, 0, pwords * 4) == hipSuccess &&
+                            launch_rows_to_frag8(nullptr, (const uint64_t*)d_off, (const uint32_t*)d_items, (uint64_t)n, (const uint32_t*)d_base, (uint2*)d_f8, (uint4*)d_e8, (uint32_t*)d_pr) == hipSuccess &&
+                            hipDeviceSynchronize() == hipSuccess;
+            if (g3) { for (void* q : {d_f8, d_e8, d_pr, d_sm}) d->allocs.push_back(q);
+                      d->bytes += (n + 1) * 8 + (blocks + 2) * 16 + pwords * 4 + 256 * sizeof(ItemMeta);
+                      d->sback.frag8 = (const uint2*)d_f8; d->sback.ext8 = (const uint4*)d_e8; d->sback.present = (const uint32_t*)d_pr; d->sback.sample = (const ItemMeta*)d_sm; }
+            else { (void)hipGetLastError(); for (void* q : {d_f8, d_e8, d_pr, d_sm}) if (q) hipFree(q); d->sback = SBackParams{}; }
+        }
         if (d_off) hipFree(d_off); if (d_items) hipFree(d_items); if (d_base) hipFree(d_base);
         if (d_slots) { d->allocs.push_back(d_slots); d->bytes += (n + 1) * slot_bytes; }
         d->di.row_frag = frag ? 1u : 0u;
@@ -146,6 +170,12 @@ void device_refresh_fast_bounds(DeviceState* d, const FlatIndex& ix) {
         d->fast.inv_idf_hot[c] = hi > 0.0 ? 1.0 / hi : 1.0;
     }
     d->fast.inv_idf_hi = 1.0 / hi_all;
+    for (uint32_t c = 0; c < SB_H / 256; ++c) {   // the wave-per-query back end's floors: chunks of 256
+        double hi = 0.0;
+        for (uint64_t i = (uint64_t)c * 256; i < std::min<uint64_t>(ix.n_items, (uint64_t)c * 256 + 256); ++i) hi = std::max(hi, ix.idf[i] > 0.0 ? ix.idf[i] : 1.0);
+        d->sback.inv_idf_chunk[c] = hi > 0.0 ? 1.0 / hi : 1.0;
+    }
+    d->sback.inv_idf_all = 1.0 / hi_all;
 }
 
 static void ws_free(Workspace* w) {
@@ -155,6 +185,7 @@ static void ws_free(Workspace* w) {
     if (w->gscratch) hipFree(w->gscratch);
     if (w->spill) hipFree(w->spill);
     if (w->prep) hipFree(w->prep);
+    if (w->order) hipFree(w->order);
     if (w->retry_list2) hipFree(w->retry_list2);
     if (w->retry_cnt2) hipFree(w->retry_cnt2);
     if (w->slow_list) hipFree(w->slow_list);
@@ -193,10 +224,16 @@ int device_update_attr(DeviceState* d, const FlatIndex& ix) {
         for (uint32_t w8 = 0; w8 < 8; ++w8) for (uint32_t l = 0; l < 64; ++l) if (8 * l + w8 < ix.n_items) ms[64 * w8 + l] = meta[8 * l + w8];
         HIP_TRY(hipMemcpy((void*)d->fast.meta_sample, ms.data(), ms.size() * sizeof(ItemMeta), hipMemcpyHostToDevice));
     }
+    if (d->sback.sample) {
+        std::vector<ItemMeta> sm(256, ItemMeta{0.0, 0u, 0u});
+        for (size_t i = 0; i < std::min<size_t>(256, ix.n_items); ++i) sm[i] = meta[i];
+        HIP_TRY(hipMemcpy((void*)d->sback.sample, sm.data(), sm.size() * sizeof(ItemMeta), hipMemcpyHostToDevice));
+    }
     return SRN_OK;
 }
 uint64_t device_bytes(const DeviceState* d) { return d ? d->bytes : 0; }
 bool device_has_packed_rows(const DeviceState* d) { return d && d->fast.row_packed != nullptr; }
+uint64_t device_sback_launches(const DeviceState* d) { return d ? d->sback_launches.load() : 0; }
 int device_count() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
 
 // Host-pointer calls borrow a workspace for the duration of the (synchronous) call.  Device-pointer
@@ -345,6 +382,17 @@ static FastPlan fast_plan(const DeviceState* d, const FlatIndex& ix, const Launc
     return f;
 }
 
+// The serving order of a batch (FastParams::order): room for the keys the prep kernel writes, their sorted copy and the sort's scratch in ONE grow-only buffer; then the sort
+// itself, enqueued on the stream the prep kernel ran on.
+static int order_room(char** buf, size_t* have, uint32_t nq, unsigned long long** keys_in, unsigned long long** keys_out, void** temp, size_t* temp_bytes) {
+    size_t tb = 0;
+    if (sort_order_keys(nullptr, nullptr, nullptr, nq, nullptr, &tb) != hipSuccess) return fail(SRN_EHIP, "rocprim::radix_sort_keys (size query) failed");
+    const size_t kb = ((size_t)nq * 8 + 255) / 256 * 256;
+    int rc = ensure(buf, have, 2 * kb + tb + 256); if (rc) return rc;
+    *keys_in = (unsigned long long*)*buf; *keys_out = (unsigned long long*)(*buf + kb); *temp = *buf + 2 * kb; *temp_bytes = tb;
+    return SRN_OK;
+}
+
 // Latency path: a handful of evolving sessions on host pointers (srn_predict: the reference's call shape, one session per call).
 // No copies, no memsets, no events: the queries are written into pinned, device-mapped memory that the kernels read directly, the
 // results come back the same way; two launches (prep kernel + general kernel, one workgroup per query) and one stream synchronise.
@@ -391,7 +439,7 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
     if (tiny_fast) {
         FastParams fp = d->fast; fp.slow_list = w->slow_list; fp.slow_cnt = w->slow_cnt; fp.nb = plan.nb_fast; fp.max_runs = plan.nb_fast; fp.fin = w->fin;
         fp.big_arena = w->big; fp.big_list = (uint32_t*)(w->big + big_entries * 16); fp.big_ticket = (unsigned long long*)(w->slow_cnt + 2); fp.big_cap_entries = (uint32_t)big_entries;
-        fp.xchg = nullptr; fp.xchg_stride = 0; fp.q_base = 0;
+        fp.xchg = nullptr; fp.xchg_stride = 0; fp.q_base = 0; fp.order = nullptr;
         fp.mid_list = plan.mid_tier ? w->slow_list + (w->slow_cap + 16) : nullptr; fp.mid_cnt = plan.mid_tier ? w->slow_cnt + 1 : nullptr;
         fp.bigq_list = nullptr; fp.bigq_cnt = nullptr;   // (no BIG tier on the latency path: one more launch for 3-4 % of the long sessions)
         HIP_TRY(launch_fast(dim3(p.nq), st, d->di, p, fp, kn.debug, 0));
@@ -544,6 +592,10 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         const uint64_t big_entries = std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)p.nq * 16 + 4096);
         { int rc = ensure(&w->big, &w->big_bytes, big_entries * 16 + (size_t)p.nq * 4 + 64); if (rc) return rc; }
     }
+    // the serving order: the batch sorted by each query's most popular item (keys from the prep kernel, one radix sort behind it)
+    const bool ordered = fast && !ext && kn.order_min > 0 && p.nq >= (uint32_t)kn.order_min;
+    unsigned long long *okeys_in = nullptr, *okeys_out = nullptr; void* otemp = nullptr; size_t otemp_bytes = 0;
+    if (ordered) { int rc = order_room(&w->order, &w->order_bytes, p.nq, &okeys_in, &okeys_out, &otemp, &otemp_bytes); if (rc) return rc; }
     if (reserve_only) return SRN_OK;   // (srn_index_reserve: the workspace is sized, nothing was enqueued)
     if (ext && ext->mode == 1) {
         // The shard group's neighbours pipeline, FRONT: find_neighbors alone for the queries [q_lo, nq) of the batch this rank fronts -- the fast kernel's front end against
@@ -553,7 +605,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         if (ext->q_lo >= p.nq) return SRN_OK;
         p.prep = ext->prep; p.prep_stride = prep_stride;
         FastParams fp = d->fast; fp.nb = nb_fast; fp.max_runs = nb_fast; fp.slow_list = nullptr; fp.slow_cnt = nullptr; fp.fin = nullptr; fp.mid_list = nullptr; fp.mid_cnt = nullptr; fp.bigq_list = nullptr; fp.bigq_cnt = nullptr;
-        fp.xchg = ext->xchg; fp.xchg_stride = ext->xchg_stride; fp.q_base = ext->q_lo;
+        fp.xchg = ext->xchg; fp.xchg_stride = ext->xchg_stride; fp.q_base = ext->q_lo; fp.order = nullptr;
         const uint64_t cnt = p.nq - ext->q_lo, res_wg = (uint64_t)d->n_cu * F_WG_PER_CU;
         const uint32_t grid_front = (uint32_t)std::min<uint64_t>(cnt, std::min<uint64_t>(res_wg * 64, std::max<uint64_t>(res_wg * 16, cnt / 12)));
         HIP_TRY(launch_fast(dim3(grid_front), st, di, p, fp, kn.debug, 1));
@@ -577,12 +629,14 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         // (ev_done[set] = the end of the LAST call that read record set `set`, resident or not: a non-resident device-pointer call on this stream reads w->prep too)
         if (!w->rec_used[par] && w->calls > 0) { HIP_TRY(hipEventRecord(w->ev_done[par], st)); w->rec_used[par] = true; }   // (earlier calls of this workspace that left no event: everything enqueued so far)
         if (w->rec_used[par]) HIP_TRY(hipStreamWaitEvent(w->side, w->ev_done[par], 0));
-        HIP_TRY(launch_prep(w->side, di, p.items_flat, p.q_off, p.nq, p.m, p.max_len, rec, prep_stride));
+        HIP_TRY(launch_prep(w->side, di, p.items_flat, p.q_off, p.nq, p.m, p.max_len, rec, prep_stride, nullptr, nullptr, nullptr, 0, okeys_in));
+        if (ordered) HIP_TRY(sort_order_keys(w->side, okeys_in, okeys_out, p.nq, otemp, &otemp_bytes));
         HIP_TRY(hipEventRecord(w->ev_prep[par], w->side));
         HIP_TRY(hipStreamWaitEvent(st, w->ev_prep[par], 0));
         p.prep = rec; p.prep_stride = prep_stride;
     }
-    else { HIP_TRY(launch_prep(st, di, p.items_flat, p.q_off, p.nq, p.m, p.max_len, w->prep, prep_stride, fast ? w->slow_cnt : nullptr, (may_overflow || dense) ? w->retry_cnt : nullptr));
+    else { HIP_TRY(launch_prep(st, di, p.items_flat, p.q_off, p.nq, p.m, p.max_len, w->prep, prep_stride, fast ? w->slow_cnt : nullptr, (may_overflow || dense) ? w->retry_cnt : nullptr, nullptr, 0, okeys_in));
+           if (ordered) HIP_TRY(sort_order_keys(st, okeys_in, okeys_out, p.nq, otemp, &otemp_bytes));
            p.prep = w->prep; p.prep_stride = prep_stride; }
     if (timed) HIP_TRY(hipEventRecord(ev[3], st));
     const uint32_t* final_list = w->retry_list; uint32_t* final_cnt = w->retry_cnt;
@@ -612,7 +666,17 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         fp.bigq_list = mid_tier && !kn.no_big ? w->slow_list + 2 * (w->slow_cap + 16) : nullptr; fp.bigq_cnt = fp.bigq_list ? w->slow_cnt + 4 : nullptr;
         const bool back = ext && ext->mode == 2;   // neighbour lists from the exchange buffer (any rank's front end), this shard's rows
         if (back) { fp.xchg = ext->xchg; fp.xchg_stride = ext->xchg_stride; }
-        HIP_TRY(launch_fast(dim3(grid_f), st, di, p, fp, kn.debug, back ? 2 : 0));
+        fp.order = ordered ? okeys_out : back ? ext->order : nullptr;
+        const uint32_t grid_fo = fp.order ? std::max<uint32_t>(8u, grid_f / 8u * 8u) : grid_f;   // (an ordered launch walks an eighth of the order per XCD: the grid is a multiple of 8)
+        if (back && d->sback.frag8 && !kn.no_sback && p.max_len <= 8) {
+            // the item shard's own back end (srn_sback.hip): one wave per query, 12 per CU; a persistent grid of a few waves per resident slot
+            SBackParams sbp = d->sback; if (kn.sback_nobitmap) sbp.present = nullptr;
+            const uint64_t slots = (uint64_t)d->n_cu * 12;
+            const uint32_t grid_b = (uint32_t)std::min<uint64_t>(p.nq, slots * (kn.grid_mult_set ? grid_mult : 8));
+            HIP_TRY(launch_shard_back(dim3(fp.order ? std::max<uint32_t>(8u, grid_b / 8u * 8u) : grid_b), st, di, p, fp, sbp, kn.debug));
+            d->sback_launches.fetch_add(1, std::memory_order_relaxed);
+        } else
+        HIP_TRY(launch_fast(dim3(grid_fo), st, di, p, fp, kn.debug, back ? 2 : 0));
         if (timed) HIP_TRY(hipEventRecord(ev[4], st));
         // The MID instantiation over what the lean one listed for it (sessions of <= 10 items, <= 8 lists); what it cannot take either joins slow_list.  The list's length
         // is known on the device only: a fixed grid, workgroups beyond the list leave at once.
@@ -759,10 +823,16 @@ int device_shard_lists_predict(DeviceState* d, const FlatIndex& ix, const Launch
 
 // ---- item-sharded index, neighbours pipeline (round 4): the posting lists are replicated (`post` = the device state of the whole index or of its postings-only view),
 // the rows stay sharded.  The record of a query is the same on every rank except for the dense idx of its items (this shard's numbering).
-int device_shard_nb_prep(DeviceState* d, DeviceState* post, const LaunchParams& p, char* records, void* stream) {
+int device_shard_nb_prep(DeviceState* d, DeviceState* post, const LaunchParams& p, char* records, void* stream, char** order_buf, size_t* order_bytes, const unsigned long long** order_out) {
     HIP_TRY(hipSetDevice(d->device));
+    if (order_out) *order_out = nullptr;
     if (p.nq == 0) return SRN_OK;
-    HIP_TRY(launch_prep((hipStream_t)stream, post->di, p.items_flat, p.q_off, p.nq, p.m, p.max_len, records, device_prep_stride(p.max_len), nullptr, nullptr, d->di.id_table, d->di.id_mask));
+    const Knobs kn = knobs();
+    const bool ordered = order_buf && kn.order_min > 0 && p.nq >= (uint32_t)kn.order_min;
+    unsigned long long *kin = nullptr, *kout = nullptr; void* temp = nullptr; size_t tb = 0;
+    if (ordered) { int rc = order_room(order_buf, order_bytes, p.nq, &kin, &kout, &temp, &tb); if (rc) return rc; }
+    HIP_TRY(launch_prep((hipStream_t)stream, post->di, p.items_flat, p.q_off, p.nq, p.m, p.max_len, records, device_prep_stride(p.max_len), nullptr, nullptr, d->di.id_table, d->di.id_mask, kin));
+    if (ordered) { HIP_TRY(sort_order_keys((hipStream_t)stream, kin, kout, p.nq, temp, &tb)); *order_out = kout; }
     return SRN_OK;
 }
 int device_shard_nb_front(DeviceState* d, const FlatIndex& ix, DeviceState* post, const LaunchParams& p_in, const char* records, uint32_t* xchg, uint32_t xchg_stride, uint32_t q_lo, uint32_t q_hi, void* stream) {
@@ -771,9 +841,9 @@ int device_shard_nb_front(DeviceState* d, const FlatIndex& ix, DeviceState* post
     ExtLists ext{records, device_prep_stride(p.max_len), post->di.post_rank, 1, xchg, xchg_stride, q_lo};
     return device_predict(d, ix, p, true, stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &ext);
 }
-int device_shard_nb_back(DeviceState* d, const FlatIndex& ix, DeviceState* post, const LaunchParams& p, const char* records, uint32_t* xchg, uint32_t xchg_stride, void* stream) {
+int device_shard_nb_back(DeviceState* d, const FlatIndex& ix, DeviceState* post, const LaunchParams& p, const char* records, uint32_t* xchg, uint32_t xchg_stride, void* stream, const unsigned long long* order) {
     if (p.nq == 0) return SRN_OK;
-    ExtLists ext{records, device_prep_stride(p.max_len), post->di.post_rank, 2, xchg, xchg_stride, 0u};
+    ExtLists ext{records, device_prep_stride(p.max_len), post->di.post_rank, 2, xchg, xchg_stride, 0u, order};
     return device_predict(d, ix, p, true, stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &ext);
 }
 

@@ -1,0 +1,463 @@
+// =====================================================================================
+// The item-sharded index's BACK END of its own (round 5): predict's scoring (src/vmisknn/mod.rs:126-214) over ONE shard's row fragments, from a neighbour list that
+// any rank's front end found (the shard group's neighbours pipeline, srn_group.hip) -- ONE WAVEFRONT PER EVOLVING SESSION, the north star's sketch.
+//
+// Why a kernel of its own.  Until round 4 the back end was an instantiation of vmis_fast_kernel (FM_BACK): a workgroup of 8 waves and 53 KB of LDS per query, sized for
+// the UNSHARDED index (4 096 + 4 096 accumulator words, 38 KB of clears, a 512-item threshold sample, four barriers in the harvest).  A shard of G sees 1 / G of the items
+// but ALL the queries, so every per-query fixed cost is paid G times per node: one rank's back end took 2.0 ms per 131 072 queries at G = 2, 4 AND 8 (profiles/r04_shard_rank_time.txt).
+// With 1 / G of the items a query's state is small -- here 1 024 direct-mapped + 1 024 sketch words: 8 KB -- and fits a single wave: no barriers at all, 12 queries in flight
+// per CU instead of 3, every per-query sweep (clear, sample, floors, sketch check) shrinks by 4-8x, and a lane's 24 neighbour slots are all requested at once.
+//
+// Rows: a third per-shard row array, `frag8` -- 8-byte slots addressed by recency rank, four 16-bit LDS byte offsets (the accumulator word of each of the <= 4 items of the
+// fragment: direct-mapped for the shard's SB_DIRECT most popular items, a sketch word for the rest, replicated words for the 16 hottest -- the same scheme as srn_fast.hip;
+// unused positions point into a dump area); a fragment of > 4 items (rare from G = 4 on) keeps all its items in 16-byte overflow blocks -- and a PRESENCE BITMAP, one bit per
+// session: at G = 8 about half of a query's neighbours hold no item of this shard at all, the bitmap (1.5 MB on config 3: L2-resident) is asked first and only the others
+// cost a fragment fetch (tools/shard_gather_bench.hip: a random fragment fetch is an HBM-granule miss at ~50 G/s chip-wide, a bitmap hit ~15x cheaper).
+//
+// Same canonical semantics, same integers: the harvest is the fast kernel's -- threshold from the most popular items' exact sums, integer floors per chunk, the sketch filter
+// (DESIGN.md "Why the sketch filter is exact"), walk B + exact table for what the sketch cannot exclude -- written wave-synchronously; the hand-off record and the finish
+// kernels (vmis_finish_kernel / vmis_finish_big_kernel) are shared with the fast kernel, and so is the fall-back: what this kernel cannot take goes to f.slow_list and the
+// general kernel behind it.
+// =====================================================================================
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+
+#include "srn_device.h"
+#include "srn_kernels.h"
+
+namespace srn {
+
+// LDS map of one wave (= one workgroup), bytes
+static constexpr uint32_t SB_MISC = 0, SB_WTAB = 128, SB_CAND = 192, SB_CAND_CAP = 128, SB_TABLE = SB_CAND + SB_CAND_CAP * 12 /* 1728 */, SB_BUCKETS = 61,
+                          SB_TABLE_WORDS = 256 /* 61 buckets of 4 slots, padded */, SB_HOT = SB_TABLE + SB_TABLE_WORDS * 8 /* 3776 */;
+static_assert(SB_H % 256 == 0 && (SB_S & (SB_S - 1)) == 0 && SB_DUMP == 64, "geometry");
+static constexpr uint32_t SB_LDS = SB_HOT + (SB_H + SB_S + SB_DUMP) * 4;
+static constexpr uint32_t SB_LQ_CAP = (SB_HOT - SB_CAND) / 8;   // long fragments a query may queue (448)
+static constexpr uint32_t SB_LQB_CAP = 128, SB_HIT_CAP = (SB_H * 4 - SB_LQB_CAP * 12) / 8;   // walk B's hit list and its queue of long fragments live in the direct-mapped words (dead by then)
+static_assert(SB_HOT % 16 == 0 && SB_TABLE % 16 == 0 && SB_CAND % 8 == 0, "alignment");
+
+// -------------------------------------------------------------------------------------
+// Attach time: an item shard's CSR row fragments -> frag8 slots + overflow blocks + presence bitmap
+// -------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t sb_offset_of(uint32_t idx, uint64_t r) {
+    if (idx < SB_REP_ITEMS) return (SB_DIRECT + idx * SB_REP + ((uint32_t)r & (SB_REP - 1u))) * 4u;
+    return idx < SB_DIRECT ? idx * 4u : (SB_H + (idx & (SB_S - 1u))) * 4u;
+}
+__device__ __forceinline__ uint32_t sb_phantom(uint64_t r, uint32_t j) {
+    return (SB_H + SB_S + ((((uint32_t)r * 0x9E3779B1u + j * 0x85EBCA6Bu) >> 23) & (SB_DUMP - 1u))) * 4u;
+}
+__global__ __launch_bounds__(1024) void rows_to_frag8_kernel(const uint64_t* __restrict__ row_off, const uint32_t* __restrict__ row_items, uint64_t n,
+                                                             const uint32_t* __restrict__ block_base, uint2* __restrict__ frag8, uint4* __restrict__ ext8, uint32_t* __restrict__ present) {
+    __shared__ uint32_t wave_tot[16];
+    const uint64_t r = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t o = 0, len = 0;
+    if (r < n) { o = row_off[r]; len = row_off[r + 1] - o; }
+    const uint32_t e = len > 4 ? (uint32_t)((len + 7) / 8) : 0u;   // overflow blocks of this fragment (ALL its items live there)
+    const uint32_t inc = wave_incl_scan(e);
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t base = block_base[blockIdx.x];
+    for (int w = 0; w < wave; ++w) base += wave_tot[w];
+    const uint32_t eblk = base + inc - e;
+    // presence: bit (r & 31) of word r >> 5 (a wave covers two words)
+    const unsigned long long pb = __ballot(len > 0);
+    if ((lane & 31) == 0 && r <= n) present[r >> 5] = (uint32_t)(pb >> (lane & 32));
+    if (r > n) return;
+    uint32_t h[4];
+    if (len <= 4) {
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) h[j] = j < len ? sb_offset_of(row_items[o + j], r) : sb_phantom(r, j);
+    } else {
+        h[0] = 0xFFFFu; h[1] = (uint32_t)(len > 0xFFFFu ? 0xFFFFu : len); h[2] = eblk & 0xFFFFu; h[3] = eblk >> 16;
+        for (uint32_t b = 0; b < e; ++b) {
+            uint32_t wv[4];
+#pragma unroll
+            for (uint32_t x = 0; x < 4; ++x) {
+                const uint64_t j0 = 8ull * b + 2 * x;
+                const uint32_t lo = j0 < len ? sb_offset_of(row_items[o + j0], r) : sb_phantom(r, (uint32_t)j0);
+                const uint32_t hi = j0 + 1 < len ? sb_offset_of(row_items[o + j0 + 1], r) : sb_phantom(r, (uint32_t)j0 + 1);
+                wv[x] = lo | (hi << 16);
+            }
+            ext8[(size_t)eblk + b] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+        }
+    }
+    frag8[r] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+}
+hipError_t launch_rows_to_frag8(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base, uint2* frag8, uint4* ext8, uint32_t* present) {
+    hipLaunchKernelGGL(rows_to_frag8_kernel, dim3((unsigned)((n_rows + 1 + 1023) / 1024)), dim3(1024), 0, st, row_off, row_items, n_rows, block_base, frag8, ext8, present);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------
+// The kernel.  One wave per query; a persistent grid strides over the batch.
+// -------------------------------------------------------------------------------------
+#ifndef SRN_SBACK_WAVES
+#define SRN_SBACK_WAVES 3   // waves per SIMD the register allocation is sized for (12 per CU: the LDS allows 13)
+#endif
+template <bool BITMAP>
+__global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(DeviceIndex ix_arg, LaunchParams p_arg, FastParams f_arg, SBackParams sb_arg) {
+    __shared__ __attribute__((aligned(16))) char smem[SB_LDS];
+    // the parameter blocks are read from the kernel-argument segment where they are used (as the fast kernel does): loaded up front they would sit in ~120 SGPRs for the
+    // kernel's whole life, and the spills of those land in VGPRs
+    typedef const __attribute__((address_space(4))) char* KArg;
+    const KArg ka = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr size_t OFF_P = (sizeof(DeviceIndex) + alignof(LaunchParams) - 1) / alignof(LaunchParams) * alignof(LaunchParams);
+    constexpr size_t OFF_F = (OFF_P + sizeof(LaunchParams) + alignof(FastParams) - 1) / alignof(FastParams) * alignof(FastParams);
+    constexpr size_t OFF_S = (OFF_F + sizeof(FastParams) + alignof(SBackParams) - 1) / alignof(SBackParams) * alignof(SBackParams);
+    const __attribute__((address_space(4))) DeviceIndex& ix = *(const __attribute__((address_space(4))) DeviceIndex*)ka;
+    const __attribute__((address_space(4))) LaunchParams& p = *(const __attribute__((address_space(4))) LaunchParams*)(ka + OFF_P);
+    const __attribute__((address_space(4))) FastParams& f = *(const __attribute__((address_space(4))) FastParams*)(ka + OFF_F);
+    const __attribute__((address_space(4))) SBackParams& sb = *(const __attribute__((address_space(4))) SBackParams*)(ka + OFF_S);
+    const uint32_t lane = threadIdx.x;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint16_t* wtab = (uint16_t*)(smem + SB_WTAB);
+    unsigned long long* ckey = (unsigned long long*)(smem + SB_CAND);
+    uint32_t* cidx = (uint32_t*)(smem + SB_CAND + SB_CAND_CAP * 8);
+    uint32_t* ikeys = (uint32_t*)(smem + SB_TABLE);
+    int* iacc = (int*)(smem + SB_TABLE + SB_TABLE_WORDS * 4);
+    char* const acc_base = smem + SB_HOT;
+    uint32_t* hot = (uint32_t*)(smem + SB_HOT);
+    uint2* hits = (uint2*)(smem + SB_HOT);
+    uint2* lqb = (uint2*)(smem + SB_HOT + SB_HIT_CAP * 8); uint32_t* lqb_len = (uint32_t*)(smem + SB_HOT + SB_HIT_CAP * 8 + SB_LQB_CAP * 8);
+    uint2* lq = (uint2*)(smem + SB_CAND);   // walk A's queue of long fragments: over the candidate buffer and the exact table, both dead until the harvest
+    const bool business = (p.flags & SRN_FLAG_BUSINESS_LOGIC) != 0u;
+    const bool wide = f.nb == 3u;
+    const uint32_t n_kept = ix.n_kept;
+    constexpr uint32_t NCH = F_K_MAX / 64u;   // 24 chunks of 64 neighbours
+
+    // the wave's sample constants: items 4 lane .. 4 lane + 3 of the shard's popularity order (loop-invariant: in registers for the wave's whole life)
+    double s_idf[4]; uint32_t s_attr = 0, s_rank[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const ItemMeta m0 = sb.sample[4u * lane + (uint32_t)j]; s_idf[j] = m0.idf > 0.0 ? m0.idf : 1.0; s_attr |= (m0.attr & 0xFFu) << (8 * j); s_rank[j] = m0.id_rank; }
+
+    // per-phase shader cycles (debug, srn_debug_phase_cycles): summed in registers by the wave, flushed once at the end.  Slots follow the fast kernel's numbering:
+    // 8 record + clears, 9 walk A, 10 sample + floors, 11 sketch check, 12 walk B + resolve, 13 hand-off; 5 listed elements, 6 candidates, 7 live queries, 14 served, 15 handed over by cause (20-bit fields: candidates | long-fragment queues | hit list; exact table: upper half of 7)
+    const bool ticking = p.phase_cycles != nullptr;
+    unsigned long long tk8 = 0, tk9 = 0, tk10 = 0, tk11 = 0, tk12 = 0, tk13 = 0, c5 = 0, c6 = 0, c7 = 0, c14 = 0, c15 = 0;
+#define SB_TICK(acc) do { if (ticking) { const long long t_ = clock64(); acc += (unsigned long long)(t_ - t_prev); t_prev = t_; } } while (0)
+    // the serving order (f.order, see vmis_fast_kernel): the batch sorted by each query's most popular item, dealt to the XCDs chunk by chunk (the grid is a multiple of 8)
+    const bool ordered = f.order != nullptr;
+    const uint32_t ox = blockIdx.x & 7u;
+    const uint32_t qi_step = ordered ? gridDim.x >> 3 : gridDim.x, qi_end = ordered ? ord_count(p.nq, ox) : p.nq;
+    for (uint32_t qi = ordered ? blockIdx.x >> 3 : blockIdx.x; qi < qi_end; qi += qi_step) {
+        const uint32_t q = ordered ? (uint32_t)f.order[ord_pos(ox, qi)] : qi;
+        long long t_prev = ticking ? clock64() : 0;
+        const char* const rec = p.prep + (size_t)q * p.prep_stride;
+        const uint32_t* const xq = f.xchg + (size_t)q * f.xchg_stride;
+        // ---- the query's record and its neighbour slots: ONE round trip (the slots past K are stale words of the query's own row, masked below) ----
+        struct { uint32_t U, xlo, L, cur_attr; } h0;   // (uniform addresses: scalar loads)
+        { const PrepHead* hp = (const PrepHead*)rec; h0.U = hp->U; h0.xlo = hp->xlo; h0.L = hp->L; h0.cur_attr = hp->cur_attr; }
+        uint32_t it_idx = kNone, it_kept = 0u;
+        if (lane < 8u && lane < h0.L && lane < p.max_len) { const PrepItem pi = ((const PrepItem*)(rec + sizeof(PrepHead)))[lane]; it_idx = pi.idx; it_kept = pi.kept; }
+        const uint32_t kv = xq[0];
+        uint32_t sv[NCH];
+#pragma unroll
+        for (uint32_t c = 0; c < NCH; ++c) sv[c] = xq[1u + min(c * 64u + lane, f.xchg_stride - 2u)];
+        const uint32_t K = (uint32_t)__builtin_amdgcn_readfirstlane((int)kv);
+        const uint32_t L = h0.L, U = h0.U, cur_attr = h0.cur_attr;
+        if (K == 0xFFFFFFFFu || L < 1u || L > 8u || L > p.max_len || K > F_K_MAX) {   // (wave-uniform) no front end took it, or not this kernel's shape: the general kernel does its candidate work itself
+            if (lane == 0u) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q;
+            continue;
+        }
+        if (K == 0u) { if (lane == 0u) p.out_counts[q] = 0u; continue; }
+        unsigned long long rm = __ballot(it_kept > 0u);
+        const uint32_t nr = (uint32_t)__popcll(rm);
+        const bool rel = wide && nr > 3u;
+        const uint32_t NB = wide && !rel ? 3u : 4u, NBM = (1u << NB) - 1u, base = rel ? h0.xlo : 0u;
+        const uint32_t cur_idx = (uint32_t)__builtin_amdgcn_readlane((int)it_idx, 0);
+        {   // weight of each list set: 10 * linear_score(first match) * numerator (mod.rs:110-116, 133-144); runs are numbered in position order
+            uint32_t ps[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { ps[r] = rm ? (uint32_t)__ffsll((long long)rm) - 1u : 0u; rm &= rm - 1ull; }
+            if (lane < 16u) {
+                const uint32_t num = ((lane & 1u) ? L - ps[0] : 0u) + ((lane & 2u) ? L - ps[1] : 0u) + ((lane & 4u) ? L - ps[2] : 0u) + ((lane & 8u) ? L - ps[3] : 0u);
+                const uint32_t lo = lane ? (uint32_t)__ffs((int)lane) - 1u : 0u;
+                const uint32_t mp = lo == 0u ? ps[0] : lo == 1u ? ps[1] : lo == 2u ? ps[2] : ps[3];
+                wtab[lane] = (uint16_t)((9u - mp) * num);
+            }
+        }
+        {   // clear: accumulators + sketch + dump (the exact table is cleared after walk A: its words hold the long fragments' queue until then)
+            uint4* z = reinterpret_cast<uint4*>(smem + SB_HOT);
+            for (uint32_t i = lane; i < (SB_H + SB_S + SB_DUMP) / 4u; i += 64u) z[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        __syncthreads();   // (one wave: orders the LDS traffic; no other wave to wait for)
+        SB_TICK(tk8);
+        // ---- walk A: ALL of a lane's <= 24 presence words in flight together, then all fragments of the present ones: a query's walk is three HBM / L2 round trips (slots,
+        // presence, fragments) whatever K is.  A first build walked in two halves with the long fragments' overflow blocks fetched inline: 30 dependent round trips per query on
+        // 12 waves per CU -- 2.9 ms per 131 072 queries against the 1.9 ms of the kernel it replaces.
+        auto add2 = [&](uint32_t wd, uint32_t w) { atomicAdd((uint32_t*)(acc_base + (wd & 0xFFFFu)), w); atomicAdd((uint32_t*)(acc_base + (wd >> 16)), w); };
+        uint32_t pm = 0u;    // bit c: this lane's neighbour of chunk c holds an item of this shard (kept for walk B)
+        uint32_t nlq = 0u;   // (wave-uniform) long fragments queued
+        {
+            uint32_t pwv[NCH];
+#pragma unroll
+            for (uint32_t c = 0; c < NCH; ++c) {
+                pwv[c] = 0u;
+                if (c * 64u < K) {   // (wave-uniform)
+                    const bool act = c * 64u + lane < K;
+                    const uint32_t r = act ? base + (sv[c] >> NB) : n_kept;   // (idle lanes: the empty row, whose presence bit is 0)
+                    if constexpr (BITMAP) pwv[c] = sb.present[r >> 5] >> (r & 31u); else pwv[c] = act ? 1u : 0u;
+                }
+            }
+#pragma unroll
+            for (uint32_t c = 0; c < NCH; ++c) pm |= (pwv[c] & 1u) << c;
+        }
+        {
+            uint2 fr[NCH];
+#pragma unroll
+            for (uint32_t c = 0; c < NCH; ++c) {
+                fr[c] = make_uint2(0u, 0u);
+                if (c * 64u < K) fr[c] = sb.frag8[(pm >> c) & 1u ? base + (sv[c] >> NB) : n_kept];   // (unconditional per lane: a load inside a divergent branch is waited for at the branch's end; the absent lanes all read the empty row's slot -- one line)
+            }
+#pragma unroll
+            for (uint32_t c = 0; c < NCH; ++c) {
+                if (c * 64u < K) {
+                    const bool pr = (pm >> c) & 1u, lng = pr && (fr[c].x & 0xFFFFu) == 0xFFFFu;
+                    const uint32_t w = (uint32_t)wtab[sv[c] & NBM];
+                    if (pr && !lng) { add2(fr[c].x, w); add2(fr[c].y, w); }
+                    const unsigned long long lb = __ballot(lng);
+                    if (lb) {   // a fragment of > 4 items (rare from G = 8 on): queued -- {weight | length, first overflow block} --, all the queue's blocks are fetched together below
+                        const uint32_t at = nlq + (uint32_t)__popcll(lb & lt);
+                        if (lng && at < SB_LQ_CAP) lq[at] = make_uint2((w << 16) | (fr[c].x >> 16), fr[c].y);
+                        nlq += (uint32_t)__popcll(lb);
+                    }
+                }
+            }
+        }
+        bool fail = nlq > SB_LQ_CAP;   // (wave-uniform)
+        if (fail) c15 += 1ull << 20;
+        if (nlq && !fail) {
+            __syncthreads();
+            for (uint32_t i0 = 0; i0 < nlq; i0 += 64u) {
+                const bool act = i0 + lane < nlq;
+                const uint2 e = lq[min(i0 + lane, nlq - 1u)];
+                const uint32_t len = act ? e.x & 0xFFFFu : 0u, w = e.x >> 16;
+                const uint4* eb = sb.ext8 + (size_t)e.y;
+                const uint4 b0 = eb[0], b1 = eb[len > 8u ? 1 : 0];   // (the first two blocks together: 16 items cover nearly every long fragment)
+                if (act) { add2(b0.x, w); add2(b0.y, w); add2(b0.z, w); add2(b0.w, w); }
+                if (len > 8u) { add2(b1.x, w); add2(b1.y, w); add2(b1.z, w); add2(b1.w, w); }
+                for (uint32_t t8 = 16u; __ballot(t8 < len) != 0ull; t8 += 8u)
+                    if (t8 < len) { const uint4 e4 = eb[t8 >> 3]; add2(e4.x, w); add2(e4.y, w); add2(e4.z, w); add2(e4.w, w); }
+            }
+        }
+        __syncthreads();
+        {   // the exact table (keys EMPTY32, sums 0) and the counters
+            reinterpret_cast<uint4*>(ikeys)[lane] = make_uint4(EMPTY32, EMPTY32, EMPTY32, EMPTY32);
+            reinterpret_cast<uint4*>(iacc)[lane] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        SB_TICK(tk9);
+        // ---- harvest: the sample (this shard's 256 most popular items, four per lane), exactly -> threshold, candidates ----
+        uint32_t v4[4];
+        { const uint4 a = reinterpret_cast<const uint4*>(hot)[lane]; v4[0] = a.x; v4[1] = a.y; v4[2] = a.z; v4[3] = a.w; }
+        if (lane < SB_REP_ITEMS / 4u) {   // replicated items: the sum is spread over SB_REP words (the item's own word stays 0)
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) { const uint4* rp = reinterpret_cast<const uint4*>(hot + SB_DIRECT + (4u * lane + j) * SB_REP); const uint4 a = rp[0], b = rp[1];
+                                                v4[j] = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w; }
+        }
+        if (lane < SB_DUMP) hot[SB_H + SB_S + lane] = 0u;   // (walk B reads the dump words, where unused positions point, as "cannot reach the floor")
+        double x4[4]; uint32_t k4[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const uint32_t e = 4u * lane + j;
+            bool valid = v4[j] != 0u && e != cur_idx && e < ix.n_items;
+            if (business) valid = valid && business_ok(cur_attr, (s_attr >> (8u * j)) & 0xFFu);   // an item the rules exclude is no candidate and sets no threshold
+            x4[j] = valid ? s_idf[j] * (double)v4[j] : 0.0;
+            k4[j] = (uint32_t)((unsigned long long)__double_as_longlong(x4[j]) >> 32);
+        }
+        // the n-th largest of the 256 keys (top 32 bits of x: a monotone truncation), bit by bit from the top down to bit 8: t32 = the largest multiple of 256 with
+        // at least n keys at or above it (0: fewer than n valid items -- no threshold, everything valid is a candidate)
+        uint32_t t32 = 0u;
+        for (int b = 31; b >= 8; --b) {
+            const uint32_t c = t32 | (1u << b);
+            const uint32_t cnt = (uint32_t)__popcll(__ballot(k4[0] >= c)) + (uint32_t)__popcll(__ballot(k4[1] >= c)) + (uint32_t)__popcll(__ballot(k4[2] >= c)) + (uint32_t)__popcll(__ballot(k4[3] >= c));
+            t32 = cnt >= p.how_many ? c : t32;
+        }
+        // everything is kept down to one step BELOW it, so that what is dropped is strictly smaller after the division by 10 U as well (ties at the cut included)
+        const uint32_t t32m1 = t32 ? t32 - 1u : 0u;
+        uint32_t ncand = 0;   // (wave-uniform)
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const bool take = x4[j] != 0.0 && k4[j] >= t32m1;
+            const unsigned long long bm = __ballot(take);
+            if (bm) {
+                const uint32_t at = ncand + (uint32_t)__popcll(bm & lt);
+                if (take) { if (at < SB_CAND_CAP) { ckey[at] = (unsigned long long)__double_as_longlong(x4[j]); cidx[at] = s_rank[j]; } }
+                ncand += (uint32_t)__popcll(bm);
+            }
+        }
+        // integer floors: an item needs idf * acc >= x_lo, i.e. acc >= x_lo / (largest idf of its chunk of 256); shaved so that rounding can only keep more
+        const double x_lo = __longlong_as_double((long long)((unsigned long long)t32m1 << 32));
+        auto floor_of = [&](double inv) -> uint32_t { return (uint32_t)fmin(4.0e9, fmax(1.0, floor(x_lo * inv * (1.0 - 1e-9)) - 1.0)); };
+        const uint32_t floor_b = floor_of(sb.inv_idf_all);
+#pragma unroll
+        for (uint32_t ch = 1; ch < SB_H / 256u; ++ch) {   // the other direct-mapped words: a quad per lane and chunk, the chunk's floor wave-uniform
+            const uint32_t fl = floor_of(sb.inv_idf_chunk[ch]);
+            const uint4 q4 = reinterpret_cast<const uint4*>(hot)[ch * 64u + lane];
+            const uint32_t mx = max(max(q4.x, q4.y), max(q4.z, q4.w));
+            if (__ballot(mx >= fl) == 0ull) continue;
+            const uint32_t vv[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) {
+                const uint32_t e = ch * 256u + 4u * lane + j;
+                const bool pass = vv[j] >= fl && e != cur_idx && e < SB_DIRECT;   // (the words from SB_DIRECT up are the replicas of the hottest items, already in the sample)
+                if (__ballot(pass) == 0ull) continue;
+                ItemMeta mt = ItemMeta{0.0, 0u, 0u};
+                if (pass) mt = ix.meta[e];
+                const double x = (mt.idf > 0.0 ? mt.idf : 1.0) * (double)vv[j];
+                const bool take = pass && (uint32_t)((unsigned long long)__double_as_longlong(x) >> 32) >= t32m1 && (!business || business_ok(cur_attr, mt.attr));
+                const unsigned long long bm = __ballot(take);
+                if (bm) {
+                    const uint32_t at = ncand + (uint32_t)__popcll(bm & lt);
+                    if (take && at < SB_CAND_CAP) { ckey[at] = (unsigned long long)__double_as_longlong(x); cidx[at] = mt.id_rank; }
+                    ncand += (uint32_t)__popcll(bm);
+                }
+            }
+        }
+        if (ncand > SB_CAND_CAP) { fail = true; c15 += 1ull; }
+        SB_TICK(tk10);
+        // ---- is any sketch word at the floor at all?  If not, no item outside the direct-mapped range can make the top n: no walk B ----
+        bool live;
+        {
+            const uint4* sk4 = reinterpret_cast<const uint4*>(hot + SB_H);
+            uint32_t mx = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < SB_S / 256u; ++i) { const uint4 w4 = sk4[i * 64u + lane]; mx = max(max(mx, w4.x), max(max(w4.y, w4.z), w4.w)); }
+            live = __ballot(mx >= floor_b) != 0ull;
+        }
+        uint32_t nt = 0;   // contenders of the exact table, listed behind the candidates
+        SB_TICK(tk11);
+        if (live && !fail) {
+            c7 += 1ull;
+            // ---- walk B: the rows again (L2 by now); an element is LISTED if its sketch word can still reach the floor (all elements of an item share the word, so an item
+            // is accumulated completely or not at all); then the list is resolved -- item id from the general fragment slots -- into the exact table ----
+            __syncthreads();   // (the direct-mapped words are dead: the hit list takes them)
+            uint32_t nh = 0;   // (wave-uniform)
+            auto chk = [&](uint32_t o) -> bool { return o >= SB_H * 4u && *(const uint32_t*)(acc_base + o) >= floor_b; };
+            auto list = [&](uint32_t hm, uint32_t s, uint32_t j0) {   // hm: bit i = position j0 + i of the fragment is a hit
+                const uint32_t c = (uint32_t)__popc(hm);
+                if (__ballot(c != 0u) == 0ull) return;
+                const uint32_t inc = wave_incl_scan(c);
+                uint32_t at = nh + inc - c;
+                while (hm) { const uint32_t b = (uint32_t)__ffs((int)hm) - 1u; hm &= hm - 1u; if (at < SB_HIT_CAP) hits[at] = make_uint2(s, j0 + b); ++at; }
+                nh += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            };
+            uint32_t nlb = 0u;   // (wave-uniform) long fragments queued for the second step
+            {
+                uint2 fr[NCH];   // the fragments again (L2 by now), all in flight together; the presence bits are walk A's
+#pragma unroll
+                for (uint32_t c = 0; c < NCH; ++c) {
+                    fr[c] = make_uint2(0u, 0u);
+                    if (c * 64u < K) fr[c] = sb.frag8[(pm >> c) & 1u ? base + (sv[c] >> NB) : n_kept];
+                }
+#pragma unroll
+                for (uint32_t c = 0; c < NCH; ++c) {
+                    if (c * 64u >= K) continue;   // (wave-uniform)
+                    const bool pr = (pm >> c) & 1u, lng = pr && (fr[c].x & 0xFFFFu) == 0xFFFFu;
+                    uint32_t hm = 0;
+                    if (pr && !lng) hm = (chk(fr[c].x & 0xFFFFu) ? 1u : 0u) | (chk(fr[c].x >> 16) ? 2u : 0u) | (chk(fr[c].y & 0xFFFFu) ? 4u : 0u) | (chk(fr[c].y >> 16) ? 8u : 0u);
+                    list(hm, sv[c], 0u);
+                    const unsigned long long lb = __ballot(lng);
+                    if (lb) {
+                        const uint32_t at = nlb + (uint32_t)__popcll(lb & lt);
+                        if (lng && at < SB_LQB_CAP) { lqb[at] = make_uint2(sv[c], fr[c].y); lqb_len[at] = fr[c].x >> 16; }
+                        nlb += (uint32_t)__popcll(lb);
+                    }
+                }
+            }
+            if (nlb > SB_LQB_CAP) { fail = true; c15 += 1ull << 20; }
+            else if (nlb) {
+                __syncthreads();
+                for (uint32_t i0 = 0; i0 < nlb; i0 += 64u) {
+                    const bool act = i0 + lane < nlb;
+                    const uint2 e = lqb[min(i0 + lane, nlb - 1u)];
+                    const uint32_t len = act ? lqb_len[min(i0 + lane, nlb - 1u)] : 0u;
+                    for (uint32_t t8 = 0; __ballot(t8 < len) != 0ull; t8 += 8u) {
+                        uint32_t h8 = 0;
+                        if (t8 < len) { const uint4 e4 = sb.ext8[(size_t)e.y + (t8 >> 3)]; const uint32_t wv[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+                                        for (uint32_t x = 0; x < 4u; ++x) h8 |= (chk(wv[x] & 0xFFFFu) ? 1u << (2u * x) : 0u) | (chk(wv[x] >> 16) ? 2u << (2u * x) : 0u); }
+                        list(h8, e.x, t8);
+                    }
+                }
+            }
+            __syncthreads();
+            c5 += nh;
+            if (nh > SB_HIT_CAP) { fail = true; c15 += 1ull << 40; }
+            else {
+                bool ovf = false;
+                for (uint32_t i = lane; i < nh; i += 64u) {
+                    const uint2 h = hits[i];
+                    const uint32_t* os = reinterpret_cast<const uint32_t*>(ix.row_slots + (size_t)(base + (h.x >> NB)));   // the general 16-byte fragment slot: {len, i0, i1, i2} | {len, ext offset, i0, i1}
+                    const uint32_t len = os[0], j = h.y;
+                    uint32_t it = EMPTY32;
+                    if (j < len) it = len <= 3u ? os[1 + j] : (j < 2u ? os[2 + j] : ix.row_ext[os[1] + (j - 2u)]);   // (a position past the end was a dump word)
+                    if (business && it != EMPTY32 && it >= SB_DIRECT && !business_ok(cur_attr, ix.meta[it].attr)) it = EMPTY32;
+                    if (it != EMPTY32 && it >= SB_DIRECT && item_insert(ikeys, iacc, SB_BUCKETS, it, (int)(uint32_t)wtab[h.x & NBM]) < 0) ovf = true;
+                }
+                if (__ballot(ovf) != 0ull) { fail = true; c7 += 1ull << 32; }
+            }
+            __syncthreads();
+            if (!fail) {   // the table's contenders (exact sum at the floor; the others were collisions in their sketch word), compacted behind the candidates' room: into the hit list's words
+                uint4 kq = make_uint4(EMPTY32, EMPTY32, EMPTY32, EMPTY32), aq = make_uint4(0u, 0u, 0u, 0u);
+                if (lane < SB_BUCKETS) { kq = reinterpret_cast<const uint4*>(ikeys)[lane]; aq = reinterpret_cast<const uint4*>(iacc)[lane]; }
+                const uint32_t kk[4] = {kq.x, kq.y, kq.z, kq.w}, aa[4] = {aq.x, aq.y, aq.z, aq.w};
+                __syncthreads();
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const bool in = kk[s4] != EMPTY32 && kk[s4] != cur_idx && aa[s4] >= floor_b;
+                    const unsigned long long bm = __ballot(in);
+                    if (in) hits[nt + (uint32_t)__popcll(bm & lt)] = make_uint2(kk[s4], aa[s4]);
+                    nt += (uint32_t)__popcll(bm);
+                }
+                __syncthreads();
+            }
+        }
+        SB_TICK(tk12);
+        if (fail) { if (lane == 0u) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q; continue; }
+        // ---- hand-off: the query's record for vmis_finish_kernel (score = x / (10 U), ranking, public ids), as the fast kernel writes it ----
+        const uint32_t M = ncand + nt;
+        uint32_t ovf_at = 0;
+        if (M > F_FIN_ENTRIES) {   // (wave-uniform, rare)
+            unsigned long long tk = 0;
+            if (lane == 0u) tk = atomicAdd(f.big_ticket, (1ull << 32) | (unsigned long long)(M - F_FIN_ENTRIES));
+            const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(tk >> 32), 0);
+            ovf_at = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tk, 0);
+            if ((unsigned long long)ovf_at + (M - F_FIN_ENTRIES) > f.big_cap_entries) {   // no room: the general kernel redoes the query
+                if (lane == 0u) { f.big_list[slot] = 0xFFFFFFFFu; f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q; }
+                continue;
+            }
+            if (lane == 0u) f.big_list[slot] = q;
+        }
+        {
+            uint4* out = reinterpret_cast<uint4*>(f.fin + (size_t)q * F_FIN_BYTES);
+            uint4* ovf = reinterpret_cast<uint4*>(f.big_arena) + ovf_at;
+            if (lane == 0u) { out[0] = make_uint4(M, U, ovf_at, 0u); p.out_counts[q] = M > F_FIN_ENTRIES ? 0x80000001u : 0x80000000u; }
+            for (uint32_t i = lane; i < M; i += 64u) {
+                uint4 e;
+                if (i < ncand) { const unsigned long long x = ckey[i]; e = make_uint4((uint32_t)x, (uint32_t)(x >> 32), cidx[i], 0u); }
+                else { const uint2 c = hits[i - ncand]; e = make_uint4(c.y, 0u, c.x, 1u); }
+                if (i < F_FIN_ENTRIES) out[1 + i] = e; else ovf[i - F_FIN_ENTRIES] = e;
+            }
+        }
+        __syncthreads();   // (the next query clears what this one still read)
+        c6 += ncand; c14 += 1ull;
+        SB_TICK(tk13);
+    }
+    if (ticking && lane == 0u) {
+        const unsigned long long v[16] = {0, 0, 0, 0, 0, c5, c6, c7, tk8, tk9, tk10, tk11, tk12, tk13, c14, c15};
+        for (int i = 5; i < 16; ++i) if (v[i]) atomicAdd(&p.phase_cycles[i], v[i]);
+    }
+}
+
+hipError_t launch_shard_back(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f, const SBackParams& sb, bool debug) {
+    static bool told = false;
+    if (!told && debug) { told = true; int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)vmis_shard_back_kernel<true>, 64, 0);
+        fprintf(stderr, "[srn] vmis_shard_back_kernel: %u bytes of LDS per wave, %d waves per CU (occupancy API)\n", SB_LDS, nb); }
+    if (sb.present) hipLaunchKernelGGL(vmis_shard_back_kernel<true>, grid, dim3(64), 0, st, di, p, f, sb);
+    else hipLaunchKernelGGL(vmis_shard_back_kernel<false>, grid, dim3(64), 0, st, di, p, f, sb);
+    return hipGetLastError();
+}
+
+}  // namespace srn

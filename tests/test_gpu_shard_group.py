@@ -479,6 +479,7 @@ def _cb_kill_worker(rank, world, port, q):
         dist.barrier()
         if rank == world - 1:
             q.put((rank, "left", None, None, first))
+            q.close(); q.join_thread()                                              # (the queue's feeder thread must have written before the process vanishes)
             os._exit(0)                                                             # gone before the second batch: no goodbye to anybody
         t0 = time.time()
         try:
@@ -494,6 +495,7 @@ def _cb_kill_worker(rank, world, port, q):
             except sa.SerenadeError as e:
                 codes.append((e.code, time.time() - t1))
         q.put((rank, outcome, codes, capi.SRN_ESTATE, first))
+        q.close(); q.join_thread()
         grp.close()                                                                 # (a broken group is freed without waiting for the device)
         os._exit(0)                                                                 # (the process group lost a member: no orderly shutdown to wait for)
     except Exception as e:  # pragma: no cover
@@ -515,7 +517,7 @@ def test_a_rank_that_dies_mid_run_fails_the_others_within_a_timeout():
     procs = [ctx.Process(target=_cb_kill_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out = [q.get(timeout=600) for _ in range(world)]
+    out = [q.get(timeout=300) for _ in range(world)]
     for p in procs:
         p.join(timeout=120)
     firsts = []
@@ -550,3 +552,54 @@ def test_group_wait_and_the_default_overlap():
     u = sa.predict_batch(full, (flat, qoff), 80, 300, 21, False)
     assert np.array_equal(got[0].cpu().numpy().view(np.uint64), u[0])          # (no torch synchronise in between: wait() was the synchronisation)
     assert grp.stats["overlapped"] == 0
+
+
+# ---- the item shard's own back end (round 5, srn_sback.hip): one wave per query, frag8 rows + presence bitmap -------------------------------------------------------
+
+@pytest.mark.parametrize("n_shards,knob", [(2, ""), (3, ""), (8, ""), (8, "SRN_SBACK_NOBITMAP"), (5, "SRN_NO_SBACK")])
+def test_wave_per_query_back_end_against_the_oracle(n_shards, knob):
+    """The neighbours pipeline's back end as a kernel of its own -- vmis_shard_back_kernel: a wave per query over 8-byte fragment slots, the presence bitmap asked first --
+    against the canonical oracle and bit-identical to the unsharded path: rows of up to 80 items (at 2 and 3 shards most fragments of the long rows have > 4 items: the
+    overflow blocks), unknown and repeated items, both cuts biting, small queries without a threshold, business rules with real flags; with the bitmap switched off; and
+    (SRN_NO_SBACK) the round-4 form, which must not have changed.  SRN_SBACK_MIN_SHARDS=2 gives the 2- and 3-shard groups the new rows too (default: from 4 shards on)."""
+    import ctypes as C
+    import serenade_amd as sa
+    from serenade_amd import sharded, capi
+    from oracle import oracle as O
+    os.environ["SRN_SBACK_MIN_SHARDS"] = "2"
+    if knob:
+        os.environ[knob] = "1"
+    capi.reload_knobs()
+    try:
+        off, items, ts, ids = small_dataset(281, n_sessions=12000, n_items=3000, max_len=80)
+        qs = random_queries(223, ids, 1500, max_len=8, unknown_rate=0.03, dup_rate=0.1)
+        flat, qoff = flatten(qs)
+        d_flat, d_off = _to_dev(flat, qoff)
+        full = sa.VMISIndex.from_sessions(off, items, ts, 500, 80, 1.0)
+        oix = O.OracleIndex(off, items, ts, 500, 80, 1.0)
+        rng = np.random.default_rng(48)
+        known = np.unique(items)
+        flags = rng.choice(np.array([0, 1, 2, 3, 0xFF], np.uint8), size=len(known), p=[0.1, 0.05, 0.55, 0.2, 0.1])
+        full.set_attributes(known, flags)
+        oix.set_attributes(known, flags)
+        shards = [sharded.ShardedVMISIndex.from_full(full, g, n_shards) for g in range(n_shards)]
+        for s in shards:
+            capi.check(capi.lib().srn_index_set_attributes(s._h, capi.ptr(capi.as_u64(known)), capi.ptr(flags), len(known)))
+        grp = sharded.ShardGroup.local(shards)
+        grp.set_postings(sharded.postings_view(full))
+        nq = len(qs)
+        for (k, m, n, business) in [(100, 500, 21, False), (1500, 500, 21, True), (40, 80, 5, False), (700, 300, 24, False)]:
+            ref = oix.predict_batch("canonical", flat, qoff, k, m, n, business, threads=4)
+            got = _np(grp.predict_batch(d_flat, d_off, nq, 8, k, m, n, business))
+            _check_oracle(got, ref, n)
+            u = sa.predict_batch(full, (flat, qoff), k, m, n, business)
+            assert np.array_equal(got[0], u[0]) and np.array_equal(got[1], u[1]) and np.array_equal(got[2], u[2])
+        assert grp.stats["neighbour_batches"] == 4
+        launches = C.c_uint64()
+        capi.check(capi.lib().srn_debug_sback_launches(shards[0]._h, C.byref(launches)))
+        assert launches.value == (0 if knob == "SRN_NO_SBACK" else 4), launches.value
+    finally:
+        os.environ.pop("SRN_SBACK_MIN_SHARDS", None)
+        if knob:
+            os.environ.pop(knob, None)
+        capi.reload_knobs()

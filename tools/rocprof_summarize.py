@@ -1,7 +1,7 @@
-"""Turns the raw rocprofv3 csv output of tools/r02_profiles.sh into the tracked summaries under profiles/ (round 2).
-python tools/r02_summarize.py kernel_trace <dir>            > profiles/r02_kernel_trace_cfg3.txt
-python tools/r02_summarize.py traffic <fetch_dir> <write_dir> <config> <batch> > profiles/r02_traffic_cfg3.json
-python tools/r02_summarize.py sq <dir_a> <dir_b> <queries per dispatch> <phase log> > profiles/r02_sq_counters_cfg3.json"""
+"""Turns the raw rocprofv3 csv output of tools/archive/r02_profiles.sh into the tracked summaries under profiles/ (round 2).
+python tools/rocprof_summarize.py kernel_trace <dir>            > profiles/r02_kernel_trace_cfg3.txt
+python tools/rocprof_summarize.py traffic <fetch_dir> <write_dir> <config> <batch> > profiles/r02_traffic_cfg3.json
+python tools/rocprof_summarize.py sq <dir_a> <dir_b> <queries per dispatch> <phase log> > profiles/r02_sq_counters_cfg3.json"""
 import csv, glob, json, re, sys, collections
 
 

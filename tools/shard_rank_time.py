@@ -64,6 +64,10 @@ if os.environ.get("SRN_NB_PHASES"):      # per-phase shader cycles of shard 0's 
     capi.check(capi.lib().srn_debug_phase_cycles(shards[0]._h, 0, capi.ptr(cyc)))
     names = ["0 record+barrier", "1 stage", "2 cuts", "3 merge tree", "4 -", "5", "6", "7", "8 row requests+clears", "9 walk A", "10 phase 4a", "11 live check", "12 walk B+resolve", "13 hand-off", "14", "15"]
     print("phase cycles per query of the batch (front end phases: 1/%d of the queries):" % G, ", ".join("%s %.0f" % (nm, c / B) for nm, c in zip(names, cyc.astype(np.float64)) if c / B > 5))
+    c15, c7 = int(cyc[15]), int(cyc[7])
+    live = c7 & 0xFFFFFFFF
+    print("wave-per-query back end: served %d, live (walk B ran) %d, listed elements / live query %.1f, candidates / served %.1f; handed over by cause: candidates %d, long-fragment queues %d, hit list %d, exact table %d" % (
+        int(cyc[14]), live, cyc[5] / max(1.0, float(live)), cyc[6] / max(1.0, float(cyc[14])), c15 & 0xFFFFF, (c15 >> 20) & 0xFFFFF, (c15 >> 40) & 0xFFFFF, c7 >> 32))
 a = np.median(np.array(res[1:]), axis=0)
 st = grp.stats
 print("%s G=%d batch %d, NEIGHBOURS pipeline, one rank: prep + front end (1/%d of the queries) %.3f ms | back end over all queries %.3f ms | merge %.3f ms -> %.3f ms per batch = %.2f M queries/s "
