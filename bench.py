@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--measure-traffic", dest="measure_traffic", action="store_true", default=True, help="N=1 (default ON where rocprofv3 exists): two extra rocprofv3 --pmc passes "
                     "(FETCH_SIZE, WRITE_SIZE) of this script with 1 + 2 steps, so that roofline.traffic is measured in this run; the committed summary under profiles/ is only a labelled fallback")
     ap.add_argument("--no-measure-traffic", dest="measure_traffic", action="store_false")
+    ap.add_argument("--no-local-g8", action="store_true", help="N = 1: skip the item_sharded.local_g8 block (one rank's work of an 8-way item-sharded index, all 8 shards on this GPU)")
     ap.add_argument("--no-postings", action="store_true", help="N > 1: the lists pipeline (posting lists sharded too: every rank redoes all candidate work on exchanged list prefixes) instead of the neighbours pipeline")
     ap.add_argument("--selftest-launch", action="store_true", help="CPU check of the launcher and the control plane (gloo): no GPU, no timing")
     ap.add_argument("--builder", default="gpu", choices=["gpu", "host"], help="index construction: rocPRIM sorts on the GPU, or the host builder (same bytes)")
@@ -424,7 +425,7 @@ def main():
             for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
                 d = os.path.join(tmp, ctr)
                 cmd = [exe, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__), "--mode", "replicas",
-                       "--config", args.config, "--batch", str(B), "--steps", "2", "--warmup", "1", "--no-sweep", "--no-cpu-baseline", "--no-measure-traffic", "--parity", "0", "--builder", args.builder]
+                       "--config", args.config, "--batch", str(B), "--steps", "2", "--warmup", "1", "--no-sweep", "--no-cpu-baseline", "--no-measure-traffic", "--no-local-g8", "--parity", "0", "--builder", args.builder]
                 env = dict(os.environ, TMPDIR="/tmp")
                 try:
                     r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
@@ -684,6 +685,49 @@ def main():
         result["_parity_checked"] = parity_checked; result["_props_ok"] = props_ok; result["_B"] = B
         return result
 
+    def local_g8_block():
+        """N = 1: what ONE rank of an 8-way item-sharded index does per batch, measured every round by the driver's own run: the index cut in 8, all
+        shards in this process on the one GPU (srn_shard_group_create_local), the NEIGHBOURS pipeline -- the one a multi-GPU run takes -- with the unsharded index as the
+        replicated postings; HIP events around shard 0's own launches (SRN_GROUP_TIMING: the measurement form synchronises per batch).  The collectives degenerate to
+        kernels: their cost over xGMI is NOT in it; the projected node rate is batch / (shard 0's front + back + merge), i.e. one batch stream with free exchanges."""
+        import ctypes as C
+        from serenade_amd import capi as _capi
+        from serenade_amd import sharded as SH8
+        Gl, Bl = 8, int(min(args.shard_batch, 1 << 17))
+        os.environ["SRN_GROUP_TIMING"] = "1"
+        t0 = time.time()
+        shards8 = [SH8.ShardedVMISIndex.from_full(index, g, Gl, device=local_rank) for g in range(Gl)]
+        grp8 = SH8.ShardGroup.local(shards8)
+        os.environ.pop("SRN_GROUP_TIMING", None)
+        grp8.set_postings(index)
+        t_setup = time.time() - t0
+        b8 = draw_batches(Bl, 1, 0)[0]
+        out8 = (torch.empty((Bl, how_many), dtype=torch.int64, device=dev), torch.empty((Bl, how_many), dtype=torch.float64, device=dev), torch.empty(Bl, dtype=torch.int32, device=dev))
+        times = []
+        for it in range(7):
+            grp8.predict_batch(b8[0], b8[1], Bl, last_items, k, m, how_many, False, stream.cuda_stream, out=out8)
+            torch.cuda.synchronize()
+            t3 = (C.c_double * 3)()
+            _capi.check(_capi.lib().srn_debug_shard_group_times(grp8._h, t3))
+            times.append(list(t3))
+        t = np.median(np.array(times[2:]), axis=0)
+        checked = 0
+        if args.parity > 0:
+            pos = gate_positions(Bl, min(args.parity, 1024))
+            checked = gate(out8[0].cpu().numpy().view(np.uint64)[pos], out8[1].cpu().numpy()[pos], out8[2].cpu().numpy().view(np.uint32)[pos], b8[2], b8[3], pos, "8 local shards, neighbours pipeline")
+        st8 = grp8.stats
+        blk = {"n_shards": Gl, "batch": Bl, "pipeline": "neighbours" if st8["neighbour_batches"] else "lists",
+               "rank0_ms": {"prep_and_front_end_over_1_of_%d_of_the_batch" % Gl: float(t[0]), "back_end_over_the_whole_batch": float(t[1]), "topn_merge": float(t[2])},
+               "rank0_ms_total": float(t.sum()), "projected_node_queries_per_s_without_exchanges": Bl / (float(t.sum()) * 1e-3),
+               "ratio_to_one_unsharded_gpu": (Bl / (float(t.sum()) * 1e-3)) / (result["value"] if result is not None else float("nan")),
+               "exchange_bytes_per_query_and_rank": {"neighbour_lists_all_gather": (k + 1) * 4 / Gl, "topn_all_gather": 16 * how_many + 4},
+               "shard0_bytes_hbm": int(shards8[0].info["device_bytes"]), "parity_checked": checked, "parity_checked_positions": "uniform over batch", "setup_s": round(t_setup, 2),
+               "note": "all 8 shards on ONE GPU, collectives degenerate to kernels: what a rank computes per batch, not what xGMI costs; results checked against the oracle"}
+        grp8.close()
+        for s8 in shards8:
+            s8.close()
+        return blk
+
     # ---- the phases.  Replicas first (no data-path collective: nothing in it can hang on a peer); the item-sharded phase runs under a watchdog, and if it
     # fails or stalls the line that is printed is the replicas' with the reason -- a SCALE run never ends without a line. ----
     result = replicas_phase() if do_rep else None
@@ -750,8 +794,19 @@ def main():
             traceback.print_exc()
             shard_error = repr(e)
         wd.cancel()
+    g8 = None
+    if rank == 0 and world == 1 and index is not None and not args.no_local_g8 and args.config in ("cfg3", "cfg2", "tiny", "small"):
+        try:
+            g8 = local_g8_block()
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            g8 = {"error": repr(e)}
     if rank == 0:
-        print(json.dumps(make_line(shard_line, shard_error, sb)))
+        final_line = make_line(shard_line, shard_error, sb)
+        if g8 is not None:
+            final_line.setdefault("item_sharded", {})["local_g8"] = g8
+        print(json.dumps(final_line))
         sys.stdout.flush()
     if shard_error is not None:      # (a communicator in an unknown state: its teardown may wait for peers that are gone -- the line is out, leave)
         sys.stderr.flush()

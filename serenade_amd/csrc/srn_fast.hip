@@ -321,7 +321,13 @@ __device__ __forceinline__ uint32_t fast_cut(const uint32_t* F, uint32_t* nbl, u
 enum { FM_FUSED = 0, FM_FRONT = 1, FM_BACK = 2 };
 // BIG (MID only): the same kernel with 80 KB of LDS -- the merge buffers' room grows from 12 032 to 19 072 words (the per-thread sample constants move to the end), two workgroups per CU --
 // for the queries MID passes on only because 2 n + 264 words do not fit the 53 KB layout (3-4 % of what it is handed on config 3); they come from a third device-side list.
-template <int WG_PER_CU, bool FRAG, bool WIDE, int MODE = FM_FUSED, bool MID = false, bool BIG = false>
+// LONG (round 5, a form of MID + BIG): sessions of 11..20 items (<= 20 lists, numerators up to 255, NEGATIVE weights from the eleventh position on).  Slots are
+// (rank - x_lo) << 5 | (31 - list number): the copies of a session are adjacent in the merged run, the FIRST of them (largest code = most recent position) is its first
+// match (mod.rs:133-140); the m-cut stores that copy and sums the copies' numerators (L - position) into a byte per session; the k-cut's classes are those bytes (256-bin
+// histogram); the neighbour list is 64-bit {slot, signed weight 10 * linear_score(first match) * numerator}.  Direct-mapped accumulators take signed adds, sketch words only the
+// positive ones (they must stay upper bounds: DESIGN.md "Why the sketch filter is exact" holds with acc <= its positive part <= the word); sums <= 0 are no candidates,
+// and a query whose positive scores do not fill the top n goes to the general kernel (an item of score <= 0 could then be returned).
+template <int WG_PER_CU, bool FRAG, bool WIDE, int MODE = FM_FUSED, bool MID = false, bool BIG = false, bool LONG = false>
 #ifndef SRN_FAST_WAVES
 #define SRN_FAST_WAVES (WG_PER_CU * 2)
 #endif
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
 #if SRN_FAST_SMALL
     // static allocation: the compiler then knows every LDS address and folds the region offsets into the instructions' offset fields
     // (with a dynamic allocation each computed address pays a v_add of the -- zero -- base: two per row item in the walks)
-    static_assert(!BIG || MID, "BIG is a form of MID");
+    static_assert(!BIG || MID, "BIG is a form of MID"); static_assert(!LONG || BIG, "LONG is a form of BIG");
     constexpr uint32_t SIDF = BIG ? F_BIG_TOTAL - (F_TOTAL - F_SIDF) : F_SIDF, SATTR = SIDF + 512 * 8;   // per-thread sample constants: behind the merge buffers' room
     constexpr uint32_t MW = (SIDF - F_WORK) / 4;   // words the merge buffers may use (= F_MERGE_WORDS in the 53 KB layout)
     __shared__ __attribute__((aligned(16))) char smem[BIG ? F_BIG_TOTAL : F_TOTAL];
@@ -344,7 +350,7 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
     const __attribute__((address_space(4))) LaunchParams& p = *(const __attribute__((address_space(4))) LaunchParams*)(ka + OFF_P);
     const __attribute__((address_space(4))) FastParams& f = *(const __attribute__((address_space(4))) FastParams*)(ka + OFF_F);
     constexpr int BLOCK = 512, NW = 8;
-    constexpr int NL = MID ? (int)F_MID_LISTS : 4;             // lists a query may have
+    constexpr int NL = LONG ? (int)F_LONG_LISTS : MID ? (int)F_MID_LISTS : 4;             // lists a query may have
     constexpr uint32_t SINV = F_SINV;                           // idf bounds of the integer floors
     static_assert(!MID || MODE == FM_FUSED, "MID: fused form only");
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -364,6 +370,9 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
     uint32_t* surv = (uint32_t*)(smem + F_SURV);
     constexpr uint32_t SURV_CAP = F_SURV_WORDS - 256u;
     uint32_t* const cls_area = BIG ? (uint32_t*)(smem + SIDF) - 256 : surv + SURV_CAP;   // MID's class histogram of the k-cut: the last 256 words of the merge buffers' room
+    // LONG: below it the numerator bytes of the m-cut's sessions, below those the 64-bit neighbour list (all beyond F_LDS_BYTES: the walks do not touch them)
+    uint32_t* const dn_area = cls_area - F_M_MAX / 4u;
+    uint2* const nb2 = reinterpret_cast<uint2*>(dn_area - F_K_MAX * 2u);
     uint32_t* thist = surv + SURV_CAP;                    // 256 bins: the sample's candidates by the top 16 bits of x, relative to the first threshold
     // numerator / 10 * linear_score(first match) * numerator of a slot's list set.  Lean: one table entry per set (16 sets).  MID (<= 10 lists: 1 024 sets): the set is split into
     // lists 0..4 and 5..9 -- wlut[0..31] / [32..63] = the halves' numerators (they add), wlut[64..95] / [96..127] = the halves' first-match positions (the low half wins)
@@ -390,7 +399,7 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
     { const ItemMeta m0 = f.meta_sample[tid];
       ((double*)(smem + SIDF))[tid] = m0.idf > 0.0 ? m0.idf : 1.0; ((uint8_t*)(smem + SATTR))[tid] = (uint8_t)m0.attr;   // (own slot only: no barrier)
       if (tid < 16u) ((double*)(smem + SINV))[tid] = tid < 8u ? f.inv_idf_hot[tid] : f.inv_idf_hi; }   // (read in phase 4a: barriers in between)
-    const uint32_t q_end = BIG ? *f.bigq_cnt : MID ? *f.mid_cnt : p.nq;   // (MID: the list is final -- the lean instantiation's launch is over)
+    const uint32_t q_end = LONG ? *f.long_cnt : BIG ? *f.bigq_cnt : MID ? *f.mid_cnt : p.nq;   // (MID: the list is final -- the lean instantiation's launch is over)
     // The serving order (round 5, f.order; lean fused and back-end forms): the batch sorted by each query's most popular item and dealt to the XCDs chunk by chunk (ord_pos,
     // srn_device.h): one XCD's L2 sees runs of like queries, whose posting lists and neighbour rows are largely the same lines.  Without an order: query index order,
     // workgroup b serves b, b + gridDim, ...
@@ -399,7 +408,7 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
     const uint32_t qi_step = ordered ? gridDim.x >> 3 : gridDim.x;
     const uint32_t qi_end = ordered ? ord_count(p.nq, ox) : q_end;
     for (uint32_t qi = ordered ? blockIdx.x >> 3 : (MODE == FM_FRONT ? f.q_base : 0u) + blockIdx.x; qi < qi_end; qi += qi_step) {
-        const uint32_t q = BIG ? f.bigq_list[qi] : MID ? f.mid_list[qi] : ordered ? (uint32_t)f.order[ord_pos(ox, qi)] : qi;
+        const uint32_t q = LONG ? f.long_list[qi] : BIG ? f.bigq_list[qi] : MID ? f.mid_list[qi] : ordered ? (uint32_t)f.order[ord_pos(ox, qi)] : qi;
         const uint32_t q_ord_next = ordered && qi + qi_step < qi_end ? (uint32_t)f.order[ord_pos(ox, qi + qi_step)] : 0xFFFFFFFFu;   // (the query this workgroup serves next: its record is parked during this one)
 #ifndef SRN_MID_PREFETCH
 #define SRN_MID_PREFETCH 0   // (experiment, measured flat: 7.73 / 8.61 ms per 2^18 queries at max_items 8 / 10 with or without it, and 16 bytes of scratch with)
@@ -415,11 +424,11 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
         if (have_pre) {
             auto uni = [&](uint32_t w) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)pre[w]); };   // (SGPRs: the branches on these stay scalar)
             hd.U = uni(0); hd.rmax = uni(1); hd.xlo = uni(2); hd.sumw = uni(3); hd.L = uni(6); hd.n_staged = uni(7); hd.cur_attr = uni(16);
-            if (lane < (MID ? 16u : 8u) && lane < hd.L) { const uint32_t* it = pre + HW + 6u * lane; x0.idx = it[0]; x0.kept = it[3]; x0.base = ((unsigned long long)it[5] << 32) | it[4]; }
+            if (lane < (LONG ? 32u : MID ? 16u : 8u) && lane < hd.L) { const uint32_t* it = pre + HW + 6u * lane; x0.idx = it[0]; x0.kept = it[3]; x0.base = ((unsigned long long)it[5] << 32) | it[4]; }
         } else {
             const PrepHead h0 = *(const PrepHead*)rec;   // (uniform address)
             hd.U = h0.U; hd.rmax = h0.rmax; hd.xlo = h0.xlo; hd.sumw = h0.sumw; hd.L = h0.L; hd.n_staged = h0.n_staged; hd.cur_attr = h0.cur_attr;
-            if ((MID ? lane < 16u && lane < p.max_len : lane < 8u) && lane < hd.L) { const PrepItem pi = ((const PrepItem*)(rec + sizeof(PrepHead)))[lane]; x0.idx = pi.idx; x0.kept = pi.kept; x0.base = pi.base; }
+            if ((MID ? lane < (LONG ? 32u : 16u) && lane < p.max_len : lane < 8u) && lane < hd.L) { const PrepItem pi = ((const PrepItem*)(rec + sizeof(PrepHead)))[lane]; x0.idx = pi.idx; x0.kept = pi.kept; x0.base = pi.base; }
         }
         have_pre = false;
         const uint32_t L = hd.L, n = hd.n_staged, U = hd.U;
@@ -431,16 +440,23 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
         // Slot = (rank - base) << NB | set of lists.  Normally NB = 4 (WIDE, above 2^28 sessions: 3) and base = 0.  A query with MORE lists than bits
         // (4 lists on an index of > 2^28 sessions) takes NB = 4 with the ranks counted from the cut x_lo -- every staged entry is >= x_lo -- if that fits 28 bits.
         const bool rel = MID || (WIDE && nr > 3u);   // (block-uniform)
-        const uint32_t NB = MID ? max(nr, 4u) : WIDE && !rel ? 3u : 4u, NBM = (1u << NB) - 1u, base = rel ? hd.xlo : 0u;
+        const uint32_t NB = LONG ? F_LONG_NB : MID ? max(nr, 4u) : WIDE && !rel ? 3u : 4u, NBM = (1u << NB) - 1u, base = rel ? hd.xlo : 0u;
         // (MID: the last 256 words of the merge buffers' room hold the class histogram of the k-cut)
-        const bool fits = MID ? L >= 1u && L <= F_MID_LMAX && L <= p.max_len && hd.sumw <= F_MID_CLASSES && nr <= F_MID_LISTS && 2u * n + 8u + 256u <= MW && hd.rmax - hd.xlo < (1u << (32u - NB))
+        const bool fits = LONG ? L >= 1u && L <= F_LONG_LMAX && L <= p.max_len && hd.sumw <= F_LONG_CLASSES && nr <= F_LONG_LISTS && 2u * n + 8u + F_LONG_RES_WORDS <= MW && hd.rmax - hd.xlo < (1u << (32u - F_LONG_NB))
+                        : MID ? L >= 1u && L <= F_MID_LMAX && L <= p.max_len && hd.sumw <= F_MID_CLASSES && nr <= F_MID_LISTS && 2u * n + 8u + 256u <= MW && hd.rmax - hd.xlo < (1u << (32u - NB))
                               : L >= 1u && L <= 8u && L <= p.max_len && hd.sumw <= 15u && nr <= 4u && 2u * n + 8u <= MW && (!rel || hd.rmax - hd.xlo < (1u << 28));
         uint32_t* const xq = MODE == FM_FUSED ? nullptr : f.xchg + (size_t)q * f.xchg_stride;   // this query's place in the exchange buffer: K | K slots
         if (!fits) {   // block-uniform: the general kernel takes it
             if constexpr (MODE == FM_FRONT) { if (tid == 0) xq[0] = 0xFFFFFFFFu; }   // (every rank's back end reads the marker and hands the query to its general kernel)
             else if (tid == 0) {
+                // (round 5) a query of the lean shape whose merged lists alone outgrow the 53 KB layout -- the headline batches' 0.3 % -- goes straight to the BIG form (80 KB of
+                // LDS: n <= 9 404), not to the general kernel: 3 209 such queries per 2^20 cost 0.27 ms there
+                if (!MID && MODE == FM_FUSED && f.bigq_list != nullptr && L >= 1u && L <= 8u && L <= p.max_len && hd.sumw <= 15u && nr <= 4u && hd.rmax - hd.xlo < (1u << 28) &&
+                    2u * n + 8u + 256u <= (F_BIG_TOTAL - (F_TOTAL - F_SIDF) - F_WORK) / 4u) f.bigq_list[atomicAdd(f.bigq_cnt, 1u)] = q;
                 // (the MID instantiation looks at the query next, if this launch sequence has one; it decides for itself)
-                if (!MID && MODE == FM_FUSED && f.mid_list != nullptr && L >= 1u && L <= F_MID_LMAX && L <= p.max_len) f.mid_list[atomicAdd(f.mid_cnt, 1u)] = q;
+                else if (!MID && MODE == FM_FUSED && f.mid_list != nullptr && L >= 1u && L <= F_MID_LMAX && L <= p.max_len) f.mid_list[atomicAdd(f.mid_cnt, 1u)] = q;
+                // (... and the LONG one at sessions of 11..20 items)
+                else if (!MID && MODE == FM_FUSED && f.long_list != nullptr && L > F_MID_LMAX && L <= F_LONG_LMAX && L <= p.max_len) f.long_list[atomicAdd(f.long_cnt, 1u)] = q;
                 else if (MID && !BIG && f.bigq_list != nullptr && L >= 1u && L <= F_MID_LMAX && L <= p.max_len && hd.sumw <= F_MID_CLASSES && nr <= F_MID_LISTS && hd.rmax - hd.xlo < (1u << (32u - NB)) &&
                          2u * n + 8u + 256u <= (F_BIG_TOTAL - (F_TOTAL - F_SIDF) - F_WORK) / 4u) f.bigq_list[atomicAdd(f.bigq_cnt, 1u)] = q;   // (only the merge buffers' room is missing: MID's BIG form has it)
                 else f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q;
@@ -504,6 +520,14 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
         }
         // A slot's low bits are the set of RUNS (not evolving positions) that hold the session: <= 4 runs, so 4 bits (3 above 2^28 sessions, see NB above) whatever the
         // session length, and 28 (29) bits for the rank.  Runs are numbered in position order, so the lowest set run is the first match (Q4).
+        if constexpr (LONG) {   // by list code (31 - list number): wlut[code] = the list's numerator share L - position, wlut[32 + code] = its position
+            if (tid < 32u) {
+                uint32_t pr = 0u;
+#pragma unroll
+                for (int r = 0; r < NL; ++r) pr = tid == (uint32_t)(31 - r) ? ps[r] : pr;
+                wlut[tid] = (uint8_t)(L - pr); wlut[32u + tid] = (uint8_t)pr;   // (codes of lists the query does not have are never looked up)
+            }
+        } else
         if constexpr (MID) {
             if (tid < 64u) {   // (two halves of 5 lists; 10 * linear_score(first match) = 9 - mp: 0 at the tenth position)
                 const uint32_t half = tid >> 5, hs = tid & 31u;
@@ -529,7 +553,9 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
             // its first min(n, m) entries, the neighbours the first k of those.  No merge, no m-cut, no k-cut: the list goes straight into the neighbour list.
             K = min(kp[0], p.k);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { const uint32_t e = tid + j * BLOCK; if ((uint32_t)j * BLOCK < K && e < K) nbl[e] = ((v[0][j] - base) << NB) | 1u; }
+            for (int j = 0; j < 3; ++j) { const uint32_t e = tid + j * BLOCK; if ((uint32_t)j * BLOCK < K && e < K) {
+                if constexpr (LONG) nb2[e] = make_uint2(((v[0][j] - base) << NB) | 31u, (uint32_t)((9 - (int)ps[0]) * (int)(L - ps[0])));   // (one class, one weight)
+                else nbl[e] = ((v[0][j] - base) << NB) | 1u; } }
             __syncthreads();
             FAST_TICK(1);
         } else {
@@ -540,7 +566,7 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
         if constexpr (MID) {
             // lists 0..3 are in flight since before the barrier; the others take one more round trip (only queries of > 4 lists pay it).  Everything is staged into ONE
             // buffer at the lists' prefix offsets, the one from which nlev merge levels end in B0.
-            const uint32_t nlev = nr <= 2u ? 1u : nr <= 4u ? 2u : nr <= 8u ? 3u : 4u;
+            const uint32_t nlev = nr <= 2u ? 1u : nr <= 4u ? 2u : nr <= 8u ? 3u : nr <= 16u ? 4u : 5u;
             uint32_t* const X = (nlev & 1u) ? B1 : B0; uint32_t* const Y = (nlev & 1u) ? B0 : B1;
             uint32_t pre_r[NL];
             { uint32_t a = 0u;
@@ -549,7 +575,7 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int j = 0; j < 5; ++j) { const uint32_t e = tid + j * BLOCK; if ((uint32_t)j * BLOCK < kp[r] && e < kp[r]) X[pre_r[r] + e] = ((v[r][j] - base) << NB) | (1u << r); }
+                for (int j = 0; j < 5; ++j) { const uint32_t e = tid + j * BLOCK; if ((uint32_t)j * BLOCK < kp[r] && e < kp[r]) X[pre_r[r] + e] = ((v[r][j] - base) << NB) | (LONG ? 31u - (uint32_t)r : 1u << r); }
 #pragma unroll
             for (int b4 = 4; b4 < NL; b4 += 4) {
                 if (nr > (uint32_t)b4) {   // (block-uniform)
@@ -565,7 +591,7 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
 #pragma unroll
                     for (int r = 0; r < R4; ++r)
 #pragma unroll
-                        for (int j = 0; j < 5; ++j) { if (b4 + r < NL) { const int rr = b4 + r < NL ? b4 + r : 0; const uint32_t e = tid + j * BLOCK; if ((uint32_t)j * BLOCK < kp[rr] && e < kp[rr]) X[pre_r[rr] + e] = ((v[r][j] - base) << NB) | (1u << rr); } }
+                        for (int j = 0; j < 5; ++j) { if (b4 + r < NL) { const int rr = b4 + r < NL ? b4 + r : 0; const uint32_t e = tid + j * BLOCK; if ((uint32_t)j * BLOCK < kp[rr] && e < kp[rr]) X[pre_r[rr] + e] = ((v[r][j] - base) << NB) | (LONG ? 31u - (uint32_t)rr : 1u << rr); } }
                 }
             }
             __syncthreads();
@@ -577,7 +603,7 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
             for (int r = 0; r < NL; ++r) len[r] = kp[r];
             uint32_t runs = nr; const uint32_t* in = X; uint32_t* out = Y;
 #pragma unroll
-            for (int lev = 0; lev < 4; ++lev) {
+            for (int lev = 0; lev < (LONG ? 5 : 4); ++lev) {
                 if ((uint32_t)lev < nlev) {   // (block-uniform)
                     uint32_t off = 0u, start = 0u;
 #pragma unroll
@@ -640,7 +666,8 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
             } else
                 for (uint32_t o = o0; o < o1; ++o) { const uint32_t r = F[o] >> NB; firsts += r != prev; prev = r; }
             for (uint32_t i = tid; i < min(n, p.m); i += BLOCK) D[i] = 0;
-            if (MID && tid < 64u) cls_area[tid] = 0u;   // (the k-cut's class histogram: the tail of the merge buffers' room, see `fits`)
+            if (MID && tid < (LONG ? 256u : 64u)) cls_area[tid] = 0u;   // (the k-cut's class histogram: the tail of the merge buffers' room, see `fits`)
+            if constexpr (LONG) for (uint32_t i = tid; i < (min(n, p.m) + 3u) / 4u; i += BLOCK) dn_area[i] = 0u;   // (a numerator byte per kept session)
             uint32_t idx = block_excl_scan<BLOCK>(firsts, misc + FS_SCAN_A, Call);   // (barrier inside)
             prev = prev0;
             if (g <= (uint32_t)MC_G) {
@@ -649,14 +676,19 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
                 for (int x = 0; x < MC_G; ++x) fv[x] = F[min(o0 + (uint32_t)x, n - 1u)];
 #pragma unroll
                 for (int x = 0; x < MC_G; ++x) {
-                    const bool in = o0 + (uint32_t)x < o1; const uint32_t r = fv[x] >> NB;
-                    idx += in && r != prev; prev = in ? r : prev;
+                    const bool in = o0 + (uint32_t)x < o1; const uint32_t r = fv[x] >> NB; const bool f1 = in && r != prev;
+                    idx += f1; prev = in ? r : prev;
+                    if constexpr (LONG) {   // the group's first copy (largest code: the first match) is the session's slot; every copy adds its list's share of the numerator
+                        if (in && idx - 1u < p.m) { if (f1) D[idx - 1u] = fv[x]; atomicAdd(&dn_area[(idx - 1u) >> 2], (uint32_t)wlut[fv[x] & 31u] << (8u * ((idx - 1u) & 3u))); }
+                    } else
                     if (in && idx - 1u < p.m) atomicOr(&D[idx - 1u], fv[x]);
                 }
             } else
                 for (uint32_t o = o0; o < o1; ++o) {
-                    const uint32_t v = F[o], r = v >> NB;
-                    idx += r != prev; prev = r;
+                    const uint32_t v = F[o], r = v >> NB; const bool f1 = r != prev;
+                    idx += f1; prev = r;
+                    if constexpr (LONG) { if (idx - 1u < p.m) { if (f1) D[idx - 1u] = v; atomicAdd(&dn_area[(idx - 1u) >> 2], (uint32_t)wlut[v & 31u] << (8u * ((idx - 1u) & 3u))); } }
+                    else
                     if (idx - 1u < p.m) atomicOr(&D[idx - 1u], v);
                 }
             Cm = min(Call, p.m);
@@ -664,15 +696,19 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
         __syncthreads();
         FAST_TICK(2);
         // ---- k-cut: D is ordered by recency, so inside one numerator class the order is already the wanted one ----
-        if (Cm <= p.k) K = Cm;   // (block-uniform; the m-cut wrote the neighbour list)
-        else {
+        auto dn_of = [&](uint32_t i) -> uint32_t { return (dn_area[i >> 2] >> (8u * (i & 3u))) & 255u; };                               // LONG: numerator of the m-cut's i-th session
+        auto w_long = [&](uint32_t slot, uint32_t num) -> uint32_t { return (uint32_t)((9 - (int)(uint32_t)wlut[32u + (slot & 31u)]) * (int)num); };   // 10 * linear_score(first match) * numerator, signed
+        if (Cm <= p.k) {   // (block-uniform; the m-cut wrote the neighbour list)
+            K = Cm;
+            if constexpr (LONG) { for (uint32_t i = tid; i < Cm; i += BLOCK) { const uint32_t dvv = D[i]; nb2[i] = make_uint2(dvv, w_long(dvv, dn_of(i))); } __syncthreads(); }
+        } else {
             uint32_t* cls = MID ? cls_area : misc + FS_CLS;
             const uint32_t g = (Cm + BLOCK - 1) / BLOCK, o0 = min(tid * g, Cm), o1 = min(o0 + g, Cm);   // g <= 5
             uint32_t dv[5], nmv[5];
 #pragma unroll
             for (int x = 0; x < 5; ++x) dv[x] = o0 + x < o1 ? D[o0 + x] : 0u;
 #pragma unroll
-            for (int x = 0; x < 5; ++x) nmv[x] = o0 + x < o1 ? num_of(dv[x] & NBM) : 0u;   // (class 0 does not exist)
+            for (int x = 0; x < 5; ++x) { if constexpr (LONG) nmv[x] = o0 + x < o1 ? dn_of(o0 + (uint32_t)x) : 0u; else nmv[x] = o0 + x < o1 ? num_of(dv[x] & NBM) : 0u; }   // (class 0 does not exist)
             if constexpr (MID) {   // <= 63 classes: a histogram in LDS (lane v of the scan below = class v)
 #pragma unroll
                 for (int x = 0; x < 5; ++x) if (o0 + x < o1) atomicAdd(&cls[nmv[x]], 1u);
@@ -696,6 +732,18 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
             }
             __syncthreads();
             uint32_t nstar, rstar;
+            if constexpr (LONG) {   // 256 classes: lane l holds classes 4 l .. 4 l + 3; suffix sums from the best class down, the boundary class is the highest one whose suffix reaches k
+                const uint4 c4 = reinterpret_cast<const uint4*>(cls)[lane];
+                const uint32_t s4 = c4.x + c4.y + c4.z + c4.w, pre4 = wave_incl_scan(s4);
+                const uint32_t above = (uint32_t)__builtin_amdgcn_readlane((int)pre4, 63) - pre4;   // entries in the classes of higher lanes
+                const uint32_t suf3 = above + c4.w, suf2 = suf3 + c4.z, suf1 = suf2 + c4.y, suf0 = suf1 + c4.x;
+                const unsigned long long reach = __ballot(suf0 >= p.k);
+                const int top = 63 - __clzll((long long)reach);
+                const uint32_t jsel = suf3 >= p.k ? 3u : suf2 >= p.k ? 2u : suf1 >= p.k ? 1u : 0u;
+                const uint32_t sufs = jsel == 3u ? suf3 : jsel == 2u ? suf2 : jsel == 1u ? suf1 : suf0, cnts = jsel == 3u ? c4.w : jsel == 2u ? c4.z : jsel == 1u ? c4.y : c4.x;
+                nstar = (uint32_t)__builtin_amdgcn_readlane((int)(4u * lane + jsel), top);
+                rstar = p.k - ((uint32_t)__builtin_amdgcn_readlane((int)sufs, top) - (uint32_t)__builtin_amdgcn_readlane((int)cnts, top));
+            } else
             {   // lane v holds class v: suffix sums from the best class down; the boundary class is the highest one whose suffix reaches k
                 const uint32_t cv = (MID || lane < 16u) ? cls[lane] : 0u; const uint32_t pre = wave_incl_scan(cv);
                 const uint32_t suf = (uint32_t)__builtin_amdgcn_readlane((int)pre, 63) - pre + cv;
@@ -719,7 +767,7 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
             uint32_t base = 0; if (lane == 63u && inc) base = atomicAdd(&misc[FS_NB], inc);
             uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)base, 63) + inc - sel;
 #pragma unroll
-            for (int x = 0; x < 5; ++x) if (take[x]) nbl[at++] = dv[x];
+            for (int x = 0; x < 5; ++x) if (take[x]) { if constexpr (LONG) nb2[at++] = make_uint2(dv[x], w_long(dv[x], nmv[x])); else nbl[at++] = dv[x]; }
             __syncthreads();
             K = misc[FS_NB];
         }
@@ -737,10 +785,12 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
 
         // ---- walk A: one neighbour row per lane; the first 16 bytes (6 items) of all the wave's rows requested at once, the next 16 only where a row has them ----
         uint32_t svr[3]; uint4 rq[3], rq1[3];
+        uint32_t wvr[3] = {0u, 0u, 0u};   // LONG: the neighbours' signed weights (everywhere else a weight is a table look-up on the slot's list set)
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const uint32_t j = wave * 64u + lane + (uint32_t)t * BLOCK;
             if constexpr (MODE == FM_BACK) svr[t] = j < K ? xsv[t] : 0u;   // (slots past K are stale words: the idle lanes read the empty row)
+            else if constexpr (LONG) { const uint2 e2 = nb2[K ? min(j, K - 1u) : 0u]; svr[t] = K ? e2.x : 0u; wvr[t] = e2.y; }
             else
             svr[t] = K ? nbl[min(j, K - 1u)] : 0u;   // (all loads unconditional: a load inside a branch is waited for at the branch's end)
             const size_t r = (MODE == FM_BACK ? j < K : K != 0u) ? (size_t)(base + (svr[t] >> NB)) : (size_t)n_kept;   // (idle lanes re-read the last neighbour's row)
@@ -757,8 +807,15 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
         __syncthreads();   // (also: every wave holds its neighbour slots in registers, the list's LDS is free for the queue)
         FAST_PRIO(FP_WALK);
         FAST_TICK(8);
+        // (LONG: a negative weight goes to the exact words only -- direct-mapped and replicas: offsets below the sketch --; a sketch word sums positive parts and stays an
+        //  upper bound of every item that shares it; a dump word takes anything)
         auto add2 = [&](uint32_t wd, uint32_t w) {
-            atomicAdd((uint32_t*)(acc_base + (wd & 0xFFFFu)), w); atomicAdd((uint32_t*)(acc_base + (wd >> 16)), w); };
+            if constexpr (LONG) {
+                const bool neg = (int)w < 0; const uint32_t a = wd & 0xFFFFu, b = wd >> 16;
+                if (!neg || a < F_SKETCH - F_HOT) atomicAdd((uint32_t*)(acc_base + a), w);
+                if (!neg || b < F_SKETCH - F_HOT) atomicAdd((uint32_t*)(acc_base + b), w);
+            } else {
+            atomicAdd((uint32_t*)(acc_base + (wd & 0xFFFFu)), w); atomicAdd((uint32_t*)(acc_base + (wd >> 16)), w); } };
         constexpr uint32_t INL1 = FRAG ? 6u : 14u, INL2 = FRAG ? 20u : 28u;   // items served by round (i) / before the overflow loop
         // rows of > 14 items queue for round (ii) in the wave's own 192 list slots (their session slots are in registers by now)
         uint32_t cnt3 = 0;
@@ -766,7 +823,7 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
         for (int t = 0; t < 3; ++t) {
             const bool m3 = wave * 64u + lane + (uint32_t)t * BLOCK < K && (rq[t].x & 0xFFFFu) > INL1;
             const unsigned long long b3 = __ballot(m3);
-            if (m3) nbl[qpos(cnt3 + (uint32_t)__popcll(b3 & lt))] = svr[t];
+            if (m3) nbl[qpos(cnt3 + (uint32_t)__popcll(b3 & lt))] = LONG ? wave * 64u + lane + (uint32_t)t * BLOCK : svr[t];   // (LONG queues the neighbour's INDEX: slot and weight are looked up in nb2)
             cnt3 += (uint32_t)__popcll(b3);
         }
 #ifdef SRN_FAST_SUBTICKS
@@ -785,8 +842,12 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
         // round (ii)'s first batch is requested BEFORE round (i)'s adds, which hide its latency (L2 hits: the lines came with round (i))
         // (FRAG: the queued fragments continue in their overflow blocks: c4 = items 4..11, d4 = items 12..19 if the fragment has that many; blk = the block the
         //  overflow loop starts at)
-        auto q3_load = [&](uint32_t p0, uint32_t& sv, uint32_t& hdr, uint4& c4, uint4& d4, uint32_t& blk) {
-            sv = nbl[qpos(min(p0 + lane, cnt3 - 1u))];
+        auto tok_slot = [&](uint32_t tok) -> uint32_t { if constexpr (LONG) return nb2[tok].x; else return tok; };
+        auto tok_w = [&](uint32_t tok, uint32_t slot) -> uint32_t { if constexpr (LONG) return nb2[tok].y; else return w10_of(slot & NBM); };
+        // (tok: what the queue holds for the lane -- the slot itself, or (LONG) the neighbour's index)
+        auto q3_load = [&](uint32_t p0, uint32_t& tok, uint32_t& sv, uint32_t& hdr, uint4& c4, uint4& d4, uint32_t& blk) {
+            tok = nbl[qpos(min(p0 + lane, cnt3 - 1u))];
+            sv = tok_slot(tok);
             if constexpr (FRAG) {
                 const uint4 s4 = *reinterpret_cast<const uint4*>(f.row_packed + (size_t)(base + (sv >> NB)));
                 hdr = s4.x;
@@ -796,8 +857,8 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
                 const RowQuad* rowp = f.row_packed + (size_t)(base + (sv >> NB)) * 4;
                 hdr = *reinterpret_cast<const uint32_t*>(rowp); c4 = *reinterpret_cast<const uint4*>(rowp + 2); d4 = *reinterpret_cast<const uint4*>(rowp + 3); blk = d4.w;
             } };
-        uint32_t sv3 = 0, hdr3 = 0, blk3 = 0; uint4 c43 = make_uint4(0u, 0u, 0u, 0u), d43 = c43;
-        if (cnt3) q3_load(0u, sv3, hdr3, c43, d43, blk3);   // (wave-uniform)
+        uint32_t tk3 = 0, sv3 = 0, hdr3 = 0, blk3 = 0; uint4 c43 = make_uint4(0u, 0u, 0u, 0u), d43 = c43;
+        if (cnt3) q3_load(0u, tk3, sv3, hdr3, c43, d43, blk3);   // (wave-uniform)
         // the next query's record: requested by wave 1 HERE -- behind its own row requests, with no other load of the wave due for thousands of cycles (loads return
         // in order: anywhere else the record's HBM round trip would sit in front of data the wave needs at once); it lands in LDS by itself, the wave
         // waits for it at the end of phase 4a, before the barrier that everybody passes on the way to the next query
@@ -812,7 +873,7 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
         for (int t = 0; t < 3; ++t) {   // (i) items 0..13
             if (wave * 64u + (uint32_t)t * BLOCK < K) {
                 const bool act = wave * 64u + lane + (uint32_t)t * BLOCK < K;
-                const uint32_t w = w10_of(svr[t] & NBM), len = rq[t].x & 0xFFFFu;
+                const uint32_t w = LONG ? wvr[t] : w10_of(svr[t] & NBM), len = rq[t].x & 0xFFFFu;
                 if constexpr (FRAG) { if (act) { add2(rq[t].y, w); add2(rq[t].z, w); if (len <= 6u) add2(rq[t].w, w); } }
                 else {
                 if (act) { add2(rq[t].y, w); add2(rq[t].z, w); add2(rq[t].w, w); }
@@ -820,9 +881,9 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
                 }
             }
         }
-        auto add_tail = [&](uint32_t p0, uint32_t sv, uint32_t hdr, const uint4& c4, const uint4& d4, uint32_t blk) {   // items 14..29 (FRAG: 4..19), then the overflow blocks
+        auto add_tail = [&](uint32_t p0, uint32_t tok, uint32_t sv, uint32_t hdr, const uint4& c4, const uint4& d4, uint32_t blk) {   // items 14..29 (FRAG: 4..19), then the overflow blocks
             const bool act = p0 + lane < cnt3;
-            const uint32_t len = hdr & 0xFFFFu, w = w10_of(sv & NBM);
+            const uint32_t len = hdr & 0xFFFFu, w = tok_w(tok, sv);
             const bool more = FRAG ? true : len > 30u;   // (a slot without overflow blocks keeps items in the words the others use for the block index)
             if constexpr (FRAG) {
                 if (act) { add2(c4.x, w); add2(c4.y, w); add2(c4.z, w); add2(c4.w, w); }
@@ -842,8 +903,8 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
         FAST_TICK(6);   // (round (i): second 16 bytes + adds issued)
 #endif
         FAST_PRIO_X(1);
-        if (cnt3) add_tail(0u, sv3, hdr3, c43, d43, blk3);
-        for (uint32_t p0 = 64u; p0 < cnt3; p0 += 64u) { uint32_t sv, hdr, blk; uint4 c4, d4; q3_load(p0, sv, hdr, c4, d4, blk); add_tail(p0, sv, hdr, c4, d4, blk); }
+        if (cnt3) add_tail(0u, tk3, sv3, hdr3, c43, d43, blk3);
+        for (uint32_t p0 = 64u; p0 < cnt3; p0 += 64u) { uint32_t tk, sv, hdr, blk; uint4 c4, d4; q3_load(p0, tk, sv, hdr, c4, d4, blk); add_tail(p0, tk, sv, hdr, c4, d4, blk); }
 #ifdef SRN_FAST_SUBTICKS
         FAST_TICK(7);   // (wave 0's tail rounds done; what follows is the wait for the other waves)
 #endif
@@ -865,7 +926,7 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
                 v = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
             }
             for (uint32_t i = tid; i < F_DUMP_WORDS; i += BLOCK) ((uint32_t*)(smem + F_DUMP))[i] = 0u;   // (walk B reads the dump words, where the positions past a row's end point, as "cannot reach the floor")
-            bool valid = v != 0u && e != cur_idx;
+            bool valid = (LONG ? (int)v > 0 : v != 0u) && e != cur_idx;   // (LONG: sums are signed; an item whose sum is <= 0 is no candidate and sets no threshold)
             double x = 0.0; uint32_t tie = 0;
             // idf_eff and the attribute byte come from the thread's LDS slot; only the id rank (wanted after the barrier below, for the few candidates) is a
             // global load -- nothing on the way to the wave reductions waits for memory
@@ -915,15 +976,15 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
                 const uint32_t fl1 = (uint32_t)__builtin_amdgcn_readlane((int)my_floor, (int)(1u + (wv >> 1)));          // floors of this wave's two chunks (lane c of my_floor = chunk c)
                 const uint32_t fl2 = (uint32_t)__builtin_amdgcn_readlane((int)my_floor, (int)min(5u + (wv >> 1), 7u));
                 auto quad = [&](const uint4& q4, uint32_t e0, uint32_t fl) {
-                    const uint32_t mx = max(max(q4.x, q4.y), max(q4.z, q4.w));
+                    const uint32_t mx = LONG ? (uint32_t)max(max(max((int)q4.x, (int)q4.y), max((int)q4.z, (int)q4.w)), 0) : max(max(q4.x, q4.y), max(q4.z, q4.w));   // (LONG: signed sums)
                     if (__ballot(mx >= fl) == 0ull) return;
                     const uint32_t vv[4] = {q4.x, q4.y, q4.z, q4.w};
 #pragma unroll
                     for (uint32_t j = 0; j < 4u; ++j) {
                         const uint32_t e2 = e0 + j;
-                        const bool pass = vv[j] >= fl && e2 != cur_idx && e2 < F_DIRECT;   // (the words from F_DIRECT up are the replicas of the hottest items, already in the sample)
+                        const bool pass = (LONG ? (int)vv[j] >= (int)fl : vv[j] >= fl) && e2 != cur_idx && e2 < F_DIRECT;   // (the words from F_DIRECT up are the replicas of the hottest items, already in the sample)
                         const uint32_t at2 = wave_append(pass, &misc[FS_SURV]);
-                        if (pass) { if (at2 < SURV_CAP) surv[at2] = (e2 << 20) | vv[j]; else atomicOr(&misc[FS_FAIL], 2u); }
+                        if (pass) { if (at2 < SURV_CAP && vv[j] < (1u << 20)) surv[at2] = (e2 << 20) | vv[j]; else atomicOr(&misc[FS_FAIL], 2u); }   // (a survivor packs 20 bits of sum: LONG sums can pass them -- the general kernel then)
                     } };
                 quad(a4, 512u + 4u * tid, fl1);
                 quad(b4, 512u + 4u * ((uint32_t)BLOCK + tid), fl2);
@@ -1007,7 +1068,7 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
             auto mx2 = [&](uint32_t mx, uint32_t wd) -> uint32_t {
                 const uint32_t a = *(const uint32_t*)(acc_base + max(wd & 0xFFFFu, F_ZERO_OFF)), b = *(const uint32_t*)(acc_base + max(wd >> 16, F_ZERO_OFF));
                 return max(max(mx, a), b); };
-            uint32_t sv3b = 0, hdr3b = 0, blk3b = 0; uint4 c43b = make_uint4(0u, 0u, 0u, 0u), d43b = c43b;
+            uint32_t tk3b = 0, sv3b = 0, hdr3b = 0, blk3b = 0; uint4 c43b = make_uint4(0u, 0u, 0u, 0u), d43b = c43b;
 #if SRN_FAST_RELOAD_ROWS
             // the rows' first 32 bytes again (L2 hits), all requested at once: keeping them in registers since walk A costs 24 VGPRs
             // across phase 4a -- at the 80-register cap of three workgroups per CU that means scratch spills on the serial paths
@@ -1018,7 +1079,7 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
                 rq1[t] = *reinterpret_cast<const uint4*>(&f.row_packed[r * 4 + 1]);
             }
 #endif
-            if (cnt3) q3_load(0u, sv3b, hdr3b, c43b, d43b, blk3b);   // requested before round (i)
+            if (cnt3) q3_load(0u, tk3b, sv3b, hdr3b, c43b, d43b, blk3b);   // requested before round (i)
 #pragma unroll
             for (int t = 0; t < 3; ++t) {   // (i) from the registers
                 if (wave * 64u + (uint32_t)t * BLOCK < K) {
@@ -1029,7 +1090,7 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
                         if (__ballot(mx >= floor_b) != 0ull) {
                             uint32_t hm = 0;
                             if (act) { hm = chk2(chk2(0u, rq[t].y), rq[t].z); hm = two ? hm << 2 : chk2(hm, rq[t].w); }
-                            list_hits(hm, 6u, svr[t], 0u);
+                            list_hits(hm, 6u, LONG ? wave * 64u + lane + (uint32_t)t * BLOCK : svr[t], 0u);
                         }
                     } else {
                     if (act) { mx = mx2(mx2(mx2(0u, rq[t].y), rq[t].z), rq[t].w); if (two) mx = mx2(mx2(mx2(mx2(mx, rq1[t].x), rq1[t].y), rq1[t].z), rq1[t].w); }
@@ -1039,12 +1100,12 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
                             hm = chk2(chk2(chk2(0u, rq[t].y), rq[t].z), rq[t].w) << 8;
                             if (two) hm = chk2(chk2(chk2(chk2(hm >> 8, rq1[t].x), rq1[t].y), rq1[t].z), rq1[t].w);
                         }
-                        list_hits(hm, 14u, svr[t], 0u);
+                        list_hits(hm, 14u, LONG ? wave * 64u + lane + (uint32_t)t * BLOCK : svr[t], 0u);   // (LONG lists the neighbour's INDEX: slot and weight come from nb2 at the resolve)
                     }
                     }
                 }
             }
-            auto chk_tail = [&](uint32_t p0, uint32_t sv, uint32_t hdr, const uint4& c4, const uint4& d4, uint32_t blk) {
+            auto chk_tail = [&](uint32_t p0, uint32_t sv, uint32_t hdr, const uint4& c4, const uint4& d4, uint32_t blk) {   // (sv: the queue's token)
                 const bool act = p0 + lane < cnt3;
                 const uint32_t len = hdr & 0xFFFFu;
                 const bool more = FRAG ? true : len > 30u;
@@ -1074,8 +1135,8 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
                     }
                     list_hits(hm2, 8u, sv, t8);   // (rows of > 30 items are few: no fast path)
                 } };
-            if (cnt3) chk_tail(0u, sv3b, hdr3b, c43b, d43b, blk3b);
-            for (uint32_t p0 = 64u; p0 < cnt3; p0 += 64u) { uint32_t sv, hdr, blk; uint4 c4, d4; q3_load(p0, sv, hdr, c4, d4, blk); chk_tail(p0, sv, hdr, c4, d4, blk); }
+            if (cnt3) chk_tail(0u, tk3b, hdr3b, c43b, d43b, blk3b);
+            for (uint32_t p0 = 64u; p0 < cnt3; p0 += 64u) { uint32_t tk, sv, hdr, blk; uint4 c4, d4; q3_load(p0, tk, sv, hdr, c4, d4, blk); chk_tail(p0, tk, hdr, c4, d4, blk); }
             if (ticking) { const uint32_t hs = wave_sum(dbg_hits); if (lane == 0u && hs) atomicAdd(&tacc[5], (unsigned long long)hs); }
         }
         __syncthreads();
@@ -1087,14 +1148,15 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
             bool ovf = false;
             for (uint32_t i = tid; i < nh; i += BLOCK) {
                 const uint2 h = hits[i];
-                const uint32_t* os = reinterpret_cast<const uint32_t*>(ix.row_slots + (size_t)(base + (h.x >> NB)) * (FRAG ? 1 : 4));
+                const uint32_t hslot = tok_slot(h.x);   // (LONG: h.x is the neighbour's index)
+                const uint32_t* os = reinterpret_cast<const uint32_t*>(ix.row_slots + (size_t)(base + (hslot >> NB)) * (FRAG ? 1 : 4));
                 const uint32_t len = os[0], j = h.y;
                 uint32_t it = EMPTY32;
                 if constexpr (FRAG) { if (j < len) it = len <= 3u ? os[1 + j] : (j < 2u ? os[2 + j] : ix.row_ext[os[1] + (j - 2u)]); }
                 else
                 if (j < len) it = len <= 15u ? os[1 + j] : (j < 14u ? os[2 + j] : ix.row_ext[os[1] + (j - 14u)]);
                 if (business && it != EMPTY32 && it >= F_DIRECT && !business_ok(cur_attr, ix.meta[it].attr)) it = EMPTY32;   // (one more gather per listed element, all in flight together)
-                if (it != EMPTY32 && it >= F_DIRECT && item_insert(ikeys, iacc, F_TABLE_BUCKETS, it, (int)w10_of(h.x & NBM)) < 0) ovf = true;
+                if (it != EMPTY32 && it >= F_DIRECT && item_insert(ikeys, iacc, F_TABLE_BUCKETS, it, (int)tok_w(h.x, hslot)) < 0) ovf = true;
             }
             if (ovf) atomicOr(&misc[FS_FAIL], 8u);
         }
@@ -1127,7 +1189,7 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
             const uint32_t kk[4] = {kq.x, kq.y, kq.z, kq.w}, aa[4] = {aq.x, aq.y, aq.z, aq.w};
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
-                const bool in = kk[s4] != EMPTY32 && kk[s4] != cur_idx && aa[s4] >= floor_b;
+                const bool in = kk[s4] != EMPTY32 && kk[s4] != cur_idx && (LONG ? (int)aa[s4] >= (int)floor_b : aa[s4] >= floor_b);   // (LONG: the table's sums are signed)
                 const unsigned long long bm = __ballot(in);
                 if (in) tl[nt + (uint32_t)__popcll(bm & ltl)] = make_uint2(kk[s4], aa[s4]);
                 nt += (uint32_t)__popcll(bm);
@@ -1139,7 +1201,7 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
         // A query with more entries (no threshold: a small query) puts the rest in an overflow arena and itself on the list of
         // vmis_finish_big_kernel: one 64-bit atomic hands out the list slot (high word) and the arena space (low word, entries).
         const uint32_t M = cnt + nt;
-        if (MID && L == 10u && M < p.how_many) {   // (wave-uniform) neighbours of weight 0 may exist and the positive scores do not fill the top n: an item of score 0 can be returned (mod.rs:143-153 inserts it)
+        if (MID && (LONG || L == 10u) && M < p.how_many) {   // (wave-uniform) neighbours of weight 0 may exist and the positive scores do not fill the top n: an item of score 0 can be returned (mod.rs:143-153 inserts it)
             if (ln == 0u) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q;
             continue;
         }
@@ -1227,12 +1289,15 @@ __global__ __launch_bounds__(256) void vmis_finish_kernel(DeviceIndex ix, const 
         // ranks: this kernel's time is this loop (2^20 queries x ~30 entries), so it first runs on the scores' top 32 bits alone -- entry j broadcast by
         // v_readlane, a compare and an add-with-carry each for "greater" and "equal" -- and only a wave in which two entries share those bits (near ties)
         // counts again on the full keys (score, then id rank)
-        uint32_t rank = 0, same = 0;
+        // (round 5: only "greater" is counted -- one readlane, one compare, one add-with-carry per entry; if no two valid entries share their top 32 bits the ranks are a
+        //  permutation of 0 .. M - 1 and sum to M (M - 1) / 2, any tie leaves the sum short: one DPP wave sum instead of an "equal" count per entry)
+        uint32_t rank = 0;
         for (uint32_t j = 0; j < M; ++j) {
             const uint32_t jh = (uint32_t)__builtin_amdgcn_readlane(khi, (int)j);
-            rank += (uint32_t)(jh > (uint32_t)khi); same += (uint32_t)(jh == (uint32_t)khi);
+            rank += (uint32_t)(jh > (uint32_t)khi);
         }
-        if (__ballot(valid[u] && same > 1u) != 0ull) {   // (wave-uniform)
+        const uint32_t Mv = min(M, 64u);
+        if (wave_sum(valid[u] ? rank : 0u) != Mv * (Mv - 1u) / 2u) {   // (wave-uniform)
             rank = 0;
             for (uint32_t j = 0; j < M; ++j) {
                 const uint32_t jl = (uint32_t)__builtin_amdgcn_readlane(klo, (int)j), jh = (uint32_t)__builtin_amdgcn_readlane(khi, (int)j), ij = (uint32_t)__builtin_amdgcn_readlane((int)tie[u], (int)j);
@@ -1332,12 +1397,14 @@ hipError_t launch_finish(hipStream_t st, const DeviceIndex& di, const FastParams
     return hipGetLastError();
 }
 
-hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f, bool debug, int mode, bool mid, bool big) {
+hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f, bool debug, int mode, bool mid, bool big, bool lng) {
     constexpr int W = (int)F_WG_PER_CU;
     const bool wide = f.nb == 3u, frag = di.row_frag != 0u;
-    if (mid && (mode != FM_FUSED || frag || f.mid_list == nullptr)) return hipErrorInvalidValue;
-    if (big && (!mid || f.bigq_list == nullptr)) return hipErrorInvalidValue;
+    if (mid && (mode != FM_FUSED || frag || (!big && f.mid_list == nullptr))) return hipErrorInvalidValue;
+    if (big && (!mid || (!lng && f.bigq_list == nullptr))) return hipErrorInvalidValue;
+    if (lng && (!big || frag || f.long_list == nullptr)) return hipErrorInvalidValue;
     void (*kern)(DeviceIndex, LaunchParams, FastParams) =
+        lng ? vmis_fast_kernel<W, false, false, FM_FUSED, true, true, true> :
         big ? vmis_fast_kernel<W, false, false, FM_FUSED, true, true> :
         mid ? vmis_fast_kernel<W, false, false, FM_FUSED, true> :
         mode == FM_FRONT ? (wide ? vmis_fast_kernel<W, false, true, FM_FRONT> : vmis_fast_kernel<W, false, false, FM_FRONT>)

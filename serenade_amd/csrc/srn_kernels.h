@@ -75,6 +75,11 @@ static constexpr uint32_t F_FIN_BYTES = 1024, F_FIN_ENTRIES = F_FIN_BYTES / 16 -
 static_assert(F_CAND + F_CAND_CAP * 12 <= F_HOT, "candidate buffer overlaps the accumulators");
 static constexpr uint32_t F_BIG_TOTAL = 80 * 1024;   // LDS of the MID instantiation's BIG form (two workgroups per CU): the same map with the merge buffers' room grown to 19 072 words (n <= 9 404 staged entries)
 static constexpr uint32_t F_MID_LISTS = 10, F_MID_LMAX = 10, F_MID_CLASSES = 63;   // the MID instantiation of vmis_fast_kernel: lists per query, session length, similarity numerators
+// the LONG instantiation (round 5): sessions of 11..20 items -- the reference's README lets last_items_in_session_range go to 20, and linear_score is NEGATIVE from the eleventh
+// position on (mod.rs:110-116).  A form of MID's BIG layout (80 KB of LDS); slots carry a 5-bit list CODE (31 - list number: the first copy of a session in the merged run is its
+// first match), numerators are summed per session in bytes, the neighbour list is 64-bit {slot, signed weight}
+static constexpr uint32_t F_LONG_LISTS = 20, F_LONG_LMAX = 20, F_LONG_CLASSES = 255, F_LONG_NB = 5;
+static constexpr uint32_t F_LONG_RES_WORDS = F_K_MAX * 2 + F_M_MAX / 4 + 256;   // the tail of the merge buffers' room it reserves: neighbour list (uint2) | numerator bytes of the m-cut | class histogram
 static_assert(F_LDS_BYTES * F_WG_PER_CU <= 160 * 1024, "LDS budget");
 static_assert(F_DUMP + F_DUMP_WORDS * 4 - F_HOT <= 65536, "16-bit row offsets");
 struct FastParams {
@@ -84,6 +89,7 @@ struct FastParams {
     double inv_idf_hi;          // 1 / max idf_eff over all items
     uint32_t* slow_list; uint32_t* slow_cnt;   // queries the fast kernel hands to vmis_predict_kernel
     uint32_t* bigq_list; uint32_t* bigq_cnt;   // ... and what MID passes on only because its merged lists outgrow the 53 KB layout: MID's BIG form (80 KB of LDS, two workgroups per CU) takes them before the general kernel
+    uint32_t* long_list; uint32_t* long_cnt;   // sessions of 11..20 items: the LONG instantiation takes them before the general kernel (null: no such tier in this launch)
     uint32_t* mid_list; uint32_t* mid_cnt;     // queries of 5..10 lists / <= 10 items / numerators up to 63: the fast kernel's MID instantiation takes them before the general kernel (null: no such tier in this launch)
     char* fin;                  // per-query records for vmis_finish_kernel: F_FIN_BYTES each, at q * F_FIN_BYTES
     char* big_arena; uint32_t* big_list; unsigned long long* big_ticket; uint32_t big_cap_entries;   // queries with > 63 entries: overflow entries, list for vmis_finish_big_kernel,
@@ -144,7 +150,7 @@ hipError_t launch_shard_mark(hipStream_t st, const uint32_t* flag, uint32_t nq, 
 hipError_t launch_shard_fill_i32(hipStream_t st, int* dst, int v, size_t n);
 hipError_t launch_shard_merge_topn(hipStream_t st, const char* part, size_t block_bytes, uint32_t n_shards, uint32_t nq, uint32_t how_many, uint64_t* out_ids, double* out_scores,
                                    uint32_t* out_counts);
-hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f, bool debug = false, int mode = 0, bool mid = false, bool big = false);   // debug: say the occupancy once (the SRN_DEBUG knob, read by the runtime); mode: 0 fused, 1 front end only (neighbour lists -> f.xchg), 2 back end only (neighbour lists <- f.xchg); mid: the MID instantiation over f.mid_list (mode 0 only)
+hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f, bool debug = false, int mode = 0, bool mid = false, bool big = false, bool lng = false);   // debug: say the occupancy once (the SRN_DEBUG knob, read by the runtime); mode: 0 fused, 1 front end only (neighbour lists -> f.xchg), 2 back end only (neighbour lists <- f.xchg); mid: the MID instantiation over f.mid_list (mode 0 only)
 hipError_t launch_rows_to_packed(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base,
                                  uint32_t* packed, uint32_t* ext16, bool frag = false);   // grid = ceil((n_rows + 1) / 1024) blocks of 1024; block_base in 16-byte blocks
 hipError_t launch_rows_to_frags(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base,

@@ -22,7 +22,7 @@ namespace srn {
 // Test / experiment knobs (environment variables SRN_*): read ONCE, when the library is first used, never on the launch path;
 // srn_debug_reload_knobs() re-reads them (the tests switch kernel paths between calls).  All defaults = production behaviour.
 struct Knobs {
-    bool no_masks = false, no_merge = false, dense = false, no_fast = false, no_mid = false, no_big = false, debug = false;   // no_mid (SRN_NO_MID): the launch sequence without the fast kernel's MID instantiation (what it would take goes to the general kernel, as before round 4)
+    bool no_masks = false, no_merge = false, dense = false, no_fast = false, no_mid = false, no_big = false, no_long = false, debug = false;   // no_long (SRN_NO_LONG): without the LONG instantiation (sessions of 11..20 items go to the general kernel, as until round 4)   // no_mid (SRN_NO_MID): the launch sequence without the fast kernel's MID instantiation (what it would take goes to the general kernel, as before round 4)
     int hot_slots = -1, sketch_slots = -1, lds_budget_kb = 0, grid_mult = 16, fast_runs = 0;
     bool grid_mult_set = false;
     int host_chunks = 0;      // SRN_HOST_CHUNKS: number of chunks a host-pointer batch is cut into (0 = by size, srn_hostpipe.hip)
@@ -40,8 +40,10 @@ struct Knobs {
     int order_min = 131072;    // SRN_ORDER_MIN: batches of at least this many queries are served in the order of their most popular item, an eighth of the order per XCD (0 = never); the ordering
                               // pass is one radix sort of the batch's keys behind the prep kernel
     bool no_sback = false;    // SRN_NO_SBACK: the shard group's back end through vmis_fast_kernel's FM_BACK instantiation (rounds 4) instead of the wave-per-query kernel of srn_sback.hip
-    bool sback_nobitmap = false;   // SRN_SBACK_NOBITMAP (experiments): that kernel without its presence bitmap (every neighbour costs a fragment fetch)
-    int sback_min_shards = 4; // SRN_SBACK_MIN_SHARDS: shards of an index cut in at least this many get the frag8 rows (below: fragments of > 4 items are common, the geometry too small)
+    bool sback_bitmap = false;     // SRN_SBACK_BITMAP=1 (experiments): that kernel asks its presence bitmap before it fetches a fragment.  Measured on config 3 cut in 8: half the fragment
+                                   // fetches, but one more DEPENDENT round trip per query on a kernel that spends 65 % of its time waiting for memory -- 1.65 ms with, 1.52 ms without
+    int sback_min_shards = 8; // SRN_SBACK_MIN_SHARDS: shards of an index cut in at least this many get the frag8 rows (below: fragments of > 4 items are common and the 1 024 + 1 024-word
+                              // geometry too small -- config 3 cut in 4 handed 117 K of 131 K queries on; the FM_BACK form of the fast kernel serves those groups)
     int lanes = 4;            // SRN_PREDICT_LANES: concurrent rounds of the srn_predict combiner (srn_combine.cpp)
     bool geometry_default() const { return !no_masks && !no_merge && !dense && hot_slots < 0 && sketch_slots < 0 && lds_budget_kb == 0; }
 };
@@ -64,6 +66,7 @@ struct Workspace {
     char* spill = nullptr; size_t spill_bytes = 0;   // per-block global copies of the neighbour lists
     char* prep = nullptr; size_t prep_bytes = 0;     // per-query records of the prep kernel
     char* order = nullptr; size_t order_bytes = 0;   // the batch's order keys as the prep kernel wrote them | sorted | the sort's scratch
+    char* order2 = nullptr; size_t order2_bytes = 0; // ... of the second record set (SRN_FLAG_INPUTS_RESIDENT: call i + 1's prep kernel and sort run beside call i's kernels, which still read theirs)
     uint32_t* retry_list2 = nullptr; size_t retry_cap2 = 0; uint32_t* retry_cnt2 = nullptr;   // what the second LDS tier could not hold either
     uint32_t* slow_list = nullptr; size_t slow_cap = 0; uint32_t* slow_cnt = nullptr;          // what the fast kernel hands to the general one
     char* fin = nullptr; size_t fin_bytes = 0;   // records for vmis_finish_kernel

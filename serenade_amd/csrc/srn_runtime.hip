@@ -21,7 +21,7 @@ static Knobs g_knobs; static std::once_flag g_knobs_once; static std::mutex g_kn
 static void knobs_read() {
     Knobs k;
     k.no_masks = getenv("SRN_NO_MASKS") != nullptr; k.no_merge = getenv("SRN_NO_MERGE") != nullptr; k.dense = getenv("SRN_DENSE") != nullptr;
-    k.no_fast = getenv("SRN_NO_FAST") != nullptr; k.no_mid = getenv("SRN_NO_MID") != nullptr; k.no_big = getenv("SRN_NO_BIG") != nullptr; k.debug = getenv("SRN_DEBUG") != nullptr;
+    k.no_fast = getenv("SRN_NO_FAST") != nullptr; k.no_mid = getenv("SRN_NO_MID") != nullptr; k.no_big = getenv("SRN_NO_BIG") != nullptr; k.no_long = getenv("SRN_NO_LONG") != nullptr; k.debug = getenv("SRN_DEBUG") != nullptr;
     if (const char* e = getenv("SRN_ROW_SLOTS")) k.row_slots16 = atoi(e) == 16 ? 1 : atoi(e) == 64 ? 0 : -1;
     if (const char* e = getenv("SRN_HOT_SLOTS")) k.hot_slots = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_SKETCH_SLOTS")) k.sketch_slots = std::max(0, atoi(e));
@@ -35,7 +35,7 @@ static void knobs_read() {
     if (const char* e = getenv("SRN_TINY_FAST")) k.tiny_fast = std::min(3, std::max(0, atoi(e)));
     if (const char* e = getenv("SRN_PREDICT_LANES")) k.lanes = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_ORDER_MIN")) k.order_min = std::max(0, atoi(e));
-    k.no_sback = getenv("SRN_NO_SBACK") != nullptr; k.sback_nobitmap = getenv("SRN_SBACK_NOBITMAP") != nullptr;
+    k.no_sback = getenv("SRN_NO_SBACK") != nullptr; k.sback_bitmap = getenv("SRN_SBACK_BITMAP") != nullptr && atoi(getenv("SRN_SBACK_BITMAP")) != 0;
     if (const char* e = getenv("SRN_SBACK_MIN_SHARDS")) k.sback_min_shards = std::max(2, atoi(e));
     if (const char* e = getenv("SRN_FAST_RUNS")) k.fast_runs = atoi(e) == 3 ? 3 : 0;   // tests: the fast kernel's 29-bit-rank form (3 lists per query) on a small index
     std::lock_guard<std::mutex> lk(g_knobs_mu); g_knobs = k;
@@ -186,6 +186,7 @@ static void ws_free(Workspace* w) {
     if (w->spill) hipFree(w->spill);
     if (w->prep) hipFree(w->prep);
     if (w->order) hipFree(w->order);
+    if (w->order2) hipFree(w->order2);
     if (w->retry_list2) hipFree(w->retry_list2);
     if (w->retry_cnt2) hipFree(w->retry_cnt2);
     if (w->slow_list) hipFree(w->slow_list);
@@ -367,7 +368,7 @@ static int make_geometry(const DeviceState* d, const FlatIndex& ix, const Launch
 // What the fast kernel needs of the LAUNCH is the position-set condition (DESIGN.md "Why MASKS is exact": m <= m_index, lists complete) and sketch words that cannot wrap
 // at ITS session lengths (<= 10 items: the admission is per query, on the device); the batch's longest session only decides which kernels serve the hand-overs -- up to
 // round 3 one session of nine items sent the whole batch to the general kernel.
-struct FastPlan { bool fast = false, mid_tier = false; uint32_t nb_fast = 0; };
+struct FastPlan { bool fast = false, mid_tier = false, long_tier = false; uint32_t nb_fast = 0; };
 static FastPlan fast_plan(const DeviceState* d, const FlatIndex& ix, const LaunchParams& p, const Geometry& geo, const Knobs& kn, bool has_ext) {
     FastPlan f;
     // the fast kernel packs (rank, set of <= 4 lists) into 32 bits whatever the general kernel's slots look like: up to 2^28 sessions with 4 lists per query,
@@ -375,8 +376,10 @@ static FastPlan fast_plan(const DeviceState* d, const FlatIndex& ix, const Launc
     const int rank_bits_f = std::max(1, bits_host(ix.n_kept ? ix.n_kept - 1 : 0));
     f.nb_fast = kn.fast_runs == 3 && rank_bits_f <= 29 ? 3u : rank_bits_f <= 28 ? 4u : rank_bits_f <= 29 ? 3u : 0u;
     const bool sets_exact = p.m <= ix.m_index && ix.lists_complete && !kn.no_masks;
-    const bool fast_sketch_ok = (uint64_t)p.k * std::max<uint64_t>(1, ix.max_row_len) * 9ull * 55ull < (1ull << 32);
+    // (a sketch word sums the POSITIVE parts: <= k rows of <= max_row_len items, weight <= 9 * numerator; numerators <= 55 at 10 items, <= 210 at 20)
+    const bool fast_sketch_ok = (uint64_t)p.k * std::max<uint64_t>(1, ix.max_row_len) * 9ull * (p.max_len > 10 ? 210ull : 55ull) < (1ull << 32);
     f.mid_tier = !kn.no_mid && !has_ext && d->di.row_frag == 0u && p.max_len >= 5;   // (a query of <= 4 items has <= 4 lists and numerators <= 10: nothing for the MID instantiation)
+    f.long_tier = f.mid_tier && !kn.no_long && !kn.no_big && p.max_len > 10;          // (round 5: sessions of 11..20 items -- LONG, a form of MID's BIG layout)
     f.fast = d->fast.row_packed != nullptr && sets_exact && (p.max_len <= 8 ? geo.masks && !geo.sketch_may_wrap : f.mid_tier && fast_sketch_ok) && f.nb_fast != 0 && kn.geometry_default() &&
              !kn.no_fast && p.k <= F_K_MAX && p.m <= F_M_MAX && p.how_many <= 24 && (p.flags & ~(unsigned)SRN_FLAG_BUSINESS_LOGIC) == 0 && p.stats == nullptr && p.nb_rank == nullptr;
     return f;
@@ -430,7 +433,7 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
     const uint64_t big_entries = (uint64_t)cap_q * 16 + 4096;
     if (tiny_fast) {   // (sized once, for the largest round)
         if (w->slow_cap < cap_q) { if (w->slow_list) HIP_TRY(hipFree(w->slow_list)); w->slow_list = nullptr; w->slow_cap = 0;
-            HIP_TRY(hipMalloc((void**)&w->slow_list, (cap_q * 4 + 64) * 3)); w->slow_cap = cap_q; }
+            HIP_TRY(hipMalloc((void**)&w->slow_list, (cap_q * 4 + 64) * 4)); w->slow_cap = cap_q; }
         { int rc = ensure(&w->fin, &w->fin_bytes, cap_q * F_FIN_BYTES + 1024); if (rc) return rc; }
         { int rc = ensure(&w->big, &w->big_bytes, big_entries * 16 + cap_q * 4 + 64); if (rc) return rc; }
     }
@@ -441,7 +444,7 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
         fp.big_arena = w->big; fp.big_list = (uint32_t*)(w->big + big_entries * 16); fp.big_ticket = (unsigned long long*)(w->slow_cnt + 2); fp.big_cap_entries = (uint32_t)big_entries;
         fp.xchg = nullptr; fp.xchg_stride = 0; fp.q_base = 0; fp.order = nullptr;
         fp.mid_list = plan.mid_tier ? w->slow_list + (w->slow_cap + 16) : nullptr; fp.mid_cnt = plan.mid_tier ? w->slow_cnt + 1 : nullptr;
-        fp.bigq_list = nullptr; fp.bigq_cnt = nullptr;   // (no BIG tier on the latency path: one more launch for 3-4 % of the long sessions)
+        fp.bigq_list = nullptr; fp.bigq_cnt = nullptr; fp.long_list = nullptr; fp.long_cnt = nullptr;   // (no BIG / LONG tier on the latency path)
         HIP_TRY(launch_fast(dim3(p.nq), st, d->di, p, fp, kn.debug, 0));
         if (plan.mid_tier) HIP_TRY(launch_fast(dim3(p.nq), st, d->di, p, fp, kn.debug, 0, true));
         HIP_TRY(launch_predict(geo.masks, geo.slot64, false, 0, dim3(p.nq), geo.lds, st, d->di, p, geo.c, w->slow_list, w->slow_cnt, (uint32_t*)(dp + o_rl), (uint32_t*)(dp + o_rc), nullptr, 0,
@@ -587,7 +590,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     const uint32_t nb_fast = plan.nb_fast; const bool mid_tier = plan.mid_tier, fast = plan.fast;
     if (fast) {   // (all allocations of a call happen before its first launch)
         if (w->slow_cap < p.nq) { if (w->slow_list) HIP_TRY(hipFree(w->slow_list)); w->slow_list = nullptr; w->slow_cap = 0;
-            HIP_TRY(hipMalloc((void**)&w->slow_list, ((size_t)p.nq * 4 + 64) * 3)); w->slow_cap = p.nq; }   // (second and third part: the MID instantiation's list, its BIG form's)
+            HIP_TRY(hipMalloc((void**)&w->slow_list, ((size_t)p.nq * 4 + 64) * 4)); w->slow_cap = p.nq; }   // (second to fourth part: the MID instantiation's list, its BIG form's, the LONG form's)
         { int rc = ensure(&w->fin, &w->fin_bytes, (size_t)p.nq * F_FIN_BYTES + 1024); if (rc) return rc; }   // one record per query for vmis_finish_kernel
         const uint64_t big_entries = std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)p.nq * 16 + 4096);
         { int rc = ensure(&w->big, &w->big_bytes, big_entries * 16 + (size_t)p.nq * 4 + 64); if (rc) return rc; }
@@ -595,7 +598,9 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     // the serving order: the batch sorted by each query's most popular item (keys from the prep kernel, one radix sort behind it)
     const bool ordered = fast && !ext && kn.order_min > 0 && p.nq >= (uint32_t)kn.order_min;
     unsigned long long *okeys_in = nullptr, *okeys_out = nullptr; void* otemp = nullptr; size_t otemp_bytes = 0;
-    if (ordered) { int rc = order_room(&w->order, &w->order_bytes, p.nq, &okeys_in, &okeys_out, &otemp, &otemp_bytes); if (rc) return rc; }
+    // (one order per set of prep records: a resident call's prep kernel and sort run on the side stream while the previous call's kernels still read THEIR order)
+    const bool order_set2 = resident && (w->resident_calls & 1u) != 0u;
+    if (ordered) { int rc = order_room(order_set2 ? &w->order2 : &w->order, order_set2 ? &w->order2_bytes : &w->order_bytes, p.nq, &okeys_in, &okeys_out, &otemp, &otemp_bytes); if (rc) return rc; }
     if (reserve_only) return SRN_OK;   // (srn_index_reserve: the workspace is sized, nothing was enqueued)
     if (ext && ext->mode == 1) {
         // The shard group's neighbours pipeline, FRONT: find_neighbors alone for the queries [q_lo, nq) of the batch this rank fronts -- the fast kernel's front end against
@@ -604,7 +609,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         if (ext->prep_stride != prep_stride) return fail(SRN_EINVAL, "prep record stride mismatch");
         if (ext->q_lo >= p.nq) return SRN_OK;
         p.prep = ext->prep; p.prep_stride = prep_stride;
-        FastParams fp = d->fast; fp.nb = nb_fast; fp.max_runs = nb_fast; fp.slow_list = nullptr; fp.slow_cnt = nullptr; fp.fin = nullptr; fp.mid_list = nullptr; fp.mid_cnt = nullptr; fp.bigq_list = nullptr; fp.bigq_cnt = nullptr;
+        FastParams fp = d->fast; fp.nb = nb_fast; fp.max_runs = nb_fast; fp.slow_list = nullptr; fp.slow_cnt = nullptr; fp.fin = nullptr; fp.mid_list = nullptr; fp.mid_cnt = nullptr; fp.bigq_list = nullptr; fp.bigq_cnt = nullptr; fp.long_list = nullptr; fp.long_cnt = nullptr;
         fp.xchg = ext->xchg; fp.xchg_stride = ext->xchg_stride; fp.q_base = ext->q_lo; fp.order = nullptr;
         const uint64_t cnt = p.nq - ext->q_lo, res_wg = (uint64_t)d->n_cu * F_WG_PER_CU;
         const uint32_t grid_front = (uint32_t)std::min<uint64_t>(cnt, std::min<uint64_t>(res_wg * 64, std::max<uint64_t>(res_wg * 16, cnt / 12)));
@@ -663,14 +668,16 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         fp.big_arena = w->big; fp.big_list = (uint32_t*)(w->big + big_entries * 16); fp.big_ticket = (unsigned long long*)(w->slow_cnt + 2); fp.big_cap_entries = (uint32_t)big_entries;
         fp.xchg = nullptr; fp.xchg_stride = 0; fp.q_base = 0;
         fp.mid_list = mid_tier ? w->slow_list + (w->slow_cap + 16) : nullptr; fp.mid_cnt = mid_tier ? w->slow_cnt + 1 : nullptr;
-        fp.bigq_list = mid_tier && !kn.no_big ? w->slow_list + 2 * (w->slow_cap + 16) : nullptr; fp.bigq_cnt = fp.bigq_list ? w->slow_cnt + 4 : nullptr;
+        // (round 5: the BIG form also without a MID tier -- it takes the lean shape's oversized queries of the headline batches; not over an item shard's fragments)
+        fp.bigq_list = !kn.no_big && !ext && d->di.row_frag == 0u ? w->slow_list + 2 * (w->slow_cap + 16) : nullptr; fp.bigq_cnt = fp.bigq_list ? w->slow_cnt + 4 : nullptr;
+        fp.long_list = plan.long_tier ? w->slow_list + 3 * (w->slow_cap + 16) : nullptr; fp.long_cnt = fp.long_list ? w->slow_cnt + 5 : nullptr;
         const bool back = ext && ext->mode == 2;   // neighbour lists from the exchange buffer (any rank's front end), this shard's rows
         if (back) { fp.xchg = ext->xchg; fp.xchg_stride = ext->xchg_stride; }
         fp.order = ordered ? okeys_out : back ? ext->order : nullptr;
         const uint32_t grid_fo = fp.order ? std::max<uint32_t>(8u, grid_f / 8u * 8u) : grid_f;   // (an ordered launch walks an eighth of the order per XCD: the grid is a multiple of 8)
         if (back && d->sback.frag8 && !kn.no_sback && p.max_len <= 8) {
             // the item shard's own back end (srn_sback.hip): one wave per query, 12 per CU; a persistent grid of a few waves per resident slot
-            SBackParams sbp = d->sback; if (kn.sback_nobitmap) sbp.present = nullptr;
+            SBackParams sbp = d->sback; if (!kn.sback_bitmap) sbp.present = nullptr;
             const uint64_t slots = (uint64_t)d->n_cu * 12;
             const uint32_t grid_b = (uint32_t)std::min<uint64_t>(p.nq, slots * (kn.grid_mult_set ? grid_mult : 8));
             HIP_TRY(launch_shard_back(dim3(fp.order ? std::max<uint32_t>(8u, grid_b / 8u * 8u) : grid_b), st, di, p, fp, sbp, kn.debug));
@@ -683,6 +690,8 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         if (mid_tier) HIP_TRY(launch_fast(dim3((uint32_t)std::min<uint64_t>(p.nq, resident * 8)), st, di, p, fp, kn.debug, 0, true));
         // ... and MID's BIG form (80 KB of LDS, two workgroups per CU) over what MID passed on only for want of merge-buffer room
         if (fp.bigq_list) HIP_TRY(launch_fast(dim3((uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * 2 * 4)), st, di, p, fp, kn.debug, 0, true, true));
+        // ... and the LONG form over the sessions of 11..20 items the lean instantiation listed for it
+        if (fp.long_list) HIP_TRY(launch_fast(dim3((uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * 2 * 4)), st, di, p, fp, kn.debug, 0, true, true, true));
         HIP_TRY(launch_predict(geo.masks, slot64, false, 0, dim3(grid), lds, st, di, p, c, w->slow_list, w->slow_cnt, w->retry_list, w->retry_cnt, nullptr, 0, spill, ShardIO{}));
         if (fork_retry) {   // the global-table pass beside the finish kernels (they touch disjoint rows: a finish kernel only completes rows flagged by the fast kernel)
             HIP_TRY(hipEventRecord(w->ev_fork, st)); HIP_TRY(hipStreamWaitEvent(w->side, w->ev_fork, 0));
@@ -897,7 +906,7 @@ int device_last_mid_count(DeviceState* d, uint32_t* listed, uint32_t* big_listed
     Workspace* w;
     { std::lock_guard<std::mutex> lk(d->mu); w = d->last_ws; }
     if (listed) *listed = w->last_fast && w->last_mid ? w->h_retry[2] : 0u;
-    if (big_listed) *big_listed = w->last_fast && w->last_mid ? w->h_retry[3] : 0u;
+    if (big_listed) *big_listed = w->last_fast ? w->h_retry[3] : 0u;   // (the BIG form also takes the lean shape's oversized queries: no MID tier needed)
     return SRN_OK;
 }
 

@@ -34,7 +34,7 @@ static constexpr uint32_t SB_MISC = 0, SB_WTAB = 128, SB_CAND = 192, SB_CAND_CAP
 static_assert(SB_H % 256 == 0 && (SB_S & (SB_S - 1)) == 0 && SB_DUMP == 64, "geometry");
 static constexpr uint32_t SB_LDS = SB_HOT + (SB_H + SB_S + SB_DUMP) * 4;
 static constexpr uint32_t SB_LQ_CAP = (SB_HOT - SB_CAND) / 8;   // long fragments a query may queue (448)
-static constexpr uint32_t SB_LQB_CAP = 128, SB_HIT_CAP = (SB_H * 4 - SB_LQB_CAP * 12) / 8;   // walk B's hit list and its queue of long fragments live in the direct-mapped words (dead by then)
+static constexpr uint32_t SB_LQB_CAP = 160, SB_HIT_CAP = (SB_H * 4 - SB_LQB_CAP * 12) / 8;   // walk B's hit list and its queue of long fragments live in the direct-mapped words (dead by then)
 static_assert(SB_HOT % 16 == 0 && SB_TABLE % 16 == 0 && SB_CAND % 8 == 0, "alignment");
 
 // -------------------------------------------------------------------------------------
@@ -198,14 +198,15 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                 if (c * 64u < K) {   // (wave-uniform)
                     const bool act = c * 64u + lane < K;
                     const uint32_t r = act ? base + (sv[c] >> NB) : n_kept;   // (idle lanes: the empty row, whose presence bit is 0)
-                    if constexpr (BITMAP) pwv[c] = sb.present[r >> 5] >> (r & 31u); else pwv[c] = act ? 1u : 0u;
+                    if constexpr (BITMAP) pwv[c] = sb.present[r >> 5] >> (r & 31u); else pwv[c] = act ? 1u : 0u;   // (no bitmap: every neighbour's fragment is fetched; the empty ones are told apart below)
                 }
             }
 #pragma unroll
             for (uint32_t c = 0; c < NCH; ++c) pm |= (pwv[c] & 1u) << c;
         }
+        uint2 fr[NCH];   // a lane's <= 24 fragments: they STAY in registers for walk B -- with 12 x 32 queries in flight per XCD (33 MB of fragment lines against 4 MB of L2) a
+                         // second fetch misses like the first: walk B took as long as walk A (54 K against 50 K cycles per query) until it stopped fetching
         {
-            uint2 fr[NCH];
 #pragma unroll
             for (uint32_t c = 0; c < NCH; ++c) {
                 fr[c] = make_uint2(0u, 0u);
@@ -214,7 +215,10 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
 #pragma unroll
             for (uint32_t c = 0; c < NCH; ++c) {
                 if (c * 64u < K) {
-                    const bool pr = (pm >> c) & 1u, lng = pr && (fr[c].x & 0xFFFFu) == 0xFFFFu;
+                    const uint32_t o0 = fr[c].x & 0xFFFFu;
+                    const bool lng = ((pm >> c) & 1u) && o0 == 0xFFFFu;
+                    const bool pr = ((pm >> c) & 1u) && (lng || o0 < (SB_H + SB_S) * 4u);   // (a fragment's items fill its positions from the first: a dump offset there = an empty fragment)
+                    if (!BITMAP && !pr) pm &= ~(1u << c);                                   // (walk B skips it too)
                     const uint32_t w = (uint32_t)wtab[sv[c] & NBM];
                     if (pr && !lng) { add2(fr[c].x, w); add2(fr[c].y, w); }
                     const unsigned long long lb = __ballot(lng);
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
         SB_TICK(tk11);
         if (live && !fail) {
             c7 += 1ull;
-            // ---- walk B: the rows again (L2 by now); an element is LISTED if its sketch word can still reach the floor (all elements of an item share the word, so an item
+            // ---- walk B: the rows again (from the registers); an element is LISTED if its sketch word can still reach the floor (all elements of an item share the word, so an item
             // is accumulated completely or not at all); then the list is resolved -- item id from the general fragment slots -- into the exact table ----
             __syncthreads();   // (the direct-mapped words are dead: the hit list takes them)
             uint32_t nh = 0;   // (wave-uniform)
@@ -344,13 +348,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                 nh += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
             };
             uint32_t nlb = 0u;   // (wave-uniform) long fragments queued for the second step
-            {
-                uint2 fr[NCH];   // the fragments again (L2 by now), all in flight together; the presence bits are walk A's
-#pragma unroll
-                for (uint32_t c = 0; c < NCH; ++c) {
-                    fr[c] = make_uint2(0u, 0u);
-                    if (c * 64u < K) fr[c] = sb.frag8[(pm >> c) & 1u ? base + (sv[c] >> NB) : n_kept];
-                }
+            {   // (the fragments are walk A's, still in registers)
 #pragma unroll
                 for (uint32_t c = 0; c < NCH; ++c) {
                     if (c * 64u >= K) continue;   // (wave-uniform)

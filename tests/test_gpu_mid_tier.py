@@ -229,3 +229,79 @@ def test_big_form_takes_what_outgrows_the_53kb_layout(monkeypatch):
             assert np.array_equal(a, b), "with and without the BIG form the results must be the same bytes"
     finally:
         monkeypatch.undo(); capi.reload_knobs()
+
+
+# ---- the LONG instantiation (round 5): sessions of 11..20 items, negative weights from the eleventh position on ---------------------------------------------------
+
+def _no_long(monkeypatch_env, off):
+    import os
+    from serenade_amd import capi
+    if off:
+        os.environ["SRN_NO_LONG"] = "1"
+    else:
+        os.environ.pop("SRN_NO_LONG", None)
+    capi.reload_knobs()
+
+
+def test_sessions_of_eleven_to_twenty_items_vs_oracle():
+    """The reference's README lets last_items_in_session_range go to 20 (README.md:116) and linear_score is negative for positions 11..99 (mod.rs:110-116).  Sessions of
+    1..20 items in one batch (device admission per query: lean / MID / BIG / LONG side by side), up to 20 posting lists merged, both cuts biting, numerators up to 210;
+    against the canonical oracle -- ids, order, scores incl. what negative weights subtract -- and the same bytes as with SRN_NO_LONG=1 (the general kernel for those
+    sessions, as until round 4); with the tier on, almost nothing of the batch may reach the general kernel."""
+    import serenade_amd as sa
+    O = _oracle()
+    off, items, ts, ids = small_dataset(41, n_sessions=40000, n_items=400, max_len=14)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, 2500, 14, 1.0)
+    oix = O.OracleIndex(off, items, ts, 2500, 14, 1.0)
+    qs = _long_queries(21, ids, 700, 1, 20, unknown_rate=0.03, dup_rate=0.08)
+    n_long = sum(1 for q in qs if len(q) > 10)
+    try:
+        for (k, m, n) in [(100, 500, 21), (1500, 2500, 21), (60, 2560, 24), (700, 1000, 5)]:
+            _no_long(None, False)
+            got = _against_oracle(gix, oix, qs, k, m, n)
+            nq, general, _glob = gix.last_path_counts()
+            assert general <= n_long // 3 + 8, "the LONG instantiation should serve most sessions of 11..20 items (%d such sessions, %d queries reached the general kernel)" % (n_long, general)
+            _no_long(None, True)
+            ref = sa.predict_batch(gix, qs, k, m, n, False)
+            assert gix.last_path_counts()[1] >= n_long
+            for a, b in zip(got, ref):
+                assert np.array_equal(a, b), "with and without the LONG tier the results must be the same bytes"
+    finally:
+        _no_long(None, False)
+
+
+def test_negative_and_zero_weights_positions_eleven_to_twenty():
+    """Queries built so that negative weights matter: (a) recent items unknown, old ones (positions 11..20) known -- every neighbour has a negative or zero weight, every
+    score is <= 0 and the positive scores cannot fill the top n: the general kernel answers (an item of score <= 0 IS returned, mod.rs:143-153); (b) popular recent items
+    plus popular OLD items -- neighbours that match only an old item subtract from items the recent ones' neighbours add to; (c) the tenth position (weight 0) between them.
+    Business rules on in one round.  Exact against the oracle."""
+    import serenade_amd as sa
+    O = _oracle()
+    off, items, ts, ids = small_dataset(6, n_sessions=30000, n_items=160, max_len=10, tied_timestamps=True)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, 2000, 10, 2.0)
+    oix = O.OracleIndex(off, items, ts, 2000, 10, 2.0)
+    rng = np.random.default_rng(9)
+    known = np.unique(items)
+    flags = rng.choice(np.array([0, 1, 2, 3, 0xFF], np.uint8), size=len(known), p=[0.05, 0.05, 0.7, 0.15, 0.05])
+    gix.set_attributes(known, flags)
+    oix.set_attributes(known, flags)
+    pop = ids[:30]
+    qs = []
+    for i in range(450):
+        L = int(rng.integers(11, 21))
+        unk = lambda c: [int(7 + rng.integers(0, 1000)) for _ in range(c)]
+        if i % 3 == 0:      # (a) only the oldest L - 10 positions are known items
+            q = [int(x) for x in pop[rng.integers(0, len(pop), size=L - 10)]] + unk(10)
+        elif i % 3 == 1:    # (b) known popular items at both ends
+            q = [int(x) for x in pop[rng.integers(0, len(pop), size=L - 9)]] + unk(5) + [int(x) for x in ids[rng.integers(0, len(ids), size=4)]]
+        else:               # (c) one known item exactly at the tenth position from the end, known old ones behind it
+            q = [int(x) for x in pop[rng.integers(0, len(pop), size=L - 10)]] + [int(pop[rng.integers(0, len(pop))])] + unk(9)
+        qs.append(q[-L:])
+    try:
+        _no_long(None, False)
+        for (k, m, n, business) in [(100, 500, 21, False), (1500, 2000, 21, True), (40, 2560, 24, False)]:
+            ids_, scores, counts = _against_oracle(gix, oix, qs, k, m, n, business)
+            assert (scores[0::3][counts[0::3] > 0][:, 0] <= 0).all(), "queries whose known items are all beyond the tenth position score <= 0 everywhere"
+            assert (scores < 0).any(), "negative scores must occur (and be returned where nothing positive fills the list)"
+    finally:
+        _no_long(None, False)

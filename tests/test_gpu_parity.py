@@ -787,3 +787,37 @@ def test_trait_accessors_find_neighbors_at_the_abi():
     with pytest.raises(sa.SerenadeError):
         gix.find_neighbors([], 10, 10)
     assert len(gix.find_neighbors([2 ** 60 + 1], 10, 10)[0]) == 0          # an unknown item alone: no neighbours (vmis_index.rs:350)
+
+
+def test_serving_order_changes_no_row():
+    """Round 5: batches of >= SRN_ORDER_MIN (131 072) queries are SERVED in the order of their most popular item -- keys from the prep kernel, one radix sort, the order
+    dealt to the XCDs in chunks of 256 -- so that like queries share an L2.  Which workgroup serves a query must not change its row: with the ordering pass forced on
+    (SRN_ORDER_MIN=1) batches of awkward sizes (below, at and above the chunk size and the 8-way deal; the host-pointer path's chunks) equal the oracle and, bit for
+    bit, the same batch without the pass; sessions of up to 10 items in the batch (the MID instantiation's list is filled in serving order)."""
+    import os
+    import serenade_amd as sa
+    from serenade_amd import capi
+    O = _oracle()
+    off, items, ts, ids = small_dataset(17, n_sessions=20000, n_items=1500, max_len=12)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, 400, 12, 1.0)
+    oix = O.OracleIndex(off, items, ts, 400, 12, 1.0)
+    try:
+        for nq, max_len in ((257, 4), (2049, 4), (5000, 10)):
+            qs = random_queries(300 + nq, ids, nq, max_len=max_len, unknown_rate=0.04, dup_rate=0.1)
+            flat, qoff = flatten(qs)
+            ref = oix.predict_batch("canonical", flat, qoff, 300, 400, 21, False, threads=4)
+            got = {}
+            for omin in ("0", "1"):
+                os.environ["SRN_ORDER_MIN"] = omin
+                capi.reload_knobs()
+                got[omin] = sa.predict_batch(gix, (flat, qoff), 300, 400, 21, False)
+            for a, b in zip(got["0"], got["1"]):
+                assert np.array_equal(a, b), "the serving order changed a row (%d queries)" % nq
+            ids_, sc_, cnt_ = got["1"]
+            assert np.array_equal(cnt_, ref["counts"])
+            mask = np.arange(21)[None, :] < ref["counts"][:, None].astype(np.int64)
+            assert np.array_equal(ids_[mask], ref["ids"][mask])
+            np.testing.assert_allclose(sc_[mask], ref["scores"][mask], rtol=SCORE_RTOL, atol=0)
+    finally:
+        os.environ.pop("SRN_ORDER_MIN", None)
+        capi.reload_knobs()

@@ -556,12 +556,12 @@ def test_group_wait_and_the_default_overlap():
 
 # ---- the item shard's own back end (round 5, srn_sback.hip): one wave per query, frag8 rows + presence bitmap -------------------------------------------------------
 
-@pytest.mark.parametrize("n_shards,knob", [(2, ""), (3, ""), (8, ""), (8, "SRN_SBACK_NOBITMAP"), (5, "SRN_NO_SBACK")])
+@pytest.mark.parametrize("n_shards,knob", [(2, ""), (3, ""), (8, ""), (8, "SRN_SBACK_BITMAP"), (8, "SRN_ORDER_MIN"), (5, "SRN_NO_SBACK")])
 def test_wave_per_query_back_end_against_the_oracle(n_shards, knob):
     """The neighbours pipeline's back end as a kernel of its own -- vmis_shard_back_kernel: a wave per query over 8-byte fragment slots, the presence bitmap asked first --
     against the canonical oracle and bit-identical to the unsharded path: rows of up to 80 items (at 2 and 3 shards most fragments of the long rows have > 4 items: the
-    overflow blocks), unknown and repeated items, both cuts biting, small queries without a threshold, business rules with real flags; with the bitmap switched off; and
-    (SRN_NO_SBACK) the round-4 form, which must not have changed.  SRN_SBACK_MIN_SHARDS=2 gives the 2- and 3-shard groups the new rows too (default: from 4 shards on)."""
+    overflow blocks), unknown and repeated items, both cuts biting, small queries without a threshold, business rules with real flags; with the presence bitmap switched on; with the batch served in the order of its queries' most popular items (SRN_ORDER_MIN=1: the ordering pass on a 1 500-query batch); and
+    (SRN_NO_SBACK) the round-4 form, which must not have changed.  SRN_SBACK_MIN_SHARDS=2 gives the 2- and 3-shard groups the new rows too (default: from 8 shards on)."""
     import ctypes as C
     import serenade_amd as sa
     from serenade_amd import sharded, capi

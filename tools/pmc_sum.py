@@ -4,7 +4,7 @@ tot = collections.defaultdict(lambda: collections.defaultdict(float)); n = colle
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         kn = r["Kernel_Name"]
-        k = "fast" if "vmis_fast_kernel" in kn else "general" if "vmis_predict_kernel" in kn else "prep" if "vmis_prep" in kn else None
+        k = "sback" if "vmis_shard_back_kernel" in kn else "fast" if "vmis_fast_kernel" in kn else "general" if "vmis_predict_kernel" in kn else "prep" if "vmis_prep" in kn else None
         if k is None: continue
         tot[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k][r["Counter_Name"]] += 1
 for k in sorted(tot):
