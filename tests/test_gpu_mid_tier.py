@@ -256,11 +256,11 @@ def test_sessions_of_eleven_to_twenty_items_vs_oracle():
     qs = _long_queries(21, ids, 700, 1, 20, unknown_rate=0.03, dup_rate=0.08)
     n_long = sum(1 for q in qs if len(q) > 10)
     try:
-        for (k, m, n) in [(100, 500, 21), (1500, 2500, 21), (60, 2560, 24), (700, 1000, 5)]:
+        for (k, m, n) in [(100, 500, 21), (1500, 2500, 21), (60, 2500, 24), (700, 1000, 5)]:
             _no_long(None, False)
             got = _against_oracle(gix, oix, qs, k, m, n)
             nq, general, _glob = gix.last_path_counts()
-            assert general <= n_long // 3 + 8, "the LONG instantiation should serve most sessions of 11..20 items (%d such sessions, %d queries reached the general kernel)" % (n_long, general)
+            assert general <= n_long // 3 + 8, "the LONG instantiation should serve most sessions of 11..20 items (%d such sessions, %d queries reached the general kernel; k %d m %d n %d, mid %d big %d)" % (n_long, general, k, m, n, gix.last_mid_count(), gix.last_big_count())
             _no_long(None, True)
             ref = sa.predict_batch(gix, qs, k, m, n, False)
             assert gix.last_path_counts()[1] >= n_long
@@ -299,7 +299,7 @@ def test_negative_and_zero_weights_positions_eleven_to_twenty():
         qs.append(q[-L:])
     try:
         _no_long(None, False)
-        for (k, m, n, business) in [(100, 500, 21, False), (1500, 2000, 21, True), (40, 2560, 24, False)]:
+        for (k, m, n, business) in [(100, 500, 21, False), (1500, 2000, 21, True), (40, 2000, 24, False)]:
             ids_, scores, counts = _against_oracle(gix, oix, qs, k, m, n, business)
             assert (scores[0::3][counts[0::3] > 0][:, 0] <= 0).all(), "queries whose known items are all beyond the tenth position score <= 0 everywhere"
             assert (scores < 0).any(), "negative scores must occur (and be returned where nothing positive fills the list)"
