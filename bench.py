@@ -548,14 +548,15 @@ def main():
             lat_single = np.array(lat[50:])
 
         # ---- 3b. sessions longer than the headline's last_items (the reference's hyper-parameter grid of last_items_in_session goes to 10,
-        # src/hyperparameter/hyperparamgrid.rs:93-139): the same index, evaluator-style queries keeping their last 8 / 10 items, resident batches of 2^18; each
-        # gated against the oracle on 256 queries; at 10 items also without the fast kernel's MID instantiation (SRN_NO_MID=1: the launch sequence of round 3)
+        # src/hyperparameter/hyperparamgrid.rs:93-139; its README's range to 20): the same index, evaluator-style queries keeping their last 8 / 10 / 20 items, resident
+        # batches of 2^18; each gated against the oracle on 256 queries drawn over the whole batch; at 10 items also without the fast kernel's MID instantiation
+        # (SRN_NO_MID=1: the launch sequence of round 3), at 20 also without its LONG instantiation (SRN_NO_LONG=1: sessions of 11..20 items on the general kernel, round 4)
         long_sessions = None
         if not args.no_sweep and world == 1 and args.config in ("cfg3", "cfg2", "tiny", "small"):
             from serenade_amd import capi as _capi
             long_sessions = []
             BL = int(min(B, 1 << 18))
-            for mi in (8, 10):
+            for mi in (8, 10, 20):   # (20: the reference's README lets last_items_in_session_range go to 20; round 5: the fast kernel's LONG instantiation)
                 n_sess = max(1024, int(BL / 2.0) + 4096)
                 while True:
                     lq_items, lq_off = synth.queries(n_sess, n_items, seed=synth.SEED + 104729, max_items=mi)
@@ -566,9 +567,11 @@ def main():
                 l_flat = torch.from_numpy(lq_items.view(np.int64).copy()).to(dev); l_off = torch.from_numpy(lq_off.view(np.int32).copy()).to(dev)
                 lens = np.diff(lq_off.astype(np.int64))
                 entry = {"max_items_in_session": mi, "batch": BL, "mean_session_items": float(lens.mean()), "share_of_sessions_over_4_items": float((lens > 4).mean())}
-                for tag in (("mid_tier", "without_mid_tier") if mi == 10 else ("mid_tier",)):
+                for tag in (("mid_tier", "without_mid_tier") if mi == 10 else ("mid_tier", "without_long_tier") if mi == 20 else ("mid_tier",)):
                     if tag == "without_mid_tier":
                         os.environ["SRN_NO_MID"] = "1"
+                    if tag == "without_long_tier":
+                        os.environ["SRN_NO_LONG"] = "1"
                     _capi.reload_knobs()
 
                     def lstep():
@@ -586,7 +589,7 @@ def main():
                     ms = float(np.median([a_.elapsed_time(b_) for a_, b_ in es]))
                     _, g_last, _ = index.last_path_counts()
                     entry[tag] = {"queries_per_s": BL / (ms * 1e-3), "ms_p50": ms, "listed_for_mid_instantiation": int(index.last_mid_count()), "reached_general_kernel": int(g_last)}
-                    os.environ.pop("SRN_NO_MID", None)
+                    os.environ.pop("SRN_NO_MID", None); os.environ.pop("SRN_NO_LONG", None)
                     _capi.reload_knobs()
                 entry["parity_checked"] = int(len(gate_positions(BL, 256))); entry["parity_checked_positions"] = "uniform over batch"
                 long_sessions.append(entry)
@@ -613,6 +616,28 @@ def main():
                         traffic, traffic_src = tj["traffic_bytes_per_launch"], os.path.relpath(cand[-1], ROOT)
             except Exception:
                 pass
+
+        # the kernel's OTHER bounds (the memory system moves half the contract's bytes -- frac_measured_copy > 1 --, so the HBM roofline does not explain the
+        # kernel): issue and LDS-pipe utilisation from the SQ counters of the committed PMC passes over this kernel (tools/profiles.sh; never measured inside this run: the
+        # counter passes serialise dispatches)
+        secondary = None
+        try:
+            import glob
+            cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_sq_counters_%s.json" % args.config)))
+            if cand and fast_used:
+                sq = json.load(open(cand[-1]))
+                dq, pq = sq["derived"], sq["per_query"]
+                secondary = [
+                    {"bound": "valu_issue", "frac": dq["valu_busy_per_simd"], "unit": "share of SIMD cycles the vector ALU is busy", "wave_instructions_per_query": {"valu": pq["SQ_INSTS_VALU"], "salu": pq["SQ_INSTS_SALU"], "lds": pq["SQ_INSTS_LDS"]},
+                     "wave_time": {"issuing": dq["wave_time_issuing"], "parked_at_waitcnt_or_barrier": dq["wave_time_parked_waitcnt_or_barrier"], "ready_but_waiting_for_an_issue_slot": dq["wave_time_waiting_for_issue"]}},
+                    {"bound": "lds_atomic", "frac": dq.get("lds_pipe_busy"), "unit": "share of cycles the CU's LDS pipe is active", "bank_conflict_share_of_lds_cycles": dq["lds_bank_conflict_share_of_lds_cycles"],
+                     "lds_cycles_per_query": pq["SQ_LDS_IDX_ACTIVE"], "of_them_bank_conflicts": pq["SQ_LDS_BANK_CONFLICT"]},
+                ]
+                secondary = {"entries": secondary, "source": os.path.relpath(cand[-1], ROOT), "measured_in_this_run": False,
+                             "note": "no single unit is saturated: the kernel is held by dependent LDS / HBM round trips on three workgroups per CU and by issue-slot contention between them (DESIGN.md 4.1); "
+                                     "what moved it in round 5 was memory locality -- the serving order -- not a unit's throughput"}
+        except Exception:
+            secondary = None
 
         result = dict(common)
         result.update({
@@ -642,6 +667,7 @@ def main():
                          "queries_handed_to_general_kernel_last_step": int(general_last), "queries_via_global_table_pass_last_step": int(global_last),
                          "whole_step": {"achieved": step_achieved, "frac": step_achieved / HBM_PEAK_GBS, "note": "all launches of a step (prep + fast + general + finish kernels) against the same algorithmic bytes"},
                          "queries_via_global_table_pass_in_sample": retried, "stats_sample_queries": nstat},
+            "roofline_secondary": secondary,
             "latency": {"step_ms_p50": float(np.percentile(step_ms, 50)), "step_ms_p90": float(np.percentile(step_ms, 90)),
                         "single_query_us_p50": float(np.percentile(lat_single, 50)) if lat_single is not None else None,
                         "single_query_us_p90": float(np.percentile(lat_single, 90)) if lat_single is not None else None,

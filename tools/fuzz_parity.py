@@ -36,8 +36,10 @@ while time.time() < t_end and rounds < max_rounds:
     rng = np.random.default_rng(seed)
     # kernel-path knobs (read once by the library: reloaded per round)
     KNOBS = [{}, {}, {}, {"SRN_NO_FAST": "1"}, {"SRN_NO_MERGE": "1"}, {"SRN_NO_MASKS": "1"}, {"SRN_HOT_SLOTS": "64", "SRN_NO_MASKS": "1"}, {"SRN_SKETCH_SLOTS": "64", "SRN_HOT_SLOTS": "32"},
-             {"SRN_FAST_RUNS": "3"}, {"SRN_NO_MID": "1"}, {"SRN_NO_BIG": "1"}, {}, {"SRN_DENSE": "1"}, {"SRN_TINY_MAX": "1"}, {"SRN_HOST_CHUNKS": "3"}, {"SRN_SKETCH_SLOTS": "0"}, {"SRN_HOT_SLOTS": "0"}]
-    for kk in ("SRN_NO_FAST", "SRN_NO_MID", "SRN_NO_BIG", "SRN_NO_MERGE", "SRN_NO_MASKS", "SRN_HOT_SLOTS", "SRN_SKETCH_SLOTS", "SRN_FAST_RUNS", "SRN_DENSE", "SRN_TINY_MAX", "SRN_HOST_CHUNKS"):
+             {"SRN_FAST_RUNS": "3"}, {"SRN_NO_MID": "1"}, {"SRN_NO_BIG": "1"}, {}, {"SRN_DENSE": "1"}, {"SRN_TINY_MAX": "1"}, {"SRN_HOST_CHUNKS": "3"}, {"SRN_SKETCH_SLOTS": "0"}, {"SRN_HOT_SLOTS": "0"},
+             # round 5: the LONG instantiation, the serving order, the shard group's wave-per-query back end
+             {"SRN_NO_LONG": "1"}, {"SRN_ORDER_MIN": "1"}, {"SRN_ORDER_MIN": "1", "SRN_SBACK_MIN_SHARDS": "2"}, {"SRN_SBACK_MIN_SHARDS": "2"}, {"SRN_SBACK_MIN_SHARDS": "2", "SRN_SBACK_BITMAP": "1"}, {"SRN_NO_SBACK": "1"}, {"SRN_ORDER_MIN": "1"}]
+    for kk in ("SRN_NO_FAST", "SRN_NO_MID", "SRN_NO_BIG", "SRN_NO_MERGE", "SRN_NO_MASKS", "SRN_HOT_SLOTS", "SRN_SKETCH_SLOTS", "SRN_FAST_RUNS", "SRN_DENSE", "SRN_TINY_MAX", "SRN_HOST_CHUNKS", "SRN_NO_LONG", "SRN_ORDER_MIN", "SRN_SBACK_MIN_SHARDS", "SRN_SBACK_BITMAP", "SRN_NO_SBACK"):
         os.environ.pop(kk, None)
     knobs = KNOBS[int(rng.integers(0, len(KNOBS)))]
     os.environ.update(knobs); capi.reload_knobs()
@@ -45,7 +47,7 @@ while time.time() < t_end and rounds < max_rounds:
     n_sessions = int(rng.choice([300, 2000, 8000, 30000])) if not big else int(rng.choice([120000, 300000])); n_items = int(rng.choice([40, 300, 2500])) if not big else int(rng.choice([2500, 20000]))
     row_max = int(rng.choice([4, 12, 34, 80])); tied = bool(rng.random() < 0.3)
     m_index = int(rng.choice([5, 60, 500, 3000])); idfw = float(rng.choice([0.0, 1.0, 2.0, 5.0]))
-    max_q = int(rng.choice([1, 3, 4, 6, 8, 9, 10, 10, 12, 20]))   # (5..10 items: the fast kernel's MID instantiation, round 4)
+    max_q = int(rng.choice([1, 3, 4, 6, 8, 9, 10, 10, 12, 15, 20, 20]))   # (5..10 items: the fast kernel's MID instantiation, round 4)
     off, items, ts, ids = small_dataset(seed, n_sessions=n_sessions, n_items=n_items, tied_timestamps=tied, max_len=row_max)
     gix = sa.VMISIndex.from_sessions(off, items, ts, m_index, row_max, idfw)
     oix = O.OracleIndex(off, items, ts, m_index, row_max, idfw)

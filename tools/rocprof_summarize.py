@@ -93,6 +93,8 @@ def sq(da, db, nq, phase_log):
                "wave_time_waiting_for_issue": c.get("SQ_WAIT_INST_ANY", 0) / wave_cycles if wave_cycles else None,
                "wave_time_issuing": c.get("SQ_ACTIVE_INST_ANY", 0) / wave_cycles if wave_cycles else None,
                "lds_bank_conflict_share_of_lds_cycles": c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"] if c.get("SQ_LDS_IDX_ACTIVE") else None,
+               # a CU retires a query every (a workgroup's wave time per query = SQ_WAVE_CYCLES x 4 / 8 waves) / 3 resident workgroups; its one LDS pipe is active SQ_LDS_IDX_ACTIVE of them
+               "lds_pipe_busy": c["SQ_LDS_IDX_ACTIVE"] / (wave_cycles * 4.0 / 8.0 / 3.0) if c.get("SQ_LDS_IDX_ACTIVE") and wave_cycles else None,
                "instruction_cache_miss_rate": c.get("SQ_IFETCH_LEVEL", None),
                "note": "SQ_WAVE_CYCLES, SQ_ACTIVE_INST_*, SQ_WAIT_* count quad-cycles summed over waves; valu_busy = 6 waves per SIMD x the per-wave share"},
            "phase_cycles_per_query": {}, "method": "rocprofv3 --pmc in two passes (kernel trace only) over tools/count_run.py (three launches of the given batch on config 3); "
