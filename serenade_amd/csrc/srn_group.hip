@@ -143,25 +143,25 @@ uint32_t G_of(const srn_shard_group* g) { return g->kind == srn_shard_group::LOC
 
 // ---- the three collectives.  channel 0 = exchange stream, 1 = caller's stream ----
 int all_reduce_max_i32(srn_shard_group* g, int channel, int* buf, size_t count, hipStream_t st) {
-    g->issued = true;
+    if (g->kind != srn_shard_group::LOCAL) g->issued = true;   // (an in-process group has no peers to leave waiting)
     if (g->kind == srn_shard_group::RCCL) NCCL_TRY(rccl()->AllReduce(buf, buf, count, ncclInt32, ncclMax, g->comm[channel], st));
     else if (g->kind == srn_shard_group::CALLBACKS) { const int rc = g->cb.all_reduce_max_i32(g->cb.user, channel, buf, count, st); if (rc) return fail(rc, "the application's all-reduce callback failed"); }
     return SRN_OK;
 }
 int all_reduce_min_i32(srn_shard_group* g, int channel, int* buf, size_t count, hipStream_t st) {
-    g->issued = true;
+    if (g->kind != srn_shard_group::LOCAL) g->issued = true;   // (an in-process group has no peers to leave waiting)
     if (g->kind == srn_shard_group::RCCL) NCCL_TRY(rccl()->AllReduce(buf, buf, count, ncclInt32, ncclMin, g->comm[channel], st));
     else if (g->kind == srn_shard_group::CALLBACKS) { const int rc = g->cb.all_reduce_min_i32(g->cb.user, channel, buf, count, st); if (rc) return fail(rc, "the application's all-reduce(min) callback failed"); }
     return SRN_OK;
 }
 int all_gather_blocks(srn_shard_group* g, int channel, char* buf, size_t block_bytes, hipStream_t st) {   // block `rank` in place
-    g->issued = true;
+    if (g->kind != srn_shard_group::LOCAL) g->issued = true;   // (an in-process group has no peers to leave waiting)
     if (g->kind == srn_shard_group::RCCL) NCCL_TRY(rccl()->AllGather(buf + (size_t)g->rank * block_bytes, buf, block_bytes, ncclChar, g->comm[channel], st));
     else if (g->kind == srn_shard_group::CALLBACKS) { const int rc = g->cb.all_gather(g->cb.user, channel, buf, block_bytes, st); if (rc) return fail(rc, "the application's all-gather callback failed"); }
     return SRN_OK;
 }
 int all_gather_v(srn_shard_group* g, int channel, char* buf, const unsigned long long* byte_off, const unsigned long long* byte_cnt, hipStream_t st) {   // segment `rank` in place
-    g->issued = true;
+    if (g->kind != srn_shard_group::LOCAL) g->issued = true;   // (an in-process group has no peers to leave waiting)
     if (g->kind == srn_shard_group::RCCL) {
         // every rank ships exactly the entries it holds: grouped point-to-point pairs (xGMI is point-to-point: 7 links per GPU, one per peer)
         NCCL_TRY(rccl()->GroupStart());
