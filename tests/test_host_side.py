@@ -57,6 +57,34 @@ def _product_sessions(path):
     return off, items, ts, q.value
 
 
+def _third_loader(path):
+    """A third, deliberately naive restatement of read_from_file (vmis_index.rs:591-686), written row by row from the reference's loop and sharing no code
+    shape with the product loader (C++) or the oracle's (C): a check that the two agree because the semantics are right, not because one hand wrote both."""
+    rows = []
+    with open(path) as f:
+        next(f)
+        for line in f:
+            a, b, c = line.rstrip("\n").split("\t")
+            t = float(c)
+            rows.append((int(a), int(b), int(np.floor(t + 0.5)) if t >= 0 else -int(np.floor(-t + 0.5))))     # f64::round: half away from zero
+    rows.sort(key=lambda r: r[0])                                 # Python's sort is stable, as sort_by_key is
+    sessions, stamps = [], []
+    cur, cur_max = [rows[0][1]], rows[0][2]
+    for i in range(1, len(rows)):
+        same = rows[i][0] == rows[i - 1][0]
+        if same and i != len(rows) - 1:
+            if rows[i][1] not in cur:
+                cur.append(rows[i][1])
+                cur_max = max(cur_max, rows[i][2])
+        else:                                                     # also taken by the file's LAST row, whatever its session: it opens a session nobody closes
+            sessions.append(sorted(cur))
+            stamps.append(cur_max & 0xFFFFFFFF)
+            cur, cur_max = [rows[i][1]], rows[i][2]
+    off = np.zeros(len(sessions) + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for s in sessions])
+    return off, np.array([x for s in sessions for x in s], np.uint64), np.array(stamps, np.uint32)
+
+
 def test_tsv_loader_matches_read_from_file_quirks(tmp_path):
     """Q8: unsorted input, stable order inside a session, de-dup keeps first, max-ts only from non-duplicate rows,
     f64 timestamps rounded, last row never added and last session dropped."""
@@ -72,6 +100,8 @@ def test_tsv_loader_matches_read_from_file_quirks(tmp_path):
     off, items, ts, q995 = _product_sessions(path)
     o_off, o_items, o_ts, _ = O.read_tsv(str(path))
     assert np.array_equal(off, o_off) and np.array_equal(items, o_items) and np.array_equal(ts, o_ts)
+    t_off, t_items, t_ts = _third_loader(path)
+    assert np.array_equal(off, t_off) and np.array_equal(items, t_items) and np.array_equal(ts, t_ts)
     # hand-made file: session 9's final row is never added; a trailing single-row session is dropped entirely
     p2 = tmp_path / "tiny.tsv"
     _write_tsv(p2, [(7, 30, "10.4"), (9, 5, "20.0"), (7, 10, "11.6"), (7, 30, "99.0"), (9, 6, "21.0"), (9, 8, "22.0")])
@@ -92,6 +122,8 @@ def test_new_from_csv_on_reference_example(tmp_path):
     off, items, ts, q995 = _product_sessions(path)
     o_off, o_items, o_ts, _ = O.read_tsv(path)
     assert np.array_equal(off, o_off) and np.array_equal(items, o_items) and np.array_equal(ts, o_ts)
+    t_off, t_items, t_ts = _third_loader(path)
+    assert np.array_equal(off, t_off) and np.array_equal(items, t_items) and np.array_equal(ts, t_ts)
     assert q995 == 15
     ix = sa.VMISIndex.new_from_csv(path, 500, 1.0, device=-1)     # VMISIndex::new_from_csv(path, m, idf_weighting)
     info = ix.info
