@@ -104,6 +104,7 @@ struct Slot {   // everything one batch in flight needs (grow-only); two slots: 
     char* cand = nullptr; size_t cand_bytes = 0; char* cand_cnt = nullptr; size_t cand_cnt_bytes = 0;
     char* nb = nullptr; size_t nb_bytes = 0; char* nb_cnt = nullptr; size_t nb_cnt_bytes = 0; char* minpos = nullptr; size_t minpos_bytes = 0; char* flagq = nullptr; size_t flagq_bytes = 0;
     // neighbours pipeline: [G * per][k + 1] words (a query's row: K | K packed slots), and every local shard's prep records of the whole batch
+    char* xpos = nullptr; size_t xpos_bytes = 0;   // the neighbours as posting positions (the streaming back end's exchange format)
     char* xchg = nullptr; size_t xchg_bytes = 0; std::vector<char*> nrec; std::vector<size_t> nrec_bytes;
     std::vector<char*> nord; std::vector<size_t> nord_bytes; std::vector<const unsigned long long*> nord_ptr;   // ... and the batch's serving order (keys, sorted keys, scratch)
     hipEvent_t e_done = nullptr;
@@ -121,6 +122,7 @@ struct srn_shard_group {
     ncclComm_t comm[2] = {nullptr, nullptr};   // [0] exchange stream, [1] caller's stream: operations on one communicator serialise in issue order
     srn_shard_comm_t cb{};
     hipStream_t s_x = nullptr; hipEvent_t e_in = nullptr, e_x = nullptr;
+    bool stream_ok = false;   // every shard of this rank holds its fragments in the posting order of g->postings (set_postings): batches of the streaming form's shape exchange positions
     bool overlap = false, no_direct = false;   // overlap: opt-in (srn_shard_group_set_overlap) -- two communicators with collectives in flight at once have never been soaked on more than one GPU
     // A batch that failed after its first collective was issued leaves the peers' collectives without their partner: the group is BROKEN on this rank from then on (every
     // further call fails at once with SRN_ESTATE, the RCCL communicators are aborted so that nothing of this rank keeps a peer waiting), and the peers find out through their
@@ -183,6 +185,7 @@ void slot_free(Slot& s) {
     for (char* p : s.nrec) if (p) hipFree(p);
     for (char* p : s.nord) if (p) hipFree(p);
     if (s.xchg) hipFree(s.xchg);
+    if (s.xpos) hipFree(s.xpos);
     for (char* p : {s.head, s.kept, s.tot, s.off, s.small, s.lists, s.records, s.part, s.cand, s.cand_cnt, s.nb, s.nb_cnt, s.minpos, s.flagq}) if (p) hipFree(p);
     if (s.tot_host) hipHostFree(s.tot_host);
     if (s.e_done) hipEventDestroy(s.e_done);
@@ -302,8 +305,14 @@ int group_predict_neighbours(srn_shard_group* g, const LaunchParams& p_in, bool 
     hipStream_t sx = overlap ? g->s_x : user;
     const uint32_t rec_stride = device_prep_stride(p.max_len), xstride = p.k + 1u, per = (nq + G - 1) / G;
     const size_t block_bytes = ((size_t)nq * n * 16 + (size_t)nq * 4 + 255) / 256 * 256, xblock = (size_t)per * xstride * 4;
+    // Streaming form (round 5): the exchange carries, instead of the neighbour slots, WHERE the neighbours sit in the query's posting lists -- a third of the bytes --, and
+    // every rank's back end streams its fragments in posting order.  Chosen from rank-invariant inputs (batch shape, knobs) + what set_postings settled for this rank.
+    const uint32_t pstride = g->stream_ok ? device_shard_nb_positions_stride(p) : 0u;
+    const bool positions = pstride != 0u;
+    const size_t pblock = (size_t)per * pstride * 4;
     {
         int rc = ensure(&s.xchg, &s.xchg_bytes, (size_t)G * xblock);
+        if (!rc && positions) rc = ensure(&s.xpos, &s.xpos_bytes, (size_t)G * pblock);
         for (size_t i = 0; i < g->shards.size() && !rc; ++i) rc = ensure(&s.nrec[i], &s.nrec_bytes[i], (size_t)nq * rec_stride);
         if (!rc) rc = ensure(&s.part, &s.part_bytes, (size_t)G * block_bytes);
         if (rc) return rc;
@@ -320,9 +329,10 @@ int group_predict_neighbours(srn_shard_group* g, const LaunchParams& p_in, bool 
         int rc = device_shard_nb_prep(g->shards[i]->dev, post, p, s.nrec[i], sx, &s.nord[i], &s.nord_bytes[i], &s.nord_ptr[i]); if (rc) return rc;
         const uint32_t q_lo = std::min<uint64_t>(nq, (uint64_t)gi * per), q_hi = std::min<uint64_t>(nq, (uint64_t)q_lo + per);
         rc = device_shard_nb_front(g->shards[i]->dev, g->shards[i]->flat, post, p, s.nrec[i], (uint32_t*)s.xchg, xstride, q_lo, q_hi, sx); if (rc) return rc;
+        if (positions) { rc = device_shard_nb_positions(g->shards[i]->dev, g->shards[i]->flat, post, p, s.nrec[i], (const uint32_t*)s.xchg, xstride, (uint32_t*)s.xpos, pstride, q_lo, q_hi, sx); if (rc) return rc; }
         if (g->timing && i == 0) HIP_TRY(hipEventRecord(g->e_t[1], sx));
     }
-    { int rc = all_gather_blocks(g, 0, s.xchg, xblock, sx); if (rc) return rc; }
+    { int rc = all_gather_blocks(g, 0, positions ? s.xpos : s.xchg, positions ? pblock : xblock, sx); if (rc) return rc; }
     if (overlap) { HIP_TRY(hipEventRecord(g->e_x, sx)); HIP_TRY(hipStreamWaitEvent(user, g->e_x, 0)); }
     for (size_t i = 0; i < g->shards.size(); ++i) {
         const uint32_t gi = local ? (uint32_t)i : (uint32_t)g->rank;
@@ -332,7 +342,7 @@ int group_predict_neighbours(srn_shard_group* g, const LaunchParams& p_in, bool 
         pi.out_ids = direct ? d_out_ids : (uint64_t*)blk; pi.out_scores = direct ? d_out_scores : (double*)(blk + (size_t)nq * n * 8); pi.out_counts = direct ? d_out_counts : (uint32_t*)(blk + (size_t)nq * n * 16);
         if (g->timing && i == 0) HIP_TRY(hipEventRecord(g->e_t[2], user));
         HIP_TRY(hipMemsetAsync(pi.out_ids, 0, (size_t)nq * n * 8, user)); HIP_TRY(hipMemsetAsync(pi.out_scores, 0, (size_t)nq * n * 8, user));
-        int rc = device_shard_nb_back(g->shards[i]->dev, g->shards[i]->flat, post, pi, s.nrec[i], (uint32_t*)s.xchg, xstride, user, s.nord_ptr[i]); if (rc) return rc;
+        int rc = device_shard_nb_back(g->shards[i]->dev, g->shards[i]->flat, post, pi, s.nrec[i], (uint32_t*)(positions ? s.xpos : s.xchg), positions ? pstride : xstride, user, s.nord_ptr[i], positions); if (rc) return rc;
         if (g->timing && i == 0) HIP_TRY(hipEventRecord(g->e_t[3], user));
     }
     if (G > 1) {
@@ -348,7 +358,7 @@ int group_predict_neighbours(srn_shard_group* g, const LaunchParams& p_in, bool 
         g->last_ms[2] = 0.f; if (G > 1) HIP_TRY(hipEventElapsedTime(&g->last_ms[2], g->e_t[4], g->e_t[5]));
     }
     ++g->calls;
-    g->st_queries += nq; ++g->st_nb_batches; g->st_bytes_nb += G > 1 ? (uint64_t)xblock * (local ? G : 1) : 0;
+    g->st_queries += nq; ++g->st_nb_batches; g->st_bytes_nb += G > 1 ? (uint64_t)(positions ? pblock : xblock) * (local ? G : 1) : 0;
     g->st_bytes_results += G > 1 ? (uint64_t)block_bytes * (local ? G : 1) : 0;
     return SRN_OK;
 }
@@ -606,6 +616,21 @@ int srn_shard_group_set_postings(srn_shard_group_t* g, const srn_index_t* postin
             if (!device_has_packed_rows(sh->dev)) return fail(SRN_ENOMEM, "this rank's shard has no packed rows (no room at attach time): the neighbours pipeline cannot run on this group -- leave the postings unset on EVERY rank");
     }
     g->postings = postings; g->postings_max_row_len = postings ? postings->flat.max_row_len : 0;
+    // this rank's shards keep their fragments a second time, in the posting order of these lists, where there is room (the streaming form of the back end; rank-local and
+    // optional: both forms give the same rows)
+    bool all = !g->shards.empty(), any_geometry = false;
+    for (const srn_index* sh : g->shards) {
+        int rc = device_sback_attach_postings(sh->dev, postings ? postings->dev : nullptr, postings ? postings->flat.nnz_post : 0); if (rc) return rc;
+        all = all && device_sback_streams(sh->dev); any_geometry = any_geometry || device_sback_wanted(sh->dev);
+    }
+    g->stream_ok = postings && all;
+    if (postings && !all && any_geometry) {
+        // the exchange FORMAT follows from this: it must be the same on every rank.  An in-process group sees all its shards and falls back as a whole; a rank of a
+        // distributed group cannot know what its peers got and must not guess
+        for (const srn_index* sh : g->shards) (void)device_sback_attach_postings(sh->dev, nullptr, 0);
+        if (g->kind != srn_shard_group::LOCAL) { g->postings = nullptr;
+            return fail(SRN_ENOMEM, "no room on this rank for its shard's fragments in posting order (8 bytes per posting): run EVERY rank with SRN_SBACK_STREAM=0 (the gather form of the back end)"); }
+    }
     return SRN_OK;
 }
 

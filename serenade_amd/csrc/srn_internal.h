@@ -124,7 +124,8 @@ uint64_t device_bytes(const DeviceState* d);
 struct ExtLists { const char* prep; uint32_t prep_stride; const uint32_t* post_rank;
                   // the shard group's neighbours pipeline: mode 1 = front end only (neighbour lists of the queries [q_lo, nq) -> xchg), 2 = back end (neighbour lists <- xchg)
                   int mode = 0; uint32_t* xchg = nullptr; uint32_t xchg_stride = 0; uint32_t q_lo = 0;
-                  const unsigned long long* order = nullptr; };   // mode 2: the batch's serving order (device_shard_nb_prep sorted it), or null
+                  const unsigned long long* order = nullptr;     // mode 2: the batch's serving order (device_shard_nb_prep sorted it), or null
+                  bool positions = false; };                     // mode 2: xchg holds position records (device_shard_nb_positions), not neighbour slots: the streaming back end
 int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p, bool buffers_on_device, void* stream,
                    // host-pointer mode: these are host buffers copied in/out by the call
                    const uint64_t* h_items, const uint32_t* h_qoff, uint64_t* h_ids, double* h_scores,
@@ -140,6 +141,11 @@ struct ShardIO {
 bool device_shard_lists_supported(DeviceState* d, const FlatIndex& ix, const LaunchParams& p);
 bool device_fast_eligible(DeviceState* d, const FlatIndex& ix, const LaunchParams& p, uint64_t max_row_len_all = 0);   // max_row_len_all != 0: from rank-invariant inputs only (srn_group.hip)
 bool device_has_packed_rows(const DeviceState* d);
+// the shard's fragments once more, in the posting order of `post`'s lists (the streaming form of the wave-per-query back end); optional: no room, or not a shard of that
+// kernel's geometry -> SRN_OK and the gather form runs.  post == nullptr: drop them.
+int device_sback_attach_postings(DeviceState* d, DeviceState* post, uint64_t n_postings);
+bool device_sback_streams(const DeviceState* d);
+bool device_sback_wanted(const DeviceState* d);   // this shard has the wave-per-query back end's rows and the streaming form is not switched off: set_postings expects the copy
 uint64_t device_sback_launches(const DeviceState* d);
 // neighbours pipeline (replicated postings `post`: the whole index's dictionary + lists): prep records of ALL queries (lists looked up in `post`, dense idx in this shard's
 // table), then the front end over the queries [q_lo, q_hi) -> xchg, or the back end over all of them <- xchg
@@ -147,7 +153,10 @@ int device_shard_nb_prep(DeviceState* d, DeviceState* post, const LaunchParams& 
                          const unsigned long long** order_out = nullptr);   // order_buf (grow-only, the caller's): the batch's serving order is sorted into it, *order_out = where (null: batch too small)
 int device_shard_nb_front(DeviceState* d, const FlatIndex& ix, DeviceState* post, const LaunchParams& p, const char* records, uint32_t* xchg, uint32_t xchg_stride, uint32_t q_lo, uint32_t q_hi, void* stream);
 int device_shard_nb_back(DeviceState* d, const FlatIndex& ix, DeviceState* post, const LaunchParams& p, const char* records, uint32_t* xchg, uint32_t xchg_stride, void* stream,
-                         const unsigned long long* order = nullptr);
+                         const unsigned long long* order = nullptr, bool positions = false);
+int device_shard_nb_positions(DeviceState* d, const FlatIndex& ix, DeviceState* post, const LaunchParams& p, const char* records, const uint32_t* xin, uint32_t in_stride, uint32_t* xout, uint32_t out_stride,
+                              uint32_t q_lo, uint32_t q_hi, void* stream);
+uint32_t device_shard_nb_positions_stride(const LaunchParams& p);   // 0: no streaming form for this batch shape / these knobs (rank-invariant)
 uint32_t device_prep_stride(uint32_t max_len);
 int device_shard_lists_head(DeviceState* d, const LaunchParams& p, void* pos, int* head, void* stream);
 int device_shard_lists_count(DeviceState* d, const LaunchParams& p, const void* pos, const int* head, uint32_t* kept, int* tot, void* stream);

@@ -117,8 +117,17 @@ struct SBackParams {
     const ItemMeta* sample;    // meta[] of the shard's 256 most popular items, zero-padded
     double inv_idf_chunk[SB_H / 256];   // 1 / max idf_eff over the dense idx [256 c, 256 c + 256)
     double inv_idf_all;        // 1 / max idf_eff over all items of the shard
+    // the streaming form (all three set, or the gather form runs): the fragments in POSTING order of the replicated lists the batch's records were written against
+    const uint2* frag_post;    // [number of postings] frag_post[e] = frag8[post_rank[e]]
+    const uint32_t* post_rank; // the replicated posting lists (recency ranks)
+    uint32_t* scr;             // shard_back_scratch_words() words per wave of the grid: the members' slots and fragments between walk A and walk B
 };
 hipError_t launch_rows_to_frag8(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base, uint2* frag8, uint4* ext8, uint32_t* present);   // block_base in 16-byte blocks
+hipError_t launch_frag_post(hipStream_t st, const uint32_t* post_rank, const uint2* frag8, uint2* out, uint64_t n);
+uint32_t shard_back_scratch_words();
+hipError_t launch_shard_nb_positions(dim3 grid, hipStream_t st, const char* prep, uint32_t prep_stride, uint32_t max_len, const uint32_t* xin, uint32_t in_stride, uint32_t* xout, uint32_t out_stride,
+                                     const uint32_t* post_rank, uint32_t q_lo, uint32_t q_hi, uint32_t m, bool wide);
+uint32_t shard_nb_positions_stride(uint32_t k, uint32_t m);   // words per query of the streaming form's exchange record; 0: this (k, m) has none
 hipError_t launch_shard_back(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f, const SBackParams& sb, bool debug = false);
 
 // ---- launchers (srn_kernels.hip) -------------------------------------------------------------

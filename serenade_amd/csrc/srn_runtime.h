@@ -42,6 +42,10 @@ struct Knobs {
     bool no_sback = false;    // SRN_NO_SBACK: the shard group's back end through vmis_fast_kernel's FM_BACK instantiation (rounds 4) instead of the wave-per-query kernel of srn_sback.hip
     bool sback_bitmap = false;     // SRN_SBACK_BITMAP=1 (experiments): that kernel asks its presence bitmap before it fetches a fragment.  Measured on config 3 cut in 8: half the fragment
                                    // fetches, but one more DEPENDENT round trip per query on a kernel that spends 65 % of its time waiting for memory -- 1.65 ms with, 1.52 ms without
+    bool no_sback_stream = true;   // SRN_SBACK_STREAM=1 (experiments) turns the STREAMING form of that kernel on: the shard keeps its fragments a second time in posting order (8 B per posting), the
+                                   // exchange carries the neighbours as positions in the posting lists (a third of the bytes), the back end reads the lists' kept prefixes coalesced.  Built and
+                                   // measured in round 5 (profiles/r05_sback_stream_ab.txt): a query's ~4 750 kept postings are 3.5 x its ~1 360 neighbours, and the walk, which memory no longer
+                                   // bounds, is issue-bound on them: 1.92 ms per 131 072 queries against 1.54 for the gather form.  Off by default; same rows either way.
     int sback_min_shards = 8; // SRN_SBACK_MIN_SHARDS: shards of an index cut in at least this many get the frag8 rows (below: fragments of > 4 items are common and the 1 024 + 1 024-word
                               // geometry too small -- config 3 cut in 4 handed 117 K of 131 K queries on; the FM_BACK form of the fast kernel serves those groups)
     int lanes = 4;            // SRN_PREDICT_LANES: concurrent rounds of the srn_predict combiner (srn_combine.cpp)
@@ -66,6 +70,7 @@ struct Workspace {
     char* spill = nullptr; size_t spill_bytes = 0;   // per-block global copies of the neighbour lists
     char* prep = nullptr; size_t prep_bytes = 0;     // per-query records of the prep kernel
     char* order = nullptr; size_t order_bytes = 0;   // the batch's order keys as the prep kernel wrote them | sorted | the sort's scratch
+    char* sb_scr = nullptr; size_t sb_scr_bytes = 0; // the streaming back end's per-wave scratch
     char* order2 = nullptr; size_t order2_bytes = 0; // ... of the second record set (SRN_FLAG_INPUTS_RESIDENT: call i + 1's prep kernel and sort run beside call i's kernels, which still read theirs)
     uint32_t* retry_list2 = nullptr; size_t retry_cap2 = 0; uint32_t* retry_cnt2 = nullptr;   // what the second LDS tier could not hold either
     uint32_t* slow_list = nullptr; size_t slow_cap = 0; uint32_t* slow_cnt = nullptr;          // what the fast kernel hands to the general one
@@ -90,6 +95,7 @@ struct DeviceState {
     ItemMeta* d_meta = nullptr;
     FastParams fast{};            // packed row slots + idf bounds of the fast kernel (row_packed == nullptr: no fast path for this index)
     std::atomic<uint64_t> sback_launches{0};
+    void* sb_frag_post = nullptr; const uint32_t* sb_post_for = nullptr; uint64_t sb_frag_post_bytes = 0;   // the fragments in the posting order of the replicated lists at sb_post_for (device_sback_attach_postings)
     SBackParams sback{};          // item shards: frag8 rows + presence bitmap of the wave-per-query back end (frag8 == nullptr: the FM_BACK form of the fast kernel serves)
     uint32_t host_max_row_len = 0;
     int n_cu = 256;

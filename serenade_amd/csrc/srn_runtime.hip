@@ -36,6 +36,7 @@ static void knobs_read() {
     if (const char* e = getenv("SRN_PREDICT_LANES")) k.lanes = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_ORDER_MIN")) k.order_min = std::max(0, atoi(e));
     k.no_sback = getenv("SRN_NO_SBACK") != nullptr; k.sback_bitmap = getenv("SRN_SBACK_BITMAP") != nullptr && atoi(getenv("SRN_SBACK_BITMAP")) != 0;
+    k.no_sback_stream = !(getenv("SRN_SBACK_STREAM") != nullptr && atoi(getenv("SRN_SBACK_STREAM")) != 0);
     if (const char* e = getenv("SRN_SBACK_MIN_SHARDS")) k.sback_min_shards = std::max(2, atoi(e));
     if (const char* e = getenv("SRN_FAST_RUNS")) k.fast_runs = atoi(e) == 3 ? 3 : 0;   // tests: the fast kernel's 29-bit-rank form (3 lists per query) on a small index
     std::lock_guard<std::mutex> lk(g_knobs_mu); g_knobs = k;
@@ -187,6 +188,7 @@ static void ws_free(Workspace* w) {
     if (w->prep) hipFree(w->prep);
     if (w->order) hipFree(w->order);
     if (w->order2) hipFree(w->order2);
+    if (w->sb_scr) hipFree(w->sb_scr);
     if (w->retry_list2) hipFree(w->retry_list2);
     if (w->retry_cnt2) hipFree(w->retry_cnt2);
     if (w->slow_list) hipFree(w->slow_list);
@@ -212,6 +214,7 @@ void device_release(DeviceState* d) {
     hostpipes_free(d);
     for (Workspace* w : d->all_ws) ws_free(w);
     for (void* p : d->allocs) hipFree(p);
+    if (d->sb_frag_post) hipFree(d->sb_frag_post);
     delete d;
 }
 
@@ -234,6 +237,30 @@ int device_update_attr(DeviceState* d, const FlatIndex& ix) {
 }
 uint64_t device_bytes(const DeviceState* d) { return d ? d->bytes : 0; }
 bool device_has_packed_rows(const DeviceState* d) { return d && d->fast.row_packed != nullptr; }
+bool device_sback_streams(const DeviceState* d) { return d && d->sb_frag_post != nullptr; }
+bool device_sback_wanted(const DeviceState* d) { return d && d->sback.frag8 != nullptr && !knobs().no_sback_stream && !knobs().no_sback; }
+int device_sback_attach_postings(DeviceState* d, DeviceState* post, uint64_t n_postings) {
+    if (!d) return SRN_OK;
+    HIP_TRY(hipSetDevice(d->device));
+    if (d->sb_frag_post && (!post || d->sb_post_for != post->di.post_rank)) {   // (another index's lists, or none: the old copy goes -- after whatever still reads it)
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(d->sb_frag_post)); d->bytes -= d->sb_frag_post_bytes; d->sb_frag_post = nullptr; d->sb_post_for = nullptr; d->sb_frag_post_bytes = 0;
+    }
+    if (!post || !d->sback.frag8 || d->sb_frag_post || n_postings == 0 || knobs().no_sback_stream || knobs().no_sback) return SRN_OK;
+    const uint64_t need = n_postings * 8;
+    size_t free_b = 0, total_b = 0; HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    if (free_b < need + std::max<uint64_t>(total_b / 16, 4ull << 30)) {   // (optional: a sixteenth of the device stays free for the batches' workspaces)
+        if (knobs().debug) fprintf(stderr, "[srn] no room for the fragments in posting order (%llu bytes, %zu free): the back end gathers\n", (unsigned long long)need, free_b);
+        return SRN_OK;
+    }
+    void* fp = nullptr;
+    if (hipMalloc(&fp, need) != hipSuccess) { (void)hipGetLastError(); return SRN_OK; }
+    if (launch_frag_post(nullptr, post->di.post_rank, d->sback.frag8, (uint2*)fp, n_postings) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        const hipError_t e = hipGetLastError(); hipFree(fp); return fail(SRN_EHIP, std::string("fragments in posting order: ") + hipGetErrorString(e));
+    }
+    d->sb_frag_post = fp; d->sb_post_for = post->di.post_rank; d->sb_frag_post_bytes = need; d->bytes += need;
+    return SRN_OK;
+}
 uint64_t device_sback_launches(const DeviceState* d) { return d ? d->sback_launches.load() : 0; }
 int device_count() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
 
@@ -369,12 +396,15 @@ static int make_geometry(const DeviceState* d, const FlatIndex& ix, const Launch
 // at ITS session lengths (<= 10 items: the admission is per query, on the device); the batch's longest session only decides which kernels serve the hand-overs -- up to
 // round 3 one session of nine items sent the whole batch to the general kernel.
 struct FastPlan { bool fast = false, mid_tier = false, long_tier = false; uint32_t nb_fast = 0; };
+static uint32_t fast_nb(const FlatIndex& ix, const Knobs& kn) {   // bits of a fast-kernel slot's list set (0: the index has too many sessions for any)
+    const int rank_bits_f = std::max(1, bits_host(ix.n_kept ? ix.n_kept - 1 : 0));
+    return kn.fast_runs == 3 && rank_bits_f <= 29 ? 3u : rank_bits_f <= 28 ? 4u : rank_bits_f <= 29 ? 3u : 0u;
+}
 static FastPlan fast_plan(const DeviceState* d, const FlatIndex& ix, const LaunchParams& p, const Geometry& geo, const Knobs& kn, bool has_ext) {
     FastPlan f;
     // the fast kernel packs (rank, set of <= 4 lists) into 32 bits whatever the general kernel's slots look like: up to 2^28 sessions with 4 lists per query,
     // up to 2^29 with 3 (queries with more go to the MID instantiation / the general kernel)
-    const int rank_bits_f = std::max(1, bits_host(ix.n_kept ? ix.n_kept - 1 : 0));
-    f.nb_fast = kn.fast_runs == 3 && rank_bits_f <= 29 ? 3u : rank_bits_f <= 28 ? 4u : rank_bits_f <= 29 ? 3u : 0u;
+    f.nb_fast = fast_nb(ix, kn);
     const bool sets_exact = p.m <= ix.m_index && ix.lists_complete && !kn.no_masks;
     // (a sketch word sums the POSITIVE parts: <= k rows of <= max_row_len items, weight <= 9 * numerator; numerators <= 55 at 10 items, <= 210 at 20)
     const bool fast_sketch_ok = (uint64_t)p.k * std::max<uint64_t>(1, ix.max_row_len) * 9ull * (p.max_len > 10 ? 210ull : 55ull) < (1ull << 32);
@@ -678,9 +708,17 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         if (back && d->sback.frag8 && !kn.no_sback && p.max_len <= 8) {
             // the item shard's own back end (srn_sback.hip): one wave per query, 12 per CU; a persistent grid of a few waves per resident slot
             SBackParams sbp = d->sback; if (!kn.sback_bitmap) sbp.present = nullptr;
-            const uint64_t slots = (uint64_t)d->n_cu * 12;
-            const uint32_t grid_b = (uint32_t)std::min<uint64_t>(p.nq, slots * (kn.grid_mult_set ? grid_mult : 8));
-            HIP_TRY(launch_shard_back(dim3(fp.order ? std::max<uint32_t>(8u, grid_b / 8u * 8u) : grid_b), st, di, p, fp, sbp, kn.debug));
+            // the streaming form where the shard holds its fragments in the posting order of the very lists the records were written against (9 waves per CU: 16.8 KB each)
+            const bool stream = ext->positions;
+            if (stream && !(d->sb_frag_post && d->sb_post_for == ext->post_rank)) return fail(SRN_ESTATE, "the batch's neighbours came as posting positions, but this shard does not hold its fragments in posting order");
+            const uint64_t slots = (uint64_t)d->n_cu * (stream ? 9 : 12);
+            uint32_t grid_b = (uint32_t)std::min<uint64_t>(p.nq, slots * (kn.grid_mult_set ? grid_mult : stream ? 4 : 8));
+            if (fp.order) grid_b = std::max<uint32_t>(8u, grid_b / 8u * 8u);
+            if (stream) {
+                int rc = ensure(&w->sb_scr, &w->sb_scr_bytes, (size_t)grid_b * shard_back_scratch_words() * 4); if (rc) return rc;
+                sbp.frag_post = (const uint2*)d->sb_frag_post; sbp.post_rank = ext->post_rank; sbp.scr = (uint32_t*)w->sb_scr;
+            }
+            HIP_TRY(launch_shard_back(dim3(grid_b), st, di, p, fp, sbp, kn.debug));
             d->sback_launches.fetch_add(1, std::memory_order_relaxed);
         } else
         HIP_TRY(launch_fast(dim3(grid_fo), st, di, p, fp, kn.debug, back ? 2 : 0));
@@ -850,9 +888,25 @@ int device_shard_nb_front(DeviceState* d, const FlatIndex& ix, DeviceState* post
     ExtLists ext{records, device_prep_stride(p.max_len), post->di.post_rank, 1, xchg, xchg_stride, q_lo};
     return device_predict(d, ix, p, true, stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &ext);
 }
-int device_shard_nb_back(DeviceState* d, const FlatIndex& ix, DeviceState* post, const LaunchParams& p, const char* records, uint32_t* xchg, uint32_t xchg_stride, void* stream, const unsigned long long* order) {
+// the fronting rank's neighbour lists [q_lo, q_hi) of `xin` -> position records in `xout` (the streaming form's exchange format, srn_sback.hip)
+int device_shard_nb_positions(DeviceState* d, const FlatIndex& ix, DeviceState* post, const LaunchParams& p, const char* records, const uint32_t* xin, uint32_t in_stride, uint32_t* xout, uint32_t out_stride,
+                              uint32_t q_lo, uint32_t q_hi, void* stream) {
+    if (q_lo >= q_hi) return SRN_OK;
+    HIP_TRY(hipSetDevice(d->device));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(q_hi - q_lo, (uint64_t)d->n_cu * 16 * 4);
+    HIP_TRY(launch_shard_nb_positions(dim3(grid), (hipStream_t)stream, records, device_prep_stride(p.max_len), p.max_len, xin, in_stride, xout, out_stride, post->di.post_rank, q_lo, q_hi, p.m,
+                                      fast_nb(ix, knobs()) == 3u));
+    return SRN_OK;
+}
+// words per query of that format for this batch shape, 0 if the batch (or this build's knobs) has no streaming form: RANK-INVARIANT inputs only
+uint32_t device_shard_nb_positions_stride(const LaunchParams& p) {
+    const Knobs kn = knobs();
+    if (kn.no_sback_stream || kn.no_sback || p.max_len > 8) return 0u;
+    return shard_nb_positions_stride(p.k, p.m);
+}
+int device_shard_nb_back(DeviceState* d, const FlatIndex& ix, DeviceState* post, const LaunchParams& p, const char* records, uint32_t* xchg, uint32_t xchg_stride, void* stream, const unsigned long long* order, bool positions) {
     if (p.nq == 0) return SRN_OK;
-    ExtLists ext{records, device_prep_stride(p.max_len), post->di.post_rank, 2, xchg, xchg_stride, 0u, order};
+    ExtLists ext{records, device_prep_stride(p.max_len), post->di.post_rank, 2, xchg, xchg_stride, 0u, order, positions};
     return device_predict(d, ix, p, true, stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &ext);
 }
 

@@ -21,6 +21,7 @@
 // =====================================================================================
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 
 #include "srn_device.h"
@@ -28,6 +29,10 @@
 
 namespace srn {
 
+#ifndef SRN_SBACK_PF
+#define SRN_SBACK_PF 10   // chunks of 64 postings a wave of the streaming form keeps in flight
+#endif
+static constexpr uint32_t SB_PF = SRN_SBACK_PF;
 // LDS map of one wave (= one workgroup), bytes
 static constexpr uint32_t SB_MISC = 0, SB_WTAB = 128, SB_CAND = 192, SB_CAND_CAP = 128, SB_TABLE = SB_CAND + SB_CAND_CAP * 12 /* 1728 */, SB_BUCKETS = 61,
                           SB_TABLE_WORDS = 256 /* 61 buckets of 4 slots, padded */, SB_HOT = SB_TABLE + SB_TABLE_WORDS * 8 /* 3776 */;
@@ -36,6 +41,14 @@ static constexpr uint32_t SB_LDS = SB_HOT + (SB_H + SB_S + SB_DUMP) * 4;
 static constexpr uint32_t SB_LQ_CAP = (SB_HOT - SB_CAND) / 8;   // long fragments a query may queue (448)
 static constexpr uint32_t SB_LQB_CAP = 160, SB_HIT_CAP = (SB_H * 4 - SB_LQB_CAP * 12) / 8;   // walk B's hit list and its queue of long fragments live in the direct-mapped words (dead by then)
 static_assert(SB_HOT % 16 == 0 && SB_TABLE % 16 == 0 && SB_CAND % 8 == 0, "alignment");
+// The STREAMING form (see the kernel) reads, instead of the neighbour slots, the query's neighbours as POSITIONS in its items' posting lists (written by
+// shard_nb_positions_kernel below on the rank that fronts the query): per run a bitmap over the kept prefix, then the members' list sets as nibbles in stream order.  Record
+// of a query, 32-bit words: [0] K (0xFFFFFFFF: no front end took it)  [1] 0  [2 + 2 (r mw + c)] 64-bit word c of run r's bitmap, mw = ceil(m / 64), r < 4
+// [2 + 8 mw + i / 8] nibble i % 8: list set of the i-th member.  In LDS the bitmaps and nibbles take the candidate buffer's and the exact table's room (dead until the harvest).
+static constexpr uint32_t SB_SCR_ENTRIES = F_K_MAX + 128, SB_SCR_WORDS = 3 * SB_SCR_ENTRIES;   // a wave's scratch in HBM: the members' positions (4 B), then their fragments (8 B)
+static constexpr uint32_t SB_REC_ROOM = SB_HOT - SB_CAND;   // bytes of bitmaps + nibbles a query may bring (3 584)
+// the conversion kernel's own LDS: the neighbour slots as a hash table, 256 buckets of 8 slots, two candidate buckets per key (no overflow in 40 x 1 500 simulated keys), + the nibbles
+static constexpr uint32_t SBP_BUCKETS = 256, SBP_CODES = SBP_BUCKETS * 32, SBP_WTAB = SBP_CODES + F_K_MAX / 2 + 32, SBP_LDS = SBP_WTAB + 64;
 
 // -------------------------------------------------------------------------------------
 // Attach time: an item shard's CSR row fragments -> frag8 slots + overflow blocks + presence bitmap
@@ -96,8 +109,9 @@ hipError_t launch_rows_to_frag8(hipStream_t st, const uint64_t* row_off, const u
 #ifndef SRN_SBACK_WAVES
 #define SRN_SBACK_WAVES 3   // waves per SIMD the register allocation is sized for (12 per CU: the LDS allows 13)
 #endif
-template <bool BITMAP>
+template <bool BITMAP, bool STREAM>
 __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(DeviceIndex ix_arg, LaunchParams p_arg, FastParams f_arg, SBackParams sb_arg) {
+    constexpr uint32_t HOT_OFF = SB_HOT;
     __shared__ __attribute__((aligned(16))) char smem[SB_LDS];
     // the parameter blocks are read from the kernel-argument segment where they are used (as the fast kernel does): loaded up front they would sit in ~120 SGPRs for the
     // kernel's whole life, and the spills of those land in VGPRs
@@ -117,10 +131,11 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
     uint32_t* cidx = (uint32_t*)(smem + SB_CAND + SB_CAND_CAP * 8);
     uint32_t* ikeys = (uint32_t*)(smem + SB_TABLE);
     int* iacc = (int*)(smem + SB_TABLE + SB_TABLE_WORDS * 4);
-    char* const acc_base = smem + SB_HOT;
-    uint32_t* hot = (uint32_t*)(smem + SB_HOT);
-    uint2* hits = (uint2*)(smem + SB_HOT);
-    uint2* lqb = (uint2*)(smem + SB_HOT + SB_HIT_CAP * 8); uint32_t* lqb_len = (uint32_t*)(smem + SB_HOT + SB_HIT_CAP * 8 + SB_LQB_CAP * 8);
+    char* const acc_base = smem + HOT_OFF;
+    uint32_t* hot = (uint32_t*)(smem + HOT_OFF);
+    uint2* hits = (uint2*)(smem + HOT_OFF);
+    uint2* lqb = (uint2*)(smem + HOT_OFF + SB_HIT_CAP * 8); uint32_t* lqb_len = (uint32_t*)(smem + HOT_OFF + SB_HIT_CAP * 8 + SB_LQB_CAP * 8);
+    uint32_t* lm = (uint32_t*)(smem + SB_CAND);   // (STREAM) the record's bitmaps, then its nibbles
     uint2* lq = (uint2*)(smem + SB_CAND);   // walk A's queue of long fragments: over the candidate buffer and the exact table, both dead until the harvest
     const bool business = (p.flags & SRN_FLAG_BUSINESS_LOGIC) != 0u;
     const bool wide = f.nb == 3u;
@@ -149,12 +164,14 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
         // ---- the query's record and its neighbour slots: ONE round trip (the slots past K are stale words of the query's own row, masked below) ----
         struct { uint32_t U, xlo, L, cur_attr; } h0;   // (uniform addresses: scalar loads)
         { const PrepHead* hp = (const PrepHead*)rec; h0.U = hp->U; h0.xlo = hp->xlo; h0.L = hp->L; h0.cur_attr = hp->cur_attr; }
-        uint32_t it_idx = kNone, it_kept = 0u;
-        if (lane < 8u && lane < h0.L && lane < p.max_len) { const PrepItem pi = ((const PrepItem*)(rec + sizeof(PrepHead)))[lane]; it_idx = pi.idx; it_kept = pi.kept; }
+        uint32_t it_idx = kNone, it_kept = 0u; unsigned long long it_base = 0ull;
+        if (lane < 8u && lane < h0.L && lane < p.max_len) { const PrepItem pi = ((const PrepItem*)(rec + sizeof(PrepHead)))[lane]; it_idx = pi.idx; it_kept = pi.kept; it_base = pi.base; }
         const uint32_t kv = xq[0];
-        uint32_t sv[NCH];
+        uint32_t sv[NCH];   // gather form: the neighbour slots; streaming form: the members' {position | run << 20 | weight << 24}, read back from the scratch after walk A
+        if constexpr (!STREAM) {
 #pragma unroll
-        for (uint32_t c = 0; c < NCH; ++c) sv[c] = xq[1u + min(c * 64u + lane, f.xchg_stride - 2u)];
+            for (uint32_t c = 0; c < NCH; ++c) sv[c] = xq[1u + min(c * 64u + lane, f.xchg_stride - 2u)];
+        }
         const uint32_t K = (uint32_t)__builtin_amdgcn_readfirstlane((int)kv);
         const uint32_t L = h0.L, U = h0.U, cur_attr = h0.cur_attr;
         if (K == 0xFFFFFFFFu || L < 1u || L > 8u || L > p.max_len || K > F_K_MAX) {   // (wave-uniform) no front end took it, or not this kernel's shape: the general kernel does its candidate work itself
@@ -167,8 +184,8 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
         const bool rel = wide && nr > 3u;
         const uint32_t NB = wide && !rel ? 3u : 4u, NBM = (1u << NB) - 1u, base = rel ? h0.xlo : 0u;
         const uint32_t cur_idx = (uint32_t)__builtin_amdgcn_readlane((int)it_idx, 0);
+        uint32_t ps[4];   // position (= lane of the record's item) of run r
         {   // weight of each list set: 10 * linear_score(first match) * numerator (mod.rs:110-116, 133-144); runs are numbered in position order
-            uint32_t ps[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { ps[r] = rm ? (uint32_t)__ffsll((long long)rm) - 1u : 0u; rm &= rm - 1ull; }
             if (lane < 16u) {
@@ -179,7 +196,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
             }
         }
         {   // clear: accumulators + sketch + dump (the exact table is cleared after walk A: its words hold the long fragments' queue until then)
-            uint4* z = reinterpret_cast<uint4*>(smem + SB_HOT);
+            uint4* z = reinterpret_cast<uint4*>(smem + HOT_OFF);
             for (uint32_t i = lane; i < (SB_H + SB_S + SB_DUMP) / 4u; i += 64u) z[i] = make_uint4(0u, 0u, 0u, 0u);
         }
         __syncthreads();   // (one wave: orders the LDS traffic; no other wave to wait for)
@@ -190,6 +207,90 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
         auto add2 = [&](uint32_t wd, uint32_t w) { atomicAdd((uint32_t*)(acc_base + (wd & 0xFFFFu)), w); atomicAdd((uint32_t*)(acc_base + (wd >> 16)), w); };
         uint32_t pm = 0u;    // bit c: this lane's neighbour of chunk c holds an item of this shard (kept for walk B)
         uint32_t nlq = 0u;   // (wave-uniform) long fragments queued
+        uint2 fr[NCH];   // a lane's <= 24 fragments: they STAY in registers for walk B -- with 12 x 32 queries in flight per XCD (33 MB of fragment lines against 4 MB of L2) a
+                                      // second fetch misses like the first: walk B took as long as walk A (54 K against 50 K cycles per query) until it stopped fetching
+        uint32_t nscr = 0u;  // (STREAM, wave-uniform) members with a non-empty fragment, listed in the wave's scratch for walk B
+        unsigned long long lbase[4] = {0ull, 0ull, 0ull, 0ull};   // (STREAM) where the runs' posting lists start
+        bool st_fail = false;
+        if constexpr (STREAM) {
+            // ---- walk A, streaming form.  The gather form asks for one fragment per (query, neighbour) at a random place: 178 M requests per batch of config 3, a third of
+            // them past the L2 -- 128 bytes fetched for 8 used, 55 G requests/s chip-wide (tools/shard_gather_bench) -- and that is the kernel's time whatever the wave count
+            // or the number of dependent trips.  Here the fragments are stored a second time IN POSTING ORDER (frag_post[e] = fragment of the session post_rank[e]): a query's
+            // neighbours all lie in the kept prefixes of its items' posting lists, the rank that fronted the query has said WHERE (a bitmap per list; a neighbour in several
+            // lists counts in the first), and the wave reads those prefixes coalesced -- the same lines for every query that shares the item, and the serving order puts
+            // such queries next to each other.  The loop body is STRAIGHT-LINE code (selects, no branches: non-members add 0 to the lane's own dump word and store into a
+            // trash place of the scratch): with a branch per chunk the compiler cannot overlap the chunks' dependent LDS reads (bitmap word -> member index -> weight), and
+            // those, not memory, were the walk's time (70 K cycles per query against 25 K for the gather form).
+            const uint2* const frag_post = sb.frag_post;
+            uint32_t* const scr_w = sb.scr + (size_t)blockIdx.x * SB_SCR_WORDS; uint2* const scr_f = reinterpret_cast<uint2*>(scr_w + SB_SCR_ENTRIES);
+            const uint32_t mw = (p.m + 63u) >> 6, ncw = (K + 7u) >> 3;
+            uint8_t* const lw8 = reinterpret_cast<uint8_t*>(lm + 8u * mw);   // the members' weights, one byte each (<= 234), in stream order
+            {   // the record's bitmaps (runs present only) -> LDS; its nibbles -> weights
+                for (uint32_t i = lane; i < 2u * nr * mw; i += 64u) lm[i] = xq[2u + i];
+                for (uint32_t i = lane; i < ncw; i += 64u) {
+                    const uint32_t c8 = xq[2u + 8u * mw + i];
+                    uint32_t lo = 0u, hi = 0u;
+#pragma unroll
+                    for (uint32_t n4 = 0; n4 < 4u; ++n4) { lo |= (uint32_t)wtab[(c8 >> (4u * n4)) & 15u] << (8u * n4); hi |= (uint32_t)wtab[(c8 >> (16u + 4u * n4)) & 15u] << (8u * n4); }
+                    reinterpret_cast<uint2*>(lw8)[i] = make_uint2(lo, hi);
+                }
+            }
+            __syncthreads();
+            const uint32_t dump1 = (SB_H + SB_S + lane) * 4u, dump2 = dump1 | (dump1 << 16);
+            uint32_t nmem = 0u;   // (wave-uniform) members met so far = index of the next weight
+            for (uint32_t r = 0; r < nr; ++r) {   // (wave-uniform)
+                const uint32_t pl = r == 0u ? ps[0] : r == 1u ? ps[1] : r == 2u ? ps[2] : ps[3];
+                const uint32_t kept = (uint32_t)__builtin_amdgcn_readlane((int)it_kept, (int)pl);
+                const unsigned long long lb = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(it_base >> 32), (int)pl) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)it_base, (int)pl);
+                lbase[0] = r == 0u ? lb : lbase[0]; lbase[1] = r == 1u ? lb : lbase[1]; lbase[2] = r == 2u ? lb : lbase[2]; lbase[3] = r == 3u ? lb : lbase[3];
+                const unsigned long long* const bm64 = reinterpret_cast<const unsigned long long*>(lm) + (size_t)r * mw;
+                for (uint32_t j0 = 0; j0 < kept; j0 += 64u * SB_PF) {   // (SB_PF chunks of 64 postings in flight at once)
+                    uint2 fg[SB_PF];
+#pragma unroll
+                    for (uint32_t u = 0; u < SB_PF; ++u) fg[u] = frag_post[lb + (j0 + u * 64u < kept ? min(j0 + u * 64u + lane, kept - 1u) : 0u)];   // (past the list's end: its first line again)
+#pragma unroll
+                    for (uint32_t u = 0; u < SB_PF; ++u) {
+                        const bool in = j0 + u * 64u < kept;   // (wave-uniform)
+                        const unsigned long long mk0 = bm64[min((j0 >> 6) + u, mw - 1u)], mk = in ? mk0 : 0ull;
+                        const bool mem = (mk >> lane) & 1ull;
+                        const uint32_t idx = nmem + (uint32_t)__popcll(mk & lt);
+                        nmem += (uint32_t)__popcll(mk);
+                        const uint32_t w0 = (uint32_t)lw8[min(idx, F_K_MAX - 1u)], w = mem ? w0 : 0u;
+                        const uint32_t o0 = fg[u].x & 0xFFFFu;
+                        const bool lng = mem && o0 == 0xFFFFu;
+                        const bool pr = mem && (lng || o0 < (SB_H + SB_S) * 4u);   // (a fragment's items fill its positions from the first: a dump offset there = an empty fragment)
+                        const bool ac = pr && !lng;                                // (long fragments: from the scratch, below)
+                        add2(ac ? fg[u].x : dump2, w); add2(ac ? fg[u].y : dump2, w);
+                        const unsigned long long bm = __ballot(pr);
+                        const uint32_t at = pr ? min(nscr + (uint32_t)__popcll(bm & lt), F_K_MAX + 63u) : F_K_MAX + 64u + lane;   // (non-members: a trash place)
+                        scr_w[at] = (j0 + u * 64u + lane) | (r << 20) | (w << 24); scr_f[at] = fg[u];
+                        nscr += (uint32_t)__popcll(bm);
+                    }
+                }
+            }
+            if (nmem != K || nscr > F_K_MAX) st_fail = true;   // (the record does not describe K neighbours: the general kernel serves the query)
+            // the members with a fragment, back from the scratch into registers (they stay there for walk B, as the gather form's do); the long ones are queued as there
+            __syncthreads();
+#pragma unroll
+            for (uint32_t c = 0; c < NCH; ++c) {
+                sv[c] = 0u; fr[c] = make_uint2(0u, 0u);
+                if (c * 64u < nscr) { const uint32_t i = min(c * 64u + lane, nscr - 1u); sv[c] = scr_w[i]; fr[c] = scr_f[i]; }   // (wave-uniform branch: no load is waited for inside)
+            }
+#pragma unroll
+            for (uint32_t c = 0; c < NCH; ++c) {
+                if (c * 64u < nscr) {
+                    const bool pr = c * 64u + lane < nscr;
+                    pm |= pr ? 1u << c : 0u;
+                    const bool lng = pr && (fr[c].x & 0xFFFFu) == 0xFFFFu;
+                    const unsigned long long lbm = __ballot(lng);
+                    if (lbm) {
+                        const uint32_t at = nlq + (uint32_t)__popcll(lbm & lt);
+                        if (lng && at < SB_LQ_CAP) lq[at] = make_uint2(((sv[c] >> 24) << 16) | (fr[c].x >> 16), fr[c].y);
+                        nlq += (uint32_t)__popcll(lbm);
+                    }
+                }
+            }
+        } else {
         {
             uint32_t pwv[NCH];
 #pragma unroll
@@ -204,8 +305,6 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
 #pragma unroll
             for (uint32_t c = 0; c < NCH; ++c) pm |= (pwv[c] & 1u) << c;
         }
-        uint2 fr[NCH];   // a lane's <= 24 fragments: they STAY in registers for walk B -- with 12 x 32 queries in flight per XCD (33 MB of fragment lines against 4 MB of L2) a
-                         // second fetch misses like the first: walk B took as long as walk A (54 K against 50 K cycles per query) until it stopped fetching
         {
 #pragma unroll
             for (uint32_t c = 0; c < NCH; ++c) {
@@ -230,7 +329,8 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                 }
             }
         }
-        bool fail = nlq > SB_LQ_CAP;   // (wave-uniform)
+        }
+        bool fail = st_fail || nlq > SB_LQ_CAP;   // (wave-uniform)
         if (fail) c15 += 1ull << 20;
         if (nlq && !fail) {
             __syncthreads();
@@ -351,7 +451,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
             {   // (the fragments are walk A's, still in registers)
 #pragma unroll
                 for (uint32_t c = 0; c < NCH; ++c) {
-                    if (c * 64u >= K) continue;   // (wave-uniform)
+                    if (c * 64u >= (STREAM ? nscr : K)) continue;   // (wave-uniform)
                     const bool pr = (pm >> c) & 1u, lng = pr && (fr[c].x & 0xFFFFu) == 0xFFFFu;
                     uint32_t hm = 0;
                     if (pr && !lng) hm = (chk(fr[c].x & 0xFFFFu) ? 1u : 0u) | (chk(fr[c].x >> 16) ? 2u : 0u) | (chk(fr[c].y & 0xFFFFu) ? 4u : 0u) | (chk(fr[c].y >> 16) ? 8u : 0u);
@@ -387,12 +487,18 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                 bool ovf = false;
                 for (uint32_t i = lane; i < nh; i += 64u) {
                     const uint2 h = hits[i];
-                    const uint32_t* os = reinterpret_cast<const uint32_t*>(ix.row_slots + (size_t)(base + (h.x >> NB)));   // the general 16-byte fragment slot: {len, i0, i1, i2} | {len, ext offset, i0, i1}
+                    size_t row;
+                    if constexpr (STREAM) {   // (the hit names a posting: run, position -> the session's rank, one more fetch for the ~60 hits of a query)
+                        const uint32_t hr = (h.x >> 20) & 3u;
+                        const unsigned long long hb = hr == 0u ? lbase[0] : hr == 1u ? lbase[1] : hr == 2u ? lbase[2] : lbase[3];
+                        row = (size_t)sb.post_rank[hb + (h.x & 0xFFFFFu)];
+                    } else row = (size_t)(base + (h.x >> NB));
+                    const uint32_t* os = reinterpret_cast<const uint32_t*>(ix.row_slots + row);   // the general 16-byte fragment slot: {len, i0, i1, i2} | {len, ext offset, i0, i1}
                     const uint32_t len = os[0], j = h.y;
                     uint32_t it = EMPTY32;
                     if (j < len) it = len <= 3u ? os[1 + j] : (j < 2u ? os[2 + j] : ix.row_ext[os[1] + (j - 2u)]);   // (a position past the end was a dump word)
                     if (business && it != EMPTY32 && it >= SB_DIRECT && !business_ok(cur_attr, ix.meta[it].attr)) it = EMPTY32;
-                    if (it != EMPTY32 && it >= SB_DIRECT && item_insert(ikeys, iacc, SB_BUCKETS, it, (int)(uint32_t)wtab[h.x & NBM]) < 0) ovf = true;
+                    if (it != EMPTY32 && it >= SB_DIRECT && item_insert(ikeys, iacc, SB_BUCKETS, it, (int)(STREAM ? h.x >> 24 : (uint32_t)wtab[h.x & NBM])) < 0) ovf = true;
                 }
                 if (__ballot(ovf) != 0ull) { fail = true; c7 += 1ull << 32; }
             }
@@ -451,10 +557,129 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
 
 hipError_t launch_shard_back(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f, const SBackParams& sb, bool debug) {
     static bool told = false;
-    if (!told && debug) { told = true; int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)vmis_shard_back_kernel<true>, 64, 0);
-        fprintf(stderr, "[srn] vmis_shard_back_kernel: %u bytes of LDS per wave, %d waves per CU (occupancy API)\n", SB_LDS, nb); }
-    if (sb.present) hipLaunchKernelGGL(vmis_shard_back_kernel<true>, grid, dim3(64), 0, st, di, p, f, sb);
-    else hipLaunchKernelGGL(vmis_shard_back_kernel<false>, grid, dim3(64), 0, st, di, p, f, sb);
+    if (!told && debug) { told = true; int nb = 0, ns = 0; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)vmis_shard_back_kernel<false, false>, 64, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&ns, (const void*)vmis_shard_back_kernel<false, true>, 64, 0);
+        fprintf(stderr, "[srn] vmis_shard_back_kernel: %u bytes of LDS per wave; gather form %d waves per CU, streaming form %d (occupancy API)\n", SB_LDS, nb, ns); }
+    if (sb.frag_post && sb.post_rank && sb.scr) hipLaunchKernelGGL((vmis_shard_back_kernel<false, true>), grid, dim3(64), 0, st, di, p, f, sb);
+    else if (sb.present) hipLaunchKernelGGL((vmis_shard_back_kernel<true, false>), grid, dim3(64), 0, st, di, p, f, sb);
+    else hipLaunchKernelGGL((vmis_shard_back_kernel<false, false>), grid, dim3(64), 0, st, di, p, f, sb);
+    return hipGetLastError();
+}
+uint32_t shard_back_scratch_words() { return SB_SCR_WORDS; }
+
+// -------------------------------------------------------------------------------------
+// Neighbour slots -> positions in the posting lists (the streaming form's record, see the constants above), on the rank that fronted the query: one wave per query; the
+// slots into a hash table (two candidate buckets of 8), the kept prefixes of the query's lists streamed past it (ranks, coalesced; the front end has just read them), a
+// ballot per 64 entries = one word of the list's bitmap.  A neighbour found in several lists is marked in the first (the lowest bit of its list set) and only there.
+// Whatever does not come out as exactly K marks goes the way of a query no front end took: marker, every rank's general kernel.
+// -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void shard_nb_positions_kernel(const char* __restrict__ prep, uint32_t prep_stride, uint32_t max_len, const uint32_t* __restrict__ xin, uint32_t in_stride,
+                                                                uint32_t* __restrict__ xout, uint32_t out_stride, const uint32_t* __restrict__ post_rank, uint32_t q_lo, uint32_t q_hi,
+                                                                uint32_t m, uint32_t wide) {
+    __shared__ __attribute__((aligned(16))) char smem[SBP_LDS];
+    uint32_t* nh = (uint32_t*)smem; uint32_t* codes = (uint32_t*)(smem + SBP_CODES);
+    const uint32_t lane = threadIdx.x; const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t mw = (m + 63u) >> 6;
+    for (uint32_t q = q_lo + blockIdx.x; q < q_hi; q += gridDim.x) {
+        const char* const rec = prep + (size_t)q * prep_stride;
+        const PrepHead* hp = (const PrepHead*)rec;
+        const uint32_t xlo = hp->xlo, L = hp->L;
+        uint32_t it_kept = 0u; unsigned long long it_base = 0ull;
+        if (lane < 8u && lane < L && lane < max_len) { const PrepItem pi = ((const PrepItem*)(rec + sizeof(PrepHead)))[lane]; it_kept = pi.kept; it_base = pi.base; }
+        const uint32_t* const xn = xin + (size_t)q * in_stride; uint32_t* const xo = xout + (size_t)q * out_stride;
+        const uint32_t K = (uint32_t)__builtin_amdgcn_readfirstlane((int)xn[0]);
+        unsigned long long rm = __ballot(it_kept > 0u);
+        const uint32_t nr = (uint32_t)__popcll(rm);
+        if (K == 0u || K == 0xFFFFFFFFu || K > F_K_MAX || L < 1u || L > 8u || L > max_len || nr > 4u) {   // (wave-uniform)
+            if (lane == 0u) xo[0] = K == 0u ? 0u : 0xFFFFFFFFu;
+            continue;
+        }
+        const bool rel = wide && nr > 3u;
+        const uint32_t NB = wide && !rel ? 3u : 4u, NBM = (1u << NB) - 1u, base = rel ? xlo : 0u;
+        uint32_t ps[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ps[r] = rm ? (uint32_t)__ffsll((long long)rm) - 1u : 0u; rm &= rm - 1ull; }
+        { uint4* z = reinterpret_cast<uint4*>(nh); for (uint32_t i = lane; i < SBP_BUCKETS * 2u; i += 64u) z[i] = make_uint4(EMPTY32, EMPTY32, EMPTY32, EMPTY32);
+          for (uint32_t i = lane; i < F_K_MAX / 8u + 8u; i += 64u) codes[i] = 0u; }
+        __syncthreads();
+        auto buckets = [&](uint32_t key, uint32_t& b1, uint32_t& b2) { b1 = (key * 0x9E3779B1u) >> 24; b2 = ((key ^ (key >> 15)) * 0x85EBCA6Bu) >> 24; };
+        auto filled = [&](uint32_t b) -> uint32_t { const uint4 a = reinterpret_cast<const uint4*>(nh)[2u * b], c = reinterpret_cast<const uint4*>(nh)[2u * b + 1u];
+            return (a.x != EMPTY32) + (a.y != EMPTY32) + (a.z != EMPTY32) + (a.w != EMPTY32) + (c.x != EMPTY32) + (c.y != EMPTY32) + (c.z != EMPTY32) + (c.w != EMPTY32); };
+        bool bad = false;
+        for (uint32_t i0 = 0; i0 < K; i0 += 64u) {   // the neighbour slots into the table: key = slot >> NB, the emptier of its two buckets, first free slot
+            bool todo = i0 + lane < K;
+            const uint32_t wd = xn[1u + min(i0 + lane, K - 1u)], key = wd >> NB;
+            uint32_t b1, b2; buckets(key, b1, b2);
+            for (int t = 0; t < 16 && __ballot(todo) != 0ull; ++t) {
+                if (todo) {
+                    const uint32_t n1 = filled(b1), n2 = filled(b2);
+                    const bool one = n1 <= n2; const uint32_t bb = one ? b1 : b2, nn = one ? n1 : n2;   // (slots fill from the first: the first free one is slot nn, unless another lane has just taken it)
+                    if (nn < 8u && atomicCAS(&nh[8u * bb + nn], EMPTY32, wd) == EMPTY32) todo = false;
+                }
+            }
+            bad = bad || todo;
+        }
+        bad = __ballot(bad) != 0ull;
+        __syncthreads();
+        uint32_t nmem = 0u;
+        if (!bad) {
+            for (uint32_t r = 0; r < nr; ++r) {
+                const uint32_t pl = r == 0u ? ps[0] : r == 1u ? ps[1] : r == 2u ? ps[2] : ps[3];
+                const uint32_t kept = (uint32_t)__builtin_amdgcn_readlane((int)it_kept, (int)pl);
+                const unsigned long long lb = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(it_base >> 32), (int)pl) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)it_base, (int)pl);
+                const uint32_t lower = (1u << r) - 1u;
+                unsigned long long* const bm64 = reinterpret_cast<unsigned long long*>(xo + 2u) + (size_t)r * mw;
+                for (uint32_t j0 = 0; j0 < kept; j0 += 64u * SB_PF) {
+                    uint32_t rk[SB_PF];
+#pragma unroll
+                    for (uint32_t u = 0; u < SB_PF; ++u) rk[u] = j0 + u * 64u < kept ? post_rank[lb + min(j0 + u * 64u + lane, kept - 1u)] : 0u;
+#pragma unroll
+                    for (uint32_t u = 0; u < SB_PF; ++u) {
+                        if (j0 + u * 64u >= kept) continue;   // (wave-uniform)
+                        const bool act = j0 + u * 64u + lane < kept;
+                        const uint32_t key = rk[u] - base;
+                        uint32_t b1, b2; buckets(key, b1, b2);
+                        const uint4 q1 = reinterpret_cast<const uint4*>(nh)[2u * b1], q2 = reinterpret_cast<const uint4*>(nh)[2u * b1 + 1u], q3 = reinterpret_cast<const uint4*>(nh)[2u * b2], q4 = reinterpret_cast<const uint4*>(nh)[2u * b2 + 1u];
+                        uint32_t wd = EMPTY32;
+                        wd = (q1.x >> NB) == key ? q1.x : wd; wd = (q1.y >> NB) == key ? q1.y : wd; wd = (q1.z >> NB) == key ? q1.z : wd; wd = (q1.w >> NB) == key ? q1.w : wd;
+                        wd = (q2.x >> NB) == key ? q2.x : wd; wd = (q2.y >> NB) == key ? q2.y : wd; wd = (q2.z >> NB) == key ? q2.z : wd; wd = (q2.w >> NB) == key ? q2.w : wd;
+                        wd = (q3.x >> NB) == key ? q3.x : wd; wd = (q3.y >> NB) == key ? q3.y : wd; wd = (q3.z >> NB) == key ? q3.z : wd; wd = (q3.w >> NB) == key ? q3.w : wd;
+                        wd = (q4.x >> NB) == key ? q4.x : wd; wd = (q4.y >> NB) == key ? q4.y : wd; wd = (q4.z >> NB) == key ? q4.z : wd; wd = (q4.w >> NB) == key ? q4.w : wd;
+                        const uint32_t code = wd & NBM;
+                        const bool first = act && wd != EMPTY32 && (code & lower) == 0u && ((code >> r) & 1u);
+                        const unsigned long long mk = __ballot(first);
+                        if (lane == 0u) bm64[(j0 >> 6) + u] = mk;
+                        if (first) { const uint32_t idx = nmem + (uint32_t)__popcll(mk & lt); if (idx < F_K_MAX) atomicOr(&codes[idx >> 3], code << (4u * (idx & 7u))); }
+                        nmem += (uint32_t)__popcll(mk);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const bool ok = !bad && nmem == K;
+        if (lane == 0u) { xo[0] = ok ? K : 0xFFFFFFFFu; xo[1] = 0u; }
+        if (ok) for (uint32_t i = lane; i < (K + 7u) >> 3; i += 64u) xo[2u + 8u * mw + i] = codes[i];
+        __syncthreads();   // (the next query clears what this one still read)
+    }
+}
+hipError_t launch_shard_nb_positions(dim3 grid, hipStream_t st, const char* prep, uint32_t prep_stride, uint32_t max_len, const uint32_t* xin, uint32_t in_stride, uint32_t* xout, uint32_t out_stride,
+                                     const uint32_t* post_rank, uint32_t q_lo, uint32_t q_hi, uint32_t m, bool wide) {
+    if (q_hi > q_lo) hipLaunchKernelGGL(shard_nb_positions_kernel, grid, dim3(64), 0, st, prep, prep_stride, max_len, xin, in_stride, xout, out_stride, post_rank, q_lo, q_hi, m, wide ? 1u : 0u);
+    return hipGetLastError();
+}
+// words of a query's position record; 0: the batch's shape has no streaming form (bitmaps + nibbles do not fit the wave's LDS room)
+uint32_t shard_nb_positions_stride(uint32_t k, uint32_t m) {
+    const uint32_t mw = (m + 63u) >> 6, ncw = (std::min<uint32_t>(k, F_K_MAX) + 7u) >> 3;
+    if (32u * mw + 8u * ncw > SB_REC_ROOM) return 0u;   // (in LDS: the bitmaps + a weight byte per member)
+    return (2u + 8u * mw + ncw + 1u) / 2u * 2u;
+}
+
+// frag_post[e] = frag8[post_rank[e]]: the fragments once more, in posting order (streaming form)
+__global__ __launch_bounds__(256) void frag_post_kernel(const uint32_t* __restrict__ post_rank, const uint2* __restrict__ frag8, uint2* __restrict__ out, uint64_t n) {
+    for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (uint64_t)gridDim.x * 256) out[e] = frag8[post_rank[e]];
+}
+hipError_t launch_frag_post(hipStream_t st, const uint32_t* post_rank, const uint2* frag8, uint2* out, uint64_t n) {
+    if (n) hipLaunchKernelGGL(frag_post_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 20)), dim3(256), 0, st, post_rank, frag8, out, n);
     return hipGetLastError();
 }
 

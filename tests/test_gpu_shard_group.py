@@ -556,12 +556,13 @@ def test_group_wait_and_the_default_overlap():
 
 # ---- the item shard's own back end (round 5, srn_sback.hip): one wave per query, frag8 rows + presence bitmap -------------------------------------------------------
 
-@pytest.mark.parametrize("n_shards,knob", [(2, ""), (3, ""), (8, ""), (8, "SRN_SBACK_BITMAP"), (8, "SRN_ORDER_MIN"), (5, "SRN_NO_SBACK")])
+@pytest.mark.parametrize("n_shards,knob", [(2, ""), (3, ""), (8, ""), (8, "SRN_SBACK_BITMAP"), (8, "SRN_ORDER_MIN"), (5, "SRN_NO_SBACK"), (8, "SRN_SBACK_STREAM"), (2, "SRN_SBACK_STREAM")])
 def test_wave_per_query_back_end_against_the_oracle(n_shards, knob):
     """The neighbours pipeline's back end as a kernel of its own -- vmis_shard_back_kernel: a wave per query over 8-byte fragment slots, the presence bitmap asked first --
     against the canonical oracle and bit-identical to the unsharded path: rows of up to 80 items (at 2 and 3 shards most fragments of the long rows have > 4 items: the
     overflow blocks), unknown and repeated items, both cuts biting, small queries without a threshold, business rules with real flags; with the presence bitmap switched on; with the batch served in the order of its queries' most popular items (SRN_ORDER_MIN=1: the ordering pass on a 1 500-query batch); and
-    (SRN_NO_SBACK) the round-4 form, which must not have changed.  SRN_SBACK_MIN_SHARDS=2 gives the 2- and 3-shard groups the new rows too (default: from 8 shards on)."""
+    (SRN_NO_SBACK) the round-4 form, which must not have changed; and (SRN_SBACK_STREAM) the streaming form -- fragments in posting order, the neighbours exchanged as positions in
+    the posting lists: fewer bytes on the wire, the same rows.  SRN_SBACK_MIN_SHARDS=2 gives the 2- and 3-shard groups the new rows too (default: from 8 shards on)."""
     import ctypes as C
     import serenade_amd as sa
     from serenade_amd import sharded, capi
@@ -595,6 +596,11 @@ def test_wave_per_query_back_end_against_the_oracle(n_shards, knob):
             u = sa.predict_batch(full, (flat, qoff), k, m, n, business)
             assert np.array_equal(got[0], u[0]) and np.array_equal(got[1], u[1]) and np.array_equal(got[2], u[2])
         assert grp.stats["neighbour_batches"] == 4
+        full_bytes = sum(n_shards * ((nq + n_shards - 1) // n_shards) * (k + 1) * 4 for k in (100, 1500, 40, 700))   # neighbour slots: (k + 1) words per query
+        if knob == "SRN_SBACK_STREAM":
+            assert 0 < grp.stats["bytes_neighbours"] < full_bytes, (grp.stats["bytes_neighbours"], full_bytes)           # position records (the m = 500 / 80 / 300 of these batches: 8 words of bitmap per list)
+        else:
+            assert grp.stats["bytes_neighbours"] == full_bytes
         launches = C.c_uint64()
         capi.check(capi.lib().srn_debug_sback_launches(shards[0]._h, C.byref(launches)))
         assert launches.value == (0 if knob == "SRN_NO_SBACK" else 4), launches.value

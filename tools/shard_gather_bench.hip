@@ -42,7 +42,7 @@ int main() {
     auto timeit = [&](auto launch) { launch(8); hipDeviceSynchronize(); hipEventRecord(e0); launch(iters); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1);
                                      return (double)blocks * threads * iters * D / ms / 1e6; };
     printf("(G look-ups/s = 1e9 fragment look-ups per second; one rank of config 3 at 131 072 queries per batch needs 178 M of them: 1 ms at 178 G/s)\n");
-    for (uint64_t mb : {25ull, 50ull, 100ull, 200ull, 400ull, 800ull, 7600ull}) {
+    for (uint64_t mb : {1ull, 4ull, 16ull, 25ull, 50ull, 100ull, 200ull, 400ull, 800ull, 7600ull}) {   // (1-4 MB: every request an L2 hit -- the ceiling of divergent requests as such)
         const uint64_t bytes = mb << 20; void* a; if (hipMalloc(&a, bytes) != hipSuccess) { printf("no room for %llu MB\n", (unsigned long long)mb); continue; } hipMemset(a, 1, bytes);
         const double r16 = timeit([&](int it) { k<D, 2, 0><<<blocks, threads>>>((const uint4*)a, bytes / 16, nullptr, 0, it, out); });
         const double r8 = timeit([&](int it) { k<D, 1, 0><<<blocks, threads>>>((const uint2*)a, bytes / 8, nullptr, 0, it, out); });
