@@ -399,17 +399,21 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
     { const ItemMeta m0 = f.meta_sample[tid];
       ((double*)(smem + SIDF))[tid] = m0.idf > 0.0 ? m0.idf : 1.0; ((uint8_t*)(smem + SATTR))[tid] = (uint8_t)m0.attr;   // (own slot only: no barrier)
       if (tid < 16u) ((double*)(smem + SINV))[tid] = tid < 8u ? f.inv_idf_hot[tid] : f.inv_idf_hi; }   // (read in phase 4a: barriers in between)
-    const uint32_t q_end = LONG ? *f.long_cnt : BIG ? *f.bigq_cnt : MID ? *f.mid_cnt : p.nq;   // (MID: the list is final -- the lean instantiation's launch is over)
+    // (round 5) the lean BACK-END form over a LIST: what the item shard's wave-per-query kernel (srn_sback.hip) could not hold -- a query with hundreds of long fragments, a hit
+    // list beyond its room -- is served here, eight waves and 53 KB per query, before the general kernel gets a look; the list is the MID tier's, which a back end never has
+    const bool listed = !MID && MODE == FM_BACK && f.mid_list != nullptr;   // (launch-uniform)
+    const uint32_t q_end = LONG ? *f.long_cnt : BIG ? *f.bigq_cnt : MID || listed ? *f.mid_cnt : p.nq;   // (MID: the list is final -- the lean instantiation's launch is over)
     // The serving order (round 5, f.order; lean fused and back-end forms): the batch sorted by each query's most popular item and dealt to the XCDs chunk by chunk (ord_pos,
     // srn_device.h): one XCD's L2 sees runs of like queries, whose posting lists and neighbour rows are largely the same lines.  Without an order: query index order,
     // workgroup b serves b, b + gridDim, ...
-    const bool ordered = !MID && MODE != FM_FRONT && f.order != nullptr;   // (launch-uniform)
+    const bool ordered = !MID && MODE != FM_FRONT && f.order != nullptr && !listed;   // (launch-uniform)
     const uint32_t ox = blockIdx.x & 7u;
     const uint32_t qi_step = ordered ? gridDim.x >> 3 : gridDim.x;
     const uint32_t qi_end = ordered ? ord_count(p.nq, ox) : q_end;
     for (uint32_t qi = ordered ? blockIdx.x >> 3 : (MODE == FM_FRONT ? f.q_base : 0u) + blockIdx.x; qi < qi_end; qi += qi_step) {
-        const uint32_t q = LONG ? f.long_list[qi] : BIG ? f.bigq_list[qi] : MID ? f.mid_list[qi] : ordered ? (uint32_t)f.order[ord_pos(ox, qi)] : qi;
-        const uint32_t q_ord_next = ordered && qi + qi_step < qi_end ? (uint32_t)f.order[ord_pos(ox, qi + qi_step)] : 0xFFFFFFFFu;   // (the query this workgroup serves next: its record is parked during this one)
+        const uint32_t q = LONG ? f.long_list[qi] : BIG ? f.bigq_list[qi] : MID || listed ? f.mid_list[qi] : ordered ? (uint32_t)f.order[ord_pos(ox, qi)] : qi;
+        const uint32_t q_ord_next = ordered && qi + qi_step < qi_end ? (uint32_t)f.order[ord_pos(ox, qi + qi_step)]
+                                  : listed && qi + qi_step < qi_end ? f.mid_list[qi + qi_step] : 0xFFFFFFFFu;   // (the query this workgroup serves next: its record is parked during this one)
 #ifndef SRN_MID_PREFETCH
 #define SRN_MID_PREFETCH 0   // (experiment, measured flat: 7.73 / 8.61 ms per 2^18 queries at max_items 8 / 10 with or without it, and 16 bytes of scratch with)
 #endif
@@ -862,8 +866,8 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
         // the next query's record: requested by wave 1 HERE -- behind its own row requests, with no other load of the wave due for thousands of cycles (loads return
         // in order: anywhere else the record's HBM round trip would sit in front of data the wave needs at once); it lands in LDS by itself, the wave
         // waits for it at the end of phase 4a, before the barrier that everybody passes on the way to the next query
-        const uint32_t qn = MID ? q_after : ordered ? q_ord_next : q + gridDim.x;
-        const bool park = MID ? q_after != 0xFFFFFFFFu : ordered ? q_ord_next != 0xFFFFFFFFu : qn < p.nq;   // (block-uniform)
+        const uint32_t qn = MID ? q_after : ordered || listed ? q_ord_next : q + gridDim.x;
+        const bool park = MID ? q_after != 0xFFFFFFFFu : ordered || listed ? q_ord_next != 0xFFFFFFFFu : qn < p.nq;   // (block-uniform)
         if (wave == 1u && park) {   // (a record is at most 72 + 8 * 24 = 264 bytes -- MID: 72 + 10 * 24 = 312 --: two rounds of a dword per lane)
             const char* const rn = p.prep + (size_t)qn * p.prep_stride + lane * 4u;
             if (lane * 4u < p.prep_stride) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)rn, (__attribute__((address_space(3))) void*)pre, 4, 0, 0);

@@ -144,6 +144,8 @@ std::vector<uint32_t> hostpipe_cuts(uint32_t nq, uint32_t how_many) {
     if (kn.host_chunks > 0) {
         const uint32_t nc = (uint32_t)std::min<uint64_t>(nq, (uint64_t)kn.host_chunks), csz = (nq + nc - 1) / nc;
         for (uint64_t q = csz; q < nq; q += csz) starts.push_back((uint32_t)q);
+    } else if (kn.host_first_pct > 0 && nq >= 8192 && nq <= 65536) {
+        starts.push_back((uint32_t)std::max<uint64_t>(1024, (uint64_t)nq * kn.host_first_pct / 100 / 256 * 256));
     } else if (nq > 65536) {
         const uint64_t chunk_max = std::max<uint64_t>(4096, (192ull << 20) / ((uint64_t)how_many * 16 + 4));
         uint64_t at = 0;

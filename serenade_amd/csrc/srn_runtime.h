@@ -25,6 +25,7 @@ struct Knobs {
     bool no_masks = false, no_merge = false, dense = false, no_fast = false, no_mid = false, no_big = false, no_long = false, debug = false;   // no_long (SRN_NO_LONG): without the LONG instantiation (sessions of 11..20 items go to the general kernel, as until round 4)   // no_mid (SRN_NO_MID): the launch sequence without the fast kernel's MID instantiation (what it would take goes to the general kernel, as before round 4)
     int hot_slots = -1, sketch_slots = -1, lds_budget_kb = 0, grid_mult = 16, fast_runs = 0;
     bool grid_mult_set = false;
+    int host_first_pct = 0;   // SRN_HOST_FIRST_PCT (experiments): a host-pointer batch of 8 192 .. 65 536 queries in TWO chunks, the first this percentage of it (0: the default policy of srn_hostpipe.hip)
     int host_chunks = 0;      // SRN_HOST_CHUNKS: number of chunks a host-pointer batch is cut into (0 = by size, srn_hostpipe.hip)
     int copy_slices = 0;      // SRN_COPY_SLICES: slices a result block is cut into for the copy threads (0 = one per thread)
     bool host_nocopy = false; // SRN_HOST_NOCOPY (experiments): the chunked host path leaves the results in its pinned staging
@@ -39,6 +40,7 @@ struct Knobs {
     int row_slots16 = -1;     // SRN_ROW_SLOTS = 16 | 64: the device row layout (-1 = by index kind: 64-byte slots unsharded, 16-byte fragment slots for item shards)
     int order_min = 131072;    // SRN_ORDER_MIN: batches of at least this many queries are served in the order of their most popular item, an eighth of the order per XCD (0 = never); the ordering
                               // pass is one radix sort of the batch's keys behind the prep kernel
+    bool no_sback_second = false;   // SRN_NO_SBACK_SECOND (experiments): what the wave-per-query back end cannot hold goes straight to the general kernel (no fast-kernel back end over the list)
     bool no_sback = false;    // SRN_NO_SBACK: the shard group's back end through vmis_fast_kernel's FM_BACK instantiation (rounds 4) instead of the wave-per-query kernel of srn_sback.hip
     bool sback_bitmap = false;     // SRN_SBACK_BITMAP=1 (experiments): that kernel asks its presence bitmap before it fetches a fragment.  Measured on config 3 cut in 8: half the fragment
                                    // fetches, but one more DEPENDENT round trip per query on a kernel that spends 65 % of its time waiting for memory -- 1.65 ms with, 1.52 ms without

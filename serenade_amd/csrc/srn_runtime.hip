@@ -28,6 +28,7 @@ static void knobs_read() {
     if (const char* e = getenv("SRN_LDS_BUDGET_KB")) k.lds_budget_kb = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_GRID_MULT")) { k.grid_mult = std::max(1, atoi(e)); k.grid_mult_set = true; }
     if (const char* e = getenv("SRN_HOST_CHUNKS")) k.host_chunks = std::max(0, atoi(e));
+    if (const char* e = getenv("SRN_HOST_FIRST_PCT")) k.host_first_pct = std::min(99, std::max(0, atoi(e)));
     if (const char* e = getenv("SRN_COPY_SLICES")) k.copy_slices = std::max(0, atoi(e));
     k.host_nocopy = getenv("SRN_HOST_NOCOPY") != nullptr; k.host_trace = getenv("SRN_HOST_TRACE") != nullptr; k.timing = getenv("SRN_TIMING") != nullptr && atoi(getenv("SRN_TIMING")) != 0;
     if (const char* e = getenv("SRN_D2H_BLOCKS")) k.d2h_blocks = std::max(0, atoi(e));
@@ -35,6 +36,7 @@ static void knobs_read() {
     if (const char* e = getenv("SRN_TINY_FAST")) k.tiny_fast = std::min(3, std::max(0, atoi(e)));
     if (const char* e = getenv("SRN_PREDICT_LANES")) k.lanes = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_ORDER_MIN")) k.order_min = std::max(0, atoi(e));
+    k.no_sback_second = getenv("SRN_NO_SBACK_SECOND") != nullptr;
     k.no_sback = getenv("SRN_NO_SBACK") != nullptr; k.sback_bitmap = getenv("SRN_SBACK_BITMAP") != nullptr && atoi(getenv("SRN_SBACK_BITMAP")) != 0;
     k.no_sback_stream = !(getenv("SRN_SBACK_STREAM") != nullptr && atoi(getenv("SRN_SBACK_STREAM")) != 0);
     if (const char* e = getenv("SRN_SBACK_MIN_SHARDS")) k.sback_min_shards = std::max(2, atoi(e));
@@ -618,6 +620,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     }
     const FastPlan plan = fast_plan(d, ix, p, geo, kn, ext != nullptr);
     const uint32_t nb_fast = plan.nb_fast; const bool mid_tier = plan.mid_tier, fast = plan.fast;
+    bool sback_second = false;   // the item shard's wave-per-query back end ran with the fast kernel's back-end form behind it (its list is the MID tier's: srn_debug_last_mid_count reports it)
     if (fast) {   // (all allocations of a call happen before its first launch)
         if (w->slow_cap < p.nq) { if (w->slow_list) HIP_TRY(hipFree(w->slow_list)); w->slow_list = nullptr; w->slow_cap = 0;
             HIP_TRY(hipMalloc((void**)&w->slow_list, ((size_t)p.nq * 4 + 64) * 4)); w->slow_cap = p.nq; }   // (second to fourth part: the MID instantiation's list, its BIG form's, the LONG form's)
@@ -718,8 +721,11 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
                 int rc = ensure(&w->sb_scr, &w->sb_scr_bytes, (size_t)grid_b * shard_back_scratch_words() * 4); if (rc) return rc;
                 sbp.frag_post = (const uint2*)d->sb_frag_post; sbp.post_rank = ext->post_rank; sbp.scr = (uint32_t*)w->sb_scr;
             }
+            const bool second = !kn.no_sback_second && !stream; sback_second = second;   // (the streaming form's records are not neighbour slots)  // what outgrows the wave's room: the round-4 back end (eight waves per query) over a list, before the general kernel
+            if (second) { fp.mid_list = w->slow_list + (w->slow_cap + 16); fp.mid_cnt = w->slow_cnt + 1; }
             HIP_TRY(launch_shard_back(dim3(grid_b), st, di, p, fp, sbp, kn.debug));
             d->sback_launches.fetch_add(1, std::memory_order_relaxed);
+            if (second) { FastParams fl = fp; fl.order = nullptr; HIP_TRY(launch_fast(dim3((uint32_t)std::min<uint64_t>(p.nq, resident * 4)), st, di, p, fl, kn.debug, 2)); fp.mid_list = nullptr; fp.mid_cnt = nullptr; }
         } else
         HIP_TRY(launch_fast(dim3(grid_fo), st, di, p, fp, kn.debug, back ? 2 : 0));
         if (timed) HIP_TRY(hipEventRecord(ev[4], st));
@@ -760,7 +766,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     HIP_TRY(hipEventRecord(ev[2], st));
     if (resident) { const int par = (int)(w->resident_calls & 1u); HIP_TRY(hipEventRecord(w->ev_done[par], st)); w->rec_used[par] = true; ++w->resident_calls; }
     else if (!ext && w->side) { HIP_TRY(hipEventRecord(w->ev_done[0], st)); w->rec_used[0] = true; }   // (a workspace that has served resident calls: the next one's side-stream prep must not overwrite w->prep under this call's kernels)
-    ++w->calls; w->last_retry = (may_overflow || dense) ? 1 : 0; w->last_nq = p.nq; w->last_fast = fast; w->last_mid = fast && mid_tier; w->last_untimed = false;
+    ++w->calls; w->last_retry = (may_overflow || dense) ? 1 : 0; w->last_nq = p.nq; w->last_fast = fast; w->last_mid = fast && (mid_tier || sback_second); w->last_untimed = false;
     if (may_overflow || dense) w->h_retry_valid = true;   // (from now on the pinned counter holds a finished call's count -- or is being overwritten by a newer one)
 
     if (!on_device) {

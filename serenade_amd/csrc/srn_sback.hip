@@ -519,7 +519,10 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
             }
         }
         SB_TICK(tk12);
-        if (fail) { if (lane == 0u) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q; continue; }
+        if (fail) {   // (beyond this kernel's room: the fast kernel's back-end form takes the query if the launch sequence has one behind this kernel, else the general kernel)
+            if (lane == 0u) { if (f.mid_list) f.mid_list[atomicAdd(f.mid_cnt, 1u)] = q; else f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q; }
+            continue;
+        }
         // ---- hand-off: the query's record for vmis_finish_kernel (score = x / (10 U), ranking, public ids), as the fast kernel writes it ----
         const uint32_t M = ncand + nt;
         uint32_t ovf_at = 0;

@@ -21,6 +21,8 @@
 // business rules (the current item's attribute byte travels with the first all-reduce); everything else takes the three-stage pipeline.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "srn_device.h"
 #include "srn_kernels.h"
 
@@ -305,10 +307,79 @@ __global__ __launch_bounds__(256) void shard_merge_topn_kernel(const char* __res
         if (sub == 0u) out_counts[q] = bad ? 0xFFFFFFFFu : keep;   // (a query some shard could not serve: the caller sees the marker, as in the unsharded path)
     }
 }
+// Round 5: the same selection with every lane's WHOLE list staged in LDS first (n entries of 16 bytes per lane, one wave per workgroup).  In the form above a lane that wins
+// twice in a row waits a memory round trip for its next head, and 64 / LPQ queries share the wave: ~21 dependent trips per wave, 0.20 ms per 131 072 queries at G = 8 for
+// 357 MB of input.  Here all loads of a wave are in flight together and a round is an LDS read.
+template <int LPQ>
+__global__ __launch_bounds__(64) void shard_merge_topn_lds_kernel(const char* __restrict__ part, size_t block_bytes, uint32_t G, uint32_t nq, uint32_t n,
+                                                                  uint64_t* __restrict__ out_ids, double* __restrict__ out_scores, uint32_t* __restrict__ out_counts) {
+    extern __shared__ __attribute__((aligned(16))) char merge_sm[];
+    constexpr uint32_t QPW = 64u / LPQ;
+    const uint32_t lane = threadIdx.x, sub = lane % LPQ;
+    const uint32_t q = blockIdx.x * QPW + lane / LPQ;
+    const bool live = q < nq && sub < G;
+    const uint32_t qc = min(q, nq - 1u), gc = min(sub, G - 1u);
+    const uint64_t* ids = reinterpret_cast<const uint64_t*>(part + (size_t)gc * block_bytes) + (size_t)qc * n;
+    const double* scs = reinterpret_cast<const double*>(part + (size_t)gc * block_bytes + (size_t)nq * n * 8) + (size_t)qc * n;
+    const uint32_t craw = reinterpret_cast<const uint32_t*>(part + (size_t)gc * block_bytes + (size_t)nq * n * 16)[qc];
+    double* const ls = reinterpret_cast<double*>(merge_sm) + (size_t)lane * n;
+    unsigned long long* const li = reinterpret_cast<unsigned long long*>(merge_sm + (size_t)64 * n * 8) + (size_t)lane * n;
+    const double NEG = -__builtin_huge_val();
+    for (uint32_t x0 = 0; x0 < n; x0 += 8u) {   // (eight entries of the lane's list at a time: sixteen loads in flight per lane; the rows are read whole, the count masks them below)
+        double sv[8]; unsigned long long iv[8];
+#pragma unroll
+        for (uint32_t x = 0; x < 8u; ++x) { const uint32_t e = min(x0 + x, n - 1u); sv[x] = scs[e]; iv[x] = ids[e]; }
+#pragma unroll
+        for (uint32_t x = 0; x < 8u; ++x) if (x0 + x < n) { ls[x0 + x] = sv[x]; li[x0 + x] = iv[x]; }
+    }
+    uint32_t bad = live && craw == 0xFFFFFFFFu ? 1u : 0u;
+    const uint32_t cnt = live && craw != 0xFFFFFFFFu ? min(craw, n) : 0u;
+    uint32_t total = cnt;
+#pragma unroll
+    for (int d = 1; d < LPQ; d <<= 1) { total += __shfl_xor(total, d, LPQ); bad |= __shfl_xor(bad, d, LPQ); }
+    const uint32_t keep = bad ? 0u : min(total, n);
+    double s0 = cnt > 0u ? ls[0] : NEG; unsigned long long i0 = cnt > 0u ? li[0] : ~0ull;
+    uint32_t pos = 0, rounds = keep;
+#pragma unroll
+    for (int d = LPQ; d < 64; d <<= 1) rounds = max(rounds, (uint32_t)__shfl_xor((int)rounds, d));   // (the wave's longest query)
+    for (uint32_t r = 0; r < rounds; ++r) {
+        double bs = s0; unsigned long long bi = i0; uint32_t bl = sub;
+#pragma unroll
+        for (int d = 1; d < LPQ; d <<= 1) {
+            const double os = __shfl_xor(bs, d, LPQ); const unsigned long long oi = __shfl_xor(bi, d, LPQ); const uint32_t ol = (uint32_t)__shfl_xor((int)bl, d, LPQ);
+            const bool other = os > bs || (os == bs && oi < bi);
+            bs = other ? os : bs; bi = other ? oi : bi; bl = other ? ol : bl;
+        }
+        if (r < keep && bl == sub) {   // (one lane of the group)
+            out_ids[(size_t)q * n + r] = i0; out_scores[(size_t)q * n + r] = s0;
+            ++pos;
+            const bool more = pos < cnt;
+            s0 = more ? ls[min(pos, n - 1u)] : NEG; i0 = more ? li[min(pos, n - 1u)] : ~0ull;
+        }
+    }
+    if (q < nq) {
+        if (!bad) for (uint32_t r = keep + sub; r < n; r += LPQ) { out_ids[(size_t)q * n + r] = 0ull; out_scores[(size_t)q * n + r] = 0.0; }   // the unused tail of a row reads as 0
+        if (sub == 0u) out_counts[q] = bad ? 0xFFFFFFFFu : keep;   // (a query some shard could not serve: the caller sees the marker, as in the unsharded path)
+    }
+}
 hipError_t launch_shard_merge_topn(hipStream_t st, const char* part, size_t block_bytes, uint32_t n_shards, uint32_t nq, uint32_t how_many, uint64_t* out_ids, double* out_scores,
                                    uint32_t* out_counts) {
     if (n_shards == 0 || n_shards > 64) return hipErrorInvalidValue;
     const uint32_t lpq = n_shards <= 2 ? 2u : n_shards <= 4 ? 4u : n_shards <= 8 ? 8u : n_shards <= 16 ? 16u : n_shards <= 32 ? 32u : 64u;
+    static const bool old_form = getenv("SRN_MERGE_OLD") != nullptr;   // (experiments: the round-4 form)
+    if (!old_form && how_many >= 1u && how_many <= 40u) {   // (<= 40 KB of LDS per wave: three waves per CU and more)
+        const dim3 grid((nq + 64u / lpq - 1) / (64u / lpq)), block(64);
+        const size_t lds = (size_t)64 * how_many * 16;
+        switch (lpq) {
+            case 2: hipLaunchKernelGGL(shard_merge_topn_lds_kernel<2>, grid, block, lds, st, part, block_bytes, n_shards, nq, how_many, out_ids, out_scores, out_counts); break;
+            case 4: hipLaunchKernelGGL(shard_merge_topn_lds_kernel<4>, grid, block, lds, st, part, block_bytes, n_shards, nq, how_many, out_ids, out_scores, out_counts); break;
+            case 8: hipLaunchKernelGGL(shard_merge_topn_lds_kernel<8>, grid, block, lds, st, part, block_bytes, n_shards, nq, how_many, out_ids, out_scores, out_counts); break;
+            case 16: hipLaunchKernelGGL(shard_merge_topn_lds_kernel<16>, grid, block, lds, st, part, block_bytes, n_shards, nq, how_many, out_ids, out_scores, out_counts); break;
+            case 32: hipLaunchKernelGGL(shard_merge_topn_lds_kernel<32>, grid, block, lds, st, part, block_bytes, n_shards, nq, how_many, out_ids, out_scores, out_counts); break;
+            default: hipLaunchKernelGGL(shard_merge_topn_lds_kernel<64>, grid, block, lds, st, part, block_bytes, n_shards, nq, how_many, out_ids, out_scores, out_counts); break;
+        }
+        return hipGetLastError();
+    }
     const uint32_t per_block = 4u * (64u / lpq);
     const dim3 grid((nq + per_block - 1) / per_block), block(256);
     switch (lpq) {

@@ -609,3 +609,48 @@ def test_wave_per_query_back_end_against_the_oracle(n_shards, knob):
         if knob:
             os.environ.pop(knob, None)
         capi.reload_knobs()
+
+
+@pytest.mark.parametrize("n_shards,knob", [(2, ""), (8, ""), (8, "SRN_NO_SBACK_SECOND")])
+def test_wave_per_query_back_end_hands_its_overflow_to_the_fast_kernels_back_end(n_shards, knob):
+    """What vmis_shard_back_kernel cannot hold in a wave's 12 KB -- a query whose neighbours bring hundreds of long fragments, a hit list beyond its room -- goes to the round-4
+    back end (vmis_fast_kernel's FM_BACK form, eight waves per query) over a LIST, and only what that refuses as well reaches the general kernel.  Rows of up to 80 items, k = 1 500
+    over m = 2 000: about half of the 1 500 queries overflow the wave (srn_debug_last_mid_count reports the list).  Against the canonical oracle and the unsharded path;
+    SRN_NO_SBACK_SECOND: straight to the general kernel, the same rows."""
+    import ctypes as C
+    import serenade_amd as sa
+    from serenade_amd import sharded, capi
+    from oracle import oracle as O
+    os.environ["SRN_SBACK_MIN_SHARDS"] = "2"
+    if knob:
+        os.environ[knob] = "1"
+    capi.reload_knobs()
+    try:
+        off, items, ts, ids = small_dataset(281, n_sessions=12000, n_items=3000, max_len=80)
+        qs = random_queries(223, ids, 1500, max_len=8, unknown_rate=0.03, dup_rate=0.1)
+        flat, qoff = flatten(qs)
+        d_flat, d_off = _to_dev(flat, qoff)
+        full = sa.VMISIndex.from_sessions(off, items, ts, 2000, 80, 1.0)
+        oix = O.OracleIndex(off, items, ts, 2000, 80, 1.0)
+        shards = [sharded.ShardedVMISIndex.from_full(full, g, n_shards) for g in range(n_shards)]
+        grp = sharded.ShardGroup.local(shards)
+        grp.set_postings(sharded.postings_view(full))
+        nq = len(qs)
+        for (k, m, n) in [(1500, 2000, 21), (900, 1200, 24)]:
+            ref = oix.predict_batch("canonical", flat, qoff, k, m, n, False, threads=4)
+            got = _np(grp.predict_batch(d_flat, d_off, nq, 8, k, m, n, False))
+            _check_oracle(got, ref, n)
+            u = sa.predict_batch(full, (flat, qoff), k, m, n, False)
+            assert np.array_equal(got[0], u[0]) and np.array_equal(got[1], u[1]) and np.array_equal(got[2], u[2])
+            listed = C.c_uint32()
+            capi.check(capi.lib().srn_debug_last_mid_count(shards[0]._h, C.byref(listed)))
+            if knob:
+                assert listed.value == 0
+            elif k == 1500:
+                assert listed.value > 100, listed.value
+        assert grp.stats["neighbour_batches"] == 2
+    finally:
+        os.environ.pop("SRN_SBACK_MIN_SHARDS", None)
+        if knob:
+            os.environ.pop(knob, None)
+        capi.reload_knobs()
