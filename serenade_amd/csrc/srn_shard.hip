@@ -307,6 +307,22 @@ __global__ __launch_bounds__(256) void shard_merge_topn_kernel(const char* __res
         if (sub == 0u) out_counts[q] = bad ? 0xFFFFFFFFu : keep;   // (a query some shard could not serve: the caller sees the marker, as in the unsharded path)
     }
 }
+// lane <- the value of its partner in step `d` of a butterfly over groups of LPQ lanes.  Up to 16 lanes per group the partners come over the VALU's DPP path (d = 1, 2:
+// quad permutations; 4: the mirror of a half row, 8: the mirror of a row -- i <-> 7 - i / 15 - i instead of i ^ d, which a selection does not mind: after the quad steps
+// all four lanes of a quad agree); __shfl_xor is ds_bpermute_b32, an LDS round trip per 32 bits: 15 of them per round, 21 rounds -- they, not memory, were the kernel's time.
+template <int LPQ> __device__ __forceinline__ uint32_t merge_partner(uint32_t v, int d) {
+    if constexpr (LPQ <= 16) {
+        switch (d) {
+            case 1: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);    // quad_perm [1, 0, 3, 2]
+            case 2: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);    // quad_perm [2, 3, 0, 1]
+            case 4: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);   // row_half_mirror
+            default: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true);  // row_mirror
+        }
+    } else return (uint32_t)__shfl_xor((int)v, d, LPQ);
+}
+template <int LPQ> __device__ __forceinline__ unsigned long long merge_partner64(unsigned long long v, int d) {
+    return ((unsigned long long)merge_partner<LPQ>((uint32_t)(v >> 32), d) << 32) | merge_partner<LPQ>((uint32_t)v, d);
+}
 // Round 5: the same selection with every lane's WHOLE list staged in LDS first (n entries of 16 bytes per lane, one wave per workgroup).  In the form above a lane that wins
 // twice in a row waits a memory round trip for its next head, and 64 / LPQ queries share the wave: ~21 dependent trips per wave, 0.20 ms per 131 072 queries at G = 8 for
 // 357 MB of input.  Here all loads of a wave are in flight together and a round is an LDS read.
@@ -319,24 +335,33 @@ __global__ __launch_bounds__(64) void shard_merge_topn_lds_kernel(const char* __
     const uint32_t q = blockIdx.x * QPW + lane / LPQ;
     const bool live = q < nq && sub < G;
     const uint32_t qc = min(q, nq - 1u), gc = min(sub, G - 1u);
-    const uint64_t* ids = reinterpret_cast<const uint64_t*>(part + (size_t)gc * block_bytes) + (size_t)qc * n;
-    const double* scs = reinterpret_cast<const double*>(part + (size_t)gc * block_bytes + (size_t)nq * n * 8) + (size_t)qc * n;
     const uint32_t craw = reinterpret_cast<const uint32_t*>(part + (size_t)gc * block_bytes + (size_t)nq * n * 16)[qc];
-    double* const ls = reinterpret_cast<double*>(merge_sm) + (size_t)lane * n;
-    unsigned long long* const li = reinterpret_cast<unsigned long long*>(merge_sm + (size_t)64 * n * 8) + (size_t)lane * n;
-    const double NEG = -__builtin_huge_val();
-    for (uint32_t x0 = 0; x0 < n; x0 += 8u) {   // (eight entries of the lane's list at a time: sixteen loads in flight per lane; the rows are read whole, the count masks them below)
-        double sv[8]; unsigned long long iv[8];
+    // staging: the wave's 64 / LPQ queries are consecutive, so a shard's ids (and scores) for them are ONE contiguous run of QPW n 8-byte words: read by consecutive lanes,
+    // 2 G runs per wave.  (A first build had every lane read its own list, 8 bytes at a time: 88 lines touched per load instruction, 21.5 KB of strided footprint per wave
+    // against a 32 KB L1 shared by seven waves -- the lines came from the L2 again and again: 0.19 ms for 357 MB.)
+    unsigned long long* const lw = reinterpret_cast<unsigned long long*>(merge_sm);
+    const uint32_t q0 = blockIdx.x * QPW, words = QPW * n, staged = 2u * G * words;
+    const size_t avail = (size_t)(nq - min(q0, nq)) * n;   // words of a run that exist (the batch's last wave)
+    for (uint32_t e0 = 0; e0 < staged; e0 += 8u * 64u) {
+        unsigned long long v[8];
 #pragma unroll
-        for (uint32_t x = 0; x < 8u; ++x) { const uint32_t e = min(x0 + x, n - 1u); sv[x] = scs[e]; iv[x] = ids[e]; }
+        for (uint32_t t = 0; t < 8u; ++t) {
+            const uint32_t e = e0 + t * 64u + lane, r = e / words, w = e - r * words;
+            v[t] = 0ull;
+            if (e < staged && w < avail) v[t] = reinterpret_cast<const unsigned long long*>(part + (size_t)(r >> 1) * block_bytes + (size_t)(r & 1u) * nq * n * 8)[(size_t)q0 * n + w];
+        }
 #pragma unroll
-        for (uint32_t x = 0; x < 8u; ++x) if (x0 + x < n) { ls[x0 + x] = sv[x]; li[x0 + x] = iv[x]; }
+        for (uint32_t t = 0; t < 8u; ++t) { const uint32_t e = e0 + t * 64u + lane; if (e < staged) lw[e] = v[t]; }
     }
+    __syncthreads();   // (one wave: orders the LDS writes before the other lanes' reads)
+    const unsigned long long* const li = lw + (size_t)(2u * gc) * words + (size_t)(lane / LPQ) * n;
+    const double* const ls = reinterpret_cast<const double*>(lw + (size_t)(2u * gc + 1u) * words + (size_t)(lane / LPQ) * n);
+    const double NEG = -__builtin_huge_val();
     uint32_t bad = live && craw == 0xFFFFFFFFu ? 1u : 0u;
     const uint32_t cnt = live && craw != 0xFFFFFFFFu ? min(craw, n) : 0u;
     uint32_t total = cnt;
 #pragma unroll
-    for (int d = 1; d < LPQ; d <<= 1) { total += __shfl_xor(total, d, LPQ); bad |= __shfl_xor(bad, d, LPQ); }
+    for (int d = 1; d < LPQ; d <<= 1) { total += merge_partner<LPQ>(total, d); bad |= merge_partner<LPQ>(bad, d); }
     const uint32_t keep = bad ? 0u : min(total, n);
     double s0 = cnt > 0u ? ls[0] : NEG; unsigned long long i0 = cnt > 0u ? li[0] : ~0ull;
     uint32_t pos = 0, rounds = keep;
@@ -346,7 +371,8 @@ __global__ __launch_bounds__(64) void shard_merge_topn_lds_kernel(const char* __
         double bs = s0; unsigned long long bi = i0; uint32_t bl = sub;
 #pragma unroll
         for (int d = 1; d < LPQ; d <<= 1) {
-            const double os = __shfl_xor(bs, d, LPQ); const unsigned long long oi = __shfl_xor(bi, d, LPQ); const uint32_t ol = (uint32_t)__shfl_xor((int)bl, d, LPQ);
+            const double os = __longlong_as_double((long long)merge_partner64<LPQ>((unsigned long long)__double_as_longlong(bs), d)); const unsigned long long oi = merge_partner64<LPQ>(bi, d);
+            const uint32_t ol = merge_partner<LPQ>(bl, d);
             const bool other = os > bs || (os == bs && oi < bi);
             bs = other ? os : bs; bi = other ? oi : bi; bl = other ? ol : bl;
         }
@@ -357,6 +383,7 @@ __global__ __launch_bounds__(64) void shard_merge_topn_lds_kernel(const char* __
             s0 = more ? ls[min(pos, n - 1u)] : NEG; i0 = more ? li[min(pos, n - 1u)] : ~0ull;
         }
     }
+    // (tried: the result rows staged in LDS and copied out in one run -- 0.180 ms against 0.153: one wave less per CU costs more than the scattered 8-byte stores)
     if (q < nq) {
         if (!bad) for (uint32_t r = keep + sub; r < n; r += LPQ) { out_ids[(size_t)q * n + r] = 0ull; out_scores[(size_t)q * n + r] = 0.0; }   // the unused tail of a row reads as 0
         if (sub == 0u) out_counts[q] = bad ? 0xFFFFFFFFu : keep;   // (a query some shard could not serve: the caller sees the marker, as in the unsharded path)
@@ -369,7 +396,7 @@ hipError_t launch_shard_merge_topn(hipStream_t st, const char* part, size_t bloc
     static const bool old_form = getenv("SRN_MERGE_OLD") != nullptr;   // (experiments: the round-4 form)
     if (!old_form && how_many >= 1u && how_many <= 40u) {   // (<= 40 KB of LDS per wave: three waves per CU and more)
         const dim3 grid((nq + 64u / lpq - 1) / (64u / lpq)), block(64);
-        const size_t lds = (size_t)64 * how_many * 16;
+        const size_t lds = (size_t)2u * n_shards * (64u / lpq) * how_many * 8;   // the 2 G input runs
         switch (lpq) {
             case 2: hipLaunchKernelGGL(shard_merge_topn_lds_kernel<2>, grid, block, lds, st, part, block_bytes, n_shards, nq, how_many, out_ids, out_scores, out_counts); break;
             case 4: hipLaunchKernelGGL(shard_merge_topn_lds_kernel<4>, grid, block, lds, st, part, block_bytes, n_shards, nq, how_many, out_ids, out_scores, out_counts); break;
