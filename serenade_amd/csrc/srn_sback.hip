@@ -106,6 +106,16 @@ hipError_t launch_rows_to_frag8(hipStream_t st, const uint64_t* row_off, const u
 // -------------------------------------------------------------------------------------
 // The kernel.  One wave per query; a persistent grid strides over the batch.
 // -------------------------------------------------------------------------------------
+#ifndef SRN_SBACK_NT
+#define SRN_SBACK_NT 1   // the one-use streams of a query (its neighbour slots in, its finish record out) as non-temporal accesses
+#endif
+#if SRN_SBACK_NT
+#define SB_NT_LOAD(p) __builtin_nontemporal_load(p)
+#define SB_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define SB_NT_LOAD(p) (*(p))
+#define SB_NT_STORE(v, p) (*(p) = (v))
+#endif
 #ifndef SRN_SBACK_WAVES
 #define SRN_SBACK_WAVES 3   // waves per SIMD the register allocation is sized for (12 per CU: the LDS allows 13)
 #endif
@@ -170,7 +180,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
         uint32_t sv[NCH];   // gather form: the neighbour slots; streaming form: the members' {position | run << 20 | weight << 24}, read back from the scratch after walk A
         if constexpr (!STREAM) {
 #pragma unroll
-            for (uint32_t c = 0; c < NCH; ++c) sv[c] = xq[1u + min(c * 64u + lane, f.xchg_stride - 2u)];
+            for (uint32_t c = 0; c < NCH; ++c) sv[c] = SB_NT_LOAD(&xq[1u + min(c * 64u + lane, f.xchg_stride - 2u)]);   // (read once: 5.4 KB per query that need not stay in the L2 the fragments want)
         }
         const uint32_t K = (uint32_t)__builtin_amdgcn_readfirstlane((int)kv);
         const uint32_t L = h0.L, U = h0.U, cur_attr = h0.cur_attr;
@@ -545,7 +555,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                 uint4 e;
                 if (i < ncand) { const unsigned long long x = ckey[i]; e = make_uint4((uint32_t)x, (uint32_t)(x >> 32), cidx[i], 0u); }
                 else { const uint2 c = hits[i - ncand]; e = make_uint4(c.y, 0u, c.x, 1u); }
-                if (i < F_FIN_ENTRIES) out[1 + i] = e; else ovf[i - F_FIN_ENTRIES] = e;
+                if (i < F_FIN_ENTRIES) { typedef uint32_t v4u __attribute__((ext_vector_type(4))); SB_NT_STORE((v4u{e.x, e.y, e.z, e.w}), reinterpret_cast<v4u*>(&out[1 + i])); } else ovf[i - F_FIN_ENTRIES] = e;
             }
         }
         __syncthreads();   // (the next query clears what this one still read)
