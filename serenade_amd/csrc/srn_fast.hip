@@ -1277,7 +1277,10 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
 // -------------------------------------------------------------------------------------
 constexpr uint32_t FIN_QPW = 4;   // queries per wave: the three dependent round trips (record, contenders' idf, public ids) of FIN_QPW queries overlap
 __global__ __launch_bounds__(256) void vmis_finish_kernel(DeviceIndex ix, const char* __restrict__ fin, uint64_t* __restrict__ out_ids, double* __restrict__ out_scores,
-                                                          uint32_t* __restrict__ out_counts, uint32_t nq, uint32_t how_many) {
+                                                          uint32_t* __restrict__ out_counts, uint32_t nq, uint32_t how_many, const uint32_t* __restrict__ cnt_slow, uint32_t* __restrict__ host_words) {
+    // (the latency path: the call's path counters into pinned words -- handed to the general kernel, listed for MID, for MID's BIG form, queries with > 63 entries -- so that the
+    //  host launches the kernels behind this one only for a call that has work for them)
+    if (host_words && blockIdx.x == 0u && threadIdx.x == 0u) { host_words[1] = cnt_slow[0]; host_words[2] = cnt_slow[1]; host_words[3] = cnt_slow[4]; host_words[4] = cnt_slow[3]; }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t q0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * FIN_QPW;
     if (q0 >= nq) return;
@@ -1424,8 +1427,9 @@ hipError_t launch_finish_big(hipStream_t st, const DeviceIndex& di, const FastPa
     return hipGetLastError();
 }
 
-hipError_t launch_finish(hipStream_t st, const DeviceIndex& di, const FastParams& f, uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint32_t nq, uint32_t how_many) {
-    hipLaunchKernelGGL(vmis_finish_kernel, dim3((nq + 4 * FIN_QPW - 1) / (4 * FIN_QPW)), dim3(256), 0, st, di, (const char*)f.fin, out_ids, out_scores, out_counts, nq, how_many);
+hipError_t launch_finish(hipStream_t st, const DeviceIndex& di, const FastParams& f, uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint32_t nq, uint32_t how_many,
+                         const uint32_t* cnt_slow, uint32_t* host_words) {
+    hipLaunchKernelGGL(vmis_finish_kernel, dim3((nq + 4 * FIN_QPW - 1) / (4 * FIN_QPW)), dim3(256), 0, st, di, (const char*)f.fin, out_ids, out_scores, out_counts, nq, how_many, cnt_slow, host_words);
     return hipGetLastError();
 }
 

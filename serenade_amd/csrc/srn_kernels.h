@@ -140,7 +140,8 @@ hipError_t launch_prep(hipStream_t st, const DeviceIndex& di, const uint64_t* it
                        uint32_t max_len, char* out, uint32_t stride, uint32_t* zero_a = nullptr, uint32_t* zero_b = nullptr,
                        const IdSlot* loc_table = nullptr, uint32_t loc_mask = 0, unsigned long long* okeys = nullptr);   // zero_a[0..7], zero_b[0]: counters cleared by the prep kernel; loc_table: the item shard's id table (the record's idx), di = the whole index's dictionary and lists
 hipError_t launch_finish_big(hipStream_t st, const DeviceIndex& di, const FastParams& f, uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint32_t how_many, uint32_t grid, const uint32_t* cnt_retry = nullptr, const uint32_t* cnt_slow = nullptr, uint32_t* host_words = nullptr);
-hipError_t launch_finish(hipStream_t st, const DeviceIndex& di, const FastParams& f, uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint32_t nq, uint32_t how_many);   // scores, ranking, public ids of the rows the fast kernel served
+hipError_t launch_finish(hipStream_t st, const DeviceIndex& di, const FastParams& f, uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint32_t nq, uint32_t how_many,
+                         const uint32_t* cnt_slow = nullptr, uint32_t* host_words = nullptr);   // (cnt_slow + host_words: the call's path counters published to pinned words, the latency path)   // scores, ranking, public ids of the rows the fast kernel served
 hipError_t launch_shard_lists_head(hipStream_t st, const DeviceIndex& di, const uint64_t* items_flat, const uint32_t* q_off, uint32_t nq, uint32_t m, uint32_t max_len,
                                    ShardPos* pos_out, int* head);
 hipError_t launch_shard_lists_count(hipStream_t st, const DeviceIndex& di, const uint32_t* q_off, uint32_t nq, uint32_t max_len, const ShardPos* pos_in, const int* head,

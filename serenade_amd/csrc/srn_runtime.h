@@ -33,6 +33,7 @@ struct Knobs {
     bool timing = false;      // SRN_TIMING: kernel timing on from the start (srn_kernel_timing switches it per index)
     int d2h_blocks = 0;       // SRN_D2H_BLOCKS: workgroups of the chunked host path's own download kernel (0 = hipMemcpyAsync, the default: measured faster, profiles/r03_host_pipe_probe.txt)
     int tiny_max = 256;       // SRN_TINY_MAX: host-pointer batches of up to this many sessions take the zero-copy latency path
+    int tiny_phases = 0;      // SRN_TINY_PHASES (experiments): the latency path's launches behind the fast kernel -- 0: all of them with every call; 1: finish + finish-big, then MID / general kernel / a second finish only for a call that listed queries for them (a second wait then); 2: finish alone in the first phase.  Measured (profiles/r05_latency_phases.txt): one query per call p50 46 us against 49 with 2, p99 71 against 63; calls of 4 and 16 queries lose at p90 (a second wait more often): 0 stays
     int tiny_fast = 2;        // SRN_TINY_FAST: the latency path's kernels -- 0: prep + general kernel (rounds 1-3); 1: the fast kernel's launch sequence only where the batch has a session of > 8 items (which puts
                               // the whole batch on the general kernel's non-position-set build: 144 us against 52 us per call on config 3); 2 (default): also for calls of <= 32 sessions (one session per call,
                               // config 3, max_items 4: p50 53.3 -> 47.8 us, p90 63.7 -> 54.1; larger rounds stay on the general kernel -- one workgroup per query runs them all at once: nothing to gain,

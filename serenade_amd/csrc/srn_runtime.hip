@@ -33,6 +33,7 @@ static void knobs_read() {
     k.host_nocopy = getenv("SRN_HOST_NOCOPY") != nullptr; k.host_trace = getenv("SRN_HOST_TRACE") != nullptr; k.timing = getenv("SRN_TIMING") != nullptr && atoi(getenv("SRN_TIMING")) != 0;
     if (const char* e = getenv("SRN_D2H_BLOCKS")) k.d2h_blocks = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_TINY_MAX")) k.tiny_max = std::max(0, atoi(e));
+    if (const char* e = getenv("SRN_TINY_PHASES")) k.tiny_phases = std::min(2, std::max(0, atoi(e)));
     if (const char* e = getenv("SRN_TINY_FAST")) k.tiny_fast = std::min(3, std::max(0, atoi(e)));
     if (const char* e = getenv("SRN_PREDICT_LANES")) k.lanes = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_ORDER_MIN")) k.order_min = std::max(0, atoi(e));
@@ -279,8 +280,8 @@ Workspace* ws_acquire(DeviceState* d, bool bind_to_stream, void* user_stream) {
     Workspace* w = new Workspace();
     if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { delete w; return nullptr; }
     for (auto& t : w->ev) for (auto& e : t) if (hipEventCreate(&e) != hipSuccess) { ws_free(w); return nullptr; }
-    if (hipMalloc((void**)&w->retry_cnt, 16) != hipSuccess || hipMalloc((void**)&w->retry_cnt2, 16) != hipSuccess || hipMalloc((void**)&w->slow_cnt, 32) != hipSuccess || hipHostMalloc((void**)&w->h_retry, 16) != hipSuccess) { ws_free(w); return nullptr; }
-    memset(w->h_retry, 0, 16);
+    if (hipMalloc((void**)&w->retry_cnt, 16) != hipSuccess || hipMalloc((void**)&w->retry_cnt2, 16) != hipSuccess || hipMalloc((void**)&w->slow_cnt, 32) != hipSuccess || hipHostMalloc((void**)&w->h_retry, 32) != hipSuccess) { ws_free(w); return nullptr; }
+    memset(w->h_retry, 0, 32);
     if (hipHostGetDevicePointer((void**)&w->h_retry_dev, w->h_retry, 0) != hipSuccess) { ws_free(w); return nullptr; }
     d->all_ws.push_back(w);
     if (bind_to_stream) { d->stream_ws.emplace_back(user_stream, w); w->call_mu.lock(); }   // (nobody else can have found it yet: d->mu is held)
@@ -478,14 +479,42 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
         fp.mid_list = plan.mid_tier ? w->slow_list + (w->slow_cap + 16) : nullptr; fp.mid_cnt = plan.mid_tier ? w->slow_cnt + 1 : nullptr;
         fp.bigq_list = nullptr; fp.bigq_cnt = nullptr; fp.long_list = nullptr; fp.long_cnt = nullptr;   // (no BIG / LONG tier on the latency path)
         HIP_TRY(launch_fast(dim3(p.nq), st, d->di, p, fp, kn.debug, 0));
-        if (plan.mid_tier) HIP_TRY(launch_fast(dim3(p.nq), st, d->di, p, fp, kn.debug, 0, true));
-        HIP_TRY(launch_predict(geo.masks, geo.slot64, false, 0, dim3(p.nq), geo.lds, st, d->di, p, geo.c, w->slow_list, w->slow_cnt, (uint32_t*)(dp + o_rl), (uint32_t*)(dp + o_rc), nullptr, 0,
-                               w->spill, ShardIO{}));
-        HIP_TRY(launch_finish(st, d->di, fp, p.out_ids, p.out_scores, p.out_counts, p.nq, p.how_many));
-        // (it also publishes the call's path counters -- handed over, listed for MID -- in the workspace's pinned words: srn_last_path_counts / srn_debug_last_mid_count after a
-        //  latency-path call used to say "all through the general kernel")
-        HIP_TRY(launch_finish_big(st, d->di, fp, p.out_ids, p.out_scores, p.out_counts, p.how_many, (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * 16), nullptr, w->slow_cnt, w->h_retry_dev));
-    } else
+        // (round 5, experiment: SRN_TINY_PHASES) A single query's call is five launches -- prep, fast kernel, general kernel, finish, finish-big -- and two of them find nothing to
+        // do in 99 calls of 100.  With the path counters published by the finish kernel the host can launch what is behind it only for a call that listed work for it, and wait a
+        // second time then: 46 us against 49 at p50 for one query per call, but 71 against 63 at p99, and calls of 4 / 16 queries lose at p90.  The default stays one phase.
+        const int phases = kn.tiny_phases;   // 0: one phase (round 4); 1: finish-big stays in the first phase (a second wait only for handed-over / MID queries); 2: the first phase ends with the finish kernel
+        const bool two_phase = phases != 0;
+        auto rest = [&]() -> int {
+            if (plan.mid_tier) HIP_TRY(launch_fast(dim3(p.nq), st, d->di, p, fp, kn.debug, 0, true));
+            HIP_TRY(launch_predict(geo.masks, geo.slot64, false, 0, dim3(p.nq), geo.lds, st, d->di, p, geo.c, w->slow_list, w->slow_cnt, (uint32_t*)(dp + o_rl), (uint32_t*)(dp + o_rc), nullptr, 0,
+                                   w->spill, ShardIO{}));
+            HIP_TRY(launch_finish(st, d->di, fp, p.out_ids, p.out_scores, p.out_counts, p.nq, p.how_many));
+            // (it also publishes the call's path counters -- handed over, listed for MID -- in the workspace's pinned words: srn_last_path_counts / srn_debug_last_mid_count after a
+            //  latency-path call used to say "all through the general kernel")
+            HIP_TRY(launch_finish_big(st, d->di, fp, p.out_ids, p.out_scores, p.out_counts, p.how_many, (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * 16), nullptr, w->slow_cnt, w->h_retry_dev));
+            return SRN_OK;
+        };
+        if (phases == 2) HIP_TRY(launch_finish(st, d->di, fp, p.out_ids, p.out_scores, p.out_counts, p.nq, p.how_many, w->slow_cnt, w->h_retry_dev));
+        else if (phases == 1) {
+            HIP_TRY(launch_finish(st, d->di, fp, p.out_ids, p.out_scores, p.out_counts, p.nq, p.how_many));
+            HIP_TRY(launch_finish_big(st, d->di, fp, p.out_ids, p.out_scores, p.out_counts, p.how_many, (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * 16), nullptr, w->slow_cnt, w->h_retry_dev));
+        }
+        else { int rc = rest(); if (rc) return rc; }
+        auto wait = [&]() -> int {
+            if (blocking_wait) {   // a round several callers share: sleep on an interrupt instead of spinning on the signal (the host's cores belong to the callers)
+                if (!w->ev_block) HIP_TRY(hipEventCreateWithFlags(&w->ev_block, hipEventBlockingSync | hipEventDisableTiming));
+                HIP_TRY(hipEventRecord(w->ev_block, st));
+                HIP_TRY(hipEventSynchronize(w->ev_block));
+            } else HIP_TRY(hipStreamSynchronize(st));
+            return SRN_OK;
+        };
+        { int rc = wait(); if (rc) return rc; }
+        const volatile uint32_t* hw = w->h_retry;
+        if (two_phase && (hw[1] | hw[2] | (phases == 2 ? hw[4] : 0u)) != 0u) {   // (handed to the general kernel | listed for MID | queries with > 63 entries)
+            int rc = rest(); if (rc) return rc;
+            rc = wait(); if (rc) return rc;
+        }
+    } else {
     HIP_TRY(launch_predict(geo.masks, geo.slot64, false, 0, dim3(p.nq), geo.lds, st, d->di, p, geo.c, nullptr, nullptr, (uint32_t*)(dp + o_rl), (uint32_t*)(dp + o_rc), nullptr, 0,
                            w->spill, ShardIO{}));
     if (blocking_wait) {   // a round several callers share: sleep on an interrupt instead of spinning on the signal (the host's cores belong to the callers)
@@ -493,6 +522,7 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
         HIP_TRY(hipEventRecord(w->ev_block, st));
         HIP_TRY(hipEventSynchronize(w->ev_block));
     } else HIP_TRY(hipStreamSynchronize(st));
+    }
     if (*(volatile uint32_t*)(w->pin + o_rc) != 0) return 1;   // (rare: tables too small for some query)
     // what the timing / path-count APIs report after this call: its query count, how many of them the fast sequence handed to the general kernel (all of them where the
     // two-launch form ran), not timed (the stream is idle here: nothing of an earlier call is still writing the pinned words)

@@ -38,8 +38,11 @@ while time.time() < t_end and rounds < max_rounds:
     KNOBS = [{}, {}, {}, {"SRN_NO_FAST": "1"}, {"SRN_NO_MERGE": "1"}, {"SRN_NO_MASKS": "1"}, {"SRN_HOT_SLOTS": "64", "SRN_NO_MASKS": "1"}, {"SRN_SKETCH_SLOTS": "64", "SRN_HOT_SLOTS": "32"},
              {"SRN_FAST_RUNS": "3"}, {"SRN_NO_MID": "1"}, {"SRN_NO_BIG": "1"}, {}, {"SRN_DENSE": "1"}, {"SRN_TINY_MAX": "1"}, {"SRN_HOST_CHUNKS": "3"}, {"SRN_SKETCH_SLOTS": "0"}, {"SRN_HOT_SLOTS": "0"},
              # round 5: the LONG instantiation, the serving order, the shard group's wave-per-query back end
-             {"SRN_NO_LONG": "1"}, {"SRN_ORDER_MIN": "1"}, {"SRN_ORDER_MIN": "1", "SRN_SBACK_MIN_SHARDS": "2"}, {"SRN_SBACK_MIN_SHARDS": "2"}, {"SRN_SBACK_MIN_SHARDS": "2", "SRN_SBACK_BITMAP": "1"}, {"SRN_NO_SBACK": "1"}, {"SRN_ORDER_MIN": "1"}]
-    for kk in ("SRN_NO_FAST", "SRN_NO_MID", "SRN_NO_BIG", "SRN_NO_MERGE", "SRN_NO_MASKS", "SRN_HOT_SLOTS", "SRN_SKETCH_SLOTS", "SRN_FAST_RUNS", "SRN_DENSE", "SRN_TINY_MAX", "SRN_HOST_CHUNKS", "SRN_NO_LONG", "SRN_ORDER_MIN", "SRN_SBACK_MIN_SHARDS", "SRN_SBACK_BITMAP", "SRN_NO_SBACK"):
+             {"SRN_NO_LONG": "1"}, {"SRN_ORDER_MIN": "1"}, {"SRN_ORDER_MIN": "1", "SRN_SBACK_MIN_SHARDS": "2"}, {"SRN_SBACK_MIN_SHARDS": "2"}, {"SRN_SBACK_MIN_SHARDS": "2", "SRN_SBACK_BITMAP": "1"}, {"SRN_NO_SBACK": "1"}, {"SRN_ORDER_MIN": "1"},
+             # ... its streaming form (neighbours exchanged as posting positions), its second tier (the fast kernel's back-end form over a list) switched off
+             {"SRN_SBACK_MIN_SHARDS": "2", "SRN_SBACK_STREAM": "1"}, {"SRN_SBACK_MIN_SHARDS": "2", "SRN_SBACK_STREAM": "1", "SRN_ORDER_MIN": "1"}, {"SRN_SBACK_MIN_SHARDS": "2", "SRN_NO_SBACK_SECOND": "1"},
+             {"SRN_SBACK_MIN_SHARDS": "2"}, {"SRN_SBACK_MIN_SHARDS": "2", "SRN_ORDER_MIN": "1"}]
+    for kk in ("SRN_NO_FAST", "SRN_NO_MID", "SRN_NO_BIG", "SRN_NO_MERGE", "SRN_NO_MASKS", "SRN_HOT_SLOTS", "SRN_SKETCH_SLOTS", "SRN_FAST_RUNS", "SRN_DENSE", "SRN_TINY_MAX", "SRN_HOST_CHUNKS", "SRN_NO_LONG", "SRN_ORDER_MIN", "SRN_SBACK_MIN_SHARDS", "SRN_SBACK_BITMAP", "SRN_NO_SBACK", "SRN_SBACK_STREAM", "SRN_NO_SBACK_SECOND"):
         os.environ.pop(kk, None)
     knobs = KNOBS[int(rng.integers(0, len(KNOBS)))]
     os.environ.update(knobs); capi.reload_knobs()
