@@ -1275,7 +1275,10 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
 // contenders, score = idf_eff * acc / (10 U) (one multiply, one divide, in that order), top-n by (score desc, public id asc)
 // -- ranks counted on the scores themselves --, public ids.  Rows of other queries are left alone.
 // -------------------------------------------------------------------------------------
-constexpr uint32_t FIN_QPW = 4;   // queries per wave: the three dependent round trips (record, contenders' idf, public ids) of FIN_QPW queries overlap
+#ifndef SRN_FIN_QPW
+#define SRN_FIN_QPW 4
+#endif
+constexpr uint32_t FIN_QPW = SRN_FIN_QPW;   // queries per wave: the three dependent round trips (record, contenders' idf, public ids) of FIN_QPW queries overlap
 __global__ __launch_bounds__(256) void vmis_finish_kernel(DeviceIndex ix, const char* __restrict__ fin, uint64_t* __restrict__ out_ids, double* __restrict__ out_scores,
                                                           uint32_t* __restrict__ out_counts, uint32_t nq, uint32_t how_many, const uint32_t* __restrict__ cnt_slow, uint32_t* __restrict__ host_words) {
     // (the latency path: the call's path counters into pinned words -- handed to the general kernel, listed for MID, for MID's BIG form, queries with > 63 entries -- so that the
@@ -1313,6 +1316,8 @@ __global__ __launch_bounds__(256) void vmis_finish_kernel(DeviceIndex ix, const 
     }
     unsigned long long pid[FIN_QPW];
 #pragma unroll
+    // (tried, round 5: the public ids fetched only for the entries that made the top n -- a dependent trip more, a quarter fewer requests: 0.750 against 0.757 ms for everything
+    //  behind the fast kernel; 8 queries per wave: 1.02 ms; 2: 0.757 -- profiles/r05_fast_ab.txt)
     for (uint32_t u = 0; u < FIN_QPW; ++u) pid[u] = ix.id_sorted[valid[u] ? tie[u] : 0u];   // (arrive while the ranks are counted)
 #pragma unroll
     for (uint32_t u = 0; u < FIN_QPW; ++u) {
