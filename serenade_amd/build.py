@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libserenade_hip.so")
 SYNTH_LIB = os.path.join(HERE, "libsrn_synth.so")
 SOURCES = ["srn_index.cpp", "srn_capi.cpp", "srn_batcher.cpp", "srn_combine.cpp", "srn_session_store.cpp", "srn_avro.cpp", "srn_kernels.hip", "srn_fast.hip", "srn_shard.hip", "srn_sback.hip", "srn_runtime.hip", "srn_hostpipe.hip", "srn_group.hip", "srn_build_gpu.hip"]
-HEADERS = ["srn_internal.h", "srn_kernels.h", "srn_device.h", "srn_runtime.h", os.path.join("..", "..", "include", "serenade_hip.h")]
+HEADERS = ["srn_internal.h", "srn_kernels.h", "srn_device.h", "srn_prep.h", "srn_runtime.h", os.path.join("..", "..", "include", "serenade_hip.h")]
 
 
 def _stale(target, deps):

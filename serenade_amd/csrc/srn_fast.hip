@@ -27,6 +27,7 @@
 #include <cstdlib>
 
 #include "srn_device.h"
+#include "srn_prep.h"
 #include "srn_kernels.h"
 
 namespace srn {
@@ -355,7 +356,31 @@ enum { FM_FUSED = 0, FM_FRONT = 1, FM_BACK = 2 };
 // histogram); the neighbour list is 64-bit {slot, signed weight 10 * linear_score(first match) * numerator}.  Direct-mapped accumulators take signed adds, sketch words only the
 // positive ones (they must stay upper bounds: DESIGN.md "Why the sketch filter is exact" holds with acc <= its positive part <= the word); sums <= 0 are no candidates,
 // and a query whose positive scores do not fill the top n goes to the general kernel (an item of score <= 0 could then be returned).
-template <int WG_PER_CU, bool FRAG, bool WIDE, int MODE = FM_FUSED, bool MID = false, bool BIG = false, bool LONG = false>
+// vmis_finish_kernel's work for ONE query whose <= 63 entries are still in the serving wave's registers (lane i: entry i): the latency path's fused launch (TINY).  Same
+// arithmetic, same order: idf of a contender, x = idf_eff * acc, score = x / (10 U), rank = entries with a better (score desc, id rank asc) key.
+__device__ __forceinline__ void finish_inline(const DeviceIndex& ix, uint32_t M, uint32_t U, const uint4& e, uint32_t ln, uint32_t q, uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint32_t how_many) {
+    const bool have = ln < M;
+    const ItemMeta mt = ix.meta[have && e.w != 0u ? e.z : 0u];
+    double x = 0.0; uint32_t tie = EMPTY32;
+    if (have) {
+        if (e.w == 0u) { x = __longlong_as_double((long long)(((unsigned long long)e.y << 32) | e.x)); tie = e.z; }
+        else { x = (mt.idf > 0.0 ? mt.idf : 1.0) * (double)e.x; tie = mt.id_rank; }
+    }
+    const unsigned long long pid = ix.id_sorted[have ? tie : 0u];
+    const double sc = have ? x / (double)(10u * U) : 0.0;
+    const unsigned long long mk = (unsigned long long)__double_as_longlong(sc);   // (positive doubles order like their bit patterns)
+    const int klo = (int)(uint32_t)mk, khi = (int)(uint32_t)(mk >> 32);
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < M; ++j) {
+        const uint32_t jl = (uint32_t)__builtin_amdgcn_readlane(klo, (int)j), jh = (uint32_t)__builtin_amdgcn_readlane(khi, (int)j), ij = (uint32_t)__builtin_amdgcn_readlane((int)tie, (int)j);
+        const unsigned long long kj = ((unsigned long long)jh << 32) | jl;
+        rank += (uint32_t)(kj > mk) | ((uint32_t)(kj == mk) & (uint32_t)(ij < tie));
+    }
+    if (have && rank < how_many) { out_ids[(size_t)q * how_many + rank] = pid; out_scores[(size_t)q * how_many + rank] = sc; }
+    if (ln == 0u) out_counts[q] = min(M, how_many);
+}
+
+template <int WG_PER_CU, bool FRAG, bool WIDE, int MODE = FM_FUSED, bool MID = false, bool BIG = false, bool LONG = false, bool TINY = false>
 #ifndef SRN_FAST_WAVES
 #define SRN_FAST_WAVES (WG_PER_CU * 2)
 #endif
@@ -383,6 +408,19 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
     static_assert(!MID || MODE == FM_FUSED, "MID: fused form only");
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
+    static_assert(!TINY || (MODE == FM_FUSED && !MID && !FRAG), "TINY: the lean fused form over an unsharded index");
+    if constexpr (TINY) {
+        // The latency path's ONE launch for ONE evolving session (srn_predict): the workgroup writes its query's prep record itself (its first eight lanes: vmis_prep_kernel's
+        // body), serves it, and wave 0 finishes it from registers (finish_inline) -- five launches of 5..18 us each became one.  The launch sequence's counters are cleared
+        // here and published to the host at the end: what this kernel hands on (general kernel, MID, > 63 entries) the host launches behind it, for that call only.
+        if (tid < 8u) f.slow_cnt[tid] = 0u;
+        // (the session's items ride in the kernel arguments where they fit: read from the pinned staging they are two dependent PCIe round trips -- offsets, then items)
+        unsigned long long* const a_items = reinterpret_cast<unsigned long long*>(smem + F_W10 + 64); uint32_t* const a_off = reinterpret_cast<uint32_t*>(smem + F_W10 + 64 + 64);   // (where a NEXT query's record would be parked: this launch has none)
+        const uint32_t alen = f.tiny_len;
+        if (alen) { if (tid < 8u) a_items[tid] = f.tiny_items[tid]; if (tid == 0u) { a_off[0] = 0u; a_off[1] = alen; } __syncthreads(); }
+        if (tid < PREP_LANES) prep_group(ix_arg, alen ? (const uint64_t*)a_items : p.items_flat, alen ? (const uint32_t*)a_off : p.q_off, 0u, tid, p.m, p.max_len, const_cast<char*>(p.prep), nullptr, 0u, nullptr);
+        __syncthreads();   // (workgroup-scope release / acquire: the record's words for every wave)
+    }
 
     uint32_t* misc = (uint32_t*)(smem + F_MISC);
     uint8_t* wlut = (uint8_t*)(smem + F_WLUT);            // numerator of each position set
@@ -1249,6 +1287,15 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
             }
             if (ln == 0u) f.big_list[slot] = q;
         }
+        if constexpr (TINY) {
+            if (M <= F_FIN_ENTRIES) {   // (wave-uniform) the row, finished here: no record, no finish kernel
+                uint4 e = make_uint4(0u, 0u, 0u, 0u);
+                if (ln < cnt) { const unsigned long long x = ckey[ln]; e = make_uint4((uint32_t)x, (uint32_t)(x >> 32), cidx[ln], 0u); }
+                else if (ln < M) { const uint2 c = tl[ln - cnt]; e = make_uint4(c.y, 0u, c.x, 1u); }
+                finish_inline(ix_arg, M, U, e, ln, q, p.out_ids, p.out_scores, p.out_counts, p.how_many);
+                continue;
+            }
+        }
         {
             uint4* rec = reinterpret_cast<uint4*>(f.fin + (size_t)q * F_FIN_BYTES);
             uint4* ovf = reinterpret_cast<uint4*>(f.big_arena) + ovf_at;
@@ -1268,6 +1315,12 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
         FAST_TICK(13);
     }
     if (ticking) { __syncthreads(); if (tid < 16u && tacc[tid]) atomicAdd(&p.phase_cycles[tid], tacc[tid]); }
+    if constexpr (TINY) {   // (every append of this one-workgroup launch was thread 0's own: its atomics are behind it in program order)
+        if (tid == 0u && f.host_words) { f.host_words[1] = atomicAdd(&f.slow_cnt[0], 0u); f.host_words[2] = atomicAdd(&f.slow_cnt[1], 0u); f.host_words[3] = atomicAdd(&f.slow_cnt[4], 0u);
+                                         f.host_words[4] = atomicAdd(&f.slow_cnt[3], 0u);
+                                         __threadfence_system();   // (wave 0's row and these words before the word the host spins on)
+                                         __atomic_store_n(&f.host_words[5], f.host_seq, __ATOMIC_RELAXED); }
+    }
 }
 
 // -------------------------------------------------------------------------------------
@@ -1438,13 +1491,15 @@ hipError_t launch_finish(hipStream_t st, const DeviceIndex& di, const FastParams
     return hipGetLastError();
 }
 
-hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f, bool debug, int mode, bool mid, bool big, bool lng) {
+hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f, bool debug, int mode, bool mid, bool big, bool lng, bool tiny) {
     constexpr int W = (int)F_WG_PER_CU;
     const bool wide = f.nb == 3u, frag = di.row_frag != 0u;
     if (mid && (mode != FM_FUSED || frag || (!big && f.mid_list == nullptr))) return hipErrorInvalidValue;
     if (big && (!mid || (!lng && f.bigq_list == nullptr))) return hipErrorInvalidValue;
     if (lng && (!big || frag || f.long_list == nullptr)) return hipErrorInvalidValue;
+    if (tiny && (mid || mode != FM_FUSED || frag || grid.x != 1u)) return hipErrorInvalidValue;   // (one workgroup: it clears and publishes the sequence's counters itself)
     void (*kern)(DeviceIndex, LaunchParams, FastParams) =
+        tiny ? (wide ? vmis_fast_kernel<W, false, true, FM_FUSED, false, false, false, true> : vmis_fast_kernel<W, false, false, FM_FUSED, false, false, false, true>) :
         lng ? vmis_fast_kernel<W, false, false, FM_FUSED, true, true, true> :
         big ? vmis_fast_kernel<W, false, false, FM_FUSED, true, true> :
         mid ? vmis_fast_kernel<W, false, false, FM_FUSED, true> :

@@ -102,6 +102,8 @@ struct FastParams {
     // the order the batch is served in (round 5; null: query index order): the batch's queries sorted by their most popular item, low word of entry i = the i-th query.
     // Workgroup b serves positions of the (b % 8)-th eighth of the order -- block b runs on XCD b % 8: what one XCD's L2 sees is a window of like queries
     const unsigned long long* order;
+    uint64_t tiny_items[8]; uint32_t tiny_len, host_seq;   // (the TINY launch) the session's items in the kernel arguments (tiny_len = 0: read p.items_flat), the call's number
+    uint32_t* host_words;       // (the TINY launch) pinned words the kernel publishes the sequence's counters in: [1] handed to the general kernel, [2] listed for MID, [3] for MID's BIG form, [4] queries with > 63 entries, and last of all [5] = host_seq: the host may read the row
 };
 // the batch's order keys (written by the prep kernel) -> sorted (srn_build_gpu.hip: rocPRIM radix sort on the key bits); temp == nullptr: only *temp_bytes is set
 hipError_t sort_order_keys(hipStream_t st, const unsigned long long* in, unsigned long long* out, size_t n, void* temp, size_t* temp_bytes);
@@ -160,7 +162,7 @@ hipError_t launch_shard_mark(hipStream_t st, const uint32_t* flag, uint32_t nq, 
 hipError_t launch_shard_fill_i32(hipStream_t st, int* dst, int v, size_t n);
 hipError_t launch_shard_merge_topn(hipStream_t st, const char* part, size_t block_bytes, uint32_t n_shards, uint32_t nq, uint32_t how_many, uint64_t* out_ids, double* out_scores,
                                    uint32_t* out_counts);
-hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f, bool debug = false, int mode = 0, bool mid = false, bool big = false, bool lng = false);   // debug: say the occupancy once (the SRN_DEBUG knob, read by the runtime); mode: 0 fused, 1 front end only (neighbour lists -> f.xchg), 2 back end only (neighbour lists <- f.xchg); mid: the MID instantiation over f.mid_list (mode 0 only)
+hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f, bool debug = false, int mode = 0, bool mid = false, bool big = false, bool lng = false, bool tiny = false);   // tiny: ONE workgroup = one query, prep record and finish inside (the latency path)   // debug: say the occupancy once (the SRN_DEBUG knob, read by the runtime); mode: 0 fused, 1 front end only (neighbour lists -> f.xchg), 2 back end only (neighbour lists <- f.xchg); mid: the MID instantiation over f.mid_list (mode 0 only)
 hipError_t launch_rows_to_packed(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base,
                                  uint32_t* packed, uint32_t* ext16, bool frag = false);   // grid = ceil((n_rows + 1) / 1024) blocks of 1024; block_base in 16-byte blocks
 hipError_t launch_rows_to_frags(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base,

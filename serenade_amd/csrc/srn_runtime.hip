@@ -5,6 +5,8 @@
 // =====================================================================================
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -33,6 +35,8 @@ static void knobs_read() {
     k.host_nocopy = getenv("SRN_HOST_NOCOPY") != nullptr; k.host_trace = getenv("SRN_HOST_TRACE") != nullptr; k.timing = getenv("SRN_TIMING") != nullptr && atoi(getenv("SRN_TIMING")) != 0;
     if (const char* e = getenv("SRN_D2H_BLOCKS")) k.d2h_blocks = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_TINY_MAX")) k.tiny_max = std::max(0, atoi(e));
+    k.no_tiny_fused = getenv("SRN_TINY_FUSED") != nullptr && atoi(getenv("SRN_TINY_FUSED")) == 0;
+    k.no_tiny_spin = getenv("SRN_TINY_SPIN") != nullptr && atoi(getenv("SRN_TINY_SPIN")) == 0;
     if (const char* e = getenv("SRN_TINY_PHASES")) k.tiny_phases = std::min(2, std::max(0, atoi(e)));
     if (const char* e = getenv("SRN_TINY_FAST")) k.tiny_fast = std::min(3, std::max(0, atoi(e)));
     if (const char* e = getenv("SRN_PREDICT_LANES")) k.lanes = std::max(0, atoi(e));
@@ -470,7 +474,10 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
         { int rc = ensure(&w->fin, &w->fin_bytes, cap_q * F_FIN_BYTES + 1024); if (rc) return rc; }
         { int rc = ensure(&w->big, &w->big_bytes, big_entries * 16 + cap_q * 4 + 64); if (rc) return rc; }
     }
-    HIP_TRY(launch_prep(st, d->di, p.items_flat, p.q_off, p.nq, p.m, p.max_len, w->prep, prep_stride, tiny_fast ? w->slow_cnt : nullptr));
+    // (round 5) ONE evolving session per call -- srn_predict, the reference's call shape: one launch.  The fast kernel's TINY instantiation writes the prep record itself,
+    // serves the query and finishes its row from registers; the counters it publishes say whether anything is left for the kernels behind it (SRN_TINY_FUSED=0: five launches).
+    const bool fused = tiny_fast && p.nq == 1 && !kn.no_tiny_fused;
+    if (!fused) HIP_TRY(launch_prep(st, d->di, p.items_flat, p.q_off, p.nq, p.m, p.max_len, w->prep, prep_stride, tiny_fast ? w->slow_cnt : nullptr));
     p.prep = w->prep; p.prep_stride = prep_stride;
     if (tiny_fast) {
         FastParams fp = d->fast; fp.slow_list = w->slow_list; fp.slow_cnt = w->slow_cnt; fp.nb = plan.nb_fast; fp.max_runs = plan.nb_fast; fp.fin = w->fin;
@@ -478,11 +485,22 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
         fp.xchg = nullptr; fp.xchg_stride = 0; fp.q_base = 0; fp.order = nullptr;
         fp.mid_list = plan.mid_tier ? w->slow_list + (w->slow_cap + 16) : nullptr; fp.mid_cnt = plan.mid_tier ? w->slow_cnt + 1 : nullptr;
         fp.bigq_list = nullptr; fp.bigq_cnt = nullptr; fp.long_list = nullptr; fp.long_cnt = nullptr;   // (no BIG / LONG tier on the latency path)
+        uint32_t seq = 0;
+        if (fused) {
+            const uint32_t L1 = h_qoff[1] - h_qoff[0];
+            fp.tiny_len = L1 >= 1u && L1 <= 8u ? L1 : 0u;   // (the items in the kernel arguments where they fit)
+            for (uint32_t i = 0; i < fp.tiny_len; ++i) fp.tiny_items[i] = h_items[h_qoff[0] + i];
+            seq = ++w->tiny_seq; if (seq == 0u) seq = ++w->tiny_seq;
+            fp.host_seq = seq; fp.host_words = w->h_retry_dev;
+            HIP_TRY(launch_fast(dim3(1), st, d->di, p, fp, kn.debug, 0, false, false, false, true));
+            fp.host_words = nullptr; fp.tiny_len = 0;
+        }
+        else
         HIP_TRY(launch_fast(dim3(p.nq), st, d->di, p, fp, kn.debug, 0));
         // (round 5, experiment: SRN_TINY_PHASES) A single query's call is five launches -- prep, fast kernel, general kernel, finish, finish-big -- and two of them find nothing to
         // do in 99 calls of 100.  With the path counters published by the finish kernel the host can launch what is behind it only for a call that listed work for it, and wait a
         // second time then: 46 us against 49 at p50 for one query per call, but 71 against 63 at p99, and calls of 4 / 16 queries lose at p90.  The default stays one phase.
-        const int phases = kn.tiny_phases;   // 0: one phase (round 4); 1: finish-big stays in the first phase (a second wait only for handed-over / MID queries); 2: the first phase ends with the finish kernel
+        const int phases = fused ? 3 : kn.tiny_phases;   // (3: the fused launch is the whole first phase)   // 0: one phase (round 4); 1: finish-big stays in the first phase (a second wait only for handed-over / MID queries); 2: the first phase ends with the finish kernel
         const bool two_phase = phases != 0;
         auto rest = [&]() -> int {
             if (plan.mid_tier) HIP_TRY(launch_fast(dim3(p.nq), st, d->di, p, fp, kn.debug, 0, true));
@@ -499,7 +517,7 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
             HIP_TRY(launch_finish(st, d->di, fp, p.out_ids, p.out_scores, p.out_counts, p.nq, p.how_many));
             HIP_TRY(launch_finish_big(st, d->di, fp, p.out_ids, p.out_scores, p.out_counts, p.how_many, (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * 16), nullptr, w->slow_cnt, w->h_retry_dev));
         }
-        else { int rc = rest(); if (rc) return rc; }
+        else if (phases == 0) { int rc = rest(); if (rc) return rc; }
         auto wait = [&]() -> int {
             if (blocking_wait) {   // a round several callers share: sleep on an interrupt instead of spinning on the signal (the host's cores belong to the callers)
                 if (!w->ev_block) HIP_TRY(hipEventCreateWithFlags(&w->ev_block, hipEventBlockingSync | hipEventDisableTiming));
@@ -508,9 +526,27 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
             } else HIP_TRY(hipStreamSynchronize(st));
             return SRN_OK;
         };
-        { int rc = wait(); if (rc) return rc; }
         const volatile uint32_t* hw = w->h_retry;
-        if (two_phase && (hw[1] | hw[2] | (phases == 2 ? hw[4] : 0u)) != 0u) {   // (handed to the general kernel | listed for MID | queries with > 63 entries)
+        bool seen = false;
+        if (fused && !blocking_wait && !kn.no_tiny_spin) {
+            // the kernel's last store is the call's number in a pinned word, behind a system-scope fence: the row is readable as soon as the host sees it -- before the
+            // queue's completion signal (end-of-kernel cache write-back, signal, the runtime's poll of it) has made its way.  A bounded spin: a fault shows in the stream's wait
+            const auto t0 = std::chrono::steady_clock::now();
+            for (uint32_t spin = 0; !seen; ++spin) {
+                seen = hw[5] == seq;
+                if (!seen && (spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
+        if (!seen) { int rc = wait(); if (rc) return rc; }
+        if (kn.debug && fused) {   // (SRN_DEBUG: how often a single-session call needs the kernels behind the fused launch, and why)
+            static std::atomic<uint64_t> calls{0}, second{0}, why[3] = {{0}, {0}, {0}};
+            const uint64_t c = calls.fetch_add(1) + 1;
+            if ((hw[1] | hw[2] | hw[4]) != 0u) { second.fetch_add(1); if (hw[1]) why[0].fetch_add(1); if (hw[2]) why[1].fetch_add(1); if (hw[4]) why[2].fetch_add(1); }
+            if (c % 1000 == 0) fprintf(stderr, "[srn] fused single-session calls: %llu, with a second phase %llu (handed to the general kernel %llu, listed for MID %llu, > 63 entries %llu)\n",
+                                       (unsigned long long)c, (unsigned long long)second.load(), (unsigned long long)why[0].load(), (unsigned long long)why[1].load(), (unsigned long long)why[2].load());
+        }
+        if (two_phase && (hw[1] | hw[2] | (phases >= 2 ? hw[4] : 0u)) != 0u) {   // (handed to the general kernel | listed for MID | queries with > 63 entries)
             int rc = rest(); if (rc) return rc;
             rc = wait(); if (rc) return rc;
         }
