@@ -5,6 +5,8 @@ is stronger: item ids and order identical, neighbour (session, numerator) sets i
 counters identical, and scores equal to 1e-12 relative (they are one f64 multiply + divide of an exact
 integer accumulator on both sides).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -842,4 +844,41 @@ def test_serving_order_changes_no_row():
             np.testing.assert_allclose(sc_[mask], ref["scores"][mask], rtol=SCORE_RTOL, atol=0)
     finally:
         os.environ.pop("SRN_ORDER_MIN", None)
+        capi.reload_knobs()
+
+
+@pytest.mark.parametrize("knobs", [{}, {"SRN_TINY_SPIN": "0"}, {"SRN_TINY_FUSED": "0"}, {"SRN_TINY_PHASES": "2", "SRN_TINY_FUSED": "0"}])
+def test_single_session_calls_one_launch_against_the_oracle(knobs):
+    """srn_predict -- the reference's call shape, one evolving session per call -- is ONE launch since round 5: the fast kernel's TINY instantiation writes the prep record
+    itself, serves the query and finishes its row from registers; what it cannot finish (a session for the MID tier, > 63 entries, a shape for the general kernel) runs behind
+    it for that call only.  Every call against the canonical oracle, on an index small enough that many queries have no threshold (> 63 entries: the second phase), with sessions
+    of 1..10 items, unknown and repeated items, business rules; the same with the caller waiting for the stream, with the five-launch form, and with that form in two phases."""
+    import serenade_amd as sa
+    from serenade_amd import capi
+    from oracle import oracle as O
+    os.environ.update(knobs)
+    capi.reload_knobs()
+    try:
+        for (n_sessions, n_items, m_index, k, m) in [(4000, 600, 500, 100, 500), (20000, 150, 2500, 1500, 2500)]:
+            off, items, ts, ids = small_dataset(97 + n_items, n_sessions=n_sessions, n_items=n_items, max_len=20)
+            gix = sa.VMISIndex.from_sessions(off, items, ts, m_index, 20, 1.0)
+            oix = O.OracleIndex(off, items, ts, m_index, 20, 1.0)
+            rng = np.random.default_rng(5)
+            known = np.unique(items)
+            flags = rng.choice(np.array([0, 1, 2, 3, 0xFF], np.uint8), size=len(known), p=[0.1, 0.05, 0.55, 0.2, 0.1])
+            gix.set_attributes(known, flags)
+            oix.set_attributes(known, flags)
+            qs = random_queries(11, ids, 260, max_len=10, unknown_rate=0.05, dup_rate=0.15)
+            flat, qoff = flatten(qs)
+            for business in (False, True):
+                for n in (21, 5):
+                    ref = oix.predict_batch("canonical", flat, qoff, k, m, n, business, threads=4)
+                    for qi, q in enumerate(qs):
+                        recs = sa.predict(gix, q, k, m, n, business)
+                        cnt = int(ref["counts"][qi])
+                        assert [r.id for r in recs] == ref["ids"][qi, :cnt].tolist(), (knobs, n_items, business, n, qi, q)
+                        np.testing.assert_allclose([r.score for r in recs], ref["scores"][qi, :cnt], rtol=1e-12, atol=0)
+    finally:
+        for kk in knobs:
+            os.environ.pop(kk, None)
         capi.reload_knobs()
