@@ -408,7 +408,7 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
     static_assert(!MID || MODE == FM_FUSED, "MID: fused form only");
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    static_assert(!TINY || (MODE == FM_FUSED && !MID && !FRAG), "TINY: the lean fused form over an unsharded index");
+    static_assert(!TINY || (MODE == FM_FUSED && !BIG && !FRAG), "TINY: the lean or the MID fused form over an unsharded index");
     if constexpr (TINY) {
         // The latency path's ONE launch for ONE evolving session (srn_predict): the workgroup writes its query's prep record itself (its first eight lanes: vmis_prep_kernel's
         // body), serves it, and wave 0 finishes it from registers (finish_inline) -- five launches of 5..18 us each became one.  The launch sequence's counters are cleared
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
     // (round 5) the lean BACK-END form over a LIST: what the item shard's wave-per-query kernel (srn_sback.hip) could not hold -- a query with hundreds of long fragments, a hit
     // list beyond its room -- is served here, eight waves and 53 KB per query, before the general kernel gets a look; the list is the MID tier's, which a back end never has
     const bool listed = !MID && MODE == FM_BACK && f.mid_list != nullptr;   // (launch-uniform)
-    const uint32_t q_end = LONG ? *f.long_cnt : BIG ? *f.bigq_cnt : MID || listed ? *f.mid_cnt : p.nq;   // (MID: the list is final -- the lean instantiation's launch is over)
+    const uint32_t q_end = TINY ? 1u : LONG ? *f.long_cnt : BIG ? *f.bigq_cnt : MID || listed ? *f.mid_cnt : p.nq;   // (MID: the list is final -- the lean instantiation's launch is over)
     // The serving order (round 5, f.order; lean fused and back-end forms): the batch sorted by each query's most popular item and dealt to the XCDs chunk by chunk (ord_pos,
     // srn_device.h): one XCD's L2 sees runs of like queries, whose posting lists and neighbour rows are largely the same lines.  Without an order: query index order,
     // workgroup b serves b, b + gridDim, ...
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
     const uint32_t qi_step = ordered ? gridDim.x >> 3 : gridDim.x;
     const uint32_t qi_end = ordered ? ord_count(p.nq, ox) : q_end;
     for (uint32_t qi = ordered ? blockIdx.x >> 3 : (MODE == FM_FRONT ? f.q_base : 0u) + blockIdx.x; qi < qi_end; qi += qi_step) {
-        const uint32_t q = LONG ? f.long_list[qi] : BIG ? f.bigq_list[qi] : MID || listed ? f.mid_list[qi] : ordered ? (uint32_t)f.order[ord_pos(ox, qi)] : qi;
+        const uint32_t q = TINY ? qi : LONG ? f.long_list[qi] : BIG ? f.bigq_list[qi] : MID || listed ? f.mid_list[qi] : ordered ? (uint32_t)f.order[ord_pos(ox, qi)] : qi;   // (TINY: the launch's one query, MID form included)
         const uint32_t q_ord_next = ordered && qi + qi_step < qi_end ? (uint32_t)f.order[ord_pos(ox, qi + qi_step)]
                                   : listed && qi + qi_step < qi_end ? f.mid_list[qi + qi_step] : 0xFFFFFFFFu;   // (the query this workgroup serves next: its record is parked during this one)
 #ifndef SRN_MID_PREFETCH
@@ -1494,12 +1494,12 @@ hipError_t launch_finish(hipStream_t st, const DeviceIndex& di, const FastParams
 hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const LaunchParams& p, const FastParams& f, bool debug, int mode, bool mid, bool big, bool lng, bool tiny) {
     constexpr int W = (int)F_WG_PER_CU;
     const bool wide = f.nb == 3u, frag = di.row_frag != 0u;
-    if (mid && (mode != FM_FUSED || frag || (!big && f.mid_list == nullptr))) return hipErrorInvalidValue;
+    if (mid && (mode != FM_FUSED || frag || (!big && !tiny && f.mid_list == nullptr))) return hipErrorInvalidValue;
     if (big && (!mid || (!lng && f.bigq_list == nullptr))) return hipErrorInvalidValue;
     if (lng && (!big || frag || f.long_list == nullptr)) return hipErrorInvalidValue;
-    if (tiny && (mid || mode != FM_FUSED || frag || grid.x != 1u)) return hipErrorInvalidValue;   // (one workgroup: it clears and publishes the sequence's counters itself)
+    if (tiny && (big || mode != FM_FUSED || frag || grid.x != 1u)) return hipErrorInvalidValue;   // (one workgroup: it clears and publishes the sequence's counters itself)
     void (*kern)(DeviceIndex, LaunchParams, FastParams) =
-        tiny ? (wide ? vmis_fast_kernel<W, false, true, FM_FUSED, false, false, false, true> : vmis_fast_kernel<W, false, false, FM_FUSED, false, false, false, true>) :
+        tiny ? (mid ? vmis_fast_kernel<W, false, false, FM_FUSED, true, false, false, true> : wide ? vmis_fast_kernel<W, false, true, FM_FUSED, false, false, false, true> : vmis_fast_kernel<W, false, false, FM_FUSED, false, false, false, true>) :
         lng ? vmis_fast_kernel<W, false, false, FM_FUSED, true, true, true> :
         big ? vmis_fast_kernel<W, false, false, FM_FUSED, true, true> :
         mid ? vmis_fast_kernel<W, false, false, FM_FUSED, true> :

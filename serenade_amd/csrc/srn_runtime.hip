@@ -492,7 +492,8 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
             for (uint32_t i = 0; i < fp.tiny_len; ++i) fp.tiny_items[i] = h_items[h_qoff[0] + i];
             seq = ++w->tiny_seq; if (seq == 0u) seq = ++w->tiny_seq;
             fp.host_seq = seq; fp.host_words = w->h_retry_dev;
-            HIP_TRY(launch_fast(dim3(1), st, d->di, p, fp, kn.debug, 0, false, false, false, true));
+            // (a session of > 4 items goes to the MID form at once -- the lean form would only list it: five lists, numerators beyond 15)
+            HIP_TRY(launch_fast(dim3(1), st, d->di, p, fp, kn.debug, 0, plan.mid_tier && L1 > 4u && L1 <= F_MID_LMAX, false, false, true));
             fp.host_words = nullptr; fp.tiny_len = 0;
         }
         else
