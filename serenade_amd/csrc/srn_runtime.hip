@@ -548,7 +548,11 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
                                        (unsigned long long)c, (unsigned long long)second.load(), (unsigned long long)why[0].load(), (unsigned long long)why[1].load(), (unsigned long long)why[2].load());
         }
         if (two_phase && (hw[1] | hw[2] | (phases >= 2 ? hw[4] : 0u)) != 0u) {   // (handed to the general kernel | listed for MID | queries with > 63 entries)
-            int rc = rest(); if (rc) return rc;
+            int rc = SRN_OK;
+            if (fused && hw[1] == 0u && hw[2] == 0u)   // (only a row of > 63 entries is left: finish-big alone)
+                HIP_TRY(launch_finish_big(st, d->di, fp, p.out_ids, p.out_scores, p.out_counts, p.how_many, (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * 16), nullptr, w->slow_cnt, w->h_retry_dev));
+            else rc = rest();
+            if (rc) return rc;
             rc = wait(); if (rc) return rc;
         }
     } else {
