@@ -410,15 +410,16 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
     const unsigned long long lt = (1ull << lane) - 1ull;
     static_assert(!TINY || (MODE == FM_FUSED && !BIG && !FRAG), "TINY: the lean or the MID fused form over an unsharded index");
     if constexpr (TINY) {
-        // The latency path's ONE launch for ONE evolving session (srn_predict): the workgroup writes its query's prep record itself (its first eight lanes: vmis_prep_kernel's
-        // body), serves it, and wave 0 finishes it from registers (finish_inline) -- five launches of 5..18 us each became one.  The launch sequence's counters are cleared
-        // here and published to the host at the end: what this kernel hands on (general kernel, MID, > 63 entries) the host launches behind it, for that call only.
-        if (tid < 8u) f.slow_cnt[tid] = 0u;
+        // The latency path's ONE launch, one workgroup per evolving session (srn_predict: one; a round of concurrent callers or a small host batch: up to 32): the workgroup
+        // writes its query's prep record itself (its first eight lanes: vmis_prep_kernel's body), serves it, and wave 0 finishes it from registers (finish_inline) -- five
+        // launches of 5..18 us each became one.  The launch sequence's counters start at zero (the host sees to it) and are published by the LAST workgroup to finish: what
+        // this kernel hands on (general kernel, MID, > 63 entries) the host launches behind it, for that call only.
         // (the session's items ride in the kernel arguments where they fit: read from the pinned staging they are two dependent PCIe round trips -- offsets, then items)
         unsigned long long* const a_items = reinterpret_cast<unsigned long long*>(smem + F_W10 + 64); uint32_t* const a_off = reinterpret_cast<uint32_t*>(smem + F_W10 + 64 + 64);   // (where a NEXT query's record would be parked: this launch has none)
         const uint32_t alen = f.tiny_len;
         if (alen) { if (tid < 8u) a_items[tid] = f.tiny_items[tid]; if (tid == 0u) { a_off[0] = 0u; a_off[1] = alen; } __syncthreads(); }
-        if (tid < PREP_LANES) prep_group(ix_arg, alen ? (const uint64_t*)a_items : p.items_flat, alen ? (const uint32_t*)a_off : p.q_off, 0u, tid, p.m, p.max_len, const_cast<char*>(p.prep), nullptr, 0u, nullptr);
+        if (tid < PREP_LANES) prep_group(ix_arg, alen ? (const uint64_t*)a_items : p.items_flat, alen ? (const uint32_t*)a_off : p.q_off, alen ? 0u : blockIdx.x, tid, p.m, p.max_len,
+                                         const_cast<char*>(p.prep) + (size_t)blockIdx.x * p.prep_stride, nullptr, 0u, nullptr);
         __syncthreads();   // (workgroup-scope release / acquire: the record's words for every wave)
     }
 
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
     // (round 5) the lean BACK-END form over a LIST: what the item shard's wave-per-query kernel (srn_sback.hip) could not hold -- a query with hundreds of long fragments, a hit
     // list beyond its room -- is served here, eight waves and 53 KB per query, before the general kernel gets a look; the list is the MID tier's, which a back end never has
     const bool listed = !MID && MODE == FM_BACK && f.mid_list != nullptr;   // (launch-uniform)
-    const uint32_t q_end = TINY ? 1u : LONG ? *f.long_cnt : BIG ? *f.bigq_cnt : MID || listed ? *f.mid_cnt : p.nq;   // (MID: the list is final -- the lean instantiation's launch is over)
+    const uint32_t q_end = TINY ? p.nq : LONG ? *f.long_cnt : BIG ? *f.bigq_cnt : MID || listed ? *f.mid_cnt : p.nq;   // (MID: the list is final -- the lean instantiation's launch is over)
     // The serving order (round 5, f.order; lean fused and back-end forms): the batch sorted by each query's most popular item and dealt to the XCDs chunk by chunk (ord_pos,
     // srn_device.h): one XCD's L2 sees runs of like queries, whose posting lists and neighbour rows are largely the same lines.  Without an order: query index order,
     // workgroup b serves b, b + gridDim, ...
@@ -1315,11 +1316,19 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
         FAST_TICK(13);
     }
     if (ticking) { __syncthreads(); if (tid < 16u && tacc[tid]) atomicAdd(&p.phase_cycles[tid], tacc[tid]); }
-    if constexpr (TINY) {   // (every append of this one-workgroup launch was thread 0's own: its atomics are behind it in program order)
-        if (tid == 0u && f.host_words) { f.host_words[1] = atomicAdd(&f.slow_cnt[0], 0u); f.host_words[2] = atomicAdd(&f.slow_cnt[1], 0u); f.host_words[3] = atomicAdd(&f.slow_cnt[4], 0u);
-                                         f.host_words[4] = atomicAdd(&f.slow_cnt[3], 0u);
-                                         __threadfence_system();   // (wave 0's row and these words before the word the host spins on)
-                                         __atomic_store_n(&f.host_words[5], f.host_seq, __ATOMIC_RELAXED); }
+    if constexpr (TINY) {
+        // every append and every row of this workgroup was wave 0's (thread 0's atomics, the wave's stores): behind thread 0 in program order.  The workgroups count
+        // themselves off; the last one publishes the counters and, behind a system-scope fence, the call's number -- the word the caller spins on.
+        if (tid == 0u && f.host_words) {
+            __threadfence_system();
+            if (atomicAdd(&f.slow_cnt[6], 1u) == gridDim.x - 1u) {
+                f.host_words[1] = atomicAdd(&f.slow_cnt[0], 0u); f.host_words[2] = atomicAdd(&f.slow_cnt[1], 0u); f.host_words[3] = atomicAdd(&f.slow_cnt[4], 0u);
+                f.host_words[4] = atomicAdd(&f.slow_cnt[3], 0u);
+                atomicExch(&f.slow_cnt[6], 0u);   // (ready for the next call: where nothing was handed on, every counter is 0 again)
+                __threadfence_system();
+                __atomic_store_n(&f.host_words[5], f.host_seq, __ATOMIC_RELAXED);
+            }
+        }
     }
 }
 
@@ -1497,7 +1506,7 @@ hipError_t launch_fast(dim3 grid, hipStream_t st, const DeviceIndex& di, const L
     if (mid && (mode != FM_FUSED || frag || (!big && !tiny && f.mid_list == nullptr))) return hipErrorInvalidValue;
     if (big && (!mid || (!lng && f.bigq_list == nullptr))) return hipErrorInvalidValue;
     if (lng && (!big || frag || f.long_list == nullptr)) return hipErrorInvalidValue;
-    if (tiny && (big || mode != FM_FUSED || frag || grid.x != 1u)) return hipErrorInvalidValue;   // (one workgroup: it clears and publishes the sequence's counters itself)
+    if (tiny && (big || mode != FM_FUSED || frag || grid.x != p.nq)) return hipErrorInvalidValue;   // (a workgroup per query: the last one to finish publishes the sequence's counters)
     void (*kern)(DeviceIndex, LaunchParams, FastParams) =
         tiny ? (mid ? vmis_fast_kernel<W, false, false, FM_FUSED, true, false, false, true> : wide ? vmis_fast_kernel<W, false, true, FM_FUSED, false, false, false, true> : vmis_fast_kernel<W, false, false, FM_FUSED, false, false, false, true>) :
         lng ? vmis_fast_kernel<W, false, false, FM_FUSED, true, true, true> :

@@ -36,6 +36,7 @@ static void knobs_read() {
     if (const char* e = getenv("SRN_D2H_BLOCKS")) k.d2h_blocks = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_TINY_MAX")) k.tiny_max = std::max(0, atoi(e));
     k.no_tiny_fused = getenv("SRN_TINY_FUSED") != nullptr && atoi(getenv("SRN_TINY_FUSED")) == 0;
+    if (const char* e = getenv("SRN_TINY_FUSED_MAX")) k.tiny_fused_max = std::min(32, std::max(1, atoi(e)));
     k.no_tiny_spin = getenv("SRN_TINY_SPIN") != nullptr && atoi(getenv("SRN_TINY_SPIN")) == 0;
     if (const char* e = getenv("SRN_TINY_PHASES")) k.tiny_phases = std::min(2, std::max(0, atoi(e)));
     if (const char* e = getenv("SRN_TINY_FAST")) k.tiny_fast = std::min(3, std::max(0, atoi(e)));
@@ -476,8 +477,8 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
     }
     // (round 5) ONE evolving session per call -- srn_predict, the reference's call shape: one launch.  The fast kernel's TINY instantiation writes the prep record itself,
     // serves the query and finishes its row from registers; the counters it publishes say whether anything is left for the kernels behind it (SRN_TINY_FUSED=0: five launches).
-    const bool fused = tiny_fast && p.nq == 1 && !kn.no_tiny_fused;
-    if (!fused) HIP_TRY(launch_prep(st, d->di, p.items_flat, p.q_off, p.nq, p.m, p.max_len, w->prep, prep_stride, tiny_fast ? w->slow_cnt : nullptr));
+    const bool fused = tiny_fast && p.nq <= (uint32_t)kn.tiny_fused_max && !kn.no_tiny_fused;
+    if (!fused) { w->cnt_dirty = true; HIP_TRY(launch_prep(st, d->di, p.items_flat, p.q_off, p.nq, p.m, p.max_len, w->prep, prep_stride, tiny_fast ? w->slow_cnt : nullptr)); }
     p.prep = w->prep; p.prep_stride = prep_stride;
     if (tiny_fast) {
         FastParams fp = d->fast; fp.slow_list = w->slow_list; fp.slow_cnt = w->slow_cnt; fp.nb = plan.nb_fast; fp.max_runs = plan.nb_fast; fp.fin = w->fin;
@@ -487,13 +488,14 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
         fp.bigq_list = nullptr; fp.bigq_cnt = nullptr; fp.long_list = nullptr; fp.long_cnt = nullptr;   // (no BIG / LONG tier on the latency path)
         uint32_t seq = 0;
         if (fused) {
-            const uint32_t L1 = h_qoff[1] - h_qoff[0];
-            fp.tiny_len = L1 >= 1u && L1 <= 8u ? L1 : 0u;   // (the items in the kernel arguments where they fit)
+            uint32_t L1 = 0; for (uint32_t q = 0; q < p.nq; ++q) L1 = std::max(L1, h_qoff[q + 1] - h_qoff[q]);   // the call's longest session
+            if (w->cnt_dirty) { HIP_TRY(hipMemsetAsync(w->slow_cnt, 0, 32, st)); w->cnt_dirty = false; }   // (only after a call that left the counters non-zero: the fused launch leaves them at 0 unless it hands work on)
+            fp.tiny_len = p.nq == 1 && L1 >= 1u && L1 <= 8u ? L1 : 0u;   // (a single session's items in the kernel arguments where they fit)
             for (uint32_t i = 0; i < fp.tiny_len; ++i) fp.tiny_items[i] = h_items[h_qoff[0] + i];
             seq = ++w->tiny_seq; if (seq == 0u) seq = ++w->tiny_seq;
             fp.host_seq = seq; fp.host_words = w->h_retry_dev;
             // (a session of > 4 items goes to the MID form at once -- the lean form would only list it: five lists, numerators beyond 15)
-            HIP_TRY(launch_fast(dim3(1), st, d->di, p, fp, kn.debug, 0, plan.mid_tier && L1 > 4u && L1 <= F_MID_LMAX, false, false, true));
+            HIP_TRY(launch_fast(dim3(p.nq), st, d->di, p, fp, kn.debug, 0, plan.mid_tier && L1 > 4u, false, false, true));
             fp.host_words = nullptr; fp.tiny_len = 0;
         }
         else
@@ -549,6 +551,7 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
         }
         if (two_phase && (hw[1] | hw[2] | (phases >= 2 ? hw[4] : 0u)) != 0u) {   // (handed to the general kernel | listed for MID | queries with > 63 entries)
             int rc = SRN_OK;
+            w->cnt_dirty = true;
             if (fused && hw[1] == 0u && hw[2] == 0u)   // (only a row of > 63 entries is left: finish-big alone)
                 HIP_TRY(launch_finish_big(st, d->di, fp, p.out_ids, p.out_scores, p.out_counts, p.how_many, (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * 16), nullptr, w->slow_cnt, w->h_retry_dev));
             else rc = rest();
@@ -760,6 +763,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
     // The fast kernel (srn_fast.hip) serves the common query shape; what it cannot take -- decided per query, on the device -- is
     // queued on slow_list and served by the general kernel right behind it.
     if (fast) {
+        w->cnt_dirty = true;   // (the latency path's fused launch wants the counters at 0 and clears them itself after a sequence like this one)
         if (!prep_clears) HIP_TRY(hipMemsetAsync(w->slow_cnt, 0, 32, st));   // (slow_cnt[0] = handed-over queries, [1] = the MID instantiation's list, [2..3] = the 64-bit ticket of vmis_finish_big_kernel's list, [4] = MID-BIG's list)
         // The fast kernel's workgroups walk their queries in a pipeline (the next record is fetched during the current query), so they want ~12 queries each;
         // beyond that, more and smaller workgroups shorten the tail of the launch.  Measured on config 3 (ms per launch at 8 / 16 / 32 / 64 resident sets): 2^20 queries
