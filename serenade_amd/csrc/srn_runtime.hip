@@ -36,7 +36,7 @@ static void knobs_read() {
     if (const char* e = getenv("SRN_D2H_BLOCKS")) k.d2h_blocks = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_TINY_MAX")) k.tiny_max = std::max(0, atoi(e));
     k.no_tiny_fused = getenv("SRN_TINY_FUSED") != nullptr && atoi(getenv("SRN_TINY_FUSED")) == 0;
-    if (const char* e = getenv("SRN_TINY_FUSED_MAX")) k.tiny_fused_max = std::min(32, std::max(1, atoi(e)));
+    if (const char* e = getenv("SRN_TINY_FUSED_MAX")) k.tiny_fused_max = std::min(256, std::max(1, atoi(e)));
     k.no_tiny_spin = getenv("SRN_TINY_SPIN") != nullptr && atoi(getenv("SRN_TINY_SPIN")) == 0;
     if (const char* e = getenv("SRN_TINY_PHASES")) k.tiny_phases = std::min(2, std::max(0, atoi(e)));
     if (const char* e = getenv("SRN_TINY_FAST")) k.tiny_fast = std::min(3, std::max(0, atoi(e)));
