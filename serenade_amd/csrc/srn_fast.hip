@@ -1276,6 +1276,62 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
             if (ln == 0u) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q;
             continue;
         }
+        if constexpr (TINY) {
+            // A row of > 63 entries (no threshold from the sample: a small query whose every scored item is a candidate) finished HERE as well -- 3 % of config 3's single-session
+            // calls, and each of them used to cost the call a second wait behind finish-big.  All M keys (x = idf_eff * acc; the contenders' idf gathered now) into the dead
+            // sketch words; the n-th largest of their top 32 bits by a bitwise search over ballots; what is at or above ONE STEP BELOW it (so that what is dropped stays strictly
+            // smaller after the division by 10 U, as everywhere) -- n entries and the ties at the cut -- compacted into the lanes and ranked by finish_inline.  More than 64
+            // such entries: the record path below, as before.
+            constexpr uint32_t TB_MAX = 704, TB_SLOTS = TB_MAX / 64;   // (M <= F_CAND_CAP + 4 * F_TABLE_BUCKETS = 668)
+            static_assert(F_CAND_CAP + 4u * F_TABLE_BUCKETS <= TB_MAX && TB_MAX * 12u + 64u * 12u <= F_SK_WORDS * 4u, "the big row's keys fit the sketch words");
+            if (M > F_FIN_ENTRIES && M <= TB_MAX && cnt <= F_CAND_CAP && M >= p.how_many) {   // (wave-uniform)
+                unsigned long long* const kx = reinterpret_cast<unsigned long long*>(smem + F_SKETCH); uint32_t* const kt = reinterpret_cast<uint32_t*>(smem + F_SKETCH + TB_MAX * 8u);
+                unsigned long long* const cx = reinterpret_cast<unsigned long long*>(smem + F_SKETCH + TB_MAX * 12u); uint32_t* const ct = reinterpret_cast<uint32_t*>(smem + F_SKETCH + TB_MAX * 12u + 64u * 8u);
+                uint32_t hk[TB_SLOTS];
+                {
+                    uint2 cc[TB_SLOTS]; ItemMeta mm[TB_SLOTS];
+#pragma unroll
+                    for (uint32_t t = 0; t < TB_SLOTS; ++t) { const uint32_t i = t * 64u + ln; cc[t] = i >= cnt && i < M ? tl[i - cnt] : make_uint2(0u, 0u); }
+#pragma unroll
+                    for (uint32_t t = 0; t < TB_SLOTS; ++t) mm[t] = ix.meta[cc[t].x];   // (all gathers in flight together; a candidate's lane reads item 0's record and drops it)
+#pragma unroll
+                    for (uint32_t t = 0; t < TB_SLOTS; ++t) {
+                        const uint32_t i = t * 64u + ln;
+                        unsigned long long x = 0ull; uint32_t tie = EMPTY32;
+                        if (i < cnt) { x = ckey[i]; tie = cidx[i]; }
+                        else if (i < M) { x = (unsigned long long)__double_as_longlong((mm[t].idf > 0.0 ? mm[t].idf : 1.0) * (double)cc[t].y); tie = mm[t].id_rank; }
+                        hk[t] = (uint32_t)(x >> 32);
+                        if (i < M) { kx[i] = x; kt[i] = tie; }
+                    }
+                }
+                uint32_t t32 = 0u;
+                for (int b = 31; b >= 0; --b) {
+                    const uint32_t c = t32 | (1u << b);
+                    uint32_t n_ge = 0;
+#pragma unroll
+                    for (uint32_t t = 0; t < TB_SLOTS; ++t) n_ge += (uint32_t)__popcll(__ballot(hk[t] >= c));
+                    t32 = n_ge >= p.how_many ? c : t32;
+                }
+                const uint32_t cut = t32 ? t32 - 1u : 0u;
+                uint32_t S = 0;   // (wave-uniform) entries at or above the cut
+#pragma unroll
+                for (uint32_t t = 0; t < TB_SLOTS; ++t) {
+                    const uint32_t i = t * 64u + ln;
+                    const bool keep = i < M && hk[t] >= cut && hk[t] != 0u;
+                    const unsigned long long bm = __ballot(keep);
+                    const uint32_t at = S + (uint32_t)__popcll(bm & ltl);
+                    if (keep && at < 64u) { cx[at] = kx[i]; ct[at] = kt[i]; }
+                    S += (uint32_t)__popcll(bm);
+                }
+                if (S <= 64u && S >= p.how_many) {
+                    __builtin_amdgcn_wave_barrier();   // (one wave, LDS in order: the compacted entries are there)
+                    uint4 e = make_uint4(0u, 0u, 0u, 0u);
+                    if (ln < S) { const unsigned long long x = cx[ln]; e = make_uint4((uint32_t)x, (uint32_t)(x >> 32), ct[ln], 0u); }
+                    finish_inline(ix_arg, S, U, e, ln, q, p.out_ids, p.out_scores, p.out_counts, p.how_many);
+                    continue;
+                }
+            }
+        }
         uint32_t ovf_at = 0;
         if (M > F_FIN_ENTRIES) {   // (wave-uniform, rare: the atomic's round trip is paid by these queries only)
             unsigned long long tk = 0;
