@@ -34,7 +34,7 @@ struct Knobs {
     int d2h_blocks = 0;       // SRN_D2H_BLOCKS: workgroups of the chunked host path's own download kernel (0 = hipMemcpyAsync, the default: measured faster, profiles/r03_host_pipe_probe.txt)
     int tiny_max = 256;       // SRN_TINY_MAX: host-pointer batches of up to this many sessions take the zero-copy latency path
     bool no_tiny_spin = false;    // SRN_TINY_SPIN=0: the fused launch's caller waits for the stream instead of spinning on the kernel's last pinned word
-    int tiny_fused_max = 32;      // SRN_TINY_FUSED_MAX: sessions per call up to which the latency path is the fused launch (one workgroup per session)
+    int tiny_fused_max = 48;      // SRN_TINY_FUSED_MAX: sessions per call up to which the latency path is the fused launch (one workgroup per session).  Measured (config 3, host batches): 48 per call p50 56 / p90 77 us against 78 / 83 for prep + general kernel; 64 per call 57 / 103 against 79 / 85 -- a call's chance of a second phase (a query for the general kernel: 0.3 % each) grows with its size, and the p90 with it
     bool no_tiny_fused = false;   // SRN_TINY_FUSED=0: a single-session call through five launches (prep, fast kernel, general kernel, finish, finish-big) instead of the fast kernel's one-launch TINY form
     int tiny_phases = 0;      // SRN_TINY_PHASES (experiments): the latency path's launches behind the fast kernel -- 0: all of them with every call; 1: finish + finish-big, then MID / general kernel / a second finish only for a call that listed queries for them (a second wait then); 2: finish alone in the first phase.  Measured (profiles/r05_latency_phases.txt): one query per call p50 46 us against 49 with 2, p99 71 against 63; calls of 4 and 16 queries lose at p90 (a second wait more often): 0 stays
     int tiny_fast = 2;        // SRN_TINY_FAST: the latency path's kernels -- 0: prep + general kernel (rounds 1-3); 1: the fast kernel's launch sequence only where the batch has a session of > 8 items (which puts

@@ -467,7 +467,7 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
     // lean / MID instantiations serve sessions of <= 10 items at the short sessions' cost.  Four more launches (~2 us each on an idle stream), no more synchronisation.
     const Knobs kn = knobs();
     const FastPlan plan = fast_plan(d, ix, p, geo, kn, false);
-    const bool tiny_fast = plan.fast && (kn.tiny_fast == 3 || (kn.tiny_fast >= 1 && p.max_len > 8) || (kn.tiny_fast == 2 && p.nq <= 32));   // (the crossover measured with tools/tiny_crossover.py: profiles/r04_serving_tiny_fast.txt)
+    const bool tiny_fast = plan.fast && (kn.tiny_fast == 3 || (kn.tiny_fast >= 1 && p.max_len > 8) || (kn.tiny_fast == 2 && p.nq <= (kn.no_tiny_fused ? 32u : (uint32_t)kn.tiny_fused_max)));   // (the crossover measured with tools/tiny_crossover.py: profiles/r04_serving_tiny_fast.txt)
     const uint64_t big_entries = (uint64_t)cap_q * 16 + 4096;
     if (tiny_fast) {   // (sized once, for the largest round)
         if (w->slow_cap < cap_q) { if (w->slow_list) HIP_TRY(hipFree(w->slow_list)); w->slow_list = nullptr; w->slow_cap = 0;
@@ -552,8 +552,12 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
         if (two_phase && (hw[1] | hw[2] | (phases >= 2 ? hw[4] : 0u)) != 0u) {   // (handed to the general kernel | listed for MID | queries with > 63 entries)
             int rc = SRN_OK;
             w->cnt_dirty = true;
-            if (fused && hw[1] == 0u && hw[2] == 0u)   // (only a row of > 63 entries is left: finish-big alone)
-                HIP_TRY(launch_finish_big(st, d->di, fp, p.out_ids, p.out_scores, p.out_counts, p.how_many, (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * 16), nullptr, w->slow_cnt, w->h_retry_dev));
+            if (fused && hw[2] == 0u) {   // (nothing listed for MID: the general kernel over what was handed to it -- it writes its rows itself -- and finish-big for a row the fused launch could not finish, each only if needed)
+                const uint32_t n_slow = hw[1], n_big = hw[4];
+                if (n_slow) HIP_TRY(launch_predict(geo.masks, geo.slot64, false, 0, dim3(std::min<uint32_t>(p.nq, n_slow)), geo.lds, st, d->di, p, geo.c, w->slow_list, w->slow_cnt, (uint32_t*)(dp + o_rl), (uint32_t*)(dp + o_rc), nullptr, 0,
+                                                   w->spill, ShardIO{}));
+                if (n_big) HIP_TRY(launch_finish_big(st, d->di, fp, p.out_ids, p.out_scores, p.out_counts, p.how_many, (uint32_t)std::min<uint64_t>(p.nq, (uint64_t)d->n_cu * 16), nullptr, w->slow_cnt, w->h_retry_dev));
+            }
             else rc = rest();
             if (rc) return rc;
             rc = wait(); if (rc) return rc;
