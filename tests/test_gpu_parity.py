@@ -878,8 +878,8 @@ def test_single_session_calls_one_launch_against_the_oracle(knobs):
                         cnt = int(ref["counts"][qi])
                         assert [r.id for r in recs] == ref["ids"][qi, :cnt].tolist(), (knobs, n_items, business, n, qi, q)
                         np.testing.assert_allclose([r.score for r in recs], ref["scores"][qi, :cnt], rtol=1e-12, atol=0)
-                    # ... and small host batches (a workgroup per session in the same launch; the last one to finish publishes): 2, 5, 32, 33 sessions per call
-                    for nb in (2, 5, 32, 33):
+                    # ... and small host batches (a workgroup per session in the same launch; the last one to finish publishes): 2, 5, 32, 48 sessions per call, and 49 -- the first size beyond the fused launch
+                    for nb in (2, 5, 32, 48, 49):
                         for q0 in range(0, len(qs) - nb, 37):
                             ids_, sc_, cnt_ = sa.predict_batch(gix, qs[q0:q0 + nb], k, m, n, business)
                             assert np.array_equal(cnt_, ref["counts"][q0:q0 + nb]), (knobs, nb, q0)
