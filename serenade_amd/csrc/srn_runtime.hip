@@ -285,7 +285,7 @@ Workspace* ws_acquire(DeviceState* d, bool bind_to_stream, void* user_stream) {
     Workspace* w = new Workspace();
     if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { delete w; return nullptr; }
     for (auto& t : w->ev) for (auto& e : t) if (hipEventCreate(&e) != hipSuccess) { ws_free(w); return nullptr; }
-    if (hipMalloc((void**)&w->retry_cnt, 16) != hipSuccess || hipMalloc((void**)&w->retry_cnt2, 16) != hipSuccess || hipMalloc((void**)&w->slow_cnt, 32) != hipSuccess || hipHostMalloc((void**)&w->h_retry, 32) != hipSuccess) { ws_free(w); return nullptr; }
+    if (hipMalloc((void**)&w->retry_cnt, 16) != hipSuccess || hipMalloc((void**)&w->retry_cnt2, 16) != hipSuccess || hipMalloc((void**)&w->slow_cnt, 32) != hipSuccess || hipHostMalloc((void**)&w->h_retry, 32, hipHostMallocCoherent) != hipSuccess)   /* (coherent whatever HIP_HOST_COHERENT says: the latency path's caller reads these words while the kernel that writes them is still running) */ { ws_free(w); return nullptr; }
     memset(w->h_retry, 0, 32);
     if (hipHostGetDevicePointer((void**)&w->h_retry_dev, w->h_retry, 0) != hipSuccess) { ws_free(w); return nullptr; }
     d->all_ws.push_back(w);
@@ -448,7 +448,7 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
         if (w->pin) HIP_TRY(hipHostFree(w->pin));
         w->pin = nullptr; w->pin_bytes = 0;
         const size_t want = std::max<size_t>(off * 2, 256 * 1024);   // (room for a full round of the combiner at once: growing a pinned buffer stalls every lane)
-        HIP_TRY(hipHostMalloc((void**)&w->pin, want, hipHostMallocMapped));
+        HIP_TRY(hipHostMalloc((void**)&w->pin, want, hipHostMallocMapped | hipHostMallocCoherent));   // (coherent: the fused launch's caller reads its rows as soon as the kernel's last pinned word says so)
         w->pin_bytes = want;
     }
     char* dp = nullptr; HIP_TRY(hipHostGetDevicePointer((void**)&dp, w->pin, 0));
