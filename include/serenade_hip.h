@@ -165,8 +165,9 @@ int srn_predict_stats(const srn_index_t* idx, uint64_t* out_rounds, uint64_t* ou
 
 /* nq sessions in CSR form: session q = items_flat[q_off[q] .. q_off[q+1]).  Host pointers.
  * out_ids / out_scores are [nq * how_many] (row q at q * how_many), out_counts [nq].
- * Up to 256 sessions take the zero-copy latency path (pinned, device-mapped staging, no copies: the fast kernel's launch sequence for calls of <= 32 sessions and for
- * batches with a session of > 8 items, prep + general kernel -- two launches -- otherwise); larger batches are cut into
+ * Up to 256 sessions take the zero-copy latency path (pinned, device-mapped staging, no copies: ONE launch for calls of <= 48 sessions -- a workgroup per session writes
+ * its query's record, serves it and finishes its row; the fast kernel's launch sequence for larger calls with a session of > 8 items; prep + general kernel -- two
+ * launches -- otherwise); larger batches are cut into
  * chunks whose uploads, kernels and downloads overlap on separate streams, the results landing in the caller's buffers while
  * the next chunks run (srn_hostpipe.hip).  The buffers may be pageable. */
 int srn_predict_batch(const srn_index_t* idx, const uint64_t* items_flat, const uint32_t* q_off, size_t nq,
