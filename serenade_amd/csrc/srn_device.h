@@ -115,4 +115,29 @@ __device__ __forceinline__ int item_insert(uint32_t* ikeys, int* iacc, uint32_t 
 }
 
 
+// vmis_finish_kernel's work for ONE query whose <= 63 entries are still in the serving wave's registers (lane i: entry i): the latency path's fused launch (vmis_fast_kernel<TINY>) and the item shard's wave-per-query back end (srn_sback.hip).  Same
+// arithmetic, same order: idf of a contender, x = idf_eff * acc, score = x / (10 U), rank = entries with a better (score desc, id rank asc) key.
+__device__ __forceinline__ void finish_inline(const DeviceIndex& ix, uint32_t M, uint32_t U, const uint4& e, uint32_t ln, uint32_t q, uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint32_t how_many) {
+    const bool have = ln < M;
+    const ItemMeta mt = ix.meta[have && e.w != 0u ? e.z : 0u];
+    double x = 0.0; uint32_t tie = EMPTY32;
+    if (have) {
+        if (e.w == 0u) { x = __longlong_as_double((long long)(((unsigned long long)e.y << 32) | e.x)); tie = e.z; }
+        else { x = (mt.idf > 0.0 ? mt.idf : 1.0) * (double)e.x; tie = mt.id_rank; }
+    }
+    const unsigned long long pid = ix.id_sorted[have ? tie : 0u];
+    const double sc = have ? x / (double)(10u * U) : 0.0;
+    const unsigned long long mk = (unsigned long long)__double_as_longlong(sc);   // (positive doubles order like their bit patterns)
+    const int klo = (int)(uint32_t)mk, khi = (int)(uint32_t)(mk >> 32);
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < M; ++j) {
+        const uint32_t jl = (uint32_t)__builtin_amdgcn_readlane(klo, (int)j), jh = (uint32_t)__builtin_amdgcn_readlane(khi, (int)j), ij = (uint32_t)__builtin_amdgcn_readlane((int)tie, (int)j);
+        const unsigned long long kj = ((unsigned long long)jh << 32) | jl;
+        rank += (uint32_t)(kj > mk) | ((uint32_t)(kj == mk) & (uint32_t)(ij < tie));
+    }
+    if (have && rank < how_many) { out_ids[(size_t)q * how_many + rank] = pid; out_scores[(size_t)q * how_many + rank] = sc; }
+    if (ln == 0u) out_counts[q] = min(M, how_many);
+}
+
+
 }  // namespace srn

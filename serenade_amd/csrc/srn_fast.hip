@@ -356,30 +356,6 @@ enum { FM_FUSED = 0, FM_FRONT = 1, FM_BACK = 2 };
 // histogram); the neighbour list is 64-bit {slot, signed weight 10 * linear_score(first match) * numerator}.  Direct-mapped accumulators take signed adds, sketch words only the
 // positive ones (they must stay upper bounds: DESIGN.md "Why the sketch filter is exact" holds with acc <= its positive part <= the word); sums <= 0 are no candidates,
 // and a query whose positive scores do not fill the top n goes to the general kernel (an item of score <= 0 could then be returned).
-// vmis_finish_kernel's work for ONE query whose <= 63 entries are still in the serving wave's registers (lane i: entry i): the latency path's fused launch (TINY).  Same
-// arithmetic, same order: idf of a contender, x = idf_eff * acc, score = x / (10 U), rank = entries with a better (score desc, id rank asc) key.
-__device__ __forceinline__ void finish_inline(const DeviceIndex& ix, uint32_t M, uint32_t U, const uint4& e, uint32_t ln, uint32_t q, uint64_t* out_ids, double* out_scores, uint32_t* out_counts, uint32_t how_many) {
-    const bool have = ln < M;
-    const ItemMeta mt = ix.meta[have && e.w != 0u ? e.z : 0u];
-    double x = 0.0; uint32_t tie = EMPTY32;
-    if (have) {
-        if (e.w == 0u) { x = __longlong_as_double((long long)(((unsigned long long)e.y << 32) | e.x)); tie = e.z; }
-        else { x = (mt.idf > 0.0 ? mt.idf : 1.0) * (double)e.x; tie = mt.id_rank; }
-    }
-    const unsigned long long pid = ix.id_sorted[have ? tie : 0u];
-    const double sc = have ? x / (double)(10u * U) : 0.0;
-    const unsigned long long mk = (unsigned long long)__double_as_longlong(sc);   // (positive doubles order like their bit patterns)
-    const int klo = (int)(uint32_t)mk, khi = (int)(uint32_t)(mk >> 32);
-    uint32_t rank = 0;
-    for (uint32_t j = 0; j < M; ++j) {
-        const uint32_t jl = (uint32_t)__builtin_amdgcn_readlane(klo, (int)j), jh = (uint32_t)__builtin_amdgcn_readlane(khi, (int)j), ij = (uint32_t)__builtin_amdgcn_readlane((int)tie, (int)j);
-        const unsigned long long kj = ((unsigned long long)jh << 32) | jl;
-        rank += (uint32_t)(kj > mk) | ((uint32_t)(kj == mk) & (uint32_t)(ij < tie));
-    }
-    if (have && rank < how_many) { out_ids[(size_t)q * how_many + rank] = pid; out_scores[(size_t)q * how_many + rank] = sc; }
-    if (ln == 0u) out_counts[q] = min(M, how_many);
-}
-
 template <int WG_PER_CU, bool FRAG, bool WIDE, int MODE = FM_FUSED, bool MID = false, bool BIG = false, bool LONG = false, bool TINY = false>
 #ifndef SRN_FAST_WAVES
 #define SRN_FAST_WAVES (WG_PER_CU * 2)

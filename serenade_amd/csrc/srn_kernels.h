@@ -122,6 +122,7 @@ struct SBackParams {
     // the streaming form (all three set, or the gather form runs): the fragments in POSTING order of the replicated lists the batch's records were written against
     const uint2* frag_post;    // [number of postings] frag_post[e] = frag8[post_rank[e]]
     const uint32_t* post_rank; // the replicated posting lists (recency ranks)
+    uint32_t finish_here;      // the serving wave finishes rows of <= 63 entries itself (score, ranking, public ids) instead of leaving a record for vmis_finish_kernel
     uint32_t* scr;             // shard_back_scratch_words() words per wave of the grid: the members' slots and fragments between walk A and walk B
 };
 hipError_t launch_rows_to_frag8(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base, uint2* frag8, uint4* ext8, uint32_t* present);   // block_base in 16-byte blocks

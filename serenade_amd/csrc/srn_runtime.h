@@ -44,6 +44,7 @@ struct Knobs {
     int row_slots16 = -1;     // SRN_ROW_SLOTS = 16 | 64: the device row layout (-1 = by index kind: 64-byte slots unsharded, 16-byte fragment slots for item shards)
     int order_min = 131072;    // SRN_ORDER_MIN: batches of at least this many queries are served in the order of their most popular item, an eighth of the order per XCD (0 = never); the ordering
                               // pass is one radix sort of the batch's keys behind the prep kernel
+    bool no_sback_finish = true;    // SRN_SBACK_FINISH=1 (experiment): the wave-per-query back end finishes rows of <= 63 entries itself instead of leaving a record for vmis_finish_kernel.  Measured: the finish kernels' share falls 0.167 -> 0.122 ms per 131 072 queries, the kernel grows 1.606 -> 1.685 (two more dependent gathers per query on a kernel bound by its requests): off
     bool no_sback_second = false;   // SRN_NO_SBACK_SECOND (experiments): what the wave-per-query back end cannot hold goes straight to the general kernel (no fast-kernel back end over the list)
     bool no_sback = false;    // SRN_NO_SBACK: the shard group's back end through vmis_fast_kernel's FM_BACK instantiation (rounds 4) instead of the wave-per-query kernel of srn_sback.hip
     bool sback_bitmap = false;     // SRN_SBACK_BITMAP=1 (experiments): that kernel asks its presence bitmap before it fetches a fragment.  Measured on config 3 cut in 8: half the fragment

@@ -43,6 +43,7 @@ static void knobs_read() {
     if (const char* e = getenv("SRN_PREDICT_LANES")) k.lanes = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_ORDER_MIN")) k.order_min = std::max(0, atoi(e));
     k.no_sback_second = getenv("SRN_NO_SBACK_SECOND") != nullptr;
+    k.no_sback_finish = !(getenv("SRN_SBACK_FINISH") != nullptr && atoi(getenv("SRN_SBACK_FINISH")) != 0);
     k.no_sback = getenv("SRN_NO_SBACK") != nullptr; k.sback_bitmap = getenv("SRN_SBACK_BITMAP") != nullptr && atoi(getenv("SRN_SBACK_BITMAP")) != 0;
     k.no_sback_stream = !(getenv("SRN_SBACK_STREAM") != nullptr && atoi(getenv("SRN_SBACK_STREAM")) != 0);
     if (const char* e = getenv("SRN_SBACK_MIN_SHARDS")) k.sback_min_shards = std::max(2, atoi(e));
@@ -790,6 +791,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         if (back && d->sback.frag8 && !kn.no_sback && p.max_len <= 8) {
             // the item shard's own back end (srn_sback.hip): one wave per query, 12 per CU; a persistent grid of a few waves per resident slot
             SBackParams sbp = d->sback; if (!kn.sback_bitmap) sbp.present = nullptr;
+            sbp.finish_here = kn.no_sback_finish ? 0u : 1u;
             // the streaming form where the shard holds its fragments in the posting order of the very lists the records were written against (9 waves per CU: 16.8 KB each)
             const bool stream = ext->positions;
             if (stream && !(d->sb_frag_post && d->sb_post_for == ext->post_rank)) return fail(SRN_ESTATE, "the batch's neighbours came as posting positions, but this shard does not hold its fragments in posting order");

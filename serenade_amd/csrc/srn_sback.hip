@@ -535,6 +535,16 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
         }
         // ---- hand-off: the query's record for vmis_finish_kernel (score = x / (10 U), ranking, public ids), as the fast kernel writes it ----
         const uint32_t M = ncand + nt;
+        if (sb.finish_here && M <= F_FIN_ENTRIES) {   // (wave-uniform) the row finished by this wave itself, from registers: no record, nothing for the finish kernel (round 5, second half)
+            uint4 e = make_uint4(0u, 0u, 0u, 0u);
+            if (lane < ncand) { const unsigned long long x = ckey[lane]; e = make_uint4((uint32_t)x, (uint32_t)(x >> 32), cidx[lane], 0u); }
+            else if (lane < M) { const uint2 c = hits[lane - ncand]; e = make_uint4(c.y, 0u, c.x, 1u); }
+            finish_inline(ix_arg, M, U, e, lane, q, p.out_ids, p.out_scores, p.out_counts, p.how_many);
+            __syncthreads();   // (the next query clears what this one still read)
+            c6 += ncand; c14 += 1ull;
+            SB_TICK(tk13);
+            continue;
+        }
         uint32_t ovf_at = 0;
         if (M > F_FIN_ENTRIES) {   // (wave-uniform, rare)
             unsigned long long tk = 0;
