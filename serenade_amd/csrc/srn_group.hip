@@ -122,6 +122,7 @@ struct srn_shard_group {
     ncclComm_t comm[2] = {nullptr, nullptr};   // [0] exchange stream, [1] caller's stream: operations on one communicator serialise in issue order
     srn_shard_comm_t cb{};
     hipStream_t s_x = nullptr; hipEvent_t e_in = nullptr, e_x = nullptr;
+    char* pres_all = nullptr; size_t pres_all_bytes = 0; uint8_t* nb_pbytes = nullptr;   // the shards' presence bitmaps (all-gathered at set_postings) and the byte per session made of them: bit g = shard g holds an item of the session
     bool stream_ok = false;   // every shard of this rank holds its fragments in the posting order of g->postings (set_postings): batches of the streaming form's shape exchange positions
     bool overlap = false, no_direct = false;   // overlap: opt-in (srn_shard_group_set_overlap) -- two communicators with collectives in flight at once have never been soaked on more than one GPU
     // A batch that failed after its first collective was issued leaves the peers' collectives without their partner: the group is BROKEN on this rank from then on (every
@@ -303,7 +304,8 @@ int group_predict_neighbours(srn_shard_group* g, const LaunchParams& p_in, bool 
     Slot& s = g->slot[g->calls & 1u];
     const bool overlap = g->overlap && !local;
     hipStream_t sx = overlap ? g->s_x : user;
-    const uint32_t rec_stride = device_prep_stride(p.max_len), xstride = p.k + 1u, per = (nq + G - 1) / G;
+    const bool pbytes = g->nb_pbytes != nullptr && device_shard_nb_presence_wanted() && p.max_len <= 8;   // (rank-invariant: the knob, the batch shape, what set_postings built on every rank)
+    const uint32_t rec_stride = device_prep_stride(p.max_len), xstride = p.k + 1u + (pbytes ? (p.k + 3u) / 4u : 0u), per = (nq + G - 1) / G;
     const size_t block_bytes = ((size_t)nq * n * 16 + (size_t)nq * 4 + 255) / 256 * 256, xblock = (size_t)per * xstride * 4;
     // Streaming form (round 5): the exchange carries, instead of the neighbour slots, WHERE the neighbours sit in the query's posting lists -- a third of the bytes --, and
     // every rank's back end streams its fragments in posting order.  Chosen from rank-invariant inputs (batch shape, knobs) + what set_postings settled for this rank.
@@ -329,6 +331,7 @@ int group_predict_neighbours(srn_shard_group* g, const LaunchParams& p_in, bool 
         int rc = device_shard_nb_prep(g->shards[i]->dev, post, p, s.nrec[i], sx, &s.nord[i], &s.nord_bytes[i], &s.nord_ptr[i]); if (rc) return rc;
         const uint32_t q_lo = std::min<uint64_t>(nq, (uint64_t)gi * per), q_hi = std::min<uint64_t>(nq, (uint64_t)q_lo + per);
         rc = device_shard_nb_front(g->shards[i]->dev, g->shards[i]->flat, post, p, s.nrec[i], (uint32_t*)s.xchg, xstride, q_lo, q_hi, sx); if (rc) return rc;
+        if (pbytes && !positions) { rc = device_shard_nb_presence(g->shards[i]->dev, g->shards[i]->flat, p, s.nrec[i], (uint32_t*)s.xchg, xstride, g->nb_pbytes, q_lo, q_hi, sx); if (rc) return rc; }
         if (positions) { rc = device_shard_nb_positions(g->shards[i]->dev, g->shards[i]->flat, post, p, s.nrec[i], (const uint32_t*)s.xchg, xstride, (uint32_t*)s.xpos, pstride, q_lo, q_hi, sx); if (rc) return rc; }
         if (g->timing && i == 0) HIP_TRY(hipEventRecord(g->e_t[1], sx));
     }
@@ -342,7 +345,7 @@ int group_predict_neighbours(srn_shard_group* g, const LaunchParams& p_in, bool 
         pi.out_ids = direct ? d_out_ids : (uint64_t*)blk; pi.out_scores = direct ? d_out_scores : (double*)(blk + (size_t)nq * n * 8); pi.out_counts = direct ? d_out_counts : (uint32_t*)(blk + (size_t)nq * n * 16);
         if (g->timing && i == 0) HIP_TRY(hipEventRecord(g->e_t[2], user));
         HIP_TRY(hipMemsetAsync(pi.out_ids, 0, (size_t)nq * n * 8, user)); HIP_TRY(hipMemsetAsync(pi.out_scores, 0, (size_t)nq * n * 8, user));
-        int rc = device_shard_nb_back(g->shards[i]->dev, g->shards[i]->flat, post, pi, s.nrec[i], (uint32_t*)(positions ? s.xpos : s.xchg), positions ? pstride : xstride, user, s.nord_ptr[i], positions); if (rc) return rc;
+        int rc = device_shard_nb_back(g->shards[i]->dev, g->shards[i]->flat, post, pi, s.nrec[i], (uint32_t*)(positions ? s.xpos : s.xchg), positions ? pstride : xstride, user, s.nord_ptr[i], positions, pbytes && !positions); if (rc) return rc;
         if (g->timing && i == 0) HIP_TRY(hipEventRecord(g->e_t[3], user));
     }
     if (G > 1) {
@@ -577,6 +580,7 @@ void srn_shard_group_free(srn_shard_group_t* g) {
     if (g->s_x) hipStreamDestroy(g->s_x);
     if (g->e_in) hipEventDestroy(g->e_in); if (g->e_x) hipEventDestroy(g->e_x); if (g->e_last) hipEventDestroy(g->e_last);
     for (auto& e : g->e_t) if (e) hipEventDestroy(e);
+    if (g->pres_all) hipFree(g->pres_all); if (g->nb_pbytes) hipFree(g->nb_pbytes);
     delete g;
 }
 
@@ -618,6 +622,29 @@ int srn_shard_group_set_postings(srn_shard_group_t* g, const srn_index_t* postin
     g->postings = postings; g->postings_max_row_len = postings ? postings->flat.max_row_len : 0;
     // this rank's shards keep their fragments a second time, in the posting order of these lists, where there is room (the streaming form of the back end; rank-local and
     // optional: both forms give the same rows)
+    // The neighbours' presence bytes (round 5): every shard's presence bitmap all-gathered ONCE (a collective: set_postings is called by every rank, like a batch), then a
+    // byte per session.  Up to 8 shards; every local shard must have its bitmap (the wave-per-query back end's rows: from SRN_SBACK_MIN_SHARDS shards on).
+    if (g->nb_pbytes) { HIP_TRY(hipSetDevice(g->device)); HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(g->nb_pbytes)); g->nb_pbytes = nullptr; }
+    if (postings && G_of(g) >= 2 && G_of(g) <= 8 && device_shard_nb_presence_wanted()) {
+        bool have = !g->shards.empty(); size_t words = 0;
+        for (const srn_index* sh : g->shards) { size_t w = 0; have = have && device_sback_present(sh->dev, &w) != nullptr; words = std::max(words, w); }
+        if (have) {
+            HIP_TRY(hipSetDevice(g->device));
+            const uint64_t n = postings->flat.n_kept + 1;
+            const size_t block_words = (std::max<size_t>(words, (size_t)((n + 31) / 32)) + 63) / 64 * 64;
+            int rc = ensure(&g->pres_all, &g->pres_all_bytes, (size_t)G_of(g) * block_words * 4); if (rc) return rc;
+            HIP_TRY(hipMemsetAsync(g->pres_all, 0, (size_t)G_of(g) * block_words * 4, nullptr));
+            for (size_t i = 0; i < g->shards.size(); ++i) {
+                const uint32_t gi = g->kind == srn_shard_group::LOCAL ? (uint32_t)i : (uint32_t)g->rank;
+                size_t w = 0; const uint32_t* pr = device_sback_present(g->shards[i]->dev, &w);
+                HIP_TRY(hipMemcpyAsync(g->pres_all + (size_t)gi * block_words * 4, pr, w * 4, hipMemcpyDeviceToDevice, nullptr));
+            }
+            rc = all_gather_blocks(g, 0, g->pres_all, block_words * 4, nullptr); if (rc) return rc;
+            HIP_TRY(hipMalloc((void**)&g->nb_pbytes, (size_t)n + 64));
+            HIP_TRY(launch_presence_bytes(nullptr, (const uint32_t*)g->pres_all, block_words, G_of(g), n, g->nb_pbytes));
+            HIP_TRY(hipDeviceSynchronize());
+        }
+    }
     bool all = !g->shards.empty(), any_geometry = false;
     for (const srn_index* sh : g->shards) {
         int rc = device_sback_attach_postings(sh->dev, postings ? postings->dev : nullptr, postings ? postings->flat.nnz_post : 0); if (rc) return rc;

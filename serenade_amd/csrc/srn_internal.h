@@ -125,7 +125,8 @@ struct ExtLists { const char* prep; uint32_t prep_stride; const uint32_t* post_r
                   // the shard group's neighbours pipeline: mode 1 = front end only (neighbour lists of the queries [q_lo, nq) -> xchg), 2 = back end (neighbour lists <- xchg)
                   int mode = 0; uint32_t* xchg = nullptr; uint32_t xchg_stride = 0; uint32_t q_lo = 0;
                   const unsigned long long* order = nullptr;     // mode 2: the batch's serving order (device_shard_nb_prep sorted it), or null
-                  bool positions = false; };                     // mode 2: xchg holds position records (device_shard_nb_positions), not neighbour slots: the streaming back end
+                  bool positions = false;                        // mode 2: xchg holds position records (device_shard_nb_positions), not neighbour slots: the streaming back end
+                  bool pbytes = false; };                        // mode 2: a presence byte per neighbour behind the slots (device_shard_nb_presence): the wave-per-query back end asks only for fragments that exist
 int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p, bool buffers_on_device, void* stream,
                    // host-pointer mode: these are host buffers copied in/out by the call
                    const uint64_t* h_items, const uint32_t* h_qoff, uint64_t* h_ids, double* h_scores,
@@ -153,10 +154,14 @@ int device_shard_nb_prep(DeviceState* d, DeviceState* post, const LaunchParams& 
                          const unsigned long long** order_out = nullptr);   // order_buf (grow-only, the caller's): the batch's serving order is sorted into it, *order_out = where (null: batch too small)
 int device_shard_nb_front(DeviceState* d, const FlatIndex& ix, DeviceState* post, const LaunchParams& p, const char* records, uint32_t* xchg, uint32_t xchg_stride, uint32_t q_lo, uint32_t q_hi, void* stream);
 int device_shard_nb_back(DeviceState* d, const FlatIndex& ix, DeviceState* post, const LaunchParams& p, const char* records, uint32_t* xchg, uint32_t xchg_stride, void* stream,
-                         const unsigned long long* order = nullptr, bool positions = false);
+                         const unsigned long long* order = nullptr, bool positions = false, bool pbytes = false);
 int device_shard_nb_positions(DeviceState* d, const FlatIndex& ix, DeviceState* post, const LaunchParams& p, const char* records, const uint32_t* xin, uint32_t in_stride, uint32_t* xout, uint32_t out_stride,
                               uint32_t q_lo, uint32_t q_hi, void* stream);
-uint32_t device_shard_nb_positions_stride(const LaunchParams& p);   // 0: no streaming form for this batch shape / these knobs (rank-invariant)
+uint32_t device_shard_nb_positions_stride(const LaunchParams& p);
+// the neighbours' presence bytes (srn_sback.hip): a shard's presence bitmap (device words, or null), and the fronting rank's pass that writes the bytes behind the slots of [q_lo, q_hi)
+const uint32_t* device_sback_present(const DeviceState* d, size_t* words);
+int device_shard_nb_presence(DeviceState* d, const FlatIndex& ix, const LaunchParams& p, const char* records, uint32_t* xchg, uint32_t stride, const uint8_t* pbytes, uint32_t q_lo, uint32_t q_hi, void* stream);
+bool device_shard_nb_presence_wanted();   // (knob; rank-invariant)   // 0: no streaming form for this batch shape / these knobs (rank-invariant)
 uint32_t device_prep_stride(uint32_t max_len);
 int device_shard_lists_head(DeviceState* d, const LaunchParams& p, void* pos, int* head, void* stream);
 int device_shard_lists_count(DeviceState* d, const LaunchParams& p, const void* pos, const int* head, uint32_t* kept, int* tot, void* stream);

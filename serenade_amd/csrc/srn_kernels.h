@@ -122,12 +122,16 @@ struct SBackParams {
     // the streaming form (all three set, or the gather form runs): the fragments in POSTING order of the replicated lists the batch's records were written against
     const uint2* frag_post;    // [number of postings] frag_post[e] = frag8[post_rank[e]]
     const uint32_t* post_rank; // the replicated posting lists (recency ranks)
+    uint32_t pbyte_shift;      // < 8: the exchange records carry a presence byte per neighbour behind the slots (at word 1 + k), this shard's bit is pbyte_shift; 8: they do not
     uint32_t finish_here;      // the serving wave finishes rows of <= 63 entries itself (score, ranking, public ids) instead of leaving a record for vmis_finish_kernel
     uint32_t* scr;             // shard_back_scratch_words() words per wave of the grid: the members' slots and fragments between walk A and walk B
 };
 hipError_t launch_rows_to_frag8(hipStream_t st, const uint64_t* row_off, const uint32_t* row_items, uint64_t n_rows, const uint32_t* block_base, uint2* frag8, uint4* ext8, uint32_t* present);   // block_base in 16-byte blocks
 hipError_t launch_frag_post(hipStream_t st, const uint32_t* post_rank, const uint2* frag8, uint2* out, uint64_t n);
 uint32_t shard_back_scratch_words();
+hipError_t launch_presence_bytes(hipStream_t st, const uint32_t* bitmaps, size_t block_words, uint32_t G, uint64_t n, uint8_t* out);   // bit g of out[r] = bit r of bitmap g
+hipError_t launch_shard_nb_presence(dim3 grid, hipStream_t st, const char* prep, uint32_t prep_stride, uint32_t max_len, uint32_t* xchg, uint32_t stride, uint32_t k, const uint8_t* pbytes, uint32_t n_kept,
+                                    uint32_t q_lo, uint32_t q_hi, bool wide);
 hipError_t launch_shard_nb_positions(dim3 grid, hipStream_t st, const char* prep, uint32_t prep_stride, uint32_t max_len, const uint32_t* xin, uint32_t in_stride, uint32_t* xout, uint32_t out_stride,
                                      const uint32_t* post_rank, uint32_t q_lo, uint32_t q_hi, uint32_t m, bool wide);
 uint32_t shard_nb_positions_stride(uint32_t k, uint32_t m);   // words per query of the streaming form's exchange record; 0: this (k, m) has none

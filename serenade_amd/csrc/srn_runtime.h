@@ -45,6 +45,7 @@ struct Knobs {
     int order_min = 131072;    // SRN_ORDER_MIN: batches of at least this many queries are served in the order of their most popular item, an eighth of the order per XCD (0 = never); the ordering
                               // pass is one radix sort of the batch's keys behind the prep kernel
     bool no_sback_finish = true;    // SRN_SBACK_FINISH=1 (experiment): the wave-per-query back end finishes rows of <= 63 entries itself instead of leaving a record for vmis_finish_kernel.  Measured: the finish kernels' share falls 0.167 -> 0.122 ms per 131 072 queries, the kernel grows 1.606 -> 1.685 (two more dependent gathers per query on a kernel bound by its requests): off
+    bool no_sback_pbytes = true;    // SRN_SBACK_PBYTES=1 (experiment): presence bytes in the neighbours pipeline's exchange records -- the fronting rank marks, per neighbour, which shards hold a fragment of it (the shards' bitmaps all-gathered at set_postings); a back end asks only for fragments that exist: half the requests at G = 8, no look-up of its own.  Measured: kernel 1.61 -> 1.95 ms, front 0.30 -> 0.37: it loses, like the bitmap -- the kernel's time does not follow its fragment requests (profiles/r05_sback_stream_ab.txt)
     bool no_sback_second = false;   // SRN_NO_SBACK_SECOND (experiments): what the wave-per-query back end cannot hold goes straight to the general kernel (no fast-kernel back end over the list)
     bool no_sback = false;    // SRN_NO_SBACK: the shard group's back end through vmis_fast_kernel's FM_BACK instantiation (rounds 4) instead of the wave-per-query kernel of srn_sback.hip
     bool sback_bitmap = false;     // SRN_SBACK_BITMAP=1 (experiments): that kernel asks its presence bitmap before it fetches a fragment.  Measured on config 3 cut in 8: half the fragment
@@ -105,6 +106,7 @@ struct DeviceState {
     FastParams fast{};            // packed row slots + idf bounds of the fast kernel (row_packed == nullptr: no fast path for this index)
     std::atomic<uint64_t> sback_launches{0};
     void* sb_frag_post = nullptr; const uint32_t* sb_post_for = nullptr; uint64_t sb_frag_post_bytes = 0;   // the fragments in the posting order of the replicated lists at sb_post_for (device_sback_attach_postings)
+    size_t sback_present_words = 0;
     SBackParams sback{};          // item shards: frag8 rows + presence bitmap of the wave-per-query back end (frag8 == nullptr: the FM_BACK form of the fast kernel serves)
     uint32_t host_max_row_len = 0;
     int n_cu = 256;

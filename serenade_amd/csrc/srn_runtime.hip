@@ -43,6 +43,7 @@ static void knobs_read() {
     if (const char* e = getenv("SRN_PREDICT_LANES")) k.lanes = std::max(0, atoi(e));
     if (const char* e = getenv("SRN_ORDER_MIN")) k.order_min = std::max(0, atoi(e));
     k.no_sback_second = getenv("SRN_NO_SBACK_SECOND") != nullptr;
+    k.no_sback_pbytes = !(getenv("SRN_SBACK_PBYTES") != nullptr && atoi(getenv("SRN_SBACK_PBYTES")) != 0);
     k.no_sback_finish = !(getenv("SRN_SBACK_FINISH") != nullptr && atoi(getenv("SRN_SBACK_FINISH")) != 0);
     k.no_sback = getenv("SRN_NO_SBACK") != nullptr; k.sback_bitmap = getenv("SRN_SBACK_BITMAP") != nullptr && atoi(getenv("SRN_SBACK_BITMAP")) != 0;
     k.no_sback_stream = !(getenv("SRN_SBACK_STREAM") != nullptr && atoi(getenv("SRN_SBACK_STREAM")) != 0);
@@ -150,7 +151,7 @@ DeviceState* device_attach(const FlatIndex& ix, int device) {
                             hipDeviceSynchronize() == hipSuccess;
             if (g3) { for (void* q : {d_f8, d_e8, d_pr, d_sm}) d->allocs.push_back(q);
                       d->bytes += (n + 1) * 8 + (blocks + 2) * 16 + pwords * 4 + 256 * sizeof(ItemMeta);
-                      d->sback.frag8 = (const uint2*)d_f8; d->sback.ext8 = (const uint4*)d_e8; d->sback.present = (const uint32_t*)d_pr; d->sback.sample = (const ItemMeta*)d_sm; }
+                      d->sback.frag8 = (const uint2*)d_f8; d->sback.ext8 = (const uint4*)d_e8; d->sback.present = (const uint32_t*)d_pr; d->sback.sample = (const ItemMeta*)d_sm; d->sback_present_words = pwords; }
             else { (void)hipGetLastError(); for (void* q : {d_f8, d_e8, d_pr, d_sm}) if (q) hipFree(q); d->sback = SBackParams{}; }
         }
         if (d_off) hipFree(d_off); if (d_items) hipFree(d_items); if (d_base) hipFree(d_base);
@@ -792,6 +793,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
             // the item shard's own back end (srn_sback.hip): one wave per query, 12 per CU; a persistent grid of a few waves per resident slot
             SBackParams sbp = d->sback; if (!kn.sback_bitmap) sbp.present = nullptr;
             sbp.finish_here = kn.no_sback_finish ? 0u : 1u;
+            sbp.pbyte_shift = ext->pbytes ? (uint32_t)ix.shard : 8u;
             // the streaming form where the shard holds its fragments in the posting order of the very lists the records were written against (9 waves per CU: 16.8 KB each)
             const bool stream = ext->positions;
             if (stream && !(d->sb_frag_post && d->sb_post_for == ext->post_rank)) return fail(SRN_ESTATE, "the batch's neighbours came as posting positions, but this shard does not hold its fragments in posting order");
@@ -991,9 +993,22 @@ uint32_t device_shard_nb_positions_stride(const LaunchParams& p) {
     if (kn.no_sback_stream || kn.no_sback || p.max_len > 8) return 0u;
     return shard_nb_positions_stride(p.k, p.m);
 }
-int device_shard_nb_back(DeviceState* d, const FlatIndex& ix, DeviceState* post, const LaunchParams& p, const char* records, uint32_t* xchg, uint32_t xchg_stride, void* stream, const unsigned long long* order, bool positions) {
+const uint32_t* device_sback_present(const DeviceState* d, size_t* words) {
+    if (!d || !d->sback.present) return nullptr;
+    if (words) *words = d->sback_present_words;
+    return d->sback.present;
+}
+bool device_shard_nb_presence_wanted() { const Knobs kn = knobs(); return !kn.no_sback_pbytes && !kn.no_sback; }
+int device_shard_nb_presence(DeviceState* d, const FlatIndex& ix, const LaunchParams& p, const char* records, uint32_t* xchg, uint32_t stride, const uint8_t* pbytes, uint32_t q_lo, uint32_t q_hi, void* stream) {
+    if (q_lo >= q_hi) return SRN_OK;
+    HIP_TRY(hipSetDevice(d->device));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(q_hi - q_lo, (uint64_t)d->n_cu * 32 * 4);
+    HIP_TRY(launch_shard_nb_presence(dim3(grid), (hipStream_t)stream, records, device_prep_stride(p.max_len), p.max_len, xchg, stride, p.k, pbytes, (uint32_t)ix.n_kept, q_lo, q_hi, fast_nb(ix, knobs()) == 3u));
+    return SRN_OK;
+}
+int device_shard_nb_back(DeviceState* d, const FlatIndex& ix, DeviceState* post, const LaunchParams& p, const char* records, uint32_t* xchg, uint32_t xchg_stride, void* stream, const unsigned long long* order, bool positions, bool pbytes) {
     if (p.nq == 0) return SRN_OK;
-    ExtLists ext{records, device_prep_stride(p.max_len), post->di.post_rank, 2, xchg, xchg_stride, 0u, order, positions};
+    ExtLists ext{records, device_prep_stride(p.max_len), post->di.post_rank, 2, xchg, xchg_stride, 0u, order, positions, pbytes};
     return device_predict(d, ix, p, true, stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &ext);
 }
 

@@ -309,7 +309,9 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                 if (c * 64u < K) {   // (wave-uniform)
                     const bool act = c * 64u + lane < K;
                     const uint32_t r = act ? base + (sv[c] >> NB) : n_kept;   // (idle lanes: the empty row, whose presence bit is 0)
-                    if constexpr (BITMAP) pwv[c] = sb.present[r >> 5] >> (r & 31u); else pwv[c] = act ? 1u : 0u;   // (no bitmap: every neighbour's fragment is fetched; the empty ones are told apart below)
+                    if constexpr (BITMAP) pwv[c] = sb.present[r >> 5] >> (r & 31u);
+                    else if (sb.pbyte_shift < 8u) pwv[c] = act ? (uint32_t)reinterpret_cast<const uint8_t*>(xq + 1u + p.k)[c * 64u + lane] >> sb.pbyte_shift : 0u;   // (the fronting rank said which neighbours have a fragment here: arrived with the slots)
+                    else pwv[c] = act ? 1u : 0u;   // (no bitmap: every neighbour's fragment is fetched; the empty ones are told apart below)
                 }
             }
 #pragma unroll
@@ -695,6 +697,47 @@ uint32_t shard_nb_positions_stride(uint32_t k, uint32_t m) {
     const uint32_t mw = (m + 63u) >> 6, ncw = (std::min<uint32_t>(k, F_K_MAX) + 7u) >> 3;
     if (32u * mw + 8u * ncw > SB_REC_ROOM) return 0u;   // (in LDS: the bitmaps + a weight byte per member)
     return (2u + 8u * mw + ncw + 1u) / 2u * 2u;
+}
+
+// -------------------------------------------------------------------------------------
+// The neighbours' PRESENCE BYTES (round 5, second half): bit g of session r's byte = shard g holds an item of r.  Built once per group from the shards' presence bitmaps
+// (all-gathered); the rank that fronts a query writes every neighbour's byte behind the neighbour slots of its exchange record, and a back end of shard g asks only for the
+// fragments whose bit g is set -- half the requests at G = 8, and no look-up of its own in front of them (what the per-shard bitmap of SRN_SBACK_BITMAP cost).
+// -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void presence_bytes_kernel(const uint32_t* __restrict__ bitmaps, size_t block_words, uint32_t G, uint64_t n, uint8_t* __restrict__ out) {
+    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (uint64_t)gridDim.x * 256) {
+        uint32_t b = 0;
+        for (uint32_t g = 0; g < G; ++g) b |= ((bitmaps[(size_t)g * block_words + (r >> 5)] >> (r & 31u)) & 1u) << g;
+        out[r] = (uint8_t)b;
+    }
+}
+hipError_t launch_presence_bytes(hipStream_t st, const uint32_t* bitmaps, size_t block_words, uint32_t G, uint64_t n, uint8_t* out) {
+    if (n) hipLaunchKernelGGL(presence_bytes_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 16)), dim3(256), 0, st, bitmaps, block_words, G, n, out);
+    return hipGetLastError();
+}
+__global__ __launch_bounds__(64) void shard_nb_presence_kernel(const char* __restrict__ prep, uint32_t prep_stride, uint32_t max_len, uint32_t* __restrict__ xchg, uint32_t stride, uint32_t k,
+                                                               const uint8_t* __restrict__ pbytes, uint32_t n_kept, uint32_t q_lo, uint32_t q_hi, uint32_t wide) {
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t q = q_lo + blockIdx.x; q < q_hi; q += gridDim.x) {
+        const char* const rec = prep + (size_t)q * prep_stride;
+        const PrepHead* hp = (const PrepHead*)rec;
+        const uint32_t xlo = hp->xlo, L = hp->L;
+        uint32_t it_kept = 0u;
+        if (lane < 8u && lane < L && lane < max_len) it_kept = ((const PrepItem*)(rec + sizeof(PrepHead)))[lane].kept;
+        uint32_t* const xq = xchg + (size_t)q * stride;
+        const uint32_t K = (uint32_t)__builtin_amdgcn_readfirstlane((int)xq[0]);
+        if (K == 0u || K == 0xFFFFFFFFu || K > k) continue;   // (wave-uniform: nothing to mark)
+        const uint32_t nr = (uint32_t)__popcll(__ballot(it_kept > 0u));
+        const bool rel = wide && nr > 3u;
+        const uint32_t NB = wide && !rel ? 3u : 4u, base = rel ? xlo : 0u;
+        uint8_t* const pb = reinterpret_cast<uint8_t*>(xq + 1u + k);
+        for (uint32_t i = lane; i < K; i += 64u) pb[i] = pbytes[min(base + (xq[1u + i] >> NB), n_kept)];
+    }
+}
+hipError_t launch_shard_nb_presence(dim3 grid, hipStream_t st, const char* prep, uint32_t prep_stride, uint32_t max_len, uint32_t* xchg, uint32_t stride, uint32_t k, const uint8_t* pbytes, uint32_t n_kept,
+                                    uint32_t q_lo, uint32_t q_hi, bool wide) {
+    if (q_hi > q_lo) hipLaunchKernelGGL(shard_nb_presence_kernel, grid, dim3(64), 0, st, prep, prep_stride, max_len, xchg, stride, k, pbytes, n_kept, q_lo, q_hi, wide ? 1u : 0u);
+    return hipGetLastError();
 }
 
 // frag_post[e] = frag8[post_rank[e]]: the fragments once more, in posting order (streaming form)

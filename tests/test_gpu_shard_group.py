@@ -556,7 +556,7 @@ def test_group_wait_and_the_default_overlap():
 
 # ---- the item shard's own back end (round 5, srn_sback.hip): one wave per query, frag8 rows + presence bitmap -------------------------------------------------------
 
-@pytest.mark.parametrize("n_shards,knob", [(2, ""), (3, ""), (8, ""), (8, "SRN_SBACK_BITMAP"), (8, "SRN_ORDER_MIN"), (5, "SRN_NO_SBACK"), (8, "SRN_SBACK_STREAM"), (2, "SRN_SBACK_STREAM"), (8, "SRN_SBACK_FINISH")])
+@pytest.mark.parametrize("n_shards,knob", [(2, ""), (3, ""), (8, ""), (8, "SRN_SBACK_BITMAP"), (8, "SRN_ORDER_MIN"), (5, "SRN_NO_SBACK"), (8, "SRN_SBACK_STREAM"), (2, "SRN_SBACK_STREAM"), (8, "SRN_SBACK_FINISH"), (8, "SRN_SBACK_PBYTES"), (3, "SRN_SBACK_PBYTES")])
 def test_wave_per_query_back_end_against_the_oracle(n_shards, knob):
     """The neighbours pipeline's back end as a kernel of its own -- vmis_shard_back_kernel: a wave per query over 8-byte fragment slots, the presence bitmap asked first --
     against the canonical oracle and bit-identical to the unsharded path: rows of up to 80 items (at 2 and 3 shards most fragments of the long rows have > 4 items: the
@@ -599,6 +599,8 @@ def test_wave_per_query_back_end_against_the_oracle(n_shards, knob):
         full_bytes = sum(n_shards * ((nq + n_shards - 1) // n_shards) * (k + 1) * 4 for k in (100, 1500, 40, 700))   # neighbour slots: (k + 1) words per query
         if knob == "SRN_SBACK_STREAM":
             assert 0 < grp.stats["bytes_neighbours"] < full_bytes, (grp.stats["bytes_neighbours"], full_bytes)           # position records (the m = 500 / 80 / 300 of these batches: 8 words of bitmap per list)
+        elif knob == "SRN_SBACK_PBYTES":                                                                                     # a presence byte per neighbour behind the slots
+            assert grp.stats["bytes_neighbours"] == sum(n_shards * ((nq + n_shards - 1) // n_shards) * (k + 1 + (k + 3) // 4) * 4 for k in (100, 1500, 40, 700))
         else:
             assert grp.stats["bytes_neighbours"] == full_bytes
         launches = C.c_uint64()
