@@ -116,10 +116,21 @@ hipError_t launch_rows_to_frag8(hipStream_t st, const uint64_t* row_off, const u
 #define SB_NT_LOAD(p) (*(p))
 #define SB_NT_STORE(v, p) (*(p) = (v))
 #endif
+// A workgroup of this kernel is ONE wave: its LDS operations execute in the order they were issued, so what __syncthreads() has to offer here is only that the COMPILER keeps
+// that order -- while its fence (s_waitcnt vmcnt(0) lgkmcnt(0) in front of the s_barrier) makes the wave sit out every load and store it still has in flight, ten times per
+// query.  SB_SYNC() with SRN_SBACK_FENCES=0 is the compiler-only form (experiment).
+#ifndef SRN_SBACK_FENCES
+#define SRN_SBACK_FENCES 1   // (measured: 1.652 ms with the compiler-only form against 1.656 -- nothing; the plain barriers stay)
+#endif
+#if SRN_SBACK_FENCES
+#define SB_SYNC() __syncthreads()
+#else
+#define SB_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#endif
 #ifndef SRN_SBACK_WAVES
 #define SRN_SBACK_WAVES 3   // waves per SIMD the register allocation is sized for (12 per CU: the LDS allows 13)
 #endif
-template <bool BITMAP, bool STREAM>
+template <bool BITMAP, bool STREAM, bool PBYTES = false>
 __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(DeviceIndex ix_arg, LaunchParams p_arg, FastParams f_arg, SBackParams sb_arg) {
     constexpr uint32_t HOT_OFF = SB_HOT;
     __shared__ __attribute__((aligned(16))) char smem[SB_LDS];
@@ -209,7 +220,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
             uint4* z = reinterpret_cast<uint4*>(smem + HOT_OFF);
             for (uint32_t i = lane; i < (SB_H + SB_S + SB_DUMP) / 4u; i += 64u) z[i] = make_uint4(0u, 0u, 0u, 0u);
         }
-        __syncthreads();   // (one wave: orders the LDS traffic; no other wave to wait for)
+        SB_SYNC();   // (one wave: orders the LDS traffic; no other wave to wait for)
         SB_TICK(tk8);
         // ---- walk A: ALL of a lane's <= 24 presence words in flight together, then all fragments of the present ones: a query's walk is three HBM / L2 round trips (slots,
         // presence, fragments) whatever K is.  A first build walked in two halves with the long fragments' overflow blocks fetched inline: 30 dependent round trips per query on
@@ -245,7 +256,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                     reinterpret_cast<uint2*>(lw8)[i] = make_uint2(lo, hi);
                 }
             }
-            __syncthreads();
+            SB_SYNC();
             const uint32_t dump1 = (SB_H + SB_S + lane) * 4u, dump2 = dump1 | (dump1 << 16);
             uint32_t nmem = 0u;   // (wave-uniform) members met so far = index of the next weight
             for (uint32_t r = 0; r < nr; ++r) {   // (wave-uniform)
@@ -310,7 +321,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                     const bool act = c * 64u + lane < K;
                     const uint32_t r = act ? base + (sv[c] >> NB) : n_kept;   // (idle lanes: the empty row, whose presence bit is 0)
                     if constexpr (BITMAP) pwv[c] = sb.present[r >> 5] >> (r & 31u);
-                    else if (sb.pbyte_shift < 8u) pwv[c] = act ? (uint32_t)reinterpret_cast<const uint8_t*>(xq + 1u + p.k)[c * 64u + lane] >> sb.pbyte_shift : 0u;   // (the fronting rank said which neighbours have a fragment here: arrived with the slots)
+                    else if constexpr (PBYTES) pwv[c] = act ? (uint32_t)reinterpret_cast<const uint8_t*>(xq + 1u + p.k)[c * 64u + lane] >> sb.pbyte_shift : 0u;   // (the fronting rank said which neighbours have a fragment here: arrived with the slots)
                     else pwv[c] = act ? 1u : 0u;   // (no bitmap: every neighbour's fragment is fetched; the empty ones are told apart below)
                 }
             }
@@ -345,7 +356,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
         bool fail = st_fail || nlq > SB_LQ_CAP;   // (wave-uniform)
         if (fail) c15 += 1ull << 20;
         if (nlq && !fail) {
-            __syncthreads();
+            SB_SYNC();
             for (uint32_t i0 = 0; i0 < nlq; i0 += 64u) {
                 const bool act = i0 + lane < nlq;
                 const uint2 e = lq[min(i0 + lane, nlq - 1u)];
@@ -358,7 +369,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                     if (t8 < len) { const uint4 e4 = eb[t8 >> 3]; add2(e4.x, w); add2(e4.y, w); add2(e4.z, w); add2(e4.w, w); }
             }
         }
-        __syncthreads();
+        SB_SYNC();
         {   // the exact table (keys EMPTY32, sums 0) and the counters
             reinterpret_cast<uint4*>(ikeys)[lane] = make_uint4(EMPTY32, EMPTY32, EMPTY32, EMPTY32);
             reinterpret_cast<uint4*>(iacc)[lane] = make_uint4(0u, 0u, 0u, 0u);
@@ -448,7 +459,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
             c7 += 1ull;
             // ---- walk B: the rows again (from the registers); an element is LISTED if its sketch word can still reach the floor (all elements of an item share the word, so an item
             // is accumulated completely or not at all); then the list is resolved -- item id from the general fragment slots -- into the exact table ----
-            __syncthreads();   // (the direct-mapped words are dead: the hit list takes them)
+            SB_SYNC();   // (the direct-mapped words are dead: the hit list takes them)
             uint32_t nh = 0;   // (wave-uniform)
             auto chk = [&](uint32_t o) -> bool { return o >= SB_H * 4u && *(const uint32_t*)(acc_base + o) >= floor_b; };
             auto list = [&](uint32_t hm, uint32_t s, uint32_t j0) {   // hm: bit i = position j0 + i of the fragment is a hit
@@ -478,7 +489,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
             }
             if (nlb > SB_LQB_CAP) { fail = true; c15 += 1ull << 20; }
             else if (nlb) {
-                __syncthreads();
+                SB_SYNC();
                 for (uint32_t i0 = 0; i0 < nlb; i0 += 64u) {
                     const bool act = i0 + lane < nlb;
                     const uint2 e = lqb[min(i0 + lane, nlb - 1u)];
@@ -492,7 +503,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                     }
                 }
             }
-            __syncthreads();
+            SB_SYNC();
             c5 += nh;
             if (nh > SB_HIT_CAP) { fail = true; c15 += 1ull << 40; }
             else {
@@ -514,12 +525,12 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                 }
                 if (__ballot(ovf) != 0ull) { fail = true; c7 += 1ull << 32; }
             }
-            __syncthreads();
+            SB_SYNC();
             if (!fail) {   // the table's contenders (exact sum at the floor; the others were collisions in their sketch word), compacted behind the candidates' room: into the hit list's words
                 uint4 kq = make_uint4(EMPTY32, EMPTY32, EMPTY32, EMPTY32), aq = make_uint4(0u, 0u, 0u, 0u);
                 if (lane < SB_BUCKETS) { kq = reinterpret_cast<const uint4*>(ikeys)[lane]; aq = reinterpret_cast<const uint4*>(iacc)[lane]; }
                 const uint32_t kk[4] = {kq.x, kq.y, kq.z, kq.w}, aa[4] = {aq.x, aq.y, aq.z, aq.w};
-                __syncthreads();
+                SB_SYNC();
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) {
                     const bool in = kk[s4] != EMPTY32 && kk[s4] != cur_idx && aa[s4] >= floor_b;
@@ -527,7 +538,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                     if (in) hits[nt + (uint32_t)__popcll(bm & lt)] = make_uint2(kk[s4], aa[s4]);
                     nt += (uint32_t)__popcll(bm);
                 }
-                __syncthreads();
+                SB_SYNC();
             }
         }
         SB_TICK(tk12);
@@ -542,7 +553,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
             if (lane < ncand) { const unsigned long long x = ckey[lane]; e = make_uint4((uint32_t)x, (uint32_t)(x >> 32), cidx[lane], 0u); }
             else if (lane < M) { const uint2 c = hits[lane - ncand]; e = make_uint4(c.y, 0u, c.x, 1u); }
             finish_inline(ix_arg, M, U, e, lane, q, p.out_ids, p.out_scores, p.out_counts, p.how_many);
-            __syncthreads();   // (the next query clears what this one still read)
+            SB_SYNC();   // (the next query clears what this one still read)
             c6 += ncand; c14 += 1ull;
             SB_TICK(tk13);
             continue;
@@ -570,7 +581,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                 if (i < F_FIN_ENTRIES) { typedef uint32_t v4u __attribute__((ext_vector_type(4))); SB_NT_STORE((v4u{e.x, e.y, e.z, e.w}), reinterpret_cast<v4u*>(&out[1 + i])); } else ovf[i - F_FIN_ENTRIES] = e;
             }
         }
-        __syncthreads();   // (the next query clears what this one still read)
+        SB_SYNC();   // (the next query clears what this one still read)
         c6 += ncand; c14 += 1ull;
         SB_TICK(tk13);
     }
@@ -587,6 +598,7 @@ hipError_t launch_shard_back(dim3 grid, hipStream_t st, const DeviceIndex& di, c
         fprintf(stderr, "[srn] vmis_shard_back_kernel: %u bytes of LDS per wave; gather form %d waves per CU, streaming form %d (occupancy API)\n", SB_LDS, nb, ns); }
     if (sb.frag_post && sb.post_rank && sb.scr) hipLaunchKernelGGL((vmis_shard_back_kernel<false, true>), grid, dim3(64), 0, st, di, p, f, sb);
     else if (sb.present) hipLaunchKernelGGL((vmis_shard_back_kernel<true, false>), grid, dim3(64), 0, st, di, p, f, sb);
+    else if (sb.pbyte_shift < 8u) hipLaunchKernelGGL((vmis_shard_back_kernel<false, false, true>), grid, dim3(64), 0, st, di, p, f, sb);
     else hipLaunchKernelGGL((vmis_shard_back_kernel<false, false>), grid, dim3(64), 0, st, di, p, f, sb);
     return hipGetLastError();
 }
