@@ -41,8 +41,11 @@ while time.time() < t_end and rounds < max_rounds:
              {"SRN_NO_LONG": "1"}, {"SRN_ORDER_MIN": "1"}, {"SRN_ORDER_MIN": "1", "SRN_SBACK_MIN_SHARDS": "2"}, {"SRN_SBACK_MIN_SHARDS": "2"}, {"SRN_SBACK_MIN_SHARDS": "2", "SRN_SBACK_BITMAP": "1"}, {"SRN_NO_SBACK": "1"}, {"SRN_ORDER_MIN": "1"},
              # ... its streaming form (neighbours exchanged as posting positions), its second tier (the fast kernel's back-end form over a list) switched off
              {"SRN_SBACK_MIN_SHARDS": "2", "SRN_SBACK_STREAM": "1"}, {"SRN_SBACK_MIN_SHARDS": "2", "SRN_SBACK_STREAM": "1", "SRN_ORDER_MIN": "1"}, {"SRN_SBACK_MIN_SHARDS": "2", "SRN_NO_SBACK_SECOND": "1"},
-             {"SRN_SBACK_MIN_SHARDS": "2"}, {"SRN_SBACK_MIN_SHARDS": "2", "SRN_ORDER_MIN": "1"}]
-    for kk in ("SRN_NO_FAST", "SRN_NO_MID", "SRN_NO_BIG", "SRN_NO_MERGE", "SRN_NO_MASKS", "SRN_HOT_SLOTS", "SRN_SKETCH_SLOTS", "SRN_FAST_RUNS", "SRN_DENSE", "SRN_TINY_MAX", "SRN_HOST_CHUNKS", "SRN_NO_LONG", "SRN_ORDER_MIN", "SRN_SBACK_MIN_SHARDS", "SRN_SBACK_BITMAP", "SRN_NO_SBACK", "SRN_SBACK_STREAM", "SRN_NO_SBACK_SECOND"):
+             {"SRN_SBACK_MIN_SHARDS": "2"}, {"SRN_SBACK_MIN_SHARDS": "2", "SRN_ORDER_MIN": "1"},
+             # ... presence bytes shipped by the fronting rank, rows finished by the serving wave; the latency path's older forms
+             {"SRN_SBACK_MIN_SHARDS": "2", "SRN_SBACK_PBYTES": "1"}, {"SRN_SBACK_MIN_SHARDS": "2", "SRN_SBACK_PBYTES": "1", "SRN_ORDER_MIN": "1"}, {"SRN_SBACK_MIN_SHARDS": "2", "SRN_SBACK_FINISH": "1"},
+             {"SRN_TINY_FUSED": "0"}, {"SRN_TINY_SPIN": "0"}, {"SRN_TINY_FUSED_MAX": "256", "SRN_TINY_FAST": "3"}, {}, {}]
+    for kk in ("SRN_NO_FAST", "SRN_NO_MID", "SRN_NO_BIG", "SRN_NO_MERGE", "SRN_NO_MASKS", "SRN_HOT_SLOTS", "SRN_SKETCH_SLOTS", "SRN_FAST_RUNS", "SRN_DENSE", "SRN_TINY_MAX", "SRN_HOST_CHUNKS", "SRN_NO_LONG", "SRN_ORDER_MIN", "SRN_SBACK_MIN_SHARDS", "SRN_SBACK_BITMAP", "SRN_NO_SBACK", "SRN_SBACK_STREAM", "SRN_NO_SBACK_SECOND", "SRN_SBACK_PBYTES", "SRN_SBACK_FINISH", "SRN_TINY_FUSED", "SRN_TINY_SPIN", "SRN_TINY_FUSED_MAX", "SRN_TINY_FAST"):
         os.environ.pop(kk, None)
     knobs = KNOBS[int(rng.integers(0, len(KNOBS)))]
     os.environ.update(knobs); capi.reload_knobs()
