@@ -82,6 +82,9 @@ typedef struct {
     int32_t device;            /* HIP device ordinal, -1 = host-only */
     int32_t offsets_64bit;     /* row offsets stored as u64 (nnz_rows >= 2^32) */
     double idf_weighting;
+    uint64_t incomplete_items; /* (round 6) items of a PRE-BUILT index (srn_index_new_from_avro) whose posting list is not "the most recent sessions that hold the item" under any
+                                * tie order the loader could infer: queries such an item can affect are served by the general kernel's row pass (lists as given,
+                                * vmis_index.rs:201-228), everything else by the fast kernels.  0 for every index built by this library */
 } srn_index_info_t;
 
 typedef struct {
@@ -145,6 +148,11 @@ int srn_index_postings(const srn_index_t* idx, uint64_t item_id, uint32_t* out_s
  *                                        the GPU, canonical semantics as everywhere */
 int srn_index_items_for_session(const srn_index_t* idx, uint32_t session, uint64_t* out_items, size_t cap, size_t* out_len);
 int srn_index_find_attributes(const srn_index_t* idx, uint64_t item_id, uint8_t* out_flags);
+/* The recency order this index serves with -- the total order behind "most recent" in find_neighbors (session_to_max_time_stamp, vmis_index.rs:33, 358-383, 404-410):
+ * out_rank[s] = the recency rank of reference session s (0 = oldest; ascending max timestamp; sessions of EQUAL timestamp, which the reference leaves to its containers,
+ * by SessionIndex -- or, for a pre-built Avro index, in the order its producer's list cuts imply), 0xFFFFFFFF for a session that is in no posting list and keeps no row.
+ * Room for srn_index_info().n_sessions_total entries.  What a checker needs to state the canonical answer for an index with tied timestamps. */
+int srn_index_session_recency(const srn_index_t* idx, uint32_t* out_rank, size_t cap);
 int srn_find_neighbors(const srn_index_t* idx, const uint64_t* evolving, size_t len, size_t k, size_t m,
                        uint32_t* out_sessions, double* out_scores, size_t* out_n);
 void srn_index_free(srn_index_t* idx);

@@ -38,6 +38,8 @@ def lib():
     L.orc_index_build.argtypes = [u64p, u64p, u32p, sz, sz, sz, C.c_double, C.c_int]
     L.orc_index_build_restricted.restype = vp
     L.orc_index_build_restricted.argtypes = [u64p, u64p, u32p, sz, sz, sz, C.c_double, u64p, sz, C.c_int, sz]
+    L.orc_index_from_parts.restype = vp
+    L.orc_index_from_parts.argtypes = [u64p, u64p, u32p, f64p, u8p, sz, u64p, u64p, u32p, sz, vp]
     L.orc_index_free.argtypes = [vp]
     L.orc_sessions_read_tsv.restype = vp
     L.orc_sessions_read_tsv.argtypes = [C.c_char_p]
@@ -114,6 +116,24 @@ class OracleIndex:
             return
         self.h = self.L.orc_index_build(self.sess_off, self.items, self.ts, len(self.ts), int(m_index),
                                         int(max_len), float(idf_weighting), int(bool(fast)))
+
+    @classmethod
+    def from_parts(cls, item_ids, lists, idf, flags, sess_off, sess_items, ts, tie_rank=None):
+        """VMISIndex::new restated (vmis_index.rs:85-314): the index a PRE-BUILT (Avro) index's records make -- posting lists (`lists`: one sequence of session
+        indices per item, in the producer's order), idf and flags (bit0 IsAdult, bit1 ForSale) AS GIVEN, session rows at their SessionIndex.  tie_rank [n_sessions]:
+        the canonical form's order among sessions of EQUAL timestamp (larger = more recent; default: by session index) -- the reference leaves it open."""
+        self = cls.__new__(cls)
+        self.L = lib()
+        self.sess_off, self.items, self.ts = _u64(sess_off), _u64(sess_items), np.ascontiguousarray(ts, np.uint32)
+        self.tie = None if tie_rank is None else np.ascontiguousarray(tie_rank, np.uint32)
+        lo = np.zeros(len(item_ids) + 1, np.uint64)
+        lo[1:] = np.cumsum([len(x) for x in lists])
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(x, np.uint32) for x in lists]) if len(lists) else np.zeros(0, np.uint32), np.uint32)
+        if len(flat) == 0:
+            flat = np.zeros(1, np.uint32)
+        self.h = self.L.orc_index_from_parts(_u64(item_ids), lo, flat, np.ascontiguousarray(idf, np.float64), np.ascontiguousarray(flags, np.uint8), len(item_ids),
+                                             self.sess_off, self.items, self.ts, len(self.ts), _ptr(self.tie))
+        return self
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -191,6 +191,9 @@ struct Index {
     const uint64_t* off_p = nullptr; const uint64_t* items_p = nullptr;
     // A RESTRICTED index (prepare_hashmap_restricted) holds posting lists only for the items in `wanted`: a query that names another KNOWN item must be refused, not answered
     bool restricted = false; FlatMap<uint64_t, uint8_t> wanted;
+    // CANONICAL form only: the order among sessions of EQUAL timestamp (larger = more recent); empty = by session index.  The reference leaves these ties to its
+    // containers: any fixed order is a valid instance, and a pre-built index is served in the order its producer's list cuts imply (orc_index_from_parts)
+    std::vector<uint32_t> tie_rank;
     const uint64_t* row(uint32_t s, size_t* len) const {
         *len = (size_t)(off_p[s + 1] - off_p[s]); return items_p + off_p[s];
     }
@@ -518,7 +521,7 @@ static void neighbors_canonical(const Index& ix, const uint64_t* evolving, size_
     *U_out = seen.size();                                                       // Q1 denominator (distinct raw ids)
     auto more_recent = [&](uint32_t a, uint32_t b) {                            // strict total recency order
         const uint32_t ta = ix.session_to_max_time_stamp[a], tb = ix.session_to_max_time_stamp[b];
-        return ta != tb ? ta > tb : a > b; };
+        return ta != tb ? ta > tb : ix.tie_rank.empty() ? a > b : ix.tie_rank[a] > ix.tie_rank[b]; };
     std::vector<Neighbor> cand; cand.reserve(num.size());
     for (auto& kv : num) cand.push_back(Neighbor{kv.first, kv.second});
     std::sort(cand.begin(), cand.end(), [&](const Neighbor& a, const Neighbor& b) { return more_recent(a.sid, b.sid); });
@@ -651,6 +654,30 @@ void* orc_index_build_restricted(const uint64_t* sess_off, const uint64_t* items
     ix->off_p = sess_off; ix->items_p = items;
     ix->session_to_max_time_stamp.assign(ts, ts + n_sessions);
     if (!prepare_hashmap_restricted(*ix, m_index, max_len, idf_weighting, wanted, n_wanted, threads, items_hint)) { delete ix; return nullptr; }
+    return ix;
+}
+// VMISIndex::new(base_path) restated (src/vmisknn/vmis_index.rs:85-314): a PRE-BUILT index is assembled from the producer's records, nothing is computed --
+// item_to_top_sessions_ordered, item_to_idf_score and item_to_product_attributes are the item records' session lists AS GIVEN, idf and flags (:193-247);
+// session_to_items_sorted / session_to_max_time_stamp are the session records placed at their SessionIndex (:256-303).  The caller has parsed the Avro files (the
+// tests' own spec reader): this is the index the reference would serve from them, for predict_literal / predict_canonical ("lists as given").
+//   flags[i]: bit0 IsAdult, bit1 ForSale.  tie_rank (or null): Index::tie_rank.
+void* orc_index_from_parts(const uint64_t* item_ids, const uint64_t* list_off, const uint32_t* list_sessions, const double* idf, const uint8_t* flags, size_t n_items,
+                           const uint64_t* sess_off, const uint64_t* sess_items, const uint32_t* ts, size_t n_sessions, const uint32_t* tie_rank) {
+    Index* ix = new Index();
+    if (tie_rank) ix->tie_rank.assign(tie_rank, tie_rank + n_sessions);
+    ix->sess_off.assign(sess_off, sess_off + n_sessions + 1); ix->sess_items.assign(sess_items, sess_items + sess_off[n_sessions]);
+    ix->off_p = ix->sess_off.data(); ix->items_p = ix->sess_items.data();
+    ix->session_to_max_time_stamp.assign(ts, ts + n_sessions);
+    ix->postings.assign(list_sessions, list_sessions + list_off[n_items]);
+    ix->item_to_top_sessions_ordered = FlatMap<uint64_t, Postings>(n_items);
+    ix->item_to_idf_score = FlatMap<uint64_t, double>(n_items);
+    ix->item_to_product_attributes = FlatMap<uint64_t, uint8_t>(n_items);
+    for (size_t i = 0; i < n_items; ++i) {
+        *ix->item_to_top_sessions_ordered.insert_slot(item_ids[i]) = Postings{list_off[i], (uint32_t)(list_off[i + 1] - list_off[i])};
+        *ix->item_to_idf_score.insert_slot(item_ids[i]) = idf[i];
+        *ix->item_to_product_attributes.insert_slot(item_ids[i]) = flags[i] & 3;
+    }
+    ix->total_pairs = sess_off[n_sessions];
     return ix;
 }
 void orc_index_free(void* h) { delete (Index*)h; }

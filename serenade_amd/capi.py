@@ -29,7 +29,7 @@ class SessionsView(C.Structure):
 class IndexInfo(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_items", "n_sessions_total", "n_sessions_kept", "nnz_rows", "nnz_postings",
                                           "m_index", "max_session_len", "max_row_len", "device_bytes")] + \
-               [("device", C.c_int32), ("offsets_64bit", C.c_int32), ("idf_weighting", C.c_double)]
+               [("device", C.c_int32), ("offsets_64bit", C.c_int32), ("idf_weighting", C.c_double), ("incomplete_items", C.c_uint64)]
 
 
 class ShardGroupStats(C.Structure):
@@ -74,6 +74,7 @@ SYMBOLS = {
     "srn_index_postings": (_i, [_vp, _u64, _vp, _sz, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "srn_index_items_for_session": (_i, [_vp, C.c_uint32, _vp, _sz, C.POINTER(_sz)]),
     "srn_index_find_attributes": (_i, [_vp, _u64, C.POINTER(C.c_uint8)]),
+    "srn_index_session_recency": (_i, [_vp, _vp, _sz]),
     "srn_find_neighbors": (_i, [_vp, _vp, _sz, _sz, _sz, _vp, _vp, C.POINTER(_sz)]),
     "srn_index_free": (None, [_vp]),
     "srn_predict": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _i, _vp, _vp, C.POINTER(_sz)]),

@@ -8,8 +8,9 @@
 // nothing is computed: posting lists, idf and the product flags are taken from the files (:201-228); the lists are re-ordered
 // by this library's canonical recency (Time, then SessionIndex).  If every list is a most-recent prefix under that order -- what
 // "time ordered, top m" lists are unless the producer broke timestamp ties differently -- the position-set kernel path applies
-// (FlatIndex::lists_complete); otherwise the lists are used as given, like the reference does, with the first-match position
-// taken from the rows.  Snappy blocks are checked against their CRC-32 trailer.
+// to the whole index (FlatIndex::lists_complete); otherwise the lists are used as given, like the reference does, and the
+// loader records PER ITEM how far its list departs from its rows (FlatIndex::viol): the prep kernel sends only the queries
+// that such an item can affect to the general kernel's row pass.  Snappy blocks are checked against their CRC-32 trailer.
 // =====================================================================================
 #include <dirent.h>
 
@@ -190,6 +191,45 @@ template <typename F> void read_container(const std::string& path, const std::ve
     }
 }
 
+// The recency order among sessions of EQUAL Time is not in the files; the reference compares timestamps only (vmis_index.rs:369, 404-410) and leaves ties to its
+// containers.  An index built here orders ties by SessionIndex; a producer that cut its "m most recent" lists with another tie-break wrote lists that are not most-recent
+// prefixes under that order -- but they are under ITS order, and any fixed order among ties is an equally valid refinement of the reference.  So the loader infers one:
+// for every list, the entries that share the Time of its last entry must be more recent than the listed sessions of the same Time that hold the item and were cut.
+// One virtual node per such item between the two sets, a topological order per group of equal Time, SessionIndex-descending wherever the lists say nothing (an index
+// whose ties ARE by SessionIndex comes out exactly as before).  A cycle (no consistent order: ties broken per item) is broken at the largest SessionIndex and shows up
+// in FlatIndex::viol.   emitted[]: the sessions of one group, most recent first.
+struct TieEdge { uint32_t from, to; };
+void order_tie_group(const std::vector<uint32_t>& sessions /* ascending SessionIndex */, const std::vector<uint32_t>& virt, const std::vector<uint64_t>& virt_key,
+                     const std::vector<TieEdge>& edges, uint32_t ns, std::vector<uint32_t>& emitted) {
+    // local ids: sessions 0..n-1 (ascending index), virtual nodes n..n+v-1
+    const size_t n = sessions.size(), v = virt.size(), tot = n + v;
+    auto local = [&](uint32_t g) -> size_t { return g < ns ? (size_t)(std::lower_bound(sessions.begin(), sessions.end(), g) - sessions.begin())
+                                                            : n + (size_t)(std::lower_bound(virt.begin(), virt.end(), g - ns) - virt.begin()); };
+    std::vector<uint32_t> indeg(tot, 0), adj_off(tot + 1, 0), adj(edges.size());
+    for (const TieEdge& e : edges) { ++adj_off[local(e.from) + 1]; ++indeg[local(e.to)]; }
+    for (size_t i = 0; i < tot; ++i) adj_off[i + 1] += adj_off[i];
+    { std::vector<uint32_t> fill(adj_off.begin(), adj_off.end() - 1); for (const TieEdge& e : edges) adj[fill[local(e.from)]++] = (uint32_t)local(e.to); }
+    auto key = [&](size_t l) -> uint64_t { return l < n ? 2ull * sessions[l] + 2ull : virt_key[l - n]; };
+    std::vector<std::pair<uint64_t, uint32_t>> heap;   // max-heap of (key, local id): the ready nodes
+    std::vector<uint8_t> done(tot, 0);
+    for (size_t l = 0; l < tot; ++l) if (indeg[l] == 0) heap.emplace_back(key(l), (uint32_t)l);
+    std::make_heap(heap.begin(), heap.end());
+    size_t left = tot, scan = tot;   // scan: cycle breaker's cursor (largest key first = highest local session id first; virtual nodes never need forcing once sessions are out)
+    emitted.clear();
+    while (left) {
+        if (heap.empty()) {   // a cycle: force the largest unfinished session
+            while (scan > 0 && (done[scan - 1] || scan - 1 >= n)) --scan;
+            size_t l = scan ? scan - 1 : 0; if (!scan) { for (l = n; l < tot && done[l]; ++l) {} }
+            indeg[l] = 0; heap.emplace_back(key(l), (uint32_t)l); std::push_heap(heap.begin(), heap.end());
+        }
+        std::pop_heap(heap.begin(), heap.end()); const uint32_t l = heap.back().second; heap.pop_back();
+        if (done[l]) continue;
+        done[l] = 1; --left;
+        if (l < n) emitted.push_back(sessions[l]);
+        for (uint32_t j = adj_off[l]; j < adj_off[l + 1]; ++j) { const uint32_t t = adj[j]; if (!done[t] && indeg[t] && --indeg[t] == 0) { heap.emplace_back(key(t), t); std::push_heap(heap.begin(), heap.end()); } }
+    }
+}
+
 }  // namespace
 
 int build_flat_index_from_avro(const char* base_path, FlatIndex& ix) {
@@ -213,24 +253,74 @@ int build_flat_index_from_avro(const char* base_path, FlatIndex& ix) {
                 items.push_back(std::move(it)); });
         const size_t ns = rows.size();
         if (ns == 0 || items.empty()) bad("empty index");
-        if (items.size() >= 0xFFFFFFF0ull) bad("too many items");
+        if (items.size() >= 0xFFFFFFF0ull || ns + items.size() >= 0xFFFFFFF0ull) bad("too many items / sessions");
         ix = FlatIndex();
         ix.n_sessions_total = ns; ix.n_kept = ns; ix.idf_weighting = 1.0;
-        // canonical recency: (Time, SessionIndex) ascending = rank
-        ix.rank_to_session.resize(ns); std::iota(ix.rank_to_session.begin(), ix.rank_to_session.end(), 0u);
-        std::sort(ix.rank_to_session.begin(), ix.rank_to_session.end(), [&](uint32_t a, uint32_t b) { return times[a] != times[b] ? times[a] < times[b] : a < b; });
-        std::vector<uint32_t> rank_of(ns); for (size_t r = 0; r < ns; ++r) rank_of[ix.rank_to_session[r]] = (uint32_t)r;
         // dense idx = popularity order over the session rows (count desc, id asc), as in the TSV builder
         std::sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.id < b.id; });
         for (size_t i = 1; i < items.size(); ++i) if (items[i].id == items[i - 1].id) bad("item " + std::to_string(items[i].id) + " appears twice in the item index");
         auto find_item = [&](uint64_t id) -> size_t { auto it = std::lower_bound(items.begin(), items.end(), id, [](const Item& a, uint64_t v) { return a.id < v; });
                                                       return it != items.end() && it->id == id ? (size_t)(it - items.begin()) : (size_t)-1; };
         std::vector<uint32_t> cnt(items.size(), 0);
+        std::vector<uint64_t> row_base(ns + 1, 0);   // rows flattened by SessionIndex: where row s starts
+        std::vector<uint32_t> row_item;              // ... and its items as by-id positions (ascending, like the ids)
         for (size_t s = 0; s < ns; ++s) { uint64_t prev = 0; bool first = true;
             for (uint64_t id : rows[s]) { if (!first && id <= prev) bad("session rows must be strictly ascending item ids (item_ids_asc)"); prev = id; first = false;
                 const size_t j = find_item(id); if (j == (size_t)-1) bad("item " + std::to_string(id) + " of a session row has no item-index record (the reference would panic when scoring it: vmis_index.rs:321-323)");
-                ++cnt[j]; ++ix.nnz_rows; } }
+                ++cnt[j]; ++ix.nnz_rows; row_item.push_back((uint32_t)j); }
+            row_base[s + 1] = row_item.size(); std::vector<uint64_t>().swap(rows[s]); }
         ix.total_pairs = ix.nnz_rows; ix.n_items = items.size();
+        for (const Item& it : items) ix.m_index = std::max<uint64_t>(ix.m_index, it.sessions.size());
+        // ---- which (session, item) pairs the lists cover; which sessions are listed at all; per item the Time of its oldest entry ----
+        std::vector<uint8_t> covered((ix.nnz_rows + 7) / 8, 0), listed((ns + 7) / 8, 0), foreign(items.size(), 0);   // foreign: the list names a session whose row does not hold the item
+        std::vector<uint32_t> t_old(items.size(), 0xFFFFFFFFu);
+        for (size_t j = 0; j < items.size(); ++j) {
+            std::vector<uint32_t> seen = items[j].sessions; std::sort(seen.begin(), seen.end());
+            for (size_t e = 1; e < seen.size(); ++e) if (seen[e] == seen[e - 1]) bad("item " + std::to_string(items[j].id) + " lists a session twice");
+            for (uint32_t s : items[j].sessions) {
+                listed[s >> 3] |= (uint8_t)(1u << (s & 7)); t_old[j] = std::min(t_old[j], times[s]);
+                const uint32_t* lo = std::lower_bound(row_item.data() + row_base[s], row_item.data() + row_base[s + 1], (uint32_t)j);
+                if (lo != row_item.data() + row_base[s + 1] && *lo == j) { const uint64_t b = (uint64_t)(lo - row_item.data()); covered[b >> 3] |= (uint8_t)(1u << (b & 7)); }
+                else foreign[j] = 1;
+            }
+        }
+        // ---- recency = (Time, tie order inferred from the full lists' cuts, SessionIndex where they say nothing) ----
+        ix.rank_to_session.resize(ns); std::iota(ix.rank_to_session.begin(), ix.rank_to_session.end(), 0u);
+        std::sort(ix.rank_to_session.begin(), ix.rank_to_session.end(), [&](uint32_t a, uint32_t b) { return times[a] != times[b] ? times[a] < times[b] : a < b; });
+        {
+            // edges of every group, as (Time, edge): kept entry -> virtual node of the item -> cut session
+            struct GE { uint32_t time; TieEdge e; };
+            std::vector<GE> ge; std::vector<uint8_t> has_kept(items.size(), 0), has_cut(items.size(), 0);
+            std::vector<uint32_t> min_kept(items.size(), 0xFFFFFFFFu);
+            for (int pass = 0; pass < 2; ++pass)   // pass 0: which items have both sides in their last entry's group; pass 1: their edges
+                for (size_t s = 0; s < ns; ++s) {
+                    if (!(listed[s >> 3] >> (s & 7) & 1)) continue;
+                    for (uint64_t b = row_base[s]; b < row_base[s + 1]; ++b) {
+                        const uint32_t j = row_item[b];
+                        if (times[s] != t_old[j]) continue;
+                        const bool cov = covered[b >> 3] >> (b & 7) & 1;
+                        if (pass == 0) { if (cov) { has_kept[j] = 1; min_kept[j] = std::min<uint32_t>(min_kept[j], (uint32_t)s); } else has_cut[j] = 1; }
+                        else if (has_kept[j] && has_cut[j]) ge.push_back(GE{times[s], cov ? TieEdge{(uint32_t)s, (uint32_t)(ns + j)} : TieEdge{(uint32_t)(ns + j), (uint32_t)s}});
+                    }
+                }
+            std::sort(ge.begin(), ge.end(), [](const GE& a, const GE& b) { return a.time < b.time; });
+            size_t g0 = 0, r0 = 0;   // r0: cursor into rank_to_session (ascending Time)
+            std::vector<uint32_t> sess, virt, emitted; std::vector<uint64_t> vkey; std::vector<TieEdge> edges;
+            while (g0 < ge.size()) {
+                size_t g1 = g0; while (g1 < ge.size() && ge[g1].time == ge[g0].time) ++g1;
+                while (times[ix.rank_to_session[r0]] != ge[g0].time) ++r0;
+                size_t r1 = r0; while (r1 < ns && times[ix.rank_to_session[r1]] == ge[g0].time) ++r1;
+                sess.assign(ix.rank_to_session.begin() + r0, ix.rank_to_session.begin() + r1);   // ascending SessionIndex
+                edges.clear(); virt.clear();
+                for (size_t g = g0; g < g1; ++g) { edges.push_back(ge[g].e); const TieEdge& e = ge[g].e; virt.push_back((e.from >= ns ? e.from : e.to) - (uint32_t)ns); }
+                std::sort(virt.begin(), virt.end()); virt.erase(std::unique(virt.begin(), virt.end()), virt.end());
+                vkey.clear(); for (uint32_t j : virt) vkey.push_back(2ull * min_kept[j] + 1ull);   // just below its lowest kept entry: an index whose ties are by SessionIndex keeps that order
+                order_tie_group(sess, virt, vkey, edges, (uint32_t)ns, emitted);
+                for (size_t e = 0; e < emitted.size(); ++e) ix.rank_to_session[r1 - 1 - e] = emitted[e];   // most recent first -> highest rank first
+                g0 = g1; r0 = r1;
+            }
+        }
+        std::vector<uint32_t> rank_of(ns); for (size_t r = 0; r < ns; ++r) rank_of[ix.rank_to_session[r]] = (uint32_t)r;
         std::vector<uint32_t> order(items.size()); std::iota(order.begin(), order.end(), 0u);
         std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cnt[a] != cnt[b] ? cnt[a] > cnt[b] : items[a].id < items[b].id; });
         std::vector<uint32_t> idx_of(items.size());   // by-id position -> dense idx
@@ -238,30 +328,39 @@ int build_flat_index_from_avro(const char* base_path, FlatIndex& ix) {
         for (uint32_t i = 0; i < ix.n_items; ++i) { const uint32_t j = order[i]; idx_of[j] = i; ix.item_id[i] = items[j].id; ix.id_rank[i] = j; ix.idf[i] = items[j].idf; ix.attr[i] = items[j].attr; }
         // rows by rank
         ix.row_off.assign(ns + 1, 0); ix.row_items.reserve(ix.nnz_rows);
-        for (size_t r = 0; r < ns; ++r) { const auto& row = rows[ix.rank_to_session[r]];
-            for (uint64_t id : row) ix.row_items.push_back(idx_of[find_item(id)]);
-            ix.row_off[r + 1] = ix.row_items.size(); ix.max_row_len = std::max<uint64_t>(ix.max_row_len, row.size()); }
+        for (size_t r = 0; r < ns; ++r) { const uint32_t s = ix.rank_to_session[r];
+            for (uint64_t b = row_base[s]; b < row_base[s + 1]; ++b) ix.row_items.push_back(idx_of[row_item[b]]);
+            ix.row_off[r + 1] = ix.row_items.size(); ix.max_row_len = std::max<uint64_t>(ix.max_row_len, row_base[s + 1] - row_base[s]); }
         ix.max_session_len = ix.max_row_len;
         // postings: the given session lists as recency ranks, most recent first; m_index = the longest list
         ix.post_off.assign(ix.n_items + 1, 0);
-        for (uint32_t i = 0; i < ix.n_items; ++i) { ix.post_off[i + 1] = ix.post_off[i] + items[order[i]].sessions.size(); ix.m_index = std::max<uint64_t>(ix.m_index, items[order[i]].sessions.size()); }
+        for (uint32_t i = 0; i < ix.n_items; ++i) ix.post_off[i + 1] = ix.post_off[i] + items[order[i]].sessions.size();
         ix.nnz_post = ix.post_off[ix.n_items]; ix.post_rank.resize(ix.nnz_post);
         std::vector<uint32_t> oldest(ix.n_items, 0xFFFFFFFFu);
         for (uint32_t i = 0; i < ix.n_items; ++i) {
             uint32_t* dst = &ix.post_rank[ix.post_off[i]]; const auto& ss = items[order[i]].sessions;
             for (size_t j = 0; j < ss.size(); ++j) dst[j] = rank_of[ss[j]];
             std::sort(dst, dst + ss.size(), std::greater<uint32_t>());
-            for (size_t j = 1; j < ss.size(); ++j) if (dst[j] == dst[j - 1]) bad("item " + std::to_string(ix.item_id[i]) + " lists a session twice");
             if (!ss.empty()) oldest[i] = dst[ss.size() - 1];
         }
-        // the lists must be most-recent prefixes: every session that holds the item and is at least as recent as the list's
-        // oldest entry is in the list, and a list shorter than m_index is complete (DESIGN.md "Why MASKS is exact")
-        { std::vector<uint32_t> newer(ix.n_items, 0), total(ix.n_items, 0);
-          for (size_t r = 0; r < ns; ++r) for (uint64_t j = ix.row_off[r]; j < ix.row_off[r + 1]; ++j) { const uint32_t it = ix.row_items[j]; ++total[it]; newer[it] += oldest[it] != 0xFFFFFFFFu && r >= oldest[it]; }
+        // Which items' lists can stand in for the reference's row test?  The position-set kernels read a neighbour's first match off the lists ("r is in list_i" for
+        // "row(r) contains i", mod.rs:133-138).  A session r is a VIOLATOR of item i if its row holds i, r is in no list of i, and r is LISTED (in some item's list: a
+        // session no list names can never be a candidate, vmis_index.rs:332-391, so it cannot be a neighbour either).  viol[i] = 1 + the most recent violator's rank
+        // (0: none; 0xFFFFFFFF: the list names a session whose row does not hold the item -- never exact).  A query is exact on the position-set path iff viol[i] <= x_lo
+        // for each of its items (x_lo = the most recent m-th entry of its full lists; every neighbour is >= x_lo): DESIGN.md 4.1.  An index built here has, per item,
+        // viol <= the list's last entry for a full list and 0 for a shorter one; a producer that cut its lists by a rule no tie order explains leaves larger values on
+        // SOME items -- the reference uses such lists as given (vmis_index.rs:201-228), and so do we: only the queries that name such an item above their cut take the
+        // general kernel's row pass.
+        { std::vector<uint32_t> viol(ix.n_items, 0u);
+          for (uint32_t i = 0; i < ix.n_items; ++i) if (foreign[order[i]]) viol[i] = 0xFFFFFFFFu;
+          for (size_t s = 0; s < ns; ++s) {
+              if (!(listed[s >> 3] >> (s & 7) & 1)) continue;
+              for (uint64_t b = row_base[s]; b < row_base[s + 1]; ++b)
+                  if (!(covered[b >> 3] >> (b & 7) & 1)) { uint32_t& v = viol[idx_of[row_item[b]]]; v = std::max<uint32_t>(v, rank_of[s] + 1u); }
+          }
           for (uint32_t i = 0; i < ix.n_items; ++i) { const uint64_t len = ix.post_off[i + 1] - ix.post_off[i];
-              // (an index built elsewhere may break ties between equal timestamps differently, or truncate by another rule: the reference
-              //  uses the lists as given, vmis_index.rs:201-228 -- so do we, without the position-set shortcut that relies on complete lists)
-              if (newer[i] != len || (len < ix.m_index && len != total[i])) ix.lists_complete = false; } }
+              if (viol[i] != 0u && !(len == ix.m_index && viol[i] <= oldest[i])) ix.lists_complete = false; }
+          if (!ix.lists_complete) ix.viol = std::move(viol); }
         size_t tcap = 16; while (tcap < ix.n_items * 2) tcap <<= 1;
         ix.id_table.assign(tcap, IdSlot{0, kNone, 0}); ix.id_mask = (uint32_t)(tcap - 1);
         for (uint32_t i = 0; i < ix.n_items; ++i) { uint32_t h = (uint32_t)mix64(ix.item_id[i]) & ix.id_mask; while (ix.id_table[h].idx != kNone) h = (h + 1) & ix.id_mask; ix.id_table[h] = IdSlot{ix.item_id[i], i, 0}; }

@@ -172,9 +172,14 @@ int srn_index_set_attributes(srn_index_t* idx, const uint64_t* item_ids, const u
 int srn_index_info(const srn_index_t* idx, srn_index_info_t* out) {
     if (!idx || !out) return fail(SRN_EINVAL, "null argument");
     const FlatIndex& f = idx->flat;
+    uint64_t incomplete = 0;
+    if (!f.lists_complete && f.viol.size() == f.n_items)
+        for (uint64_t i = 0; i < f.n_items; ++i) { const uint64_t len = f.post_off[i + 1] - f.post_off[i];
+            if (f.viol[i] != 0u && !(len == f.m_index && len != 0 && f.viol[i] <= f.post_rank[f.post_off[i + 1] - 1])) ++incomplete; }
+    else if (!f.lists_complete) incomplete = f.n_items;   // (a shard cut from such an index: not measured per item)
     *out = srn_index_info_t{f.n_items, f.n_sessions_total, f.n_kept, f.nnz_rows, f.nnz_post, f.m_index, f.max_session_len,
                             f.max_row_len, device_bytes(idx->dev), idx->dev ? idx->device : -1,
-                            f.nnz_rows >= 0xFFFFFFFFull ? 1 : 0, f.idf_weighting};
+                            f.nnz_rows >= 0xFFFFFFFFull ? 1 : 0, f.idf_weighting, incomplete};
     return SRN_OK;
 }
 int srn_index_postings(const srn_index_t* idx, uint64_t item_id, uint32_t* out_sessions, size_t cap, int64_t* out_len, double* out_idf) {
@@ -206,6 +211,16 @@ int srn_index_items_for_session(const srn_index_t* idx, uint32_t session, uint64
         const uint64_t o0 = f.row_off[r], o1 = f.row_off[r + 1];
         *out_len = (size_t)(o1 - o0);
         if (out_items) for (uint64_t t = o0; t < o1 && t - o0 < cap; ++t) out_items[t - o0] = f.item_id[f.row_items[t]];   // (row order = ascending public id, as the reference's item_ids_asc)
+        return SRN_OK; });
+}
+int srn_index_session_recency(const srn_index_t* idx, uint32_t* out_rank, size_t cap) {
+    return guarded([&]() -> int {
+        if (!idx || !out_rank) return fail(SRN_EINVAL, "null argument");
+        const FlatIndex& f = idx->flat;
+        int rc = check_has_rows(f, "srn_index_session_recency"); if (rc) return rc;
+        if (cap < f.n_sessions_total) return fail(SRN_EINVAL, "room for n_sessions entries needed");
+        std::fill(out_rank, out_rank + f.n_sessions_total, kNone);
+        for (uint64_t r = 0; r < f.n_kept; ++r) out_rank[f.rank_to_session[r]] = (uint32_t)r;
         return SRN_OK; });
 }
 int srn_index_find_attributes(const srn_index_t* idx, uint64_t item_id, uint8_t* out_flags) {

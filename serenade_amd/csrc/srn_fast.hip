@@ -465,16 +465,16 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
         FAST_PRIO(FP_REC);
         // ---- phase 0: the query's prep record -> run descriptors in SGPRs ------------------------------
         const char* const rec = p.prep + (size_t)q * p.prep_stride;
-        struct { uint32_t U, rmax, xlo, sumw, L, n_staged, cur_attr; } hd;
+        struct { uint32_t U, rmax, xlo, sumw, L, n_staged, cur_attr, unsafe; } hd;
         constexpr uint32_t HW = (uint32_t)sizeof(PrepHead) / 4u;   // record words before the items
         struct { uint32_t idx, kept; unsigned long long base; } x0{kNone, 0u, 0ull};
         if (have_pre) {
             auto uni = [&](uint32_t w) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)pre[w]); };   // (SGPRs: the branches on these stay scalar)
-            hd.U = uni(0); hd.rmax = uni(1); hd.xlo = uni(2); hd.sumw = uni(3); hd.L = uni(6); hd.n_staged = uni(7); hd.cur_attr = uni(16);
+            hd.U = uni(0); hd.rmax = uni(1); hd.xlo = uni(2); hd.sumw = uni(3); hd.L = uni(6); hd.n_staged = uni(7); hd.cur_attr = uni(16); hd.unsafe = uni(17);
             if (lane < (LONG ? 32u : MID ? 16u : 8u) && lane < hd.L) { const uint32_t* it = pre + HW + 6u * lane; x0.idx = it[0]; x0.kept = it[3]; x0.base = ((unsigned long long)it[5] << 32) | it[4]; }
         } else {
             const PrepHead h0 = *(const PrepHead*)rec;   // (uniform address)
-            hd.U = h0.U; hd.rmax = h0.rmax; hd.xlo = h0.xlo; hd.sumw = h0.sumw; hd.L = h0.L; hd.n_staged = h0.n_staged; hd.cur_attr = h0.cur_attr;
+            hd.U = h0.U; hd.rmax = h0.rmax; hd.xlo = h0.xlo; hd.sumw = h0.sumw; hd.L = h0.L; hd.n_staged = h0.n_staged; hd.cur_attr = h0.cur_attr; hd.unsafe = h0.unsafe;
             if ((MID ? lane < (LONG ? 32u : 16u) && lane < p.max_len : lane < 8u) && lane < hd.L) { const PrepItem pi = ((const PrepItem*)(rec + sizeof(PrepHead)))[lane]; x0.idx = pi.idx; x0.kept = pi.kept; x0.base = pi.base; }
         }
         have_pre = false;
@@ -489,7 +489,8 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
         const bool rel = MID || (WIDE && nr > 3u);   // (block-uniform)
         const uint32_t NB = LONG ? F_LONG_NB : MID ? max(nr, 4u) : WIDE && !rel ? 3u : 4u, NBM = (1u << NB) - 1u, base = rel ? hd.xlo : 0u;
         // (MID: the last 256 words of the merge buffers' room hold the class histogram of the k-cut)
-        const bool fits = LONG ? L >= 1u && L <= F_LONG_LMAX && L <= p.max_len && hd.sumw <= F_LONG_CLASSES && nr <= F_LONG_LISTS && 2u * n + 8u + F_LONG_RES_WORDS <= MW && hd.rmax - hd.xlo < (1u << (32u - F_LONG_NB))
+        // (round 6: hd.unsafe -- an incomplete posting list of a pre-built index can reach this query's neighbours: the general kernel's row pass serves it, srn_prep.h)
+        const bool fits = hd.unsafe != 0u ? false : LONG ? L >= 1u && L <= F_LONG_LMAX && L <= p.max_len && hd.sumw <= F_LONG_CLASSES && nr <= F_LONG_LISTS && 2u * n + 8u + F_LONG_RES_WORDS <= MW && hd.rmax - hd.xlo < (1u << (32u - F_LONG_NB))
                         : MID ? L >= 1u && L <= F_MID_LMAX && L <= p.max_len && hd.sumw <= F_MID_CLASSES && nr <= F_MID_LISTS && 2u * n + 8u + 256u <= MW && hd.rmax - hd.xlo < (1u << (32u - NB))
                               : L >= 1u && L <= 8u && L <= p.max_len && hd.sumw <= 15u && nr <= 4u && 2u * n + 8u <= MW && (!rel || hd.rmax - hd.xlo < (1u << 28));
         uint32_t* const xq = MODE == FM_FUSED ? nullptr : f.xchg + (size_t)q * f.xchg_stride;   // this query's place in the exchange buffer: K | K slots
@@ -498,7 +499,8 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
             else if (tid == 0) {
                 // (round 5) a query of the lean shape whose merged lists alone outgrow the 53 KB layout -- the headline batches' 0.3 % -- goes straight to the BIG form (80 KB of
                 // LDS: n <= 9 404), not to the general kernel: 3 209 such queries per 2^20 cost 0.27 ms there
-                if (!MID && MODE == FM_FUSED && f.bigq_list != nullptr && L >= 1u && L <= 8u && L <= p.max_len && hd.sumw <= 15u && nr <= 4u && hd.rmax - hd.xlo < (1u << 28) &&
+                if (hd.unsafe != 0u) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q;
+                else if (!MID && MODE == FM_FUSED && f.bigq_list != nullptr && L >= 1u && L <= 8u && L <= p.max_len && hd.sumw <= 15u && nr <= 4u && hd.rmax - hd.xlo < (1u << 28) &&
                     2u * n + 8u + 256u <= (F_BIG_TOTAL - (F_TOTAL - F_SIDF) - F_WORK) / 4u) f.bigq_list[atomicAdd(f.bigq_cnt, 1u)] = q;
                 // (the MID instantiation looks at the query next, if this launch sequence has one; it decides for itself)
                 else if (!MID && MODE == FM_FUSED && f.mid_list != nullptr && L >= 1u && L <= F_MID_LMAX && L <= p.max_len) f.mid_list[atomicAdd(f.mid_cnt, 1u)] = q;

@@ -302,10 +302,10 @@ int save_flat_index(const FlatIndex& ix, const char* path) {
     FILE* f = fopen(path, "wb"); if (!f) return fail(SRN_EIO, std::string("cannot create ") + path);
     const char magic[8] = {'S', 'R', 'N', 'F', 'L', 'A', 'T', '4'};
     uint64_t hdr[13] = {ix.n_items, ix.n_sessions_total, ix.n_kept, ix.nnz_rows, ix.nnz_post, ix.m_index, ix.max_session_len, ix.max_row_len, ix.id_mask,
-                        ix.shard, ix.n_shards, ix.total_pairs, ix.lists_complete ? 1ull : 0ull};
+                        ix.shard, ix.n_shards, ix.total_pairs, (ix.lists_complete ? 1ull : 0ull) | (ix.viol.empty() ? 0ull : 2ull)};   // (flags: bit 0 lists complete, bit 1 the per-item viol array follows)
     bool ok = fwrite(magic, 8, 1, f) == 1 && fwrite(hdr, 8, 13, f) == 13 && fwrite(&ix.idf_weighting, 8, 1, f) == 1 &&
               wr(f, ix.item_id) && wr(f, ix.id_rank) && wr(f, ix.idf) && wr(f, ix.attr) && wr(f, ix.post_off) && wr(f, ix.post_rank) &&
-              wr(f, ix.row_off) && wr(f, ix.row_items) && wr(f, ix.rank_to_session) && wr(f, ix.id_table);
+              wr(f, ix.row_off) && wr(f, ix.row_items) && wr(f, ix.rank_to_session) && wr(f, ix.id_table) && (ix.viol.empty() || wr(f, ix.viol));
     ok = (fclose(f) == 0) && ok;
     return ok ? SRN_OK : fail(SRN_EIO, std::string("short write to ") + path);
 }
@@ -350,7 +350,7 @@ int load_flat_index(const char* path, FlatIndex& ix) {
         ix.m_index = hdr[5]; ix.max_session_len = hdr[6]; ix.max_row_len = hdr[7]; ix.id_mask = (uint32_t)hdr[8];
         ix.shard = (uint32_t)hdr[9]; ix.n_shards = (uint32_t)hdr[10]; ix.total_pairs = hdr[11]; ix.lists_complete = (hdr[12] & 1) != 0;
         ok = rd(f, ix.item_id) && rd(f, ix.id_rank) && rd(f, ix.idf) && rd(f, ix.attr) && rd(f, ix.post_off) && rd(f, ix.post_rank) &&
-             rd(f, ix.row_off) && rd(f, ix.row_items) && rd(f, ix.rank_to_session) && rd(f, ix.id_table);
+             rd(f, ix.row_off) && rd(f, ix.row_items) && rd(f, ix.rank_to_session) && rd(f, ix.id_table) && ((hdr[12] & 2) == 0 || (rd(f, ix.viol) && ix.viol.size() == ix.n_items && !ix.lists_complete));
         ok = ok && ix.item_id.size() == ix.n_items && ix.id_rank.size() == ix.n_items && ix.idf.size() == ix.n_items && ix.attr.size() == ix.n_items &&
              ix.post_off.size() == ix.n_items + 1 && ix.post_rank.size() == ix.nnz_post && ix.row_off.size() == ix.n_kept + 1 &&
              ix.row_items.size() == ix.nnz_rows && ix.rank_to_session.size() == ix.n_kept && ix.id_table.size() == (size_t)ix.id_mask + 1;

@@ -46,6 +46,9 @@ struct FlatIndex {
     bool lists_complete = true;             // every posting list holds ALL sessions of its item that are at least as recent as its last entry (and is complete if
                                             // shorter than m_index): true for every index built here; a pre-built (Avro) index may not satisfy it -- then the
                                             // first-match position comes from the rows (the reference's contains() test), not from posting-list membership
+    std::vector<uint32_t> viol;             // [n_items] iff !lists_complete on an index whose loader measured it (srn_avro.cpp): 1 + the most recent rank of a LISTED session whose row holds the
+                                            // item but which the item's list does not name (0: none; 0xFFFFFFFF: the list names a session without the item).  A query whose items all have
+                                            // viol <= its cut x_lo is exact on the position-set path; the prep kernel flags the others for the general kernel's row pass
     bool postings_only = false;             // the REPLICATED part of an item-sharded index (srn_index_postings_view): dictionary, idf / attributes and posting lists of the whole index,
                                             // no rows -- what every rank of a shard group keeps beside its shard for the neighbours pipeline; answers no predict call itself
     uint32_t shard = 0, n_shards = 1;       // item-sharded index: this shard holds the items with owner(id) == shard
@@ -90,6 +93,7 @@ struct DeviceIndex {  // pointers into HBM; passed by value to the kernels
     const ItemMeta* meta;        // [n_items] by dense idx
     const uint64_t* id_sorted;   // [n_items] public ids ascending (indexed by id_rank)
     const uint64_t* post_off; const uint32_t* post_rank;
+    const uint32_t* viol;        // [n_items] or null (every list complete): FlatIndex::viol -- the prep kernel sets PrepHead::unsafe from it
     // Rows in HBM: one 64-byte, 64-byte-aligned slot per session, addressed by recency rank -- ONE line fetch per
     // neighbour and no offset lookup.  word 0 = row length; length <= 15: words 1..15 hold the items; longer rows:
     // word 1 = offset (in items) of items 14.. in row_ext, words 2..15 = items 0..13.

@@ -32,7 +32,7 @@ struct KernelCfg {
 struct LaunchAux { const uint32_t* qlist; const uint32_t* qlist_n; uint32_t* retry_list; uint32_t* retry_cnt; char* gscratch; unsigned long long gscratch_stride; char* nb_spill; };
 
 // record written by the prep kernel for every query: PrepHead + max_len * PrepItem, positions counted from the most recent item
-struct PrepHead { uint32_t U, rmax, xlo, sumw, P, nruns, L, n_staged, run_start[8], cur_attr, pad_; };   // S_U, S_RMAX, S_XLO, S_SUMW, S_P of the query; number of non-empty lists, session length as given, sum of the lists' kept counts, where the first 8 lists start; cur_attr = the attribute byte of the current (most recent) item, SRN_ATTR_NONE if unknown
+struct PrepHead { uint32_t U, rmax, xlo, sumw, P, nruns, L, n_staged, run_start[8], cur_attr, unsafe; };   // S_U, S_RMAX, S_XLO, S_SUMW, S_P of the query; number of non-empty lists, session length as given, sum of the lists' kept counts, where the first 8 lists start; cur_attr = the attribute byte of the current (most recent) item, SRN_ATTR_NONE if unknown
 struct PrepItem { uint32_t idx, len, pre, kept; unsigned long long base; };   // dense idx | kNone, truncated list length, prefix of len, entries >= x_lo (a prefix of the list), list start
 
 // item-sharded index, lists mode (srn_shard.hip): what a shard knows about one evolving position of a query

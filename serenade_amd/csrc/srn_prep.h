@@ -16,6 +16,7 @@ __device__ __forceinline__ void prep_group(const DeviceIndex& ix, const uint64_t
     uint32_t U = 0, rmax = 0, xlo = 0, sumw = 0, P = 0, nruns = 0, n_staged = 0, cur_attr = SRN_ATTR_NONE, my_run_start = 0;
     const bool ok = L != 0 && L <= max_len;
     const uint32_t rounds = ok ? (L + PREP_LANES - 1) / PREP_LANES : 0;
+    uint32_t vmax = 0;          // largest FlatIndex::viol among this lane's known items (an index with incomplete lists only)
     uint32_t hot_key = kNone;   // smallest dense idx (of the index the lists come from) among this lane's known items
     uint32_t idx = kNone, len = 0, pre = 0; unsigned long long base = 0;   // this lane's item of the LAST round (a session of <= 8 items has one round: its record is written once, with `kept`)
     for (uint32_t r = 0; r < rounds; ++r) {
@@ -30,6 +31,7 @@ __device__ __forceinline__ void prep_group(const DeviceIndex& ix, const uint64_t
             { uint32_t hh = (uint32_t)dev_mix64(raw) & ix.id_mask;
               for (;;) { const IdSlot s = ix.id_table[hh]; if (s.idx == kNone) break; if (s.key == raw) { idx = s.idx; break; } hh = (hh + 1) & ix.id_mask; } }
             hot_key = min(hot_key, idx);
+            if (ix.viol != nullptr && idx != kNone) vmax = max(vmax, ix.viol[idx]);
             first_i = first ? 1u : 0u;   // Q1: distinct raw ids, known or not
             if (first && idx != kNone) {
                 const unsigned long long o0 = ix.post_off[idx], o1 = ix.post_off[idx + 1];
@@ -90,12 +92,14 @@ __device__ __forceinline__ void prep_group(const DeviceIndex& ix, const uint64_t
     }
     cur_attr = __shfl(cur_attr, 0, PREP_LANES);
     #pragma unroll
-    for (uint32_t d = 1; d < PREP_LANES; d <<= 1) hot_key = min(hot_key, (uint32_t)__shfl_xor((int)hot_key, d, PREP_LANES));
+    for (uint32_t d = 1; d < PREP_LANES; d <<= 1) { hot_key = min(hot_key, (uint32_t)__shfl_xor((int)hot_key, d, PREP_LANES)); vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, d, PREP_LANES)); }
+    // position sets are exact for this query iff no listed session at or above its cut holds one of its items without being in that item's list
+    const uint32_t unsafe = vmax > xlo ? 1u : 0u;
     if (okeys && sub == 0) okeys[q] = ((unsigned long long)min(hot_key, 0xFFFFu) << 32) | q;   // (16 key bits: beyond the 65 535 most popular items there is nothing to group -- two radix passes instead of three)
-    uint32_t* hw = (uint32_t*)rec;   // PrepHead, word by word: U rmax xlo sumw | P nruns L n_staged | run_start[8] | cur_attr pad_
+    uint32_t* hw = (uint32_t*)rec;   // PrepHead, word by word: U rmax xlo sumw | P nruns L n_staged | run_start[8] | cur_attr unsafe
     if (sub == 0) {   // (records are 8-byte aligned: 72 + 24 * max_len)
         *(uint2*)hw = make_uint2(U, rmax); *(uint2*)(hw + 2) = make_uint2(xlo, sumw); *(uint2*)(hw + 4) = make_uint2(P, nruns); *(uint2*)(hw + 6) = make_uint2(L, n_staged);
-        *(uint2*)(hw + 16) = make_uint2(cur_attr, 0u);
+        *(uint2*)(hw + 16) = make_uint2(cur_attr, unsafe);
     }
     hw[8 + sub] = sub < nruns ? my_run_start : 0u;
 }

@@ -22,7 +22,7 @@ namespace srn {
 static Knobs g_knobs; static std::once_flag g_knobs_once; static std::mutex g_knobs_mu;
 static void knobs_read() {
     Knobs k;
-    k.no_masks = getenv("SRN_NO_MASKS") != nullptr; k.no_merge = getenv("SRN_NO_MERGE") != nullptr; k.dense = getenv("SRN_DENSE") != nullptr;
+    k.no_masks = getenv("SRN_NO_MASKS") != nullptr; k.no_viol = getenv("SRN_NO_VIOL") != nullptr; k.no_merge = getenv("SRN_NO_MERGE") != nullptr; k.dense = getenv("SRN_DENSE") != nullptr;
     k.no_fast = getenv("SRN_NO_FAST") != nullptr; k.no_mid = getenv("SRN_NO_MID") != nullptr; k.no_big = getenv("SRN_NO_BIG") != nullptr; k.no_long = getenv("SRN_NO_LONG") != nullptr; k.debug = getenv("SRN_DEBUG") != nullptr;
     if (const char* e = getenv("SRN_ROW_SLOTS")) k.row_slots16 = atoi(e) == 16 ? 1 : atoi(e) == 64 ? 0 : -1;
     if (const char* e = getenv("SRN_HOT_SLOTS")) k.hot_slots = std::max(0, atoi(e));
@@ -83,6 +83,7 @@ DeviceState* device_attach(const FlatIndex& ix, int device) {
       for (uint32_t w8 = 0; w8 < 8; ++w8) for (uint32_t l = 0; l < 64; ++l) if (8 * l + w8 < ix.n_items) ms[64 * w8 + l] = meta[8 * l + w8];
       d->fast.meta_sample = upload(d, ms, ok); }
     d->di.post_off = upload(d, ix.post_off, ok); d->di.post_rank = upload(d, ix.post_rank, ok);
+    d->di.viol = !ix.lists_complete && ix.viol.size() == ix.n_items && ix.n_shards == 1 ? upload(d, ix.viol, ok) : nullptr;   // (a pre-built index whose lists are not all complete: the prep kernel's per-query test)
     if (ok && !ix.postings_only) {   // rows -> 64-byte slots (+ overflow area) on the device, see DeviceIndex and rows_to_slots_kernel
         // item shards: 16-byte FRAGMENT slots (a shard holds ~1/n_shards of a row's items), DeviceIndex::row_frag
         const int rs16 = knobs().row_slots16;
@@ -415,12 +416,14 @@ static FastPlan fast_plan(const DeviceState* d, const FlatIndex& ix, const Launc
     // the fast kernel packs (rank, set of <= 4 lists) into 32 bits whatever the general kernel's slots look like: up to 2^28 sessions with 4 lists per query,
     // up to 2^29 with 3 (queries with more go to the MID instantiation / the general kernel)
     f.nb_fast = fast_nb(ix, kn);
-    const bool sets_exact = p.m <= ix.m_index && ix.lists_complete && !kn.no_masks;
+    // (round 6) an index whose lists are not ALL complete (a pre-built Avro index: srn_avro.cpp) keeps the fast kernels: the prep kernel marks the queries that an
+    // incomplete list can affect (PrepHead::unsafe) and only those go to the general kernel, which then runs its row pass (geo.masks is false for such an index)
+    const bool sets_exact = p.m <= ix.m_index && (ix.lists_complete || (d->di.viol != nullptr && !kn.no_viol)) && !kn.no_masks;
     // (a sketch word sums the POSITIVE parts: <= k rows of <= max_row_len items, weight <= 9 * numerator; numerators <= 55 at 10 items, <= 210 at 20)
     const bool fast_sketch_ok = (uint64_t)p.k * std::max<uint64_t>(1, ix.max_row_len) * 9ull * (p.max_len > 10 ? 210ull : 55ull) < (1ull << 32);
     f.mid_tier = !kn.no_mid && !has_ext && d->di.row_frag == 0u && p.max_len >= 5;   // (a query of <= 4 items has <= 4 lists and numerators <= 10: nothing for the MID instantiation)
     f.long_tier = f.mid_tier && !kn.no_long && !kn.no_big && p.max_len > 10;          // (round 5: sessions of 11..20 items -- LONG, a form of MID's BIG layout)
-    f.fast = d->fast.row_packed != nullptr && sets_exact && (p.max_len <= 8 ? geo.masks && !geo.sketch_may_wrap : f.mid_tier && fast_sketch_ok) && f.nb_fast != 0 && kn.geometry_default() &&
+    f.fast = d->fast.row_packed != nullptr && sets_exact && (p.max_len <= 8 ? (geo.masks || !ix.lists_complete) && !geo.sketch_may_wrap : f.mid_tier && fast_sketch_ok) && f.nb_fast != 0 && kn.geometry_default() &&
              !kn.no_fast && p.k <= F_K_MAX && p.m <= F_M_MAX && p.how_many <= 24 && (p.flags & ~(unsigned)SRN_FLAG_BUSINESS_LOGIC) == 0 && p.stats == nullptr && p.nb_rank == nullptr;
     return f;
 }

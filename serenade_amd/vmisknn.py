@@ -114,6 +114,13 @@ class VMISIndex:
         capi.check(capi.lib().srn_index_items_for_session(self._h, int(session), capi.ptr(out), n.value, C.byref(n)))
         return out[:n.value]
 
+    def session_recency(self):
+        """Recency rank of every reference session (0 = oldest; 0xFFFFFFFF: not kept): the total order behind "most recent", ties among equal timestamps included."""
+        n = int(self.info["n_sessions_total"])
+        out = np.zeros(max(n, 1), np.uint32)
+        capi.check(capi.lib().srn_index_session_recency(self._h, capi.ptr(out), len(out)))
+        return out[:n]
+
     def find_attributes(self, item_id):
         """find_attributes(&u64) -> Option<&ProductAttributes> (vmis_index.rs:417-419): the SRN_ATTR_* bits, or None."""
         fl = C.c_uint8()

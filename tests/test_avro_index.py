@@ -143,7 +143,7 @@ def test_avro_index_rejects_what_it_cannot_represent(tmp_path):
         sa.VMISIndex.new_from_avro(tmp_path / "nothing-here", device=-1)
     assert e.value.code == -5          # SRN_EIO
     n = len(ts)
-    item_recs, sess_recs = _records(off, items, ts, idf)
+    item_recs, sess_recs, _ = _records(off, items, ts, idf)
     # malformed containers: a CRC that does not match, a wrong sync marker, a block cut in half
     for how in ("crc", "sync", "truncate"):
         base = tmp_path / how
@@ -161,17 +161,25 @@ def test_avro_index_rejects_what_it_cannot_represent(tmp_path):
     assert e.value.code == -1
 
 
-def _records(off, items, ts, idf, m_index=10**9, tie_break=-1):
+def _records(off, items, ts, idf, m_index=10**9, tie_break=-1, max_session_len=10**9):
     """Item / session records as a producer with its own tie-break among equal timestamps would write them
-    (tie_break = -1: larger session index first, as prepare_hashmap does; +1: smaller first)."""
+    (tie_break = -1: larger session index first, as prepare_hashmap does; +1: smaller first; a callable: j-th item (ascending id) -> -1 / +1).
+    Sessions of more than max_session_len items are in the session index only, in no list (as the CSV path keeps them: vmis_index.rs:79, 452).
+    -> (item records, session records, lists {item: sessions in the producer's order})"""
     n = len(ts)
     per_item = {}
     for s in range(n):
+        if off[s + 1] - off[s] > max_session_len:
+            continue
         for it in items[off[s]:off[s + 1]].tolist():
             per_item.setdefault(it, []).append(s)
-    item_recs = [AW.enc_item(it, sorted(ss, key=lambda s: (-int(ts[s]), tie_break * s))[:m_index], idf[it], True, False) for it, ss in sorted(per_item.items())]
+    lists = {}
+    for j, (it, ss) in enumerate(sorted(per_item.items())):
+        tb = tie_break(j) if callable(tie_break) else tie_break
+        lists[it] = sorted(ss, key=lambda s: (-int(ts[s]), tb * s))[:m_index]
+    item_recs = [AW.enc_item(it, ss, idf[it], True, False) for it, ss in sorted(lists.items())]
     sess_recs = [AW.enc_session(s, items[off[s]:off[s + 1]].tolist(), int(ts[s])) for s in range(n)]
-    return item_recs, sess_recs
+    return item_recs, sess_recs, lists
 
 
 def test_avro_schema_with_reordered_and_extra_fields(tmp_path):
@@ -197,7 +205,7 @@ def test_avro_schema_with_reordered_and_extra_fields(tmp_path):
     for j, (it, ss) in enumerate(sorted(per_item.items())):
         ss = sorted(ss, key=lambda s: (-int(ts[s]), -s))
         recs.append(AW.zz(3) + b"abc" + __import__("struct").pack("<d", idf[it]) + bytes([0]) + AW.zz(it) + (AW.zz(1) + AW.zz(j) if j % 2 else AW.zz(0)) + bytes([1]) + AW.enc_array(ss))
-    _, sess_recs = _records(off, items, ts, idf)
+    _, sess_recs, _ = _records(off, items, ts, idf)
     AW.write_container(f"{tmp_path}/itemindex/a.avro", item_schema, recs, "snappy", compressor=AW.snappy_with_copies)
     AW.write_container(f"{tmp_path}/sessionindex/a.avro", AW.SESSION_SCHEMA, sess_recs, "null")
     ix = sa.VMISIndex.new_from_avro(tmp_path, device=-1)
@@ -207,19 +215,19 @@ def test_avro_schema_with_reordered_and_extra_fields(tmp_path):
         assert np.array_equal(a[0], b[0]) and a[1] == b[1]
 
 
-def _canonical_over_given_lists(lists, rows, ts, idf, session, k, m, n):
+def _canonical_over_given_lists(lists, rows, ts, idf, session, k, m, n, rank=None):
     """DESIGN.md section 1 with the posting lists AS GIVEN (not rebuilt from the rows): what a pre-built index whose lists are not
     most-recent prefixes must still produce -- the reference uses the lists as they are (vmis_index.rs:201-228, 332-391) and tests
     the first match against the full row (mod.rs:133-138)."""
     L = len(session)
-    recency = lambda s: (int(ts[s]), s)
+    recency = (lambda s: (int(ts[s]), s)) if rank is None else (lambda s: int(rank[s]))   # rank: the index's own order among equal timestamps (srn_index_session_recency)
     seen, num = set(), {}
     for pos in range(L):
         it = session[L - 1 - pos]
         if it in seen:
             continue
         seen.add(it)
-        for s in lists.get(it, [])[:m]:
+        for s in sorted(lists.get(it, []), key=recency, reverse=True)[:m]:
             num[s] = num.get(s, 0) + (L - pos)
     U = len(seen)
     cand = sorted(num, key=recency, reverse=True)[:m]
@@ -236,38 +244,177 @@ def _canonical_over_given_lists(lists, rows, ts, idf, session, k, m, n):
     return [it for _, it in scored], [-x for x, _ in scored]
 
 
+def _write(tmp_path, item_recs, sess_recs):
+    AW.write_container(f"{tmp_path}/itemindex/a.avro", AW.ITEM_SCHEMA, item_recs, "snappy", compressor=AW.snappy_with_copies)
+    AW.write_container(f"{tmp_path}/sessionindex/a.avro", AW.SESSION_SCHEMA, sess_recs, "snappy")
+
+
+def _heavily_tied_dataset():
+    """3 000 sessions over 30 distinct timestamps (100 per second), 60 items: list cuts fall INSIDE large groups of equal Time."""
+    off, items, ts, ids = small_dataset(47, n_sessions=3000, n_items=60, tied_timestamps=True, max_len=12)
+    ts = (1000 + (ts.astype(np.int64) - 1000) * 8 // 100).astype(np.uint32)
+    return off, items, ts, ids
+
+
+def _violations(lists, rows, rank, m_index):
+    """Python restatement of FlatIndex::viol (srn_avro.cpp): per item, 1 + the highest recency rank of a LISTED session that holds the item but is not in its list
+    (0: none), and the number of items that fail the completeness test."""
+    listed = set(s for l in lists.values() for s in l)
+    viol, bad = {}, 0
+    for it, l in lists.items():
+        ls = set(l)
+        v = [int(rank[s]) for s in listed if it in rows[s] and s not in ls]
+        viol[it] = max(v) + 1 if v else 0
+        if viol[it] and not (len(l) == m_index and viol[it] <= min(int(rank[s]) for s in l)):
+            bad += 1
+    return viol, bad
+
+
+def test_the_loader_infers_the_producers_tie_order():
+    """srn_avro.cpp: the recency order among sessions of equal Time is inferred from the producer's list cuts.  (a) ties by larger SessionIndex (prepare_hashmap's
+    order): the index is what the TSV builder makes; (b) ties by SMALLER SessionIndex, consistently: a different but equally valid order, every list complete under it;
+    (c) ties broken one way on every other item and the other way on the rest, 100 sessions per timestamp: under (Time, SessionIndex) a third of the lists would be
+    incomplete; the inferred order explains all cuts but one (two items want two sessions in opposite orders) -- that item is counted and carries FlatIndex::viol."""
+    import tempfile
+    import serenade_amd as sa
+    off, items, ts, ids = _heavily_tied_dataset()
+    idf = _idf_like_builder(off, items, 1.0)
+    n = len(ts)
+    rows = [set(items[off[s]:off[s + 1]].tolist()) for s in range(n)]
+    canon = np.empty(n, np.int64); canon[np.lexsort((np.arange(n), ts))] = np.arange(n)
+    m_index, max_len = 40, 9
+    for name, tb in (("ours", -1), ("reverse", +1), ("mixed", lambda j: +1 if j % 2 == 0 else -1)):
+        with tempfile.TemporaryDirectory() as d:
+            item_recs, sess_recs, lists = _records(off, items, ts, idf, m_index=m_index, tie_break=tb, max_session_len=max_len)
+            _write(d, item_recs, sess_recs)
+            ix = sa.VMISIndex.new_from_avro(d, device=-1)
+        rank = ix.session_recency()
+        assert sorted(rank.tolist()) == list(range(n))                      # a permutation: every session of the session index keeps its row
+        assert all(ts[a] <= ts[b] for a, b in zip(np.argsort(rank)[:-1], np.argsort(rank)[1:]))   # ... ordered by Time; only the order among equal Times is the loader's
+        viol, bad = _violations(lists, rows, rank, m_index)
+        assert ix.info["incomplete_items"] == bad, name
+        for it in list(lists)[:25]:                                          # the lists are the producer's SETS, most recent first under the index's order
+            got, f = ix.postings(it)
+            assert sorted(got.tolist()) == sorted(lists[it]) and got.tolist() == sorted(lists[it], key=lambda s: -int(rank[s])) and f == idf[it]
+        if name == "ours":
+            assert bad == 0 and np.array_equal(rank, canon)
+        elif name == "reverse":
+            assert bad == 0 and not np.array_equal(rank, canon)
+            _, bad_canon = _violations(lists, rows, canon, m_index)
+            assert bad_canon > 0, "under (Time, SessionIndex) these lists are not most-recent prefixes: the fixture should need the inferred order"
+        else:
+            _, bad_canon = _violations(lists, rows, canon, m_index)
+            assert 0 < bad <= 3 and bad_canon >= 15, (bad, bad_canon)
+        # the flat on-disk format keeps what the loader found
+        with tempfile.TemporaryDirectory() as d:
+            ix.save(d + "/ix.bin")
+            ix2 = sa.VMISIndex.load(d + "/ix.bin", device=-1)
+            assert ix2.info["incomplete_items"] == bad and np.array_equal(ix2.session_recency(), rank)
+
+
+def _check_against_lists_as_given(sa, gix, lists, rows, off, items, ts, idf, qs, k, m, nrec, python_share=4):
+    """HIP answers == the canonical closed form over the lists AS GIVEN, recency = the index's own order: by the oracle's restatement of VMISIndex::new
+    (orc_index_from_parts) on every query and by the pure-Python statement above on every python_share-th."""
+    from oracle import oracle as O
+    rank = gix.session_recency()
+    n = len(ts)
+    order = np.argsort(rank)
+    assert all(ts[a] <= ts[b] for a, b in zip(order[:-1], order[1:]))       # the order the product serves with refines Time: only ties are its own
+    its = sorted(lists)
+    oix = O.OracleIndex.from_parts(its, [lists[i] for i in its], [idf[i] for i in its], [2] * len(its), off, items, ts, tie_rank=rank)
+    flat, qo = flatten(qs)
+    got_ids, got_sc, got_cnt = sa.predict_batch(gix, qs, k, m, nrec, False)
+    ref = oix.predict_batch("canonical", flat, qo, k, m, nrec, False, threads=2)
+    assert np.array_equal(got_cnt, ref["counts"]) and np.array_equal(got_ids, ref["ids"])
+    np.testing.assert_allclose(got_sc, ref["scores"], rtol=1e-12, atol=0)
+    for q in range(0, len(qs), python_share):
+        want_ids, want_sc = _canonical_over_given_lists(lists, rows, ts, idf, qs[q], k, m, nrec, rank=rank)
+        c = int(got_cnt[q])
+        assert c == len(want_ids) and got_ids[q, :c].tolist() == want_ids, (q, qs[q])
+        np.testing.assert_allclose(got_sc[q, :c], want_sc, rtol=1e-12, atol=0)
+    return got_ids, got_sc, got_cnt
+
+
 @pytest.mark.gpu
 def test_avro_index_with_a_different_tie_break_uses_the_lists_as_given(tmp_path):
-    """Timestamps tie and the producer truncated its lists with ANOTHER tie-break than ours: the lists are not most-recent prefixes
-    under (Time, SessionIndex), the load must not fail and the answers are those of the lists as given."""
+    """Timestamps tie and the producer truncated its lists with ANOTHER tie-break than ours: the lists are not most-recent prefixes under (Time, SessionIndex), the load
+    must not fail and the answers are those of the lists as given.  Round 6: the loader infers the producer's order among equal timestamps, under which the
+    lists ARE complete -- the whole index stays on the fast kernels."""
     import serenade_amd as sa
     off, items, ts, ids = small_dataset(45, n_sessions=600, n_items=40, tied_timestamps=True)
     idf = _idf_like_builder(off, items, 1.0)
     m_index = 12
-    item_recs, sess_recs = _records(off, items, ts, idf, m_index=m_index, tie_break=+1)
-    AW.write_container(f"{tmp_path}/itemindex/a.avro", AW.ITEM_SCHEMA, item_recs, "snappy", compressor=AW.snappy_with_copies)
-    AW.write_container(f"{tmp_path}/sessionindex/a.avro", AW.SESSION_SCHEMA, sess_recs, "snappy")
+    item_recs, sess_recs, lists = _records(off, items, ts, idf, m_index=m_index, tie_break=+1)
+    _write(tmp_path, item_recs, sess_recs)
     gix = sa.VMISIndex.new_from_avro(tmp_path)
     n = len(ts)
     rows = [set(items[off[s]:off[s + 1]].tolist()) for s in range(n)]
-    per_item = {}
-    for s in range(n):
-        for it in items[off[s]:off[s + 1]].tolist():
-            per_item.setdefault(it, []).append(s)
-    # the loader re-orders every list by (Time, SessionIndex) descending; the SET of sessions is the producer's
-    lists = {it: sorted(sorted(ss, key=lambda s: (-int(ts[s]), s))[:m_index], key=lambda s: (int(ts[s]), s), reverse=True) for it, ss in per_item.items()}
-    differs = sum(lists[it] != sorted(ss, key=lambda s: (int(ts[s]), s), reverse=True)[:m_index] for it, ss in per_item.items())
-    assert differs > 0, "the fixture should contain lists that are not most-recent prefixes under our order"
-    qs = random_queries(7, ids, 120, max_len=4, unknown_rate=0.0)
-    k, m, nrec = 8, m_index, 10
-    got_ids, got_sc, got_cnt = sa.predict_batch(gix, qs, k, m, nrec, False)
-    for q, sess in enumerate(qs):
-        want_ids, want_sc = _canonical_over_given_lists(lists, rows, ts, idf, sess, k, m, nrec)
-        c = int(got_cnt[q])
-        assert c == len(want_ids), (q, sess)
-        np.testing.assert_allclose(got_sc[q, :c], want_sc, rtol=1e-12, atol=0)
-        # equal scores are ordered by public id ascending on both sides (sorted() above: (-score, id))
-        assert got_ids[q, :c].tolist() == want_ids, (q, sess)
+    canon = np.empty(n, np.int64); canon[np.lexsort((np.arange(n), ts))] = np.arange(n)
+    assert _violations(lists, rows, canon, m_index)[1] > 0, "the fixture should contain lists that are not most-recent prefixes under our order"
+    assert gix.info["incomplete_items"] == 0
+    qs = random_queries(7, ids, 300, max_len=4, unknown_rate=0.0)
+    _check_against_lists_as_given(sa, gix, lists, rows, off, items, ts, idf, qs, 8, m_index, 10, python_share=2)
+    nq, general, _ = gix.last_path_counts()
+    assert nq == len(qs) and general == 0
+
+
+@pytest.mark.gpu
+def test_avro_index_of_an_inconsistent_producer_stays_on_the_fast_kernels(tmp_path):
+    """VERDICT r5 item 1.  A production index (VMISIndex::new, vmis_index.rs:85-314, lists as given :201-228) whose producer (i) broke timestamp ties the other way on SOME
+    items -- no tie order explains all its cuts -- and (ii) kept the sessions longer than its length cut in the session index only (as the CSV path does, :79, :452).
+    Until round 5 one such list sent every query of every batch to the general kernel.  Now: answers == the lists as given; the prep kernel flags only the queries an
+    incomplete list can reach (PrepHead::unsafe), >= 95 % of the batch is served by the fast kernels, and a single-session call is the one-launch latency path."""
+    import serenade_amd as sa
+    off, items, ts, ids = _heavily_tied_dataset()
+    idf = _idf_like_builder(off, items, 1.0)
+    m_index, max_len = 40, 9
+    item_recs, sess_recs, lists = _records(off, items, ts, idf, m_index=m_index, tie_break=lambda j: +1 if j % 2 == 0 else -1, max_session_len=max_len)
+    _write(tmp_path, item_recs, sess_recs)
+    gix = sa.VMISIndex.new_from_avro(tmp_path)
+    n = len(ts)
+    assert sum(off[s + 1] - off[s] > max_len for s in range(n)) > 100          # (ii): sessions that are in no list
+    rows = [set(items[off[s]:off[s + 1]].tolist()) for s in range(n)]
+    rank = gix.session_recency()
+    viol, bad = _violations(lists, rows, rank, m_index)
+    assert gix.info["incomplete_items"] == bad and bad > 0
+    qs = random_queries(8, ids, 2000, max_len=4, unknown_rate=0.02)
+    # which queries CAN an incomplete list reach?  (srn_prep.h: max viol of the query's known items > x_lo, the most recent m-th entry of its full lists)
+    k, m, nrec = 30, m_index, 21
+    unsafe = []
+    for q in qs:
+        xlo = vm = 0
+        for it in set(q):
+            if it in lists:
+                l = sorted((int(rank[s]) for s in lists[it]), reverse=True)
+                if len(l) >= m:
+                    xlo = max(xlo, l[m - 1])
+                vm = max(vm, viol[it])
+        unsafe.append(vm > xlo)
+    assert 0 < sum(unsafe) <= len(qs) // 20
+    _check_against_lists_as_given(sa, gix, lists, rows, off, items, ts, idf, qs, k, m, nrec, python_share=8)
+    nq, general, _ = gix.last_path_counts()
+    assert nq == len(qs) and sum(unsafe) <= general <= len(qs) // 20, (general, sum(unsafe))   # (>= 95 % on the fast kernels)
+    # the same answers with the per-item test switched off (every query through the general kernel's row pass, as until round 5) -- and that IS what SRN_NO_VIOL does
+    import os
+    ref_rows = sa.predict_batch(gix, qs, k, m, nrec, False)
+    from serenade_amd import capi
+    os.environ["SRN_NO_VIOL"] = "1"; capi.reload_knobs()
+    try:
+        old_rows = sa.predict_batch(gix, qs, k, m, nrec, False)
+        assert gix.last_path_counts()[1] == len(qs)
+    finally:
+        del os.environ["SRN_NO_VIOL"]; capi.reload_knobs()
+    for x, y in zip(ref_rows, old_rows):
+        assert np.array_equal(x, y)
+    # single-session calls (srn_predict, the reference's call shape): a safe session is one fused launch, an unsafe one gets the general kernel behind it; both exact
+    safe_q = next(q for q, u in zip(qs, unsafe) if not u and all(it in lists for it in q))
+    unsafe_q = next(q for q, u in zip(qs, unsafe) if u)
+    for q, want_general in ((safe_q, 0), (unsafe_q, 1)):
+        got = sa.predict(gix, q, k, m, nrec, False)
+        want_ids, want_sc = _canonical_over_given_lists(lists, rows, ts, idf, q, k, m, nrec, rank=rank)
+        assert [i for i, _ in got] == want_ids
+        np.testing.assert_allclose([x for _, x in got], want_sc, rtol=1e-12, atol=0)
+        assert gix.last_path_counts()[:2] == (1, want_general), (q, gix.last_path_counts())
 
 
 @pytest.mark.gpu
