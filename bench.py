@@ -115,6 +115,14 @@ def main():
     ap.add_argument("--no-local-g8", action="store_true", help="N = 1: skip the item_sharded.local_g8 block (one rank's work of an 8-way item-sharded index, all 8 shards on this GPU)")
     ap.add_argument("--no-postings", action="store_true", help="N > 1: the lists pipeline (posting lists sharded too: every rank redoes all candidate work on exchanged list prefixes) instead of the neighbours pipeline")
     ap.add_argument("--selftest-launch", action="store_true", help="CPU check of the launcher and the control plane (gloo): no GPU, no timing")
+    ap.add_argument("--index", default="csr", help="csr: the index built by this library from the synthetic sessions (the headline); avro[:PRODUCER]: the same sessions through the "
+                    "reference's production route -- a stand-in for its offline producer (synth.avro_index; PRODUCER = ours | reverse | mixed | per-item: how it orders sessions of equal "
+                    "timestamp when it cuts a list; default reverse) writes <tmp>/itemindex + sessionindex Avro files, sessions of more than --producer-max-len items into the session index only, "
+                    "and srn_index_new_from_avro loads them (VMISIndex::new, vmis_index.rs:85-314); the parity gate then checks against the oracle's restatement of that constructor "
+                    "(lists as given).  N = 1 only; use with --tie-per-second > 1 (unique timestamps leave a producer nothing to do differently)")
+    ap.add_argument("--tie-per-second", type=int, default=1, help="coarsen the synthetic timestamps so that ~this many sessions share each value (1: unique, the headline)")
+    ap.add_argument("--max-session-len", type=int, default=34, help="csr: max_session_len of the build (34 keeps every synthetic session)")
+    ap.add_argument("--producer-max-len", type=int, default=30, help="avro: the producer's session-length cut (longer sessions are in the session index only)")
     ap.add_argument("--builder", default="gpu", choices=["gpu", "host"], help="index construction: rocPRIM sorts on the GPU, or the host builder (same bytes)")
     ap.add_argument("--parity", type=int, default=2048, help="queries of batch 0 checked against the canonical oracle before anything is timed (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -186,10 +194,34 @@ def main():
     do_rep, do_shard = mode in ("replicas", "both"), mode in ("item-sharded", "both")
     t0 = time.time()
     off, items, ts = synth.training_sessions(inter, n_items)
+    if args.tie_per_second > 1:
+        ts = synth.tie_timestamps(ts, args.tie_per_second)
     t_gen = time.time() - t0
     t0 = time.time()
-    # the whole index: what the replicas serve from, and (rank 0) where the per-query counters of the roofline come from
-    index = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw, device=local_rank, builder=args.builder) if (do_rep or rank == 0 or (do_shard and world > 1 and not args.no_postings)) else None
+    avro = None   # --index avro: what the producer wrote (the lists as given), for the checker
+    if args.index.startswith("avro"):
+        if world != 1:
+            print("bench.py: --index avro is a one-GPU line", file=sys.stderr)
+            sys.exit(2)
+        import shutil
+        import tempfile
+        producer = args.index.split(":", 1)[1] if ":" in args.index else "reverse"
+        tmpd = tempfile.mkdtemp(prefix="srn_avro_")
+        try:
+            t1 = time.time()
+            p_ids, p_off, p_sess, p_idf = synth.avro_index(tmpd, off, items, ts, m, args.producer_max_len, idfw, producer)
+            t_write = time.time() - t1
+            avro_bytes = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(tmpd) for f in fs)
+            t1 = time.time()
+            index = sa.VMISIndex.new_from_avro(tmpd, device=local_rank)
+            t_load = time.time() - t1
+        finally:
+            shutil.rmtree(tmpd, ignore_errors=True)
+        avro = {"producer": producer, "ids": p_ids, "off": p_off, "sess": p_sess, "idf": p_idf, "write_s": t_write, "load_s": t_load, "file_bytes": int(avro_bytes)}
+        args.no_local_g8 = True   # (the 8-shard block cuts shards from a CSR-built index)
+    else:
+        # the whole index: what the replicas serve from, and (rank 0) where the per-query counters of the roofline come from
+        index = sa.VMISIndex.from_sessions(off, items, ts, m, args.max_session_len, idfw, device=local_rank, builder=args.builder) if (do_rep or rank == 0 or (do_shard and world > 1 and not args.no_postings)) else None
     t_build = time.time() - t0
     shard = group = None
     t_shard = None
@@ -228,7 +260,11 @@ def main():
         if oracle_box["oix"] is None:
             from oracle import oracle as O   # the CPU oracle is the checker here (and the timed baseline at the end), never the thing measured
             t1 = time.time()
-            oracle_box["oix"] = O.OracleIndex(off, items, ts, m, 34, idfw, fast=True)
+            if avro is not None:   # VMISIndex::new restated: the producer's lists, idf and flags as given; ties among equal timestamps in the order the product serves with
+                oracle_box["oix"] = O.OracleIndex.from_parts(avro["ids"], (avro["off"], avro["sess"]), avro["idf"], np.full(len(avro["ids"]), 2, np.uint8), off, items, ts,
+                                                             tie_rank=index.session_recency())
+            else:
+                oracle_box["oix"] = O.OracleIndex(off, items, ts, m, args.max_session_len, idfw, fast=True)
             oracle_box["t_build"] = time.time() - t1
         return oracle_box["oix"]
 
@@ -649,7 +685,18 @@ def main():
                        "sessions": int(info["n_sessions_kept"]), "items": int(info["n_items"]), "interactions": int(info["nnz_rows"]),
                        "posting_entries": int(info["nnz_postings"]), "index_bytes_hbm": int(info["device_bytes"]),
                        "parallelism": "query-sharded replicas x%d (no data-path collective)" % args.gpus,
-                       "setup_s": {"generate": round(t_gen, 2), "index_build_upload": round(t_build, 2), "index_builder": args.builder}},
+                       "setup_s": {"generate": round(t_gen, 2), "index_build_upload": round(t_build, 2), "index_builder": args.builder if avro is None else "avro loader"},
+                       "index": "csr (built by this library)" if avro is None else "avro (pre-built: VMISIndex::new, vmis_index.rs:85-314)",
+                       "timestamps": "unique" if args.tie_per_second <= 1 else "~%d sessions per timestamp value" % args.tie_per_second,
+                       "max_session_len": args.max_session_len if avro is None else None,
+                       "avro": None if avro is None else {
+                           "producer_tie_order": avro["producer"], "producer_max_session_len": args.producer_max_len, "file_bytes": avro["file_bytes"],
+                           "write_s": round(avro["write_s"], 2), "load_parse_infer_upload_s": round(avro["load_s"], 2),
+                           "sessions_in_the_session_index": int(info["n_sessions_total"]), "sessions_named_by_some_list": int(info["n_sessions_kept"]),
+                           "incomplete_items": int(info["incomplete_items"]),
+                           "tie_order_inference": "off (SRN_AVRO_NO_TIE_INFERENCE)" if os.environ.get("SRN_AVRO_NO_TIE_INFERENCE") else "on",
+                           "queries_of_the_last_step_on_the_general_kernel": int(general_last), "share_on_the_fast_kernels": (nq_last - general_last) / float(max(1, nq_last)),
+                           "checker": "oracle restatement of VMISIndex::new (orc_index_from_parts): lists, idf, flags as given; ties among equal timestamps in the order the index serves with (srn_index_session_recency)"}},
             "parity_checked": parity_checked, "parity_checked_positions": "uniform over batch (seeded permutation of the full-size launch's rows, its first and last 32 included)", "full_batch_properties_ok": props_ok,
             "roofline": {"bound": "hbm", "kernel": "vmis_fast_kernel" if fast_used else "vmis_predict_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE)",

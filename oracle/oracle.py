@@ -126,9 +126,12 @@ class OracleIndex:
         self.L = lib()
         self.sess_off, self.items, self.ts = _u64(sess_off), _u64(sess_items), np.ascontiguousarray(ts, np.uint32)
         self.tie = None if tie_rank is None else np.ascontiguousarray(tie_rank, np.uint32)
-        lo = np.zeros(len(item_ids) + 1, np.uint64)
-        lo[1:] = np.cumsum([len(x) for x in lists])
-        flat = np.ascontiguousarray(np.concatenate([np.asarray(x, np.uint32) for x in lists]) if len(lists) else np.zeros(0, np.uint32), np.uint32)
+        if isinstance(lists, tuple):       # (list_off u64[n + 1], sessions u32[nnz]) already flat
+            lo, flat = _u64(lists[0]), np.ascontiguousarray(lists[1], np.uint32)
+        else:
+            lo = np.zeros(len(item_ids) + 1, np.uint64)
+            lo[1:] = np.cumsum([len(x) for x in lists])
+            flat = np.ascontiguousarray(np.concatenate([np.asarray(x, np.uint32) for x in lists]) if len(lists) else np.zeros(0, np.uint32), np.uint32)
         if len(flat) == 0:
             flat = np.zeros(1, np.uint32)
         self.h = self.L.orc_index_from_parts(_u64(item_ids), lo, flat, np.ascontiguousarray(idf, np.float64), np.ascontiguousarray(flags, np.uint8), len(item_ids),

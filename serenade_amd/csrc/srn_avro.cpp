@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <numeric>
@@ -255,7 +256,14 @@ int build_flat_index_from_avro(const char* base_path, FlatIndex& ix) {
         if (ns == 0 || items.empty()) bad("empty index");
         if (items.size() >= 0xFFFFFFF0ull || ns + items.size() >= 0xFFFFFFF0ull) bad("too many items / sessions");
         ix = FlatIndex();
-        ix.n_sessions_total = ns; ix.n_kept = ns; ix.idf_weighting = 1.0;
+        // A session that no list names can never be a candidate (vmis_index.rs:332-391), so it is never a neighbour and its row is never read (mod.rs:131): like the TSV
+        // builder with the sessions beyond max_session_len (:452), the loader keeps neither row nor rank for it -- a producer that writes such sessions into the
+        // session index only (the CSV path keeps their rows too, :79) costs no memory, and items that occur in such rows alone need no item record
+        std::vector<uint8_t> listed((ns + 7) / 8, 0);
+        for (const Item& it : items) for (uint32_t s : it.sessions) listed[s >> 3] |= (uint8_t)(1u << (s & 7));
+        auto is_listed = [&](size_t s) -> bool { return listed[s >> 3] >> (s & 7) & 1; };
+        uint64_t n_listed = 0; for (size_t s = 0; s < ns; ++s) n_listed += is_listed(s);
+        ix.n_sessions_total = ns; ix.n_kept = n_listed; ix.idf_weighting = 1.0;
         // dense idx = popularity order over the session rows (count desc, id asc), as in the TSV builder
         std::sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.id < b.id; });
         for (size_t i = 1; i < items.size(); ++i) if (items[i].id == items[i - 1].id) bad("item " + std::to_string(items[i].id) + " appears twice in the item index");
@@ -265,6 +273,7 @@ int build_flat_index_from_avro(const char* base_path, FlatIndex& ix) {
         std::vector<uint64_t> row_base(ns + 1, 0);   // rows flattened by SessionIndex: where row s starts
         std::vector<uint32_t> row_item;              // ... and its items as by-id positions (ascending, like the ids)
         for (size_t s = 0; s < ns; ++s) { uint64_t prev = 0; bool first = true;
+            if (!is_listed(s)) { row_base[s + 1] = row_item.size(); std::vector<uint64_t>().swap(rows[s]); continue; }
             for (uint64_t id : rows[s]) { if (!first && id <= prev) bad("session rows must be strictly ascending item ids (item_ids_asc)"); prev = id; first = false;
                 const size_t j = find_item(id); if (j == (size_t)-1) bad("item " + std::to_string(id) + " of a session row has no item-index record (the reference would panic when scoring it: vmis_index.rs:321-323)");
                 ++cnt[j]; ++ix.nnz_rows; row_item.push_back((uint32_t)j); }
@@ -272,20 +281,21 @@ int build_flat_index_from_avro(const char* base_path, FlatIndex& ix) {
         ix.total_pairs = ix.nnz_rows; ix.n_items = items.size();
         for (const Item& it : items) ix.m_index = std::max<uint64_t>(ix.m_index, it.sessions.size());
         // ---- which (session, item) pairs the lists cover; which sessions are listed at all; per item the Time of its oldest entry ----
-        std::vector<uint8_t> covered((ix.nnz_rows + 7) / 8, 0), listed((ns + 7) / 8, 0), foreign(items.size(), 0);   // foreign: the list names a session whose row does not hold the item
+        std::vector<uint8_t> covered((ix.nnz_rows + 7) / 8, 0), foreign(items.size(), 0);   // foreign: the list names a session whose row does not hold the item
         std::vector<uint32_t> t_old(items.size(), 0xFFFFFFFFu);
         for (size_t j = 0; j < items.size(); ++j) {
             std::vector<uint32_t> seen = items[j].sessions; std::sort(seen.begin(), seen.end());
             for (size_t e = 1; e < seen.size(); ++e) if (seen[e] == seen[e - 1]) bad("item " + std::to_string(items[j].id) + " lists a session twice");
             for (uint32_t s : items[j].sessions) {
-                listed[s >> 3] |= (uint8_t)(1u << (s & 7)); t_old[j] = std::min(t_old[j], times[s]);
+                t_old[j] = std::min(t_old[j], times[s]);
                 const uint32_t* lo = std::lower_bound(row_item.data() + row_base[s], row_item.data() + row_base[s + 1], (uint32_t)j);
                 if (lo != row_item.data() + row_base[s + 1] && *lo == j) { const uint64_t b = (uint64_t)(lo - row_item.data()); covered[b >> 3] |= (uint8_t)(1u << (b & 7)); }
                 else foreign[j] = 1;
             }
         }
         // ---- recency = (Time, tie order inferred from the full lists' cuts, SessionIndex where they say nothing) ----
-        ix.rank_to_session.resize(ns); std::iota(ix.rank_to_session.begin(), ix.rank_to_session.end(), 0u);
+        ix.rank_to_session.clear(); ix.rank_to_session.reserve(n_listed);
+        for (size_t s = 0; s < ns; ++s) if (is_listed(s)) ix.rank_to_session.push_back((uint32_t)s);
         std::sort(ix.rank_to_session.begin(), ix.rank_to_session.end(), [&](uint32_t a, uint32_t b) { return times[a] != times[b] ? times[a] < times[b] : a < b; });
         {
             // edges of every group, as (Time, edge): kept entry -> virtual node of the item -> cut session
@@ -294,8 +304,7 @@ int build_flat_index_from_avro(const char* base_path, FlatIndex& ix) {
             std::vector<uint32_t> min_kept(items.size(), 0xFFFFFFFFu);
             for (int pass = 0; pass < 2; ++pass)   // pass 0: which items have both sides in their last entry's group; pass 1: their edges
                 for (size_t s = 0; s < ns; ++s) {
-                    if (!(listed[s >> 3] >> (s & 7) & 1)) continue;
-                    for (uint64_t b = row_base[s]; b < row_base[s + 1]; ++b) {
+                    for (uint64_t b = row_base[s]; b < row_base[s + 1]; ++b) {   // (unlisted sessions have no row here)
                         const uint32_t j = row_item[b];
                         if (times[s] != t_old[j]) continue;
                         const bool cov = covered[b >> 3] >> (b & 7) & 1;
@@ -303,13 +312,14 @@ int build_flat_index_from_avro(const char* base_path, FlatIndex& ix) {
                         else if (has_kept[j] && has_cut[j]) ge.push_back(GE{times[s], cov ? TieEdge{(uint32_t)s, (uint32_t)(ns + j)} : TieEdge{(uint32_t)(ns + j), (uint32_t)s}});
                     }
                 }
+            if (getenv("SRN_AVRO_NO_TIE_INFERENCE")) ge.clear();   // (A/B knob: ties by SessionIndex, as until round 5 -- what the per-item test then has to carry)
             std::sort(ge.begin(), ge.end(), [](const GE& a, const GE& b) { return a.time < b.time; });
             size_t g0 = 0, r0 = 0;   // r0: cursor into rank_to_session (ascending Time)
             std::vector<uint32_t> sess, virt, emitted; std::vector<uint64_t> vkey; std::vector<TieEdge> edges;
             while (g0 < ge.size()) {
                 size_t g1 = g0; while (g1 < ge.size() && ge[g1].time == ge[g0].time) ++g1;
                 while (times[ix.rank_to_session[r0]] != ge[g0].time) ++r0;
-                size_t r1 = r0; while (r1 < ns && times[ix.rank_to_session[r1]] == ge[g0].time) ++r1;
+                size_t r1 = r0; while (r1 < n_listed && times[ix.rank_to_session[r1]] == ge[g0].time) ++r1;
                 sess.assign(ix.rank_to_session.begin() + r0, ix.rank_to_session.begin() + r1);   // ascending SessionIndex
                 edges.clear(); virt.clear();
                 for (size_t g = g0; g < g1; ++g) { edges.push_back(ge[g].e); const TieEdge& e = ge[g].e; virt.push_back((e.from >= ns ? e.from : e.to) - (uint32_t)ns); }
@@ -320,15 +330,15 @@ int build_flat_index_from_avro(const char* base_path, FlatIndex& ix) {
                 g0 = g1; r0 = r1;
             }
         }
-        std::vector<uint32_t> rank_of(ns); for (size_t r = 0; r < ns; ++r) rank_of[ix.rank_to_session[r]] = (uint32_t)r;
+        std::vector<uint32_t> rank_of(ns, kNone); for (size_t r = 0; r < n_listed; ++r) rank_of[ix.rank_to_session[r]] = (uint32_t)r;
         std::vector<uint32_t> order(items.size()); std::iota(order.begin(), order.end(), 0u);
         std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cnt[a] != cnt[b] ? cnt[a] > cnt[b] : items[a].id < items[b].id; });
         std::vector<uint32_t> idx_of(items.size());   // by-id position -> dense idx
         ix.item_id.resize(ix.n_items); ix.id_rank.resize(ix.n_items); ix.idf.resize(ix.n_items); ix.attr.resize(ix.n_items);
         for (uint32_t i = 0; i < ix.n_items; ++i) { const uint32_t j = order[i]; idx_of[j] = i; ix.item_id[i] = items[j].id; ix.id_rank[i] = j; ix.idf[i] = items[j].idf; ix.attr[i] = items[j].attr; }
         // rows by rank
-        ix.row_off.assign(ns + 1, 0); ix.row_items.reserve(ix.nnz_rows);
-        for (size_t r = 0; r < ns; ++r) { const uint32_t s = ix.rank_to_session[r];
+        ix.row_off.assign(n_listed + 1, 0); ix.row_items.reserve(ix.nnz_rows);
+        for (size_t r = 0; r < n_listed; ++r) { const uint32_t s = ix.rank_to_session[r];
             for (uint64_t b = row_base[s]; b < row_base[s + 1]; ++b) ix.row_items.push_back(idx_of[row_item[b]]);
             ix.row_off[r + 1] = ix.row_items.size(); ix.max_row_len = std::max<uint64_t>(ix.max_row_len, row_base[s + 1] - row_base[s]); }
         ix.max_session_len = ix.max_row_len;
@@ -354,7 +364,6 @@ int build_flat_index_from_avro(const char* base_path, FlatIndex& ix) {
         { std::vector<uint32_t> viol(ix.n_items, 0u);
           for (uint32_t i = 0; i < ix.n_items; ++i) if (foreign[order[i]]) viol[i] = 0xFFFFFFFFu;
           for (size_t s = 0; s < ns; ++s) {
-              if (!(listed[s >> 3] >> (s & 7) & 1)) continue;
               for (uint64_t b = row_base[s]; b < row_base[s + 1]; ++b)
                   if (!(covered[b >> 3] >> (b & 7) & 1)) { uint32_t& v = viol[idx_of[row_item[b]]]; v = std::max<uint32_t>(v, rank_of[s] + 1u); }
           }

@@ -207,7 +207,7 @@ int srn_index_items_for_session(const srn_index_t* idx, uint32_t session, uint64
         const uint32_t r = idx->session_to_rank[session];
         // (the reference keeps the rows of ALL sessions, vmis_index.rs:79, but only sessions of <= max_session_len items enter the posting lists, :452 -- and only those can
         //  ever be neighbours, so only their rows are kept here)
-        if (r == kNone) return fail(SRN_ERANGE, "this session is longer than max_session_len: it is in no posting list (vmis_index.rs:452), never a neighbour, and its row is not kept");
+        if (r == kNone) return fail(SRN_ERANGE, "this session is in no posting list (longer than max_session_len, vmis_index.rs:452, or named by no list of a pre-built index): never a neighbour, and its row is not kept");
         const uint64_t o0 = f.row_off[r], o1 = f.row_off[r + 1];
         *out_len = (size_t)(o1 - o0);
         if (out_items) for (uint64_t t = o0; t < o1 && t - o0 < cap; ++t) out_items[t - o0] = f.item_id[f.row_items[t]];   // (row order = ascending public id, as the reference's item_ids_asc)

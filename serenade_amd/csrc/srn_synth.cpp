@@ -17,7 +17,9 @@
 #include <atomic>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -178,5 +180,118 @@ void srn_synth_copy_queries(void* h, uint64_t* q_items, uint32_t* q_off) {
     memcpy(q_items, S->q_items.data(), S->q_items.size() * 8); memcpy(q_off, S->q_off.data(), S->q_off.size() * 4);
 }
 void srn_synth_free(void* h) { delete (Synth*)h; }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// A stand-in for the OFFLINE PRODUCER of the reference's pre-built index (the Spark job behind VMISIndex::new, src/vmisknn/vmis_index.rs:85-314; its code is not in the
+// reference repository): per item the m_index most recent sessions that hold it, idf, flags -- and the files in the Avro layout srn_index_new_from_avro reads
+// (schemas :184-192, :249-255; codec "null").  What the producer is free to do differently from this library's builder, and what the knobs emulate:
+//   * sessions of more than max_len items go to the session index only, into no list (the CSV path does the same: :79, :452);
+//   * tie_mode -- the order among sessions of EQUAL timestamp when a list is cut: 0 larger SessionIndex first (this library's builder), 1 smaller first,
+//     2 larger first for every other item and smaller for the rest, 3 a different pseudo-random order PER ITEM (a window function without a tie-break column).
+// Workload generator code: no product or oracle code involved.
+struct Producer { std::vector<uint64_t> item_ids, list_off; std::vector<uint32_t> list_sessions; std::vector<double> idf; };
+
+void* srn_synth_producer(const uint64_t* off, const uint64_t* items, const uint32_t* ts, uint64_t n_sessions, uint64_t m_index, uint64_t max_len, double idf_weighting, int tie_mode) {
+    struct Pair { uint64_t id, key; uint32_t s; };
+    std::vector<Pair> pairs; uint64_t total = 0;
+    for (uint64_t s = 0; s < n_sessions; ++s) if (off[s + 1] - off[s] <= max_len) total += off[s + 1] - off[s];
+    pairs.reserve(total);
+    for (uint64_t s = 0; s < n_sessions; ++s) {
+        if (off[s + 1] - off[s] > max_len) continue;
+        for (uint64_t j = off[s]; j < off[s + 1]; ++j) {
+            const uint64_t id = items[j];
+            uint32_t tie;
+            switch (tie_mode) {
+                case 0: tie = ~(uint32_t)s; break;
+                case 1: tie = (uint32_t)s; break;
+                case 2: tie = (splitmix_once(id) & 1) ? (uint32_t)s : ~(uint32_t)s; break;
+                default: tie = (uint32_t)splitmix_once(id * 0x9E3779B97F4A7C15ULL ^ s); break;
+            }
+            pairs.push_back(Pair{id, ((uint64_t)(~ts[s]) << 32) | tie, (uint32_t)s});   // ascending key = most recent first
+        }
+    }
+    std::sort(pairs.begin(), pairs.end(), [](const Pair& a, const Pair& b) { return a.id != b.id ? a.id < b.id : a.key != b.key ? a.key < b.key : a.s < b.s; });
+    Producer* P = new Producer(); P->list_off.push_back(0);
+    for (size_t i = 0; i < pairs.size();) {
+        size_t j = i; while (j < pairs.size() && pairs[j].id == pairs[i].id) ++j;
+        P->item_ids.push_back(pairs[i].id);
+        for (size_t e = i; e < j && e - i < m_index; ++e) P->list_sessions.push_back(pairs[e].s);
+        P->list_off.push_back(P->list_sessions.size());
+        P->idf.push_back(std::log((double)total / (double)(j - i)) * idf_weighting);   // (prepare_hashmap's formula, vmis_index.rs:509-512)
+        i = j;
+    }
+    return P;
+}
+uint64_t srn_synth_producer_n_items(void* h) { return ((Producer*)h)->item_ids.size(); }
+uint64_t srn_synth_producer_nnz(void* h) { return ((Producer*)h)->list_sessions.size(); }
+void srn_synth_producer_copy(void* h, uint64_t* item_ids, uint64_t* list_off, uint32_t* list_sessions, double* idf) {
+    Producer* P = (Producer*)h;
+    memcpy(item_ids, P->item_ids.data(), P->item_ids.size() * 8); memcpy(list_off, P->list_off.data(), P->list_off.size() * 8);
+    memcpy(list_sessions, P->list_sessions.data(), P->list_sessions.size() * 4); memcpy(idf, P->idf.data(), P->idf.size() * 8);
+}
+void srn_synth_producer_free(void* h) { delete (Producer*)h; }
+
+}  // extern "C"
+
+namespace {
+struct AvroOut {
+    FILE* f = nullptr; std::vector<uint8_t> blk; uint64_t in_blk = 0; uint8_t sync[16];
+    static void zz(std::vector<uint8_t>& o, int64_t v) { uint64_t n = ((uint64_t)v << 1) ^ (uint64_t)(v >> 63); while (n >= 0x80) { o.push_back((uint8_t)(n | 0x80)); n >>= 7; } o.push_back((uint8_t)n); }
+    bool open(const std::string& path, const char* schema) {
+        f = fopen(path.c_str(), "wb"); if (!f) return false;
+        for (int i = 0; i < 16; ++i) sync[i] = (uint8_t)(i * 37 + 11);
+        std::vector<uint8_t> h = {'O', 'b', 'j', 1};
+        zz(h, 2);
+        auto str = [&](const char* t) { const size_t n = strlen(t); zz(h, (int64_t)n); h.insert(h.end(), t, t + n); };
+        str("avro.schema"); str(schema); str("avro.codec"); str("null");
+        zz(h, 0); h.insert(h.end(), sync, sync + 16);
+        return fwrite(h.data(), 1, h.size(), f) == h.size();
+    }
+    bool flush() {
+        if (!in_blk) return true;
+        std::vector<uint8_t> h; zz(h, (int64_t)in_blk); zz(h, (int64_t)blk.size());
+        const bool ok = fwrite(h.data(), 1, h.size(), f) == h.size() && fwrite(blk.data(), 1, blk.size(), f) == blk.size() && fwrite(sync, 1, 16, f) == 16;
+        blk.clear(); in_blk = 0; return ok;
+    }
+    bool end_record() { ++in_blk; return blk.size() < (1u << 20) || flush(); }
+    bool close() { const bool ok = flush(); const bool ok2 = fclose(f) == 0; f = nullptr; return ok && ok2; }
+};
+}  // namespace
+
+extern "C" {
+
+// <base>/itemindex/part-N.avro + <base>/sessionindex/part-N.avro (the directories must exist); every session of the arrays gets a session record (SessionIndex = its position)
+int srn_synth_write_avro(const char* base, void* producer, const uint64_t* off, const uint64_t* items, const uint32_t* ts, uint64_t n_sessions, int n_files) {
+    const Producer* P = (const Producer*)producer;
+    if (n_files < 1) n_files = 1;
+    static const char* ITEM = "{\"type\": \"record\", \"name\": \"ItemIndex\", \"fields\": [{\"name\": \"ItemId\", \"type\": \"long\"}, {\"name\": \"session_indices_time_ordered\", \"type\": {\"type\": \"array\", \"items\": \"int\"}}, "
+                              "{\"name\": \"idf\", \"type\": \"double\"}, {\"name\": \"ForSale\", \"type\": \"boolean\"}, {\"name\": \"IsAdult\", \"type\": \"boolean\"}]}";
+    static const char* SESS = "{\"type\": \"record\", \"name\": \"SessionIndex\", \"fields\": [{\"name\": \"SessionIndex\", \"type\": \"int\"}, {\"name\": \"item_ids_asc\", \"type\": {\"type\": \"array\", \"items\": \"long\"}}, {\"name\": \"Time\", \"type\": \"int\"}]}";
+    const std::string b = base;
+    for (int part = 0; part < n_files; ++part) {
+        AvroOut o; if (!o.open(b + "/itemindex/part-" + std::to_string(part) + ".avro", ITEM)) return -1;
+        const size_t ni = P->item_ids.size();
+        for (size_t i = ni * (size_t)part / n_files; i < ni * (size_t)(part + 1) / n_files; ++i) {
+            AvroOut::zz(o.blk, (int64_t)P->item_ids[i]);
+            const uint64_t a = P->list_off[i], e = P->list_off[i + 1];
+            if (e > a) { AvroOut::zz(o.blk, (int64_t)(e - a)); for (uint64_t j = a; j < e; ++j) AvroOut::zz(o.blk, (int64_t)P->list_sessions[j]); }
+            AvroOut::zz(o.blk, 0);
+            uint8_t d[8]; memcpy(d, &P->idf[i], 8); o.blk.insert(o.blk.end(), d, d + 8);
+            o.blk.push_back(1); o.blk.push_back(0);   // ForSale, IsAdult
+            if (!o.end_record()) return -1;
+        }
+        if (!o.close()) return -1;
+        AvroOut q; if (!q.open(b + "/sessionindex/part-" + std::to_string(part) + ".avro", SESS)) return -1;
+        for (uint64_t s = n_sessions * (uint64_t)part / n_files; s < n_sessions * (uint64_t)(part + 1) / n_files; ++s) {
+            AvroOut::zz(q.blk, (int64_t)s);
+            if (off[s + 1] > off[s]) { AvroOut::zz(q.blk, (int64_t)(off[s + 1] - off[s])); for (uint64_t j = off[s]; j < off[s + 1]; ++j) AvroOut::zz(q.blk, (int64_t)items[j]); }
+            AvroOut::zz(q.blk, 0);
+            AvroOut::zz(q.blk, (int64_t)ts[s]);
+            if (!q.end_record()) return -1;
+        }
+        if (!q.close()) return -1;
+    }
+    return 0;
+}
 
 }  // extern "C"

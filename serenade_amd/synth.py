@@ -45,6 +45,16 @@ def lib():
         L.srn_synth_copy_training.argtypes = [vp, vp, vp, vp]
         L.srn_synth_copy_queries.argtypes = [vp, vp, vp]
         L.srn_synth_free.argtypes = [vp]
+        L.srn_synth_producer.restype = vp
+        L.srn_synth_producer.argtypes = [vp, vp, vp, u64, u64, u64, C.c_double, C.c_int]
+        L.srn_synth_producer_n_items.restype = u64
+        L.srn_synth_producer_n_items.argtypes = [vp]
+        L.srn_synth_producer_nnz.restype = u64
+        L.srn_synth_producer_nnz.argtypes = [vp]
+        L.srn_synth_producer_copy.argtypes = [vp, vp, vp, vp, vp]
+        L.srn_synth_producer_free.argtypes = [vp]
+        L.srn_synth_write_avro.restype = C.c_int
+        L.srn_synth_write_avro.argtypes = [C.c_char_p, vp, vp, vp, vp, u64, C.c_int]
         _lib = L
     return _lib
 
@@ -73,3 +83,30 @@ def queries(n_sessions, n_items, seed=SEED, alpha=ZIPF_ALPHA, max_items=LAST_ITE
     L.srn_synth_copy_queries(h, items.ctypes.data, off.ctypes.data)
     L.srn_synth_free(h)
     return items, off
+
+
+TIE_MODES = {"ours": 0, "reverse": 1, "mixed": 2, "per-item": 3}
+
+
+def tie_timestamps(ts, per_second, t0=T0):
+    """The unique synthetic timestamps at a coarser clock: ~per_second sessions share each value (production data has second resolution)."""
+    return (t0 + (ts.astype(np.int64) - t0) // int(per_second)).astype(np.uint32)
+
+
+def avro_index(base, off, items, ts, m_index, max_len, idf_weighting, tie_mode="reverse", files=4):
+    """A stand-in for the reference's offline index producer (srn_synth.cpp): writes <base>/itemindex/*.avro + <base>/sessionindex/*.avro and returns what it
+    wrote as arrays (item_ids ascending, list_off, list_sessions, idf) -- the lists AS GIVEN, for a checker."""
+    L = lib()
+    off, items, ts = np.ascontiguousarray(off, np.uint64), np.ascontiguousarray(items, np.uint64), np.ascontiguousarray(ts, np.uint32)
+    n = len(ts)
+    h = L.srn_synth_producer(off.ctypes.data, items.ctypes.data, ts.ctypes.data, n, int(m_index), int(max_len), float(idf_weighting), TIE_MODES[tie_mode])
+    ni, nnz = L.srn_synth_producer_n_items(h), L.srn_synth_producer_nnz(h)
+    ids, loff, lsess, idf = np.empty(ni, np.uint64), np.empty(ni + 1, np.uint64), np.empty(max(nnz, 1), np.uint32), np.empty(ni, np.float64)
+    L.srn_synth_producer_copy(h, ids.ctypes.data, loff.ctypes.data, lsess.ctypes.data, idf.ctypes.data)
+    os.makedirs(os.path.join(base, "itemindex"), exist_ok=True)
+    os.makedirs(os.path.join(base, "sessionindex"), exist_ok=True)
+    rc = L.srn_synth_write_avro(str(base).encode(), h, off.ctypes.data, items.ctypes.data, ts.ctypes.data, n, int(files))
+    L.srn_synth_producer_free(h)
+    if rc:
+        raise IOError("could not write the Avro index under %s" % base)
+    return ids, loff, lsess[:nnz], idf

@@ -127,8 +127,19 @@ def test_avro_index_contents_on_host(tmp_path, codec):
     ix = sa.VMISIndex.new_from_avro(tmp_path, device=-1)
     ref = sa.VMISIndex.from_sessions(off, items, ts, 40, 10**6, 1.0, device=-1)
     info, rinfo = ix.info, ref.info
-    for key in ("n_items", "n_sessions_kept", "nnz_rows", "nnz_postings", "m_index"):
+    for key in ("n_items", "nnz_postings", "m_index", "n_sessions_total"):
         assert info[key] == rinfo[key], key
+    # rows and ranks only for the sessions some list names (round 6): the others can never be neighbours
+    n = len(ts)
+    order = np.lexsort((np.arange(n), ts)); rank = np.empty(n, np.int64); rank[order] = np.arange(n)
+    listed = sorted(set(s for ss in per_item.values() for s in sorted(ss, key=lambda s: -rank[s])[:40]))
+    assert info["n_sessions_kept"] == len(listed) < rinfo["n_sessions_kept"] and info["nnz_rows"] == sum(int(off[s + 1] - off[s]) for s in listed)
+    assert info["incomplete_items"] == 0
+    rec = ix.session_recency()
+    assert np.flatnonzero(rec != 0xFFFFFFFF).tolist() == listed and np.array_equal(np.argsort(rec[listed]), np.argsort(rank[listed]))
+    assert ix.items_for_session(listed[0]).tolist() == items[off[listed[0]]:off[listed[0] + 1]].tolist()
+    with pytest.raises(sa.SerenadeError):
+        ix.items_for_session(next(s for s in range(n) if s not in set(listed)))
     for it in list(per_item)[:60] + [int(ids[0]), int(ids[1])]:
         a, b = ix.postings(it), ref.postings(it)
         assert np.array_equal(a[0], b[0]) and a[1] == pytest.approx(b[1], rel=0, abs=0)      # same sessions, same order, the file's idf
@@ -289,8 +300,12 @@ def test_the_loader_infers_the_producers_tie_order():
             _write(d, item_recs, sess_recs)
             ix = sa.VMISIndex.new_from_avro(d, device=-1)
         rank = ix.session_recency()
-        assert sorted(rank.tolist()) == list(range(n))                      # a permutation: every session of the session index keeps its row
-        assert all(ts[a] <= ts[b] for a, b in zip(np.argsort(rank)[:-1], np.argsort(rank)[1:]))   # ... ordered by Time; only the order among equal Times is the loader's
+        kept = np.flatnonzero(rank != 0xFFFFFFFF)
+        assert kept.tolist() == sorted(set(s for l in lists.values() for s in l))   # the sessions some list names keep a row and a rank; the others (> max_len items) neither
+        assert sorted(rank[kept].tolist()) == list(range(len(kept)))
+        by_rank = kept[np.argsort(rank[kept])]
+        assert all(ts[a] <= ts[b] for a, b in zip(by_rank[:-1], by_rank[1:]))   # ... ordered by Time; only the order among equal Times is the loader's
+        canon = np.full(n, 0xFFFFFFFF, np.int64); canon[kept[np.lexsort((kept, ts[kept]))]] = np.arange(len(kept))
         viol, bad = _violations(lists, rows, rank, m_index)
         assert ix.info["incomplete_items"] == bad, name
         for it in list(lists)[:25]:                                          # the lists are the producer's SETS, most recent first under the index's order
@@ -318,7 +333,8 @@ def _check_against_lists_as_given(sa, gix, lists, rows, off, items, ts, idf, qs,
     from oracle import oracle as O
     rank = gix.session_recency()
     n = len(ts)
-    order = np.argsort(rank)
+    kept = np.flatnonzero(rank != 0xFFFFFFFF)
+    order = kept[np.argsort(rank[kept])]
     assert all(ts[a] <= ts[b] for a, b in zip(order[:-1], order[1:]))       # the order the product serves with refines Time: only ties are its own
     its = sorted(lists)
     oix = O.OracleIndex.from_parts(its, [lists[i] for i in its], [idf[i] for i in its], [2] * len(its), off, items, ts, tie_rank=rank)
