@@ -241,11 +241,12 @@ def main():
         need = B * pool
         n_sess = max(1024, int(need / 3.2) + 4096)
         while True:
-            q_items, q_off = synth.queries(n_sess, n_items, seed=synth.SEED + 7919 * (seed_rank + 1), max_items=last_items)
+            q_items, q_off, q_next = synth.queries(n_sess, n_items, seed=synth.SEED + 7919 * (seed_rank + 1), max_items=last_items, with_next=True)
             if len(q_off) - 1 >= need:
                 break
             n_sess = int(n_sess * 1.5)
         out = []
+        draw_batches.next_items = [q_next[b * B:(b + 1) * B] for b in range(pool)]   # the held-out item behind each query (evaluator.rs:75), for literal_vs_canonical
         for b in range(pool):
             lo, hi = b * B, (b + 1) * B
             fo = q_off[lo:hi + 1].astype(np.int64)
@@ -481,6 +482,7 @@ def main():
     def replicas_phase():
         B = args.batch
         batches = draw_batches(B, args.pool, rank)                        # every rank draws its own slice of the query stream
+        next0 = draw_batches.next_items[0]
         out_ids = torch.zeros(B * how_many, dtype=torch.int64, device=dev)
         out_sc = torch.zeros(B * how_many, dtype=torch.float64, device=dev)
         out_cnt = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -745,6 +747,16 @@ def main():
             one = {"p%s" % str(q).replace(".", "_"): float(np.percentile(r1["lat_us"], q)) for q in (25, 50, 75, 90, 95, 99.5)}
             one.update({"queries": n_one, "seconds": float(r1["elapsed"]), "queries_per_s": n_one / r1["elapsed"],
                         "note": "one host thread, one evolving session per call like evaluator.rs:46-76; the percentiles the reference prints (p25/50/75/90/95/99.5, microseconds)"})
+            # What the canonical refinement costs against the literal loops AT THIS CONFIG: the first n_lvc queries of the timed batch through both
+            # restatements and through the product, the evaluator's Mrr@20 / HitRate@20 against the held-out next item of each query
+            from oracle import refinement as RF
+            n_lvc = int(min(n_cpu, 32768))
+            hip_rows = sa.predict_batch(index, (flat0[:qo0[n_lvc]], qo0[:n_lvc + 1]), k, m, how_many, False)
+            t1 = time.time()
+            lvc = RF.literal_vs_canonical(oix, flat0[:qo0[n_lvc]], qo0[:n_lvc + 1], next0[:n_lvc], k, m, how_many, threads=cores, hip=hip_rows)
+            lvc["seconds"] = round(time.time() - t1, 2)
+            lvc["sample"] = "first %d queries of the timed batch" % n_lvc
+            result["literal_vs_canonical"] = lvc
             result["cpu_baseline"] = {
                 "single_thread_per_call_us": one,
                 "value": n_cpu / r["elapsed"], "unit": "queries/s", "cores": cores, "kind": "port",

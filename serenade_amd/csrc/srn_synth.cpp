@@ -82,6 +82,7 @@ constexpr size_t CHUNK = 4096;
 struct Synth {
     std::vector<uint64_t> off, items; std::vector<uint32_t> ts;   // training sessions (rows ascending, de-duplicated)
     std::vector<uint64_t> q_items; std::vector<uint32_t> q_off;    // queries
+    std::vector<uint64_t> q_next;                                   // the held-out item that followed each query's prefix (evaluator.rs:75: next_items[0], what Mrr / HitRate look at)
 };
 
 static void gen_chunk(uint64_t seed, uint64_t stream, size_t chunk, const Alias& al, const std::vector<uint64_t>& ids,
@@ -161,6 +162,7 @@ void* srn_synth_queries(uint64_t seed, uint64_t n_sessions, uint64_t n_items, do
                 const uint32_t start = state > max_items ? state - max_items : 0;
                 S->q_items.insert(S->q_items.end(), ev + start, ev + state);
                 S->q_off.push_back((uint32_t)S->q_items.size());
+                S->q_next.push_back(ev[state]);
             }
         }
     }
@@ -179,6 +181,7 @@ void srn_synth_copy_queries(void* h, uint64_t* q_items, uint32_t* q_off) {
     Synth* S = (Synth*)h;
     memcpy(q_items, S->q_items.data(), S->q_items.size() * 8); memcpy(q_off, S->q_off.data(), S->q_off.size() * 4);
 }
+void srn_synth_copy_next(void* h, uint64_t* q_next) { Synth* S = (Synth*)h; memcpy(q_next, S->q_next.data(), S->q_next.size() * 8); }
 void srn_synth_free(void* h) { delete (Synth*)h; }
 
 // ---------------------------------------------------------------------------------------------------------------------------------

@@ -44,6 +44,7 @@ def lib():
             getattr(L, n).argtypes = [vp]
         L.srn_synth_copy_training.argtypes = [vp, vp, vp, vp]
         L.srn_synth_copy_queries.argtypes = [vp, vp, vp]
+        L.srn_synth_copy_next.argtypes = [vp, vp]
         L.srn_synth_free.argtypes = [vp]
         L.srn_synth_producer.restype = vp
         L.srn_synth_producer.argtypes = [vp, vp, vp, u64, u64, u64, C.c_double, C.c_int]
@@ -74,15 +75,20 @@ def training_sessions(n_interactions, n_items, seed=SEED, alpha=ZIPF_ALPHA, t0=T
     return off, items, ts
 
 
-def queries(n_sessions, n_items, seed=SEED, alpha=ZIPF_ALPHA, max_items=LAST_ITEMS):
-    """Evaluator-style query stream -> (items_flat u64, q_off u32[nq+1])."""
+def queries(n_sessions, n_items, seed=SEED, alpha=ZIPF_ALPHA, max_items=LAST_ITEMS, with_next=False):
+    """Evaluator-style query stream -> (items_flat u64, q_off u32[nq+1]); with_next: also next u64[nq], the held-out item that followed each prefix
+    (src/bin/evaluator.rs:75 -- the item Mrr / HitRate score a recommendation list against)."""
     L = lib()
     h = L.srn_synth_queries(seed, int(n_sessions), int(n_items), float(alpha), int(max_items), _threads())
     nq, nnz = L.srn_synth_n_queries(h), L.srn_synth_q_nnz(h)
     items, off = np.empty(nnz, np.uint64), np.empty(nq + 1, np.uint32)
     L.srn_synth_copy_queries(h, items.ctypes.data, off.ctypes.data)
+    nxt = None
+    if with_next:
+        nxt = np.empty(nq, np.uint64)
+        L.srn_synth_copy_next(h, nxt.ctypes.data)
     L.srn_synth_free(h)
-    return items, off
+    return (items, off, nxt) if with_next else (items, off)
 
 
 TIE_MODES = {"ours": 0, "reverse": 1, "mixed": 2, "per-item": 3}

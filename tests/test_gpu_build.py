@@ -47,3 +47,34 @@ def test_gpu_builder_rejects_unsorted_rows():
     with pytest.raises(sa.SerenadeError) as e:
         sa.VMISIndex.from_sessions(off, items[::-1].copy(), ts, 10, 12, 1.0, builder="gpu")
     assert e.value.code == -1
+
+
+@pytest.mark.parametrize("tied", [False, True])
+def test_gpu_built_index_content_equals_the_oracles_literal_prepare_hashmap(tied):
+    """A8 directly on the box that runs the benchmark: the index srn_index_build_gpu makes, item by item, against the ORACLE's literal restatement of
+    prepare_hashmap (vmis_index.rs:422-528) -- posting lists in order (timestamp desc, session index desc), cut to m (:497-504), idf (:509-512), the session-length filter (:452) --
+    not against the product's other builder."""
+    import serenade_amd as sa
+    from oracle import oracle as O
+    off, items, ts, ids = small_dataset(40 + tied, n_sessions=4000, n_items=300, tied_timestamps=tied)
+    for (m_index, max_len, idfw) in [(50, 7, 1.0), (1000, 12, 2.0), (1, 3, 0.0)]:
+        ix = sa.VMISIndex.from_sessions(off, items, ts, m_index, max_len, idfw, builder="gpu")
+        oix = O.OracleIndex(off, items, ts, m_index, max_len, idfw)          # fast=False: the literal loops
+        info = ix.info
+        lens = np.diff(off.astype(np.int64))
+        assert info["n_sessions_kept"] == int((lens <= max_len).sum())
+        assert info["n_items"] == oix.num_items and info["nnz_rows"] == oix.total_pairs
+        n_lists = 0
+        for it in ids:
+            a, ia = ix.postings(int(it))
+            b, ib = oix.postings(int(it))
+            if b is None:
+                assert a is None
+                continue
+            assert np.array_equal(a, b), it
+            assert ia == ib                                                   # the same double
+            n_lists += 1
+        assert n_lists == info["n_items"] and ix.postings(5)[0] is None
+        # and the rows the scoring loop reads (items_for_session, vmis_index.rs:317-319) for the kept sessions
+        for s in np.flatnonzero(lens <= max_len)[:200]:
+            assert ix.items_for_session(int(s)).tolist() == items[off[s]:off[s + 1]].tolist()
