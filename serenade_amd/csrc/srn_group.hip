@@ -122,6 +122,7 @@ struct srn_shard_group {
     ncclComm_t comm[2] = {nullptr, nullptr};   // [0] exchange stream, [1] caller's stream: operations on one communicator serialise in issue order
     srn_shard_comm_t cb{};
     hipStream_t s_x = nullptr; hipEvent_t e_in = nullptr, e_x = nullptr;
+    int* agree_dev = nullptr;   // three flags of set_postings' agreement
     char* pres_all = nullptr; size_t pres_all_bytes = 0; uint8_t* nb_pbytes = nullptr;   // the shards' presence bitmaps (all-gathered at set_postings) and the byte per session made of them: bit g = shard g holds an item of the session
     bool stream_ok = false;   // every shard of this rank holds its fragments in the posting order of g->postings (set_postings): batches of the streaming form's shape exchange positions
     bool overlap = false, no_direct = false;   // overlap: opt-in (srn_shard_group_set_overlap) -- two communicators with collectives in flight at once have never been soaked on more than one GPU
@@ -580,7 +581,7 @@ void srn_shard_group_free(srn_shard_group_t* g) {
     if (g->s_x) hipStreamDestroy(g->s_x);
     if (g->e_in) hipEventDestroy(g->e_in); if (g->e_x) hipEventDestroy(g->e_x); if (g->e_last) hipEventDestroy(g->e_last);
     for (auto& e : g->e_t) if (e) hipEventDestroy(e);
-    if (g->pres_all) hipFree(g->pres_all); if (g->nb_pbytes) hipFree(g->nb_pbytes);
+    if (g->pres_all) hipFree(g->pres_all); if (g->nb_pbytes) hipFree(g->nb_pbytes); if (g->agree_dev) hipFree(g->agree_dev);
     delete g;
 }
 
@@ -602,62 +603,93 @@ int srn_debug_shard_group_times(const srn_shard_group_t* g, double* out3) {   //
     for (int i = 0; i < 3; ++i) out3[i] = g->last_ms[i];
     return SRN_OK;
 }
+// Collective over the group (every rank calls it with the postings of the same index, or every rank with NULL): what is rank-LOCAL and can fail -- packed rows that did
+// not fit at attach time, no room for the streaming form's second copy of the fragments, the presence bytes' buffers -- is attempted first, the outcomes are AGREED on
+// (one all-reduce-min of three flags), and only then is anything committed: either every rank takes the neighbours pipeline in the same exchange format, or none does.
+// (a rank that failed alone used to keep the lists pipeline while its peers issued the neighbours pipeline's collectives on the same communicator.)
 int srn_shard_group_set_postings(srn_shard_group_t* g, const srn_index_t* postings) {
     if (!g) return fail(SRN_EINVAL, "null group");
     std::lock_guard<std::mutex> lk(g->mu);
-    if (postings) {
-        if (!postings->dev) return fail(SRN_ENODEV, "the postings index has no device attached");
-        if (postings->flat.n_shards != 1) return fail(SRN_EINVAL, "the replicated postings are those of the UNSHARDED index (the index itself, or srn_index_postings_view of it)");
-        if (postings->device != g->device) return fail(SRN_EINVAL, "the postings must live on the group's device");
+    if (g->broken) return fail(SRN_ESTATE, "the shard group is unusable since an earlier batch failed (" + g->broken_why + ")");
+    HIP_TRY(hipSetDevice(g->device));
+    auto detach = [&]() {   // back to the lists pipeline: nothing of an earlier set_postings stays
+        for (const srn_index* sh : g->shards) (void)device_sback_attach_postings(sh->dev, nullptr, 0);
+        if (g->nb_pbytes) { (void)hipDeviceSynchronize(); (void)hipFree(g->nb_pbytes); g->nb_pbytes = nullptr; }
+        g->postings = nullptr; g->postings_max_row_len = 0; g->stream_ok = false;
+    };
+    detach();
+    if (!postings) return SRN_OK;
+    int local_rc = SRN_OK; std::string why;
+    auto bad = [&](int code, const std::string& msg) { if (local_rc == SRN_OK) { local_rc = code; why = msg; } };
+    if (!postings->dev) bad(SRN_ENODEV, "the postings index has no device attached");
+    else if (postings->flat.n_shards != 1) bad(SRN_EINVAL, "the replicated postings are those of the UNSHARDED index (the index itself, or srn_index_postings_view of it)");
+    else if (postings->device != g->device) bad(SRN_EINVAL, "the postings must live on the group's device");
+    else {
         for (const srn_index* sh : g->shards)
             if (sh->flat.n_kept != postings->flat.n_kept || sh->flat.total_pairs != postings->flat.total_pairs || sh->flat.m_index != postings->flat.m_index ||
                 sh->flat.n_sessions_total != postings->flat.n_sessions_total)
-                return fail(SRN_EINVAL, "the postings index is not the index these shards were cut from (sessions / pairs / m_index differ)");
-        if (!postings->flat.lists_complete) return fail(SRN_EINVAL, "the neighbours pipeline needs complete posting lists");
-        // the choice between the pipelines is made per batch from rank-INVARIANT inputs; what is rank-local is settled here, loudly: a shard whose packed rows did not fit
-        // its GPU (device_attach lets that allocation fail) cannot take the neighbours pipeline, and its peers must not find out in the middle of a batch
+                bad(SRN_EINVAL, "the postings index is not the index these shards were cut from (sessions / pairs / m_index differ)");
+        if (!postings->flat.lists_complete) bad(SRN_EINVAL, "the neighbours pipeline needs complete posting lists");
+        // a shard whose packed rows did not fit its GPU (device_attach lets that allocation fail) cannot take the neighbours pipeline
         for (const srn_index* sh : g->shards)
-            if (!device_has_packed_rows(sh->dev)) return fail(SRN_ENOMEM, "this rank's shard has no packed rows (no room at attach time): the neighbours pipeline cannot run on this group -- leave the postings unset on EVERY rank");
+            if (!device_has_packed_rows(sh->dev)) bad(SRN_ENOMEM, "this rank's shard has no packed rows (no room at attach time): the neighbours pipeline cannot run on this group");
+        if (getenv("SRN_DEBUG_FAIL_SET_POSTINGS")) bad(SRN_ENOMEM, "simulated rank-local failure (SRN_DEBUG_FAIL_SET_POSTINGS)");   // (tests: one rank of a group fails alone)
     }
-    g->postings = postings; g->postings_max_row_len = postings ? postings->flat.max_row_len : 0;
-    // this rank's shards keep their fragments a second time, in the posting order of these lists, where there is room (the streaming form of the back end; rank-local and
-    // optional: both forms give the same rows)
-    // The neighbours' presence bytes (round 5): every shard's presence bitmap all-gathered ONCE (a collective: set_postings is called by every rank, like a batch), then a
-    // byte per session.  Up to 8 shards; every local shard must have its bitmap (the wave-per-query back end's rows: from SRN_SBACK_MIN_SHARDS shards on).
-    if (g->nb_pbytes) { HIP_TRY(hipSetDevice(g->device)); HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(g->nb_pbytes)); g->nb_pbytes = nullptr; }
-    if (postings && G_of(g) >= 2 && G_of(g) <= 8 && device_shard_nb_presence_wanted()) {
+    // this rank's shards keep their fragments a second time, in the posting order of these lists, where there is room (the streaming form of the back end: optional, both
+    // forms give the same rows -- but the exchange FORMAT follows from it, so it is used only if EVERY rank has it)
+    bool stream_here = false;
+    if (local_rc == SRN_OK) {
+        bool all = !g->shards.empty();
+        for (const srn_index* sh : g->shards) {
+            const int rc = device_sback_attach_postings(sh->dev, postings->dev, postings->flat.nnz_post);
+            if (rc) { bad(rc, last_error_string()); break; }
+            all = all && device_sback_streams(sh->dev);
+        }
+        stream_here = local_rc == SRN_OK && all;
+    }
+    // The neighbours' presence bytes (round 5, opt-in knob): every shard's presence bitmap all-gathered once, then a byte per session.  Up to 8 shards; every local shard
+    // must have its bitmap (the wave-per-query back end's rows: from SRN_SBACK_MIN_SHARDS shards on).  Buffers first, the collective only if every rank has them.
+    bool pbytes_here = false; size_t block_words = 0; uint8_t* pb = nullptr;
+    const uint64_t n_sess = postings->flat.n_kept + 1;
+    if (local_rc == SRN_OK && G_of(g) >= 2 && G_of(g) <= 8 && device_shard_nb_presence_wanted()) {
         bool have = !g->shards.empty(); size_t words = 0;
         for (const srn_index* sh : g->shards) { size_t w = 0; have = have && device_sback_present(sh->dev, &w) != nullptr; words = std::max(words, w); }
         if (have) {
-            HIP_TRY(hipSetDevice(g->device));
-            const uint64_t n = postings->flat.n_kept + 1;
-            const size_t block_words = (std::max<size_t>(words, (size_t)((n + 31) / 32)) + 63) / 64 * 64;
-            int rc = ensure(&g->pres_all, &g->pres_all_bytes, (size_t)G_of(g) * block_words * 4); if (rc) return rc;
-            HIP_TRY(hipMemsetAsync(g->pres_all, 0, (size_t)G_of(g) * block_words * 4, nullptr));
-            for (size_t i = 0; i < g->shards.size(); ++i) {
-                const uint32_t gi = g->kind == srn_shard_group::LOCAL ? (uint32_t)i : (uint32_t)g->rank;
-                size_t w = 0; const uint32_t* pr = device_sback_present(g->shards[i]->dev, &w);
-                HIP_TRY(hipMemcpyAsync(g->pres_all + (size_t)gi * block_words * 4, pr, w * 4, hipMemcpyDeviceToDevice, nullptr));
-            }
-            rc = all_gather_blocks(g, 0, g->pres_all, block_words * 4, nullptr); if (rc) return rc;
-            HIP_TRY(hipMalloc((void**)&g->nb_pbytes, (size_t)n + 64));
-            HIP_TRY(launch_presence_bytes(nullptr, (const uint32_t*)g->pres_all, block_words, G_of(g), n, g->nb_pbytes));
-            HIP_TRY(hipDeviceSynchronize());
+            block_words = (std::max<size_t>(words, (size_t)((n_sess + 31) / 32)) + 63) / 64 * 64;
+            pbytes_here = ensure(&g->pres_all, &g->pres_all_bytes, (size_t)G_of(g) * block_words * 4) == SRN_OK && hipMalloc((void**)&pb, (size_t)n_sess + 64) == hipSuccess;
+            if (!pbytes_here && pb) { (void)hipFree(pb); pb = nullptr; }
         }
     }
-    bool all = !g->shards.empty(), any_geometry = false;
-    for (const srn_index* sh : g->shards) {
-        int rc = device_sback_attach_postings(sh->dev, postings ? postings->dev : nullptr, postings ? postings->flat.nnz_post : 0); if (rc) return rc;
-        all = all && device_sback_streams(sh->dev); any_geometry = any_geometry || device_sback_wanted(sh->dev);
+    // ---- the agreement: min over the ranks of (this rank can take the postings | ... stream | ... has the presence buffers) ----
+    int flags[3] = {local_rc == SRN_OK ? 1 : 0, stream_here ? 1 : 0, pbytes_here ? 1 : 0};
+    if (g->kind != srn_shard_group::LOCAL) {
+        if (!g->agree_dev) HIP_TRY(hipMalloc((void**)&g->agree_dev, 64));
+        HIP_TRY(hipMemcpyAsync(g->agree_dev, flags, sizeof flags, hipMemcpyHostToDevice, g->s_x));
+        { const int rc = all_reduce_min_i32(g, 0, g->agree_dev, 3, g->s_x); g->issued = false; if (rc) { if (pb) (void)hipFree(pb); detach(); return rc; } }
+        HIP_TRY(hipMemcpyAsync(flags, g->agree_dev, sizeof flags, hipMemcpyDeviceToHost, g->s_x));
+        HIP_TRY(hipStreamSynchronize(g->s_x));
     }
-    g->stream_ok = postings && all;
-    if (postings && !all && any_geometry) {
-        // the exchange FORMAT follows from this: it must be the same on every rank.  An in-process group sees all its shards and falls back as a whole; a rank of a
-        // distributed group cannot know what its peers got and must not guess
+    if (!flags[0]) {
+        if (pb) (void)hipFree(pb);
+        detach();
+        return local_rc != SRN_OK ? fail(local_rc, why) : fail(SRN_ESTATE, "a peer rank could not take the replicated postings (its error says why): no rank of the group took them -- the lists pipeline stays");
+    }
+    if (!flags[1] && stream_here)   // a peer has no room for the streaming form: every rank runs the gather form
         for (const srn_index* sh : g->shards) (void)device_sback_attach_postings(sh->dev, nullptr, 0);
-        if (g->kind != srn_shard_group::LOCAL) { g->postings = nullptr;
-            return fail(SRN_ENOMEM, "no room on this rank for its shard's fragments in posting order (8 bytes per posting): run EVERY rank with SRN_SBACK_STREAM=0 (the gather form of the back end)"); }
-    }
+    if (flags[2]) {
+        HIP_TRY(hipMemsetAsync(g->pres_all, 0, (size_t)G_of(g) * block_words * 4, nullptr));
+        for (size_t i = 0; i < g->shards.size(); ++i) {
+            const uint32_t gi = g->kind == srn_shard_group::LOCAL ? (uint32_t)i : (uint32_t)g->rank;
+            size_t w = 0; const uint32_t* pr = device_sback_present(g->shards[i]->dev, &w);
+            HIP_TRY(hipMemcpyAsync(g->pres_all + (size_t)gi * block_words * 4, pr, w * 4, hipMemcpyDeviceToDevice, nullptr));
+        }
+        { const int rc = all_gather_blocks(g, 0, g->pres_all, block_words * 4, nullptr); g->issued = false; if (rc) { (void)hipFree(pb); detach(); return rc; } }
+        HIP_TRY(launch_presence_bytes(nullptr, (const uint32_t*)g->pres_all, block_words, G_of(g), n_sess, pb));
+        HIP_TRY(hipDeviceSynchronize());
+        g->nb_pbytes = pb;
+    } else if (pb) (void)hipFree(pb);
+    // committed last, and the same on every rank
+    g->stream_ok = flags[1] != 0; g->postings_max_row_len = postings->flat.max_row_len; g->postings = postings;
     return SRN_OK;
 }
 

@@ -455,6 +455,72 @@ def test_neighbours_pipeline_over_application_callbacks(world):
             _check_oracle(r, ref, n)
 
 
+def _cb_disagree_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if rank == 1:
+        os.environ["SRN_DEBUG_FAIL_SET_POSTINGS"] = "1"        # this rank alone cannot take the postings (stands for: its packed rows did not fit, no room for a buffer)
+    try:
+        import torch.distributed as dist
+        import serenade_amd as sa
+        from serenade_amd import distributed as D
+        from serenade_amd import sharded
+        D.init("gloo")
+        off, items, ts, ids = small_dataset(84, n_sessions=5000, n_items=400, max_len=40)
+        qs = random_queries(31, ids, 401, max_len=7, unknown_rate=0.02)
+        flat, qoff = flatten(qs)
+        d_flat, d_off = _to_dev(flat, qoff)
+        full = sa.VMISIndex.from_sessions(off, items, ts, 300, 40, 1.0)
+        ix = sharded.ShardedVMISIndex.from_full(full, rank, world)
+        post = sharded.postings_view(full)
+        grp = sharded.ShardGroup.over(ix, rank, world, sharded.DistComm())
+        err = None
+        try:
+            grp.set_postings(post)
+        except sa.SerenadeError as e:
+            err = (e.code, str(e))
+        res = _np(grp.predict_batch(d_flat, d_off, len(qs), 7, 80, 300, 21))     # every rank is on the lists pipeline: no collective of the other pipeline is left without its partner
+        q.put((rank, (err, res), grp.stats))
+        D.barrier()
+        grp.close()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "error: %r\n%s" % (e, traceback.format_exc()), None))
+
+
+def test_set_postings_is_agreed_on_by_the_ranks():
+    """srn_shard_group_set_postings used to decide from rank-local state -- a rank whose packed rows or buffers did not fit kept the lists pipeline while
+    its peers took the neighbours pipeline, and the next batch hung on mismatched collectives.  Now the outcome is an all-reduce-min over the ranks: one rank fails locally
+    (simulated), BOTH get an error (the failing rank its own, the peer SRN_ESTATE), neither keeps the postings, and the next batch runs -- and is right -- on the lists pipeline."""
+    mp = pytest.importorskip("torch.multiprocessing")
+    from oracle import oracle as O
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cb_disagree_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+    off, items, ts, ids = small_dataset(84, n_sessions=5000, n_items=400, max_len=40)
+    qs = random_queries(31, ids, 401, max_len=7, unknown_rate=0.02)
+    flat, qoff = flatten(qs)
+    ref = O.OracleIndex(off, items, ts, 300, 40, 1.0).predict_batch("canonical", flat, qoff, 80, 300, 21, False, threads=4)
+    for rank, res, st in out:
+        assert not isinstance(res, str), res
+        err, rows = res
+        assert err is not None, "rank %d took the postings although its peer could not" % rank
+        if rank == 1:
+            assert err[0] == -2 and "simulated" in err[1], err       # SRN_ENOMEM: its own reason
+        else:
+            assert "peer" in err[1], err
+        assert st["neighbour_batches"] == 0
+        _check_oracle(rows, ref, 21)
+
+
 # ---- a rank that dies in the middle of a run (VERDICT r4 next 2): the others get an error, not a hang --------------------------------------------------------------
 
 def _cb_kill_worker(rank, world, port, q):
