@@ -386,7 +386,7 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
     const unsigned long long lt = (1ull << lane) - 1ull;
     static_assert(!TINY || (MODE == FM_FUSED && !BIG && !FRAG), "TINY: the lean or the MID fused form over an unsharded index");
     if constexpr (TINY) {
-        // The latency path's ONE launch, one workgroup per evolving session (srn_predict: one; a round of concurrent callers or a small host batch: up to 32): the workgroup
+        // The latency path's ONE launch, one workgroup per evolving session (srn_predict: one; a round of concurrent callers or a small host batch: up to SRN_TINY_FUSED_MAX = 48 by default): the workgroup
         // writes its query's prep record itself (its first eight lanes: vmis_prep_kernel's body), serves it, and wave 0 finishes it from registers (finish_inline) -- five
         // launches of 5..18 us each became one.  The launch sequence's counters start at zero (the host sees to it) and are published by the LAST workgroup to finish: what
         // this kernel hands on (general kernel, MID, > 63 entries) the host launches behind it, for that call only.
@@ -962,7 +962,7 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
         FAST_TICK(9);
         // ---- phase 4a: the direct-mapped items, exactly -> threshold, candidates ----------------------------
         // Sample = the 512 most popular items, dealt round-robin to the waves: every wave takes the 3rd largest of its 64 values
-        // of x = idf_eff * acc (top 32 bits of the f64: a monotone truncation); the smallest of the 8 has >= 24 >= n items at or
+        // of x = idf_eff * acc (top 32 bits of the f64: a monotone truncation; how_many > 24: the ceil(n / 8)-th largest); the smallest of the 8 has >= 24 >= n items at or
         // above it.  Everything is kept down to one step (2^-20 relative) BELOW it, so that what is dropped is strictly smaller
         // after the division by 10 U as well (ties at the cut included).
         uint32_t t32m1; uint32_t floor_b;
@@ -992,7 +992,15 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
                     const unsigned long long bal = __ballot(vv == mx);
                     if ((int)lane == __ffsll((long long)bal) - 1) vv = 0;   // take one holder of the maximum out
                 }
-                if (lane == 0u) misc[FS_W3 + wave] = third;   // (0 if the wave has < 3 valid items)
+                // (round 6) how_many up to 64: the j-th largest of every wave, j = ceil(n / 8) -- the smallest of the 8 then has >= 8 j >= n items at or above it
+                // (launch-uniform; the default n = 21 runs the three steps above and nothing else)
+                for (uint32_t t = 3u; t < ((p.how_many + 7u) >> 3); ++t) {
+                    const uint32_t mx = wave_max(vv);
+                    third = mx;
+                    const unsigned long long bal = __ballot(vv == mx);
+                    if ((int)lane == __ffsll((long long)bal) - 1) vv = 0;
+                }
+                if (lane == 0u) misc[FS_W3 + wave] = third;   // (0 if the wave has < max(3, ceil(n / 8)) valid items)
             }
             __syncthreads();
             uint32_t t32 = 0xFFFFFFFFu;
@@ -1353,8 +1361,8 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
     if constexpr (TINY) {
         // every append and every row of this workgroup was wave 0's (thread 0's atomics, the wave's stores): behind thread 0 in program order.  The workgroups count
         // themselves off; the last one publishes the counters and, behind a system-scope fence, the call's number -- the word the caller spins on.
+        if (wave == 0u && f.host_words) __threadfence_system();   // (executed by EVERY lane that stored a row: a fence orders the executing thread's accesses -- ADVICE r5)
         if (tid == 0u && f.host_words) {
-            __threadfence_system();
             if (atomicAdd(&f.slow_cnt[6], 1u) == gridDim.x - 1u) {
                 f.host_words[1] = atomicAdd(&f.slow_cnt[0], 0u); f.host_words[2] = atomicAdd(&f.slow_cnt[1], 0u); f.host_words[3] = atomicAdd(&f.slow_cnt[4], 0u);
                 f.host_words[4] = atomicAdd(&f.slow_cnt[3], 0u);

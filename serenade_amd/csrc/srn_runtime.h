@@ -22,6 +22,7 @@ namespace srn {
 // Test / experiment knobs (environment variables SRN_*): read ONCE, when the library is first used, never on the launch path;
 // srn_debug_reload_knobs() re-reads them (the tests switch kernel paths between calls).  All defaults = production behaviour.
 struct Knobs {
+    int fast_how_many_max = 64;   // SRN_FAST_HOW_MANY_MAX: the largest how_many the fast kernels take (round 6: 64 -- the threshold sample takes the ceil(n / 8)-th largest per wave; until round 5: 24)
     bool no_viol = false;   // SRN_NO_VIOL: an index with incomplete lists takes the general kernel for every query, as until round 5 (A/B)
     bool no_masks = false, no_merge = false, dense = false, no_fast = false, no_mid = false, no_big = false, no_long = false, debug = false;   // no_long (SRN_NO_LONG): without the LONG instantiation (sessions of 11..20 items go to the general kernel, as until round 4)   // no_mid (SRN_NO_MID): the launch sequence without the fast kernel's MID instantiation (what it would take goes to the general kernel, as before round 4)
     int hot_slots = -1, sketch_slots = -1, lds_budget_kb = 0, grid_mult = 16, fast_runs = 0;

@@ -22,6 +22,7 @@ namespace srn {
 static Knobs g_knobs; static std::once_flag g_knobs_once; static std::mutex g_knobs_mu;
 static void knobs_read() {
     Knobs k;
+    if (const char* e = getenv("SRN_FAST_HOW_MANY_MAX")) k.fast_how_many_max = std::max(1, std::min(64, atoi(e)));
     k.no_masks = getenv("SRN_NO_MASKS") != nullptr; k.no_viol = getenv("SRN_NO_VIOL") != nullptr; k.no_merge = getenv("SRN_NO_MERGE") != nullptr; k.dense = getenv("SRN_DENSE") != nullptr;
     k.no_fast = getenv("SRN_NO_FAST") != nullptr; k.no_mid = getenv("SRN_NO_MID") != nullptr; k.no_big = getenv("SRN_NO_BIG") != nullptr; k.no_long = getenv("SRN_NO_LONG") != nullptr; k.debug = getenv("SRN_DEBUG") != nullptr;
     if (const char* e = getenv("SRN_ROW_SLOTS")) k.row_slots16 = atoi(e) == 16 ? 1 : atoi(e) == 64 ? 0 : -1;
@@ -424,7 +425,7 @@ static FastPlan fast_plan(const DeviceState* d, const FlatIndex& ix, const Launc
     f.mid_tier = !kn.no_mid && !has_ext && d->di.row_frag == 0u && p.max_len >= 5;   // (a query of <= 4 items has <= 4 lists and numerators <= 10: nothing for the MID instantiation)
     f.long_tier = f.mid_tier && !kn.no_long && !kn.no_big && p.max_len > 10;          // (round 5: sessions of 11..20 items -- LONG, a form of MID's BIG layout)
     f.fast = d->fast.row_packed != nullptr && sets_exact && (p.max_len <= 8 ? (geo.masks || !ix.lists_complete) && !geo.sketch_may_wrap : f.mid_tier && fast_sketch_ok) && f.nb_fast != 0 && kn.geometry_default() &&
-             !kn.no_fast && p.k <= F_K_MAX && p.m <= F_M_MAX && p.how_many <= 24 && (p.flags & ~(unsigned)SRN_FLAG_BUSINESS_LOGIC) == 0 && p.stats == nullptr && p.nb_rank == nullptr;
+             !kn.no_fast && p.k <= F_K_MAX && p.m <= F_M_MAX && p.how_many <= (uint32_t)kn.fast_how_many_max && (p.flags & ~(unsigned)SRN_FLAG_BUSINESS_LOGIC) == 0 && p.stats == nullptr && p.nb_rank == nullptr;
     return f;
 }
 
@@ -494,7 +495,8 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
         uint32_t seq = 0;
         if (fused) {
             uint32_t L1 = 0; for (uint32_t q = 0; q < p.nq; ++q) L1 = std::max(L1, h_qoff[q + 1] - h_qoff[q]);   // the call's longest session
-            if (w->cnt_dirty) { HIP_TRY(hipMemsetAsync(w->slow_cnt, 0, 32, st)); w->cnt_dirty = false; }   // (only after a call that left the counters non-zero: the fused launch leaves them at 0 unless it hands work on)
+            if (w->cnt_dirty) HIP_TRY(hipMemsetAsync(w->slow_cnt, 0, 32, st));   // (only after a call that left the counters non-zero: the fused launch leaves them at 0 unless it hands work on)
+            w->cnt_dirty = true;   // (until this call is known to have ended cleanly with nothing handed on: an error return in between must not leave a stale ticket behind a "clean" flag -- ADVICE r5)
             fp.tiny_len = p.nq == 1 && L1 >= 1u && L1 <= 8u ? L1 : 0u;   // (a single session's items in the kernel arguments where they fit)
             for (uint32_t i = 0; i < fp.tiny_len; ++i) fp.tiny_items[i] = h_items[h_qoff[0] + i];
             seq = ++w->tiny_seq; if (seq == 0u) seq = ++w->tiny_seq;
@@ -542,11 +544,19 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
             const auto t0 = std::chrono::steady_clock::now();
             for (uint32_t spin = 0; !seen; ++spin) {
                 seen = hw[5] == seq;
-                if (!seen && (spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+                if (!seen) {
+                    __builtin_ia32_pause();   // (the sibling hyper-thread may be another caller spinning on ITS workspace)
+                    if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+                }
             }
             std::atomic_thread_fence(std::memory_order_acquire);
         }
         if (!seen) { int rc = wait(); if (rc) return rc; }
+        // the counters hw[1..4] are this call's only if the kernel published its number behind them; a fused launch that ended without doing so (it cannot, short of a
+        // fault the wait above would have reported) gets the full second phase rather than a guess from stale words
+        const bool published = !fused || hw[5] == seq;
+        if (fused && !published) { int rc = rest(); if (rc) return rc; rc = wait(); if (rc) return rc; }
+        else
         if (kn.debug && fused) {   // (SRN_DEBUG: how often a single-session call needs the kernels behind the fused launch, and why)
             static std::atomic<uint64_t> calls{0}, second{0}, why[3] = {{0}, {0}, {0}};
             const uint64_t c = calls.fetch_add(1) + 1;
@@ -554,7 +564,8 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
             if (c % 1000 == 0) fprintf(stderr, "[srn] fused single-session calls: %llu, with a second phase %llu (handed to the general kernel %llu, listed for MID %llu, > 63 entries %llu)\n",
                                        (unsigned long long)c, (unsigned long long)second.load(), (unsigned long long)why[0].load(), (unsigned long long)why[1].load(), (unsigned long long)why[2].load());
         }
-        if (two_phase && (hw[1] | hw[2] | (phases >= 2 ? hw[4] : 0u)) != 0u) {   // (handed to the general kernel | listed for MID | queries with > 63 entries)
+        if (fused && published && (hw[1] | hw[2] | hw[4]) == 0u) w->cnt_dirty = false;   // (a clean end with nothing handed on: the counters and the workgroup ticket are back at 0)
+        if (published && two_phase && (hw[1] | hw[2] | (phases >= 2 ? hw[4] : 0u)) != 0u) {   // (handed to the general kernel | listed for MID | queries with > 63 entries)
             int rc = SRN_OK;
             w->cnt_dirty = true;
             if (fused && hw[2] == 0u) {   // (nothing listed for MID: the general kernel over what was handed to it -- it writes its rows itself -- and finish-big for a row the fused launch could not finish, each only if needed)

@@ -305,3 +305,41 @@ def test_negative_and_zero_weights_positions_eleven_to_twenty():
             assert (scores < 0).any(), "negative scores must occur (and be returned where nothing positive fills the list)"
     finally:
         _no_long(None, False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("how_many", [25, 50, 64])
+def test_more_than_24_recommendations_stay_on_the_fast_kernels(how_many, monkeypatch):
+    """num_items_to_recommend is a free config value (src/config.rs:17, docs/CONFIG.md:23).  Until round 5 a caller asking for more than 24 items sent the whole batch to the
+    general kernel (7x slower); the threshold sample now takes the ceil(n / 8)-th largest of every wave, so the fast kernels serve n <= 64.  Against the oracle on
+    BASELINE configs[1]'s index (lean shape) and on sessions of up to 10 / 20 items (MID / BIG / LONG), and bit-identical to the general kernel's rows (SRN_FAST_HOW_MANY_MAX=24)."""
+    import serenade_amd as sa
+    from serenade_amd import capi, synth
+    from oracle import oracle as O
+    inter, n_items, k, m, idfw = synth.CONFIGS["cfg2"]
+    off, items, ts = synth.training_sessions(inter, n_items)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw, builder="gpu")
+    oix = O.OracleIndex(off, items, ts, m, 34, idfw, fast=True)
+    for max_items, nq_s, min_fast in ((4, 3000, 0.97), (10, 1500, 0.9), (20, 1500, 0.8)):
+        qi, qo = synth.queries(nq_s, n_items, max_items=max_items)
+        nq = len(qo) - 1
+        got = sa.predict_batch(gix, (qi, qo), k, m, how_many, False)
+        n_all, general, _ = gix.last_path_counts()
+        assert n_all == nq and general <= (1.0 - min_fast) * nq, (max_items, general, nq)
+        ref = oix.predict_batch("canonical", qi, qo, k, m, how_many, False, threads=8)
+        assert np.array_equal(got[2], ref["counts"]) and np.array_equal(got[0], ref["ids"]), max_items
+        np.testing.assert_allclose(got[1], ref["scores"], rtol=1e-12, atol=0)
+        assert (got[2] == how_many).mean() > 0.5                         # most queries do fill the longer list
+        monkeypatch.setenv("SRN_FAST_HOW_MANY_MAX", "24"); capi.reload_knobs()
+        try:
+            old = sa.predict_batch(gix, (qi, qo), k, m, how_many, False)
+            assert gix.last_path_counts()[1] == nq
+        finally:
+            monkeypatch.undo(); capi.reload_knobs()
+        for x, y in zip(got, old):
+            assert np.array_equal(x, y)
+    # a single-session call (srn_predict) with a long list
+    q1 = qi[qo[5]:qo[6]]
+    one = sa.predict(gix, q1, k, m, how_many, False)
+    want = oix.predict_canonical(q1, k, m, how_many)
+    assert [i for i, _ in one] == want[0].tolist()
