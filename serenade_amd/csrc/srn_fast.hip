@@ -1252,7 +1252,25 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
                 nt += (uint32_t)__popcll(bm);
             }
         }
-        const uint32_t cnt = misc[FS_CCNT];   // (this wave's own LDS traffic is ordered; the other waves' appends are behind the barrier above)
+        uint32_t cnt = misc[FS_CCNT];   // (this wave's own LDS traffic is ordered; the other waves' appends are behind the barrier above)
+        // (round 6) The sample's candidates were taken at the FIRST, loose threshold; the second one (the bin of the n-th best: t32m1 now) came later.  With the default
+        // n = 21 that leaves ~29 entries and nobody cares; with n = 50 the loose cut keeps 70-90 -- beyond the 63 a record holds, and the query would take the one-wave-per-
+        // query finish-big kernel.  Only then (wave-uniform): the candidates below the tight threshold are dropped here, by the argument that dropped the survivors and the
+        // contenders below it (>= n valid items sit at or above the bin's lower edge; everything down to one step below it is kept).
+        if (cnt + nt > F_FIN_ENTRIES && cnt <= F_CAND_CAP) {
+            unsigned long long xs[3]; uint32_t ti[3];
+#pragma unroll
+            for (uint32_t t = 0; t < 3u; ++t) { const uint32_t i = t * 64u + ln; xs[t] = i < cnt ? ckey[i] : 0ull; ti[t] = i < cnt ? cidx[i] : 0u; }
+            uint32_t c2 = 0;
+#pragma unroll
+            for (uint32_t t = 0; t < 3u; ++t) {
+                const bool keep = t * 64u + ln < cnt && (uint32_t)(xs[t] >> 32) >= t32m1;
+                const unsigned long long bm = __ballot(keep);
+                if (keep) { const uint32_t at = c2 + (uint32_t)__popcll(bm & ltl); ckey[at] = xs[t]; cidx[at] = ti[t]; }
+                c2 += (uint32_t)__popcll(bm);
+            }
+            cnt = c2;
+        }
         // record of query q: 1 KB at a FIXED place (vmis_finish_kernel then needs no index look-up before it can ask for the entries):
         // {M, U, 0, 0} | M <= 63 entries of 16 bytes: {x (f64 bits), id rank, 0} for a candidate, {sum, item, 1} for a contender of the table
         // A query with more entries (no threshold: a small query) puts the rest in an overflow arena and itself on the list of

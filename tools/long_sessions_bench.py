@@ -14,7 +14,7 @@ lens = [int(x) for x in sys.argv[3:]] or [4, 5, 8, 10]
 inter, n_items, k, m, idfw = synth.CONFIGS[cfg]
 off, items, ts = synth.training_sessions(inter, n_items)
 ix = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw, builder="gpu")
-dev = torch.device("cuda:0"); n = synth.HOW_MANY
+dev = torch.device("cuda:0"); n = int(os.environ.get("SRN_LSB_HOW_MANY", synth.HOW_MANY))   # (num_items_to_recommend: 21 by default, src/config.rs:17)
 st = torch.cuda.current_stream().cuda_stream
 oix = None
 if os.environ.get("SRN_LSB_ORACLE", "1") != "0":
