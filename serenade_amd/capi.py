@@ -75,6 +75,9 @@ SYMBOLS = {
     "srn_index_items_for_session": (_i, [_vp, C.c_uint32, _vp, _sz, C.POINTER(_sz)]),
     "srn_index_find_attributes": (_i, [_vp, _u64, C.POINTER(C.c_uint8)]),
     "srn_index_session_recency": (_i, [_vp, _vp, _sz]),
+    "srn_index_serve_start": (_i, [_vp, _sz, _sz, _sz, C.c_int, C.c_uint, C.c_uint, C.c_uint]),
+    "srn_index_serve_stop": (_i, [_vp]),
+    "srn_index_serve_stats": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "srn_find_neighbors": (_i, [_vp, _vp, _sz, _sz, _sz, _vp, _vp, C.POINTER(_sz)]),
     "srn_index_free": (None, [_vp]),
     "srn_predict": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _i, _vp, _vp, C.POINTER(_sz)]),

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "srn_internal.h"
+#include "srn_hipsync.h"
 
 namespace srn {
 

@@ -273,6 +273,10 @@ int srn_predict(const srn_index_t* idx, const uint64_t* evolving, size_t len, si
         *out_n = 0;
         if (!evolving || len == 0) return fail(SRN_EINVAL, "empty evolving session (the reference panics: src/vmisknn/mod.rs:157)");
         if (len > SRN_MAX_SESSION_LEN) return fail(SRN_ERANGE, "evolving session longer than SRN_MAX_SESSION_LEN");
+        // (round 6) a resident workgroup of the persistent latency path, if the handle has them and this call is what they serve: no launch at all
+        if (idx && idx->dev && out_ids && out_scores && len <= 16 && k <= 0xFFFFFFFFull && m <= 0xFFFFFFFFull && how_many <= 0xFFFFFFFFull &&
+            device_serve_predict(idx->dev, evolving, (uint32_t)len, (uint32_t)k, (uint32_t)m, (uint32_t)how_many, enable_business_logic ? SRN_FLAG_BUSINESS_LOGIC : 0u, out_ids, out_scores, out_n) == 0)
+            return SRN_OK;
         // concurrent calls on one handle share launches (srn_combine.cpp); a lone caller runs its own round of one at once
         const int lanes = knob_predict_lanes();
         if (lanes > 0 && idx && idx->comb) {
@@ -287,6 +291,25 @@ int srn_predict(const srn_index_t* idx, const uint64_t* evolving, size_t len, si
                               out_scores, &cnt, nullptr, nullptr, nullptr, nullptr);
         if (rc == SRN_OK) *out_n = cnt;
         return rc; });
+}
+
+// ---- the persistent latency path (srn_runtime.hip, "serve") ----
+int srn_index_serve_start(srn_index_t* idx, size_t k, size_t m, size_t how_many, int enable_business_logic, unsigned lanes, unsigned max_items_in_session, unsigned idle_ms) {
+    return guarded([&]() -> int {
+        if (!idx) return fail(SRN_EINVAL, "null index");
+        if (!idx->dev) return fail(SRN_ENODEV, "index has no device attached");
+        int rc = check_predict_args(idx, k, m, how_many); if (rc) return rc;
+        rc = check_not_a_shard(idx); if (rc) return rc;
+        return device_serve_start(idx->dev, idx->flat, (uint32_t)k, (uint32_t)m, (uint32_t)how_many, enable_business_logic ? SRN_FLAG_BUSINESS_LOGIC : 0u, lanes, max_items_in_session, idle_ms); });
+}
+int srn_index_serve_stop(srn_index_t* idx) {
+    return guarded([&]() -> int {
+        if (!idx) return fail(SRN_EINVAL, "null index");
+        return idx->dev ? device_serve_stop(idx->dev) : SRN_OK; });
+}
+int srn_index_serve_stats(const srn_index_t* idx, uint64_t* out_served, uint64_t* out_not_served, uint64_t* out_launches, uint32_t* out_lanes) {
+    if (!idx || !idx->dev) return fail(SRN_ENODEV, "index has no device attached");
+    return device_serve_stats(idx->dev, out_served, out_not_served, out_launches, out_lanes);
 }
 
 int srn_predict_stats(const srn_index_t* idx, uint64_t* out_rounds, uint64_t* out_requests, uint64_t* out_max_round) {

@@ -393,10 +393,12 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
         // (the session's items ride in the kernel arguments where they fit: read from the pinned staging they are two dependent PCIe round trips -- offsets, then items)
         unsigned long long* const a_items = reinterpret_cast<unsigned long long*>(smem + F_W10 + 64); uint32_t* const a_off = reinterpret_cast<uint32_t*>(smem + F_W10 + 64 + 64);   // (where a NEXT query's record would be parked: this launch has none)
         const uint32_t alen = f.tiny_len;
+        if (f.serve == nullptr) {   // (the persistent form writes the record per request, at the top of the loop below)
         if (alen) { if (tid < 8u) a_items[tid] = f.tiny_items[tid]; if (tid == 0u) { a_off[0] = 0u; a_off[1] = alen; } __syncthreads(); }
         if (tid < PREP_LANES) prep_group(ix_arg, alen ? (const uint64_t*)a_items : p.items_flat, alen ? (const uint32_t*)a_off : p.q_off, alen ? 0u : blockIdx.x, tid, p.m, p.max_len,
                                          const_cast<char*>(p.prep) + (size_t)blockIdx.x * p.prep_stride, nullptr, 0u, nullptr);
         __syncthreads();   // (workgroup-scope release / acquire: the record's words for every wave)
+        }
     }
 
     uint32_t* misc = (uint32_t*)(smem + F_MISC);
@@ -451,9 +453,53 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
     // workgroup b serves b, b + gridDim, ...
     const bool ordered = !MID && MODE != FM_FRONT && f.order != nullptr && !listed;   // (launch-uniform)
     const uint32_t ox = blockIdx.x & 7u;
-    const uint32_t qi_step = ordered ? gridDim.x >> 3 : gridDim.x;
+    const bool serving = TINY && f.serve != nullptr;   // (launch-uniform) the persistent form: the loop below never advances, every round is one posted session
+    const uint32_t qi_step = serving ? 0u : ordered ? gridDim.x >> 3 : gridDim.x;
+    uint32_t serve_seq = 0u; bool serve_have = false;   // (thread 0) the number of the request being served (before the first one: the number that was current at the launch)
+    if constexpr (TINY) { if (serving && tid == 0u) serve_seq = __atomic_load_n(&f.serve->seq, __ATOMIC_RELAXED); }
     const uint32_t qi_end = ordered ? ord_count(p.nq, ox) : q_end;
     for (uint32_t qi = ordered ? blockIdx.x >> 3 : (MODE == FM_FRONT ? f.q_base : 0u) + blockIdx.x; qi < qi_end; qi += qi_step) {
+        if constexpr (TINY) {
+            if (serving) {
+                // ---- the persistent form: answer the previous session, wait for the next one, write its record ----
+                // (every path of the body ends here: the `continue`s of the hand-overs too; wave 0 finished the row from its registers before it arrived)
+                uint32_t* const sv_flag = reinterpret_cast<uint32_t*>(smem + F_W10 + 64 + 192);   // (behind the posted items and their offsets; the weight table's tail is unused in this launch)
+                unsigned long long* const sv_items = reinterpret_cast<unsigned long long*>(smem + F_W10 + 64); uint32_t* const sv_off = reinterpret_cast<uint32_t*>(smem + F_W10 + 64 + 128);
+                __syncthreads();
+                if (wave == 0u) __threadfence_system();   // (the row's stores of every lane before the answer)
+                if (tid == 0u) {
+                    ServeCtl* const c = f.serve;
+                    if (serve_have) {
+                        // what the body handed on (general kernel, MID, BIG, LONG, > 63 entries) nobody will launch: the caller takes the launch path for this session
+                        const uint32_t handed = atomicExch(&f.slow_cnt[0], 0u) | atomicExch(&f.slow_cnt[1], 0u) | atomicExch(&f.slow_cnt[2], 0u) | atomicExch(&f.slow_cnt[3], 0u) |
+                                                atomicExch(&f.slow_cnt[4], 0u) | atomicExch(&f.slow_cnt[5], 0u);
+                        __atomic_store_n(&c->status, handed ? 1u : 0u, __ATOMIC_RELAXED);
+                        __atomic_store_n(&c->served, c->served + 1u, __ATOMIC_RELAXED);
+                        __threadfence_system();
+                        __atomic_store_n(&c->done_seq, serve_seq, __ATOMIC_RELAXED);
+                    }
+                    const unsigned long long t0 = wall_clock64(), idle = __atomic_load_n(&c->idle_ticks, __ATOMIC_RELAXED);
+                    uint32_t leave = 0u, s = serve_seq;
+                    for (;;) {
+                        s = __atomic_load_n(&c->seq, __ATOMIC_RELAXED);
+                        if (s != serve_seq) break;
+                        if (__atomic_load_n(&c->stop, __ATOMIC_RELAXED) != 0u || wall_clock64() - t0 > idle) { leave = 1u; break; }
+                    }
+                    if (!leave) {
+                        __threadfence_system();   // (acquire: the session was written before its number)
+                        serve_seq = s; serve_have = true;
+                        const uint32_t n = min(__atomic_load_n(&c->len, __ATOMIC_RELAXED), 16u);
+                        for (uint32_t i = 0; i < n; ++i) sv_items[i] = __atomic_load_n(&c->items[i], __ATOMIC_RELAXED);
+                        sv_off[0] = 0u; sv_off[1] = n;
+                    }
+                    sv_flag[0] = leave;
+                }
+                __syncthreads();
+                if (sv_flag[0] != 0u) break;   // (block-uniform)
+                if (tid < PREP_LANES) prep_group(ix_arg, (const uint64_t*)sv_items, (const uint32_t*)sv_off, 0u, tid, p.m, p.max_len, const_cast<char*>(p.prep), nullptr, 0u, nullptr);
+                __syncthreads();
+            }
+        }
         const uint32_t q = TINY ? qi : LONG ? f.long_list[qi] : BIG ? f.bigq_list[qi] : MID || listed ? f.mid_list[qi] : ordered ? (uint32_t)f.order[ord_pos(ox, qi)] : qi;   // (TINY: the launch's one query, MID form included)
         const uint32_t q_ord_next = ordered && qi + qi_step < qi_end ? (uint32_t)f.order[ord_pos(ox, qi + qi_step)]
                                   : listed && qi + qi_step < qi_end ? f.mid_list[qi + qi_step] : 0xFFFFFFFFu;   // (the query this workgroup serves next: its record is parked during this one)
@@ -1377,6 +1423,7 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
     }
     if (ticking) { __syncthreads(); if (tid < 16u && tacc[tid]) atomicAdd(&p.phase_cycles[tid], tacc[tid]); }
     if constexpr (TINY) {
+        if (serving) { if (tid == 0u) { __threadfence_system(); __atomic_store_n(&f.serve->alive, 0u, __ATOMIC_RELAXED); } return; }
         // every append and every row of this workgroup was wave 0's (thread 0's atomics, the wave's stores): behind thread 0 in program order.  The workgroups count
         // themselves off; the last one publishes the counters and, behind a system-scope fence, the call's number -- the word the caller spins on.
         if (wave == 0u && f.host_words) __threadfence_system();   // (executed by EVERY lane that stored a row: a fence orders the executing thread's accesses -- ADVICE r5)

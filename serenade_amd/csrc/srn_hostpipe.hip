@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "srn_runtime.h"
+#include "srn_hipsync.h"
 
 namespace srn {
 

@@ -175,6 +175,14 @@ int device_shard_lists_predict(DeviceState* d, const FlatIndex& ix, const Launch
                                const unsigned long long* shard_base = nullptr, bool direct = false);   // shard_base [n_shards] (device): the shards' segment starts (null: g * shard_stride); direct: a group of one shard reads its lists in place (lists_g = null)
 int device_shard_stage(DeviceState* d, const FlatIndex& ix, int stage, const LaunchParams& p, const ShardIO& sh, void* stream);
 int device_slot_bytes(DeviceState* d, const FlatIndex& ix, uint32_t max_len, uint32_t* num_bits = nullptr);
+// ---- the persistent latency path (round 6): resident workgroups that serve srn_predict's call shape without a launch ----
+// lanes: resident workgroups of the lean form (sessions of <= 4 items); max_items >= 5: as many of the MID form (5..10 items) beside them; idle_ms: a resident workgroup
+// leaves by itself after that long without a request (it is started again by the next call that wants it)
+int device_serve_start(DeviceState* d, const FlatIndex& ix, uint32_t k, uint32_t m, uint32_t how_many, uint32_t flags, uint32_t lanes, uint32_t max_items, uint32_t idle_ms);
+int device_serve_stop(DeviceState* d);
+// 0: served, *out_n rows written; 1: not served (no free lane, another configuration, a session the fused form hands on): the caller takes the launch path
+int device_serve_predict(DeviceState* d, const uint64_t* items, uint32_t len, uint32_t k, uint32_t m, uint32_t how_many, uint32_t flags, uint64_t* out_ids, double* out_scores, size_t* out_n);
+int device_serve_stats(DeviceState* d, uint64_t* served, uint64_t* not_served, uint64_t* launches, uint32_t* lanes);
 int device_last_kernel_ms(DeviceState* d, double* ms_main, double* ms_retry, uint32_t* retried);
 int device_phase_cycles(DeviceState* d, int enable, unsigned long long* out16);
 int device_kernel_timing(DeviceState* d, int enable);

@@ -82,6 +82,18 @@ static constexpr uint32_t F_LONG_LISTS = 20, F_LONG_LMAX = 20, F_LONG_CLASSES = 
 static constexpr uint32_t F_LONG_RES_WORDS = F_K_MAX * 2 + F_M_MAX / 4 + 256;   // the tail of the merge buffers' room it reserves: neighbour list (uint2) | numerator bytes of the m-cut | class histogram
 static_assert(F_LDS_BYTES * F_WG_PER_CU <= 160 * 1024, "LDS budget");
 static_assert(F_DUMP + F_DUMP_WORDS * 4 - F_HOT <= 65536, "16-bit row offsets");
+// (round 6) The PERSISTENT latency path's control block: 256 bytes of pinned, device-mapped, coherent host memory per resident workgroup.  The host writes a session
+// and then its number (seq); thread 0 of the workgroup polls seq (1.6 us round trip measured, tools/ring_probe.hip), the workgroup serves the session exactly like the
+// one-launch form (vmis_fast_kernel<TINY>: prep record, query, row finished from registers into the pinned row) and answers with done_seq.  No launch, no completion signal.
+struct ServeCtl {
+    unsigned long long items[16];            // host -> device: the evolving session (public ids, oldest first)
+    uint32_t len, seq, stop, pad0;           //                 seq is written LAST; stop != 0: leave
+    unsigned long long idle_ticks, pad1;     //                 leave after this many wall-clock ticks (100 MHz) without a request: a host that died leaves no kernel behind
+    uint32_t pad_h[8];                       // (the device's words in a 64-byte line of their own)
+    uint32_t done_seq, status, alive, served;   // device -> host: status 0 = the row is final, 1 = the session needs the kernels behind the fused form (the caller takes the launch path); alive = 0 once the kernel has left
+    uint32_t pad2[12];
+};
+static_assert(sizeof(ServeCtl) == 256, "ServeCtl layout");
 struct FastParams {
     const RowQuad* row_packed; const uint32_t* row_ext16;   // 64-byte slots of 16-bit LDS offsets + overflow blocks (8 items per 16 bytes)
     const ItemMeta* meta_sample;   // meta[] of the 512 most popular items in the order the threshold sample reads them: entry 64 w + l = item 8 l + w
@@ -103,6 +115,7 @@ struct FastParams {
     // Workgroup b serves positions of the (b % 8)-th eighth of the order -- block b runs on XCD b % 8: what one XCD's L2 sees is a window of like queries
     const unsigned long long* order;
     uint64_t tiny_items[8]; uint32_t tiny_len, host_seq;   // (the TINY launch) the session's items in the kernel arguments (tiny_len = 0: read p.items_flat), the call's number
+    ServeCtl* serve;            // (the TINY launch) non-null: the persistent form -- grid of ONE workgroup that serves the sessions the host posts here until told to leave
     uint32_t* host_words;       // (the TINY launch) pinned words the kernel publishes the sequence's counters in: [1] handed to the general kernel, [2] listed for MID, [3] for MID's BIG form, [4] queries with > 63 entries, and last of all [5] = host_seq: the host may read the row
 };
 // the batch's order keys (written by the prep kernel) -> sorted (srn_build_gpu.hip: rocPRIM radix sort on the key bits); temp == nullptr: only *temp_bytes is set

@@ -100,8 +100,10 @@ struct Workspace {
     hipStream_t side = nullptr; hipEvent_t ev_prep[2] = {}, ev_done[2] = {}; char* prep2 = nullptr; size_t prep2_bytes = 0; uint64_t resident_calls = 0; bool rec_used[2] = {false, false};
 };
 
+struct ServeState;   // the persistent latency path's resident workgroups (srn_runtime.hip, "serve")
 struct DeviceState {
     int device = 0;
+    std::atomic<ServeState*> serve{nullptr};
     std::vector<void*> allocs; uint64_t bytes = 0;
     DeviceIndex di{};
     ItemMeta* d_meta = nullptr;

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "srn_runtime.h"
+#include "srn_hipsync.h"
 
 namespace srn {
 
@@ -222,6 +223,7 @@ static void ws_free(Workspace* w) {
 
 void device_release(DeviceState* d) {
     if (!d) return;
+    (void)device_serve_stop(d);
     hipSetDevice(d->device);
     hostpipes_free(d);
     for (Workspace* w : d->all_ws) ws_free(w);
@@ -601,6 +603,162 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
         std::fill(h_scores + (size_t)q * p.how_many + n, h_scores + (size_t)(q + 1) * p.how_many, 0.0);
     }
     return SRN_OK;
+}
+
+
+// =====================================================================================================================================================================
+// The PERSISTENT latency path (round 6).  srn_predict on the one-launch form costs 28 us from a C++ host of which ~13 us are the GPU's work: the rest
+// is queue submission and completion signalling.  Here a workgroup of vmis_fast_kernel<TINY> stays RESIDENT (one third of one CU) and polls a pinned control block
+// (ServeCtl, srn_kernels.h): the host writes the session and then its number, the workgroup serves it -- same code, same rows -- and answers with the number; the host
+// spins on its own memory.  Doorbell round trip measured on this platform: 1.6 us (tools/ring_probe.hip).  A session the fused form would hand on (general kernel, MID,
+// > 63 entries: 0.3-3 % of config 3's) comes back with status 1 and takes the launch path, as does any call whose k / m / how_many / flags are not the resident ones.
+// hipFree / hipDeviceSynchronize would wait for a resident workgroup for ever: every such call of the library goes through srn_hipsync.h, which makes them leave first.
+// =====================================================================================================================================================================
+struct ServeLane {
+    DeviceState* d = nullptr; bool mid = false; bool dead = false;
+    hipStream_t st = nullptr;
+    ServeCtl* ctl = nullptr; ServeCtl* ctl_dev = nullptr;
+    char* rows = nullptr; char* rows_dev = nullptr;   // pinned: ids | scores | count
+    char *prep = nullptr, *fin = nullptr, *big = nullptr; uint32_t *slow_list = nullptr, *slow_cnt = nullptr;
+    LaunchParams p{}; FastParams fp{};
+    std::atomic<int> busy{0}; bool running = false; uint32_t seq = 0;
+};
+struct ServeState {
+    std::vector<ServeLane*> lanes; uint32_t k = 0, m = 0, how_many = 0, flags = 0, max_items = 0; unsigned long long idle_ticks = 0;
+    std::atomic<uint64_t> served{0}, not_served{0}, launches{0};
+};
+static std::mutex g_serve_mu; static std::vector<ServeLane*> g_serve_lanes; static std::atomic<int> g_serve_running{0};
+
+static void lane_lock(ServeLane* l) { int e = 0; while (!l->busy.compare_exchange_weak(e, 1, std::memory_order_acquire)) { e = 0; __builtin_ia32_pause(); } }
+static void lane_unlock(ServeLane* l) { l->busy.store(0, std::memory_order_release); }
+// (lane held) the resident workgroup leaves: told to, or already gone by its idle timeout
+static void lane_park(ServeLane* l) {
+    if (!l->running) return;
+    int cur = 0; (void)hipGetDevice(&cur);
+    if (cur != l->d->device) (void)hipSetDevice(l->d->device);
+    __atomic_store_n(&l->ctl->stop, 1u, __ATOMIC_RELEASE);
+    (void)hipStreamSynchronize(l->st);
+    if (cur != l->d->device) (void)hipSetDevice(cur);
+    l->running = false; g_serve_running.fetch_sub(1);
+}
+void serve_quiesce_all() {
+    if (g_serve_running.load(std::memory_order_acquire) == 0) return;
+    std::lock_guard<std::mutex> lk(g_serve_mu);
+    for (ServeLane* l : g_serve_lanes) { lane_lock(l); lane_park(l); lane_unlock(l); }
+}
+// (lane held) start the resident workgroup
+static int lane_launch(ServeState* s, ServeLane* l) {
+    HIP_TRY(hipSetDevice(l->d->device));
+    if (l->running) { HIP_TRY(hipStreamSynchronize(l->st)); l->running = false; g_serve_running.fetch_sub(1); }   // (it left by its idle timeout: alive == 0)
+    l->ctl->stop = 0; l->ctl->alive = 1; l->ctl->idle_ticks = s->idle_ticks;
+    l->ctl->seq = l->seq; l->ctl->done_seq = l->seq;   // (the kernel takes the number it finds as "already dealt with": a post that an earlier launch never answered is not served late)
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    HIP_TRY(hipMemsetAsync(l->slow_cnt, 0, 32, l->st));
+    HIP_TRY(launch_fast(dim3(1), l->st, l->d->di, l->p, l->fp, false, 0, l->mid, false, false, true));
+    l->running = true; g_serve_running.fetch_add(1); s->launches.fetch_add(1);
+    return SRN_OK;
+}
+static void lane_free(ServeLane* l) {
+    { std::lock_guard<std::mutex> lk(g_serve_mu); g_serve_lanes.erase(std::remove(g_serve_lanes.begin(), g_serve_lanes.end(), l), g_serve_lanes.end()); }
+    lane_lock(l); lane_park(l);
+    for (void* q : {(void*)l->prep, (void*)l->fin, (void*)l->big, (void*)l->slow_list, (void*)l->slow_cnt}) if (q) (void)hipFree(q);
+    if (l->ctl) (void)hipHostFree(l->ctl); if (l->rows) (void)hipHostFree(l->rows);
+    if (l->st) (void)hipStreamDestroy(l->st);
+    delete l;
+}
+int device_serve_stop(DeviceState* d) {
+    ServeState* s = d->serve.exchange(nullptr);
+    if (!s) return SRN_OK;
+    HIP_TRY(hipSetDevice(d->device));
+    for (ServeLane* l : s->lanes) lane_free(l);
+    delete s;
+    return SRN_OK;
+}
+int device_serve_start(DeviceState* d, const FlatIndex& ix, uint32_t k, uint32_t m, uint32_t how_many, uint32_t flags, uint32_t lanes, uint32_t max_items, uint32_t idle_ms) {
+    int rc = device_serve_stop(d); if (rc) return rc;
+    if (lanes == 0) return SRN_OK;
+    if (lanes > 64) return fail(SRN_ERANGE, "at most 64 resident workgroups");
+    HIP_TRY(hipSetDevice(d->device));
+    const Knobs kn = knobs();
+    ServeState* s = new ServeState(); s->k = k; s->m = m; s->how_many = how_many; s->flags = flags; s->max_items = std::min<uint32_t>(std::max<uint32_t>(max_items, 1), F_MID_LMAX);
+    s->idle_ticks = (unsigned long long)std::max<uint32_t>(idle_ms, 1) * 100000ull;   // (wall_clock64: 100 MHz)
+    auto undo = [&](int code, const std::string& why) { for (ServeLane* l : s->lanes) lane_free(l); delete s; return fail(code, why); };
+    for (int form = 0; form < (s->max_items > 4 ? 2 : 1); ++form)
+        for (uint32_t i = 0; i < lanes; ++i) {
+            ServeLane* l = new ServeLane(); l->d = d; l->mid = form == 1; s->lanes.push_back(l);
+            { std::lock_guard<std::mutex> lk(g_serve_mu); g_serve_lanes.push_back(l); }
+            LaunchParams& p = l->p;
+            p.nq = 1; p.k = k; p.m = m; p.how_many = how_many; p.flags = flags; p.max_len = l->mid ? F_MID_LMAX : 8u;
+            Geometry geo; if (make_geometry(d, ix, p, 0, geo) != SRN_OK) return undo(SRN_EINVAL, "the persistent latency path: no LDS geometry for these parameters");
+            const FastPlan plan = fast_plan(d, ix, p, geo, kn, false);
+            if (!plan.fast || (l->mid && !plan.mid_tier)) return undo(SRN_EINVAL, "the persistent latency path serves what the fast kernels serve (k <= 1536, m <= 2560 and <= m_index, how_many <= 64, complete lists)");
+            const size_t row_bytes = (size_t)how_many * 16 + 64;
+            if (hipStreamCreateWithFlags(&l->st, hipStreamNonBlocking) != hipSuccess ||
+                hipHostMalloc((void**)&l->ctl, sizeof(ServeCtl), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+                hipHostMalloc((void**)&l->rows, row_bytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+                hipHostGetDevicePointer((void**)&l->ctl_dev, l->ctl, 0) != hipSuccess || hipHostGetDevicePointer((void**)&l->rows_dev, l->rows, 0) != hipSuccess)
+                return undo(SRN_ENOMEM, "the persistent latency path: pinned control block");
+            memset(l->ctl, 0, sizeof(ServeCtl)); memset(l->rows, 0, row_bytes);
+            const uint32_t prep_stride = (uint32_t)(sizeof(PrepHead) + (size_t)p.max_len * sizeof(PrepItem));
+            const uint64_t big_entries = 16 + 4096;
+            if (hipMalloc((void**)&l->prep, prep_stride + 256) != hipSuccess || hipMalloc((void**)&l->fin, F_FIN_BYTES + 1024) != hipSuccess || hipMalloc((void**)&l->big, big_entries * 16 + 4 + 64) != hipSuccess ||
+                hipMalloc((void**)&l->slow_list, (1 * 4 + 64) * 4) != hipSuccess || hipMalloc((void**)&l->slow_cnt, 32) != hipSuccess)
+                return undo(SRN_ENOMEM, "the persistent latency path: device scratch");
+            p.items_flat = nullptr; p.q_off = nullptr;
+            p.out_ids = (uint64_t*)l->rows_dev; p.out_scores = (double*)(l->rows_dev + (size_t)how_many * 8); p.out_counts = (uint32_t*)(l->rows_dev + (size_t)how_many * 16);
+            p.stats = nullptr; p.nb_rank = p.nb_num = p.nb_cnt = nullptr; p.phase_cycles = nullptr; p.prep = l->prep; p.prep_stride = prep_stride;
+            FastParams& fp = l->fp; fp = d->fast;
+            fp.slow_list = l->slow_list; fp.slow_cnt = l->slow_cnt; fp.nb = plan.nb_fast; fp.max_runs = plan.nb_fast; fp.fin = l->fin;
+            fp.big_arena = l->big; fp.big_list = (uint32_t*)(l->big + big_entries * 16); fp.big_ticket = (unsigned long long*)(l->slow_cnt + 2); fp.big_cap_entries = (uint32_t)big_entries;
+            fp.xchg = nullptr; fp.xchg_stride = 0; fp.q_base = 0; fp.order = nullptr; fp.mid_list = nullptr; fp.mid_cnt = nullptr; fp.bigq_list = nullptr; fp.bigq_cnt = nullptr; fp.long_list = nullptr; fp.long_cnt = nullptr;
+            fp.tiny_len = 0; fp.host_seq = 0; fp.host_words = nullptr; fp.serve = l->ctl_dev;
+        }
+    for (ServeLane* l : s->lanes) { lane_lock(l); rc = lane_launch(s, l); lane_unlock(l); if (rc) return undo(rc, last_error_string()); }
+    d->serve.store(s);
+    return SRN_OK;
+}
+int device_serve_stats(DeviceState* d, uint64_t* served, uint64_t* not_served, uint64_t* launches, uint32_t* lanes) {
+    ServeState* s = d->serve.load();
+    if (served) *served = s ? s->served.load() : 0; if (not_served) *not_served = s ? s->not_served.load() : 0; if (launches) *launches = s ? s->launches.load() : 0;
+    if (lanes) *lanes = s ? (uint32_t)s->lanes.size() : 0;
+    return SRN_OK;
+}
+int device_serve_predict(DeviceState* d, const uint64_t* items, uint32_t len, uint32_t k, uint32_t m, uint32_t how_many, uint32_t flags, uint64_t* out_ids, double* out_scores, size_t* out_n) {
+    ServeState* s = d->serve.load(std::memory_order_acquire);
+    if (!s || k != s->k || m != s->m || how_many != s->how_many || flags != s->flags || len == 0 || len > s->max_items) return 1;
+    const bool want_mid = len > 4;
+    ServeLane* l = nullptr;
+    for (ServeLane* c : s->lanes) { if (c->mid != want_mid || c->dead) continue; int e = 0; if (c->busy.compare_exchange_strong(e, 1, std::memory_order_acquire)) { l = c; break; } }
+    if (!l) { s->not_served.fetch_add(1); return 1; }   // (every resident workgroup of that form is taken: the launch path)
+    if (!l->running || __atomic_load_n(&l->ctl->alive, __ATOMIC_ACQUIRE) == 0u) { const int rc = lane_launch(s, l); if (rc) { l->dead = true; lane_unlock(l); return 1; } }
+    ServeCtl* c = l->ctl;
+    for (uint32_t i = 0; i < len; ++i) c->items[i] = items[i];
+    c->len = len;
+    uint32_t seq = ++l->seq; if (seq == 0u) seq = ++l->seq;
+    __atomic_store_n(&c->seq, seq, __ATOMIC_RELEASE);
+    const auto t0 = std::chrono::steady_clock::now();
+    bool seen = false;
+    for (uint32_t spin = 0;; ++spin) {
+        if (__atomic_load_n(&c->done_seq, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
+        __builtin_ia32_pause();
+        if ((spin & 1023u) == 1023u) {
+            if (__atomic_load_n(&c->alive, __ATOMIC_ACQUIRE) == 0u) break;   // (it left between our look and our post: its idle timeout)
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) { l->dead = true; break; }   // (a fault: the lane is not used again; srn_index_serve_stop reports what the stream says)
+        }
+    }
+    int ret = 1;
+    if (seen && __atomic_load_n(&c->status, __ATOMIC_RELAXED) == 0u) {
+        const uint32_t cnt = *(volatile uint32_t*)(l->rows + (size_t)how_many * 16);
+        if ((cnt & 0x80000000u) == 0u) {
+            const uint32_t n = std::min<uint32_t>(cnt, how_many);
+            memcpy(out_ids, l->rows, (size_t)n * 8); memcpy(out_scores, l->rows + (size_t)how_many * 8, (size_t)n * 8);
+            *out_n = n; ret = 0;
+        }
+    }
+    if (!seen && !l->dead) { /* the post may still be picked up by a later launch: make it a no-op */ l->seq = seq; }
+    lane_unlock(l);
+    (ret == 0 ? s->served : s->not_served).fetch_add(1);
+    return ret;
 }
 
 // the workspace's side stream (highest priority: a hardware queue of its own, dispatched ahead of the running call's persistent workgroups) and its events

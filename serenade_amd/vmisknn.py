@@ -114,6 +114,19 @@ class VMISIndex:
         capi.check(capi.lib().srn_index_items_for_session(self._h, int(session), capi.ptr(out), n.value, C.byref(n)))
         return out[:n.value]
 
+    def serve_start(self, k, m, how_many, enable_business_logic=False, lanes=1, max_items_in_session=4, idle_ms=2000):
+        """srn_index_serve_start: park `lanes` resident workgroups that answer predict() calls of exactly these parameters without a kernel launch."""
+        capi.check(capi.lib().srn_index_serve_start(self._h, int(k), int(m), int(how_many), int(bool(enable_business_logic)), int(lanes), int(max_items_in_session), int(idle_ms)))
+
+    def serve_stop(self):
+        capi.check(capi.lib().srn_index_serve_stop(self._h))
+
+    def serve_stats(self):
+        """(answered by a resident workgroup, sent to the launch path, kernel launches, resident workgroups)"""
+        a, b, c, n = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint32()
+        capi.check(capi.lib().srn_index_serve_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
+        return a.value, b.value, c.value, n.value
+
     def session_recency(self):
         """Recency rank of every reference session (0 = oldest; 0xFFFFFFFF: not kept): the total order behind "most recent", ties among equal timestamps included."""
         n = int(self.info["n_sessions_total"])

@@ -116,3 +116,75 @@ def test_recommend_follows_the_reference_handler():
     assert recommend(b, None, "x", int(ids[0]), False, 3) == [int(i) for i in oix.predict_canonical([int(ids[0])], 50, 200, 21, False)[0]]
     b.close()
     store.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_persistent_latency_path_against_the_oracle():
+    """srn_index_serve_start (round 6): resident workgroups answer srn_predict -- the reference's call shape, recommend_resource.rs:56 / evaluator.rs:58 -- without a kernel
+    launch.  Every answer against the canonical oracle (a session the resident form cannot finish silently takes the launch path: same rows); calls with other
+    parameters are not served by it; a call that frees device memory (a workspace that grows) makes the resident workgroups leave instead of waiting for them for ever,
+    and they come back; they leave by themselves after idle_ms; concurrent callers share the lanes."""
+    import threading
+    import time
+    import serenade_amd as sa
+    from serenade_amd import synth
+    from oracle import oracle as O
+    inter, n_items, k, m, idfw = synth.CONFIGS["tiny"]
+    off, items, ts = synth.training_sessions(inter, n_items)
+    gix = sa.VMISIndex.from_sessions(off, items, ts, m, 34, idfw)
+    oix = O.OracleIndex(off, items, ts, m, 34, idfw, fast=True)
+    qi, qo = synth.queries(400, n_items, max_items=10)
+    sessions = [qi[qo[q]:qo[q + 1]] for q in range(600)]
+    want = [oix.predict_canonical(s, k, m, 21) for s in sessions]
+
+    def check(q, got):
+        ids, sc = want[q]
+        assert [i for i, _ in got] == ids.tolist(), q
+        np.testing.assert_allclose([x for _, x in got], sc, rtol=1e-12, atol=0)
+
+    sa.predict(gix, sessions[0], k, m, 21, False)                          # (the launch path's workspace exists before anything is resident)
+    gix.serve_start(k, m, 21, False, lanes=2, max_items_in_session=10, idle_ms=1500)
+    assert gix.serve_stats()[2:] == (4, 4)                                  # 2 lanes of the lean form + 2 of the form for 5..10 items, one launch each
+    for q in range(300):
+        check(q, sa.predict(gix, sessions[q], k, m, 21, False))
+    served, not_served, launches, lanes = gix.serve_stats()
+    assert served + not_served == 300 and served >= 270 and launches == 4, (served, not_served, launches)
+    # other parameters: the launch path, same answers as ever
+    got = sa.predict(gix, sessions[5], k // 2, m, 21, False)
+    ids, sc = oix.predict_canonical(sessions[5], k // 2, m, 21)
+    assert [i for i, _ in got] == ids.tolist() and gix.serve_stats()[0] == served
+    # a batch whose workspace has to grow frees device memory: the resident workgroups leave first (no deadlock) and are started again on demand
+    bq, bo = synth.queries(3000, n_items)
+    rows = sa.predict_batch(gix, (bq, bo), k, m, 21, False)
+    ref = oix.predict_batch("canonical", bq, bo, k, m, 21, False, threads=4)
+    assert np.array_equal(rows[0], ref["ids"]) and np.array_equal(rows[2], ref["counts"])
+    for q in range(300, 340):
+        check(q, sa.predict(gix, sessions[q], k, m, 21, False))
+    s2 = gix.serve_stats()
+    assert s2[0] > served and s2[2] > launches, s2                          # served again, after a restart
+    # idle: they leave by themselves ...
+    time.sleep(2.5)
+    launches = gix.serve_stats()[2]
+    for q in range(340, 360):
+        check(q, sa.predict(gix, sessions[q], k, m, 21, False))
+    assert gix.serve_stats()[2] > launches                                  # ... and come back
+    # concurrent callers share the lanes; who finds them taken runs the launch path
+    errs = []
+
+    def worker(t):
+        try:
+            for q in range(360 + t * 60, 360 + (t + 1) * 60):
+                check(q, sa.predict(gix, sessions[q], k, m, 21, False))
+        except Exception as e:  # pragma: no cover
+            errs.append(repr(e))
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    gix.serve_stop()
+    assert gix.serve_stats()[3] == 0
+    check(1, sa.predict(gix, sessions[1], k, m, 21, False))
+    gix.close()
