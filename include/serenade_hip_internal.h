@@ -26,6 +26,9 @@ int srn_debug_shard_group_times(const srn_shard_group_t* g, double* out_ms3);
 /* Measurement aid: how many queries of the last predict call the lean fast kernel listed for its MID instantiation (sessions of <= 10 items with 5..8 posting lists or
  * similarity numerators above 15: DESIGN.md section 4.1); srn_last_path_counts' `general` counts what reached the general kernel after both.  0 when the call had no such tier. */
 int srn_debug_last_mid_count(const srn_index_t* idx, uint32_t* out_listed);
+/* the persistent latency path: 100 MHz ticks of the last session the lean form's first resident workgroup served -- [0] waited for the doorbell, [1] doorbell -> prep record
+ * written, [2] doorbell -> answer posted */
+int srn_debug_serve_stamps(const srn_index_t* idx, uint32_t* out4);
 /* ... and how many of those MID listed for its BIG form (80 KB of LDS: merged lists beyond the 53 KB layout's buffers). */
 int srn_debug_last_big_count(const srn_index_t* idx, uint32_t* out_listed);
 

@@ -461,6 +461,10 @@ int srn_last_path_counts(const srn_index_t* idx, uint32_t* out_nq, uint32_t* out
     if (!idx || !idx->dev) return fail(SRN_ENODEV, "index has no device attached");
     return guarded([&]() -> int { return device_last_path_counts(idx->dev, out_nq, out_general, out_global_pass); });
 }
+int srn_debug_serve_stamps(const srn_index_t* idx, uint32_t* out4) {
+    if (!idx || !idx->dev || !out4) return fail(SRN_EINVAL, "null argument");
+    return device_serve_last_stamps(idx->dev, out4);
+}
 int srn_debug_last_mid_count(const srn_index_t* idx, uint32_t* out_listed) {
     if (!idx || !idx->dev) return fail(SRN_ENODEV, "index has no device attached");
     return guarded([&]() -> int { return device_last_mid_count(idx->dev, out_listed); });

@@ -455,8 +455,8 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
     const uint32_t ox = blockIdx.x & 7u;
     const bool serving = TINY && f.serve != nullptr;   // (launch-uniform) the persistent form: the loop below never advances, every round is one posted session
     const uint32_t qi_step = serving ? 0u : ordered ? gridDim.x >> 3 : gridDim.x;
-    uint32_t serve_seq = 0u; bool serve_have = false;   // (thread 0) the number of the request being served (before the first one: the number that was current at the launch)
-    if constexpr (TINY) { if (serving && tid == 0u) serve_seq = __atomic_load_n(&f.serve->seq, __ATOMIC_RELAXED); }
+    uint32_t serve_seq = 0u; bool serve_have = false; unsigned long long serve_t0 = 0ull, serve_c0 = 0ull;   // (wave 0) the number of the request being served; before the first one: the number the host left in done_seq at the launch
+    if constexpr (TINY) { if (serving) serve_seq = __atomic_load_n(&(f.serve + blockIdx.x)->done_seq, __ATOMIC_RELAXED); }   // (the host writes done_seq only while no kernel is resident)
     const uint32_t qi_end = ordered ? ord_count(p.nq, ox) : q_end;
     for (uint32_t qi = ordered ? blockIdx.x >> 3 : (MODE == FM_FRONT ? f.q_base : 0u) + blockIdx.x; qi < qi_end; qi += qi_step) {
         if constexpr (TINY) {
@@ -465,39 +465,51 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
                 // (every path of the body ends here: the `continue`s of the hand-overs too; wave 0 finished the row from its registers before it arrived)
                 uint32_t* const sv_flag = reinterpret_cast<uint32_t*>(smem + F_W10 + 64 + 192);   // (behind the posted items and their offsets; the weight table's tail is unused in this launch)
                 unsigned long long* const sv_items = reinterpret_cast<unsigned long long*>(smem + F_W10 + 64); uint32_t* const sv_off = reinterpret_cast<uint32_t*>(smem + F_W10 + 64 + 128);
+                ServeCtl* const c = f.serve + blockIdx.x;
                 __syncthreads();
-                if (wave == 0u) __threadfence_system();   // (the row's stores of every lane before the answer)
-                if (tid == 0u) {
-                    ServeCtl* const c = f.serve;
-                    if (serve_have) {
-                        // what the body handed on (general kernel, MID, BIG, LONG, > 63 entries) nobody will launch: the caller takes the launch path for this session
-                        const uint32_t handed = atomicExch(&f.slow_cnt[0], 0u) | atomicExch(&f.slow_cnt[1], 0u) | atomicExch(&f.slow_cnt[2], 0u) | atomicExch(&f.slow_cnt[3], 0u) |
-                                                atomicExch(&f.slow_cnt[4], 0u) | atomicExch(&f.slow_cnt[5], 0u);
-                        __atomic_store_n(&c->status, handed ? 1u : 0u, __ATOMIC_RELAXED);
-                        __atomic_store_n(&c->served, c->served + 1u, __ATOMIC_RELAXED);
+                if (wave == 0u) {
+                    __threadfence_system();   // (the row's stores of every lane before the answer)
+                    uint32_t leave = 0u;
+                    if (serve_have && lane == 0u) {
+                        // a row is final iff a finishing path wrote its count over the sentinel; what the body handed on (general kernel, MID, > 63 entries) nobody
+                        // will launch: the caller takes the launch path for this session.  The hand-over counters are nobody's business here: back to 0
+                        const uint32_t cnt = __atomic_load_n(&p.out_counts[blockIdx.x], __ATOMIC_RELAXED);
+                        if (cnt & 0x80000000u) { (void)atomicExch(&f.slow_cnt[0], 0u); (void)atomicExch(&f.slow_cnt[1], 0u); (void)atomicExch(&f.slow_cnt[2], 0u); (void)atomicExch(&f.slow_cnt[3], 0u); }
+                        const unsigned long long t_end = wall_clock64();
+                        c->stamp[2] = (uint32_t)(t_end - serve_t0); c->stamp[3] = (uint32_t)((unsigned long long)clock64() - serve_c0);   // ([3]: the same span in shader cycles)
+                        __atomic_store_n(&c->count, cnt, __ATOMIC_RELAXED);
+                        __atomic_store_n(&c->status, (cnt & 0x80000000u) ? 1u : 0u, __ATOMIC_RELAXED);
                         __threadfence_system();
                         __atomic_store_n(&c->done_seq, serve_seq, __ATOMIC_RELAXED);
                     }
-                    const unsigned long long t0 = wall_clock64(), idle = __atomic_load_n(&c->idle_ticks, __ATOMIC_RELAXED);
-                    uint32_t leave = 0u, s = serve_seq;
+                    // the doorbell: the first 64-byte line of the control block in ONE 16-lane load -- number, length, check word, the first five items; the host wrote the
+                    // number last, and the check word (number ^ length ^ the items' halves) says the line was seen whole
+                    const unsigned long long t0 = wall_clock64(), idle = __builtin_nontemporal_load(&c->idle_ticks);
+                    uint32_t w = 0u, s_new = 0u, n = 0u;
                     for (;;) {
-                        s = __atomic_load_n(&c->seq, __ATOMIC_RELAXED);
-                        if (s != serve_seq) break;
-                        if (__atomic_load_n(&c->stop, __ATOMIC_RELAXED) != 0u || wall_clock64() - t0 > idle) { leave = 1u; break; }
+                        if (lane < 16u) w = __atomic_load_n(reinterpret_cast<const uint32_t*>(c) + lane, __ATOMIC_RELAXED);
+                        s_new = (uint32_t)__builtin_amdgcn_readlane((int)w, 0); n = min((uint32_t)__builtin_amdgcn_readlane((int)w, 1), 16u);
+                        if (s_new != serve_seq) {
+                            uint32_t x = lane >= 4u && lane < 4u + 2u * min(n, 5u) ? w : 0u;
+#pragma unroll
+                            for (int d = 1; d < 16; d <<= 1) x ^= __shfl_xor(x, d, 16);
+                            if ((uint32_t)__builtin_amdgcn_readlane((int)x, 0) == ((uint32_t)__builtin_amdgcn_readlane((int)w, 2) ^ s_new ^ n)) break;   // (a torn line: look again)
+                        }
+                        if ((uint32_t)__builtin_amdgcn_readlane((int)w, 3) != 0u || wall_clock64() - t0 > idle) { leave = 1u; break; }   // (stop rides in the doorbell's line)
                     }
                     if (!leave) {
-                        __threadfence_system();   // (acquire: the session was written before its number)
-                        serve_seq = s; serve_have = true;
-                        const uint32_t n = min(__atomic_load_n(&c->len, __ATOMIC_RELAXED), 16u);
-                        for (uint32_t i = 0; i < n; ++i) sv_items[i] = __atomic_load_n(&c->items[i], __ATOMIC_RELAXED);
-                        sv_off[0] = 0u; sv_off[1] = n;
+                        serve_seq = s_new; serve_have = true; serve_t0 = wall_clock64(); serve_c0 = (unsigned long long)clock64();
+                        if (lane >= 4u && lane < 14u) reinterpret_cast<uint32_t*>(sv_items)[lane - 4u] = w;                                       // items 0..4 came with the doorbell
+                        if (n > 5u && lane < 2u * (n - 5u)) reinterpret_cast<uint32_t*>(sv_items)[10u + lane] = __atomic_load_n(reinterpret_cast<const uint32_t*>(c->more) + lane, __ATOMIC_RELAXED);   // (a session of > 5 items: one more line)
+                        if (lane == 0u) { sv_off[0] = 0u; sv_off[1] = n; p.out_counts[blockIdx.x] = 0x80000002u; c->stamp[0] = (uint32_t)(serve_t0 - t0); }   // (the sentinel: no finishing path has written this row's count)
                     }
-                    sv_flag[0] = leave;
+                    if (lane == 0u) sv_flag[0] = leave;
                 }
                 __syncthreads();
                 if (sv_flag[0] != 0u) break;   // (block-uniform)
-                if (tid < PREP_LANES) prep_group(ix_arg, (const uint64_t*)sv_items, (const uint32_t*)sv_off, 0u, tid, p.m, p.max_len, const_cast<char*>(p.prep), nullptr, 0u, nullptr);
+                if (tid < PREP_LANES) prep_group(ix_arg, (const uint64_t*)sv_items, (const uint32_t*)sv_off, 0u, tid, p.m, p.max_len, const_cast<char*>(p.prep) + (size_t)blockIdx.x * p.prep_stride, nullptr, 0u, nullptr);
                 __syncthreads();
+                if (tid == 0u) c->stamp[1] = (uint32_t)(wall_clock64() - serve_t0);
             }
         }
         const uint32_t q = TINY ? qi : LONG ? f.long_list[qi] : BIG ? f.bigq_list[qi] : MID || listed ? f.mid_list[qi] : ordered ? (uint32_t)f.order[ord_pos(ox, qi)] : qi;   // (TINY: the launch's one query, MID form included)
@@ -1423,7 +1435,7 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
     }
     if (ticking) { __syncthreads(); if (tid < 16u && tacc[tid]) atomicAdd(&p.phase_cycles[tid], tacc[tid]); }
     if constexpr (TINY) {
-        if (serving) { if (tid == 0u) { __threadfence_system(); __atomic_store_n(&f.serve->alive, 0u, __ATOMIC_RELAXED); } return; }
+        if (serving) { if (tid == 0u) { __threadfence_system(); __atomic_store_n(&(f.serve + blockIdx.x)->alive, 0u, __ATOMIC_RELAXED); } return; }
         // every append and every row of this workgroup was wave 0's (thread 0's atomics, the wave's stores): behind thread 0 in program order.  The workgroups count
         // themselves off; the last one publishes the counters and, behind a system-scope fence, the call's number -- the word the caller spins on.
         if (wave == 0u && f.host_words) __threadfence_system();   // (executed by EVERY lane that stored a row: a fence orders the executing thread's accesses -- ADVICE r5)

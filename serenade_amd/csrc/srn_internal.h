@@ -182,6 +182,7 @@ int device_serve_start(DeviceState* d, const FlatIndex& ix, uint32_t k, uint32_t
 int device_serve_stop(DeviceState* d);
 // 0: served, *out_n rows written; 1: not served (no free lane, another configuration, a session the fused form hands on): the caller takes the launch path
 int device_serve_predict(DeviceState* d, const uint64_t* items, uint32_t len, uint32_t k, uint32_t m, uint32_t how_many, uint32_t flags, uint64_t* out_ids, double* out_scores, size_t* out_n);
+int device_serve_last_stamps(DeviceState* d, uint32_t* out4);
 int device_serve_stats(DeviceState* d, uint64_t* served, uint64_t* not_served, uint64_t* launches, uint32_t* lanes);
 int device_last_kernel_ms(DeviceState* d, double* ms_main, double* ms_retry, uint32_t* retried);
 int device_phase_cycles(DeviceState* d, int enable, unsigned long long* out16);

@@ -86,12 +86,17 @@ static_assert(F_DUMP + F_DUMP_WORDS * 4 - F_HOT <= 65536, "16-bit row offsets");
 // and then its number (seq); thread 0 of the workgroup polls seq (1.6 us round trip measured, tools/ring_probe.hip), the workgroup serves the session exactly like the
 // one-launch form (vmis_fast_kernel<TINY>: prep record, query, row finished from registers into the pinned row) and answers with done_seq.  No launch, no completion signal.
 struct ServeCtl {
-    unsigned long long items[16];            // host -> device: the evolving session (public ids, oldest first)
-    uint32_t len, seq, stop, pad0;           //                 seq is written LAST; stop != 0: leave
-    unsigned long long idle_ticks, pad1;     //                 leave after this many wall-clock ticks (100 MHz) without a request: a host that died leaves no kernel behind
-    uint32_t pad_h[8];                       // (the device's words in a 64-byte line of their own)
-    uint32_t done_seq, status, alive, served;   // device -> host: status 0 = the row is final, 1 = the session needs the kernels behind the fused form (the caller takes the launch path); alive = 0 once the kernel has left
-    uint32_t pad2[12];
+    // line 0, host -> device: the doorbell and the first five items in ONE 64-byte line (the workgroup polls it with one 16-lane load); seq is written LAST;
+    // check = seq ^ len ^ (xor of the 32-bit halves of items[0 .. min(len, 5))): a line seen torn is read again
+    uint32_t seq, len, check, stop;   // stop != 0: leave
+    unsigned long long items[5]; unsigned long long pad1;
+    // line 1: items 5..12 of a longer session (read after the doorbell)
+    unsigned long long more[8];
+    // line 2, host -> device, written at the launch: idle_ticks: leave after this many wall-clock ticks (100 MHz) without a request -- a host that died leaves no kernel behind
+    uint32_t pad2[2]; unsigned long long idle_ticks; uint32_t pad3[12];
+    // line 3, device -> host: done_seq is written LAST; status 0 = the row is final (count entries), 1 = the session needs the kernels behind the fused form (the caller
+    // takes the launch path); alive = 0 once the workgroup has left; stamp: 100 MHz ticks -- waited for the doorbell | doorbell -> record written | doorbell -> answer
+    uint32_t done_seq, status, count, alive; uint32_t stamp[4]; uint32_t pad4[8];
 };
 static_assert(sizeof(ServeCtl) == 256, "ServeCtl layout");
 struct FastParams {

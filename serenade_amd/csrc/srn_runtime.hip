@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -614,151 +615,182 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
 // > 63 entries: 0.3-3 % of config 3's) comes back with status 1 and takes the launch path, as does any call whose k / m / how_many / flags are not the resident ones.
 // hipFree / hipDeviceSynchronize would wait for a resident workgroup for ever: every such call of the library goes through srn_hipsync.h, which makes them leave first.
 // =====================================================================================================================================================================
-struct ServeLane {
-    DeviceState* d = nullptr; bool mid = false; bool dead = false;
+struct ServeForm {   // one resident launch: N workgroups of the lean form (sessions of <= 4 items) or of the form for 5..10 items
+    DeviceState* d = nullptr; bool mid = false; bool dead = false; uint32_t n = 0;
     hipStream_t st = nullptr;
-    ServeCtl* ctl = nullptr; ServeCtl* ctl_dev = nullptr;
-    char* rows = nullptr; char* rows_dev = nullptr;   // pinned: ids | scores | count
-    char *prep = nullptr, *fin = nullptr, *big = nullptr; uint32_t *slow_list = nullptr, *slow_cnt = nullptr;
+    ServeCtl* ctl = nullptr; ServeCtl* ctl_dev = nullptr;   // [n], pinned
+    char* rows = nullptr; char* rows_dev = nullptr; size_t row_bytes = 0;   // [n] x (ids | scores), pinned
+    char *prep = nullptr, *fin = nullptr, *big = nullptr; uint32_t *slow_list = nullptr, *slow_cnt = nullptr, *counts = nullptr;
     LaunchParams p{}; FastParams fp{};
-    std::atomic<int> busy{0}; bool running = false; uint32_t seq = 0;
+    std::unique_ptr<std::atomic<int>[]> busy; std::vector<uint32_t> seq;   // per workgroup: taken by a caller; the last number posted
+    std::mutex mu; bool running = false;   // (mu: starting / parking the launch)
 };
 struct ServeState {
-    std::vector<ServeLane*> lanes; uint32_t k = 0, m = 0, how_many = 0, flags = 0, max_items = 0; unsigned long long idle_ticks = 0;
+    std::vector<ServeForm*> forms; uint32_t k = 0, m = 0, how_many = 0, flags = 0, max_items = 0; unsigned long long idle_ticks = 0;
     std::atomic<uint64_t> served{0}, not_served{0}, launches{0};
 };
-static std::mutex g_serve_mu; static std::vector<ServeLane*> g_serve_lanes; static std::atomic<int> g_serve_running{0};
+static std::mutex g_serve_mu; static std::vector<ServeForm*> g_serve_forms; static std::atomic<int> g_serve_running{0};
 
-static void lane_lock(ServeLane* l) { int e = 0; while (!l->busy.compare_exchange_weak(e, 1, std::memory_order_acquire)) { e = 0; __builtin_ia32_pause(); } }
-static void lane_unlock(ServeLane* l) { l->busy.store(0, std::memory_order_release); }
-// (lane held) the resident workgroup leaves: told to, or already gone by its idle timeout
-static void lane_park(ServeLane* l) {
-    if (!l->running) return;
+static void lane_lock(ServeForm* f, uint32_t i) { int e = 0; while (!f->busy[i].compare_exchange_weak(e, 1, std::memory_order_acquire)) { e = 0; __builtin_ia32_pause(); } }
+static void lane_unlock(ServeForm* f, uint32_t i) { f->busy[i].store(0, std::memory_order_release); }
+// (f->mu held, no lane held by this thread) the resident workgroups leave -- after the sessions they are serving
+static void form_park(ServeForm* f) {
+    if (!f->running) return;
+    for (uint32_t i = 0; i < f->n; ++i) lane_lock(f, i);   // (nobody is posting, nothing is in flight)
     int cur = 0; (void)hipGetDevice(&cur);
-    if (cur != l->d->device) (void)hipSetDevice(l->d->device);
-    __atomic_store_n(&l->ctl->stop, 1u, __ATOMIC_RELEASE);
-    (void)hipStreamSynchronize(l->st);
-    if (cur != l->d->device) (void)hipSetDevice(cur);
-    l->running = false; g_serve_running.fetch_sub(1);
+    if (cur != f->d->device) (void)hipSetDevice(f->d->device);
+    for (uint32_t i = 0; i < f->n; ++i) __atomic_store_n(&f->ctl[i].stop, 1u, __ATOMIC_RELEASE);
+    (void)hipStreamSynchronize(f->st);
+    if (cur != f->d->device) (void)hipSetDevice(cur);
+    f->running = false; g_serve_running.fetch_sub(1);
+    for (uint32_t i = 0; i < f->n; ++i) lane_unlock(f, i);
 }
 void serve_quiesce_all() {
     if (g_serve_running.load(std::memory_order_acquire) == 0) return;
     std::lock_guard<std::mutex> lk(g_serve_mu);
-    for (ServeLane* l : g_serve_lanes) { lane_lock(l); lane_park(l); lane_unlock(l); }
+    for (ServeForm* f : g_serve_forms) { std::lock_guard<std::mutex> fl(f->mu); form_park(f); }
 }
-// (lane held) start the resident workgroup
-static int lane_launch(ServeState* s, ServeLane* l) {
-    HIP_TRY(hipSetDevice(l->d->device));
-    if (l->running) { HIP_TRY(hipStreamSynchronize(l->st)); l->running = false; g_serve_running.fetch_sub(1); }   // (it left by its idle timeout: alive == 0)
-    l->ctl->stop = 0; l->ctl->alive = 1; l->ctl->idle_ticks = s->idle_ticks;
-    l->ctl->seq = l->seq; l->ctl->done_seq = l->seq;   // (the kernel takes the number it finds as "already dealt with": a post that an earlier launch never answered is not served late)
+// (f->mu held, no lane held by this thread) start the resident launch
+static int form_launch(ServeState* s, ServeForm* f) {
+    if (f->running) {   // (workgroups that left by their idle timeout: the launch is over once all have)
+        bool all_gone = true; for (uint32_t i = 0; i < f->n; ++i) all_gone = all_gone && __atomic_load_n(&f->ctl[i].alive, __ATOMIC_ACQUIRE) == 0u;
+        if (!all_gone) { form_park(f); } else { HIP_TRY(hipSetDevice(f->d->device)); HIP_TRY(hipStreamSynchronize(f->st)); f->running = false; g_serve_running.fetch_sub(1); }
+    }
+    for (uint32_t i = 0; i < f->n; ++i) lane_lock(f, i);
+    auto unlock_all = [&]() { for (uint32_t i = 0; i < f->n; ++i) lane_unlock(f, i); };
+    hipError_t e = hipSetDevice(f->d->device);
+    for (uint32_t i = 0; i < f->n && e == hipSuccess; ++i) { ServeCtl& c = f->ctl[i]; c.stop = 0; c.alive = 1; c.idle_ticks = s->idle_ticks; c.seq = f->seq[i]; c.done_seq = f->seq[i]; }   // (a post an earlier launch never answered is not served late)
     std::atomic_thread_fence(std::memory_order_seq_cst);
-    HIP_TRY(hipMemsetAsync(l->slow_cnt, 0, 32, l->st));
-    HIP_TRY(launch_fast(dim3(1), l->st, l->d->di, l->p, l->fp, false, 0, l->mid, false, false, true));
-    l->running = true; g_serve_running.fetch_add(1); s->launches.fetch_add(1);
-    return SRN_OK;
+    if (e == hipSuccess) e = hipMemsetAsync(f->slow_cnt, 0, 32, f->st);
+    if (e == hipSuccess) e = launch_fast(dim3(f->n), f->st, f->d->di, f->p, f->fp, false, 0, f->mid, false, false, true);
+    if (e == hipSuccess) { f->running = true; g_serve_running.fetch_add(1); s->launches.fetch_add(1); }
+    unlock_all();
+    return e == hipSuccess ? SRN_OK : fail(SRN_EHIP, std::string("the persistent latency path: ") + hipGetErrorString(e));
 }
-static void lane_free(ServeLane* l) {
-    { std::lock_guard<std::mutex> lk(g_serve_mu); g_serve_lanes.erase(std::remove(g_serve_lanes.begin(), g_serve_lanes.end(), l), g_serve_lanes.end()); }
-    lane_lock(l); lane_park(l);
-    for (void* q : {(void*)l->prep, (void*)l->fin, (void*)l->big, (void*)l->slow_list, (void*)l->slow_cnt}) if (q) (void)hipFree(q);
-    if (l->ctl) (void)hipHostFree(l->ctl); if (l->rows) (void)hipHostFree(l->rows);
-    if (l->st) (void)hipStreamDestroy(l->st);
-    delete l;
+static void form_free(ServeForm* f) {
+    { std::lock_guard<std::mutex> lk(g_serve_mu); g_serve_forms.erase(std::remove(g_serve_forms.begin(), g_serve_forms.end(), f), g_serve_forms.end()); }
+    { std::lock_guard<std::mutex> fl(f->mu); form_park(f); }
+    for (void* q : {(void*)f->prep, (void*)f->fin, (void*)f->big, (void*)f->slow_list, (void*)f->slow_cnt, (void*)f->counts}) if (q) (void)hipFree(q);
+    if (f->ctl) (void)hipHostFree(f->ctl); if (f->rows) (void)hipHostFree(f->rows);
+    if (f->st) (void)hipStreamDestroy(f->st);
+    delete f;
 }
 int device_serve_stop(DeviceState* d) {
     ServeState* s = d->serve.exchange(nullptr);
     if (!s) return SRN_OK;
     HIP_TRY(hipSetDevice(d->device));
-    for (ServeLane* l : s->lanes) lane_free(l);
+    for (ServeForm* f : s->forms) form_free(f);
     delete s;
     return SRN_OK;
 }
 int device_serve_start(DeviceState* d, const FlatIndex& ix, uint32_t k, uint32_t m, uint32_t how_many, uint32_t flags, uint32_t lanes, uint32_t max_items, uint32_t idle_ms) {
     int rc = device_serve_stop(d); if (rc) return rc;
     if (lanes == 0) return SRN_OK;
-    if (lanes > 64) return fail(SRN_ERANGE, "at most 64 resident workgroups");
+    if (lanes > 256) return fail(SRN_ERANGE, "at most 256 resident workgroups per form");
     HIP_TRY(hipSetDevice(d->device));
     const Knobs kn = knobs();
     ServeState* s = new ServeState(); s->k = k; s->m = m; s->how_many = how_many; s->flags = flags; s->max_items = std::min<uint32_t>(std::max<uint32_t>(max_items, 1), F_MID_LMAX);
     s->idle_ticks = (unsigned long long)std::max<uint32_t>(idle_ms, 1) * 100000ull;   // (wall_clock64: 100 MHz)
-    auto undo = [&](int code, const std::string& why) { for (ServeLane* l : s->lanes) lane_free(l); delete s; return fail(code, why); };
-    for (int form = 0; form < (s->max_items > 4 ? 2 : 1); ++form)
-        for (uint32_t i = 0; i < lanes; ++i) {
-            ServeLane* l = new ServeLane(); l->d = d; l->mid = form == 1; s->lanes.push_back(l);
-            { std::lock_guard<std::mutex> lk(g_serve_mu); g_serve_lanes.push_back(l); }
-            LaunchParams& p = l->p;
-            p.nq = 1; p.k = k; p.m = m; p.how_many = how_many; p.flags = flags; p.max_len = l->mid ? F_MID_LMAX : 8u;
-            Geometry geo; if (make_geometry(d, ix, p, 0, geo) != SRN_OK) return undo(SRN_EINVAL, "the persistent latency path: no LDS geometry for these parameters");
-            const FastPlan plan = fast_plan(d, ix, p, geo, kn, false);
-            if (!plan.fast || (l->mid && !plan.mid_tier)) return undo(SRN_EINVAL, "the persistent latency path serves what the fast kernels serve (k <= 1536, m <= 2560 and <= m_index, how_many <= 64, complete lists)");
-            const size_t row_bytes = (size_t)how_many * 16 + 64;
-            if (hipStreamCreateWithFlags(&l->st, hipStreamNonBlocking) != hipSuccess ||
-                hipHostMalloc((void**)&l->ctl, sizeof(ServeCtl), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
-                hipHostMalloc((void**)&l->rows, row_bytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
-                hipHostGetDevicePointer((void**)&l->ctl_dev, l->ctl, 0) != hipSuccess || hipHostGetDevicePointer((void**)&l->rows_dev, l->rows, 0) != hipSuccess)
-                return undo(SRN_ENOMEM, "the persistent latency path: pinned control block");
-            memset(l->ctl, 0, sizeof(ServeCtl)); memset(l->rows, 0, row_bytes);
-            const uint32_t prep_stride = (uint32_t)(sizeof(PrepHead) + (size_t)p.max_len * sizeof(PrepItem));
-            const uint64_t big_entries = 16 + 4096;
-            if (hipMalloc((void**)&l->prep, prep_stride + 256) != hipSuccess || hipMalloc((void**)&l->fin, F_FIN_BYTES + 1024) != hipSuccess || hipMalloc((void**)&l->big, big_entries * 16 + 4 + 64) != hipSuccess ||
-                hipMalloc((void**)&l->slow_list, (1 * 4 + 64) * 4) != hipSuccess || hipMalloc((void**)&l->slow_cnt, 32) != hipSuccess)
-                return undo(SRN_ENOMEM, "the persistent latency path: device scratch");
-            p.items_flat = nullptr; p.q_off = nullptr;
-            p.out_ids = (uint64_t*)l->rows_dev; p.out_scores = (double*)(l->rows_dev + (size_t)how_many * 8); p.out_counts = (uint32_t*)(l->rows_dev + (size_t)how_many * 16);
-            p.stats = nullptr; p.nb_rank = p.nb_num = p.nb_cnt = nullptr; p.phase_cycles = nullptr; p.prep = l->prep; p.prep_stride = prep_stride;
-            FastParams& fp = l->fp; fp = d->fast;
-            fp.slow_list = l->slow_list; fp.slow_cnt = l->slow_cnt; fp.nb = plan.nb_fast; fp.max_runs = plan.nb_fast; fp.fin = l->fin;
-            fp.big_arena = l->big; fp.big_list = (uint32_t*)(l->big + big_entries * 16); fp.big_ticket = (unsigned long long*)(l->slow_cnt + 2); fp.big_cap_entries = (uint32_t)big_entries;
-            fp.xchg = nullptr; fp.xchg_stride = 0; fp.q_base = 0; fp.order = nullptr; fp.mid_list = nullptr; fp.mid_cnt = nullptr; fp.bigq_list = nullptr; fp.bigq_cnt = nullptr; fp.long_list = nullptr; fp.long_cnt = nullptr;
-            fp.tiny_len = 0; fp.host_seq = 0; fp.host_words = nullptr; fp.serve = l->ctl_dev;
-        }
-    for (ServeLane* l : s->lanes) { lane_lock(l); rc = lane_launch(s, l); lane_unlock(l); if (rc) return undo(rc, last_error_string()); }
+    auto undo = [&](int code, const std::string& why) { for (ServeForm* f : s->forms) form_free(f); delete s; return fail(code, why); };
+    // A resident launch never ends, and HIP multiplexes its streams onto a few hardware queues per priority level: on a queue shared with another stream everything
+    // behind the resident kernel would wait for ever.  The resident streams take the LOWEST priority level, which nothing else in this library uses.
+    int prio_lo = 0, prio_hi = 0; (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    for (int form = 0; form < (s->max_items > 4 ? 2 : 1); ++form) {
+        ServeForm* f = new ServeForm(); f->d = d; f->mid = form == 1; f->n = lanes; s->forms.push_back(f);
+        f->busy.reset(new std::atomic<int>[lanes]); for (uint32_t i = 0; i < lanes; ++i) f->busy[i].store(0); f->seq.assign(lanes, 0u);
+        { std::lock_guard<std::mutex> lk(g_serve_mu); g_serve_forms.push_back(f); }
+        LaunchParams& p = f->p;
+        p.nq = lanes; p.k = k; p.m = m; p.how_many = how_many; p.flags = flags; p.max_len = f->mid ? F_MID_LMAX : 8u;
+        Geometry geo; if (make_geometry(d, ix, p, 0, geo) != SRN_OK) return undo(SRN_EINVAL, "the persistent latency path: no LDS geometry for these parameters");
+        const FastPlan plan = fast_plan(d, ix, p, geo, kn, false);
+        if (!plan.fast || (f->mid && !plan.mid_tier)) return undo(SRN_EINVAL, "the persistent latency path serves what the fast kernels serve (k <= 1536, m <= 2560 and <= m_index, how_many <= 64, complete lists)");
+        f->row_bytes = ((size_t)how_many * 16 + 63) / 64 * 64;
+        if (hipStreamCreateWithPriority(&f->st, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+            hipHostMalloc((void**)&f->ctl, sizeof(ServeCtl) * lanes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            hipHostMalloc((void**)&f->rows, f->row_bytes * lanes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&f->ctl_dev, f->ctl, 0) != hipSuccess || hipHostGetDevicePointer((void**)&f->rows_dev, f->rows, 0) != hipSuccess)
+            return undo(SRN_ENOMEM, "the persistent latency path: pinned control blocks");
+        memset(f->ctl, 0, sizeof(ServeCtl) * lanes); memset(f->rows, 0, f->row_bytes * lanes);
+        const uint32_t prep_stride = (uint32_t)(sizeof(PrepHead) + (size_t)p.max_len * sizeof(PrepItem));
+        const uint64_t big_entries = (uint64_t)lanes * 1024 + 4096;
+        if (hipMalloc((void**)&f->prep, (size_t)prep_stride * lanes + 256) != hipSuccess || hipMalloc((void**)&f->fin, (size_t)F_FIN_BYTES * lanes + 1024) != hipSuccess ||
+            hipMalloc((void**)&f->big, big_entries * 16 + (size_t)lanes * 4 + 64) != hipSuccess || hipMalloc((void**)&f->slow_list, ((size_t)lanes * 4 + 64) * 4) != hipSuccess ||
+            hipMalloc((void**)&f->slow_cnt, 32) != hipSuccess || hipMalloc((void**)&f->counts, (size_t)lanes * 4 + 64) != hipSuccess)
+            return undo(SRN_ENOMEM, "the persistent latency path: device scratch");
+        p.items_flat = nullptr; p.q_off = nullptr;
+        // a workgroup's row: ids at rows + q * how_many * 8 ... the kernels address rows as out_ids[q * how_many + rank]: ids of all workgroups, then scores of all
+        p.out_ids = (uint64_t*)f->rows_dev; p.out_scores = (double*)(f->rows_dev + (size_t)lanes * how_many * 8); p.out_counts = f->counts;
+        if ((size_t)lanes * how_many * 16 > f->row_bytes * lanes) return undo(SRN_EINVAL, "row buffer");
+        p.stats = nullptr; p.nb_rank = p.nb_num = p.nb_cnt = nullptr; p.phase_cycles = nullptr; p.prep = f->prep; p.prep_stride = prep_stride;
+        FastParams& fp = f->fp; fp = d->fast;
+        fp.slow_list = f->slow_list; fp.slow_cnt = f->slow_cnt; fp.nb = plan.nb_fast; fp.max_runs = plan.nb_fast; fp.fin = f->fin;
+        fp.big_arena = f->big; fp.big_list = (uint32_t*)(f->big + big_entries * 16); fp.big_ticket = (unsigned long long*)(f->slow_cnt + 2); fp.big_cap_entries = (uint32_t)big_entries;
+        fp.xchg = nullptr; fp.xchg_stride = 0; fp.q_base = 0; fp.order = nullptr; fp.mid_list = nullptr; fp.mid_cnt = nullptr; fp.bigq_list = nullptr; fp.bigq_cnt = nullptr; fp.long_list = nullptr; fp.long_cnt = nullptr;
+        fp.tiny_len = 0; fp.host_seq = 0; fp.host_words = nullptr; fp.serve = f->ctl_dev;
+    }
+    for (ServeForm* f : s->forms) { std::lock_guard<std::mutex> fl(f->mu); rc = form_launch(s, f); if (rc) return undo(rc, last_error_string()); }
     d->serve.store(s);
     return SRN_OK;
 }
 int device_serve_stats(DeviceState* d, uint64_t* served, uint64_t* not_served, uint64_t* launches, uint32_t* lanes) {
     ServeState* s = d->serve.load();
     if (served) *served = s ? s->served.load() : 0; if (not_served) *not_served = s ? s->not_served.load() : 0; if (launches) *launches = s ? s->launches.load() : 0;
-    if (lanes) *lanes = s ? (uint32_t)s->lanes.size() : 0;
+    uint32_t n = 0; if (s) for (ServeForm* f : s->forms) n += f->n;
+    if (lanes) *lanes = n;
+    return SRN_OK;
+}
+int device_serve_last_stamps(DeviceState* d, uint32_t* out4) {   // (measurement aid) 100 MHz ticks of the lean form's first workgroup's last session: waited | record written | answered
+    ServeState* s = d->serve.load();
+    if (!s || s->forms.empty()) return fail(SRN_ESTATE, "nothing resident");
+    for (int i = 0; i < 4; ++i) out4[i] = s->forms[0]->ctl[0].stamp[i];
     return SRN_OK;
 }
 int device_serve_predict(DeviceState* d, const uint64_t* items, uint32_t len, uint32_t k, uint32_t m, uint32_t how_many, uint32_t flags, uint64_t* out_ids, double* out_scores, size_t* out_n) {
     ServeState* s = d->serve.load(std::memory_order_acquire);
     if (!s || k != s->k || m != s->m || how_many != s->how_many || flags != s->flags || len == 0 || len > s->max_items) return 1;
-    const bool want_mid = len > 4;
-    ServeLane* l = nullptr;
-    for (ServeLane* c : s->lanes) { if (c->mid != want_mid || c->dead) continue; int e = 0; if (c->busy.compare_exchange_strong(e, 1, std::memory_order_acquire)) { l = c; break; } }
-    if (!l) { s->not_served.fetch_add(1); return 1; }   // (every resident workgroup of that form is taken: the launch path)
-    if (!l->running || __atomic_load_n(&l->ctl->alive, __ATOMIC_ACQUIRE) == 0u) { const int rc = lane_launch(s, l); if (rc) { l->dead = true; lane_unlock(l); return 1; } }
-    ServeCtl* c = l->ctl;
-    for (uint32_t i = 0; i < len; ++i) c->items[i] = items[i];
-    c->len = len;
-    uint32_t seq = ++l->seq; if (seq == 0u) seq = ++l->seq;
-    __atomic_store_n(&c->seq, seq, __ATOMIC_RELEASE);
-    const auto t0 = std::chrono::steady_clock::now();
-    bool seen = false;
-    for (uint32_t spin = 0;; ++spin) {
-        if (__atomic_load_n(&c->done_seq, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
-        __builtin_ia32_pause();
-        if ((spin & 1023u) == 1023u) {
-            if (__atomic_load_n(&c->alive, __ATOMIC_ACQUIRE) == 0u) break;   // (it left between our look and our post: its idle timeout)
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) { l->dead = true; break; }   // (a fault: the lane is not used again; srn_index_serve_stop reports what the stream says)
+    ServeForm* f = s->forms[len > 4 ? 1 : 0];
+    if (f->dead) return 1;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        uint32_t li = f->n;
+        for (uint32_t i = 0; i < f->n; ++i) { int e = 0; if (f->busy[i].compare_exchange_strong(e, 1, std::memory_order_acquire)) { li = i; break; } }
+        if (li == f->n) { s->not_served.fetch_add(1); return 1; }   // (every resident workgroup of that form is taken: the launch path)
+        ServeCtl* c = &f->ctl[li];
+        if (!f->running || __atomic_load_n(&c->alive, __ATOMIC_ACQUIRE) == 0u) {   // parked (something freed device memory) or gone (idle): start the launch again, then look for a lane again
+            lane_unlock(f, li);
+            std::lock_guard<std::mutex> fl(f->mu);
+            bool gone = !f->running; for (uint32_t i = 0; i < f->n && !gone; ++i) gone = __atomic_load_n(&f->ctl[i].alive, __ATOMIC_ACQUIRE) == 0u;
+            if (gone && form_launch(s, f) != SRN_OK) { f->dead = true; s->not_served.fetch_add(1); return 1; }
+            continue;
         }
-    }
-    int ret = 1;
-    if (seen && __atomic_load_n(&c->status, __ATOMIC_RELAXED) == 0u) {
-        const uint32_t cnt = *(volatile uint32_t*)(l->rows + (size_t)how_many * 16);
-        if ((cnt & 0x80000000u) == 0u) {
-            const uint32_t n = std::min<uint32_t>(cnt, how_many);
-            memcpy(out_ids, l->rows, (size_t)n * 8); memcpy(out_scores, l->rows + (size_t)how_many * 8, (size_t)n * 8);
+        uint32_t chk = 0; for (uint32_t i = 0; i < std::min<uint32_t>(len, 5u); ++i) chk ^= (uint32_t)items[i] ^ (uint32_t)(items[i] >> 32);
+        for (uint32_t i = 5; i < len; ++i) c->more[i - 5] = items[i];
+        for (uint32_t i = 0; i < std::min<uint32_t>(len, 5u); ++i) c->items[i] = items[i];
+        uint32_t seq = ++f->seq[li]; if (seq == 0u) seq = ++f->seq[li];
+        c->len = len; c->check = chk ^ seq ^ len;
+        __atomic_store_n(&c->seq, seq, __ATOMIC_RELEASE);
+        const auto t0 = std::chrono::steady_clock::now();
+        bool seen = false;
+        for (uint32_t spin = 0;; ++spin) {
+            if (__atomic_load_n(&c->done_seq, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
+            __builtin_ia32_pause();
+            if ((spin & 1023u) == 1023u) {
+                if (__atomic_load_n(&c->alive, __ATOMIC_ACQUIRE) == 0u) break;   // (it left between our look and our post: its idle timeout)
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(500)) { f->dead = true; break; }   // (a fault: the form is not used again)
+            }
+        }
+        int ret = 1;
+        if (seen && __atomic_load_n(&c->status, __ATOMIC_RELAXED) == 0u) {
+            const uint32_t n = std::min<uint32_t>(__atomic_load_n(&c->count, __ATOMIC_RELAXED), how_many);
+            memcpy(out_ids, f->rows + ((size_t)li * how_many) * 8, (size_t)n * 8);
+            memcpy(out_scores, f->rows + ((size_t)f->n * how_many + (size_t)li * how_many) * 8, (size_t)n * 8);
             *out_n = n; ret = 0;
         }
+        lane_unlock(f, li);
+        (ret == 0 ? s->served : s->not_served).fetch_add(1);
+        return ret;
     }
-    if (!seen && !l->dead) { /* the post may still be picked up by a later launch: make it a no-op */ l->seq = seq; }
-    lane_unlock(l);
-    (ret == 0 ? s->served : s->not_served).fetch_add(1);
-    return ret;
+    s->not_served.fetch_add(1);
+    return 1;
 }
 
 // the workspace's side stream (highest priority: a hardware queue of its own, dispatched ahead of the running call's persistent workgroups) and its events

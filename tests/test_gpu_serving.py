@@ -145,11 +145,11 @@ def test_persistent_latency_path_against_the_oracle():
 
     sa.predict(gix, sessions[0], k, m, 21, False)                          # (the launch path's workspace exists before anything is resident)
     gix.serve_start(k, m, 21, False, lanes=2, max_items_in_session=10, idle_ms=1500)
-    assert gix.serve_stats()[2:] == (4, 4)                                  # 2 lanes of the lean form + 2 of the form for 5..10 items, one launch each
+    assert gix.serve_stats()[2:] == (2, 4)                                  # 2 workgroups of the lean form + 2 of the form for 5..10 items: one launch per form
     for q in range(300):
         check(q, sa.predict(gix, sessions[q], k, m, 21, False))
     served, not_served, launches, lanes = gix.serve_stats()
-    assert served + not_served == 300 and served >= 270 and launches == 4, (served, not_served, launches)
+    assert served + not_served == 300 and served >= 270 and 2 <= launches <= 12, (served, not_served, launches)   # (a session that took the launch path may have grown its workspace: a hipFree, before which the resident workgroups leave)
     # other parameters: the launch path, same answers as ever
     got = sa.predict(gix, sessions[5], k // 2, m, 21, False)
     ids, sc = oix.predict_canonical(sessions[5], k // 2, m, 21)
