@@ -808,6 +808,46 @@ def main():
                "exchange_bytes_per_query_and_rank": {"neighbour_lists_all_gather": (k + 1) * 4 / Gl, "topn_all_gather": 16 * how_many + 4},
                "shard0_bytes_hbm": int(shards8[0].info["device_bytes"]), "parity_checked": checked, "parity_checked_positions": "uniform over batch", "setup_s": round(t_setup, 2),
                "note": "all 8 shards on ONE GPU, collectives degenerate to kernels: what a rank computes per batch, not what xGMI costs; results checked against the oracle"}
+        # ---- the exchange term: the same rank once more in the STREAMING form (neighbours shipped as posting positions: a third of the bytes, more
+        # compute), then both forms priced with what their exchanges ship per rank over xGMI.  A MODEL: no collective of this library has crossed xGMI yet (SCALE runs skipped).
+        try:
+            grp8.set_postings(None)
+            os.environ["SRN_SBACK_STREAM"] = "1"; os.environ["SRN_GROUP_TIMING"] = "1"; _capi.reload_knobs()
+            grp8.set_postings(index)
+            times_s = []
+            for it in range(7):
+                grp8.predict_batch(b8[0], b8[1], Bl, last_items, k, m, how_many, False, stream.cuda_stream, out=out8)
+                torch.cuda.synchronize()
+                t3 = (C.c_double * 3)()
+                _capi.check(_capi.lib().srn_debug_shard_group_times(grp8._h, t3))
+                times_s.append(list(t3))
+            ts_ = np.median(np.array(times_s[2:]), axis=0)
+            streamed = grp8.stats["bytes_neighbours"] > st8["bytes_neighbours"]
+            checked_s = 0
+            if args.parity > 0:
+                pos = gate_positions(Bl, min(args.parity, 512))
+                checked_s = gate(out8[0].cpu().numpy().view(np.uint64)[pos], out8[1].cpu().numpy()[pos], out8[2].cpu().numpy().view(np.uint32)[pos], b8[2], b8[3], pos, "8 local shards, streaming back end")
+            # bytes ONE rank sends to EACH of its G - 1 peers per batch (and receives from each): its slice of the neighbour exchange + its partial top-n of every query
+            per_q_gather, per_q_stream, per_q_topn = (k + 1) * 4, int(_capi.lib().srn_debug_shard_nb_positions_stride(k, m)) * 4, 16 * how_many + 4
+            out_gather = Bl / Gl * per_q_gather + Bl * per_q_topn
+            out_stream = Bl / Gl * per_q_stream + Bl * per_q_topn
+            rates = {"per_link_and_direction_GBps_conservative": 76.8, "per_link_and_direction_GBps_optimistic": 153.6}
+            model = {"source_of_the_rate": "the round's task statement and SURVEY.md section 5: xGMI is point-to-point, 7 links x ~153 GB/s per GPU (one link per peer in an 8-GPU node); "
+                                           "conservative = that figure read as both directions together (76.8 GB/s each way), optimistic = per direction",
+                     "bytes_to_each_peer_per_batch": {"gather": int(out_gather), "streaming": int(out_stream)},
+                     "bytes_received_per_rank_and_batch": {"gather": int(out_gather * (Gl - 1)), "streaming": int(out_stream * (Gl - 1))},
+                     "rank_compute_ms": {"gather": float(t.sum()), "streaming": float(ts_.sum()), "streaming_form_really_ran": bool(streamed), "streaming_parity_checked": checked_s}}
+            for name, gbps in rates.items():
+                xg, xs = out_gather / (gbps * 1e9) * 1e3, out_stream / (gbps * 1e9) * 1e3   # every peer pair has its own link: the 7 transfers of a rank run side by side
+                model[name] = {"GBps": gbps, "exchange_ms": {"gather": xg, "streaming": xs},
+                               "projected_node_queries_per_s": {"gather_not_overlapped": Bl / ((float(t.sum()) + xg) * 1e-3), "streaming_not_overlapped": Bl / ((float(ts_.sum()) + xs) * 1e-3),
+                                                                "gather_overlapped": Bl / (max(float(t.sum()), xg) * 1e-3), "streaming_overlapped": Bl / (max(float(ts_.sum()), xs) * 1e-3)}}
+            model["what_the_library_does"] = "SRN_SBACK_STREAM unset (round 6): a group with real peers takes the streaming form unless srn_shard_group_set_overlap(1) -- not overlapped the exchange is on the batch's critical path and the streaming form's total is lower at either rate; overlapped the gather form's smaller compute wins"
+            blk["exchange_model"] = model
+        except Exception as e:   # (the block is an extra: its failure must not cost the line)
+            blk["exchange_model"] = {"error": repr(e)[:300]}
+        finally:
+            os.environ.pop("SRN_SBACK_STREAM", None); os.environ.pop("SRN_GROUP_TIMING", None); _capi.reload_knobs()
         grp8.close()
         for s8 in shards8:
             s8.close()

@@ -29,6 +29,8 @@ int srn_debug_last_mid_count(const srn_index_t* idx, uint32_t* out_listed);
 /* the persistent latency path: 100 MHz ticks of the last session the lean form's first resident workgroup served -- [0] waited for the doorbell, [1] doorbell -> prep record
  * written, [2] doorbell -> answer posted */
 int srn_debug_serve_stamps(const srn_index_t* idx, uint32_t* out4);
+/* 32-bit words per query of the streaming back end's exchange record at this (k, m) -- 0: none (knobs, shape); the gather form ships k + 1 words */
+uint32_t srn_debug_shard_nb_positions_stride(size_t k, size_t m);
 /* ... and how many of those MID listed for its BIG form (80 KB of LDS: merged lists beyond the 53 KB layout's buffers). */
 int srn_debug_last_big_count(const srn_index_t* idx, uint32_t* out_listed);
 

@@ -122,6 +122,7 @@ SYMBOLS = {
     "srn_debug_reload_knobs": (None, []),
     "srn_debug_last_mid_count": (_i, [_vp, C.POINTER(C.c_uint32)]),
     "srn_debug_serve_stamps": (_i, [_vp, _vp]),
+    "srn_debug_shard_nb_positions_stride": (C.c_uint32, [_sz, _sz]),
     "srn_debug_last_big_count": (_i, [_vp, C.POINTER(C.c_uint32)]),
     "srn_debug_sback_launches": (_i, [_vp, C.POINTER(_u64)]),
     "srn_last_path_counts": (_i, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),

@@ -461,6 +461,10 @@ int srn_last_path_counts(const srn_index_t* idx, uint32_t* out_nq, uint32_t* out
     if (!idx || !idx->dev) return fail(SRN_ENODEV, "index has no device attached");
     return guarded([&]() -> int { return device_last_path_counts(idx->dev, out_nq, out_general, out_global_pass); });
 }
+uint32_t srn_debug_shard_nb_positions_stride(size_t k, size_t m) {
+    LaunchParams p{}; p.k = (uint32_t)k; p.m = (uint32_t)m; p.max_len = 4; p.nq = 1; p.how_many = 21;
+    return device_shard_nb_positions_stride(p);
+}
 int srn_debug_serve_stamps(const srn_index_t* idx, uint32_t* out4) {
     if (!idx || !idx->dev || !out4) return fail(SRN_EINVAL, "null argument");
     return device_serve_last_stamps(idx->dev, out4);

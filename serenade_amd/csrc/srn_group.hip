@@ -311,7 +311,10 @@ int group_predict_neighbours(srn_shard_group* g, const LaunchParams& p_in, bool 
     const size_t block_bytes = ((size_t)nq * n * 16 + (size_t)nq * 4 + 255) / 256 * 256, xblock = (size_t)per * xstride * 4;
     // Streaming form (round 5): the exchange carries, instead of the neighbour slots, WHERE the neighbours sit in the query's posting lists -- a third of the bytes --, and
     // every rank's back end streams its fragments in posting order.  Chosen from rank-invariant inputs (batch shape, knobs) + what set_postings settled for this rank.
-    const uint32_t pstride = g->stream_ok ? device_shard_nb_positions_stride(p) : 0u;
+    // streaming or gather form (rank-invariant inputs only: the knob, the group's kind, the overlap switch, what set_postings agreed on): see Knobs::sback_stream_mode
+    const int smode = knobs().sback_stream_mode;
+    const bool want_stream = smode == 1 || (smode < 0 && g->kind != srn_shard_group::LOCAL && !g->overlap);
+    const uint32_t pstride = g->stream_ok && want_stream ? device_shard_nb_positions_stride(p) : 0u;
     const bool positions = pstride != 0u;
     const size_t pblock = (size_t)per * pstride * 4;
     {
@@ -639,10 +642,11 @@ int srn_shard_group_set_postings(srn_shard_group_t* g, const srn_index_t* postin
     // this rank's shards keep their fragments a second time, in the posting order of these lists, where there is room (the streaming form of the back end: optional, both
     // forms give the same rows -- but the exchange FORMAT follows from it, so it is used only if EVERY rank has it)
     bool stream_here = false;
+    const bool copy_wanted = knobs().sback_stream_mode == 1 || (knobs().sback_stream_mode < 0 && g->kind != srn_shard_group::LOCAL);   // (an in-process group's AUTO is the gather form: no second copy of the fragments)
     if (local_rc == SRN_OK) {
         bool all = !g->shards.empty();
         for (const srn_index* sh : g->shards) {
-            const int rc = device_sback_attach_postings(sh->dev, postings->dev, postings->flat.nnz_post);
+            const int rc = device_sback_attach_postings(sh->dev, postings->dev, copy_wanted ? postings->flat.nnz_post : 0);
             if (rc) { bad(rc, last_error_string()); break; }
             all = all && device_sback_streams(sh->dev);
         }

@@ -52,7 +52,11 @@ struct Knobs {
     bool no_sback = false;    // SRN_NO_SBACK: the shard group's back end through vmis_fast_kernel's FM_BACK instantiation (rounds 4) instead of the wave-per-query kernel of srn_sback.hip
     bool sback_bitmap = false;     // SRN_SBACK_BITMAP=1 (experiments): that kernel asks its presence bitmap before it fetches a fragment.  Measured on config 3 cut in 8: half the fragment
                                    // fetches, but one more DEPENDENT round trip per query on a kernel that spends 65 % of its time waiting for memory -- 1.65 ms with, 1.52 ms without
-    bool no_sback_stream = true;   // SRN_SBACK_STREAM=1 (experiments) turns the STREAMING form of that kernel on: the shard keeps its fragments a second time in posting order (8 B per posting), the
+    int sback_stream_mode = -1;    // SRN_SBACK_STREAM: 1 = the streaming form wherever the shards have it, 0 = never, unset = AUTO (round 6): a group with real peers (RCCL / callbacks) takes it
+                                   // unless its exchanges overlap the previous batch (srn_shard_group_set_overlap) -- it ships a third of the gather form's bytes and costs 0.4 ms more compute per
+                                   // rank and batch, which pays as soon as the exchange is on the batch's critical path (bench.py: item_sharded.local_g8.exchange_model); an in-process group's
+                                   // "exchange" is a device copy: gather
+    bool no_sback_stream = false;  // (= sback_stream_mode == 0)  SRN_SBACK_STREAM=1 (experiments) turns the STREAMING form of that kernel on: the shard keeps its fragments a second time in posting order (8 B per posting), the
                                    // exchange carries the neighbours as positions in the posting lists (a third of the bytes), the back end reads the lists' kept prefixes coalesced.  Built and
                                    // measured in round 5 (profiles/r05_sback_stream_ab.txt): a query's ~4 750 kept postings are 3.5 x its ~1 360 neighbours, and the walk, which memory no longer
                                    // bounds, is issue-bound on them: 1.92 ms per 131 072 queries against 1.54 for the gather form.  Off by default; same rows either way.
