@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--measure-traffic", dest="measure_traffic", action="store_true", default=True, help="N=1 (default ON where rocprofv3 exists): two extra rocprofv3 --pmc passes "
                     "(FETCH_SIZE, WRITE_SIZE) of this script with 1 + 2 steps, so that roofline.traffic is measured in this run; the committed summary under profiles/ is only a labelled fallback")
     ap.add_argument("--no-measure-traffic", dest="measure_traffic", action="store_false")
+    ap.add_argument("--no-sq-passes", action="store_true", help="with --measure-traffic: only the two HBM passes, not the three SQ / L2 counter passes behind roofline_secondary")
     ap.add_argument("--no-local-g8", action="store_true", help="N = 1: skip the item_sharded.local_g8 block (one rank's work of an 8-way item-sharded index, all 8 shards on this GPU)")
     ap.add_argument("--no-postings", action="store_true", help="N > 1: the lists pipeline (posting lists sharded too: every rank redoes all candidate work on exchanged list prefixes) instead of the neighbours pipeline")
     ap.add_argument("--selftest-launch", action="store_true", help="CPU check of the launcher and the control plane (gloo): no GPU, no timing")
@@ -458,24 +459,36 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import rocprof_summarize as RS
         vals = {}
+        # (round 6) beside the two HBM passes: the SQ counters behind roofline_secondary and the L2's hit / miss / request counters, at THIS batch size, in this run --
+        # own passes each (counters only with --kernel-trace: MI355X_MICROARCH.md); a pass that fails costs its block, not the line
+        passes = [("FETCH_SIZE",), ("WRITE_SIZE",)]
+        if not args.no_sq_passes:
+            passes += [("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS"),
+                       ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INST_CYCLES_SALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VMEM_RD", "SQ_WAIT_INST_LDS"),
+                       ("TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum", "TCP_TCC_READ_REQ_sum")]
         with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
-            for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-                d = os.path.join(tmp, ctr)
-                cmd = [exe, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__), "--mode", "replicas",
+            for pi, ctrs in enumerate(passes):
+                d = os.path.join(tmp, "pass%d" % pi)
+                cmd = [exe, "--pmc"] + list(ctrs) + ["--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__), "--mode", "replicas",
                        "--config", args.config, "--batch", str(B), "--steps", "2", "--warmup", "1", "--no-sweep", "--no-cpu-baseline", "--no-measure-traffic", "--no-local-g8", "--parity", "0", "--builder", args.builder]
                 env = dict(os.environ, TMPDIR="/tmp")
+                ok = True
                 try:
                     r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+                    ok = r.returncode == 0
                 except subprocess.TimeoutExpired:
+                    ok = False
+                got = RS.counters(d, "vmis_fast_kernel") if ok else {}
+                for ctr in ctrs:
+                    c = got.get(ctr, [])
+                    if not c:
+                        continue
+                    top = max(g for _, _, g in c)
+                    full = [x for _, x, g in sorted(c) if g >= 0.5 * top][:3]
+                    vals[ctr] = sum(full) / len(full)
+                if pi < 2 and ctrs[0] not in vals:
                     return None, None
-                if r.returncode != 0:
-                    return None, None
-                c = RS.counters(d, "vmis_fast_kernel").get(ctr, [])
-                if not c:
-                    return None, None
-                top = max(g for _, _, g in c)
-                full = [x for _, x, g in sorted(c) if g >= 0.5 * top][:3]
-                vals[ctr] = sum(full) / len(full)
+        measure_traffic_now.counters = {k: v for k, v in vals.items() if k not in ("FETCH_SIZE", "WRITE_SIZE")}
         return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own passes, 3 full-batch launches each"
 
     # =========================== the whole index on every GPU: replicas, query-sharded (N = 1: THE bench line) ===========================
@@ -662,16 +675,34 @@ def main():
         try:
             import glob
             cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_sq_counters_%s.json" % args.config)))
-            if cand and fast_used:
-                sq = json.load(open(cand[-1]))
-                dq, pq = sq["derived"], sq["per_query"]
+            cin = getattr(measure_traffic_now, "counters", None) if traffic_in_run else None
+            sq_in_run = bool(cin) and all(kk in cin for kk in ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"))
+            if sq_in_run and fast_used:
+                wc = cin["SQ_WAVE_CYCLES"]
+                pq = {kk: vv / float(B) for kk, vv in cin.items()}
+                dq = {"valu_busy_per_simd": 6.0 * cin["SQ_ACTIVE_INST_VALU"] / wc, "wave_time_issuing": cin["SQ_ACTIVE_INST_ANY"] / wc, "wave_time_parked_waitcnt_or_barrier": cin["SQ_WAIT_ANY"] / wc,
+                      "wave_time_waiting_for_issue": cin["SQ_WAIT_INST_ANY"] / wc, "lds_bank_conflict_share_of_lds_cycles": cin["SQ_LDS_BANK_CONFLICT"] / cin["SQ_LDS_IDX_ACTIVE"],
+                      "lds_pipe_busy": cin["SQ_LDS_IDX_ACTIVE"] / (wc * 4.0 / 8.0 / 3.0)}
+            if (sq_in_run or cand) and fast_used:
+                if not sq_in_run:
+                    sq = json.load(open(cand[-1]))
+                    dq, pq = sq["derived"], sq["per_query"]
                 secondary = [
                     {"bound": "valu_issue", "frac": dq["valu_busy_per_simd"], "unit": "share of SIMD cycles the vector ALU is busy", "wave_instructions_per_query": {"valu": pq["SQ_INSTS_VALU"], "salu": pq["SQ_INSTS_SALU"], "lds": pq["SQ_INSTS_LDS"]},
                      "wave_time": {"issuing": dq["wave_time_issuing"], "parked_at_waitcnt_or_barrier": dq["wave_time_parked_waitcnt_or_barrier"], "ready_but_waiting_for_an_issue_slot": dq["wave_time_waiting_for_issue"]}},
                     {"bound": "lds_atomic", "frac": dq.get("lds_pipe_busy"), "unit": "share of cycles the CU's LDS pipe is active", "bank_conflict_share_of_lds_cycles": dq["lds_bank_conflict_share_of_lds_cycles"],
                      "lds_cycles_per_query": pq["SQ_LDS_IDX_ACTIVE"], "of_them_bank_conflicts": pq["SQ_LDS_BANK_CONFLICT"]},
                 ]
-                secondary = {"entries": secondary, "source": os.path.relpath(cand[-1], ROOT), "measured_in_this_run": False,
+                l2 = None
+                if sq_in_run and cin.get("TCC_HIT_sum") is not None and cin.get("TCC_MISS_sum") is not None:
+                    req = cin.get("TCC_REQ_sum", cin["TCC_HIT_sum"] + cin["TCC_MISS_sum"])
+                    # (a TCC request moves up to one 128-byte line: the upper bound of what the L2s delivered; peak 34.5 TB/s aggregate, MI355X_MICROARCH.md "L2 (per XCD)")
+                    l2 = {"bound": "l2", "hit_rate": cin["TCC_HIT_sum"] / max(1.0, cin["TCC_HIT_sum"] + cin["TCC_MISS_sum"]), "requests_per_launch": req, "tcp_read_requests_per_launch": cin.get("TCP_TCC_READ_REQ_sum"),
+                          "bytes_per_launch_upper_bound": req * 128.0, "achieved_upper_bound_GBps": req * 128.0 / (kernel_ms * 1e-3) / 1e9, "peak_GBps": 34500.0,
+                          "frac_upper_bound": req * 128.0 / (kernel_ms * 1e-3) / 1e9 / 34500.0, "requests_per_query": req / float(B)}
+                    secondary.append(l2)
+                secondary = {"entries": secondary, "source": "rocprofv3 --pmc passes of this command at the timed batch size" if sq_in_run else os.path.relpath(cand[-1], ROOT),
+                             "measured_in_this_run": bool(sq_in_run), "queries_per_dispatch": int(B) if sq_in_run else None,
                              "note": "no single unit is saturated: the kernel is held by dependent LDS / HBM round trips on three workgroups per CU and by issue-slot contention between them (DESIGN.md 4.1); "
                                      "what moved it in round 5 was memory locality -- the serving order -- not a unit's throughput"}
         except Exception:
@@ -842,7 +873,9 @@ def main():
                 model[name] = {"GBps": gbps, "exchange_ms": {"gather": xg, "streaming": xs},
                                "projected_node_queries_per_s": {"gather_not_overlapped": Bl / ((float(t.sum()) + xg) * 1e-3), "streaming_not_overlapped": Bl / ((float(ts_.sum()) + xs) * 1e-3),
                                                                 "gather_overlapped": Bl / (max(float(t.sum()), xg) * 1e-3), "streaming_overlapped": Bl / (max(float(ts_.sum()), xs) * 1e-3)}}
-            model["what_the_library_does"] = "SRN_SBACK_STREAM unset (round 6): a group with real peers takes the streaming form unless srn_shard_group_set_overlap(1) -- not overlapped the exchange is on the batch's critical path and the streaming form's total is lower at either rate; overlapped the gather form's smaller compute wins"
+            model["what_the_library_does"] = ("SRN_SBACK_STREAM unset (round 6): a group with real peers whose exchanges are NOT overlapped (the default) takes the form with the lower modelled total -- "
+                                              "streaming iff the bytes it saves per query and link / SRN_XGMI_GBPS (default 76.8 GB/s per direction) exceed the 5.9 ns of extra compute per query; "
+                                              "with srn_shard_group_set_overlap(1) the gather form (its smaller compute decides)")
             blk["exchange_model"] = model
         except Exception as e:   # (the block is an extra: its failure must not cost the line)
             blk["exchange_model"] = {"error": repr(e)[:300]}

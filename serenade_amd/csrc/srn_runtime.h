@@ -52,6 +52,7 @@ struct Knobs {
     bool no_sback = false;    // SRN_NO_SBACK: the shard group's back end through vmis_fast_kernel's FM_BACK instantiation (rounds 4) instead of the wave-per-query kernel of srn_sback.hip
     bool sback_bitmap = false;     // SRN_SBACK_BITMAP=1 (experiments): that kernel asks its presence bitmap before it fetches a fragment.  Measured on config 3 cut in 8: half the fragment
                                    // fetches, but one more DEPENDENT round trip per query on a kernel that spends 65 % of its time waiting for memory -- 1.65 ms with, 1.52 ms without
+    double xgmi_gbps = 76.8;       // SRN_XGMI_GBPS: what one xGMI link moves per direction (AUTO's input below)
     int sback_stream_mode = -1;    // SRN_SBACK_STREAM: 1 = the streaming form wherever the shards have it, 0 = never, unset = AUTO (round 6): a group with real peers (RCCL / callbacks) takes it
                                    // unless its exchanges overlap the previous batch (srn_shard_group_set_overlap) -- it ships a third of the gather form's bytes and costs 0.4 ms more compute per
                                    // rank and batch, which pays as soon as the exchange is on the batch's critical path (bench.py: item_sharded.local_g8.exchange_model); an in-process group's

@@ -51,6 +51,7 @@ static void knobs_read() {
     k.no_sback = getenv("SRN_NO_SBACK") != nullptr; k.sback_bitmap = getenv("SRN_SBACK_BITMAP") != nullptr && atoi(getenv("SRN_SBACK_BITMAP")) != 0;
     k.sback_stream_mode = getenv("SRN_SBACK_STREAM") == nullptr ? -1 : atoi(getenv("SRN_SBACK_STREAM")) != 0 ? 1 : 0;
     k.no_sback_stream = k.sback_stream_mode == 0;
+    if (const char* e = getenv("SRN_XGMI_GBPS")) { const double v = atof(e); if (v > 0.0) k.xgmi_gbps = v; }
     if (const char* e = getenv("SRN_SBACK_MIN_SHARDS")) k.sback_min_shards = std::max(2, atoi(e));
     if (const char* e = getenv("SRN_FAST_RUNS")) k.fast_runs = atoi(e) == 3 ? 3 : 0;   // tests: the fast kernel's 29-bit-rank form (3 lists per query) on a small index
     std::lock_guard<std::mutex> lk(g_knobs_mu); g_knobs = k;
