@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--shard-timeout", type=int, default=420, help="seconds the item-sharded phase may take before the line falls back to the replicas mode alone")
     ap.add_argument("--rehearse", type=int, default=0, help="N processes on device 0 over the callback transport (gloo): the N > 1 code path of this script on a one-GPU box")
     ap.add_argument("--overlap-probe-timeout", type=float, default=30.0, help="seconds (plus three times the non-overlapped run's duration) the overlapped item-sharded run may take at N > 1")
+    ap.add_argument("--no-stream-probe", action="store_true", help="N > 1: skip the third item-sharded run (the streaming form of the neighbours exchange, not overlapped)")
     ap.add_argument("--shard-steps", type=int, default=0, help="timed steps of the item-sharded phase (0: --steps)")
     ap.add_argument("--measure-traffic", dest="measure_traffic", action="store_true", default=True, help="N=1 (default ON where rocprofv3 exists): two extra rocprofv3 --pmc passes "
                     "(FETCH_SIZE, WRITE_SIZE) of this script with 1 + 2 steps, so that roofline.traffic is measured in this run; the committed summary under profiles/ is only a labelled fallback")
@@ -354,6 +355,12 @@ def main():
                 resident["replicated_postings"] = int(postings.info["device_bytes"])
                 index.close(); index = None
                 torch.cuda.empty_cache()
+            # the exchange FORMAT of the neighbours pipeline: the first two timed runs use the gather form (SRN_SBACK_STREAM=0: the form every earlier round's tests and
+            # rehearsals ran), the streaming form (a third of the bytes, more compute; the library's AUTO for a non-overlapped exchange) is a third run under the watchdog
+            stream_env_user = os.environ.get("SRN_SBACK_STREAM")
+            if stream_env_user is None:
+                from serenade_amd import capi as _capi0
+                os.environ["SRN_SBACK_STREAM"] = "0"; _capi0.reload_knobs()
             group.set_postings(postings)
         t_group = time.time() - t0g
         s_out = (torch.empty((Bs, how_many), dtype=torch.int64, device=dev), torch.empty((Bs, how_many), dtype=torch.float64, device=dev),
@@ -441,11 +448,36 @@ def main():
         wd2.start()
         second = one_run(True)
         wd2.cancel()
-        pending["line"] = None
         best_is_second = second["value"] >= first["value"]
         probe = {"non_overlapped": {"value": first["value"], "ms_per_step": first["ms_per_step"]}, "overlapped": {"value": second["value"], "ms_per_step": second["ms_per_step"]},
-                 "timed_run": "overlapped" if best_is_second else "non-overlapped", "watchdog_s": round(limit, 1)}
-        return (shard_line_of(second if best_is_second else first, probe) if rank == 0 else None), sbatches
+                 "timed_run": "overlapped" if best_is_second else "non-overlapped", "watchdog_s": round(limit, 1), "streaming_non_overlapped": None}
+        best = second if best_is_second else first
+        # third: the streaming form of the exchange, not overlapped (what the library's AUTO takes for a group with real peers) -- set_postings again (a collective: the
+        # ranks agree on it), under the watchdog like the overlapped run; it only replaces the line if it is faster
+        if postings is not None and os.environ.get("SRN_SBACK_STREAM") == "0" and not args.no_stream_probe:
+            if rank == 0:
+                pending["line"] = make_line(shard_line_of(best, dict(probe, streaming_non_overlapped="did not finish within the watchdog: this line was printed by it")))
+            wd3 = threading.Timer(limit, probe_hung)
+            wd3.daemon = True
+            D.barrier()
+            wd3.start()
+            try:
+                from serenade_amd import capi as _capi1
+                ref_rows = (s_out[0].clone(), s_out[2].clone())     # (the last timed step of every run serves the same batch: the rows must be the same bytes)
+                os.environ.pop("SRN_SBACK_STREAM", None); _capi1.reload_knobs()
+                group.set_postings(postings)
+                third = one_run(False)
+                rows_equal = bool(torch.equal(ref_rows[0], s_out[0]) and torch.equal(ref_rows[1], s_out[2]))
+                streamed = third["per_q"]["bytes_neighbours"] < 0.75 * first["per_q"]["bytes_neighbours"]
+                probe["streaming_non_overlapped"] = {"value": third["value"], "ms_per_step": third["ms_per_step"], "streaming_form_ran": bool(streamed),
+                                                     "neighbour_exchange_bytes_per_query_rank0": third["per_q"]["bytes_neighbours"], "rows_equal_the_gather_form_rows": rows_equal}
+                if third["value"] > best["value"] and rows_equal:
+                    best = third; probe["timed_run"] = "streaming, non-overlapped"
+            except Exception as e:
+                probe["streaming_non_overlapped"] = {"error": repr(e)[:300]}
+            wd3.cancel()
+        pending["line"] = None
+        return (shard_line_of(best, probe) if rank == 0 else None), sbatches
 
     def measure_traffic_now(B):
         """HBM traffic of the dominant kernel, measured NOW: this script again under rocprofv3 --pmc, FETCH_SIZE and WRITE_SIZE in separate passes (kernel trace only,

@@ -14,6 +14,9 @@ SOURCES = ["srn_index.cpp", "srn_capi.cpp", "srn_batcher.cpp", "srn_combine.cpp"
 HEADERS = ["srn_internal.h", "srn_kernels.h", "srn_device.h", "srn_prep.h", "srn_runtime.h", os.path.join("..", "..", "include", "serenade_hip.h")]
 
 
+EXPERIMENT_ONLY_FLAGS = ("SRN_FAST_EXP_", "SRN_FAST_STOP", "SRN_ABLATE")   # "timing only, wrong results" macros of the kernels
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -41,6 +44,16 @@ def build_hip(force=False, verbose=False):
     """One object per source (rebuilt only when that source or a header changed), then one link."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = os.environ.get("SRN_CFLAGS", "").split()          # experiments only (e.g. -DSRN_ABLATE=1)
+    # libserenade_hip.so is THE library -- what ships to the GPU box and what every test loads.  Flags that make a kernel compute something else ("timing only, wrong
+    # results": SRN_FAST_EXP_*, SRN_FAST_STOP, SRN_FAST_EARLY_CLEAR ...) may only ever produce a variant file (build_variant -> serenade_amd/variants/, loaded through
+    # SRN_LIB_PATH); and no SRN_CFLAGS build may replace the default library in place at all unless SRN_CFLAGS_INPLACE=1 says the caller knows (VERDICT r5 weak 8)
+    banned = [f for f in extra if any(t in f for t in EXPERIMENT_ONLY_FLAGS)]
+    if banned:
+        raise RuntimeError("SRN_CFLAGS holds experiment-only flags %s: they change what the kernels compute and may not be built into libserenade_hip.so -- "
+                           "use build.build_variant(name, cflags) and SRN_LIB_PATH" % banned)
+    if extra and os.environ.get("SRN_CFLAGS_INPLACE") != "1":
+        raise RuntimeError("SRN_CFLAGS=%r would rebuild libserenade_hip.so in place with non-default flags: use build.build_variant(name, cflags) + SRN_LIB_PATH, "
+                           "or set SRN_CFLAGS_INPLACE=1 if that is really what you want" % " ".join(extra))
     objdir = os.path.join(CSRC, "_obj")
     headers = [os.path.join(CSRC, h) for h in HEADERS]
     if not force and not extra and not _stale(LIB, [os.path.join(CSRC, n) for n in SOURCES] + headers):
