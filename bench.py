@@ -471,7 +471,7 @@ def main():
                 streamed = third["per_q"]["bytes_neighbours"] < 0.75 * first["per_q"]["bytes_neighbours"]
                 probe["streaming_non_overlapped"] = {"value": third["value"], "ms_per_step": third["ms_per_step"], "streaming_form_ran": bool(streamed),
                                                      "neighbour_exchange_bytes_per_query_rank0": third["per_q"]["bytes_neighbours"], "rows_equal_the_gather_form_rows": rows_equal}
-                if third["value"] > best["value"] and rows_equal:
+                if third["value"] > best["value"] and rows_equal and streamed:   # (a group whose shards have no streaming form -- fewer than SRN_SBACK_MIN_SHARDS -- just ran the gather form again)
                     best = third; probe["timed_run"] = "streaming, non-overlapped"
             except Exception as e:
                 probe["streaming_non_overlapped"] = {"error": repr(e)[:300]}

@@ -33,8 +33,10 @@ def test_rehearsal_of_the_multi_gpu_line(world):
     cfg = line["config"]
     assert cfg["transport"] == "callbacks" and cfg["rccl_ranks"] == 0 and "rehearsal" in cfg and cfg["rehearsal"]
     probe = cfg["overlap_probe"]
-    assert probe["non_overlapped"]["value"] > 0 and probe["overlapped"]["value"] > 0 and probe["timed_run"] in ("overlapped", "non-overlapped")
+    assert probe["non_overlapped"]["value"] > 0 and probe["overlapped"]["value"] > 0 and probe["timed_run"] in ("overlapped", "non-overlapped", "streaming, non-overlapped")
     assert cfg["exchange_overlapped_with_previous_batch"] == (probe["timed_run"] == "overlapped")
+    third = probe["streaming_non_overlapped"]           # round 6: the streaming form of the neighbours exchange as a third run (set_postings again: a collective) -- same rows
+    assert third["value"] > 0 and third["rows_equal_the_gather_form_rows"] is True and (third["streaming_form_ran"] or probe["timed_run"] != "streaming, non-overlapped")
     assert line["parity_checked"] > 0 and line["queries_served_last_step"] == 4096
     rep = line["replicas"]
     assert rep["value"] == line["value_replicas"] and rep["parity_checked"] > 0 and rep["full_batch_properties_ok"] is True and rep["kernel"]["kernel"].startswith("vmis_")
