@@ -629,6 +629,26 @@ def main():
                 sa.predict(index, q, k, m, how_many, False)
                 lat.append((time.perf_counter() - t1) * 1e6)
             lat_single = np.array(lat[50:])
+            # ... and the same calls through a RESIDENT workgroup of the persistent latency path (round 6: srn_index_serve_start -- no kernel launch per call); a workgroup
+            # leaves by itself after 2 s without a request, so nothing outlives this block whatever happens
+            lat_resident = None
+            try:
+                index.serve_start(k, m, how_many, False, lanes=1, max_items_in_session=last_items, idle_ms=2000)
+                lat = []
+                for i in range(600):
+                    q = flat0[qo0[i]:qo0[i + 1]]
+                    t1 = time.perf_counter()
+                    sa.predict(index, q, k, m, how_many, False)
+                    lat.append((time.perf_counter() - t1) * 1e6)
+                sv = index.serve_stats()
+                lat_resident = {"us": np.array(lat[100:]), "answered_without_a_launch": int(sv[0]), "sent_to_the_launch_path": int(sv[1])}
+            except Exception as e:
+                lat_resident = {"error": repr(e)[:200]}
+            finally:
+                try:
+                    index.serve_stop()
+                except Exception:
+                    pass
 
         # ---- 3b. sessions longer than the headline's last_items (the reference's hyper-parameter grid of last_items_in_session goes to 10,
         # src/hyperparameter/hyperparamgrid.rs:93-139; its README's range to 20): the same index, evaluator-style queries keeping their last 8 / 10 / 20 items, resident
@@ -783,6 +803,10 @@ def main():
             "latency": {"step_ms_p50": float(np.percentile(step_ms, 50)), "step_ms_p90": float(np.percentile(step_ms, 90)),
                         "single_query_us_p50": float(np.percentile(lat_single, 50)) if lat_single is not None else None,
                         "single_query_us_p90": float(np.percentile(lat_single, 90)) if lat_single is not None else None,
+                        "single_query_resident_workgroup": None if (lat_single is None or lat_resident is None) else (lat_resident if "error" in lat_resident else {
+                            "us_p50": float(np.percentile(lat_resident["us"], 50)), "us_p90": float(np.percentile(lat_resident["us"], 90)), "us_p99": float(np.percentile(lat_resident["us"], 99)),
+                            "answered_without_a_launch": lat_resident["answered_without_a_launch"], "sent_to_the_launch_path": lat_resident["sent_to_the_launch_path"],
+                            "note": "srn_predict through the Python binding (~5 us of it) with one resident workgroup of the persistent latency path parked on the GPU (srn_index_serve_start): no kernel launch per call; C++ host: profiles/r06_latency_resident_cfg3.json"}),
                         "batch_sweep": sweep,
                         "long_sessions": long_sessions,
                         "note": "batch_sweep: srn_predict_batch_device on resident buffers (HIP events) vs srn_predict_batch on host buffers (pageable numpy arrays, result buffers "
