@@ -108,7 +108,7 @@ struct Workspace {
 struct ServeState;   // the persistent latency path's resident workgroups (srn_runtime.hip, "serve")
 struct DeviceState {
     int device = 0;
-    std::atomic<ServeState*> serve{nullptr};
+    std::atomic<ServeState*> serve{nullptr}; std::vector<ServeState*> serve_retired;   // (retired: stopped, kept until device_release -- a concurrent srn_predict may still hold the pointer)
     std::vector<void*> allocs; uint64_t bytes = 0;
     DeviceIndex di{};
     ItemMeta* d_meta = nullptr;

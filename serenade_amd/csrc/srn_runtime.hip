@@ -226,7 +226,7 @@ static void ws_free(Workspace* w) {
 
 void device_release(DeviceState* d) {
     if (!d) return;
-    (void)device_serve_stop(d);
+    (void)device_serve_stop(d); serve_free_retired(d);
     hipSetDevice(d->device);
     hostpipes_free(d);
     for (Workspace* w : d->all_ws) ws_free(w);
@@ -618,7 +618,7 @@ static int device_predict_tiny(DeviceState* d, const FlatIndex& ix, Workspace* w
 // hipFree / hipDeviceSynchronize would wait for a resident workgroup for ever: every such call of the library goes through srn_hipsync.h, which makes them leave first.
 // =====================================================================================================================================================================
 struct ServeForm {   // one resident launch: N workgroups of the lean form (sessions of <= 4 items) or of the form for 5..10 items
-    DeviceState* d = nullptr; bool mid = false; bool dead = false; uint32_t n = 0;
+    DeviceState* d = nullptr; bool mid = false; std::atomic<bool> dead{false}; uint32_t n = 0;
     hipStream_t st = nullptr;
     ServeCtl* ctl = nullptr; ServeCtl* ctl_dev = nullptr;   // [n], pinned
     char* rows = nullptr; char* rows_dev = nullptr; size_t row_bytes = 0;   // [n] x (ids | scores), pinned
@@ -677,12 +677,20 @@ static void form_free(ServeForm* f) {
     if (f->st) (void)hipStreamDestroy(f->st);
     delete f;
 }
+// srn_index_serve_stop may run while other threads are inside srn_predict: a caller that read the state's pointer a moment ago must still find its memory.  Stop therefore
+// RETIRES the state -- its forms are marked dead (no new session is posted, no launch is started again) and parked (every session in flight is answered first) -- and
+// only device_release (srn_index_free: nobody may be using the index any more) frees it.
+static void serve_free_retired(DeviceState* d) {
+    std::vector<ServeState*> old;
+    { std::lock_guard<std::mutex> lk(d->mu); old.swap(d->serve_retired); }
+    for (ServeState* s : old) { for (ServeForm* f : s->forms) form_free(f); delete s; }
+}
 int device_serve_stop(DeviceState* d) {
     ServeState* s = d->serve.exchange(nullptr);
     if (!s) return SRN_OK;
     HIP_TRY(hipSetDevice(d->device));
-    for (ServeForm* f : s->forms) form_free(f);
-    delete s;
+    for (ServeForm* f : s->forms) { f->dead.store(true); std::lock_guard<std::mutex> fl(f->mu); form_park(f); }
+    { std::lock_guard<std::mutex> lk(d->mu); d->serve_retired.push_back(s); }
     return SRN_OK;
 }
 int device_serve_start(DeviceState* d, const FlatIndex& ix, uint32_t k, uint32_t m, uint32_t how_many, uint32_t flags, uint32_t lanes, uint32_t max_items, uint32_t idle_ms) {
@@ -693,7 +701,7 @@ int device_serve_start(DeviceState* d, const FlatIndex& ix, uint32_t k, uint32_t
     const Knobs kn = knobs();
     ServeState* s = new ServeState(); s->k = k; s->m = m; s->how_many = how_many; s->flags = flags; s->max_items = std::min<uint32_t>(std::max<uint32_t>(max_items, 1), F_MID_LMAX);
     s->idle_ticks = (unsigned long long)std::max<uint32_t>(idle_ms, 1) * 100000ull;   // (wall_clock64: 100 MHz)
-    auto undo = [&](int code, const std::string& why) { for (ServeForm* f : s->forms) form_free(f); delete s; return fail(code, why); };
+    auto undo = [&](int code, const std::string& why) { for (ServeForm* f : s->forms) form_free(f); delete s; return fail(code, why); };   // (never published: nobody else holds it)
     // A resident launch never ends, and HIP multiplexes its streams onto a few hardware queues per priority level: on a queue shared with another stream everything
     // behind the resident kernel would wait for ever.  The resident streams take the LOWEST priority level, which nothing else in this library uses.
     int prio_lo = 0, prio_hi = 0; (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
@@ -760,6 +768,7 @@ int device_serve_predict(DeviceState* d, const uint64_t* items, uint32_t len, ui
         if (!f->running || __atomic_load_n(&c->alive, __ATOMIC_ACQUIRE) == 0u) {   // parked (something freed device memory) or gone (idle): start the launch again, then look for a lane again
             lane_unlock(f, li);
             std::lock_guard<std::mutex> fl(f->mu);
+            if (f->dead.load()) { s->not_served.fetch_add(1); return 1; }   // (retired by srn_index_serve_stop in the meantime: never started again)
             bool gone = !f->running; for (uint32_t i = 0; i < f->n && !gone; ++i) gone = __atomic_load_n(&f->ctl[i].alive, __ATOMIC_ACQUIRE) == 0u;
             if (gone && form_launch(s, f) != SRN_OK) { f->dead = true; s->not_served.fetch_add(1); return 1; }
             continue;

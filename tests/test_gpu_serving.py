@@ -181,6 +181,11 @@ def test_persistent_latency_path_against_the_oracle():
     th = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
     for t in th:
         t.start()
+    for _ in range(3):          # stopped and started again UNDER the callers: a stop retires the resident state (a caller may still hold it), the calls fall through to the launch path
+        time.sleep(0.01)
+        gix.serve_stop()
+        time.sleep(0.01)
+        gix.serve_start(k, m, 21, False, lanes=2, max_items_in_session=10, idle_ms=1500)
     for t in th:
         t.join()
     assert not errs, errs
