@@ -224,6 +224,7 @@ static void ws_free(Workspace* w) {
     delete w;
 }
 
+void serve_free_retired(DeviceState* d);
 void device_release(DeviceState* d) {
     if (!d) return;
     (void)device_serve_stop(d); serve_free_retired(d);
@@ -680,7 +681,7 @@ static void form_free(ServeForm* f) {
 // srn_index_serve_stop may run while other threads are inside srn_predict: a caller that read the state's pointer a moment ago must still find its memory.  Stop therefore
 // RETIRES the state -- its forms are marked dead (no new session is posted, no launch is started again) and parked (every session in flight is answered first) -- and
 // only device_release (srn_index_free: nobody may be using the index any more) frees it.
-static void serve_free_retired(DeviceState* d) {
+void serve_free_retired(DeviceState* d) {
     std::vector<ServeState*> old;
     { std::lock_guard<std::mutex> lk(d->mu); old.swap(d->serve_retired); }
     for (ServeState* s : old) { for (ServeForm* f : s->forms) form_free(f); delete s; }
