@@ -109,8 +109,22 @@ __device__ __forceinline__ uint32_t fast_offset_of(uint32_t idx, uint64_t r) {  
     if (idx < F_REP_ITEMS) return (F_DIRECT + idx * F_REP + ((uint32_t)r & (F_REP - 1u))) * 4u;
     return idx < F_DIRECT ? idx * 4u : (F_SKETCH - F_HOT) + (idx & (F_SK_WORDS - 1u)) * 4u;
 }
+// (round 6) WHERE the unused positions of a row slot point.  Only ~30 % of the lanes of a walk's ds_add carry a real row element; until round 5 the others added into a
+// 256-word dump area inside the accumulators' map -- real LDS work, with same-address collisions among 45 lanes in 256 words.  A DS access beyond the workgroup's LDS
+// allocation is dropped by the hardware (writes ignored, reads return 0) before it costs a bank cycle: tools/lds_oor_bench.hip, 24 waves per CU -- 1.57 LDS cycles per
+// ds_add with the phantoms in a dump area, 1.15 with them out of range (reads: 1.91 / 1.45).  So the phantoms now point at [F_PHANTOM, + 1 KB): beyond the 53 760 bytes
+// of the lean / MID / TINY / back-end forms, and inside the BIG / LONG forms' 80 KB at a place that is dead during the walks (the LONG form's numerator bytes of the
+// m-cut, read for the last time in the k-cut; plain merge room in BIG) and zeroed where the dump area used to be zeroed, before walk B looks at it.
+#ifndef SRN_FAST_PHANTOM_OOR
+#define SRN_FAST_PHANTOM_OOR 1
+#endif
+static constexpr uint32_t F_PHANTOM_WORDS = 256u;
+static constexpr uint32_t F_PHANTOM = SRN_FAST_PHANTOM_OOR ? F_BIG_TOTAL - (F_TOTAL - F_SIDF) - 256u * 4u - F_M_MAX : F_DUMP;   // (BIG: below the class histogram = the start of the LONG form's numerator bytes)
+static_assert(!SRN_FAST_PHANTOM_OOR || (F_PHANTOM >= F_TOTAL && F_PHANTOM % 4u == 0u), "the phantom words lie beyond the 53 KB forms' LDS allocation");
+static_assert(F_PHANTOM + F_PHANTOM_WORDS * 4u - F_HOT <= 65536u, "16-bit row offsets");
+static_assert(!SRN_FAST_PHANTOM_OOR || F_PHANTOM_WORDS * 4u <= F_M_MAX, "inside the numerator bytes' room");
 __device__ __forceinline__ uint32_t fast_phantom(uint64_t r, uint32_t j) {
-    return (F_DUMP - F_HOT) + ((((uint32_t)r * 0x9E3779B1u + j * 0x85EBCA6Bu) >> 21) & (F_DUMP_WORDS - 1u)) * 4u;
+    return (F_PHANTOM - F_HOT) + ((((uint32_t)r * 0x9E3779B1u + j * 0x85EBCA6Bu) >> 21) & (F_PHANTOM_WORDS - 1u)) * 4u;
 }
 __global__ __launch_bounds__(1024) void rows_to_packed_kernel(const uint64_t* __restrict__ row_off, const uint32_t* __restrict__ row_items, uint64_t n,
                                                               const uint32_t* __restrict__ block_base, uint32_t* __restrict__ packed, uint32_t* __restrict__ ext16) {
@@ -207,7 +221,12 @@ __device__ __forceinline__ uint32_t merge_team(uint32_t total) {   // log2 of th
 }
 __device__ __forceinline__ void merge_pair(const uint32_t* in, uint32_t* out, uint32_t sa, uint32_t la, uint32_t lb, uint32_t ttid, uint32_t lg_nthr) {
     if ((ttid >> lg_nthr) != 0u) return;   // (whole waves)
-    const uint32_t sb = sa + la, total = la + lb, g = (total + (1u << lg_nthr) - 1u) >> lg_nthr;
+#ifndef SRN_MERGE_ODD
+#define SRN_MERGE_ODD 1
+#endif
+    // (round 6) a thread's share is made ODD: lane l writes out[d0 + i] with d0 = l g -- an even g puts the 64 lanes of a store on 32 / 16 / 8 of the 64 banks
+    // (g = 8, a quarter of the merges: an 8-way conflict on every step); an odd stride touches all banks.  The last threads of the team get nothing: they leave at once
+    const uint32_t sb = sa + la, total = la + lb, g = ((total + (1u << lg_nthr) - 1u) >> lg_nthr) | (SRN_MERGE_ODD ? 1u : 0u);
     const uint32_t d0 = min(ttid * g, total), d1 = min(d0 + g, total);
     if (d0 >= d1) return;
     uint32_t lo = d0 > lb ? d0 - lb : 0u, hi = min(d0, la);
@@ -750,6 +769,23 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
         FAST_TICK(3);
         FAST_PRIO(FP_CUT);
         const uint32_t* F = B0; uint32_t* D = B1;
+        // Experiment (round 6, measured, NOT kept: 26.5 against 21.5 ms): the CANDIDATES' row slots prefetched here, 5-6 K cycles before the cuts have named the neighbours
+        // -- one dword per candidate into a dead LDS line (global_load_lds) -- so that the real requests find their lines in the L2.  The memory system moves a tenth of
+        // the algorithmic bytes and the L2s run at <= 41 %, yet 3 072 more scattered requests per query (+130 %) cost a quarter of the kernel: what a CU can ISSUE in scattered
+        // 64-lane gathers is the scarce thing, not bytes.  (profiles/r06_row_prefetch_ab.txt)
+#ifndef SRN_FAST_ROW_PREFETCH
+#define SRN_FAST_ROW_PREFETCH 0
+#endif
+        if constexpr (SRN_FAST_ROW_PREFETCH != 0 && !MID && MODE == FM_FUSED && !FRAG) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                if ((uint32_t)j * BLOCK < n) {   // (block-uniform)
+                    const uint32_t sl = F[min(tid + (uint32_t)j * BLOCK, n - 1u)];
+                    const char* a = reinterpret_cast<const char*>(f.row_packed) + (size_t)(base + (sl >> NB)) * 64u;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a, (__attribute__((address_space(3))) void*)pre, 4, 0, 0);
+                }
+            }
+        }
         // ---- the two cuts in one pass over the merged run (fast_cut above) where a thread's chunk is <= 6 entries (n <= 3072: four queries in five); the two-pass form below otherwise ----
         if (!MID && SRN_FAST_FUSED_CUT && n <= 6u * BLOCK) {   // (block-uniform)
             const uint32_t kc = fast_cut<6>(F, nbl, n, NB, p.m, p.k, wlut, misc, tid, lane);
@@ -1032,7 +1068,8 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
                 const uint4 a = rp[0], b = rp[1];
                 v = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
             }
-            for (uint32_t i = tid; i < F_DUMP_WORDS; i += BLOCK) ((uint32_t*)(smem + F_DUMP))[i] = 0u;   // (walk B reads the dump words, where the positions past a row's end point, as "cannot reach the floor")
+            if (!SRN_FAST_PHANTOM_OOR || BIG)   // (the 53 KB forms: out of range -- nothing there to zero, walk B's reads of it return 0)
+            for (uint32_t i = tid; i < F_PHANTOM_WORDS; i += BLOCK) ((uint32_t*)(smem + F_PHANTOM))[i] = 0u;   // (walk B reads the phantom words, where the positions past a row's end point, as "cannot reach the floor")
             bool valid = (LONG ? (int)v > 0 : v != 0u) && e != cur_idx;   // (LONG: sums are signed; an item whose sum is <= 0 is no candidate and sets no threshold)
             double x = 0.0; uint32_t tie = 0;
             // idf_eff and the attribute byte come from the thread's LDS slot; only the id rank (wanted after the barrier below, for the few candidates) is a
