@@ -608,6 +608,7 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
         // query's candidates, and their share of the posting lists is in flight meanwhile.
         uint32_t v[4][5];   // every load of every list in flight at once (uniform skips; past a list's end the lanes re-read its last entry)
         uint32_t K = 0;
+        uint32_t pfv[4] = {0u, 0u, 0u, 0u};   // (experiment SRN_FAST_ROW_PREFETCH=2 only)
         uint32_t xsv[3] = {0u, 0u, 0u};
         if constexpr (MODE == FM_BACK) {   // K and this lane's <= 3 neighbour slots in ONE round trip, requested before the barrier like the lists of the fused form (slots past K: stale words of
                                            // the query's own row of the exchange buffer, masked below)
@@ -778,11 +779,12 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
 #endif
         if constexpr (SRN_FAST_ROW_PREFETCH != 0 && !MID && MODE == FM_FUSED && !FRAG) {
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
+            for (int j = 0; j < (SRN_FAST_ROW_PREFETCH == 1 ? 6 : 4); ++j) {
                 if ((uint32_t)j * BLOCK < n) {   // (block-uniform)
                     const uint32_t sl = F[min(tid + (uint32_t)j * BLOCK, n - 1u)];
                     const char* a = reinterpret_cast<const char*>(f.row_packed) + (size_t)(base + (sl >> NB)) * 64u;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a, (__attribute__((address_space(3))) void*)pre, 4, 0, 0);
+                    if (SRN_FAST_ROW_PREFETCH == 1) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a, (__attribute__((address_space(3))) void*)pre, 4, 0, 0);
+                    else if (j < 4) pfv[j] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a));   // (2: plain loads into registers that stay live across the cuts)
                 }
             }
         }
@@ -918,6 +920,7 @@ __global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kerne
         }
 
         FAST_TICK(4);
+        if constexpr (SRN_FAST_ROW_PREFETCH == 2 && !MID && MODE == FM_FUSED && !FRAG) asm volatile("" :: "v"(pfv[0]), "v"(pfv[1]), "v"(pfv[2]), "v"(pfv[3]));
         FAST_PRIO(FP_REQ); FAST_PRIO_X(10);
         if constexpr (MODE == FM_FRONT) {   // the neighbour list leaves for the exchange buffer (a barrier stands between its last write and here in every branch above)
             if (tid == 0) xq[0] = K;
