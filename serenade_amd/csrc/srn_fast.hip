@@ -379,7 +379,12 @@ template <int WG_PER_CU, bool FRAG, bool WIDE, int MODE = FM_FUSED, bool MID = f
 #ifndef SRN_FAST_WAVES
 #define SRN_FAST_WAVES (WG_PER_CU * 2)
 #endif
-__global__ __launch_bounds__(512, BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIndex ix_arg, LaunchParams p_arg, FastParams f_arg) {
+// (round 6) the TINY form -- one workgroup per session on the latency path, a handful of them on the whole GPU -- has no use for three workgroups per CU: at the 80-register
+// cap it spilled 45-48 VGPRs, and those come back from scratch on the serial tail of a single session's latency.  SRN_TINY_WAVES waves per SIMD (2: up to 256 registers).
+#ifndef SRN_TINY_WAVES
+#define SRN_TINY_WAVES 2
+#endif
+__global__ __launch_bounds__(512, TINY ? SRN_TINY_WAVES : BIG ? 4 : SRN_FAST_WAVES) void vmis_fast_kernel(DeviceIndex ix_arg, LaunchParams p_arg, FastParams f_arg) {
 #if SRN_FAST_SMALL
     // static allocation: the compiler then knows every LDS address and folds the region offsets into the instructions' offset fields
     // (with a dynamic allocation each computed address pays a v_add of the -- zero -- base: two per row item in the walks)
