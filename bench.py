@@ -622,24 +622,30 @@ def main():
                 hms = np.array(hms[2:])
                 sweep.append({"batch": s, "device_resident": {"queries_per_s": s / (float(np.median(dms)) * 1e-3), "ms_p50": float(np.median(dms)), "ms_p90": float(np.percentile(dms, 90))},
                               "host_inclusive": {"queries_per_s": s / (float(np.median(hms)) * 1e-3), "ms_p50": float(np.median(hms)), "ms_p90": float(np.percentile(hms, 90))}})
-            lat = []
-            for i in range(300):   # the reference's call shape: one evolving session per call, host pointers (srn_predict)
-                q = flat0[qo0[i]:qo0[i + 1]]
+            # the reference's call shape: one evolving session per call, host pointers (srn_predict).  Since round 6 the C entry point is called directly with buffers that
+            # live across the calls, as a serving host would (until round 5 through serenade_amd.predict, whose per-call numpy allocations and result objects were ~9 us of
+            # the figure); profiles/r06_latency_resident_cfg3.json has the C++ host's percentiles
+            import ctypes as _C
+            from serenade_amd import capi as _capi2
+            _L = _capi2.lib()
+            r_ids, r_sc, r_n = np.zeros(how_many, np.uint64), np.zeros(how_many), _C.c_size_t()
+            q_list = [np.ascontiguousarray(flat0[qo0[i]:qo0[i + 1]]) for i in range(600)]
+
+            def one_call(q):
                 t1 = time.perf_counter()
-                sa.predict(index, q, k, m, how_many, False)
-                lat.append((time.perf_counter() - t1) * 1e6)
+                rc = _L.srn_predict(index._h, q.ctypes.data, len(q), k, m, how_many, 0, r_ids.ctypes.data, r_sc.ctypes.data, _C.byref(r_n))
+                dt = (time.perf_counter() - t1) * 1e6
+                if rc:
+                    raise RuntimeError("srn_predict failed")
+                return dt
+            lat = [one_call(q) for q in q_list[:300]]
             lat_single = np.array(lat[50:])
             # ... and the same calls through a RESIDENT workgroup of the persistent latency path (round 6: srn_index_serve_start -- no kernel launch per call); a workgroup
             # leaves by itself after 2 s without a request, so nothing outlives this block whatever happens
             lat_resident = None
             try:
                 index.serve_start(k, m, how_many, False, lanes=1, max_items_in_session=last_items, idle_ms=2000)
-                lat = []
-                for i in range(600):
-                    q = flat0[qo0[i]:qo0[i + 1]]
-                    t1 = time.perf_counter()
-                    sa.predict(index, q, k, m, how_many, False)
-                    lat.append((time.perf_counter() - t1) * 1e6)
+                lat = [one_call(q) for q in q_list]
                 sv = index.serve_stats()
                 lat_resident = {"us": np.array(lat[100:]), "answered_without_a_launch": int(sv[0]), "sent_to_the_launch_path": int(sv[1])}
             except Exception as e:
@@ -803,10 +809,11 @@ def main():
             "latency": {"step_ms_p50": float(np.percentile(step_ms, 50)), "step_ms_p90": float(np.percentile(step_ms, 90)),
                         "single_query_us_p50": float(np.percentile(lat_single, 50)) if lat_single is not None else None,
                         "single_query_us_p90": float(np.percentile(lat_single, 90)) if lat_single is not None else None,
+                        "single_query_note": "srn_predict called through ctypes with preallocated buffers (round 6; rounds 1-5: through serenade_amd.predict, ~9 us of Python per call more): the one-launch latency path",
                         "single_query_resident_workgroup": None if (lat_single is None or lat_resident is None) else (lat_resident if "error" in lat_resident else {
                             "us_p50": float(np.percentile(lat_resident["us"], 50)), "us_p90": float(np.percentile(lat_resident["us"], 90)), "us_p99": float(np.percentile(lat_resident["us"], 99)),
                             "answered_without_a_launch": lat_resident["answered_without_a_launch"], "sent_to_the_launch_path": lat_resident["sent_to_the_launch_path"],
-                            "note": "srn_predict through the Python binding (~5 us of it) with one resident workgroup of the persistent latency path parked on the GPU (srn_index_serve_start): no kernel launch per call; C++ host: profiles/r06_latency_resident_cfg3.json"}),
+                            "note": "srn_predict (ctypes, preallocated buffers) with one resident workgroup of the persistent latency path parked on the GPU (srn_index_serve_start): no kernel launch per call; C++ host: profiles/r06_latency_resident_cfg3.json"}),
                         "batch_sweep": sweep,
                         "long_sessions": long_sessions,
                         "note": "batch_sweep: srn_predict_batch_device on resident buffers (HIP events) vs srn_predict_batch on host buffers (pageable numpy arrays, result buffers "
