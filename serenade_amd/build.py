@@ -154,11 +154,24 @@ def build_serve_bench(force=False):
     return SERVE_BENCH
 
 
+ROW_FETCH_BENCH = os.path.join(HERE, "bin", "row_fetch_bench")
+
+
+def build_row_fetch_bench(force=False):
+    """The random-row gather ceiling of the GPU in the fast kernel's own access shape (tools/row_fetch_bench.hip): bench.py runs it for roofline_secondary's row_gather entry."""
+    src = os.path.join(os.path.dirname(HERE), "tools", "row_fetch_bench.hip")
+    if force or _stale(ROW_FETCH_BENCH, [src]):
+        os.makedirs(os.path.dirname(ROW_FETCH_BENCH), exist_ok=True)
+        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-Wno-unused-result", "-o", ROW_FETCH_BENCH, src])
+    return ROW_FETCH_BENCH
+
+
 def build_all(force=False, verbose=False):
     build_hip(force, verbose)
     build_synth(force)
     build_evaluator(force)
     build_serve_bench(force)
+    build_row_fetch_bench(force)
 
 
 if __name__ == "__main__":
