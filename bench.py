@@ -759,9 +759,9 @@ def main():
                           "bytes_per_launch_upper_bound": req * 128.0, "achieved_upper_bound_GBps": req * 128.0 / (kernel_ms * 1e-3) / 1e9, "peak_GBps": 34500.0,
                           "frac_upper_bound": req * 128.0 / (kernel_ms * 1e-3) / 1e9 / 34500.0, "requests_per_query": req / float(B)}
                     secondary.append(l2)
-                # (round 6) the bound that explains the kernel: the rate at which the GPU serves RANDOM 64-byte row slots in this kernel's access shape (one 16-byte load per
-                # lane, three in flight, a second 16 bytes for one row in four; 24 waves per CU) -- measured now with serenade_amd/bin/row_fetch_bench over a region that lives in
-                # the L2s and over one far beyond them, blended with the L2 hit rate measured above; the kernel fetches K rows per query
+                # (round 6) the request side: the rate at which the GPU serves RANDOM 64-byte row slots in this kernel's access shape (one 16-byte load per lane, three in
+                # flight, a second 16 bytes for one row in four; 24 waves per CU) -- measured now with serenade_amd/bin/row_fetch_bench over a region that lives in one XCD's L2
+                # (2 MB), one in the Infinity Cache (64 MB) and one far beyond both (4 GB), blended with the L2 hit rate measured above; the kernel fetches K rows per query
                 try:
                     import subprocess as _sp
                     from serenade_amd import build as _bld
@@ -773,16 +773,18 @@ def main():
                         for ln in out_rf.splitlines():
                             if ln.startswith("{"):
                                 jj = json.loads(ln)["row_gather_ceiling"]; ceil[int(jj["region_mb"])] = float(jj["g_rows_per_s"]) * 1e9
-                        if len(ceil) == 2:
+                        if len(ceil) == 3:
                             hit = l2["hit_rate"] if l2 else 0.95
-                            c_hit, c_miss = ceil[min(ceil)], ceil[max(ceil)]
+                            c_hit, c_mall, c_miss = ceil[min(ceil)], ceil[sorted(ceil)[1]], ceil[max(ceil)]
                             blended = 1.0 / (hit / c_hit + (1.0 - hit) / c_miss)
                             rows_per_launch = float(dbg["stats"][:, 2].astype(np.float64).mean()) * B * (fast_share if fast_used else 1.0)   # K: neighbours = rows fetched
                             ach_rows = rows_per_launch / (kernel_ms * 1e-3)
                             secondary.append({"bound": "row_gather", "unit": "random 64-byte row slots per second, chip-wide, in the kernel's access shape", "achieved": ach_rows,
-                                              "ceiling_l2_resident": c_hit, "ceiling_beyond_l2": c_miss, "l2_hit_rate_used": hit, "peak": blended, "frac": ach_rows / blended,
+                                              "ceiling_l2_resident": c_hit, "ceiling_infinity_cache": c_mall, "ceiling_hbm": c_miss, "l2_hit_rate_used": hit, "peak": blended, "frac": ach_rows / blended,
+                                              "peak_note": "harmonic blend: hits at the L2-resident rate, misses at the HBM rate (at the Infinity-Cache rate: %.3g)" % (1.0 / (hit / c_hit + (1.0 - hit) / c_mall)),
                                               "rows_per_query": rows_per_launch / float(B), "measured_in_this_run": True,
-                                              "note": "the kernel's neighbours' rows are its scattered requests; a query's other requests (posting lists, record, resolve) are coalesced or few"})
+                                              "note": "the neighbours' rows are the kernel's scattered requests (a query's posting lists, record and hand-off are coalesced, its resolve fetches few); "
+                                                      "a request that hits the L2 costs a CU ~2.4 cycles of its request path, one that misses 10-14"})
                 except Exception:
                     pass
                 secondary = {"entries": secondary, "source": "rocprofv3 --pmc passes of this command at the timed batch size" if sq_in_run else os.path.relpath(cand[-1], ROOT),

@@ -30,7 +30,7 @@ template <int MODE> __global__ __launch_bounds__(512) void k(const uint4* __rest
 int main() {
     uint32_t* out; hipMalloc(&out, 4 * 512 * 768);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (uint64_t mb : {16ull, 4096ull}) {
+    for (uint64_t mb : {2ull, 64ull, 4096ull}) {
         const uint64_t bytes = mb << 20, nrows = bytes / 64; uint4* a; hipMalloc(&a, bytes); hipMemset(a, 1, bytes);
         for (int rep = 0; rep < 2; ++rep) for (int mode = 0; mode < 2; ++mode) {
             const int iters = 400;
