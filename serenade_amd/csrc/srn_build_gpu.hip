@@ -104,7 +104,10 @@ __global__ void k_postings(const uint64_t* sorted_key, uint64_t nnz, const uint6
 // The serving order of a batch (srn_kernels.h FastParams::order): 64-bit keys (dense idx of the query's most popular item << 32 | query) sorted on the 16 key bits;
 // asynchronous on `st`, no allocation (the caller owns `temp`: first call with temp == nullptr for its size).
 hipError_t sort_order_keys(hipStream_t st, const unsigned long long* in, unsigned long long* out, size_t n, void* temp, size_t* temp_bytes) {
-    return rocprim::radix_sort_keys(temp, *temp_bytes, in, out, n, 32, 32 + 16, st);
+#ifndef SRN_ORDER_KEY2
+#define SRN_ORDER_KEY2 0
+#endif
+    return rocprim::radix_sort_keys(temp, *temp_bytes, in, out, n, 32, 32 + (SRN_ORDER_KEY2 ? 24 : 16), st);
 }
 namespace {
 template <typename K, typename V>

@@ -17,6 +17,7 @@ __device__ __forceinline__ void prep_group(const DeviceIndex& ix, const uint64_t
     const bool ok = L != 0 && L <= max_len;
     const uint32_t rounds = ok ? (L + PREP_LANES - 1) / PREP_LANES : 0;
     uint32_t vmax = 0;          // largest FlatIndex::viol among this lane's known items (an index with incomplete lists only)
+    uint32_t hot_key2 = kNone;  // ... and the second smallest (SRN_ORDER_KEY2: the order's secondary key)
     uint32_t hot_key = kNone;   // smallest dense idx (of the index the lists come from) among this lane's known items
     uint32_t idx = kNone, len = 0, pre = 0; unsigned long long base = 0;   // this lane's item of the LAST round (a session of <= 8 items has one round: its record is written once, with `kept`)
     for (uint32_t r = 0; r < rounds; ++r) {
@@ -30,7 +31,7 @@ __device__ __forceinline__ void prep_group(const DeviceIndex& ix, const uint64_t
             for (uint32_t j = 0; j < pos; ++j) first = first && (items_flat[qb + (L - 1 - j)] != raw);   // Q2: most recent occurrence only
             { uint32_t hh = (uint32_t)dev_mix64(raw) & ix.id_mask;
               for (;;) { const IdSlot s = ix.id_table[hh]; if (s.idx == kNone) break; if (s.key == raw) { idx = s.idx; break; } hh = (hh + 1) & ix.id_mask; } }
-            hot_key = min(hot_key, idx);
+            if (idx < hot_key) { hot_key2 = hot_key; hot_key = idx; } else if (idx != hot_key) hot_key2 = min(hot_key2, idx);
             if (ix.viol != nullptr && idx != kNone) vmax = max(vmax, ix.viol[idx]);
             first_i = first ? 1u : 0u;   // Q1: distinct raw ids, known or not
             if (first && idx != kNone) {
@@ -92,10 +93,20 @@ __device__ __forceinline__ void prep_group(const DeviceIndex& ix, const uint64_t
     }
     cur_attr = __shfl(cur_attr, 0, PREP_LANES);
     #pragma unroll
-    for (uint32_t d = 1; d < PREP_LANES; d <<= 1) { hot_key = min(hot_key, (uint32_t)__shfl_xor((int)hot_key, d, PREP_LANES)); vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, d, PREP_LANES)); }
+    for (uint32_t d = 1; d < PREP_LANES; d <<= 1) {
+        const uint32_t o1 = (uint32_t)__shfl_xor((int)hot_key, d, PREP_LANES), o2 = (uint32_t)__shfl_xor((int)hot_key2, d, PREP_LANES);
+        hot_key2 = o1 == hot_key ? min(hot_key2, o2) : min(max(hot_key, o1), min(hot_key2, o2));   // (the two smallest DISTINCT idx of the group)
+        hot_key = min(hot_key, o1);
+        vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, d, PREP_LANES));
+    }
     // position sets are exact for this query iff no listed session at or above its cut holds one of its items without being in that item's list
     const uint32_t unsafe = vmax > xlo ? 1u : 0u;
-    if (okeys && sub == 0) okeys[q] = ((unsigned long long)min(hot_key, 0xFFFFu) << 32) | q;   // (16 key bits: beyond the 65 535 most popular items there is nothing to group -- two radix passes instead of three)
+#ifndef SRN_ORDER_KEY2
+#define SRN_ORDER_KEY2 0   // (experiment, round 6) 8 more key bits: the SECOND most popular item of the session, in buckets of 16 popularity ranks -- fast kernel 21.48 -> 21.39 ms,
+                           //  a third radix pass in exchange: nothing left of it in the step (profiles/r06_order_key2_ab.txt); off
+#endif
+    if (okeys && sub == 0) okeys[q] = SRN_ORDER_KEY2 ? ((unsigned long long)min(hot_key, 0xFFFFu) << 40) | ((unsigned long long)min(hot_key2 >> 4, 0xFFu) << 32) | q :
+                                      ((unsigned long long)min(hot_key, 0xFFFFu) << 32) | q;   // (16 key bits: beyond the 65 535 most popular items there is nothing to group -- two radix passes instead of three)
     uint32_t* hw = (uint32_t*)rec;   // PrepHead, word by word: U rmax xlo sumw | P nruns L n_staged | run_start[8] | cur_attr unsafe
     if (sub == 0) {   // (records are 8-byte aligned: 72 + 24 * max_len)
         *(uint2*)hw = make_uint2(U, rmax); *(uint2*)(hw + 2) = make_uint2(xlo, sumw); *(uint2*)(hw + 4) = make_uint2(P, nruns); *(uint2*)(hw + 6) = make_uint2(L, n_staged);
