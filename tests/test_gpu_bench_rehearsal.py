@@ -82,3 +82,15 @@ def test_default_bench_line_on_the_tiny_config_carries_every_block():
         assert e["parity_checked"] == 256 and e["mid_tier"]["queries_per_s"] > 0 and e["mid_tier"]["listed_for_mid_instantiation"] > 0
     assert ls[1]["without_mid_tier"]["listed_for_mid_instantiation"] == 0 and ls[1]["without_mid_tier"]["reached_general_kernel"] == ls[1]["batch"]
     assert len(line["latency"]["batch_sweep"]) >= 5 and line["latency"]["single_query_us_p50"] > 0
+
+
+def test_bench_line_through_the_avro_route():
+    """`bench.py --index avro:per-item --tie-per-second 8` (round 6): the same synthetic sessions through the reference's production route -- a stand-in producer writes the
+    Avro item / session index with its own order among equal timestamps, srn_index_new_from_avro loads it, the parity gate checks against the oracle's restatement of
+    VMISIndex::new -- on the tiny config, so that the path stays alive between rounds."""
+    line = _run(["--config", "tiny", "--batch", "16384", "--steps", "2", "--warmup", "1", "--no-sweep", "--no-cpu-baseline", "--no-measure-traffic", "--mode", "replicas",
+                 "--index", "avro:per-item", "--tie-per-second", "8", "--producer-max-len", "30"])
+    cfg = line["config"]
+    assert cfg["index"].startswith("avro") and cfg["avro"]["producer_tie_order"] == "per-item" and cfg["avro"]["tie_order_inference"] == "on"
+    assert cfg["avro"]["sessions_named_by_some_list"] < cfg["avro"]["sessions_in_the_session_index"]      # sessions beyond the producer's length cut are in no list
+    assert line["parity_checked"] > 0 and line["value"] > 0 and cfg["avro"]["share_on_the_fast_kernels"] > 0.95
