@@ -81,7 +81,29 @@ __device__ __forceinline__ void prep_group(const DeviceIndex& ix, const uint64_t
                 const uint32_t* __restrict__ lst = ix.post_rank + base;
                 uint32_t lo = 0, hi = len;   // first index whose entry is < x_lo
                 if (xlo == 0u || lst[len - 1] >= xlo) lo = len;   // (the usual case: the whole list is kept -- one look instead of ~11 dependent ones)
-                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (lst[mid] >= xlo) lo = mid + 1; else hi = mid; }
+                // (round 6) an 8-ary search: seven independent probes per step instead of one -- a list of 2 500 entries takes 4 dependent round trips instead of 12.  On the
+                // latency path (one session, this chain in front of everything) that is up to ~4 us of a call; the batch prep kernel does not notice either way
+                while (hi - lo > 8u) {
+                    const uint32_t w = hi - lo;
+                    uint32_t b[7], v[7];
+#pragma unroll
+                    for (uint32_t j = 0; j < 7u; ++j) { b[j] = lo + (uint32_t)(((unsigned long long)w * (j + 1u)) >> 3); v[j] = lst[b[j]]; }   // (lo < b[0] <= ... <= b[6] < hi)
+                    uint32_t c = 0;
+#pragma unroll
+                    for (uint32_t j = 0; j < 7u; ++j) c += v[j] >= xlo ? 1u : 0u;   // (descending list: the probes at or above x_lo are a prefix)
+                    uint32_t nlo = lo, nhi = hi;
+#pragma unroll
+                    for (uint32_t j = 0; j < 7u; ++j) { if (c == j + 1u) nlo = b[j] + 1u; if (c == j) nhi = b[j]; }
+                    lo = nlo; hi = nhi;
+                }
+                {   // <= 8 entries left: all at once
+                    uint32_t v[8], c = 0;
+#pragma unroll
+                    for (uint32_t j = 0; j < 8u; ++j) v[j] = lst[min(lo + j, len - 1u)];
+#pragma unroll
+                    for (uint32_t j = 0; j < 8u; ++j) c += lo + j < hi && v[j] >= xlo ? 1u : 0u;
+                    lo += c; hi = lo;
+                }
                 kept = lo;
             }
             if (rounds > 1) items[pos].kept = kept; else items[pos] = PrepItem{idx, len, pre, kept, base};
