@@ -648,6 +648,9 @@ static void form_park(ServeForm* f) {
     f->running = false; g_serve_running.fetch_sub(1);
     for (uint32_t i = 0; i < f->n; ++i) lane_unlock(f, i);
 }
+static std::atomic<int> g_serve_hold{0};   // > 0: some thread is inside a call that waits for the whole device (hipFree ...): no resident launch may start
+void serve_hold_begin() { g_serve_hold.fetch_add(1, std::memory_order_acq_rel); serve_quiesce_all(); }
+void serve_hold_end() { g_serve_hold.fetch_sub(1, std::memory_order_acq_rel); }
 void serve_quiesce_all() {
     if (g_serve_running.load(std::memory_order_acquire) == 0) return;
     std::lock_guard<std::mutex> lk(g_serve_mu);
@@ -655,6 +658,9 @@ void serve_quiesce_all() {
 }
 // (f->mu held, no lane held by this thread) start the resident launch
 static int form_launch(ServeState* s, ServeForm* f) {
+    // (a launch that starts now would be parked at once, or worse, waited for by the free in progress: the caller takes the launch path this time.  A hold that begins
+    //  right after this look parks what is started here: its quiesce takes f->mu, which the caller of this function holds)
+    if (g_serve_hold.load(std::memory_order_acquire) > 0) return SRN_ESTATE;
     if (f->running) {   // (workgroups that left by their idle timeout: the launch is over once all have)
         bool all_gone = true; for (uint32_t i = 0; i < f->n; ++i) all_gone = all_gone && __atomic_load_n(&f->ctl[i].alive, __ATOMIC_ACQUIRE) == 0u;
         if (!all_gone) { form_park(f); } else { HIP_TRY(hipSetDevice(f->d->device)); HIP_TRY(hipStreamSynchronize(f->st)); f->running = false; g_serve_running.fetch_sub(1); }
@@ -739,7 +745,7 @@ int device_serve_start(DeviceState* d, const FlatIndex& ix, uint32_t k, uint32_t
         fp.xchg = nullptr; fp.xchg_stride = 0; fp.q_base = 0; fp.order = nullptr; fp.mid_list = nullptr; fp.mid_cnt = nullptr; fp.bigq_list = nullptr; fp.bigq_cnt = nullptr; fp.long_list = nullptr; fp.long_cnt = nullptr;
         fp.tiny_len = 0; fp.host_seq = 0; fp.host_words = nullptr; fp.serve = f->ctl_dev;
     }
-    for (ServeForm* f : s->forms) { std::lock_guard<std::mutex> fl(f->mu); rc = form_launch(s, f); if (rc) return undo(rc, last_error_string()); }
+    for (ServeForm* f : s->forms) { std::lock_guard<std::mutex> fl(f->mu); rc = form_launch(s, f); if (rc && rc != SRN_ESTATE) return undo(rc, last_error_string()); }   // (SRN_ESTATE: another thread is freeing device memory right now -- the first call that wants the form starts it)
     d->serve.store(s);
     return SRN_OK;
 }
@@ -771,7 +777,7 @@ int device_serve_predict(DeviceState* d, const uint64_t* items, uint32_t len, ui
             std::lock_guard<std::mutex> fl(f->mu);
             if (f->dead.load()) { s->not_served.fetch_add(1); return 1; }   // (retired by srn_index_serve_stop in the meantime: never started again)
             bool gone = !f->running; for (uint32_t i = 0; i < f->n && !gone; ++i) gone = __atomic_load_n(&f->ctl[i].alive, __ATOMIC_ACQUIRE) == 0u;
-            if (gone && form_launch(s, f) != SRN_OK) { f->dead = true; s->not_served.fetch_add(1); return 1; }
+            if (gone) { const int lrc = form_launch(s, f); if (lrc != SRN_OK) { if (lrc != SRN_ESTATE) f->dead = true; s->not_served.fetch_add(1); return 1; } }
             continue;
         }
         uint32_t chk = 0; for (uint32_t i = 0; i < std::min<uint32_t>(len, 5u); ++i) chk ^= (uint32_t)items[i] ^ (uint32_t)(items[i] >> 32);
