@@ -167,8 +167,9 @@ int srn_predict(const srn_index_t* idx, const uint64_t* evolving, size_t len, si
                 size_t* out_n);
 /* ---- the persistent latency path (round 6) ------------------------------------------------------------------------------------------------------------
  * srn_predict is the reference's call shape (one evolving session per call: src/endpoints/recommend_resource.rs:56, src/bin/evaluator.rs:58).  On the one-launch form a
- * call costs ~28 us from a C++ host, of which ~13 us are the GPU's work; the rest is queue submission and completion signalling.  srn_index_serve_start parks `lanes`
- * RESIDENT workgroups on the index's GPU (one third of a CU each; with max_items_in_session > 4 as many again of the form that serves sessions of 5..10 items): a call of
+ * call costs ~28 us from a C++ host, of which ~18 us are the GPU's work; the rest is queue submission and completion signalling.  srn_index_serve_start parks `lanes`
+ * (<= 256) RESIDENT workgroups on the index's GPU (a CU each, ONE launch on a stream of the lowest priority; with max_items_in_session > 4 a second launch of as many
+ * workgroups of the form that serves sessions of 5..10 items; sessions of more items always take the launch path): a call of
  * srn_predict with the same k / m / how_many / business-logic flag then posts its session to a free one through pinned memory and spins on the answer -- no launch.
  * A session the resident form cannot finish (0.3-3 % of config 3's: merged lists beyond its layout, > 63 scored candidates of a small query), a call with other
  * parameters, and a call that finds every resident workgroup taken run exactly as without this: the rows are the same bytes either way.
@@ -176,7 +177,9 @@ int srn_predict(const srn_index_t* idx, const uint64_t* evolving, size_t len, si
  *   Anything in this library that frees device memory or synchronises the device makes the resident workgroups leave first (they come back on demand): allocate and
  *   reserve (srn_index_reserve) BEFORE serving.  APPLICATION code that calls hipFree / hipDeviceSynchronize on this device while workgroups are resident waits until they
  *   leave (idle_ms at most): call srn_index_serve_stop first.
- * srn_index_serve_stats: sessions answered by a resident workgroup | sent to the launch path | kernel launches so far (1 per lane + restarts) | resident workgroups. */
+ *   Measured on config 3 (C++ host, profiles/r06_latency_resident_cfg3.json): p50 / p90 22.6 / 27.4 us against 27.8 / 32.7 on the launch path; 16 callers on 16 resident
+ *   workgroups 23.7 / 30.0 us and 655 K requests/s against 62.8 / 86.6 us and 246 K.  srn_index_serve_stop may be called while other threads are inside srn_predict.
+ * srn_index_serve_stats: sessions answered by a resident workgroup | sent to the launch path | kernel launches so far (1 per form + restarts) | resident workgroups. */
 int srn_index_serve_start(srn_index_t* idx, size_t k, size_t m, size_t how_many, int enable_business_logic, unsigned lanes, unsigned max_items_in_session, unsigned idle_ms);
 int srn_index_serve_stop(srn_index_t* idx);
 int srn_index_serve_stats(const srn_index_t* idx, uint64_t* out_served, uint64_t* out_not_served, uint64_t* out_launches, uint32_t* out_lanes);
