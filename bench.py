@@ -766,7 +766,7 @@ def main():
                     import subprocess as _sp
                     from serenade_amd import build as _bld
                     exe_rf = _bld.ROW_FETCH_BENCH
-                    if os.path.exists(exe_rf):
+                    if os.path.exists(exe_rf) and args.measure_traffic:   # (not in the counter passes' child runs of this script)
                         torch.cuda.synchronize()
                         out_rf = _sp.run([exe_rf], capture_output=True, text=True, timeout=120).stdout
                         ceil = {}
