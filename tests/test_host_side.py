@@ -362,3 +362,22 @@ def test_trait_accessors_items_for_session_and_find_attributes():
     assert ix.idf(it) == pytest.approx(np.log(total_pairs / n_with), rel=1e-15)             # vmis_index.rs:509-512
     with pytest.raises(KeyError):
         ix.idf(2 ** 61 + 5)
+
+
+def test_the_default_library_can_only_be_the_default_build(monkeypatch):
+    """SRN_CFLAGS used to rebuild libserenade_hip.so IN PLACE -- the file that ships to the GPU box -- and the kernels keep "timing only, wrong
+    results" macros.  build_hip() now refuses experiment flags outright and any other SRN_CFLAGS unless SRN_CFLAGS_INPLACE=1; variants go to serenade_amd/variants/."""
+    from serenade_amd import build as B
+    monkeypatch.setenv("SRN_CFLAGS", "-DSRN_FAST_EXP_ONELIST=1")
+    with pytest.raises(RuntimeError, match="experiment-only"):
+        B.build_hip()
+    monkeypatch.setenv("SRN_CFLAGS", "-DSRN_FAST_STOP=3")
+    monkeypatch.setenv("SRN_CFLAGS_INPLACE", "1")          # (not even then)
+    with pytest.raises(RuntimeError, match="experiment-only"):
+        B.build_hip()
+    monkeypatch.delenv("SRN_CFLAGS_INPLACE")
+    monkeypatch.setenv("SRN_CFLAGS", "-DSRN_MERGE_G=12")
+    with pytest.raises(RuntimeError, match="in place"):
+        B.build_hip()
+    monkeypatch.delenv("SRN_CFLAGS")
+    assert B.build_hip() == B.LIB                             # the default build: up to date, nothing to do
