@@ -1013,9 +1013,10 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
         const uint32_t grid_fo = fp.order ? std::max<uint32_t>(8u, grid_f / 8u * 8u) : grid_f;   // (an ordered launch walks an eighth of the order per XCD: the grid is a multiple of 8)
         if (back && d->sback.frag8 && !kn.no_sback && p.max_len <= 8) {
             // the item shard's own back end (srn_sback.hip): one wave per query, 12 per CU; a persistent grid of a few waves per resident slot
-            SBackParams sbp = d->sback; if (!kn.sback_bitmap) sbp.present = nullptr;
+            const bool small = (uint64_t)d->di.n_kept + 1u < (1ull << 29);   // (the kernel's presence forms address the fragments through a 32-bit buffer descriptor)
+            SBackParams sbp = d->sback; if (!kn.sback_bitmap || !small) sbp.present = nullptr;
             sbp.finish_here = kn.no_sback_finish ? 0u : 1u;
-            sbp.pbyte_shift = ext->pbytes ? (uint32_t)ix.shard : 8u;
+            sbp.pbyte_shift = ext->pbytes && small ? (uint32_t)ix.shard : 8u;   // (not small: the bytes are in the records, this shard fetches every fragment all the same)
             // the streaming form where the shard holds its fragments in the posting order of the very lists the records were written against (9 waves per CU: 16.8 KB each)
             const bool stream = ext->positions;
             if (stream && !(d->sb_frag_post && d->sb_post_for == ext->post_rank)) return fail(SRN_ESTATE, "the batch's neighbours came as posting positions, but this shard does not hold its fragments in posting order");

@@ -57,9 +57,12 @@ __device__ __forceinline__ uint32_t sb_offset_of(uint32_t idx, uint64_t r) {
     if (idx < SB_REP_ITEMS) return (SB_DIRECT + idx * SB_REP + ((uint32_t)r & (SB_REP - 1u))) * 4u;
     return idx < SB_DIRECT ? idx * 4u : (SB_H + (idx & (SB_S - 1u))) * 4u;
 }
-__device__ __forceinline__ uint32_t sb_phantom(uint64_t r, uint32_t j) {
-    return (SB_H + SB_S + ((((uint32_t)r * 0x9E3779B1u + j * 0x85EBCA6Bu) >> 23) & (SB_DUMP - 1u))) * 4u;
-}
+// Unused positions of a fragment / an overflow block point BEYOND the wave's LDS allocation (round 6; until then: into a dump area of 64 words): a DS access out of the
+// workgroup's range is dropped by the hardware before it costs a bank cycle -- adds vanish, reads return 0 (tools/lds_oor_bench.hip; the fast kernel's phantom rows, DESIGN
+// section 4.5) -- so the walks add and read all four positions of every fragment WITHOUT a branch, and the 60 % of them that name no item collide with nobody.
+static constexpr uint32_t SB_OOR = 0xC000u;   // (byte offset from the accumulators' base; the wave's whole allocation is 12 KB)
+static_assert(SB_OOR >= 4u * SB_LDS && SB_OOR < 0xFFFFu && SB_OOR >= (SB_H + SB_S) * 4u, "out of the allocation whatever its granule, and not the long-fragment marker");
+__device__ __forceinline__ uint32_t sb_phantom(uint64_t, uint32_t) { return SB_OOR; }
 __global__ __launch_bounds__(1024) void rows_to_frag8_kernel(const uint64_t* __restrict__ row_off, const uint32_t* __restrict__ row_items, uint64_t n,
                                                              const uint32_t* __restrict__ block_base, uint2* __restrict__ frag8, uint4* __restrict__ ext8, uint32_t* __restrict__ present) {
     __shared__ uint32_t wave_tot[16];
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
     const __attribute__((address_space(4))) FastParams& f = *(const __attribute__((address_space(4))) FastParams*)(ka + OFF_F);
     const __attribute__((address_space(4))) SBackParams& sb = *(const __attribute__((address_space(4))) SBackParams*)(ka + OFF_S);
     const uint32_t lane = threadIdx.x;
-    const unsigned long long lt = (1ull << lane) - 1ull;
+    auto below = [](unsigned long long bm) -> uint32_t { return __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u)); };   // set bits of bm below this lane (v_mbcnt: no mask register to keep)
     uint16_t* wtab = (uint16_t*)(smem + SB_WTAB);
     unsigned long long* ckey = (unsigned long long*)(smem + SB_CAND);
     uint32_t* cidx = (uint32_t*)(smem + SB_CAND + SB_CAND_CAP * 8);
@@ -162,16 +165,18 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
     const bool wide = f.nb == 3u;
     const uint32_t n_kept = ix.n_kept;
     constexpr uint32_t NCH = F_K_MAX / 64u;   // 24 chunks of 64 neighbours
-
-    // the wave's sample constants: items 4 lane .. 4 lane + 3 of the shard's popularity order (loop-invariant: in registers for the wave's whole life)
-    double s_idf[4]; uint32_t s_attr = 0, s_rank[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { const ItemMeta m0 = sb.sample[4u * lane + (uint32_t)j]; s_idf[j] = m0.idf > 0.0 ? m0.idf : 1.0; s_attr |= (m0.attr & 0xFFu) << (8 * j); s_rank[j] = m0.id_rank; }
+    const __amdgpu_buffer_rsrc_t frag_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)sb.frag8, 0, (int)((n_kept + 1u) * 8u), 0x00020000);   // (the forms that know which neighbours are absent; the host admits them only below 2^29 sessions)
 
     // per-phase shader cycles (debug, srn_debug_phase_cycles): summed in registers by the wave, flushed once at the end.  Slots follow the fast kernel's numbering:
     // 8 record + clears, 9 walk A, 10 sample + floors, 11 sketch check, 12 walk B + resolve, 13 hand-off; 5 listed elements, 6 candidates, 7 live queries, 14 served, 15 handed over by cause (20-bit fields: candidates | long-fragment queues | hit list; exact table: upper half of 7)
     const bool ticking = p.phase_cycles != nullptr;
     unsigned long long tk8 = 0, tk9 = 0, tk10 = 0, tk11 = 0, tk12 = 0, tk13 = 0, c5 = 0, c6 = 0, c7 = 0, c14 = 0, c15 = 0;
+#ifdef SRN_SBACK_SUBTICKS
+    unsigned long long tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0;
+#define SB_SUBTICK(acc) SB_TICK(acc)
+#else
+#define SB_SUBTICK(acc) do {} while (0)
+#endif
 #define SB_TICK(acc) do { if (ticking) { const long long t_ = clock64(); acc += (unsigned long long)(t_ - t_prev); t_prev = t_; } } while (0)
     // the serving order (f.order, see vmis_fast_kernel): the batch sorted by each query's most popular item, dealt to the XCDs chunk by chunk (the grid is a multiple of 8)
     const bool ordered = f.order != nullptr;
@@ -186,20 +191,16 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
         struct { uint32_t U, xlo, L, cur_attr; } h0;   // (uniform addresses: scalar loads)
         { const PrepHead* hp = (const PrepHead*)rec; h0.U = hp->U; h0.xlo = hp->xlo; h0.L = hp->L; h0.cur_attr = hp->cur_attr; }
         uint32_t it_idx = kNone, it_kept = 0u; unsigned long long it_base = 0ull;
-        if (lane < 8u && lane < h0.L && lane < p.max_len) { const PrepItem pi = ((const PrepItem*)(rec + sizeof(PrepHead)))[lane]; it_idx = pi.idx; it_kept = pi.kept; it_base = pi.base; }
+        if (lane < 8u && lane < p.max_len) { const PrepItem pi = ((const PrepItem*)(rec + sizeof(PrepHead)))[lane]; it_idx = pi.idx; it_kept = pi.kept; it_base = pi.base; }   // (all the record's places, with the head: asked for behind L they were a dependent trip of their own)
+        if (lane >= h0.L) { it_idx = kNone; it_kept = 0u; it_base = 0ull; }   // (places past L hold an earlier batch's items)
         const uint32_t kv = xq[0];
+        uint32_t ln = lane; asm volatile("" : "+v"(ln));   // (the lane number as the optimiser cannot see through it: the 24 clamped slot offsets below are loop-invariant, and hoisted out of the query loop they were spilled -- each reload a s_waitcnt vmcnt(0) between two of the slot loads)
         uint32_t sv[NCH];   // gather form: the neighbour slots; streaming form: the members' {position | run << 20 | weight << 24}, read back from the scratch after walk A
         if constexpr (!STREAM) {
 #pragma unroll
-            for (uint32_t c = 0; c < NCH; ++c) sv[c] = SB_NT_LOAD(&xq[1u + min(c * 64u + lane, f.xchg_stride - 2u)]);   // (read once: 5.4 KB per query that need not stay in the L2 the fragments want)
+            for (uint32_t c = 0; c < NCH; ++c) sv[c] = SB_NT_LOAD(&xq[1u + min(c * 64u + ln, f.xchg_stride - 2u)]);   // (read once: 5.4 KB per query that need not stay in the L2 the fragments want)
         }
-        const uint32_t K = (uint32_t)__builtin_amdgcn_readfirstlane((int)kv);
         const uint32_t L = h0.L, U = h0.U, cur_attr = h0.cur_attr;
-        if (K == 0xFFFFFFFFu || L < 1u || L > 8u || L > p.max_len || K > F_K_MAX) {   // (wave-uniform) no front end took it, or not this kernel's shape: the general kernel does its candidate work itself
-            if (lane == 0u) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q;
-            continue;
-        }
-        if (K == 0u) { if (lane == 0u) p.out_counts[q] = 0u; continue; }
         unsigned long long rm = __ballot(it_kept > 0u);
         const uint32_t nr = (uint32_t)__popcll(rm);
         const bool rel = wide && nr > 3u;
@@ -218,9 +219,18 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
         }
         {   // clear: accumulators + sketch + dump (the exact table is cleared after walk A: its words hold the long fragments' queue until then)
             uint4* z = reinterpret_cast<uint4*>(smem + HOT_OFF);
-            for (uint32_t i = lane; i < (SB_H + SB_S + SB_DUMP) / 4u; i += 64u) z[i] = make_uint4(0u, 0u, 0u, 0u);
+            uint32_t z0 = 0u; asm volatile("" : "+v"(z0));   // (a zero the optimiser cannot see through: the constant quad was hoisted out of the query loop into four registers for the wave's life -- and spilled)
+            for (uint32_t i = lane; i < (SB_H + SB_S + SB_DUMP) / 4u; i += 64u) z[i] = make_uint4(z0, z0, z0, z0);
         }
         SB_SYNC();   // (one wave: orders the LDS traffic; no other wave to wait for)
+        // (K is looked at only HERE, behind the barrier's wait for everything in flight: tested right after its load, the compiler sinks the 24 slot loads below the two
+        // early exits, i.e. issues them when K has arrived -- a second dependent round trip per query)
+        const uint32_t K = (uint32_t)__builtin_amdgcn_readfirstlane((int)kv);
+        if (K == 0xFFFFFFFFu || L < 1u || L > 8u || L > p.max_len || K > F_K_MAX) {   // (wave-uniform) no front end took it, or not this kernel's shape: the general kernel does its candidate work itself
+            if (lane == 0u) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q;
+            continue;
+        }
+        if (K == 0u) { if (lane == 0u) p.out_counts[q] = 0u; continue; }
         SB_TICK(tk8);
         // ---- walk A: ALL of a lane's <= 24 presence words in flight together, then all fragments of the present ones: a query's walk is three HBM / L2 round trips (slots,
         // presence, fragments) whatever K is.  A first build walked in two halves with the long fragments' overflow blocks fetched inline: 30 dependent round trips per query on
@@ -274,7 +284,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                         const bool in = j0 + u * 64u < kept;   // (wave-uniform)
                         const unsigned long long mk0 = bm64[min((j0 >> 6) + u, mw - 1u)], mk = in ? mk0 : 0ull;
                         const bool mem = (mk >> lane) & 1ull;
-                        const uint32_t idx = nmem + (uint32_t)__popcll(mk & lt);
+                        const uint32_t idx = nmem + below(mk);
                         nmem += (uint32_t)__popcll(mk);
                         const uint32_t w0 = (uint32_t)lw8[min(idx, F_K_MAX - 1u)], w = mem ? w0 : 0u;
                         const uint32_t o0 = fg[u].x & 0xFFFFu;
@@ -283,7 +293,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                         const bool ac = pr && !lng;                                // (long fragments: from the scratch, below)
                         add2(ac ? fg[u].x : dump2, w); add2(ac ? fg[u].y : dump2, w);
                         const unsigned long long bm = __ballot(pr);
-                        const uint32_t at = pr ? min(nscr + (uint32_t)__popcll(bm & lt), F_K_MAX + 63u) : F_K_MAX + 64u + lane;   // (non-members: a trash place)
+                        const uint32_t at = pr ? min(nscr + below(bm), F_K_MAX + 63u) : F_K_MAX + 64u + lane;   // (non-members: a trash place)
                         scr_w[at] = (j0 + u * 64u + lane) | (r << 20) | (w << 24); scr_f[at] = fg[u];
                         nscr += (uint32_t)__popcll(bm);
                     }
@@ -305,7 +315,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                     const bool lng = pr && (fr[c].x & 0xFFFFu) == 0xFFFFu;
                     const unsigned long long lbm = __ballot(lng);
                     if (lbm) {
-                        const uint32_t at = nlq + (uint32_t)__popcll(lbm & lt);
+                        const uint32_t at = nlq + below(lbm);
                         if (lng && at < SB_LQ_CAP) lq[at] = make_uint2(((sv[c] >> 24) << 16) | (fr[c].x >> 16), fr[c].y);
                         nlq += (uint32_t)__popcll(lbm);
                     }
@@ -317,7 +327,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
 #pragma unroll
             for (uint32_t c = 0; c < NCH; ++c) {
                 pwv[c] = 0u;
-                if (c * 64u < K) {   // (wave-uniform)
+                if ((c & ~3u) * 64u < K) {   // (wave-uniform, per GROUP of four chunks: a branch per chunk ends the scheduler's region there, and every chunk's loads and LDS reads are then waited for inside their own block; the lanes past K behave as absent neighbours)
                     const bool act = c * 64u + lane < K;
                     const uint32_t r = act ? base + (sv[c] >> NB) : n_kept;   // (idle lanes: the empty row, whose presence bit is 0)
                     if constexpr (BITMAP) pwv[c] = sb.present[r >> 5] >> (r & 31u);
@@ -332,22 +342,52 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
 #pragma unroll
             for (uint32_t c = 0; c < NCH; ++c) {
                 fr[c] = make_uint2(0u, 0u);
-                if (c * 64u < K) fr[c] = sb.frag8[(pm >> c) & 1u ? base + (sv[c] >> NB) : n_kept];   // (unconditional per lane: a load inside a divergent branch is waited for at the branch's end; the absent lanes all read the empty row's slot -- one line)
+                if ((c & ~3u) * 64u < K) {
+                    if constexpr (BITMAP || PBYTES) {   // (round 6) the absent lanes ask for NOTHING: a buffer load past the descriptor's range is answered with 0 by the address unit, no request leaves it
+                        typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+                        const v2u v = __builtin_amdgcn_raw_buffer_load_b64(frag_rsrc, (pm >> c) & 1u ? (base + (sv[c] >> NB)) * 8u : 0xFFFFFFF8u, 0, 0);
+                        fr[c] = make_uint2(v.x, v.y);
+                    } else fr[c] = sb.frag8[(pm >> c) & 1u ? base + (sv[c] >> NB) : n_kept];   // (unconditional per lane: a load inside a divergent branch is waited for at the branch's end; the lanes past K all read the empty row's slot -- one line)
+                }
             }
+            // the neighbours' weights, a byte each (<= 9 * 26), looked up while the fragments travel: the adds below then depend on no LDS read of their own
+            uint32_t wq[NCH / 4u];
+#pragma unroll
+            for (uint32_t c = 0; c < NCH; c += 4u) wq[c >> 2] = 0u;
+#pragma unroll
+            for (uint32_t c = 0; c < NCH; ++c) wq[c >> 2] |= (uint32_t)wtab[sv[c] & NBM] << (8u * (c & 3u));   // (all 24, whatever K: one batch of LDS reads)
+            // STRAIGHT-LINE adds (round 6): all four positions of every fragment, whoever holds it -- unused positions, the absent lanes' empty row and the lanes past K
+            // point out of the allocation (SB_OOR: dropped by the hardware), a long fragment's words are replaced by such.  With a branch per chunk (and the weight's
+            // LDS read in front of its adds) the chunks ran one after the other, each behind its own s_waitcnt.
+#ifdef SRN_SBACK_SUBTICKS
+            if (ticking) __builtin_amdgcn_s_waitcnt(0);
+            SB_SUBTICK(tk3);
+#endif
+            uint32_t lngm = 0u;   // bit c: this lane's fragment of chunk c is a long one (> 4 items: queued below)
 #pragma unroll
             for (uint32_t c = 0; c < NCH; ++c) {
-                if (c * 64u < K) {
+                if ((c & ~3u) * 64u < K) {
                     const uint32_t o0 = fr[c].x & 0xFFFFu;
-                    const bool lng = ((pm >> c) & 1u) && o0 == 0xFFFFu;
-                    const bool pr = ((pm >> c) & 1u) && (lng || o0 < (SB_H + SB_S) * 4u);   // (a fragment's items fill its positions from the first: a dump offset there = an empty fragment)
-                    if (!BITMAP && !pr) pm &= ~(1u << c);                                   // (walk B skips it too)
-                    const uint32_t w = (uint32_t)wtab[sv[c] & NBM];
-                    if (pr && !lng) { add2(fr[c].x, w); add2(fr[c].y, w); }
-                    const unsigned long long lb = __ballot(lng);
-                    if (lb) {   // a fragment of > 4 items (rare from G = 8 on): queued -- {weight | length, first overflow block} --, all the queue's blocks are fetched together below
-                        const uint32_t at = nlq + (uint32_t)__popcll(lb & lt);
-                        if (lng && at < SB_LQ_CAP) lq[at] = make_uint2((w << 16) | (fr[c].x >> 16), fr[c].y);
-                        nlq += (uint32_t)__popcll(lb);
+                    const bool here = (BITMAP || PBYTES) ? ((pm >> c) & 1u) != 0u : true;   // (those forms' absent lanes hold zeros)
+                    const bool lng = here && o0 == 0xFFFFu;   // (never the empty row's slot)
+                    const bool pr = here && (lng || o0 < (SB_H + SB_S) * 4u);   // (a fragment's items fill its positions from the first: an out-of-range offset there = an empty fragment)
+                    pm = pr ? pm : pm & ~(1u << c);                  // (walk B skips it too)
+                    lngm |= lng ? 1u << c : 0u;
+                    const uint32_t w = (wq[c >> 2] >> (8u * (c & 3u))) & 0xFFu;
+                    add2(lng || !here ? SB_OOR * 0x10001u : fr[c].x, w); add2(lng || !here ? SB_OOR * 0x10001u : fr[c].y, w);
+                }
+            }
+            if (__ballot(lngm != 0u) != 0ull) {   // fragments of > 4 items (rare from G = 8 on): queued -- {weight | length, first overflow block} --, all the queue's blocks are fetched together below
+#pragma unroll
+                for (uint32_t c = 0; c < NCH; ++c) {
+                    if (c * 64u < K) {
+                        const bool lng = (lngm >> c) & 1u;
+                        const unsigned long long lb = __ballot(lng);
+                        if (lb) {
+                            const uint32_t at = nlq + below(lb);
+                            if (lng && at < SB_LQ_CAP) lq[at] = make_uint2((((wq[c >> 2] >> (8u * (c & 3u))) & 0xFFu) << 16) | (fr[c].x >> 16), fr[c].y);
+                            nlq += (uint32_t)__popcll(lb);
+                        }
                     }
                 }
             }
@@ -370,12 +410,19 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
             }
         }
         SB_SYNC();
-        {   // the exact table (keys EMPTY32, sums 0) and the counters
-            reinterpret_cast<uint4*>(ikeys)[lane] = make_uint4(EMPTY32, EMPTY32, EMPTY32, EMPTY32);
-            reinterpret_cast<uint4*>(iacc)[lane] = make_uint4(0u, 0u, 0u, 0u);
-        }
         SB_TICK(tk9);
         // ---- harvest: the sample (this shard's 256 most popular items, four per lane), exactly -> threshold, candidates ----
+        // (the sample's constants -- items 4 lane .. 4 lane + 3 of the shard's popularity order: 4 KB that every wave of the chip reads, L1-resident -- are fetched per query:
+        // kept in 13 registers for the wave's life they were spilled, and each of the four reloads from scratch was waited for on its own)
+        double s_idf[4]; uint32_t s_attr = 0, s_rank[4];
+        uint32_t ls = lane; asm volatile("" : "+v"(ls));
+        {
+            ItemMeta m0[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m0[j] = sb.sample[4u * ls + (uint32_t)j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s_idf[j] = m0[j].idf > 0.0 ? m0[j].idf : 1.0; s_attr |= (m0[j].attr & 0xFFu) << (8 * j); s_rank[j] = m0[j].id_rank; }
+        }
         uint32_t v4[4];
         { const uint4 a = reinterpret_cast<const uint4*>(hot)[lane]; v4[0] = a.x; v4[1] = a.y; v4[2] = a.z; v4[3] = a.w; }
         if (lane < SB_REP_ITEMS / 4u) {   // replicated items: the sum is spread over SB_REP words (the item's own word stays 0)
@@ -387,7 +434,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
         double x4[4]; uint32_t k4[4];
 #pragma unroll
         for (uint32_t j = 0; j < 4u; ++j) {
-            const uint32_t e = 4u * lane + j;
+            const uint32_t e = 4u * ls + j;
             bool valid = v4[j] != 0u && e != cur_idx && e < ix.n_items;
             if (business) valid = valid && business_ok(cur_attr, (s_attr >> (8u * j)) & 0xFFu);   // an item the rules exclude is no candidate and sets no threshold
             x4[j] = valid ? s_idf[j] * (double)v4[j] : 0.0;
@@ -401,6 +448,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
             const uint32_t cnt = (uint32_t)__popcll(__ballot(k4[0] >= c)) + (uint32_t)__popcll(__ballot(k4[1] >= c)) + (uint32_t)__popcll(__ballot(k4[2] >= c)) + (uint32_t)__popcll(__ballot(k4[3] >= c));
             t32 = cnt >= p.how_many ? c : t32;
         }
+        SB_SUBTICK(tk4);
         // everything is kept down to one step BELOW it, so that what is dropped is strictly smaller after the division by 10 U as well (ties at the cut included)
         const uint32_t t32m1 = t32 ? t32 - 1u : 0u;
         uint32_t ncand = 0;   // (wave-uniform)
@@ -409,7 +457,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
             const bool take = x4[j] != 0.0 && k4[j] >= t32m1;
             const unsigned long long bm = __ballot(take);
             if (bm) {
-                const uint32_t at = ncand + (uint32_t)__popcll(bm & lt);
+                const uint32_t at = ncand + below(bm);
                 if (take) { if (at < SB_CAND_CAP) { ckey[at] = (unsigned long long)__double_as_longlong(x4[j]); cidx[at] = s_rank[j]; } }
                 ncand += (uint32_t)__popcll(bm);
             }
@@ -418,8 +466,15 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
         const double x_lo = __longlong_as_double((long long)((unsigned long long)t32m1 << 32));
         auto floor_of = [&](double inv) -> uint32_t { return (uint32_t)fmin(4.0e9, fmax(1.0, floor(x_lo * inv * (1.0 - 1e-9)) - 1.0)); };
         const uint32_t floor_b = floor_of(sb.inv_idf_all);
+        // the other direct-mapped words: a quad per lane and chunk, the chunk's floor wave-uniform.  What reaches its floor is LISTED first -- {entry, sum} in the exact table's
+        // room, which walk B initialises when it runs -- and the listed entries' idf / attributes / id ranks are then fetched TOGETHER: one round trip per 64 of them
+        // (round 6; until then one per (chunk, position) with an entry at the floor, each waited for: ~5 dependent trips per query, the bulk of this phase's 17 K cycles)
+        uint32_t lf = lane; asm volatile("" : "+v"(lf));   // (as `ln` above: the twelve entry numbers below are loop-invariant -- hoisted, they were spilled and reloaded one by one)
+        uint2* const plist = reinterpret_cast<uint2*>(smem + SB_TABLE);
+        constexpr uint32_t PLIST_CAP = SB_TABLE_WORDS;   // (8 bytes per entry in the table's 2 KB)
+        uint32_t npass = 0u;   // (wave-uniform)
 #pragma unroll
-        for (uint32_t ch = 1; ch < SB_H / 256u; ++ch) {   // the other direct-mapped words: a quad per lane and chunk, the chunk's floor wave-uniform
+        for (uint32_t ch = 1; ch < SB_H / 256u; ++ch) {
             const uint32_t fl = floor_of(sb.inv_idf_chunk[ch]);
             const uint4 q4 = reinterpret_cast<const uint4*>(hot)[ch * 64u + lane];
             const uint32_t mx = max(max(q4.x, q4.y), max(q4.z, q4.w));
@@ -427,19 +482,29 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
             const uint32_t vv[4] = {q4.x, q4.y, q4.z, q4.w};
 #pragma unroll
             for (uint32_t j = 0; j < 4u; ++j) {
-                const uint32_t e = ch * 256u + 4u * lane + j;
+                const uint32_t e = ch * 256u + 4u * lf + j;
                 const bool pass = vv[j] >= fl && e != cur_idx && e < SB_DIRECT;   // (the words from SB_DIRECT up are the replicas of the hottest items, already in the sample)
-                if (__ballot(pass) == 0ull) continue;
-                ItemMeta mt = ItemMeta{0.0, 0u, 0u};
-                if (pass) mt = ix.meta[e];
-                const double x = (mt.idf > 0.0 ? mt.idf : 1.0) * (double)vv[j];
-                const bool take = pass && (uint32_t)((unsigned long long)__double_as_longlong(x) >> 32) >= t32m1 && (!business || business_ok(cur_attr, mt.attr));
-                const unsigned long long bm = __ballot(take);
+                const unsigned long long bm = __ballot(pass);
                 if (bm) {
-                    const uint32_t at = ncand + (uint32_t)__popcll(bm & lt);
-                    if (take && at < SB_CAND_CAP) { ckey[at] = (unsigned long long)__double_as_longlong(x); cidx[at] = mt.id_rank; }
-                    ncand += (uint32_t)__popcll(bm);
+                    const uint32_t at = npass + below(bm);
+                    if (pass && at < PLIST_CAP) plist[at] = make_uint2(e, vv[j]);
+                    npass += (uint32_t)__popcll(bm);
                 }
+            }
+        }
+        if (npass > PLIST_CAP) { fail = true; c15 += 1ull; npass = 0u; }   // (more entries at their floors than candidates the record could hold)
+        for (uint32_t i0 = 0; i0 < npass; i0 += 64u) {
+            const bool act = i0 + lane < npass;
+            const uint2 pe = plist[min(i0 + lane, npass - 1u)];
+            ItemMeta mt = ItemMeta{0.0, 0u, 0u};
+            if (act) mt = ix.meta[pe.x];
+            const double x = (mt.idf > 0.0 ? mt.idf : 1.0) * (double)pe.y;
+            const bool take = act && (uint32_t)((unsigned long long)__double_as_longlong(x) >> 32) >= t32m1 && (!business || business_ok(cur_attr, mt.attr));
+            const unsigned long long bm = __ballot(take);
+            if (bm) {
+                const uint32_t at = ncand + below(bm);
+                if (take && at < SB_CAND_CAP) { ckey[at] = (unsigned long long)__double_as_longlong(x); cidx[at] = mt.id_rank; }
+                ncand += (uint32_t)__popcll(bm);
             }
         }
         if (ncand > SB_CAND_CAP) { fail = true; c15 += 1ull; }
@@ -459,10 +524,13 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
             c7 += 1ull;
             // ---- walk B: the rows again (from the registers); an element is LISTED if its sketch word can still reach the floor (all elements of an item share the word, so an item
             // is accumulated completely or not at all); then the list is resolved -- item id from the general fragment slots -- into the exact table ----
+            uint32_t e0 = EMPTY32, z0 = 0u; asm volatile("" : "+v"(e0), "+v"(z0));   // (see the clears: no constant quads kept across queries)
+            reinterpret_cast<uint4*>(ikeys)[lane] = make_uint4(e0, e0, e0, e0);   // the exact table (keys EMPTY32, sums 0); its room held the floors' list until here
+            reinterpret_cast<uint4*>(iacc)[lane] = make_uint4(z0, z0, z0, z0);
             SB_SYNC();   // (the direct-mapped words are dead: the hit list takes them)
             uint32_t nh = 0;   // (wave-uniform)
             auto chk = [&](uint32_t o) -> bool { return o >= SB_H * 4u && *(const uint32_t*)(acc_base + o) >= floor_b; };
-            auto list = [&](uint32_t hm, uint32_t s, uint32_t j0) {   // hm: bit i = position j0 + i of the fragment is a hit
+            auto list = [&](uint32_t hm, uint32_t s, uint32_t j0) {   // hm: bit i = position j0 + i of the fragment is a hit (the long fragments' blocks)
                 const uint32_t c = (uint32_t)__popc(hm);
                 if (__ballot(c != 0u) == 0ull) return;
                 const uint32_t inc = wave_incl_scan(c);
@@ -471,22 +539,55 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                 nh += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
             };
             uint32_t nlb = 0u;   // (wave-uniform) long fragments queued for the second step
-            {   // (the fragments are walk A's, still in registers)
+            {   // (the fragments are walk A's, still in registers.)  Round 6: every position's word is read WITHOUT a branch -- absent lanes hold the empty row's slot, unused
+                // positions point out of the allocation and read 0 -- and a lane's hits are kept as four bits per chunk; ONE scan then places all of them.  Until then a
+                // chunk was four predicated reads, each waited for, a ballot and a scan of its own: 22 dependent chains of ~600 cycles per query.
+                const uint32_t lim = STREAM ? nscr : K;
+                uint32_t hmw[NCH / 8u];
+#pragma unroll
+                for (uint32_t c = 0; c < NCH; c += 8u) hmw[c >> 3] = 0u;
+                uint32_t lngm = 0u;
+                auto at_floor = [&](uint32_t o) -> uint32_t { return ((o >= SB_H * 4u) & (*(const uint32_t*)(acc_base + o) >= floor_b)) ? 1u : 0u; };
 #pragma unroll
                 for (uint32_t c = 0; c < NCH; ++c) {
-                    if (c * 64u >= (STREAM ? nscr : K)) continue;   // (wave-uniform)
+                    if ((c & ~3u) * 64u >= lim) continue;   // (wave-uniform, per group of four chunks)
                     const bool pr = (pm >> c) & 1u, lng = pr && (fr[c].x & 0xFFFFu) == 0xFFFFu;
-                    uint32_t hm = 0;
-                    if (pr && !lng) hm = (chk(fr[c].x & 0xFFFFu) ? 1u : 0u) | (chk(fr[c].x >> 16) ? 2u : 0u) | (chk(fr[c].y & 0xFFFFu) ? 4u : 0u) | (chk(fr[c].y >> 16) ? 8u : 0u);
-                    list(hm, sv[c], 0u);
-                    const unsigned long long lb = __ballot(lng);
-                    if (lb) {
-                        const uint32_t at = nlb + (uint32_t)__popcll(lb & lt);
-                        if (lng && at < SB_LQB_CAP) { lqb[at] = make_uint2(sv[c], fr[c].y); lqb_len[at] = fr[c].x >> 16; }
-                        nlb += (uint32_t)__popcll(lb);
+                    const uint32_t fx = pr && !lng ? fr[c].x : SB_OOR * 0x10001u, fy = pr && !lng ? fr[c].y : SB_OOR * 0x10001u;
+                    const uint32_t hm = at_floor(fx & 0xFFFFu) | (at_floor(fx >> 16) << 1) | (at_floor(fy & 0xFFFFu) << 2) | (at_floor(fy >> 16) << 3);
+                    hmw[c >> 3] |= hm << (4u * (c & 7u));
+                    lngm |= lng ? 1u << c : 0u;
+                }
+                uint32_t cnt = 0u;
+#pragma unroll
+                for (uint32_t c = 0; c < NCH; c += 8u) cnt += (uint32_t)__popc(hmw[c >> 3]);
+                if (__ballot(cnt != 0u) != 0ull) {
+                    const uint32_t inc = wave_incl_scan(cnt);
+                    uint32_t at = inc - cnt;
+                    nh = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                    if (nh <= SB_HIT_CAP) {
+#pragma unroll
+                        for (uint32_t c = 0; c < NCH; ++c) {
+                            if (c * 64u >= lim) continue;
+                            uint32_t hm = (hmw[c >> 3] >> (4u * (c & 7u))) & 15u;
+                            while (hm) { const uint32_t b = (uint32_t)__ffs((int)hm) - 1u; hm &= hm - 1u; hits[at] = make_uint2(sv[c], b); ++at; }
+                        }
+                    }
+                }
+                if (__ballot(lngm != 0u) != 0ull) {
+#pragma unroll
+                    for (uint32_t c = 0; c < NCH; ++c) {
+                        if (c * 64u >= lim) continue;
+                        const bool lng = (lngm >> c) & 1u;
+                        const unsigned long long lb = __ballot(lng);
+                        if (lb) {
+                            const uint32_t at = nlb + below(lb);
+                            if (lng && at < SB_LQB_CAP) { lqb[at] = make_uint2(sv[c], fr[c].y); lqb_len[at] = fr[c].x >> 16; }
+                            nlb += (uint32_t)__popcll(lb);
+                        }
                     }
                 }
             }
+            SB_SUBTICK(tk1);
             if (nlb > SB_LQB_CAP) { fail = true; c15 += 1ull << 20; }
             else if (nlb) {
                 SB_SYNC();
@@ -516,15 +617,16 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                         const unsigned long long hb = hr == 0u ? lbase[0] : hr == 1u ? lbase[1] : hr == 2u ? lbase[2] : lbase[3];
                         row = (size_t)sb.post_rank[hb + (h.x & 0xFFFFFu)];
                     } else row = (size_t)(base + (h.x >> NB));
-                    const uint32_t* os = reinterpret_cast<const uint32_t*>(ix.row_slots + row);   // the general 16-byte fragment slot: {len, i0, i1, i2} | {len, ext offset, i0, i1}
-                    const uint32_t len = os[0], j = h.y;
+                    const uint4 os = *reinterpret_cast<const uint4*>(ix.row_slots + row);   // the general 16-byte fragment slot, all of it in ONE load: {len, i0, i1, i2} | {len, ext offset, i0, i1}
+                    const uint32_t len = os.x, j = h.y;
                     uint32_t it = EMPTY32;
-                    if (j < len) it = len <= 3u ? os[1 + j] : (j < 2u ? os[2 + j] : ix.row_ext[os[1] + (j - 2u)]);   // (a position past the end was a dump word)
+                    if (j < len) it = len <= 3u ? (j == 0u ? os.y : j == 1u ? os.z : os.w) : (j < 2u ? (j == 0u ? os.z : os.w) : ix.row_ext[os.y + (j - 2u)]);   // (a position past the end names no item)
                     if (business && it != EMPTY32 && it >= SB_DIRECT && !business_ok(cur_attr, ix.meta[it].attr)) it = EMPTY32;
                     if (it != EMPTY32 && it >= SB_DIRECT && item_insert(ikeys, iacc, SB_BUCKETS, it, (int)(STREAM ? h.x >> 24 : (uint32_t)wtab[h.x & NBM])) < 0) ovf = true;
                 }
                 if (__ballot(ovf) != 0ull) { fail = true; c7 += 1ull << 32; }
             }
+            SB_SUBTICK(tk2);
             SB_SYNC();
             if (!fail) {   // the table's contenders (exact sum at the floor; the others were collisions in their sketch word), compacted behind the candidates' room: into the hit list's words
                 uint4 kq = make_uint4(EMPTY32, EMPTY32, EMPTY32, EMPTY32), aq = make_uint4(0u, 0u, 0u, 0u);
@@ -535,7 +637,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                 for (int s4 = 0; s4 < 4; ++s4) {
                     const bool in = kk[s4] != EMPTY32 && kk[s4] != cur_idx && aa[s4] >= floor_b;
                     const unsigned long long bm = __ballot(in);
-                    if (in) hits[nt + (uint32_t)__popcll(bm & lt)] = make_uint2(kk[s4], aa[s4]);
+                    if (in) hits[nt + below(bm)] = make_uint2(kk[s4], aa[s4]);
                     nt += (uint32_t)__popcll(bm);
                 }
                 SB_SYNC();
@@ -586,8 +688,13 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
         SB_TICK(tk13);
     }
     if (ticking && lane == 0u) {
+#ifdef SRN_SBACK_SUBTICKS
+        const unsigned long long v[16] = {0, tk1, tk2, tk3, tk4, c5, c6, c7, tk8, tk9, tk10, tk11, tk12, tk13, c14, c15};
+        for (int i = 1; i < 16; ++i) if (v[i]) atomicAdd(&p.phase_cycles[i], v[i]);
+#else
         const unsigned long long v[16] = {0, 0, 0, 0, 0, c5, c6, c7, tk8, tk9, tk10, tk11, tk12, tk13, c14, c15};
         for (int i = 5; i < 16; ++i) if (v[i]) atomicAdd(&p.phase_cycles[i], v[i]);
+#endif
     }
 }
 
