@@ -325,15 +325,14 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
         {
             uint32_t pwv[NCH];
 #pragma unroll
-            for (uint32_t c = 0; c < NCH; ++c) {
-                pwv[c] = 0u;
-                if ((c & ~3u) * 64u < K) {   // (wave-uniform, per GROUP of four chunks: a branch per chunk ends the scheduler's region there, and every chunk's loads and LDS reads are then waited for inside their own block; the lanes past K behave as absent neighbours)
-                    const bool act = c * 64u + lane < K;
-                    const uint32_t r = act ? base + (sv[c] >> NB) : n_kept;   // (idle lanes: the empty row, whose presence bit is 0)
-                    if constexpr (BITMAP) pwv[c] = sb.present[r >> 5] >> (r & 31u);
-                    else if constexpr (PBYTES) pwv[c] = act ? (uint32_t)reinterpret_cast<const uint8_t*>(xq + 1u + p.k)[c * 64u + lane] >> sb.pbyte_shift : 0u;   // (the fronting rank said which neighbours have a fragment here: arrived with the slots)
-                    else pwv[c] = act ? 1u : 0u;   // (no bitmap: every neighbour's fragment is fetched; the empty ones are told apart below)
+            for (uint32_t c = 0; c < NCH; ++c) {   // (all 24 chunks whatever K, no branch: one batch of look-ups.  With a wave-uniform branch per chunk -- or group of chunks -- each look-up was waited for in its own block)
+                const bool act = c * 64u + lane < K;
+                if constexpr (BITMAP) { const uint32_t r = act ? base + (sv[c] >> NB) : n_kept; pwv[c] = sb.present[r >> 5] >> (r & 31u); }   // (idle lanes: the empty row, whose presence bit is 0)
+                else if constexpr (PBYTES) {   // the fronting rank said which neighbours have a fragment here: a byte each behind the slots.  Clamped and unconditional: inside `act ? ... : 0` each byte load sat in a divergent branch of its own and was waited for there -- 22 round trips, what made this form lose until round 6
+                    const uint32_t pb = (uint32_t)reinterpret_cast<const uint8_t*>(xq + 1u + p.k)[min(c * 64u + ln, p.k - 1u)];
+                    pwv[c] = (pb >> sb.pbyte_shift) & (act ? 1u : 0u);   // (an AND, not a select: the code generator turns a select whose operand is a load back into a branch around the load)
                 }
+                else pwv[c] = act ? 1u : 0u;   // (no bitmap: every neighbour's fragment is fetched; the empty ones are told apart below)
             }
 #pragma unroll
             for (uint32_t c = 0; c < NCH; ++c) pm |= (pwv[c] & 1u) << c;
