@@ -182,24 +182,50 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
     const bool ordered = f.order != nullptr;
     const uint32_t ox = blockIdx.x & 7u;
     const uint32_t qi_step = ordered ? gridDim.x >> 3 : gridDim.x, qi_end = ordered ? ord_count(p.nq, ox) : p.nq;
-    for (uint32_t qi = ordered ? blockIdx.x >> 3 : blockIdx.x; qi < qi_end; qi += qi_step) {
-        const uint32_t q = ordered ? (uint32_t)f.order[ord_pos(ox, qi)] : qi;
-        long long t_prev = ticking ? clock64() : 0;
+    // ---- a query's record, K and neighbour slots are requested ONE QUERY AHEAD (round 6), at the point where the query being served has nothing left in registers that
+    // its resolve needs (the hit list carries the slots): the next query's round trip runs beside this query's resolve (item ids from the general fragment slots, a round
+    // trip of its own), hand-off and finish.  Every dependent trip of a wave costs ~13 K ticks here whatever it fetches; this takes one of four off a query's chain.
+    // The query INDEX is read a further step ahead (a scalar load that has a whole query's time to arrive).
+    struct Pre { uint32_t q, U, xlo, L, attr, idx, kept, kv; unsigned long long base; uint32_t sv[NCH]; } pre;
+    const uint32_t qi_first = ordered ? blockIdx.x >> 3 : blockIdx.x;
+    auto q_at = [&](uint32_t qi) -> uint32_t { return qi < qi_end ? (ordered ? (uint32_t)f.order[ord_pos(ox, qi)] : qi) : 0u; };
+    uint32_t q_ahead = q_at(qi_first);
+    auto fetch = [&](uint32_t qi) {   // (no branch around any of these loads: a load inside a divergent branch is waited for at the branch's end)
+        const uint32_t q = q_ahead;
+        q_ahead = q_at(qi + qi_step);
         const char* const rec = p.prep + (size_t)q * p.prep_stride;
         const uint32_t* const xq = f.xchg + (size_t)q * f.xchg_stride;
-        // ---- the query's record and its neighbour slots: ONE round trip (the slots past K are stale words of the query's own row, masked below) ----
-        struct { uint32_t U, xlo, L, cur_attr; } h0;   // (uniform addresses: scalar loads)
-        { const PrepHead* hp = (const PrepHead*)rec; h0.U = hp->U; h0.xlo = hp->xlo; h0.L = hp->L; h0.cur_attr = hp->cur_attr; }
-        uint32_t it_idx = kNone, it_kept = 0u; unsigned long long it_base = 0ull;
-        if (lane < 8u && lane < p.max_len) { const PrepItem pi = ((const PrepItem*)(rec + sizeof(PrepHead)))[lane]; it_idx = pi.idx; it_kept = pi.kept; it_base = pi.base; }   // (all the record's places, with the head: asked for behind L they were a dependent trip of their own)
-        if (lane >= h0.L) { it_idx = kNone; it_kept = 0u; it_base = 0ull; }   // (places past L hold an earlier batch's items)
-        const uint32_t kv = xq[0];
-        uint32_t ln = lane; asm volatile("" : "+v"(ln));   // (the lane number as the optimiser cannot see through it: the 24 clamped slot offsets below are loop-invariant, and hoisted out of the query loop they were spilled -- each reload a s_waitcnt vmcnt(0) between two of the slot loads)
+        uint32_t ln = lane; asm volatile("" : "+v"(ln));   // (the lane number as the optimiser cannot see through it: the 24 clamped slot offsets are loop-invariant, and hoisted out of the query loop they were spilled -- each reload a s_waitcnt vmcnt(0) between two of the slot loads)
+        const PrepHead* hp = (const PrepHead*)rec;
+        pre.q = q; pre.U = hp->U; pre.xlo = hp->xlo; pre.L = hp->L; pre.attr = hp->cur_attr;
+        const PrepItem* pi = (const PrepItem*)(rec + sizeof(PrepHead)) + min(ln, min(p.max_len, 8u) - 1u);   // (all the record's places, with the head: asked for behind L they were a dependent trip of their own; lanes past them are masked where the values are used)
+        pre.idx = pi->idx; pre.kept = pi->kept; pre.base = pi->base;
+        pre.kv = xq[0];
+        if constexpr (!STREAM) {
+#pragma unroll
+            for (uint32_t c = 0; c < NCH; ++c) pre.sv[c] = SB_NT_LOAD(&xq[1u + min(c * 64u + ln, f.xchg_stride - 2u)]);   // (read once: 5.4 KB per query that need not stay in the L2 the fragments want; the slots past K are stale words of the query's own row, masked below)
+        }
+    };
+    if (qi_first < qi_end) fetch(qi_first);
+    for (uint32_t qi = qi_first; qi < qi_end; qi += qi_step) {
+        long long t_prev = ticking ? clock64() : 0;
+        // ---- the query's record and its neighbour slots, requested during the query before ----
+        const uint32_t q = pre.q;
+        const uint32_t* const xq = f.xchg + (size_t)q * f.xchg_stride;
+        struct { uint32_t U, xlo, L, cur_attr; } h0;
+        h0.U = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.U); h0.xlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.xlo);
+        h0.L = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.L); h0.cur_attr = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre.attr);
+        const bool place = lane < 8u && lane < p.max_len && lane < h0.L;   // (places past L hold an earlier batch's items)
+        const uint32_t it_idx = place ? pre.idx : kNone, it_kept = place ? pre.kept : 0u; const unsigned long long it_base = place ? pre.base : 0ull;
+        const uint32_t kv = pre.kv;
+        uint32_t ln = lane; asm volatile("" : "+v"(ln));
         uint32_t sv[NCH];   // gather form: the neighbour slots; streaming form: the members' {position | run << 20 | weight << 24}, read back from the scratch after walk A
         if constexpr (!STREAM) {
 #pragma unroll
-            for (uint32_t c = 0; c < NCH; ++c) sv[c] = SB_NT_LOAD(&xq[1u + min(c * 64u + ln, f.xchg_stride - 2u)]);   // (read once: 5.4 KB per query that need not stay in the L2 the fragments want)
+            for (uint32_t c = 0; c < NCH; ++c) sv[c] = pre.sv[c];
         }
+        bool fetched = false;   // (wave-uniform)
+        auto fetch_next = [&]() { if (!fetched) { fetched = true; if (qi + qi_step < qi_end) fetch(qi + qi_step); } };
         const uint32_t L = h0.L, U = h0.U, cur_attr = h0.cur_attr;
         unsigned long long rm = __ballot(it_kept > 0u);
         const uint32_t nr = (uint32_t)__popcll(rm);
@@ -228,9 +254,10 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
         const uint32_t K = (uint32_t)__builtin_amdgcn_readfirstlane((int)kv);
         if (K == 0xFFFFFFFFu || L < 1u || L > 8u || L > p.max_len || K > F_K_MAX) {   // (wave-uniform) no front end took it, or not this kernel's shape: the general kernel does its candidate work itself
             if (lane == 0u) f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q;
+            fetch_next();
             continue;
         }
-        if (K == 0u) { if (lane == 0u) p.out_counts[q] = 0u; continue; }
+        if (K == 0u) { if (lane == 0u) p.out_counts[q] = 0u; fetch_next(); continue; }
         SB_TICK(tk8);
         // ---- walk A: ALL of a lane's <= 24 presence words in flight together, then all fragments of the present ones: a query's walk is three HBM / L2 round trips (slots,
         // presence, fragments) whatever K is.  A first build walked in two halves with the long fragments' overflow blocks fetched inline: 30 dependent round trips per query on
@@ -339,9 +366,11 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
         }
         {
 #pragma unroll
-            for (uint32_t c = 0; c < NCH; ++c) {
-                fr[c] = make_uint2(0u, 0u);
-                if ((c & ~3u) * 64u < K) {
+            for (uint32_t c = 0; c < NCH; ++c) fr[c] = make_uint2(0u, 0u);
+#pragma unroll
+            for (uint32_t g = 0; g < NCH; g += 4u) if (g * 64u < K) {   // (wave-uniform, per GROUP of four chunks: a branch per chunk ends the scheduler's region there, and every chunk's loads and LDS reads are then waited for inside their own block; the lanes past K behave as absent neighbours)
+#pragma unroll
+                for (uint32_t c = g; c < g + 4u; ++c) {
                     if constexpr (BITMAP || PBYTES) {   // (round 6) the absent lanes ask for NOTHING: a buffer load past the descriptor's range is answered with 0 by the address unit, no request leaves it
                         typedef uint32_t v2u __attribute__((ext_vector_type(2)));
                         const v2u v = __builtin_amdgcn_raw_buffer_load_b64(frag_rsrc, (pm >> c) & 1u ? (base + (sv[c] >> NB)) * 8u : 0xFFFFFFF8u, 0, 0);
@@ -364,8 +393,9 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
 #endif
             uint32_t lngm = 0u;   // bit c: this lane's fragment of chunk c is a long one (> 4 items: queued below)
 #pragma unroll
-            for (uint32_t c = 0; c < NCH; ++c) {
-                if ((c & ~3u) * 64u < K) {
+            for (uint32_t g = 0; g < NCH; g += 4u) if (g * 64u < K) {
+#pragma unroll
+                for (uint32_t c = g; c < g + 4u; ++c) {
                     const uint32_t o0 = fr[c].x & 0xFFFFu;
                     const bool here = (BITMAP || PBYTES) ? ((pm >> c) & 1u) != 0u : true;   // (those forms' absent lanes hold zeros)
                     const bool lng = here && o0 == 0xFFFFu;   // (never the empty row's slot)
@@ -429,7 +459,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
             for (uint32_t j = 0; j < 4u; ++j) { const uint4* rp = reinterpret_cast<const uint4*>(hot + SB_DIRECT + (4u * lane + j) * SB_REP); const uint4 a = rp[0], b = rp[1];
                                                 v4[j] = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w; }
         }
-        if (lane < SB_DUMP) hot[SB_H + SB_S + lane] = 0u;   // (walk B reads the dump words, where unused positions point, as "cannot reach the floor")
+        if (ls < SB_DUMP) hot[SB_H + SB_S + ls] = 0u;   // (walk B reads the dump words, where unused positions point, as "cannot reach the floor")
         double x4[4]; uint32_t k4[4];
 #pragma unroll
         for (uint32_t j = 0; j < 4u; ++j) {
@@ -526,6 +556,8 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
             uint32_t e0 = EMPTY32, z0 = 0u; asm volatile("" : "+v"(e0), "+v"(z0));   // (see the clears: no constant quads kept across queries)
             reinterpret_cast<uint4*>(ikeys)[lane] = make_uint4(e0, e0, e0, e0);   // the exact table (keys EMPTY32, sums 0); its room held the floors' list until here
             reinterpret_cast<uint4*>(iacc)[lane] = make_uint4(z0, z0, z0, z0);
+#pragma unroll
+            for (uint32_t i = 0; i < SB_H / 256u; ++i) reinterpret_cast<uint4*>(hot)[i * 64u + lane] = make_uint4(z0, z0, z0, z0);   // (the direct-mapped words are dead: zeroed, none of them is "at the floor" -- four stores instead of a range test per position read below)
             SB_SYNC();   // (the direct-mapped words are dead: the hit list takes them)
             uint32_t nh = 0;   // (wave-uniform)
             auto chk = [&](uint32_t o) -> bool { return o >= SB_H * 4u && *(const uint32_t*)(acc_base + o) >= floor_b; };
@@ -546,15 +578,23 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
 #pragma unroll
                 for (uint32_t c = 0; c < NCH; c += 8u) hmw[c >> 3] = 0u;
                 uint32_t lngm = 0u;
-                auto at_floor = [&](uint32_t o) -> uint32_t { return ((o >= SB_H * 4u) & (*(const uint32_t*)(acc_base + o) >= floor_b)) ? 1u : 0u; };
 #pragma unroll
-                for (uint32_t c = 0; c < NCH; ++c) {
-                    if ((c & ~3u) * 64u >= lim) continue;   // (wave-uniform, per group of four chunks)
-                    const bool pr = (pm >> c) & 1u, lng = pr && (fr[c].x & 0xFFFFu) == 0xFFFFu;
-                    const uint32_t fx = pr && !lng ? fr[c].x : SB_OOR * 0x10001u, fy = pr && !lng ? fr[c].y : SB_OOR * 0x10001u;
-                    const uint32_t hm = at_floor(fx & 0xFFFFu) | (at_floor(fx >> 16) << 1) | (at_floor(fy & 0xFFFFu) << 2) | (at_floor(fy >> 16) << 3);
-                    hmw[c >> 3] |= hm << (4u * (c & 7u));
-                    lngm |= lng ? 1u << c : 0u;
+                for (uint32_t g = 0; g < NCH; g += 4u) if (g * 64u < lim) {   // (wave-uniform, per group of four chunks)
+                    uint32_t wv[16];   // the group's sixteen words, all asked for before the first is looked at (the scheduler, left alone, reads two and waits)
+#pragma unroll
+                    for (uint32_t c = g; c < g + 4u; ++c) {
+                        const bool pr = (pm >> c) & 1u, lng = pr && (fr[c].x & 0xFFFFu) == 0xFFFFu;
+                        const uint32_t fx = pr && !lng ? fr[c].x : SB_OOR * 0x10001u, fy = pr && !lng ? fr[c].y : SB_OOR * 0x10001u;
+                        const uint32_t i = 4u * (c - g);
+                        wv[i] = *(const uint32_t*)(acc_base + (fx & 0xFFFFu)); wv[i + 1u] = *(const uint32_t*)(acc_base + (fx >> 16));
+                        wv[i + 2u] = *(const uint32_t*)(acc_base + (fy & 0xFFFFu)); wv[i + 3u] = *(const uint32_t*)(acc_base + (fy >> 16));
+                        lngm |= lng ? 1u << c : 0u;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    uint32_t hm16 = 0u;
+#pragma unroll
+                    for (uint32_t i = 0; i < 16u; ++i) hm16 |= wv[i] >= floor_b ? 1u << i : 0u;   // (direct-mapped words: zeroed above; out of range: 0)
+                    hmw[g >> 3] |= hm16 << (4u * (g & 7u));
                 }
                 uint32_t cnt = 0u;
 #pragma unroll
@@ -586,6 +626,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                     }
                 }
             }
+            fetch_next();   // (the slots and the fragments are dead from here on: the next query's take their registers)
             SB_SUBTICK(tk1);
             if (nlb > SB_LQB_CAP) { fail = true; c15 += 1ull << 20; }
             else if (nlb) {
@@ -642,6 +683,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                 SB_SYNC();
             }
         }
+        fetch_next();   // (a query without a walk B)
         SB_TICK(tk12);
         if (fail) {   // (beyond this kernel's room: the fast kernel's back-end form takes the query if the launch sequence has one behind this kernel, else the general kernel)
             if (lane == 0u) { if (f.mid_list) f.mid_list[atomicAdd(f.mid_cnt, 1u)] = q; else f.slow_list[atomicAdd(f.slow_cnt, 1u)] = q; }
@@ -649,10 +691,11 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
         }
         // ---- hand-off: the query's record for vmis_finish_kernel (score = x / (10 U), ranking, public ids), as the fast kernel writes it ----
         const uint32_t M = ncand + nt;
+        uint32_t lh = lane; asm volatile("" : "+v"(lh));   // (opaque, as `ln`: the LDS addresses made of the lane number below were hoisted and spilled -- and a reload's s_waitcnt vmcnt(0) here also sits out the NEXT query's requests)
         if (sb.finish_here && M <= F_FIN_ENTRIES) {   // (wave-uniform) the row finished by this wave itself, from registers: no record, nothing for the finish kernel (round 5, second half)
             uint4 e = make_uint4(0u, 0u, 0u, 0u);
-            if (lane < ncand) { const unsigned long long x = ckey[lane]; e = make_uint4((uint32_t)x, (uint32_t)(x >> 32), cidx[lane], 0u); }
-            else if (lane < M) { const uint2 c = hits[lane - ncand]; e = make_uint4(c.y, 0u, c.x, 1u); }
+            if (lh < ncand) { const unsigned long long x = ckey[lh]; e = make_uint4((uint32_t)x, (uint32_t)(x >> 32), cidx[lh], 0u); }
+            else if (lh < M) { const uint2 c = hits[lh - ncand]; e = make_uint4(c.y, 0u, c.x, 1u); }
             finish_inline(ix_arg, M, U, e, lane, q, p.out_ids, p.out_scores, p.out_counts, p.how_many);
             SB_SYNC();   // (the next query clears what this one still read)
             c6 += ncand; c14 += 1ull;
@@ -675,7 +718,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
             uint4* out = reinterpret_cast<uint4*>(f.fin + (size_t)q * F_FIN_BYTES);
             uint4* ovf = reinterpret_cast<uint4*>(f.big_arena) + ovf_at;
             if (lane == 0u) { out[0] = make_uint4(M, U, ovf_at, 0u); p.out_counts[q] = M > F_FIN_ENTRIES ? 0x80000001u : 0x80000000u; }
-            for (uint32_t i = lane; i < M; i += 64u) {
+            for (uint32_t i = lh; i < M; i += 64u) {
                 uint4 e;
                 if (i < ncand) { const unsigned long long x = ckey[i]; e = make_uint4((uint32_t)x, (uint32_t)(x >> 32), cidx[i], 0u); }
                 else { const uint2 c = hits[i - ncand]; e = make_uint4(c.y, 0u, c.x, 1u); }
