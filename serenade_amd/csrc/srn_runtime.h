@@ -47,7 +47,7 @@ struct Knobs {
     int order_min = 131072;    // SRN_ORDER_MIN: batches of at least this many queries are served in the order of their most popular item, an eighth of the order per XCD (0 = never); the ordering
                               // pass is one radix sort of the batch's keys behind the prep kernel
     bool no_sback_finish = true;    // SRN_SBACK_FINISH=1 (experiment): the wave-per-query back end finishes rows of <= 63 entries itself instead of leaving a record for vmis_finish_kernel.  Measured: the finish kernels' share falls 0.167 -> 0.122 ms per 131 072 queries, the kernel grows 1.606 -> 1.685 (two more dependent gathers per query on a kernel bound by its requests): off
-    bool no_sback_pbytes = true;    // SRN_SBACK_PBYTES=1 (experiment): presence bytes in the neighbours pipeline's exchange records -- the fronting rank marks, per neighbour, which shards hold a fragment of it (the shards' bitmaps all-gathered at set_postings); a back end asks only for fragments that exist: half the requests at G = 8, no look-up of its own.  Measured: kernel 1.61 -> 1.95 ms, front 0.30 -> 0.37: it loses, like the bitmap -- the kernel's time does not follow its fragment requests (profiles/r05_sback_stream_ab.txt)
+    bool no_sback_pbytes = true;    // SRN_SBACK_PBYTES=1 (experiment): presence bytes in the neighbours pipeline's exchange records -- the fronting rank marks, per neighbour, which shards hold a fragment of it (the shards' bitmaps all-gathered at set_postings); a back end asks only for fragments that exist: half the requests at G = 8, no look-up of its own.  Measured in round 5: kernel 1.61 -> 1.95 ms (its 22 byte loads were waited for one by one); round 6, read in one batch and the absent lanes truly silent: 1.149 against 1.149 ms, front 0.30 -> 0.36 -- half the fragment requests buy nothing, the kernel's time does not follow them (profiles/r06_sback_ab.txt)
     bool no_sback_second = false;   // SRN_NO_SBACK_SECOND (experiments): what the wave-per-query back end cannot hold goes straight to the general kernel (no fast-kernel back end over the list)
     bool no_sback = false;    // SRN_NO_SBACK: the shard group's back end through vmis_fast_kernel's FM_BACK instantiation (rounds 4) instead of the wave-per-query kernel of srn_sback.hip
     bool sback_bitmap = false;     // SRN_SBACK_BITMAP=1 (experiments): that kernel asks its presence bitmap before it fetches a fragment.  Measured on config 3 cut in 8: half the fragment

@@ -10,7 +10,7 @@
 //
 // Rows: a third per-shard row array, `frag8` -- 8-byte slots addressed by recency rank, four 16-bit LDS byte offsets (the accumulator word of each of the <= 4 items of the
 // fragment: direct-mapped for the shard's SB_DIRECT most popular items, a sketch word for the rest, replicated words for the 16 hottest -- the same scheme as srn_fast.hip;
-// unused positions point into a dump area); a fragment of > 4 items (rare from G = 4 on) keeps all its items in 16-byte overflow blocks -- and a PRESENCE BITMAP, one bit per
+// unused positions point OUT of the wave's LDS allocation (round 6: dropped by the hardware)); a fragment of > 4 items (rare from G = 8 on) keeps all its items in 16-byte overflow blocks -- and a PRESENCE BITMAP, one bit per
 // session: at G = 8 about half of a query's neighbours hold no item of this shard at all, the bitmap (1.5 MB on config 3: L2-resident) is asked first and only the others
 // cost a fragment fetch (tools/shard_gather_bench.hip: a random fragment fetch is an HBM-granule miss at ~50 G/s chip-wide, a bitmap hit ~15x cheaper).
 //
@@ -18,6 +18,15 @@
 // (DESIGN.md "Why the sketch filter is exact"), walk B + exact table for what the sketch cannot exclude -- written wave-synchronously; the hand-off record and the finish
 // kernels (vmis_finish_kernel / vmis_finish_big_kernel) are shared with the fast kernel, and so is the fall-back: what this kernel cannot take goes to f.slow_list and the
 // general kernel behind it.
+//
+// Round 6 (1.60 -> 1.15 ms per 131 072 queries at G = 8, profiles/r06_sback_ab.txt): what the compiler made of the source mattered more than any memory-side redesign of
+// round 5.  (1) NO SCRATCH: values made of the lane number are loop-invariant; hoisted out of the query loop they occupied registers for the wave's life, the kernel sat at its
+// 168-register limit and they were spilled -- and a reload is a vector-memory load whose s_waitcnt vmcnt(0) also sits out every other request the wave has in flight
+// (opaque copies of the lane number at the points of use; sample constants fetched per query).  (2) Loads the source asks for unconditionally were moved behind branches:
+// the 24 slot loads below the early exits on K (a second dependent trip), loads under `cond ? load : 0` into divergent branches (each waited for there).  (3) A
+// wave-uniform branch per chunk of 64 neighbours ends the scheduler's region: every chunk's LDS reads were waited for in its own block -- chunks now go in groups of four,
+// walk B reads a group's sixteen words behind a scheduling barrier, one scan per query places the hits.  (4) Straight-line walks: unused positions and absent lanes add to /
+// read from offsets out of the allocation.  (5) The next query's record and slots are requested before this query's resolve.
 // =====================================================================================
 #include <hip/hip_runtime.h>
 
@@ -382,8 +391,15 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
             uint32_t wq[NCH / 4u];
 #pragma unroll
             for (uint32_t c = 0; c < NCH; c += 4u) wq[c >> 2] = 0u;
+            {
+                uint32_t w16[NCH];
 #pragma unroll
-            for (uint32_t c = 0; c < NCH; ++c) wq[c >> 2] |= (uint32_t)wtab[sv[c] & NBM] << (8u * (c & 3u));   // (all 24, whatever K: one batch of LDS reads)
+                for (uint32_t c = 0; c < NCH; ++c) w16[c] = (uint32_t)wtab[sv[c] & NBM];   // (all 24, whatever K: one batch of LDS reads -- the barriers keep the scheduler from dealing them out between the adds, two at a time and each pair waited for)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (uint32_t c = 0; c < NCH; ++c) wq[c >> 2] |= w16[c] << (8u * (c & 3u));
+                __builtin_amdgcn_sched_barrier(0);
+            }
             // STRAIGHT-LINE adds (round 6): all four positions of every fragment, whoever holds it -- unused positions, the absent lanes' empty row and the lanes past K
             // point out of the allocation (SB_OOR: dropped by the hardware), a long fragment's words are replaced by such.  With a branch per chunk (and the weight's
             // LDS read in front of its adds) the chunks ran one after the other, each behind its own s_waitcnt.
@@ -472,7 +488,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
         // the n-th largest of the 256 keys (top 32 bits of x: a monotone truncation), bit by bit from the top down to bit 8: t32 = the largest multiple of 256 with
         // at least n keys at or above it (0: fewer than n valid items -- no threshold, everything valid is a candidate)
         uint32_t t32 = 0u;
-        for (int b = 31; b >= 8; --b) {
+        for (int b = 30; b >= 8; --b) {   // (bit 31 is the sign of a non-negative number)
             const uint32_t c = t32 | (1u << b);
             const uint32_t cnt = (uint32_t)__popcll(__ballot(k4[0] >= c)) + (uint32_t)__popcll(__ballot(k4[1] >= c)) + (uint32_t)__popcll(__ballot(k4[2] >= c)) + (uint32_t)__popcll(__ballot(k4[3] >= c));
             t32 = cnt >= p.how_many ? c : t32;
@@ -502,10 +518,13 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
         uint2* const plist = reinterpret_cast<uint2*>(smem + SB_TABLE);
         constexpr uint32_t PLIST_CAP = SB_TABLE_WORDS;   // (8 bytes per entry in the table's 2 KB)
         uint32_t npass = 0u;   // (wave-uniform)
+        uint4 dq[SB_H / 256u];
+#pragma unroll
+        for (uint32_t ch = 1; ch < SB_H / 256u; ++ch) dq[ch] = reinterpret_cast<const uint4*>(hot)[ch * 64u + lane];   // (the three quads in one batch)
 #pragma unroll
         for (uint32_t ch = 1; ch < SB_H / 256u; ++ch) {
             const uint32_t fl = floor_of(sb.inv_idf_chunk[ch]);
-            const uint4 q4 = reinterpret_cast<const uint4*>(hot)[ch * 64u + lane];
+            const uint4 q4 = dq[ch];
             const uint32_t mx = max(max(q4.x, q4.y), max(q4.z, q4.w));
             if (__ballot(mx >= fl) == 0ull) continue;
             const uint32_t vv[4] = {q4.x, q4.y, q4.z, q4.w};
