@@ -965,7 +965,7 @@ def main():
                                "projected_node_queries_per_s": {"gather_not_overlapped": Bl / ((float(t.sum()) + xg) * 1e-3), "streaming_not_overlapped": Bl / ((float(ts_.sum()) + xs) * 1e-3),
                                                                 "gather_overlapped": Bl / (max(float(t.sum()), xg) * 1e-3), "streaming_overlapped": Bl / (max(float(ts_.sum()), xs) * 1e-3)}}
             model["what_the_library_does"] = ("SRN_SBACK_STREAM unset (round 6): a group with real peers whose exchanges are NOT overlapped (the default) takes the form with the lower modelled total -- "
-                                              "streaming iff the bytes it saves per query and link / SRN_XGMI_GBPS (default 76.8 GB/s per direction) exceed the 8.1 ns of extra compute per query (at the default rate: 6.45 ns saved -- the gather form); "
+                                              "streaming iff the bytes it saves per query and link / SRN_XGMI_GBPS (default 76.8 GB/s per direction) exceed the 8.5 ns of extra compute per query (at the default rate: 6.45 ns saved -- the gather form); "
                                               "with srn_shard_group_set_overlap(1) the gather form (its smaller compute decides)")
             blk["exchange_model"] = model
         except Exception as e:   # (the block is an extra: its failure must not cost the line)

@@ -313,7 +313,7 @@ int group_predict_neighbours(srn_shard_group* g, const LaunchParams& p_in, bool 
     // every rank's back end streams its fragments in posting order.  Chosen from rank-invariant inputs (batch shape, knobs) + what set_postings settled for this rank.
     // streaming or gather form (rank-invariant inputs only: the knob, the group's kind, the overlap switch, what set_postings agreed on): see Knobs::sback_stream_mode
     // AUTO: the form with the lower modelled batch time when the exchange is on the critical path -- the streaming form saves ((k + 1) - stride) * 4 / G bytes per query and
-    // link, and costs 8.1 ns more compute per query and rank (config 3, G = 8: 2.85 against 1.79 ms per 131 072 queries since the gather form's back end was rebuilt in round 6
+    // link, and costs 8.5 ns more compute per query and rank (config 3, G = 8: 2.86 against 1.75 ms per 131 072 queries since the gather form's back end was rebuilt in round 6
     // -- 5.9 ns until then --, bench.py's exchange_model); SRN_XGMI_GBPS = the
     // link's rate per direction (default 76.8: a 153.6 GB/s link counted both ways).  Overlapped, the gather form's smaller compute decides.
     const int smode = knobs().sback_stream_mode;
@@ -321,7 +321,7 @@ int group_predict_neighbours(srn_shard_group* g, const LaunchParams& p_in, bool 
     bool want_stream = smode == 1;
     if (smode < 0 && pstride_all != 0u && g->kind != srn_shard_group::LOCAL && !g->overlap) {
         const double saved_ns = ((double)(p.k + 1u) - (double)pstride_all) * 4.0 / (double)G / knobs().xgmi_gbps;   // bytes / (GB/s) = ns
-        want_stream = saved_ns > 8.1;
+        want_stream = saved_ns > 8.5;
     }
     const uint32_t pstride = want_stream ? pstride_all : 0u;
     const bool positions = pstride != 0u;

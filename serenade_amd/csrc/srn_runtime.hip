@@ -1021,7 +1021,7 @@ int device_predict(DeviceState* d, const FlatIndex& ix, const LaunchParams& p_in
             const bool stream = ext->positions;
             if (stream && !(d->sb_frag_post && d->sb_post_for == ext->post_rank)) return fail(SRN_ESTATE, "the batch's neighbours came as posting positions, but this shard does not hold its fragments in posting order");
             const uint64_t slots = (uint64_t)d->n_cu * (stream ? 9 : 12);
-            uint32_t grid_b = (uint32_t)std::min<uint64_t>(p.nq, slots * (kn.grid_mult_set ? grid_mult : stream ? 4 : 8));
+            uint32_t grid_b = (uint32_t)std::min<uint64_t>(p.nq, slots * (kn.grid_mult_set ? grid_mult : stream ? 4 : 16));   // (gather form, round 6: 1 / 2 / 4 / 8 / 16 / 32 waves per slot = 1.295 / 1.247 / 1.191 / 1.148 / 1.115 / 1.114 ms -- the tail of a persistent grid costs more than the first query of a wave, which has no prefetched record)
             if (fp.order) grid_b = std::max<uint32_t>(8u, grid_b / 8u * 8u);
             if (stream) {
                 int rc = ensure(&w->sb_scr, &w->sb_scr_bytes, (size_t)grid_b * shard_back_scratch_words() * 4); if (rc) return rc;
