@@ -207,7 +207,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
         uint32_t ln = lane; asm volatile("" : "+v"(ln));   // (the lane number as the optimiser cannot see through it: the 24 clamped slot offsets are loop-invariant, and hoisted out of the query loop they were spilled -- each reload a s_waitcnt vmcnt(0) between two of the slot loads)
         const PrepHead* hp = (const PrepHead*)rec;
         pre.q = q; pre.U = hp->U; pre.xlo = hp->xlo; pre.L = hp->L; pre.attr = hp->cur_attr;
-        const PrepItem* pi = (const PrepItem*)(rec + sizeof(PrepHead)) + min(ln, min(p.max_len, 8u) - 1u);   // (all the record's places, with the head: asked for behind L they were a dependent trip of their own; lanes past them are masked where the values are used)
+        const PrepItem* pi = (const PrepItem*)(rec + sizeof(PrepHead)) + min(ln, max(1u, min(p.max_len, 8u)) - 1u);   // (all the record's places, with the head: asked for behind L they were a dependent trip of their own; lanes past them are masked where the values are used)
         pre.idx = pi->idx; pre.kept = pi->kept; pre.base = pi->base;
         pre.kv = xq[0];
         if constexpr (!STREAM) {
