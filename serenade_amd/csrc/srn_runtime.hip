@@ -140,17 +140,18 @@ DeviceState* device_attach(const FlatIndex& ix, int device) {
             }
         }
         if (good && frag && ix.n_shards >= (uint32_t)knobs().sback_min_shards) {   // the wave-per-query back end's rows (srn_sback.hip): 8-byte slots + overflow blocks + presence bitmap; optional like the packed rows
-            std::vector<uint32_t> bb(nblocks); uint64_t blocks = 1;
+            std::vector<uint32_t> bb(nblocks); uint64_t blocks = 1, longest = 0;
             for (size_t b0 = 0; b0 < nblocks; ++b0) {
                 bb[b0] = (uint32_t)blocks;
                 const size_t hi = std::min(n, (b0 + 1) * 1024);
-                for (size_t r = b0 * 1024; r < hi; ++r) { const uint64_t len = ix.row_off[r + 1] - ix.row_off[r]; if (len > 4) blocks += (len + 7) / 8; }
+                for (size_t r = b0 * 1024; r < hi; ++r) { const uint64_t len = ix.row_off[r + 1] - ix.row_off[r]; longest = std::max(longest, len); if (len > 4) blocks += (len + 7) / 8; }
             }
             const size_t pwords = (n + 1 + 31) / 32 + 32;
             void *d_f8 = nullptr, *d_e8 = nullptr, *d_pr = nullptr, *d_sm = nullptr;
             std::vector<ItemMeta> sm(256, ItemMeta{0.0, 0u, 0u});
             for (size_t i = 0; i < std::min<size_t>(256, ix.n_items); ++i) sm[i] = ItemMeta{ix.idf[i], ix.id_rank[i], ix.attr[i]};
-            const bool g3 = blocks < 0xFFFFFFF0ull && hipMalloc(&d_f8, (n + 1) * 8) == hipSuccess && hipMalloc(&d_e8, (blocks + 2) * 16) == hipSuccess && hipMalloc(&d_pr, pwords * 4) == hipSuccess &&
+            const bool g3 = blocks < 0xFFFFFFF0ull && longest < (1ull << 11) &&   // (what a long fragment's slot can say: srn_sback.hip, SB_LONG)
+                            hipMalloc(&d_f8, (n + 1) * 8) == hipSuccess && hipMalloc(&d_e8, (blocks + 2) * 16) == hipSuccess && hipMalloc(&d_pr, pwords * 4) == hipSuccess &&
                             hipMalloc(&d_sm, 256 * sizeof(ItemMeta)) == hipSuccess && hipMemcpy(d_sm, sm.data(), 256 * sizeof(ItemMeta), hipMemcpyHostToDevice) == hipSuccess &&
                             hipMemcpy(d_base, bb.data(), nblocks * 4, hipMemcpyHostToDevice) == hipSuccess && hipMemset(d_e8, 0, (blocks + 2) * 16) == hipSuccess && hipMemset(d_pr, 0, pwords * 4) == hipSuccess &&
                             launch_rows_to_frag8(nullptr, (const uint64_t*)d_off, (const uint32_t*)d_items, (uint64_t)n, (const uint32_t*)d_base, (uint2*)d_f8, (uint4*)d_e8, (uint32_t*)d_pr) == hipSuccess &&

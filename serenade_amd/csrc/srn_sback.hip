@@ -70,7 +70,15 @@ __device__ __forceinline__ uint32_t sb_offset_of(uint32_t idx, uint64_t r) {
 // workgroup's range is dropped by the hardware before it costs a bank cycle -- adds vanish, reads return 0 (tools/lds_oor_bench.hip; the fast kernel's phantom rows, DESIGN
 // section 4.5) -- so the walks add and read all four positions of every fragment WITHOUT a branch, and the 60 % of them that name no item collide with nobody.
 static constexpr uint32_t SB_OOR = 0xC000u;   // (byte offset from the accumulators' base; the wave's whole allocation is 12 KB)
-static_assert(SB_OOR >= 4u * SB_LDS && SB_OOR < 0xFFFFu && SB_OOR >= (SB_H + SB_S) * 4u, "out of the allocation whatever its granule, and not the long-fragment marker");
+static_assert(SB_OOR >= 4u * SB_LDS && SB_OOR < 0xFFFFu && SB_OOR >= (SB_H + SB_S) * 4u, "out of the allocation whatever its granule");
+// A fragment of > 4 items keeps its length and its first overflow block in four words that are ALL out-of-range offsets, 4-byte aligned (a misaligned DS atomic faults even
+// out of range): {SB_LONG | block bits 22..31, SB_OOR | length, SB_OOR | block bits 0..10, SB_OOR | block bits 11..21}, every field shifted left by two (round 6: until
+// then {0xFFFF, length, block index}, which the walks had to replace by out-of-range offsets before adding / reading them: two selects per chunk and walk)
+static constexpr uint32_t SB_LONG = 0xE000u, SB_LF_BITS = 11u, SB_LF_MASK = (1u << SB_LF_BITS) - 1u;
+static_assert(SB_OOR + (SB_LF_MASK << 2) < SB_LONG && SB_LONG + (0x3FFu << 2) + SB_HOT < 0x10000u, "fields do not reach the marker, and everything stays below 64 KB");
+__device__ __forceinline__ bool sb_is_long(uint32_t x) { return (x & 0xFFFFu) >= SB_LONG; }
+__device__ __forceinline__ uint32_t sb_long_len(uint32_t x) { return (x >> 18) & SB_LF_MASK; }
+__device__ __forceinline__ uint32_t sb_long_block(uint32_t x, uint32_t y) { return ((y >> 2) & SB_LF_MASK) | (((y >> 18) & SB_LF_MASK) << SB_LF_BITS) | (((x >> 2) & 0x3FFu) << (2u * SB_LF_BITS)); }
 __device__ __forceinline__ uint32_t sb_phantom(uint64_t, uint32_t) { return SB_OOR; }
 __global__ __launch_bounds__(1024) void rows_to_frag8_kernel(const uint64_t* __restrict__ row_off, const uint32_t* __restrict__ row_items, uint64_t n,
                                                              const uint32_t* __restrict__ block_base, uint2* __restrict__ frag8, uint4* __restrict__ ext8, uint32_t* __restrict__ present) {
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(1024) void rows_to_frag8_kernel(const uint64_t* __r
 #pragma unroll
         for (uint32_t j = 0; j < 4; ++j) h[j] = j < len ? sb_offset_of(row_items[o + j], r) : sb_phantom(r, j);
     } else {
-        h[0] = 0xFFFFu; h[1] = (uint32_t)(len > 0xFFFFu ? 0xFFFFu : len); h[2] = eblk & 0xFFFFu; h[3] = eblk >> 16;
+        h[0] = SB_LONG | ((eblk >> (2u * SB_LF_BITS)) << 2); h[1] = SB_OOR | ((uint32_t)len << 2); h[2] = SB_OOR | ((eblk & SB_LF_MASK) << 2); h[3] = SB_OOR | (((eblk >> SB_LF_BITS) & SB_LF_MASK) << 2);   // (the host admits the shard only with fragments of < 2 048 items)
         for (uint32_t b = 0; b < e; ++b) {
             uint32_t wv[4];
 #pragma unroll
@@ -211,8 +219,11 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
         pre.idx = pi->idx; pre.kept = pi->kept; pre.base = pi->base;
         pre.kv = xq[0];
         if constexpr (!STREAM) {
+            // (through a buffer descriptor of the record: the address is lane * 4 + a constant per chunk -- the instruction's own offset field --, and what lies past the
+            // record's end comes back as 0 from the address unit: no clamp, no 64-bit address per load)
+            const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xq, 0, (int)(f.xchg_stride * 4u), 0x00020000);
 #pragma unroll
-            for (uint32_t c = 0; c < NCH; ++c) pre.sv[c] = SB_NT_LOAD(&xq[1u + min(c * 64u + ln, f.xchg_stride - 2u)]);   // (read once: 5.4 KB per query that need not stay in the L2 the fragments want; the slots past K are stale words of the query's own row, masked below)
+            for (uint32_t c = 0; c < NCH; ++c) pre.sv[c] = __builtin_amdgcn_raw_buffer_load_b32(xr, ln * 4u + (4u + c * 256u), 0, SRN_SBACK_NT ? 2 : 0);   // (read once: 5.4 KB per query that need not stay in the L2 the fragments want; the slots past K are stale words of the query's own row, masked below)
         }
     };
     if (qi_first < qi_end) fetch(qi_first);
@@ -324,7 +335,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                         nmem += (uint32_t)__popcll(mk);
                         const uint32_t w0 = (uint32_t)lw8[min(idx, F_K_MAX - 1u)], w = mem ? w0 : 0u;
                         const uint32_t o0 = fg[u].x & 0xFFFFu;
-                        const bool lng = mem && o0 == 0xFFFFu;
+                        const bool lng = mem && o0 >= SB_LONG;
                         const bool pr = mem && (lng || o0 < (SB_H + SB_S) * 4u);   // (a fragment's items fill its positions from the first: a dump offset there = an empty fragment)
                         const bool ac = pr && !lng;                                // (long fragments: from the scratch, below)
                         add2(ac ? fg[u].x : dump2, w); add2(ac ? fg[u].y : dump2, w);
@@ -348,11 +359,11 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                 if (c * 64u < nscr) {
                     const bool pr = c * 64u + lane < nscr;
                     pm |= pr ? 1u << c : 0u;
-                    const bool lng = pr && (fr[c].x & 0xFFFFu) == 0xFFFFu;
+                    const bool lng = pr && sb_is_long(fr[c].x);
                     const unsigned long long lbm = __ballot(lng);
                     if (lbm) {
                         const uint32_t at = nlq + below(lbm);
-                        if (lng && at < SB_LQ_CAP) lq[at] = make_uint2(((sv[c] >> 24) << 16) | (fr[c].x >> 16), fr[c].y);
+                        if (lng && at < SB_LQ_CAP) lq[at] = make_uint2(((sv[c] >> 24) << 16) | sb_long_len(fr[c].x), sb_long_block(fr[c].x, fr[c].y));
                         nlq += (uint32_t)__popcll(lbm);
                     }
                 }
@@ -414,12 +425,12 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                 for (uint32_t c = g; c < g + 4u; ++c) {
                     const uint32_t o0 = fr[c].x & 0xFFFFu;
                     const bool here = (BITMAP || PBYTES) ? ((pm >> c) & 1u) != 0u : true;   // (those forms' absent lanes hold zeros)
-                    const bool lng = here && o0 == 0xFFFFu;   // (never the empty row's slot)
+                    const bool lng = here && o0 >= SB_LONG;   // (never the empty row's slot; a long fragment's four words are out-of-range offsets themselves)
                     const bool pr = here && (lng || o0 < (SB_H + SB_S) * 4u);   // (a fragment's items fill its positions from the first: an out-of-range offset there = an empty fragment)
                     pm = pr ? pm : pm & ~(1u << c);                  // (walk B skips it too)
                     lngm |= lng ? 1u << c : 0u;
                     const uint32_t w = (wq[c >> 2] >> (8u * (c & 3u))) & 0xFFu;
-                    add2(lng || !here ? SB_OOR * 0x10001u : fr[c].x, w); add2(lng || !here ? SB_OOR * 0x10001u : fr[c].y, w);
+                    add2(!here ? SB_OOR * 0x10001u : fr[c].x, w); add2(!here ? SB_OOR * 0x10001u : fr[c].y, w);   // (`here` is a constant in the default form: no select)
                 }
             }
             if (__ballot(lngm != 0u) != 0ull) {   // fragments of > 4 items (rare from G = 8 on): queued -- {weight | length, first overflow block} --, all the queue's blocks are fetched together below
@@ -430,7 +441,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                         const unsigned long long lb = __ballot(lng);
                         if (lb) {
                             const uint32_t at = nlq + below(lb);
-                            if (lng && at < SB_LQ_CAP) lq[at] = make_uint2((((wq[c >> 2] >> (8u * (c & 3u))) & 0xFFu) << 16) | (fr[c].x >> 16), fr[c].y);
+                            if (lng && at < SB_LQ_CAP) lq[at] = make_uint2((((wq[c >> 2] >> (8u * (c & 3u))) & 0xFFu) << 16) | sb_long_len(fr[c].x), sb_long_block(fr[c].x, fr[c].y));
                             nlq += (uint32_t)__popcll(lb);
                         }
                     }
@@ -593,6 +604,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                 // positions point out of the allocation and read 0 -- and a lane's hits are kept as four bits per chunk; ONE scan then places all of them.  Until then a
                 // chunk was four predicated reads, each waited for, a ballot and a scan of its own: 22 dependent chains of ~600 cycles per query.
                 const uint32_t lim = STREAM ? nscr : K;
+                const uint32_t floor31 = min(floor_b, 0x7FFFFFFFu);
                 uint32_t hmw[NCH / 8u];
 #pragma unroll
                 for (uint32_t c = 0; c < NCH; c += 8u) hmw[c >> 3] = 0u;
@@ -602,18 +614,19 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                     uint32_t wv[16];   // the group's sixteen words, all asked for before the first is looked at (the scheduler, left alone, reads two and waits)
 #pragma unroll
                     for (uint32_t c = g; c < g + 4u; ++c) {
-                        const bool pr = (pm >> c) & 1u, lng = pr && (fr[c].x & 0xFFFFu) == 0xFFFFu;
-                        const uint32_t fx = pr && !lng ? fr[c].x : SB_OOR * 0x10001u, fy = pr && !lng ? fr[c].y : SB_OOR * 0x10001u;
+                        const bool pr = (pm >> c) & 1u, lng = pr && sb_is_long(fr[c].x);
+                        const uint32_t fx = STREAM && !pr ? SB_OOR * 0x10001u : fr[c].x, fy = STREAM && !pr ? SB_OOR * 0x10001u : fr[c].y;   // (the streaming form's lanes past the last member hold a copy of its fragment.  Otherwise as they are: unused positions and a long fragment's words read 0 from out of range; the opt-in forms' absent lanes and the lanes past the last member hold zeros -- the direct-mapped word 0, zeroed above)
                         const uint32_t i = 4u * (c - g);
                         wv[i] = *(const uint32_t*)(acc_base + (fx & 0xFFFFu)); wv[i + 1u] = *(const uint32_t*)(acc_base + (fx >> 16));
                         wv[i + 2u] = *(const uint32_t*)(acc_base + (fy & 0xFFFFu)); wv[i + 3u] = *(const uint32_t*)(acc_base + (fy >> 16));
                         lngm |= lng ? 1u << c : 0u;
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    uint32_t hm16 = 0u;
+                    // bit i = word i is BELOW the floor: the sign of (word - floor) shifted in (v_sub + v_alignbit: no condition code, no constants; sums are far below 2^31)
+                    uint32_t miss = 0u;
 #pragma unroll
-                    for (uint32_t i = 0; i < 16u; ++i) hm16 |= wv[i] >= floor_b ? 1u << i : 0u;   // (direct-mapped words: zeroed above; out of range: 0)
-                    hmw[g >> 3] |= hm16 << (4u * (g & 7u));
+                    for (uint32_t i = 16u; i-- > 0u;) miss = __builtin_amdgcn_alignbit(miss, wv[i] - floor31, 31u);   // (direct-mapped words: zeroed above; out of range: 0)
+                    hmw[g >> 3] |= (~miss & 0xFFFFu) << (4u * (g & 7u));
                 }
                 uint32_t cnt = 0u;
 #pragma unroll
@@ -639,7 +652,7 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                         const unsigned long long lb = __ballot(lng);
                         if (lb) {
                             const uint32_t at = nlb + below(lb);
-                            if (lng && at < SB_LQB_CAP) { lqb[at] = make_uint2(sv[c], fr[c].y); lqb_len[at] = fr[c].x >> 16; }
+                            if (lng && at < SB_LQB_CAP) { lqb[at] = make_uint2(sv[c], sb_long_block(fr[c].x, fr[c].y)); lqb_len[at] = sb_long_len(fr[c].x); }
                             nlb += (uint32_t)__popcll(lb);
                         }
                     }
