@@ -19,7 +19,7 @@
 // kernels (vmis_finish_kernel / vmis_finish_big_kernel) are shared with the fast kernel, and so is the fall-back: what this kernel cannot take goes to f.slow_list and the
 // general kernel behind it.
 //
-// Round 6 (1.60 -> 1.11 ms per 131 072 queries at G = 8, profiles/r06_sback_ab.txt): what the compiler made of the source mattered more than any memory-side redesign of
+// Round 6 (1.60 -> 1.09 ms per 131 072 queries at G = 8, profiles/r06_sback_ab.txt): what the compiler made of the source mattered more than any memory-side redesign of
 // round 5.  (1) NO SCRATCH: values made of the lane number are loop-invariant; hoisted out of the query loop they occupied registers for the wave's life, the kernel sat at its
 // 168-register limit and they were spilled -- and a reload is a vector-memory load whose s_waitcnt vmcnt(0) also sits out every other request the wave has in flight
 // (opaque copies of the lane number at the points of use; sample constants fetched per query).  (2) Loads the source asks for unconditionally were moved behind branches:
