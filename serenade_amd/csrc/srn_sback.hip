@@ -188,7 +188,8 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
     // 8 record + clears, 9 walk A, 10 sample + floors, 11 sketch check, 12 walk B + resolve, 13 hand-off; 5 listed elements, 6 candidates, 7 live queries, 14 served, 15 handed over by cause (20-bit fields: candidates | long-fragment queues | hit list; exact table: upper half of 7)
     const bool ticking = p.phase_cycles != nullptr;
     unsigned long long tk8 = 0, tk9 = 0, tk10 = 0, tk11 = 0, tk12 = 0, tk13 = 0, c5 = 0, c6 = 0, c7 = 0, c14 = 0, c15 = 0;
-#ifdef SRN_SBACK_SUBTICKS
+#ifdef SRN_SBACK_SUBTICKS   // (a variant build, build.build_variant(..., ["-DSRN_SBACK_SUBTICKS=1"], sources=("srn_sback.hip",)): four more stamps in the slots the FRONT end's phases use in
+                            //  its own launches (1 walk B up to the hit list, 2 resolve, 3 walk A up to the fragments' arrival -- with a forced wait --, 4 sample + threshold): subtract the front end's figures
     unsigned long long tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0;
 #define SB_SUBTICK(acc) SB_TICK(acc)
 #else
