@@ -638,10 +638,14 @@ __global__ __launch_bounds__(64, SRN_SBACK_WAVES) void vmis_shard_back_kernel(De
                     nh = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
                     if (nh <= SB_HIT_CAP) {
 #pragma unroll
-                        for (uint32_t c = 0; c < NCH; ++c) {
-                            if (c * 64u >= lim) continue;
-                            uint32_t hm = (hmw[c >> 3] >> (4u * (c & 7u))) & 15u;
-                            while (hm) { const uint32_t b = (uint32_t)__ffs((int)hm) - 1u; hm &= hm - 1u; hits[at] = make_uint2(sv[c], b); ++at; }
+                        for (uint32_t g = 0; g < NCH; g += 4u) {   // (per GROUP of four chunks: a lane has a hit in one group in seven -- six short blocks instead of 24)
+                            if (g * 64u >= lim) continue;
+                            uint32_t hm = (hmw[g >> 3] >> (4u * (g & 7u))) & 0xFFFFu;
+                            while (hm) {
+                                const uint32_t b = (uint32_t)__ffs((int)hm) - 1u, cc = b >> 2; hm &= hm - 1u;
+                                const uint32_t s_ = cc == 0u ? sv[g] : cc == 1u ? sv[g + 1u] : cc == 2u ? sv[g + 2u] : sv[g + 3u];
+                                hits[at] = make_uint2(s_, b & 3u); ++at;
+                            }
                         }
                     }
                 }
